@@ -1,0 +1,107 @@
+"""State-dict key/shape specifications of the reference task models (checkpoint-compatible names).
+
+The key names are an API (SURVEY.md section 8(b) "state keys"): reference checkpoints are loaded BY NAME
+(models/blip_nlvr.py:146-158, models/vit.py:380-395), so the mirrors in this package and the synthetic
+weight generator both use exactly these names.
+"""
+from collections import OrderedDict
+
+D = 768
+FFN = 3072
+SD_NUM = 100
+VOCAB = 30524  # configs/med_config.json
+MAX_POS = 512
+
+
+def _linear(sd, name, out_f, in_f, bias=True):
+    sd[name + ".weight"] = (out_f, in_f)
+    if bias:
+        sd[name + ".bias"] = (out_f,)
+
+
+def _ln(sd, name, dim=D):
+    sd[name + ".weight"] = (dim,)
+    sd[name + ".bias"] = (dim,)
+
+
+def vit_shapes(prefix="visual_encoder.", img_size=224, patch=16, depth=12, dim=D):
+    """models/vit.py VisionTransformer (BLIP create_vit('base'), models/blip.py:228-238)."""
+    sd = OrderedDict()
+    n = (img_size // patch) ** 2
+    sd[prefix + "cls_token"] = (1, 1, dim)
+    sd[prefix + "pos_embed"] = (1, n + 1, dim)
+    sd[prefix + "patch_embed.proj.weight"] = (dim, 3, patch, patch)
+    sd[prefix + "patch_embed.proj.bias"] = (dim,)
+    for i in range(depth):
+        p = f"{prefix}blocks.{i}."
+        _ln(sd, p + "norm1", dim)
+        _linear(sd, p + "attn.qkv", 3 * dim, dim)
+        _linear(sd, p + "attn.proj", dim, dim)
+        _ln(sd, p + "norm2", dim)
+        _linear(sd, p + "mlp.fc1", 4 * dim, dim)
+        _linear(sd, p + "mlp.fc2", dim, 4 * dim)
+    _ln(sd, prefix + "norm", dim)
+    return sd
+
+
+def _bert_self(sd, p, kv_in=D):
+    _linear(sd, p + "query", D, D)
+    _linear(sd, p + "key", D, kv_in)
+    _linear(sd, p + "value", D, kv_in)
+
+
+def bert_shapes(prefix="text_encoder.", variant="med", layers=12, cross=True):
+    """models/med.py BertModel(add_pooling_layer=False) ('med') or models/nlvr_encoder.py ('nlvr')."""
+    sd = OrderedDict()
+    e = prefix + "embeddings."
+    sd[e + "position_ids"] = ("int64", 1, MAX_POS)
+    sd[e + "word_embeddings.weight"] = (VOCAB, D)
+    sd[e + "position_embeddings.weight"] = (MAX_POS, D)
+    _ln(sd, e + "LayerNorm")
+    for i in range(layers):
+        p = f"{prefix}encoder.layer.{i}."
+        _bert_self(sd, p + "attention.self.")
+        _linear(sd, p + "attention.output.dense", D, D)
+        _ln(sd, p + "attention.output.LayerNorm")
+        if cross:
+            c = p + "crossattention."
+            if variant == "nlvr":
+                _bert_self(sd, c + "self0.")
+                _bert_self(sd, c + "self1.")
+                _ln(sd, c + "output.LayerNorm")
+                _linear(sd, c + "output.dense0", D, D)
+                _linear(sd, c + "output.dense1", D, D)
+                if i >= 6:
+                    _linear(sd, c + "output.merge_layer", D, 2 * D)
+            else:
+                _bert_self(sd, c + "self.")
+                _linear(sd, c + "output.dense", D, D)
+                _ln(sd, c + "output.LayerNorm")
+        _linear(sd, p + "intermediate.dense", FFN, D)
+        _linear(sd, p + "output.dense", D, FFN)
+        _ln(sd, p + "output.LayerNorm")
+    return sd
+
+
+def blip_nlvr_shapes(img_size=224):
+    """models/blip_nlvr.py BLIP_NLVR.__init__ :20-61."""
+    sd = OrderedDict()
+    sd["space_dict"] = (SD_NUM, D)
+    sd.update(vit_shapes("visual_encoder.", img_size))
+    sd.update(bert_shapes("text_encoder.", "nlvr"))
+    _linear(sd, "cls_head.0", D, D)
+    _linear(sd, "cls_head.2", 2, D)
+    return sd
+
+
+def synth_weights(shapes, seed=0):
+    """{key: tensor} from a shape spec using the deterministic generator."""
+    import torch
+    from . import synth
+    out = {}
+    for k, shp in shapes.items():
+        if shp and shp[0] == "int64":
+            out[k] = torch.arange(shp[-1]).expand(shp[1:]).clone()
+        else:
+            out[k] = synth.synth_tensor(k, shp, seed)
+    return out

@@ -1,0 +1,103 @@
+"""Deterministic synthetic weights and inputs.
+
+There is no network, so no pretrained BLIP/CLIP checkpoint exists on either box; 259 M parameters are
+also far too many to commit.  Both the golden-vector generator (this container, reference imported)
+and the tests/bench on the GPU box therefore REGENERATE identical weights from a counter-based integer
+hash: value = f(seed, parameter name, flat element index).  Pure uint32 arithmetic in numpy followed by
+two exactly-rounded float32 ops, so the bits are identical on every machine and independent of the
+torch RNG.  (SURVEY.md section 7 step 1 / section 8(c) "what never travels".)
+"""
+import math
+
+import numpy as np
+import torch
+
+_U32 = np.uint32
+
+
+def _fnv1a(name: str, seed: int) -> int:
+    h = 0x811C9DC5 ^ (seed * 0x9E3779B1 & 0xFFFFFFFF)
+    for ch in name.encode():
+        h ^= ch
+        h = (h * 0x01000193) & 0xFFFFFFFF
+    return h
+
+
+def hash_u32(name: str, n: int, seed: int = 0) -> np.ndarray:
+    """n well-mixed uint32 values for stream `name` (lowbias32 finaliser over a Weyl sequence)."""
+    x = np.arange(n, dtype=np.uint64)
+    x = ((x * np.uint64(0x9E3779B9) + np.uint64(_fnv1a(name, seed))) & np.uint64(0xFFFFFFFF)).astype(_U32)
+    x ^= x >> _U32(16)
+    x *= _U32(0x7FEB352D)
+    x ^= x >> _U32(15)
+    x *= _U32(0x846CA68B)
+    x ^= x >> _U32(16)
+    return x
+
+
+def uniform_pm1(name: str, n: int, seed: int = 0) -> np.ndarray:
+    """float32 uniform in [-1, 1) with 24-bit resolution."""
+    u = (hash_u32(name, n, seed) >> _U32(8)).astype(np.float32) * np.float32(1.0 / (1 << 24))
+    return (u - np.float32(0.5)) * np.float32(2.0)
+
+
+_SQRT3 = math.sqrt(3.0)
+
+
+def _std_for(name: str, shape) -> tuple:
+    """(mean, std) of the synthetic value for a parameter, by reference naming convention."""
+    leaf = name.rsplit(".", 1)[-1]
+    parent = name.rsplit(".", 2)[-2] if name.count(".") >= 1 else ""
+    is_norm = parent.startswith(("norm", "LayerNorm", "ln_")) or parent in ("norm",) or name.startswith("norm.")
+    if len(shape) == 1:
+        if is_norm and leaf == "weight":
+            return 1.0, 0.05
+        if is_norm and leaf == "bias":
+            return 0.0, 0.02
+        return 0.0, 0.02  # Linear / conv biases: non-zero so a dropped bias is caught by parity
+    if leaf == "space_dict" or name.endswith("space_dict"):
+        return 0.0, 1.0  # nn.Parameter(torch.randn(sd_num, sd_dim)) models/blip_nlvr.py:46
+    if name.endswith(("positional_embedding", "class_embedding")):
+        return 0.0, 0.02
+    return 0.0, 0.02  # trunc_normal_(std=.02) vit.py:266-270; BERT initializer_range 0.02
+
+
+def synth_tensor(name: str, shape, seed: int = 0, dtype=torch.float32) -> torch.Tensor:
+    shape = tuple(int(s) for s in shape)
+    n = int(np.prod(shape)) if len(shape) else 1
+    mean, std = _std_for(name, shape)
+    v = uniform_pm1(name, n, seed) * np.float32(std * _SQRT3)
+    if mean != 0.0:
+        v = v + np.float32(mean)
+    return torch.from_numpy(v.reshape(shape)).to(dtype)
+
+
+def fill_state_dict(module_or_sd, seed: int = 0, prefix: str = ""):
+    """Returns {key: tensor} with synthetic values for every floating-point entry of a state_dict
+    (integer buffers such as position_ids are left as they are)."""
+    sd = module_or_sd.state_dict() if hasattr(module_or_sd, "state_dict") else module_or_sd
+    out = {}
+    for k, v in sd.items():
+        if v.is_floating_point():
+            out[k] = synth_tensor(prefix + k, v.shape, seed)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def synth_images(n: int, size: int = 224, seed: int = 0) -> torch.Tensor:
+    """[n,3,size,size] fp32, zero-mean unit-variance i.i.d. (uniform) pixels."""
+    v = uniform_pm1("images", n * 3 * size * size, seed) * np.float32(_SQRT3)
+    return torch.from_numpy(v.reshape(n, 3, size, size))
+
+
+def synth_token_ids(batch: int, length: int, seed: int = 0, lo: int = 1000, hi: int = 30000,
+                    first_id=None) -> torch.Tensor:
+    """[batch,length] int64 ids uniform in [lo,hi); position 0 optionally overwritten (the reference
+    writes tokenizer.enc_token_id there, models/blip_nlvr.py:69)."""
+    h = hash_u32("token_ids", batch * length, seed).astype(np.int64)
+    ids = lo + (h % (hi - lo))
+    ids = torch.from_numpy(ids.reshape(batch, length))
+    if first_id is not None:
+        ids[:, 0] = first_id
+    return ids

@@ -1,0 +1,53 @@
+"""Pins the CPU oracle (oracle/madtp_oracle.py) to fixtures recorded from the REFERENCE itself
+(tools/make_golden.py imported /root/reference in the build container).  CPU only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from madtp_amd import specs, synth
+from oracle import madtp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "nlvr_*.npz")))
+
+
+def test_synth_generator_is_bit_stable():
+    # known-answer: the generator must give identical bits on every box (weights are regenerated, never shipped)
+    h = synth.hash_u32("visual_encoder.blocks.0.attn.qkv.weight", 4, 0)
+    assert h.dtype == np.uint32
+    t = synth.synth_tensor("visual_encoder.blocks.0.attn.qkv.weight", (2, 3), 0)
+    t2 = synth.synth_tensor("visual_encoder.blocks.0.attn.qkv.weight", (2, 3), 0)
+    assert torch.equal(t, t2)
+    assert abs(float(synth.synth_tensor("x.weight", (512, 512), 1).std()) - 0.02) < 5e-4
+    ids = synth.synth_token_ids(3, 20, 0)
+    assert ids.min() >= 1000 and ids.max() < 30000
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c)[:-4] for c in CASES])
+def test_oracle_matches_reference_fixture(path):
+    g = np.load(path)
+    B, size, L, T, seed = int(g["B"]), int(g["size"]), int(g["L"]), float(g["temperature"]), int(g["seed"])
+    shapes = specs.blip_nlvr_shapes(size)
+    assert sorted(shapes.keys()) == [str(k) for k in g["state_dict_keys"]], "state_dict key names are an API"
+    W = specs.synth_weights(shapes, seed)
+    images = synth.synth_images(2 * B, size, seed)
+    ids = synth.synth_token_ids(B, L, seed)
+    trace = {}
+    with torch.no_grad():
+        logits = O.blip_nlvr_forward(W, images, ids, torch.ones_like(ids), T, trace=trace)
+    # same torch ops on the same box => exact; 1e-5 leaves room for a different CPU/BLAS on the GPU box's host
+    assert np.abs(logits.numpy() - g["logits"]).max() < 1e-5
+    assert np.abs(trace["image_embeds"][:, 0, :16].numpy() - g["img_embeds_cls"]).max() < 1e-4
+    for side, key in (("vit", "vit"), ("text", "txt")):
+        lens = g[f"{key}_lens"]
+        for l, info in enumerate(trace[side]):
+            if f"{key}{l}_idx" not in g.files:
+                assert not info["pruned"]
+                continue
+            assert info["pruned"] and info["k"] + 2 == lens[l]
+            # bit-exact kept-token index SETS (order of topk(sorted=False) is implementation-defined)
+            assert (np.sort(info["indices"].numpy(), 1) == np.sort(g[f"{key}{l}_idx"], 1)).all()
+            assert (info["indices_sort"].numpy() == g[f"{key}{l}_sort"]).all()

@@ -1,0 +1,112 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz by IMPORTING THE REFERENCE (read-only, /root/reference) in this container.
+
+Runs only here (the reference never travels to the GPU box).  For each case it
+  1. builds the reference model (models.blip_nlvr.BLIP_NLVR, ...) behind tools/ref_shims.py,
+  2. loads the repo's deterministic synthetic weights (madtp_amd.synth) into it BY STATE-DICT KEY,
+  3. runs the reference forward on the repo's synthetic inputs and records, per layer, the `indices` the
+     reference passes to vector_gather (kept tokens, vit.py:153-154 / nlvr_encoder.py:440-441), plus logits
+     and a few float checksums.
+The fixtures are data only: seeds, temperatures, integer index arrays, small float vectors.
+
+usage: python tools/make_golden.py [case ...]     (default: all cases)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+
+from madtp_amd import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+class GatherTap:
+    """Wraps a module-global `vector_gather` so the first call of each Reduce_token (kept `indices`) and the
+    second (`indices_sort`) are recorded under the current layer tag."""
+
+    def __init__(self, module):
+        self.module = module
+        self.orig = module.vector_gather
+        self.records = {}
+        self.tag = None
+        self.calls = 0
+        module.vector_gather = self
+
+    def set_tag(self, tag):
+        self.tag = tag
+        self.calls = 0
+
+    def __call__(self, vectors, indices):
+        if self.tag is not None and vectors.shape[-1] > 1:
+            name = "idx" if self.calls == 0 else "sort"
+            if self.calls < 2:
+                self.records[f"{self.tag}_{name}"] = indices.detach().cpu().numpy().astype(np.int32)
+            self.calls += 1
+        return self.orig(vectors, indices)
+
+    def restore(self):
+        self.module.vector_gather = self.orig
+
+
+def nlvr_case(name, B, size, L, temperature, seed=0):
+    import models.blip_nlvr as bn
+    import models.vit as rvit
+    import models.nlvr_encoder as rnl
+    ref_shims.patch_tokenizer(bn)
+    model = bn.BLIP_NLVR(image_size=size, evaluate=True, config={"sd_num": 100, "sd_dim": 768, "batch_size_train": 16})
+    model.eval()
+    sd = synth.fill_state_dict(model, seed)
+    missing = model.load_state_dict(sd, strict=True)
+    images = synth.synth_images(2 * B, size, seed)
+    ids = synth.synth_token_ids(B, L, seed, first_id=None)
+    text = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+    tap_v, tap_t = GatherTap(rvit), GatherTap(rnl)
+    hooks = []
+    lens_v, lens_t = [], []
+    for i, blk in enumerate(model.visual_encoder.blocks):
+        hooks.append(blk.register_forward_pre_hook(lambda m, a, i=i: tap_v.set_tag(f"vit{i}")))
+        hooks.append(blk.register_forward_hook(lambda m, a, o: lens_v.append(o.shape[1])))
+    for i, lay in enumerate(model.text_encoder.encoder.layer):
+        hooks.append(lay.register_forward_pre_hook(lambda m, a, i=i: tap_t.set_tag(f"txt{i}")))
+        hooks.append(lay.register_forward_hook(lambda m, a, o: lens_t.append(o[0].shape[1])))
+    feats = {}
+    hooks.append(model.visual_encoder.register_forward_hook(lambda m, a, o: feats.__setitem__("img", o[0].detach())))
+    t0 = time.time()
+    with torch.no_grad():
+        logits = model(images, text, torch.zeros(B, dtype=torch.long), temperature=temperature, train=False)
+    dt = time.time() - t0
+    for h in hooks:
+        h.remove()
+    tap_v.restore()
+    tap_t.restore()
+    out = {"kind": "nlvr", "B": B, "size": size, "L": L, "temperature": np.float64(temperature), "seed": seed,
+           "logits": logits.numpy(), "vit_lens": np.array(lens_v), "txt_lens": np.array(lens_t),
+           "img_embeds_cls": feats["img"][:, 0, :16].numpy(), "img_embeds_absmean": feats["img"].abs().mean().numpy(),
+           "state_dict_keys": np.array(sorted(sd.keys())), "ref_seconds": dt, "threads": torch.get_num_threads()}
+    out.update(tap_v.records)
+    out.update(tap_t.records)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[{name}] T={temperature} vit_lens={lens_v} txt_lens={lens_t} logits={logits.numpy().round(4).tolist()} "
+          f"({dt:.2f}s)")
+
+
+CASES = {
+    "nlvr_b2_T1": lambda: nlvr_case("nlvr_b2_T1", 2, 224, 20, 1.0),
+    "nlvr_b2_T5": lambda: nlvr_case("nlvr_b2_T5", 2, 224, 20, 5.0),
+}
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    todo = sys.argv[1:] or list(CASES)
+    for c in todo:
+        CASES[c]()

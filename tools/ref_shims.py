@@ -1,0 +1,173 @@
+"""Import-time shims that let the (read-only) MADTP reference at /root/reference be imported
+in THIS container for golden-vector generation.  Nothing here ships to the GPU box as product
+code and nothing here edits or copies reference files: the shims only provide the third-party
+symbols the reference imports that are absent from this image (timm 0.4.12, fairscale, tkinter,
+a few transformers 4.15 helpers removed in transformers 5.x, torchvision, ftfy).
+
+Shim list follows SURVEY.md section 8(c).  Call ``install()`` BEFORE importing ``models.*``.
+"""
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+REFERENCE_ROOT = "/root/reference"
+
+
+def _mod(name):
+    m = types.ModuleType(name)
+    m.__path__ = []  # behave like a package so sub-modules can hang off it
+    sys.modules[name] = m
+    return m
+
+
+class _PatchEmbed(nn.Module):
+    """timm==0.4.12 PatchEmbed restated: Conv2d(kernel=stride=patch) -> flatten(2) -> transpose(1,2).
+    (third-party dependency absent from /root/reference; call site models/vit.py:241-242,283)"""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None, flatten=True):
+        super().__init__()
+        img_size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
+        patch_size = (patch_size, patch_size) if isinstance(patch_size, int) else tuple(patch_size)
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.grid_size = (img_size[0] // patch_size[0], img_size[1] // patch_size[1])
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.flatten = flatten
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+
+    def forward(self, x):
+        x = self.proj(x)
+        if self.flatten:
+            x = x.flatten(2).transpose(1, 2)
+        return self.norm(x)
+
+
+class _DropPath(nn.Module):
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):  # eval-only harness: identity
+        return x
+
+
+class FakeTokenizer:
+    """Stands in for BertTokenizer('./pretrained/bert-base-uncased') (models/blip.py:219-225): the
+    harness feeds synthetic id tensors straight through.  ``text`` is a dict-like with input_ids /
+    attention_mask tensors."""
+    enc_token_id = 30523
+    bos_token_id = 30522
+    pad_token_id = 0
+    sep_token_id = 102
+    cls_token_id = 101
+    additional_special_tokens_ids = [30523]
+
+    class _Batch(dict):
+        def __getattr__(self, k):
+            return self[k]
+
+        def to(self, device):
+            return FakeTokenizer._Batch({k: v.to(device) for k, v in self.items()})
+
+    def __call__(self, text, **kw):
+        if isinstance(text, dict):
+            return FakeTokenizer._Batch({k: v.clone() for k, v in text.items()})
+        raise TypeError("FakeTokenizer expects {'input_ids','attention_mask'} tensors")
+
+
+_installed = False
+
+
+def install(chdir=True):
+    global _installed
+    if _installed:
+        return
+    _installed = True
+    import transformers  # noqa: F401  (must precede the fakes below)
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+
+    # (4) helpers that moved / were removed after transformers 4.15
+    mu.apply_chunking_to_forward = pu.apply_chunking_to_forward
+    mu.prune_linear_layer = pu.prune_linear_layer
+    mu.find_pruneable_heads_and_indices = getattr(pu, "find_pruneable_heads_and_indices", lambda *a, **k: (set(), None))
+
+    # (5) PreTrainedModel conveniences whose semantics changed in 5.x
+    PT = mu.PreTrainedModel
+    PT.get_head_mask = lambda self, head_mask, num_hidden_layers, is_attention_chunked=False: [None] * num_hidden_layers
+    PT.init_weights = lambda self: self.apply(self._init_weights)
+    PT.tie_weights = lambda self, *a, **k: None
+    if not hasattr(PT, "invert_attention_mask_orig"):
+        def invert_attention_mask(self, encoder_attention_mask):
+            # transformers 4.15 ModuleUtilsMixin.invert_attention_mask (fp32 branch): (1-m) * -1e4
+            m = encoder_attention_mask
+            if m.dim() == 3:
+                ext = m[:, None, :, :]
+            else:
+                ext = m[:, None, None, :]
+            ext = ext.to(dtype=torch.float32)
+            return (1.0 - ext) * -10000.0
+        PT.invert_attention_mask = invert_attention_mask
+
+    # (1) timm 0.4.12 surface used by models/vit.py:7-10 and models/blip*.py
+    timm = _mod("timm")
+    tm = _mod("timm.models")
+    vt = _mod("timm.models.vision_transformer")
+    vt.PatchEmbed = _PatchEmbed
+    vt._cfg = lambda **kw: dict(kw)
+    reg = _mod("timm.models.registry")
+    reg.register_model = lambda f: f
+    lay = _mod("timm.models.layers")
+    lay.trunc_normal_ = lambda t, std=1.0, **kw: nn.init.trunc_normal_(t, std=std, a=-2 * std, b=2 * std)
+    lay.DropPath = _DropPath
+    hlp = _mod("timm.models.helpers")
+    hlp.named_apply = lambda *a, **k: None
+    hlp.adapt_input_conv = lambda *a, **k: None
+    hub = _mod("timm.models.hub")
+    hub.download_cached_file = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("offline"))
+    timm.models = tm
+
+    # (2) fairscale checkpoint_wrapper -> identity
+    _mod("fairscale")
+    _mod("fairscale.nn")
+    _mod("fairscale.nn.checkpoint")
+    ca = _mod("fairscale.nn.checkpoint.checkpoint_activations")
+    ca.checkpoint_wrapper = lambda m, *a, **k: m
+
+    # (3) tkinter.messagebox.NO (models/blip_retrieval.py:1)
+    if "tkinter" not in sys.modules:
+        tk = _mod("tkinter")
+        mb = _mod("tkinter.messagebox")
+        mb.NO = "no"
+        tk.messagebox = mb
+
+    # telnetlib was removed in python 3.13; present in 3.10 - nothing to do.
+
+    # (7) CLIP-only fakes: torchvision.transforms, ftfy
+    if "torchvision" not in sys.modules:
+        tv = _mod("torchvision")
+        tvt = _mod("torchvision.transforms")
+        for n in ("Compose", "Resize", "CenterCrop", "ToTensor", "Normalize", "InterpolationMode"):
+            setattr(tvt, n, type(n, (), {"BICUBIC": 3, "__init__": lambda self, *a, **k: None}))
+        tv.transforms = tvt
+    if "ftfy" not in sys.modules:
+        ft = _mod("ftfy")
+        ft.fix_text = lambda s: s
+
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    if chdir:
+        os.chdir(REFERENCE_ROOT)  # (8) relative 'configs/med_config.json'
+
+    # (6) tokenizer: replace by-name copies after the modules are imported
+    import models.blip as blip_mod
+    blip_mod.init_tokenizer = lambda: FakeTokenizer()
+
+
+def patch_tokenizer(module):
+    """models.blip_nlvr & co. did `from models.blip import init_tokenizer` - rebind the local name."""
+    module.init_tokenizer = lambda: FakeTokenizer()
