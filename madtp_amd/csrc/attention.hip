@@ -1,0 +1,261 @@
+// Multi-head attention core fused with the pruning-score reductions (k4 + k5, and k11 for
+// cross-attention).  The reference materialises P[B,H,N,N] in HBM (vit.py:81-83, 238 MB/layer at B=128,N=197)
+// and re-reads it for the head-max column mass (vit.py:126-127) and the CLS row (vit.py:96); here P never leaves
+// registers.
+//
+// Work decomposition (gfx950, 64-lane waves):
+//   * workgroup = (batch element b, 64 query rows); wave w owns the 16-row query tile 4*blockIdx.x + w and
+//     loops over ALL heads, so the running head-max of P for its rows stays in registers.
+//   * per head the workgroup stages K_h and V_h (Nk x 64) in LDS once (row pitch padded by 16 B), shared by the
+//     four waves; Q rows are read straight from global/L2 into registers.
+//   * S^T = K Q^T is computed "swapped" with v_mfma_f32_16x16x4_f32 so that lane (i = lane&15, g = lane>>4) ends
+//     up holding key columns j = 16t + 4g + r of query row i: the softmax row reduction is in-lane plus two
+//     cross-lane steps, and the same registers are exactly the A operand (row i, k-slot g) of the P.V MFMA.
+//   * arithmetic is f32 throughout (exact-f32 MFMA); T is only the storage type of q/k/v/out (f32 or bf16).
+//   * side outputs: colsum_part[b, row tile, j] (column mass of head-max P over this wave's rows, row 0 excluded),
+//     p0[b,h,j] (CLS row), onorm[b,h,i] (||P V||_2 per row).  The tiny cross-tile / cross-head combination is
+//     done by madtp_token_score in a fixed order (deterministic, no atomics).
+// Roofline: MFMA f32 (157 TF) - 4*Nq*Nk*64 flops per (b,h); HBM traffic is q,k,v,out once (K/V re-reads by the
+// other query tiles of the same b hit L2).
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+    const char* q; const char* k; const char* v; char* out; const float* mask;
+    float* colsum; float* p0; float* onorm;
+    int B, H, Nq, Nk, ldq, ldk, ldv, ldo, nrt;
+    float scale;
+};
+
+template <typename T> __device__ __forceinline__ f32x4 load4(const char* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const char* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const char* p) {
+    const uint2 u = *(const uint2*)p;
+    f32x4 r;
+    r[0] = __uint_as_float(u.x << 16); r[1] = __uint_as_float(u.x & 0xffff0000u);
+    r[2] = __uint_as_float(u.y << 16); r[3] = __uint_as_float(u.y & 0xffff0000u);
+    return r;
+}
+template <typename T> __device__ __forceinline__ float load1(const char* p);
+template <> __device__ __forceinline__ float load1<float>(const char* p) { return *(const float*)p; }
+template <> __device__ __forceinline__ float load1<bf16_t>(const char* p) { return bf16_to_f32(*(const bf16_t*)p); }
+
+template <typename T, int NT, bool SCORES>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int RB = 64 * ESZ + 16;        // LDS row pitch in bytes (pad one 16-B slot)
+    constexpr int CPR = 64 * ESZ / 16;       // 16-byte chunks per row
+    constexpr int NKP = NT * 16;             // padded key count
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + NKP * RB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int rt = blockIdx.x * 4 + wave;    // 16-row query tile of this wave
+    const int i0 = rt * 16;
+    const bool active = i0 < a.Nq;
+    const int irow = min(i0 + l16, a.Nq - 1);  // clamped query row for loads
+
+    f32x4 pmax[NT];
+    if constexpr (SCORES) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pmax[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int h = blockIdx.z; h < a.H; h += gridDim.z) {
+        __syncthreads();
+        // ---- stage K_h, V_h (zero rows beyond Nk: 0 * finite stays 0 in P.V) ----
+        for (int idx = tid; idx < NKP * CPR; idx += 256) {
+            const int row = idx / CPR, c = idx % CPR;
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if (row < a.Nk) {
+                const size_t grow = (size_t)b * a.Nk + row;
+                kv = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * ESZ + c * 16);
+                vv = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * ESZ + c * 16);
+            }
+            *(uint4*)(Ks + row * RB + c * 16) = kv;
+            *(uint4*)(Vs + row * RB + c * 16) = vv;
+        }
+        __syncthreads();
+        if (!active) continue;
+
+        // ---- Q fragment: row i, d = 4*(4s+g)+e ----
+        f32x4 q[4];
+        {
+            const char* qp = a.q + (((size_t)b * a.Nq + irow) * a.ldq + h * 64) * ESZ;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) q[s] = load4<T>(qp + (4 * s + g) * 4 * ESZ);
+        }
+
+        // ---- S^T = K Q^T ----
+        f32x4 sc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 kf[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) kf[t] = load4<T>(Ks + (16 * t + l16) * RB + (4 * s + g) * 4 * ESZ);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t][e], q[s][e], sc[t], 0, 0, 0);
+        }
+
+        // ---- softmax over keys (lane holds j = 16t+4g+r of row i) ----
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * t + 4 * g + r;
+                float v = sc[t][r] * a.scale;
+                if (a.mask && j < a.Nk) v += a.mask[(size_t)b * a.Nk + j];
+                v = j < a.Nk ? v : -INFINITY;
+                sc[t][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = expf(sc[t][r] - m);
+                sc[t][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = sc[t][r] / sum;
+                sc[t][r] = p;
+                if constexpr (SCORES) pmax[t][r] = fmaxf(pmax[t][r], p);
+            }
+        if constexpr (SCORES) {
+            if (i0 + l16 == 0) {  // CLS row of this batch element
+                float* dst = a.p0 + ((size_t)b * a.H + h) * a.Nk;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * t + 4 * g + r;
+                        if (j < a.Nk) dst[j] = sc[t][r];
+                    }
+            }
+        }
+
+        // ---- O = P V : A = P (row i, k-slot g <-> j = 16t+4g+r), B = V[j][d] ----
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const char* vrow = Vs + (16 * t + 4 * g + r) * RB + l16 * ESZ;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[t][r], load1<T>(vrow + dt * 16 * ESZ), o[dt], 0, 0, 0);
+            }
+
+        // ---- write O (row = i0+4g+r, col = h*64+dt*16+l16), row norms ----
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 4 * g + r;
+            float n2 = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) n2 += o[dt][r] * o[dt][r];
+            if constexpr (SCORES) n2 = row16_sum(n2);
+            if (i < a.Nq) {
+                T* orow = (T*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * ESZ);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) orow[dt * 16 + l16] = from_f32<T>(o[dt][r]);
+                if constexpr (SCORES)
+                    if (l16 == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
+            }
+        }
+    }
+
+    if constexpr (SCORES) {
+        if (active) {
+            const int i = i0 + l16;
+            const bool valid = i >= 1 && i < a.Nq;
+            float* dst = a.colsum + ((size_t)b * a.nrt + rt) * a.Nk;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = row16_sum(valid ? pmax[t][r] : 0.f);
+                    const int j = 16 * t + 4 * g + r;
+                    if (l16 == 0 && j < a.Nk) dst[j] = v;
+                }
+        }
+    }
+}
+
+template <typename T, int NT, bool SCORES>
+int launch_attn(const AttnArgs& a, hipStream_t s) {
+    constexpr int RB = 64 * (int)sizeof(T) + 16;
+    const size_t lds = (size_t)2 * NT * 16 * RB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<T, NT, SCORES>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int gz = 1;
+    if (!SCORES) {  // cross-attention has few query rows: spread heads over workgroups
+        const int wgs = ((a.Nq + 63) / 64) * a.B;
+        gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
+        if (gz > a.H) gz = a.H;
+    }
+    hipLaunchKernelGGL((attn_kernel<T, NT, SCORES>), dim3((a.Nq + 63) / 64, a.B, gz), dim3(256), lds, s, a);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, bool SCORES>
+int dispatch_nt(const AttnArgs& a, hipStream_t s) {
+    const int nt = (a.Nk + 15) / 16;
+    if (nt <= 4) return launch_attn<T, 4, SCORES>(a, s);
+    if (nt <= 8) return launch_attn<T, 8, SCORES>(a, s);
+    if (nt <= 10) return launch_attn<T, 10, SCORES>(a, s);
+    if (nt <= 12) return launch_attn<T, 12, SCORES>(a, s);
+    if (nt <= 13) return launch_attn<T, 13, SCORES>(a, s);
+    if (nt <= 16) return launch_attn<T, 16, SCORES>(a, s);
+    return MADTP_E_SHAPE;
+}
+
+}  // namespace
+
+extern "C" int madtp_attention(const void* q, const void* k, const void* v, void* out, const float* add_mask,
+                               float* colsum_part, float* p0, float* onorm, int B, int H, int Nq, int Nk, int ldq,
+                               int ldk, int ldv, int ldo, float scale, int io_dtype, void* stream) {
+    if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
+    if (io_dtype != MADTP_F32 && io_dtype != MADTP_BF16) return MADTP_E_DTYPE;
+    if (colsum_part && (!p0 || !onorm || Nq != Nk)) return MADTP_E_BADARG;
+    const int esz = io_dtype == MADTP_BF16 ? 2 : 4;
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (ldq * esz) % 16 || (ldk * esz) % 16 || (ldv * esz) % 16)
+        return MADTP_E_ALIGN;
+    if (Nk > 256) return MADTP_E_SHAPE;
+    AttnArgs a;
+    a.q = (const char*)q; a.k = (const char*)k; a.v = (const char*)v; a.out = (char*)out; a.mask = add_mask;
+    a.colsum = colsum_part; a.p0 = p0; a.onorm = onorm;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.nrt = (Nq + 15) / 16;
+    a.scale = scale;
+    hipStream_t s = (hipStream_t)stream;
+    const bool scores = colsum_part != nullptr;
+    if (io_dtype == MADTP_F32) return scores ? dispatch_nt<float, true>(a, s) : dispatch_nt<float, false>(a, s);
+    return scores ? dispatch_nt<bf16_t, true>(a, s) : dispatch_nt<bf16_t, false>(a, s);
+}

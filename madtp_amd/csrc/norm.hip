@@ -1,0 +1,233 @@
+// HBM-bound row kernels: LayerNorm, BERT embeddings(+LN), patch im2col, CLS/pos assembly, small elementwise.
+// One 64-lane wave owns one row; each lane moves 16-byte vectors (float4), so a wave instruction covers 1 KiB
+// of a row and consecutive waves cover consecutive rows (fully coalesced).  Roofline: HBM bandwidth,
+// algorithmic bytes per row = dim*4 read + dim*(4 and/or 2) written.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAX_CHUNKS = 4;  // dim <= 1024
+
+// normalise a row held as float4 chunks in registers; two-pass (mean, then centred variance) in f32
+__device__ __forceinline__ void ln_row(float4 (&v)[LN_MAX_CHUNKS], int nchunk_lane, int dim, float eps, float& mean,
+                                       float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+        if (c < nchunk_lane) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+    mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+        if (c < nchunk_lane) {
+            const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    const float var = wave_sum(q) / (float)dim;
+    rstd = 1.0f / sqrtf(var + eps);
+}
+
+__device__ __forceinline__ void ln_store(const float4 (&v)[LN_MAX_CHUNKS], int lane, int dim, float mean, float rstd,
+                                         const float* gamma, const float* beta, float* y32, bf16_t* ylp) {
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int col = (lane + 64 * c) * 4;
+        if (col >= dim) break;
+        const float4 gm = *(const float4*)(gamma + col);
+        const float4 bt = *(const float4*)(beta + col);
+        float4 o;
+        o.x = (v[c].x - mean) * rstd * gm.x + bt.x;
+        o.y = (v[c].y - mean) * rstd * gm.y + bt.y;
+        o.z = (v[c].z - mean) * rstd * gm.z + bt.z;
+        o.w = (v[c].w - mean) * rstd * gm.w + bt.w;
+        if (y32) *(float4*)(y32 + col) = o;
+        if (ylp) {
+            bf16x4 p;
+            p[0] = (short)f32_to_bf16(o.x); p[1] = (short)f32_to_bf16(o.y);
+            p[2] = (short)f32_to_bf16(o.z); p[3] = (short)f32_to_bf16(o.w);
+            *(bf16x4*)(ylp + col) = p;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* y32, bf16_t* ylp,
+                                                        int rows, int dim, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * dim;
+    float4 v[LN_MAX_CHUNKS];
+    int n = 0;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int col = (lane + 64 * c) * 4;
+        if (col < dim) { v[c] = *(const float4*)(xr + col); n = c + 1; } else v[c] = make_float4(0, 0, 0, 0);
+    }
+    float mean, rstd;
+    ln_row(v, n, dim, eps, mean, rstd);
+    ln_store(v, lane, dim, mean, rstd, gamma, beta, y32 ? y32 + (size_t)row * dim : nullptr,
+             ylp ? ylp + (size_t)row * dim : nullptr);
+}
+
+__global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ wemb,
+                                                         const float* __restrict__ pemb, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* y32, bf16_t* ylp,
+                                                         int rows, int L, int dim, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t id = ids[row];
+    const float* wr = wemb + (size_t)id * dim;
+    const float* pr = pemb + (size_t)(row % L) * dim;
+    float4 v[LN_MAX_CHUNKS];
+    int n = 0;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int col = (lane + 64 * c) * 4;
+        if (col < dim) {
+            const float4 a = *(const float4*)(wr + col), b = *(const float4*)(pr + col);
+            v[c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            n = c + 1;
+        } else v[c] = make_float4(0, 0, 0, 0);
+    }
+    float mean, rstd;
+    ln_row(v, n, dim, eps, mean, rstd);
+    ln_store(v, lane, dim, mean, rstd, gamma, beta, y32 ? y32 + (size_t)row * dim : nullptr,
+             ylp ? ylp + (size_t)row * dim : nullptr);
+}
+
+// one thread per 4 consecutive kx of one (b, patch, c, ky): reads 16 B of an image row, writes 16 B / 8 B
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int S,
+                                                       int P, size_t total4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int kcols = 3 * P * P;
+    const int g = S / P;
+    const size_t e = i * 4;
+    const int col = (int)(e % kcols);
+    const size_t prow = e / kcols;
+    const int kx = col % P, ky = (col / P) % P, c = col / (P * P);
+    const int px = (int)(prow % g), py = (int)((prow / g) % g);
+    const int b = (int)(prow / ((size_t)g * g));
+    const float4 v = *(const float4*)(img + (((size_t)b * 3 + c) * S + (py * P + ky)) * S + px * P + kx);
+    T* o = cols + e;
+    o[0] = from_f32<T>(v.x); o[1] = from_f32<T>(v.y); o[2] = from_f32<T>(v.z); o[3] = from_f32<T>(v.w);
+}
+
+__global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ patches, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, float* __restrict__ x, int B, int np,
+                                                       int dim4, size_t total4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c = (int)(i % dim4);
+    const size_t row = i / dim4;
+    const int t = (int)(row % (np + 1));
+    const size_t b = row / (np + 1);
+    const float4 p = ((const float4*)pos)[(size_t)t * dim4 + c];
+    const float4 s = t == 0 ? ((const float4*)cls)[c] : ((const float4*)patches)[(b * np + (t - 1)) * dim4 + c];
+    ((float4*)x)[i] = make_float4(s.x + p.x, s.y + p.y, s.z + p.z, s.w + p.w);
+}
+
+__global__ __launch_bounds__(256) void add_scale_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ o, float scale, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 x = ((const float4*)a)[i], y = ((const float4*)b)[i];
+    ((float4*)o)[i] = make_float4((x.x + y.x) * scale, (x.y + y.y) * scale, (x.z + y.z) * scale, (x.w + y.w) * scale);
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *(const float4*)(src + i);
+        bf16x4 p;
+        p[0] = (short)f32_to_bf16(v.x); p[1] = (short)f32_to_bf16(v.y);
+        p[2] = (short)f32_to_bf16(v.z); p[3] = (short)f32_to_bf16(v.w);
+        *(bf16x4*)(dst + i) = p;
+    } else {
+        for (size_t j = i; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
+    }
+}
+
+}  // namespace
+
+extern "C" int madtp_layernorm(const float* x, const float* gamma, const float* beta, float* y32, void* ylp, int rows,
+                               int dim, float eps, void* stream) {
+    if (!x || !gamma || !beta || (!y32 && !ylp) || rows <= 0 || dim <= 0) return MADTP_E_BADARG;
+    if (dim % 4 || dim > 256 * LN_MAX_CHUNKS) return MADTP_E_SHAPE;
+    if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || (y32 && !aligned16(y32)) || (ylp && ((uintptr_t)ylp & 7)))
+        return MADTP_E_ALIGN;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y32,
+                       (bf16_t*)ylp, rows, dim, eps);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_bert_embed(const int64_t* ids, const float* word_emb, const float* pos_emb, const float* gamma,
+                                const float* beta, float* y32, void* ylp, int B, int L, int dim, float eps, void* stream) {
+    if (!ids || !word_emb || !pos_emb || !gamma || !beta || (!y32 && !ylp) || B <= 0 || L <= 0) return MADTP_E_BADARG;
+    if (dim % 4 || dim > 256 * LN_MAX_CHUNKS) return MADTP_E_SHAPE;
+    const int rows = B * L;
+    hipLaunchKernelGGL(bert_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, word_emb, pos_emb,
+                       gamma, beta, y32, (bf16_t*)ylp, rows, L, dim, eps);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_patchify(const float* img, void* cols, int B, int S, int P, int out_dtype, void* stream) {
+    if (!img || !cols || B <= 0 || S <= 0 || P <= 0) return MADTP_E_BADARG;
+    if (S % P || P % 4) return MADTP_E_SHAPE;
+    const size_t total4 = (size_t)B * 3 * S * S / 4;
+    const dim3 grid((unsigned)((total4 + 255) / 256));
+    if (out_dtype == MADTP_F32)
+        hipLaunchKernelGGL(patchify_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, img, (float*)cols, B, S, P, total4);
+    else if (out_dtype == MADTP_BF16)
+        hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)cols, B, S, P, total4);
+    else
+        return MADTP_E_DTYPE;
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_assemble_tokens(const float* patches, const float* cls, const float* pos, float* x, int B, int np,
+                                     int dim, void* stream) {
+    if (!patches || !cls || !pos || !x || B <= 0 || np <= 0 || dim <= 0) return MADTP_E_BADARG;
+    if (dim % 4) return MADTP_E_SHAPE;
+    const size_t total4 = (size_t)B * (np + 1) * (dim / 4);
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, patches,
+                       cls, pos, x, B, np, dim / 4, total4);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_add_scale(const float* a, const float* b, float* out, float scale, size_t n, void* stream) {
+    if (!a || !b || !out || n == 0) return MADTP_E_BADARG;
+    if (n % 4) return MADTP_E_SHAPE;
+    hipLaunchKernelGGL(add_scale_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out,
+                       scale, n / 4);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_cast_bf16(const float* src, void* dst, size_t n, void* stream) {
+    if (!src || !dst || n == 0) return MADTP_E_BADARG;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst, n);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_abi_version(void) { return 1; }
+
+extern "C" const char* madtp_strerror(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case MADTP_E_BADARG: return "bad argument (null pointer or non-positive size)";
+        case MADTP_E_SHAPE: return "unsupported shape";
+        case MADTP_E_DTYPE: return "unknown dtype";
+        case MADTP_E_ALIGN: return "pointer / leading dimension not 16-byte aligned";
+        default: return code > 0 ? "HIP launch error (hipError_t)" : "unknown error";
+    }
+}

@@ -1,0 +1,339 @@
+// The memory-bound half of MADTP's dynamic token pruning (k8, k9, k12, k7b):
+//   token_score  - importance score, alignment-guided threshold, survivor count, batch max   (vit.py:125-145)
+//   token_select - rank-based top-k, compaction map, merge weights                          (vit.py:153-159)
+//   token_gather - gather kept rows + weighted merge of dropped rows into one token          (vit.py:154-161)
+//   mask_gather  - additive-mask compaction for the text encoders                             (nlvr_encoder.py:451-452)
+//   query_att_ft - Query_model's att_ft = softmax_t(x.sd^T/sqrt(d)) @ x                       (models/utils.py:174-178)
+// No MFMA except att_ft (a 100 x n x 768 batched product).  These kernels are HBM/L2 bound integer+f32 work:
+// coalesced row reads, wave shuffle reductions, ballot/popcount prefix sums, fixed reduction orders (no float
+// atomics, so results are run-to-run deterministic and independent of workgroup placement).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXN = 1024;  // max patch tokens per sample handled by the LDS-resident kernels
+
+__device__ __forceinline__ float block_sum(float v, float* red, int tid, int nwaves) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int w = 0; w < nwaves; ++w) s += red[w];
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------ token_score
+// one 512-thread workgroup per sample.  phase A: per-token terms; phase B: per-dictionary-column softmax over
+// tokens (4 token slices x 128 columns), threshold = min_k sum_t softmax_t(x/T)[t,k] * I[t].
+__global__ __launch_bounds__(512) void token_score_kernel(const float* __restrict__ colsum, int nrt,
+                                                          const float* __restrict__ p0, const float* __restrict__ onorm,
+                                                          const float* __restrict__ ta, int ldt, int K, float temperature,
+                                                          float* __restrict__ score, float* __restrict__ threshold,
+                                                          int32_t* __restrict__ count, int32_t* __restrict__ kmax, int H,
+                                                          int N) {
+    __shared__ float I_s[MAXN];
+    __shared__ float tw_s[MAXN];
+    __shared__ float red[8];
+    __shared__ float colred[4][128];
+    __shared__ float colstat[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, n = N - 1;
+    const float* ta_b = ta + ((size_t)b * N + 1) * ldt;  // row t <-> patch token t
+
+    // token_attn_w = max over dictionary columns (vit.py:131): one wave per row, lanes over columns
+    for (int t = wave; t < n; t += 8) {
+        float m = -INFINITY;
+        for (int k = lane; k < K; k += 64) m = fmaxf(m, ta_b[(size_t)t * ldt + k]);
+        m = wave_max(m);
+        if (lane == 0) tw_s[t] = m;
+    }
+    __syncthreads();
+
+    // a = column mass of head-max attention (vit.py:126-127), c = head-diversity weighted CLS attention (vit.py:96-101)
+    float a_loc[2], c_loc[2], suma_l = 0.f, sumt_l = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = tid + u * 512;
+        a_loc[u] = 0.f; c_loc[u] = 0.f;
+        if (t < n) {
+            float a = 0.f;
+            for (int r = 0; r < nrt; ++r) a += colsum[((size_t)b * nrt + r) * N + t + 1];
+            float hs = 0.f;
+            for (int h = 0; h < H; ++h) hs += onorm[((size_t)b * H + h) * N + t + 1];
+            float c = 0.f;
+            for (int h = 0; h < H; ++h) {
+                const size_t o = ((size_t)b * H + h) * N + t + 1;
+                c += p0[o] * (onorm[o] / (hs + 1e-8f));
+            }
+            a_loc[u] = a; c_loc[u] = c;
+            suma_l += a; sumt_l += tw_s[t];
+        }
+    }
+    const float suma = block_sum(suma_l, red, tid, 8);
+    const float sumt = block_sum(sumt_l, red, tid, 8);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = tid + u * 512;
+        if (t < n) {
+            const float aw = a_loc[u] / (suma + 1e-8f);
+            const float tw = tw_s[t] / (sumt + 1e-8f);
+            const float sc = (aw + tw + c_loc[u]) / 3.0f;  // vit.py:134
+            I_s[t] = sc;
+            score[(size_t)b * n + t] = sc;
+        }
+    }
+    __syncthreads();
+
+    // phase B: softmax over tokens of token_attn/T per column (vit.py:137-139), 4 slices x 128 columns
+    const int col = tid & 127, slice = tid >> 7;
+    const int t0 = (n * slice) / 4, t1 = (n * (slice + 1)) / 4;
+    const bool cval = col < K;
+    float m = -INFINITY;
+    if (cval)
+        for (int t = t0; t < t1; ++t) m = fmaxf(m, ta_b[(size_t)t * ldt + col] / temperature);
+    colred[slice][col] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(colred[0][col], colred[1][col]), fmaxf(colred[2][col], colred[3][col]));
+    __syncthreads();
+    float se = 0.f;
+    if (cval)
+        for (int t = t0; t < t1; ++t) se += expf(ta_b[(size_t)t * ldt + col] / temperature - m);
+    colred[slice][col] = se;
+    __syncthreads();
+    const float sum = ((colred[0][col] + colred[1][col]) + colred[2][col]) + colred[3][col];
+    __syncthreads();
+    float sw = 0.f;
+    if (cval)
+        for (int t = t0; t < t1; ++t) sw += (expf(ta_b[(size_t)t * ldt + col] / temperature - m) / sum) * I_s[t];
+    colred[slice][col] = sw;
+    __syncthreads();
+    if (tid < 128) colstat[tid] = cval ? ((colred[0][col] + colred[1][col]) + colred[2][col]) + colred[3][col] : INFINITY;
+    __syncthreads();
+    // threshold = min over columns (vit.py:141)
+    float thr = INFINITY;
+    for (int k = lane; k < 128; k += 64) thr = fminf(thr, colstat[k]);
+    thr = wave_min(thr);
+    // survivors (vit.py:143-145)
+    int cnt = 0;
+    for (int t = tid; t < n; t += 512) cnt += I_s[t] > thr ? 1 : 0;
+    const float total = block_sum((float)cnt, red, tid, 8);  // exact: counts <= 1024
+    if (tid == 0) {
+        threshold[b] = thr;
+        count[b] = (int)total;
+        atomicMax(kmax, (int)total);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- token_select
+__global__ __launch_bounds__(256) void token_select_kernel(const float* __restrict__ score, int k,
+                                                           int64_t* __restrict__ indices, int64_t* __restrict__ indices_sort,
+                                                           int32_t* __restrict__ dst_pos, float* __restrict__ merge_w, int n) {
+    __shared__ float s[MAXN];
+    __shared__ int rank_s[MAXN];
+    __shared__ float red[4];
+    __shared__ int wsum[4];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    for (int t = tid; t < n; t += 256) s[t] = score[(size_t)b * n + t];
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    // rank by counting: #tokens with a larger score (ties: lower index first) == position in a stable descending sort
+    float dsum_l = 0.f;
+    for (int t = tid; t < n; t += 256) {
+        const float v = s[t];
+        int r = 0;
+        for (int u = 0; u < n; ++u) {
+            const float w = s[u];
+            r += (w > v || (w == v && u < t)) ? 1 : 0;
+        }
+        rank_s[t] = r;
+        indices_sort[(size_t)b * n + r] = t;
+        if (r >= k) dsum_l += v;
+    }
+    const float dsum = block_sum(dsum_l, red, tid, 4);  // sum of dropped scores (vit.py:158-159)
+    // stable compaction of kept tokens in ascending token order: ballot + popcount prefix per wave, serial over chunks
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int t = c0 + tid;
+        const bool keep = t < n && rank_s[t] < k;
+        const unsigned long long bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (t < n) {
+            if (keep) {
+                indices[(size_t)b * k + off + before] = t;
+                dst_pos[(size_t)b * n + t] = off + before;
+                merge_w[(size_t)b * n + t] = 0.f;
+            } else {
+                dst_pos[(size_t)b * n + t] = -1;
+                merge_w[(size_t)b * n + t] = s[t] / (dsum + 1e-8f);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- token_gather
+// grid (chunks+1, B): chunk c copies source tokens [16c,16c+16) that survive (token 0 = CLS -> slot 0); the extra
+// last workgroup of each sample builds the merged token (fixed wave/token order, LDS combine).
+constexpr int GATHER_ROWS = 16;
+__global__ __launch_bounds__(256) void token_gather_kernel(const float* __restrict__ x, const int32_t* __restrict__ dst_pos,
+                                                           const float* __restrict__ merge_w, float* __restrict__ y, int N,
+                                                           int k, int dim4) {
+    __shared__ float4 part[4][256];  // dim <= 1024
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, n = N - 1, No = k + 2;
+    const float4* xb = (const float4*)x + (size_t)b * N * dim4;
+    float4* yb = (float4*)y + (size_t)b * No * dim4;
+    if ((int)blockIdx.x < (int)gridDim.x - 1) {
+        for (int rr = wave; rr < GATHER_ROWS; rr += 4) {
+            const int t = blockIdx.x * GATHER_ROWS + rr;  // source token incl. CLS
+            if (t >= N) break;
+            const int dst = t == 0 ? 0 : dst_pos[(size_t)b * n + t - 1] + 1;
+            if (dst <= 0 && t != 0) continue;
+            for (int c = lane; c < dim4; c += 64) yb[(size_t)dst * dim4 + c] = xb[(size_t)t * dim4 + c];
+        }
+    } else {
+        float4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = make_float4(0, 0, 0, 0);
+        for (int t = wave; t < n; t += 4) {
+            const float w = merge_w[(size_t)b * n + t];
+            if (dst_pos[(size_t)b * n + t] >= 0) continue;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int cc = lane + 64 * c;
+                if (cc < dim4) {
+                    const float4 v = xb[(size_t)(t + 1) * dim4 + cc];
+                    acc[c].x += w * v.x; acc[c].y += w * v.y; acc[c].z += w * v.z; acc[c].w += w * v.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) part[wave][lane + 64 * c] = acc[c];
+        __syncthreads();
+        for (int c = tid; c < dim4; c += 256) {
+            const float4 p0 = part[0][c], p1 = part[1][c], p2 = part[2][c], p3 = part[3][c];
+            yb[(size_t)(k + 1) * dim4 + c] = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
+                                                         ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+        }
+    }
+}
+
+__global__ void mask_gather_kernel(const float* __restrict__ mask, const int64_t* __restrict__ order, int ld_order,
+                                   float* __restrict__ out, int N, int k) {
+    const int b = blockIdx.x;
+    for (int p = threadIdx.x; p < k + 2; p += blockDim.x)
+        out[(size_t)b * (k + 2) + p] = p == 0 ? mask[(size_t)b * N] : mask[(size_t)b * N + 1 + order[(size_t)b * ld_order + p - 1]];
+}
+
+// ----------------------------------------------------------------------------------------------- query_att_ft
+// grid (dim/64, B); 4 waves, wave w owns output columns [64*bx + 16w, +16) for all K<=112 dictionary rows.
+// C[c, d] = sum_t w[c,t] * x[1+t, d] with exact-f32 MFMA 16x16x4: A = w (row c, k-slot g <-> t = 4*step+g),
+// B = x (k-slot g, column d).
+__global__ __launch_bounds__(256) void query_att_ft_kernel(const float* __restrict__ ta, int ldt, int K,
+                                                           const float* __restrict__ x, float* __restrict__ out,
+                                                           float inv_sqrt_sd, int accumulate, int N, int dim) {
+    __shared__ float mx[128], sm[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y, n = N - 1;
+    const float* ta_b = ta + ((size_t)b * N + 1) * ldt;
+    if (tid < 128) {
+        float m = -INFINITY, s = 1.f;
+        if (tid < K) {
+            for (int t = 0; t < n; ++t) m = fmaxf(m, ta_b[(size_t)t * ldt + tid] * inv_sqrt_sd);
+            s = 0.f;
+            for (int t = 0; t < n; ++t) s += expf(ta_b[(size_t)t * ldt + tid] * inv_sqrt_sd - m);
+        }
+        mx[tid] = m; sm[tid] = s;
+    }
+    __syncthreads();
+    const int d = blockIdx.x * 64 + wave * 16 + l16;
+    f32x4 acc[7];
+#pragma unroll
+    for (int mt = 0; mt < 7; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* xb = x + ((size_t)b * N + 1) * dim;
+    for (int t4 = 0; t4 < n; t4 += 4) {
+        const int t = t4 + g;
+        const bool tv = t < n;
+        const float xv = tv ? xb[(size_t)t * dim + d] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 7; ++mt) {
+            const int c = mt * 16 + l16;
+            float w = 0.f;
+            if (tv && c < K) w = expf(ta_b[(size_t)t * ldt + c] * inv_sqrt_sd - mx[c]) / sm[c];
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xv, acc[mt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = mt * 16 + g * 4 + r;
+            if (c < K) {
+                float* o = out + ((size_t)b * K + c) * dim + d;
+                *o = accumulate ? *o + acc[mt][r] : acc[mt][r];
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int madtp_token_score(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
+                                 const float* token_attn, int ldt, int K, float temperature, float* score,
+                                 float* threshold, int32_t* count, int32_t* kmax, int B, int H, int N, void* stream) {
+    if (!colsum_part || !p0 || !onorm || !token_attn || !score || !threshold || !count || !kmax) return MADTP_E_BADARG;
+    if (B <= 0 || H <= 0 || N < 2 || n_row_tiles <= 0 || !(temperature > 0.f)) return MADTP_E_BADARG;
+    if (N - 1 > MAXN || K > 128 || K <= 0 || ldt < K) return MADTP_E_SHAPE;
+    hipLaunchKernelGGL(token_score_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, colsum_part, n_row_tiles, p0, onorm,
+                       token_attn, ldt, K, temperature, score, threshold, count, kmax, H, N);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_token_select(const float* score, int k, int64_t* indices, int64_t* indices_sort, int32_t* dst_pos,
+                                  float* merge_w, int B, int n, void* stream) {
+    if (!score || !indices || !indices_sort || !dst_pos || !merge_w || B <= 0 || n <= 0) return MADTP_E_BADARG;
+    if (k < 1 || k > n || n > MAXN) return MADTP_E_SHAPE;
+    hipLaunchKernelGGL(token_select_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, score, k, indices, indices_sort,
+                       dst_pos, merge_w, n);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_token_gather(const float* x, const int32_t* dst_pos, const float* merge_w, float* y, int B, int N,
+                                  int k, int dim, void* stream) {
+    if (!x || !dst_pos || !merge_w || !y || B <= 0 || N < 2 || k < 1 || k > N - 1) return MADTP_E_BADARG;
+    if (dim % 4 || dim > 1024) return MADTP_E_SHAPE;
+    if (!aligned16(x) || !aligned16(y)) return MADTP_E_ALIGN;
+    const int chunks = (N + GATHER_ROWS - 1) / GATHER_ROWS;
+    hipLaunchKernelGGL(token_gather_kernel, dim3(chunks + 1, B), dim3(256), 0, (hipStream_t)stream, x, dst_pos, merge_w, y, N,
+                       k, dim / 4);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_mask_gather(const float* mask, const int64_t* order, int ld_order, float* out, int B, int N, int k,
+                                 void* stream) {
+    if (!mask || !order || !out || B <= 0 || N < 2 || k < 1 || k + 1 > ld_order) return MADTP_E_BADARG;
+    hipLaunchKernelGGL(mask_gather_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mask, order, ld_order, out, N, k);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_query_att_ft(const float* token_attn, int ldt, int K, const float* x, float* out, float inv_sqrt_sd,
+                                  int accumulate, int B, int N, int dim, void* stream) {
+    if (!token_attn || !x || !out || B <= 0 || N < 2) return MADTP_E_BADARG;
+    if (K <= 0 || K > 112 || dim % 64 || ldt < K) return MADTP_E_SHAPE;
+    hipLaunchKernelGGL(query_att_ft_kernel, dim3(dim / 64, B), dim3(256), 0, (hipStream_t)stream, token_attn, ldt, K, x, out,
+                       inv_sqrt_sd, accumulate, N, dim);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}

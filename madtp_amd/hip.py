@@ -1,0 +1,252 @@
+"""ctypes binding of libmadtp_hip.so (include/madtp_hip.h) + thin tensor-level wrappers.
+
+PyTorch is plumbing here: it owns device memory and the stream; every arithmetic op on the product path is one
+of the hand-written gfx950 kernels behind the C-ABI.  There is NO fallback: if the library is missing or a kernel
+rejects its arguments a RuntimeError is raised.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_size_t, c_void_p
+
+import torch
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
+ABI_VERSION = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
+
+_SIGS = {
+    "madtp_abi_version": (c_int, []),
+    "madtp_strerror": (ctypes.c_char_p, [c_int]),
+    "madtp_gemm": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_int, c_int, c_int, c_float, c_void_p]),
+    "madtp_layernorm": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p]),
+    "madtp_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "madtp_assemble_tokens": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
+    "madtp_bert_embed": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_void_p]),
+    "madtp_attention": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float, c_int, c_void_p]),
+    "madtp_token_score": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]
+                          + [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
+    "madtp_token_select": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_void_p]),
+    "madtp_token_gather": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "madtp_mask_gather": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "madtp_query_att_ft": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,
+                                   c_void_p]),
+    "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
+    "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def load(path=None):
+    """Loads the library (no GPU needed for loading / symbol resolution)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found - run `python -m madtp_amd.build` (hipcc, gfx950). "
+                           "There is no CPU/eager fallback for the product path.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError => header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.madtp_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"libmadtp_hip ABI {v} != binding {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def _check(code, what):
+    if code != 0:
+        msg = load().madtp_strerror(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _req(t, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU: the MADTP hot path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+# --------------------------------------------------------------------------------------------------------------
+def gemm(a, w, bias=None, residual=None, out_dtype=None, act=ACT_NONE, n=None, out=None, out_scale=1.0):
+    """act(a[M,K] @ w[Npad,K]^T + bias) * out_scale (+ residual) -> [M, n].  w must be padded to 128 rows."""
+    _req(w, name="w")
+    if not a.is_cuda or a.dim() != 2 or a.stride(1) != 1:
+        raise RuntimeError("gemm: a must be a GPU row-major 2-D view (no CPU fallback)")
+    M, K = a.shape
+    n = n if n is not None else w.shape[0]
+    if w.shape[0] % 128 or w.shape[1] != K or a.dtype != w.dtype:
+        raise RuntimeError(f"gemm: bad weight {tuple(w.shape)} {w.dtype} for a {tuple(a.shape)} {a.dtype}")
+    out_dtype = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty((M, n), device=a.device, dtype=out_dtype)
+    ldr = residual.stride(0) if residual is not None else 0
+    if residual is not None:
+        _req(residual, torch.float32, "residual")
+    if bias is not None:
+        _req(bias, torch.float32, "bias")
+    _check(load().madtp_gemm(_p(a), _p(w), _p(bias), _p(residual), _p(out), M, n, K, a.stride(0), w.stride(0),
+                             out.stride(0), ldr, _dt(a), _dt(out), act, float(out_scale), _stream()), "madtp_gemm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, want_f32=True, want_bf16=False):
+    _req(x, torch.float32, "x")
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    y32 = torch.empty_like(x) if want_f32 else None
+    ylp = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    _check(load().madtp_layernorm(_p(x), _p(gamma), _p(beta), _p(y32), _p(ylp), rows, dim, float(eps), _stream()),
+           "madtp_layernorm")
+    return y32, ylp
+
+
+def patchify(img, patch, out_dtype):
+    _req(img, torch.float32, "img")
+    B, C, S, _ = img.shape
+    g = S // patch
+    cols = torch.empty((B * g * g, C * patch * patch), device=img.device, dtype=out_dtype)
+    _check(load().madtp_patchify(_p(img), _p(cols), B, S, patch, _dt(cols), _stream()), "madtp_patchify")
+    return cols
+
+
+def assemble_tokens(patches, cls, pos, B, np_):
+    dim = patches.shape[-1]
+    x = torch.empty((B, np_ + 1, dim), device=patches.device, dtype=torch.float32)
+    _check(load().madtp_assemble_tokens(_p(patches), _p(cls), _p(pos), _p(x), B, np_, dim, _stream()),
+           "madtp_assemble_tokens")
+    return x
+
+
+def bert_embed(ids, word_emb, pos_emb, gamma, beta, eps, want_bf16=False):
+    _req(ids, torch.int64, "input_ids")
+    B, L = ids.shape
+    dim = word_emb.shape[1]
+    y32 = torch.empty((B, L, dim), device=ids.device, dtype=torch.float32)
+    ylp = torch.empty((B, L, dim), device=ids.device, dtype=torch.bfloat16) if want_bf16 else None
+    _check(load().madtp_bert_embed(_p(ids), _p(word_emb), _p(pos_emb), _p(gamma), _p(beta), _p(y32), _p(ylp), B, L, dim,
+                                   float(eps), _stream()), "madtp_bert_embed")
+    return y32, ylp
+
+
+def attention(q, k, v, B, H, Nq, Nk, scale, add_mask=None, scores=False):
+    """q,k,v: 2-D row views [B*N, >=H*64] (may be column slices of one fused projection).  Returns
+    (out[B*Nq, H*64], (colsum_part, p0, onorm) or None)."""
+    for t in (q, k, v):
+        if not t.is_cuda or t.stride(1) != 1:
+            raise RuntimeError("attention operands must be GPU row-major views")
+    out = torch.empty((B * Nq, H * 64), device=q.device, dtype=q.dtype)
+    side = None
+    cs = p0 = on = None
+    if scores:
+        nrt = (Nq + 15) // 16
+        cs = torch.empty((B, nrt, Nk), device=q.device, dtype=torch.float32)
+        p0 = torch.empty((B, H, Nk), device=q.device, dtype=torch.float32)
+        on = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
+        side = (cs, p0, on)
+    if add_mask is not None:
+        _req(add_mask, torch.float32, "add_mask")
+    _check(load().madtp_attention(_p(q), _p(k), _p(v), _p(out), _p(add_mask), _p(cs), _p(p0), _p(on), B, H, Nq, Nk,
+                                  q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), _dt(q), _stream()),
+           "madtp_attention")
+    return out, side
+
+
+def token_score(side, token_attn, K, temperature, B, H, N):
+    cs, p0, on = side
+    n = N - 1
+    dev = token_attn.device
+    score = torch.empty((B, n), device=dev, dtype=torch.float32)
+    thr = torch.empty((B,), device=dev, dtype=torch.float32)
+    count = torch.empty((B,), device=dev, dtype=torch.int32)
+    kmax = torch.zeros((1,), device=dev, dtype=torch.int32)
+    _check(load().madtp_token_score(_p(cs), cs.shape[1], _p(p0), _p(on), _p(token_attn), token_attn.stride(0), K,
+                                    float(temperature), _p(score), _p(thr), _p(count), _p(kmax), B, H, N, _stream()),
+           "madtp_token_score")
+    return score, thr, count, kmax
+
+
+def token_select(score, k):
+    B, n = score.shape
+    dev = score.device
+    indices = torch.empty((B, k), device=dev, dtype=torch.int64)
+    indices_sort = torch.empty((B, n), device=dev, dtype=torch.int64)
+    dst_pos = torch.empty((B, n), device=dev, dtype=torch.int32)
+    merge_w = torch.empty((B, n), device=dev, dtype=torch.float32)
+    _check(load().madtp_token_select(_p(score), k, _p(indices), _p(indices_sort), _p(dst_pos), _p(merge_w), B, n,
+                                     _stream()), "madtp_token_select")
+    return indices, indices_sort, dst_pos, merge_w
+
+
+def token_gather(x, dst_pos, merge_w, k):
+    _req(x, torch.float32, "x")
+    B, N, dim = x.shape
+    y = torch.empty((B, k + 2, dim), device=x.device, dtype=torch.float32)
+    _check(load().madtp_token_gather(_p(x), _p(dst_pos), _p(merge_w), _p(y), B, N, k, dim, _stream()),
+           "madtp_token_gather")
+    return y
+
+
+def mask_gather(mask2d, order, k):
+    """mask2d f32 [B,N] additive; order int64 [B,>=k+1] -> [B,k+2]."""
+    _req(mask2d, torch.float32, "mask")
+    B, N = mask2d.shape
+    out = torch.empty((B, k + 2), device=mask2d.device, dtype=torch.float32)
+    _check(load().madtp_mask_gather(_p(mask2d), _p(order), order.stride(0), _p(out), B, N, k, _stream()),
+           "madtp_mask_gather")
+    return out
+
+
+def query_att_ft(token_attn, K, x, out=None, sd_dim=768):
+    _req(x, torch.float32, "x")
+    B, N, dim = x.shape
+    acc = 1
+    if out is None:
+        out = torch.empty((B, K, dim), device=x.device, dtype=torch.float32)
+        acc = 0
+    _check(load().madtp_query_att_ft(_p(token_attn), token_attn.stride(0), K, _p(x), _p(out), 1.0 / (sd_dim ** 0.5), acc,
+                                     B, N, dim, _stream()), "madtp_query_att_ft")
+    return out
+
+
+def add_scale(a, b, scale):
+    out = torch.empty_like(a)
+    _check(load().madtp_add_scale(_p(a), _p(b), _p(out), float(scale), a.numel(), _stream()), "madtp_add_scale")
+    return out
+
+
+def cast_bf16(src):
+    _req(src, torch.float32, "src")
+    dst = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
+    _check(load().madtp_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "madtp_cast_bf16")
+    return dst

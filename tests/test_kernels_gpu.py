@@ -1,0 +1,247 @@
+"""Per-kernel parity on a real MI355X: each C-ABI entry point vs a plain PyTorch fp32 (CPU) restatement of the
+same op on seeded inputs, including ragged / edge shapes.  Integer outputs (indices, counts, compaction maps)
+must be bit-exact; f32 kernels within 2e-5 relative; bf16-input GEMMs within bf16 rounding of the inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from madtp_amd import build, hip as h
+    build.build(verbose=False)
+    h.load()
+    assert torch.cuda.is_available()
+    return h
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _pad128(w):
+    n = w.shape[0]
+    npad = (n + 127) // 128 * 128
+    if npad == n:
+        return w.contiguous()
+    return torch.cat([w, torch.zeros(npad - n, w.shape[1], dtype=w.dtype)], 0).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (197, 768, 768), (300, 100, 768), (1000, 2304, 768), (130, 768, 3072),
+                                   (257, 2, 768)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gemm(hip, M, N, K, dtype):
+    a = _rand(M, K, seed=1)
+    w = _rand(N, K, seed=2, scale=0.05)
+    bias = _rand(N, seed=3)
+    res = _rand(M, N, seed=4)
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    a_d, w_d = a.to(td), _pad128(w).to(td)
+    ref_a, ref_w = a_d.float(), w.to(td).float()  # reference sees the same (rounded) operands
+    for act, fn in ((hip.ACT_NONE, lambda t: t), (hip.ACT_GELU, F.gelu), (hip.ACT_RELU, F.relu),
+                    (hip.ACT_QUICK_GELU, lambda t: t * torch.sigmoid(1.702 * t))):
+        out = hip.gemm(a_d.cuda(), w_d.cuda(), bias.cuda(), res.cuda(), out_dtype=torch.float32, act=act, n=N)
+        ref = fn(ref_a.double() @ ref_w.double().t() + bias.double()).float() + res
+        err = (out.cpu() - ref).abs().max().item()
+        tol = 2e-5 * max(1.0, ref.abs().max().item()) * (1 if dtype == "f32" else 4)
+        assert err < tol, (act, err, tol)
+    # no bias / no residual / bf16 out / scaling
+    out = hip.gemm(a_d.cuda(), w_d.cuda(), out_dtype=torch.bfloat16, n=N, out_scale=0.5)
+    ref = ((ref_a.double() @ ref_w.double().t()) * 0.5).float()
+    assert (out.float().cpu() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_strided_a_and_transpose_detect(hip):
+    # A given as a column slice of a wider matrix (lda > K); asymmetric operands catch a swapped C layout
+    big = _rand(70, 2304, seed=5)
+    a = big[:, 768:1536]
+    w = _rand(256, 768, seed=6, scale=0.05)
+    out = hip.gemm(big.cuda()[:, 768:1536], w.cuda(), n=256)
+    ref = a.double() @ w.double().t()
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("rows,dim,eps", [(1, 768, 1e-6), (197 * 3, 768, 1e-12), (5, 512, 1e-5), (7, 1024, 1e-5)])
+def test_layernorm(hip, rows, dim, eps):
+    x = _rand(rows, dim, seed=7) * 3 + 0.5
+    g, b = _rand(dim, seed=8), _rand(dim, seed=9)
+    y32, ybf = hip.layernorm(x.cuda(), g.cuda(), b.cuda(), eps, want_f32=True, want_bf16=True)
+    ref = F.layer_norm(x, (dim,), g, b, eps)
+    assert (y32.cpu() - ref).abs().max().item() < 2e-5
+    assert (ybf.float().cpu() - ref).abs().max().item() < 0.04
+
+
+def test_patchify_assemble(hip):
+    B, S, P, D = 3, 64, 16, 768
+    img = _rand(B, 3, S, S, seed=10)
+    w = _rand(D, 3, P, P, seed=11, scale=0.02)
+    bias = _rand(D, seed=12, scale=0.02)
+    cls, pos = _rand(1, 1, D, seed=13), _rand(1, (S // P) ** 2 + 1, D, seed=14)
+    cols = hip.patchify(img.cuda(), P, torch.float32)
+    unf = F.unfold(img, P, stride=P).transpose(1, 2).reshape(-1, 3 * P * P)
+    assert torch.equal(cols.cpu(), unf)
+    pe = hip.gemm(cols, w.reshape(D, -1).contiguous().cuda(), bias.cuda(), n=D)
+    x = hip.assemble_tokens(pe, cls.cuda(), pos.cuda(), B, (S // P) ** 2)
+    ref = F.conv2d(img, w, bias, stride=P).flatten(2).transpose(1, 2)
+    ref = torch.cat([cls.expand(B, -1, -1), ref], 1) + pos
+    assert (x.cpu() - ref).abs().max().item() < 2e-5
+    colsb = hip.patchify(img.cuda(), P, torch.bfloat16)
+    assert torch.equal(colsb.cpu(), unf.to(torch.bfloat16))
+
+
+def test_bert_embed(hip):
+    B, L, D, V = 3, 20, 768, 1000
+    ids = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(1))
+    we, pe = _rand(V, D, seed=15, scale=0.02), _rand(512, D, seed=16, scale=0.02)
+    g, b = _rand(D, seed=17), _rand(D, seed=18)
+    y32, ybf = hip.bert_embed(ids.cuda(), we.cuda(), pe.cuda(), g.cuda(), b.cuda(), 1e-12, want_bf16=True)
+    ref = F.layer_norm(we[ids] + pe[:L][None], (D,), g, b, 1e-12)
+    assert (y32.cpu() - ref).abs().max().item() < 2e-5
+    assert (ybf.float().cpu() - ref).abs().max().item() < 0.04
+
+
+def _ref_attention(qkv, B, N, H, scale, mask=None):
+    q, k, v = qkv.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * scale
+    if mask is not None:
+        s = s + mask[:, None, None, :]
+    p = s.softmax(-1)
+    o = p @ v
+    colsum = p[:, :, 1:, :].max(1)[0].sum(1)          # [B,N] column mass of head-max P over rows i>=1
+    return o.transpose(1, 2).reshape(B * N, H * 64), p, colsum, p[:, :, 0, :], o.norm(dim=-1)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 20, 12), (1, 1 + 16 * 4, 2), (2, 130, 12), (1, 256, 3), (2, 17, 1)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_self_attention_with_scores(hip, B, N, H, dtype):
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    qkv = (_rand(B * N, 3 * H * 64, seed=20)).to(td)
+    mask = (torch.rand(B, N, generator=torch.Generator().manual_seed(3)) > 0.8).float() * -10000.0
+    mask[:, 0] = 0
+    for m in (None, mask):
+        qd = qkv.cuda()
+        out, (cs, p0, on) = hip.attention(qd[:, : H * 64], qd[:, H * 64: 2 * H * 64], qd[:, 2 * H * 64:], B, H, N, N,
+                                          0.125, add_mask=None if m is None else m.cuda(), scores=True)
+        ro, rp, rcol, rp0, rn = _ref_attention(qkv.float(), B, N, H, 0.125, m)
+        tol = 3e-5 if dtype == "f32" else 2e-2
+        assert (out.float().cpu() - ro).abs().max().item() < tol * max(1, ro.abs().max().item())
+        assert (cs.sum(1).cpu() - rcol).abs().max().item() < 1e-4
+        assert (p0.cpu() - rp0).abs().max().item() < 1e-5
+        assert (on.cpu() - rn).abs().max().item() < 1e-4 * max(1, rn.max().item())
+
+
+@pytest.mark.parametrize("B,L,Nk", [(2, 20, 143), (3, 35, 197), (1, 5, 9), (64, 20, 130)])
+def test_cross_attention(hip, B, L, Nk):
+    H = 12
+    q = _rand(B * L, H * 64, seed=21)
+    kv = _rand(B * Nk, 2 * H * 64, seed=22)
+    kvd = kv.cuda()
+    out, side = hip.attention(q.cuda(), kvd[:, : H * 64], kvd[:, H * 64:], B, H, L, Nk, 0.125)
+    assert side is None
+    qq = q.reshape(B, L, H, 64).transpose(1, 2)
+    kk, vv = kv.reshape(B, Nk, 2, H, 64).permute(2, 0, 3, 1, 4)
+    ref = ((qq @ kk.transpose(-1, -2)) * 0.125).softmax(-1) @ vv
+    ref = ref.transpose(1, 2).reshape(B * L, H * 64)
+    assert (out.cpu() - ref).abs().max().item() < 3e-5 * max(1, ref.abs().max().item())
+
+
+def _ref_reduce(x, probs, cls_attn, token_attn, T):
+    """the reference rule, plain torch (vit.py:123-163)."""
+    a = probs[:, :, 1:, 1:].max(1)[0].sum(1)
+    a = a / (a.sum(1, keepdim=True) + 1e-8)
+    t = token_attn.max(2)[0]
+    t = t / (t.sum(1, keepdim=True) + 1e-8)
+    score = (a + t + cls_attn) / 3.0
+    w = torch.softmax(token_attn / T, dim=1).permute(0, 2, 1)
+    thr = torch.bmm(w, score.unsqueeze(-1)).min(1)[0]
+    cnt = (score > thr).sum(1)
+    return score, thr.squeeze(-1), cnt
+
+
+@pytest.mark.parametrize("B,N,T", [(4, 197, 1.0), (3, 197, 5.0), (2, 20, 3.0), (5, 131, 10.0), (2, 250, 2.0)])
+def test_token_score_select_gather(hip, B, N, T):
+    H, K, D = 12, 100, 768
+    qkv = _rand(B * N, 3 * H * 64, seed=30)
+    x = _rand(B, N, D, seed=31)
+    sd = _rand(K, D, seed=32)
+    qd = qkv.cuda()
+    _, side = hip.attention(qd[:, :768], qd[:, 768:1536], qd[:, 1536:], B, H, N, N, 0.125, scores=True)
+    ta_full = hip.gemm(x.reshape(B * N, D).cuda(), _pad128(sd).cuda(), n=128)     # rows incl. CLS, ld 128
+    score, thr, count, kmax = hip.token_score(side, ta_full, K, T, B, H, N)
+    _, rp, _, _, _ = _ref_attention(qkv, B, N, H, 0.125)
+    q, k, v = qkv.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    o = rp @ v
+    hi = o[..., 1:, :].norm(dim=-1)
+    cls_attn = (rp[:, :, 0, 1:] * (hi / (hi.sum(1, keepdim=True) + 1e-8))).sum(1)
+    token_attn = x[:, 1:, :] @ sd.t()
+    rs, rthr, rcnt = _ref_reduce(x[:, 1:], rp, cls_attn, token_attn, T)
+    assert (score.cpu() - rs).abs().max().item() < 2e-6 * max(1.0, rs.abs().max().item() * 100)
+    assert (thr.cpu() - rthr).abs().max().item() < 1e-6
+    # counts are integers: exact unless a score sits within float noise of the threshold
+    margin = (rs - rthr[:, None]).abs().min(1)[0]
+    safe = margin > 2e-7
+    assert torch.equal(count.cpu()[safe].long(), rcnt[safe])
+    assert int(kmax.item()) == int(count.max().item())
+
+    # selection on the DEVICE scores must be exactly the stable descending order of those same scores
+    n = N - 1
+    for k in sorted({1, max(1, n // 2), n - 2, int(kmax.item())} - {0, n}):
+        idx, idx_sort, dst, mw = hip.token_select(score, k)
+        s = score.cpu()
+        order = torch.argsort(s, dim=1, descending=True, stable=True)
+        assert torch.equal(idx_sort.cpu(), order)
+        keep = torch.zeros(B, n, dtype=torch.bool).scatter_(1, order[:, :k], True)
+        ref_idx = torch.stack([torch.nonzero(keep[b]).squeeze(1) for b in range(B)])
+        assert torch.equal(idx.cpu(), ref_idx)
+        ref_dst = torch.full((B, n), -1, dtype=torch.int32)
+        for b in range(B):
+            ref_dst[b, ref_idx[b]] = torch.arange(k, dtype=torch.int32)
+        assert torch.equal(dst.cpu(), ref_dst)
+        w = torch.where(keep, torch.zeros_like(s), s)
+        w = w / (w.sum(1, keepdim=True) + 1e-8)
+        assert (mw.cpu() - w).abs().max().item() < 1e-6
+        y = hip.token_gather(x.cuda(), dst, mw, k)
+        ref_y = torch.cat([x[:, :1], torch.gather(x[:, 1:], 1, ref_idx[..., None].expand(-1, -1, D)),
+                           torch.bmm(w.unsqueeze(1), x[:, 1:])], 1)
+        assert y.shape == (B, k + 2, D)
+        assert torch.equal(y[:, : k + 1].cpu(), ref_y[:, : k + 1])           # pure copies: bit-exact
+        assert (y[:, k + 1].cpu() - ref_y[:, k + 1]).abs().max().item() < 1e-5
+        m2 = _rand(B, N, seed=33)
+        mg = hip.mask_gather(m2.cuda(), idx_sort, k)
+        ref_m = torch.cat([m2[:, :1], torch.gather(m2[:, 1:], 1, order[:, : k + 1])], 1)
+        assert torch.equal(mg.cpu(), ref_m)
+
+
+def test_select_ties_and_extremes(hip):
+    # ties resolve to the lower index (stable), all-equal scores, k = n
+    s = torch.tensor([[0.5, 0.5, 0.1, 0.9, 0.5, 0.1, 0.9, 0.0]] * 2)
+    idx, idx_sort, dst, mw = hip.token_select(s.cuda(), 3)
+    assert idx_sort.cpu()[0].tolist() == [3, 6, 0, 1, 4, 2, 5, 7]
+    assert idx.cpu()[0].tolist() == [0, 3, 6]
+    idx, idx_sort, dst, mw = hip.token_select(torch.ones(1, 8).cuda(), 8)
+    assert idx.cpu()[0].tolist() == list(range(8)) and (mw.cpu() == 0).all()
+
+
+def test_query_att_ft(hip):
+    B, N, D, K = 3, 131, 768, 100
+    x = _rand(B, N, D, seed=40)
+    sd = _rand(K, D, seed=41, scale=0.2)
+    ta = hip.gemm(x.reshape(B * N, D).cuda(), _pad128(sd).cuda(), n=128)
+    out = hip.query_att_ft(ta, K, x.cuda())
+    inner = x[:, 1:] @ sd.t()
+    ref = torch.bmm(torch.softmax((inner / math.sqrt(D)).permute(0, 2, 1), -1), x[:, 1:])
+    assert (out.cpu() - ref).abs().max().item() < 2e-5 * max(1, ref.abs().max().item())
+    out2 = hip.query_att_ft(ta, K, x.cuda(), out=out.clone())
+    assert (out2.cpu() - 2 * ref).abs().max().item() < 4e-5 * max(1, ref.abs().max().item())
+
+
+def test_small_elementwise(hip):
+    a, b = _rand(8, 768, seed=50), _rand(8, 768, seed=51)
+    assert torch.equal(hip.add_scale(a.cuda(), b.cuda(), 0.5).cpu(), (a + b) / 2)
+    assert torch.equal(hip.cast_bf16(a.cuda()).cpu(), a.to(torch.bfloat16))
