@@ -85,11 +85,12 @@ int madtp_attention(const void* q, const void* k, const void* v, void* out, cons
 
 /* Alignment-guided token-importance score, per-sample threshold and survivor count
  * (Block.Reduce_token vit.py:125-145 == med.py:347-371 == nlvr_encoder.py:404-432 == clip/model.py:196-218).
- * n = N-1 patch tokens.  token_attn f32 rows (b*N + 1 + t) with leading dim ldt, K columns (raw x.sd^T logits).
+ * n = N-1 patch tokens.  token_attn f32: element [b,t,c] at token_attn[b*ldt_batch + t*ldt_row + c], c < K (raw
+ * x.sd^T logits of patch token t; any strided [B,n,K] view with unit column stride).
  * Outputs: score f32 [B,n]; threshold f32 [B]; count int32 [B]; kmax int32[1] = max_b count (must be zeroed by
  * the caller before the launch). */
 int madtp_token_score(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
-                      const float* token_attn, int ldt, int K, float temperature,
+                      const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature,
                       float* score, float* threshold, int32_t* count, int32_t* kmax,
                       int B, int H, int N, void* stream);
 
@@ -114,10 +115,16 @@ int madtp_mask_gather(const float* mask, const int64_t* order, int ld_order, flo
                       void* stream);
 
 /* Query_model's att_ft (models/utils.py:174-178): att_ft[b,c,:] (+)= sum_t softmax_t(token_attn[b,t,c]/sqrt(dim_sd)) * x[b,1+t,:]
- * token_attn as in madtp_token_score; x f32 [B,N,dim]; out f32 [B,K,dim]; accumulate!=0 adds into out
- * (sd_img_ft_all += sd_img_ft, vit.py:300-303). */
-int madtp_query_att_ft(const float* token_attn, int ldt, int K, const float* x, float* out, float inv_sqrt_sd,
-                       int accumulate, int B, int N, int dim, void* stream);
+ * token_attn as in madtp_token_score; ft f32: patch token t of sample b at ft[b*ldf_batch + t*ldf_row + d] (so
+ * x[:,1:,:] of a [B,N,dim] tensor is passed without a copy); n patch tokens; out f32 [B,K,dim] contiguous;
+ * accumulate!=0 adds into out (sd_img_ft_all += sd_img_ft, vit.py:300-303). */
+int madtp_query_att_ft(const float* token_attn, int ldt_row, int ldt_batch, int K, const float* ft, int ldf_row,
+                       int ldf_batch, float* out, float inv_sqrt_sd, int accumulate, int B, int n, int dim,
+                       void* stream);
+
+/* vector_gather (models/utils.py:13-33): out[b,k,:] = vectors[b, indices[b,k], :]; f32 [B,L,D], int64 [B,K]. */
+int madtp_vector_gather(const float* vectors, const int64_t* indices, float* out, int B, int L, int K, int D,
+                        void* stream);
 
 /* (a+b)*scale elementwise, f32 (nlvr_encoder.py:266 average of the two cross-attention branches). */
 int madtp_add_scale(const float* a, const float* b, float* out, float scale, size_t n, void* stream);

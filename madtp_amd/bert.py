@@ -1,0 +1,528 @@
+"""Mirror of the reference's BERT text encoders with token pruning:
+     variant 'med'  - models/med.py           (BertLayer :332-467, BertEncoder :470-598, BertModel :686-929)
+     variant 'nlvr' - models/nlvr_encoder.py  (twin cross-attention; BertLayer :385-559, BertEncoder :562-687)
+Same sub-module / parameter names (checkpoint keys) and forward() signatures; the arithmetic is enqueued on the
+hand-written gfx950 kernels.  madtp_amd/med.py and madtp_amd/nlvr_encoder.py export the two variants under the
+reference's class names.
+"""
+import json
+import math
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .runtime import PreparedCache, compute_dtype, lin_of, require_gpu, as_f32_contig
+from .utils import Query_model
+
+
+class BertConfig:
+    """Minimal stand-in for transformers.BertConfig (the reference loads configs/med_config.json with it)."""
+    _defaults = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                     intermediate_size=3072, hidden_act="gelu", hidden_dropout_prob=0.1,
+                     attention_probs_dropout_prob=0.1, max_position_embeddings=512, type_vocab_size=2,
+                     initializer_range=0.02, layer_norm_eps=1e-12, pad_token_id=0, position_embedding_type="absolute",
+                     add_cross_attention=False, encoder_width=768, chunk_size_feed_forward=0, evaluate=True,
+                     output_attentions=False, output_hidden_states=False, use_return_dict=True, is_decoder=False)
+
+    def __init__(self, **kw):
+        for k, v in {**self._defaults, **kw}.items():
+            setattr(self, k, v)
+
+    @classmethod
+    def from_json_file(cls, path):
+        with open(path) as f:
+            return cls(**json.load(f))
+
+    @classmethod
+    def med_default(cls):
+        """configs/med_config.json of the reference."""
+        return cls(vocab_size=30524, encoder_width=768, add_cross_attention=True)
+
+
+_ENC_STORE = []
+
+
+def _cast(x2d):
+    return x2d if compute_dtype() == torch.float32 else hip.cast_bf16(x2d)
+
+
+def _ln_dual(norm, x2d):
+    """post-LN: returns (f32 residual copy, compute-dtype GEMM operand)."""
+    bf = compute_dtype() == torch.bfloat16
+    y32, ybf = hip.layernorm(x2d, norm.weight, norm.bias, norm.eps, want_f32=True, want_bf16=bf)
+    return y32, (ybf if bf else y32)
+
+
+class BertEmbeddings(nn.Module):
+    """med.py:43-86 / nlvr_encoder.py:43-86 (absolute positions; no token-type embeddings in BLIP's MED)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=config.pad_token_id)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.register_buffer("position_ids", torch.arange(config.max_position_embeddings).expand((1, -1)))
+        self.position_embedding_type = getattr(config, "position_embedding_type", "absolute")
+        self.config = config
+
+    def forward(self, input_ids=None, position_ids=None, inputs_embeds=None, past_key_values_length=0):
+        if input_ids is None or position_ids is not None or past_key_values_length != 0:
+            raise NotImplementedError("only the encoder use (input_ids, default positions) is on the pruned forward path")
+        require_gpu(input_ids, "input_ids")
+        y32, _ = hip.bert_embed(input_ids.contiguous(), self.word_embeddings.weight, self.position_embeddings.weight,
+                                self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+        return y32
+
+
+class BertSelfAttention(nn.Module):
+    """med.py:89-236 / nlvr_encoder.py:88-237."""
+
+    def __init__(self, config, is_cross_attention):
+        super().__init__()
+        self.config = config
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                             % (config.hidden_size, config.num_attention_heads))
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = int(config.hidden_size / config.num_attention_heads)
+        if self.attention_head_size != 64:
+            raise ValueError("the gfx950 attention kernels are built for head_dim 64")
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.query = nn.Linear(config.hidden_size, self.all_head_size)
+        kv_in = config.encoder_width if is_cross_attention else config.hidden_size
+        self.key = nn.Linear(kv_in, self.all_head_size)
+        self.value = nn.Linear(kv_in, self.all_head_size)
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+        self.position_embedding_type = getattr(config, "position_embedding_type", "absolute")
+        self.save_attention = False
+        self.attention_map = None
+        self.cls_attn = None
+        self.score_side = None
+        self.is_cross_attention = is_cross_attention
+        self._cache = PreparedCache()
+
+    def save_attn_gradients(self, g): self.attn_gradients = g
+    def get_attn_gradients(self): return self.attn_gradients
+    def save_attention_map(self, m): self.attention_map = m
+    def get_attention_map(self): return self.attention_map
+    def save_cls_attn(self, c): self.cls_attn = c
+    def get_cls_attn(self): return self.cls_attn
+
+    def run_self(self, hc2d, B, L, mask2d, want_scores):
+        """hc2d [B*L, 768] compute dtype -> (context [B*L,768] compute dtype, (key, value) views)."""
+        qkv = lin_of(self._cache, "qkv", [self.query, self.key, self.value])
+        C = self.all_head_size
+        y = hip.gemm(hc2d, qkv.w, qkv.b, n=qkv.n)
+        ctx, side = hip.attention(y[:, :C], y[:, C:2 * C], y[:, 2 * C:], B, self.num_attention_heads, L, L,
+                                  1.0 / math.sqrt(self.attention_head_size), add_mask=mask2d, scores=want_scores)
+        self.score_side = side
+        H, d = self.num_attention_heads, self.attention_head_size
+        kv = (y[:, C:2 * C].view(B, L, H, d).permute(0, 2, 1, 3), y[:, 2 * C:].view(B, L, H, d).permute(0, 2, 1, 3))
+        return ctx, kv
+
+    def run_cross(self, hc2d, B, L, enc_c2d, Nk, enc_mask2d):
+        q = lin_of(self._cache, "q", [self.query])
+        kv = lin_of(self._cache, "kv", [self.key, self.value])
+        C = self.all_head_size
+        qy = hip.gemm(hc2d, q.w, q.b, n=q.n)
+        kvy = hip.gemm(enc_c2d, kv.w, kv.b, n=kv.n)
+        ctx, _ = hip.attention(qy, kvy[:, :C], kvy[:, C:], B, self.num_attention_heads, L, Nk,
+                               1.0 / math.sqrt(self.attention_head_size), add_mask=enc_mask2d, scores=False)
+        return ctx
+
+
+class BertSelfOutput(nn.Module):
+    """med.py:239-250; nlvr_encoder.py:240-271 (twin / merge)."""
+
+    def __init__(self, config, twin=False, merge=False):
+        super().__init__()
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        if twin:
+            self.dense0 = nn.Linear(config.hidden_size, config.hidden_size)
+            self.dense1 = nn.Linear(config.hidden_size, config.hidden_size)
+        else:
+            self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        if merge:
+            self.merge_layer = nn.Linear(config.hidden_size * 2, config.hidden_size)
+            self.merge = True
+        else:
+            self.merge = False
+        self.twin = twin
+        self._cache = PreparedCache()
+
+    def run(self, ctx, inp32):
+        """ctx: [M,768] (or a pair for twin) in the compute dtype; inp32: f32 residual -> (f32, compute dtype)."""
+        if self.twin:
+            d0 = lin_of(self._cache, "d0", [self.dense0])
+            d1 = lin_of(self._cache, "d1", [self.dense1])
+            if self.merge:  # nlvr_encoder.py:263-264: merge_layer(cat[dense0(c0), dense1(c1)])
+                mg = lin_of(self._cache, "mg", [self.merge_layer])
+                M = ctx[0].shape[0]
+                cat = torch.empty((M, 2 * d0.n), device=inp32.device, dtype=compute_dtype())
+                hip.gemm(ctx[0], d0.w, d0.b, n=d0.n, out=cat[:, :d0.n])
+                hip.gemm(ctx[1], d1.w, d1.b, n=d1.n, out=cat[:, d0.n:])
+                s = hip.gemm(cat, mg.w, mg.b, residual=inp32, out_dtype=torch.float32, n=mg.n)
+            else:  # :266 (h0+h1)/2, folded into the GEMM epilogues: 0.5*h0 + input, then 0.5*h1 + that
+                t = hip.gemm(ctx[0], d0.w, d0.b, residual=inp32, out_dtype=torch.float32, n=d0.n, out_scale=0.5)
+                s = hip.gemm(ctx[1], d1.w, d1.b, residual=t, out_dtype=torch.float32, n=d1.n, out_scale=0.5)
+        else:
+            d = lin_of(self._cache, "d", [self.dense])
+            s = hip.gemm(ctx, d.w, d.b, residual=inp32, out_dtype=torch.float32, n=d.n)
+        return _ln_dual(self.LayerNorm, s)
+
+
+class BertAttention(nn.Module):
+    """med.py:253-299 / nlvr_encoder.py:274-349."""
+
+    def __init__(self, config, is_cross_attention=False, layer_num=-1, twin_cross=False):
+        super().__init__()
+        self.twin = is_cross_attention and twin_cross
+        if self.twin:
+            self.self0 = BertSelfAttention(config, is_cross_attention)
+            self.self1 = BertSelfAttention(config, is_cross_attention)
+            self.output = BertSelfOutput(config, twin=True, merge=layer_num >= 6)
+        else:
+            self.self = BertSelfAttention(config, is_cross_attention)
+            self.output = BertSelfOutput(config)
+        self.pruned_heads = set()
+
+
+class BertIntermediate(nn.Module):
+    """med.py:302-315."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+        if config.hidden_act != "gelu":
+            raise ValueError("only the erf-GELU of med_config.json is implemented")
+
+
+class BertOutput(nn.Module):
+    """med.py:318-329."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+class _BertLayerBase(nn.Module):
+    variant = "med"
+
+    def __init__(self, config, layer_num):
+        super().__init__()
+        self.config = config
+        self.chunk_size_feed_forward = config.chunk_size_feed_forward
+        self.seq_len_dim = 1
+        self.attention = BertAttention(config)
+        self.layer_num = layer_num
+        if self.config.add_cross_attention:
+            self.crossattention = BertAttention(config, is_cross_attention=True, layer_num=layer_num,
+                                                twin_cross=self.variant == "nlvr")
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+        self._cache = PreparedCache()
+        self.last_prune = None
+        self._enc_cache = None  # (key, compute-dtype copies of encoder_hidden_states) shared across layers by the encoder
+
+    # ---- pruning -------------------------------------------------------------------------------------------
+    def Reduce_token(self, x, reduce_num, temperature=0, self_attn=None, cls_attn=None, token_attn=None, mask=None):
+        """med.py:345-391 / nlvr_encoder.py:400-454.  x: FULL [B,L,D] f32 (row 0 = [ENC]/CLS kept); mask: additive
+        f32 [B,L].  Returns (x', mask')."""
+        B, L, D = x.shape
+        n = L - 1
+        sa = self.attention.self
+        score, thr, count, kmax = hip.token_score(sa.score_side, token_attn, temperature, B, sa.num_attention_heads, L)
+        k = int(kmax.item())
+        info = {"k": k, "score": score, "threshold": thr, "count": count, "pruned": False, "indices": None,
+                "indices_sort": None}
+        self.last_prune = info
+        if k < 1 or (n - k) <= 1:
+            return x, mask
+        indices, indices_sort, dst_pos, merge_w = hip.token_select(score, k)
+        info.update(pruned=True, indices=indices, indices_sort=indices_sort)
+        y = hip.token_gather(x, dst_pos, merge_w, k)
+        if mask is not None:
+            if self.variant == "nlvr":
+                order = indices_sort  # nlvr_encoder.py:452 gathers the mask with indices_sort[:, :k+1]
+            else:
+                # med.py:377,388-390: topk(k+1, sorted=False) - kept tokens keep their own mask, the merged slot takes
+                # the mask of the (k+1)-th ranked token (torch-CPU places it last)
+                order = torch.cat([indices, indices_sort[:, k:k + 1]], dim=1).contiguous()
+            mask = hip.mask_gather(mask, order, k)
+        return y, mask
+
+    # ---- forward --------------------------------------------------------------------------------------------
+    def _forward(self, hidden_states, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask,
+                 past_key_value, output_attentions, mode, token_attn, temperature):
+        require_gpu(hidden_states, "hidden_states")
+        if past_key_value is not None or output_attentions or head_mask is not None:
+            raise NotImplementedError("decoder caching / attention outputs / head masks are off the pruned forward path")
+        hidden = as_f32_contig(hidden_states)
+        B, L, D = hidden.shape
+        mask2d = None
+        if attention_mask is not None:
+            if attention_mask.dim() != 4 or attention_mask.shape[2] != 1:
+                raise NotImplementedError("only padding masks [B,1,1,L] (encoder use) are supported")
+            mask2d = as_f32_contig(attention_mask[:, 0, 0, :])
+        prune = temperature > 0
+        h2 = hidden.view(B * L, D)
+        ctx, present = self.attention.self.run_self(_cast(h2), B, L, mask2d, want_scores=prune)
+        att32, attc = self.attention.output.run(ctx, h2)
+        self.last_prune = None
+        if prune:
+            if mask2d is None:
+                raise ValueError("attention_mask is required when temperature > 0 (med.py:424)")
+            x, mask2d = self.Reduce_token(att32.view(B, L, D), 0, temperature, token_attn=token_attn, mask=mask2d)
+            if self.last_prune["pruned"]:
+                B, L, D = x.shape
+                att32 = x.view(B * L, D)
+                attc = _cast(att32)
+                attention_mask = mask2d[:, None, None, :]
+        if mode == 'multimodal':
+            assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
+            att32, attc = self._cross(att32, attc, B, L, encoder_hidden_states, encoder_attention_mask)
+        inter = lin_of(self._cache, "inter", [self.intermediate.dense])
+        outp = lin_of(self._cache, "out", [self.output.dense])
+        mid = hip.gemm(attc, inter.w, inter.b, act=hip.ACT_GELU, n=inter.n)
+        t = hip.gemm(mid, outp.w, outp.b, residual=att32, out_dtype=torch.float32, n=outp.n)
+        y32, _ = hip.layernorm(t, self.output.LayerNorm.weight, self.output.LayerNorm.bias, self.output.LayerNorm.eps)
+        return (y32.view(B, L, D), present, attention_mask)
+
+    def _enc_operand(self, enc):
+        """compute-dtype 2-D copy of an encoder tensor, shared by the 12 layers that receive the same tensor object
+        (the entry keeps `enc` alive, so identity + version cannot alias a recycled allocation)."""
+        dt = compute_dtype()
+        for src, ver, d, val in _ENC_STORE:
+            if src is enc and ver == enc._version and d == dt:
+                return val
+        e = as_f32_contig(enc)
+        val = _cast(e.view(-1, e.shape[-1]))
+        _ENC_STORE.append((enc, enc._version, dt, val))
+        while len(_ENC_STORE) > 4:
+            _ENC_STORE.pop(0)
+        return val
+
+    @staticmethod
+    def _enc_mask2d(m):
+        if m is None:
+            return None
+        return as_f32_contig(m[:, 0, 0, :]) if m.dim() == 4 else as_f32_contig(m)
+
+    def feed_forward_chunk(self, attention_output):
+        raise NotImplementedError("fused into forward()")
+
+
+class MedBertLayer(_BertLayerBase):
+    """models/med.py BertLayer :332-467."""
+    variant = "med"
+
+    def _cross(self, att32, attc, B, L, enc, enc_mask):
+        # med.py:197-199 ignores the encoder mask in cross-attention (`and not is_cross_attention`)
+        ca = self.crossattention
+        ctx = ca.self.run_cross(attc, B, L, self._enc_operand(enc), enc.shape[1], None)
+        return ca.output.run(ctx, att32)
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
+                encoder_attention_mask=None, past_key_value=None, output_attentions=False, mode=None, space_dict=None,
+                token_attn=None, reduce_num=0, temperature=0):
+        return self._forward(hidden_states, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask,
+                             past_key_value, output_attentions, mode, token_attn, temperature)
+
+
+class NlvrBertLayer(_BertLayerBase):
+    """models/nlvr_encoder.py BertLayer :385-559 (note the different positional order: space_dict is arg 3)."""
+    variant = "nlvr"
+
+    def _cross(self, att32, attc, B, L, enc, enc_mask):
+        ca = self.crossattention
+        c0 = ca.self0.run_cross(attc, B, L, self._enc_operand(enc[0]), enc[0].shape[1], self._enc_mask2d(enc_mask[0]))
+        c1 = ca.self1.run_cross(attc, B, L, self._enc_operand(enc[1]), enc[1].shape[1], self._enc_mask2d(enc_mask[1]))
+        return ca.output.run([c0, c1], att32)
+
+    def forward(self, hidden_states, attention_mask=None, space_dict=None, head_mask=None, encoder_hidden_states=None,
+                encoder_attention_mask=None, past_key_value=None, output_attentions=False, mode=None, token_attn=None,
+                reduce_num=0, temperature=0):
+        return self._forward(hidden_states, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask,
+                             past_key_value, output_attentions, mode, token_attn, temperature)
+
+
+class _Out(tuple):
+    """BaseModelOutput* stand-in: tuple with attribute access."""
+
+    def __new__(cls, last_hidden_state):
+        o = super().__new__(cls, (last_hidden_state,))
+        o.last_hidden_state = last_hidden_state
+        o.past_key_values = None
+        o.hidden_states = None
+        o.attentions = None
+        o.cross_attentions = None
+        o.pooler_output = None
+        return o
+
+
+class _BertEncoderBase(nn.Module):
+    layer_cls = MedBertLayer
+
+    def __init__(self, config, sd_dim=768):
+        super().__init__()
+        self.config = config
+        self.layer = nn.ModuleList([self.layer_cls(config, i) for i in range(config.num_hidden_layers)])
+        self.gradient_checkpointing = False
+        self.txt_query_model = Query_model(ft_dim=config.hidden_size, sd_dim=sd_dim, temperature=1,
+                                           att_func_type='sparsemax', pool_type='max')
+
+    def _run(self, hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states, encoder_attention_mask,
+             mode, always_query):
+        sd_txt_ft_all = None
+        reduce_num = int((hidden_states.shape[-2] - 1) // self.config.num_hidden_layers)
+        for i, layer_module in enumerate(self.layer):
+            token_attn = None
+            if space_dict is not None or always_query:
+                if space_dict is None:
+                    raise TypeError("nlvr_encoder.BertEncoder calls txt_query_model unconditionally (:608): "
+                                    "space_dict must be given")
+                token_attn, sd_txt_ft, _ = self.txt_query_model(hidden_states[:, 1:, :], space_dict,
+                                                                return_token_att=True, temperature=temperature)
+                if sd_txt_ft is not None:
+                    sd_txt_ft_all = sd_txt_ft if sd_txt_ft_all is None else hip.add_scale(sd_txt_ft_all, sd_txt_ft, 1.0)
+            t = temperature if space_dict is not None else 0
+            if self.layer_cls.variant == "nlvr":
+                outs = layer_module(hidden_states, attention_mask, space_dict, None, encoder_hidden_states,
+                                    encoder_attention_mask, None, False, mode=mode, token_attn=token_attn,
+                                    reduce_num=reduce_num, temperature=t)
+            else:
+                outs = layer_module(hidden_states, attention_mask, None, encoder_hidden_states, encoder_attention_mask,
+                                    None, False, mode=mode, space_dict=space_dict, token_attn=token_attn,
+                                    reduce_num=reduce_num, temperature=t)
+            hidden_states = outs[0]
+            attention_mask = outs[-1]
+        return _Out(hidden_states), sd_txt_ft_all
+
+
+class MedBertEncoder(_BertEncoderBase):
+    """models/med.py BertEncoder :470-598."""
+    layer_cls = MedBertLayer
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
+                encoder_attention_mask=None, past_key_values=None, use_cache=None, output_attentions=False,
+                output_hidden_states=False, return_dict=True, mode='multimodal', space_dict=None, temperature=0):
+        return self._run(hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states,
+                         encoder_attention_mask, mode, always_query=False)
+
+
+class NlvrBertEncoder(_BertEncoderBase):
+    """models/nlvr_encoder.py BertEncoder :562-687."""
+    layer_cls = NlvrBertLayer
+
+    def forward(self, hidden_states, attention_mask=None, space_dict=None, temperature=0, head_mask=None,
+                encoder_hidden_states=None, encoder_attention_mask=None, past_key_values=None, use_cache=None,
+                output_attentions=False, output_hidden_states=False, return_dict=True, mode='multimodal'):
+        return self._run(hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states,
+                         encoder_attention_mask, mode, always_query=True)
+
+
+class _BertModelBase(nn.Module):
+    encoder_cls = MedBertEncoder
+
+    def __init__(self, config, add_pooling_layer=True, sd_dim=768):
+        super().__init__()
+        if add_pooling_layer:
+            raise NotImplementedError("BLIP builds its text encoders with add_pooling_layer=False")
+        self.config = config
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = self.encoder_cls(config, sd_dim)
+        self.pooler = None
+        if not getattr(config, "evaluate", True):
+            self.apply(self._init_weights)
+
+    def _init_weights(self, module):
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    def get_input_embeddings(self):
+        return self.embeddings.word_embeddings
+
+    def get_extended_attention_mask(self, attention_mask, input_shape=None, device=None, is_decoder=False):
+        """med.py:728-786 (encoder branch): (1 - m) * -10000 broadcast as [B,1,1,L]."""
+        if is_decoder:
+            raise NotImplementedError("causal (decoder) masks are off the pruned forward path")
+        if attention_mask.dim() == 3:
+            ext = attention_mask[:, None, :, :]
+        elif attention_mask.dim() == 2:
+            ext = attention_mask[:, None, None, :]
+        else:
+            raise ValueError("Wrong shape for input_ids (shape {}) or attention_mask (shape {})".format(
+                input_shape, attention_mask.shape))
+        return (1.0 - ext.to(torch.float32)) * -10000.0
+
+    def invert_attention_mask(self, m):
+        return self.get_extended_attention_mask(m)
+
+    def _run(self, input_ids, attention_mask, space_dict, temperature, encoder_embeds, encoder_hidden_states,
+             encoder_attention_mask, mode, inputs_embeds=None):
+        if input_ids is not None and inputs_embeds is not None:
+            raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+        if input_ids is not None:
+            batch_size, seq_length = input_ids.size()
+            device = input_ids.device
+        elif encoder_embeds is not None:
+            batch_size, seq_length = encoder_embeds.size()[:-1]
+            device = encoder_embeds.device
+        else:
+            raise ValueError("You have to specify either input_ids or inputs_embeds or encoder_embeds")
+        if attention_mask is None:
+            attention_mask = torch.ones((batch_size, seq_length), device=device)
+        ext = self.get_extended_attention_mask(attention_mask, (batch_size, seq_length), device, False)
+        if encoder_hidden_states is not None:
+            if isinstance(encoder_hidden_states, list):
+                enc_ext = [self.invert_attention_mask(m) for m in encoder_attention_mask]
+            elif encoder_attention_mask is None:
+                enc_ext = None
+            else:
+                enc_ext = self.invert_attention_mask(encoder_attention_mask)
+        else:
+            enc_ext = None
+        emb = self.embeddings(input_ids=input_ids) if encoder_embeds is None else encoder_embeds
+        return emb, ext, enc_ext
+
+
+class MedBertModel(_BertModelBase):
+    """models/med.py BertModel :686-929."""
+    encoder_cls = MedBertEncoder
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, head_mask=None, inputs_embeds=None,
+                encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None, past_key_values=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, is_decoder=False,
+                mode='multimodal', space_dict=None, temperature=0):
+        emb, ext, enc_ext = self._run(input_ids, attention_mask, space_dict, temperature, encoder_embeds,
+                                      encoder_hidden_states, encoder_attention_mask, mode, inputs_embeds)
+        out, sd_txt_ft = self.encoder(emb, attention_mask=ext, encoder_hidden_states=encoder_hidden_states,
+                                      encoder_attention_mask=enc_ext, mode=mode, space_dict=space_dict,
+                                      temperature=temperature)
+        return out, sd_txt_ft
+
+
+class NlvrBertModel(_BertModelBase):
+    """models/nlvr_encoder.py BertModel :775-1015."""
+    encoder_cls = NlvrBertEncoder
+
+    def forward(self, input_ids=None, attention_mask=None, space_dict=None, temperature=0, position_ids=None,
+                head_mask=None, inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None,
+                encoder_attention_mask=None, past_key_values=None, use_cache=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None, is_decoder=False, mode='multimodal'):
+        emb, ext, enc_ext = self._run(input_ids, attention_mask, space_dict, temperature, encoder_embeds,
+                                      encoder_hidden_states, encoder_attention_mask, mode, inputs_embeds)
+        out, sd_txt_ft = self.encoder(emb, attention_mask=ext, space_dict=space_dict, temperature=temperature,
+                                      encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=enc_ext,
+                                      mode=mode)
+        return out, sd_txt_ft

@@ -1,0 +1,96 @@
+"""Mirror of the reference's models/blip_nlvr.py BLIP_NLVR (:19-100) - the caller of the hot path whose
+forward(train=False) is the end-to-end forward BASELINE.json's metric times."""
+import os
+
+import torch
+from torch import nn
+
+from . import hip
+from .bert import BertConfig
+from .nlvr_encoder import BertModel
+from .runtime import PreparedCache, compute_dtype, lin_of, require_gpu
+from .vit import VisionTransformer
+
+ENC_TOKEN_ID = 30523  # tokenizer.enc_token_id ('[ENC]', models/blip.py:221-224)
+
+
+def create_vit(vit, image_size, use_grad_checkpointing=False, ckpt_layer=0, drop_path_rate=0, evaluate=False,
+               sd_dim=768, map_func=False):
+    """models/blip.py:228-252."""
+    if vit != 'base':
+        raise NotImplementedError("ViT-L (head_dim 64, 24 layers) is not wired in this round")
+    vision_width = 768
+    visual_encoder = VisionTransformer(img_size=image_size, patch_size=16, embed_dim=vision_width, depth=12,
+                                       num_heads=12, use_grad_checkpointing=use_grad_checkpointing,
+                                       ckpt_layer=ckpt_layer, drop_path_rate=0 or drop_path_rate, evaluate=evaluate,
+                                       sd_dim=sd_dim, map_func=map_func)
+    return visual_encoder, vision_width
+
+
+class BLIP_NLVR(nn.Module):
+    def __init__(self, med_config='configs/med_config.json', image_size=480, vit='base', vit_grad_ckpt=False,
+                 vit_ckpt_layer=0, evaluate=False, config=None):
+        super().__init__()
+        self.layers = 12 if vit == 'base' else 24
+        if config is None:
+            self.sd_num, self.sd_dim, self.batch_size = 100, 768, 16
+        else:
+            self.sd_num, self.sd_dim, self.batch_size = config['sd_num'], config['sd_dim'], config['batch_size_train']
+        self.space_dict = nn.Parameter(torch.randn(self.sd_num, self.sd_dim))
+        self.world_size = int(os.environ.get('WORLD_SIZE', 1))
+        self.visual_encoder, vision_width = create_vit(vit, image_size, vit_grad_ckpt, vit_ckpt_layer,
+                                                       drop_path_rate=0.1, evaluate=evaluate, sd_dim=self.sd_dim)
+        self.tokenizer = None  # set to a BertTokenizer-like callable to pass raw strings, as the reference does
+        if isinstance(med_config, str):
+            med_config = BertConfig.from_json_file(med_config) if os.path.exists(med_config) else BertConfig.med_default()
+        med_config.encoder_width = vision_width
+        med_config.evaluate = evaluate
+        self.text_encoder = BertModel(config=med_config, add_pooling_layer=False, sd_dim=self.sd_dim)
+        self.cls_head = nn.Sequential(nn.Linear(self.text_encoder.config.hidden_size, self.text_encoder.config.hidden_size),
+                                      nn.ReLU(),
+                                      nn.Linear(self.text_encoder.config.hidden_size, 2))
+        self._cache = PreparedCache()
+        self.compute_sd_ft = True  # sd_*_ft only feed the training loss (:86-96); set False to skip them in eval
+
+    def _tokens(self, text, device):
+        if isinstance(text, dict) or hasattr(text, "input_ids"):
+            ids = text["input_ids"] if isinstance(text, dict) else text.input_ids
+            att = text["attention_mask"] if isinstance(text, dict) else text.attention_mask
+        elif self.tokenizer is not None:
+            t = self.tokenizer(text, padding='longest', return_tensors="pt")
+            ids, att = t.input_ids, t.attention_mask
+        else:
+            raise TypeError("pass {'input_ids','attention_mask'} tensors or set model.tokenizer (no vocabulary offline)")
+        ids = ids.to(device).clone()
+        ids[:, 0] = ENC_TOKEN_ID  # :69
+        return ids, att.to(device)
+
+    def forward(self, image, text, targets, temperature=0, train=True):
+        if train:
+            raise NotImplementedError("training losses / backward are out of scope of the pruned forward path")
+        require_gpu(image, "image")
+        self.visual_encoder.img_query_model.compute_att_ft = self.compute_sd_ft
+        self.text_encoder.encoder.txt_query_model.compute_att_ft = self.compute_sd_ft
+        image_embeds, sd_img_ft = self.visual_encoder(image, space_dict=self.space_dict, temperature=temperature)  # :64
+        image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
+        image0_embeds, image1_embeds = torch.split(image_embeds, targets.size(0))  # :67
+        ids, att = self._tokens(text, image.device)
+        output, sd_txt_ft = self.text_encoder(ids, attention_mask=att,
+                                              encoder_hidden_states=[image0_embeds, image1_embeds],
+                                              encoder_attention_mask=[image_atts[:image0_embeds.size(0)],
+                                                                      image_atts[image0_embeds.size(0):]],
+                                              return_dict=True, space_dict=self.space_dict, temperature=temperature)
+        hidden_state = output.last_hidden_state[:, 0, :]  # :80
+        h = hidden_state.contiguous()
+        l0 = lin_of(self._cache, "c0", [self.cls_head[0]])
+        l2 = lin_of(self._cache, "c2", [self.cls_head[2]])
+        h = h if compute_dtype() == torch.float32 else hip.cast_bf16(h)
+        h = hip.gemm(h, l0.w, l0.b, act=hip.ACT_RELU, n=l0.n)
+        return hip.gemm(h, l2.w, l2.b, out_dtype=torch.float32, n=l2.n)  # :81
+
+
+def blip_nlvr(pretrained='', **kwargs):
+    model = BLIP_NLVR(**kwargs)
+    if pretrained:
+        raise NotImplementedError("checkpoint loading: use model.load_state_dict(); key names match the reference")
+    return model

@@ -28,7 +28,7 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nwa
 // tokens (4 token slices x 128 columns), threshold = min_k sum_t softmax_t(x/T)[t,k] * I[t].
 __global__ __launch_bounds__(512) void token_score_kernel(const float* __restrict__ colsum, int nrt,
                                                           const float* __restrict__ p0, const float* __restrict__ onorm,
-                                                          const float* __restrict__ ta, int ldt, int K, float temperature,
+                                                          const float* __restrict__ ta, int ldt, int ldb, int K, float temperature,
                                                           float* __restrict__ score, float* __restrict__ threshold,
                                                           int32_t* __restrict__ count, int32_t* __restrict__ kmax, int H,
                                                           int N) {
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     __shared__ float colstat[128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, n = N - 1;
-    const float* ta_b = ta + ((size_t)b * N + 1) * ldt;  // row t <-> patch token t
+    const float* ta_b = ta + (size_t)b * ldb;  // row t <-> patch token t
 
     // token_attn_w = max over dictionary columns (vit.py:131): one wave per row, lanes over columns
     for (int t = wave; t < n; t += 8) {
@@ -233,18 +233,30 @@ __global__ void mask_gather_kernel(const float* __restrict__ mask, const int64_t
         out[(size_t)b * (k + 2) + p] = p == 0 ? mask[(size_t)b * N] : mask[(size_t)b * N + 1 + order[(size_t)b * ld_order + p - 1]];
 }
 
+__global__ __launch_bounds__(256) void vector_gather_kernel(const float* __restrict__ v, const int64_t* __restrict__ idx,
+                                                            float* __restrict__ out, int L, int K, int dim4, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int b = row / K;
+    const int64_t src = idx[row];
+    const float4* s = (const float4*)v + ((size_t)b * L + src) * dim4;
+    float4* o = (float4*)out + (size_t)row * dim4;
+    for (int c = lane; c < dim4; c += 64) o[c] = s[c];
+}
+
 // ----------------------------------------------------------------------------------------------- query_att_ft
 // grid (dim/64, B); 4 waves, wave w owns output columns [64*bx + 16w, +16) for all K<=112 dictionary rows.
 // C[c, d] = sum_t w[c,t] * x[1+t, d] with exact-f32 MFMA 16x16x4: A = w (row c, k-slot g <-> t = 4*step+g),
 // B = x (k-slot g, column d).
-__global__ __launch_bounds__(256) void query_att_ft_kernel(const float* __restrict__ ta, int ldt, int K,
-                                                           const float* __restrict__ x, float* __restrict__ out,
-                                                           float inv_sqrt_sd, int accumulate, int N, int dim) {
+__global__ __launch_bounds__(256) void query_att_ft_kernel(const float* __restrict__ ta, int ldt, int ldb, int K,
+                                                           const float* __restrict__ ft, int ldf, int ldfb,
+                                                           float* __restrict__ out, float inv_sqrt_sd, int accumulate,
+                                                           int n, int dim) {
     __shared__ float mx[128], sm[128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, g = lane >> 4;
-    const int b = blockIdx.y, n = N - 1;
-    const float* ta_b = ta + ((size_t)b * N + 1) * ldt;
+    const int b = blockIdx.y;
+    const float* ta_b = ta + (size_t)b * ldb;
     if (tid < 128) {
         float m = -INFINITY, s = 1.f;
         if (tid < K) {
@@ -259,11 +271,11 @@ __global__ __launch_bounds__(256) void query_att_ft_kernel(const float* __restri
     f32x4 acc[7];
 #pragma unroll
     for (int mt = 0; mt < 7; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* xb = x + ((size_t)b * N + 1) * dim;
+    const float* xb = ft + (size_t)b * ldfb;
     for (int t4 = 0; t4 < n; t4 += 4) {
         const int t = t4 + g;
         const bool tv = t < n;
-        const float xv = tv ? xb[(size_t)t * dim + d] : 0.f;
+        const float xv = tv ? xb[(size_t)t * ldf + d] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 7; ++mt) {
             const int c = mt * 16 + l16;
@@ -287,13 +299,13 @@ __global__ __launch_bounds__(256) void query_att_ft_kernel(const float* __restri
 }  // namespace
 
 extern "C" int madtp_token_score(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
-                                 const float* token_attn, int ldt, int K, float temperature, float* score,
+                                 const float* token_attn, int ldt, int ldb, int K, float temperature, float* score,
                                  float* threshold, int32_t* count, int32_t* kmax, int B, int H, int N, void* stream) {
     if (!colsum_part || !p0 || !onorm || !token_attn || !score || !threshold || !count || !kmax) return MADTP_E_BADARG;
     if (B <= 0 || H <= 0 || N < 2 || n_row_tiles <= 0 || !(temperature > 0.f)) return MADTP_E_BADARG;
     if (N - 1 > MAXN || K > 128 || K <= 0 || ldt < K) return MADTP_E_SHAPE;
     hipLaunchKernelGGL(token_score_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, colsum_part, n_row_tiles, p0, onorm,
-                       token_attn, ldt, K, temperature, score, threshold, count, kmax, H, N);
+                       token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
@@ -328,12 +340,24 @@ extern "C" int madtp_mask_gather(const float* mask, const int64_t* order, int ld
     return 0;
 }
 
-extern "C" int madtp_query_att_ft(const float* token_attn, int ldt, int K, const float* x, float* out, float inv_sqrt_sd,
-                                  int accumulate, int B, int N, int dim, void* stream) {
-    if (!token_attn || !x || !out || B <= 0 || N < 2) return MADTP_E_BADARG;
+extern "C" int madtp_query_att_ft(const float* token_attn, int ldt, int ldb, int K, const float* x, int ldf, int ldfb,
+                                  float* out, float inv_sqrt_sd, int accumulate, int B, int n, int dim, void* stream) {
+    if (!token_attn || !x || !out || B <= 0 || n < 1) return MADTP_E_BADARG;
     if (K <= 0 || K > 112 || dim % 64 || ldt < K) return MADTP_E_SHAPE;
-    hipLaunchKernelGGL(query_att_ft_kernel, dim3(dim / 64, B), dim3(256), 0, (hipStream_t)stream, token_attn, ldt, K, x, out,
-                       inv_sqrt_sd, accumulate, N, dim);
+    hipLaunchKernelGGL(query_att_ft_kernel, dim3(dim / 64, B), dim3(256), 0, (hipStream_t)stream, token_attn, ldt, ldb, K, x,
+                       ldf, ldfb, out, inv_sqrt_sd, accumulate, n, dim);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_vector_gather(const float* vectors, const int64_t* indices, float* out, int B, int L, int K, int D,
+                                   void* stream) {
+    if (!vectors || !indices || !out || B <= 0 || L <= 0 || K <= 0 || D <= 0) return MADTP_E_BADARG;
+    if (D % 4) return MADTP_E_SHAPE;
+    if (!aligned16(vectors) || !aligned16(out)) return MADTP_E_ALIGN;
+    const int rows = B * K;
+    hipLaunchKernelGGL(vector_gather_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, vectors, indices, out, L,
+                       K, D / 4, rows);
     MADTP_LAUNCH_CHECK();
     return 0;
 }

@@ -26,13 +26,14 @@ _SIGS = {
     "madtp_assemble_tokens": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "madtp_bert_embed": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_void_p]),
     "madtp_attention": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float, c_int, c_void_p]),
-    "madtp_token_score": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]
+    "madtp_token_score": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float]
                           + [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "madtp_token_select": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "madtp_token_gather": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "madtp_mask_gather": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "madtp_query_att_ft": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,
-                                   c_void_p]),
+    "madtp_query_att_ft": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_int,
+                                   c_int, c_int, c_int, c_void_p]),
+    "madtp_vector_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
 }
@@ -182,15 +183,23 @@ def attention(q, k, v, B, H, Nq, Nk, scale, add_mask=None, scores=False):
     return out, side
 
 
-def token_score(side, token_attn, K, temperature, B, H, N):
+def _ta_view(token_attn):
+    """token_attn: any [B,n,K] f32 GPU view with unit column stride -> (ptr, row stride, batch stride, K)."""
+    if not token_attn.is_cuda or token_attn.dtype != torch.float32 or token_attn.dim() != 3 or token_attn.stride(2) != 1:
+        raise RuntimeError("token_attn must be a GPU f32 [B,n,K] view with unit column stride")
+    return token_attn.data_ptr(), token_attn.stride(1), token_attn.stride(0), token_attn.shape[2]
+
+
+def token_score(side, token_attn, temperature, B, H, N):
     cs, p0, on = side
     n = N - 1
+    tp, ldr, ldb, K = _ta_view(token_attn)
     dev = token_attn.device
     score = torch.empty((B, n), device=dev, dtype=torch.float32)
     thr = torch.empty((B,), device=dev, dtype=torch.float32)
     count = torch.empty((B,), device=dev, dtype=torch.int32)
     kmax = torch.zeros((1,), device=dev, dtype=torch.int32)
-    _check(load().madtp_token_score(_p(cs), cs.shape[1], _p(p0), _p(on), _p(token_attn), token_attn.stride(0), K,
+    _check(load().madtp_token_score(_p(cs), cs.shape[1], _p(p0), _p(on), tp, ldr, ldb, K,
                                     float(temperature), _p(score), _p(thr), _p(count), _p(kmax), B, H, N, _stream()),
            "madtp_token_score")
     return score, thr, count, kmax
@@ -227,15 +236,17 @@ def mask_gather(mask2d, order, k):
     return out
 
 
-def query_att_ft(token_attn, K, x, out=None, sd_dim=768):
-    _req(x, torch.float32, "x")
-    B, N, dim = x.shape
+def query_att_ft(token_attn, ft, out=None, sd_dim=768):
+    """ft: [B,n,dim] f32 GPU view with unit column stride (e.g. x[:,1:,:]); token_attn [B,n,K] view."""
+    fp, ldf, ldfb, dim = _ta_view(ft)
+    B, n = ft.shape[0], ft.shape[1]
+    tp, ldr, ldb, K = _ta_view(token_attn)
     acc = 1
     if out is None:
-        out = torch.empty((B, K, dim), device=x.device, dtype=torch.float32)
+        out = torch.empty((B, K, dim), device=ft.device, dtype=torch.float32)
         acc = 0
-    _check(load().madtp_query_att_ft(_p(token_attn), token_attn.stride(0), K, _p(x), _p(out), 1.0 / (sd_dim ** 0.5), acc,
-                                     B, N, dim, _stream()), "madtp_query_att_ft")
+    _check(load().madtp_query_att_ft(tp, ldr, ldb, K, fp, ldf, ldfb, _p(out), 1.0 / (sd_dim ** 0.5), acc,
+                                     B, n, dim, _stream()), "madtp_query_att_ft")
     return out
 
 
@@ -250,3 +261,12 @@ def cast_bf16(src):
     dst = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
     _check(load().madtp_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "madtp_cast_bf16")
     return dst
+
+
+def vector_gather(vectors, indices):
+    _req(vectors, torch.float32, "vectors"); _req(indices, torch.int64, "indices")
+    B, L, D = vectors.shape
+    K = indices.shape[1]
+    out = torch.empty((B, K, D), device=vectors.device, dtype=torch.float32)
+    _check(load().madtp_vector_gather(_p(vectors), _p(indices), _p(out), B, L, K, D, _stream()), "madtp_vector_gather")
+    return out

@@ -1,0 +1,84 @@
+"""Mirror of the reference's models/utils.py hot-path helpers (vector_gather :13-33, Query_model :109-183) with
+the same names, arguments and return values, executed by the HIP kernels."""
+import math
+
+import torch
+from torch import nn
+
+from . import hip
+from .runtime import PreparedCache, prepare_linear, require_gpu
+
+
+def vector_gather(vectors, indices):
+    """models/utils.py:13-33 - Tensor[N,L,D], indices Tensor[N,K] or [N] -> Tensor[N,K,D] or [N,D]."""
+    require_gpu(vectors, "vectors")
+    N, L, D = vectors.shape
+    squeeze = False
+    if indices.ndim == 1:
+        squeeze = True
+        indices = indices.unsqueeze(-1)
+    N2, K = indices.shape
+    assert N == N2
+    out = hip.vector_gather(vectors.float().contiguous(), indices.to(torch.int64).contiguous())
+    return out.squeeze(1) if squeeze else out
+
+
+def full_rows_of(ft):
+    """If ft is x[:,1:,:] of a contiguous [B,N,D] f32 tensor, return x as a [B*N, D] alias (no copy), else None.
+    Lets the alignment GEMM run over the token buffer in place instead of copying the patch slice."""
+    if ft.dim() != 3 or ft.dtype != torch.float32:
+        return None
+    B, n, D = ft.shape
+    if ft.stride(2) != 1 or ft.stride(1) != D or ft.stride(0) != (n + 1) * D or ft.storage_offset() < D:
+        return None
+    return torch.as_strided(ft, (B * (n + 1), D), (D, 1), ft.storage_offset() - D)
+
+
+class Query_model(nn.Module):
+    """models/utils.py:109-183.  forward(ft, sd, mask=None, return_token_att=False, temperature=1) ->
+    (token_att[B,n,K] raw logits, att_ft[B,K,sd_dim], sd).  The logits x.sd^T always run on the exact-f32 MFMA
+    (they feed the pruning threshold); att_ft uses the fused softmax-over-tokens kernel."""
+
+    def __init__(self, ft_dim, sd_dim, temperature=1, att_func_type='softmax', pool_type='sum', map_func=False):
+        super().__init__()
+        assert att_func_type in ['softmax', 'sigmoid', 'sparsemax']
+        assert pool_type in ['mean', 'max', 'sum']
+        self.att_func_type = att_func_type
+        self.pool_type = pool_type
+        self.att_dim = sd_dim
+        self.temperature = temperature
+        self.map_func = map_func
+        if self.map_func:
+            self.q_map = nn.Sequential(nn.Linear(ft_dim, sd_dim))
+        self._cache = PreparedCache()
+        self.compute_att_ft = True  # att_ft only feeds the training loss (blip_nlvr.py:86-96); eval callers may clear
+
+    def forward(self, ft, sd, mask=None, return_token_att=False, temperature=1):
+        require_gpu(ft, "ft")
+        if not return_token_att:
+            raise NotImplementedError("Query_model(return_token_att=False) returns the normalised attention weights; "
+                                      "no reference call site on the pruned forward path uses it")
+        B, n, D = ft.shape
+        K = sd.shape[0]
+        sdl = self._cache.get(("sd", id(sd)), [sd], lambda: prepare_linear([sd], None, torch.float32))
+        if self.map_func:
+            qm = self._cache.get("qmap", [self.q_map[0].weight, self.q_map[0].bias],
+                                 lambda: prepare_linear([self.q_map[0].weight], [self.q_map[0].bias], torch.float32))
+            q = hip.gemm(ft.float().reshape(B * n, D) if ft.is_contiguous() else ft.float().contiguous().view(B * n, D),
+                         qm.w, qm.b, n=qm.n).view(B, n, -1)
+            rows, off = q.view(B * n, -1), 0
+            ftq = q
+        else:
+            rows = full_rows_of(ft)
+            off = 1
+            ftq = ft
+            if rows is None:
+                ftq = ft.float().contiguous()
+                rows, off = ftq.view(B * n, D), 0
+        kp = sdl.w.shape[0]
+        full = hip.gemm(rows, sdl.w, n=kp)  # [rows, 128], zero weight rows beyond K
+        token_att = full.view(B, n + off, kp)[:, off:, :K]
+        att_ft = None
+        if self.compute_att_ft:
+            att_ft = hip.query_att_ft(token_att, ftq, sd_dim=self.att_dim)
+        return token_att, att_ft, sd

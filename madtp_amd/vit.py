@@ -1,0 +1,255 @@
+"""Mirror of the reference's models/vit.py (Mlp :15-36, Attention :39-103, Block :106-207, VisionTransformer
+:210-310): same constructor arguments, sub-module / parameter names (checkpoint keys) and forward() signatures,
+so models/blip_*.py and the compress_*_dtp.py drivers can use these classes unchanged.  forward() enqueues the
+hand-written gfx950 kernels (madtp_amd.hip); there is no eager fallback.
+
+Differences a caller can observe (documented in INTEGRATION.md):
+  * kept tokens come out in ascending token order (the reference's topk(sorted=False) order is implementation
+    defined; attention is permutation-equivariant so downstream values agree to f32 rounding);
+  * `token_attn` is not divided by the temperature in place (vit.py:137 mutates the caller's tensor);
+  * the [B,H,N,N] attention map is never materialised: get_attention_map() returns None unless
+    Attention.keep_attention_map is set (slow debug path is not provided in this round).
+"""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .runtime import PreparedCache, compute_dtype, lin_of, require_gpu, as_f32_contig
+from .utils import Query_model, vector_gather  # noqa: F401  (re-exported like `from models.utils import *`)
+
+
+class Mlp(nn.Module):
+    """vit.py:15-36 - fc2(GELU(fc1(x))) (dropout p=0 in every BLIP config)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.hidden_features = hidden_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+        self._cache = PreparedCache()
+
+    def run(self, h2d, residual2d=None):
+        """h2d: [M, in] in the compute dtype -> f32 [M, out] (+ residual)."""
+        fc1 = lin_of(self._cache, "fc1", [self.fc1])
+        fc2 = lin_of(self._cache, "fc2", [self.fc2])
+        mid = hip.gemm(h2d, fc1.w, fc1.b, act=hip.ACT_GELU, n=fc1.n)
+        return hip.gemm(mid, fc2.w, fc2.b, residual=residual2d, out_dtype=torch.float32, n=fc2.n)
+
+    def forward(self, x):
+        require_gpu(x)
+        shp = x.shape
+        h = as_f32_contig(x).view(-1, shp[-1])
+        h = h if compute_dtype() == torch.float32 else hip.cast_bf16(h)
+        return self.run(h).view(*shp[:-1], -1)
+
+
+class Attention(nn.Module):
+    """vit.py:39-103."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.dim = dim
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        if head_dim != 64:
+            raise ValueError("the gfx950 attention kernels are built for head_dim 64 (ViT-B/16, BERT-base, CLIP-B)")
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.attn_gradients = None
+        self.attention_map = None
+        self.cls_attn = None
+        self.score_side = None  # (colsum_part, p0, onorm) of the last call - consumed by Block.Reduce_token
+        self._cache = PreparedCache()
+
+    def save_attn_gradients(self, attn_gradients):
+        self.attn_gradients = attn_gradients
+
+    def get_attn_gradients(self):
+        return self.attn_gradients
+
+    def save_attention_map(self, attention_map):
+        self.attention_map = attention_map
+
+    def get_attention_map(self):
+        return self.attention_map
+
+    def save_cls_attn(self, cls_attn):
+        self.cls_attn = cls_attn
+
+    def get_cls_attn(self):
+        return self.cls_attn
+
+    def run(self, h2d, B, N, residual2d=None, want_scores=True):
+        """h2d: normalised tokens [B*N, dim] in the compute dtype -> f32 [B*N, dim] (= proj(attn) + residual)."""
+        qkv = lin_of(self._cache, "qkv", [self.qkv])
+        proj = lin_of(self._cache, "proj", [self.proj])
+        C = self.dim
+        y = hip.gemm(h2d, qkv.w, qkv.b, n=qkv.n)  # [B*N, 3C]: q | k | v, head-major inside each (vit.py:77)
+        o, side = hip.attention(y[:, :C], y[:, C:2 * C], y[:, 2 * C:], B, self.num_heads, N, N, self.scale,
+                                scores=want_scores)
+        self.score_side = side
+        return hip.gemm(o, proj.w, proj.b, residual=residual2d, out_dtype=torch.float32, n=proj.n)
+
+    def forward(self, x, register_hook=False):
+        if register_hook:
+            raise NotImplementedError("attention-gradient hooks need the materialised map (training path, out of scope)")
+        require_gpu(x)
+        B, N, C = x.shape
+        h = as_f32_contig(x).view(B * N, C)
+        h = h if compute_dtype() == torch.float32 else hip.cast_bf16(h)
+        return self.run(h, B, N).view(B, N, C)
+
+
+class Block(nn.Module):
+    """vit.py:106-207."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, use_grad_checkpointing=False):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=drop)
+        self.drop_path = nn.Identity()  # DropPath is the identity in eval (the only mode this path runs in)
+        self.norm2 = norm_layer(dim)
+        mlp_hidden_dim = int(dim * mlp_ratio)
+        self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
+        self.last_prune = None  # dict(k, indices, indices_sort, score, threshold, count) of the last forward
+
+    def _ln(self, norm, x2d):
+        bf = compute_dtype() == torch.bfloat16
+        y32, ybf = hip.layernorm(x2d, norm.weight, norm.bias, norm.eps, want_f32=not bf, want_bf16=bf)
+        return ybf if bf else y32
+
+    def Reduce_token(self, x, reduce_num=0, temperature=0, self_attn=None, cls_attn=None, token_attn=None):
+        """vit.py:123-163.  `x` is the FULL token tensor [B,N,D] here (CLS included) - the kernels skip row 0 -
+        and the attention statistics come from self.attn.score_side instead of a materialised map."""
+        B, N, D = x.shape
+        n = N - 1
+        score, thr, count, kmax = hip.token_score(self.attn.score_side, token_attn, temperature, B, self.attn.num_heads, N)
+        k = int(kmax.item())  # topk_num = max_b count: one host sync per layer, as vit.py:145
+        info = {"k": k, "score": score, "threshold": thr, "count": count, "pruned": False, "indices": None,
+                "indices_sort": None}
+        self.last_prune = info
+        if k < 1 or (n - k) <= 1:  # vit.py:148-149
+            return x
+        indices, indices_sort, dst_pos, merge_w = hip.token_select(score, k)
+        info.update(pruned=True, indices=indices, indices_sort=indices_sort)
+        return hip.token_gather(x, dst_pos, merge_w, k)
+
+    def forward(self, x, register_hook=False, reduce_num=0, temperature=0, token_attn=None):
+        require_gpu(x, "x")
+        if register_hook:
+            raise NotImplementedError("register_hook needs the materialised attention map (Grad-CAM path, out of scope)")
+        x = as_f32_contig(x)
+        B, N, D = x.shape
+        prune = temperature > 0
+        if prune and token_attn is None:
+            raise ValueError("temperature > 0 requires token_attn (the reference fails in Reduce_token as well)")
+        x2 = x.view(B * N, D)
+        # x = x + attn(norm1(x))   vit.py:186
+        x2 = self.attn.run(self._ln(self.norm1, x2), B, N, residual2d=x2, want_scores=prune)
+        x = x2.view(B, N, D)
+        self.last_prune = None
+        if prune:  # vit.py:193-202
+            x = self.Reduce_token(x, reduce_num, temperature, token_attn=token_attn)
+            B, N, D = x.shape
+            x2 = x.view(B * N, D)
+        # x = x + mlp(norm2(x))   vit.py:205
+        return self.mlp.run(self._ln(self.norm2, x2), residual2d=x2).view(B, N, D)
+
+
+class PatchEmbed(nn.Module):
+    """timm==0.4.12 PatchEmbed (un-vendored dependency of the reference; call site vit.py:241-242): parameter
+    `proj` is a Conv2d(k=s=patch) so checkpoints load by name; executed as im2col + MFMA GEMM."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self._cache = PreparedCache()
+
+    def run(self, img):
+        img = as_f32_contig(require_gpu(img, "image"))
+        B, C, H, W = img.shape
+        if H != W or H % self.patch_size[0]:
+            raise ValueError(f"image {H}x{W} is not a square multiple of the patch size")
+        lin = lin_of(self._cache, "proj", [self.proj])
+        cols = hip.patchify(img, self.patch_size[0], compute_dtype())
+        return hip.gemm(cols, lin.w, lin.b, out_dtype=torch.float32, n=lin.n), (H // self.patch_size[0]) ** 2
+
+    def forward(self, x):
+        y, np_ = self.run(x)
+        return y.view(x.shape[0], np_, -1)
+
+
+class VisionTransformer(nn.Module):
+    """vit.py:210-310."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=True, qk_scale=None, representation_size=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., norm_layer=None,
+                 use_grad_checkpointing=False, ckpt_layer=0, evaluate=False, sd_dim=768, map_func=False):
+        super().__init__()
+        self.num_features = self.embed_dim = embed_dim
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate, drop_path=0., norm_layer=norm_layer)
+            for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.depth = depth
+        if not evaluate:
+            nn.init.trunc_normal_(self.pos_embed, std=.02)
+            nn.init.trunc_normal_(self.cls_token, std=.02)
+            self.apply(self._init_weights)
+        self.img_query_model = Query_model(ft_dim=embed_dim, sd_dim=sd_dim, temperature=1, att_func_type='sparsemax',
+                                           pool_type='max', map_func=map_func)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token'}
+
+    def forward(self, x, register_blk=-1, space_dict=None, temperature=0):
+        B = x.shape[0]
+        patches, np_ = self.patch_embed.run(x)  # vit.py:283
+        x = hip.assemble_tokens(patches, self.cls_token, self.pos_embed, B, np_)  # vit.py:285-289
+        token_num = x.shape[-2]
+        reduce_num = int((token_num - 1) // self.depth)
+        sd_img_ft_all = None
+        for i, blk in enumerate(self.blocks):
+            if space_dict is not None:
+                token_attn, sd_img_ft, _ = self.img_query_model(x[:, 1:, :], space_dict, return_token_att=True)  # :297-298
+                if sd_img_ft is not None:
+                    sd_img_ft_all = sd_img_ft if sd_img_ft_all is None else hip.add_scale(sd_img_ft_all, sd_img_ft, 1.0)
+                x = blk(x, register_blk == i, reduce_num, temperature, token_attn)  # :304
+            else:
+                x = blk(x, register_blk == i)
+        B, N, D = x.shape
+        y, _ = hip.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)  # :309
+        return y, sd_img_ft_all

@@ -173,7 +173,11 @@ def test_token_score_select_gather(hip, B, N, T):
     qd = qkv.cuda()
     _, side = hip.attention(qd[:, :768], qd[:, 768:1536], qd[:, 1536:], B, H, N, N, 0.125, scores=True)
     ta_full = hip.gemm(x.reshape(B * N, D).cuda(), _pad128(sd).cuda(), n=128)     # rows incl. CLS, ld 128
-    score, thr, count, kmax = hip.token_score(side, ta_full, K, T, B, H, N)
+    ta_view = ta_full.view(B, N, 128)[:, 1:, :K]
+    score, thr, count, kmax = hip.token_score(side, ta_view, T, B, H, N)
+    ta_c = ta_view.contiguous()                                                   # dense [B,n,K] layout must agree
+    score2, thr2, count2, _ = hip.token_score(side, ta_c, T, B, H, N)
+    assert torch.equal(score, score2) and torch.equal(thr, thr2) and torch.equal(count, count2)
     _, rp, _, _, _ = _ref_attention(qkv, B, N, H, 0.125)
     q, k, v = qkv.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     o = rp @ v
@@ -233,12 +237,21 @@ def test_query_att_ft(hip):
     x = _rand(B, N, D, seed=40)
     sd = _rand(K, D, seed=41, scale=0.2)
     ta = hip.gemm(x.reshape(B * N, D).cuda(), _pad128(sd).cuda(), n=128)
-    out = hip.query_att_ft(ta, K, x.cuda())
+    tav = ta.view(B, N, 128)[:, 1:, :K]
+    xd = x.cuda()
+    out = hip.query_att_ft(tav, xd[:, 1:, :])
     inner = x[:, 1:] @ sd.t()
     ref = torch.bmm(torch.softmax((inner / math.sqrt(D)).permute(0, 2, 1), -1), x[:, 1:])
     assert (out.cpu() - ref).abs().max().item() < 2e-5 * max(1, ref.abs().max().item())
-    out2 = hip.query_att_ft(ta, K, x.cuda(), out=out.clone())
+    out2 = hip.query_att_ft(tav, xd[:, 1:, :].contiguous(), out=out.clone())
     assert (out2.cpu() - 2 * ref).abs().max().item() < 4e-5 * max(1, ref.abs().max().item())
+
+
+def test_vector_gather(hip):
+    v = _rand(3, 50, 768, seed=60)
+    idx = torch.randint(0, 50, (3, 17), generator=torch.Generator().manual_seed(2))
+    out = hip.vector_gather(v.cuda(), idx.cuda())
+    assert torch.equal(out.cpu(), torch.gather(v, 1, idx[..., None].expand(-1, -1, 768)))
 
 
 def test_small_elementwise(hip):
