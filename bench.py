@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the pruned BLIP-base NLVR2 forward (BLIP_NLVR.forward(train=False) dataflow,
+reference models/blip_nlvr.py:63-100) at p=0.5, 64 samples (= 128 images) per GPU, bf16 GEMM operands, on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W --precision bf16|fp32 --batch 64]
+
+N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`:
+one process per GPU, batch sharded data-parallel (each rank owns 64 whole samples - both images of a pair stay on
+one rank), weights replicated, NO collective inside the forward (the path has no exchange step);
+RCCL is used only for the barrier and the MAX-reduction of the elapsed time.  Scaling is therefore "weak".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     - the dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs of every GEMM launch in the timed
+                 region / the sum of their durations, measured live with HIP events on the launch stream.
+  cpu_baseline - oracle/ (the CPU restatement of the reference forward, kind "port") timed on this box's host
+                 cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def load_calibration(batch, p=0.5):
+    from madtp_amd import configs
+    return configs.temperature_for("nlvr", batch, p)
+
+
+class GemmTimer:
+    """HIP-event timing of every madtp_gemm launch on torch's current stream (the stream the kernels run on)."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def wrap(self, hip):
+        orig = hip.gemm
+        timer = self
+
+        def gemm(a, w, *args, **kw):
+            if not timer.enabled:
+                return orig(a, w, *args, **kw)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(a, w, *args, **kw)
+            e1.record()
+            n = kw.get("n", None) or w.shape[0]
+            timer.records.append((e0, e1, 2.0 * a.shape[0] * n * a.shape[1], a.dtype))
+            return out
+
+        hip.gemm = gemm
+
+    def summary(self, dtype):
+        ms = fl = 0.0
+        cnt = 0
+        for e0, e1, f, dt in self.records:
+            if dt == dtype:
+                ms += e0.elapsed_time(e1)
+                fl += f
+                cnt += 1
+        return ms, fl, cnt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=64, help="NLVR samples per GPU (2 images each)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-gemm-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", init_method="env://")  # "nccl" is RCCL on ROCm
+        dist = dist_mod
+
+    from madtp_amd import build, harness, hip, runtime
+    if rank == 0 or not os.path.exists(build.LIB):
+        build.build(verbose=False)
+    if dist is not None:
+        dist.barrier()
+    hip.load()
+    runtime.set_precision(args.precision)
+    timer = GemmTimer()
+    if not args.no_gemm_events:
+        timer.wrap(hip)
+        # the mirrors imported `hip` as a module, so the wrapped attribute is what they call
+
+    T, calib = load_calibration(args.batch, 0.5)
+    model = harness.build_nlvr(224, 0, "cuda")
+    images, text, targets = harness.nlvr_inputs(args.batch, 224, 20, seed=rank)  # resident in HBM before timing
+
+    def step():
+        return model(images, text, targets, temperature=T, train=False)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            logits = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        timer.enabled = False
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    images_per_step = 2 * args.batch * world
+    value = images_per_step * args.steps / elapsed
+    _, trace = harness.run_nlvr(model, images, text, targets, T)
+    vit_lens = harness.token_lengths(trace["vit"], 197)
+    txt_lens = harness.token_lengths(trace["text"], 20)
+    flops_sample = harness.nlvr_forward_flops(vit_lens, txt_lens)
+    flops_full = harness.nlvr_forward_flops([197] * 12, [20] * 12)
+
+    cdt = torch.bfloat16 if args.precision == "bf16" else torch.float32
+    roof = None
+    if not args.no_gemm_events:
+        ms, fl, cnt = timer.summary(cdt)
+        if ms > 0:
+            ach = fl / (ms * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS[args.precision]
+            ms32, fl32, cnt32 = timer.summary(torch.float32) if args.precision == "bf16" else (0, 0, 0)
+            roof = {"bound": "mfma", "kernel": f"gemm_kernel<{args.precision}> (madtp_gemm)", "achieved": round(ach, 1),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "launches_per_step": cnt // args.steps, "gemm_ms_per_step": round(ms / args.steps, 3),
+                    "f32_alignment_gemm_ms_per_step": round(ms32 / args.steps, 3) if cnt32 else 0.0}
+
+    out = {
+        "metric": "images/sec forward, BLIP-base NLVR2 p=0.5 b64; pruned-token index match",
+        "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": "BLIP-base NLVR2 forward (BLIP_NLVR.forward(train=False)), p=0.5, 64 samples = 128 "
+                               "images 224x224 + 20 text tokens per GPU, random-init weights",
+                   "samples_per_gpu": args.batch, "images_per_gpu": 2 * args.batch, "temperature": T,
+                   "flops_ratio_vs_unpruned": round(flops_sample / flops_full, 4), "vit_tokens_per_layer": vit_lens,
+                   "text_tokens_per_layer": txt_lens, "parallelism": f"dp{world}"},
+        "samples_per_s": round(value / 2, 1),
+        "model_tflops": round(flops_sample * args.batch * world * args.steps / elapsed / 1e12, 1),
+        "roofline": roof,
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_parity:
+            out["index_match"] = parity_report(model, harness, runtime, T, args.precision)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(T)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _match(mine, ref):
+    pairs = eq = 0
+    jac = 0.0
+    for a, b in zip(mine, ref):
+        if a is None and b is None:
+            continue
+        if a is None or b is None:
+            n = len(a or b)
+            pairs += n
+            continue
+        for x, y in zip(a, b):
+            pairs += 1
+            eq += int(x == y)
+            jac += len(x & y) / max(1, len(x | y))
+    return pairs, eq, jac
+
+
+def parity_report(model, harness, runtime, T, precision, B=8, seed=11):
+    """kept-token index match of the timed precision mode and of fp32 parity mode vs the CPU oracle on a small batch
+    (the oracle is the checker here, never the thing measured)."""
+    from madtp_amd import specs
+    from oracle import madtp_oracle as O
+    images, text, targets = harness.nlvr_inputs(B, 224, 20, seed)
+    W = specs.synth_weights(specs.blip_nlvr_shapes(224), 0)
+    tr = {}
+    with torch.no_grad():
+        ref_logits = O.blip_nlvr_forward(W, images.cpu(), text["input_ids"].cpu(), text["attention_mask"].cpu(), T, trace=tr)
+    rep = {"batch": B, "temperature": T, "oracle": "oracle/madtp_oracle.py (CPU fp32 restatement of the reference)"}
+    for mode in sorted({"fp32", precision}):
+        with runtime.precision(mode):
+            logits, trace = harness.run_nlvr(model, images, text, targets, T)
+        pairs = eq = 0
+        jac = 0.0
+        for side, n0 in (("vit", 196), ("text", 19)):
+            p, e, j = _match(harness.compose_ids(trace[side], n0), O.compose_ids(tr[side], n0))
+            pairs, eq, jac = pairs + p, eq + e, jac + j
+        rep[mode] = {"kept_set_exact_match": round(eq / max(1, pairs), 4), "mean_jaccard": round(jac / max(1, pairs), 4),
+                     "sample_layer_pairs": pairs, "max_abs_dlogit": round((logits.cpu() - ref_logits).abs().max().item(), 6)}
+    return rep
+
+
+def cpu_baseline(T, B=8, budget_s=12.0):
+    """The CPU oracle (a port of the reference forward; the reference itself cannot travel to this box) timed on the
+    host cores: B=8 samples (16 images) of the same synthetic workload, repeated for ~budget_s seconds."""
+    from madtp_amd import specs, synth
+    from oracle import madtp_oracle as O
+    W = specs.synth_weights(specs.blip_nlvr_shapes(224), 0)
+    images = synth.synth_images(2 * B, 224, 0)
+    ids = synth.synth_token_ids(B, 20, 0)
+    att = torch.ones_like(ids)
+    with torch.no_grad():
+        O.blip_nlvr_forward(W, images, ids, att, T)  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            O.blip_nlvr_forward(W, images, ids, att, T)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or n >= 50:
+                break
+    return {"value": round(2 * B * n / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} forwards of {B} samples ({2 * B} images 224x224 + 20 tokens), same weights/temperature, "
+                      f"PyTorch CPU eager fp32 via oracle/madtp_oracle.py, {dt:.1f}s",
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,17 @@
+#!/usr/bin/env python
+"""Per-kernel summary (calls, total, avg, min, max, %) of a rocprofv3 rocpd SQLite result (`*_results.db`), the
+format this image's rocprofv3 writes for --kernel-trace --stats.  usage: rocpd_stats.py results.db [header text]"""
+import sqlite3
+import sys
+
+db = sys.argv[1]
+c = sqlite3.connect(db)
+rows = c.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 "
+                 "from kernels group by name order by 3 desc").fetchall()
+tot = sum(r[2] for r in rows)
+for h in sys.argv[2:]:
+    print("# " + h)
+print(f"# total kernel time {tot / 1e3:.3f} ms")
+print(f"{'kernel':110s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>8s} {'max_us':>8s} {'pct':>6s}")
+for r in rows:
+    print(f"{r[0][:110]:110s} {r[1]:6d} {r[2] / 1e3:10.3f} {r[3]:9.1f} {r[4]:8.1f} {r[5]:8.1f} {100 * r[2] / tot:6.2f}")
