@@ -386,10 +386,9 @@ class _BertEncoderBase(nn.Module):
                 if space_dict is None:
                     raise TypeError("nlvr_encoder.BertEncoder calls txt_query_model unconditionally (:608): "
                                     "space_dict must be given")
-                token_attn, sd_txt_ft, _ = self.txt_query_model(hidden_states[:, 1:, :], space_dict,
-                                                                return_token_att=True, temperature=temperature)
-                if sd_txt_ft is not None:
-                    sd_txt_ft_all = sd_txt_ft if sd_txt_ft_all is None else hip.add_scale(sd_txt_ft_all, sd_txt_ft, 1.0)
+                token_attn, sd_txt_ft_all, _ = self.txt_query_model(hidden_states[:, 1:, :], space_dict,
+                                                                    return_token_att=True, temperature=temperature,
+                                                                    acc_ft=sd_txt_ft_all)
             t = temperature if space_dict is not None else 0
             if self.layer_cls.variant == "nlvr":
                 outs = layer_module(hidden_states, attention_mask, space_dict, None, encoder_hidden_states,

@@ -202,6 +202,217 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 fast-mode kernel: same decomposition and register layouts, but both products run on the bf16 MFMA
+// (v_mfma_f32_16x16x32_bf16, f32 accumulate); softmax and all score reductions stay f32.
+//   * K_h is DMA'd into LDS as 128-byte rows with the 16-B chunk index XOR (row&7) (swizzle on the source address),
+//     so the K fragment reads (ds_read_b128) are conflict-free.
+//   * The P.V product needs V with the KEY index contiguous per lane, so V_h is transposed while it is staged:
+//     Vt[d][j] (pitch NKP+8).  The k-slot <-> key mapping of the MFMA is a free permutation; with
+//     key(chunk c, group g, slot e) = 32c + 16(e>>2) + 4g + (e&3) the A operand is exactly the lane's own eight
+//     probabilities (tiles 2c and 2c+1) - no cross-lane traffic - and the B operand is two 8-byte reads of Vt.
+//   * exp via v_exp_f32 (__expf) and one reciprocal per row: this is the fast mode; the f32 kernel above keeps
+//     expf/division for the parity mode.
+template <int NT, bool SCORES>
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnArgs a) {
+    constexpr int NKP = NT * 16;
+    constexpr int NC = (NT + 1) / 2;          // 32-key chunks
+    constexpr int VP = NC * 32 + 8;           // Vt pitch in elements
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                          // [NKP][128 B], swizzled
+    bf16_t* Vt = (bf16_t*)(smem + NKP * 128); // [64][VP]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int rt = blockIdx.x * 4 + wave;
+    const int i0 = rt * 16;
+    const bool active = i0 < a.Nq;
+    const int irow = min(i0 + l16, a.Nq - 1);
+
+    f32x4 pmax[NT];
+    if constexpr (SCORES) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pmax[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // zero the padded key columns of Vt once (keys >= Nk contribute 0 * 0)
+    for (int idx = tid; idx < 64 * (VP / 2); idx += 256) ((uint32_t*)Vt)[idx] = 0u;
+
+    for (int h = blockIdx.z; h < a.H; h += gridDim.z) {
+        __syncthreads();
+        // ---- K_h: LDS-DMA, 8 rows (1 KiB) per wave-instruction, inverse swizzle on the source ----
+        {
+            const int sub = lane >> 3, chunk = (lane & 7) ^ sub;
+            for (int grp = wave; grp < NKP / 8; grp += 4) {
+                int row = grp * 8 + sub;
+                row = row < a.Nk ? row : a.Nk - 1;  // rows >= Nk are masked to -inf below; any finite data will do
+                const char* src = a.k + (((size_t)b * a.Nk + row) * a.ldk + h * 64) * 2 + chunk * 16;
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(Ks + grp * 1024), 16, 0, 0);
+            }
+        }
+        // ---- V_h -> Vt[d][j] (transpose through 2-byte LDS writes) ----
+        for (int idx = tid; idx < a.Nk * 8; idx += 256) {
+            const int j = idx >> 3, c = idx & 7;
+            const bf16x8 vv = *(const bf16x8*)(a.v + (((size_t)b * a.Nk + j) * a.ldv + h * 64) * 2 + c * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * VP + j] = (bf16_t)vv[e];
+        }
+        __syncthreads();
+        if (!active) continue;
+
+        // ---- Q fragment (B operand): row i, k-slot group g <-> d = 32kk + 8g .. +7 ----
+        bf16x8 q[2];
+        {
+            const char* qp = a.q + (((size_t)b * a.Nq + irow) * a.ldq + h * 64) * 2;
+            q[0] = *(const bf16x8*)(qp + g * 16);
+            q[1] = *(const bf16x8*)(qp + 64 + g * 16);
+        }
+        // ---- S^T = K Q^T ----
+        f32x4 sc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int row = 16 * t + l16;
+            const bf16x8 k0 = *(const bf16x8*)(Ks + row * 128 + (((0 + g) ^ (row & 7)) << 4));
+            const bf16x8 k1 = *(const bf16x8*)(Ks + row * 128 + (((4 + g) ^ (row & 7)) << 4));
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q[0], acc, 0, 0, 0);
+            sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q[1], acc, 0, 0, 0);
+        }
+        // ---- softmax over keys (lane holds j = 16t+4g+r of row i) ----
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * t + 4 * g + r;
+                float v = sc[t][r] * a.scale;
+                if (a.mask && j < a.Nk) v += a.mask[(size_t)b * a.Nk + j];
+                v = j < a.Nk ? v : -INFINITY;
+                sc[t][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[t][r] - m);
+                sc[t][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            sc[t] *= inv;
+            if constexpr (SCORES) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pmax[t][r] = fmaxf(pmax[t][r], sc[t][r]);
+            }
+        }
+        if constexpr (SCORES) {
+            if (i0 + l16 == 0) {
+                float* dst = a.p0 + ((size_t)b * a.H + h) * a.Nk;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * t + 4 * g + r;
+                        if (j < a.Nk) dst[j] = sc[t][r];
+                    }
+            }
+        }
+        // ---- O = P V on the bf16 MFMA ----
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f32x4 hi = (2 * c + 1 < NT) ? sc[2 * c + 1 < NT ? 2 * c + 1 : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bf16x8 pa = pack_bf16x8(sc[2 * c], hi);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16_t* vr = Vt + (dt * 16 + l16) * VP + 32 * c + 4 * g;
+                const bf16x4 v0 = *(const bf16x4*)vr;
+                const bf16x4 v1 = *(const bf16x4*)(vr + 16);
+                const bf16x8 vb = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[dt], 0, 0, 0);
+            }
+        }
+        // ---- write O (row = i0+4g+r, col = h*64+dt*16+l16), row norms ----
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 4 * g + r;
+            float n2 = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) n2 += o[dt][r] * o[dt][r];
+            if constexpr (SCORES) n2 = row16_sum(n2);
+            if (i < a.Nq) {
+                bf16_t* orow = (bf16_t*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 2);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) orow[dt * 16 + l16] = f32_to_bf16(o[dt][r]);
+                if constexpr (SCORES)
+                    if (l16 == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
+            }
+        }
+    }
+
+    if constexpr (SCORES) {
+        if (active) {
+            const int i = i0 + l16;
+            const bool valid = i >= 1 && i < a.Nq;
+            float* dst = a.colsum + ((size_t)b * a.nrt + rt) * a.Nk;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = row16_sum(valid ? pmax[t][r] : 0.f);
+                    const int j = 16 * t + 4 * g + r;
+                    if (l16 == 0 && j < a.Nk) dst[j] = v;
+                }
+        }
+    }
+}
+
+template <int NT, bool SCORES>
+int launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
+    constexpr int NC = (NT + 1) / 2;
+    const size_t lds = (size_t)NT * 16 * 128 + (size_t)64 * (NC * 32 + 8) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bf16_kernel<NT, SCORES>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int gz = 1;
+    if (!SCORES) {
+        const int wgs = ((a.Nq + 63) / 64) * a.B;
+        gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
+        if (gz > a.H) gz = a.H;
+    }
+    hipLaunchKernelGGL((attn_bf16_kernel<NT, SCORES>), dim3((a.Nq + 63) / 64, a.B, gz), dim3(256), lds, s, a);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool SCORES>
+int dispatch_nt_bf16(const AttnArgs& a, hipStream_t s) {
+    const int nt = (a.Nk + 15) / 16;
+    if (nt <= 4) return launch_attn_bf16<4, SCORES>(a, s);
+    if (nt <= 6) return launch_attn_bf16<6, SCORES>(a, s);
+    if (nt <= 8) return launch_attn_bf16<8, SCORES>(a, s);
+    if (nt <= 10) return launch_attn_bf16<10, SCORES>(a, s);
+    if (nt <= 12) return launch_attn_bf16<12, SCORES>(a, s);
+    if (nt <= 13) return launch_attn_bf16<13, SCORES>(a, s);
+    if (nt <= 16) return launch_attn_bf16<16, SCORES>(a, s);
+    return MADTP_E_SHAPE;
+}
+
 template <typename T, int NT, bool SCORES>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     constexpr int RB = 64 * (int)sizeof(T) + 16;
@@ -257,5 +468,6 @@ extern "C" int madtp_attention(const void* q, const void* k, const void* v, void
     hipStream_t s = (hipStream_t)stream;
     const bool scores = colsum_part != nullptr;
     if (io_dtype == MADTP_F32) return scores ? dispatch_nt<float, true>(a, s) : dispatch_nt<float, false>(a, s);
-    return scores ? dispatch_nt<bf16_t, true>(a, s) : dispatch_nt<bf16_t, false>(a, s);
+    if ((ldk * 2) % 16 || (ldv * 2) % 16) return MADTP_E_ALIGN;
+    return scores ? dispatch_nt_bf16<true>(a, s) : dispatch_nt_bf16<false>(a, s);
 }

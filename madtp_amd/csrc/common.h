@@ -15,12 +15,21 @@ typedef unsigned short bf16_t;  // raw bfloat16 bits
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN kept quiet
+typedef __bf16 hwbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hwbf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+// round-to-nearest-even through the hardware converter (v_cvt_pk_bf16_f32 on gfx950)
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ bf16x8 pack_bf16x8(f32x4 lo, f32x4 hi) {
+    f32x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, __builtin_convertvector(v, hwbf16x8));
+}
+__device__ __forceinline__ bf16x4 pack_bf16x4(f32x4 v) {
+    return __builtin_bit_cast(bf16x4, __builtin_convertvector(v, hwbf16x4));
 }
 
 template <typename T> __device__ __forceinline__ float to_f32(T v);

@@ -209,10 +209,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
                                 const float* rp = g.residual + (size_t)row * g.ldr + col;
                                 v0 += *(const f32x4*)rp; v1 += *(const f32x4*)(rp + 4);
                             }
-                            bf16x8 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { o[e] = (short)f32_to_bf16(v0[e]); o[4 + e] = (short)f32_to_bf16(v1[e]); }
-                            *(bf16x8*)((bf16_t*)g.C + (size_t)row * ldc + col) = o;
+                            *(bf16x8*)((bf16_t*)g.C + (size_t)row * ldc + col) = pack_bf16x8(v0, v1);
                         }
                     }
                 } else {

@@ -42,10 +42,7 @@ __device__ __forceinline__ void ln_store(const float4 (&v)[LN_MAX_CHUNKS], int l
         o.w = (v[c].w - mean) * rstd * gm.w + bt.w;
         if (y32) *(float4*)(y32 + col) = o;
         if (ylp) {
-            bf16x4 p;
-            p[0] = (short)f32_to_bf16(o.x); p[1] = (short)f32_to_bf16(o.y);
-            p[2] = (short)f32_to_bf16(o.z); p[3] = (short)f32_to_bf16(o.w);
-            *(bf16x4*)(ylp + col) = p;
+            *(bf16x4*)(ylp + col) = pack_bf16x4((f32x4){o.x, o.y, o.z, o.w});
         }
     }
 }
@@ -142,10 +139,7 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
         const float4 v = *(const float4*)(src + i);
-        bf16x4 p;
-        p[0] = (short)f32_to_bf16(v.x); p[1] = (short)f32_to_bf16(v.y);
-        p[2] = (short)f32_to_bf16(v.z); p[3] = (short)f32_to_bf16(v.w);
-        *(bf16x4*)(dst + i) = p;
+        *(bf16x4*)(dst + i) = pack_bf16x4((f32x4){v.x, v.y, v.z, v.w});
     } else {
         for (size_t j = i; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
     }

@@ -245,43 +245,72 @@ __global__ __launch_bounds__(256) void vector_gather_kernel(const float* __restr
 }
 
 // ----------------------------------------------------------------------------------------------- query_att_ft
-// grid (dim/64, B); 4 waves, wave w owns output columns [64*bx + 16w, +16) for all K<=112 dictionary rows.
-// C[c, d] = sum_t w[c,t] * x[1+t, d] with exact-f32 MFMA 16x16x4: A = w (row c, k-slot g <-> t = 4*step+g),
-// B = x (k-slot g, column d).
+// grid (dim/256, B); 4 waves, wave w owns output columns [256*bx + 64w, +64) (4 MFMA column tiles) for all K<=112
+// dictionary rows (7 row tiles): C[c, d] = sum_t w[c,t] * ft[t, d] with the exact-f32 MFMA 16x16x4
+// (A = w: row c, k-slot g <-> t = 4*step+g;  B = ft: k-slot g, column d).  The softmax weights of a 128-token chunk
+// are computed ONCE per workgroup into LDS (they used to be re-evaluated by every wave of every column block) so the
+// MFMA loop only issues ds_read_b32 + coalesced 64-byte row-segment loads.
+constexpr int AF_TCHUNK = 128, AF_KP = 112;
 __global__ __launch_bounds__(256) void query_att_ft_kernel(const float* __restrict__ ta, int ldt, int ldb, int K,
                                                            const float* __restrict__ ft, int ldf, int ldfb,
                                                            float* __restrict__ out, float inv_sqrt_sd, int accumulate,
                                                            int n, int dim) {
     __shared__ float mx[128], sm[128];
+    __shared__ float part[2][128];
+    __shared__ float wl[AF_TCHUNK * AF_KP];  // [t][c]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
     const float* ta_b = ta + (size_t)b * ldb;
-    if (tid < 128) {
-        float m = -INFINITY, s = 1.f;
-        if (tid < K) {
-            for (int t = 0; t < n; ++t) m = fmaxf(m, ta_b[(size_t)t * ldt + tid] * inv_sqrt_sd);
-            s = 0.f;
-            for (int t = 0; t < n; ++t) s += expf(ta_b[(size_t)t * ldt + tid] * inv_sqrt_sd - m);
-        }
-        mx[tid] = m; sm[tid] = s;
+    // column softmax statistics over tokens: 2 token slices x 128 columns
+    {
+        const int c = tid & 127, sl = tid >> 7;
+        const int t0 = sl ? n / 2 : 0, t1 = sl ? n : n / 2;
+        float m = -INFINITY;
+        if (c < K)
+            for (int t = t0; t < t1; ++t) m = fmaxf(m, ta_b[(size_t)t * ldt + c] * inv_sqrt_sd);
+        part[sl][c] = m;
+        __syncthreads();
+        m = fmaxf(part[0][c], part[1][c]);
+        __syncthreads();
+        float s = 0.f;
+        if (c < K)
+            for (int t = t0; t < t1; ++t) s += expf(ta_b[(size_t)t * ldt + c] * inv_sqrt_sd - m);
+        part[sl][c] = s;
+        __syncthreads();
+        if (tid < 128) { mx[tid] = m; sm[tid] = c < K ? part[0][c] + part[1][c] : 1.f; }
+        __syncthreads();
     }
-    __syncthreads();
-    const int d = blockIdx.x * 64 + wave * 16 + l16;
-    f32x4 acc[7];
+    const int d0 = blockIdx.x * 256 + wave * 64 + l16;
+    f32x4 acc[7][4];
 #pragma unroll
-    for (int mt = 0; mt < 7; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* xb = ft + (size_t)b * ldfb;
-    for (int t4 = 0; t4 < n; t4 += 4) {
-        const int t = t4 + g;
-        const bool tv = t < n;
-        const float xv = tv ? xb[(size_t)t * ldf + d] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 7; ++mt) {
-            const int c = mt * 16 + l16;
+    for (int tc = 0; tc < n; tc += AF_TCHUNK) {
+        const int tn = min(AF_TCHUNK, n - tc);
+        const int tn4 = (tn + 3) & ~3;
+        __syncthreads();
+        for (int idx = tid; idx < tn4 * AF_KP; idx += 256) {
+            const int t = idx / AF_KP, c = idx % AF_KP;
             float w = 0.f;
-            if (tv && c < K) w = expf(ta_b[(size_t)t * ldt + c] * inv_sqrt_sd - mx[c]) / sm[c];
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xv, acc[mt], 0, 0, 0);
+            if (t < tn && c < K) w = expf(ta_b[(size_t)(tc + t) * ldt + c] * inv_sqrt_sd - mx[c]) / sm[c];
+            wl[idx] = w;
+        }
+        __syncthreads();
+        for (int t4 = 0; t4 < tn; t4 += 4) {
+            const int t = t4 + g;
+            float xv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) xv[nt] = t < tn ? xb[(size_t)(tc + t) * ldf + d0 + 16 * nt] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 7; ++mt) {
+                const float w = wl[t * AF_KP + mt * 16 + l16];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xv[nt], acc[mt][nt], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -290,8 +319,11 @@ __global__ __launch_bounds__(256) void query_att_ft_kernel(const float* __restri
         for (int r = 0; r < 4; ++r) {
             const int c = mt * 16 + g * 4 + r;
             if (c < K) {
-                float* o = out + ((size_t)b * K + c) * dim + d;
-                *o = accumulate ? *o + acc[mt][r] : acc[mt][r];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    float* o = out + ((size_t)b * K + c) * dim + d0 + 16 * nt;
+                    *o = accumulate ? *o + acc[mt][nt][r] : acc[mt][nt][r];
+                }
             }
         }
 }
@@ -343,8 +375,8 @@ extern "C" int madtp_mask_gather(const float* mask, const int64_t* order, int ld
 extern "C" int madtp_query_att_ft(const float* token_attn, int ldt, int ldb, int K, const float* x, int ldf, int ldfb,
                                   float* out, float inv_sqrt_sd, int accumulate, int B, int n, int dim, void* stream) {
     if (!token_attn || !x || !out || B <= 0 || n < 1) return MADTP_E_BADARG;
-    if (K <= 0 || K > 112 || dim % 64 || ldt < K) return MADTP_E_SHAPE;
-    hipLaunchKernelGGL(query_att_ft_kernel, dim3(dim / 64, B), dim3(256), 0, (hipStream_t)stream, token_attn, ldt, ldb, K, x,
+    if (K <= 0 || K > 112 || dim % 256 || ldt < K) return MADTP_E_SHAPE;
+    hipLaunchKernelGGL(query_att_ft_kernel, dim3(dim / 256, B), dim3(256), 0, (hipStream_t)stream, token_attn, ldt, ldb, K, x,
                        ldf, ldfb, out, inv_sqrt_sd, accumulate, n, dim);
     MADTP_LAUNCH_CHECK();
     return 0;

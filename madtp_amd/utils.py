@@ -53,7 +53,8 @@ class Query_model(nn.Module):
         self._cache = PreparedCache()
         self.compute_att_ft = True  # att_ft only feeds the training loss (blip_nlvr.py:86-96); eval callers may clear
 
-    def forward(self, ft, sd, mask=None, return_token_att=False, temperature=1):
+    def forward(self, ft, sd, mask=None, return_token_att=False, temperature=1, acc_ft=None):
+        """acc_ft (extension): running sum tensor to accumulate att_ft into (the encoders' `sd_ft_all += sd_ft`)."""
         require_gpu(ft, "ft")
         if not return_token_att:
             raise NotImplementedError("Query_model(return_token_att=False) returns the normalised attention weights; "
@@ -78,7 +79,7 @@ class Query_model(nn.Module):
         kp = sdl.w.shape[0]
         full = hip.gemm(rows, sdl.w, n=kp)  # [rows, 128], zero weight rows beyond K
         token_att = full.view(B, n + off, kp)[:, off:, :K]
-        att_ft = None
+        att_ft = acc_ft
         if self.compute_att_ft:
-            att_ft = hip.query_att_ft(token_att, ftq, sd_dim=self.att_dim)
+            att_ft = hip.query_att_ft(token_att, ftq, out=acc_ft, sd_dim=self.att_dim)
         return token_att, att_ft, sd

@@ -244,9 +244,9 @@ class VisionTransformer(nn.Module):
         sd_img_ft_all = None
         for i, blk in enumerate(self.blocks):
             if space_dict is not None:
-                token_attn, sd_img_ft, _ = self.img_query_model(x[:, 1:, :], space_dict, return_token_att=True)  # :297-298
-                if sd_img_ft is not None:
-                    sd_img_ft_all = sd_img_ft if sd_img_ft_all is None else hip.add_scale(sd_img_ft_all, sd_img_ft, 1.0)
+                # :297-303; `sd_img_ft_all += sd_img_ft` is folded into the kernel (accumulate into the running sum)
+                token_attn, sd_img_ft_all, _ = self.img_query_model(x[:, 1:, :], space_dict, return_token_att=True,
+                                                                    acc_ft=sd_img_ft_all)
                 x = blk(x, register_blk == i, reduce_num, temperature, token_attn)  # :304
             else:
                 x = blk(x, register_blk == i)
