@@ -49,6 +49,12 @@ int madtp_gemm(const void* A, const void* W, const float* bias, const float* res
                int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                int ab_dtype, int c_dtype, int act, float out_scale, void* stream);
 
+/* Optional profiling of madtp_gemm launches with HIP events recorded on the launch stream (bench.py roofline leg).
+ * madtp_profile_begin() starts recording; madtp_profile_end() stops, waits for the events and writes one line per
+ * (dtype, M, N, K): "dtype M N K launches total_ms flops" into buf; returns the bytes written. */
+int madtp_profile_begin(void);
+int madtp_profile_end(char* buf, int cap);
+
 /* y = LayerNorm(x) * gamma + beta over the last dim (dim % 4 == 0, dim <= 1024); x is f32.
  * Writes y32 (f32, may be NULL) and/or ylp (bf16, may be NULL).
  * vit.py:186,205,309 (eps 1e-6); med.py:79,249,328 (eps 1e-12); clip/model.py:160-166 (eps 1e-5). */
@@ -110,9 +116,11 @@ int madtp_token_gather(const float* x, const int32_t* dst_pos, const float* merg
                        int B, int N, int k, int dim, void* stream);
 
 /* Additive-mask compaction for the text encoders (nlvr_encoder.py:451-452,531-533; med.py:388-390,429-440):
- * out[b,0]=mask[b,0]; out[b,1+p] = mask[b,1+order[b,p]] for p in [0,k].  order = indices_sort (NLVR) . */
-int madtp_mask_gather(const float* mask, const int64_t* order, int ld_order, float* out, int B, int N, int k,
-                      void* stream);
+ * out[b,0]=mask[b,0]; out[b,1+p] = mask[b,1+order[b,p]] for p in [0,k]  with order = indices_sort (NLVR, order2 = NULL);
+ * MED (order = indices, order2 = indices_sort): slots p<k take mask[b,1+order[b,p]], slot k takes the mask of the
+ * (k+1)-th ranked token mask[b,1+order2[b,k]]. */
+int madtp_mask_gather(const float* mask, const int64_t* order, int ld_order, const int64_t* order2, int ld_order2,
+                      float* out, int B, int N, int k, void* stream);
 
 /* Query_model's att_ft (models/utils.py:174-178): att_ft[b,c,:] (+)= sum_t softmax_t(token_attn[b,t,c]/sqrt(dim_sd)) * x[b,1+t,:]
  * token_attn as in madtp_token_score; ft f32: patch token t of sample b at ft[b*ldf_batch + t*ldf_row + d] (so
@@ -131,6 +139,75 @@ int madtp_add_scale(const float* a, const float* b, float* out, float scale, siz
 
 /* f32 -> bf16 copy (weight preparation, activations entering a bf16 GEMM). */
 int madtp_cast_bf16(const float* src, void* dst, size_t n, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Layer-level entry points.  One call enqueues the kernel sequence of half a transformer layer (the host-side cut is
+ * where the reference reads k = max_b count back with `.item()`: vit.py:145 / med.py:373 / nlvr_encoder.py:432).
+ * Weights are "prepared" Linears: w is [n padded to 128 rows, k] in the compute dtype, b is f32 (may be NULL).
+ * Scratch comes from a caller-owned workspace of at least *_workspace() bytes (256-byte aligned base).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct madtp_lin {
+    const void* w;  /* [n_pad, k] row-major, compute dtype */
+    const float* b; /* [n] or NULL */
+    int n, k;
+} madtp_lin;
+
+/* models/vit.py Block (:106-207): norm1, attn.qkv, attn.proj, norm2, mlp.fc1, mlp.fc2 */
+typedef struct madtp_vit_block_w {
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    float eps, scale; /* LayerNorm eps; attention scale head_dim^-0.5 */
+    madtp_lin qkv, proj, fc1, fc2;
+    int heads, dim, dtype; /* dtype: MADTP_F32 (parity mode) or MADTP_BF16 (fast mode) */
+} madtp_vit_block_w;
+
+size_t madtp_vit_block_workspace(int B, int N, int dim, int hidden, int heads, int dtype);
+
+/* Block.forward up to the pruning decision (vit.py:186-190 + Reduce_token :125-145):
+ * x_out = x + proj(attention(qkv(norm1(x)))); if temperature > 0 also score[B,N-1], threshold[B], count[B], kmax[1]. */
+int madtp_vit_block_attn(const madtp_vit_block_w* w, const float* x, float* x_out, void* ws, size_t ws_bytes, int B, int N,
+                         const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature, float* score,
+                         float* threshold, int32_t* count, int32_t* kmax, void* stream);
+
+/* Rest of Block.forward (vit.py:148-161,195-205): k > 0 -> select/gather/merge to [B,k+2,dim] (writes indices[B,k],
+ * indices_sort[B,N-1]); then y = x' + fc2(GELU(fc1(norm2(x')))).  k == 0 -> no pruning. */
+int madtp_vit_block_mlp(const madtp_vit_block_w* w, const float* x, float* y, void* ws, size_t ws_bytes, int B, int N, int k,
+                        const float* score, int64_t* indices, int64_t* indices_sort, void* stream);
+
+/* Query_model.forward(return_token_att=True) (models/utils.py:147-183) over a contiguous token buffer x[B,N,dim]:
+ * token_attn_full[B*N, 128] = x @ sd^T (exact-f32 MFMA; sd_w is f32 [128,dim], rows >= K zero); row b*N+1+t is patch t.
+ * att_ft[B,K,dim] (+)= softmax_t(logits/sqrt(sd_dim)) @ x[:,1:]  (skipped when att_ft is NULL). */
+int madtp_query_model(const float* x, const void* sd_w, int K, float* token_attn_full, float* att_ft, int accumulate,
+                      float inv_sqrt_sd, int B, int N, int dim, void* stream);
+
+/* models/med.py BertLayer (:332-467) / models/nlvr_encoder.py BertLayer (:385-559) */
+typedef struct madtp_bert_layer_w {
+    madtp_lin qkv, attn_out;            /* attention.self.{query|key|value} fused; attention.output.dense */
+    const float *ln_att_g, *ln_att_b;   /* attention.output.LayerNorm */
+    int cross;                          /* 0 no crossattention module, 1 single (MED), 2 twin (NLVR self0/self1) */
+    int variant_nlvr;                   /* mask-gather rule and cross-attention mask rule of nlvr_encoder.py */
+    int has_merge;                      /* crossattention.output.merge_layer present (NLVR layers >= 6) */
+    madtp_lin cq[2], ckv[2], cdense[2], merge;
+    const float *ln_cross_g, *ln_cross_b;
+    madtp_lin inter, out;               /* intermediate.dense, output.dense */
+    const float *ln_out_g, *ln_out_b;
+    float eps, scale;
+    int heads, dim, dtype;
+} madtp_bert_layer_w;
+
+size_t madtp_bert_layer_workspace(int B, int L, int Nk, int dim, int hidden, int heads, int dtype);
+
+/* att = LayerNorm(attention.output.dense(self_attention(hidden)) + hidden)  (med.py:408-418) [+ score/threshold/count/kmax] */
+int madtp_bert_layer_attn(const madtp_bert_layer_w* w, const float* hidden, const float* mask2d, float* att, void* ws,
+                          size_t ws_bytes, int B, int L, int Nk, const float* token_attn, int ldt_row, int ldt_batch, int K,
+                          float temperature, float* score, float* threshold, int32_t* count, int32_t* kmax, void* stream);
+
+/* Rest of BertLayer.forward (med.py:422-462 / nlvr_encoder.py:519-554): prune att+mask (k > 0), optional
+ * cross-attention to enc0/enc1 ([B*Nk,dim], compute dtype), FFN.  y is [B,L',dim], mask_out [B,L'] (L' = k+2 or L). */
+int madtp_bert_layer_rest(const madtp_bert_layer_w* w, const float* att, const float* mask2d, float* y, float* mask_out,
+                          void* ws, size_t ws_bytes, int B, int L, int k, const float* score, int64_t* indices,
+                          int64_t* indices_sort, int cross_mode, const void* enc0, const void* enc1, int Nk,
+                          const float* enc_mask0, const float* enc_mask1, void* stream);
 
 #ifdef __cplusplus
 }

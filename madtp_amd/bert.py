@@ -248,15 +248,67 @@ class _BertLayerBase(nn.Module):
         y = hip.token_gather(x, dst_pos, merge_w, k)
         if mask is not None:
             if self.variant == "nlvr":
-                order = indices_sort  # nlvr_encoder.py:452 gathers the mask with indices_sort[:, :k+1]
+                mask = hip.mask_gather(mask, indices_sort, k)  # nlvr_encoder.py:452: indices_sort[:, :k+1]
             else:
                 # med.py:377,388-390: topk(k+1, sorted=False) - kept tokens keep their own mask, the merged slot takes
                 # the mask of the (k+1)-th ranked token (torch-CPU places it last)
-                order = torch.cat([indices, indices_sort[:, k:k + 1]], dim=1).contiguous()
-            mask = hip.mask_gather(mask, order, k)
+                mask = hip.mask_gather(mask, indices, k, order2=indices_sort)
         return y, mask
 
     # ---- forward --------------------------------------------------------------------------------------------
+    def _weights(self):
+        """madtp_bert_layer_w for the layer-level C entry points."""
+        sa, ao = self.attention.self, self.attention.output
+        params = [sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias,
+                  ao.dense.weight, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias, self.intermediate.dense.weight,
+                  self.intermediate.dense.bias, self.output.dense.weight, self.output.dense.bias,
+                  self.output.LayerNorm.weight, self.output.LayerNorm.bias]
+        has_cross = hasattr(self, "crossattention")
+        if has_cross:
+            params += list(self.crossattention.parameters())
+
+        def build():
+            keep = []
+
+            def L(cache, key, mods):
+                l = lin_of(cache, key, mods)
+                keep.append(l)
+                return hip.lin_struct(l)
+
+            w = hip.BertLayerW()
+            w.qkv = L(sa._cache, "qkv", [sa.query, sa.key, sa.value])
+            w.attn_out = L(ao._cache, "d", [ao.dense])
+            w.ln_att_g, w.ln_att_b = ao.LayerNorm.weight.data_ptr(), ao.LayerNorm.bias.data_ptr()
+            w.cross, w.variant_nlvr, w.has_merge = 0, int(self.variant == "nlvr"), 0
+            if has_cross:
+                ca = self.crossattention
+                co = ca.output
+                if ca.twin:
+                    w.cross = 2
+                    for br, sm in enumerate((ca.self0, ca.self1)):
+                        w.cq[br] = L(sm._cache, "q", [sm.query])
+                        w.ckv[br] = L(sm._cache, "kv", [sm.key, sm.value])
+                    w.cdense[0] = L(co._cache, "d0", [co.dense0])
+                    w.cdense[1] = L(co._cache, "d1", [co.dense1])
+                    if co.merge:
+                        w.has_merge = 1
+                        w.merge = L(co._cache, "mg", [co.merge_layer])
+                else:
+                    w.cross = 1
+                    w.cq[0] = L(ca.self._cache, "q", [ca.self.query])
+                    w.ckv[0] = L(ca.self._cache, "kv", [ca.self.key, ca.self.value])
+                    w.cdense[0] = L(co._cache, "d", [co.dense])
+                w.ln_cross_g, w.ln_cross_b = co.LayerNorm.weight.data_ptr(), co.LayerNorm.bias.data_ptr()
+            w.inter = L(self._cache, "inter", [self.intermediate.dense])
+            w.out = L(self._cache, "out", [self.output.dense])
+            w.ln_out_g, w.ln_out_b = self.output.LayerNorm.weight.data_ptr(), self.output.LayerNorm.bias.data_ptr()
+            w.eps, w.scale = self.output.LayerNorm.eps, 1.0 / math.sqrt(sa.attention_head_size)
+            w.heads, w.dim = sa.num_attention_heads, sa.all_head_size
+            w.dtype = hip.F32 if compute_dtype() == torch.float32 else hip.BF16
+            return (w, keep)
+
+        return self._cache.get("w", params, build)[0]
+
     def _forward(self, hidden_states, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask,
                  past_key_value, output_attentions, mode, token_attn, temperature):
         require_gpu(hidden_states, "hidden_states")
@@ -270,28 +322,37 @@ class _BertLayerBase(nn.Module):
                 raise NotImplementedError("only padding masks [B,1,1,L] (encoder use) are supported")
             mask2d = as_f32_contig(attention_mask[:, 0, 0, :])
         prune = temperature > 0
-        h2 = hidden.view(B * L, D)
-        ctx, present = self.attention.self.run_self(_cast(h2), B, L, mask2d, want_scores=prune)
-        att32, attc = self.attention.output.run(ctx, h2)
-        self.last_prune = None
-        if prune:
-            if mask2d is None:
-                raise ValueError("attention_mask is required when temperature > 0 (med.py:424)")
-            x, mask2d = self.Reduce_token(att32.view(B, L, D), 0, temperature, token_attn=token_attn, mask=mask2d)
-            if self.last_prune["pruned"]:
-                B, L, D = x.shape
-                att32 = x.view(B * L, D)
-                attc = _cast(att32)
-                attention_mask = mask2d[:, None, None, :]
-        if mode == 'multimodal':
+        if prune and mask2d is None:
+            raise ValueError("attention_mask is required when temperature > 0 (med.py:424)")
+        cross = mode == 'multimodal'
+        enc0 = enc1 = em0 = em1 = None
+        Nk = 0
+        if cross:
             assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
-            att32, attc = self._cross(att32, attc, B, L, encoder_hidden_states, encoder_attention_mask)
-        inter = lin_of(self._cache, "inter", [self.intermediate.dense])
-        outp = lin_of(self._cache, "out", [self.output.dense])
-        mid = hip.gemm(attc, inter.w, inter.b, act=hip.ACT_GELU, n=inter.n)
-        t = hip.gemm(mid, outp.w, outp.b, residual=att32, out_dtype=torch.float32, n=outp.n)
-        y32, _ = hip.layernorm(t, self.output.LayerNorm.weight, self.output.LayerNorm.bias, self.output.LayerNorm.eps)
-        return (y32.view(B, L, D), present, attention_mask)
+            if self.variant == "nlvr":
+                Nk = encoder_hidden_states[0].shape[1]
+                enc0, enc1 = self._enc_operand(encoder_hidden_states[0]), self._enc_operand(encoder_hidden_states[1])
+                em0, em1 = self._enc_mask2d(encoder_attention_mask[0]), self._enc_mask2d(encoder_attention_mask[1])
+            else:
+                Nk = encoder_hidden_states.shape[1]
+                enc0 = self._enc_operand(encoder_hidden_states)
+        w = self._weights()
+        # self-attention + output LayerNorm (+ importance score / threshold / count)   med.py:408-418,347-371
+        att, po = hip.bert_layer_attn(w, hidden, mask2d, token_attn, temperature if prune else 0, Nk)
+        self.last_prune = None
+        k_use, score = 0, None
+        if prune:
+            score, thr, count, kmax = po
+            k = int(kmax.item())
+            self.last_prune = {"k": k, "score": score, "threshold": thr, "count": count, "pruned": False,
+                               "indices": None, "indices_sort": None}
+            if not (k < 1 or (L - 1 - k) <= 1):
+                k_use = k
+        y, mask_out, indices, indices_sort = hip.bert_layer_rest(w, att, mask2d, k_use, score, cross, enc0, enc1, Nk, em0, em1)
+        if k_use:
+            self.last_prune.update(pruned=True, indices=indices, indices_sort=indices_sort)
+            attention_mask = mask_out[:, None, None, :]
+        return (y, None, attention_mask)  # present_key_value is not kept (encoder use, use_cache=False)
 
     def _enc_operand(self, enc):
         """compute-dtype 2-D copy of an encoder tensor, shared by the 12 layers that receive the same tensor object

@@ -17,13 +17,15 @@
 //   * M edge: source rows are clamped to M-1 (reads stay in bounds, results discarded); W is padded by the caller
 //     to a multiple of 128 rows; stores are guarded by row<M, col<N.
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
+#include <map>
+#include <tuple>
+#include <vector>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, ROWB = 128;      // tile rows, bytes per row slab
-constexpr int TILE_BYTES = BM * ROWB;              // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;        // A + W
+constexpr int ROWB = 128;      // bytes per operand row slab (64 bf16 / 32 f32 along K)
 constexpr int NTHREADS = 256;
 
 struct GemmArgs {
@@ -41,21 +43,23 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
-// issue the LDS-DMA of one 128x128B operand tile: 16 wave-instructions of 1 KiB, 4 per wave
-template <int ESZ>
+// issue the LDS-DMA of one ROWS x 128 B operand tile: ROWS/8 wave-instructions of 1 KiB, ROWS/32 per wave
+template <int ESZ, int ROWS>
 __device__ __forceinline__ void stage_tile(const char* base, int row0, int max_row, int ld_elems, int kbyte0,
                                            char* lds_tile, int wave, int lane) {
     const int sub = lane >> 3;                       // row within the 8-row group
     const int chunk = (lane & 7) ^ sub;              // inverse swizzle on the SOURCE
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int grp = wave * 4 + q;
+    for (int q = 0; q < ROWS / 32; ++q) {
+        const int grp = wave * (ROWS / 32) + q;
         int row = row0 + grp * 8 + sub;
         row = row < max_row ? row : max_row;
         const char* src = base + ((size_t)row * ld_elems) * ESZ + kbyte0 + chunk * 16;
         __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_tile + grp * 1024), 16, 0, 0);
     }
 }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // fast erf for outputs that are rounded to bf16 anyway: Abramowitz-Stegun 7.1.26, |err| < 2e-7 (+ fast exp/rcp)
 __device__ __forceinline__ float gelu_fast(float v) {
@@ -66,10 +70,13 @@ __device__ __forceinline__ float gelu_fast(float v) {
     return 0.5f * v * (1.0f + copysignf(erf_abs, v));
 }
 
-template <bool LP_OUT>
-__device__ __forceinline__ float epi_act(float v, int act) {
-    if (LP_OUT && act == MADTP_ACT_GELU_ERF) return gelu_fast(v);
-    return apply_act(v, act);
+// compile-time activation: the epilogue is instantiated per activation code so it stays straight-line code
+template <bool LP_OUT, int ACT>
+__device__ __forceinline__ float epi_act(float v) {
+    if constexpr (ACT == MADTP_ACT_GELU_ERF) return LP_OUT ? gelu_fast(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    else if constexpr (ACT == MADTP_ACT_QUICK_GELU) return v / (1.0f + expf(-1.702f * v));
+    else if constexpr (ACT == MADTP_ACT_RELU) return fmaxf(v, 0.0f);
+    else return v;
 }
 
 // Output-fragment geometry.  The MFMA is issued with the operands SWAPPED (D = Wfrag . Afrag^T), so lane
@@ -84,9 +91,84 @@ __device__ __forceinline__ int wfrag_row(int j, int rho) {
     return LP_OUT ? 32 * (j >> 1) + 8 * (rho >> 2) + 4 * (j & 1) + (rho & 3) : 16 * j + rho;
 }
 
-template <typename T, bool LP_OUT>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
+template <bool LP_OUT, int ACT, int FM, int FN, int BM, int BN>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[FM][FN], int m0, int n0, int wr, int wc,
+                                         int l16, int grp4) {
+    const bool c_bf16 = g.ldc < 0;
+    const int ldc = c_bf16 ? -g.ldc : g.ldc;
+            const int col_w = n0 + wc * (BN / 2);
+            if (g.fast_epi) {
+                if constexpr (LP_OUT) {
+#pragma unroll
+                    for (int jp = 0; jp < FN / 2; ++jp) {
+                        const int col = col_w + 32 * jp + 8 * grp4;
+                        if (col >= g.N) continue;
+                        f32x4 b0 = (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = b0;
+                        if (g.bias) { b0 = *(const f32x4*)(g.bias + col); b1 = *(const f32x4*)(g.bias + col + 4); }
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) {
+                            const int row = m0 + wr * (BM / 2) + i * 16 + l16;
+                            if (row >= g.M) continue;
+                            f32x4 v0 = acc[i][2 * jp] + b0, v1 = acc[i][2 * jp + 1] + b1;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v0[e] = epi_act<true, ACT>(v0[e]) * g.out_scale;
+                                v1[e] = epi_act<true, ACT>(v1[e]) * g.out_scale;
+                            }
+                            if (g.residual) {
+                                const float* rp = g.residual + (size_t)row * g.ldr + col;
+                                v0 += *(const f32x4*)rp; v1 += *(const f32x4*)(rp + 4);
+                            }
+                            *(bf16x8*)((bf16_t*)g.C + (size_t)row * ldc + col) = pack_bf16x8(v0, v1);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const int col = col_w + 16 * j + 4 * grp4;
+                        if (col >= g.N) continue;
+                        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (g.bias) bv = *(const f32x4*)(g.bias + col);
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) {
+                            const int row = m0 + wr * (BM / 2) + i * 16 + l16;
+                            if (row >= g.M) continue;
+                            f32x4 v = acc[i][j] + bv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = epi_act<false, ACT>(v[e]) * g.out_scale;
+                            if (g.residual) v += *(const f32x4*)(g.residual + (size_t)row * g.ldr + col);
+                            *(f32x4*)((float*)g.C + (size_t)row * ldc + col) = v;
+                        }
+                    }
+                }
+            } else {
+                // generic fallback (N or a leading dimension not a multiple of 8 elements, e.g. the 2-logit head)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = col_w + wfrag_row<LP_OUT>(j, 4 * grp4 + r);
+                        if (col >= g.N) continue;
+                        const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) {
+                            const int row = m0 + wr * (BM / 2) + i * 16 + l16;
+                            if (row >= g.M) continue;
+                            float v = epi_act<LP_OUT, ACT>(acc[i][j][r] + bv) * g.out_scale;
+                            if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+                            if (c_bf16) ((bf16_t*)g.C)[(size_t)row * ldc + col] = f32_to_bf16(v);
+                            else ((float*)g.C)[(size_t)row * ldc + col] = v;
+                        }
+                    }
+            }
+}
+
+template <typename T, bool LP_OUT, int BM, int BN, int STAGES>
+__global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 1) void gemm_kernel(GemmArgs g) {
     constexpr int ESZ = sizeof(T);
+    constexpr int FM = BM / 32, FN = BN / 32;          // 16x16 fragments per wave (wave tile = BM/2 x BN/2)
+    constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int PER = (BM + BN) / 32;                // LDS-DMA instructions per wave per slab
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // Persistent, XCD-aware tile schedule: block b runs on XCD b%8 (observed dispatch rule; only speed depends on
@@ -103,11 +185,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
     const int wr = wave >> 1, wc = wave & 1;
     const int l16 = lane & 15, grp4 = lane >> 4;
 
-    f32x4 acc[4][4];
+    f32x4 acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.K * ESZ / ROWB;
     const int n_pad_max = g.ntn * BN - 1;
@@ -115,70 +197,77 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
     const int ldc = c_bf16 ? -g.ldc : g.ldc;
 
     // LDS byte offsets of this lane's fragment rows (row*128) and their swizzle keys (row&7)
-    int a_off[4], a_key[4], b_off[4], b_key[4];
+    int a_off[FM], a_key[FM], b_off[FN], b_key[FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ra = wr * 64 + i * 16 + l16;
+    for (int i = 0; i < FM; ++i) {
+        const int ra = wr * (BM / 2) + i * 16 + l16;
         a_off[i] = ra * ROWB; a_key[i] = ra & 7;
-        const int rb = wc * 64 + wfrag_row<LP_OUT>(i, l16);
-        b_off[i] = rb * ROWB; b_key[i] = rb & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int rb = wc * (BN / 2) + wfrag_row<LP_OUT>(j, l16);
+        b_off[j] = rb * ROWB; b_key[j] = rb & 7;
     }
 
+    // The operand slabs of ALL tiles of this workgroup form one continuous stream through a ring of STAGES LDS
+    // stages: slab q lives in stage q % STAGES and STAGES-1 slabs are always in flight (LDS-DMA), across tile
+    // boundaries too, so the pipeline never drains and a tile's epilogue overlaps the next tile's loads.  The ring
+    // is synchronised with a COUNTED s_waitcnt vmcnt + raw s_barrier (a __syncthreads() would drain every DMA).
+    const int my_slots = (nslots - lb + gl - 1) / gl;
+    const long total_slabs = (long)my_slots * nk;
+    int is_slot = slot, is_kt = 0;  // coordinates of the next slab to issue
+    long issued = 0;
+    auto issue_next = [&]() {
+        if (issued < total_slabs && !(g.dbg & 2)) {
+            char* st = smem + (int)(issued % STAGES) * STAGE_BYTES;
+            const int im0 = ((is_slot / g.ntn) * 8 + xcd) * BM, in0 = (is_slot % g.ntn) * BN;
+            stage_tile<ESZ, BM>(g.A, im0, g.M - 1, g.lda, is_kt * ROWB, st, wave, lane);
+            stage_tile<ESZ, BN>(g.W, in0, n_pad_max, g.ldw, is_kt * ROWB, st + A_BYTES, wave, lane);
+        }
+        ++issued;  // phantom slabs past the end keep the wait counts uniform (they issue nothing: see tail wait)
+        if (++is_kt == nk) { is_kt = 0; is_slot += gl; }
+    };
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p) issue_next();
+
     int m0 = ((slot / g.ntn) * 8 + xcd) * BM, n0 = (slot % g.ntn) * BN;
-    // the operand slabs of ALL tiles of this workgroup form one continuous double-buffered stream: slab s lives in
-    // stage s&1 and the DMA of slab s+1 (same tile, or the first slab of the NEXT tile) is issued right after the
-    // barrier of slab s, so the pipeline never drains and the epilogue stores overlap the next tile's loads.
-    unsigned s = 0;
-    if (!(g.dbg & 2)) {
-        stage_tile<ESZ>(g.A, m0, g.M - 1, g.lda, 0, smem, wave, lane);
-        stage_tile<ESZ>(g.W, n0, n_pad_max, g.ldw, 0, smem + TILE_BYTES, wave, lane);
-    }
+    long s = 0;
     while (true) {
-        const int next_slot = slot + gl;
         for (int kt = 0; kt < nk; ++kt, ++s) {
-            __syncthreads();  // slab s landed (the barrier drains the LDS-DMA); stage (s+1)&1 is free again
-            if (!(g.dbg & 2)) {
-                char* nxt = smem + ((s + 1) & 1) * STAGE_BYTES;
-                if (kt + 1 < nk) {
-                    stage_tile<ESZ>(g.A, m0, g.M - 1, g.lda, (kt + 1) * ROWB, nxt, wave, lane);
-                    stage_tile<ESZ>(g.W, n0, n_pad_max, g.ldw, (kt + 1) * ROWB, nxt + TILE_BYTES, wave, lane);
-                } else if (next_slot < nslots) {
-                    const int nm0 = ((next_slot / g.ntn) * 8 + xcd) * BM, nn0 = (next_slot % g.ntn) * BN;
-                    stage_tile<ESZ>(g.A, nm0, g.M - 1, g.lda, 0, nxt, wave, lane);
-                    stage_tile<ESZ>(g.W, nn0, n_pad_max, g.ldw, 0, nxt + TILE_BYTES, wave, lane);
-                }
-            }
-            const char* sa = smem + (s & 1) * STAGE_BYTES;
-            const char* sw = sa + TILE_BYTES;
+            // slab s must have landed: this wave's DMAs newer than slab s are those of slabs s+1 .. s+STAGES-2
+            if (s + STAGES - 1 <= total_slabs) wait_vmcnt<(STAGES - 2) * PER>();
+            else wait_vmcnt<0>();  // tail of the stream: fewer real slabs behind slab s
+            __builtin_amdgcn_s_barrier();  // all waves' parts of slab s landed; stage (s-1)%STAGES is free again
+            issue_next();                   // slab s+STAGES-1 -> stage (s-1)%STAGES
+            const char* sa = smem + (int)(s % STAGES) * STAGE_BYTES;
+            const char* sw = sa + A_BYTES;
             if (g.dbg & 4) continue;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int chunk = kk * 4 + grp4;
                 if constexpr (ESZ == 2) {
-                    bf16x8 a[4], b[4];
+                    bf16x8 a[FM], b[FN];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        a[i] = *(const bf16x8*)(sa + a_off[i] + ((chunk ^ a_key[i]) << 4));
-                        b[i] = *(const bf16x8*)(sw + b_off[i] + ((chunk ^ b_key[i]) << 4));
-                    }
+                    for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(sa + a_off[i] + ((chunk ^ a_key[i]) << 4));
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(sw + b_off[j] + ((chunk ^ b_key[j]) << 4));
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
                 } else {
-                    f32x4 a[4], b[4];
+                    f32x4 a[FM], b[FN];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        a[i] = *(const f32x4*)(sa + a_off[i] + ((chunk ^ a_key[i]) << 4));
-                        b[i] = *(const f32x4*)(sw + b_off[i] + ((chunk ^ b_key[i]) << 4));
-                    }
+                    for (int i = 0; i < FM; ++i) a[i] = *(const f32x4*)(sa + a_off[i] + ((chunk ^ a_key[i]) << 4));
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) b[j] = *(const f32x4*)(sw + b_off[j] + ((chunk ^ b_key[j]) << 4));
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < FM; ++i)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
+                            for (int j = 0; j < FN; ++j)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][e], a[i][e], acc[i][j], 0, 0, 0);
                 }
             }
@@ -186,83 +275,63 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
 
         // ---- epilogue of tile (m0,n0): vectors straight from the accumulators ----
         if (!((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {
-            const int col_w = n0 + wc * 64;
-            if (g.fast_epi) {
-                if constexpr (LP_OUT) {
-#pragma unroll
-                    for (int jp = 0; jp < 2; ++jp) {
-                        const int col = col_w + 32 * jp + 8 * grp4;
-                        if (col >= g.N) continue;
-                        f32x4 b0 = (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = b0;
-                        if (g.bias) { b0 = *(const f32x4*)(g.bias + col); b1 = *(const f32x4*)(g.bias + col + 4); }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int row = m0 + wr * 64 + i * 16 + l16;
-                            if (row >= g.M) continue;
-                            f32x4 v0 = acc[i][2 * jp] + b0, v1 = acc[i][2 * jp + 1] + b1;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v0[e] = epi_act<true>(v0[e], g.act) * g.out_scale;
-                                v1[e] = epi_act<true>(v1[e], g.act) * g.out_scale;
-                            }
-                            if (g.residual) {
-                                const float* rp = g.residual + (size_t)row * g.ldr + col;
-                                v0 += *(const f32x4*)rp; v1 += *(const f32x4*)(rp + 4);
-                            }
-                            *(bf16x8*)((bf16_t*)g.C + (size_t)row * ldc + col) = pack_bf16x8(v0, v1);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int col = col_w + 16 * j + 4 * grp4;
-                        if (col >= g.N) continue;
-                        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (g.bias) bv = *(const f32x4*)(g.bias + col);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int row = m0 + wr * 64 + i * 16 + l16;
-                            if (row >= g.M) continue;
-                            f32x4 v = acc[i][j] + bv;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], g.act) * g.out_scale;
-                            if (g.residual) v += *(const f32x4*)(g.residual + (size_t)row * g.ldr + col);
-                            *(f32x4*)((float*)g.C + (size_t)row * ldc + col) = v;
-                        }
-                    }
-                }
-            } else {
-                // generic fallback (N or a leading dimension not a multiple of 8 elements, e.g. the 2-logit head)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int col = col_w + wfrag_row<LP_OUT>(j, 4 * grp4 + r);
-                        if (col >= g.N) continue;
-                        const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int row = m0 + wr * 64 + i * 16 + l16;
-                            if (row >= g.M) continue;
-                            float v = apply_act(acc[i][j][r] + bv, g.act) * g.out_scale;
-                            if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
-                            if (c_bf16) ((bf16_t*)g.C)[(size_t)row * ldc + col] = f32_to_bf16(v);
-                            else ((float*)g.C)[(size_t)row * ldc + col] = v;
-                        }
-                    }
+            switch (g.act) {
+                case MADTP_ACT_GELU_ERF: epilogue<LP_OUT, MADTP_ACT_GELU_ERF, FM, FN, BM, BN>(g, acc, m0, n0, wr, wc, l16, grp4); break;
+                case MADTP_ACT_QUICK_GELU: epilogue<LP_OUT, MADTP_ACT_QUICK_GELU, FM, FN, BM, BN>(g, acc, m0, n0, wr, wc, l16, grp4); break;
+                case MADTP_ACT_RELU: epilogue<LP_OUT, MADTP_ACT_RELU, FM, FN, BM, BN>(g, acc, m0, n0, wr, wc, l16, grp4); break;
+                default: epilogue<LP_OUT, MADTP_ACT_NONE, FM, FN, BM, BN>(g, acc, m0, n0, wr, wc, l16, grp4); break;
             }
         }
-        slot = next_slot;
+        slot += gl;
         if (slot >= nslots) break;
         m0 = ((slot / g.ntn) * 8 + xcd) * BM; n0 = (slot % g.ntn) * BN;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 }
 
 }  // namespace
+
+// ---- optional HIP-event profiling of every GEMM launch (bench.py's roofline leg) -----------------------------------
+namespace {
+struct GemmRecord { hipEvent_t e0, e1; double flops; int dt, M, N, K; };
+bool g_prof_on = false;
+std::vector<GemmRecord> g_prof;
+}  // namespace
+
+extern "C" int madtp_profile_begin(void) {
+    for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_on = true;
+    return 0;
+}
+
+// Stops recording, waits for the recorded events and writes one text line per (dtype, M, N, K):
+// "dtype M N K launches total_ms flops".  Returns the number of bytes written (0 if nothing was recorded).
+extern "C" int madtp_profile_end(char* buf, int cap) {
+    g_prof_on = false;
+    std::map<std::tuple<int, int, int, int>, std::tuple<int, double, double>> agg;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            auto& a = agg[std::make_tuple(r.dt, r.M, r.N, r.K)];
+            std::get<0>(a) += 1; std::get<1>(a) += ms; std::get<2>(a) += r.flops;
+        }
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    int off = 0;
+    for (auto& kv : agg) {
+        const int n = snprintf(buf + off, cap > off ? cap - off : 0, "%d %d %d %d %d %.6f %.0f\n", std::get<0>(kv.first),
+                               std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first), std::get<0>(kv.second),
+                               std::get<1>(kv.second), std::get<2>(kv.second));
+        if (n < 0 || off + n >= cap) break;
+        off += n;
+    }
+    return off;
+}
 
 extern "C" int madtp_gemm(const void* A, const void* W, const float* bias, const float* residual, void* C,
                           int M, int N, int K, int lda, int ldw, int ldc, int ldr,
@@ -278,26 +347,57 @@ extern "C" int madtp_gemm(const void* A, const void* W, const float* bias, const
     g.A = (const char*)A; g.W = (const char*)W; g.bias = bias; g.residual = residual; g.C = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.act = act; g.out_scale = out_scale;
     g.ldc = c_dtype == MADTP_BF16 ? -ldc : ldc;
-    g.ntm = (M + BM - 1) / BM;
-    g.ntn = (N + BN - 1) / BN;
-    static int dbg = -1;
+    static int dbg = -1, force_cfg = -1;
     if (dbg < 0) { const char* e = getenv("MADTP_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (force_cfg < 0) { const char* e = getenv("MADTP_GEMM_CFG"); force_cfg = e ? atoi(e) : 0; }
     g.dbg = dbg;
     // vector epilogue needs 16-byte aligned rows on every epilogue operand
     g.fast_epi = (N % 8 == 0) && (ldc % 8 == 0) && aligned16(C) && (!bias || aligned16(bias)) &&
                  (!residual || (aligned16(residual) && ldr % 4 == 0));
-    // persistent grid: at most 2 workgroups per CU (64 KiB LDS each), 64 per XCD
-    const int slots_max = ((g.ntm + 7) / 8) * g.ntn;
-    const int grid = 8 * (slots_max < 64 ? slots_max : 64);
-    const size_t lds = 2 * STAGE_BYTES;
+    // tile configuration: 128x128 tiles, 2 workgroups/CU, 2-stage ring.  MADTP_GEMM_CFG=2/3/4 selects the
+    // experimental 64x64x6 / 128x128x3 / 128x128x4 variants (kept for A/B measurements).
+    int cfg = 0;  // measured on MI355X: the 64x64 / deeper-ring variants lose to 128x128x2 on every shape of the path
+    if (force_cfg > 0) cfg = force_cfg - 1;
     hipStream_t s = (hipStream_t)stream;
     const bool lp = c_dtype == MADTP_BF16;
+    GemmRecord rec;
+    if (g_prof_on) {
+        hipEventCreate(&rec.e0); hipEventCreate(&rec.e1);
+        rec.flops = 2.0 * M * N * K; rec.dt = ab_dtype; rec.M = M; rec.N = N; rec.K = K;
+        hipEventRecord(rec.e0, s);
+    }
+#define MADTP_LAUNCH_GEMM(TT, LP, BM_, BN_, ST_, WGCU)                                                                   \
+    do {                                                                                                               \
+        g.ntm = (M + BM_ - 1) / BM_;                                                                                   \
+        g.ntn = (N + BN_ - 1) / BN_;                                                                                   \
+        const int slots_max = ((g.ntm + 7) / 8) * g.ntn;                                                               \
+        const int per_xcd = 32 * WGCU;                                                                                 \
+        const int grid = 8 * (slots_max < per_xcd ? slots_max : per_xcd);                                              \
+        const size_t lds = (size_t)(BM_ + BN_) * ROWB * ST_;                                                           \
+        static bool attr = false;                                                                                      \
+        if (!attr) {                                                                                                   \
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<TT, LP, BM_, BN_, ST_>,                        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+            if (e != hipSuccess) return (int)e;                                                                        \
+            attr = true;                                                                                               \
+        }                                                                                                              \
+        hipLaunchKernelGGL((gemm_kernel<TT, LP, BM_, BN_, ST_>), dim3(grid), dim3(NTHREADS), lds, s, g);               \
+    } while (0)
+#define MADTP_DISPATCH_CFG(TT, LP)                                             \
+    do {                                                                       \
+        if (cfg == 0) MADTP_LAUNCH_GEMM(TT, LP, 128, 128, 2, 2);               \
+        else if (cfg == 1) MADTP_LAUNCH_GEMM(TT, LP, 64, 64, 6, 1);            \
+        else if (cfg == 2) MADTP_LAUNCH_GEMM(TT, LP, 128, 128, 3, 1);          \
+        else MADTP_LAUNCH_GEMM(TT, LP, 128, 128, 4, 1);                        \
+    } while (0)
     if (ab_dtype == MADTP_BF16) {
-        if (lp) hipLaunchKernelGGL((gemm_kernel<bf16_t, true>), dim3(grid), dim3(NTHREADS), lds, s, g);
-        else hipLaunchKernelGGL((gemm_kernel<bf16_t, false>), dim3(grid), dim3(NTHREADS), lds, s, g);
+        if (lp) MADTP_DISPATCH_CFG(bf16_t, true); else MADTP_DISPATCH_CFG(bf16_t, false);
     } else {
-        if (lp) hipLaunchKernelGGL((gemm_kernel<float, true>), dim3(grid), dim3(NTHREADS), lds, s, g);
-        else hipLaunchKernelGGL((gemm_kernel<float, false>), dim3(grid), dim3(NTHREADS), lds, s, g);
+        if (lp) MADTP_DISPATCH_CFG(float, true); else MADTP_DISPATCH_CFG(float, false);
+    }
+    if (g_prof_on) {
+        hipEventRecord(rec.e1, s);
+        g_prof.push_back(rec);
     }
     MADTP_LAUNCH_CHECK();
     return 0;

@@ -1,0 +1,288 @@
+// Layer-level entry points: one C call enqueues the whole kernel sequence of half a transformer layer, so the host
+// pays one FFI crossing instead of ~15-40 (the text encoder at B=64 x 20 tokens is launch-bound: its kernels run
+// for 3-15 us each, less than a Python-side launch costs).  Pure host code; every op is one of the kernels of this
+// library; nothing allocates - scratch comes from a caller-provided workspace whose size the *_workspace() queries
+// return.  The only host<->device round trip of a layer stays where the reference has it: the read-back of
+// k = max_b count between the two halves (vit.py:145 `.item()`).
+#include "common.h"
+
+namespace {
+
+struct Carver {
+    char* base; size_t off; size_t cap;
+    void* take(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+    bool fits() const { return !base || off <= cap; }
+};
+
+inline size_t esz_of(int dt) { return dt == MADTP_BF16 ? 2 : 4; }
+
+#define TRY(call)                  \
+    do {                           \
+        int rc__ = (call);         \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+inline int lin(const void* a, int lda, const madtp_lin& L, const float* residual, int ldr, void* c, int ldc, int M,
+               int dt, int c_dt, int act, float scale, void* stream) {
+    return madtp_gemm(a, L.w, L.b, residual, c, M, L.n, L.k, lda, L.k, ldc, ldr, dt, c_dt, act, scale, stream);
+}
+
+// LayerNorm into the compute dtype (and optionally an f32 copy)
+inline int ln_to(const float* x, const float* g, const float* b, float* y32, void* yc, int rows, int dim, float eps, int dt,
+                 void* stream) {
+    if (dt == MADTP_F32) return madtp_layernorm(x, g, b, (float*)yc, nullptr, rows, dim, eps, stream);  // yc doubles as y32
+    return madtp_layernorm(x, g, b, y32, yc, rows, dim, eps, stream);
+}
+
+struct VitWs {
+    void *h, *qkv, *o, *mid;
+    float *colsum, *p0, *onorm, *xp, *merge_w;
+    int32_t* dst_pos;
+    size_t bytes;
+};
+
+VitWs vit_carve(char* base, size_t cap, int B, int N, int dim, int hidden, int heads, int dt, bool* ok) {
+    Carver c{base, 0, cap};
+    const size_t M = (size_t)B * N, e = esz_of(dt);
+    VitWs w;
+    w.h = c.take(M * dim * e);
+    w.qkv = c.take(M * 3 * dim * e);
+    w.o = c.take(M * dim * e);
+    w.mid = c.take(M * hidden * e);
+    w.colsum = (float*)c.take((size_t)B * ((N + 15) / 16) * N * 4);
+    w.p0 = (float*)c.take((size_t)B * heads * N * 4);
+    w.onorm = (float*)c.take((size_t)B * heads * N * 4);
+    w.xp = (float*)c.take(M * dim * 4);
+    w.merge_w = (float*)c.take((size_t)B * N * 4);
+    w.dst_pos = (int32_t*)c.take((size_t)B * N * 4);
+    w.bytes = c.off;
+    *ok = c.fits();
+    return w;
+}
+
+struct BertWs {
+    void *hc, *qkv, *ctx, *q, *kv, *c0, *c1, *cat, *mid, *attc;
+    float *t, *xp, *s, *att2, *merge_w, *colsum, *p0, *onorm;
+    int32_t* dst_pos;
+    size_t bytes;
+};
+
+BertWs bert_carve(char* base, size_t cap, int B, int L, int Nk, int dim, int hidden, int heads, int dt, bool* ok) {
+    Carver c{base, 0, cap};
+    const size_t M = (size_t)B * L, MK = (size_t)B * (Nk > 0 ? Nk : 1), e = esz_of(dt);
+    BertWs w;
+    w.hc = c.take(M * dim * e);
+    w.qkv = c.take(M * 3 * dim * e);
+    w.ctx = c.take(M * dim * e);
+    w.q = c.take(M * dim * e);
+    w.kv = c.take(MK * 2 * dim * e);
+    w.c0 = c.take(M * dim * e);
+    w.c1 = c.take(M * dim * e);
+    w.cat = c.take(M * 2 * dim * e);
+    w.mid = c.take(M * hidden * e);
+    w.attc = c.take(M * dim * e);
+    w.t = (float*)c.take(M * dim * 4);
+    w.xp = (float*)c.take(M * dim * 4);
+    w.s = (float*)c.take(M * dim * 4);
+    w.att2 = (float*)c.take(M * dim * 4);
+    w.merge_w = (float*)c.take((size_t)B * L * 4);
+    w.colsum = (float*)c.take((size_t)B * ((L + 15) / 16) * L * 4);
+    w.p0 = (float*)c.take((size_t)B * heads * L * 4);
+    w.onorm = (float*)c.take((size_t)B * heads * L * 4);
+    w.dst_pos = (int32_t*)c.take((size_t)B * L * 4);
+    w.bytes = c.off;
+    *ok = c.fits();
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t madtp_vit_block_workspace(int B, int N, int dim, int hidden, int heads, int dtype) {
+    bool ok;
+    return vit_carve(nullptr, 0, B, N, dim, hidden, heads, dtype, &ok).bytes;
+}
+
+// x = x + proj(attention(qkv(LN1(x))))  [+ importance score / threshold / count / kmax when temperature > 0]
+extern "C" int madtp_vit_block_attn(const madtp_vit_block_w* w, const float* x, float* x_out, void* ws, size_t ws_bytes,
+                                    int B, int N, const float* token_attn, int ldt_row, int ldt_batch, int K,
+                                    float temperature, float* score, float* threshold, int32_t* count, int32_t* kmax,
+                                    void* stream) {
+    if (!w || !x || !x_out || !ws || B <= 0 || N <= 0) return MADTP_E_BADARG;
+    bool ok;
+    VitWs s = vit_carve((char*)ws, ws_bytes, B, N, w->dim, w->fc1.n, w->heads, w->dtype, &ok);
+    if (!ok) return MADTP_E_SHAPE;
+    const int M = B * N, D = w->dim, dt = w->dtype;
+    const size_t e = esz_of(dt);
+    const bool prune = temperature > 0.f;
+    if (prune && (!token_attn || !score || !threshold || !count || !kmax)) return MADTP_E_BADARG;
+    TRY(ln_to(x, w->ln1_g, w->ln1_b, nullptr, s.h, M, D, w->eps, dt, stream));
+    TRY(lin(s.h, D, w->qkv, nullptr, 0, s.qkv, 3 * D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+    const char* q = (const char*)s.qkv;
+    TRY(madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.o, nullptr, prune ? s.colsum : nullptr, s.p0, s.onorm,
+                        B, w->heads, N, N, 3 * D, 3 * D, 3 * D, D, w->scale, dt, stream));
+    TRY(lin(s.o, D, w->proj, x, D, x_out, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
+    if (prune) {
+        hipError_t he = hipMemsetAsync(kmax, 0, sizeof(int32_t), (hipStream_t)stream);
+        if (he != hipSuccess) return (int)he;
+        TRY(madtp_token_score(s.colsum, (N + 15) / 16, s.p0, s.onorm, token_attn, ldt_row, ldt_batch, K, temperature, score,
+                              threshold, count, kmax, B, w->heads, N, stream));
+    }
+    return 0;
+}
+
+// [select top-k, gather + merge] ; y = x' + fc2(GELU(fc1(LN2(x'))))    k == 0: no pruning (x' = x), y is [B,N,dim];
+// k > 0: y is [B,k+2,dim], indices [B,k], indices_sort [B,N-1] are written.
+extern "C" int madtp_vit_block_mlp(const madtp_vit_block_w* w, const float* x, float* y, void* ws, size_t ws_bytes, int B,
+                                   int N, int k, const float* score, int64_t* indices, int64_t* indices_sort, void* stream) {
+    if (!w || !x || !y || !ws || B <= 0 || N <= 0 || k < 0) return MADTP_E_BADARG;
+    bool ok;
+    VitWs s = vit_carve((char*)ws, ws_bytes, B, N, w->dim, w->fc1.n, w->heads, w->dtype, &ok);
+    if (!ok) return MADTP_E_SHAPE;
+    const int D = w->dim, dt = w->dtype;
+    const float* xr = x;
+    int Np = N;
+    if (k > 0) {
+        if (!score || !indices || !indices_sort) return MADTP_E_BADARG;
+        TRY(madtp_token_select(score, k, indices, indices_sort, s.dst_pos, s.merge_w, B, N - 1, stream));
+        TRY(madtp_token_gather(x, s.dst_pos, s.merge_w, s.xp, B, N, k, D, stream));
+        xr = s.xp;
+        Np = k + 2;
+    }
+    const int M = B * Np;
+    TRY(ln_to(xr, w->ln2_g, w->ln2_b, nullptr, s.h, M, D, w->eps, dt, stream));
+    TRY(lin(s.h, D, w->fc1, nullptr, 0, s.mid, w->fc1.n, M, dt, dt, MADTP_ACT_GELU_ERF, 1.f, stream));
+    TRY(lin(s.mid, w->fc1.n, w->fc2, xr, D, y, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
+    return 0;
+}
+
+// Query_model (models/utils.py:147-183) on the token buffer in place: logits of ALL rows of x (the CLS row is computed
+// and ignored) with the exact-f32 MFMA, then att_ft over the patch rows.
+extern "C" int madtp_query_model(const float* x, const void* sd_w, int K, float* token_attn_full, float* att_ft,
+                                 int accumulate, float inv_sqrt_sd, int B, int N, int dim, void* stream) {
+    if (!x || !sd_w || !token_attn_full || B <= 0 || N < 2) return MADTP_E_BADARG;
+    const int kp = (K + 127) / 128 * 128;
+    TRY(madtp_gemm(x, sd_w, nullptr, nullptr, token_attn_full, B * N, kp, dim, dim, dim, kp, 0, MADTP_F32, MADTP_F32,
+                   MADTP_ACT_NONE, 1.f, stream));
+    if (att_ft)
+        TRY(madtp_query_att_ft(token_attn_full + kp, kp, N * kp, K, x + dim, dim, N * dim, att_ft, inv_sqrt_sd, accumulate, B,
+                               N - 1, dim, stream));
+    return 0;
+}
+
+extern "C" size_t madtp_bert_layer_workspace(int B, int L, int Nk, int dim, int hidden, int heads, int dtype) {
+    bool ok;
+    return bert_carve(nullptr, 0, B, L, Nk, dim, hidden, heads, dtype, &ok).bytes;
+}
+
+// att = LayerNorm(dense(self_attention(hidden)) + hidden)   [+ score/threshold/count/kmax when temperature > 0]
+extern "C" int madtp_bert_layer_attn(const madtp_bert_layer_w* w, const float* hidden, const float* mask2d, float* att,
+                                     void* ws, size_t ws_bytes, int B, int L, int Nk, const float* token_attn, int ldt_row,
+                                     int ldt_batch, int K, float temperature, float* score, float* threshold, int32_t* count,
+                                     int32_t* kmax, void* stream) {
+    if (!w || !hidden || !att || !ws || B <= 0 || L <= 0) return MADTP_E_BADARG;
+    bool ok;
+    BertWs s = bert_carve((char*)ws, ws_bytes, B, L, Nk, w->dim, w->inter.n, w->heads, w->dtype, &ok);
+    if (!ok) return MADTP_E_SHAPE;
+    const int M = B * L, D = w->dim, dt = w->dtype;
+    const size_t e = esz_of(dt);
+    const bool prune = temperature > 0.f;
+    if (prune && (!token_attn || !score || !threshold || !count || !kmax || !mask2d)) return MADTP_E_BADARG;
+    const void* hc = hidden;
+    if (dt == MADTP_BF16) {
+        TRY(madtp_cast_bf16(hidden, s.hc, (size_t)M * D, stream));
+        hc = s.hc;
+    }
+    TRY(lin(hc, D, w->qkv, nullptr, 0, s.qkv, 3 * D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+    const char* q = (const char*)s.qkv;
+    TRY(madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.ctx, mask2d, prune ? s.colsum : nullptr, s.p0, s.onorm,
+                        B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale, dt, stream));
+    TRY(lin(s.ctx, D, w->attn_out, hidden, D, s.t, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
+    TRY(madtp_layernorm(s.t, w->ln_att_g, w->ln_att_b, att, nullptr, M, D, w->eps, stream));
+    if (prune) {
+        hipError_t he = hipMemsetAsync(kmax, 0, sizeof(int32_t), (hipStream_t)stream);
+        if (he != hipSuccess) return (int)he;
+        TRY(madtp_token_score(s.colsum, (L + 15) / 16, s.p0, s.onorm, token_attn, ldt_row, ldt_batch, K, temperature, score,
+                              threshold, count, kmax, B, w->heads, L, stream));
+    }
+    return 0;
+}
+
+// [prune att + mask] ; [cross-attention to the image tokens] ; y = LayerNorm(output(GELU(intermediate(a))) + a)
+// cross_mode: 0 = text mode (no cross-attention), otherwise w->cross selects single (MED) or twin (NLVR).
+// enc0/enc1: image tokens [B*Nk, dim] in the compute dtype; enc_mask0/1: additive f32 [B,Nk] or NULL.
+extern "C" int madtp_bert_layer_rest(const madtp_bert_layer_w* w, const float* att, const float* mask2d, float* y,
+                                     float* mask_out, void* ws, size_t ws_bytes, int B, int L, int k, const float* score,
+                                     int64_t* indices, int64_t* indices_sort, int cross_mode, const void* enc0,
+                                     const void* enc1, int Nk, const float* enc_mask0, const float* enc_mask1, void* stream) {
+    if (!w || !att || !y || !ws || B <= 0 || L <= 0 || k < 0) return MADTP_E_BADARG;
+    bool ok;
+    BertWs s = bert_carve((char*)ws, ws_bytes, B, L, Nk, w->dim, w->inter.n, w->heads, w->dtype, &ok);
+    if (!ok) return MADTP_E_SHAPE;
+    const int D = w->dim, dt = w->dtype;
+    const size_t e = esz_of(dt);
+    const float* a32 = att;
+    const float* m2 = mask2d;
+    int Lp = L;
+    if (k > 0) {
+        if (!score || !indices || !indices_sort) return MADTP_E_BADARG;
+        TRY(madtp_token_select(score, k, indices, indices_sort, s.dst_pos, s.merge_w, B, L - 1, stream));
+        TRY(madtp_token_gather(att, s.dst_pos, s.merge_w, s.xp, B, L, k, D, stream));
+        if (mask2d) {
+            if (!mask_out) return MADTP_E_BADARG;
+            if (w->variant_nlvr) TRY(madtp_mask_gather(mask2d, indices_sort, L - 1, nullptr, 0, mask_out, B, L, k, stream));
+            else TRY(madtp_mask_gather(mask2d, indices, k, indices_sort, L - 1, mask_out, B, L, k, stream));
+            m2 = mask_out;
+        }
+        a32 = s.xp;
+        Lp = k + 2;
+    }
+    (void)m2;  // the text-side padding mask only feeds the NEXT layer's self-attention
+    const int M = B * Lp;
+    const void* ac = a32;
+    if (dt == MADTP_BF16) {
+        TRY(madtp_cast_bf16(a32, s.attc, (size_t)M * D, stream));
+        ac = s.attc;
+    }
+    if (cross_mode && w->cross) {
+        if (!enc0 || Nk <= 0) return MADTP_E_BADARG;
+        const int nbr = w->cross == 2 ? 2 : 1;
+        if (nbr == 2 && !enc1) return MADTP_E_BADARG;
+        void* cbuf[2] = {s.c0, s.c1};
+        for (int br = 0; br < nbr; ++br) {
+            const void* enc = br ? enc1 : enc0;
+            // med.py:197-199 drops the encoder mask in cross-attention; nlvr_encoder.py:196-198 applies it
+            const float* em = w->variant_nlvr ? (br ? enc_mask1 : enc_mask0) : nullptr;
+            TRY(lin(ac, D, w->cq[br], nullptr, 0, s.q, D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+            TRY(lin(enc, D, w->ckv[br], nullptr, 0, s.kv, 2 * D, B * Nk, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+            const char* kv = (const char*)s.kv;
+            TRY(madtp_attention(s.q, kv, kv + (size_t)D * e, cbuf[br], em, nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, D,
+                                2 * D, 2 * D, D, w->scale, dt, stream));
+        }
+        if (nbr == 2) {
+            if (w->has_merge) {  // nlvr_encoder.py:263-264
+                char* cat = (char*)s.cat;
+                TRY(lin(s.c0, D, w->cdense[0], nullptr, 0, cat, 2 * D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+                TRY(lin(s.c1, D, w->cdense[1], nullptr, 0, cat + (size_t)D * e, 2 * D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+                TRY(lin(s.cat, 2 * D, w->merge, a32, D, s.s, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
+            } else {  // :266 (h0+h1)/2 folded into the epilogues
+                TRY(lin(s.c0, D, w->cdense[0], a32, D, s.t, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 0.5f, stream));
+                TRY(lin(s.c1, D, w->cdense[1], s.t, D, s.s, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 0.5f, stream));
+            }
+        } else {
+            TRY(lin(s.c0, D, w->cdense[0], a32, D, s.s, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
+        }
+        TRY(madtp_layernorm(s.s, w->ln_cross_g, w->ln_cross_b, s.att2, dt == MADTP_BF16 ? s.attc : nullptr, M, D, w->eps,
+                            stream));
+        a32 = s.att2;
+        ac = dt == MADTP_BF16 ? (const void*)s.attc : (const void*)s.att2;
+    }
+    TRY(lin(ac, D, w->inter, nullptr, 0, s.mid, w->inter.n, M, dt, dt, MADTP_ACT_GELU_ERF, 1.f, stream));
+    TRY(lin(s.mid, w->inter.n, w->out, a32, D, s.t, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
+    TRY(madtp_layernorm(s.t, w->ln_out_g, w->ln_out_b, y, nullptr, M, D, w->eps, stream));
+    return 0;
+}

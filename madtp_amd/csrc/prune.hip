@@ -226,11 +226,19 @@ __global__ __launch_bounds__(256) void token_gather_kernel(const float* __restri
     }
 }
 
+// order2 == NULL: slot p takes mask[1+order[p]] for p in [0,k]            (NLVR: order = indices_sort)
+// order2 != NULL: slots p<k take mask[1+order[p]] (order = indices), slot k takes mask[1+order2[k]] (order2 =
+//                 indices_sort: the (k+1)-th ranked token, med.py:377,388-390)
 __global__ void mask_gather_kernel(const float* __restrict__ mask, const int64_t* __restrict__ order, int ld_order,
-                                   float* __restrict__ out, int N, int k) {
+                                   const int64_t* __restrict__ order2, int ld_order2, float* __restrict__ out, int N, int k) {
     const int b = blockIdx.x;
-    for (int p = threadIdx.x; p < k + 2; p += blockDim.x)
-        out[(size_t)b * (k + 2) + p] = p == 0 ? mask[(size_t)b * N] : mask[(size_t)b * N + 1 + order[(size_t)b * ld_order + p - 1]];
+    for (int p = threadIdx.x; p < k + 2; p += blockDim.x) {
+        float v;
+        if (p == 0) v = mask[(size_t)b * N];
+        else if (order2 && p - 1 == k) v = mask[(size_t)b * N + 1 + order2[(size_t)b * ld_order2 + k]];
+        else v = mask[(size_t)b * N + 1 + order[(size_t)b * ld_order + p - 1]];
+        out[(size_t)b * (k + 2) + p] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void vector_gather_kernel(const float* __restrict__ v, const int64_t* __restrict__ idx,
@@ -364,10 +372,12 @@ extern "C" int madtp_token_gather(const float* x, const int32_t* dst_pos, const 
     return 0;
 }
 
-extern "C" int madtp_mask_gather(const float* mask, const int64_t* order, int ld_order, float* out, int B, int N, int k,
-                                 void* stream) {
-    if (!mask || !order || !out || B <= 0 || N < 2 || k < 1 || k + 1 > ld_order) return MADTP_E_BADARG;
-    hipLaunchKernelGGL(mask_gather_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mask, order, ld_order, out, N, k);
+extern "C" int madtp_mask_gather(const float* mask, const int64_t* order, int ld_order, const int64_t* order2,
+                                 int ld_order2, float* out, int B, int N, int k, void* stream) {
+    if (!mask || !order || !out || B <= 0 || N < 2 || k < 1) return MADTP_E_BADARG;
+    if (order2 ? (k > ld_order || k + 1 > ld_order2) : (k + 1 > ld_order)) return MADTP_E_BADARG;
+    hipLaunchKernelGGL(mask_gather_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mask, order, ld_order, order2, ld_order2,
+                       out, N, k);
     MADTP_LAUNCH_CHECK();
     return 0;
 }

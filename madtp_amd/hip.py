@@ -20,6 +20,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
 _SIGS = {
     "madtp_abi_version": (c_int, []),
     "madtp_strerror": (ctypes.c_char_p, [c_int]),
+    "madtp_profile_begin": (c_int, []),
+    "madtp_profile_end": (c_int, [ctypes.c_char_p, c_int]),
     "madtp_gemm": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_int, c_int, c_int, c_float, c_void_p]),
     "madtp_layernorm": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p]),
     "madtp_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -30,13 +32,54 @@ _SIGS = {
                           + [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "madtp_token_select": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "madtp_token_gather": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
-    "madtp_mask_gather": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "madtp_mask_gather": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "madtp_query_att_ft": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_int,
                                    c_int, c_int, c_int, c_void_p]),
     "madtp_vector_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "madtp_vit_block_workspace": (c_size_t, [c_int] * 6),
+    "madtp_vit_block_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_int, c_int,
+                                     c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "madtp_vit_block_mlp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_void_p]),
+    "madtp_query_model": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int,
+                                  c_void_p]),
+    "madtp_bert_layer_workspace": (c_size_t, [c_int] * 7),
+    "madtp_bert_layer_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
+                                      c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
+    "madtp_bert_layer_rest": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
+                                      c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                      c_void_p, c_void_p]),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
 }
+
+
+
+class LinStruct(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("b", c_void_p), ("n", c_int), ("k", c_int)]
+
+
+class VitBlockW(ctypes.Structure):
+    _fields_ = [("ln1_g", c_void_p), ("ln1_b", c_void_p), ("ln2_g", c_void_p), ("ln2_b", c_void_p),
+                ("eps", c_float), ("scale", c_float),
+                ("qkv", LinStruct), ("proj", LinStruct), ("fc1", LinStruct), ("fc2", LinStruct),
+                ("heads", c_int), ("dim", c_int), ("dtype", c_int)]
+
+
+class BertLayerW(ctypes.Structure):
+    _fields_ = [("qkv", LinStruct), ("attn_out", LinStruct), ("ln_att_g", c_void_p), ("ln_att_b", c_void_p),
+                ("cross", c_int), ("variant_nlvr", c_int), ("has_merge", c_int),
+                ("cq", LinStruct * 2), ("ckv", LinStruct * 2), ("cdense", LinStruct * 2), ("merge", LinStruct),
+                ("ln_cross_g", c_void_p), ("ln_cross_b", c_void_p),
+                ("inter", LinStruct), ("out", LinStruct), ("ln_out_g", c_void_p), ("ln_out_b", c_void_p),
+                ("eps", c_float), ("scale", c_float), ("heads", c_int), ("dim", c_int), ("dtype", c_int)]
+
+
+def lin_struct(lin):
+    """runtime.Lin -> LinStruct (the Lin object must stay alive while the struct is in use)."""
+    return LinStruct(lin.w.data_ptr(), 0 if lin.b is None else lin.b.data_ptr(), lin.n, lin.w.shape[1])
+
 
 _lib = None
 
@@ -226,12 +269,13 @@ def token_gather(x, dst_pos, merge_w, k):
     return y
 
 
-def mask_gather(mask2d, order, k):
-    """mask2d f32 [B,N] additive; order int64 [B,>=k+1] -> [B,k+2]."""
+def mask_gather(mask2d, order, k, order2=None):
+    """mask2d f32 [B,N] additive; order int64 [B,>=k+1] (NLVR: indices_sort) or (MED) order=indices, order2=indices_sort."""
     _req(mask2d, torch.float32, "mask")
     B, N = mask2d.shape
     out = torch.empty((B, k + 2), device=mask2d.device, dtype=torch.float32)
-    _check(load().madtp_mask_gather(_p(mask2d), _p(order), order.stride(0), _p(out), B, N, k, _stream()),
+    _check(load().madtp_mask_gather(_p(mask2d), _p(order), order.stride(0), _p(order2),
+                                    order2.stride(0) if order2 is not None else 0, _p(out), B, N, k, _stream()),
            "madtp_mask_gather")
     return out
 
@@ -270,3 +314,124 @@ def vector_gather(vectors, indices):
     out = torch.empty((B, K, D), device=vectors.device, dtype=torch.float32)
     _check(load().madtp_vector_gather(_p(vectors), _p(indices), _p(out), B, L, K, D, _stream()), "madtp_vector_gather")
     return out
+
+
+# ---- layer-level calls --------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device (all kernels run in stream order, so layers can share it)."""
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def prune_outputs(B, n, device):
+    return (torch.empty((B, n), device=device, dtype=torch.float32), torch.empty((B,), device=device, dtype=torch.float32),
+            torch.empty((B,), device=device, dtype=torch.int32), torch.empty((1,), device=device, dtype=torch.int32))
+
+
+def vit_block_attn(wstruct, x, token_attn, temperature):
+    """x f32 [B,N,D] contiguous -> (x_attn, (score, thr, count, kmax) or None)."""
+    B, N, D = x.shape
+    lib = load()
+    nbytes = lib.madtp_vit_block_workspace(B, N, wstruct.dim, wstruct.fc1.n, wstruct.heads, wstruct.dtype)
+    ws = workspace(nbytes, x.device)
+    out = torch.empty_like(x)
+    if temperature > 0:
+        tp, ldr, ldb, K = _ta_view(token_attn)
+        po = prune_outputs(B, N - 1, x.device)
+        _check(lib.madtp_vit_block_attn(ctypes.byref(wstruct), _p(x), _p(out), _p(ws), ws.numel(), B, N, tp, ldr, ldb, K,
+                                        float(temperature), _p(po[0]), _p(po[1]), _p(po[2]), _p(po[3]), _stream()),
+               "madtp_vit_block_attn")
+        return out, po
+    _check(lib.madtp_vit_block_attn(ctypes.byref(wstruct), _p(x), _p(out), _p(ws), ws.numel(), B, N, 0, 0, 0, 0, 0.0, 0, 0,
+                                    0, 0, _stream()), "madtp_vit_block_attn")
+    return out, None
+
+
+def vit_block_mlp(wstruct, x, k, score):
+    B, N, D = x.shape
+    lib = load()
+    nbytes = lib.madtp_vit_block_workspace(B, N, wstruct.dim, wstruct.fc1.n, wstruct.heads, wstruct.dtype)
+    ws = workspace(nbytes, x.device)
+    if k > 0:
+        y = torch.empty((B, k + 2, D), device=x.device, dtype=torch.float32)
+        indices = torch.empty((B, k), device=x.device, dtype=torch.int64)
+        indices_sort = torch.empty((B, N - 1), device=x.device, dtype=torch.int64)
+    else:
+        y = torch.empty_like(x)
+        indices = indices_sort = None
+    _check(lib.madtp_vit_block_mlp(ctypes.byref(wstruct), _p(x), _p(y), _p(ws), ws.numel(), B, N, k, _p(score), _p(indices),
+                                   _p(indices_sort), _stream()), "madtp_vit_block_mlp")
+    return y, indices, indices_sort
+
+
+def query_model(x, sd_w, K, att_ft=None, want_att_ft=True, sd_dim=768):
+    """x f32 [B,N,D] contiguous -> (token_attn view [B,N-1,K], att_ft)."""
+    B, N, D = x.shape
+    kp = sd_w.shape[0]
+    full = torch.empty((B * N, kp), device=x.device, dtype=torch.float32)
+    acc = 1 if att_ft is not None else 0
+    if want_att_ft and att_ft is None:
+        att_ft = torch.empty((B, K, D), device=x.device, dtype=torch.float32)
+    _check(load().madtp_query_model(_p(x), _p(sd_w), K, _p(full), _p(att_ft) if want_att_ft else 0, acc, 1.0 / (sd_dim ** 0.5),
+                                    B, N, D, _stream()), "madtp_query_model")
+    return full.view(B, N, kp)[:, 1:, :K], att_ft
+
+
+def bert_layer_attn(wstruct, hidden, mask2d, token_attn, temperature, Nk):
+    B, L, D = hidden.shape
+    lib = load()
+    nbytes = lib.madtp_bert_layer_workspace(B, L, Nk, wstruct.dim, wstruct.inter.n, wstruct.heads, wstruct.dtype)
+    ws = workspace(nbytes, hidden.device)
+    att = torch.empty_like(hidden)
+    if temperature > 0:
+        tp, ldr, ldb, K = _ta_view(token_attn)
+        po = prune_outputs(B, L - 1, hidden.device)
+        _check(lib.madtp_bert_layer_attn(ctypes.byref(wstruct), _p(hidden), _p(mask2d), _p(att), _p(ws), ws.numel(), B, L, Nk,
+                                         tp, ldr, ldb, K, float(temperature), _p(po[0]), _p(po[1]), _p(po[2]), _p(po[3]),
+                                         _stream()), "madtp_bert_layer_attn")
+        return att, po
+    _check(lib.madtp_bert_layer_attn(ctypes.byref(wstruct), _p(hidden), _p(mask2d), _p(att), _p(ws), ws.numel(), B, L, Nk, 0,
+                                     0, 0, 0, 0.0, 0, 0, 0, 0, _stream()), "madtp_bert_layer_attn")
+    return att, None
+
+
+def bert_layer_rest(wstruct, att, mask2d, k, score, cross_mode, enc0, enc1, Nk, enc_mask0, enc_mask1):
+    B, L, D = att.shape
+    lib = load()
+    nbytes = lib.madtp_bert_layer_workspace(B, L, Nk, wstruct.dim, wstruct.inter.n, wstruct.heads, wstruct.dtype)
+    ws = workspace(nbytes, att.device)
+    Lp = k + 2 if k > 0 else L
+    y = torch.empty((B, Lp, D), device=att.device, dtype=torch.float32)
+    indices = indices_sort = mask_out = None
+    if k > 0:
+        indices = torch.empty((B, k), device=att.device, dtype=torch.int64)
+        indices_sort = torch.empty((B, L - 1), device=att.device, dtype=torch.int64)
+        if mask2d is not None:
+            mask_out = torch.empty((B, Lp), device=att.device, dtype=torch.float32)
+    _check(lib.madtp_bert_layer_rest(ctypes.byref(wstruct), _p(att), _p(mask2d), _p(y), _p(mask_out), _p(ws), ws.numel(), B, L,
+                                     k, _p(score), _p(indices), _p(indices_sort), int(cross_mode), _p(enc0), _p(enc1), Nk,
+                                     _p(enc_mask0), _p(enc_mask1), _stream()), "madtp_bert_layer_rest")
+    return y, mask_out, indices, indices_sort
+
+
+def profile_begin():
+    load().madtp_profile_begin()
+
+
+def profile_end():
+    """-> list of dicts(dtype, M, N, K, launches, ms, flops) for every GEMM shape launched since profile_begin()."""
+    buf = ctypes.create_string_buffer(1 << 20)
+    n = load().madtp_profile_end(buf, len(buf))
+    rows = []
+    for line in buf.raw[:n].decode().splitlines():
+        dt, M, N, K, c, ms, fl = line.split()
+        rows.append({"dtype": "bf16" if int(dt) == BF16 else "f32", "M": int(M), "N": int(N), "K": int(K),
+                     "launches": int(c), "ms": float(ms), "flops": float(fl)})
+    return rows

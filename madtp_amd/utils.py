@@ -73,9 +73,13 @@ class Query_model(nn.Module):
             rows = full_rows_of(ft)
             off = 1
             ftq = ft
-            if rows is None:
-                ftq = ft.float().contiguous()
-                rows, off = ftq.view(B * n, D), 0
+            if rows is not None:
+                # fast path: ft is x[:,1:,:] of a contiguous token buffer -> one C call (logits GEMM + att_ft)
+                token_att, att_ft = hip.query_model(rows.view(B, n + 1, D), sdl.w, K, att_ft=acc_ft,
+                                                    want_att_ft=self.compute_att_ft, sd_dim=self.att_dim)
+                return token_att, (att_ft if self.compute_att_ft else acc_ft), sd
+            ftq = ft.float().contiguous()
+            rows, off = ftq.view(B * n, D), 0
         kp = sdl.w.shape[0]
         full = hip.gemm(rows, sdl.w, n=kp)  # [rows, 128], zero weight rows beyond K
         token_att = full.view(B, n + off, kp)[:, off:, :K]

@@ -123,6 +123,7 @@ class Block(nn.Module):
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
         self.last_prune = None  # dict(k, indices, indices_sort, score, threshold, count) of the last forward
+        self._cache = PreparedCache()
 
     def _ln(self, norm, x2d):
         bf = compute_dtype() == torch.bfloat16
@@ -145,6 +146,26 @@ class Block(nn.Module):
         info.update(pruned=True, indices=indices, indices_sort=indices_sort)
         return hip.token_gather(x, dst_pos, merge_w, k)
 
+    def _weights(self):
+        """madtp_vit_block_w for the layer-level C entry points (rebuilt when a parameter or the precision changes)."""
+        params = [self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.attn.qkv.weight,
+                  self.attn.qkv.bias, self.attn.proj.weight, self.attn.proj.bias, self.mlp.fc1.weight, self.mlp.fc1.bias,
+                  self.mlp.fc2.weight, self.mlp.fc2.bias]
+
+        def build():
+            lins = [lin_of(self.attn._cache, "qkv", [self.attn.qkv]), lin_of(self.attn._cache, "proj", [self.attn.proj]),
+                    lin_of(self.mlp._cache, "fc1", [self.mlp.fc1]), lin_of(self.mlp._cache, "fc2", [self.mlp.fc2])]
+            w = hip.VitBlockW()
+            w.ln1_g, w.ln1_b = self.norm1.weight.data_ptr(), self.norm1.bias.data_ptr()
+            w.ln2_g, w.ln2_b = self.norm2.weight.data_ptr(), self.norm2.bias.data_ptr()
+            w.eps, w.scale = self.norm1.eps, self.attn.scale
+            w.qkv, w.proj, w.fc1, w.fc2 = [hip.lin_struct(l) for l in lins]
+            w.heads, w.dim = self.attn.num_heads, self.attn.dim
+            w.dtype = hip.F32 if compute_dtype() == torch.float32 else hip.BF16
+            return (w, lins)  # keep the prepared tensors alive next to the raw pointers
+
+        return self._cache.get("w", params, build)[0]
+
     def forward(self, x, register_hook=False, reduce_num=0, temperature=0, token_attn=None):
         require_gpu(x, "x")
         if register_hook:
@@ -154,17 +175,23 @@ class Block(nn.Module):
         prune = temperature > 0
         if prune and token_attn is None:
             raise ValueError("temperature > 0 requires token_attn (the reference fails in Reduce_token as well)")
-        x2 = x.view(B * N, D)
-        # x = x + attn(norm1(x))   vit.py:186
-        x2 = self.attn.run(self._ln(self.norm1, x2), B, N, residual2d=x2, want_scores=prune)
-        x = x2.view(B, N, D)
+        w = self._weights()
+        # x = x + attn(norm1(x)) and the importance score / threshold / survivor count   vit.py:186-190,125-145
+        x_attn, po = hip.vit_block_attn(w, x, token_attn, temperature if prune else 0)
         self.last_prune = None
-        if prune:  # vit.py:193-202
-            x = self.Reduce_token(x, reduce_num, temperature, token_attn=token_attn)
-            B, N, D = x.shape
-            x2 = x.view(B * N, D)
-        # x = x + mlp(norm2(x))   vit.py:205
-        return self.mlp.run(self._ln(self.norm2, x2), residual2d=x2).view(B, N, D)
+        k_use, score = 0, None
+        if prune:
+            score, thr, count, kmax = po
+            k = int(kmax.item())  # topk_num = max_b count: one host sync per layer, as vit.py:145
+            self.last_prune = {"k": k, "score": score, "threshold": thr, "count": count, "pruned": False,
+                               "indices": None, "indices_sort": None}
+            if not (k < 1 or (N - 1 - k) <= 1):  # vit.py:148-149
+                k_use = k
+        # [top-k, gather, merge] and x = x + mlp(norm2(x))   vit.py:153-161,195-205
+        y, indices, indices_sort = hip.vit_block_mlp(w, x_attn, k_use, score)
+        if k_use:
+            self.last_prune.update(pruned=True, indices=indices, indices_sort=indices_sort)
+        return y
 
 
 class PatchEmbed(nn.Module):

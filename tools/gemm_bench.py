@@ -7,9 +7,12 @@ from madtp_amd import hip
 hip.load()
 shapes = [(25216, 2304, 768), (25216, 768, 768), (25216, 3072, 768), (25216, 768, 3072),
           (10496, 2304, 768), (10496, 768, 768), (10496, 3072, 768), (10496, 768, 3072),
-          (5248, 1536, 768), (1280, 2304, 768), (1280, 768, 768), (8192, 8192, 8192), (4096, 4096, 4096)]
+          (5120, 1536, 768), (1280, 2304, 768), (1280, 768, 768), (1280, 3072, 768), (1280, 768, 3072), (1280, 768, 1536),
+          (1280, 128, 768), (10496, 128, 768), (4096, 4096, 4096)]
+if len(sys.argv) > 2 and sys.argv[2] == "small":
+    shapes = [sh for sh in shapes if sh[0] <= 5120 or sh[1] == 128]
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
-print("dtype", dt, "MADTP_GEMM_DEBUG", os.environ.get("MADTP_GEMM_DEBUG"))
+print("dtype", dt, "MADTP_GEMM_DEBUG", os.environ.get("MADTP_GEMM_DEBUG"), "CFG", os.environ.get("MADTP_GEMM_CFG"))
 for M, N, K in shapes:
     if dt == torch.float32 and M * N * K > 4096**3: continue
     a = torch.randn(M, K, device="cuda").to(dt); w = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
