@@ -60,18 +60,13 @@ def main():
     ap.add_argument("--gemm-breakdown", action="store_true", help="per-shape GEMM time table on stderr")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from madtp_amd import dist as mdist
+    world, rank, local_rank = mdist.env_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", init_method="env://")  # "nccl" is RCCL on ROCm
-        dist = dist_mod
+    mdist.init("nccl")  # "nccl" is RCCL on ROCm; no-op for a single process
+    dist = torch.distributed if world > 1 else None
 
     from madtp_amd import build, harness, hip, runtime
     if rank == 0 or not os.path.exists(build.LIB):
@@ -116,10 +111,7 @@ def main():
             torch.cuda.synchronize()
             instr_elapsed = time.perf_counter() - t1
             prof_rows = hip.profile_end()
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = mdist.max_over_ranks(elapsed, device="cuda")
 
     images_per_step = 2 * args.batch * world
     value = images_per_step * args.steps / elapsed

@@ -1,0 +1,76 @@
+"""Data-parallel helpers: one process per GPU, batch sharded, weights replicated, no collective
+inside the forward.  RCCL ("nccl" backend on ROCm) / gloo (CPU tests) is used only for barriers and for reducing
+timing / metric scalars, exactly as the reference's eval loops do (utils.py:48-59, compress_nlvr_dtp.py:128-136)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment; returns (world, rank, local_rank)."""
+    world, rank, local_rank = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend=backend, init_method="env://")
+    return world, rank, local_rank
+
+
+def shard_range(n_samples, rank, world):
+    """Contiguous split of `n_samples` NLVR samples; each sample's two images stay on the same rank
+    (blip_nlvr.py:67 splits image_embeds by targets.size(0))."""
+    base, rem = divmod(n_samples, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_nlvr_batch(images, input_ids, attention_mask, rank, world):
+    """images [2B,...] (image0 batch then image1 batch), ids/mask [B,L] -> this rank's shard in the same layout."""
+    B = input_ids.shape[0]
+    lo, hi = shard_range(B, rank, world)
+    img = torch.cat([images[lo:hi], images[B + lo:B + hi]], dim=0)
+    return img, input_ids[lo:hi], attention_mask[lo:hi]
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    """MAX all-reduce of a python float (the elapsed time of the timed region)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(values, device="cpu"):
+    if not dist.is_initialized():
+        return [float(v) for v in values]
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.tolist()
+
+
+def gather_logits(logits):
+    """all_gather of per-rank logits [b_r,2] (variable b_r padded to the max) -> [B,2] on every rank."""
+    if not dist.is_initialized():
+        return logits
+    world = dist.get_world_size()
+    n = torch.tensor([logits.shape[0]], device=logits.device)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n)
+    m = int(max(int(x.item()) for x in ns))
+    pad = torch.zeros((m,) + tuple(logits.shape[1:]), dtype=logits.dtype, device=logits.device)
+    pad[: logits.shape[0]] = logits
+    outs = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    return torch.cat([o[: int(k.item())] for o, k in zip(outs, ns)], dim=0)

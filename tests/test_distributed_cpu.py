@@ -1,0 +1,83 @@
+"""N>1 data-parallel path on CPU: world_size-2 gloo.  Checks the sharding rule (pairs stay together, shards cover the
+batch), the barrier / MAX / SUM reductions bench.py relies on, and the multi-GPU parity rule of SURVEY.md 8(e):
+each shard's result equals the oracle run on that shard's samples (k = batch max couples samples only within a
+shard, so a sharded global batch is NOT expected to equal the unsharded batch)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from madtp_amd import dist as mdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from madtp_amd import specs, synth
+    from oracle import madtp_oracle as O
+    w, r, _ = mdist.init("gloo")
+    assert (w, r) == (world, rank)
+    B, T = 3, 6.0  # odd batch: ranks get 2 and 1 samples
+    images = synth.synth_images(2 * B, 224, 7)
+    ids = synth.synth_token_ids(B, 12, 7)
+    att = torch.ones_like(ids)
+    img_s, ids_s, att_s = mdist.shard_nlvr_batch(images, ids, att, rank, world)
+    lo, hi = mdist.shard_range(B, rank, world)
+    assert img_s.shape[0] == 2 * (hi - lo) and torch.equal(img_s[: hi - lo], images[lo:hi])
+    assert torch.equal(img_s[hi - lo:], images[B + lo:B + hi])
+    W = specs.synth_weights(specs.blip_nlvr_shapes(224), 0)
+    with torch.no_grad():
+        logits = O.blip_nlvr_forward(W, img_s, ids_s, att_s, T)
+    mdist.barrier()
+    allv = mdist.gather_logits(logits)
+    assert allv.shape == (B, 2)
+    t = mdist.max_over_ranks(1.0 + rank)
+    assert t == float(world)
+    assert mdist.sum_over_ranks([hi - lo, 1.0]) == [float(B), float(world)]
+    torch.save({"logits": logits, "all": allv, "range": (lo, hi)}, os.path.join(out_dir, f"r{rank}.pt"))
+    mdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_range_covers_batch():
+    for n in (1, 2, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [mdist.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(600)
+def test_world2_gloo_sharded_forward_matches_per_shard_oracle(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    # every rank saw the same gathered logits, in global sample order
+    assert torch.equal(res[0]["all"], res[1]["all"])
+    assert torch.equal(res[0]["all"], torch.cat([res[0]["logits"], res[1]["logits"]]))
+    # per-shard parity: re-run each shard standalone in this process
+    from madtp_amd import specs, synth
+    from oracle import madtp_oracle as O
+    images = synth.synth_images(6, 224, 7)
+    ids = synth.synth_token_ids(3, 12, 7)
+    W = specs.synth_weights(specs.blip_nlvr_shapes(224), 0)
+    for r in range(world):
+        lo, hi = res[r]["range"]
+        img = torch.cat([images[lo:hi], images[3 + lo:3 + hi]])
+        with torch.no_grad():
+            ref = O.blip_nlvr_forward(W, img, ids[lo:hi], torch.ones_like(ids[lo:hi]), 6.0)
+        assert (ref - res[r]["logits"]).abs().max().item() < 1e-5
