@@ -127,8 +127,13 @@ int madtp_mask_gather(const float* mask, const int64_t* order, int ld_order, con
  * x[:,1:,:] of a [B,N,dim] tensor is passed without a copy); n patch tokens; out f32 [B,K,dim] contiguous;
  * accumulate!=0 adds into out (sd_img_ft_all += sd_img_ft, vit.py:300-303). */
 int madtp_query_att_ft(const float* token_attn, int ldt_row, int ldt_batch, int K, const float* ft, int ldf_row,
-                       int ldf_batch, float* out, float inv_sqrt_sd, int accumulate, int B, int n, int dim,
-                       void* stream);
+                       int ldf_batch, float* out, float inv_sqrt_sd, int accumulate, int B, int n, int dim, int fast,
+                       void* stream);  /* fast != 0: bf16-MFMA variant (fast mode); 0: exact-f32 MFMA */
+
+/* Fast-mode alignment logits out[M,128] = x[M,dim] @ sd^T with sd given as a bf16 hi/lo split ([128,dim] each, rows
+ * beyond the dictionary size zero): x is split in registers and xh.sh + xl.sh + xh.sl runs on the bf16 MFMA
+ * (~2^-16 relative error instead of bf16's 2^-9).  models/utils.py:170. */
+int madtp_align_logits(const float* x, const void* sd_hi, const void* sd_lo, float* out, int M, int dim, void* stream);
 
 /* vector_gather (models/utils.py:13-33): out[b,k,:] = vectors[b, indices[b,k], :]; f32 [B,L,D], int64 [B,K]. */
 int madtp_vector_gather(const float* vectors, const int64_t* indices, float* out, int B, int L, int K, int D,
@@ -177,8 +182,9 @@ int madtp_vit_block_mlp(const madtp_vit_block_w* w, const float* x, float* y, vo
 /* Query_model.forward(return_token_att=True) (models/utils.py:147-183) over a contiguous token buffer x[B,N,dim]:
  * token_attn_full[B*N, 128] = x @ sd^T (exact-f32 MFMA; sd_w is f32 [128,dim], rows >= K zero); row b*N+1+t is patch t.
  * att_ft[B,K,dim] (+)= softmax_t(logits/sqrt(sd_dim)) @ x[:,1:]  (skipped when att_ft is NULL). */
-int madtp_query_model(const float* x, const void* sd_w, int K, float* token_attn_full, float* att_ft, int accumulate,
-                      float inv_sqrt_sd, int B, int N, int dim, void* stream);
+int madtp_query_model(const float* x, const void* sd_w, const void* sd_hi, const void* sd_lo, int K,
+                      float* token_attn_full, float* att_ft, int accumulate, float inv_sqrt_sd, int B, int N, int dim,
+                      void* stream);  /* sd_hi/sd_lo != NULL selects the fast-mode kernels (bf16x3 logits, bf16 att_ft) */
 
 /* models/med.py BertLayer (:332-467) / models/nlvr_encoder.py BertLayer (:385-559) */
 typedef struct madtp_bert_layer_w {

@@ -207,20 +207,21 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 // (v_mfma_f32_16x16x32_bf16, f32 accumulate); softmax and all score reductions stay f32.
 //   * K_h is DMA'd into LDS as 128-byte rows with the 16-B chunk index XOR (row&7) (swizzle on the source address),
 //     so the K fragment reads (ds_read_b128) are conflict-free.
-//   * The P.V product needs V with the KEY index contiguous per lane, so V_h is transposed while it is staged:
-//     Vt[d][j] (pitch NKP+8).  The k-slot <-> key mapping of the MFMA is a free permutation; with
-//     key(chunk c, group g, slot e) = 32c + 16(e>>2) + 4g + (e&3) the A operand is exactly the lane's own eight
-//     probabilities (tiles 2c and 2c+1) - no cross-lane traffic - and the B operand is two 8-byte reads of Vt.
+//   * The P.V product needs V with the KEY index running along the MFMA k slots.  V_h is staged ROW-major (128-byte
+//     rows, LDS-DMA like K) and the B operand is fetched with the hardware transpose read ds_read_b64_tr_b16
+//     (4 keys x 16 columns per 16 lanes).
+//     The k-slot <-> key mapping of the MFMA is a free permutation; with key(chunk c, group g, slot e) =
+//     32c + 16(e>>2) + 4g + (e&3) the A operand is exactly the lane's own eight probabilities (tiles 2c, 2c+1) -
+//     no cross-lane traffic - and the B operand is two transpose reads (keys 32c+4g.. and 32c+16+4g..).
 //   * exp via v_exp_f32 (__expf) and one reciprocal per row: this is the fast mode; the f32 kernel above keeps
 //     expf/division for the parity mode.
 template <int NT, bool SCORES>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnArgs a) {
     constexpr int NKP = NT * 16;
     constexpr int NC = (NT + 1) / 2;          // 32-key chunks
-    constexpr int VP = NC * 32 + 8;           // Vt pitch in elements
+    constexpr int VR = NC * 32;               // staged V rows (whole chunks)
+    constexpr int STAGE = (NKP + VR) * 128;   // bytes per head: K image then V image, 128-byte rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;                          // [NKP][128 B], swizzled
-    bf16_t* Vt = (bf16_t*)(smem + NKP * 128); // [64][VP]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -236,30 +237,33 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) pmax[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    // zero the padded key columns of Vt once (keys >= Nk contribute 0 * 0)
-    for (int idx = tid; idx < 64 * (VP / 2); idx += 256) ((uint32_t*)Vt)[idx] = 0u;
 
-    for (int h = blockIdx.z; h < a.H; h += gridDim.z) {
-        __syncthreads();
-        // ---- K_h: LDS-DMA, 8 rows (1 KiB) per wave-instruction, inverse swizzle on the source ----
-        {
-            const int sub = lane >> 3, chunk = (lane & 7) ^ sub;
-            for (int grp = wave; grp < NKP / 8; grp += 4) {
-                int row = grp * 8 + sub;
-                row = row < a.Nk ? row : a.Nk - 1;  // rows >= Nk are masked to -inf below; any finite data will do
-                const char* src = a.k + (((size_t)b * a.Nk + row) * a.ldk + h * 64) * 2 + chunk * 16;
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(Ks + grp * 1024), 16, 0, 0);
-            }
+    // K_h and V_h are LDS-DMA'd (8 rows = 1 KiB per wave-instruction) into a 2-stage ring over the heads: the DMA of
+    // head h+1 is in flight while head h is computed.  Swizzles live on the SOURCE address (the DMA destination is
+    // lane-linear): K chunk ^= row&7 (conflict-free ds_read_b128 of 16 rows); V chunk ^= 2*((row>>1)&3), which puts
+    // the 8 key rows of a transpose read (ds_read_b64_tr_b16) on 8 disjoint bank octets.  Rows >= Nk are clamped
+    // to a valid row: their probabilities are exactly 0, so any finite data is fine.
+    const int sub = lane >> 3, pos = lane & 7;
+    auto stage_head = [&](int h, int st) {
+        char* base = smem + st * STAGE;
+        for (int grp = wave; grp < (NKP + VR) / 8; grp += 4) {
+            const bool is_v = grp >= NKP / 8;
+            int row = (is_v ? grp - NKP / 8 : grp) * 8 + sub;
+            const int chunk = is_v ? (pos ^ (((row >> 1) & 3) << 1)) : (pos ^ (row & 7));
+            row = row < a.Nk ? row : a.Nk - 1;
+            const char* src = is_v ? a.v + (((size_t)b * a.Nk + row) * a.ldv + h * 64) * 2 + chunk * 16
+                                   : a.k + (((size_t)b * a.Nk + row) * a.ldk + h * 64) * 2 + chunk * 16;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(base + grp * 1024), 16, 0, 0);
         }
-        // ---- V_h -> Vt[d][j] (transpose through 2-byte LDS writes) ----
-        for (int idx = tid; idx < a.Nk * 8; idx += 256) {
-            const int j = idx >> 3, c = idx & 7;
-            const bf16x8 vv = *(const bf16x8*)(a.v + (((size_t)b * a.Nk + j) * a.ldv + h * 64) * 2 + c * 16);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * VP + j] = (bf16_t)vv[e];
-        }
-        __syncthreads();
+    };
+    int st = 0;
+    stage_head(blockIdx.z, 0);
+    for (int h = blockIdx.z; h < a.H; h += gridDim.z, st ^= 1) {
+        __syncthreads();  // head h landed (the barrier drains the DMA); the other stage is free again
+        if (h + (int)gridDim.z < a.H) stage_head(h + gridDim.z, st ^ 1);
         if (!active) continue;
+        const char* Ks = smem + st * STAGE;
+        const char* Vs = Ks + NKP * 128;
 
         // ---- Q fragment (B operand): row i, k-slot group g <-> d = 32kk + 8g .. +7 ----
         bf16x8 q[2];
@@ -334,12 +338,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnArgs a) {
         for (int c = 0; c < NC; ++c) {
             const f32x4 hi = (2 * c + 1 < NT) ? sc[2 * c + 1 < NT ? 2 * c + 1 : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
             const bf16x8 pa = pack_bf16x8(sc[2 * c], hi);
+            // transpose read: lane 4r+q of the group addresses (key row r, columns 4q..4q+3), receives column l16.
+            // key rows of this lane group: 32c + 4g + r (first read) and +16 (second); both have the same (row>>1)&3.
+            const int vrow = 32 * c + 4 * g + (l16 >> 2);
+            const int vkey = ((vrow >> 1) & 3) << 1;
+            const char* vr = Vs + vrow * 128 + 8 * (l16 & 1);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const bf16_t* vr = Vt + (dt * 16 + l16) * VP + 32 * c + 4 * g;
-                const bf16x4 v0 = *(const bf16x4*)vr;
-                const bf16x4 v1 = *(const bf16x4*)(vr + 16);
-                const bf16x8 vb = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const int p = ((2 * dt + ((l16 & 3) >> 1)) ^ vkey) << 4;
+                const bf16x8 vb = cat_bf16x4(lds_read_tr16(vr + p), lds_read_tr16(vr + 16 * 128 + p));
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[dt], 0, 0, 0);
             }
         }
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnArgs a) {
 template <int NT, bool SCORES>
 int launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     constexpr int NC = (NT + 1) / 2;
-    const size_t lds = (size_t)NT * 16 * 128 + (size_t)64 * (NC * 32 + 8) * 2;
+    const size_t lds = (size_t)2 * (NT * 16 + NC * 32) * 128;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_bf16_kernel<NT, SCORES>,

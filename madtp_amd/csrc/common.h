@@ -32,6 +32,14 @@ __device__ __forceinline__ bf16x4 pack_bf16x4(f32x4 v) {
     return __builtin_bit_cast(bf16x4, __builtin_convertvector(v, hwbf16x4));
 }
 
+// ds_read_b64_tr_b16: within each 16-lane group, lane 4r+q supplies the LDS address of the 8-byte piece (row r, columns
+// 4q..4q+3) of a 4x16 bf16 block and lane i receives column i of that block (rows 0..3) - verified on MI355X with
+// tools/probes/probe_tr.hip.  It turns a ROW-major LDS image into MFMA operands whose k index runs along the rows.
+__device__ __forceinline__ bf16x4 lds_read_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
+}
+__device__ __forceinline__ bf16x8 cat_bf16x4(bf16x4 a, bf16x4 b) { return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }

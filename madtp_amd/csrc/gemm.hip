@@ -215,23 +215,29 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
     // is synchronised with a COUNTED s_waitcnt vmcnt + raw s_barrier (a __syncthreads() would drain every DMA).
     const int my_slots = (nslots - lb + gl - 1) / gl;
     const long total_slabs = (long)my_slots * nk;
-    int is_slot = slot, is_kt = 0;  // coordinates of the next slab to issue
+    int is_slot = slot, is_kt = 0, is_stage = 0;  // coordinates / ring stage of the next slab to issue
+    int im0 = ((is_slot / g.ntn) * 8 + xcd) * BM, in0 = (is_slot % g.ntn) * BN;
     long issued = 0;
     auto issue_next = [&]() {
         if (issued < total_slabs && !(g.dbg & 2)) {
-            char* st = smem + (int)(issued % STAGES) * STAGE_BYTES;
-            const int im0 = ((is_slot / g.ntn) * 8 + xcd) * BM, in0 = (is_slot % g.ntn) * BN;
+            char* st = smem + is_stage * STAGE_BYTES;
             stage_tile<ESZ, BM>(g.A, im0, g.M - 1, g.lda, is_kt * ROWB, st, wave, lane);
             stage_tile<ESZ, BN>(g.W, in0, n_pad_max, g.ldw, is_kt * ROWB, st + A_BYTES, wave, lane);
         }
         ++issued;  // phantom slabs past the end keep the wait counts uniform (they issue nothing: see tail wait)
-        if (++is_kt == nk) { is_kt = 0; is_slot += gl; }
+        if (++is_stage == STAGES) is_stage = 0;
+        if (++is_kt == nk) {
+            is_kt = 0;
+            is_slot += gl;
+            im0 = ((is_slot / g.ntn) * 8 + xcd) * BM; in0 = (is_slot % g.ntn) * BN;
+        }
     };
 #pragma unroll
     for (int p = 0; p < STAGES - 1; ++p) issue_next();
 
     int m0 = ((slot / g.ntn) * 8 + xcd) * BM, n0 = (slot % g.ntn) * BN;
     long s = 0;
+    int cur_stage = 0;
     while (true) {
         for (int kt = 0; kt < nk; ++kt, ++s) {
             // slab s must have landed: this wave's DMAs newer than slab s are those of slabs s+1 .. s+STAGES-2
@@ -239,8 +245,9 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
             else wait_vmcnt<0>();  // tail of the stream: fewer real slabs behind slab s
             __builtin_amdgcn_s_barrier();  // all waves' parts of slab s landed; stage (s-1)%STAGES is free again
             issue_next();                   // slab s+STAGES-1 -> stage (s-1)%STAGES
-            const char* sa = smem + (int)(s % STAGES) * STAGE_BYTES;
+            const char* sa = smem + cur_stage * STAGE_BYTES;
             const char* sw = sa + A_BYTES;
+            if (++cur_stage == STAGES) cur_stage = 0;
             if (g.dbg & 4) continue;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {

@@ -58,10 +58,13 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
         a_loc[u] = 0.f; c_loc[u] = 0.f;
         if (t < n) {
             float a = 0.f;
+#pragma unroll 4
             for (int r = 0; r < nrt; ++r) a += colsum[((size_t)b * nrt + r) * N + t + 1];
             float hs = 0.f;
+#pragma unroll 4
             for (int h = 0; h < H; ++h) hs += onorm[((size_t)b * H + h) * N + t + 1];
             float c = 0.f;
+#pragma unroll 4
             for (int h = 0; h < H; ++h) {
                 const size_t o = ((size_t)b * H + h) * N + t + 1;
                 c += p0[o] * (onorm[o] / (hs + 1e-8f));
@@ -90,22 +93,28 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     const int t0 = (n * slice) / 4, t1 = (n * (slice + 1)) / 4;
     const bool cval = col < K;
     float m = -INFINITY;
-    if (cval)
+    if (cval) {
+#pragma unroll 8
         for (int t = t0; t < t1; ++t) m = fmaxf(m, ta_b[(size_t)t * ldt + col] / temperature);
+    }
     colred[slice][col] = m;
     __syncthreads();
     m = fmaxf(fmaxf(colred[0][col], colred[1][col]), fmaxf(colred[2][col], colred[3][col]));
     __syncthreads();
     float se = 0.f;
-    if (cval)
+    if (cval) {
+#pragma unroll 8
         for (int t = t0; t < t1; ++t) se += expf(ta_b[(size_t)t * ldt + col] / temperature - m);
+    }
     colred[slice][col] = se;
     __syncthreads();
     const float sum = ((colred[0][col] + colred[1][col]) + colred[2][col]) + colred[3][col];
     __syncthreads();
     float sw = 0.f;
-    if (cval)
+    if (cval) {
+#pragma unroll 8
         for (int t = t0; t < t1; ++t) sw += (expf(ta_b[(size_t)t * ldt + col] / temperature - m) / sum) * I_s[t];
+    }
     colred[slice][col] = sw;
     __syncthreads();
     if (tid < 128) colstat[tid] = cval ? ((colred[0][col] + colred[1][col]) + colred[2][col]) + colred[3][col] : INFINITY;
@@ -275,15 +284,19 @@ __global__ __launch_bounds__(256) void query_att_ft_kernel(const float* __restri
         const int c = tid & 127, sl = tid >> 7;
         const int t0 = sl ? n / 2 : 0, t1 = sl ? n : n / 2;
         float m = -INFINITY;
-        if (c < K)
+        if (c < K) {
+#pragma unroll 8
             for (int t = t0; t < t1; ++t) m = fmaxf(m, ta_b[(size_t)t * ldt + c] * inv_sqrt_sd);
+        }
         part[sl][c] = m;
         __syncthreads();
         m = fmaxf(part[0][c], part[1][c]);
         __syncthreads();
         float s = 0.f;
-        if (c < K)
+        if (c < K) {
+#pragma unroll 8
             for (int t = t0; t < t1; ++t) s += expf(ta_b[(size_t)t * ldt + c] * inv_sqrt_sd - m);
+        }
         part[sl][c] = s;
         __syncthreads();
         if (tid < 128) { mx[tid] = m; sm[tid] = c < K ? part[0][c] + part[1][c] : 1.f; }
@@ -336,6 +349,189 @@ __global__ __launch_bounds__(256) void query_att_ft_kernel(const float* __restri
         }
 }
 
+// ----------------------------------------------------------------------------------------- query_att_ft (bf16 MFMA)
+// Fast-mode variant: same decomposition, but the product runs on v_mfma_f32_16x16x32_bf16.  Both operands need the
+// TOKEN index along the MFMA k slots while the data is token-major in memory, so per 64-token chunk the softmax
+// weights Wt[t][c] and the token rows Xs[t][d] are staged ROW-major as bf16 (coalesced reads, conflict-free 8-byte
+// LDS writes) and BOTH fragments are fetched with the hardware transpose read ds_read_b64_tr_b16.  Pitches 144 /
+// 272 elements put the 8 rows of a 32-lane access on disjoint bank octets.
+constexpr int AB_TCH = 64, AB_WP = 144, AB_XP = 272;
+__global__ __launch_bounds__(256, 2) void query_att_ft_bf16_kernel(const float* __restrict__ ta, int ldt, int ldb, int K,
+                                                                   const float* __restrict__ ft, int ldf, int ldfb,
+                                                                   float* __restrict__ out, float inv_sqrt_sd,
+                                                                   int accumulate, int n, int dim) {
+    __shared__ float mx[128], sm[128];
+    __shared__ float part[2][128];
+    __shared__ __attribute__((aligned(16))) bf16_t Wt[AB_TCH * AB_WP];
+    __shared__ __attribute__((aligned(16))) bf16_t Xs[AB_TCH * AB_XP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const float* ta_b = ta + (size_t)b * ldb;
+    {
+        const int c = tid & 127, sl = tid >> 7;
+        const int t0 = sl ? n / 2 : 0, t1 = sl ? n : n / 2;
+        float m = -INFINITY;
+        if (c < K) {
+#pragma unroll 8
+            for (int t = t0; t < t1; ++t) m = fmaxf(m, ta_b[(size_t)t * ldt + c] * inv_sqrt_sd);
+        }
+        part[sl][c] = m;
+        __syncthreads();
+        m = fmaxf(part[0][c], part[1][c]);
+        __syncthreads();
+        float s = 0.f;
+        if (c < K) {
+#pragma unroll 8
+            for (int t = t0; t < t1; ++t) s += __expf(ta_b[(size_t)t * ldt + c] * inv_sqrt_sd - m);
+        }
+        part[sl][c] = s;
+        __syncthreads();
+        if (tid < 128) { mx[tid] = m; sm[tid] = c < K ? 1.0f / (part[0][c] + part[1][c]) : 0.f; }
+        __syncthreads();
+    }
+    const int dblk = blockIdx.x * 256;
+    f32x4 acc[7][4];
+#pragma unroll
+    for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* xb = ft + (size_t)b * ldfb;
+    for (int tc = 0; tc < n; tc += AB_TCH) {
+        const int tn = min(AB_TCH, n - tc);
+        __syncthreads();
+        // weights Wt[t][c]: thread -> (t, 4 consecutive c): coalesced logits read, one 8-byte LDS write
+#pragma unroll 2
+        for (int idx = tid; idx < AB_TCH * 28; idx += 256) {
+            const int t = idx / 28, c4 = (idx % 28) * 4;
+            f32x4 w = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (t < tn) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c4 + e < K) w[e] = __expf(ta_b[(size_t)(tc + t) * ldt + c4 + e] * inv_sqrt_sd - mx[c4 + e]) * sm[c4 + e];
+            }
+            *(bf16x4*)(Wt + t * AB_WP + c4) = pack_bf16x4(w);
+        }
+        // token rows Xs[t][d]: thread -> (t, 4 consecutive d): coalesced float4 read, one 8-byte LDS write
+#pragma unroll 4
+        for (int idx = tid; idx < AB_TCH * 64; idx += 256) {
+            const int t = idx >> 6, d4 = (idx & 63) * 4;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (t < tn) v = *(const f32x4*)(xb + (size_t)(tc + t) * ldf + dblk + d4);
+            *(bf16x4*)(Xs + t * AB_XP + d4) = pack_bf16x4(v);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < AB_TCH / 32; ++ks) {
+            // lane 4r+q of a 16-lane group addresses (token row r, columns 4q..4q+3); k slots 8g..8g+7 = two reads
+            const int trow = ks * 32 + 8 * g + (l16 >> 2), cpart = 4 * (l16 & 3);
+            bf16x8 xf[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const bf16_t* p = Xs + trow * AB_XP + wave * 64 + nt * 16 + cpart;
+                xf[nt] = cat_bf16x4(lds_read_tr16(p), lds_read_tr16(p + 4 * AB_XP));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 7; ++mt) {
+                const bf16_t* p = Wt + trow * AB_WP + mt * 16 + cpart;
+                const bf16x8 wf = cat_bf16x4(lds_read_tr16(p), lds_read_tr16(p + 4 * AB_WP));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)  // operands swapped: lane (c = l16, g) ends up with 4 consecutive d
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[nt], wf, acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: D[row = d-fragment row 4g+r][col = c]: one float4 (read-modify-)write per (mt, nt)
+#pragma unroll
+    for (int mt = 0; mt < 7; ++mt) {
+        const int c = mt * 16 + l16;
+        if (c >= K) continue;
+        float* orow = out + ((size_t)b * K + c) * dim + dblk + wave * 64 + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4* o = (f32x4*)(orow + 16 * nt);
+            *o = accumulate ? *o + acc[mt][nt] : acc[mt][nt];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------- alignment logits (bf16 x 3)
+// token_attn = x @ sd^T for the fast mode: f32 accuracy class on the bf16 matrix cores via a two-term split
+// x = xh + xl, sd = sh + sl (bf16 each):  x.sd ~= xh.sh + xl.sh + xh.sl  (the dropped xl.sl term is 2^-16 relative).
+// x rows are read as f32 straight into registers and split there; the 128 dictionary rows (hi and lo slabs) are
+// LDS-DMA'd in 128-byte K slabs with the GEMM kernel's swizzle; workgroup = 64 token rows x 128 columns, one 16-row
+// MFMA fragment per wave, operand-swapped MFMA so each lane stores float4s.
+constexpr int AL_ROWB = 128, AL_TILE = 128 * AL_ROWB;
+__global__ __launch_bounds__(256, 2) void align_logits_kernel(const float* __restrict__ x, const char* __restrict__ sd_hi,
+                                                              const char* __restrict__ sd_lo, float* __restrict__ out, int M,
+                                                              int dim) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (hi tile, lo tile)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 64 + wave * 16;
+    const int row = min(m0 + l16, M - 1);
+    const float* xr = x + (size_t)row * dim;
+    const int nk = dim * 2 / AL_ROWB;
+    const int sub = lane >> 3, chunk_src = (lane & 7) ^ sub;
+    auto stage = [&](int kt, int st) {
+        char* base = smem + st * 2 * AL_TILE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int grp = wave * 4 + q;
+            const size_t src = ((size_t)(grp * 8 + sub) * dim) * 2 + (size_t)kt * AL_ROWB + chunk_src * 16;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(sd_hi + src), LDS_PTR(base + grp * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(sd_lo + src), LDS_PTR(base + AL_TILE + grp * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // this lane's x slice of the slab: k = 64kt + 32kk + 8g .. +7
+        f32x4 xa[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const float* p = xr + kt * 64 + kk * 32 + g * 8;
+            xa[kk][0] = *(const f32x4*)p;
+            xa[kk][1] = *(const f32x4*)(p + 4);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* sh = smem + (kt & 1) * 2 * AL_TILE;
+        const char* sl = sh + AL_TILE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 ah = pack_bf16x8(xa[kk][0], xa[kk][1]);
+            f32x4 r0, r1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r0[e] = xa[kk][0][e] - bf16_to_f32((bf16_t)ah[e]);
+                r1[e] = xa[kk][1][e] - bf16_to_f32((bf16_t)ah[4 + e]);
+            }
+            const bf16x8 al = pack_bf16x8(r0, r1);
+            const int chunk = kk * 4 + g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int rb = j * 16 + l16;
+                const int off = rb * AL_ROWB + ((chunk ^ (rb & 7)) << 4);
+                const bf16x8 bh = *(const bf16x8*)(sh + off);
+                const bf16x8 bl = *(const bf16x8*)(sl + off);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    if (m0 + l16 < M) {
+        float* o = out + (size_t)(m0 + l16) * 128 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(f32x4*)(o + 16 * j) = acc[j];
+    }
+}
+
 }  // namespace
 
 extern "C" int madtp_token_score(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
@@ -383,9 +579,17 @@ extern "C" int madtp_mask_gather(const float* mask, const int64_t* order, int ld
 }
 
 extern "C" int madtp_query_att_ft(const float* token_attn, int ldt, int ldb, int K, const float* x, int ldf, int ldfb,
-                                  float* out, float inv_sqrt_sd, int accumulate, int B, int n, int dim, void* stream) {
+                                  float* out, float inv_sqrt_sd, int accumulate, int B, int n, int dim, int fast,
+                                  void* stream) {
     if (!token_attn || !x || !out || B <= 0 || n < 1) return MADTP_E_BADARG;
     if (K <= 0 || K > 112 || dim % 256 || ldt < K) return MADTP_E_SHAPE;
+    if (fast) {
+        if (ldf % 4 || ldfb % 4 || !aligned16(x)) return MADTP_E_ALIGN;
+        hipLaunchKernelGGL(query_att_ft_bf16_kernel, dim3(dim / 256, B), dim3(256), 0, (hipStream_t)stream, token_attn, ldt,
+                           ldb, K, x, ldf, ldfb, out, inv_sqrt_sd, accumulate, n, dim);
+        MADTP_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(query_att_ft_kernel, dim3(dim / 256, B), dim3(256), 0, (hipStream_t)stream, token_attn, ldt, ldb, K, x,
                        ldf, ldfb, out, inv_sqrt_sd, accumulate, n, dim);
     MADTP_LAUNCH_CHECK();
@@ -400,6 +604,17 @@ extern "C" int madtp_vector_gather(const float* vectors, const int64_t* indices,
     const int rows = B * K;
     hipLaunchKernelGGL(vector_gather_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, vectors, indices, out, L,
                        K, D / 4, rows);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_align_logits(const float* x, const void* sd_hi, const void* sd_lo, float* out, int M, int dim,
+                                  void* stream) {
+    if (!x || !sd_hi || !sd_lo || !out || M <= 0) return MADTP_E_BADARG;
+    if (dim % 64) return MADTP_E_SHAPE;
+    if (!aligned16(x) || !aligned16(sd_hi) || !aligned16(sd_lo) || !aligned16(out)) return MADTP_E_ALIGN;
+    hipLaunchKernelGGL(align_logits_kernel, dim3((M + 63) / 64), dim3(256), 4 * AL_TILE, (hipStream_t)stream, x,
+                       (const char*)sd_hi, (const char*)sd_lo, out, M, dim);
     MADTP_LAUNCH_CHECK();
     return 0;
 }

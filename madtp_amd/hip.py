@@ -34,15 +34,16 @@ _SIGS = {
     "madtp_token_gather": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "madtp_mask_gather": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "madtp_query_att_ft": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_int,
-                                   c_int, c_int, c_int, c_void_p]),
+                                   c_int, c_int, c_int, c_int, c_void_p]),
+    "madtp_align_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "madtp_vector_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "madtp_vit_block_workspace": (c_size_t, [c_int] * 6),
     "madtp_vit_block_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_int, c_int,
                                      c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "madtp_vit_block_mlp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
-    "madtp_query_model": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int,
-                                  c_void_p]),
+    "madtp_query_model": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_int,
+                                  c_int, c_int, c_void_p]),
     "madtp_bert_layer_workspace": (c_size_t, [c_int] * 7),
     "madtp_bert_layer_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
                                       c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -280,8 +281,9 @@ def mask_gather(mask2d, order, k, order2=None):
     return out
 
 
-def query_att_ft(token_attn, ft, out=None, sd_dim=768):
-    """ft: [B,n,dim] f32 GPU view with unit column stride (e.g. x[:,1:,:]); token_attn [B,n,K] view."""
+def query_att_ft(token_attn, ft, out=None, sd_dim=768, fast=False):
+    """ft: [B,n,dim] f32 GPU view with unit column stride (e.g. x[:,1:,:]); token_attn [B,n,K] view.
+    fast: bf16-MFMA variant (fast mode)."""
     fp, ldf, ldfb, dim = _ta_view(ft)
     B, n = ft.shape[0], ft.shape[1]
     tp, ldr, ldb, K = _ta_view(token_attn)
@@ -290,7 +292,7 @@ def query_att_ft(token_attn, ft, out=None, sd_dim=768):
         out = torch.empty((B, K, dim), device=ft.device, dtype=torch.float32)
         acc = 0
     _check(load().madtp_query_att_ft(tp, ldr, ldb, K, fp, ldf, ldfb, _p(out), 1.0 / (sd_dim ** 0.5), acc,
-                                     B, n, dim, _stream()), "madtp_query_att_ft")
+                                     B, n, dim, 1 if fast else 0, _stream()), "madtp_query_att_ft")
     return out
 
 
@@ -371,16 +373,24 @@ def vit_block_mlp(wstruct, x, k, score):
     return y, indices, indices_sort
 
 
-def query_model(x, sd_w, K, att_ft=None, want_att_ft=True, sd_dim=768):
-    """x f32 [B,N,D] contiguous -> (token_attn view [B,N-1,K], att_ft)."""
+def align_logits(x2d, sd_hi, sd_lo):
+    M, D = x2d.shape
+    out = torch.empty((M, 128), device=x2d.device, dtype=torch.float32)
+    _check(load().madtp_align_logits(_p(x2d), _p(sd_hi), _p(sd_lo), _p(out), M, D, _stream()), "madtp_align_logits")
+    return out
+
+
+def query_model(x, sd_w, K, att_ft=None, want_att_ft=True, sd_dim=768, sd_split=None):
+    """x f32 [B,N,D] contiguous -> (token_attn view [B,N-1,K], att_ft).  sd_split=(hi,lo) bf16 selects fast mode."""
     B, N, D = x.shape
     kp = sd_w.shape[0]
     full = torch.empty((B * N, kp), device=x.device, dtype=torch.float32)
     acc = 1 if att_ft is not None else 0
     if want_att_ft and att_ft is None:
         att_ft = torch.empty((B, K, D), device=x.device, dtype=torch.float32)
-    _check(load().madtp_query_model(_p(x), _p(sd_w), K, _p(full), _p(att_ft) if want_att_ft else 0, acc, 1.0 / (sd_dim ** 0.5),
-                                    B, N, D, _stream()), "madtp_query_model")
+    hi, lo = sd_split if sd_split is not None else (None, None)
+    _check(load().madtp_query_model(_p(x), _p(sd_w), _p(hi), _p(lo), K, _p(full), _p(att_ft) if want_att_ft else 0, acc,
+                                    1.0 / (sd_dim ** 0.5), B, N, D, _stream()), "madtp_query_model")
     return full.view(B, N, kp)[:, 1:, :K], att_ft
 
 

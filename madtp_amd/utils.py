@@ -6,7 +6,7 @@ import torch
 from torch import nn
 
 from . import hip
-from .runtime import PreparedCache, prepare_linear, require_gpu
+from .runtime import PreparedCache, compute_dtype, prepare_linear, require_gpu
 
 
 def vector_gather(vectors, indices):
@@ -62,6 +62,14 @@ class Query_model(nn.Module):
         B, n, D = ft.shape
         K = sd.shape[0]
         sdl = self._cache.get(("sd", id(sd)), [sd], lambda: prepare_linear([sd], None, torch.float32))
+        split = None
+        if compute_dtype() == torch.bfloat16 and sdl.w.shape[0] == 128:
+            # fast mode: dictionary as a bf16 hi/lo pair for the split-precision logits kernel
+            def _split():
+                hi = hip.cast_bf16(sdl.w)
+                lo = hip.cast_bf16((sdl.w - hi.float()).contiguous())
+                return hi, lo
+            split = self._cache.get(("sd_split", id(sd)), [sd], _split)
         if self.map_func:
             qm = self._cache.get("qmap", [self.q_map[0].weight, self.q_map[0].bias],
                                  lambda: prepare_linear([self.q_map[0].weight], [self.q_map[0].bias], torch.float32))
@@ -76,7 +84,7 @@ class Query_model(nn.Module):
             if rows is not None:
                 # fast path: ft is x[:,1:,:] of a contiguous token buffer -> one C call (logits GEMM + att_ft)
                 token_att, att_ft = hip.query_model(rows.view(B, n + 1, D), sdl.w, K, att_ft=acc_ft,
-                                                    want_att_ft=self.compute_att_ft, sd_dim=self.att_dim)
+                                                    want_att_ft=self.compute_att_ft, sd_dim=self.att_dim, sd_split=split)
                 return token_att, (att_ft if self.compute_att_ft else acc_ft), sd
             ftq = ft.float().contiguous()
             rows, off = ftq.view(B * n, D), 0
@@ -85,5 +93,5 @@ class Query_model(nn.Module):
         token_att = full.view(B, n + off, kp)[:, off:, :K]
         att_ft = acc_ft
         if self.compute_att_ft:
-            att_ft = hip.query_att_ft(token_att, ftq, out=acc_ft, sd_dim=self.att_dim)
+            att_ft = hip.query_att_ft(token_att, ftq, out=acc_ft, sd_dim=self.att_dim, fast=split is not None)
         return token_att, att_ft, sd

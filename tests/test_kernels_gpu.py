@@ -251,6 +251,35 @@ def test_query_att_ft(hip):
     assert (out2.cpu() - 2 * ref).abs().max().item() < 4e-5 * max(1, ref.abs().max().item())
 
 
+def test_fast_mode_alignment_and_att_ft(hip):
+    """bf16x3 split-precision logits (~2^-16 relative) and the bf16-MFMA att_ft."""
+    B, N, D, K = 3, 150, 768, 100
+    x = _rand(B, N, D, seed=70)
+    sd = _rand(K, D, seed=71)
+    sdp = _pad128(sd).cuda()
+    hi = hip.cast_bf16(sdp)
+    lo = hip.cast_bf16((sdp - hi.float()).contiguous())
+    xd = x.cuda()
+    out = hip.align_logits(xd.view(B * N, D), hi, lo)
+    ref = (x.reshape(B * N, D).double() @ sd.double().t()).float()
+    err = (out.cpu()[:, :K] - ref).abs().max().item()
+    assert err < 3e-5 * ref.abs().max().item() * 4, err
+    assert (out.cpu()[:, K:] == 0).all()
+    tav = out.view(B, N, 128)[:, 1:, :K]
+    af = hip.query_att_ft(tav, xd[:, 1:, :], fast=True)
+    inner = x[:, 1:] @ sd.t()
+    refa = torch.bmm(torch.softmax((inner / math.sqrt(D)).permute(0, 2, 1), -1), x[:, 1:])
+    assert (af.cpu() - refa).abs().max().item() < 2e-2 * max(1, refa.abs().max().item())
+    af2 = hip.query_att_ft(tav, xd[:, 1:, :], out=af.clone(), fast=True)
+    assert (af2.cpu() - 2 * refa).abs().max().item() < 4e-2 * max(1, refa.abs().max().item())
+    # layer-level call, both modes
+    ta, ft = hip.query_model(xd, sdp, K, sd_split=(hi, lo))
+    assert torch.equal(ta, tav) and (ft.cpu() - refa).abs().max().item() < 2e-2 * max(1, refa.abs().max().item())
+    ta32, ft32 = hip.query_model(xd, sdp, K)
+    assert (ta32.cpu() - ref.view(B, N, K)[:, 1:]).abs().max().item() < 2e-5 * ref.abs().max().item()
+    assert (ft32.cpu() - refa).abs().max().item() < 2e-5 * max(1, refa.abs().max().item())
+
+
 def test_vector_gather(hip):
     v = _rand(3, 50, 768, seed=60)
     idx = torch.randint(0, 50, (3, 17), generator=torch.Generator().manual_seed(2))
