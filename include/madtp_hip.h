@@ -194,6 +194,11 @@ typedef struct madtp_bert_layer_w {
     int variant_nlvr;                   /* mask-gather rule and cross-attention mask rule of nlvr_encoder.py */
     int has_merge;                      /* crossattention.output.merge_layer present (NLVR layers >= 6) */
     madtp_lin cq[2], ckv[2], cdense[2], merge;
+    /* optional fused twin projections (fused_twin != 0): cq_fused = [q0;q1] ([2*dim, dim]); cdense_fused has K = 2*dim
+     * and consumes [c0|c1]: either [W0|W1] with bias b0+b1 and epilogue scale 0.5 (average, layers < 6) or the
+     * merge_layer folded in, Wm[:, :dim] W0 | Wm[:, dim:] W1 (fused_twin == 2, epilogue scale 1). */
+    int fused_twin;
+    madtp_lin cq_fused, cdense_fused;
     const float *ln_cross_g, *ln_cross_b;
     madtp_lin inter, out;               /* intermediate.dense, output.dense */
     const float *ln_out_g, *ln_out_b;

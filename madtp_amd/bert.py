@@ -174,6 +174,35 @@ class BertSelfOutput(nn.Module):
         return _ln_dual(self.LayerNorm, s)
 
 
+def _fused_twin_output(co, fold_merge):
+    """[W0 | W1] along K for the twin cross-attention output (nlvr_encoder.py:259-266).  Average layers: bias b0+b1,
+    the 0.5 goes into the GEMM epilogue scale.  Merge layers (fast mode only): merge_layer folded in,
+    Wm[:, :D] W0 | Wm[:, D:] W1 and bias Wm[:, :D] b0 + Wm[:, D:] b1 + bm, computed once in f32 on the f32 GEMM."""
+    from .runtime import prepare_linear
+    W0, W1 = co.dense0.weight.detach().float(), co.dense1.weight.detach().float()
+    b0, b1 = co.dense0.bias.detach().float(), co.dense1.bias.detach().float()
+    if fold_merge:
+        Wm, bm = co.merge_layer.weight.detach().float(), co.merge_layer.bias.detach().float()
+        D = W0.shape[0]
+
+        def mm(a, b_t):  # a [m,k] @ b_t[n,k]^T on the exact-f32 kernel
+            bt = b_t.contiguous()
+            pad = (-bt.shape[0]) % 128
+            if pad:
+                bt = torch.cat([bt, torch.zeros(pad, bt.shape[1], device=bt.device)], 0)
+            return hip.gemm(a.contiguous(), bt.contiguous(), n=b_t.shape[0])
+
+        Wl, Wr = Wm[:, :D].contiguous(), Wm[:, D:].contiguous()
+        W0f = mm(Wl, W0.t().contiguous())  # Wl @ W0
+        W1f = mm(Wr, W1.t().contiguous())
+        bias = mm(b0[None, :], Wl)[0] + mm(b1[None, :], Wr)[0] + bm
+        Wcat = torch.cat([W0f, W1f], dim=1)
+    else:
+        Wcat = torch.cat([W0, W1], dim=1)
+        bias = b0 + b1
+    return prepare_linear([Wcat], [bias], compute_dtype())
+
+
 class BertAttention(nn.Module):
     """med.py:253-299 / nlvr_encoder.py:274-349."""
 
@@ -188,6 +217,7 @@ class BertAttention(nn.Module):
             self.self = BertSelfAttention(config, is_cross_attention)
             self.output = BertSelfOutput(config)
         self.pruned_heads = set()
+        self._cache = PreparedCache()
 
 
 class BertIntermediate(nn.Module):
@@ -293,6 +323,14 @@ class _BertLayerBase(nn.Module):
                     if co.merge:
                         w.has_merge = 1
                         w.merge = L(co._cache, "mg", [co.merge_layer])
+                    # fused twin projections (one-time weight preparation; see madtp_bert_layer_w in the header)
+                    bf = compute_dtype() == torch.bfloat16
+                    if not co.merge or bf:
+                        w.cq_fused = L(ca._cache, "qq", [ca.self0.query, ca.self1.query])
+                        fl = _fused_twin_output(co, fold_merge=co.merge)
+                        keep.append(fl)
+                        w.cdense_fused = hip.lin_struct(fl)
+                        w.fused_twin = 2 if co.merge else 1
                 else:
                     w.cross = 1
                     w.cq[0] = L(ca.self._cache, "q", [ca.self.query])

@@ -91,9 +91,9 @@ __device__ __forceinline__ int wfrag_row(int j, int rho) {
     return LP_OUT ? 32 * (j >> 1) + 8 * (rho >> 2) + 4 * (j & 1) + (rho & 3) : 16 * j + rho;
 }
 
-template <bool LP_OUT, int ACT, int FM, int FN, int BM, int BN>
-__device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[FM][FN], int m0, int n0, int wr, int wc,
-                                         int l16, int grp4) {
+template <bool LP_OUT, int ACT, int FM, int FN, int BM, int BN, int RM, int RN>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[FM][FN], const f32x4 (&res)[RM][RN],
+                                         int m0, int n0, int wr, int wc, int l16, int grp4) {
     const bool c_bf16 = g.ldc < 0;
     const int ldc = c_bf16 ? -g.ldc : g.ldc;
             const int col_w = n0 + wc * (BN / 2);
@@ -136,7 +136,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[F
                             f32x4 v = acc[i][j] + bv;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = epi_act<false, ACT>(v[e]) * g.out_scale;
-                            if (g.residual) v += *(const f32x4*)(g.residual + (size_t)row * g.ldr + col);
+                            if constexpr (!LP_OUT) { if (g.residual) v += res[i][j]; }
                             *(f32x4*)((float*)g.C + (size_t)row * ldc + col) = v;
                         }
                     }
@@ -238,8 +238,28 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
     int m0 = ((slot / g.ntn) * 8 + xcd) * BM, n0 = (slot % g.ntn) * BN;
     long s = 0;
     int cur_stage = 0;
+    // f32-output tiles carry the residual stream: its float4s are fetched two slabs before the epilogue so the HBM
+    // latency hides under the last MFMAs instead of stalling the store phase.
+    f32x4 res[LP_OUT ? 1 : FM][LP_OUT ? 1 : FN];
+    const bool res_pref = !LP_OUT && g.residual && g.fast_epi;
+    const int kt_pref = nk >= 2 ? nk - 2 : 0;
     while (true) {
         for (int kt = 0; kt < nk; ++kt, ++s) {
+            if constexpr (!LP_OUT) {
+                if (res_pref && kt == kt_pref) {
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        int row = m0 + wr * (BM / 2) + i * 16 + l16;
+                        row = row < g.M ? row : g.M - 1;
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            int col = n0 + wc * (BN / 2) + 16 * j + 4 * grp4;
+                            col = col < g.N ? col : 0;
+                            res[i][j] = *(const f32x4*)(g.residual + (size_t)row * g.ldr + col);
+                        }
+                    }
+                }
+            }
             // slab s must have landed: this wave's DMAs newer than slab s are those of slabs s+1 .. s+STAGES-2
             if (s + STAGES - 1 <= total_slabs) wait_vmcnt<(STAGES - 2) * PER>();
             else wait_vmcnt<0>();  // tail of the stream: fewer real slabs behind slab s
@@ -283,10 +303,10 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
         // ---- epilogue of tile (m0,n0): vectors straight from the accumulators ----
         if (!((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {
             switch (g.act) {
-                case MADTP_ACT_GELU_ERF: epilogue<LP_OUT, MADTP_ACT_GELU_ERF, FM, FN, BM, BN>(g, acc, m0, n0, wr, wc, l16, grp4); break;
-                case MADTP_ACT_QUICK_GELU: epilogue<LP_OUT, MADTP_ACT_QUICK_GELU, FM, FN, BM, BN>(g, acc, m0, n0, wr, wc, l16, grp4); break;
-                case MADTP_ACT_RELU: epilogue<LP_OUT, MADTP_ACT_RELU, FM, FN, BM, BN>(g, acc, m0, n0, wr, wc, l16, grp4); break;
-                default: epilogue<LP_OUT, MADTP_ACT_NONE, FM, FN, BM, BN>(g, acc, m0, n0, wr, wc, l16, grp4); break;
+                case MADTP_ACT_GELU_ERF: epilogue<LP_OUT, MADTP_ACT_GELU_ERF, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4); break;
+                case MADTP_ACT_QUICK_GELU: epilogue<LP_OUT, MADTP_ACT_QUICK_GELU, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4); break;
+                case MADTP_ACT_RELU: epilogue<LP_OUT, MADTP_ACT_RELU, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4); break;
+                default: epilogue<LP_OUT, MADTP_ACT_NONE, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4); break;
             }
         }
         slot += gl;

@@ -66,7 +66,7 @@ VitWs vit_carve(char* base, size_t cap, int B, int N, int dim, int hidden, int h
 }
 
 struct BertWs {
-    void *hc, *qkv, *ctx, *q, *kv, *c0, *c1, *cat, *mid, *attc;
+    void *hc, *qkv, *ctx, *q, *q2, *kv, *c0, *c1, *cat, *mid, *attc;
     float *t, *xp, *s, *att2, *merge_w, *colsum, *p0, *onorm;
     int32_t* dst_pos;
     size_t bytes;
@@ -80,6 +80,7 @@ BertWs bert_carve(char* base, size_t cap, int B, int L, int Nk, int dim, int hid
     w.qkv = c.take(M * 3 * dim * e);
     w.ctx = c.take(M * dim * e);
     w.q = c.take(M * dim * e);
+    w.q2 = c.take(M * 2 * dim * e);
     w.kv = c.take(MK * 2 * dim * e);
     w.c0 = c.take(M * dim * e);
     w.c1 = c.take(M * dim * e);
@@ -260,6 +261,27 @@ extern "C" int madtp_bert_layer_rest(const madtp_bert_layer_w* w, const float* a
         if (!enc0 || Nk <= 0) return MADTP_E_BADARG;
         const int nbr = w->cross == 2 ? 2 : 1;
         if (nbr == 2 && !enc1) return MADTP_E_BADARG;
+        if (nbr == 2 && w->fused_twin) {
+            // twin branches with fused projections: one q GEMM ([q0|q1], N = 2D), the two context tensors written
+            // side by side ([c0|c1], ld 2D) and ONE output GEMM over K = 2D (dense0|dense1, merge_layer folded in)
+            TRY(lin(ac, D, w->cq_fused, nullptr, 0, s.q2, 2 * D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+            for (int br = 0; br < 2; ++br) {
+                const void* enc = br ? enc1 : enc0;
+                const float* em = w->variant_nlvr ? (br ? enc_mask1 : enc_mask0) : nullptr;
+                TRY(lin(enc, D, w->ckv[br], nullptr, 0, s.kv, 2 * D, B * Nk, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+                const char* kv = (const char*)s.kv;
+                TRY(madtp_attention((const char*)s.q2 + (size_t)br * D * e, kv, kv + (size_t)D * e,
+                                    (char*)s.cat + (size_t)br * D * e, em, nullptr, nullptr, nullptr, B, w->heads, Lp, Nk,
+                                    2 * D, 2 * D, 2 * D, 2 * D, w->scale, dt, stream));
+            }
+            TRY(lin(s.cat, 2 * D, w->cdense_fused, a32, D, s.s, D, M, dt, MADTP_F32, MADTP_ACT_NONE,
+                    w->fused_twin == 2 ? 1.f : 0.5f, stream));
+            TRY(madtp_layernorm(s.s, w->ln_cross_g, w->ln_cross_b, s.att2, dt == MADTP_BF16 ? s.attc : nullptr, M, D, w->eps,
+                                stream));
+            a32 = s.att2;
+            ac = dt == MADTP_BF16 ? (const void*)s.attc : (const void*)s.att2;
+            goto ffn;
+        }
         void* cbuf[2] = {s.c0, s.c1};
         for (int br = 0; br < nbr; ++br) {
             const void* enc = br ? enc1 : enc0;
@@ -289,6 +311,7 @@ extern "C" int madtp_bert_layer_rest(const madtp_bert_layer_w* w, const float* a
         a32 = s.att2;
         ac = dt == MADTP_BF16 ? (const void*)s.attc : (const void*)s.att2;
     }
+ffn:
     TRY(lin(ac, D, w->inter, nullptr, 0, s.mid, w->inter.n, M, dt, dt, MADTP_ACT_GELU_ERF, 1.f, stream));
     TRY(lin(s.mid, w->inter.n, w->out, a32, D, s.t, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
     TRY(madtp_layernorm(s.t, w->ln_out_g, w->ln_out_b, y, nullptr, M, D, w->eps, stream));

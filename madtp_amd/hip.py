@@ -72,6 +72,7 @@ class BertLayerW(ctypes.Structure):
     _fields_ = [("qkv", LinStruct), ("attn_out", LinStruct), ("ln_att_g", c_void_p), ("ln_att_b", c_void_p),
                 ("cross", c_int), ("variant_nlvr", c_int), ("has_merge", c_int),
                 ("cq", LinStruct * 2), ("ckv", LinStruct * 2), ("cdense", LinStruct * 2), ("merge", LinStruct),
+                ("fused_twin", c_int), ("cq_fused", LinStruct), ("cdense_fused", LinStruct),
                 ("ln_cross_g", c_void_p), ("ln_cross_b", c_void_p),
                 ("inter", LinStruct), ("out", LinStruct), ("ln_out_g", c_void_p), ("ln_out_b", c_void_p),
                 ("eps", c_float), ("scale", c_float), ("heads", c_int), ("dim", c_int), ("dtype", c_int)]
