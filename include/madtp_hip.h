@@ -49,6 +49,15 @@ int madtp_gemm(const void* A, const void* W, const float* bias, const float* res
                int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                int ab_dtype, int c_dtype, int act, float out_scale, void* stream);
 
+/* Split-K form for small-M projections (latency-bound at one workgroup per tile): part[s,M,N] (f32, contiguous) holds
+ * the partial product of K range s; madtp_splitk_ln then computes
+ *   y = LayerNorm(scale * (sum_s part[s] + bias) + residual)          (med.py:246-250,326-328; nlvr_encoder.py:259-271)
+ * with the reduction in a fixed order.  (K*esz/128) must be divisible by `splits`; dim % 4 == 0, dim <= 1024. */
+int madtp_gemm_splitk(const void* A, const void* W, float* part, int M, int N, int K, int lda, int ldw, int splits,
+                      int ab_dtype, void* stream);
+int madtp_splitk_ln(const float* part, int splits, const float* bias, const float* residual, const float* gamma,
+                    const float* beta, float* y32, void* ylp, int rows, int dim, float eps, float scale, void* stream);
+
 /* Optional profiling of madtp_gemm launches with HIP events recorded on the launch stream (bench.py roofline leg).
  * madtp_profile_begin() starts recording; madtp_profile_end() stops, waits for the events and writes one line per
  * (dtype, M, N, K): "dtype M N K launches total_ms flops" into buf; returns the bytes written. */

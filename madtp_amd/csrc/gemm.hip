@@ -30,7 +30,7 @@ constexpr int NTHREADS = 256;
 
 struct GemmArgs {
     const char* A; const char* W; const float* bias; const float* residual; void* C;
-    int M, N, K, lda, ldw, ldc, ldr, act, ntm, ntn, dbg, fast_epi;
+    int M, N, K, lda, ldw, ldc, ldr, act, ntm, ntn, dbg, fast_epi, splitk;
     float out_scale;
 };
 
@@ -93,7 +93,7 @@ __device__ __forceinline__ int wfrag_row(int j, int rho) {
 
 template <bool LP_OUT, int ACT, int FM, int FN, int BM, int BN, int RM, int RN>
 __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[FM][FN], const f32x4 (&res)[RM][RN],
-                                         int m0, int n0, int wr, int wc, int l16, int grp4) {
+                                         int m0, int n0, int wr, int wc, int l16, int grp4, size_t c_off) {
     const bool c_bf16 = g.ldc < 0;
     const int ldc = c_bf16 ? -g.ldc : g.ldc;
             const int col_w = n0 + wc * (BN / 2);
@@ -137,7 +137,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[F
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = epi_act<false, ACT>(v[e]) * g.out_scale;
                             if constexpr (!LP_OUT) { if (g.residual) v += res[i][j]; }
-                            *(f32x4*)((float*)g.C + (size_t)row * ldc + col) = v;
+                            *(f32x4*)((float*)g.C + c_off + (size_t)row * ldc + col) = v;
                         }
                     }
                 }
@@ -176,7 +176,10 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
     // fetched from HBM once and then served by that XCD's L2 to the workgroups computing its other column tiles.
     const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, gl = gridDim.x >> 3;
     const int npanel = (g.ntm - xcd + 7) >> 3;
-    const int nslots = npanel * g.ntn;
+    // split-K (small-M problems): every output tile is cut into g.splitk K ranges, each its own slot; a slot stores its
+    // raw f32 partial tile to C + split*M*ldc and a row kernel (madtp_splitk_ln) reduces them in a fixed order.
+    const int S = g.splitk;
+    const int nslots = npanel * g.ntn * S;
     int slot = lb;
     if (slot >= nslots) return;
 
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = g.K * ESZ / ROWB;
+    const int nk = g.K * ESZ / ROWB / S;  // slabs per slot
     const int n_pad_max = g.ntn * BN - 1;
     const bool c_bf16 = g.ldc < 0;  // sign bit of ldc carries the output dtype (see launcher)
     const int ldc = c_bf16 ? -g.ldc : g.ldc;
@@ -215,27 +218,34 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
     // is synchronised with a COUNTED s_waitcnt vmcnt + raw s_barrier (a __syncthreads() would drain every DMA).
     const int my_slots = (nslots - lb + gl - 1) / gl;
     const long total_slabs = (long)my_slots * nk;
+    auto decode = [&](int sl, int& tm0, int& tn0, int& kb) {
+        const int ts = sl / S, sp = sl - ts * S;
+        tm0 = ((ts / g.ntn) * 8 + xcd) * BM; tn0 = (ts % g.ntn) * BN; kb = sp * nk;
+    };
     int is_slot = slot, is_kt = 0, is_stage = 0;  // coordinates / ring stage of the next slab to issue
-    int im0 = ((is_slot / g.ntn) * 8 + xcd) * BM, in0 = (is_slot % g.ntn) * BN;
+    int im0, in0, ikb;
+    decode(is_slot, im0, in0, ikb);
     long issued = 0;
     auto issue_next = [&]() {
         if (issued < total_slabs && !(g.dbg & 2)) {
             char* st = smem + is_stage * STAGE_BYTES;
-            stage_tile<ESZ, BM>(g.A, im0, g.M - 1, g.lda, is_kt * ROWB, st, wave, lane);
-            stage_tile<ESZ, BN>(g.W, in0, n_pad_max, g.ldw, is_kt * ROWB, st + A_BYTES, wave, lane);
+            stage_tile<ESZ, BM>(g.A, im0, g.M - 1, g.lda, (ikb + is_kt) * ROWB, st, wave, lane);
+            stage_tile<ESZ, BN>(g.W, in0, n_pad_max, g.ldw, (ikb + is_kt) * ROWB, st + A_BYTES, wave, lane);
         }
         ++issued;  // phantom slabs past the end keep the wait counts uniform (they issue nothing: see tail wait)
         if (++is_stage == STAGES) is_stage = 0;
         if (++is_kt == nk) {
             is_kt = 0;
             is_slot += gl;
-            im0 = ((is_slot / g.ntn) * 8 + xcd) * BM; in0 = (is_slot % g.ntn) * BN;
+            decode(is_slot, im0, in0, ikb);
         }
     };
 #pragma unroll
     for (int p = 0; p < STAGES - 1; ++p) issue_next();
 
-    int m0 = ((slot / g.ntn) * 8 + xcd) * BM, n0 = (slot % g.ntn) * BN;
+    int m0, n0, kb_unused;
+    decode(slot, m0, n0, kb_unused);
+    size_t c_off = S > 1 ? (size_t)(slot % S) * g.M * (g.ldc < 0 ? -g.ldc : g.ldc) : 0;
     long s = 0;
     int cur_stage = 0;
     // f32-output tiles carry the residual stream: its float4s are fetched two slabs before the epilogue so the HBM
@@ -303,15 +313,16 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
         // ---- epilogue of tile (m0,n0): vectors straight from the accumulators ----
         if (!((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {
             switch (g.act) {
-                case MADTP_ACT_GELU_ERF: epilogue<LP_OUT, MADTP_ACT_GELU_ERF, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4); break;
-                case MADTP_ACT_QUICK_GELU: epilogue<LP_OUT, MADTP_ACT_QUICK_GELU, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4); break;
-                case MADTP_ACT_RELU: epilogue<LP_OUT, MADTP_ACT_RELU, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4); break;
-                default: epilogue<LP_OUT, MADTP_ACT_NONE, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4); break;
+                case MADTP_ACT_GELU_ERF: epilogue<LP_OUT, MADTP_ACT_GELU_ERF, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off); break;
+                case MADTP_ACT_QUICK_GELU: epilogue<LP_OUT, MADTP_ACT_QUICK_GELU, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off); break;
+                case MADTP_ACT_RELU: epilogue<LP_OUT, MADTP_ACT_RELU, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off); break;
+                default: epilogue<LP_OUT, MADTP_ACT_NONE, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off); break;
             }
         }
         slot += gl;
         if (slot >= nslots) break;
-        m0 = ((slot / g.ntn) * 8 + xcd) * BM; n0 = (slot % g.ntn) * BN;
+        decode(slot, m0, n0, kb_unused);
+        c_off = S > 1 ? (size_t)(slot % S) * g.M * (g.ldc < 0 ? -g.ldc : g.ldc) : 0;
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -360,9 +371,30 @@ extern "C" int madtp_profile_end(char* buf, int cap) {
     return off;
 }
 
+static int gemm_launch(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
+                       int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float out_scale, int splitk,
+                       void* stream);
+
 extern "C" int madtp_gemm(const void* A, const void* W, const float* bias, const float* residual, void* C,
                           int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                           int ab_dtype, int c_dtype, int act, float out_scale, void* stream) {
+    return gemm_launch(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, ab_dtype, c_dtype, act, out_scale, 1, stream);
+}
+
+// Split-K variant for small-M problems: part[s, M, N] (f32, contiguous) = A[:, Ks] @ W[:, Ks]^T for K range s of
+// `splits`; no bias/activation/residual (madtp_splitk_ln applies them after the fixed-order reduction).
+extern "C" int madtp_gemm_splitk(const void* A, const void* W, float* part, int M, int N, int K, int lda, int ldw, int splits,
+                                 int ab_dtype, void* stream) {
+    if (splits < 1) return MADTP_E_BADARG;
+    const int esz = ab_dtype == MADTP_BF16 ? 2 : 4;
+    if ((K * esz / ROWB) % splits) return MADTP_E_SHAPE;
+    return gemm_launch(A, W, nullptr, nullptr, part, M, N, K, lda, ldw, N, 0, ab_dtype, MADTP_F32, MADTP_ACT_NONE, 1.f, splits,
+                       stream);
+}
+
+static int gemm_launch(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
+                       int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float out_scale, int splitk,
+                       void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return MADTP_E_BADARG;
     if (ab_dtype != MADTP_F32 && ab_dtype != MADTP_BF16) return MADTP_E_DTYPE;
     if (c_dtype != MADTP_F32 && c_dtype != MADTP_BF16) return MADTP_E_DTYPE;
@@ -378,6 +410,7 @@ extern "C" int madtp_gemm(const void* A, const void* W, const float* bias, const
     if (dbg < 0) { const char* e = getenv("MADTP_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
     if (force_cfg < 0) { const char* e = getenv("MADTP_GEMM_CFG"); force_cfg = e ? atoi(e) : 0; }
     g.dbg = dbg;
+    g.splitk = splitk;
     // vector epilogue needs 16-byte aligned rows on every epilogue operand
     g.fast_epi = (N % 8 == 0) && (ldc % 8 == 0) && aligned16(C) && (!bias || aligned16(bias)) &&
                  (!residual || (aligned16(residual) && ldr % 4 == 0));
@@ -397,7 +430,7 @@ extern "C" int madtp_gemm(const void* A, const void* W, const float* bias, const
     do {                                                                                                               \
         g.ntm = (M + BM_ - 1) / BM_;                                                                                   \
         g.ntn = (N + BN_ - 1) / BN_;                                                                                   \
-        const int slots_max = ((g.ntm + 7) / 8) * g.ntn;                                                               \
+        const int slots_max = ((g.ntm + 7) / 8) * g.ntn * g.splitk;                                                    \
         const int per_xcd = 32 * WGCU;                                                                                 \
         const int grid = 8 * (slots_max < per_xcd ? slots_max : per_xcd);                                              \
         const size_t lds = (size_t)(BM_ + BN_) * ROWB * ST_;                                                           \

@@ -39,6 +39,30 @@ inline int ln_to(const float* x, const float* g, const float* b, float* y32, voi
     return madtp_layernorm(x, g, b, y32, yc, rows, dim, eps, stream);
 }
 
+// split-K factor for a small-M projection that feeds a LayerNorm: only when the tile count leaves most CUs idle and the
+// K loop is long enough that cutting it beats the extra partial traffic (S*M*N*4 bytes written and re-read)
+inline int choose_splits(int M, int N, int K, int dt) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int nk = (int)(K * esz_of(dt) / 128);
+    if (tiles > 128 || nk < 24) return 1;
+    int best = 1;
+    for (int sp = 2; sp <= 4; ++sp)
+        if (nk % sp == 0 && nk / sp >= 6 && tiles * sp <= 512) best = sp;
+    return best;
+}
+
+// y = LayerNorm(scale*(a @ W^T + b) + residual) -> y32 (f32) and/or ylp (bf16); `part` is scratch of >= 4*M*N floats
+inline int lin_ln(const void* a, int lda, const madtp_lin& L, const float* residual, float scale, const float* gamma,
+                  const float* beta, float* y32, void* ylp, int M, int dt, float eps, float* part, void* stream) {
+    const int S = choose_splits(M, L.n, L.k, dt);
+    if (S > 1) {
+        TRY(madtp_gemm_splitk(a, L.w, part, M, L.n, L.k, lda, L.k, S, dt, stream));
+        return madtp_splitk_ln(part, S, L.b, residual, gamma, beta, y32, ylp, M, L.n, eps, scale, stream);
+    }
+    TRY(madtp_gemm(a, L.w, L.b, residual, part, M, L.n, L.k, lda, L.k, L.n, L.n, dt, MADTP_F32, MADTP_ACT_NONE, scale, stream));
+    return madtp_layernorm(part, gamma, beta, y32, ylp, M, L.n, eps, stream);
+}
+
 struct VitWs {
     void *h, *qkv, *o, *mid;
     float *colsum, *p0, *onorm, *xp, *merge_w;
@@ -67,7 +91,7 @@ VitWs vit_carve(char* base, size_t cap, int B, int N, int dim, int hidden, int h
 
 struct BertWs {
     void *hc, *qkv, *ctx, *q, *q2, *kv, *c0, *c1, *cat, *mid, *attc;
-    float *t, *xp, *s, *att2, *merge_w, *colsum, *p0, *onorm;
+    float *t, *xp, *s, *att2, *merge_w, *colsum, *p0, *onorm, *part;
     int32_t* dst_pos;
     size_t bytes;
 };
@@ -91,6 +115,7 @@ BertWs bert_carve(char* base, size_t cap, int B, int L, int Nk, int dim, int hid
     w.xp = (float*)c.take(M * dim * 4);
     w.s = (float*)c.take(M * dim * 4);
     w.att2 = (float*)c.take(M * dim * 4);
+    w.part = (float*)c.take(4 * M * dim * 4);
     w.merge_w = (float*)c.take((size_t)B * L * 4);
     w.colsum = (float*)c.take((size_t)B * ((L + 15) / 16) * L * 4);
     w.p0 = (float*)c.take((size_t)B * heads * L * 4);
@@ -210,8 +235,7 @@ extern "C" int madtp_bert_layer_attn(const madtp_bert_layer_w* w, const float* h
     const char* q = (const char*)s.qkv;
     TRY(madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.ctx, mask2d, prune ? s.colsum : nullptr, s.p0, s.onorm,
                         B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale, dt, stream));
-    TRY(lin(s.ctx, D, w->attn_out, hidden, D, s.t, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
-    TRY(madtp_layernorm(s.t, w->ln_att_g, w->ln_att_b, att, nullptr, M, D, w->eps, stream));
+    TRY(lin_ln(s.ctx, D, w->attn_out, hidden, 1.f, w->ln_att_g, w->ln_att_b, att, nullptr, M, dt, w->eps, s.part, stream));
     if (prune) {
         hipError_t he = hipMemsetAsync(kmax, 0, sizeof(int32_t), (hipStream_t)stream);
         if (he != hipSuccess) return (int)he;
@@ -274,10 +298,8 @@ extern "C" int madtp_bert_layer_rest(const madtp_bert_layer_w* w, const float* a
                                     (char*)s.cat + (size_t)br * D * e, em, nullptr, nullptr, nullptr, B, w->heads, Lp, Nk,
                                     2 * D, 2 * D, 2 * D, 2 * D, w->scale, dt, stream));
             }
-            TRY(lin(s.cat, 2 * D, w->cdense_fused, a32, D, s.s, D, M, dt, MADTP_F32, MADTP_ACT_NONE,
-                    w->fused_twin == 2 ? 1.f : 0.5f, stream));
-            TRY(madtp_layernorm(s.s, w->ln_cross_g, w->ln_cross_b, s.att2, dt == MADTP_BF16 ? s.attc : nullptr, M, D, w->eps,
-                                stream));
+            TRY(lin_ln(s.cat, 2 * D, w->cdense_fused, a32, w->fused_twin == 2 ? 1.f : 0.5f, w->ln_cross_g, w->ln_cross_b, s.att2,
+                       dt == MADTP_BF16 ? s.attc : nullptr, M, dt, w->eps, s.part, stream));
             a32 = s.att2;
             ac = dt == MADTP_BF16 ? (const void*)s.attc : (const void*)s.att2;
             goto ffn;
@@ -313,7 +335,6 @@ extern "C" int madtp_bert_layer_rest(const madtp_bert_layer_w* w, const float* a
     }
 ffn:
     TRY(lin(ac, D, w->inter, nullptr, 0, s.mid, w->inter.n, M, dt, dt, MADTP_ACT_GELU_ERF, 1.f, stream));
-    TRY(lin(s.mid, w->inter.n, w->out, a32, D, s.t, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
-    TRY(madtp_layernorm(s.t, w->ln_out_g, w->ln_out_b, y, nullptr, M, D, w->eps, stream));
+    TRY(lin_ln(s.mid, w->inter.n, w->out, a32, 1.f, w->ln_out_g, w->ln_out_b, y, nullptr, M, dt, w->eps, s.part, stream));
     return 0;
 }

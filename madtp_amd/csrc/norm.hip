@@ -94,6 +94,43 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restri
              ylp ? ylp + (size_t)row * dim : nullptr);
 }
 
+// y = LayerNorm(scale * (sum_s part[s] + bias) + residual): the fixed-order reduction of split-K partials fused with the
+// bias / residual / LayerNorm that follows every small-M projection of the BERT layers.
+__global__ __launch_bounds__(256) void splitk_ln_kernel(const float* __restrict__ part, int S, size_t pstride,
+                                                        const float* __restrict__ bias, const float* __restrict__ residual,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* y32, bf16_t* ylp, int rows, int dim, float eps, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float4 v[LN_MAX_CHUNKS];
+    int n = 0;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int col = (lane + 64 * c) * 4;
+        v[c] = make_float4(0, 0, 0, 0);
+        if (col < dim) {
+            float4 a = *(const float4*)(part + (size_t)row * dim + col);
+            for (int s = 1; s < S; ++s) {
+                const float4 p = *(const float4*)(part + s * pstride + (size_t)row * dim + col);
+                a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+            }
+            if (bias) { const float4 b = *(const float4*)(bias + col); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+            if (residual) {
+                const float4 r = *(const float4*)(residual + (size_t)row * dim + col);
+                a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+            }
+            v[c] = a;
+            n = c + 1;
+        }
+    }
+    float mean, rstd;
+    ln_row(v, n, dim, eps, mean, rstd);
+    ln_store(v, lane, dim, mean, rstd, gamma, beta, y32 ? y32 + (size_t)row * dim : nullptr,
+             ylp ? ylp + (size_t)row * dim : nullptr);
+}
+
 // one thread per 4 consecutive kx of one (b, patch, c, ky): reads 16 B of an image row, writes 16 B / 8 B
 template <typename T>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int S,
@@ -155,6 +192,17 @@ extern "C" int madtp_layernorm(const float* x, const float* gamma, const float* 
         return MADTP_E_ALIGN;
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y32,
                        (bf16_t*)ylp, rows, dim, eps);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_splitk_ln(const float* part, int splits, const float* bias, const float* residual, const float* gamma,
+                               const float* beta, float* y32, void* ylp, int rows, int dim, float eps, float scale,
+                               void* stream) {
+    if (!part || !gamma || !beta || (!y32 && !ylp) || rows <= 0 || dim <= 0 || splits < 1) return MADTP_E_BADARG;
+    if (dim % 4 || dim > 256 * LN_MAX_CHUNKS) return MADTP_E_SHAPE;
+    hipLaunchKernelGGL(splitk_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, splits,
+                       (size_t)rows * dim, bias, residual, gamma, beta, y32, (bf16_t*)ylp, rows, dim, eps, scale);
     MADTP_LAUNCH_CHECK();
     return 0;
 }

@@ -23,6 +23,9 @@ _SIGS = {
     "madtp_profile_begin": (c_int, []),
     "madtp_profile_end": (c_int, [ctypes.c_char_p, c_int]),
     "madtp_gemm": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_int, c_int, c_int, c_float, c_void_p]),
+    "madtp_gemm_splitk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "madtp_splitk_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                c_float, c_float, c_void_p]),
     "madtp_layernorm": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p]),
     "madtp_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "madtp_assemble_tokens": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
@@ -446,3 +449,16 @@ def profile_end():
         rows.append({"dtype": "bf16" if int(dt) == BF16 else "f32", "M": int(M), "N": int(N), "K": int(K),
                      "launches": int(c), "ms": float(ms), "flops": float(fl)})
     return rows
+
+
+def gemm_splitk_ln(a, w, bias, residual, gamma, beta, eps, splits, n, scale=1.0, want_bf16=False):
+    """LayerNorm(scale*(a @ w^T + bias) + residual) via split-K partials; returns (y32, ybf16 or None)."""
+    M, K = a.shape
+    part = torch.empty((splits, M, n), device=a.device, dtype=torch.float32)
+    _check(load().madtp_gemm_splitk(_p(a), _p(w), _p(part), M, n, K, a.stride(0), w.stride(0), splits, _dt(a), _stream()),
+           "madtp_gemm_splitk")
+    y32 = torch.empty((M, n), device=a.device, dtype=torch.float32)
+    ylp = torch.empty((M, n), device=a.device, dtype=torch.bfloat16) if want_bf16 else None
+    _check(load().madtp_splitk_ln(_p(part), splits, _p(bias), _p(residual), _p(gamma), _p(beta), _p(y32), _p(ylp), M, n,
+                                  float(eps), float(scale), _stream()), "madtp_splitk_ln")
+    return y32, ylp

@@ -57,6 +57,23 @@ def test_gemm(hip, M, N, K, dtype):
     assert (out.float().cpu() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K,S", [(1280, 768, 3072, 4), (1280, 768, 1536, 4), (300, 768, 768, 2), (77, 768, 768, 12)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gemm_splitk_ln(hip, M, N, K, S, dtype):
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    a = _rand(M, K, seed=1).to(td)
+    w = _rand(N, K, seed=2, scale=0.05).to(td)
+    bias, res = _rand(N, seed=3), _rand(M, N, seed=4)
+    g, b = _rand(N, seed=5), _rand(N, seed=6)
+    y32, ybf = hip.gemm_splitk_ln(a.cuda(), _pad128(w.float()).to(td).cuda(), bias.cuda(), res.cuda(), g.cuda(), b.cuda(),
+                                  1e-12, S, N, scale=0.5, want_bf16=True)
+    t = (0.5 * (a.double() @ w.double().t() + bias.double()) + res.double()).float()
+    ref = F.layer_norm(t, (N,), g, b, 1e-12)
+    tol = 5e-5 if dtype == "f32" else 5e-5
+    assert (y32.cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    assert (ybf.float().cpu() - ref).abs().max().item() < 0.05
+
+
 def test_gemm_strided_a_and_transpose_detect(hip):
     # A given as a column slice of a wider matrix (lda > K); asymmetric operands catch a swapped C layout
     big = _rand(70, 2304, seed=5)
