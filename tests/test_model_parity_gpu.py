@@ -106,3 +106,42 @@ def test_module_error_behaviour(env):
         blk(torch.zeros(1, 197, 768))  # CPU tensor: loud failure, no eager fallback
     with pytest.raises(ValueError):
         blk(torch.zeros(1, 197, 768, device="cuda"), False, 0, 1.0, None)  # temperature>0 without token_attn
+
+
+MED_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "med_*.npz")))
+
+
+@pytest.mark.parametrize("path", MED_CASES, ids=[os.path.basename(c)[:-4] for c in MED_CASES])
+def test_med_bert_fp32_matches_reference_fixture(path):
+    """models/med.py BertModel mirror (text mode and multimodal mode, padded masks) vs the reference fixture."""
+    from madtp_amd import build, hip, harness, runtime, specs
+    from madtp_amd.med import BertConfig, BertModel
+    from tests.test_oracle_golden import med_inputs
+    build.build(verbose=False)
+    hip.load()
+    g = np.load(path)
+    ids, att, enc, enc_att, sd, mode, T = med_inputs(g)
+    cfg = BertConfig.med_default()
+    model = BertModel(cfg, add_pooling_layer=False)
+    model.load_state_dict(specs.synth_weights(specs.bert_shapes("", "med"), int(g["seed"])), strict=False)
+    model = model.eval().cuda()
+    with runtime.precision("fp32"), torch.no_grad():
+        out, _ = model(ids.cuda(), attention_mask=att.cuda(), encoder_hidden_states=None if enc is None else enc.cuda(),
+                       encoder_attention_mask=None if enc_att is None else enc_att.cuda(), mode=mode,
+                       space_dict=sd.cuda(), temperature=T)
+    hid = out.last_hidden_state
+    assert list(hid.shape) == g["hidden_shape"].tolist()
+    trace = [None if l.last_prune is None else {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in l.last_prune.items()}
+             for l in model.encoder.layer]
+    assert harness.token_lengths(trace, int(g["L"])) == g["txt_lens"].tolist()
+    mine = harness.compose_ids(trace, int(g["L"]) - 1)
+    ref_trace = [{"pruned": True, "indices": g[f"txt{l}_idx"][:, : trace[l]["k"]]} if f"txt{l}_idx" in g.files else None
+                 for l in range(12)]
+    ref = harness.compose_ids(ref_trace, int(g["L"]) - 1)
+    assert mine == ref
+    assert np.abs(hid[:, 0, :32].cpu().numpy() - g["hidden_cls"]).max() < 1e-3
+    with runtime.precision("bf16"), torch.no_grad():
+        outb, _ = model(ids.cuda(), attention_mask=att.cuda(), encoder_hidden_states=None if enc is None else enc.cuda(),
+                        encoder_attention_mask=None if enc_att is None else enc_att.cuda(), mode=mode,
+                        space_dict=sd.cuda(), temperature=T)
+    assert torch.isfinite(outb.last_hidden_state).all()

@@ -51,3 +51,43 @@ def test_oracle_matches_reference_fixture(path):
             # bit-exact kept-token index SETS (order of topk(sorted=False) is implementation-defined)
             assert (np.sort(info["indices"].numpy(), 1) == np.sort(g[f"{key}{l}_idx"], 1)).all()
             assert (info["indices_sort"].numpy() == g[f"{key}{l}_sort"]).all()
+
+
+MED_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "med_*.npz")))
+
+
+def med_inputs(g):
+    """inputs of tools/make_golden.py::med_case, rebuilt from the fixture's scalars."""
+    B, L, Nimg, seed, pad_tail = int(g["B"]), int(g["L"]), int(g["Nimg"]), int(g["seed"]), int(g["pad_tail"])
+    mode = str(g["mode"])
+    ids = synth.synth_token_ids(B, L, seed + 1)
+    att = torch.ones_like(ids)
+    if pad_tail:
+        for b in range(B):
+            att[b, L - (b % (pad_tail + 1)):] = 0
+    enc = synth.synth_tensor("image_embeds", (B, Nimg, 768), seed).mul(25.0) if mode == "multimodal" else None
+    enc_att = torch.ones(B, Nimg, dtype=torch.long) if enc is not None else None
+    sd = synth.synth_tensor("space_dict", (100, 768), seed)
+    return ids, att, enc, enc_att, sd, mode, float(g["temperature"])
+
+
+@pytest.mark.parametrize("path", MED_CASES, ids=[os.path.basename(c)[:-4] for c in MED_CASES])
+def test_oracle_med_matches_reference_fixture(path):
+    """models/med.py BertModel (text / multimodal mode, padded attention masks) - SURVEY.md 8 rows a9-a11."""
+    g = np.load(path)
+    ids, att, enc, enc_att, sd, mode, T = med_inputs(g)
+    W = specs.synth_weights(specs.bert_shapes("", "med"), int(g["seed"]))
+    trace = []
+    with torch.no_grad():
+        hidden, _, _ = O.bert_model(W, "", ids, att, sd, T, enc=enc, enc_atts=enc_att, mode=mode, variant="med", trace=trace)
+    assert list(hidden.shape) == g["hidden_shape"].tolist()
+    assert np.abs(hidden[:, 0, :32].numpy() - g["hidden_cls"]).max() < 1e-4
+    lens = g["txt_lens"]
+    for l, info in enumerate(trace):
+        if f"txt{l}_idx" not in g.files:
+            assert not info["pruned"]
+            continue
+        assert info["pruned"] and info["k"] + 2 == lens[l]
+        # the reference gathers topk(k+1) and keeps the first k (med.py:377-378)
+        assert (np.sort(info["indices"].numpy(), 1) == np.sort(g[f"txt{l}_idx"][:, : info["k"]], 1)).all()
+        assert (info["indices_sort"].numpy() == g[f"txt{l}_sort"]).all()

@@ -100,9 +100,53 @@ def nlvr_case(name, B, size, L, temperature, seed=0):
           f"({dt:.2f}s)")
 
 
+def med_case(name, B, L, Nimg, temperature, mode, seed=0, pad_tail=0):
+    """models/med.py BertModel (MED) stand-alone: text mode / multimodal mode with synthetic image tokens and an
+    optional padded tail in attention_mask (exercises med.py:388-390 mask compaction)."""
+    import models.med as rmed
+    from madtp_amd import specs
+    cfg = rmed.BertConfig.from_json_file("configs/med_config.json")
+    cfg.encoder_width = 768
+    cfg.evaluate = True
+    model = rmed.BertModel(config=cfg, add_pooling_layer=False)
+    model.eval()
+    shapes = specs.bert_shapes("", "med")
+    sd = specs.synth_weights(shapes, seed)
+    msg = model.load_state_dict(sd, strict=False)
+    assert not msg.unexpected_keys and all("query_model" in k or "position_ids" in k for k in msg.missing_keys), msg
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed)
+    ids = synth.synth_token_ids(B, L, seed + 1)
+    att = torch.ones_like(ids)
+    if pad_tail:
+        for b in range(B):
+            att[b, L - (b % (pad_tail + 1)):] = 0
+    enc = synth.synth_tensor("image_embeds", (B, Nimg, 768), seed).mul(25.0) if mode == "multimodal" else None
+    enc_att = torch.ones(B, Nimg, dtype=torch.long) if enc is not None else None
+    tap = GatherTap(rmed)
+    hooks, lens = [], []
+    for i, lay in enumerate(model.encoder.layer):
+        hooks.append(lay.register_forward_pre_hook(lambda m, a, i=i: tap.set_tag(f"txt{i}")))
+        hooks.append(lay.register_forward_hook(lambda m, a, o: lens.append(o[0].shape[1])))
+    with torch.no_grad():
+        out, _ = model(ids, attention_mask=att, encoder_hidden_states=enc, encoder_attention_mask=enc_att, return_dict=True,
+                       mode=mode, space_dict=space_dict, temperature=temperature)
+    for h in hooks:
+        h.remove()
+    tap.restore()
+    hid = out.last_hidden_state
+    rec = {"kind": "med", "B": B, "L": L, "Nimg": Nimg, "mode": mode, "temperature": np.float64(temperature), "seed": seed,
+           "pad_tail": pad_tail, "txt_lens": np.array(lens), "hidden_cls": hid[:, 0, :32].numpy(),
+           "hidden_absmean": hid.abs().mean().numpy(), "hidden_shape": np.array(hid.shape)}
+    rec.update(tap.records)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] T={temperature} mode={mode} txt_lens={lens}")
+
+
 CASES = {
     "nlvr_b2_T1": lambda: nlvr_case("nlvr_b2_T1", 2, 224, 20, 1.0),
     "nlvr_b2_T5": lambda: nlvr_case("nlvr_b2_T5", 2, 224, 20, 5.0),
+    "med_text_b3": lambda: med_case("med_text_b3", 3, 35, 0, 30.0, "text", pad_tail=3),
+    "med_mm_b3": lambda: med_case("med_mm_b3", 3, 35, 50, 30.0, "multimodal", pad_tail=3),
 }
 
 if __name__ == "__main__":
