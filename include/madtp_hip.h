@@ -167,12 +167,14 @@ typedef struct madtp_lin {
     int n, k;
 } madtp_lin;
 
-/* models/vit.py Block (:106-207): norm1, attn.qkv, attn.proj, norm2, mlp.fc1, mlp.fc2 */
+/* models/vit.py Block (:106-207): norm1, attn.qkv, attn.proj, norm2, mlp.fc1, mlp.fc2; also clip/model.py
+ * ResidualAttentionBlock (:174-261): ln_1, attn.in_proj, attn.out_proj, ln_2, mlp.c_fc, mlp.c_proj */
 typedef struct madtp_vit_block_w {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     float eps, scale; /* LayerNorm eps; attention scale head_dim^-0.5 */
     madtp_lin qkv, proj, fc1, fc2;
     int heads, dim, dtype; /* dtype: MADTP_F32 (parity mode) or MADTP_BF16 (fast mode) */
+    int act;               /* MLP activation: MADTP_ACT_GELU_ERF (BLIP ViT) or MADTP_ACT_QUICK_GELU (CLIP) */
 } madtp_vit_block_w;
 
 size_t madtp_vit_block_workspace(int B, int N, int dim, int hidden, int heads, int dtype);

@@ -181,7 +181,7 @@ extern "C" int madtp_vit_block_mlp(const madtp_vit_block_w* w, const float* x, f
     }
     const int M = B * Np;
     TRY(ln_to(xr, w->ln2_g, w->ln2_b, nullptr, s.h, M, D, w->eps, dt, stream));
-    TRY(lin(s.h, D, w->fc1, nullptr, 0, s.mid, w->fc1.n, M, dt, dt, MADTP_ACT_GELU_ERF, 1.f, stream));
+    TRY(lin(s.h, D, w->fc1, nullptr, 0, s.mid, w->fc1.n, M, dt, dt, w->act, 1.f, stream));
     TRY(lin(s.mid, w->fc1.n, w->fc2, xr, D, y, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
     return 0;
 }

@@ -68,7 +68,7 @@ class VitBlockW(ctypes.Structure):
     _fields_ = [("ln1_g", c_void_p), ("ln1_b", c_void_p), ("ln2_g", c_void_p), ("ln2_b", c_void_p),
                 ("eps", c_float), ("scale", c_float),
                 ("qkv", LinStruct), ("proj", LinStruct), ("fc1", LinStruct), ("fc2", LinStruct),
-                ("heads", c_int), ("dim", c_int), ("dtype", c_int)]
+                ("heads", c_int), ("dim", c_int), ("dtype", c_int), ("act", c_int)]
 
 
 class BertLayerW(ctypes.Structure):

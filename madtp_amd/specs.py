@@ -94,6 +94,29 @@ def blip_nlvr_shapes(img_size=224):
     return sd
 
 
+def clip_vit_shapes(prefix="", img_size=224, patch=16, width=768, layers=12, out_dim=512, sd_dim=768):
+    """clip/model.py VisionTransformer (:275-313) with ResidualAttentionBlock (:174-261); ViT-B/16 geometry."""
+    sd = OrderedDict()
+    n = (img_size // patch) ** 2
+    sd[prefix + "class_embedding"] = (width,)
+    sd[prefix + "positional_embedding"] = (n + 1, width)
+    sd[prefix + "proj"] = (width, out_dim)
+    sd[prefix + "conv1.weight"] = (width, 3, patch, patch)
+    _ln(sd, prefix + "ln_pre", width)
+    for i in range(layers):
+        p = f"{prefix}transformer.resblocks.{i}."
+        sd[p + "attn.in_proj_weight"] = (3 * width, width)
+        sd[p + "attn.in_proj_bias"] = (3 * width,)
+        _linear(sd, p + "attn.out_proj", width, width)
+        _ln(sd, p + "ln_1", width)
+        _linear(sd, p + "mlp.c_fc", 4 * width, width)
+        _linear(sd, p + "mlp.c_proj", width, 4 * width)
+        _ln(sd, p + "ln_2", width)
+        _linear(sd, p + "query_model.q_map.0", sd_dim, width)
+    _ln(sd, prefix + "ln_post", width)
+    return sd
+
+
 def synth_weights(shapes, seed=0):
     """{key: tensor} from a shape spec using the deterministic generator."""
     import torch

@@ -71,12 +71,23 @@ class Query_model(nn.Module):
                 return hi, lo
             split = self._cache.get(("sd_split", id(sd)), [sd], _split)
         if self.map_func:
-            qm = self._cache.get("qmap", [self.q_map[0].weight, self.q_map[0].bias],
-                                 lambda: prepare_linear([self.q_map[0].weight], [self.q_map[0].bias], torch.float32))
-            q = hip.gemm(ft.float().reshape(B * n, D) if ft.is_contiguous() else ft.float().contiguous().view(B * n, D),
-                         qm.w, qm.b, n=qm.n).view(B, n, -1)
-            rows, off = q.view(B * n, -1), 0
-            ftq = q
+            # CLIP: q = q_map(ft) (clip/model.py:188, models/utils.py:160-163).  Mapped over ALL rows of the token buffer
+            # when ft is x[:,1:,:] of a contiguous tensor (the CLS row is computed and ignored), then the same
+            # logits / att_ft kernels run on q.
+            cdt = compute_dtype()
+            qm = self._cache.get(("qmap", cdt), [self.q_map[0].weight, self.q_map[0].bias],
+                                 lambda: prepare_linear([self.q_map[0].weight], [self.q_map[0].bias], cdt))
+            rows = full_rows_of(ft)
+            off = 1
+            if rows is None:
+                rows, off = ft.float().contiguous().view(B * n, D), 0
+            a = rows if cdt == torch.float32 else hip.cast_bf16(rows.contiguous())
+            q = hip.gemm(a, qm.w, qm.b, out_dtype=torch.float32, n=qm.n).view(B, n + off, -1)
+            if off == 1:
+                token_att, att_ft = hip.query_model(q, sdl.w, K, att_ft=acc_ft, want_att_ft=self.compute_att_ft,
+                                                    sd_dim=self.att_dim, sd_split=split)
+                return token_att, (att_ft if self.compute_att_ft else acc_ft), sd
+            rows, ftq = q.view(B * n, -1), q
         else:
             rows = full_rows_of(ft)
             off = 1

@@ -162,6 +162,7 @@ class Block(nn.Module):
             w.qkv, w.proj, w.fc1, w.fc2 = [hip.lin_struct(l) for l in lins]
             w.heads, w.dim = self.attn.num_heads, self.attn.dim
             w.dtype = hip.F32 if compute_dtype() == torch.float32 else hip.BF16
+            w.act = hip.ACT_GELU
             return (w, lins)  # keep the prepared tensors alive next to the raw pointers
 
         return self._cache.get("w", params, build)[0]

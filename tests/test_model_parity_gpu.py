@@ -145,3 +145,41 @@ def test_med_bert_fp32_matches_reference_fixture(path):
                         encoder_attention_mask=None if enc_att is None else enc_att.cuda(), mode=mode,
                         space_dict=sd.cuda(), temperature=T)
     assert torch.isfinite(outb.last_hidden_state).all()
+
+
+CLIP_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clip_*.npz")))
+
+
+@pytest.mark.parametrize("path", CLIP_CASES, ids=[os.path.basename(c)[:-4] for c in CLIP_CASES])
+def test_clip_vision_fp32_matches_reference_fixture(path):
+    """clip/model.py VisionTransformer/ResidualAttentionBlock mirror vs the reference fixture (row a14, config 4)."""
+    from madtp_amd import build, hip, harness, runtime, specs, synth
+    from madtp_amd.clip_model import VisionTransformer
+    build.build(verbose=False)
+    hip.load()
+    g = np.load(path)
+    B, size, T, seed = int(g["B"]), int(g["size"]), float(g["temperature"]), int(g["seed"])
+    model = VisionTransformer(input_resolution=size, patch_size=16, width=768, layers=12, heads=12, output_dim=512, sd_dim=768)
+    sd = specs.synth_weights(specs.clip_vit_shapes("", size), seed)
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys())
+    model.load_state_dict(sd, strict=True)
+    model = model.eval().cuda()
+    images = synth.synth_images(B, size, seed).cuda()
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed).cuda()
+    with runtime.precision("fp32"), torch.no_grad():
+        feat, sd_ft = model(images, space_dict, T, 1)
+    trace = [None if b.last_prune is None else {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.last_prune.items()}
+             for b in model.transformer.resblocks]
+    assert harness.token_lengths(trace, 197) == g["vit_lens"].tolist()
+    ref_trace = [{"pruned": True, "indices": g[f"vit{l}_idx"]} if f"vit{l}_idx" in g.files else None for l in range(12)]
+    assert harness.compose_ids(trace, 196) == harness.compose_ids(ref_trace, 196)
+    assert np.abs(feat.cpu().numpy() - g["features"]).max() < 1e-3
+    assert np.abs(sd_ft[:, :4, :16].cpu().numpy() - g["sd_ft_head"]).max() < 1e-2
+    with runtime.precision("bf16"), torch.no_grad():
+        fb, _ = model(images, space_dict, T, 1)
+    assert torch.isfinite(fb).all() and (fb.cpu() - torch.from_numpy(g["features"])).abs().max().item() < 0.25
+    blk = model.transformer.resblocks[0]
+    blk.attn_mask = torch.zeros(4, 4)
+    with pytest.raises(NotImplementedError):
+        blk((torch.zeros(4, 1, 768, device="cuda"), None, 0, None, 1))
+    blk.attn_mask = None

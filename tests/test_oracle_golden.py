@@ -91,3 +91,29 @@ def test_oracle_med_matches_reference_fixture(path):
         # the reference gathers topk(k+1) and keeps the first k (med.py:377-378)
         assert (np.sort(info["indices"].numpy(), 1) == np.sort(g[f"txt{l}_idx"][:, : info["k"]], 1)).all()
         assert (info["indices_sort"].numpy() == g[f"txt{l}_sort"]).all()
+
+
+CLIP_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clip_*.npz")))
+
+
+@pytest.mark.parametrize("path", CLIP_CASES, ids=[os.path.basename(c)[:-4] for c in CLIP_CASES])
+def test_oracle_clip_vision_matches_reference_fixture(path):
+    """clip/model.py VisionTransformer + ResidualAttentionBlock (vision tower)."""
+    g = np.load(path)
+    B, size, T, seed = int(g["B"]), int(g["size"]), float(g["temperature"]), int(g["seed"])
+    shapes = specs.clip_vit_shapes("", size)
+    assert sorted(shapes.keys()) == [str(k) for k in g["state_dict_keys"]]
+    W = specs.synth_weights(shapes, seed)
+    trace = []
+    with torch.no_grad():
+        feat, sd_ft = O.clip_vision_forward(W, "", synth.synth_images(B, size, seed),
+                                            synth.synth_tensor("space_dict", (100, 768), seed), T, 1, trace=trace)
+    assert np.abs(feat.numpy() - g["features"]).max() < 1e-4
+    assert np.abs(sd_ft[:, :4, :16].numpy() - g["sd_ft_head"]).max() < 1e-3
+    lens = g["vit_lens"]
+    for l, info in enumerate(trace):
+        if f"vit{l}_idx" not in g.files:
+            assert not info["pruned"]
+            continue
+        assert info["pruned"] and info["k"] + 2 == lens[l]
+        assert (np.sort(info["indices"].numpy(), 1) == np.sort(g[f"vit{l}_idx"], 1)).all()

@@ -142,11 +142,41 @@ def med_case(name, B, L, Nimg, temperature, mode, seed=0, pad_tail=0):
     print(f"[{name}] T={temperature} mode={mode} txt_lens={lens}")
 
 
+def clip_case(name, B, temperature, seed=0, size=224):
+    """clip/model.py VisionTransformer (ViT-B/16 geometry) with clip/mock.py's patched MultiheadAttention."""
+    import clip.mock  # noqa: F401  (monkey-patches torch.nn.MultiheadAttention, as the reference does on import)
+    import clip.model as cm
+    from madtp_amd import specs
+    model = cm.VisionTransformer(input_resolution=size, patch_size=16, width=768, layers=12, heads=12, output_dim=512, sd_dim=768)
+    model.eval()
+    sd = specs.synth_weights(specs.clip_vit_shapes("", size), seed)
+    model.load_state_dict(sd, strict=True)
+    images = synth.synth_images(B, size, seed)
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed)
+    tap = GatherTap(cm)
+    hooks, lens = [], []
+    for i, blk in enumerate(model.transformer.resblocks):
+        hooks.append(blk.register_forward_pre_hook(lambda m, a, i=i: tap.set_tag(f"vit{i}")))
+        hooks.append(blk.register_forward_hook(lambda m, a, o: lens.append(o[0].shape[0])))
+    with torch.no_grad():
+        feat, sd_ft = model(images, space_dict, temperature, 1)
+    for h in hooks:
+        h.remove()
+    tap.restore()
+    rec = {"kind": "clip_vit", "B": B, "size": size, "temperature": np.float64(temperature), "seed": seed,
+           "vit_lens": np.array(lens), "features": feat.numpy(), "sd_ft_head": sd_ft[:, :4, :16].numpy(),
+           "state_dict_keys": np.array(sorted(sd.keys()))}
+    rec.update(tap.records)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] T={temperature} vit_lens={lens}")
+
+
 CASES = {
     "nlvr_b2_T1": lambda: nlvr_case("nlvr_b2_T1", 2, 224, 20, 1.0),
     "nlvr_b2_T5": lambda: nlvr_case("nlvr_b2_T5", 2, 224, 20, 5.0),
     "med_text_b3": lambda: med_case("med_text_b3", 3, 35, 0, 30.0, "text", pad_tail=3),
     "med_mm_b3": lambda: med_case("med_mm_b3", 3, 35, 50, 30.0, "multimodal", pad_tail=3),
+    "clip_vit_b2": lambda: clip_case("clip_vit_b2", 2, 4.0),
 }
 
 if __name__ == "__main__":

@@ -158,6 +158,34 @@ def install(chdir=True):
         ft = _mod("ftfy")
         ft.fix_text = lambda s: s
 
+    # (7) CLIP only: clip/mock.py imports torch-1.11 internals of nn.functional / nn.modules.activation
+    import math
+    import typing
+    import warnings as _warnings
+    import torch.nn.functional as F
+    import torch.nn.modules.activation as act
+    if not hasattr(F, "_scaled_dot_product_attention"):
+        def _scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0):
+            """torch==1.11 nn.functional._scaled_dot_product_attention restated (clip/mock.py:220 call site)."""
+            B, Nt, E = q.shape
+            q = q / math.sqrt(E)
+            if attn_mask is not None:
+                attn = torch.baddbmm(attn_mask, q, k.transpose(-2, -1))
+            else:
+                attn = torch.bmm(q, k.transpose(-2, -1))
+            attn = F.softmax(attn, dim=-1)
+            if dropout_p > 0.0:
+                attn = F.dropout(attn, p=dropout_p)
+            return torch.bmm(attn, v), attn
+        F._scaled_dot_product_attention = _scaled_dot_product_attention
+    for name, val in (("math", math), ("warnings", _warnings)):
+        if not hasattr(F, name):
+            setattr(F, name, val)
+    for name, val in (("torch", torch), ("Optional", typing.Optional), ("Tuple", typing.Tuple), ("Tensor", torch.Tensor),
+                      ("Parameter", torch.nn.Parameter)):
+        if not hasattr(act, name):
+            setattr(act, name, val)
+
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     if chdir:
