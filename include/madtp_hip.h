@@ -92,7 +92,7 @@ int madtp_bert_embed(const int64_t* ids, const float* word_emb, const float* pos
  *   colsum_part[b, rt, j] = sum over query rows i in 16-row tile rt, i>=1, of max_h P[b,h,i,j]   (vit.py:126-127)
  *   p0[b,h,j]   = P[b,h,0,j]                                                                      (vit.py:96)
  *   onorm[b,h,i]= || out[b,h,i,:] ||_2                                                            (vit.py:97)
- * Limits: head_dim 64; Nk <= 256 in this family. */
+ * Limits: head_dim 64; Nk <= 1024 (Nk > 256 takes a two-pass kernel on the exact-f32 MFMA). */
 int madtp_attention(const void* q, const void* k, const void* v, void* out, const float* add_mask,
                     float* colsum_part, float* p0, float* onorm,
                     int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo,

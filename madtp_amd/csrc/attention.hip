@@ -420,6 +420,223 @@ int dispatch_nt_bf16(const AttnArgs& a, hipStream_t s) {
     return MADTP_E_SHAPE;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Long-sequence variant (256 < Nk <= 1024: 384x384 / 480x480 images give 577 / 901 tokens).  The score row no longer
+// fits in registers next to the head-max, so every head makes two passes over the keys in 128-key chunks staged in LDS:
+//   pass A: S = K Q^T chunk by chunk -> running row maximum m and sum l (online softmax statistics, exact at the end);
+//   pass B: S recomputed, P = exp(S - m) / l (the same normalised probabilities as the short kernel), head-max of P
+//           kept in registers for ALL key tiles (NCH*8 x 4 floats per lane), P.V accumulated, CLS row written.
+// Arithmetic is the exact-f32 MFMA path in both precision modes (T is only the storage type): this kernel exists for
+// the parity cases at large images, not for the headline benchmark.
+template <typename T, int NCH, bool SCORES>
+__global__ __launch_bounds__(256, 1) void attn_large_kernel(AttnArgs a) {
+    constexpr int ESZ = sizeof(T);
+    constexpr int RB = 64 * ESZ + 16;
+    constexpr int CPR = 64 * ESZ / 16;
+    constexpr int CK = 128;                  // keys per chunk
+    constexpr int NT = NCH * 8;              // 16-key tiles in total
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + CK * RB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int rt = blockIdx.x * 4 + wave;
+    const int i0 = rt * 16;
+    const bool active = i0 < a.Nq;
+    const int irow = min(i0 + l16, a.Nq - 1);
+
+    f32x4 pmax[SCORES ? NT : 1];
+    if constexpr (SCORES) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pmax[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    auto stage = [&](int h, int c, bool with_v) {
+        for (int idx = tid; idx < CK * CPR; idx += 256) {
+            const int row = idx / CPR, ch = idx % CPR, j = c * CK + row;
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if (j < a.Nk) {
+                const size_t grow = (size_t)b * a.Nk + j;
+                kv = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * ESZ + ch * 16);
+                if (with_v) vv = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * ESZ + ch * 16);
+            }
+            *(uint4*)(Ks + row * RB + ch * 16) = kv;
+            if (with_v) *(uint4*)(Vs + row * RB + ch * 16) = vv;
+        }
+    };
+    // S^T for the 8 tiles of one chunk (scale and mask applied, keys beyond Nk -> -inf)
+    auto scores = [&](int c, const f32x4 (&q)[4], f32x4 (&sc)[8]) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 kf[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) kf[t] = load4<T>(Ks + (16 * t + l16) * RB + (4 * s + g) * 4 * ESZ);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t][e], q[s][e], sc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = c * CK + 16 * t + 4 * g + r;
+                float v = sc[t][r] * a.scale;
+                if (a.mask && j < a.Nk) v += a.mask[(size_t)b * a.Nk + j];
+                sc[t][r] = j < a.Nk ? v : -INFINITY;
+            }
+    };
+
+    for (int h = blockIdx.z; h < a.H; h += gridDim.z) {
+        f32x4 q[4];
+        {
+            const char* qp = a.q + (((size_t)b * a.Nq + irow) * a.ldq + h * 64) * ESZ;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) q[s] = load4<T>(qp + (4 * s + g) * 4 * ESZ);
+        }
+        // ---- pass A: row statistics ----
+        float m = -INFINITY, l = 0.f;
+        for (int c = 0; c < NCH; ++c) {
+            if (c * CK >= a.Nk) break;
+            __syncthreads();
+            stage(h, c, false);
+            __syncthreads();
+            if (!active) continue;
+            f32x4 sc[8];
+            scores(c, q, sc);
+            float cm = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cm = fmaxf(cm, sc[t][r]);
+            cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+            cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+            const float mn = fmaxf(m, cm);  // chunk 0 always holds key 0, so mn is finite
+            float cs = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs += expf(sc[t][r] - mn);
+            cs += __shfl_xor(cs, 16, 64);
+            cs += __shfl_xor(cs, 32, 64);
+            l = l * expf(m - mn) + cs;
+            m = mn;
+        }
+        // ---- pass B: probabilities, head-max, P.V ----
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c * CK < a.Nk) {  // block-uniform
+                __syncthreads();
+                stage(h, c, true);
+                __syncthreads();
+                if (active) {
+                    f32x4 sc[8];
+                    scores(c, q, sc);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = expf(sc[t][r] - m) / l;
+                            sc[t][r] = p;
+                            if constexpr (SCORES) pmax[c * 8 + t][r] = fmaxf(pmax[c * 8 + t][r], p);
+                        }
+                    }
+                    if constexpr (SCORES) {
+                        if (i0 + l16 == 0) {
+                            float* dst = a.p0 + ((size_t)b * a.H + h) * a.Nk;
+#pragma unroll
+                            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int j = c * CK + 16 * t + 4 * g + r;
+                                    if (j < a.Nk) dst[j] = sc[t][r];
+                                }
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const char* vrow = Vs + (16 * t + 4 * g + r) * RB + l16 * ESZ;
+#pragma unroll
+                            for (int dt = 0; dt < 4; ++dt)
+                                o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[t][r], load1<T>(vrow + dt * 16 * ESZ), o[dt], 0, 0, 0);
+                        }
+                }
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 4 * g + r;
+                float n2 = 0.f;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) n2 += o[dt][r] * o[dt][r];
+                if constexpr (SCORES) n2 = row16_sum(n2);
+                if (i < a.Nq) {
+                    T* orow = (T*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * ESZ);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) orow[dt * 16 + l16] = from_f32<T>(o[dt][r]);
+                    if constexpr (SCORES)
+                        if (l16 == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
+                }
+            }
+        }
+    }
+    if constexpr (SCORES) {
+        if (active) {
+            const int i = i0 + l16;
+            const bool valid = i >= 1 && i < a.Nq;
+            float* dst = a.colsum + ((size_t)b * a.nrt + rt) * a.Nk;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = row16_sum(valid ? pmax[t][r] : 0.f);
+                    const int j = 16 * t + 4 * g + r;
+                    if (l16 == 0 && j < a.Nk) dst[j] = v;
+                }
+        }
+    }
+}
+
+template <typename T, int NCH, bool SCORES>
+int launch_attn_large(const AttnArgs& a, hipStream_t s) {
+    constexpr int RB = 64 * (int)sizeof(T) + 16;
+    const size_t lds = (size_t)2 * 128 * RB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_large_kernel<T, NCH, SCORES>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int gz = 1;
+    if (!SCORES) {
+        const int wgs = ((a.Nq + 63) / 64) * a.B;
+        gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
+        if (gz > a.H) gz = a.H;
+    }
+    hipLaunchKernelGGL((attn_large_kernel<T, NCH, SCORES>), dim3((a.Nq + 63) / 64, a.B, gz), dim3(256), lds, s, a);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, bool SCORES>
+int dispatch_large(const AttnArgs& a, hipStream_t s) {
+    const int nch = (a.Nk + 127) / 128;
+    if (nch <= 5) return launch_attn_large<T, 5, SCORES>(a, s);
+    if (nch <= 8) return launch_attn_large<T, 8, SCORES>(a, s);
+    return MADTP_E_SHAPE;
+}
+
 template <typename T, int NT, bool SCORES>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     constexpr int RB = 64 * (int)sizeof(T) + 16;
@@ -465,7 +682,7 @@ extern "C" int madtp_attention(const void* q, const void* k, const void* v, void
     const int esz = io_dtype == MADTP_BF16 ? 2 : 4;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (ldq * esz) % 16 || (ldk * esz) % 16 || (ldv * esz) % 16)
         return MADTP_E_ALIGN;
-    if (Nk > 256) return MADTP_E_SHAPE;
+    if (Nk > 1024) return MADTP_E_SHAPE;
     AttnArgs a;
     a.q = (const char*)q; a.k = (const char*)k; a.v = (const char*)v; a.out = (char*)out; a.mask = add_mask;
     a.colsum = colsum_part; a.p0 = p0; a.onorm = onorm;
@@ -474,6 +691,10 @@ extern "C" int madtp_attention(const void* q, const void* k, const void* v, void
     a.scale = scale;
     hipStream_t s = (hipStream_t)stream;
     const bool scores = colsum_part != nullptr;
+    if (Nk > 256) {  // long sequences (384^2 / 480^2 images): two-pass kernel, exact-f32 MFMA in both modes
+        if (io_dtype == MADTP_F32) return scores ? dispatch_large<float, true>(a, s) : dispatch_large<float, false>(a, s);
+        return scores ? dispatch_large<bf16_t, true>(a, s) : dispatch_large<bf16_t, false>(a, s);
+    }
     if (io_dtype == MADTP_F32) return scores ? dispatch_nt<float, true>(a, s) : dispatch_nt<float, false>(a, s);
     if ((ldk * 2) % 16 || (ldv * 2) % 16) return MADTP_E_ALIGN;
     return scores ? dispatch_nt_bf16<true>(a, s) : dispatch_nt_bf16<false>(a, s);

@@ -134,7 +134,8 @@ def _ref_attention(qkv, B, N, H, scale, mask=None):
     return o.transpose(1, 2).reshape(B * N, H * 64), p, colsum, p[:, :, 0, :], o.norm(dim=-1)
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 20, 12), (1, 1 + 16 * 4, 2), (2, 130, 12), (1, 256, 3), (2, 17, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 20, 12), (1, 1 + 16 * 4, 2), (2, 130, 12), (1, 256, 3), (2, 17, 1),
+                                   (1, 577, 12), (2, 901, 3), (1, 257, 2), (1, 1024, 1)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_self_attention_with_scores(hip, B, N, H, dtype):
     td = torch.float32 if dtype == "f32" else torch.bfloat16
@@ -154,7 +155,7 @@ def test_self_attention_with_scores(hip, B, N, H, dtype):
         assert (on.cpu() - rn).abs().max().item() < (1e-4 if dtype == "f32" else 1e-2) * max(1, rn.max().item())
 
 
-@pytest.mark.parametrize("B,L,Nk", [(2, 20, 143), (3, 35, 197), (1, 5, 9), (64, 20, 130)])
+@pytest.mark.parametrize("B,L,Nk", [(2, 20, 143), (3, 35, 197), (1, 5, 9), (64, 20, 130), (2, 20, 577), (1, 35, 901)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_cross_attention(hip, B, L, Nk, dtype):
     H = 12

@@ -183,3 +183,36 @@ def test_clip_vision_fp32_matches_reference_fixture(path):
     with pytest.raises(NotImplementedError):
         blk((torch.zeros(4, 1, 768, device="cuda"), None, 0, None, 1))
     blk.attn_mask = None
+
+
+VIT_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vit*_b*.npz")))
+
+
+@pytest.mark.parametrize("path", VIT_CASES, ids=[os.path.basename(c)[:-4] for c in VIT_CASES])
+def test_vit_large_image_fp32_matches_reference_fixture(path):
+    """VisionTransformer mirror at 384^2 (577 tokens) and 480^2 (901 tokens - BASELINE config 5, heaviest ragged
+    compaction): long-sequence attention kernel + the same pruning kernels, vs the reference fixture."""
+    from madtp_amd import build, hip, harness, runtime, specs, synth
+    from madtp_amd.vit import VisionTransformer
+    build.build(verbose=False)
+    hip.load()
+    g = np.load(path)
+    B, size, T, seed = int(g["B"]), int(g["size"]), float(g["temperature"]), int(g["seed"])
+    model = VisionTransformer(img_size=size, patch_size=16, embed_dim=768, depth=12, num_heads=12, evaluate=True, sd_dim=768)
+    model.load_state_dict(specs.synth_weights(specs.vit_shapes("", size), seed), strict=True)
+    model = model.eval().cuda()
+    images = synth.synth_images(B, size, seed).cuda()
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed).cuda()
+    n0 = (size // 16) ** 2
+    with runtime.precision("fp32"), torch.no_grad():
+        out, sd_ft = model(images, space_dict=space_dict, temperature=T)
+    trace = [None if b.last_prune is None else {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.last_prune.items()}
+             for b in model.blocks]
+    assert harness.token_lengths(trace, n0 + 1) == g["vit_lens"].tolist()
+    ref_trace = [{"pruned": True, "indices": g[f"vit{l}_idx"]} if f"vit{l}_idx" in g.files else None for l in range(12)]
+    assert harness.compose_ids(trace, n0) == harness.compose_ids(ref_trace, n0)
+    assert list(out.shape) == g["out_shape"].tolist()
+    assert np.abs(out[:, 0, :32].cpu().numpy() - g["cls"]).max() < 1e-3
+    with runtime.precision("bf16"), torch.no_grad():
+        ob, _ = model(images, space_dict=space_dict, temperature=T)
+    assert torch.isfinite(ob).all()

@@ -117,3 +117,25 @@ def test_oracle_clip_vision_matches_reference_fixture(path):
             continue
         assert info["pruned"] and info["k"] + 2 == lens[l]
         assert (np.sort(info["indices"].numpy(), 1) == np.sort(g[f"vit{l}_idx"], 1)).all()
+
+
+VIT_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vit*_b*.npz")))
+
+
+@pytest.mark.parametrize("path", VIT_CASES, ids=[os.path.basename(c)[:-4] for c in VIT_CASES])
+def test_oracle_vit_large_image_matches_reference_fixture(path):
+    """models/vit.py VisionTransformer at 384^2 (577 tokens) / 480^2 (901 tokens, the VQA configuration)."""
+    g = np.load(path)
+    B, size, T, seed = int(g["B"]), int(g["size"]), float(g["temperature"]), int(g["seed"])
+    W = specs.synth_weights(specs.vit_shapes("", size), seed)
+    trace = []
+    with torch.no_grad():
+        out, sd_ft = O.vit_forward(W, "", synth.synth_images(B, size, seed), synth.synth_tensor("space_dict", (100, 768), seed),
+                                   T, trace=trace)
+    assert list(out.shape) == g["out_shape"].tolist()
+    assert np.abs(out[:, 0, :32].numpy() - g["cls"]).max() < 1e-4
+    for l, info in enumerate(trace):
+        if f"vit{l}_idx" in g.files:
+            assert (np.sort(info["indices"].numpy(), 1) == np.sort(g[f"vit{l}_idx"], 1)).all()
+        else:
+            assert not info["pruned"]

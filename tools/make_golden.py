@@ -142,6 +142,35 @@ def med_case(name, B, L, Nimg, temperature, mode, seed=0, pad_tail=0):
     print(f"[{name}] T={temperature} mode={mode} txt_lens={lens}")
 
 
+def vit_case(name, B, size, temperature, seed=0):
+    """models/vit.py VisionTransformer stand-alone at a large image size (384 -> 577 tokens: retrieval/NLVR yaml
+    configs; 480 -> 901 tokens: configs/vqa.yaml)."""
+    import models.vit as rvit
+    from madtp_amd import specs
+    model = rvit.VisionTransformer(img_size=size, patch_size=16, embed_dim=768, depth=12, num_heads=12, evaluate=True, sd_dim=768)
+    model.eval()
+    sd = specs.synth_weights(specs.vit_shapes("", size), seed)
+    model.load_state_dict(sd, strict=True)
+    images = synth.synth_images(B, size, seed)
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed)
+    tap = GatherTap(rvit)
+    hooks, lens = [], []
+    for i, blk in enumerate(model.blocks):
+        hooks.append(blk.register_forward_pre_hook(lambda m, a, i=i: tap.set_tag(f"vit{i}")))
+        hooks.append(blk.register_forward_hook(lambda m, a, o: lens.append(o.shape[1])))
+    with torch.no_grad():
+        out, sd_ft = model(images, space_dict=space_dict, temperature=temperature)
+    for h in hooks:
+        h.remove()
+    tap.restore()
+    rec = {"kind": "vit", "B": B, "size": size, "temperature": np.float64(temperature), "seed": seed,
+           "vit_lens": np.array(lens), "cls": out[:, 0, :32].numpy(), "out_shape": np.array(out.shape),
+           "sd_ft_head": sd_ft[:, :4, :16].numpy()}
+    rec.update({k: v for k, v in tap.records.items() if k.endswith("_idx")})
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] size={size} T={temperature} vit_lens={lens}")
+
+
 def clip_case(name, B, temperature, seed=0, size=224):
     """clip/model.py VisionTransformer (ViT-B/16 geometry) with clip/mock.py's patched MultiheadAttention."""
     import clip.mock  # noqa: F401  (monkey-patches torch.nn.MultiheadAttention, as the reference does on import)
@@ -177,6 +206,8 @@ CASES = {
     "med_text_b3": lambda: med_case("med_text_b3", 3, 35, 0, 30.0, "text", pad_tail=3),
     "med_mm_b3": lambda: med_case("med_mm_b3", 3, 35, 50, 30.0, "multimodal", pad_tail=3),
     "clip_vit_b2": lambda: clip_case("clip_vit_b2", 2, 4.0),
+    "vit384_b2": lambda: vit_case("vit384_b2", 2, 384, 6.0),
+    "vit480_b1": lambda: vit_case("vit480_b1", 1, 480, 6.0),
 }
 
 if __name__ == "__main__":
