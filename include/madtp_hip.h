@@ -102,8 +102,8 @@ int madtp_attention(const void* q, const void* k, const void* v, void* out, cons
  * (Block.Reduce_token vit.py:125-145 == med.py:347-371 == nlvr_encoder.py:404-432 == clip/model.py:196-218).
  * n = N-1 patch tokens.  token_attn f32: element [b,t,c] at token_attn[b*ldt_batch + t*ldt_row + c], c < K (raw
  * x.sd^T logits of patch token t; any strided [B,n,K] view with unit column stride).
- * Outputs: score f32 [B,n]; threshold f32 [B]; count int32 [B]; kmax int32[1] = max_b count (must be zeroed by
- * the caller before the launch). */
+ * Outputs: score f32 [B,n]; threshold f32 [B]; count int32 [B]; kmax int32[1] (optional, may be NULL) = max_b count
+ * by atomicMax - the caller zeroes it before the launch; callers that read `count` back can do the max on the host. */
 int madtp_token_score(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
                       const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature,
                       float* score, float* threshold, int32_t* count, int32_t* kmax,

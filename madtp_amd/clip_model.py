@@ -90,7 +90,7 @@ class ResidualAttentionBlock(nn.Module):
         k_use, score = 0, None
         if prune:
             score, thr, count, kmax = po
-            k = int(kmax.item())
+            k = hip.batch_max_count(count)
             self.last_prune = {"k": k, "score": score, "threshold": thr, "count": count, "pruned": False,
                                "indices": None, "indices_sort": None}
             if not (k <= max_keep or (N - 1 - k) <= 1):  # :220-221

@@ -145,7 +145,7 @@ extern "C" int madtp_vit_block_attn(const madtp_vit_block_w* w, const float* x, 
     const int M = B * N, D = w->dim, dt = w->dtype;
     const size_t e = esz_of(dt);
     const bool prune = temperature > 0.f;
-    if (prune && (!token_attn || !score || !threshold || !count || !kmax)) return MADTP_E_BADARG;
+    if (prune && (!token_attn || !score || !threshold || !count)) return MADTP_E_BADARG;
     TRY(ln_to(x, w->ln1_g, w->ln1_b, nullptr, s.h, M, D, w->eps, dt, stream));
     TRY(lin(s.h, D, w->qkv, nullptr, 0, s.qkv, 3 * D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
     const char* q = (const char*)s.qkv;
@@ -153,8 +153,10 @@ extern "C" int madtp_vit_block_attn(const madtp_vit_block_w* w, const float* x, 
                         B, w->heads, N, N, 3 * D, 3 * D, 3 * D, D, w->scale, dt, stream));
     TRY(lin(s.o, D, w->proj, x, D, x_out, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
     if (prune) {
-        hipError_t he = hipMemsetAsync(kmax, 0, sizeof(int32_t), (hipStream_t)stream);
-        if (he != hipSuccess) return (int)he;
+        if (kmax) {
+            hipError_t he = hipMemsetAsync(kmax, 0, sizeof(int32_t), (hipStream_t)stream);
+            if (he != hipSuccess) return (int)he;
+        }
         TRY(madtp_token_score(s.colsum, (N + 15) / 16, s.p0, s.onorm, token_attn, ldt_row, ldt_batch, K, temperature, score,
                               threshold, count, kmax, B, w->heads, N, stream));
     }
@@ -225,7 +227,7 @@ extern "C" int madtp_bert_layer_attn(const madtp_bert_layer_w* w, const float* h
     const int M = B * L, D = w->dim, dt = w->dtype;
     const size_t e = esz_of(dt);
     const bool prune = temperature > 0.f;
-    if (prune && (!token_attn || !score || !threshold || !count || !kmax || !mask2d)) return MADTP_E_BADARG;
+    if (prune && (!token_attn || !score || !threshold || !count || !mask2d)) return MADTP_E_BADARG;
     const void* hc = hidden;
     if (dt == MADTP_BF16) {
         TRY(madtp_cast_bf16(hidden, s.hc, (size_t)M * D, stream));
@@ -237,8 +239,10 @@ extern "C" int madtp_bert_layer_attn(const madtp_bert_layer_w* w, const float* h
                         B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale, dt, stream));
     TRY(lin_ln(s.ctx, D, w->attn_out, hidden, 1.f, w->ln_att_g, w->ln_att_b, att, nullptr, M, dt, w->eps, s.part, stream));
     if (prune) {
-        hipError_t he = hipMemsetAsync(kmax, 0, sizeof(int32_t), (hipStream_t)stream);
-        if (he != hipSuccess) return (int)he;
+        if (kmax) {
+            hipError_t he = hipMemsetAsync(kmax, 0, sizeof(int32_t), (hipStream_t)stream);
+            if (he != hipSuccess) return (int)he;
+        }
         TRY(madtp_token_score(s.colsum, (L + 15) / 16, s.p0, s.onorm, token_attn, ldt_row, ldt_batch, K, temperature, score,
                               threshold, count, kmax, B, w->heads, L, stream));
     }

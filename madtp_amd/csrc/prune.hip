@@ -24,11 +24,15 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nwa
 }
 
 // ------------------------------------------------------------------------------------------------ token_score
-// one 512-thread workgroup per sample.  phase A: per-token terms; phase B: per-dictionary-column softmax over
-// tokens (4 token slices x 128 columns), threshold = min_k sum_t softmax_t(x/T)[t,k] * I[t].
+// one 512-thread workgroup per sample.  The sample's logits token_attn[b] (n x K f32, <= 150 KB) are staged in LDS
+// once with coalesced float4 loads (STAGED; falls back to reading global memory for very long sequences), then
+//   phase A: per-token terms (row max of the logits, column mass of head-max attention, CLS attention);
+//   phase B: per-dictionary-column softmax over tokens (4 token slices x 128 columns) and
+//            threshold = min_k sum_t softmax_t(x/T)[t,k] * I[t]; survivor count; optional batch max (atomicMax).
+template <bool STAGED>
 __global__ __launch_bounds__(512) void token_score_kernel(const float* __restrict__ colsum, int nrt,
                                                           const float* __restrict__ p0, const float* __restrict__ onorm,
-                                                          const float* __restrict__ ta, int ldt, int ldb, int K, float temperature,
+                                                          const float* __restrict__ ta, int ldt_g, int ldb, int K, float temperature,
                                                           float* __restrict__ score, float* __restrict__ threshold,
                                                           int32_t* __restrict__ count, int32_t* __restrict__ kmax, int H,
                                                           int N) {
@@ -37,14 +41,25 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     __shared__ float red[8];
     __shared__ float colred[4][128];
     __shared__ float colstat[128];
+    extern __shared__ __attribute__((aligned(16))) float ta_s[];  // [n][K] when STAGED
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, n = N - 1;
-    const float* ta_b = ta + (size_t)b * ldb;  // row t <-> patch token t
+    const float* ta_g = ta + (size_t)b * ldb;  // row t <-> patch token t
+    if constexpr (STAGED) {
+        const int k4 = K >> 2;  // K % 4 == 0 on this path
+        for (int idx = tid; idx < n * k4; idx += 512) {
+            const int t = idx / k4, c4 = (idx - t * k4) * 4;
+            *(float4*)(ta_s + t * K + c4) = *(const float4*)(ta_g + (size_t)t * ldt_g + c4);
+        }
+        __syncthreads();
+    }
+    const int ldt = STAGED ? K : ldt_g;
+    auto TA = [&](int t, int c) -> float { return STAGED ? ta_s[t * ldt + c] : ta_g[(size_t)t * ldt + c]; };
 
     // token_attn_w = max over dictionary columns (vit.py:131): one wave per row, lanes over columns
     for (int t = wave; t < n; t += 8) {
         float m = -INFINITY;
-        for (int k = lane; k < K; k += 64) m = fmaxf(m, ta_b[(size_t)t * ldt + k]);
+        for (int k = lane; k < K; k += 64) m = fmaxf(m, TA(t, k));
         m = wave_max(m);
         if (lane == 0) tw_s[t] = m;
     }
@@ -95,7 +110,7 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     float m = -INFINITY;
     if (cval) {
 #pragma unroll 8
-        for (int t = t0; t < t1; ++t) m = fmaxf(m, ta_b[(size_t)t * ldt + col] / temperature);
+        for (int t = t0; t < t1; ++t) m = fmaxf(m, TA(t, col) / temperature);
     }
     colred[slice][col] = m;
     __syncthreads();
@@ -104,7 +119,7 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     float se = 0.f;
     if (cval) {
 #pragma unroll 8
-        for (int t = t0; t < t1; ++t) se += expf(ta_b[(size_t)t * ldt + col] / temperature - m);
+        for (int t = t0; t < t1; ++t) se += expf(TA(t, col) / temperature - m);
     }
     colred[slice][col] = se;
     __syncthreads();
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     float sw = 0.f;
     if (cval) {
 #pragma unroll 8
-        for (int t = t0; t < t1; ++t) sw += (expf(ta_b[(size_t)t * ldt + col] / temperature - m) / sum) * I_s[t];
+        for (int t = t0; t < t1; ++t) sw += (expf(TA(t, col) / temperature - m) / sum) * I_s[t];
     }
     colred[slice][col] = sw;
     __syncthreads();
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     if (tid == 0) {
         threshold[b] = thr;
         count[b] = (int)total;
-        atomicMax(kmax, (int)total);
+        if (kmax) atomicMax(kmax, (int)total);
     }
 }
 
@@ -537,11 +552,25 @@ __global__ __launch_bounds__(256, 2) void align_logits_kernel(const float* __res
 extern "C" int madtp_token_score(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
                                  const float* token_attn, int ldt, int ldb, int K, float temperature, float* score,
                                  float* threshold, int32_t* count, int32_t* kmax, int B, int H, int N, void* stream) {
-    if (!colsum_part || !p0 || !onorm || !token_attn || !score || !threshold || !count || !kmax) return MADTP_E_BADARG;
+    if (!colsum_part || !p0 || !onorm || !token_attn || !score || !threshold || !count) return MADTP_E_BADARG;
     if (B <= 0 || H <= 0 || N < 2 || n_row_tiles <= 0 || !(temperature > 0.f)) return MADTP_E_BADARG;
     if (N - 1 > MAXN || K > 128 || K <= 0 || ldt < K) return MADTP_E_SHAPE;
-    hipLaunchKernelGGL(token_score_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, colsum_part, n_row_tiles, p0, onorm,
-                       token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N);
+    const size_t stage_bytes = (size_t)(N - 1) * K * sizeof(float);
+    const bool staged = K % 4 == 0 && ldt % 4 == 0 && ldb % 4 == 0 && aligned16(token_attn) && stage_bytes <= 140 * 1024;
+    if (staged) {
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)token_score_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               140 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr = true;
+        }
+        hipLaunchKernelGGL(token_score_kernel<true>, dim3(B), dim3(512), stage_bytes, (hipStream_t)stream, colsum_part,
+                           n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N);
+    } else {
+        hipLaunchKernelGGL(token_score_kernel<false>, dim3(B), dim3(512), 0, (hipStream_t)stream, colsum_part, n_row_tiles, p0,
+                           onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N);
+    }
     MADTP_LAUNCH_CHECK();
     return 0;
 }

@@ -337,8 +337,15 @@ def workspace(nbytes, device):
 
 
 def prune_outputs(B, n, device):
+    """(score, threshold, count, kmax): kmax is None - callers read `count` back and take the max on the host, which
+    saves the memset + atomic of the device-side batch max (the read-back is the layer's one host sync either way)."""
     return (torch.empty((B, n), device=device, dtype=torch.float32), torch.empty((B,), device=device, dtype=torch.float32),
-            torch.empty((B,), device=device, dtype=torch.int32), torch.empty((1,), device=device, dtype=torch.int32))
+            torch.empty((B,), device=device, dtype=torch.int32), None)
+
+
+def batch_max_count(count):
+    """k = max_b count (vit.py:145 `.item()`): one D2H copy of B int32 values, max on the host."""
+    return int(count.cpu().max())
 
 
 def vit_block_attn(wstruct, x, token_attn, temperature):

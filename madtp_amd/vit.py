@@ -183,7 +183,7 @@ class Block(nn.Module):
         k_use, score = 0, None
         if prune:
             score, thr, count, kmax = po
-            k = int(kmax.item())  # topk_num = max_b count: one host sync per layer, as vit.py:145
+            k = hip.batch_max_count(count)  # topk_num = max_b count: one host sync per layer, as vit.py:145
             self.last_prune = {"k": k, "score": score, "threshold": thr, "count": count, "pruned": False,
                                "indices": None, "indices_sort": None}
             if not (k < 1 or (N - 1 - k) <= 1):  # vit.py:148-149
