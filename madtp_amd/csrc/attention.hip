@@ -256,22 +256,27 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnArgs a) {
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(base + grp * 1024), 16, 0, 0);
         }
     };
+    // Q fragment (B operand of S^T = K Q^T): row i, k-slot group g <-> d = 32kk + 8g .. +7; fetched one head ahead
+    auto load_q = [&](int h, bf16x8 (&qq)[2]) {
+        const char* qp = a.q + (((size_t)b * a.Nq + irow) * a.ldq + h * 64) * 2;
+        qq[0] = *(const bf16x8*)(qp + g * 16);
+        qq[1] = *(const bf16x8*)(qp + 64 + g * 16);
+    };
     int st = 0;
     stage_head(blockIdx.z, 0);
+    bf16x8 qn[2];
+    load_q(blockIdx.z, qn);
     for (int h = blockIdx.z; h < a.H; h += gridDim.z, st ^= 1) {
+        bf16x8 q[2] = {qn[0], qn[1]};
         __syncthreads();  // head h landed (the barrier drains the DMA); the other stage is free again
-        if (h + (int)gridDim.z < a.H) stage_head(h + gridDim.z, st ^ 1);
+        if (h + (int)gridDim.z < a.H) {
+            stage_head(h + gridDim.z, st ^ 1);
+            load_q(h + gridDim.z, qn);
+        }
         if (!active) continue;
         const char* Ks = smem + st * STAGE;
         const char* Vs = Ks + NKP * 128;
 
-        // ---- Q fragment (B operand): row i, k-slot group g <-> d = 32kk + 8g .. +7 ----
-        bf16x8 q[2];
-        {
-            const char* qp = a.q + (((size_t)b * a.Nq + irow) * a.ldq + h * 64) * 2;
-            q[0] = *(const bf16x8*)(qp + g * 16);
-            q[1] = *(const bf16x8*)(qp + 64 + g * 16);
-        }
         // ---- S^T = K Q^T ----
         f32x4 sc[NT];
 #pragma unroll
@@ -347,23 +352,27 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnArgs a) {
             for (int dt = 0; dt < 4; ++dt) {
                 const int p = ((2 * dt + ((l16 & 3) >> 1)) ^ vkey) << 4;
                 const bf16x8 vb = cat_bf16x4(lds_read_tr16(vr + p), lds_read_tr16(vr + 16 * 128 + p));
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, o[dt], 0, 0, 0);  // O^T: row d = 4g+r, col i
             }
         }
-        // ---- write O (row = i0+4g+r, col = h*64+dt*16+l16), row norms ----
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = i0 + 4 * g + r;
+        // ---- write O: with the operands swapped lane (i = l16, g) holds columns h*64 + 16dt + 4g .. +3 of row i ----
+        {
+            const int i = i0 + l16;
             float n2 = 0.f;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) n2 += o[dt][r] * o[dt][r];
-            if constexpr (SCORES) n2 = row16_sum(n2);
-            if (i < a.Nq) {
-                bf16_t* orow = (bf16_t*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 2);
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) orow[dt * 16 + l16] = f32_to_bf16(o[dt][r]);
+                for (int r = 0; r < 4; ++r) n2 += o[dt][r] * o[dt][r];
+            if constexpr (SCORES) {
+                n2 += __shfl_xor(n2, 16, 64);
+                n2 += __shfl_xor(n2, 32, 64);
+            }
+            if (i < a.Nq) {
+                bf16_t* orow = (bf16_t*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 2) + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + dt * 16) = pack_bf16x4(o[dt]);
                 if constexpr (SCORES)
-                    if (l16 == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
+                    if (g == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
             }
         }
     }
