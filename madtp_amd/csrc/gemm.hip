@@ -136,7 +136,12 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[F
                             f32x4 v = acc[i][j] + bv;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = epi_act<false, ACT>(v[e]) * g.out_scale;
-                            if constexpr (!LP_OUT) { if (g.residual) v += res[i][j]; }
+                            if constexpr (!LP_OUT) {
+                                if (g.residual) {
+                                    if constexpr (RM == FM) v += res[i][j];  // prefetched two slabs earlier
+                                    else v += *(const f32x4*)(g.residual + (size_t)row * g.ldr + col);
+                                }
+                            }
                             *(f32x4*)((float*)g.C + c_off + (size_t)row * ldc + col) = v;
                         }
                     }
@@ -332,6 +337,140 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------------
+// "Ping-pong" bf16 kernel for the big GEMMs: 256x128 output tile, 512 threads = two groups of four waves.  Group g
+// owns the 128x128 half tile of rows [128g, 128g+128) (the same 2x2 wave layout and fragment code as above); the W
+// slab is SHARED by the two groups, so a K slab costs 48 KiB of LDS-DMA instead of 2 x 32 KiB, and a 3-stage ring
+// (144 KiB) fits.  The groups run the same instruction stream ONE PHASE APART:
+//     phase 2i   : group 0 LOAD(i)    (16 x ds_read_b128 of slab i -> registers, issue its share of slab i+2's DMA)
+//                  group 1 COMPUTE(i-1) (32 MFMAs from registers only)
+//     phase 2i+1 : group 0 COMPUTE(i),  group 1 LOAD(i)
+// Each SIMD hosts one wave of each group (waves 0-3 and 4-7 are dealt over the four SIMDs), so while one wave keeps the
+// matrix pipe busy its partner issues LDS reads and DMA - the overlap the two-independent-workgroup kernel only gets by
+// chance.  Phases are separated by raw s_barrier; LDS-DMA completion is tracked with counted s_waitcnt vmcnt:
+//   RAW: slab i's shares were issued 4 phases before its first read; every wave waits for its own share (vmcnt(PER):
+//        all but the newest share) at the end of an ODD phase, i.e. before the barrier that precedes LOAD(i) of group 0;
+//   WAR: slab i+2 overwrites the stage of slab i-1, whose last ds_reads (group 1, phase 2i-1) are drained with
+//        lgkmcnt(0) before the barrier that ends that phase.
+// The slab stream is persistent across the workgroup's tiles exactly as in gemm_kernel.
+template <bool LP_OUT>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
+    constexpr int ESZ = 2, BMG = 128, BN = 128, STAGES = 3;
+    constexpr int A_BYTES = BMG * ROWB, STAGE_BYTES = (2 * BMG + BN) * ROWB;  // A0 | A1 | W
+    constexpr int PER = 6;  // DMA instructions per wave per slab share: 4 (own A half) + 2 (half of W)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, gl = gridDim.x >> 3;
+    const int npanel = (g.ntm - xcd + 7) >> 3;
+    const int nslots = npanel * g.ntn;
+    int slot = lb;
+    if (slot >= nslots) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave8 >> 2, wave = wave8 & 3;  // group, wave within the group
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l16 = lane & 15, grp4 = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K * ESZ / ROWB;
+    const int n_pad_max = g.ntn * BN - 1;
+    int a_off[4], a_key[4], b_off[4], b_key[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = wr * 64 + i * 16 + l16;
+        a_off[i] = grp * A_BYTES + ra * ROWB; a_key[i] = ra & 7;
+        const int rb = wc * 64 + wfrag_row<LP_OUT>(i, l16);
+        b_off[i] = 2 * A_BYTES + rb * ROWB; b_key[i] = rb & 7;
+    }
+
+    const int my_slots = (nslots - lb + gl - 1) / gl;
+    const long total_slabs = (long)my_slots * nk;
+    int is_slot = slot, is_kt = 0, is_stage = 0;
+    int im0 = ((is_slot / g.ntn) * 8 + xcd) * 256, in0 = (is_slot % g.ntn) * BN;
+    long issued = 0;
+    auto issue_next = [&]() {  // this wave's share of the next slab: 4 x own A half + 2 x half of W
+        if (issued < total_slabs) {
+            char* st = smem + is_stage * STAGE_BYTES;
+            stage_tile<ESZ, 128>(g.A, im0 + grp * BMG, g.M - 1, g.lda, is_kt * ROWB, st + grp * A_BYTES, wave, lane);
+            stage_tile<ESZ, 64>(g.W, in0 + grp * 64, n_pad_max, g.ldw, is_kt * ROWB, st + 2 * A_BYTES + grp * 64 * ROWB, wave, lane);
+        }
+        ++issued;
+        if (++is_stage == STAGES) is_stage = 0;
+        if (++is_kt == nk) {
+            is_kt = 0;
+            is_slot += gl;
+            im0 = ((is_slot / g.ntn) * 8 + xcd) * 256; in0 = (is_slot % g.ntn) * BN;
+        }
+    };
+    issue_next();
+    issue_next();
+    if (total_slabs >= 2) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                    // slab 0 landed for everybody
+    if (grp == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one phase behind
+
+    int m0 = ((slot / g.ntn) * 8 + xcd) * 256 + grp * BMG, n0 = (slot % g.ntn) * BN;
+    long s = 0;
+    int cur_stage = 0;
+    f32x4 res[1][1];  // no residual prefetch here (register budget): the epilogue reads the residual directly
+    while (true) {
+        for (int kt = 0; kt < nk; ++kt, ++s) {
+            // ---------------- LOAD(s) ----------------
+            const char* st = smem + cur_stage * STAGE_BYTES;
+            if (++cur_stage == STAGES) cur_stage = 0;
+            bf16x8 a[2][4], b[2][4];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int chunk = kk * 4 + grp4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a[kk][i] = *(const bf16x8*)(st + a_off[i] + ((chunk ^ a_key[i]) << 4));
+                    b[kk][i] = *(const bf16x8*)(st + b_off[i] + ((chunk ^ b_key[i]) << 4));
+                }
+            }
+            issue_next();  // slab s+2 -> the stage slab s-1 used (its reads were drained two phases ago)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers; LDS reads of this stage done
+            if (grp == 1) { if (s + 2 < total_slabs) wait_vmcnt<PER>(); else wait_vmcnt<0>(); }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- COMPUTE(s) ----------------
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (kt == nk - 1) {  // tile finished for this group: epilogue straight from the accumulators
+                switch (g.act) {
+                    case MADTP_ACT_GELU_ERF: epilogue<LP_OUT, MADTP_ACT_GELU_ERF, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
+                    case MADTP_ACT_QUICK_GELU: epilogue<LP_OUT, MADTP_ACT_QUICK_GELU, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
+                    case MADTP_ACT_RELU: epilogue<LP_OUT, MADTP_ACT_RELU, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
+                    default: epilogue<LP_OUT, MADTP_ACT_NONE, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (grp == 0) { if (s + 2 < total_slabs) wait_vmcnt<PER>(); else wait_vmcnt<0>(); }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        slot += gl;
+        if (slot >= nslots) break;
+        m0 = ((slot / g.ntn) * 8 + xcd) * 256 + grp * BMG; n0 = (slot % g.ntn) * BN;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // balances group 1's extra barrier at the start
+}
+
 // ---- optional HIP-event profiling of every GEMM launch (bench.py's roofline leg) -----------------------------------
 namespace {
 struct GemmRecord { hipEvent_t e0, e1; double flops; int dt, M, N, K; };
@@ -417,7 +556,8 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     // tile configuration: 128x128 tiles, 2 workgroups/CU, 2-stage ring.  MADTP_GEMM_CFG=2/3/4 selects the
     // experimental 64x64x6 / 128x128x3 / 128x128x4 variants (kept for A/B measurements).
     int cfg = 0;  // measured on MI355X: the 64x64 / deeper-ring variants lose to 128x128x2 on every shape of the path
-    if (force_cfg > 0) cfg = force_cfg - 1;
+    const bool pp_ok = ab_dtype == MADTP_BF16 && splitk == 1;
+    if (force_cfg > 0 && force_cfg <= 4) cfg = force_cfg - 1;
     hipStream_t s = (hipStream_t)stream;
     const bool lp = c_dtype == MADTP_BF16;
     GemmRecord rec;
@@ -450,7 +590,24 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         else if (cfg == 2) MADTP_LAUNCH_GEMM(TT, LP, 128, 128, 3, 1);          \
         else MADTP_LAUNCH_GEMM(TT, LP, 128, 128, 4, 1);                        \
     } while (0)
-    if (ab_dtype == MADTP_BF16) {
+    if (pp_ok && (force_cfg == 5)) {
+        // ping-pong 256x128 kernel (one 8-wave workgroup per CU, 144 KiB LDS ring)
+        g.ntm = (M + 255) / 256;
+        g.ntn = (N + 127) / 128;
+        const int slots_max = ((g.ntm + 7) / 8) * g.ntn;
+        const int grid = 8 * (slots_max < 32 ? slots_max : 32);
+        const size_t lds = (size_t)3 * (2 * 128 + 128) * ROWB;
+        static bool attr_pp = false;
+        if (!attr_pp) {
+            hipError_t e1 = hipFuncSetAttribute((const void*)gemm_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e2 = hipFuncSetAttribute((const void*)gemm_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e1 != hipSuccess) return (int)e1;
+            if (e2 != hipSuccess) return (int)e2;
+            attr_pp = true;
+        }
+        if (lp) hipLaunchKernelGGL(gemm_pp_kernel<true>, dim3(grid), dim3(512), lds, s, g);
+        else hipLaunchKernelGGL(gemm_pp_kernel<false>, dim3(grid), dim3(512), lds, s, g);
+    } else if (ab_dtype == MADTP_BF16) {
         if (lp) MADTP_DISPATCH_CFG(bf16_t, true); else MADTP_DISPATCH_CFG(bf16_t, false);
     } else {
         if (lp) MADTP_DISPATCH_CFG(float, true); else MADTP_DISPATCH_CFG(float, false);
