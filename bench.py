@@ -39,6 +39,17 @@ def gemm_summary(rows, dtype):
     return sum(r["ms"] for r in sel), sum(r["flops"] for r in sel), sum(r["launches"] for r in sel)
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (collected and corrected
+    as MI355X_MICROARCH.md prescribes: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled on gfx950); produced
+    by tools/rocpd_pmc.py, see profiles/.  None when no such file is present."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_gemm_bf16.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
 def gemm_breakdown(rows, steps):
     out = []
     for r in sorted(rows, key=lambda r: -r["ms"]):
@@ -129,8 +140,12 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
             ms32, fl32, cnt32 = gemm_summary(prof_rows, "f32") if args.precision == "bf16" else (0, 0, 0)
+            pmc = pmc_traffic() if args.precision == "bf16" else None
+            alg_bytes = sum(r["bytes"] for r in prof_rows if r["dtype"] == ("bf16" if args.precision == "bf16" else "f32"))
             roof = {"bound": "mfma", "kernel": f"gemm_kernel<{args.precision}> (madtp_gemm)", "achieved": round(ach, 1),
-                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+                    "algorithmic_bytes_per_launch": round(alg_bytes / cnt),
                     "launches_per_step": cnt // args.steps, "gemm_ms_per_step": round(ms / args.steps, 3),
                     "avg_launch_us": round(1e3 * ms / cnt, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
                     "instrumented_ms_per_step": round(1e3 * instr_elapsed / args.steps, 3),

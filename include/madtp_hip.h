@@ -60,7 +60,7 @@ int madtp_splitk_ln(const float* part, int splits, const float* bias, const floa
 
 /* Optional profiling of madtp_gemm launches with HIP events recorded on the launch stream (bench.py roofline leg).
  * madtp_profile_begin() starts recording; madtp_profile_end() stops, waits for the events and writes one line per
- * (dtype, M, N, K): "dtype M N K launches total_ms flops" into buf; returns the bytes written. */
+ * (dtype, M, N, K): "dtype M N K launches total_ms flops algorithmic_bytes" into buf; returns the bytes written. */
 int madtp_profile_begin(void);
 int madtp_profile_end(char* buf, int cap);
 

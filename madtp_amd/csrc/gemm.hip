@@ -473,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
 
 // ---- optional HIP-event profiling of every GEMM launch (bench.py's roofline leg) -----------------------------------
 namespace {
-struct GemmRecord { hipEvent_t e0, e1; double flops; int dt, M, N, K; };
+struct GemmRecord { hipEvent_t e0, e1; double flops, bytes; int dt, M, N, K; };
 bool g_prof_on = false;
 std::vector<GemmRecord> g_prof;
 }  // namespace
@@ -486,24 +486,24 @@ extern "C" int madtp_profile_begin(void) {
 }
 
 // Stops recording, waits for the recorded events and writes one text line per (dtype, M, N, K):
-// "dtype M N K launches total_ms flops".  Returns the number of bytes written (0 if nothing was recorded).
+// "dtype M N K launches total_ms flops algorithmic_bytes".  Returns the number of bytes written (0 if nothing was recorded).
 extern "C" int madtp_profile_end(char* buf, int cap) {
     g_prof_on = false;
-    std::map<std::tuple<int, int, int, int>, std::tuple<int, double, double>> agg;
+    std::map<std::tuple<int, int, int, int>, std::tuple<int, double, double, double>> agg;
     for (auto& r : g_prof) {
         float ms = 0.f;
         if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
             auto& a = agg[std::make_tuple(r.dt, r.M, r.N, r.K)];
-            std::get<0>(a) += 1; std::get<1>(a) += ms; std::get<2>(a) += r.flops;
+            std::get<0>(a) += 1; std::get<1>(a) += ms; std::get<2>(a) += r.flops; std::get<3>(a) += r.bytes;
         }
         hipEventDestroy(r.e0); hipEventDestroy(r.e1);
     }
     g_prof.clear();
     int off = 0;
     for (auto& kv : agg) {
-        const int n = snprintf(buf + off, cap > off ? cap - off : 0, "%d %d %d %d %d %.6f %.0f\n", std::get<0>(kv.first),
+        const int n = snprintf(buf + off, cap > off ? cap - off : 0, "%d %d %d %d %d %.6f %.0f %.0f\n", std::get<0>(kv.first),
                                std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first), std::get<0>(kv.second),
-                               std::get<1>(kv.second), std::get<2>(kv.second));
+                               std::get<1>(kv.second), std::get<2>(kv.second), std::get<3>(kv.second));
         if (n < 0 || off + n >= cap) break;
         off += n;
     }
@@ -564,6 +564,9 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     if (g_prof_on) {
         hipEventCreate(&rec.e0); hipEventCreate(&rec.e1);
         rec.flops = 2.0 * M * N * K; rec.dt = ab_dtype; rec.M = M; rec.N = N; rec.K = K;
+        // algorithmic HBM bytes: A and W once, C once (x splits), bias, residual once
+        rec.bytes = (double)esz * ((double)M * K + (double)N * K) + (double)M * N * (c_dtype == MADTP_BF16 ? 2 : 4) * splitk +
+                    (bias ? 4.0 * N : 0.0) + (residual ? 4.0 * M * N : 0.0);
         hipEventRecord(rec.e0, s);
     }
 #define MADTP_LAUNCH_GEMM(TT, LP, BM_, BN_, ST_, WGCU)                                                                   \

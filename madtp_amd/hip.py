@@ -452,9 +452,9 @@ def profile_end():
     n = load().madtp_profile_end(buf, len(buf))
     rows = []
     for line in buf.raw[:n].decode().splitlines():
-        dt, M, N, K, c, ms, fl = line.split()
+        dt, M, N, K, c, ms, fl, by = line.split()
         rows.append({"dtype": "bf16" if int(dt) == BF16 else "f32", "M": int(M), "N": int(N), "K": int(K),
-                     "launches": int(c), "ms": float(ms), "flops": float(fl)})
+                     "launches": int(c), "ms": float(ms), "flops": float(fl), "bytes": float(by)})
     return rows
 
 
