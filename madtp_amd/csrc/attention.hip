@@ -394,6 +394,151 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Short-sequence self-attention with scores (Nq = Nk <= 32: the 20-token text side of NLVR).  With one or two 16-row
+// query tiles the general kernel leaves half its waves idle and serialises 12 heads behind block barriers.  Here a
+// workgroup is one sample and every wave is independent: wave w takes heads w, w+4, w+8 for BOTH query tiles, reads K
+// and Q fragments straight from global memory, stages V_h (<= 32 x 64 bf16 = 4 KiB) in its private LDS slice for the
+// transpose reads, and keeps its partial head-max in registers; the four partial maxima are combined through LDS once.
+__global__ __launch_bounds__(256, 2) void attn_bf16_small_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char vbuf[4][32 * 128];
+    __shared__ float pm[4][2][2][64][4];  // [wave][row tile][key tile][lane][r]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x;
+    const int N = a.Nk;
+    char* Vs = vbuf[wave];
+    f32x4 pmax[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) pmax[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nrt = (N + 15) / 16;
+
+    for (int h = wave; h < a.H; h += 4) {
+        // V_h rows -> private LDS (row-major 128-byte rows, chunk ^= 2*((row>>1)&3) as in the general kernel)
+        {
+            const int sub = lane >> 3, pos = lane & 7;
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                int row = grp * 8 + sub;
+                const int chunk = pos ^ (((row >> 1) & 3) << 1);
+                row = row < N ? row : N - 1;
+                *(bf16x8*)(Vs + grp * 1024 + lane * 16) =
+                    *(const bf16x8*)(a.v + (((size_t)b * N + row) * a.ldv + h * 64) * 2 + chunk * 16);
+            }
+        }
+        // K fragments (A operand): key row j = 16t + l16, d = 32kk + 8g .. +7, straight from global
+        bf16x8 kf[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = min(16 * t + l16, N - 1);
+            const char* kp = a.k + (((size_t)b * N + j) * a.ldk + h * 64) * 2 + g * 16;
+            kf[t][0] = *(const bf16x8*)kp;
+            kf[t][1] = *(const bf16x8*)(kp + 64);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            if (rt >= nrt) break;
+            const int i0 = rt * 16;
+            const int irow = min(i0 + l16, N - 1);
+            const char* qp = a.q + (((size_t)b * N + irow) * a.ldq + h * 64) * 2 + g * 16;
+            const bf16x8 q0 = *(const bf16x8*)qp, q1 = *(const bf16x8*)(qp + 64);
+            f32x4 sc[2];
+            float m = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], q0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], q1, acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * t + 4 * g + r;
+                    float v = acc[r] * a.scale;
+                    if (a.mask && j < N) v += a.mask[(size_t)b * N + j];
+                    v = j < N ? v : -INFINITY;
+                    acc[r] = v;
+                    m = fmaxf(m, v);
+                }
+                sc[t] = acc;
+            }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sc[t][r] = __expf(sc[t][r] - m); sum += sc[t][r]; }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                sc[t] *= inv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pmax[rt][t][r] = fmaxf(pmax[rt][t][r], sc[t][r]);
+            }
+            if (i0 + l16 == 0) {
+                float* dst = a.p0 + ((size_t)b * a.H + h) * N;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * t + 4 * g + r;
+                        if (j < N) dst[j] = sc[t][r];
+                    }
+            }
+            // O^T = V^T P^T (operands swapped): lane (i = l16, g) gets columns 16dt + 4g .. +3 of row i
+            const bf16x8 pa = pack_bf16x8(sc[0], sc[1]);
+            const int vrow = 4 * g + (l16 >> 2);
+            const int vkey = ((vrow >> 1) & 3) << 1;
+            const char* vr = Vs + vrow * 128 + 8 * (l16 & 1);
+            f32x4 o[4];
+            float n2 = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int p = ((2 * dt + ((l16 & 3) >> 1)) ^ vkey) << 4;
+                const bf16x8 vb = cat_bf16x4(lds_read_tr16(vr + p), lds_read_tr16(vr + 16 * 128 + p));
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) n2 += o[dt][r] * o[dt][r];
+            }
+            n2 += __shfl_xor(n2, 16, 64);
+            n2 += __shfl_xor(n2, 32, 64);
+            const int i = i0 + l16;
+            if (i < N) {
+                bf16_t* orow = (bf16_t*)(a.out + (((size_t)b * N + i) * a.ldo + h * 64) * 2) + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + dt * 16) = pack_bf16x4(o[dt]);
+                if (g == 0) a.onorm[((size_t)b * a.H + h) * N + i] = sqrtf(n2);
+            }
+        }
+    }
+    // combine the per-wave partial head-max, then the column mass per 16-row tile
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pm[wave][rt][t][lane][r] = pmax[rt][t][r];
+    __syncthreads();
+    if (wave < nrt) {  // wave w finishes row tile w
+        const int rt = wave, i = rt * 16 + l16;
+        const bool valid = i >= 1 && i < N;
+        float* dst = a.colsum + ((size_t)b * a.nrt + rt) * N;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaxf(fmaxf(pm[0][rt][t][lane][r], pm[1][rt][t][lane][r]), fmaxf(pm[2][rt][t][lane][r], pm[3][rt][t][lane][r]));
+                v = row16_sum(valid ? v : 0.f);
+                const int j = 16 * t + 4 * g + r;
+                if (l16 == 0 && j < N) dst[j] = v;
+            }
+    }
+}
+
 template <int NT, bool SCORES>
 int launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     constexpr int NC = (NT + 1) / 2;
@@ -706,5 +851,10 @@ extern "C" int madtp_attention(const void* q, const void* k, const void* v, void
     }
     if (io_dtype == MADTP_F32) return scores ? dispatch_nt<float, true>(a, s) : dispatch_nt<float, false>(a, s);
     if ((ldk * 2) % 16 || (ldv * 2) % 16) return MADTP_E_ALIGN;
+    if (scores && Nk <= 32) {  // short text sequences: one sample per workgroup, heads spread over the waves
+        hipLaunchKernelGGL(attn_bf16_small_kernel, dim3(B), dim3(256), 0, s, a);
+        MADTP_LAUNCH_CHECK();
+        return 0;
+    }
     return scores ? dispatch_nt_bf16<true>(a, s) : dispatch_nt_bf16<false>(a, s);
 }

@@ -504,17 +504,24 @@ __global__ __launch_bounds__(256, 2) void align_logits_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        // this lane's x slice of the slab: k = 64kt + 32kk + 8g .. +7
-        f32x4 xa[2][2];
+    // this lane's x slice of a slab: k = 64kt + 32kk + 8g .. +7; fetched one slab ahead (software pipelining) so the HBM
+    // latency of the f32 rows hides under the previous slab's MFMAs
+    f32x4 xn[2][2];
+    auto load_x = [&](int kt) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const float* p = xr + kt * 64 + kk * 32 + g * 8;
-            xa[kk][0] = *(const f32x4*)p;
-            xa[kk][1] = *(const f32x4*)(p + 4);
+            xn[kk][0] = *(const f32x4*)p;
+            xn[kk][1] = *(const f32x4*)(p + 4);
         }
+    };
+    load_x(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        f32x4 xa[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) { xa[kk][0] = xn[kk][0]; xa[kk][1] = xn[kk][1]; }
         __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < nk) { stage(kt + 1, (kt + 1) & 1); load_x(kt + 1); }
         const char* sh = smem + (kt & 1) * 2 * AL_TILE;
         const char* sl = sh + AL_TILE;
 #pragma unroll
