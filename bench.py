@@ -218,6 +218,34 @@ def parity_report(model, harness, runtime, T, precision, B=8, seed=11):
             pairs, eq, jac = pairs + p, eq + e, jac + j
         rep[mode] = {"kept_set_exact_match": round(eq / max(1, pairs), 4), "mean_jaccard": round(jac / max(1, pairs), 4),
                      "sample_layer_pairs": pairs, "max_abs_dlogit": round((logits.cpu() - ref_logits).abs().max().item(), 6)}
+    # teacher-forced per-layer decisions of the ViT: every block is fed the ORACLE's input of that layer, so one early flip
+    # does not cascade into all later layers (the free-running numbers above do cascade)
+    xs, vtr = [], []
+    with torch.no_grad():
+        O.vit_forward(W, "visual_encoder.", images.cpu(), W["space_dict"], T, trace=vtr, layer_inputs=xs)
+    venc = model.visual_encoder
+    for mode in sorted({"fp32", precision}):
+        pairs = eq = 0
+        jac = 0.0
+        with runtime.precision(mode), torch.no_grad():
+            for l, blk in enumerate(venc.blocks):
+                if vtr[l] is None or not vtr[l]["pruned"]:
+                    continue
+                x = xs[l].cuda().contiguous()
+                ta, _, _ = venc.img_query_model(x[:, 1:, :], model.space_dict, return_token_att=True)
+                blk(x, False, 0, T, ta)
+                mine = blk.last_prune
+                if mine is None or not mine["pruned"]:
+                    pairs += x.shape[0]
+                    continue
+                a, b = mine["indices"].cpu().numpy(), vtr[l]["indices"].numpy()
+                for r in range(x.shape[0]):
+                    sa, sb = set(a[r].tolist()), set(b[r].tolist())
+                    pairs += 1
+                    eq += int(sa == sb)
+                    jac += len(sa & sb) / max(1, len(sa | sb))
+        rep[mode]["vit_layerwise_exact_match"] = round(eq / max(1, pairs), 4)
+        rep[mode]["vit_layerwise_jaccard"] = round(jac / max(1, pairs), 4)
     return rep
 
 
