@@ -43,15 +43,23 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// LDS swizzle key of a tile row: the 16-byte chunk index of row r is XORed with key(r).  Consecutive fragment rows use
+// r&7.  The bf16-output kernels read W fragments through the permuted row map of wfrag_row<true> (rows 8a+b+const), for
+// which r&7 repeats every 8 rows and costs a 2-way bank conflict; PERM keys on bits 1,3,4 instead (conflict-free,
+// checked with the ds_read_b128 lane-group model of MI355X_MICROARCH.md).
+template <bool PERM>
+__device__ __forceinline__ int swz_key(int r) { return PERM ? (((r >> 1) & 1) | (((r >> 3) & 3) << 1)) : (r & 7); }
+
 // issue the LDS-DMA of one ROWS x 128 B operand tile: ROWS/8 wave-instructions of 1 KiB, ROWS/32 per wave
-template <int ESZ, int ROWS>
+// (tile_row0: row of the tile this piece starts at - the swizzle key is a function of the row WITHIN the tile)
+template <int ESZ, int ROWS, bool PERM = false>
 __device__ __forceinline__ void stage_tile(const char* base, int row0, int max_row, int ld_elems, int kbyte0,
-                                           char* lds_tile, int wave, int lane) {
+                                           char* lds_tile, int wave, int lane, int tile_row0 = 0) {
     const int sub = lane >> 3;                       // row within the 8-row group
-    const int chunk = (lane & 7) ^ sub;              // inverse swizzle on the SOURCE
 #pragma unroll
     for (int q = 0; q < ROWS / 32; ++q) {
         const int grp = wave * (ROWS / 32) + q;
+        const int chunk = (lane & 7) ^ swz_key<PERM>(tile_row0 + grp * 8 + sub);  // inverse swizzle on the SOURCE
         int row = row0 + grp * 8 + sub;
         row = row < max_row ? row : max_row;
         const char* src = base + ((size_t)row * ld_elems) * ESZ + kbyte0 + chunk * 16;
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int rb = wc * (BN / 2) + wfrag_row<LP_OUT>(j, l16);
-        b_off[j] = rb * ROWB; b_key[j] = rb & 7;
+        b_off[j] = rb * ROWB; b_key[j] = swz_key<LP_OUT>(rb);
     }
 
     // The operand slabs of ALL tiles of this workgroup form one continuous stream through a ring of STAGES LDS
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
         if (issued < total_slabs && !(g.dbg & 2)) {
             char* st = smem + is_stage * STAGE_BYTES;
             stage_tile<ESZ, BM>(g.A, im0, g.M - 1, g.lda, (ikb + is_kt) * ROWB, st, wave, lane);
-            stage_tile<ESZ, BN>(g.W, in0, n_pad_max, g.ldw, (ikb + is_kt) * ROWB, st + A_BYTES, wave, lane);
+            stage_tile<ESZ, BN, LP_OUT>(g.W, in0, n_pad_max, g.ldw, (ikb + is_kt) * ROWB, st + A_BYTES, wave, lane);
         }
         ++issued;  // phantom slabs past the end keep the wait counts uniform (they issue nothing: see tail wait)
         if (++is_stage == STAGES) is_stage = 0;
@@ -386,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         const int ra = wr * 64 + i * 16 + l16;
         a_off[i] = grp * A_BYTES + ra * ROWB; a_key[i] = ra & 7;
         const int rb = wc * 64 + wfrag_row<LP_OUT>(i, l16);
-        b_off[i] = 2 * A_BYTES + rb * ROWB; b_key[i] = rb & 7;
+        b_off[i] = 2 * A_BYTES + rb * ROWB; b_key[i] = swz_key<LP_OUT>(rb);
     }
 
     const int my_slots = (nslots - lb + gl - 1) / gl;
@@ -395,10 +403,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
     int im0 = ((is_slot / g.ntn) * 8 + xcd) * 256, in0 = (is_slot % g.ntn) * BN;
     long issued = 0;
     auto issue_next = [&]() {  // this wave's share of the next slab: 4 x own A half + 2 x half of W
-        if (issued < total_slabs) {
+        if (issued < total_slabs && !(g.dbg & 2)) {
             char* st = smem + is_stage * STAGE_BYTES;
             stage_tile<ESZ, 128>(g.A, im0 + grp * BMG, g.M - 1, g.lda, is_kt * ROWB, st + grp * A_BYTES, wave, lane);
-            stage_tile<ESZ, 64>(g.W, in0 + grp * 64, n_pad_max, g.ldw, is_kt * ROWB, st + 2 * A_BYTES + grp * 64 * ROWB, wave, lane);
+            stage_tile<ESZ, 64, LP_OUT>(g.W, in0 + grp * 64, n_pad_max, g.ldw, is_kt * ROWB, st + 2 * A_BYTES + grp * 64 * ROWB, wave,
+                                        lane, grp * 64);
         }
         ++issued;
         if (++is_stage == STAGES) is_stage = 0;
@@ -440,6 +449,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
             __builtin_amdgcn_s_barrier();
             // ---------------- COMPUTE(s) ----------------
             __builtin_amdgcn_s_setprio(1);
+            if (!(g.dbg & 4))
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -448,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
-            if (kt == nk - 1) {  // tile finished for this group: epilogue straight from the accumulators
+            if (kt == nk - 1 && !((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {  // tile finished: epilogue from the accumulators
                 switch (g.act) {
                     case MADTP_ACT_GELU_ERF: epilogue<LP_OUT, MADTP_ACT_GELU_ERF, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
                     case MADTP_ACT_QUICK_GELU: epilogue<LP_OUT, MADTP_ACT_QUICK_GELU, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
