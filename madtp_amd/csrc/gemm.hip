@@ -50,6 +50,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 template <bool PERM>
 __device__ __forceinline__ int swz_key(int r) { return PERM ? (((r >> 1) & 1) | (((r >> 3) & 3) << 1)) : (r & 7); }
 
+// Balanced XCD-aware tile partition: the ntm*ntn output tiles are numbered row-panel major (t = panel*ntn + column tile)
+// and XCD x (workgroups with blockIdx%8 == x) owns the contiguous range [x*T/8, (x+1)*T/8): every XCD gets T/8 tiles
+// +-1 (no 8-panel quantisation), the column tiles of an A panel are walked back-to-back by neighbouring workgroups of
+// one XCD (the panel is fetched from HBM once and then hits that XCD's L2), and W streams from L2 / Infinity Cache.
+__device__ __forceinline__ void xcd_tiles(int T, int xcd, int& t0, int& nt) {
+    t0 = (int)(((long)xcd * T) >> 3);
+    nt = (int)(((long)(xcd + 1) * T) >> 3) - t0;
+}
+
 // issue the LDS-DMA of one ROWS x 128 B operand tile: ROWS/8 wave-instructions of 1 KiB, ROWS/32 per wave
 // (tile_row0: row of the tile this piece starts at - the swizzle key is a function of the row WITHIN the tile)
 template <int ESZ, int ROWS, bool PERM = false>
@@ -69,20 +78,27 @@ __device__ __forceinline__ void stage_tile(const char* base, int row0, int max_r
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// fast erf for outputs that are rounded to bf16 anyway: Abramowitz-Stegun 7.1.26, |err| < 2e-7 (+ fast exp/rcp)
+// GELU for outputs that are rounded to bf16 anyway (fast mode only; the f32 path keeps erff):
+//   gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) ~= x * sigmoid(x (a + b x^2 + c x^4)),   x^2 clamped to 25,
+// a, b, c fitted (minimax on [-8, 8]) to a maximum ABSOLUTE error of 2.6e-5 - a tenth of a bf16 ulp at |y| = 0.06 -
+// for 7 VALU + 2 transcendental instructions per element (the erf form costs twice that, and with one
+// 64-accumulator epilogue per 12 K slabs the activation is a visible part of the fc1 GEMM).
 __device__ __forceinline__ float gelu_fast(float v) {
-    const float x = fabsf(v) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * x);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * __expf(-x * x);
-    return 0.5f * v * (1.0f + copysignf(erf_abs, v));
+    constexpr float L2E = 1.4426950408889634f;
+    const float x2 = fminf(v * v, 25.0f);
+    float p = fmaf(x2, 7.03033581e-04f * L2E, -7.40112921e-02f * L2E);
+    p = fmaf(x2, p, -1.59501577f * L2E);
+    const float e = __builtin_amdgcn_exp2f(v * p);  // exp(-u); +inf for very negative v -> rcp = 0 -> -0
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // compile-time activation: the epilogue is instantiated per activation code so it stays straight-line code
 template <bool LP_OUT, int ACT>
 __device__ __forceinline__ float epi_act(float v) {
     if constexpr (ACT == MADTP_ACT_GELU_ERF) return LP_OUT ? gelu_fast(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    else if constexpr (ACT == MADTP_ACT_QUICK_GELU) return v / (1.0f + expf(-1.702f * v));
+    else if constexpr (ACT == MADTP_ACT_QUICK_GELU)
+        return LP_OUT ? v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v))
+                      : v / (1.0f + expf(-1.702f * v));
     else if constexpr (ACT == MADTP_ACT_RELU) return fmaxf(v, 0.0f);
     else return v;
 }
@@ -185,14 +201,14 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // Persistent, XCD-aware tile schedule: block b runs on XCD b%8 (observed dispatch rule; only speed depends on
-    // it).  XCD x owns row panels x, x+8, ... and walks (panel, column tile) slots in order, so an A panel is
-    // fetched from HBM once and then served by that XCD's L2 to the workgroups computing its other column tiles.
+    // it); XCD x owns the tile range of xcd_tiles() and its workgroups walk it round-robin.
     const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, gl = gridDim.x >> 3;
-    const int npanel = (g.ntm - xcd + 7) >> 3;
+    int t0, ntile_x;
+    xcd_tiles(g.ntm * g.ntn, xcd, t0, ntile_x);
     // split-K (small-M problems): every output tile is cut into g.splitk K ranges, each its own slot; a slot stores its
     // raw f32 partial tile to C + split*M*ldc and a row kernel (madtp_splitk_ln) reduces them in a fixed order.
     const int S = g.splitk;
-    const int nslots = npanel * g.ntn * S;
+    const int nslots = ntile_x * S;
     int slot = lb;
     if (slot >= nslots) return;
 
@@ -232,8 +248,8 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
     const int my_slots = (nslots - lb + gl - 1) / gl;
     const long total_slabs = (long)my_slots * nk;
     auto decode = [&](int sl, int& tm0, int& tn0, int& kb) {
-        const int ts = sl / S, sp = sl - ts * S;
-        tm0 = ((ts / g.ntn) * 8 + xcd) * BM; tn0 = (ts % g.ntn) * BN; kb = sp * nk;
+        const int ts = sl / S, sp = sl - ts * S, t = t0 + ts;
+        tm0 = (t / g.ntn) * BM; tn0 = (t % g.ntn) * BN; kb = sp * nk;
     };
     int is_slot = slot, is_kt = 0, is_stage = 0;  // coordinates / ring stage of the next slab to issue
     int im0, in0, ikb;
@@ -346,139 +362,162 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
-// "Ping-pong" bf16 kernel for the big GEMMs: 256x128 output tile, 512 threads = two groups of four waves.  Group g
-// owns the 128x128 half tile of rows [128g, 128g+128) (the same 2x2 wave layout and fragment code as above); the W
-// slab is SHARED by the two groups, so a K slab costs 48 KiB of LDS-DMA instead of 2 x 32 KiB, and a 3-stage ring
-// (144 KiB) fits.  The groups run the same instruction stream ONE PHASE APART:
-//     phase 2i   : group 0 LOAD(i)    (16 x ds_read_b128 of slab i -> registers, issue its share of slab i+2's DMA)
-//                  group 1 COMPUTE(i-1) (32 MFMAs from registers only)
-//     phase 2i+1 : group 0 COMPUTE(i),  group 1 LOAD(i)
-// Each SIMD hosts one wave of each group (waves 0-3 and 4-7 are dealt over the four SIMDs), so while one wave keeps the
-// matrix pipe busy its partner issues LDS reads and DMA - the overlap the two-independent-workgroup kernel only gets by
-// chance.  Phases are separated by raw s_barrier; LDS-DMA completion is tracked with counted s_waitcnt vmcnt:
-//   RAW: slab i's shares were issued 4 phases before its first read; every wave waits for its own share (vmcnt(PER):
-//        all but the newest share) at the end of an ODD phase, i.e. before the barrier that precedes LOAD(i) of group 0;
-//   WAR: slab i+2 overwrites the stage of slab i-1, whose last ds_reads (group 1, phase 2i-1) are drained with
-//        lgkmcnt(0) before the barrier that ends that phase.
+// Wave-specialised bf16 kernel for the big GEMMs: 256x128 output tile, one 768-thread workgroup per CU =
+//   8 CONSUMER waves (4x2, 64x64 each: ds_read_b128 fragments -> MFMA -> epilogue stores, never touch vmcnt) and
+//   4 LOADER waves (address generation + LDS-DMA of the operand slabs + counted vmcnt waits, no MFMA).
+// Why: (a) the 256-row tile shares one W slab between two 128-row halves, so the L2->LDS volume per flop drops by a
+// quarter versus two independent 128x128 workgroups (the 128x128 kernel's DMA stream alone runs at ~20 TB/s of L2
+// bandwidth, as long as its MFMA phase); (b) a 3-stage ring (144 KiB) keeps TWO slabs in flight; (c) gfx950 counts
+// loads and stores in ONE vmcnt, so in the unspecialised kernel the first slab wait after an epilogue also drains the
+// tile's output stores - here the stores belong to waves that never wait on vmcnt; (d) the consumers' issue slots are
+// not spent on DMA address arithmetic.  One s_barrier per slab synchronises all twelve waves:
+//   loader  : wait own DMAs of slab s (vmcnt(PER): only slab s+1 may still fly) -> barrier s -> issue slab s+2
+//             into the stage slab s-1 used (every consumer finished reading it before it arrived at barrier s)
+//   consumer: barrier s -> 16 x ds_read_b128 + 32 x MFMA on slab s
 // The slab stream is persistent across the workgroup's tiles exactly as in gemm_kernel.
 template <bool LP_OUT>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
-    constexpr int ESZ = 2, BMG = 128, BN = 128, STAGES = 3;
-    constexpr int A_BYTES = BMG * ROWB, STAGE_BYTES = (2 * BMG + BN) * ROWB;  // A0 | A1 | W
-    constexpr int PER = 6;  // DMA instructions per wave per slab share: 4 (own A half) + 2 (half of W)
+__global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
+    constexpr int ESZ = 2, BM = 256, BN = 128, STAGES = 3, NCW = 8, NLW = 4;
+    constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int PER = (BM + BN) / 8 / NLW;  // 1 KiB DMA instructions per loader wave per slab (12)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, gl = gridDim.x >> 3;
-    const int npanel = (g.ntm - xcd + 7) >> 3;
-    const int nslots = npanel * g.ntn;
-    int slot = lb;
-    if (slot >= nslots) return;
+    int t0, nslots;
+    xcd_tiles(g.ntm * g.ntn, xcd, t0, nslots);
+    if (lb >= nslots) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave8 >> 2, wave = wave8 & 3;  // group, wave within the group
-    const int wr = wave >> 1, wc = wave & 1;
-    const int l16 = lane & 15, grp4 = lane >> 4;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = g.K * ESZ / ROWB;
-    const int n_pad_max = g.ntn * BN - 1;
+    const int my_slots = (nslots - lb + gl - 1) / gl;
+    const long total_slabs = (long)my_slots * nk;
+
+    if (wave >= NCW) {
+        // ------------------------------------------ loader ------------------------------------------
+        const int lw = wave - NCW, sub = lane >> 3;
+        const int n_pad_max = g.ntn * BN - 1;
+        int is_slot = lb, is_kt = 0, is_stage = 0;
+        long issued = 0;
+        const char* srcp[PER];  // per-lane source of each DMA instruction at k = 0 of the current tile
+        auto tile_ptrs = [&]() {
+            const int t = t0 + is_slot;
+            const int im0 = (t / g.ntn) * BM, in0 = (t % g.ntn) * BN;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int idx = lw * PER + q;                     // 8-row group of the stage image: A groups, then W groups
+                const bool is_a = idx < BM / 8;
+                const int r = (is_a ? idx : idx - BM / 8) * 8 + sub;  // row within the A / W tile
+                const int key = is_a ? (r & 7) : swz_key<LP_OUT>(r);
+                int row = (is_a ? im0 : in0) + r;
+                const int lim = is_a ? g.M - 1 : n_pad_max;
+                row = row < lim ? row : lim;
+                srcp[q] = (is_a ? g.A : g.W) + (size_t)row * (is_a ? g.lda : g.ldw) * ESZ + (((lane & 7) ^ key) << 4);
+            }
+        };
+        tile_ptrs();
+        auto issue_next = [&]() {
+            if (issued < total_slabs && !(g.dbg & 2)) {
+                char* st = smem + is_stage * STAGE_BYTES + lw * PER * 1024;
+#pragma unroll
+                for (int q = 0; q < PER; ++q)
+                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(srcp[q] + is_kt * ROWB), LDS_PTR(st + q * 1024), 16, 0, 0);
+            }
+            ++issued;
+            if (++is_stage == STAGES) is_stage = 0;
+            if (++is_kt == nk) {
+                is_kt = 0;
+                is_slot += gl;
+                if (issued < total_slabs) tile_ptrs();
+            }
+        };
+        issue_next();
+        issue_next();
+        for (long s = 0; s < total_slabs; ++s) {
+            if (s + STAGES - 1 <= total_slabs) wait_vmcnt<(STAGES - 2) * PER>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            issue_next();
+        }
+        return;
+    }
+
+    // ------------------------------------------ consumer ------------------------------------------
+    const int grp = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
+    const int l16 = lane & 15, grp4 = lane >> 4;
+    f32x4 acc[4][4];
     int a_off[4], a_key[4], b_off[4], b_key[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int ra = wr * 64 + i * 16 + l16;
-        a_off[i] = grp * A_BYTES + ra * ROWB; a_key[i] = ra & 7;
+        const int ra = grp * 128 + wr * 64 + i * 16 + l16;
+        a_off[i] = ra * ROWB; a_key[i] = ra & 7;
         const int rb = wc * 64 + wfrag_row<LP_OUT>(i, l16);
-        b_off[i] = 2 * A_BYTES + rb * ROWB; b_key[i] = swz_key<LP_OUT>(rb);
+        b_off[i] = A_BYTES + rb * ROWB; b_key[i] = swz_key<LP_OUT>(rb);
     }
-
-    const int my_slots = (nslots - lb + gl - 1) / gl;
-    const long total_slabs = (long)my_slots * nk;
-    int is_slot = slot, is_kt = 0, is_stage = 0;
-    int im0 = ((is_slot / g.ntn) * 8 + xcd) * 256, in0 = (is_slot % g.ntn) * BN;
-    long issued = 0;
-    auto issue_next = [&]() {  // this wave's share of the next slab: 4 x own A half + 2 x half of W
-        if (issued < total_slabs && !(g.dbg & 2)) {
-            char* st = smem + is_stage * STAGE_BYTES;
-            stage_tile<ESZ, 128>(g.A, im0 + grp * BMG, g.M - 1, g.lda, is_kt * ROWB, st + grp * A_BYTES, wave, lane);
-            stage_tile<ESZ, 64, LP_OUT>(g.W, in0 + grp * 64, n_pad_max, g.ldw, is_kt * ROWB, st + 2 * A_BYTES + grp * 64 * ROWB, wave,
-                                        lane, grp * 64);
-        }
-        ++issued;
-        if (++is_stage == STAGES) is_stage = 0;
-        if (++is_kt == nk) {
-            is_kt = 0;
-            is_slot += gl;
-            im0 = ((is_slot / g.ntn) * 8 + xcd) * 256; in0 = (is_slot % g.ntn) * BN;
-        }
-    };
-    issue_next();
-    issue_next();
-    if (total_slabs >= 2) wait_vmcnt<PER>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                    // slab 0 landed for everybody
-    if (grp == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one phase behind
-
-    int m0 = ((slot / g.ntn) * 8 + xcd) * 256 + grp * BMG, n0 = (slot % g.ntn) * BN;
-    long s = 0;
+    f32x4 res[1][1];  // the epilogue reads the residual directly
+    // Fragment reads run HALF A SLAB ahead of the MFMAs that use them: X = the kk=0 fragments of slab s are read right
+    // after barrier s and land while the 16 MFMAs on Y = the kk=1 fragments of slab s-1 execute; Y(s) is read while
+    // the MFMAs on X(s) execute.  (Holding Y(s-1) in registers across barrier s is fine: its ds_reads completed
+    // before the barrier, which is what frees the stage for the loaders.)  The loop bodies are straight-line code -
+    // the compiler's s_waitcnt insertion turns conservative at control-flow merges - so a tile's first slab is peeled.
+    bf16x8 xa[4], xb[4], ya[4], yb[4];
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     int cur_stage = 0;
-    f32x4 res[1][1];  // no residual prefetch here (register budget): the epilogue reads the residual directly
-    while (true) {
-        for (int kt = 0; kt < nk; ++kt, ++s) {
-            // ---------------- LOAD(s) ----------------
-            const char* st = smem + cur_stage * STAGE_BYTES;
-            if (++cur_stage == STAGES) cur_stage = 0;
-            bf16x8 a[2][4], b[2][4];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int chunk = kk * 4 + grp4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a[kk][i] = *(const bf16x8*)(st + a_off[i] + ((chunk ^ a_key[i]) << 4));
-                    b[kk][i] = *(const bf16x8*)(st + b_off[i] + ((chunk ^ b_key[i]) << 4));
-                }
-            }
-            issue_next();  // slab s+2 -> the stage slab s-1 used (its reads were drained two phases ago)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers; LDS reads of this stage done
-            if (grp == 1) { if (s + 2 < total_slabs) wait_vmcnt<PER>(); else wait_vmcnt<0>(); }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // ---------------- COMPUTE(s) ----------------
-            __builtin_amdgcn_s_setprio(1);
-            if (!(g.dbg & 4))
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[kk][j], a[kk][i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            if (kt == nk - 1 && !((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {  // tile finished: epilogue from the accumulators
-                switch (g.act) {
-                    case MADTP_ACT_GELU_ERF: epilogue<LP_OUT, MADTP_ACT_GELU_ERF, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
-                    case MADTP_ACT_QUICK_GELU: epilogue<LP_OUT, MADTP_ACT_QUICK_GELU, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
-                    case MADTP_ACT_RELU: epilogue<LP_OUT, MADTP_ACT_RELU, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
-                    default: epilogue<LP_OUT, MADTP_ACT_NONE, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            if (grp == 0) { if (s + 2 < total_slabs) wait_vmcnt<PER>(); else wait_vmcnt<0>(); }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-        }
-        slot += gl;
-        if (slot >= nslots) break;
-        m0 = ((slot / g.ntn) * 8 + xcd) * 256 + grp * BMG; n0 = (slot % g.ntn) * BN;
+#define MADTP_WS_READ(XA, XB, CH)                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+        XA[i] = *(const bf16x8*)(st + a_off[i] + ((((CH) + grp4) ^ a_key[i]) << 4));      \
+        XB[i] = *(const bf16x8*)(st + b_off[i] + ((((CH) + grp4) ^ b_key[i]) << 4));      \
     }
-    if (grp == 0) __builtin_amdgcn_s_barrier();  // balances group 1's extra barrier at the start
+#define MADTP_WS_MFMA(XA, XB)                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(XB[j], XA[i], acc[i][j], 0, 0, 0);
+    for (int slot = lb; slot < nslots; slot += gl) {
+        {   // first slab of the tile: accumulators start from zero, no Y pending
+            const char* st = smem + cur_stage * STAGE_BYTES;
+            __builtin_amdgcn_s_barrier();  // slab landed (the loaders waited for it before arriving)
+            MADTP_WS_READ(xa, xb, 0)
+            MADTP_WS_READ(ya, yb, 4)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[j], xa[i], zero4, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): Y is in registers, this wave is done with the stage
+            __builtin_amdgcn_sched_barrier(0);
+            if (++cur_stage == STAGES) cur_stage = 0;
+        }
+        for (int kt = 1; kt < nk; ++kt) {
+            const char* st = smem + cur_stage * STAGE_BYTES;
+            __builtin_amdgcn_s_barrier();
+            MADTP_WS_READ(xa, xb, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            MADTP_WS_MFMA(ya, yb)
+            __builtin_amdgcn_sched_barrier(0);
+            MADTP_WS_READ(ya, yb, 4)
+            __builtin_amdgcn_sched_barrier(0);
+            MADTP_WS_MFMA(xa, xb)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            if (++cur_stage == STAGES) cur_stage = 0;
+        }
+        MADTP_WS_MFMA(ya, yb)
+        if (!((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {
+            const int t = t0 + slot;
+            const int m0 = (t / g.ntn) * BM + grp * 128, n0 = (t % g.ntn) * BN;
+            switch (g.act) {
+                case MADTP_ACT_GELU_ERF: epilogue<LP_OUT, MADTP_ACT_GELU_ERF, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
+                case MADTP_ACT_QUICK_GELU: epilogue<LP_OUT, MADTP_ACT_QUICK_GELU, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
+                case MADTP_ACT_RELU: epilogue<LP_OUT, MADTP_ACT_RELU, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
+                default: epilogue<LP_OUT, MADTP_ACT_NONE, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
+            }
+        }
+    }
+#undef MADTP_WS_READ
+#undef MADTP_WS_MFMA
 }
 
 // ---- optional HIP-event profiling of every GEMM launch (bench.py's roofline leg) -----------------------------------
@@ -566,7 +605,8 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     // tile configuration: 128x128 tiles, 2 workgroups/CU, 2-stage ring.  MADTP_GEMM_CFG=2/3/4 selects the
     // experimental 64x64x6 / 128x128x3 / 128x128x4 variants (kept for A/B measurements).
     int cfg = 0;  // measured on MI355X: the 64x64 / deeper-ring variants lose to 128x128x2 on every shape of the path
-    const bool pp_ok = ab_dtype == MADTP_BF16 && splitk == 1;
+    // MADTP_GEMM_CFG=5 forces the wave-specialised kernel, 1..4 force a gemm_kernel variant (A/B measurements)
+    const bool ws_ok = ab_dtype == MADTP_BF16 && splitk == 1 && (force_cfg == 5 || (force_cfg == 0 && M >= 4096));
     if (force_cfg > 0 && force_cfg <= 4) cfg = force_cfg - 1;
     hipStream_t s = (hipStream_t)stream;
     const bool lp = c_dtype == MADTP_BF16;
@@ -583,7 +623,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     do {                                                                                                               \
         g.ntm = (M + BM_ - 1) / BM_;                                                                                   \
         g.ntn = (N + BN_ - 1) / BN_;                                                                                   \
-        const int slots_max = ((g.ntm + 7) / 8) * g.ntn * g.splitk;                                                    \
+        const int slots_max = ((g.ntm * g.ntn + 7) / 8) * g.splitk;                                                    \
         const int per_xcd = 32 * WGCU;                                                                                 \
         const int grid = 8 * (slots_max < per_xcd ? slots_max : per_xcd);                                              \
         const size_t lds = (size_t)(BM_ + BN_) * ROWB * ST_;                                                           \
@@ -603,23 +643,23 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         else if (cfg == 2) MADTP_LAUNCH_GEMM(TT, LP, 128, 128, 3, 1);          \
         else MADTP_LAUNCH_GEMM(TT, LP, 128, 128, 4, 1);                        \
     } while (0)
-    if (pp_ok && (force_cfg == 5)) {
-        // ping-pong 256x128 kernel (one 8-wave workgroup per CU, 144 KiB LDS ring)
+    if (ws_ok) {
+        // wave-specialised 256x128 kernel (one 12-wave workgroup per CU, 144 KiB LDS ring)
         g.ntm = (M + 255) / 256;
         g.ntn = (N + 127) / 128;
-        const int slots_max = ((g.ntm + 7) / 8) * g.ntn;
+        const int slots_max = (g.ntm * g.ntn + 7) / 8;
         const int grid = 8 * (slots_max < 32 ? slots_max : 32);
-        const size_t lds = (size_t)3 * (2 * 128 + 128) * ROWB;
-        static bool attr_pp = false;
-        if (!attr_pp) {
-            hipError_t e1 = hipFuncSetAttribute((const void*)gemm_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipError_t e2 = hipFuncSetAttribute((const void*)gemm_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const size_t lds = (size_t)3 * (256 + 128) * ROWB;
+        static bool attr_ws = false;
+        if (!attr_ws) {
+            hipError_t e1 = hipFuncSetAttribute((const void*)gemm_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e2 = hipFuncSetAttribute((const void*)gemm_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e1 != hipSuccess) return (int)e1;
             if (e2 != hipSuccess) return (int)e2;
-            attr_pp = true;
+            attr_ws = true;
         }
-        if (lp) hipLaunchKernelGGL(gemm_pp_kernel<true>, dim3(grid), dim3(512), lds, s, g);
-        else hipLaunchKernelGGL(gemm_pp_kernel<false>, dim3(grid), dim3(512), lds, s, g);
+        if (lp) hipLaunchKernelGGL(gemm_ws_kernel<true>, dim3(grid), dim3(768), lds, s, g);
+        else hipLaunchKernelGGL(gemm_ws_kernel<false>, dim3(grid), dim3(768), lds, s, g);
     } else if (ab_dtype == MADTP_BF16) {
         if (lp) MADTP_DISPATCH_CFG(bf16_t, true); else MADTP_DISPATCH_CFG(bf16_t, false);
     } else {
