@@ -139,6 +139,18 @@ int madtp_query_att_ft(const float* token_attn, int ldt_row, int ldt_batch, int 
                        int ldf_batch, float* out, float inv_sqrt_sd, int accumulate, int B, int n, int dim, int fast,
                        void* stream);  /* fast != 0: bf16-MFMA variant (fast mode); 0: exact-f32 MFMA */
 
+/* The encoders' running sum  sd_ft_all = sum over layers l of att_ft_l  (vit.py:297-303, nlvr_encoder.py:608-613) in ONE
+ * launch (fast mode, bf16 MFMA): segment l is layer l's (token_attn, ft) pair with the strides of madtp_query_att_ft;
+ * the [K,dim] block of a sample stays in registers across the segments and is written once.  The caller keeps every
+ * layer's token buffer and logits alive until the stream has run this call. */
+typedef struct madtp_att_ft_seg {
+    const float* token_attn;
+    const float* ft;
+    int n, ldt_row, ldt_batch, ldf_row, ldf_batch;
+} madtp_att_ft_seg;
+int madtp_query_att_ft_multi(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float inv_sqrt_sd, int accumulate,
+                             int B, int dim, void* stream);
+
 /* Fast-mode alignment logits out[M,128] = x[M,dim] @ sd^T with sd given as a bf16 hi/lo split ([128,dim] each, rows
  * beyond the dictionary size zero): x is split in registers and xh.sh + xl.sh + xh.sl runs on the bf16 MFMA
  * (~2^-16 relative error instead of bf16's 2^-9).  models/utils.py:170. */

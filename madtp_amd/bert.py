@@ -478,6 +478,7 @@ class _BertEncoderBase(nn.Module):
     def _run(self, hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states, encoder_attention_mask,
              mode, always_query):
         sd_txt_ft_all = None
+        defer = self.txt_query_model.deferred() if space_dict is not None else None
         reduce_num = int((hidden_states.shape[-2] - 1) // self.config.num_hidden_layers)
         for i, layer_module in enumerate(self.layer):
             token_attn = None
@@ -487,7 +488,7 @@ class _BertEncoderBase(nn.Module):
                                     "space_dict must be given")
                 token_attn, sd_txt_ft_all, _ = self.txt_query_model(hidden_states[:, 1:, :], space_dict,
                                                                     return_token_att=True, temperature=temperature,
-                                                                    acc_ft=sd_txt_ft_all)
+                                                                    acc_ft=sd_txt_ft_all, defer=defer)
             t = temperature if space_dict is not None else 0
             if self.layer_cls.variant == "nlvr":
                 outs = layer_module(hidden_states, attention_mask, space_dict, None, encoder_hidden_states,
@@ -499,6 +500,8 @@ class _BertEncoderBase(nn.Module):
                                     reduce_num=reduce_num, temperature=t)
             hidden_states = outs[0]
             attention_mask = outs[-1]
+        if defer is not None and defer.pairs:
+            sd_txt_ft_all = defer.finish()
         return _Out(hidden_states), sd_txt_ft_all
 
 

@@ -375,6 +375,11 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
 //             into the stage slab s-1 used (every consumer finished reading it before it arrived at barrier s)
 //   consumer: barrier s -> 16 x ds_read_b128 + 32 x MFMA on slab s
 // The slab stream is persistent across the workgroup's tiles exactly as in gemm_kernel.
+// MADTP_WS_ABLATE (tools/build_ablate.py, timing experiments only - results are wrong): bit 0 drops the steady-state
+// fragment reads, bit 1 the per-slab barriers, bit 2 the MFMAs.
+#ifndef MADTP_WS_ABLATE
+#define MADTP_WS_ABLATE 0
+#endif
 template <bool LP_OUT>
 __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
     constexpr int ESZ = 2, BM = 256, BN = 128, STAGES = 3, NCW = 8, NLW = 4;
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
         for (long s = 0; s < total_slabs; ++s) {
             if (s + STAGES - 1 <= total_slabs) wait_vmcnt<(STAGES - 2) * PER>();
             else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
+            if (!(MADTP_WS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
             issue_next();
         }
         return;
@@ -464,18 +469,21 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     int cur_stage = 0;
 #define MADTP_WS_READ(XA, XB, CH)                                                         \
+    if (!(MADTP_WS_ABLATE & 1) || first)                                                  \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
         XA[i] = *(const bf16x8*)(st + a_off[i] + ((((CH) + grp4) ^ a_key[i]) << 4));      \
         XB[i] = *(const bf16x8*)(st + b_off[i] + ((((CH) + grp4) ^ b_key[i]) << 4));      \
     }
 #define MADTP_WS_MFMA(XA, XB)                                                             \
+    if (!(MADTP_WS_ABLATE & 4))                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(XB[j], XA[i], acc[i][j], 0, 0, 0);
     for (int slot = lb; slot < nslots; slot += gl) {
         {   // first slab of the tile: accumulators start from zero, no Y pending
+            constexpr bool first = true;
             const char* st = smem + cur_stage * STAGE_BYTES;
-            __builtin_amdgcn_s_barrier();  // slab landed (the loaders waited for it before arriving)
+            if (!(MADTP_WS_ABLATE & 2)) __builtin_amdgcn_s_barrier();  // slab landed (the loaders waited before arriving)
             MADTP_WS_READ(xa, xb, 0)
             MADTP_WS_READ(ya, yb, 4)
             __builtin_amdgcn_sched_barrier(0);
@@ -490,8 +498,9 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             if (++cur_stage == STAGES) cur_stage = 0;
         }
         for (int kt = 1; kt < nk; ++kt) {
+            constexpr bool first = false;
             const char* st = smem + cur_stage * STAGE_BYTES;
-            __builtin_amdgcn_s_barrier();
+            if (!(MADTP_WS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
             MADTP_WS_READ(xa, xb, 0)
             __builtin_amdgcn_sched_barrier(0);
             MADTP_WS_MFMA(ya, yb)
@@ -504,7 +513,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             if (++cur_stage == STAGES) cur_stage = 0;
         }
-        MADTP_WS_MFMA(ya, yb)
+        { MADTP_WS_MFMA(ya, yb) }
         if (!((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {
             const int t = t0 + slot;
             const int m0 = (t / g.ntn) * BM + grp * 128, n0 = (t % g.ntn) * BN;

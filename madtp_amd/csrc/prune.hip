@@ -370,11 +370,14 @@ __global__ __launch_bounds__(256) void query_att_ft_kernel(const float* __restri
 // weights Wt[t][c] and the token rows Xs[t][d] are staged ROW-major as bf16 (coalesced reads, conflict-free 8-byte
 // LDS writes) and BOTH fragments are fetched with the hardware transpose read ds_read_b64_tr_b16.  Pitches 144 /
 // 272 elements put the 8 rows of a 32-lane access on disjoint bank octets.
-constexpr int AB_TCH = 64, AB_WP = 144, AB_XP = 272;
-__global__ __launch_bounds__(256, 2) void query_att_ft_bf16_kernel(const float* __restrict__ ta, int ldt, int ldb, int K,
-                                                                   const float* __restrict__ ft, int ldf, int ldfb,
-                                                                   float* __restrict__ out, float inv_sqrt_sd,
-                                                                   int accumulate, int n, int dim) {
+// The kernel walks a LIST of (logits, token rows) segments - the layers of an encoder - and keeps the [K, 256] output
+// block in registers across them: att_ft_all = sum_l softmax_t(logits_l)^T x_l is written once instead of being
+// read-modified-written (B*K*dim f32 = 39 MB at B=128) after every layer.
+constexpr int AB_TCH = 64, AB_WP = 144, AB_XP = 272, AB_MAXSEG = 16;
+struct AttFtSeg { const float* ta; const float* ft; int n, ldt, ldb, ldf, ldfb; };
+struct AttFtSegs { AttFtSeg s[AB_MAXSEG]; int nseg; };
+__global__ __launch_bounds__(256, 2) void query_att_ft_bf16_kernel(AttFtSegs segs, int K, float* __restrict__ out,
+                                                                   float inv_sqrt_sd, int accumulate, int dim) {
     __shared__ float mx[128], sm[128];
     __shared__ float part[2][128];
     __shared__ __attribute__((aligned(16))) bf16_t Wt[AB_TCH * AB_WP];
@@ -383,7 +386,17 @@ __global__ __launch_bounds__(256, 2) void query_att_ft_bf16_kernel(const float* 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
-    const float* ta_b = ta + (size_t)b * ldb;
+    const int dblk = blockIdx.x * 256;
+    f32x4 acc[7][4];
+#pragma unroll
+    for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int si = 0; si < segs.nseg; ++si) {
+    const float* ta_b = segs.s[si].ta + (size_t)b * segs.s[si].ldb;
+    const float* xb = segs.s[si].ft + (size_t)b * segs.s[si].ldfb;
+    const int n = segs.s[si].n, ldt = segs.s[si].ldt, ldf = segs.s[si].ldf;
+    __syncthreads();  // previous segment's MFMA reads of Wt/Xs and its mx/sm are done
     {
         const int c = tid & 127, sl = tid >> 7;
         const int t0 = sl ? n / 2 : 0, t1 = sl ? n : n / 2;
@@ -406,13 +419,6 @@ __global__ __launch_bounds__(256, 2) void query_att_ft_bf16_kernel(const float* 
         if (tid < 128) { mx[tid] = m; sm[tid] = c < K ? 1.0f / (part[0][c] + part[1][c]) : 0.f; }
         __syncthreads();
     }
-    const int dblk = blockIdx.x * 256;
-    f32x4 acc[7][4];
-#pragma unroll
-    for (int mt = 0; mt < 7; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* xb = ft + (size_t)b * ldfb;
     for (int tc = 0; tc < n; tc += AB_TCH) {
         const int tn = min(AB_TCH, n - tc);
         __syncthreads();
@@ -456,6 +462,7 @@ __global__ __launch_bounds__(256, 2) void query_att_ft_bf16_kernel(const float* 
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[nt], wf, acc[mt][nt], 0, 0, 0);
             }
         }
+    }
     }
     // epilogue: D[row = d-fragment row 4g+r][col = c]: one float4 (read-modify-)write per (mt, nt)
 #pragma unroll
@@ -620,15 +627,33 @@ extern "C" int madtp_query_att_ft(const float* token_attn, int ldt, int ldb, int
     if (!token_attn || !x || !out || B <= 0 || n < 1) return MADTP_E_BADARG;
     if (K <= 0 || K > 112 || dim % 256 || ldt < K) return MADTP_E_SHAPE;
     if (fast) {
-        if (ldf % 4 || ldfb % 4 || !aligned16(x)) return MADTP_E_ALIGN;
-        hipLaunchKernelGGL(query_att_ft_bf16_kernel, dim3(dim / 256, B), dim3(256), 0, (hipStream_t)stream, token_attn, ldt,
-                           ldb, K, x, ldf, ldfb, out, inv_sqrt_sd, accumulate, n, dim);
-        MADTP_LAUNCH_CHECK();
-        return 0;
+        const madtp_att_ft_seg one = {token_attn, x, n, ldt, ldb, ldf, ldfb};
+        return madtp_query_att_ft_multi(&one, 1, K, out, inv_sqrt_sd, accumulate, B, dim, stream);
     }
     hipLaunchKernelGGL(query_att_ft_kernel, dim3(dim / 256, B), dim3(256), 0, (hipStream_t)stream, token_attn, ldt, ldb, K, x,
                        ldf, ldfb, out, inv_sqrt_sd, accumulate, n, dim);
     MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_query_att_ft_multi(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float inv_sqrt_sd,
+                                        int accumulate, int B, int dim, void* stream) {
+    if (!segs || !out || nseg < 1 || B <= 0) return MADTP_E_BADARG;
+    if (K <= 0 || K > 112 || dim % 256) return MADTP_E_SHAPE;
+    for (int first = 0; first < nseg; first += AB_MAXSEG) {
+        AttFtSegs a;
+        a.nseg = nseg - first < AB_MAXSEG ? nseg - first : AB_MAXSEG;
+        for (int i = 0; i < a.nseg; ++i) {
+            const madtp_att_ft_seg& g = segs[first + i];
+            if (!g.token_attn || !g.ft || g.n < 1) return MADTP_E_BADARG;
+            if (g.ldt_row < K) return MADTP_E_SHAPE;
+            if (g.ldf_row % 4 || g.ldf_batch % 4 || !aligned16(g.ft)) return MADTP_E_ALIGN;
+            a.s[i] = AttFtSeg{g.token_attn, g.ft, g.n, g.ldt_row, g.ldt_batch, g.ldf_row, g.ldf_batch};
+        }
+        hipLaunchKernelGGL(query_att_ft_bf16_kernel, dim3(dim / 256, B), dim3(256), 0, (hipStream_t)stream, a, K, out,
+                           inv_sqrt_sd, (accumulate || first > 0) ? 1 : 0, dim);
+        MADTP_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -55,6 +55,7 @@ _SIGS = {
                                       c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                       c_void_p, c_void_p]),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
+    "madtp_query_att_ft_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
@@ -297,6 +298,29 @@ def query_att_ft(token_attn, ft, out=None, sd_dim=768, fast=False):
         acc = 0
     _check(load().madtp_query_att_ft(tp, ldr, ldb, K, fp, ldf, ldfb, _p(out), 1.0 / (sd_dim ** 0.5), acc,
                                      B, n, dim, 1 if fast else 0, _stream()), "madtp_query_att_ft")
+    return out
+
+
+class AttFtSeg(ctypes.Structure):
+    _fields_ = [("token_attn", c_void_p), ("ft", c_void_p), ("n", c_int), ("ldt_row", c_int), ("ldt_batch", c_int),
+                ("ldf_row", c_int), ("ldf_batch", c_int)]
+
+
+def query_att_ft_multi(pairs, out=None, sd_dim=768):
+    """pairs: list of (token_attn [B,n,K] view, ft [B,n,dim] f32 view) of the layers of an encoder -> their summed att_ft
+    [B,K,dim] in one launch (fast mode)."""
+    segs = (AttFtSeg * len(pairs))()
+    for i, (ta, ft) in enumerate(pairs):
+        fp, ldf, ldfb, dim = _ta_view(ft)
+        tp, ldr, ldb, K = _ta_view(ta)
+        segs[i] = AttFtSeg(tp, fp, ft.shape[1], ldr, ldb, ldf, ldfb)
+    B = pairs[0][1].shape[0]
+    acc = 1
+    if out is None:
+        out = torch.empty((B, K, dim), device=pairs[0][1].device, dtype=torch.float32)
+        acc = 0
+    _check(load().madtp_query_att_ft_multi(segs, len(pairs), K, _p(out), 1.0 / (sd_dim ** 0.5), acc, B, dim, _stream()),
+           "madtp_query_att_ft_multi")
     return out
 
 

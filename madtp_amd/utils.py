@@ -34,6 +34,25 @@ def full_rows_of(ft):
     return torch.as_strided(ft, (B * (n + 1), D), (D, 1), ft.storage_offset() - D)
 
 
+class DeferredAttFt:
+    """Fast-mode bookkeeping for an encoder's `sd_ft_all += sd_ft` (vit.py:297-303, nlvr_encoder.py:608-613): the layers
+    only record their (logits, token rows) pair - both stay alive as ordinary tensors - and finish() sums all the
+    layers' att_ft in ONE kernel (madtp_query_att_ft_multi) instead of a 39 MB read-modify-write per layer."""
+
+    def __init__(self, sd_dim):
+        self.pairs, self.sd_dim = [], sd_dim
+
+    def add(self, token_att, ft):
+        self.pairs.append((token_att, ft))
+
+    def finish(self):
+        if not self.pairs:
+            return None
+        out = hip.query_att_ft_multi(self.pairs, sd_dim=self.sd_dim)
+        self.pairs = []
+        return out
+
+
 class Query_model(nn.Module):
     """models/utils.py:109-183.  forward(ft, sd, mask=None, return_token_att=False, temperature=1) ->
     (token_att[B,n,K] raw logits, att_ft[B,K,sd_dim], sd).  The logits x.sd^T always run on the exact-f32 MFMA
@@ -53,8 +72,16 @@ class Query_model(nn.Module):
         self._cache = PreparedCache()
         self.compute_att_ft = True  # att_ft only feeds the training loss (blip_nlvr.py:86-96); eval callers may clear
 
-    def forward(self, ft, sd, mask=None, return_token_att=False, temperature=1, acc_ft=None):
-        """acc_ft (extension): running sum tensor to accumulate att_ft into (the encoders' `sd_ft_all += sd_ft`)."""
+    def deferred(self):
+        """A DeferredAttFt for an encoder loop, or None when att_ft must be produced per call (parity mode keeps the
+        reference's per-layer summation order; no q_map: the mapped q of CLIP is a per-layer temporary)."""
+        if compute_dtype() == torch.bfloat16 and self.compute_att_ft and not self.map_func:
+            return DeferredAttFt(self.att_dim)
+        return None
+
+    def forward(self, ft, sd, mask=None, return_token_att=False, temperature=1, acc_ft=None, defer=None):
+        """acc_ft (extension): running sum tensor to accumulate att_ft into (the encoders' `sd_ft_all += sd_ft`).
+        defer (extension): a DeferredAttFt - att_ft is not computed here (returned as None) but summed by defer.finish()."""
         require_gpu(ft, "ft")
         if not return_token_att:
             raise NotImplementedError("Query_model(return_token_att=False) returns the normalised attention weights; "
@@ -94,8 +121,12 @@ class Query_model(nn.Module):
             ftq = ft
             if rows is not None:
                 # fast path: ft is x[:,1:,:] of a contiguous token buffer -> one C call (logits GEMM + att_ft)
-                token_att, att_ft = hip.query_model(rows.view(B, n + 1, D), sdl.w, K, att_ft=acc_ft,
-                                                    want_att_ft=self.compute_att_ft, sd_dim=self.att_dim, sd_split=split)
+                want = self.compute_att_ft and not (defer is not None and split is not None)
+                token_att, att_ft = hip.query_model(rows.view(B, n + 1, D), sdl.w, K, att_ft=acc_ft, want_att_ft=want,
+                                                    sd_dim=self.att_dim, sd_split=split)
+                if self.compute_att_ft and not want:
+                    defer.add(token_att, ft)
+                    return token_att, None, sd
                 return token_att, (att_ft if self.compute_att_ft else acc_ft), sd
             ftq = ft.float().contiguous()
             rows, off = ftq.view(B * n, D), 0

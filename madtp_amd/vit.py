@@ -270,14 +270,18 @@ class VisionTransformer(nn.Module):
         token_num = x.shape[-2]
         reduce_num = int((token_num - 1) // self.depth)
         sd_img_ft_all = None
+        defer = self.img_query_model.deferred() if space_dict is not None else None
         for i, blk in enumerate(self.blocks):
             if space_dict is not None:
-                # :297-303; `sd_img_ft_all += sd_img_ft` is folded into the kernel (accumulate into the running sum)
+                # :297-303; `sd_img_ft_all += sd_img_ft` is folded into the kernels: parity mode accumulates into the
+                # running sum per layer, fast mode sums all layers in one launch after the loop (DeferredAttFt)
                 token_attn, sd_img_ft_all, _ = self.img_query_model(x[:, 1:, :], space_dict, return_token_att=True,
-                                                                    acc_ft=sd_img_ft_all)
+                                                                    acc_ft=sd_img_ft_all, defer=defer)
                 x = blk(x, register_blk == i, reduce_num, temperature, token_attn)  # :304
             else:
                 x = blk(x, register_blk == i)
+        if defer is not None and defer.pairs:
+            sd_img_ft_all = defer.finish()
         B, N, D = x.shape
         y, _ = hip.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)  # :309
         return y, sd_img_ft_all

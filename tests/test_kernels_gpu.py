@@ -269,6 +269,31 @@ def test_query_att_ft(hip):
     assert (out2.cpu() - 2 * ref).abs().max().item() < 4e-5 * max(1, ref.abs().max().item())
 
 
+def test_query_att_ft_multi_segment(hip):
+    """The one-launch sum over an encoder's layers equals the per-layer accumulate chain (ragged token counts, >16 segments)."""
+    B, D, K = 3, 768, 100
+    sd = _rand(K, D, seed=81)
+    sdp = _pad128(sd).cuda()
+    hi = hip.cast_bf16(sdp)
+    lo = hip.cast_bf16((sdp - hi.float()).contiguous())
+    pairs, ref, chain = [], 0, None
+    for li, N in enumerate([150, 131, 64, 65, 33, 2, 20] + [17] * 12):
+        x = _rand(B, N, D, seed=90 + li)
+        xd = x.cuda()
+        tav = hip.align_logits(xd.view(B * N, D), hi, lo).view(B, N, 128)[:, 1:, :K]
+        pairs.append((tav, xd[:, 1:, :]))
+        inner = x[:, 1:] @ sd.t()
+        ref = ref + torch.bmm(torch.softmax((inner / math.sqrt(D)).permute(0, 2, 1), -1), x[:, 1:])
+        chain = hip.query_att_ft(tav, xd[:, 1:, :], out=chain, fast=True)
+    out = hip.query_att_ft_multi(pairs)
+    scale = max(1, ref.abs().max().item())
+    assert (out.cpu() - ref).abs().max().item() < 2e-2 * scale
+    assert (out - chain).abs().max().item() < 1e-4 * scale  # same products, different f32 summation order
+    out2 = hip.query_att_ft_multi(pairs[:3], out=out.clone())
+    part = hip.query_att_ft_multi(pairs[:3])
+    assert (out2 - out - part).abs().max().item() < 1e-4 * scale
+
+
 def test_fast_mode_alignment_and_att_ft(hip):
     """bf16x3 split-precision logits (~2^-16 relative) and the bf16-MFMA att_ft."""
     B, N, D, K = 3, 150, 768, 100

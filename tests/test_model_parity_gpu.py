@@ -214,5 +214,12 @@ def test_vit_large_image_fp32_matches_reference_fixture(path):
     assert list(out.shape) == g["out_shape"].tolist()
     assert np.abs(out[:, 0, :32].cpu().numpy() - g["cls"]).max() < 1e-3
     with runtime.precision("bf16"), torch.no_grad():
-        ob, _ = model(images, space_dict=space_dict, temperature=T)
+        ob, sd_b = model(images, space_dict=space_dict, temperature=T)
     assert torch.isfinite(ob).all()
+    # fast mode sums the 12 layers' att_ft in one deferred launch: same result as the per-layer accumulate chain
+    model.img_query_model.deferred = lambda: None
+    with runtime.precision("bf16"), torch.no_grad():
+        ob2, sd_b2 = model(images, space_dict=space_dict, temperature=T)
+    del model.img_query_model.deferred
+    assert torch.equal(ob, ob2) and sd_b.shape == sd_ft.shape
+    assert (sd_b - sd_b2).abs().max().item() < 1e-4 * sd_b2.abs().max().item()

@@ -1,0 +1,14 @@
+"""Builds timing-only variants of the library with parts of the wave-specialised GEMM main loop removed
+(MADTP_WS_ABLATE bit mask, see gemm.hip): madtp_amd/lib/libmadtp_hip_abl<N>.so.  Used with tools/gemm_ablate.py."""
+import os, subprocess, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from madtp_amd import build as b
+
+b.build()
+for n in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]:
+    o = os.path.join(b.LIBDIR, f"gemm_abl{n}.o")
+    subprocess.check_call([b._hipcc()] + b.FLAGS + [f"-DMADTP_WS_ABLATE={n}", "-c", os.path.join(b.CSRC, "gemm.hip"), "-o", o])
+    objs = [o] + [os.path.join(b.LIBDIR, s.replace(".hip", ".o")) for s in b.SOURCES if s != "gemm.hip"]
+    lib = os.path.join(b.LIBDIR, f"libmadtp_hip_abl{n}.so")
+    subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    print(lib)
