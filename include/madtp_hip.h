@@ -137,7 +137,8 @@ int madtp_mask_gather(const float* mask, const int64_t* order, int ld_order, con
  * accumulate!=0 adds into out (sd_img_ft_all += sd_img_ft, vit.py:300-303). */
 int madtp_query_att_ft(const float* token_attn, int ldt_row, int ldt_batch, int K, const float* ft, int ldf_row,
                        int ldf_batch, float* out, float inv_sqrt_sd, int accumulate, int B, int n, int dim, int fast,
-                       void* stream);  /* fast != 0: bf16-MFMA variant (fast mode); 0: exact-f32 MFMA */
+                       float* stats_ws, void* stream);
+/* fast != 0: bf16-MFMA variant (fast mode), needs stats_ws = B*256 floats of scratch; 0: exact-f32 MFMA (stats_ws unused) */
 
 /* The encoders' running sum  sd_ft_all = sum over layers l of att_ft_l  (vit.py:297-303, nlvr_encoder.py:608-613) in ONE
  * launch (fast mode, bf16 MFMA): segment l is layer l's (token_attn, ft) pair with the strides of madtp_query_att_ft;
@@ -148,8 +149,8 @@ typedef struct madtp_att_ft_seg {
     const float* ft;
     int n, ldt_row, ldt_batch, ldf_row, ldf_batch;
 } madtp_att_ft_seg;
-int madtp_query_att_ft_multi(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float inv_sqrt_sd, int accumulate,
-                             int B, int dim, void* stream);
+int madtp_query_att_ft_multi(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float* stats_ws, float inv_sqrt_sd,
+                             int accumulate, int B, int dim, void* stream);  /* stats_ws: nseg*B*256 floats of scratch */
 
 /* Fast-mode alignment logits out[M,128] = x[M,dim] @ sd^T with sd given as a bf16 hi/lo split ([128,dim] each, rows
  * beyond the dictionary size zero): x is split in registers and xh.sh + xl.sh + xh.sl runs on the bf16 MFMA
@@ -206,8 +207,9 @@ int madtp_vit_block_mlp(const madtp_vit_block_w* w, const float* x, float* y, vo
  * token_attn_full[B*N, 128] = x @ sd^T (exact-f32 MFMA; sd_w is f32 [128,dim], rows >= K zero); row b*N+1+t is patch t.
  * att_ft[B,K,dim] (+)= softmax_t(logits/sqrt(sd_dim)) @ x[:,1:]  (skipped when att_ft is NULL). */
 int madtp_query_model(const float* x, const void* sd_w, const void* sd_hi, const void* sd_lo, int K,
-                      float* token_attn_full, float* att_ft, int accumulate, float inv_sqrt_sd, int B, int N, int dim,
-                      void* stream);  /* sd_hi/sd_lo != NULL selects the fast-mode kernels (bf16x3 logits, bf16 att_ft) */
+                      float* token_attn_full, float* att_ft, float* stats_ws, int accumulate, float inv_sqrt_sd, int B, int N,
+                      int dim, void* stream);
+/* sd_hi/sd_lo != NULL selects the fast-mode kernels (bf16x3 logits, bf16 att_ft; att_ft then needs stats_ws = B*256 floats) */
 
 /* models/med.py BertLayer (:332-467) / models/nlvr_encoder.py BertLayer (:385-559) */
 typedef struct madtp_bert_layer_w {

@@ -40,6 +40,15 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const void* p) {
 }
 __device__ __forceinline__ bf16x8 cat_bf16x4(bf16x4 a, bf16x4 b) { return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a full release/acquire fence, which on gfx950
+// drains EVERY outstanding vector-memory operation (s_waitcnt vmcnt(0)) - including global loads and LDS-DMAs a kernel
+// issued ahead on purpose.  This one waits for the wave's LDS operations (lgkmcnt) and leaves vmcnt alone.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }

@@ -191,8 +191,8 @@ extern "C" int madtp_vit_block_mlp(const madtp_vit_block_w* w, const float* x, f
 // Query_model (models/utils.py:147-183) on the token buffer in place: logits of ALL rows of x (the CLS row is computed
 // and ignored) with the exact-f32 MFMA, then att_ft over the patch rows.
 extern "C" int madtp_query_model(const float* x, const void* sd_w, const void* sd_hi, const void* sd_lo, int K,
-                                 float* token_attn_full, float* att_ft, int accumulate, float inv_sqrt_sd, int B, int N,
-                                 int dim, void* stream) {
+                                 float* token_attn_full, float* att_ft, float* stats_ws, int accumulate, float inv_sqrt_sd,
+                                 int B, int N, int dim, void* stream) {
     if (!x || !token_attn_full || B <= 0 || N < 2) return MADTP_E_BADARG;
     const int kp = (K + 127) / 128 * 128;
     const bool fast = sd_hi && sd_lo;
@@ -206,7 +206,7 @@ extern "C" int madtp_query_model(const float* x, const void* sd_w, const void* s
     }
     if (att_ft)
         TRY(madtp_query_att_ft(token_attn_full + kp, kp, N * kp, K, x + dim, dim, N * dim, att_ft, inv_sqrt_sd, accumulate, B,
-                               N - 1, dim, fast ? 1 : 0, stream));
+                               N - 1, dim, fast ? 1 : 0, stats_ws, stream));
     return 0;
 }
 

@@ -373,105 +373,171 @@ __global__ __launch_bounds__(256) void query_att_ft_kernel(const float* __restri
 // The kernel walks a LIST of (logits, token rows) segments - the layers of an encoder - and keeps the [K, 256] output
 // block in registers across them: att_ft_all = sum_l softmax_t(logits_l)^T x_l is written once instead of being
 // read-modified-written (B*K*dim f32 = 39 MB at B=128) after every layer.
-constexpr int AB_TCH = 64, AB_WP = 144, AB_XP = 272, AB_MAXSEG = 16;
+// Two kernels: att_ft_stats_kernel (grid nseg x B) computes the softmax statistics of every (segment, sample) - the
+// maximum and 1/sum over tokens of each dictionary column, two passes with four independent float4 loads in flight per
+// thread; query_att_ft_bf16_kernel then streams ALL 32-token chunks of the sample's segments as one sequence: the next
+// chunk's logits and token rows are fetched into registers while the current one is multiplied, converted (softmax weight /
+// bf16) into one of two LDS buffers, one barrier per chunk.
+// Workgroup = one sample x 128 output columns (wave w: columns [32w, 32w+32), 2 MFMA column tiles): 6 x B workgroups of
+// 56 accumulator registers, three resident per CU.
+constexpr int AB_TCH = 32, AB_WP = 144, AB_COLS = 128, AB_XP = AB_COLS + 16, AB_NT = AB_COLS / 64, AB_MAXSEG = 16, AB_SL = 9;
 struct AttFtSeg { const float* ta; const float* ft; int n, ldt, ldb, ldf, ldfb; };
 struct AttFtSegs { AttFtSeg s[AB_MAXSEG]; int nseg; };
-__global__ __launch_bounds__(256, 2) void query_att_ft_bf16_kernel(AttFtSegs segs, int K, float* __restrict__ out,
-                                                                   float inv_sqrt_sd, int accumulate, int dim) {
-    __shared__ float mx[128], sm[128];
-    __shared__ float part[2][128];
-    __shared__ __attribute__((aligned(16))) bf16_t Wt[AB_TCH * AB_WP];
-    __shared__ __attribute__((aligned(16))) bf16_t Xs[AB_TCH * AB_XP];
+
+// stats[(seg*B + b)*256 + c] = max_t logit*inv, [.. + 128 + c] = 1 / sum_t exp(logit*inv - max)  (0 for c >= K)
+__global__ __launch_bounds__(256) void att_ft_stats_kernel(AttFtSegs segs, int K, float inv_sqrt_sd, float* __restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) float part[AB_SL][128];
+    __shared__ __attribute__((aligned(16))) float mx[128];
+    const int tid = threadIdx.x, si = blockIdx.x, b = blockIdx.y;
+    const int K4 = (K + 3) & ~3;
+    const int c4 = (tid % 28) * 4, sl = tid / 28;
+    const float* ta_b = segs.s[si].ta + (size_t)b * segs.s[si].ldb + c4;
+    const int n = segs.s[si].n, ldt = segs.s[si].ldt;
+    const bool act = sl < AB_SL && c4 < K4;
+    const f32x4 ninf = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    f32x4 m = ninf;
+    if (act)
+        for (int t = sl; t < n; t += 4 * AB_SL) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = t + u * AB_SL < n ? *(const f32x4*)(ta_b + (size_t)(t + u * AB_SL) * ldt) : ninf;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[u][e] * inv_sqrt_sd);
+        }
+    if (sl < AB_SL) *(f32x4*)(&part[sl][c4]) = m;
+    __syncthreads();
+    if (tid < 128) {
+        float mm = part[0][tid];
+#pragma unroll
+        for (int q = 1; q < AB_SL; ++q) mm = fmaxf(mm, part[q][tid]);
+        mx[tid] = mm;
+    }
+    __syncthreads();
+    f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (act) {
+        const f32x4 mc = *(const f32x4*)(&mx[c4]);
+        for (int t = sl; t < n; t += 4 * AB_SL) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = t + u * AB_SL < n ? *(const f32x4*)(ta_b + (size_t)(t + u * AB_SL) * ldt) : ninf;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] += __expf(v[u][e] * inv_sqrt_sd - mc[e]);
+        }
+    }
+    if (sl < AB_SL) *(f32x4*)(&part[sl][c4]) = sum;
+    __syncthreads();
+    if (tid < 128) {
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < AB_SL; ++q) ss += part[q][tid];
+        float* o = stats + ((size_t)si * gridDim.y + b) * 256;
+        o[tid] = tid < K ? mx[tid] : 0.f;
+        o[128 + tid] = tid < K ? 1.0f / ss : 0.f;  // weight 0 for the padding columns K..127
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void query_att_ft_bf16_kernel(AttFtSegs segs, int K, const float* __restrict__ stats,
+                                                                   float* __restrict__ out, float inv_sqrt_sd, int accumulate,
+                                                                   int dim) {
+    __shared__ __attribute__((aligned(16))) float st[AB_MAXSEG][256];  // per segment: max[128] | 1/sum[128]
+    __shared__ __attribute__((aligned(16))) bf16_t Wt[2][AB_TCH * AB_WP];
+    __shared__ __attribute__((aligned(16))) bf16_t Xs[2][AB_TCH * AB_XP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, g = lane >> 4;
-    const int b = blockIdx.y;
-    const int dblk = blockIdx.x * 256;
-    f32x4 acc[7][4];
+    const int b = blockIdx.y, B = gridDim.y;
+    const int dblk = blockIdx.x * AB_COLS;
+    const int K4 = (K + 3) & ~3;  // logits are read as float4s: columns K..K4-1 exist (row pitch >= K4) and get weight 0
+    f32x4 acc[7][AB_NT];
 #pragma unroll
     for (int mt = 0; mt < 7; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < AB_NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int nchunks = 0;
     for (int si = 0; si < segs.nseg; ++si) {
-    const float* ta_b = segs.s[si].ta + (size_t)b * segs.s[si].ldb;
-    const float* xb = segs.s[si].ft + (size_t)b * segs.s[si].ldfb;
-    const int n = segs.s[si].n, ldt = segs.s[si].ldt, ldf = segs.s[si].ldf;
-    __syncthreads();  // previous segment's MFMA reads of Wt/Xs and its mx/sm are done
-    {
-        const int c = tid & 127, sl = tid >> 7;
-        const int t0 = sl ? n / 2 : 0, t1 = sl ? n : n / 2;
-        float m = -INFINITY;
-        if (c < K) {
-#pragma unroll 8
-            for (int t = t0; t < t1; ++t) m = fmaxf(m, ta_b[(size_t)t * ldt + c] * inv_sqrt_sd);
-        }
-        part[sl][c] = m;
-        __syncthreads();
-        m = fmaxf(part[0][c], part[1][c]);
-        __syncthreads();
-        float s = 0.f;
-        if (c < K) {
-#pragma unroll 8
-            for (int t = t0; t < t1; ++t) s += __expf(ta_b[(size_t)t * ldt + c] * inv_sqrt_sd - m);
-        }
-        part[sl][c] = s;
-        __syncthreads();
-        if (tid < 128) { mx[tid] = m; sm[tid] = c < K ? 1.0f / (part[0][c] + part[1][c]) : 0.f; }
-        __syncthreads();
+        st[si][tid] = stats[((size_t)si * B + b) * 256 + tid];
+        nchunks += (segs.s[si].n + AB_TCH - 1) / AB_TCH;
     }
-    for (int tc = 0; tc < n; tc += AB_TCH) {
-        const int tn = min(AB_TCH, n - tc);
-        __syncthreads();
-        // weights Wt[t][c]: thread -> (t, 4 consecutive c): coalesced logits read, one 8-byte LDS write
-#pragma unroll 2
-        for (int idx = tid; idx < AB_TCH * 28; idx += 256) {
-            const int t = idx / 28, c4 = (idx % 28) * 4;
-            f32x4 w = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (t < tn) {
+    constexpr int XL = AB_TCH * AB_COLS / 4 / 256, XC4 = AB_COLS / 4;  // float4 loads per thread, float4s per row
+    f32x4 xr[XL], lr[4];
+    int f_si = 0, f_tc = 0, r_si = 0;  // next chunk to fetch; segment of the chunk held in registers
+    auto fetch = [&]() {
+        const float* ta_b = segs.s[f_si].ta + (size_t)b * segs.s[f_si].ldb;
+        const float* xb = segs.s[f_si].ft + (size_t)b * segs.s[f_si].ldfb + dblk;
+        const int n = segs.s[f_si].n, ldt = segs.s[f_si].ldt, ldf = segs.s[f_si].ldf;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (c4 + e < K) w[e] = __expf(ta_b[(size_t)(tc + t) * ldt + c4 + e] * inv_sqrt_sd - mx[c4 + e]) * sm[c4 + e];
-            }
-            *(bf16x4*)(Wt + t * AB_WP + c4) = pack_bf16x4(w);
+        for (int i = 0; i < XL; ++i) {
+            const int t = f_tc + tid / XC4 + (256 / XC4) * i;
+            xr[i] = t < n ? *(const f32x4*)(xb + (size_t)t * ldf + (tid % XC4) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        // token rows Xs[t][d]: thread -> (t, 4 consecutive d): coalesced float4 read, one 8-byte LDS write
-#pragma unroll 4
-        for (int idx = tid; idx < AB_TCH * 64; idx += 256) {
-            const int t = idx >> 6, d4 = (idx & 63) * 4;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (t < tn) v = *(const f32x4*)(xb + (size_t)(tc + t) * ldf + dblk + d4);
-            *(bf16x4*)(Xs + t * AB_XP + d4) = pack_bf16x4(v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, t = f_tc + idx / 28, c4 = (idx % 28) * 4;
+            lr[i] = (idx < AB_TCH * 28 && t < n && c4 < K4) ? *(const f32x4*)(ta_b + (size_t)t * ldt + c4)
+                                                            : (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         }
-        __syncthreads();
+        r_si = f_si;
+        f_tc += AB_TCH;
+        if (f_tc >= n) { f_tc = 0; ++f_si; }
+    };
+    auto commit = [&](int buf) {  // registers -> LDS: bf16 token rows, softmax weights (exp(-inf) = 0 pads)
 #pragma unroll
-        for (int ks = 0; ks < AB_TCH / 32; ++ks) {
-            // lane 4r+q of a 16-lane group addresses (token row r, columns 4q..4q+3); k slots 8g..8g+7 = two reads
-            const int trow = ks * 32 + 8 * g + (l16 >> 2), cpart = 4 * (l16 & 3);
-            bf16x8 xf[4];
+        for (int i = 0; i < XL; ++i)
+            *(bf16x4*)(&Xs[buf][(tid / XC4 + (256 / XC4) * i) * AB_XP + (tid % XC4) * 4]) = pack_bf16x4(xr[i]);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const bf16_t* p = Xs + trow * AB_XP + wave * 64 + nt * 16 + cpart;
-                xf[nt] = cat_bf16x4(lds_read_tr16(p), lds_read_tr16(p + 4 * AB_XP));
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, t = idx / 28, c4 = (idx % 28) * 4;
+            if (idx < AB_TCH * 28) {
+                const f32x4 mc = *(const f32x4*)(&st[r_si][c4]), sc = *(const f32x4*)(&st[r_si][128 + c4]);
+                f32x4 w;
 #pragma unroll
-            for (int mt = 0; mt < 7; ++mt) {
-                const bf16_t* p = Wt + trow * AB_WP + mt * 16 + cpart;
-                const bf16x8 wf = cat_bf16x4(lds_read_tr16(p), lds_read_tr16(p + 4 * AB_WP));
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)  // operands swapped: lane (c = l16, g) ends up with 4 consecutive d
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[nt], wf, acc[mt][nt], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) w[e] = __expf(lr[i][e] * inv_sqrt_sd - mc[e]) * sc[e];
+                *(bf16x4*)(&Wt[buf][t * AB_WP + c4]) = pack_bf16x4(w);
             }
         }
-    }
+    };
+    fetch();
+    __syncthreads();  // st[] visible
+    commit(0);
+    if (nchunks > 1) fetch();
+    lds_barrier();  // (not __syncthreads(): the fetches stay in flight across the barriers)
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch + 1 < nchunks) {
+            commit((ch + 1) & 1);  // that buffer's readers finished before the barrier that ended chunk ch-1
+            if (ch + 2 < nchunks) fetch();
+        }
+        const bf16_t* xs = Xs[ch & 1];
+        const bf16_t* wt = Wt[ch & 1];
+        // lane 4r+q of a 16-lane group addresses (token row r, columns 4q..4q+3); k slots 8g..8g+7 = two reads
+        const int trow = 8 * g + (l16 >> 2), cpart = 4 * (l16 & 3);
+        bf16x8 xf[AB_NT];
+#pragma unroll
+        for (int nt = 0; nt < AB_NT; ++nt) {
+            const bf16_t* p = xs + trow * AB_XP + wave * (16 * AB_NT) + nt * 16 + cpart;
+            xf[nt] = cat_bf16x4(lds_read_tr16(p), lds_read_tr16(p + 4 * AB_XP));
+        }
+#pragma unroll
+        for (int mt = 0; mt < 7; ++mt) {
+            const bf16_t* p = wt + trow * AB_WP + mt * 16 + cpart;
+            const bf16x8 wf = cat_bf16x4(lds_read_tr16(p), lds_read_tr16(p + 4 * AB_WP));
+#pragma unroll
+            for (int nt = 0; nt < AB_NT; ++nt)  // operands swapped: lane (c = l16, g) ends up with 4 consecutive d
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[nt], wf, acc[mt][nt], 0, 0, 0);
+        }
+        lds_barrier();
     }
     // epilogue: D[row = d-fragment row 4g+r][col = c]: one float4 (read-modify-)write per (mt, nt)
 #pragma unroll
     for (int mt = 0; mt < 7; ++mt) {
         const int c = mt * 16 + l16;
         if (c >= K) continue;
-        float* orow = out + ((size_t)b * K + c) * dim + dblk + wave * 64 + 4 * g;
+        float* orow = out + ((size_t)b * K + c) * dim + dblk + wave * (16 * AB_NT) + 4 * g;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < AB_NT; ++nt) {
             f32x4* o = (f32x4*)(orow + 16 * nt);
             *o = accumulate ? *o + acc[mt][nt] : acc[mt][nt];
         }
@@ -484,21 +550,30 @@ __global__ __launch_bounds__(256, 2) void query_att_ft_bf16_kernel(AttFtSegs seg
 // x rows are read as f32 straight into registers and split there; the 128 dictionary rows (hi and lo slabs) are
 // LDS-DMA'd in 128-byte K slabs with the GEMM kernel's swizzle; workgroup = 64 token rows x 128 columns, one 16-row
 // MFMA fragment per wave, operand-swapped MFMA so each lane stores float4s.
-constexpr int AL_ROWB = 128, AL_TILE = 128 * AL_ROWB;
-__global__ __launch_bounds__(256, 2) void align_logits_kernel(const float* __restrict__ x, const char* __restrict__ sd_hi,
+constexpr int AL_ROWB = 128, AL_TILE = 128 * AL_ROWB, AL_STAGES = 3;
+// MADTP_AL_ABLATE (tools/build_ablate.py, timing experiments only): bit 0 drops the MFMAs, bit 1 the x loads, bit 2 the
+// LDS-DMAs, bit 3 the fragment reads.
+#ifndef MADTP_AL_ABLATE
+#define MADTP_AL_ABLATE 0
+#endif
+// NK = dim/64 as a compile-time constant fully unrolls the slab loop: in a rolled loop the compiler carries the in-flight
+// x registers through copies at the back edge, and a copy of a pending load is a wait for it (NK = 0: runtime loop).
+template <int NK>
+__global__ __launch_bounds__(256, 1) void align_logits_kernel(const float* __restrict__ x, const char* __restrict__ sd_hi,
                                                               const char* __restrict__ sd_lo, float* __restrict__ out, int M,
                                                               int dim) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (hi tile, lo tile)
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // AL_STAGES x (hi tile, lo tile) = 96 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * 64 + wave * 16;
     const int row = min(m0 + l16, M - 1);
     const float* xr = x + (size_t)row * dim;
-    const int nk = dim * 2 / AL_ROWB;
+    const int nk = NK ? NK : dim * 2 / AL_ROWB;
     const int sub = lane >> 3, chunk_src = (lane & 7) ^ sub;
-    auto stage = [&](int kt, int st) {
-        char* base = smem + st * 2 * AL_TILE;
+    auto stage = [&](int kt) {  // 8 LDS-DMA instructions per wave
+        char* base = smem + (kt % AL_STAGES) * 2 * AL_TILE;
+        if (MADTP_AL_ABLATE & 4) return;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int grp = wave * 4 + q;
@@ -510,48 +585,96 @@ __global__ __launch_bounds__(256, 2) void align_logits_kernel(const float* __res
     f32x4 acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    stage(0, 0);
-    // this lane's x slice of a slab: k = 64kt + 32kk + 8g .. +7; fetched one slab ahead (software pipelining) so the HBM
-    // latency of the f32 rows hides under the previous slab's MFMAs
-    f32x4 xn[2][2];
-    auto load_x = [&](int kt) {
+    // this lane's x slice of a slab: k = 64kt + 32kk + 8g .. +7, read as f32 straight into registers TWO slabs ahead
+    // (the HBM latency of the token rows hides under two slabs of MFMAs); the dictionary slabs run two ahead as well,
+    // through a 3-stage LDS ring synchronised with a counted s_waitcnt.
+    f32x4 xq[2][2][2];  // register set kt&1 holds x(kt); it is refilled with x(kt+2) as soon as it has been split
+    auto load_x = [&](int kt, f32x4 (&d)[2][2]) {
+        if ((MADTP_AL_ABLATE & 2) && kt > 1) return;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const float* p = xr + kt * 64 + kk * 32 + g * 8;
-            xn[kk][0] = *(const f32x4*)p;
-            xn[kk][1] = *(const f32x4*)(p + 4);
+            d[kk][0] = *(const f32x4*)p;
+            d[kk][1] = *(const f32x4*)(p + 4);
         }
     };
-    load_x(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        f32x4 xa[2][2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) { xa[kk][0] = xn[kk][0]; xa[kk][1] = xn[kk][1]; }
-        __syncthreads();
-        if (kt + 1 < nk) { stage(kt + 1, (kt + 1) & 1); load_x(kt + 1); }
-        const char* sh = smem + (kt & 1) * 2 * AL_TILE;
-        const char* sl = sh + AL_TILE;
+    load_x(0, xq[0]);
+    stage(0);
+    load_x(1, xq[1]);  // nk is even (dim % 128 == 0, checked by the launcher)
+    stage(1);
+    auto slab = [&](int kt, f32x4 (&xs)[2][2]) {
+        // vmcnt is one in-order counter: slab kt (and x(kt)) were issued two iterations ago, so everything issued in
+        // the previous iteration - 4 x loads + 8 DMAs - may still be in flight
+        if (MADTP_AL_ABLATE & 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // raw barrier, no fence: a fence would drain the LDS-DMAs in flight (the compiler tracks them as pending LDS
+        // writes); the counted wait above is what makes slab kt visible, and every ds_read of slab kt-1 has been
+        // consumed by an MFMA before its wave gets here
+        __builtin_amdgcn_s_barrier();
+        bf16x8 ah[2], al[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const bf16x8 ah = pack_bf16x8(xa[kk][0], xa[kk][1]);
+            ah[kk] = pack_bf16x8(xs[kk][0], xs[kk][1]);
             f32x4 r0, r1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                r0[e] = xa[kk][0][e] - bf16_to_f32((bf16_t)ah[e]);
-                r1[e] = xa[kk][1][e] - bf16_to_f32((bf16_t)ah[4 + e]);
+                r0[e] = xs[kk][0][e] - bf16_to_f32((bf16_t)ah[kk][e]);
+                r1[e] = xs[kk][1][e] - bf16_to_f32((bf16_t)ah[kk][4 + e]);
             }
-            const bf16x8 al = pack_bf16x8(r0, r1);
-            const int chunk = kk * 4 + g;
+            al[kk] = pack_bf16x8(r0, r1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) { load_x(kt + 2, xs); stage(kt + 2); }
+        const char* sh = smem + (kt % AL_STAGES) * 2 * AL_TILE;
+        const char* sl = sh + AL_TILE;
+        // Each accumulator's three products are issued in three passes over the 8 column tiles, so consecutive MFMAs
+        // never depend on each other (the order per accumulator - hi.hi, hi.lo, lo.hi - and therefore the result is
+        // unchanged); the kk=1 fragments are read under the first kk=0 pass (lgkmcnt is a 4-bit counter: at most 16
+        // reads are kept in flight).
+        bf16x8 bh[2][8], bl[2][8];
+        auto read_frags = [&](int kk) {
+            if ((MADTP_AL_ABLATE & 8) && kt > 0) return;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int rb = j * 16 + l16;
-                const int off = rb * AL_ROWB + ((chunk ^ (rb & 7)) << 4);
-                const bf16x8 bh = *(const bf16x8*)(sh + off);
-                const bf16x8 bl = *(const bf16x8*)(sl + off);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[j], 0, 0, 0);
+                const int off = rb * AL_ROWB + (((kk * 4 + g) ^ (rb & 7)) << 4);
+                bh[kk][j] = *(const bf16x8*)(sh + off);
+                bl[kk][j] = *(const bf16x8*)(sl + off);
             }
+        };
+        read_frags(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(MADTP_AL_ABLATE & 1))
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[0][j], ah[0], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(MADTP_AL_ABLATE & 1)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[0][j], al[0], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[0][j], ah[0], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[1][j], ah[1], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[1][j], al[1], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[1][j], ah[1], acc[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (NK > 0) {
+#pragma unroll
+        for (int kt = 0; kt < NK; kt += 2) {
+            slab(kt, xq[0]);
+            slab(kt + 1, xq[1]);
+        }
+    } else {
+        for (int kt = 0; kt < nk; kt += 2) {
+            slab(kt, xq[0]);
+            slab(kt + 1, xq[1]);
         }
     }
     if (m0 + l16 < M) {
@@ -623,12 +746,12 @@ extern "C" int madtp_mask_gather(const float* mask, const int64_t* order, int ld
 
 extern "C" int madtp_query_att_ft(const float* token_attn, int ldt, int ldb, int K, const float* x, int ldf, int ldfb,
                                   float* out, float inv_sqrt_sd, int accumulate, int B, int n, int dim, int fast,
-                                  void* stream) {
+                                  float* stats_ws, void* stream) {
     if (!token_attn || !x || !out || B <= 0 || n < 1) return MADTP_E_BADARG;
     if (K <= 0 || K > 112 || dim % 256 || ldt < K) return MADTP_E_SHAPE;
     if (fast) {
         const madtp_att_ft_seg one = {token_attn, x, n, ldt, ldb, ldf, ldfb};
-        return madtp_query_att_ft_multi(&one, 1, K, out, inv_sqrt_sd, accumulate, B, dim, stream);
+        return madtp_query_att_ft_multi(&one, 1, K, out, stats_ws, inv_sqrt_sd, accumulate, B, dim, stream);
     }
     hipLaunchKernelGGL(query_att_ft_kernel, dim3(dim / 256, B), dim3(256), 0, (hipStream_t)stream, token_attn, ldt, ldb, K, x,
                        ldf, ldfb, out, inv_sqrt_sd, accumulate, n, dim);
@@ -636,21 +759,24 @@ extern "C" int madtp_query_att_ft(const float* token_attn, int ldt, int ldb, int
     return 0;
 }
 
-extern "C" int madtp_query_att_ft_multi(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float inv_sqrt_sd,
-                                        int accumulate, int B, int dim, void* stream) {
-    if (!segs || !out || nseg < 1 || B <= 0) return MADTP_E_BADARG;
-    if (K <= 0 || K > 112 || dim % 256) return MADTP_E_SHAPE;
+extern "C" int madtp_query_att_ft_multi(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float* stats_ws,
+                                        float inv_sqrt_sd, int accumulate, int B, int dim, void* stream) {
+    if (!segs || !out || !stats_ws || nseg < 1 || B <= 0) return MADTP_E_BADARG;
+    if (K <= 0 || K > 112 || dim % AB_COLS) return MADTP_E_SHAPE;
     for (int first = 0; first < nseg; first += AB_MAXSEG) {
         AttFtSegs a;
         a.nseg = nseg - first < AB_MAXSEG ? nseg - first : AB_MAXSEG;
         for (int i = 0; i < a.nseg; ++i) {
             const madtp_att_ft_seg& g = segs[first + i];
             if (!g.token_attn || !g.ft || g.n < 1) return MADTP_E_BADARG;
-            if (g.ldt_row < K) return MADTP_E_SHAPE;
+            if (g.ldt_row < ((K + 3) & ~3)) return MADTP_E_SHAPE;
             if (g.ldf_row % 4 || g.ldf_batch % 4 || !aligned16(g.ft)) return MADTP_E_ALIGN;
+            if (g.ldt_row % 4 || g.ldt_batch % 4 || !aligned16(g.token_attn)) return MADTP_E_ALIGN;
             a.s[i] = AttFtSeg{g.token_attn, g.ft, g.n, g.ldt_row, g.ldt_batch, g.ldf_row, g.ldf_batch};
         }
-        hipLaunchKernelGGL(query_att_ft_bf16_kernel, dim3(dim / 256, B), dim3(256), 0, (hipStream_t)stream, a, K, out,
+        float* stats = stats_ws + (size_t)first * B * 256;
+        hipLaunchKernelGGL(att_ft_stats_kernel, dim3(a.nseg, B), dim3(256), 0, (hipStream_t)stream, a, K, inv_sqrt_sd, stats);
+        hipLaunchKernelGGL(query_att_ft_bf16_kernel, dim3(dim / AB_COLS, B), dim3(256), 0, (hipStream_t)stream, a, K, stats, out,
                            inv_sqrt_sd, (accumulate || first > 0) ? 1 : 0, dim);
         MADTP_LAUNCH_CHECK();
     }
@@ -672,10 +798,21 @@ extern "C" int madtp_vector_gather(const float* vectors, const int64_t* indices,
 extern "C" int madtp_align_logits(const float* x, const void* sd_hi, const void* sd_lo, float* out, int M, int dim,
                                   void* stream) {
     if (!x || !sd_hi || !sd_lo || !out || M <= 0) return MADTP_E_BADARG;
-    if (dim % 64) return MADTP_E_SHAPE;
+    if (dim % 128) return MADTP_E_SHAPE;
     if (!aligned16(x) || !aligned16(sd_hi) || !aligned16(sd_lo) || !aligned16(out)) return MADTP_E_ALIGN;
-    hipLaunchKernelGGL(align_logits_kernel, dim3((M + 63) / 64), dim3(256), 4 * AL_TILE, (hipStream_t)stream, x,
-                       (const char*)sd_hi, (const char*)sd_lo, out, M, dim);
+    constexpr int lds = AL_STAGES * 2 * AL_TILE;
+    static bool attr = false;
+    if (!attr) {
+        for (const void* f : {(const void*)align_logits_kernel<12>, (const void*)align_logits_kernel<8>,
+                              (const void*)align_logits_kernel<0>}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        attr = true;
+    }
+    auto kern = dim == 768 ? align_logits_kernel<12> : dim == 512 ? align_logits_kernel<8> : align_logits_kernel<0>;
+    hipLaunchKernelGGL(kern, dim3((M + 63) / 64), dim3(256), lds, (hipStream_t)stream, x, (const char*)sd_hi,
+                       (const char*)sd_lo, out, M, dim);
     MADTP_LAUNCH_CHECK();
     return 0;
 }

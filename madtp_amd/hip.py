@@ -12,7 +12,7 @@ import torch
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -37,7 +37,7 @@ _SIGS = {
     "madtp_token_gather": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "madtp_mask_gather": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "madtp_query_att_ft": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_int,
-                                   c_int, c_int, c_int, c_int, c_void_p]),
+                                   c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "madtp_align_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "madtp_vector_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "madtp_vit_block_workspace": (c_size_t, [c_int] * 6),
@@ -45,8 +45,8 @@ _SIGS = {
                                      c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "madtp_vit_block_mlp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
-    "madtp_query_model": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_int,
-                                  c_int, c_int, c_void_p]),
+    "madtp_query_model": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                  c_int, c_int, c_int, c_void_p]),
     "madtp_bert_layer_workspace": (c_size_t, [c_int] * 7),
     "madtp_bert_layer_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
                                       c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -55,7 +55,7 @@ _SIGS = {
                                       c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                       c_void_p, c_void_p]),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
-    "madtp_query_att_ft_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
+    "madtp_query_att_ft_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
@@ -296,8 +296,9 @@ def query_att_ft(token_attn, ft, out=None, sd_dim=768, fast=False):
     if out is None:
         out = torch.empty((B, K, dim), device=ft.device, dtype=torch.float32)
         acc = 0
+    ws = torch.empty(B * 256, device=ft.device, dtype=torch.float32) if fast else None
     _check(load().madtp_query_att_ft(tp, ldr, ldb, K, fp, ldf, ldfb, _p(out), 1.0 / (sd_dim ** 0.5), acc,
-                                     B, n, dim, 1 if fast else 0, _stream()), "madtp_query_att_ft")
+                                     B, n, dim, 1 if fast else 0, _p(ws), _stream()), "madtp_query_att_ft")
     return out
 
 
@@ -319,8 +320,9 @@ def query_att_ft_multi(pairs, out=None, sd_dim=768):
     if out is None:
         out = torch.empty((B, K, dim), device=pairs[0][1].device, dtype=torch.float32)
         acc = 0
-    _check(load().madtp_query_att_ft_multi(segs, len(pairs), K, _p(out), 1.0 / (sd_dim ** 0.5), acc, B, dim, _stream()),
-           "madtp_query_att_ft_multi")
+    ws = torch.empty(len(pairs) * B * 256, device=out.device, dtype=torch.float32)
+    _check(load().madtp_query_att_ft_multi(segs, len(pairs), K, _p(out), _p(ws), 1.0 / (sd_dim ** 0.5), acc, B, dim,
+                                           _stream()), "madtp_query_att_ft_multi")
     return out
 
 
@@ -424,7 +426,8 @@ def query_model(x, sd_w, K, att_ft=None, want_att_ft=True, sd_dim=768, sd_split=
     if want_att_ft and att_ft is None:
         att_ft = torch.empty((B, K, D), device=x.device, dtype=torch.float32)
     hi, lo = sd_split if sd_split is not None else (None, None)
-    _check(load().madtp_query_model(_p(x), _p(sd_w), _p(hi), _p(lo), K, _p(full), _p(att_ft) if want_att_ft else 0, acc,
+    ws = torch.empty(B * 256, device=x.device, dtype=torch.float32) if (want_att_ft and hi is not None) else None
+    _check(load().madtp_query_model(_p(x), _p(sd_w), _p(hi), _p(lo), K, _p(full), _p(att_ft) if want_att_ft else 0, _p(ws), acc,
                                     1.0 / (sd_dim ** 0.5), B, N, D, _stream()), "madtp_query_model")
     return full.view(B, N, kp)[:, 1:, :K], att_ft
 

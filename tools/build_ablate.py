@@ -5,10 +5,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from madtp_amd import build as b
 
 b.build()
+src, macro = ("prune.hip", "MADTP_AL_ABLATE") if os.environ.get("ABLATE") == "align" else ("gemm.hip", "MADTP_WS_ABLATE")
 for n in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]:
-    o = os.path.join(b.LIBDIR, f"gemm_abl{n}.o")
-    subprocess.check_call([b._hipcc()] + b.FLAGS + [f"-DMADTP_WS_ABLATE={n}", "-c", os.path.join(b.CSRC, "gemm.hip"), "-o", o])
-    objs = [o] + [os.path.join(b.LIBDIR, s.replace(".hip", ".o")) for s in b.SOURCES if s != "gemm.hip"]
+    o = os.path.join(b.LIBDIR, f"{src[:-4]}_abl{n}.o")
+    subprocess.check_call([b._hipcc()] + b.FLAGS + [f"-D{macro}={n}", "-c", os.path.join(b.CSRC, src), "-o", o])
+    objs = [o] + [os.path.join(b.LIBDIR, s.replace(".hip", ".o")) for s in b.SOURCES if s != src]
     lib = os.path.join(b.LIBDIR, f"libmadtp_hip_abl{n}.so")
     subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     print(lib)
