@@ -109,6 +109,15 @@ int madtp_token_score(const float* colsum_part, int n_row_tiles, const float* p0
                       float* score, float* threshold, int32_t* count, int32_t* kmax,
                       int B, int H, int N, void* stream);
 
+/* Same launch, but k = max_b count is handed to the HOST: the last workgroup writes it to pinned host memory and the call
+ * returns once it has arrived (*k_host).  This is the reference's one synchronisation per layer (`topk_num.item()`,
+ * vit.py:145) without a device-to-host copy and a stream synchronisation; work queued on `stream` before the call has
+ * completed when it returns.  Calls are serialised on a process-wide slot. */
+int madtp_token_score_sync(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
+                           const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature,
+                           float* score, float* threshold, int32_t* count, int32_t* k_host,
+                           int B, int H, int N, void* stream);
+
 /* Top-k selection by rank + merge weights (vit.py:153-159).  For each sample: rank tokens by score (descending,
  * ties -> lower index first); kept = rank < k, emitted in ascending token order.
  *   indices      int64 [B,k]   kept token ids (the reference's `indices`, order implementation-defined there)
@@ -203,6 +212,15 @@ int madtp_vit_block_attn(const madtp_vit_block_w* w, const float* x, float* x_ou
 int madtp_vit_block_mlp(const madtp_vit_block_w* w, const float* x, float* y, void* ws, size_t ws_bytes, int B, int N, int k,
                         const float* score, int64_t* indices, int64_t* indices_sort, void* stream);
 
+/* Block.forward (vit.py:184-205) in one call = madtp_vit_block_attn, host read of k (madtp_token_score_sync), pruning rule
+ * vit.py:148-149, madtp_vit_block_mlp.  x_attn [B,N,dim] scratch/output of the attention half; y and indices sized for the
+ * unpruned case ([B,N,dim], [B,N-1]); *k_out = max_b count (0 when temperature <= 0), *k_used = k actually applied: when
+ * > 0, y holds [B,k_used+2,dim] and indices [B,k_used] (both contiguous from the start of their buffers). */
+int madtp_vit_block(const madtp_vit_block_w* w, const float* x, float* x_attn, float* y, void* ws, size_t ws_bytes, int B, int N,
+                    const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature, float* score,
+                    float* threshold, int32_t* count, int64_t* indices, int64_t* indices_sort, int* k_out, int* k_used,
+                    void* stream);
+
 /* Query_model.forward(return_token_att=True) (models/utils.py:147-183) over a contiguous token buffer x[B,N,dim]:
  * token_attn_full[B*N, 128] = x @ sd^T (exact-f32 MFMA; sd_w is f32 [128,dim], rows >= K zero); row b*N+1+t is patch t.
  * att_ft[B,K,dim] (+)= softmax_t(logits/sqrt(sd_dim)) @ x[:,1:]  (skipped when att_ft is NULL). */
@@ -244,6 +262,15 @@ int madtp_bert_layer_rest(const madtp_bert_layer_w* w, const float* att, const f
                           void* ws, size_t ws_bytes, int B, int L, int k, const float* score, int64_t* indices,
                           int64_t* indices_sort, int cross_mode, const void* enc0, const void* enc1, int Nk,
                           const float* enc_mask0, const float* enc_mask1, void* stream);
+
+/* BertLayer.forward in one call = madtp_bert_layer_attn, host read of k, pruning rule med.py:374-375,
+ * madtp_bert_layer_rest.  Buffers sized for the unpruned case (y [B,L,dim], mask_out [B,L], indices [B,L-1]); *k_used > 0:
+ * y is [B,k_used+2,dim], mask_out [B,k_used+2], indices [B,k_used]. */
+int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden, const float* mask2d, float* att, float* y,
+                     float* mask_out, void* ws, size_t ws_bytes, int B, int L, int Nk, const float* token_attn, int ldt_row,
+                     int ldt_batch, int K, float temperature, float* score, float* threshold, int32_t* count,
+                     int64_t* indices, int64_t* indices_sort, int cross_mode, const void* enc0, const void* enc1,
+                     const float* enc_mask0, const float* enc_mask1, int* k_out, int* k_used, void* stream);
 
 #ifdef __cplusplus
 }

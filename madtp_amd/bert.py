@@ -375,20 +375,11 @@ class _BertLayerBase(nn.Module):
                 Nk = encoder_hidden_states.shape[1]
                 enc0 = self._enc_operand(encoder_hidden_states)
         w = self._weights()
-        # self-attention + output LayerNorm (+ importance score / threshold / count)   med.py:408-418,347-371
-        att, po = hip.bert_layer_attn(w, hidden, mask2d, token_attn, temperature if prune else 0, Nk)
-        self.last_prune = None
-        k_use, score = 0, None
-        if prune:
-            score, thr, count, kmax = po
-            k = hip.batch_max_count(count)
-            self.last_prune = {"k": k, "score": score, "threshold": thr, "count": count, "pruned": False,
-                               "indices": None, "indices_sort": None}
-            if not (k < 1 or (L - 1 - k) <= 1):
-                k_use = k
-        y, mask_out, indices, indices_sort = hip.bert_layer_rest(w, att, mask2d, k_use, score, cross, enc0, enc1, Nk, em0, em1)
-        if k_use:
-            self.last_prune.update(pruned=True, indices=indices, indices_sort=indices_sort)
+        # one library call: self-attention + output LayerNorm, importance score / threshold / count (med.py:408-418,
+        # 347-371), host read of k, [prune att + mask], cross-attention, FFN
+        y, mask_out, self.last_prune = hip.bert_layer(w, hidden, mask2d, token_attn, temperature if prune else 0, cross, enc0, enc1,
+                                                      Nk, em0, em1)
+        if mask_out is not None:
             attention_mask = mask_out[:, None, None, :]
         return (y, None, attention_mask)  # present_key_value is not kept (encoder use, use_cache=False)
 

@@ -134,10 +134,9 @@ extern "C" size_t madtp_vit_block_workspace(int B, int N, int dim, int hidden, i
 }
 
 // x = x + proj(attention(qkv(LN1(x))))  [+ importance score / threshold / count / kmax when temperature > 0]
-extern "C" int madtp_vit_block_attn(const madtp_vit_block_w* w, const float* x, float* x_out, void* ws, size_t ws_bytes,
-                                    int B, int N, const float* token_attn, int ldt_row, int ldt_batch, int K,
-                                    float temperature, float* score, float* threshold, int32_t* count, int32_t* kmax,
-                                    void* stream) {
+static int vit_attn_impl(const madtp_vit_block_w* w, const float* x, float* x_out, void* ws, size_t ws_bytes, int B, int N,
+                         const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature, float* score,
+                         float* threshold, int32_t* count, int32_t* kmax, int32_t* k_host, void* stream) {
     if (!w || !x || !x_out || !ws || B <= 0 || N <= 0) return MADTP_E_BADARG;
     bool ok;
     VitWs s = vit_carve((char*)ws, ws_bytes, B, N, w->dim, w->fc1.n, w->heads, w->dtype, &ok);
@@ -153,6 +152,9 @@ extern "C" int madtp_vit_block_attn(const madtp_vit_block_w* w, const float* x, 
                         B, w->heads, N, N, 3 * D, 3 * D, 3 * D, D, w->scale, dt, stream));
     TRY(lin(s.o, D, w->proj, x, D, x_out, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
     if (prune) {
+        if (k_host)  // k = max_b count delivered through pinned host memory (returns once the value is there)
+            return madtp_token_score_sync(s.colsum, (N + 15) / 16, s.p0, s.onorm, token_attn, ldt_row, ldt_batch, K, temperature,
+                                          score, threshold, count, k_host, B, w->heads, N, stream);
         if (kmax) {
             hipError_t he = hipMemsetAsync(kmax, 0, sizeof(int32_t), (hipStream_t)stream);
             if (he != hipSuccess) return (int)he;
@@ -161,6 +163,14 @@ extern "C" int madtp_vit_block_attn(const madtp_vit_block_w* w, const float* x, 
                               threshold, count, kmax, B, w->heads, N, stream));
     }
     return 0;
+}
+
+extern "C" int madtp_vit_block_attn(const madtp_vit_block_w* w, const float* x, float* x_out, void* ws, size_t ws_bytes,
+                                    int B, int N, const float* token_attn, int ldt_row, int ldt_batch, int K,
+                                    float temperature, float* score, float* threshold, int32_t* count, int32_t* kmax,
+                                    void* stream) {
+    return vit_attn_impl(w, x, x_out, ws, ws_bytes, B, N, token_attn, ldt_row, ldt_batch, K, temperature, score, threshold,
+                         count, kmax, nullptr, stream);
 }
 
 // [select top-k, gather + merge] ; y = x' + fc2(GELU(fc1(LN2(x'))))    k == 0: no pruning (x' = x), y is [B,N,dim];
@@ -186,6 +196,25 @@ extern "C" int madtp_vit_block_mlp(const madtp_vit_block_w* w, const float* x, f
     TRY(lin(s.h, D, w->fc1, nullptr, 0, s.mid, w->fc1.n, M, dt, dt, w->act, 1.f, stream));
     TRY(lin(s.mid, w->fc1.n, w->fc2, xr, D, y, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
     return 0;
+}
+
+// Whole Block.forward (vit.py:184-205) in one call: attention half, k = max_b count read on the host (the reference's one
+// synchronisation per layer, vit.py:145), the pruning rule of vit.py:148-149, MLP half launched straight away.
+// y has room for [B,N,dim], indices for [B,N-1]; on return *k_used > 0 means y is [B,k_used+2,dim] and indices [B,k_used].
+extern "C" int madtp_vit_block(const madtp_vit_block_w* w, const float* x, float* x_attn, float* y, void* ws, size_t ws_bytes,
+                               int B, int N, const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature,
+                               float* score, float* threshold, int32_t* count, int64_t* indices, int64_t* indices_sort,
+                               int* k_out, int* k_used, void* stream) {
+    if (!k_out || !k_used) return MADTP_E_BADARG;
+    *k_out = 0; *k_used = 0;
+    int32_t k = 0;
+    TRY(vit_attn_impl(w, x, x_attn, ws, ws_bytes, B, N, token_attn, ldt_row, ldt_batch, K, temperature, score, threshold, count,
+                      nullptr, temperature > 0.f ? &k : nullptr, stream));
+    if (temperature > 0.f) {
+        *k_out = k;
+        if (!(k < 1 || (N - 1 - k) <= 1)) *k_used = k;  // vit.py:148-149
+    }
+    return madtp_vit_block_mlp(w, x_attn, y, ws, ws_bytes, B, N, *k_used, score, indices, indices_sort, stream);
 }
 
 // Query_model (models/utils.py:147-183) on the token buffer in place: logits of ALL rows of x (the CLS row is computed
@@ -216,10 +245,10 @@ extern "C" size_t madtp_bert_layer_workspace(int B, int L, int Nk, int dim, int 
 }
 
 // att = LayerNorm(dense(self_attention(hidden)) + hidden)   [+ score/threshold/count/kmax when temperature > 0]
-extern "C" int madtp_bert_layer_attn(const madtp_bert_layer_w* w, const float* hidden, const float* mask2d, float* att,
-                                     void* ws, size_t ws_bytes, int B, int L, int Nk, const float* token_attn, int ldt_row,
-                                     int ldt_batch, int K, float temperature, float* score, float* threshold, int32_t* count,
-                                     int32_t* kmax, void* stream) {
+static int bert_attn_impl(const madtp_bert_layer_w* w, const float* hidden, const float* mask2d, float* att, void* ws,
+                          size_t ws_bytes, int B, int L, int Nk, const float* token_attn, int ldt_row, int ldt_batch, int K,
+                          float temperature, float* score, float* threshold, int32_t* count, int32_t* kmax, int32_t* k_host,
+                          void* stream) {
     if (!w || !hidden || !att || !ws || B <= 0 || L <= 0) return MADTP_E_BADARG;
     bool ok;
     BertWs s = bert_carve((char*)ws, ws_bytes, B, L, Nk, w->dim, w->inter.n, w->heads, w->dtype, &ok);
@@ -239,6 +268,9 @@ extern "C" int madtp_bert_layer_attn(const madtp_bert_layer_w* w, const float* h
                         B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale, dt, stream));
     TRY(lin_ln(s.ctx, D, w->attn_out, hidden, 1.f, w->ln_att_g, w->ln_att_b, att, nullptr, M, dt, w->eps, s.part, stream));
     if (prune) {
+        if (k_host)
+            return madtp_token_score_sync(s.colsum, (L + 15) / 16, s.p0, s.onorm, token_attn, ldt_row, ldt_batch, K, temperature,
+                                          score, threshold, count, k_host, B, w->heads, L, stream);
         if (kmax) {
             hipError_t he = hipMemsetAsync(kmax, 0, sizeof(int32_t), (hipStream_t)stream);
             if (he != hipSuccess) return (int)he;
@@ -247,6 +279,14 @@ extern "C" int madtp_bert_layer_attn(const madtp_bert_layer_w* w, const float* h
                               threshold, count, kmax, B, w->heads, L, stream));
     }
     return 0;
+}
+
+extern "C" int madtp_bert_layer_attn(const madtp_bert_layer_w* w, const float* hidden, const float* mask2d, float* att,
+                                     void* ws, size_t ws_bytes, int B, int L, int Nk, const float* token_attn, int ldt_row,
+                                     int ldt_batch, int K, float temperature, float* score, float* threshold, int32_t* count,
+                                     int32_t* kmax, void* stream) {
+    return bert_attn_impl(w, hidden, mask2d, att, ws, ws_bytes, B, L, Nk, token_attn, ldt_row, ldt_batch, K, temperature, score,
+                          threshold, count, kmax, nullptr, stream);
 }
 
 // [prune att + mask] ; [cross-attention to the image tokens] ; y = LayerNorm(output(GELU(intermediate(a))) + a)
@@ -341,4 +381,26 @@ ffn:
     TRY(lin(ac, D, w->inter, nullptr, 0, s.mid, w->inter.n, M, dt, dt, MADTP_ACT_GELU_ERF, 1.f, stream));
     TRY(lin_ln(s.mid, w->inter.n, w->out, a32, 1.f, w->ln_out_g, w->ln_out_b, y, nullptr, M, dt, w->eps, s.part, stream));
     return 0;
+}
+
+// Whole BertLayer.forward in one call (med.py:393-467 / nlvr_encoder.py:484-559): self-attention half, host read of
+// k = max_b count, the pruning rule of med.py:374-375, then the rest.  y has room for [B,L,dim], mask_out for [B,L],
+// indices for [B,L-1]; *k_used > 0 means y is [B,k_used+2,dim], mask_out [B,k_used+2], indices [B,k_used].
+extern "C" int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden, const float* mask2d, float* att, float* y,
+                                float* mask_out, void* ws, size_t ws_bytes, int B, int L, int Nk, const float* token_attn,
+                                int ldt_row, int ldt_batch, int K, float temperature, float* score, float* threshold,
+                                int32_t* count, int64_t* indices, int64_t* indices_sort, int cross_mode, const void* enc0,
+                                const void* enc1, const float* enc_mask0, const float* enc_mask1, int* k_out, int* k_used,
+                                void* stream) {
+    if (!k_out || !k_used) return MADTP_E_BADARG;
+    *k_out = 0; *k_used = 0;
+    int32_t k = 0;
+    TRY(bert_attn_impl(w, hidden, mask2d, att, ws, ws_bytes, B, L, Nk, token_attn, ldt_row, ldt_batch, K, temperature, score,
+                       threshold, count, nullptr, temperature > 0.f ? &k : nullptr, stream));
+    if (temperature > 0.f) {
+        *k_out = k;
+        if (!(k < 1 || (L - 1 - k) <= 1)) *k_used = k;
+    }
+    return madtp_bert_layer_rest(w, att, mask2d, y, mask_out, ws, ws_bytes, B, L, *k_used, score, indices, indices_sort, cross_mode,
+                                 enc0, enc1, Nk, enc_mask0, enc_mask1, stream);
 }

@@ -8,6 +8,13 @@
 // coalesced row reads, wave shuffle reductions, ballot/popcount prefix sums, fixed reduction orders (no float
 // atomics, so results are run-to-run deterministic and independent of workgroup placement).
 #include "common.h"
+#include <chrono>
+#include <mutex>
+#include <vector>
+
+#ifndef TRY
+#define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+#endif
 
 namespace {
 
@@ -23,6 +30,16 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid, int nwa
     return s;
 }
 
+__device__ __forceinline__ float block_max_f(float v, float* red, int tid, int nwaves) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float m = red[0];
+    for (int w = 1; w < nwaves; ++w) m = fmaxf(m, red[w]);
+    return m;
+}
+
 // ------------------------------------------------------------------------------------------------ token_score
 // one 512-thread workgroup per sample.  The sample's logits token_attn[b] (n x K f32, <= 150 KB) are staged in LDS
 // once with coalesced float4 loads (STAGED; falls back to reading global memory for very long sequences), then
@@ -35,8 +52,9 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
                                                           const float* __restrict__ ta, int ldt_g, int ldb, int K, float temperature,
                                                           float* __restrict__ score, float* __restrict__ threshold,
                                                           int32_t* __restrict__ count, int32_t* __restrict__ kmax, int H,
-                                                          int N) {
+                                                          int N, int32_t* done_ctr, int32_t* host_slot, int seq) {
     __shared__ float I_s[MAXN];
+    __shared__ int last_s;
     __shared__ float tw_s[MAXN];
     __shared__ float red[8];
     __shared__ float colred[4][128];
@@ -146,6 +164,26 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
         threshold[b] = thr;
         count[b] = (int)total;
         if (kmax) atomicMax(kmax, (int)total);
+        int last = 0;
+        if (done_ctr) {
+            __threadfence();  // count[b] is visible before the ticket
+            last = atomicAdd(done_ctr, 1) == (int)gridDim.x - 1;
+        }
+        last_s = last;
+    }
+    if (!done_ctr) return;
+    __syncthreads();
+    if (!last_s) return;
+    // Last workgroup of the launch: k = max_b count goes straight to host-visible pinned memory (slot[0] = k, then
+    // slot[1] = sequence number with system-scope release) - the host spins on the sequence number instead of paying a
+    // device-to-host copy plus a stream synchronisation for the one value it needs per layer (vit.py:145 `.item()`).
+    int mloc = 0;
+    for (int i = tid; i < (int)gridDim.x; i += 512) mloc = max(mloc, __hip_atomic_load(count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const int kk = (int)block_max_f((float)mloc, red, tid, 8);  // exact: counts <= 1024
+    if (tid == 0) {
+        *done_ctr = 0;
+        __hip_atomic_store(host_slot, kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_slot + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -686,9 +724,10 @@ __global__ __launch_bounds__(256, 1) void align_logits_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int madtp_token_score(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
-                                 const float* token_attn, int ldt, int ldb, int K, float temperature, float* score,
-                                 float* threshold, int32_t* count, int32_t* kmax, int B, int H, int N, void* stream) {
+static int token_score_launch(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
+                              const float* token_attn, int ldt, int ldb, int K, float temperature, float* score,
+                              float* threshold, int32_t* count, int32_t* kmax, int B, int H, int N, int32_t* done_ctr,
+                              int32_t* host_slot, int seq, void* stream) {
     if (!colsum_part || !p0 || !onorm || !token_attn || !score || !threshold || !count) return MADTP_E_BADARG;
     if (B <= 0 || H <= 0 || N < 2 || n_row_tiles <= 0 || !(temperature > 0.f)) return MADTP_E_BADARG;
     if (N - 1 > MAXN || K > 128 || K <= 0 || ldt < K) return MADTP_E_SHAPE;
@@ -703,12 +742,73 @@ extern "C" int madtp_token_score(const float* colsum_part, int n_row_tiles, cons
             attr = true;
         }
         hipLaunchKernelGGL(token_score_kernel<true>, dim3(B), dim3(512), stage_bytes, (hipStream_t)stream, colsum_part,
-                           n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N);
+                           n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N,
+                           done_ctr, host_slot, seq);
     } else {
         hipLaunchKernelGGL(token_score_kernel<false>, dim3(B), dim3(512), 0, (hipStream_t)stream, colsum_part, n_row_tiles, p0,
-                           onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N);
+                           onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N, done_ctr, host_slot,
+                           seq);
     }
     MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_token_score(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
+                                 const float* token_attn, int ldt, int ldb, int K, float temperature, float* score,
+                                 float* threshold, int32_t* count, int32_t* kmax, int B, int H, int N, void* stream) {
+    return token_score_launch(colsum_part, n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count,
+                              kmax, B, H, N, nullptr, nullptr, 0, stream);
+}
+
+// Host-visible batch maximum: process-wide pinned slot {k, sequence} + a device ticket counter (allocated on first use).
+namespace {
+struct HostSync {
+    int32_t* host = nullptr;      // pinned, device-accessible: [0] = k, [1] = sequence number of the launch that wrote it
+    int32_t* host_dev = nullptr;  // the same memory as the device sees it
+    int32_t* ctr = nullptr;       // device ticket counter (the last workgroup resets it)
+    int seq = 0;
+    std::mutex mu;
+};
+HostSync g_sync;
+int host_sync_init() {
+    if (g_sync.host) return 0;
+    hipError_t e = hipHostMalloc((void**)&g_sync.host, 64, hipHostMallocMapped);
+    if (e != hipSuccess) return (int)e;
+    g_sync.host[0] = 0; g_sync.host[1] = 0;
+    e = hipHostGetDevicePointer((void**)&g_sync.host_dev, g_sync.host, 0);
+    if (e != hipSuccess) return (int)e;
+    e = hipMalloc((void**)&g_sync.ctr, sizeof(int32_t));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemset(g_sync.ctr, 0, sizeof(int32_t));
+}
+}  // namespace
+
+extern "C" int madtp_token_score_sync(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
+                                      const float* token_attn, int ldt, int ldb, int K, float temperature, float* score,
+                                      float* threshold, int32_t* count, int32_t* k_host, int B, int H, int N, void* stream) {
+    if (!k_host) return MADTP_E_BADARG;
+    std::lock_guard<std::mutex> lock(g_sync.mu);
+    TRY(host_sync_init());
+    const int seq = ++g_sync.seq;
+    TRY(token_score_launch(colsum_part, n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count,
+                           nullptr, B, H, N, g_sync.ctr, g_sync.host_dev, seq, stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; __atomic_load_n(&g_sync.host[1], __ATOMIC_ACQUIRE) != seq; ++spins) {
+        if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+            // never signalled (failed launch / lost stream): fall back to the ordinary path so the error surfaces
+            hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+            std::vector<int32_t> h(B);
+            e = hipMemcpy(h.data(), count, sizeof(int32_t) * B, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return (int)e;
+            int m = 0;
+            for (int v : h) m = v > m ? v : m;
+            (void)hipMemset(g_sync.ctr, 0, sizeof(int32_t));
+            *k_host = m;
+            return 0;
+        }
+    }
+    *k_host = __atomic_load_n(&g_sync.host[0], __ATOMIC_RELAXED);
     return 0;
 }
 

@@ -54,6 +54,12 @@ _SIGS = {
     "madtp_bert_layer_rest": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
                                       c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                       c_void_p, c_void_p]),
+    "madtp_token_score_sync": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float]
+                               + [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
+    "madtp_vit_block": (c_int, [c_void_p] * 5 + [c_size_t, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
+                        + [c_void_p] * 7 + [c_void_p]),
+    "madtp_bert_layer": (c_int, [c_void_p] * 7 + [c_size_t, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
+                         + [c_void_p] * 5 + [c_int] + [c_void_p] * 6 + [c_void_p]),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
     "madtp_query_att_ft_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -372,6 +378,77 @@ def prune_outputs(B, n, device):
 def batch_max_count(count):
     """k = max_b count (vit.py:145 `.item()`): one D2H copy of B int32 values, max on the host."""
     return int(count.cpu().max())
+
+
+def _carve(buf, *shape):
+    """leading contiguous [*shape] view of a (larger) flat buffer."""
+    n = 1
+    for d in shape:
+        n *= d
+    return buf.view(-1)[:n].view(*shape)
+
+
+def vit_block(wstruct, x, token_attn, temperature):
+    """Block.forward in ONE library call (attention half, host read of k, pruning rule, MLP half).
+    -> (y [B,N',D], info or None); info = dict(k, score, threshold, count, pruned, indices, indices_sort)."""
+    B, N, D = x.shape
+    lib = load()
+    nbytes = lib.madtp_vit_block_workspace(B, N, wstruct.dim, wstruct.fc1.n, wstruct.heads, wstruct.dtype)
+    ws = workspace(nbytes, x.device)
+    x_attn = torch.empty_like(x)
+    ybuf = torch.empty_like(x)
+    k_out, k_used = ctypes.c_int(0), ctypes.c_int(0)
+    if temperature > 0:
+        tp, ldr, ldb, K = _ta_view(token_attn)
+        score, thr, count, _ = prune_outputs(B, N - 1, x.device)
+        idx = torch.empty((B, N - 1), device=x.device, dtype=torch.int64)
+        idx_sort = torch.empty((B, N - 1), device=x.device, dtype=torch.int64)
+        _check(lib.madtp_vit_block(ctypes.byref(wstruct), _p(x), _p(x_attn), _p(ybuf), _p(ws), ws.numel(), B, N, tp, ldr, ldb, K,
+                                   float(temperature), _p(score), _p(thr), _p(count), _p(idx), _p(idx_sort),
+                                   ctypes.byref(k_out), ctypes.byref(k_used), _stream()), "madtp_vit_block")
+        info = {"k": k_out.value, "score": score, "threshold": thr, "count": count, "pruned": False, "indices": None,
+                "indices_sort": None}
+        if k_used.value > 0:
+            k = k_used.value
+            info.update(pruned=True, indices=_carve(idx, B, k), indices_sort=idx_sort)
+            return _carve(ybuf, B, k + 2, D), info
+        return ybuf, info
+    _check(lib.madtp_vit_block(ctypes.byref(wstruct), _p(x), _p(x_attn), _p(ybuf), _p(ws), ws.numel(), B, N, 0, 0, 0, 0, 0.0,
+                               0, 0, 0, 0, 0, ctypes.byref(k_out), ctypes.byref(k_used), _stream()), "madtp_vit_block")
+    return ybuf, None
+
+
+def bert_layer(wstruct, hidden, mask2d, token_attn, temperature, cross_mode, enc0, enc1, Nk, enc_mask0, enc_mask1):
+    """BertLayer.forward in ONE library call.  -> (y [B,L',D], mask_out [B,L'] or None, info or None)."""
+    B, L, D = hidden.shape
+    lib = load()
+    nbytes = lib.madtp_bert_layer_workspace(B, L, Nk, wstruct.dim, wstruct.inter.n, wstruct.heads, wstruct.dtype)
+    ws = workspace(nbytes, hidden.device)
+    att = torch.empty_like(hidden)
+    ybuf = torch.empty_like(hidden)
+    k_out, k_used = ctypes.c_int(0), ctypes.c_int(0)
+    dev = hidden.device
+    if temperature > 0:
+        tp, ldr, ldb, K = _ta_view(token_attn)
+        score, thr, count, _ = prune_outputs(B, L - 1, dev)
+        idx = torch.empty((B, L - 1), device=dev, dtype=torch.int64)
+        idx_sort = torch.empty((B, L - 1), device=dev, dtype=torch.int64)
+        mbuf = torch.empty((B, L), device=dev, dtype=torch.float32) if mask2d is not None else None
+        _check(lib.madtp_bert_layer(ctypes.byref(wstruct), _p(hidden), _p(mask2d), _p(att), _p(ybuf), _p(mbuf), _p(ws), ws.numel(),
+                                    B, L, Nk, tp, ldr, ldb, K, float(temperature), _p(score), _p(thr), _p(count), _p(idx),
+                                    _p(idx_sort), int(cross_mode), _p(enc0), _p(enc1), _p(enc_mask0), _p(enc_mask1),
+                                    ctypes.byref(k_out), ctypes.byref(k_used), _stream()), "madtp_bert_layer")
+        info = {"k": k_out.value, "score": score, "threshold": thr, "count": count, "pruned": False, "indices": None,
+                "indices_sort": None}
+        if k_used.value > 0:
+            k = k_used.value
+            info.update(pruned=True, indices=_carve(idx, B, k), indices_sort=idx_sort)
+            return _carve(ybuf, B, k + 2, D), (_carve(mbuf, B, k + 2) if mbuf is not None else None), info
+        return ybuf, None, info
+    _check(lib.madtp_bert_layer(ctypes.byref(wstruct), _p(hidden), _p(mask2d), _p(att), _p(ybuf), 0, _p(ws), ws.numel(), B, L, Nk,
+                                0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, int(cross_mode), _p(enc0), _p(enc1), _p(enc_mask0), _p(enc_mask1),
+                                ctypes.byref(k_out), ctypes.byref(k_used), _stream()), "madtp_bert_layer")
+    return ybuf, None, None
 
 
 def vit_block_attn(wstruct, x, token_attn, temperature):

@@ -177,21 +177,9 @@ class Block(nn.Module):
         if prune and token_attn is None:
             raise ValueError("temperature > 0 requires token_attn (the reference fails in Reduce_token as well)")
         w = self._weights()
-        # x = x + attn(norm1(x)) and the importance score / threshold / survivor count   vit.py:186-190,125-145
-        x_attn, po = hip.vit_block_attn(w, x, token_attn, temperature if prune else 0)
-        self.last_prune = None
-        k_use, score = 0, None
-        if prune:
-            score, thr, count, kmax = po
-            k = hip.batch_max_count(count)  # topk_num = max_b count: one host sync per layer, as vit.py:145
-            self.last_prune = {"k": k, "score": score, "threshold": thr, "count": count, "pruned": False,
-                               "indices": None, "indices_sort": None}
-            if not (k < 1 or (N - 1 - k) <= 1):  # vit.py:148-149
-                k_use = k
-        # [top-k, gather, merge] and x = x + mlp(norm2(x))   vit.py:153-161,195-205
-        y, indices, indices_sort = hip.vit_block_mlp(w, x_attn, k_use, score)
-        if k_use:
-            self.last_prune.update(pruned=True, indices=indices, indices_sort=indices_sort)
+        # one library call: x = x + attn(norm1(x)), importance score / threshold / count (vit.py:186-190,125-145), the host
+        # read of k = max_b count (vit.py:145), [top-k, gather, merge] and x = x + mlp(norm2(x)) (vit.py:153-161,195-205)
+        y, self.last_prune = hip.vit_block(w, x, token_attn, temperature if prune else 0)
         return y
 
 
