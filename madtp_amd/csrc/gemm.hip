@@ -611,9 +611,19 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     // vector epilogue needs 16-byte aligned rows on every epilogue operand
     g.fast_epi = (N % 8 == 0) && (ldc % 8 == 0) && aligned16(C) && (!bias || aligned16(bias)) &&
                  (!residual || (aligned16(residual) && ldr % 4 == 0));
-    // tile configuration: 128x128 tiles, 2 workgroups/CU, 2-stage ring.  MADTP_GEMM_CFG=2/3/4 selects the
-    // experimental 64x64x6 / 128x128x3 / 128x128x4 variants (kept for A/B measurements).
-    int cfg = 0;  // measured on MI355X: the 64x64 / deeper-ring variants lose to 128x128x2 on every shape of the path
+    // tile configuration (MADTP_GEMM_CFG=1..4 forces one of the gemm_kernel variants for A/B measurements):
+    //   0: 128x128, 2-stage ring, 2 workgroups/CU  - default, and the f32 path
+    //   1: 64x128, 2 stages, 3 WG/CU   2: 64x128, 3 stages, 2 WG/CU   3: 64x64, 3 stages, 3 WG/CU
+    // Small bf16 problems (the 1280-row GEMMs of the text encoder) are bound by the LDS-DMA rate of a CU (~40 GB/s with one
+    // resident workgroup): what counts is spreading the operand bytes over ALL CUs in one round, so they take the
+    // smallest tile whose grid still fits one round of 3 workgroups per CU (measured: 64x64 beats 128x128 by 20-45 % on
+    // M=1280, N<=2304; 64x128 wins for N=3072).
+    int cfg = 0;
+    if (ab_dtype == MADTP_BF16 && M < 4096) {
+        const int t64 = ((M + 63) / 64) * ((N + 63) / 64) * splitk, t64x128 = ((M + 63) / 64) * ((N + 127) / 128) * splitk;
+        if (t64 <= 768) cfg = 3;
+        else if (t64x128 <= 768) cfg = 1;
+    }
     // MADTP_GEMM_CFG=5 forces the wave-specialised kernel, 1..4 force a gemm_kernel variant (A/B measurements)
     const bool ws_ok = ab_dtype == MADTP_BF16 && splitk == 1 && (force_cfg == 5 || (force_cfg == 0 && M >= 4096));
     if (force_cfg > 0 && force_cfg <= 4) cfg = force_cfg - 1;
@@ -648,9 +658,9 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
 #define MADTP_DISPATCH_CFG(TT, LP)                                             \
     do {                                                                       \
         if (cfg == 0) MADTP_LAUNCH_GEMM(TT, LP, 128, 128, 2, 2);               \
-        else if (cfg == 1) MADTP_LAUNCH_GEMM(TT, LP, 64, 64, 6, 1);            \
-        else if (cfg == 2) MADTP_LAUNCH_GEMM(TT, LP, 128, 128, 3, 1);          \
-        else MADTP_LAUNCH_GEMM(TT, LP, 128, 128, 4, 1);                        \
+        else if (cfg == 1) MADTP_LAUNCH_GEMM(TT, LP, 64, 128, 2, 3);           \
+        else if (cfg == 2) MADTP_LAUNCH_GEMM(TT, LP, 64, 128, 3, 2);           \
+        else MADTP_LAUNCH_GEMM(TT, LP, 64, 64, 3, 3);                          \
     } while (0)
     if (ws_ok) {
         // wave-specialised 256x128 kernel (one 12-wave workgroup per CU, 144 KiB LDS ring)

@@ -42,8 +42,17 @@ inline int ln_to(const float* x, const float* g, const float* b, float* y32, voi
 // split-K factor for a small-M projection that feeds a LayerNorm: only when the tile count leaves most CUs idle and the
 // K loop is long enough that cutting it beats the extra partial traffic (S*M*N*4 bytes written and re-read)
 inline int choose_splits(int M, int N, int K, int dt) {
-    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int nk = (int)(K * esz_of(dt) / 128);
+    if (dt == MADTP_BF16 && M < 4096) {
+        // small bf16 problem: madtp_gemm runs it on 64x64 tiles, 3 workgroups per CU; split K while the grid still fits
+        // one round (768 workgroups) and every split keeps >= 12 slabs
+        const int t64 = ((M + 63) / 64) * ((N + 63) / 64);
+        int best = 1;
+        for (int sp = 2; sp <= 4; ++sp)
+            if (nk % sp == 0 && nk / sp >= 12 && t64 * sp <= 768) best = sp;
+        return best;
+    }
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     if (tiles > 128 || nk < 24) return 1;
     int best = 1;
     for (int sp = 2; sp <= 4; ++sp)
