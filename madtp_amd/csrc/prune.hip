@@ -46,6 +46,12 @@ __device__ __forceinline__ float block_max_f(float v, float* red, int tid, int n
 //   phase A: per-token terms (row max of the logits, column mass of head-max attention, CLS attention);
 //   phase B: per-dictionary-column softmax over tokens (4 token slices x 128 columns) and
 //            threshold = min_k sum_t softmax_t(x/T)[t,k] * I[t]; survivor count; optional batch max (atomicMax).
+#ifdef MADTP_TS_TIMING
+__device__ long long g_ts_dbg[16];
+#define TS_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_ts_dbg[i] = wall_clock64(); } while (0)
+#else
+#define TS_MARK(i)
+#endif
 template <bool STAGED>
 __global__ __launch_bounds__(512) void token_score_kernel(const float* __restrict__ colsum, int nrt,
                                                           const float* __restrict__ p0, const float* __restrict__ onorm,
@@ -63,6 +69,7 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, n = N - 1;
     const float* ta_g = ta + (size_t)b * ldb;  // row t <-> patch token t
+    TS_MARK(0);
     if constexpr (STAGED) {
         const int k4 = K >> 2;  // K % 4 == 0 on this path
         for (int idx = tid; idx < n * k4; idx += 512) {
@@ -71,41 +78,76 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
         }
         __syncthreads();
     }
+    TS_MARK(1);
     const int ldt = STAGED ? K : ldt_g;
     auto TA = [&](int t, int c) -> float { return STAGED ? ta_s[t * ldt + c] : ta_g[(size_t)t * ldt + c]; };
 
-    // token_attn_w = max over dictionary columns (vit.py:131): one wave per row, lanes over columns
-    for (int t = wave; t < n; t += 8) {
-        float m = -INFINITY;
-        for (int k = lane; k < K; k += 64) m = fmaxf(m, TA(t, k));
-        m = wave_max(m);
-        if (lane == 0) tw_s[t] = m;
+    // token_attn_w = max over dictionary columns (vit.py:131)
+    if constexpr (STAGED) {
+        // four lanes per row, float4 reads, two quad shuffles: 128 rows per pass (a wave-wide reduction per row costs six
+        // dependent cross-lane steps - it was a third of the kernel)
+        const int k4 = K >> 2, q = tid & 3;
+        for (int t = tid >> 2; t < n; t += 128) {
+            float m = -INFINITY;
+            for (int c = q; c < k4; c += 4) {
+                const float4 v = *(const float4*)(ta_s + t * K + 4 * c);
+                m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+            }
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            if (q == 0) tw_s[t] = m;
+        }
+    } else {
+        for (int t = wave; t < n; t += 8) {
+            float m = -INFINITY;
+            for (int k = lane; k < K; k += 64) m = fmaxf(m, TA(t, k));
+            m = wave_max(m);
+            if (lane == 0) tw_s[t] = m;
+        }
     }
     __syncthreads();
 
+    TS_MARK(2);
     // a = column mass of head-max attention (vit.py:126-127), c = head-diversity weighted CLS attention (vit.py:96-101)
+    // All global operands of a token are requested before any is used (fully unrolled, predicated loads: the head and
+    // row-tile counts are small): one memory latency instead of one per group of four.
+    constexpr int HMAX = 16, RMAX = 16;
     float a_loc[2], c_loc[2], suma_l = 0.f, sumt_l = 0.f;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int t = tid + u * 512;
         a_loc[u] = 0.f; c_loc[u] = 0.f;
         if (t < n) {
-            float a = 0.f;
-#pragma unroll 4
-            for (int r = 0; r < nrt; ++r) a += colsum[((size_t)b * nrt + r) * N + t + 1];
-            float hs = 0.f;
-#pragma unroll 4
-            for (int h = 0; h < H; ++h) hs += onorm[((size_t)b * H + h) * N + t + 1];
-            float c = 0.f;
-#pragma unroll 4
-            for (int h = 0; h < H; ++h) {
-                const size_t o = ((size_t)b * H + h) * N + t + 1;
-                c += p0[o] * (onorm[o] / (hs + 1e-8f));
+            float a = 0.f, hs = 0.f, c = 0.f;
+            if (H <= HMAX && nrt <= RMAX) {
+                float on[HMAX], pz[HMAX], cs[RMAX];
+#pragma unroll
+                for (int h = 0; h < HMAX; ++h) {
+                    const size_t o = ((size_t)b * H + h) * N + t + 1;
+                    on[h] = h < H ? onorm[o] : 0.f;
+                    pz[h] = h < H ? p0[o] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) cs[r] = r < nrt ? colsum[((size_t)b * nrt + r) * N + t + 1] : 0.f;
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) if (r < nrt) a += cs[r];
+#pragma unroll
+                for (int h = 0; h < HMAX; ++h) if (h < H) hs += on[h];
+#pragma unroll
+                for (int h = 0; h < HMAX; ++h) if (h < H) c += pz[h] * (on[h] / (hs + 1e-8f));
+            } else {
+                for (int r = 0; r < nrt; ++r) a += colsum[((size_t)b * nrt + r) * N + t + 1];
+                for (int h = 0; h < H; ++h) hs += onorm[((size_t)b * H + h) * N + t + 1];
+                for (int h = 0; h < H; ++h) {
+                    const size_t o = ((size_t)b * H + h) * N + t + 1;
+                    c += p0[o] * (onorm[o] / (hs + 1e-8f));
+                }
             }
             a_loc[u] = a; c_loc[u] = c;
             suma_l += a; sumt_l += tw_s[t];
         }
     }
+    TS_MARK(3);
     const float suma = block_sum(suma_l, red, tid, 8);
     const float sumt = block_sum(sumt_l, red, tid, 8);
 #pragma unroll
@@ -121,14 +163,22 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     }
     __syncthreads();
 
+    TS_MARK(4);
     // phase B: softmax over tokens of token_attn/T per column (vit.py:137-139), 4 slices x 128 columns
     const int col = tid & 127, slice = tid >> 7;
     const int t0 = (n * slice) / 4, t1 = (n * (slice + 1)) / 4;
     const bool cval = col < K;
+    // (STAGED: the LDS copy is private to this kernel and element [t][col] is only touched by this thread from here on,
+    //  so x/T and then exp(x/T - max) overwrite it in place - the arithmetic of each pass is unchanged, it just is not
+    //  repeated by the next one)
     float m = -INFINITY;
     if (cval) {
 #pragma unroll 8
-        for (int t = t0; t < t1; ++t) m = fmaxf(m, TA(t, col) / temperature);
+        for (int t = t0; t < t1; ++t) {
+            const float v = TA(t, col) / temperature;
+            if constexpr (STAGED) ta_s[t * K + col] = v;
+            m = fmaxf(m, v);
+        }
     }
     colred[slice][col] = m;
     __syncthreads();
@@ -137,7 +187,12 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     float se = 0.f;
     if (cval) {
 #pragma unroll 8
-        for (int t = t0; t < t1; ++t) se += expf(TA(t, col) / temperature - m);
+        for (int t = t0; t < t1; ++t) {
+            float e;
+            if constexpr (STAGED) { e = expf(ta_s[t * K + col] - m); ta_s[t * K + col] = e; }
+            else e = expf(TA(t, col) / temperature - m);
+            se += e;
+        }
     }
     colred[slice][col] = se;
     __syncthreads();
@@ -146,12 +201,16 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     float sw = 0.f;
     if (cval) {
 #pragma unroll 8
-        for (int t = t0; t < t1; ++t) sw += (expf(TA(t, col) / temperature - m) / sum) * I_s[t];
+        for (int t = t0; t < t1; ++t) {
+            const float e = STAGED ? ta_s[t * K + col] : expf(TA(t, col) / temperature - m);
+            sw += (e / sum) * I_s[t];
+        }
     }
     colred[slice][col] = sw;
     __syncthreads();
     if (tid < 128) colstat[tid] = cval ? ((colred[0][col] + colred[1][col]) + colred[2][col]) + colred[3][col] : INFINITY;
     __syncthreads();
+    TS_MARK(5);
     // threshold = min over columns (vit.py:141)
     float thr = INFINITY;
     for (int k = lane; k < 128; k += 64) thr = fminf(thr, colstat[k]);
@@ -160,6 +219,7 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     int cnt = 0;
     for (int t = tid; t < n; t += 512) cnt += I_s[t] > thr ? 1 : 0;
     const float total = block_sum((float)cnt, red, tid, 8);  // exact: counts <= 1024
+    TS_MARK(6);
     if (tid == 0) {
         threshold[b] = thr;
         count[b] = (int)total;
@@ -811,6 +871,13 @@ extern "C" int madtp_token_score_sync(const float* colsum_part, int n_row_tiles,
     *k_host = __atomic_load_n(&g_sync.host[0], __ATOMIC_RELAXED);
     return 0;
 }
+
+#ifdef MADTP_TS_TIMING
+extern "C" int madtp_debug_read_ts(long long* out) {
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts_dbg), sizeof(long long) * 16);
+}
+#endif
 
 extern "C" int madtp_token_select(const float* score, int k, int64_t* indices, int64_t* indices_sort, int32_t* dst_pos,
                                   float* merge_w, int B, int n, void* stream) {
