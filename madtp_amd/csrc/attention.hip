@@ -215,8 +215,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 //     no cross-lane traffic - and the B operand is two transpose reads (keys 32c+4g.. and 32c+16+4g..).
 //   * exp via v_exp_f32 (__expf) and one reciprocal per row: this is the fast mode; the f32 kernel above keeps
 //     expf/division for the parity mode.
-template <int NT, bool SCORES>
-__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnArgs a) {
+//   * HS = 2 (scores variant, <= 128 keys): the workgroup is 8 waves = 4 query-row tiles x 2 HEAD PARITIES.  With 64 rows
+//     per workgroup a 128-image batch of ~90-token sequences is only 256 workgroups - one wave per SIMD, every LDS /
+//     exp / cross-lane latency of the per-head chain exposed.  The two parity groups walk heads h = 0,2,4.. and 1,3,5..
+//     with their own K/V rings, two independent instruction streams per SIMD, and merge their head-max once at the end.
+template <int NT, bool SCORES, int HS>
+__global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(AttnArgs a) {
     constexpr int NKP = NT * 16;
     constexpr int NC = (NT + 1) / 2;          // 32-key chunks
     constexpr int VR = NC * 32;               // staged V rows (whole chunks)
@@ -224,7 +228,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, hp = wave8 >> 2;  // query-row tile within the workgroup, head parity group
+    char* const ring = smem + hp * 2 * STAGE;
     const int l16 = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
     const int rt = blockIdx.x * 4 + wave;
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnArgs a) {
     // to a valid row: their probabilities are exactly 0, so any finite data is fine.
     const int sub = lane >> 3, pos = lane & 7;
     auto stage_head = [&](int h, int st) {
-        char* base = smem + st * STAGE;
+        char* base = ring + st * STAGE;
         for (int grp = wave; grp < (NKP + VR) / 8; grp += 4) {
             const bool is_v = grp >= NKP / 8;
             int row = (is_v ? grp - NKP / 8 : grp) * 8 + sub;
@@ -263,18 +269,24 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnArgs a) {
         qq[1] = *(const bf16x8*)(qp + 64 + g * 16);
     };
     int st = 0;
-    stage_head(blockIdx.z, 0);
+    const int hstep = gridDim.z * HS;
+    const int hfirst = blockIdx.z * HS + hp;
+    const int niter = (a.H - (int)blockIdx.z * HS + hstep - 1) / hstep;  // the same for both parity groups (barriers)
     bf16x8 qn[2];
-    load_q(blockIdx.z, qn);
-    for (int h = blockIdx.z; h < a.H; h += gridDim.z, st ^= 1) {
+    if (hfirst < a.H) {
+        stage_head(hfirst, 0);
+        load_q(hfirst, qn);
+    }
+    for (int it = 0; it < niter; ++it, st ^= 1) {
+        const int h = hfirst + it * hstep;
         bf16x8 q[2] = {qn[0], qn[1]};
         __syncthreads();  // head h landed (the barrier drains the DMA); the other stage is free again
-        if (h + (int)gridDim.z < a.H) {
-            stage_head(h + gridDim.z, st ^ 1);
-            load_q(h + gridDim.z, qn);
+        if (h + hstep < a.H) {
+            stage_head(h + hstep, st ^ 1);
+            load_q(h + hstep, qn);
         }
-        if (!active) continue;
-        const char* Ks = smem + st * STAGE;
+        if (!active || h >= a.H) continue;
+        const char* Ks = ring + st * STAGE;
         const char* Vs = Ks + NKP * 128;
 
         // ---- S^T = K Q^T ----
@@ -377,6 +389,21 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(AttnArgs a) {
         }
     }
 
+    if constexpr (SCORES && HS == 2) {  // merge the two parity groups' head-max through the (now idle) ring memory
+        f32x4* xch = (f32x4*)smem;
+        __syncthreads();
+        if (hp == 1)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xch[(wave * NT + t) * 64 + lane] = pmax[t];
+        __syncthreads();
+        if (hp == 1) return;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 o = xch[(wave * NT + t) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pmax[t][r] = fmaxf(pmax[t][r], o[r]);
+        }
+    }
     if constexpr (SCORES) {
         if (active) {
             const int i = i0 + l16;
@@ -542,10 +569,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_small_kernel(AttnArgs a) {
 template <int NT, bool SCORES>
 int launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     constexpr int NC = (NT + 1) / 2;
-    const size_t lds = (size_t)2 * (NT * 16 + NC * 32) * 128;
+    constexpr int HS = (SCORES && NT <= 8) ? 2 : 1;  // head-parity split: 4 rings must fit the 160 KiB of LDS
+    const size_t lds = (size_t)2 * HS * (NT * 16 + NC * 32) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_bf16_kernel<NT, SCORES>,
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bf16_kernel<NT, SCORES, HS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -556,7 +584,7 @@ int launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
         gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
         if (gz > a.H) gz = a.H;
     }
-    hipLaunchKernelGGL((attn_bf16_kernel<NT, SCORES>), dim3((a.Nq + 63) / 64, a.B, gz), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((attn_bf16_kernel<NT, SCORES, HS>), dim3((a.Nq + 63) / 64, a.B, gz), dim3(256 * HS), lds, s, a);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
