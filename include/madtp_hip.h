@@ -118,6 +118,15 @@ int madtp_token_score_sync(const float* colsum_part, int n_row_tiles, const floa
                            float* score, float* threshold, int32_t* count, int32_t* k_host,
                            int B, int H, int N, void* stream);
 
+/* The same in two steps: _publish launches token_score with the host slot armed and takes the process-wide slot, _wait spins
+ * until k has arrived and releases the slot (every _publish must be followed by exactly one _wait).  Kernels enqueued
+ * between the two run while the host waits; the layer-level calls put the projection GEMM there. */
+int madtp_token_score_publish(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
+                              const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature,
+                              float* score, float* threshold, int32_t* count, int B, int H, int N, int* seq_out,
+                              void* stream);
+int madtp_token_score_wait(int seq, const int32_t* count, int B, int32_t* k_host, void* stream);
+
 /* Top-k selection by rank + merge weights (vit.py:153-159).  For each sample: rank tokens by score (descending,
  * ties -> lower index first); kept = rank < k, emitted in ascending token order.
  *   indices      int64 [B,k]   kept token ids (the reference's `indices`, order implementation-defined there)

@@ -159,11 +159,18 @@ static int vit_attn_impl(const madtp_vit_block_w* w, const float* x, float* x_ou
     const char* q = (const char*)s.qkv;
     TRY(madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.o, nullptr, prune ? s.colsum : nullptr, s.p0, s.onorm,
                         B, w->heads, N, N, 3 * D, 3 * D, 3 * D, D, w->scale, dt, stream));
+    if (prune && k_host) {
+        // k = max_b count is delivered through pinned host memory.  token_score only needs the attention statistics, so it
+        // is launched BEFORE the projection GEMM and the host waits for k while that GEMM runs.
+        int seq = 0;
+        TRY(madtp_token_score_publish(s.colsum, (N + 15) / 16, s.p0, s.onorm, token_attn, ldt_row, ldt_batch, K, temperature,
+                                      score, threshold, count, B, w->heads, N, &seq, stream));
+        const int rc = lin(s.o, D, w->proj, x, D, x_out, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream);
+        const int rw = madtp_token_score_wait(seq, count, B, k_host, stream);
+        return rc ? rc : rw;
+    }
     TRY(lin(s.o, D, w->proj, x, D, x_out, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
     if (prune) {
-        if (k_host)  // k = max_b count delivered through pinned host memory (returns once the value is there)
-            return madtp_token_score_sync(s.colsum, (N + 15) / 16, s.p0, s.onorm, token_attn, ldt_row, ldt_batch, K, temperature,
-                                          score, threshold, count, k_host, B, w->heads, N, stream);
         if (kmax) {
             hipError_t he = hipMemsetAsync(kmax, 0, sizeof(int32_t), (hipStream_t)stream);
             if (he != hipSuccess) return (int)he;
@@ -275,11 +282,17 @@ static int bert_attn_impl(const madtp_bert_layer_w* w, const float* hidden, cons
     const char* q = (const char*)s.qkv;
     TRY(madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.ctx, mask2d, prune ? s.colsum : nullptr, s.p0, s.onorm,
                         B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale, dt, stream));
+    if (prune && k_host) {  // as in the ViT block: score first, the output projection + LayerNorm run while the host waits
+        int seq = 0;
+        TRY(madtp_token_score_publish(s.colsum, (L + 15) / 16, s.p0, s.onorm, token_attn, ldt_row, ldt_batch, K, temperature,
+                                      score, threshold, count, B, w->heads, L, &seq, stream));
+        const int rc = lin_ln(s.ctx, D, w->attn_out, hidden, 1.f, w->ln_att_g, w->ln_att_b, att, nullptr, M, dt, w->eps, s.part,
+                              stream);
+        const int rw = madtp_token_score_wait(seq, count, B, k_host, stream);
+        return rc ? rc : rw;
+    }
     TRY(lin_ln(s.ctx, D, w->attn_out, hidden, 1.f, w->ln_att_g, w->ln_att_b, att, nullptr, M, dt, w->eps, s.part, stream));
     if (prune) {
-        if (k_host)
-            return madtp_token_score_sync(s.colsum, (L + 15) / 16, s.p0, s.onorm, token_attn, ldt_row, ldt_batch, K, temperature,
-                                          score, threshold, count, k_host, B, w->heads, L, stream);
         if (kmax) {
             hipError_t he = hipMemsetAsync(kmax, 0, sizeof(int32_t), (hipStream_t)stream);
             if (he != hipSuccess) return (int)he;

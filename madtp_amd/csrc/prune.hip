@@ -8,6 +8,7 @@
 // coalesced row reads, wave shuffle reductions, ballot/popcount prefix sums, fixed reduction orders (no float
 // atomics, so results are run-to-run deterministic and independent of workgroup placement).
 #include "common.h"
+#include <stdlib.h>
 #include <chrono>
 #include <mutex>
 #include <vector>
@@ -782,6 +783,118 @@ __global__ __launch_bounds__(256, 1) void align_logits_kernel(const float* __res
     }
 }
 
+// Wave-specialised variant (the one the fast mode runs): workgroup = 64 token rows x 128 columns as 8 CONSUMER waves (4 row
+// tiles x 2 column halves: two MFMA instruction streams per SIMD) + 4 LOADER waves that LDS-DMA the f32 token rows (64 x
+// 256 B per K slab) and the dictionary hi/lo slabs into a 3-stage 144 KiB ring with counted vmcnt waits, one raw barrier per
+// slab.  The consumers never touch vector memory until their epilogue, so no HBM latency sits in the MFMA stream (the
+// register-prefetching kernel above loses ~7 us per launch to it).  x rows are swizzled with chunk ^= row&15 (256-byte rows
+// span all 64 banks), the dictionary with the GEMM swizzle.
+constexpr int AW_XT = 64 * 256, AW_STAGE = AW_XT + 2 * AL_TILE;  // 16 KiB + 2 x 16 KiB
+__global__ __launch_bounds__(768, 1) void align_ws_kernel(const float* __restrict__ x, const char* __restrict__ sd_hi,
+                                                          const char* __restrict__ sd_lo, float* __restrict__ out, int M, int dim) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGES = 3, PER = 12;  // 48 one-KiB DMA instructions per slab, 12 per loader wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = dim / 64;
+    const int row0 = blockIdx.x * 64;
+    if (wave >= 8) {
+        // ------------------------------------------ loader ------------------------------------------
+        const int lw = wave - 8;
+        const char* srcp[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx = lw * PER + q;  // 0..15: x groups of 4 rows; 16..31: hi groups of 8 rows; 32..47: lo groups
+            if (idx < 16) {
+                const int r = idx * 4 + (lane >> 4);
+                int row = row0 + r;
+                row = row < M ? row : M - 1;
+                srcp[q] = (const char*)(x + (size_t)row * dim) + (((lane & 15) ^ (r & 15)) << 4);
+            } else {
+                const int grp = (idx - 16) & 15, r = grp * 8 + (lane >> 3);
+                const char* base = idx < 32 ? sd_hi : sd_lo;
+                srcp[q] = base + (size_t)r * dim * 2 + (((lane & 7) ^ (r & 7)) << 4);
+            }
+        }
+        auto issue = [&](int kt) {
+            char* st = smem + (kt % STAGES) * AW_STAGE + lw * PER * 1024;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int idx = lw * PER + q;
+                const int koff = idx < 16 ? kt * 256 : kt * 128;
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(srcp[q] + koff), LDS_PTR(st + q * 1024), 16, 0, 0);
+            }
+        };
+        issue(0);
+        if (nk > 1) issue(1);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // only slab kt+1 may still fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) issue(kt + 2);  // into the stage slab kt-1 used: every consumer is past its reads
+        }
+        return;
+    }
+    // ------------------------------------------ consumer ------------------------------------------
+    const int l16 = lane & 15, g = lane >> 4;
+    const int rw = wave & 3, cw = wave >> 2;
+    const int xr = rw * 16 + l16;  // row of the x tile
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* st = smem + (kt % STAGES) * AW_STAGE;
+        const char* sh = st + AW_XT;
+        const char* sl = sh + AL_TILE;
+        __builtin_amdgcn_s_barrier();  // slab kt landed (the loaders waited for it before arriving)
+        f32x4 xa[2][2];
+        bf16x8 bh[2][4], bl[2][4];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int c = kk * 8 + g * 2;  // 16-byte chunk of k = 32kk + 8g
+            xa[kk][0] = *(const f32x4*)(st + xr * 256 + (((c + 0) ^ (xr & 15)) << 4));
+            xa[kk][1] = *(const f32x4*)(st + xr * 256 + (((c + 1) ^ (xr & 15)) << 4));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rb = (cw * 4 + j) * 16 + l16;
+                const int off = rb * AL_ROWB + (((kk * 4 + g) ^ (rb & 7)) << 4);
+                bh[kk][j] = *(const bf16x8*)(sh + off);
+                bl[kk][j] = *(const bf16x8*)(sl + off);
+            }
+        bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            ah[kk] = pack_bf16x8(xa[kk][0], xa[kk][1]);
+            f32x4 r0, r1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r0[e] = xa[kk][0][e] - bf16_to_f32((bf16_t)ah[kk][e]);
+                r1[e] = xa[kk][1][e] - bf16_to_f32((bf16_t)ah[kk][4 + e]);
+            }
+            al[kk] = pack_bf16x8(r0, r1);
+        }
+        // per accumulator: hi.hi, hi.lo, lo.hi (kk = 0), then the same for kk = 1 - the order of the kernel above
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[kk][j], ah[kk], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[kk][j], al[kk], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[kk][j], ah[kk], acc[j], 0, 0, 0);
+        }
+    }
+    const int m = row0 + xr;
+    if (m < M) {
+        float* o = out + (size_t)m * 128 + cw * 64 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(f32x4*)(o + 16 * j) = acc[j];
+    }
+}
+
 }  // namespace
 
 static int token_score_launch(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
@@ -843,33 +956,58 @@ int host_sync_init() {
 }
 }  // namespace
 
-extern "C" int madtp_token_score_sync(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
-                                      const float* token_attn, int ldt, int ldb, int K, float temperature, float* score,
-                                      float* threshold, int32_t* count, int32_t* k_host, int B, int H, int N, void* stream) {
-    if (!k_host) return MADTP_E_BADARG;
-    std::lock_guard<std::mutex> lock(g_sync.mu);
-    TRY(host_sync_init());
-    const int seq = ++g_sync.seq;
-    TRY(token_score_launch(colsum_part, n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count,
-                           nullptr, B, H, N, g_sync.ctr, g_sync.host_dev, seq, stream));
+// Two-step form used by the layer-level calls: publish = launch with the host slot armed (takes the process-wide slot);
+// wait = spin until the last workgroup has written k (releases the slot).  Work enqueued between the two calls runs on
+// the GPU while the host waits - the layers put the projection GEMM there, so the read-back costs no GPU idle time.
+extern "C" int madtp_token_score_publish(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
+                                         const float* token_attn, int ldt, int ldb, int K, float temperature, float* score,
+                                         float* threshold, int32_t* count, int B, int H, int N, int* seq_out, void* stream) {
+    if (!seq_out) return MADTP_E_BADARG;
+    g_sync.mu.lock();
+    int rc = host_sync_init();
+    if (!rc) {
+        *seq_out = ++g_sync.seq;
+        rc = token_score_launch(colsum_part, n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count,
+                                nullptr, B, H, N, g_sync.ctr, g_sync.host_dev, *seq_out, stream);
+    }
+    if (rc) g_sync.mu.unlock();
+    return rc;
+}
+
+extern "C" int madtp_token_score_wait(int seq, const int32_t* count, int B, int32_t* k_host, void* stream) {
+    if (!k_host || !count) { g_sync.mu.unlock(); return MADTP_E_BADARG; }
+    int rc = 0;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0; __atomic_load_n(&g_sync.host[1], __ATOMIC_ACQUIRE) != seq; ++spins) {
         if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
             // never signalled (failed launch / lost stream): fall back to the ordinary path so the error surfaces
             hipError_t e = hipStreamSynchronize((hipStream_t)stream);
-            if (e != hipSuccess) return (int)e;
             std::vector<int32_t> h(B);
-            e = hipMemcpy(h.data(), count, sizeof(int32_t) * B, hipMemcpyDeviceToHost);
-            if (e != hipSuccess) return (int)e;
-            int m = 0;
-            for (int v : h) m = v > m ? v : m;
-            (void)hipMemset(g_sync.ctr, 0, sizeof(int32_t));
-            *k_host = m;
-            return 0;
+            if (e == hipSuccess) e = hipMemcpy(h.data(), count, sizeof(int32_t) * B, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) {
+                int m = 0;
+                for (int v : h) m = v > m ? v : m;
+                (void)hipMemset(g_sync.ctr, 0, sizeof(int32_t));
+                *k_host = m;
+            }
+            rc = (int)e;
+            g_sync.mu.unlock();
+            return rc;
         }
     }
     *k_host = __atomic_load_n(&g_sync.host[0], __ATOMIC_RELAXED);
+    g_sync.mu.unlock();
     return 0;
+}
+
+extern "C" int madtp_token_score_sync(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
+                                      const float* token_attn, int ldt, int ldb, int K, float temperature, float* score,
+                                      float* threshold, int32_t* count, int32_t* k_host, int B, int H, int N, void* stream) {
+    if (!k_host) return MADTP_E_BADARG;
+    int seq = 0;
+    TRY(madtp_token_score_publish(colsum_part, n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold,
+                                  count, B, H, N, &seq, stream));
+    return madtp_token_score_wait(seq, count, B, k_host, stream);
 }
 
 #ifdef MADTP_TS_TIMING
@@ -976,6 +1114,20 @@ extern "C" int madtp_align_logits(const float* x, const void* sd_hi, const void*
             if (e != hipSuccess) return (int)e;
         }
         attr = true;
+    }
+    static int variant = -1;  // MADTP_ALIGN_KERNEL=1 selects the register-prefetching kernel (A/B measurements)
+    if (variant < 0) { const char* e = getenv("MADTP_ALIGN_KERNEL"); variant = e ? atoi(e) : 0; }
+    if (variant == 0) {
+        static bool attr_ws = false;
+        if (!attr_ws) {
+            hipError_t e = hipFuncSetAttribute((const void*)align_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AW_STAGE);
+            if (e != hipSuccess) return (int)e;
+            attr_ws = true;
+        }
+        hipLaunchKernelGGL(align_ws_kernel, dim3((M + 63) / 64), dim3(768), 3 * AW_STAGE, (hipStream_t)stream, x, (const char*)sd_hi,
+                           (const char*)sd_lo, out, M, dim);
+        MADTP_LAUNCH_CHECK();
+        return 0;
     }
     auto kern = dim == 768 ? align_logits_kernel<12> : dim == 512 ? align_logits_kernel<8> : align_logits_kernel<0>;
     hipLaunchKernelGGL(kern, dim3((M + 63) / 64), dim3(256), lds, (hipStream_t)stream, x, (const char*)sd_hi,

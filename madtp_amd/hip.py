@@ -56,6 +56,9 @@ _SIGS = {
                                       c_void_p, c_void_p]),
     "madtp_token_score_sync": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float]
                                + [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
+    "madtp_token_score_publish": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float]
+                                  + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p, c_void_p]),
+    "madtp_token_score_wait": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "madtp_vit_block": (c_int, [c_void_p] * 5 + [c_size_t, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
                         + [c_void_p] * 7 + [c_void_p]),
     "madtp_bert_layer": (c_int, [c_void_p] * 7 + [c_size_t, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
