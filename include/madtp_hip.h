@@ -279,7 +279,10 @@ int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden, const flo
                      float* mask_out, void* ws, size_t ws_bytes, int B, int L, int Nk, const float* token_attn, int ldt_row,
                      int ldt_batch, int K, float temperature, float* score, float* threshold, int32_t* count,
                      int64_t* indices, int64_t* indices_sort, int cross_mode, const void* enc0, const void* enc1,
-                     const float* enc_mask0, const float* enc_mask1, int* k_out, int* k_used, void* stream);
+                     const float* enc_mask0, const float* enc_mask1, const void* hidden_lp, void* y_lp, int* k_out, int* k_used,
+                     void* stream);
+/* hidden_lp (optional, bf16 mode): compute-dtype copy of `hidden` - skips the cast; y_lp (optional): receives the
+ * compute-dtype copy of y, emitted by the output LayerNorm, to be passed as the next layer's hidden_lp. */
 
 #ifdef __cplusplus
 }

@@ -377,8 +377,16 @@ class _BertLayerBase(nn.Module):
         w = self._weights()
         # one library call: self-attention + output LayerNorm, importance score / threshold / count (med.py:408-418,
         # 347-371), host read of k, [prune att + mask], cross-attention, FFN
-        y, mask_out, self.last_prune = hip.bert_layer(w, hidden, mask2d, token_attn, temperature if prune else 0, cross, enc0, enc1,
-                                                      Nk, em0, em1)
+        # (fast mode: the bf16 copy of the layer output, emitted by the output LayerNorm, rides along on the returned tensor
+        #  so the next layer does not cast its input again; it is only trusted for the very same, unmodified tensor)
+        lp = getattr(hidden_states, "_madtp_lp", None)
+        if lp is not None and (lp[1] != hidden._version or hidden is not hidden_states or lp[0].shape != hidden.shape
+                               or compute_dtype() != torch.bfloat16):
+            lp = None
+        y, mask_out, self.last_prune, ylp = hip.bert_layer(w, hidden, mask2d, token_attn, temperature if prune else 0, cross, enc0,
+                                                           enc1, Nk, em0, em1, hidden_lp=lp[0] if lp else None)
+        if ylp is not None:
+            y._madtp_lp = (ylp, y._version)
         if mask_out is not None:
             attention_mask = mask_out[:, None, None, :]
         return (y, None, attention_mask)  # present_key_value is not kept (encoder use, use_cache=False)

@@ -264,7 +264,7 @@ extern "C" size_t madtp_bert_layer_workspace(int B, int L, int Nk, int dim, int 
 static int bert_attn_impl(const madtp_bert_layer_w* w, const float* hidden, const float* mask2d, float* att, void* ws,
                           size_t ws_bytes, int B, int L, int Nk, const float* token_attn, int ldt_row, int ldt_batch, int K,
                           float temperature, float* score, float* threshold, int32_t* count, int32_t* kmax, int32_t* k_host,
-                          void* stream) {
+                          const void* hidden_lp, void* stream) {
     if (!w || !hidden || !att || !ws || B <= 0 || L <= 0) return MADTP_E_BADARG;
     bool ok;
     BertWs s = bert_carve((char*)ws, ws_bytes, B, L, Nk, w->dim, w->inter.n, w->heads, w->dtype, &ok);
@@ -275,9 +275,13 @@ static int bert_attn_impl(const madtp_bert_layer_w* w, const float* hidden, cons
     if (prune && (!token_attn || !score || !threshold || !count || !mask2d)) return MADTP_E_BADARG;
     const void* hc = hidden;
     if (dt == MADTP_BF16) {
-        TRY(madtp_cast_bf16(hidden, s.hc, (size_t)M * D, stream));
-        hc = s.hc;
+        if (hidden_lp) hc = hidden_lp;  // the previous layer's LayerNorm already emitted the bf16 copy
+        else {
+            TRY(madtp_cast_bf16(hidden, s.hc, (size_t)M * D, stream));
+            hc = s.hc;
+        }
     }
+    void* att_lp = dt == MADTP_BF16 ? s.attc : nullptr;  // bf16 copy of att for the second half (same workspace)
     TRY(lin(hc, D, w->qkv, nullptr, 0, s.qkv, 3 * D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
     const char* q = (const char*)s.qkv;
     TRY(madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.ctx, mask2d, prune ? s.colsum : nullptr, s.p0, s.onorm,
@@ -286,12 +290,12 @@ static int bert_attn_impl(const madtp_bert_layer_w* w, const float* hidden, cons
         int seq = 0;
         TRY(madtp_token_score_publish(s.colsum, (L + 15) / 16, s.p0, s.onorm, token_attn, ldt_row, ldt_batch, K, temperature,
                                       score, threshold, count, B, w->heads, L, &seq, stream));
-        const int rc = lin_ln(s.ctx, D, w->attn_out, hidden, 1.f, w->ln_att_g, w->ln_att_b, att, nullptr, M, dt, w->eps, s.part,
+        const int rc = lin_ln(s.ctx, D, w->attn_out, hidden, 1.f, w->ln_att_g, w->ln_att_b, att, att_lp, M, dt, w->eps, s.part,
                               stream);
         const int rw = madtp_token_score_wait(seq, count, B, k_host, stream);
         return rc ? rc : rw;
     }
-    TRY(lin_ln(s.ctx, D, w->attn_out, hidden, 1.f, w->ln_att_g, w->ln_att_b, att, nullptr, M, dt, w->eps, s.part, stream));
+    TRY(lin_ln(s.ctx, D, w->attn_out, hidden, 1.f, w->ln_att_g, w->ln_att_b, att, att_lp, M, dt, w->eps, s.part, stream));
     if (prune) {
         if (kmax) {
             hipError_t he = hipMemsetAsync(kmax, 0, sizeof(int32_t), (hipStream_t)stream);
@@ -308,16 +312,18 @@ extern "C" int madtp_bert_layer_attn(const madtp_bert_layer_w* w, const float* h
                                      int ldt_batch, int K, float temperature, float* score, float* threshold, int32_t* count,
                                      int32_t* kmax, void* stream) {
     return bert_attn_impl(w, hidden, mask2d, att, ws, ws_bytes, B, L, Nk, token_attn, ldt_row, ldt_batch, K, temperature, score,
-                          threshold, count, kmax, nullptr, stream);
+                          threshold, count, kmax, nullptr, nullptr, stream);
 }
 
 // [prune att + mask] ; [cross-attention to the image tokens] ; y = LayerNorm(output(GELU(intermediate(a))) + a)
 // cross_mode: 0 = text mode (no cross-attention), otherwise w->cross selects single (MED) or twin (NLVR).
 // enc0/enc1: image tokens [B*Nk, dim] in the compute dtype; enc_mask0/1: additive f32 [B,Nk] or NULL.
-extern "C" int madtp_bert_layer_rest(const madtp_bert_layer_w* w, const float* att, const float* mask2d, float* y,
-                                     float* mask_out, void* ws, size_t ws_bytes, int B, int L, int k, const float* score,
-                                     int64_t* indices, int64_t* indices_sort, int cross_mode, const void* enc0,
-                                     const void* enc1, int Nk, const float* enc_mask0, const float* enc_mask1, void* stream) {
+// att_lp_ready: the workspace's bf16 copy of att was written by the first half of the SAME call (fused layer entry point);
+// y_lp (optional): bf16 copy of y for the next layer.
+static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const float* mask2d, float* y, float* mask_out, void* ws,
+                          size_t ws_bytes, int B, int L, int k, const float* score, int64_t* indices, int64_t* indices_sort,
+                          int cross_mode, const void* enc0, const void* enc1, int Nk, const float* enc_mask0,
+                          const float* enc_mask1, bool att_lp_ready, void* y_lp, void* stream) {
     if (!w || !att || !y || !ws || B <= 0 || L <= 0 || k < 0) return MADTP_E_BADARG;
     bool ok;
     BertWs s = bert_carve((char*)ws, ws_bytes, B, L, Nk, w->dim, w->inter.n, w->heads, w->dtype, &ok);
@@ -344,7 +350,7 @@ extern "C" int madtp_bert_layer_rest(const madtp_bert_layer_w* w, const float* a
     const int M = B * Lp;
     const void* ac = a32;
     if (dt == MADTP_BF16) {
-        TRY(madtp_cast_bf16(a32, s.attc, (size_t)M * D, stream));
+        if (!(att_lp_ready && k == 0)) TRY(madtp_cast_bf16(a32, s.attc, (size_t)M * D, stream));
         ac = s.attc;
     }
     if (cross_mode && w->cross) {
@@ -401,8 +407,17 @@ extern "C" int madtp_bert_layer_rest(const madtp_bert_layer_w* w, const float* a
     }
 ffn:
     TRY(lin(ac, D, w->inter, nullptr, 0, s.mid, w->inter.n, M, dt, dt, MADTP_ACT_GELU_ERF, 1.f, stream));
-    TRY(lin_ln(s.mid, w->inter.n, w->out, a32, 1.f, w->ln_out_g, w->ln_out_b, y, nullptr, M, dt, w->eps, s.part, stream));
+    TRY(lin_ln(s.mid, w->inter.n, w->out, a32, 1.f, w->ln_out_g, w->ln_out_b, y, dt == MADTP_BF16 ? y_lp : nullptr, M, dt, w->eps,
+               s.part, stream));
     return 0;
+}
+
+extern "C" int madtp_bert_layer_rest(const madtp_bert_layer_w* w, const float* att, const float* mask2d, float* y,
+                                     float* mask_out, void* ws, size_t ws_bytes, int B, int L, int k, const float* score,
+                                     int64_t* indices, int64_t* indices_sort, int cross_mode, const void* enc0,
+                                     const void* enc1, int Nk, const float* enc_mask0, const float* enc_mask1, void* stream) {
+    return bert_rest_impl(w, att, mask2d, y, mask_out, ws, ws_bytes, B, L, k, score, indices, indices_sort, cross_mode, enc0, enc1,
+                          Nk, enc_mask0, enc_mask1, false, nullptr, stream);
 }
 
 // Whole BertLayer.forward in one call (med.py:393-467 / nlvr_encoder.py:484-559): self-attention half, host read of
@@ -412,17 +427,17 @@ extern "C" int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden
                                 float* mask_out, void* ws, size_t ws_bytes, int B, int L, int Nk, const float* token_attn,
                                 int ldt_row, int ldt_batch, int K, float temperature, float* score, float* threshold,
                                 int32_t* count, int64_t* indices, int64_t* indices_sort, int cross_mode, const void* enc0,
-                                const void* enc1, const float* enc_mask0, const float* enc_mask1, int* k_out, int* k_used,
-                                void* stream) {
+                                const void* enc1, const float* enc_mask0, const float* enc_mask1, const void* hidden_lp,
+                                void* y_lp, int* k_out, int* k_used, void* stream) {
     if (!k_out || !k_used) return MADTP_E_BADARG;
     *k_out = 0; *k_used = 0;
     int32_t k = 0;
     TRY(bert_attn_impl(w, hidden, mask2d, att, ws, ws_bytes, B, L, Nk, token_attn, ldt_row, ldt_batch, K, temperature, score,
-                       threshold, count, nullptr, temperature > 0.f ? &k : nullptr, stream));
+                       threshold, count, nullptr, temperature > 0.f ? &k : nullptr, hidden_lp, stream));
     if (temperature > 0.f) {
         *k_out = k;
         if (!(k < 1 || (L - 1 - k) <= 1)) *k_used = k;
     }
-    return madtp_bert_layer_rest(w, att, mask2d, y, mask_out, ws, ws_bytes, B, L, *k_used, score, indices, indices_sort, cross_mode,
-                                 enc0, enc1, Nk, enc_mask0, enc_mask1, stream);
+    return bert_rest_impl(w, att, mask2d, y, mask_out, ws, ws_bytes, B, L, *k_used, score, indices, indices_sort, cross_mode, enc0,
+                          enc1, Nk, enc_mask0, enc_mask1, true, y_lp, stream);
 }

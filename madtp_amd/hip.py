@@ -62,7 +62,7 @@ _SIGS = {
     "madtp_vit_block": (c_int, [c_void_p] * 5 + [c_size_t, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
                         + [c_void_p] * 7 + [c_void_p]),
     "madtp_bert_layer": (c_int, [c_void_p] * 7 + [c_size_t, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
-                         + [c_void_p] * 5 + [c_int] + [c_void_p] * 6 + [c_void_p]),
+                         + [c_void_p] * 5 + [c_int] + [c_void_p] * 8 + [c_void_p]),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
     "madtp_query_att_ft_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -421,8 +421,10 @@ def vit_block(wstruct, x, token_attn, temperature):
     return ybuf, None
 
 
-def bert_layer(wstruct, hidden, mask2d, token_attn, temperature, cross_mode, enc0, enc1, Nk, enc_mask0, enc_mask1):
-    """BertLayer.forward in ONE library call.  -> (y [B,L',D], mask_out [B,L'] or None, info or None)."""
+def bert_layer(wstruct, hidden, mask2d, token_attn, temperature, cross_mode, enc0, enc1, Nk, enc_mask0, enc_mask1,
+               hidden_lp=None):
+    """BertLayer.forward in ONE library call.  -> (y [B,L',D], mask_out [B,L'] or None, info or None, y_lp).
+    hidden_lp / y_lp: bf16 copies of the layer input / output (fast mode; the LayerNorms emit them, saving the casts)."""
     B, L, D = hidden.shape
     lib = load()
     nbytes = lib.madtp_bert_layer_workspace(B, L, Nk, wstruct.dim, wstruct.inter.n, wstruct.heads, wstruct.dtype)
@@ -431,6 +433,7 @@ def bert_layer(wstruct, hidden, mask2d, token_attn, temperature, cross_mode, enc
     ybuf = torch.empty_like(hidden)
     k_out, k_used = ctypes.c_int(0), ctypes.c_int(0)
     dev = hidden.device
+    ylp = torch.empty(hidden.shape, device=dev, dtype=torch.bfloat16) if wstruct.dtype == BF16 else None
     if temperature > 0:
         tp, ldr, ldb, K = _ta_view(token_attn)
         score, thr, count, _ = prune_outputs(B, L - 1, dev)
@@ -440,18 +443,20 @@ def bert_layer(wstruct, hidden, mask2d, token_attn, temperature, cross_mode, enc
         _check(lib.madtp_bert_layer(ctypes.byref(wstruct), _p(hidden), _p(mask2d), _p(att), _p(ybuf), _p(mbuf), _p(ws), ws.numel(),
                                     B, L, Nk, tp, ldr, ldb, K, float(temperature), _p(score), _p(thr), _p(count), _p(idx),
                                     _p(idx_sort), int(cross_mode), _p(enc0), _p(enc1), _p(enc_mask0), _p(enc_mask1),
-                                    ctypes.byref(k_out), ctypes.byref(k_used), _stream()), "madtp_bert_layer")
+                                    _p(hidden_lp), _p(ylp), ctypes.byref(k_out), ctypes.byref(k_used), _stream()),
+               "madtp_bert_layer")
         info = {"k": k_out.value, "score": score, "threshold": thr, "count": count, "pruned": False, "indices": None,
                 "indices_sort": None}
         if k_used.value > 0:
             k = k_used.value
             info.update(pruned=True, indices=_carve(idx, B, k), indices_sort=idx_sort)
-            return _carve(ybuf, B, k + 2, D), (_carve(mbuf, B, k + 2) if mbuf is not None else None), info
-        return ybuf, None, info
+            return (_carve(ybuf, B, k + 2, D), (_carve(mbuf, B, k + 2) if mbuf is not None else None), info,
+                    _carve(ylp, B, k + 2, D) if ylp is not None else None)
+        return ybuf, None, info, ylp
     _check(lib.madtp_bert_layer(ctypes.byref(wstruct), _p(hidden), _p(mask2d), _p(att), _p(ybuf), 0, _p(ws), ws.numel(), B, L, Nk,
                                 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, int(cross_mode), _p(enc0), _p(enc1), _p(enc_mask0), _p(enc_mask1),
-                                ctypes.byref(k_out), ctypes.byref(k_used), _stream()), "madtp_bert_layer")
-    return ybuf, None, None
+                                _p(hidden_lp), _p(ylp), ctypes.byref(k_out), ctypes.byref(k_used), _stream()), "madtp_bert_layer")
+    return ybuf, None, None, ylp
 
 
 def vit_block_attn(wstruct, x, token_attn, temperature):
