@@ -378,6 +378,18 @@ def prune_outputs(B, n, device):
             torch.empty((B,), device=device, dtype=torch.int32), None)
 
 
+def token_score_sync(side, token_attn, temperature, B, H, N):
+    """token_score whose k = max_b count arrives on the HOST through pinned memory (madtp_token_score_sync).
+    -> (score, threshold, count, k:int)"""
+    cs, p0, on = side
+    tp, ldr, ldb, K = _ta_view(token_attn)
+    score, thr, count, _ = prune_outputs(B, N - 1, token_attn.device)
+    k = ctypes.c_int32(-1)
+    _check(load().madtp_token_score_sync(_p(cs), cs.shape[1], _p(p0), _p(on), tp, ldr, ldb, K, float(temperature), _p(score),
+                                         _p(thr), _p(count), ctypes.byref(k), B, H, N, _stream()), "madtp_token_score_sync")
+    return score, thr, count, k.value
+
+
 def batch_max_count(count):
     """k = max_b count (vit.py:145 `.item()`): one D2H copy of B int32 values, max on the host."""
     return int(count.cpu().max())

@@ -244,6 +244,25 @@ def test_token_score_select_gather(hip, B, N, T):
         assert torch.equal(mg.cpu(), ref_m)
 
 
+@pytest.mark.parametrize("B,N", [(1, 20), (7, 131), (130, 81)])
+def test_token_score_host_visible_k(hip, B, N):
+    """k = max_b count delivered through pinned host memory (last workgroup publishes, host spins) equals the device
+    results, repeatedly (the ticket counter re-arms itself) and with other work queued behind it."""
+    H, K, D = 12, 100, 768
+    qkv = _rand(B * N, 3 * H * 64, seed=50).cuda()
+    x = _rand(B, N, D, seed=51).cuda()
+    sd = _pad128(_rand(K, D, seed=52)).cuda()
+    _, side = hip.attention(qkv[:, :768], qkv[:, 768:1536], qkv[:, 1536:], B, H, N, N, 0.125, scores=True)
+    ta = hip.gemm(x.view(B * N, D), sd, n=128).view(B, N, 128)[:, 1:, :K]
+    ref = hip.token_score(side, ta, 4.0, B, H, N)
+    for _ in range(5):
+        score, thr, count, k = hip.token_score_sync(side, ta, 4.0, B, H, N)
+        junk = hip.gemm(x.view(B * N, D), sd, n=128)  # queued right behind: must not disturb the protocol
+        assert k == int(ref[2].max().item()) == int(count.max().item())
+        assert torch.equal(score, ref[0]) and torch.equal(thr, ref[1]) and torch.equal(count, ref[2])
+    del junk
+
+
 def test_select_ties_and_extremes(hip):
     # ties resolve to the lower index (stable), all-equal scores, k = n
     s = torch.tensor([[0.5, 0.5, 0.1, 0.9, 0.5, 0.1, 0.9, 0.0]] * 2)

@@ -223,3 +223,36 @@ def test_vit_large_image_fp32_matches_reference_fixture(path):
     del model.img_query_model.deferred
     assert torch.equal(ob, ob2) and sd_b.shape == sd_ft.shape
     assert (sd_b - sd_b2).abs().max().item() < 1e-4 * sd_b2.abs().max().item()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_fused_layer_calls_equal_two_step(mode):
+    """madtp_vit_block / madtp_bert_layer (one library call, k through pinned host memory, score launched before the
+    projection) give bit-identical results to the half-layer entry points with the host decision made in Python."""
+    from madtp_amd import build, hip, runtime, synth
+    from madtp_amd.vit import Block
+    from madtp_amd.utils import Query_model
+    build.build(verbose=False)
+    hip.load()
+    torch.manual_seed(0)
+    B, N, D = 6, 101, 768
+    blk = Block(dim=D, num_heads=12, mlp_ratio=4, qkv_bias=True).cuda().eval()
+    qm = Query_model(ft_dim=D, sd_dim=D, temperature=1, att_func_type='sparsemax', pool_type='max').cuda()
+    x = synth.synth_tensor("x", (B, N, D), 3).cuda()
+    sd = synth.synth_tensor("space_dict", (100, D), 3).cuda()
+    with runtime.precision(mode), torch.no_grad():
+        ta, _, _ = qm(x[:, 1:, :], sd, return_token_att=True)
+        w = blk._weights()
+        for T in (0.0, 3.0, 50.0):
+            y, info = hip.vit_block(w, x, ta if T > 0 else None, T)
+            xa, po = hip.vit_block_attn(w, x, ta if T > 0 else None, T)
+            k_use = 0
+            if T > 0:
+                k = hip.batch_max_count(po[2])
+                assert info["k"] == k and torch.equal(info["score"], po[0]) and torch.equal(info["count"], po[2])
+                if not (k < 1 or (N - 1 - k) <= 1):
+                    k_use = k
+            y2, idx, idx_sort = hip.vit_block_mlp(w, xa, k_use, po[0] if po else None)
+            assert y.shape == y2.shape and torch.equal(y, y2)
+            if k_use:
+                assert info["pruned"] and torch.equal(info["indices"], idx) and torch.equal(info["indices_sort"], idx_sort)
