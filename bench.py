@@ -34,9 +34,12 @@ def load_calibration(batch, p=0.5):
     return configs.temperature_for("nlvr", batch, p)
 
 
-def gemm_summary(rows, dtype):
-    sel = [r for r in rows if r["dtype"] == dtype]
+def gemm_summary(rows, dtype, min_m=0):
+    sel = [r for r in rows if r["dtype"] == dtype and r["M"] >= min_m]
     return sum(r["ms"] for r in sel), sum(r["flops"] for r in sel), sum(r["launches"] for r in sel)
+
+
+WS_MIN_M = 4096  # madtp_gemm runs bf16 problems with M >= 4096 (and no split-K) on gemm_ws_kernel (csrc/gemm.hip)
 
 
 def pmc_traffic():
@@ -47,7 +50,16 @@ def pmc_traffic():
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f)
+        d = json.load(f)
+    # traffic of the dominant kernel alone: launch-weighted over gemm_ws_kernel<true> / <false>
+    fk = {k: v for k, v in d.get("per_kernel_fetch", {}).items() if "gemm_ws_kernel" in k}
+    wk = {k: v for k, v in d.get("per_kernel_write", {}).items() if "gemm_ws_kernel" in k}
+    n = sum(v["launches"] for v in fk.values())
+    if n:
+        fetch = sum(v["launches"] * v["kib_per_launch"] for v in fk.values()) / n
+        write = sum(v["launches"] * v["kib_per_launch"] for v in wk.values()) / max(1, sum(v["launches"] for v in wk.values()))
+        d["ws_hbm_bytes_per_launch"] = int((2 * fetch + write) * 1024)
+    return d
 
 
 def gemm_breakdown(rows, steps):
@@ -135,21 +147,29 @@ def main():
     cdt = torch.bfloat16 if args.precision == "bf16" else torch.float32
     roof = None
     if not args.no_gemm_events:
-        ms, fl, cnt = gemm_summary(prof_rows, "bf16" if args.precision == "bf16" else "f32")
+        dt_name = "bf16" if args.precision == "bf16" else "f32"
+        ms_all, fl_all, cnt_all = gemm_summary(prof_rows, dt_name)
+        # dominant kernel: gemm_ws_kernel (bf16, M >= 4096) in the fast mode; gemm_kernel<float> in the parity mode
+        min_m = WS_MIN_M if args.precision == "bf16" else 0
+        ms, fl, cnt = gemm_summary(prof_rows, dt_name, min_m)
         if ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
-            ms32, fl32, cnt32 = gemm_summary(prof_rows, "f32") if args.precision == "bf16" else (0, 0, 0)
             pmc = pmc_traffic() if args.precision == "bf16" else None
-            alg_bytes = sum(r["bytes"] for r in prof_rows if r["dtype"] == ("bf16" if args.precision == "bf16" else "f32"))
-            roof = {"bound": "mfma", "kernel": f"gemm_kernel<{args.precision}> (madtp_gemm)", "achieved": round(ach, 1),
+            alg_bytes = sum(r["bytes"] for r in prof_rows if r["dtype"] == dt_name and r["M"] >= min_m)
+            kname = ("gemm_ws_kernel (all bf16 madtp_gemm launches with M >= 4096: ViT qkv/proj/fc1/fc2, cross-attention K/V)"
+                     if args.precision == "bf16" else "gemm_kernel<float> (madtp_gemm)")
+            roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+                    "traffic": pmc.get("ws_hbm_bytes_per_launch") if pmc else None,
                     "algorithmic_bytes_per_launch": round(alg_bytes / cnt),
-                    "launches_per_step": cnt // args.steps, "gemm_ms_per_step": round(ms / args.steps, 3),
+                    "launches_per_step": cnt // args.steps, "kernel_ms_per_step": round(ms / args.steps, 3),
                     "avg_launch_us": round(1e3 * ms / cnt, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
                     "instrumented_ms_per_step": round(1e3 * instr_elapsed / args.steps, 3),
-                    "f32_alignment_gemm_ms_per_step": round(ms32 / args.steps, 3) if cnt32 else 0.0}
+                    "all_gemm_launches": {"achieved": round(fl_all / (ms_all * 1e-3) / 1e12, 1),
+                                          "frac": round(fl_all / (ms_all * 1e-3) / 1e12 / peak, 4),
+                                          "launches_per_step": cnt_all // args.steps,
+                                          "ms_per_step": round(ms_all / args.steps, 3)}}
 
     out = {
         "metric": "images/sec forward, BLIP-base NLVR2 p=0.5 b64; pruned-token index match",
