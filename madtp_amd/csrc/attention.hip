@@ -64,6 +64,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) pmax[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    // additive key mask of this lane's columns, loaded ONCE (it does not depend on the head): 0 without a mask, -inf for the
+    // padding columns j >= Nk.  (Inside the head loop these were 4*NT predicated scalar loads, each with its own wait.)
+    f32x4 mk[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * t + 4 * g + r;
+            mk[t][r] = j < a.Nk ? (a.mask ? a.mask[(size_t)b * a.Nk + j] : 0.f) : -INFINITY;
+        }
 
     for (int h = blockIdx.z; h < a.H; h += gridDim.z) {
         __syncthreads();
@@ -112,10 +122,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int j = 16 * t + 4 * g + r;
-                float v = sc[t][r] * a.scale;
-                if (a.mask && j < a.Nk) v += a.mask[(size_t)b * a.Nk + j];
-                v = j < a.Nk ? v : -INFINITY;
+                // parity mode: multiply, then add, each rounded (the reference scales, then adds the mask)
+                const float v = __fadd_rn(__fmul_rn(sc[t][r], a.scale), mk[t][r]);
                 sc[t][r] = v;
                 m = fmaxf(m, v);
             }
@@ -219,6 +227,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 //     per workgroup a 128-image batch of ~90-token sequences is only 256 workgroups - one wave per SIMD, every LDS /
 //     exp / cross-lane latency of the per-head chain exposed.  The two parity groups walk heads h = 0,2,4.. and 1,3,5..
 //     with their own K/V rings, two independent instruction streams per SIMD, and merge their head-max once at the end.
+#ifdef MADTP_TS_TIMING
+__device__ long long g_attn_dbg[8];
+#define AT_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && it == 2) { __builtin_amdgcn_s_waitcnt(0); g_attn_dbg[i] = wall_clock64(); } } while (0)
+#else
+#define AT_MARK(i)
+#endif
 template <int NT, bool SCORES, int HS>
 __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(AttnArgs a) {
     constexpr int NKP = NT * 16;
@@ -243,6 +257,14 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
 #pragma unroll
         for (int t = 0; t < NT; ++t) pmax[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    f32x4 mk[NT];  // additive key mask of this lane's columns (0 without a mask, -inf for j >= Nk), loaded once
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * t + 4 * g + r;
+            mk[t][r] = j < a.Nk ? (a.mask ? a.mask[(size_t)b * a.Nk + j] : 0.f) : -INFINITY;
+        }
 
     // K_h and V_h are LDS-DMA'd (8 rows = 1 KiB per wave-instruction) into a 2-stage ring over the heads: the DMA of
     // head h+1 is in flight while head h is computed.  Swizzles live on the SOURCE address (the DMA destination is
@@ -250,23 +272,34 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
     // the 8 key rows of a transpose read (ds_read_b64_tr_b16) on 8 disjoint bank octets.  Rows >= Nk are clamped
     // to a valid row: their probabilities are exactly 0, so any finite data is fine.
     const int sub = lane >> 3, pos = lane & 7;
+    // per-lane source of every DMA instruction of this wave for head 0, computed ONCE (the 64-bit row arithmetic used to be
+    // redone for each of the 6-14 instructions of every head); head h adds 128 bytes
+    constexpr int NDMA = ((NKP + VR) / 8 + 3) / 4;
+    const char* srcb[NDMA];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int grp = wave + 4 * i;
+        const bool is_v = grp >= NKP / 8;
+        int row = (is_v ? grp - NKP / 8 : grp) * 8 + sub;
+        const int chunk = is_v ? (pos ^ (((row >> 1) & 3) << 1)) : (pos ^ (row & 7));
+        row = row < a.Nk ? row : a.Nk - 1;
+        srcb[i] = (is_v ? a.v + ((size_t)b * a.Nk + row) * a.ldv * 2 : a.k + ((size_t)b * a.Nk + row) * a.ldk * 2) + chunk * 16;
+    }
     auto stage_head = [&](int h, int st) {
         char* base = ring + st * STAGE;
-        for (int grp = wave; grp < (NKP + VR) / 8; grp += 4) {
-            const bool is_v = grp >= NKP / 8;
-            int row = (is_v ? grp - NKP / 8 : grp) * 8 + sub;
-            const int chunk = is_v ? (pos ^ (((row >> 1) & 3) << 1)) : (pos ^ (row & 7));
-            row = row < a.Nk ? row : a.Nk - 1;
-            const char* src = is_v ? a.v + (((size_t)b * a.Nk + row) * a.ldv + h * 64) * 2 + chunk * 16
-                                   : a.k + (((size_t)b * a.Nk + row) * a.ldk + h * 64) * 2 + chunk * 16;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(base + grp * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int grp = wave + 4 * i;
+            if (grp < (NKP + VR) / 8)
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(srcb[i] + h * 128), LDS_PTR(base + grp * 1024), 16, 0, 0);
         }
     };
     // Q fragment (B operand of S^T = K Q^T): row i, k-slot group g <-> d = 32kk + 8g .. +7; fetched one head ahead
+    const char* qbase = a.q + ((size_t)b * a.Nq + irow) * a.ldq * 2 + g * 16;
     auto load_q = [&](int h, bf16x8 (&qq)[2]) {
-        const char* qp = a.q + (((size_t)b * a.Nq + irow) * a.ldq + h * 64) * 2;
-        qq[0] = *(const bf16x8*)(qp + g * 16);
-        qq[1] = *(const bf16x8*)(qp + 64 + g * 16);
+        const char* qp = qbase + h * 128;
+        qq[0] = *(const bf16x8*)qp;
+        qq[1] = *(const bf16x8*)(qp + 64);
     };
     int st = 0;
     const int hstep = gridDim.z * HS;
@@ -280,12 +313,15 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
     for (int it = 0; it < niter; ++it, st ^= 1) {
         const int h = hfirst + it * hstep;
         bf16x8 q[2] = {qn[0], qn[1]};
+        AT_MARK(0);
         __syncthreads();  // head h landed (the barrier drains the DMA); the other stage is free again
+        AT_MARK(1);
         if (h + hstep < a.H) {
             stage_head(h + hstep, st ^ 1);
             load_q(h + hstep, qn);
         }
         if (!active || h >= a.H) continue;
+        AT_MARK(2);
         const char* Ks = ring + st * STAGE;
         const char* Vs = Ks + NKP * 128;
 
@@ -300,16 +336,14 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q[0], acc, 0, 0, 0);
             sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q[1], acc, 0, 0, 0);
         }
+        AT_MARK(3);
         // ---- softmax over keys (lane holds j = 16t+4g+r of row i) ----
         float m = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int j = 16 * t + 4 * g + r;
-                float v = sc[t][r] * a.scale;
-                if (a.mask && j < a.Nk) v += a.mask[(size_t)b * a.Nk + j];
-                v = j < a.Nk ? v : -INFINITY;
+                const float v = fmaf(sc[t][r], a.scale, mk[t][r]);
                 sc[t][r] = v;
                 m = fmaxf(m, v);
             }
@@ -326,7 +360,7 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             sc[t] *= inv;
@@ -336,17 +370,20 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
             }
         }
         if constexpr (SCORES) {
-            if (i0 + l16 == 0) {
-                float* dst = a.p0 + ((size_t)b * a.H + h) * a.Nk;
+            if (i0 == 0) {  // wave-uniform: only the wave that owns query row 0 enters (the other waves skip 4*NT branches)
+                if (l16 == 0) {
+                    float* dst = a.p0 + ((size_t)b * a.H + h) * a.Nk;
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                    for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = 16 * t + 4 * g + r;
-                        if (j < a.Nk) dst[j] = sc[t][r];
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            const int j = 16 * t + 4 * g + r;
+                            if (j < a.Nk) dst[j] = sc[t][r];
+                        }
+                }
             }
         }
+        AT_MARK(4);
         // ---- O = P V on the bf16 MFMA ----
         f32x4 o[4];
 #pragma unroll
@@ -367,6 +404,7 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, o[dt], 0, 0, 0);  // O^T: row d = 4g+r, col i
             }
         }
+        AT_MARK(5);
         // ---- write O: with the operands swapped lane (i = l16, g) holds columns h*64 + 16dt + 4g .. +3 of row i ----
         {
             const int i = i0 + l16;
@@ -387,6 +425,7 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
                     if (g == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
             }
         }
+        AT_MARK(6);
     }
 
     if constexpr (SCORES && HS == 2) {  // merge the two parity groups' head-max through the (now idle) ring memory
@@ -442,6 +481,14 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_small_kernel(AttnArgs a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) pmax[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nrt = (N + 15) / 16;
+    f32x4 mk[2];  // additive key mask of this lane's columns (0 without a mask, -inf for j >= N), loaded once
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * t + 4 * g + r;
+            mk[t][r] = j < N ? (a.mask ? a.mask[(size_t)b * N + j] : 0.f) : -INFINITY;
+        }
 
     for (int h = wave; h < a.H; h += 4) {
         // V_h rows -> private LDS (row-major 128-byte rows, chunk ^= 2*((row>>1)&3) as in the general kernel)
@@ -481,10 +528,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_small_kernel(AttnArgs a) {
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], q1, acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int j = 16 * t + 4 * g + r;
-                    float v = acc[r] * a.scale;
-                    if (a.mask && j < N) v += a.mask[(size_t)b * N + j];
-                    v = j < N ? v : -INFINITY;
+                    const float v = fmaf(acc[r], a.scale, mk[t][r]);
                     acc[r] = v;
                     m = fmaxf(m, v);
                 }
@@ -499,14 +543,14 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_small_kernel(AttnArgs a) {
                 for (int r = 0; r < 4; ++r) { sc[t][r] = __expf(sc[t][r] - m); sum += sc[t][r]; }
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.0f / sum;
+            const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 sc[t] *= inv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pmax[rt][t][r] = fmaxf(pmax[rt][t][r], sc[t][r]);
             }
-            if (i0 + l16 == 0) {
+            if (i0 == 0) if (l16 == 0) {
                 float* dst = a.p0 + ((size_t)b * a.H + h) * N;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -886,3 +930,10 @@ extern "C" int madtp_attention(const void* q, const void* k, const void* v, void
     }
     return scores ? dispatch_nt_bf16<true>(a, s) : dispatch_nt_bf16<false>(a, s);
 }
+
+#ifdef MADTP_TS_TIMING
+extern "C" int madtp_debug_read_attn_ts(long long* out) {
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_dbg), sizeof(long long) * 8);
+}
+#endif
