@@ -71,7 +71,11 @@ class BLIP_NLVR(nn.Module):
         require_gpu(image, "image")
         self.visual_encoder.img_query_model.compute_att_ft = self.compute_sd_ft
         self.text_encoder.encoder.txt_query_model.compute_att_ft = self.compute_sd_ft
-        image_embeds, sd_img_ft = self.visual_encoder(image, space_dict=self.space_dict, temperature=temperature)  # :64
+        # sd_img_ft only feeds the training loss (:86-96): its (fast-mode) sum over the layers runs on the auxiliary stream,
+        # under the text encoder, and is joined before this forward returns
+        pending = []
+        image_embeds, sd_img_ft = self.visual_encoder(image, space_dict=self.space_dict, temperature=temperature,
+                                                      _pending=pending)  # :64
         image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
         image0_embeds, image1_embeds = torch.split(image_embeds, targets.size(0))  # :67
         ids, att = self._tokens(text, image.device)
@@ -86,7 +90,11 @@ class BLIP_NLVR(nn.Module):
         l2 = lin_of(self._cache, "c2", [self.cls_head[2]])
         h = h if compute_dtype() == torch.float32 else hip.cast_bf16(h)
         h = hip.gemm(h, l0.w, l0.b, act=hip.ACT_RELU, n=l0.n)
-        return hip.gemm(h, l2.w, l2.b, out_dtype=torch.float32, n=l2.n)  # :81
+        logits = hip.gemm(h, l2.w, l2.b, out_dtype=torch.float32, n=l2.n)  # :81
+        for p in pending:
+            p.sync()
+        self.last_sd_ft = (sd_img_ft, sd_txt_ft)
+        return logits
 
 
 def blip_nlvr(pretrained='', **kwargs):

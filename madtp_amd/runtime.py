@@ -104,6 +104,18 @@ def lin_of(cache, key, linears, dtype=None):
                      lambda: prepare_linear([l.weight for l in linears], [l.bias for l in linears], dtype))
 
 
+_SIDE = {}
+
+
+def side_stream(device=None):
+    """One auxiliary HIP stream per device for work the main stream does not depend on (the deferred att_ft sum of the
+    vision encoder runs there, under the text encoder's latency-bound kernels)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE[dev]
+
+
 def require_gpu(t, name="input"):
     if not t.is_cuda:
         raise RuntimeError(f"{name} is on {t.device}: madtp_amd modules run only on an MI355X through the HIP "

@@ -45,12 +45,33 @@ class DeferredAttFt:
     def add(self, token_att, ft):
         self.pairs.append((token_att, ft))
 
-    def finish(self):
+    def finish(self, pending=None):
+        """pending (optional list): run the sum on the auxiliary stream and append a handle whose .sync() makes the
+        current stream wait for it; the returned tensor must not be consumed (or freed) before that."""
         if not self.pairs:
             return None
-        out = hip.query_att_ft_multi(self.pairs, sd_dim=self.sd_dim)
+        if pending is None:
+            out = hip.query_att_ft_multi(self.pairs, sd_dim=self.sd_dim)
+            self.pairs = []
+            return out
+        from .runtime import side_stream
+        main, side = torch.cuda.current_stream(), side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = hip.query_att_ft_multi(self.pairs, sd_dim=self.sd_dim)
+        out.record_stream(main)
+        pending.append(_SideWork(side, self.pairs))  # the handle keeps the layers' tensors alive until the wait
         self.pairs = []
         return out
+
+
+class _SideWork:
+    def __init__(self, stream, keep):
+        self.stream, self.keep = stream, keep
+
+    def sync(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.keep = None
 
 
 class Query_model(nn.Module):

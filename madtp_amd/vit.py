@@ -251,7 +251,9 @@ class VisionTransformer(nn.Module):
     def no_weight_decay(self):
         return {'pos_embed', 'cls_token'}
 
-    def forward(self, x, register_blk=-1, space_dict=None, temperature=0):
+    def forward(self, x, register_blk=-1, space_dict=None, temperature=0, _pending=None):
+        """_pending (extension used by BLIP_NLVR): a list - the fast-mode sum of the layers' att_ft then runs on the
+        auxiliary stream and the caller makes its stream wait (handle.sync()) before sd_img_ft_all is consumed."""
         B = x.shape[0]
         patches, np_ = self.patch_embed.run(x)  # vit.py:283
         x = hip.assemble_tokens(patches, self.cls_token, self.pos_embed, B, np_)  # vit.py:285-289
@@ -269,7 +271,7 @@ class VisionTransformer(nn.Module):
             else:
                 x = blk(x, register_blk == i)
         if defer is not None and defer.pairs:
-            sd_img_ft_all = defer.finish()
+            sd_img_ft_all = defer.finish(_pending)
         B, N, D = x.shape
         y, _ = hip.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)  # :309
         return y, sd_img_ft_all
