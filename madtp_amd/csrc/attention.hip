@@ -463,12 +463,15 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
 // ------------------------------------------------------------------------------------------------------------------
 // Short-sequence self-attention with scores (Nq = Nk <= 32: the 20-token text side of NLVR).  With one or two 16-row
 // query tiles the general kernel leaves half its waves idle and serialises 12 heads behind block barriers.  Here a
-// workgroup is one sample and every wave is independent: wave w takes heads w, w+4, w+8 for BOTH query tiles, reads K
+// workgroup is one sample and every wave is independent: wave w takes heads w, w+SMALL_NW, .. for BOTH query tiles, reads K
 // and Q fragments straight from global memory, stages V_h (<= 32 x 64 bf16 = 4 KiB) in its private LDS slice for the
 // transpose reads, and keeps its partial head-max in registers; the four partial maxima are combined through LDS once.
-__global__ __launch_bounds__(256, 2) void attn_bf16_small_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char vbuf[4][32 * 128];
-    __shared__ float pm[4][2][2][64][4];  // [wave][row tile][key tile][lane][r]
+// SMALL_NW waves per workgroup: with 12 heads every wave owns exactly one head (a head is a ~3 us dependent chain; four
+// waves walking three heads each made the kernel three chains long).
+constexpr int SMALL_NW = 12;
+__global__ __launch_bounds__(64 * SMALL_NW, 1) void attn_bf16_small_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char vbuf[SMALL_NW][32 * 128];
+    __shared__ float pm[SMALL_NW][2][2][64][4];  // [wave][row tile][key tile][lane][r]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, g = lane >> 4;
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_small_kernel(AttnArgs a) {
             mk[t][r] = j < N ? (a.mask ? a.mask[(size_t)b * N + j] : 0.f) : -INFINITY;
         }
 
-    for (int h = wave; h < a.H; h += 4) {
+    for (int h = wave; h < a.H; h += SMALL_NW) {
         // V_h rows -> private LDS (row-major 128-byte rows, chunk ^= 2*((row>>1)&3) as in the general kernel)
         {
             const int sub = lane >> 3, pos = lane & 7;
@@ -602,7 +605,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_small_kernel(AttnArgs a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = fmaxf(fmaxf(pm[0][rt][t][lane][r], pm[1][rt][t][lane][r]), fmaxf(pm[2][rt][t][lane][r], pm[3][rt][t][lane][r]));
+                float v = pm[0][rt][t][lane][r];
+#pragma unroll
+                for (int w = 1; w < SMALL_NW; ++w) v = fmaxf(v, pm[w][rt][t][lane][r]);
                 v = row16_sum(valid ? v : 0.f);
                 const int j = 16 * t + 4 * g + r;
                 if (l16 == 0 && j < N) dst[j] = v;
@@ -924,7 +929,7 @@ extern "C" int madtp_attention(const void* q, const void* k, const void* v, void
     if (io_dtype == MADTP_F32) return scores ? dispatch_nt<float, true>(a, s) : dispatch_nt<float, false>(a, s);
     if ((ldk * 2) % 16 || (ldv * 2) % 16) return MADTP_E_ALIGN;
     if (scores && Nk <= 32) {  // short text sequences: one sample per workgroup, heads spread over the waves
-        hipLaunchKernelGGL(attn_bf16_small_kernel, dim3(B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attn_bf16_small_kernel, dim3(B), dim3(64 * SMALL_NW), 0, s, a);
         MADTP_LAUNCH_CHECK();
         return 0;
     }
