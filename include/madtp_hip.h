@@ -141,6 +141,10 @@ int madtp_token_select(const float* score, int k, int64_t* indices, int64_t* ind
  * x f32 [B,N,dim] -> y f32 [B,k+2,dim]. */
 int madtp_token_gather(const float* x, const int32_t* dst_pos, const float* merge_w, float* y,
                        int B, int N, int k, int dim, void* stream);
+/* The same with the following LayerNorm fused in (Block.norm2, vit.py:195): h32 and/or h_lp (compute dtype) receive
+ * LayerNorm(y) row by row, bit-identical to madtp_layernorm(y); gamma == NULL: plain gather. */
+int madtp_token_gather_ln(const float* x, const int32_t* dst_pos, const float* merge_w, float* y, int B, int N, int k, int dim,
+                          const float* gamma, const float* beta, float eps, float* h32, void* h_lp, void* stream);
 
 /* Additive-mask compaction for the text encoders (nlvr_encoder.py:451-452,531-533; med.py:388-390,429-440):
  * out[b,0]=mask[b,0]; out[b,1+p] = mask[b,1+order[b,p]] for p in [0,k]  with order = indices_sort (NLVR, order2 = NULL);

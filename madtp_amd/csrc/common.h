@@ -87,3 +87,47 @@ __device__ __forceinline__ float row16_sum(float v) {
     } while (0)
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---- LayerNorm of one row held by one wave (shared by norm.hip and the gather+LayerNorm fusion in prune.hip) ----
+constexpr int LN_MAX_CHUNKS = 4;  // dim <= 1024
+
+// normalise a row held as float4 chunks in registers; two-pass (mean, then centred variance) in f32
+__device__ __forceinline__ void ln_row(float4 (&v)[LN_MAX_CHUNKS], int nchunk_lane, int dim, float eps, float& mean,
+                                       float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+        if (c < nchunk_lane) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+    mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+        if (c < nchunk_lane) {
+            const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    const float var = wave_sum(q) / (float)dim;
+    rstd = 1.0f / sqrtf(var + eps);
+}
+
+__device__ __forceinline__ void ln_store(const float4 (&v)[LN_MAX_CHUNKS], int lane, int dim, float mean, float rstd,
+                                         const float* gamma, const float* beta, float* y32, bf16_t* ylp) {
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int col = (lane + 64 * c) * 4;
+        if (col >= dim) break;
+        const float4 gm = *(const float4*)(gamma + col);
+        const float4 bt = *(const float4*)(beta + col);
+        float4 o;
+        o.x = (v[c].x - mean) * rstd * gm.x + bt.x;
+        o.y = (v[c].y - mean) * rstd * gm.y + bt.y;
+        o.z = (v[c].z - mean) * rstd * gm.z + bt.z;
+        o.w = (v[c].w - mean) * rstd * gm.w + bt.w;
+        if (y32) *(float4*)(y32 + col) = o;
+        if (ylp) {
+            *(bf16x4*)(ylp + col) = pack_bf16x4((f32x4){o.x, o.y, o.z, o.w});
+        }
+    }
+}
+
+

@@ -203,12 +203,14 @@ extern "C" int madtp_vit_block_mlp(const madtp_vit_block_w* w, const float* x, f
     if (k > 0) {
         if (!score || !indices || !indices_sort) return MADTP_E_BADARG;
         TRY(madtp_token_select(score, k, indices, indices_sort, s.dst_pos, s.merge_w, B, N - 1, stream));
-        TRY(madtp_token_gather(x, s.dst_pos, s.merge_w, s.xp, B, N, k, D, stream));
+        // gather + merge with norm2 fused in: the copying wave holds the row, so it emits LN(row) as well
+        TRY(madtp_token_gather_ln(x, s.dst_pos, s.merge_w, s.xp, B, N, k, D, w->ln2_g, w->ln2_b, w->eps,
+                                  dt == MADTP_F32 ? (float*)s.h : nullptr, dt == MADTP_F32 ? nullptr : s.h, stream));
         xr = s.xp;
         Np = k + 2;
     }
     const int M = B * Np;
-    TRY(ln_to(xr, w->ln2_g, w->ln2_b, nullptr, s.h, M, D, w->eps, dt, stream));
+    if (k == 0) TRY(ln_to(xr, w->ln2_g, w->ln2_b, nullptr, s.h, M, D, w->eps, dt, stream));
     TRY(lin(s.h, D, w->fc1, nullptr, 0, s.mid, w->fc1.n, M, dt, dt, w->act, 1.f, stream));
     TRY(lin(s.mid, w->fc1.n, w->fc2, xr, D, y, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
     return 0;

@@ -306,21 +306,40 @@ __global__ __launch_bounds__(256) void token_select_kernel(const float* __restri
 // grid (chunks+1, B): chunk c copies source tokens [16c,16c+16) that survive (token 0 = CLS -> slot 0); the extra
 // last workgroup of each sample builds the merged token (fixed wave/token order, LDS combine).
 constexpr int GATHER_ROWS = 16;
+// Optional fused LayerNorm (the Block's norm2, vit.py:195): the wave that copies a row holds it in registers, so it also
+// emits LN(row) (f32 and/or compute dtype) - the separate LayerNorm kernel re-read the whole gathered tensor.  The
+// arithmetic is the row routine of layernorm_kernel (common.h), so the result is bit-identical to the two-kernel path.
 __global__ __launch_bounds__(256) void token_gather_kernel(const float* __restrict__ x, const int32_t* __restrict__ dst_pos,
                                                            const float* __restrict__ merge_w, float* __restrict__ y, int N,
-                                                           int k, int dim4) {
+                                                           int k, int dim4, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float* h32, bf16_t* hlp) {
     __shared__ float4 part[4][256];  // dim <= 1024
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, n = N - 1, No = k + 2;
+    const int b = blockIdx.y, n = N - 1, No = k + 2, dim = dim4 * 4;
     const float4* xb = (const float4*)x + (size_t)b * N * dim4;
     float4* yb = (float4*)y + (size_t)b * No * dim4;
+    const bool ln = gamma != nullptr;
+    auto ln_out = [&](float4 (&v)[LN_MAX_CHUNKS], int nch, int dst) {
+        float mean, rstd;
+        ln_row(v, nch, dim, eps, mean, rstd);
+        const size_t off = ((size_t)b * No + dst) * dim;
+        ln_store(v, lane, dim, mean, rstd, gamma, beta, h32 ? h32 + off : nullptr, hlp ? hlp + off : nullptr);
+    };
     if ((int)blockIdx.x < (int)gridDim.x - 1) {
         for (int rr = wave; rr < GATHER_ROWS; rr += 4) {
             const int t = blockIdx.x * GATHER_ROWS + rr;  // source token incl. CLS
             if (t >= N) break;
             const int dst = t == 0 ? 0 : dst_pos[(size_t)b * n + t - 1] + 1;
             if (dst <= 0 && t != 0) continue;
-            for (int c = lane; c < dim4; c += 64) yb[(size_t)dst * dim4 + c] = xb[(size_t)t * dim4 + c];
+            float4 v[LN_MAX_CHUNKS];
+            int nch = 0;
+#pragma unroll
+            for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+                const int cc = lane + 64 * c;
+                if (cc < dim4) { v[c] = xb[(size_t)t * dim4 + cc]; yb[(size_t)dst * dim4 + cc] = v[c]; nch = c + 1; }
+                else v[c] = make_float4(0, 0, 0, 0);
+            }
+            if (ln) ln_out(v, nch, dst);
         }
     } else {
         float4 acc[4];
@@ -343,8 +362,23 @@ __global__ __launch_bounds__(256) void token_gather_kernel(const float* __restri
         __syncthreads();
         for (int c = tid; c < dim4; c += 256) {
             const float4 p0 = part[0][c], p1 = part[1][c], p2 = part[2][c], p3 = part[3][c];
-            yb[(size_t)(k + 1) * dim4 + c] = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
-                                                         ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+            const float4 f = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
+                                         ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+            yb[(size_t)(k + 1) * dim4 + c] = f;
+            part[0][c] = f;  // only this thread touches column c of part[0] from here on
+        }
+        if (ln) {
+            __syncthreads();
+            if (wave == 0) {
+                float4 v[LN_MAX_CHUNKS];
+                int nch = 0;
+#pragma unroll
+                for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+                    const int cc = lane + 64 * c;
+                    if (cc < dim4) { v[c] = part[0][cc]; nch = c + 1; } else v[c] = make_float4(0, 0, 0, 0);
+                }
+                ln_out(v, nch, k + 1);
+            }
         }
     }
 }
@@ -1027,16 +1061,24 @@ extern "C" int madtp_token_select(const float* score, int k, int64_t* indices, i
     return 0;
 }
 
-extern "C" int madtp_token_gather(const float* x, const int32_t* dst_pos, const float* merge_w, float* y, int B, int N,
-                                  int k, int dim, void* stream) {
+extern "C" int madtp_token_gather_ln(const float* x, const int32_t* dst_pos, const float* merge_w, float* y, int B, int N,
+                                     int k, int dim, const float* gamma, const float* beta, float eps, float* h32, void* h_lp,
+                                     void* stream) {
     if (!x || !dst_pos || !merge_w || !y || B <= 0 || N < 2 || k < 1 || k > N - 1) return MADTP_E_BADARG;
+    if (gamma && (!beta || (!h32 && !h_lp))) return MADTP_E_BADARG;
     if (dim % 4 || dim > 1024) return MADTP_E_SHAPE;
-    if (!aligned16(x) || !aligned16(y)) return MADTP_E_ALIGN;
+    if (!aligned16(x) || !aligned16(y) || (gamma && (!aligned16(gamma) || !aligned16(beta) || !aligned16(h32) || !aligned16(h_lp))))
+        return MADTP_E_ALIGN;
     const int chunks = (N + GATHER_ROWS - 1) / GATHER_ROWS;
     hipLaunchKernelGGL(token_gather_kernel, dim3(chunks + 1, B), dim3(256), 0, (hipStream_t)stream, x, dst_pos, merge_w, y, N,
-                       k, dim / 4);
+                       k, dim / 4, gamma, beta, eps, h32, (bf16_t*)h_lp);
     MADTP_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int madtp_token_gather(const float* x, const int32_t* dst_pos, const float* merge_w, float* y, int B, int N,
+                                  int k, int dim, void* stream) {
+    return madtp_token_gather_ln(x, dst_pos, merge_w, y, B, N, k, dim, nullptr, nullptr, 0.f, nullptr, nullptr, stream);
 }
 
 extern "C" int madtp_mask_gather(const float* mask, const int64_t* order, int ld_order, const int64_t* order2,

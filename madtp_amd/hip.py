@@ -35,6 +35,7 @@ _SIGS = {
                           + [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "madtp_token_select": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "madtp_token_gather": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "madtp_token_gather_ln": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "madtp_mask_gather": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "madtp_query_att_ft": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_int,
                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -282,6 +283,18 @@ def token_gather(x, dst_pos, merge_w, k):
     _check(load().madtp_token_gather(_p(x), _p(dst_pos), _p(merge_w), _p(y), B, N, k, dim, _stream()),
            "madtp_token_gather")
     return y
+
+
+def token_gather_ln(x, dst_pos, merge_w, k, gamma, beta, eps, want_f32=True, want_bf16=True):
+    """token_gather with the following LayerNorm fused in -> (y, LN(y) f32 or None, LN(y) bf16 or None)."""
+    _req(x, torch.float32, "x")
+    B, N, dim = x.shape
+    y = torch.empty((B, k + 2, dim), device=x.device, dtype=torch.float32)
+    h32 = torch.empty_like(y) if want_f32 else None
+    hlp = torch.empty(y.shape, device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    _check(load().madtp_token_gather_ln(_p(x), _p(dst_pos), _p(merge_w), _p(y), B, N, k, dim, _p(gamma), _p(beta), float(eps),
+                                        _p(h32), _p(hlp), _stream()), "madtp_token_gather_ln")
+    return y, h32, hlp
 
 
 def mask_gather(mask2d, order, k, order2=None):

@@ -263,6 +263,19 @@ def test_token_score_host_visible_k(hip, B, N):
     del junk
 
 
+@pytest.mark.parametrize("B,N,k,D", [(3, 197, 120, 768), (2, 20, 7, 768), (2, 131, 129, 512)])
+def test_token_gather_fused_layernorm(hip, B, N, k, D):
+    """gather + merge with the following LayerNorm fused in == gather, then layernorm (bit for bit)."""
+    x = _rand(B, N, D, seed=60).cuda()
+    score = _rand(B, N - 1, seed=61).abs().cuda().contiguous()
+    gamma, beta = _rand(D, seed=62).cuda(), _rand(D, seed=63).cuda()
+    _, _, dst, mw = hip.token_select(score, k)
+    y = hip.token_gather(x, dst, mw, k)
+    h32, hlp = hip.layernorm(y, gamma, beta, 1e-6, want_f32=True, want_bf16=True)
+    y2, g32, glp = hip.token_gather_ln(x, dst, mw, k, gamma, beta, 1e-6)
+    assert torch.equal(y, y2) and torch.equal(h32, g32) and torch.equal(hlp, glp)
+
+
 def test_select_ties_and_extremes(hip):
     # ties resolve to the lower index (stable), all-equal scores, k = n
     s = torch.tensor([[0.5, 0.5, 0.1, 0.9, 0.5, 0.1, 0.9, 0.0]] * 2)
