@@ -9,6 +9,8 @@ shapes = [(25216, 2304, 768), (25216, 768, 768), (25216, 3072, 768), (25216, 768
           (10496, 2304, 768), (10496, 768, 768), (10496, 3072, 768), (10496, 768, 3072),
           (5120, 1536, 768), (1280, 2304, 768), (1280, 768, 768), (1280, 3072, 768), (1280, 768, 3072), (1280, 768, 1536),
           (1280, 128, 768), (10496, 128, 768), (4096, 4096, 4096)]
+if len(sys.argv) > 2 and sys.argv[2] == "quant":  # tile-count quantisation of the N=768 problems between 10k and 18k rows
+    shapes = [(M, 768, K) for M in (10496, 11008, 11648, 12160, 14208, 17152) for K in (768, 3072)]
 if len(sys.argv) > 2 and sys.argv[2] == "small":
     shapes = [sh for sh in shapes if sh[0] <= 5120 or sh[1] == 128]
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
