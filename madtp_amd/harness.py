@@ -23,6 +23,21 @@ def nlvr_inputs(B, image_size=224, L=20, seed=0, device="cuda"):
     return images, {"input_ids": ids, "attention_mask": torch.ones_like(ids)}, torch.zeros(B, dtype=torch.long, device=device)
 
 
+def retrieval_inputs(n_img, img_bs, n_txt, image_size=224, L=35, seed=0, device="cpu"):
+    """Synthetic retrieval evaluation set: image loader batches (list of [<=img_bs,3,S,S]), caption ids/masks [n_txt,L] padded
+    to max_length 35 with ragged true lengths (pad id 0), as tokenizer(padding='max_length') yields (compress_retrieval_dtp.py:102)."""
+    images = synth.synth_images(n_img, image_size, seed)
+    batches = [images[i:i + img_bs].to(device) for i in range(0, n_img, img_bs)]
+    ids = synth.synth_token_ids(n_txt, L, seed + 1, first_id=101)
+    att = torch.ones_like(ids)
+    for t in range(n_txt):
+        n = 6 + (7 * t + 3 * seed) % (L - 5)  # 6 .. L true tokens
+        ids[t, n - 1] = 102  # [SEP]
+        ids[t, n:] = 0
+        att[t, n:] = 0
+    return batches, ids.to(device), att.to(device)
+
+
 def _cpu_info(info):
     if info is None:
         return None

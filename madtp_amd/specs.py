@@ -94,6 +94,19 @@ def blip_nlvr_shapes(img_size=224):
     return sd
 
 
+def blip_retrieval_shapes(img_size=384, embed_dim=256):
+    """models/blip_retrieval.py BLIP_Retrieval.__init__ :20-66 - the modules the evaluation path uses (the momentum
+    encoders, queues and `temp` of :67-93 only feed the training loss)."""
+    sd = OrderedDict()
+    sd["space_dict"] = (SD_NUM, D)
+    sd.update(vit_shapes("visual_encoder.", img_size))
+    sd.update(bert_shapes("text_encoder.", "med"))
+    _linear(sd, "vision_proj", embed_dim, D)
+    _linear(sd, "text_proj", embed_dim, D)
+    _linear(sd, "itm_head", 2, D)
+    return sd
+
+
 def clip_vit_shapes(prefix="", img_size=224, patch=16, width=768, layers=12, out_dim=512, sd_dim=768):
     """clip/model.py VisionTransformer (:275-313) with ResidualAttentionBlock (:174-261); ViT-B/16 geometry."""
     sd = OrderedDict()

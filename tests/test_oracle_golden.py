@@ -139,3 +139,28 @@ def test_oracle_vit_large_image_matches_reference_fixture(path):
             assert (np.sort(info["indices"].numpy(), 1) == np.sort(g[f"vit{l}_idx"], 1)).all()
         else:
             assert not info["pruned"]
+
+
+RETR_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "retr_*.npz")))
+
+
+@pytest.mark.parametrize("path", RETR_CASES, ids=[os.path.basename(c)[:-4] for c in RETR_CASES])
+def test_oracle_retrieval_matches_reference_fixture(path):
+    """ITM re-ranking evaluation: the fixture was produced by the reference's OWN evaluate()
+    (compress_retrieval_dtp.py:84-207) on the synthetic set; the oracle restatement must give the same score matrices
+    (same candidates re-ranked, same scores) including the cross-batch CLS-repeat padding of the image tokens."""
+    from madtp_amd import harness
+    g = np.load(path)
+    n_img, img_bs, n_txt, size = int(g["n_img"]), int(g["img_bs"]), int(g["n_txt"]), int(g["size"])
+    T, k_test, seed = float(g["temperature"]), int(g["k_test"]), int(g["seed"])
+    shapes = specs.blip_retrieval_shapes(size)
+    assert sorted(shapes.keys()) == g["state_dict_keys"].tolist()
+    W = specs.synth_weights(shapes, seed)
+    batches, ids, att = harness.retrieval_inputs(n_img, img_bs, n_txt, size, 35, seed)
+    ex = {}
+    with torch.no_grad():
+        i2t, t2i = O.retrieval_evaluate(W, batches, ids, att, T, k_test, extras=ex)
+    assert ex["image_feats"].shape[1] == int(g["vit_out_lens"].max())
+    for ours, ref in ((i2t.numpy(), g["score_i2t"]), (t2i.numpy(), g["score_t2i"])):
+        assert ((ours == -100.0) == (ref == -100.0)).all()          # the same candidates were re-ranked
+        assert np.abs(ours - ref).max() < 1e-5

@@ -200,6 +200,50 @@ def clip_case(name, B, temperature, seed=0, size=224):
     print(f"[{name}] T={temperature} vit_lens={lens}")
 
 
+def retrieval_case(name, n_img, img_bs, n_txt, size, temperature, k_test, seed=0):
+    """compress_retrieval_dtp.py evaluate() - the reference's own function, imported behind the shims - on a synthetic
+    evaluation set: text features (text mode), image features with the cross-batch CLS-repeat padding, similarity
+    matrix, ITM re-ranking of the top k_test candidates in both directions."""
+    import types
+    import compress_retrieval_dtp as crd
+    import models.blip_retrieval as rbr
+    from madtp_amd import harness, specs
+    ref_shims.patch_tokenizer(rbr)
+    model = rbr.BLIP_Retrieval(image_size=size, vit="base", queue_size=8, evaluate=True)
+    model.eval()
+    sd = specs.synth_weights(specs.blip_retrieval_shapes(size), seed)
+    msg = model.load_state_dict(sd, strict=False)
+    used = ("visual_encoder.", "text_encoder.", "vision_proj.", "text_proj.", "itm_head.", "space_dict")
+    assert not msg.unexpected_keys, msg.unexpected_keys
+    assert all((not k.startswith(used)) or "query_model" in k or "position_ids" in k for k in msg.missing_keys), \
+        [k for k in msg.missing_keys if k.startswith(used)]
+    batches, ids, att = harness.retrieval_inputs(n_img, img_bs, n_txt, size, 35, seed)
+
+    class Texts:  # data_loader.dataset.text: len() and slicing -> what FakeTokenizer passes through
+        def __len__(self): return n_txt
+        def __getitem__(self, sl): return {"input_ids": ids[sl], "attention_mask": att[sl]}
+
+    class Loader:
+        dataset = types.SimpleNamespace(text=Texts(), image=list(range(n_img)))
+        def __len__(self): return len(batches)
+        def __iter__(self):
+            for b, img in enumerate(batches):
+                yield img, ["caption"] * img.shape[0], torch.arange(img.shape[0]) + b * img_bs
+
+    lens = []
+    hook = model.visual_encoder.register_forward_hook(lambda m, a, o: lens.append(o[0].shape[1]))
+    crd.args = types.SimpleNamespace(distributed=False)
+    t0 = time.time()
+    i2t, t2i, _ = crd.evaluate(model, Loader(), torch.device("cpu"), {"k_test": k_test, "alpha": 0.4}, temperature)
+    dt = time.time() - t0
+    hook.remove()
+    rec = {"kind": "retrieval", "n_img": n_img, "img_bs": img_bs, "n_txt": n_txt, "size": size, "k_test": k_test,
+           "temperature": np.float64(temperature), "seed": seed, "score_i2t": i2t, "score_t2i": t2i,
+           "vit_out_lens": np.array(lens), "ref_seconds": dt, "state_dict_keys": np.array(sorted(sd.keys()))}
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] T={temperature} vit_out_lens={lens} i2t[0]={np.round(i2t[0], 3).tolist()} ({dt:.1f}s)")
+
+
 CASES = {
     "nlvr_b2_T1": lambda: nlvr_case("nlvr_b2_T1", 2, 224, 20, 1.0),
     "nlvr_b2_T5": lambda: nlvr_case("nlvr_b2_T5", 2, 224, 20, 5.0),
@@ -208,6 +252,7 @@ CASES = {
     "clip_vit_b2": lambda: clip_case("clip_vit_b2", 2, 4.0),
     "vit384_b2": lambda: vit_case("vit384_b2", 2, 384, 6.0),
     "vit480_b1": lambda: vit_case("vit480_b1", 1, 480, 6.0),
+    "retr_i6_t12": lambda: retrieval_case("retr_i6_t12", 6, 3, 12, 224, 6.0, 4),
 }
 
 if __name__ == "__main__":

@@ -186,6 +186,29 @@ def install(chdir=True):
         if not hasattr(act, name):
             setattr(act, name, val)
 
+    # (9) compress_retrieval_dtp.py imports: ruamel_yaml, the dataset package, fvcore's FLOP counter
+    if "ruamel_yaml" not in sys.modules:
+        import yaml as _yaml
+        ry = _mod("ruamel_yaml")
+        ry.load = lambda f, Loader=None: _yaml.safe_load(f)
+        ry.Loader = None
+        ry.dump = _yaml.safe_dump
+    if "data" not in sys.modules:
+        dm = _mod("data")
+        dm.create_dataset = dm.create_sampler = dm.create_loader = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no datasets offline"))
+    if "fvcore" not in sys.modules:
+        _mod("fvcore")
+        fn = _mod("fvcore.nn")
+
+        class _Flops:  # the evaluation only averages .total(); the traced forward itself is the training branch
+            def __init__(self, *a, **k): pass
+            def total(self): return 0.0
+            def unsupported_ops_warnings(self, *a): pass
+            def uncalled_modules_warnings(self, *a): pass
+            def tracer_warnings(self, *a): pass
+        fn.FlopCountAnalysis = _Flops
+        fn.flop_count_str = fn.flop_count_table = lambda *a, **k: ""
+
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     if chdir:
