@@ -23,6 +23,46 @@ def nlvr_inputs(B, image_size=224, L=20, seed=0, device="cuda"):
     return images, {"input_ids": ids, "attention_mask": torch.ones_like(ids)}, torch.zeros(B, dtype=torch.long, device=device)
 
 
+def build_retrieval(image_size=224, seed=0, device="cuda"):
+    """BLIP_Retrieval mirror with the deterministic synthetic weights (same bits as the golden generator used)."""
+    from .blip_retrieval import BLIP_Retrieval
+    model = BLIP_Retrieval(image_size=image_size, evaluate=True)
+    msg = model.load_state_dict(specs.synth_weights(specs.blip_retrieval_shapes(image_size), seed), strict=False)
+    assert not msg.unexpected_keys and all("query_model" in k or "position_ids" in k for k in msg.missing_keys), msg
+    return model.eval().to(device)
+
+
+class RetrievalLoader:
+    """Stand-in for the reference's data loader over a synthetic evaluation set: iterating yields (image batch, captions,
+    image ids); .dataset.text slices to {'input_ids','attention_mask'}; .dataset.image has one entry per image."""
+
+    def __init__(self, batches, ids, att):
+        self.batches = batches
+        outer = self
+
+        class _Text:
+            def __len__(self):
+                return ids.shape[0]
+
+            def __getitem__(self, sl):
+                return {"input_ids": ids[sl], "attention_mask": att[sl]}
+
+        class _DS:
+            text = _Text()
+            image = list(range(sum(b.shape[0] for b in batches)))
+        self.dataset = _DS()
+        del outer
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        n = 0
+        for b in self.batches:
+            yield b, ["caption"] * b.shape[0], torch.arange(n, n + b.shape[0])
+            n += b.shape[0]
+
+
 def retrieval_inputs(n_img, img_bs, n_txt, image_size=224, L=35, seed=0, device="cpu"):
     """Synthetic retrieval evaluation set: image loader batches (list of [<=img_bs,3,S,S]), caption ids/masks [n_txt,L] padded
     to max_length 35 with ragged true lengths (pad id 0), as tokenizer(padding='max_length') yields (compress_retrieval_dtp.py:102)."""

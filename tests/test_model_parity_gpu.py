@@ -256,3 +256,38 @@ def test_fused_layer_calls_equal_two_step(mode):
             assert y.shape == y2.shape and torch.equal(y, y2)
             if k_use:
                 assert info["pruned"] and torch.equal(info["indices"], idx) and torch.equal(info["indices_sort"], idx_sort)
+
+
+RETR_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "retr_*.npz")))
+
+
+@pytest.mark.parametrize("path", RETR_CASES, ids=[os.path.basename(c)[:-4] for c in RETR_CASES])
+def test_retrieval_itm_reranking_matches_reference_fixture(path):
+    """blip_retrieval.evaluate() mirror vs the score matrices the reference's own evaluate() produced:
+    fp32 mode re-ranks the same candidates with the same scores (incl. the cross-batch CLS-repeat padding and the text-side
+    pruning inside the k_test-pair multimodal batches); bf16 mode stays close; rank slicing (2 ranks) sums to the whole."""
+    from madtp_amd import build, hip, harness, runtime
+    from madtp_amd import blip_retrieval as br
+    build.build(verbose=False)
+    hip.load()
+    g = np.load(path)
+    n_img, img_bs, n_txt, size = int(g["n_img"]), int(g["img_bs"]), int(g["n_txt"]), int(g["size"])
+    T, k_test, seed = float(g["temperature"]), int(g["k_test"]), int(g["seed"])
+    model = harness.build_retrieval(size, seed)
+    batches, ids, att = harness.retrieval_inputs(n_img, img_bs, n_txt, size, 35, seed, device="cuda")
+    loader = harness.RetrievalLoader(batches, ids, att)
+    cfg = {"k_test": k_test}
+    with runtime.precision("fp32"):
+        i2t, t2i, _ = br.evaluate(model, loader, torch.device("cuda"), cfg, T)
+        parts = [br.evaluate(model, loader, torch.device("cuda"), cfg, T, rank=r, world_size=2) for r in range(2)]
+    for ours, ref in ((i2t, g["score_i2t"]), (t2i, g["score_t2i"])):
+        assert ((ours == -100.0) == (ref == -100.0)).all()
+        assert np.abs(ours - ref).max() < 1e-3
+    # the reference all-reduces (SUM) matrices initialised to -100 on every rank: rows owned by a rank carry its scores
+    for k, full in ((0, i2t), (1, t2i)):
+        merged = np.where(parts[0][k] != -100.0, parts[0][k], parts[1][k])
+        assert np.array_equal(merged, full)
+        assert not ((parts[0][k] != -100.0) & (parts[1][k] != -100.0)).any()
+    with runtime.precision("bf16"):
+        b_i2t, b_t2i, _ = br.evaluate(model, loader, torch.device("cuda"), cfg, T)
+    assert np.isfinite(b_i2t).all() and np.isfinite(b_t2i).all()

@@ -164,3 +164,14 @@ def test_oracle_retrieval_matches_reference_fixture(path):
     for ours, ref in ((i2t.numpy(), g["score_i2t"]), (t2i.numpy(), g["score_t2i"])):
         assert ((ours == -100.0) == (ref == -100.0)).all()          # the same candidates were re-ranked
         assert np.abs(ours - ref).max() < 1e-5
+
+
+def test_retrieval_mirror_state_dict_keys():
+    """The BLIP_Retrieval mirror exposes every evaluation-path key of the reference's state dict (checked against the key
+    list the fixture recorded from the reference model), so reference checkpoints load by name (strict=False drops the
+    momentum / queue entries)."""
+    from madtp_amd.blip_retrieval import BLIP_Retrieval
+    ref_keys = set(np.load(RETR_CASES[0])["state_dict_keys"].tolist())
+    mine = set(BLIP_Retrieval(image_size=224, evaluate=True).state_dict().keys())
+    assert ref_keys <= mine, sorted(ref_keys - mine)[:5]
+    assert all("query_model" in k for k in mine - ref_keys), sorted(mine - ref_keys)[:5]
