@@ -97,6 +97,13 @@ int madtp_attention(const void* q, const void* k, const void* v, void* out, cons
                     float* colsum_part, float* p0, float* onorm,
                     int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo,
                     float scale, int io_dtype, void* stream);
+/* Cross-attention against a CACHE of encoder K/V blocks: sample b attends to block kv_batch_index[b] (int32 [B], device) of
+ * k / v, i.e. rows kv_batch_index[b]*Nk .. +Nk-1 (NULL = block b, which is madtp_attention).  Lets many queries share the
+ * projected K/V of one image (retrieval re-ranking) without copying them; no score side outputs. */
+int madtp_attention_indexed(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
+                            const float* add_mask, float* colsum_part, float* p0, float* onorm,
+                            int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo,
+                            float scale, int io_dtype, void* stream);
 
 /* Alignment-guided token-importance score, per-sample threshold and survivor count
  * (Block.Reduce_token vit.py:125-145 == med.py:347-371 == nlvr_encoder.py:404-432 == clip/model.py:196-218).
@@ -283,10 +290,14 @@ int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden, const flo
                      float* mask_out, void* ws, size_t ws_bytes, int B, int L, int Nk, const float* token_attn, int ldt_row,
                      int ldt_batch, int K, float temperature, float* score, float* threshold, int32_t* count,
                      int64_t* indices, int64_t* indices_sort, int cross_mode, const void* enc0, const void* enc1,
-                     const float* enc_mask0, const float* enc_mask1, const void* hidden_lp, void* y_lp, int* k_out, int* k_used,
-                     void* stream);
+                     const float* enc_mask0, const float* enc_mask1, const void* hidden_lp, void* y_lp, const void* kv_pre0,
+                     const void* kv_pre1, const int32_t* kv_index, int* k_out, int* k_used, void* stream);
 /* hidden_lp (optional, bf16 mode): compute-dtype copy of `hidden` - skips the cast; y_lp (optional): receives the
- * compute-dtype copy of y, emitted by the output LayerNorm, to be passed as the next layer's hidden_lp. */
+ * compute-dtype copy of y, emitted by the output LayerNorm, to be passed as the next layer's hidden_lp.
+ * kv_pre0 / kv_pre1 (optional): a cache of this layer's cross-attention [k|v] projections ([blocks*Nk, 2*dim], compute dtype,
+ * = madtp_gemm of the encoder tokens with the layer's fused key|value weights) - the projection GEMM is skipped (enc0/enc1
+ * may then be NULL) and sample b attends to block kv_index[b] (NULL: block b).  Retrieval re-ranking projects every image
+ * once per layer instead of once per (query, candidate) pair. */
 
 #ifdef __cplusplus
 }

@@ -365,7 +365,10 @@ class _BertLayerBase(nn.Module):
         cross = mode == 'multimodal'
         enc0 = enc1 = em0 = em1 = None
         Nk = 0
-        if cross:
+        pre = self.__dict__.pop("_kv_pre", None)  # (kv cache of THIS layer, Nk, int32 index [B]) set by the encoder for this call
+        if cross and pre is not None:
+            Nk = pre[1]
+        elif cross:
             assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
             if self.variant == "nlvr":
                 Nk = encoder_hidden_states[0].shape[1]
@@ -384,7 +387,9 @@ class _BertLayerBase(nn.Module):
                                or compute_dtype() != torch.bfloat16):
             lp = None
         y, mask_out, self.last_prune, ylp = hip.bert_layer(w, hidden, mask2d, token_attn, temperature if prune else 0, cross, enc0,
-                                                           enc1, Nk, em0, em1, hidden_lp=lp[0] if lp else None)
+                                                           enc1, Nk, em0, em1, hidden_lp=lp[0] if lp else None,
+                                                           kv_pre=(pre[0], None) if (cross and pre) else (None, None),
+                                                           kv_index=pre[2] if (cross and pre) else None)
         if ylp is not None:
             y._madtp_lp = (ylp, y._version)
         if mask_out is not None:
@@ -479,7 +484,11 @@ class _BertEncoderBase(nn.Module):
         sd_txt_ft_all = None
         defer = self.txt_query_model.deferred() if space_dict is not None else None
         reduce_num = int((hidden_states.shape[-2] - 1) // self.config.num_hidden_layers)
+        cache = self.__dict__.pop("_kv_cache", None)  # EncoderKVCache for THIS call (MedBertModel.forward(encoder_kv_cache=...))
         for i, layer_module in enumerate(self.layer):
+            layer_module.__dict__.pop("_kv_pre", None)
+            if cache is not None and mode == 'multimodal':
+                layer_module._kv_pre = (cache.kv[i], cache.Nk, cache.index)
             token_attn = None
             if space_dict is not None or always_query:
                 if space_dict is None:
@@ -603,13 +612,46 @@ class MedBertModel(_BertModelBase):
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, head_mask=None, inputs_embeds=None,
                 encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None, past_key_values=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, is_decoder=False,
-                mode='multimodal', space_dict=None, temperature=0):
+                mode='multimodal', space_dict=None, temperature=0, encoder_kv_cache=None):
+        """encoder_kv_cache (extension): an EncoderKVCache - the layers' cross-attention then reads the cached [k|v]
+        projections of encoder block index[b] for sample b instead of projecting encoder_hidden_states (which may be None)."""
         emb, ext, enc_ext = self._run(input_ids, attention_mask, space_dict, temperature, encoder_embeds,
                                       encoder_hidden_states, encoder_attention_mask, mode, inputs_embeds)
+        if encoder_kv_cache is not None:
+            if self.encoder.layer_cls.variant != "med":
+                raise NotImplementedError("encoder_kv_cache is wired for the single-cross-attention (MED) layers")
+            self.encoder._kv_cache = encoder_kv_cache
         out, sd_txt_ft = self.encoder(emb, attention_mask=ext, encoder_hidden_states=encoder_hidden_states,
                                       encoder_attention_mask=enc_ext, mode=mode, space_dict=space_dict,
                                       temperature=temperature)
         return out, sd_txt_ft
+
+
+class EncoderKVCache:
+    """Cross-attention [k|v] projections of a set of encoder token blocks, one tensor [blocks*Nk, 2*hidden] per layer in the
+    compute dtype (bit-identical to what each layer would project itself), plus the block index of every sample of the next
+    forward (int32 [B], set with .select()).  At 288 GB per GPU the projections of a whole retrieval test set stay resident
+    (7 MB per 190-token image): re-ranking projects every image once instead of once per (query, candidate) pair."""
+
+    def __init__(self, kv, Nk):
+        self.kv, self.Nk, self.index = kv, Nk, None
+
+    def select(self, index):
+        self.index = index.to(torch.int32).contiguous()
+        return self
+
+    @staticmethod
+    def build(bert_model, enc):
+        """enc: [blocks, Nk, hidden] f32 GPU tensor (e.g. the padded image tokens of the evaluation set)."""
+        enc = as_f32_contig(require_gpu(enc, "enc"))
+        blocks, Nk, D = enc.shape
+        a = _cast(enc.view(blocks * Nk, D))
+        kv = []
+        for l in bert_model.encoder.layer:
+            sm = l.crossattention.self
+            lin = lin_of(sm._cache, "kv", [sm.key, sm.value])
+            kv.append(hip.gemm(a, lin.w, lin.b, n=lin.n))
+        return EncoderKVCache(kv, Nk)
 
 
 class NlvrBertModel(_BertModelBase):

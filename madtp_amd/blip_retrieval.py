@@ -17,6 +17,7 @@ from torch import nn
 from . import hip
 from .bert import BertConfig
 from .blip_nlvr import ENC_TOKEN_ID, create_vit
+from .bert import EncoderKVCache
 from .med import BertModel
 from .runtime import PreparedCache, compute_dtype, lin_of, require_gpu
 
@@ -89,11 +90,13 @@ def _tokens(model, text, device):
 
 
 @torch.no_grad()
-def evaluate(model, data_loader, device, config, temperature=0, rank=0, world_size=1, text_bs=256):
+def evaluate(model, data_loader, device, config, temperature=0, rank=0, world_size=1, text_bs=256, kv_cache=True):
     """compress_retrieval_dtp.py evaluate() :84-207 -> (score_matrix_i2t, score_matrix_t2i) as numpy arrays and the GFLOPs
     placeholder (0.0: the reference's fvcore count of the TRAINING forward is out of scope, harness.nlvr_forward_flops is
     the analytic counter of this repo).  rank / world_size select this process's row slices exactly as :158-162 / :181-183
-    do; the caller all-reduces the two matrices (SUM) when world_size > 1, as :200-203."""
+    do; the caller all-reduces the two matrices (SUM) when world_size > 1, as :200-203.
+    kv_cache: project the image tokens to every layer's cross-attention [k|v] ONCE (EncoderKVCache) and let the re-ranking
+    batches index that cache; False reproduces the reference's data flow (each pair re-projects its image)."""
     k_test = config['k_test']
     sd = model.space_dict
     texts = data_loader.dataset.text
@@ -120,6 +123,19 @@ def evaluate(model, data_loader, device, config, temperature=0, rank=0, world_si
     image_feats = torch.cat([torch.cat([f, f[:, 0:1, :].expand(-1, n - f.shape[1], -1)], 1) if f.shape[1] < n else f
                              for f in image_feats], 0)
 
+    cache = EncoderKVCache.build(model.text_encoder, image_feats) if kv_cache else None
+
+    def rerank(ids, att, img_index):
+        if cache is not None:
+            out = model.text_encoder(ids, attention_mask=att, return_dict=True, space_dict=sd, temperature=temperature,
+                                     encoder_kv_cache=cache.select(img_index))[0]
+        else:
+            enc = image_feats[img_index].contiguous()
+            enc_att = torch.ones(enc.shape[:-1], dtype=torch.long, device=device)
+            out = model.text_encoder(ids, attention_mask=att, encoder_hidden_states=enc, encoder_attention_mask=enc_att,
+                                     return_dict=True, space_dict=sd, temperature=temperature)[0]
+        return model.itm_score(out.last_hidden_state[:, 0, :])
+
     sims_matrix = image_embeds @ text_embeds.t()  # :155
     n_img = sims_matrix.shape[0]
     score_i2t = torch.full((n_img, num_text), -100.0, device=device)
@@ -127,11 +143,8 @@ def evaluate(model, data_loader, device, config, temperature=0, rank=0, world_si
     start, end = rank * step, min(n_img, rank * step + step)
     for i in range(start, end):  # :164-174
         topk_sim, topk_idx = sims_matrix[i].topk(k=k_test, dim=0)
-        enc = image_feats[i].unsqueeze(0).expand(k_test, -1, -1).contiguous()
-        enc_att = torch.ones(enc.shape[:-1], dtype=torch.long, device=device)
-        out = model.text_encoder(text_ids[topk_idx], attention_mask=text_atts[topk_idx], encoder_hidden_states=enc,
-                                 encoder_attention_mask=enc_att, return_dict=True, space_dict=sd, temperature=temperature)[0]
-        score_i2t[i, topk_idx] = model.itm_score(out.last_hidden_state[:, 0, :]) + topk_sim
+        score_i2t[i, topk_idx] = rerank(text_ids[topk_idx], text_atts[topk_idx],
+                                        torch.full((k_test,), i, dtype=torch.long, device=device)) + topk_sim
 
     sims_t = sims_matrix.t()
     score_t2i = torch.full((num_text, n_img), -100.0, device=device)
@@ -139,10 +152,5 @@ def evaluate(model, data_loader, device, config, temperature=0, rank=0, world_si
     start, end = rank * step, min(num_text, rank * step + step)
     for i in range(start, end):  # :186-198
         topk_sim, topk_idx = sims_t[i].topk(k=k_test, dim=0)
-        enc = image_feats[topk_idx].contiguous()
-        enc_att = torch.ones(enc.shape[:-1], dtype=torch.long, device=device)
-        out = model.text_encoder(text_ids[i].repeat(k_test, 1), attention_mask=text_atts[i].repeat(k_test, 1),
-                                 encoder_hidden_states=enc, encoder_attention_mask=enc_att, return_dict=True, space_dict=sd,
-                                 temperature=temperature)[0]
-        score_t2i[i, topk_idx] = model.itm_score(out.last_hidden_state[:, 0, :]) + topk_sim
+        score_t2i[i, topk_idx] = rerank(text_ids[i].repeat(k_test, 1), text_atts[i].repeat(k_test, 1), topk_idx) + topk_sim
     return score_i2t.cpu().numpy(), score_t2i.cpu().numpy(), 0.0

@@ -26,6 +26,7 @@ struct AttnArgs {
     float* colsum; float* p0; float* onorm;
     int B, H, Nq, Nk, ldq, ldk, ldv, ldo, nrt;
     float scale;
+    const int* kvidx;  // optional: sample b reads K/V block kvidx[b] (cross-attention against a cache of encoder K/V)
 };
 
 template <typename T> __device__ __forceinline__ f32x4 load4(const char* p);
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
+    const int bkv = a.kvidx ? a.kvidx[b] : b;  // K/V block of this sample
     const int rt = blockIdx.x * 4 + wave;    // 16-row query tile of this wave
     const int i0 = rt * 16;
     const bool active = i0 < a.Nq;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             const int row = idx / CPR, c = idx % CPR;
             uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
             if (row < a.Nk) {
-                const size_t grow = (size_t)b * a.Nk + row;
+                const size_t grow = (size_t)bkv * a.Nk + row;
                 kv = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * ESZ + c * 16);
                 vv = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * ESZ + c * 16);
             }
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
     char* const ring = smem + hp * 2 * STAGE;
     const int l16 = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
+    const int bkv = a.kvidx ? a.kvidx[b] : b;  // K/V block of this sample
     const int rt = blockIdx.x * 4 + wave;
     const int i0 = rt * 16;
     const bool active = i0 < a.Nq;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
         int row = (is_v ? grp - NKP / 8 : grp) * 8 + sub;
         const int chunk = is_v ? (pos ^ (((row >> 1) & 3) << 1)) : (pos ^ (row & 7));
         row = row < a.Nk ? row : a.Nk - 1;
-        srcb[i] = (is_v ? a.v + ((size_t)b * a.Nk + row) * a.ldv * 2 : a.k + ((size_t)b * a.Nk + row) * a.ldk * 2) + chunk * 16;
+        srcb[i] = (is_v ? a.v + ((size_t)bkv * a.Nk + row) * a.ldv * 2 : a.k + ((size_t)bkv * a.Nk + row) * a.ldk * 2) + chunk * 16;
     }
     auto stage_head = [&](int h, int st) {
         char* base = ring + st * STAGE;
@@ -673,6 +676,7 @@ __global__ __launch_bounds__(256, 1) void attn_large_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
+    const int bkv = a.kvidx ? a.kvidx[b] : b;  // K/V block of this sample
     const int rt = blockIdx.x * 4 + wave;
     const int i0 = rt * 16;
     const bool active = i0 < a.Nq;
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(256, 1) void attn_large_kernel(AttnArgs a) {
             const int row = idx / CPR, ch = idx % CPR, j = c * CK + row;
             uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
             if (j < a.Nk) {
-                const size_t grow = (size_t)b * a.Nk + j;
+                const size_t grow = (size_t)bkv * a.Nk + j;
                 kv = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * ESZ + ch * 16);
                 if (with_v) vv = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * ESZ + ch * 16);
             }
@@ -907,7 +911,16 @@ int dispatch_nt(const AttnArgs& a, hipStream_t s) {
 extern "C" int madtp_attention(const void* q, const void* k, const void* v, void* out, const float* add_mask,
                                float* colsum_part, float* p0, float* onorm, int B, int H, int Nq, int Nk, int ldq,
                                int ldk, int ldv, int ldo, float scale, int io_dtype, void* stream) {
+    return madtp_attention_indexed(q, k, v, nullptr, out, add_mask, colsum_part, p0, onorm, B, H, Nq, Nk, ldq, ldk, ldv, ldo,
+                                   scale, io_dtype, stream);
+}
+
+extern "C" int madtp_attention_indexed(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
+                                       const float* add_mask, float* colsum_part, float* p0, float* onorm, int B, int H,
+                                       int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale, int io_dtype,
+                                       void* stream) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
+    if (kv_batch_index && colsum_part) return MADTP_E_BADARG;  // indexed K/V is a cross-attention feature
     if (io_dtype != MADTP_F32 && io_dtype != MADTP_BF16) return MADTP_E_DTYPE;
     if (colsum_part && (!p0 || !onorm || Nq != Nk)) return MADTP_E_BADARG;
     const int esz = io_dtype == MADTP_BF16 ? 2 : 4;
@@ -920,6 +933,7 @@ extern "C" int madtp_attention(const void* q, const void* k, const void* v, void
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.nrt = (Nq + 15) / 16;
     a.scale = scale;
+    a.kvidx = kv_batch_index;
     hipStream_t s = (hipStream_t)stream;
     const bool scores = colsum_part != nullptr;
     if (Nk > 256) {  // long sequences (384^2 / 480^2 images): two-pass kernel, exact-f32 MFMA in both modes

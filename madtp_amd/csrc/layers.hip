@@ -325,7 +325,8 @@ extern "C" int madtp_bert_layer_attn(const madtp_bert_layer_w* w, const float* h
 static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const float* mask2d, float* y, float* mask_out, void* ws,
                           size_t ws_bytes, int B, int L, int k, const float* score, int64_t* indices, int64_t* indices_sort,
                           int cross_mode, const void* enc0, const void* enc1, int Nk, const float* enc_mask0,
-                          const float* enc_mask1, bool att_lp_ready, void* y_lp, void* stream) {
+                          const float* enc_mask1, bool att_lp_ready, void* y_lp, const void* kv_pre0, const void* kv_pre1,
+                          const int32_t* kv_index, void* stream) {
     if (!w || !att || !y || !ws || B <= 0 || L <= 0 || k < 0) return MADTP_E_BADARG;
     bool ok;
     BertWs s = bert_carve((char*)ws, ws_bytes, B, L, Nk, w->dim, w->inter.n, w->heads, w->dtype, &ok);
@@ -356,9 +357,8 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
         ac = s.attc;
     }
     if (cross_mode && w->cross) {
-        if (!enc0 || Nk <= 0) return MADTP_E_BADARG;
         const int nbr = w->cross == 2 ? 2 : 1;
-        if (nbr == 2 && !enc1) return MADTP_E_BADARG;
+        if (Nk <= 0 || (!enc0 && !kv_pre0) || (nbr == 2 && !enc1 && !kv_pre1)) return MADTP_E_BADARG;
         if (nbr == 2 && w->fused_twin) {
             // twin branches with fused projections: one q GEMM ([q0|q1], N = 2D), the two context tensors written
             // side by side ([c0|c1], ld 2D) and ONE output GEMM over K = 2D (dense0|dense1, merge_layer folded in)
@@ -366,11 +366,16 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
             for (int br = 0; br < 2; ++br) {
                 const void* enc = br ? enc1 : enc0;
                 const float* em = w->variant_nlvr ? (br ? enc_mask1 : enc_mask0) : nullptr;
-                TRY(lin(enc, D, w->ckv[br], nullptr, 0, s.kv, 2 * D, B * Nk, dt, dt, MADTP_ACT_NONE, 1.f, stream));
-                const char* kv = (const char*)s.kv;
-                TRY(madtp_attention((const char*)s.q2 + (size_t)br * D * e, kv, kv + (size_t)D * e,
-                                    (char*)s.cat + (size_t)br * D * e, em, nullptr, nullptr, nullptr, B, w->heads, Lp, Nk,
-                                    2 * D, 2 * D, 2 * D, 2 * D, w->scale, dt, stream));
+                // [k|v] = enc @ [Wk|Wv]^T: done here, or read from the caller's cache of projected encoder blocks
+                const char* kv = (const char*)(br ? kv_pre1 : kv_pre0);
+                if (!kv) {
+                    TRY(lin(enc, D, w->ckv[br], nullptr, 0, s.kv, 2 * D, B * Nk, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+                    kv = (const char*)s.kv;
+                }
+                TRY(madtp_attention_indexed((const char*)s.q2 + (size_t)br * D * e, kv, kv + (size_t)D * e,
+                                            (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, (char*)s.cat + (size_t)br * D * e, em,
+                                            nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, 2 * D, 2 * D, 2 * D, 2 * D, w->scale,
+                                            dt, stream));
             }
             TRY(lin_ln(s.cat, 2 * D, w->cdense_fused, a32, w->fused_twin == 2 ? 1.f : 0.5f, w->ln_cross_g, w->ln_cross_b, s.att2,
                        dt == MADTP_BF16 ? s.attc : nullptr, M, dt, w->eps, s.part, stream));
@@ -384,10 +389,13 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
             // med.py:197-199 drops the encoder mask in cross-attention; nlvr_encoder.py:196-198 applies it
             const float* em = w->variant_nlvr ? (br ? enc_mask1 : enc_mask0) : nullptr;
             TRY(lin(ac, D, w->cq[br], nullptr, 0, s.q, D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
-            TRY(lin(enc, D, w->ckv[br], nullptr, 0, s.kv, 2 * D, B * Nk, dt, dt, MADTP_ACT_NONE, 1.f, stream));
-            const char* kv = (const char*)s.kv;
-            TRY(madtp_attention(s.q, kv, kv + (size_t)D * e, cbuf[br], em, nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, D,
-                                2 * D, 2 * D, D, w->scale, dt, stream));
+            const char* kv = (const char*)(br ? kv_pre1 : kv_pre0);
+            if (!kv) {
+                TRY(lin(enc, D, w->ckv[br], nullptr, 0, s.kv, 2 * D, B * Nk, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+                kv = (const char*)s.kv;
+            }
+            TRY(madtp_attention_indexed(s.q, kv, kv + (size_t)D * e, (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, cbuf[br], em,
+                                        nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, D, 2 * D, 2 * D, D, w->scale, dt, stream));
         }
         if (nbr == 2) {
             if (w->has_merge) {  // nlvr_encoder.py:263-264
@@ -419,7 +427,7 @@ extern "C" int madtp_bert_layer_rest(const madtp_bert_layer_w* w, const float* a
                                      int64_t* indices, int64_t* indices_sort, int cross_mode, const void* enc0,
                                      const void* enc1, int Nk, const float* enc_mask0, const float* enc_mask1, void* stream) {
     return bert_rest_impl(w, att, mask2d, y, mask_out, ws, ws_bytes, B, L, k, score, indices, indices_sort, cross_mode, enc0, enc1,
-                          Nk, enc_mask0, enc_mask1, false, nullptr, stream);
+                          Nk, enc_mask0, enc_mask1, false, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 // Whole BertLayer.forward in one call (med.py:393-467 / nlvr_encoder.py:484-559): self-attention half, host read of
@@ -430,7 +438,8 @@ extern "C" int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden
                                 int ldt_row, int ldt_batch, int K, float temperature, float* score, float* threshold,
                                 int32_t* count, int64_t* indices, int64_t* indices_sort, int cross_mode, const void* enc0,
                                 const void* enc1, const float* enc_mask0, const float* enc_mask1, const void* hidden_lp,
-                                void* y_lp, int* k_out, int* k_used, void* stream) {
+                                void* y_lp, const void* kv_pre0, const void* kv_pre1, const int32_t* kv_index, int* k_out,
+                                int* k_used, void* stream) {
     if (!k_out || !k_used) return MADTP_E_BADARG;
     *k_out = 0; *k_used = 0;
     int32_t k = 0;
@@ -441,5 +450,5 @@ extern "C" int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden
         if (!(k < 1 || (L - 1 - k) <= 1)) *k_used = k;
     }
     return bert_rest_impl(w, att, mask2d, y, mask_out, ws, ws_bytes, B, L, *k_used, score, indices, indices_sort, cross_mode, enc0,
-                          enc1, Nk, enc_mask0, enc_mask1, true, y_lp, stream);
+                          enc1, Nk, enc_mask0, enc_mask1, true, y_lp, kv_pre0, kv_pre1, kv_index, stream);
 }

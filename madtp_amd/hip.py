@@ -12,7 +12,7 @@ import torch
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -60,10 +60,11 @@ _SIGS = {
     "madtp_token_score_publish": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float]
                                   + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p, c_void_p]),
     "madtp_token_score_wait": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "madtp_attention_indexed": (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_float, c_int, c_void_p]),
     "madtp_vit_block": (c_int, [c_void_p] * 5 + [c_size_t, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
                         + [c_void_p] * 7 + [c_void_p]),
     "madtp_bert_layer": (c_int, [c_void_p] * 7 + [c_size_t, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
-                         + [c_void_p] * 5 + [c_int] + [c_void_p] * 8 + [c_void_p]),
+                         + [c_void_p] * 5 + [c_int] + [c_void_p] * 11 + [c_void_p]),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
     "madtp_query_att_ft_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -447,7 +448,7 @@ def vit_block(wstruct, x, token_attn, temperature):
 
 
 def bert_layer(wstruct, hidden, mask2d, token_attn, temperature, cross_mode, enc0, enc1, Nk, enc_mask0, enc_mask1,
-               hidden_lp=None):
+               hidden_lp=None, kv_pre=(None, None), kv_index=None):
     """BertLayer.forward in ONE library call.  -> (y [B,L',D], mask_out [B,L'] or None, info or None, y_lp).
     hidden_lp / y_lp: bf16 copies of the layer input / output (fast mode; the LayerNorms emit them, saving the casts)."""
     B, L, D = hidden.shape
@@ -468,8 +469,8 @@ def bert_layer(wstruct, hidden, mask2d, token_attn, temperature, cross_mode, enc
         _check(lib.madtp_bert_layer(ctypes.byref(wstruct), _p(hidden), _p(mask2d), _p(att), _p(ybuf), _p(mbuf), _p(ws), ws.numel(),
                                     B, L, Nk, tp, ldr, ldb, K, float(temperature), _p(score), _p(thr), _p(count), _p(idx),
                                     _p(idx_sort), int(cross_mode), _p(enc0), _p(enc1), _p(enc_mask0), _p(enc_mask1),
-                                    _p(hidden_lp), _p(ylp), ctypes.byref(k_out), ctypes.byref(k_used), _stream()),
-               "madtp_bert_layer")
+                                    _p(hidden_lp), _p(ylp), _p(kv_pre[0]), _p(kv_pre[1]), _p(kv_index), ctypes.byref(k_out),
+                                    ctypes.byref(k_used), _stream()), "madtp_bert_layer")
         info = {"k": k_out.value, "score": score, "threshold": thr, "count": count, "pruned": False, "indices": None,
                 "indices_sort": None}
         if k_used.value > 0:
@@ -480,7 +481,8 @@ def bert_layer(wstruct, hidden, mask2d, token_attn, temperature, cross_mode, enc
         return ybuf, None, info, ylp
     _check(lib.madtp_bert_layer(ctypes.byref(wstruct), _p(hidden), _p(mask2d), _p(att), _p(ybuf), 0, _p(ws), ws.numel(), B, L, Nk,
                                 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, int(cross_mode), _p(enc0), _p(enc1), _p(enc_mask0), _p(enc_mask1),
-                                _p(hidden_lp), _p(ylp), ctypes.byref(k_out), ctypes.byref(k_used), _stream()), "madtp_bert_layer")
+                                _p(hidden_lp), _p(ylp), _p(kv_pre[0]), _p(kv_pre[1]), _p(kv_index), ctypes.byref(k_out),
+                                ctypes.byref(k_used), _stream()), "madtp_bert_layer")
     return ybuf, None, None, ylp
 
 

@@ -288,6 +288,12 @@ def test_retrieval_itm_reranking_matches_reference_fixture(path):
         merged = np.where(parts[0][k] != -100.0, parts[0][k], parts[1][k])
         assert np.array_equal(merged, full)
         assert not ((parts[0][k] != -100.0) & (parts[1][k] != -100.0)).any()
+    # the K/V cache (images projected once per layer, attention indexes the cache) changes no bit of the scores
+    with runtime.precision("fp32"):
+        n_i2t, n_t2i, _ = br.evaluate(model, loader, torch.device("cuda"), cfg, T, kv_cache=False)
+    assert np.array_equal(n_i2t, i2t) and np.array_equal(n_t2i, t2i)
     with runtime.precision("bf16"):
         b_i2t, b_t2i, _ = br.evaluate(model, loader, torch.device("cuda"), cfg, T)
+        c_i2t, c_t2i, _ = br.evaluate(model, loader, torch.device("cuda"), cfg, T, kv_cache=False)
     assert np.isfinite(b_i2t).all() and np.isfinite(b_t2i).all()
+    assert np.array_equal(b_i2t, c_i2t) and np.array_equal(b_t2i, c_t2i)
