@@ -618,14 +618,19 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     // resident workgroup): what counts is spreading the operand bytes over ALL CUs in one round, so they take the
     // smallest tile whose grid still fits one round of 3 workgroups per CU (measured: 64x64 beats 128x128 by 20-45 % on
     // M=1280, N<=2304; 64x128 wins for N=3072).
+    // The wave-specialised 256x128 kernel takes a problem once its tiles fill most of the chip (>= 200 of 256 CUs) - e.g. not
+    // the 4480 x 768 GEMMs of a 128-pair re-ranking batch (108 tiles), which run better on 420 64x128 tiles.
     int cfg = 0;
-    if (ab_dtype == MADTP_BF16 && M < 4096) {
+    const int t256 = ((M + 255) / 256) * ((N + 127) / 128);
+    const bool big = M >= 4096 && t256 >= 200;
+    if (ab_dtype == MADTP_BF16 && !big) {
         const int t64 = ((M + 63) / 64) * ((N + 63) / 64) * splitk, t64x128 = ((M + 63) / 64) * ((N + 127) / 128) * splitk;
         if (t64 <= 768) cfg = 3;
         else if (t64x128 <= 768) cfg = 1;
     }
     // MADTP_GEMM_CFG=5 forces the wave-specialised kernel, 1..4 force a gemm_kernel variant (A/B measurements)
-    const bool ws_ok = ab_dtype == MADTP_BF16 && splitk == 1 && (force_cfg == 5 || (force_cfg == 0 && M >= 4096));
+    const bool ws_ok = ab_dtype == MADTP_BF16 && splitk == 1 &&
+                       (force_cfg == 5 || (force_cfg == 0 && M >= 4096 && (big || cfg == 0)));
     if (force_cfg > 0 && force_cfg <= 4) cfg = force_cfg - 1;
     hipStream_t s = (hipStream_t)stream;
     const bool lp = c_dtype == MADTP_BF16;
