@@ -175,3 +175,18 @@ def test_retrieval_mirror_state_dict_keys():
     mine = set(BLIP_Retrieval(image_size=224, evaluate=True).state_dict().keys())
     assert ref_keys <= mine, sorted(ref_keys - mine)[:5]
     assert all("query_model" in k for k in mine - ref_keys), sorted(mine - ref_keys)[:5]
+
+
+def test_controller_matches_reference_rule_and_constant():
+    """temperature step rule (compress_nlvr_dtp.py:175-200) and the analytic GFLOPs counter pinned on
+    the reference's own unpruned figure Ori_Gflops = 132.54 (:162, fvcore)."""
+    from madtp_amd import controller as C
+    for cur, step in ((200.0, 1.0), (80.0, 0.5), (73.0, 0.25), (68.0, 0.1), (66.5, 0.01)):
+        assert abs(C.step_temperature(3.0, cur, 66.27) - (3.0 + step)) < 1e-12
+        assert abs(C.step_temperature(3.0, 2 * 66.27 - cur, 66.27) - (3.0 - step)) < 1e-12
+    assert abs(C.step_temperature(3.0, 66.27, 66.27) - 2.99) < 1e-12          # not greater -> the `else` branch, smallest step
+    full = C.nlvr_gflops([577] * 12, [20] * 12, 384, 20)
+    assert abs(full - C.ORI_GFLOPS["nlvr"]) / C.ORI_GFLOPS["nlvr"] < 5e-3, full
+    # a toy plant: GFLOPs fall with T; the controller settles within one small step of the target
+    log = C.run_controller(lambda T: 132.54 / (1.0 + 0.2 * T), 0.0, 0.5, 132.54, 60)
+    assert abs(log[-1][2] - 66.27) < 1.5
