@@ -89,6 +89,20 @@ def _tokens(model, text, device):
     return ids.to(device), att.to(device)
 
 
+def all_reduce_scores(score_i2t, score_t2i):
+    """compress_retrieval_dtp.py:200-203: SUM all-reduce of the two score matrices over the ranks (every rank filled only the
+    rows of its slice, the rest is -100), so all entries re-ranked by some rank end up shifted by the same -100*(world-1)
+    and the rankings of itm_eval() are those of a single-rank run.  numpy in, numpy out; no-op without a process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return score_i2t, score_t2i
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    a, b = torch.from_numpy(score_i2t.copy()).to(dev), torch.from_numpy(score_t2i.copy()).to(dev)
+    dist.all_reduce(a, op=dist.ReduceOp.SUM)
+    dist.all_reduce(b, op=dist.ReduceOp.SUM)
+    return a.cpu().numpy(), b.cpu().numpy()
+
+
 @torch.no_grad()
 def evaluate(model, data_loader, device, config, temperature=0, rank=0, world_size=1, text_bs=256, kv_cache=True):
     """compress_retrieval_dtp.py evaluate() :84-207 -> (score_matrix_i2t, score_matrix_t2i) as numpy arrays and the GFLOPs

@@ -81,3 +81,45 @@ def test_world2_gloo_sharded_forward_matches_per_shard_oracle(tmp_path):
         with torch.no_grad():
             ref = O.blip_nlvr_forward(W, img, ids[lo:hi], torch.ones_like(ids[lo:hi]), 6.0)
         assert (ref - res[r]["logits"]).abs().max().item() < 1e-5
+
+
+def _retrieval_worker(rank, world, port, out_dir):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from madtp_amd import blip_retrieval as br, harness, specs
+    from oracle import madtp_oracle as O
+    mdist.init("gloo")
+    W = specs.synth_weights(specs.blip_retrieval_shapes(224), 0)
+    batches, ids, att = harness.retrieval_inputs(3, 2, 4, 224, 35, 0)
+    with torch.no_grad():
+        i2t, t2i = O.retrieval_evaluate(W, batches, ids, att, 6.0, 2, rank=rank, world=world)
+    a, b = br.all_reduce_scores(i2t.numpy(), t2i.numpy())
+    torch.save({"i2t": i2t, "t2i": t2i, "sum_i2t": a, "sum_t2i": b}, os.path.join(out_dir, f"retr{rank}.pt"))
+    mdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_retrieval_rank_slices_and_all_reduce(tmp_path):
+    """SURVEY 8f rank 1, multi-GPU: queries shard by rank (compress_retrieval_dtp.py:158-162, 181-183), one SUM all-reduce
+    of the score matrices (:200-203).  world_size-2 gloo with the CPU oracle as the scorer: the slices are disjoint, cover
+    all queries, and the reduced matrices rank candidates exactly like the single-rank evaluation."""
+    import numpy as np
+    from madtp_amd import harness, specs
+    from oracle import madtp_oracle as O
+    world = 2
+    mp.spawn(_retrieval_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), f"retr{r}.pt"), weights_only=False) for r in range(world)]
+    W = specs.synth_weights(specs.blip_retrieval_shapes(224), 0)
+    batches, ids, att = harness.retrieval_inputs(3, 2, 4, 224, 35, 0)
+    torch.set_num_threads(4)
+    with torch.no_grad():
+        full_i2t, full_t2i = O.retrieval_evaluate(W, batches, ids, att, 6.0, 2)
+    for key, full in (("i2t", full_i2t.numpy()), ("t2i", full_t2i.numpy())):
+        own = [(o[key].numpy() != -100.0) for o in outs]
+        assert not (own[0] & own[1]).any() and np.array_equal(own[0] | own[1], full != -100.0)
+        red = outs[0]["sum_" + key]
+        assert np.array_equal(red, outs[1]["sum_" + key])
+        done = full != -100.0
+        assert np.allclose(red[done], full[done] - 100.0 * (world - 1), atol=1e-4)   # uniform shift: same ranking
+        assert (red[~done] == -100.0 * world).all()
