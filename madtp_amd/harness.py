@@ -17,10 +17,20 @@ def build_nlvr(image_size=224, seed=0, device="cuda"):
     return model.eval().to(device)
 
 
-def nlvr_inputs(B, image_size=224, L=20, seed=0, device="cuda"):
+def padded_mask(B, L, pad_tail=0):
+    """attention_mask [B,L] of ones with a zero tail of b % (pad_tail+1) tokens in sample b (padded captions)."""
+    att = torch.ones(B, L, dtype=torch.long)
+    if pad_tail:
+        for b in range(B):
+            att[b, L - (b % (pad_tail + 1)):] = 0
+    return att
+
+
+def nlvr_inputs(B, image_size=224, L=20, seed=0, device="cuda", pad_tail=0):
     images = synth.synth_images(2 * B, image_size, seed).to(device)
     ids = synth.synth_token_ids(B, L, seed).to(device)
-    return images, {"input_ids": ids, "attention_mask": torch.ones_like(ids)}, torch.zeros(B, dtype=torch.long, device=device)
+    return images, {"input_ids": ids, "attention_mask": padded_mask(B, L, pad_tail).to(device)}, \
+        torch.zeros(B, dtype=torch.long, device=device)
 
 
 def build_retrieval(image_size=224, seed=0, device="cuda"):

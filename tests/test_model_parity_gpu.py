@@ -41,7 +41,7 @@ def test_fp32_mode_matches_reference_fixture(env, path):
     harness, runtime, model = env
     g = np.load(path)
     B, size, L, T, seed = int(g["B"]), int(g["size"]), int(g["L"]), float(g["temperature"]), int(g["seed"])
-    images, text, targets = harness.nlvr_inputs(B, size, L, seed)
+    images, text, targets = harness.nlvr_inputs(B, size, L, seed, pad_tail=int(g["pad_tail"]) if "pad_tail" in g.files else 0)
     with runtime.precision("fp32"):
         logits, trace = harness.run_nlvr(model, images, text, targets, T)
     assert harness.token_lengths(trace["vit"], 197) == g["vit_lens"].tolist()

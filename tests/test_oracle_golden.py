@@ -35,9 +35,11 @@ def test_oracle_matches_reference_fixture(path):
     W = specs.synth_weights(shapes, seed)
     images = synth.synth_images(2 * B, size, seed)
     ids = synth.synth_token_ids(B, L, seed)
+    from madtp_amd import harness
+    att = harness.padded_mask(B, L, int(g["pad_tail"]) if "pad_tail" in g.files else 0)  # padded captions: mask compaction
     trace = {}
     with torch.no_grad():
-        logits = O.blip_nlvr_forward(W, images, ids, torch.ones_like(ids), T, trace=trace)
+        logits = O.blip_nlvr_forward(W, images, ids, att, T, trace=trace)
     # same torch ops on the same box => exact; 1e-5 leaves room for a different CPU/BLAS on the GPU box's host
     assert np.abs(logits.numpy() - g["logits"]).max() < 1e-5
     assert np.abs(trace["image_embeds"][:, 0, :16].numpy() - g["img_embeds_cls"]).max() < 1e-4

@@ -58,7 +58,7 @@ class GatherTap:
         self.module.vector_gather = self.orig
 
 
-def nlvr_case(name, B, size, L, temperature, seed=0):
+def nlvr_case(name, B, size, L, temperature, seed=0, pad_tail=0):
     import models.blip_nlvr as bn
     import models.vit as rvit
     import models.nlvr_encoder as rnl
@@ -69,7 +69,8 @@ def nlvr_case(name, B, size, L, temperature, seed=0):
     missing = model.load_state_dict(sd, strict=True)
     images = synth.synth_images(2 * B, size, seed)
     ids = synth.synth_token_ids(B, L, seed, first_id=None)
-    text = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+    from madtp_amd import harness
+    text = {"input_ids": ids, "attention_mask": harness.padded_mask(B, L, pad_tail)}
     tap_v, tap_t = GatherTap(rvit), GatherTap(rnl)
     hooks = []
     lens_v, lens_t = [], []
@@ -89,7 +90,7 @@ def nlvr_case(name, B, size, L, temperature, seed=0):
         h.remove()
     tap_v.restore()
     tap_t.restore()
-    out = {"kind": "nlvr", "B": B, "size": size, "L": L, "temperature": np.float64(temperature), "seed": seed,
+    out = {"kind": "nlvr", "B": B, "size": size, "L": L, "temperature": np.float64(temperature), "seed": seed, "pad_tail": pad_tail,
            "logits": logits.numpy(), "vit_lens": np.array(lens_v), "txt_lens": np.array(lens_t),
            "img_embeds_cls": feats["img"][:, 0, :16].numpy(), "img_embeds_absmean": feats["img"].abs().mean().numpy(),
            "state_dict_keys": np.array(sorted(sd.keys())), "ref_seconds": dt, "threads": torch.get_num_threads()}
@@ -247,6 +248,7 @@ def retrieval_case(name, n_img, img_bs, n_txt, size, temperature, k_test, seed=0
 CASES = {
     "nlvr_b2_T1": lambda: nlvr_case("nlvr_b2_T1", 2, 224, 20, 1.0),
     "nlvr_b2_T5": lambda: nlvr_case("nlvr_b2_T5", 2, 224, 20, 5.0),
+    "nlvr_b3_T30_pad": lambda: nlvr_case("nlvr_b3_T30_pad", 3, 224, 35, 30.0, pad_tail=3),
     "med_text_b3": lambda: med_case("med_text_b3", 3, 35, 0, 30.0, "text", pad_tail=3),
     "med_mm_b3": lambda: med_case("med_mm_b3", 3, 35, 50, 30.0, "multimodal", pad_tail=3),
     "clip_vit_b2": lambda: clip_case("clip_vit_b2", 2, 4.0),
