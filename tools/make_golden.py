@@ -255,6 +255,7 @@ CASES = {
     "vit384_b2": lambda: vit_case("vit384_b2", 2, 384, 6.0),
     "vit480_b1": lambda: vit_case("vit480_b1", 1, 480, 6.0),
     "retr_i6_t12": lambda: retrieval_case("retr_i6_t12", 6, 3, 12, 224, 6.0, 4),
+    "retr_384_i4_t6": lambda: retrieval_case("retr_384_i4_t6", 4, 2, 6, 384, 4.0, 3, seed=1),
 }
 
 if __name__ == "__main__":
