@@ -129,8 +129,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                 sc[t][r] = v;
                 m = fmaxf(m, v);
             }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = rows4_max(m);
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -140,8 +139,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                 sc[t][r] = p;
                 sum += p;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows4_sum(sum);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -350,8 +348,7 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
                 sc[t][r] = v;
                 m = fmaxf(m, v);
             }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = rows4_max(m);
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -361,8 +358,7 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
                 sc[t][r] = p;
                 sum += p;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows4_sum(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -417,8 +413,7 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
 #pragma unroll
                 for (int r = 0; r < 4; ++r) n2 += o[dt][r] * o[dt][r];
             if constexpr (SCORES) {
-                n2 += __shfl_xor(n2, 16, 64);
-                n2 += __shfl_xor(n2, 32, 64);
+                n2 = rows4_sum(n2);
             }
             if (i < a.Nq) {
                 bf16_t* orow = (bf16_t*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 2) + 4 * g;
@@ -540,15 +535,13 @@ __global__ __launch_bounds__(64 * SMALL_NW, 1) void attn_bf16_small_kernel(AttnA
                 }
                 sc[t] = acc;
             }
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            m = rows4_max(m);
             float sum = 0.f;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { sc[t][r] = __expf(sc[t][r] - m); sum += sc[t][r]; }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            sum = rows4_sum(sum);
             const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -581,8 +574,7 @@ __global__ __launch_bounds__(64 * SMALL_NW, 1) void attn_bf16_small_kernel(AttnA
 #pragma unroll
                 for (int r = 0; r < 4; ++r) n2 += o[dt][r] * o[dt][r];
             }
-            n2 += __shfl_xor(n2, 16, 64);
-            n2 += __shfl_xor(n2, 32, 64);
+            n2 = rows4_sum(n2);
             const int i = i0 + l16;
             if (i < N) {
                 bf16_t* orow = (bf16_t*)(a.out + (((size_t)b * N + i) * a.ldo + h * 64) * 2) + 4 * g;
@@ -748,16 +740,14 @@ __global__ __launch_bounds__(256, 1) void attn_large_kernel(AttnArgs a) {
             for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cm = fmaxf(cm, sc[t][r]);
-            cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
-            cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+            cm = rows4_max(cm);
             const float mn = fmaxf(m, cm);  // chunk 0 always holds key 0, so mn is finite
             float cs = 0.f;
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cs += expf(sc[t][r] - mn);
-            cs += __shfl_xor(cs, 16, 64);
-            cs += __shfl_xor(cs, 32, 64);
+            cs = rows4_sum(cs);
             l = l * expf(m - mn) + cs;
             m = mn;
         }

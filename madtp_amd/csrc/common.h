@@ -57,20 +57,67 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
 
-// butterfly reductions over the 64-lane wave
+// Exchanges between the 16-lane rows of a wave on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap) instead of
+// ds_bpermute: no LDS-pipe round trip and no lgkmcnt wait.  xor16_pair / xor32_pair return (a, b) with {a, b} =
+// {v[lane], v[lane ^ 16 (32)]} in some order - enough for the commutative reductions below, whose results are bit-identical
+// to the __shfl_xor butterflies they replace.
+__device__ __forceinline__ void xor16_pair(float v, float& a, float& b) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void xor32_pair(float v, float& a, float& b) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+// reductions over the 4 lanes l, l^16, l^32, l^48 (the four row groups of an MFMA 16x16 tile), xor-16 step first
+__device__ __forceinline__ float rows4_max(float v) {
+    float a, b;
+    xor16_pair(v, a, b);
+    v = fmaxf(a, b);
+    xor32_pair(v, a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows4_sum(float v) {
+    float a, b;
+    xor16_pair(v, a, b);
+    v = a + b;
+    xor32_pair(v, a, b);
+    return a + b;
+}
+
+// butterfly reductions over the 64-lane wave (xor 32 and 16 on the swaps above, the rest through ds_bpermute)
 __device__ __forceinline__ float wave_sum(float v) {
+    float a, b;
+    xor32_pair(v, a, b);
+    v = a + b;
+    xor16_pair(v, a, b);
+    v = a + b;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
+    float a, b;
+    xor32_pair(v, a, b);
+    v = fmaxf(a, b);
+    xor16_pair(v, a, b);
+    v = fmaxf(a, b);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 __device__ __forceinline__ float wave_min(float v) {
+    float a, b;
+    xor32_pair(v, a, b);
+    v = fminf(a, b);
+    xor16_pair(v, a, b);
+    v = fminf(a, b);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    for (int o = 8; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
     return v;
 }
 // reduce across the 16 lanes that share lane>>4 (an MFMA 16x16 column group)
