@@ -115,58 +115,99 @@ __device__ __forceinline__ int wfrag_row(int j, int rho) {
     return LP_OUT ? 32 * (j >> 1) + 8 * (rho >> 2) + 4 * (j & 1) + (rho & 3) : 16 * j + rho;
 }
 
-template <bool LP_OUT, int ACT, int FM, int FN, int BM, int BN, int RM, int RN>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// HAS_RES: the residual is read by the epilogue itself (kernels that do not prefetch it into `res`); compile-time so
+// that the fast path below is straight-line code.
+template <bool LP_OUT, int ACT, bool HAS_RES, int FM, int FN, int BM, int BN, int RM, int RN>
 __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[FM][FN], const f32x4 (&res)[RM][RN],
                                          int m0, int n0, int wr, int wc, int l16, int grp4, size_t c_off) {
     const bool c_bf16 = g.ldc < 0;
     const int ldc = c_bf16 ? -g.ldc : g.ldc;
             const int col_w = n0 + wc * (BN / 2);
             if (g.fast_epi) {
-                if constexpr (LP_OUT) {
+                // The fast path is STRAIGHT-LINE code with every load (bias, residual) issued before the first store.
+                // gfx950 counts loads and stores in one in-order vmcnt and the compiler's s_waitcnt insertion is
+                // conservative at control-flow merges: with the old per-vector `if (row < M) { load residual; store }`
+                // every store was followed by an s_waitcnt vmcnt(0), i.e. one L2 write round trip per output vector
+                // (~3 us per 256x128 tile, a fifth of the big GEMMs).  So: loads first, one wait, then fire-and-forget
+                // stores, and the row / column bounds are enforced by the buffer descriptor (out-of-range offsets are
+                // dropped by the hardware) instead of by branches.
+                constexpr int NJ = LP_OUT ? FN / 2 : FN;  // column vectors per lane: 8 (bf16 out) or 4 (f32 out) columns each
+                constexpr int NV = LP_OUT ? 2 : 1;        // float4s per column vector
+                constexpr int CSZ = LP_OUT ? 2 : 4;
+                constexpr bool RES_PREF = !LP_OUT && RM == FM;
+                const int row_t = m0 + wr * (BM / 2);  // first row of this wave's 64-row (BM/2) block: wave-uniform
+                const int rows_valid = max(min(g.M - row_t, BM / 2), 0);
+                const unsigned long long cb = (unsigned long long)((char*)g.C + (c_off + (size_t)row_t * ldc) * CSZ);
+                const unsigned cb_lo = __builtin_amdgcn_readfirstlane((unsigned)cb);  // pin the descriptor in SGPRs
+                const unsigned cb_hi = __builtin_amdgcn_readfirstlane((unsigned)(cb >> 32));
+                const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(((unsigned long long)cb_hi << 32) | cb_lo), 0,
+                    __builtin_amdgcn_readfirstlane(rows_valid * ldc * CSZ), 0x00020000);
+                int colv[NJ];
+                bool cok[NJ];
+                f32x4 bv[NJ][NV];
 #pragma unroll
-                    for (int jp = 0; jp < FN / 2; ++jp) {
-                        const int col = col_w + 32 * jp + 8 * grp4;
-                        if (col >= g.N) continue;
-                        f32x4 b0 = (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = b0;
-                        if (g.bias) { b0 = *(const f32x4*)(g.bias + col); b1 = *(const f32x4*)(g.bias + col + 4); }
+                for (int jv = 0; jv < NJ; ++jv) {
+                    colv[jv] = col_w + (LP_OUT ? 32 * jv + 8 * grp4 : 16 * jv + 4 * grp4);
+                    cok[jv] = colv[jv] < g.N;
 #pragma unroll
-                        for (int i = 0; i < FM; ++i) {
-                            const int row = m0 + wr * (BM / 2) + i * 16 + l16;
-                            if (row >= g.M) continue;
-                            f32x4 v0 = acc[i][2 * jp] + b0, v1 = acc[i][2 * jp + 1] + b1;
+                    for (int u = 0; u < NV; ++u) bv[jv][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                if (g.bias) {  // uniform; the unconditional wait below closes this diamond
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v0[e] = epi_act<true, ACT>(v0[e]) * g.out_scale;
-                                v1[e] = epi_act<true, ACT>(v1[e]) * g.out_scale;
+                    for (int jv = 0; jv < NJ; ++jv)
+#pragma unroll
+                        for (int u = 0; u < NV; ++u) bv[jv][u] = *(const f32x4*)(g.bias + (cok[jv] ? colv[jv] : 0) + 4 * u);
+                }
+                // Residual of the f32-output tiles (HAS_RES):
+                //   RES_PREF: the kernel prefetched all FM fragment rows into `res` two slabs before the epilogue;
+                //   RES_LOAD: (12-wave kernel, 168 VGPRs) the epilogue fetches IC = FM/2 fragment rows at a time: loads, ONE
+                //             full wait, then that chunk's stores - two exposed round trips per tile instead of one per vector.
+                constexpr bool RES_LOAD = HAS_RES && !RES_PREF;
+                constexpr int IC = RES_LOAD ? (FM > 2 ? FM / 2 : FM) : FM;
+                f32x4 rv[RES_LOAD ? IC : 1][RES_LOAD ? NJ : 1][NV];
+#pragma unroll
+                for (int i0 = 0; i0 < FM; i0 += IC) {
+                    if constexpr (RES_LOAD) {
+#pragma unroll
+                        for (int ii = 0; ii < IC; ++ii) {
+                            const int row = min(row_t + l16 + 16 * (i0 + ii), g.M - 1);
+#pragma unroll
+                            for (int jv = 0; jv < NJ; ++jv) {
+                                const float* rp = g.residual + (size_t)row * g.ldr + (cok[jv] ? colv[jv] : 0);
+#pragma unroll
+                                for (int u = 0; u < NV; ++u) rv[ii][jv][u] = *(const f32x4*)(rp + 4 * u);
                             }
-                            if (g.residual) {
-                                const float* rp = g.residual + (size_t)row * g.ldr + col;
-                                v0 += *(const f32x4*)rp; v1 += *(const f32x4*)(rp + 4);
-                            }
-                            *(bf16x8*)((bf16_t*)g.C + (size_t)row * ldc + col) = pack_bf16x8(v0, v1);
                         }
                     }
-                } else {
+                    if (RES_LOAD || i0 == 0) {
+                        // (the first wait also covers the previous tile's stores, issued a whole main loop ago)
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        const int col = col_w + 16 * j + 4 * grp4;
-                        if (col >= g.N) continue;
-                        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (g.bias) bv = *(const f32x4*)(g.bias + col);
+                    for (int ii = 0; ii < IC; ++ii) {
+                        const int i = i0 + ii;
 #pragma unroll
-                        for (int i = 0; i < FM; ++i) {
-                            const int row = m0 + wr * (BM / 2) + i * 16 + l16;
-                            if (row >= g.M) continue;
-                            f32x4 v = acc[i][j] + bv;
+                        for (int jv = 0; jv < NJ; ++jv) {
+                            f32x4 v[NV];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = epi_act<false, ACT>(v[e]) * g.out_scale;
-                            if constexpr (!LP_OUT) {
-                                if (g.residual) {
-                                    if constexpr (RM == FM) v += res[i][j];  // prefetched two slabs earlier
-                                    else v += *(const f32x4*)(g.residual + (size_t)row * g.ldr + col);
-                                }
+                            for (int u = 0; u < NV; ++u) {
+                                v[u] = acc[i][NV * jv + u] + bv[jv][u];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[u][e] = epi_act<LP_OUT, ACT>(v[u][e]) * g.out_scale;
+                                if constexpr (RES_PREF && HAS_RES) v[u] += res[i][jv];
+                                if constexpr (RES_LOAD) v[u] += rv[ii][jv][u];
                             }
-                            *(f32x4*)((float*)g.C + c_off + (size_t)row * ldc + col) = v;
+                            // rows past M fall outside the descriptor; columns past N are pushed outside it
+                            const unsigned off = cok[jv] ? (unsigned)((16 * i + l16) * ldc + colv[jv]) * CSZ : 0x80000000u;
+                            u32x4 bits;
+                            if constexpr (LP_OUT) bits = __builtin_bit_cast(u32x4, pack_bf16x8(v[0], v[1]));
+                            else bits = __builtin_bit_cast(u32x4, v[0]);
+                            __builtin_amdgcn_raw_buffer_store_b128(bits, crsrc, off, 0, 0);
                         }
                     }
                 }
@@ -340,14 +381,22 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
         }
 
         // ---- epilogue of tile (m0,n0): vectors straight from the accumulators ----
+#define EPI(ACT)                                                                                                  \
+    if constexpr (LP_OUT) {                                                                                       \
+        epilogue<LP_OUT, ACT, false, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off);              \
+    } else {                                                                                                      \
+        if (g.residual) epilogue<LP_OUT, ACT, true, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off); \
+        else epilogue<LP_OUT, ACT, false, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off);         \
+    }
         if (!((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {
             switch (g.act) {
-                case MADTP_ACT_GELU_ERF: epilogue<LP_OUT, MADTP_ACT_GELU_ERF, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off); break;
-                case MADTP_ACT_QUICK_GELU: epilogue<LP_OUT, MADTP_ACT_QUICK_GELU, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off); break;
-                case MADTP_ACT_RELU: epilogue<LP_OUT, MADTP_ACT_RELU, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off); break;
-                default: epilogue<LP_OUT, MADTP_ACT_NONE, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off); break;
+                case MADTP_ACT_GELU_ERF: EPI(MADTP_ACT_GELU_ERF) break;
+                case MADTP_ACT_QUICK_GELU: EPI(MADTP_ACT_QUICK_GELU) break;
+                case MADTP_ACT_RELU: EPI(MADTP_ACT_RELU) break;
+                default: EPI(MADTP_ACT_NONE) break;
             }
         }
+#undef EPI
         slot += gl;
         if (slot >= nslots) break;
         decode(slot, m0, n0, kb_unused);
@@ -459,7 +508,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
         const int rb = wc * 64 + wfrag_row<LP_OUT>(i, l16);
         b_off[i] = A_BYTES + rb * ROWB; b_key[i] = swz_key<LP_OUT>(rb);
     }
-    f32x4 res[1][1];  // the epilogue reads the residual directly
+    f32x4 res[1][1];  // the epilogue reads the residual itself (RES_LOAD)
     // Fragment reads run HALF A SLAB ahead of the MFMAs that use them: X = the kk=0 fragments of slab s are read right
     // after barrier s and land while the 16 MFMAs on Y = the kk=1 fragments of slab s-1 execute; Y(s) is read while
     // the MFMAs on X(s) execute.  (Holding Y(s-1) in registers across barrier s is fine: its ds_reads completed
@@ -513,16 +562,24 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             if (++cur_stage == STAGES) cur_stage = 0;
         }
+        const int t = t0 + slot;
+        const int m0 = (t / g.ntn) * BM + grp * 128, n0 = (t % g.ntn) * BN;
         { MADTP_WS_MFMA(ya, yb) }
         if (!((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {
-            const int t = t0 + slot;
-            const int m0 = (t / g.ntn) * BM + grp * 128, n0 = (t % g.ntn) * BN;
+#define EPI(ACT)                                                                                              \
+    if constexpr (LP_OUT) {                                                                                   \
+        epilogue<LP_OUT, ACT, false, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0);              \
+    } else {                                                                                                  \
+        if (g.residual) epilogue<LP_OUT, ACT, true, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); \
+        else epilogue<LP_OUT, ACT, false, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0);         \
+    }
             switch (g.act) {
-                case MADTP_ACT_GELU_ERF: epilogue<LP_OUT, MADTP_ACT_GELU_ERF, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
-                case MADTP_ACT_QUICK_GELU: epilogue<LP_OUT, MADTP_ACT_QUICK_GELU, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
-                case MADTP_ACT_RELU: epilogue<LP_OUT, MADTP_ACT_RELU, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
-                default: epilogue<LP_OUT, MADTP_ACT_NONE, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); break;
+                case MADTP_ACT_GELU_ERF: EPI(MADTP_ACT_GELU_ERF) break;
+                case MADTP_ACT_QUICK_GELU: EPI(MADTP_ACT_QUICK_GELU) break;
+                case MADTP_ACT_RELU: EPI(MADTP_ACT_RELU) break;
+                default: EPI(MADTP_ACT_NONE) break;
             }
+#undef EPI
         }
     }
 #undef MADTP_WS_READ
@@ -609,8 +666,11 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     g.dbg = dbg;
     g.splitk = splitk;
     // vector epilogue needs 16-byte aligned rows on every epilogue operand
+    // (and, for the descriptor-bounded stores, a 256-row block of C below 2 GiB; bf16 output with an f32 residual has no
+    // caller on the path and takes the scalar epilogue)
     g.fast_epi = (N % 8 == 0) && (ldc % 8 == 0) && aligned16(C) && (!bias || aligned16(bias)) &&
-                 (!residual || (aligned16(residual) && ldr % 4 == 0));
+                 (!residual || (aligned16(residual) && ldr % 4 == 0 && c_dtype != MADTP_BF16)) &&
+                 (size_t)ldc * 256 * 4 < ((size_t)1 << 31);
     // tile configuration (MADTP_GEMM_CFG=1..4 forces one of the gemm_kernel variants for A/B measurements):
     //   0: 128x128, 2-stage ring, 2 workgroups/CU  - default, and the f32 path
     //   1: 64x128, 2 stages, 3 WG/CU   2: 64x128, 3 stages, 2 WG/CU   3: 64x64, 3 stages, 3 WG/CU
