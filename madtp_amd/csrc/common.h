@@ -157,14 +157,28 @@ __device__ __forceinline__ void ln_row(float4 (&v)[LN_MAX_CHUNKS], int nchunk_la
     rstd = 1.0f / sqrtf(var + eps);
 }
 
+// gamma / beta chunks of this lane, fetched BEFORE the row reductions (their latency hides under the x loads; a wave that
+// normalises several rows fetches them once)
+struct LnParams { float4 gm[LN_MAX_CHUNKS], bt[LN_MAX_CHUNKS]; };
+__device__ __forceinline__ LnParams ln_params(const float* gamma, const float* beta, int lane, int dim) {
+    LnParams p;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int col = (lane + 64 * c) * 4;
+        const bool ok = col < dim;
+        p.gm[c] = *(const float4*)(gamma + (ok ? col : 0));
+        p.bt[c] = *(const float4*)(beta + (ok ? col : 0));
+    }
+    return p;
+}
+
 __device__ __forceinline__ void ln_store(const float4 (&v)[LN_MAX_CHUNKS], int lane, int dim, float mean, float rstd,
-                                         const float* gamma, const float* beta, float* y32, bf16_t* ylp) {
+                                         const LnParams& p, float* y32, bf16_t* ylp) {
 #pragma unroll
     for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
         const int col = (lane + 64 * c) * 4;
         if (col >= dim) break;
-        const float4 gm = *(const float4*)(gamma + col);
-        const float4 bt = *(const float4*)(beta + col);
+        const float4 gm = p.gm[c], bt = p.bt[c];
         float4 o;
         o.x = (v[c].x - mean) * rstd * gm.x + bt.x;
         o.y = (v[c].y - mean) * rstd * gm.y + bt.y;

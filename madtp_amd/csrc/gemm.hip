@@ -139,7 +139,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[F
                 constexpr bool RES_PREF = !LP_OUT && RM == FM;
                 const int row_t = m0 + wr * (BM / 2);  // first row of this wave's 64-row (BM/2) block: wave-uniform
                 const int rows_valid = max(min(g.M - row_t, BM / 2), 0);
-                const unsigned long long cb = (unsigned long long)((char*)g.C + (c_off + (size_t)row_t * ldc) * CSZ);
+                const unsigned long long cb = (unsigned long long)((char*)g.C + (c_off + (size_t)((g.dbg & 8) ? (row_t & 127) : row_t) * ldc) * CSZ);  // dbg 8: timing experiment, all tiles store to the first 128 rows (L2-resident)
                 const unsigned cb_lo = __builtin_amdgcn_readfirstlane((unsigned)cb);  // pin the descriptor in SGPRs
                 const unsigned cb_hi = __builtin_amdgcn_readfirstlane((unsigned)(cb >> 32));
                 const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -429,6 +429,19 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
 #ifndef MADTP_WS_ABLATE
 #define MADTP_WS_ABLATE 0
 #endif
+// -DMADTP_WS_TIMING (ABLATE=wstime tools/build_ablate.py): consumer wave 0 of workgroup 0 accumulates wall_clock64 (100 MHz)
+// phase times over its tiles: [0] main loops, [1] epilogues, [2] tiles, [3] kernel total.  tools/gemm_ws_phases.py reads them.
+#ifdef MADTP_WS_TIMING
+__device__ long long g_ws_dbg[8];
+__device__ __forceinline__ long long ws_now() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const long long t = wall_clock64();
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define WS_NOW() ws_now()
+#endif
 template <bool LP_OUT>
 __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
     constexpr int ESZ = 2, BM = 256, BN = 128, STAGES = 3, NCW = 8, NLW = 4;
@@ -528,6 +541,11 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(XB[j], XA[i], acc[i][j], 0, 0, 0);
+#ifdef MADTP_WS_TIMING
+    long long ws_t_main = 0, ws_t_epi = 0, ws_tiles = 0;
+    const long long ws_t_begin = WS_NOW();
+    long long ws_t0 = ws_t_begin;
+#endif
     for (int slot = lb; slot < nslots; slot += gl) {
         {   // first slab of the tile: accumulators start from zero, no Y pending
             constexpr bool first = true;
@@ -565,6 +583,9 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
         const int t = t0 + slot;
         const int m0 = (t / g.ntn) * BM + grp * 128, n0 = (t % g.ntn) * BN;
         { MADTP_WS_MFMA(ya, yb) }
+#ifdef MADTP_WS_TIMING
+        { const long long now = WS_NOW(); ws_t_main += now - ws_t0; ws_t0 = now; }
+#endif
         if (!((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {
 #define EPI(ACT)                                                                                              \
     if constexpr (LP_OUT) {                                                                                   \
@@ -581,10 +602,24 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             }
 #undef EPI
         }
+#ifdef MADTP_WS_TIMING
+        { const long long now = WS_NOW(); ws_t_epi += now - ws_t0; ws_t0 = now; ++ws_tiles; }
+#endif
     }
+#ifdef MADTP_WS_TIMING
+    if (blockIdx.x == 0 && tid == 0) {
+        g_ws_dbg[0] = ws_t_main; g_ws_dbg[1] = ws_t_epi; g_ws_dbg[2] = ws_tiles; g_ws_dbg[3] = ws_t0 - ws_t_begin;
+    }
+#endif
 #undef MADTP_WS_READ
 #undef MADTP_WS_MFMA
 }
+
+#ifdef MADTP_WS_TIMING
+extern "C" int madtp_debug_read_ws_ts(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ws_dbg), sizeof(long long) * 8);
+}
+#endif
 
 // ---- optional HIP-event profiling of every GEMM launch (bench.py's roofline leg) -----------------------------------
 namespace {

@@ -13,6 +13,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (size_t)row * dim;
+    const LnParams prm = ln_params(gamma, beta, lane, dim);
     float4 v[LN_MAX_CHUNKS];
     int n = 0;
 #pragma unroll
@@ -22,7 +23,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     float mean, rstd;
     ln_row(v, n, dim, eps, mean, rstd);
-    ln_store(v, lane, dim, mean, rstd, gamma, beta, y32 ? y32 + (size_t)row * dim : nullptr,
+    ln_store(v, lane, dim, mean, rstd, prm, y32 ? y32 + (size_t)row * dim : nullptr,
              ylp ? ylp + (size_t)row * dim : nullptr);
 }
 
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restri
     const int64_t id = ids[row];
     const float* wr = wemb + (size_t)id * dim;
     const float* pr = pemb + (size_t)(row % L) * dim;
+    const LnParams prm = ln_params(gamma, beta, lane, dim);
     float4 v[LN_MAX_CHUNKS];
     int n = 0;
 #pragma unroll
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restri
     }
     float mean, rstd;
     ln_row(v, n, dim, eps, mean, rstd);
-    ln_store(v, lane, dim, mean, rstd, gamma, beta, y32 ? y32 + (size_t)row * dim : nullptr,
+    ln_store(v, lane, dim, mean, rstd, prm, y32 ? y32 + (size_t)row * dim : nullptr,
              ylp ? ylp + (size_t)row * dim : nullptr);
 }
 
@@ -62,6 +64,7 @@ __global__ __launch_bounds__(256) void splitk_ln_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    const LnParams prm = ln_params(gamma, beta, lane, dim);
     float4 v[LN_MAX_CHUNKS];
     int n = 0;
 #pragma unroll
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void splitk_ln_kernel(const float* __restrict_
     }
     float mean, rstd;
     ln_row(v, n, dim, eps, mean, rstd);
-    ln_store(v, lane, dim, mean, rstd, gamma, beta, y32 ? y32 + (size_t)row * dim : nullptr,
+    ln_store(v, lane, dim, mean, rstd, prm, y32 ? y32 + (size_t)row * dim : nullptr,
              ylp ? ylp + (size_t)row * dim : nullptr);
 }
 

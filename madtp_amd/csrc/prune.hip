@@ -319,11 +319,13 @@ __global__ __launch_bounds__(256) void token_gather_kernel(const float* __restri
     const float4* xb = (const float4*)x + (size_t)b * N * dim4;
     float4* yb = (float4*)y + (size_t)b * No * dim4;
     const bool ln = gamma != nullptr;
+    LnParams prm;
+    if (ln) prm = ln_params(gamma, beta, lane, dim);
     auto ln_out = [&](float4 (&v)[LN_MAX_CHUNKS], int nch, int dst) {
         float mean, rstd;
         ln_row(v, nch, dim, eps, mean, rstd);
         const size_t off = ((size_t)b * No + dst) * dim;
-        ln_store(v, lane, dim, mean, rstd, gamma, beta, h32 ? h32 + off : nullptr, hlp ? hlp + off : nullptr);
+        ln_store(v, lane, dim, mean, rstd, prm, h32 ? h32 + off : nullptr, hlp ? hlp + off : nullptr);
     };
     if ((int)blockIdx.x < (int)gridDim.x - 1) {
         for (int rr = wave; rr < GATHER_ROWS; rr += 4) {

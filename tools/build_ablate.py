@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from madtp_amd import build as b
 
 b.build()
-src, macro = {"align": ("prune.hip", "MADTP_AL_ABLATE"), "tstime": ("prune.hip", "MADTP_TS_TIMING"), "attime": ("attention.hip", "MADTP_TS_TIMING")}.get(
+src, macro = {"align": ("prune.hip", "MADTP_AL_ABLATE"), "tstime": ("prune.hip", "MADTP_TS_TIMING"), "attime": ("attention.hip", "MADTP_TS_TIMING"),
+             "wstime": ("gemm.hip", "MADTP_WS_TIMING")}.get(
     os.environ.get("ABLATE"), ("gemm.hip", "MADTP_WS_ABLATE"))
 for n in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]:
     o = os.path.join(b.LIBDIR, f"{src[:-4]}_abl{n}.o")
