@@ -536,11 +536,22 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
         XA[i] = *(const bf16x8*)(st + a_off[i] + ((((CH) + grp4) ^ a_key[i]) << 4));      \
         XB[i] = *(const bf16x8*)(st + b_off[i] + ((((CH) + grp4) ^ b_key[i]) << 4));      \
     }
+#if MADTP_WS_ABLATE & 8
+    // timing experiment only (results are garbage): the same flops on 8 x v_mfma_f32_32x32x16_bf16 per half slab
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc32[4];
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int e = 0; e < 16; ++e) acc32[i][e] = 0.f;
+#define MADTP_WS_MFMA(XA, XB)                                                             \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                         \
+        _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                                  \
+            acc32[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(XB[(q & 1) * 2 + k2], XA[(q >> 1) * 2 + k2], acc32[q], 0, 0, 0);
+#else
 #define MADTP_WS_MFMA(XA, XB)                                                             \
     if (!(MADTP_WS_ABLATE & 4))                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(XB[j], XA[i], acc[i][j], 0, 0, 0);
+#endif
 #ifdef MADTP_WS_TIMING
     long long ws_t_main = 0, ws_t_epi = 0, ws_tiles = 0;
     const long long ws_t_begin = WS_NOW();
@@ -554,11 +565,19 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             MADTP_WS_READ(xa, xb, 0)
             MADTP_WS_READ(ya, yb, 4)
             __builtin_amdgcn_sched_barrier(0);
+#if MADTP_WS_ABLATE & 8
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = zero4;
+            MADTP_WS_MFMA(xa, xb)
+#else
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[j], xa[i], zero4, 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): Y is in registers, this wave is done with the stage
             __builtin_amdgcn_sched_barrier(0);
@@ -583,6 +602,9 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
         const int t = t0 + slot;
         const int m0 = (t / g.ntn) * BM + grp * 128, n0 = (t % g.ntn) * BN;
         { MADTP_WS_MFMA(ya, yb) }
+#if MADTP_WS_ABLATE & 8
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int e = 0; e < 16; ++e) { acc[q][e >> 2][e & 3] += acc32[q][e]; acc32[q][e] = 0.f; }
+#endif
 #ifdef MADTP_WS_TIMING
         { const long long now = WS_NOW(); ws_t_main += now - ws_t0; ws_t0 = now; }
 #endif
