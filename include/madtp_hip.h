@@ -291,13 +291,15 @@ int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden, const flo
                      int ldt_batch, int K, float temperature, float* score, float* threshold, int32_t* count,
                      int64_t* indices, int64_t* indices_sort, int cross_mode, const void* enc0, const void* enc1,
                      const float* enc_mask0, const float* enc_mask1, const void* hidden_lp, void* y_lp, const void* kv_pre0,
-                     const void* kv_pre1, const int32_t* kv_index, int* k_out, int* k_used, void* stream);
+                     const void* kv_pre1, const int32_t* kv_index, int kv_ld, int* k_out, int* k_used, void* stream);
 /* hidden_lp (optional, bf16 mode): compute-dtype copy of `hidden` - skips the cast; y_lp (optional): receives the
  * compute-dtype copy of y, emitted by the output LayerNorm, to be passed as the next layer's hidden_lp.
  * kv_pre0 / kv_pre1 (optional): a cache of this layer's cross-attention [k|v] projections ([blocks*Nk, 2*dim], compute dtype,
  * = madtp_gemm of the encoder tokens with the layer's fused key|value weights) - the projection GEMM is skipped (enc0/enc1
- * may then be NULL) and sample b attends to block kv_index[b] (NULL: block b).  Retrieval re-ranking projects every image
- * once per layer instead of once per (query, candidate) pair. */
+ * may then be NULL) and sample b attends to block kv_index[b] (NULL: block b).  kv_ld: row stride of kv_pre in elements (0 =
+ * 2*dim) - the rows may be column slices of ONE [blocks*Nk, layers*2*dim] projection of the encoder tokens with all layers'
+ * key|value weights stacked (the NLVR text encoder does that: 2 GEMMs per forward instead of 24).  Retrieval re-ranking
+ * projects every image once per layer instead of once per (query, candidate) pair. */
 
 #ifdef __cplusplus
 }

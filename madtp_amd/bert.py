@@ -7,6 +7,7 @@ reference's class names.
 """
 import json
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -41,6 +42,11 @@ class BertConfig:
 
 
 _ENC_STORE = []
+# MADTP_KV_AHEAD=1: project the encoder tokens to every layer's cross-attention [k|v] in one GEMM per branch before the layer
+# loop instead of inside each layer (the reference's data flow, default).  Measured neutral on the NLVR2 headline (2 x 183 us
+# instead of 24 x 17.8 us of GEMM, but the strided K/V rows cost the 24 cross-attention kernels 6.7 -> 8.1 us each and the two
+# chip-filling GEMMs no longer leave room for the vision encoder's deferred att_ft kernel on the auxiliary stream).
+_KV_AHEAD = os.environ.get("MADTP_KV_AHEAD", "0") == "1"
 
 
 def _cast(x2d):
@@ -388,7 +394,8 @@ class _BertLayerBase(nn.Module):
             lp = None
         y, mask_out, self.last_prune, ylp = hip.bert_layer(w, hidden, mask2d, token_attn, temperature if prune else 0, cross, enc0,
                                                            enc1, Nk, em0, em1, hidden_lp=lp[0] if lp else None,
-                                                           kv_pre=(pre[0], None) if (cross and pre) else (None, None),
+                                                           kv_pre=((pre[0] if isinstance(pre[0], tuple) else (pre[0], None))
+                                                                   if (cross and pre) else (None, None)),
                                                            kv_index=pre[2] if (cross and pre) else None)
         if ylp is not None:
             y._madtp_lp = (ylp, y._version)
@@ -478,6 +485,7 @@ class _BertEncoderBase(nn.Module):
         self.gradient_checkpointing = False
         self.txt_query_model = Query_model(ft_dim=config.hidden_size, sd_dim=sd_dim, temperature=1,
                                            att_func_type='sparsemax', pool_type='max')
+        self._cache = PreparedCache()
 
     def _run(self, hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states, encoder_attention_mask,
              mode, always_query):
@@ -485,10 +493,17 @@ class _BertEncoderBase(nn.Module):
         defer = self.txt_query_model.deferred() if space_dict is not None else None
         reduce_num = int((hidden_states.shape[-2] - 1) // self.config.num_hidden_layers)
         cache = self.__dict__.pop("_kv_cache", None)  # EncoderKVCache for THIS call (MedBertModel.forward(encoder_kv_cache=...))
+        ahead = None
+        if cache is None and mode == 'multimodal' and encoder_hidden_states is not None and _KV_AHEAD:
+            ahead = self._project_encoder_tokens(encoder_hidden_states)
         for i, layer_module in enumerate(self.layer):
             layer_module.__dict__.pop("_kv_pre", None)
             if cache is not None and mode == 'multimodal':
                 layer_module._kv_pre = (cache.kv[i], cache.Nk, cache.index)
+            elif ahead is not None:
+                kvs, Nk, width = ahead
+                layer_module._kv_pre = (tuple(kv[:, i * width:(i + 1) * width] for kv in kvs) if len(kvs) == 2
+                                        else kvs[0][:, i * width:(i + 1) * width], Nk, None)
             token_attn = None
             if space_dict is not None or always_query:
                 if space_dict is None:
@@ -511,6 +526,27 @@ class _BertEncoderBase(nn.Module):
         if defer is not None and defer.pairs:
             sd_txt_ft_all = defer.finish()
         return _Out(hidden_states), sd_txt_ft_all
+
+
+    def _project_encoder_tokens(self, encoder_hidden_states):
+        """The cross-attention [k|v] projections of ALL layers in one GEMM per branch: the layers' fused key|value weights
+        stacked along N ([layers*2*hidden, hidden], prepared once), the encoder tokens read once.  The reference projects
+        inside every layer (med.py:178-179, nlvr_encoder.py:177-178); the values are the same (each output column is the
+        same dot product), but 24 one-round launches of 240 tiles become 2 launches of 2880.  Layer i reads the column
+        slice [i*2*hidden, (i+1)*2*hidden) through kv_ld.  -> ([kv per branch], Nk, 2*hidden) or None."""
+        encs = list(encoder_hidden_states) if isinstance(encoder_hidden_states, (list, tuple)) else [encoder_hidden_states]
+        if not all(getattr(l, "has_cross", hasattr(l, "crossattention")) for l in self.layer):
+            return None
+        kvs = []
+        for br, enc in enumerate(encs):
+            mods = []
+            for l in self.layer:
+                ca = l.crossattention
+                sm = (ca.self0, ca.self1)[br] if ca.twin else ca.self
+                mods += [sm.key, sm.value]
+            lin = lin_of(self._cache, ("kv_all", br), mods)
+            kvs.append(hip.gemm(self.layer[0]._enc_operand(enc), lin.w, lin.b, n=lin.n))
+        return kvs, encs[0].shape[1], 2 * self.config.hidden_size
 
 
 class MedBertEncoder(_BertEncoderBase):

@@ -30,7 +30,7 @@ constexpr int NTHREADS = 256;
 
 struct GemmArgs {
     const char* A; const char* W; const float* bias; const float* residual; void* C;
-    int M, N, K, lda, ldw, ldc, ldr, act, ntm, ntn, dbg, fast_epi, splitk;
+    int M, N, K, lda, ldw, ldc, ldr, act, ntm, ntn, dbg, fast_epi, splitk, ngrp;
     float out_scale;
 };
 
@@ -61,6 +61,18 @@ __device__ __forceinline__ void xcd_tiles(int T, int xcd, int& t0, int& nt) {
 
 // issue the LDS-DMA of one ROWS x 128 B operand tile: ROWS/8 wave-instructions of 1 KiB, ROWS/32 per wave
 // (tile_row0: row of the tile this piece starts at - the swizzle key is a function of the row WITHIN the tile)
+// Tile t of the launch order -> (row tile, column tile).  Plain row-major when ngrp == 0.  For very wide outputs (the
+// stacked cross-attention K/V projection of all text layers, N = 18432: W is 28 MB) the column tiles are walked in GROUPS
+// of ngrp: all row tiles of one group before the next group, so the group's W rows (<= ~2.4 MB) stay in every XCD's L2
+// instead of the whole W streaming through it once per row panel.
+__device__ __forceinline__ void tile_mn(const GemmArgs& g, int t, int& tm, int& tn) {
+    if (g.ngrp == 0) { tm = t / g.ntn; tn = t % g.ntn; return; }
+    const int per = g.ntm * g.ngrp;
+    const int grp = t / per, r = t - grp * per;
+    const int gw = min(g.ngrp, g.ntn - grp * g.ngrp);
+    tm = r / gw; tn = grp * g.ngrp + (r - tm * gw);
+}
+
 template <int ESZ, int ROWS, bool PERM = false>
 __device__ __forceinline__ void stage_tile(const char* base, int row0, int max_row, int ld_elems, int kbyte0,
                                            char* lds_tile, int wave, int lane, int tile_row0 = 0) {
@@ -469,7 +481,9 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
         const char* srcp[PER];  // per-lane source of each DMA instruction at k = 0 of the current tile
         auto tile_ptrs = [&]() {
             const int t = t0 + is_slot;
-            const int im0 = (t / g.ntn) * BM, in0 = (t % g.ntn) * BN;
+            int itm, itn;
+            tile_mn(g, t, itm, itn);
+            const int im0 = itm * BM, in0 = itn * BN;
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
                 const int idx = lw * PER + q;                     // 8-row group of the stage image: A groups, then W groups
@@ -600,7 +614,9 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             if (++cur_stage == STAGES) cur_stage = 0;
         }
         const int t = t0 + slot;
-        const int m0 = (t / g.ntn) * BM + grp * 128, n0 = (t % g.ntn) * BN;
+        int ctm, ctn;
+        tile_mn(g, t, ctm, ctn);
+        const int m0 = ctm * BM + grp * 128, n0 = ctn * BN;
         { MADTP_WS_MFMA(ya, yb) }
 #if MADTP_WS_ABLATE & 8
         _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int e = 0; e < 16; ++e) { acc[q][e >> 2][e & 3] += acc32[q][e]; acc32[q][e] = 0.f; }
@@ -722,6 +738,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     if (force_cfg < 0) { const char* e = getenv("MADTP_GEMM_CFG"); force_cfg = e ? atoi(e) : 0; }
     g.dbg = dbg;
     g.splitk = splitk;
+    g.ngrp = 0;
     // vector epilogue needs 16-byte aligned rows on every epilogue operand
     // (and, for the descriptor-bounded stores, a 256-row block of C below 2 GiB; bf16 output with an f32 residual has no
     // caller on the path and takes the scalar epilogue)
@@ -788,6 +805,15 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         // wave-specialised 256x128 kernel (one 12-wave workgroup per CU, 144 KiB LDS ring)
         g.ntm = (M + 255) / 256;
         g.ntn = (N + 127) / 128;
+        // column groups (tile_mn): keep one group's W rows (~2.4 MB) L2-resident when W as a whole is far larger than L2
+        {
+            static int grp_env = -2;  // MADTP_GEMM_NGRP: unset = automatic, 0 = off, n > 0 = forced group width (A/B runs)
+            if (grp_env == -2) { const char* e = getenv("MADTP_GEMM_NGRP"); grp_env = e ? atoi(e) : -1; }
+            int G = grp_env > 0 ? grp_env : (12 * 768) / K;
+            if (G < 1) G = 1;
+            const bool on = grp_env > 0 || (grp_env == -1 && g.ntn >= 4 * G);
+            g.ngrp = (on && G < g.ntn) ? G : 0;
+        }
         const int slots_max = (g.ntm * g.ntn + 7) / 8;
         const int grid = 8 * (slots_max < 32 ? slots_max : 32);
         const size_t lds = (size_t)3 * (256 + 128) * ROWB;

@@ -326,7 +326,7 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
                           size_t ws_bytes, int B, int L, int k, const float* score, int64_t* indices, int64_t* indices_sort,
                           int cross_mode, const void* enc0, const void* enc1, int Nk, const float* enc_mask0,
                           const float* enc_mask1, bool att_lp_ready, void* y_lp, const void* kv_pre0, const void* kv_pre1,
-                          const int32_t* kv_index, void* stream) {
+                          const int32_t* kv_index, int kv_ld, void* stream) {
     if (!w || !att || !y || !ws || B <= 0 || L <= 0 || k < 0) return MADTP_E_BADARG;
     bool ok;
     BertWs s = bert_carve((char*)ws, ws_bytes, B, L, Nk, w->dim, w->inter.n, w->heads, w->dtype, &ok);
@@ -372,9 +372,10 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
                     TRY(lin(enc, D, w->ckv[br], nullptr, 0, s.kv, 2 * D, B * Nk, dt, dt, MADTP_ACT_NONE, 1.f, stream));
                     kv = (const char*)s.kv;
                 }
+                const int ldkv = ((br ? kv_pre1 : kv_pre0) && kv_ld) ? kv_ld : 2 * D;
                 TRY(madtp_attention_indexed((const char*)s.q2 + (size_t)br * D * e, kv, kv + (size_t)D * e,
                                             (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, (char*)s.cat + (size_t)br * D * e, em,
-                                            nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, 2 * D, 2 * D, 2 * D, 2 * D, w->scale,
+                                            nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, 2 * D, ldkv, ldkv, 2 * D, w->scale,
                                             dt, stream));
             }
             TRY(lin_ln(s.cat, 2 * D, w->cdense_fused, a32, w->fused_twin == 2 ? 1.f : 0.5f, w->ln_cross_g, w->ln_cross_b, s.att2,
@@ -394,8 +395,9 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
                 TRY(lin(enc, D, w->ckv[br], nullptr, 0, s.kv, 2 * D, B * Nk, dt, dt, MADTP_ACT_NONE, 1.f, stream));
                 kv = (const char*)s.kv;
             }
+            const int ldkv = ((br ? kv_pre1 : kv_pre0) && kv_ld) ? kv_ld : 2 * D;
             TRY(madtp_attention_indexed(s.q, kv, kv + (size_t)D * e, (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, cbuf[br], em,
-                                        nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, D, 2 * D, 2 * D, D, w->scale, dt, stream));
+                                        nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, D, ldkv, ldkv, D, w->scale, dt, stream));
         }
         if (nbr == 2) {
             if (w->has_merge) {  // nlvr_encoder.py:263-264
@@ -427,7 +429,7 @@ extern "C" int madtp_bert_layer_rest(const madtp_bert_layer_w* w, const float* a
                                      int64_t* indices, int64_t* indices_sort, int cross_mode, const void* enc0,
                                      const void* enc1, int Nk, const float* enc_mask0, const float* enc_mask1, void* stream) {
     return bert_rest_impl(w, att, mask2d, y, mask_out, ws, ws_bytes, B, L, k, score, indices, indices_sort, cross_mode, enc0, enc1,
-                          Nk, enc_mask0, enc_mask1, false, nullptr, nullptr, nullptr, nullptr, stream);
+                          Nk, enc_mask0, enc_mask1, false, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 // Whole BertLayer.forward in one call (med.py:393-467 / nlvr_encoder.py:484-559): self-attention half, host read of
@@ -438,7 +440,7 @@ extern "C" int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden
                                 int ldt_row, int ldt_batch, int K, float temperature, float* score, float* threshold,
                                 int32_t* count, int64_t* indices, int64_t* indices_sort, int cross_mode, const void* enc0,
                                 const void* enc1, const float* enc_mask0, const float* enc_mask1, const void* hidden_lp,
-                                void* y_lp, const void* kv_pre0, const void* kv_pre1, const int32_t* kv_index, int* k_out,
+                                void* y_lp, const void* kv_pre0, const void* kv_pre1, const int32_t* kv_index, int kv_ld, int* k_out,
                                 int* k_used, void* stream) {
     if (!k_out || !k_used) return MADTP_E_BADARG;
     *k_out = 0; *k_used = 0;
@@ -450,5 +452,5 @@ extern "C" int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden
         if (!(k < 1 || (L - 1 - k) <= 1)) *k_used = k;
     }
     return bert_rest_impl(w, att, mask2d, y, mask_out, ws, ws_bytes, B, L, *k_used, score, indices, indices_sort, cross_mode, enc0,
-                          enc1, Nk, enc_mask0, enc_mask1, true, y_lp, kv_pre0, kv_pre1, kv_index, stream);
+                          enc1, Nk, enc_mask0, enc_mask1, true, y_lp, kv_pre0, kv_pre1, kv_index, kv_ld, stream);
 }

@@ -12,7 +12,7 @@ import torch
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -64,7 +64,7 @@ _SIGS = {
     "madtp_vit_block": (c_int, [c_void_p] * 5 + [c_size_t, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
                         + [c_void_p] * 7 + [c_void_p]),
     "madtp_bert_layer": (c_int, [c_void_p] * 7 + [c_size_t, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
-                         + [c_void_p] * 5 + [c_int] + [c_void_p] * 11 + [c_void_p]),
+                         + [c_void_p] * 5 + [c_int] + [c_void_p] * 9 + [c_int] + [c_void_p] * 3),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
     "madtp_query_att_ft_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -453,6 +453,12 @@ def bert_layer(wstruct, hidden, mask2d, token_attn, temperature, cross_mode, enc
     hidden_lp / y_lp: bf16 copies of the layer input / output (fast mode; the LayerNorms emit them, saving the casts)."""
     B, L, D = hidden.shape
     lib = load()
+    kv_ld = 0
+    for t in kv_pre:  # cached [k|v] rows may be column slices of a wider projection (all layers side by side)
+        if t is not None:
+            if t.stride(-1) != 1 or (kv_ld and kv_ld != t.stride(0)):
+                raise RuntimeError("bert_layer: kv_pre tensors must be row-major with one common row stride")
+            kv_ld = t.stride(0)
     nbytes = lib.madtp_bert_layer_workspace(B, L, Nk, wstruct.dim, wstruct.inter.n, wstruct.heads, wstruct.dtype)
     ws = workspace(nbytes, hidden.device)
     att = torch.empty_like(hidden)
@@ -469,7 +475,7 @@ def bert_layer(wstruct, hidden, mask2d, token_attn, temperature, cross_mode, enc
         _check(lib.madtp_bert_layer(ctypes.byref(wstruct), _p(hidden), _p(mask2d), _p(att), _p(ybuf), _p(mbuf), _p(ws), ws.numel(),
                                     B, L, Nk, tp, ldr, ldb, K, float(temperature), _p(score), _p(thr), _p(count), _p(idx),
                                     _p(idx_sort), int(cross_mode), _p(enc0), _p(enc1), _p(enc_mask0), _p(enc_mask1),
-                                    _p(hidden_lp), _p(ylp), _p(kv_pre[0]), _p(kv_pre[1]), _p(kv_index), ctypes.byref(k_out),
+                                    _p(hidden_lp), _p(ylp), _p(kv_pre[0]), _p(kv_pre[1]), _p(kv_index), kv_ld, ctypes.byref(k_out),
                                     ctypes.byref(k_used), _stream()), "madtp_bert_layer")
         info = {"k": k_out.value, "score": score, "threshold": thr, "count": count, "pruned": False, "indices": None,
                 "indices_sort": None}
@@ -481,7 +487,7 @@ def bert_layer(wstruct, hidden, mask2d, token_attn, temperature, cross_mode, enc
         return ybuf, None, info, ylp
     _check(lib.madtp_bert_layer(ctypes.byref(wstruct), _p(hidden), _p(mask2d), _p(att), _p(ybuf), 0, _p(ws), ws.numel(), B, L, Nk,
                                 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, int(cross_mode), _p(enc0), _p(enc1), _p(enc_mask0), _p(enc_mask1),
-                                _p(hidden_lp), _p(ylp), _p(kv_pre[0]), _p(kv_pre[1]), _p(kv_index), ctypes.byref(k_out),
+                                _p(hidden_lp), _p(ylp), _p(kv_pre[0]), _p(kv_pre[1]), _p(kv_index), kv_ld, ctypes.byref(k_out),
                                 ctypes.byref(k_used), _stream()), "madtp_bert_layer")
     return ybuf, None, None, ylp
 
@@ -547,6 +553,12 @@ def query_model(x, sd_w, K, att_ft=None, want_att_ft=True, sd_dim=768, sd_split=
 def bert_layer_attn(wstruct, hidden, mask2d, token_attn, temperature, Nk):
     B, L, D = hidden.shape
     lib = load()
+    kv_ld = 0
+    for t in kv_pre:  # cached [k|v] rows may be column slices of a wider projection (all layers side by side)
+        if t is not None:
+            if t.stride(-1) != 1 or (kv_ld and kv_ld != t.stride(0)):
+                raise RuntimeError("bert_layer: kv_pre tensors must be row-major with one common row stride")
+            kv_ld = t.stride(0)
     nbytes = lib.madtp_bert_layer_workspace(B, L, Nk, wstruct.dim, wstruct.inter.n, wstruct.heads, wstruct.dtype)
     ws = workspace(nbytes, hidden.device)
     att = torch.empty_like(hidden)
