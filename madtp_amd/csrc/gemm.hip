@@ -550,22 +550,11 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
         XA[i] = *(const bf16x8*)(st + a_off[i] + ((((CH) + grp4) ^ a_key[i]) << 4));      \
         XB[i] = *(const bf16x8*)(st + b_off[i] + ((((CH) + grp4) ^ b_key[i]) << 4));      \
     }
-#if MADTP_WS_ABLATE & 8
-    // timing experiment only (results are garbage): the same flops on 8 x v_mfma_f32_32x32x16_bf16 per half slab
-    typedef float f32x16 __attribute__((ext_vector_type(16)));
-    f32x16 acc32[4];
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int e = 0; e < 16; ++e) acc32[i][e] = 0.f;
-#define MADTP_WS_MFMA(XA, XB)                                                             \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                         \
-        _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                                  \
-            acc32[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(XB[(q & 1) * 2 + k2], XA[(q >> 1) * 2 + k2], acc32[q], 0, 0, 0);
-#else
 #define MADTP_WS_MFMA(XA, XB)                                                             \
     if (!(MADTP_WS_ABLATE & 4))                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(XB[j], XA[i], acc[i][j], 0, 0, 0);
-#endif
 #ifdef MADTP_WS_TIMING
     long long ws_t_main = 0, ws_t_epi = 0, ws_tiles = 0;
     const long long ws_t_begin = WS_NOW();
@@ -579,19 +568,11 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             MADTP_WS_READ(xa, xb, 0)
             MADTP_WS_READ(ya, yb, 4)
             __builtin_amdgcn_sched_barrier(0);
-#if MADTP_WS_ABLATE & 8
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = zero4;
-            MADTP_WS_MFMA(xa, xb)
-#else
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[j], xa[i], zero4, 0, 0, 0);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): Y is in registers, this wave is done with the stage
             __builtin_amdgcn_sched_barrier(0);
@@ -618,9 +599,6 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
         tile_mn(g, t, ctm, ctn);
         const int m0 = ctm * BM + grp * 128, n0 = ctn * BN;
         { MADTP_WS_MFMA(ya, yb) }
-#if MADTP_WS_ABLATE & 8
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int e = 0; e < 16; ++e) { acc[q][e >> 2][e & 3] += acc32[q][e]; acc32[q][e] = 0.f; }
-#endif
 #ifdef MADTP_WS_TIMING
         { const long long now = WS_NOW(); ws_t_main += now - ws_t0; ws_t0 = now; }
 #endif
@@ -667,7 +645,7 @@ std::vector<GemmRecord> g_prof;
 }  // namespace
 
 extern "C" int madtp_profile_begin(void) {
-    for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof.clear();
     g_prof_on = true;
     return 0;
@@ -684,7 +662,7 @@ extern "C" int madtp_profile_end(char* buf, int cap) {
             auto& a = agg[std::make_tuple(r.dt, r.M, r.N, r.K)];
             std::get<0>(a) += 1; std::get<1>(a) += ms; std::get<2>(a) += r.flops; std::get<3>(a) += r.bytes;
         }
-        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
     g_prof.clear();
     int off = 0;
@@ -770,12 +748,12 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     const bool lp = c_dtype == MADTP_BF16;
     GemmRecord rec;
     if (g_prof_on) {
-        hipEventCreate(&rec.e0); hipEventCreate(&rec.e1);
+        (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
         rec.flops = 2.0 * M * N * K; rec.dt = ab_dtype; rec.M = M; rec.N = N; rec.K = K;
         // algorithmic HBM bytes: A and W once, C once (x splits), bias, residual once
         rec.bytes = (double)esz * ((double)M * K + (double)N * K) + (double)M * N * (c_dtype == MADTP_BF16 ? 2 : 4) * splitk +
                     (bias ? 4.0 * N : 0.0) + (residual ? 4.0 * M * N : 0.0);
-        hipEventRecord(rec.e0, s);
+        (void)hipEventRecord(rec.e0, s);
     }
 #define MADTP_LAUNCH_GEMM(TT, LP, BM_, BN_, ST_, WGCU)                                                                   \
     do {                                                                                                               \
@@ -833,7 +811,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         if (lp) MADTP_DISPATCH_CFG(float, true); else MADTP_DISPATCH_CFG(float, false);
     }
     if (g_prof_on) {
-        hipEventRecord(rec.e1, s);
+        (void)hipEventRecord(rec.e1, s);
         g_prof.push_back(rec);
     }
     MADTP_LAUNCH_CHECK();
