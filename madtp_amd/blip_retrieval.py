@@ -103,6 +103,39 @@ def all_reduce_scores(score_i2t, score_t2i):
     return a.cpu().numpy(), b.cpu().numpy()
 
 
+def rank_rows(n, rank, world_size):
+    """Row slice [start, end) of an n-row score matrix that `rank` fills (compress_retrieval_dtp.py:158-162 / :181-183)."""
+    step = n // world_size + 1
+    return min(n, rank * step), min(n, rank * step + step)
+
+
+def all_gather_scores(score_i2t, score_t2i):
+    """the exchange the path actually needs - every rank contributes only the ROWS it re-ranked (rank_rows) and
+    all ranks end up with exactly the matrices of a single-rank evaluation (no -100*(world-1) shift, 1/world of the
+    all-reduce's traffic: at COCO 5k x 25k the two SUM all-reduces move 2 x 500 MB per rank).  numpy in, numpy out; no-op
+    without a process group.  Slices are padded to the common step so one all_gather per matrix suffices."""
+    import numpy as np
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return score_i2t, score_t2i
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    outs = []
+    for m in (score_i2t, score_t2i):
+        n, step = m.shape[0], m.shape[0] // world + 1
+        s, e = rank_rows(n, rank, world)
+        mine = np.full((step, m.shape[1]), -100.0, dtype=m.dtype)
+        mine[:e - s] = m[s:e]
+        parts = [torch.empty((step, m.shape[1]), dtype=torch.from_numpy(mine).dtype, device=dev) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(mine).to(dev))
+        full = np.full_like(m, -100.0)
+        for r, part in enumerate(parts):
+            rs, re = rank_rows(n, r, world)
+            full[rs:re] = part[:re - rs].cpu().numpy()
+        outs.append(full)
+    return outs[0], outs[1]
+
+
 @torch.no_grad()
 def evaluate(model, data_loader, device, config, temperature=0, rank=0, world_size=1, text_bs=256, kv_cache=True):
     """compress_retrieval_dtp.py evaluate() :84-207 -> (score_matrix_i2t, score_matrix_t2i) as numpy arrays and the GFLOPs
@@ -153,8 +186,7 @@ def evaluate(model, data_loader, device, config, temperature=0, rank=0, world_si
     sims_matrix = image_embeds @ text_embeds.t()  # :155
     n_img = sims_matrix.shape[0]
     score_i2t = torch.full((n_img, num_text), -100.0, device=device)
-    step = n_img // world_size + 1
-    start, end = rank * step, min(n_img, rank * step + step)
+    start, end = rank_rows(n_img, rank, world_size)
     for i in range(start, end):  # :164-174
         topk_sim, topk_idx = sims_matrix[i].topk(k=k_test, dim=0)
         score_i2t[i, topk_idx] = rerank(text_ids[topk_idx], text_atts[topk_idx],
@@ -162,8 +194,7 @@ def evaluate(model, data_loader, device, config, temperature=0, rank=0, world_si
 
     sims_t = sims_matrix.t()
     score_t2i = torch.full((num_text, n_img), -100.0, device=device)
-    step = num_text // world_size + 1
-    start, end = rank * step, min(num_text, rank * step + step)
+    start, end = rank_rows(num_text, rank, world_size)
     for i in range(start, end):  # :186-198
         topk_sim, topk_idx = sims_t[i].topk(k=k_test, dim=0)
         score_t2i[i, topk_idx] = rerank(text_ids[i].repeat(k_test, 1), text_atts[i].repeat(k_test, 1), topk_idx) + topk_sim

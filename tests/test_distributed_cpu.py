@@ -95,7 +95,9 @@ def _retrieval_worker(rank, world, port, out_dir):
     with torch.no_grad():
         i2t, t2i = O.retrieval_evaluate(W, batches, ids, att, 6.0, 2, rank=rank, world=world)
     a, b = br.all_reduce_scores(i2t.numpy(), t2i.numpy())
-    torch.save({"i2t": i2t, "t2i": t2i, "sum_i2t": a, "sum_t2i": b}, os.path.join(out_dir, f"retr{rank}.pt"))
+    c, d = br.all_gather_scores(i2t.numpy(), t2i.numpy())
+    torch.save({"i2t": i2t, "t2i": t2i, "sum_i2t": a, "sum_t2i": b, "gat_i2t": c, "gat_t2i": d},
+               os.path.join(out_dir, f"retr{rank}.pt"))
     mdist.barrier()
     torch.distributed.destroy_process_group()
 
@@ -123,3 +125,11 @@ def test_retrieval_rank_slices_and_all_reduce(tmp_path):
         done = full != -100.0
         assert np.allclose(red[done], full[done] - 100.0 * (world - 1), atol=1e-4)   # uniform shift: same ranking
         assert (red[~done] == -100.0 * world).all()
+        # the row-slice all-gather reproduces the single-rank matrices themselves, on every rank
+        # (bit-exactly the rows each rank computed; against the separate single-rank oracle run only to float noise, the CPU
+        #  oracle's reductions depend on the thread count)
+        assert np.array_equal(outs[0]["gat_" + key], outs[1]["gat_" + key])
+        gat = outs[0]["gat_" + key]
+        for r, o in enumerate(outs):
+            assert np.array_equal(gat[own[r]], o[key].numpy()[own[r]])
+        assert np.array_equal(gat != -100.0, done) and np.allclose(gat[done], full[done], atol=1e-4)
