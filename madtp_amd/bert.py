@@ -291,17 +291,27 @@ class _BertLayerBase(nn.Module):
                 mask = hip.mask_gather(mask, indices, k, order2=indices_sort)
         return y, mask
 
+    def _apply(self, fn, recurse=True):
+        self.__dict__.pop("_madtp_params", None)
+        return super()._apply(fn, recurse)
+
     # ---- forward --------------------------------------------------------------------------------------------
     def _weights(self):
         """madtp_bert_layer_w for the layer-level C entry points."""
         sa, ao = self.attention.self, self.attention.output
-        params = [sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias,
-                  ao.dense.weight, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias, self.intermediate.dense.weight,
-                  self.intermediate.dense.bias, self.output.dense.weight, self.output.dense.bias,
-                  self.output.LayerNorm.weight, self.output.LayerNorm.bias]
         has_cross = hasattr(self, "crossattention")
-        if has_cross:
-            params += list(self.crossattention.parameters())
+        # the Parameter objects whose (data_ptr, version, device) key the prepared weights; collected once per module
+        # (walking the sub-modules costs ~0.1 ms per layer call - visible in the launch-bound small-batch regime) and
+        # dropped by _apply() (.to / .half / ...), which may replace Parameter objects
+        params = self.__dict__.get("_madtp_params")
+        if params is None:
+            params = [sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias,
+                      ao.dense.weight, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias, self.intermediate.dense.weight,
+                      self.intermediate.dense.bias, self.output.dense.weight, self.output.dense.bias,
+                      self.output.LayerNorm.weight, self.output.LayerNorm.bias]
+            if has_cross:
+                params += list(self.crossattention.parameters())
+            self.__dict__["_madtp_params"] = params
 
         def build():
             keep = []

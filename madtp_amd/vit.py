@@ -146,11 +146,18 @@ class Block(nn.Module):
         info.update(pruned=True, indices=indices, indices_sort=indices_sort)
         return hip.token_gather(x, dst_pos, merge_w, k)
 
+    def _apply(self, fn, recurse=True):
+        self.__dict__.pop("_madtp_params", None)
+        return super()._apply(fn, recurse)
+
     def _weights(self):
         """madtp_vit_block_w for the layer-level C entry points (rebuilt when a parameter or the precision changes)."""
-        params = [self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.attn.qkv.weight,
-                  self.attn.qkv.bias, self.attn.proj.weight, self.attn.proj.bias, self.mlp.fc1.weight, self.mlp.fc1.bias,
-                  self.mlp.fc2.weight, self.mlp.fc2.bias]
+        params = self.__dict__.get("_madtp_params")  # collected once per module, dropped by _apply() (see bert.py)
+        if params is None:
+            params = [self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.attn.qkv.weight,
+                      self.attn.qkv.bias, self.attn.proj.weight, self.attn.proj.bias, self.mlp.fc1.weight,
+                      self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias]
+            self.__dict__["_madtp_params"] = params
 
         def build():
             lins = [lin_of(self.attn._cache, "qkv", [self.attn.qkv]), lin_of(self.attn._cache, "proj", [self.attn.proj]),
