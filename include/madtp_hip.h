@@ -58,6 +58,13 @@ int madtp_gemm_splitk(const void* A, const void* W, float* part, int M, int N, i
 int madtp_splitk_ln(const float* part, int splits, const float* bias, const float* residual, const float* gamma,
                     const float* beta, float* y32, void* ylp, int rows, int dim, float eps, float scale, void* stream);
 
+/* Two independent GEMMs of identical shape, leading dimensions and dtypes (C_i = A_i @ W_i^T + bias_i; bias0 and bias1 both
+ * given or both NULL) in ONE launch when the shape runs on the wave-specialised bf16 kernel, two madtp_gemm launches otherwise.
+ * Replaces the key/value nn.Linear pairs of the two cross-attention branches (nlvr_encoder.py:177-178 for self0 and self1). */
+int madtp_gemm_pair(const void* A0, const void* A1, const void* W0, const void* W1, const float* bias0, const float* bias1,
+                    void* C0, void* C1, int M, int N, int K, int lda, int ldw, int ldc, int ab_dtype, int c_dtype,
+                    void* stream);
+
 /* Optional profiling of madtp_gemm launches with HIP events recorded on the launch stream (bench.py roofline leg).
  * madtp_profile_begin() starts recording; madtp_profile_end() stops, waits for the events and writes one line per
  * (dtype, M, N, K): "dtype M N K launches total_ms flops algorithmic_bytes" into buf; returns the bytes written. */

@@ -31,6 +31,8 @@ constexpr int NTHREADS = 256;
 struct GemmArgs {
     const char* A; const char* W; const float* bias; const float* residual; void* C;
     int M, N, K, lda, ldw, ldc, ldr, act, ntm, ntn, dbg, fast_epi, splitk, ngrp;
+    // madtp_gemm_pair (wave-specialised kernel only): a second problem of the same shape, tiles [ntm*ntn, 2*ntm*ntn)
+    const char* A2; const char* W2; const float* bias2; void* C2; int pair;
     float out_scale;
 };
 
@@ -463,7 +465,8 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
 
     const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, gl = gridDim.x >> 3;
     int t0, nslots;
-    xcd_tiles(g.ntm * g.ntn, xcd, t0, nslots);
+    const int tiles1 = g.ntm * g.ntn;
+    xcd_tiles(g.pair ? 2 * tiles1 : tiles1, xcd, t0, nslots);
     if (lb >= nslots) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -480,7 +483,11 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
         long issued = 0;
         const char* srcp[PER];  // per-lane source of each DMA instruction at k = 0 of the current tile
         auto tile_ptrs = [&]() {
-            const int t = t0 + is_slot;
+            int t = t0 + is_slot;
+            const bool second = g.pair && t >= tiles1;
+            if (second) t -= tiles1;
+            const char* pA = second ? g.A2 : g.A;
+            const char* pW = second ? g.W2 : g.W;
             int itm, itn;
             tile_mn(g, t, itm, itn);
             const int im0 = itm * BM, in0 = itn * BN;
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
                 int row = (is_a ? im0 : in0) + r;
                 const int lim = is_a ? g.M - 1 : n_pad_max;
                 row = row < lim ? row : lim;
-                srcp[q] = (is_a ? g.A : g.W) + (size_t)row * (is_a ? g.lda : g.ldw) * ESZ + (((lane & 7) ^ key) << 4);
+                srcp[q] = (is_a ? pA : pW) + (size_t)row * (is_a ? g.lda : g.ldw) * ESZ + (((lane & 7) ^ key) << 4);
             }
         };
         tile_ptrs();
@@ -594,7 +601,9 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             if (++cur_stage == STAGES) cur_stage = 0;
         }
-        const int t = t0 + slot;
+        int t = t0 + slot;
+        const bool second = g.pair && t >= tiles1;
+        if (second) t -= tiles1;
         int ctm, ctn;
         tile_mn(g, t, ctm, ctn);
         const int m0 = ctm * BM + grp * 128, n0 = ctn * BN;
@@ -603,12 +612,14 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
         { const long long now = WS_NOW(); ws_t_main += now - ws_t0; ws_t0 = now; }
 #endif
         if (!((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {
+            GemmArgs ge = g;  // (kernel arguments live in SGPRs: this is two scalar selects)
+            if (second) { ge.bias = g.bias2; ge.C = g.C2; }
 #define EPI(ACT)                                                                                              \
     if constexpr (LP_OUT) {                                                                                   \
-        epilogue<LP_OUT, ACT, false, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0);              \
+        epilogue<LP_OUT, ACT, false, 4, 4, 128, 128>(ge, acc, res, m0, n0, wr, wc, l16, grp4, 0);              \
     } else {                                                                                                  \
-        if (g.residual) epilogue<LP_OUT, ACT, true, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0); \
-        else epilogue<LP_OUT, ACT, false, 4, 4, 128, 128>(g, acc, res, m0, n0, wr, wc, l16, grp4, 0);         \
+        if (g.residual) epilogue<LP_OUT, ACT, true, 4, 4, 128, 128>(ge, acc, res, m0, n0, wr, wc, l16, grp4, 0); \
+        else epilogue<LP_OUT, ACT, false, 4, 4, 128, 128>(ge, acc, res, m0, n0, wr, wc, l16, grp4, 0);         \
     }
             switch (g.act) {
                 case MADTP_ACT_GELU_ERF: EPI(MADTP_ACT_GELU_ERF) break;
@@ -676,9 +687,29 @@ extern "C" int madtp_profile_end(char* buf, int cap) {
     return off;
 }
 
+// second problem of a madtp_gemm_pair launch (same shape, leading dimensions and dtypes as the first)
+struct GemmPair { const void* A; const void* W; const float* bias; void* C; };
+constexpr int PAIR_UNSUPPORTED = 1000;  // internal: this shape does not run on the wave-specialised kernel
+
 static int gemm_launch(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
                        int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float out_scale, int splitk,
-                       void* stream);
+                       void* stream, const GemmPair* pair = nullptr);
+
+// Two independent GEMMs of identical shape (C_i = A_i @ W_i^T + bias_i) in ONE launch of the wave-specialised kernel: the
+// twin cross-attention branches of the NLVR text layers project their image tokens to [k|v] with two 240-tile problems, each
+// a single round on 256 CUs - as one 480-tile launch they share the launch, ramp-up and drain (~6 us of a 17.8 us kernel).
+// Shapes the wave-specialised kernel does not take run as two madtp_gemm launches.
+extern "C" int madtp_gemm_pair(const void* A0, const void* A1, const void* W0, const void* W1, const float* bias0,
+                               const float* bias1, void* C0, void* C1, int M, int N, int K, int lda, int ldw, int ldc,
+                               int ab_dtype, int c_dtype, void* stream) {
+    if (!A1 || !W1 || !C1 || (!bias0) != (!bias1)) return MADTP_E_BADARG;
+    const GemmPair p{A1, W1, bias1, C1};
+    int rc = gemm_launch(A0, W0, bias0, nullptr, C0, M, N, K, lda, ldw, ldc, 0, ab_dtype, c_dtype, MADTP_ACT_NONE, 1.f, 1, stream, &p);
+    if (rc != PAIR_UNSUPPORTED) return rc;
+    rc = gemm_launch(A0, W0, bias0, nullptr, C0, M, N, K, lda, ldw, ldc, 0, ab_dtype, c_dtype, MADTP_ACT_NONE, 1.f, 1, stream);
+    if (rc) return rc;
+    return gemm_launch(A1, W1, bias1, nullptr, C1, M, N, K, lda, ldw, ldc, 0, ab_dtype, c_dtype, MADTP_ACT_NONE, 1.f, 1, stream);
+}
 
 extern "C" int madtp_gemm(const void* A, const void* W, const float* bias, const float* residual, void* C,
                           int M, int N, int K, int lda, int ldw, int ldc, int ldr,
@@ -699,7 +730,7 @@ extern "C" int madtp_gemm_splitk(const void* A, const void* W, float* part, int 
 
 static int gemm_launch(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
                        int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float out_scale, int splitk,
-                       void* stream) {
+                       void* stream, const GemmPair* pair) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return MADTP_E_BADARG;
     if (ab_dtype != MADTP_F32 && ab_dtype != MADTP_BF16) return MADTP_E_DTYPE;
     if (c_dtype != MADTP_F32 && c_dtype != MADTP_BF16) return MADTP_E_DTYPE;
@@ -717,6 +748,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     g.dbg = dbg;
     g.splitk = splitk;
     g.ngrp = 0;
+    g.pair = 0; g.A2 = g.W2 = nullptr; g.bias2 = nullptr; g.C2 = nullptr;
     // vector epilogue needs 16-byte aligned rows on every epilogue operand
     // (and, for the descriptor-bounded stores, a 256-row block of C below 2 GiB; bf16 output with an f32 residual has no
     // caller on the path and takes the scalar epilogue)
@@ -741,8 +773,16 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         else if (t64x128 <= 768) cfg = 1;
     }
     // MADTP_GEMM_CFG=5 forces the wave-specialised kernel, 1..4 force a gemm_kernel variant (A/B measurements)
-    const bool ws_ok = ab_dtype == MADTP_BF16 && splitk == 1 &&
-                       (force_cfg == 5 || (force_cfg == 0 && M >= 4096 && (big || cfg == 0)));
+    bool ws_ok = ab_dtype == MADTP_BF16 && splitk == 1 &&
+                 (force_cfg == 5 || (force_cfg == 0 && M >= 4096 && (big || cfg == 0)));
+    if (pair) {
+        static int pair_env = -1;  // MADTP_GEMM_PAIR=0: always two launches (A/B runs)
+        if (pair_env < 0) { const char* e = getenv("MADTP_GEMM_PAIR"); pair_env = e ? atoi(e) : 1; }
+        ws_ok = pair_env && ab_dtype == MADTP_BF16 && force_cfg == 0 && M >= 4096 && 2 * t256 >= 200 && g.fast_epi &&
+                aligned16(pair->A) && aligned16(pair->W) && aligned16(pair->C) && (!pair->bias || aligned16(pair->bias));
+        if (!ws_ok) return PAIR_UNSUPPORTED;
+        g.pair = 1; g.A2 = (const char*)pair->A; g.W2 = (const char*)pair->W; g.bias2 = pair->bias; g.C2 = pair->C;
+    }
     if (force_cfg > 0 && force_cfg <= 4) cfg = force_cfg - 1;
     hipStream_t s = (hipStream_t)stream;
     const bool lp = c_dtype == MADTP_BF16;
@@ -753,6 +793,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         // algorithmic HBM bytes: A and W once, C once (x splits), bias, residual once
         rec.bytes = (double)esz * ((double)M * K + (double)N * K) + (double)M * N * (c_dtype == MADTP_BF16 ? 2 : 4) * splitk +
                     (bias ? 4.0 * N : 0.0) + (residual ? 4.0 * M * N : 0.0);
+        if (pair) { rec.flops *= 2.0; rec.bytes *= 2.0; }  // two problems in this launch
         (void)hipEventRecord(rec.e0, s);
     }
 #define MADTP_LAUNCH_GEMM(TT, LP, BM_, BN_, ST_, WGCU)                                                                   \
@@ -792,7 +833,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
             const bool on = grp_env > 0 || (grp_env == -1 && g.ntn >= 4 * G);
             g.ngrp = (on && G < g.ntn) ? G : 0;
         }
-        const int slots_max = (g.ntm * g.ntn + 7) / 8;
+        const int slots_max = (g.ntm * g.ntn * (g.pair ? 2 : 1) + 7) / 8;
         const int grid = 8 * (slots_max < 32 ? slots_max : 32);
         const size_t lds = (size_t)3 * (256 + 128) * ROWB;
         static bool attr_ws = false;

@@ -99,7 +99,7 @@ VitWs vit_carve(char* base, size_t cap, int B, int N, int dim, int hidden, int h
 }
 
 struct BertWs {
-    void *hc, *qkv, *ctx, *q, *q2, *kv, *c0, *c1, *cat, *mid, *attc;
+    void *hc, *qkv, *ctx, *q, *q2, *kv, *kv1, *c0, *c1, *cat, *mid, *attc;
     float *t, *xp, *s, *att2, *merge_w, *colsum, *p0, *onorm, *part;
     int32_t* dst_pos;
     size_t bytes;
@@ -115,6 +115,7 @@ BertWs bert_carve(char* base, size_t cap, int B, int L, int Nk, int dim, int hid
     w.q = c.take(M * dim * e);
     w.q2 = c.take(M * 2 * dim * e);
     w.kv = c.take(MK * 2 * dim * e);
+    w.kv1 = c.take(MK * 2 * dim * e);  // second branch (twin cross-attention: both projections in one launch)
     w.c0 = c.take(M * dim * e);
     w.c1 = c.take(M * dim * e);
     w.cat = c.take(M * 2 * dim * e);
@@ -363,14 +364,19 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
             // twin branches with fused projections: one q GEMM ([q0|q1], N = 2D), the two context tensors written
             // side by side ([c0|c1], ld 2D) and ONE output GEMM over K = 2D (dense0|dense1, merge_layer folded in)
             TRY(lin(ac, D, w->cq_fused, nullptr, 0, s.q2, 2 * D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+            // [k|v] = enc @ [Wk|Wv]^T of BOTH branches in one launch (or read from the caller's cache of projected blocks)
+            const bool both_here = !kv_pre0 && !kv_pre1 && w->ckv[0].n == w->ckv[1].n && w->ckv[0].k == w->ckv[1].k;
+            if (both_here)
+                TRY(madtp_gemm_pair(enc0, enc1, w->ckv[0].w, w->ckv[1].w, w->ckv[0].b, w->ckv[1].b, s.kv, s.kv1, B * Nk,
+                                    w->ckv[0].n, w->ckv[0].k, D, w->ckv[0].k, 2 * D, dt, dt, stream));
             for (int br = 0; br < 2; ++br) {
                 const void* enc = br ? enc1 : enc0;
                 const float* em = w->variant_nlvr ? (br ? enc_mask1 : enc_mask0) : nullptr;
-                // [k|v] = enc @ [Wk|Wv]^T: done here, or read from the caller's cache of projected encoder blocks
                 const char* kv = (const char*)(br ? kv_pre1 : kv_pre0);
                 if (!kv) {
-                    TRY(lin(enc, D, w->ckv[br], nullptr, 0, s.kv, 2 * D, B * Nk, dt, dt, MADTP_ACT_NONE, 1.f, stream));
-                    kv = (const char*)s.kv;
+                    void* dst = br ? s.kv1 : s.kv;
+                    if (!both_here) TRY(lin(enc, D, w->ckv[br], nullptr, 0, dst, 2 * D, B * Nk, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+                    kv = (const char*)dst;
                 }
                 const int ldkv = ((br ? kv_pre1 : kv_pre0) && kv_ld) ? kv_ld : 2 * D;
                 TRY(madtp_attention_indexed((const char*)s.q2 + (size_t)br * D * e, kv, kv + (size_t)D * e,

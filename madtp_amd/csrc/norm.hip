@@ -223,7 +223,7 @@ extern "C" int madtp_cast_bf16(const float* src, void* dst, size_t n, void* stre
     return 0;
 }
 
-extern "C" int madtp_abi_version(void) { return 5; }
+extern "C" int madtp_abi_version(void) { return 6; }
 
 extern "C" const char* madtp_strerror(int code) {
     switch (code) {

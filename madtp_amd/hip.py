@@ -12,7 +12,7 @@ import torch
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -66,6 +66,7 @@ _SIGS = {
     "madtp_bert_layer": (c_int, [c_void_p] * 7 + [c_size_t, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
                          + [c_void_p] * 5 + [c_int] + [c_void_p] * 9 + [c_int] + [c_void_p] * 3),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
+    "madtp_gemm_pair": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_void_p]),
     "madtp_query_att_ft_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
 }
@@ -179,6 +180,21 @@ def gemm(a, w, bias=None, residual=None, out_dtype=None, act=ACT_NONE, n=None, o
     _check(load().madtp_gemm(_p(a), _p(w), _p(bias), _p(residual), _p(out), M, n, K, a.stride(0), w.stride(0),
                              out.stride(0), ldr, _dt(a), _dt(out), act, float(out_scale), _stream()), "madtp_gemm")
     return out
+
+
+def gemm_pair(a0, a1, w0, w1, bias0, bias1, n, out_dtype=None):
+    """(a0 @ w0^T + bias0, a1 @ w1^T + bias1): two GEMMs of identical shape in one launch where the kernel allows."""
+    for t, name in ((a0, "a0"), (a1, "a1"), (w0, "w0"), (w1, "w1")):
+        _req(t, name=name)
+    M, K = a0.shape
+    if a1.shape != a0.shape or w1.shape != w0.shape or a0.stride(0) != a1.stride(0) or a0.dtype != w0.dtype:
+        raise RuntimeError("gemm_pair: the two problems must have identical shapes and dtypes")
+    out_dtype = out_dtype or a0.dtype
+    c0 = torch.empty((M, n), device=a0.device, dtype=out_dtype)
+    c1 = torch.empty((M, n), device=a0.device, dtype=out_dtype)
+    _check(load().madtp_gemm_pair(_p(a0), _p(a1), _p(w0), _p(w1), _p(bias0), _p(bias1), _p(c0), _p(c1), M, n, K, a0.stride(0),
+                                  w0.stride(0), n, _dt(a0), _dt(c0), _stream()), "madtp_gemm_pair")
+    return c0, c1
 
 
 def layernorm(x, gamma, beta, eps, want_f32=True, want_bf16=False):

@@ -90,6 +90,20 @@ def test_gemm_wave_specialised(hip, M, N, K):
         assert torch.all(wide[:, :8] == 7.0) and torch.all(wide[:, 8 + N:] == 7.0)
 
 
+@pytest.mark.parametrize("M,N,K", [(5120, 1536, 768), (5043, 1536, 768), (300, 256, 768)])
+def test_gemm_pair(hip, M, N, K):
+    """madtp_gemm_pair: two problems in one wave-specialised launch (the first two shapes: 2 x 240 tiles, the second with a
+    ragged last row tile) or two plain launches (small shape) - either way bit-identical to two madtp_gemm calls."""
+    td = torch.bfloat16
+    a0, a1 = _rand(M, K, seed=1).to(td).cuda(), _rand(M, K, seed=2).to(td).cuda()
+    w0, w1 = _pad128(_rand(N, K, seed=3, scale=0.05)).to(td).cuda(), _pad128(_rand(N, K, seed=4, scale=0.05)).to(td).cuda()
+    b0, b1 = _rand(N, seed=5).cuda(), _rand(N, seed=6).cuda()
+    c0, c1 = hip.gemm_pair(a0, a1, w0, w1, b0, b1, N)
+    assert torch.equal(c0, hip.gemm(a0, w0, b0, n=N)) and torch.equal(c1, hip.gemm(a1, w1, b1, n=N))
+    ref = a1.double() @ w1[:N].double().t() + b1.double()
+    assert (c1.double() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("M,N,K,S", [(1280, 768, 3072, 4), (1280, 768, 1536, 4), (300, 768, 768, 2), (77, 768, 768, 12)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_gemm_splitk_ln(hip, M, N, K, S, dtype):
