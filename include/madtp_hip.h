@@ -112,6 +112,14 @@ int madtp_attention_indexed(const void* q, const void* k, const void* v, const i
                             int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo,
                             float scale, int io_dtype, void* stream);
 
+/* Two attention problems of identical shape, without the score side outputs, in ONE launch where the bf16 kernel allows
+ * (<= 256 keys), two madtp_attention_indexed launches otherwise.  The twin cross-attention branches of an NLVR text layer
+ * (nlvr_encoder.py:314-333: self0 attends to image 0, self1 to image 1). */
+int madtp_attention_pair(const void* q0, const void* q1, const void* k0, const void* k1, const void* v0, const void* v1,
+                         const int32_t* kv_batch_index, void* out0, void* out1, const float* add_mask0, const float* add_mask1,
+                         int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale, int io_dtype,
+                         void* stream);
+
 /* Alignment-guided token-importance score, per-sample threshold and survivor count
  * (Block.Reduce_token vit.py:125-145 == med.py:347-371 == nlvr_encoder.py:404-432 == clip/model.py:196-218).
  * n = N-1 patch tokens.  token_attn f32: element [b,t,c] at token_attn[b*ldt_batch + t*ldt_row + c], c < K (raw

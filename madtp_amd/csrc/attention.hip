@@ -27,6 +27,8 @@ struct AttnArgs {
     int B, H, Nq, Nk, ldq, ldk, ldv, ldo, nrt;
     float scale;
     const int* kvidx;  // optional: sample b reads K/V block kvidx[b] (cross-attention against a cache of encoder K/V)
+    // madtp_attention_pair (attn_bf16_kernel without scores only): a second problem of identical shape, blockIdx.y in [B, 2B)
+    const char* q2; const char* k2; const char* v2; char* out2; const float* mask2; int pair;
 };
 
 template <typename T> __device__ __forceinline__ f32x4 load4(const char* p);
@@ -246,7 +248,11 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
     const int wave = wave8 & 3, hp = wave8 >> 2;  // query-row tile within the workgroup, head parity group
     char* const ring = smem + hp * 2 * STAGE;
     const int l16 = lane & 15, g = lane >> 4;
-    const int b = blockIdx.y;
+    int b = blockIdx.y;
+    if (a.pair && b >= a.B) {  // second problem of a pair launch (the twin cross-attention branches of an NLVR text layer)
+        b -= a.B;
+        a.q = a.q2; a.k = a.k2; a.v = a.v2; a.out = a.out2; a.mask = a.mask2;
+    }
     const int bkv = a.kvidx ? a.kvidx[b] : b;  // K/V block of this sample
     const int rt = blockIdx.x * 4 + wave;
     const int i0 = rt * 16;
@@ -628,7 +634,7 @@ int launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
         gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
         if (gz > a.H) gz = a.H;
     }
-    hipLaunchKernelGGL((attn_bf16_kernel<NT, SCORES, HS>), dim3((a.Nq + 63) / 64, a.B, gz), dim3(256 * HS), lds, s, a);
+    hipLaunchKernelGGL((attn_bf16_kernel<NT, SCORES, HS>), dim3((a.Nq + 63) / 64, (!SCORES && a.pair) ? 2 * a.B : a.B, gz), dim3(256 * HS), lds, s, a);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
@@ -924,6 +930,7 @@ extern "C" int madtp_attention_indexed(const void* q, const void* k, const void*
     a.nrt = (Nq + 15) / 16;
     a.scale = scale;
     a.kvidx = kv_batch_index;
+    a.pair = 0; a.q2 = a.k2 = a.v2 = nullptr; a.out2 = nullptr; a.mask2 = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const bool scores = colsum_part != nullptr;
     if (Nk > 256) {  // long sequences (384^2 / 480^2 images): two-pass kernel, exact-f32 MFMA in both modes
@@ -938,6 +945,38 @@ extern "C" int madtp_attention_indexed(const void* q, const void* k, const void*
         return 0;
     }
     return scores ? dispatch_nt_bf16<true>(a, s) : dispatch_nt_bf16<false>(a, s);
+}
+
+// Two attention problems of identical shape (no score side outputs) in one launch when they run on the bf16 kernel for
+// <= 256 keys, two madtp_attention_indexed launches otherwise: the twin cross-attention branches of an NLVR text layer
+// (nlvr_encoder.py:314-333: self0 against image 0, self1 against image 1) are 6.7 us launches of 768 small workgroups each.
+extern "C" int madtp_attention_pair(const void* q0, const void* q1, const void* k0, const void* k1, const void* v0, const void* v1,
+                                    const int32_t* kv_batch_index, void* out0, void* out1, const float* add_mask0,
+                                    const float* add_mask1, int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo,
+                                    float scale, int io_dtype, void* stream) {
+    if (!q0 || !q1 || !k0 || !k1 || !v0 || !v1 || !out0 || !out1 || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
+    static int pair_env = -1;  // MADTP_ATTN_PAIR=0: always two launches (A/B runs)
+    if (pair_env < 0) { const char* e = getenv("MADTP_ATTN_PAIR"); pair_env = e ? atoi(e) : 1; }
+    const bool one = pair_env && io_dtype == MADTP_BF16 && Nk <= 256 && (!add_mask0) == (!add_mask1) && aligned16(q0) &&
+                     aligned16(q1) && aligned16(k0) && aligned16(k1) && aligned16(v0) && aligned16(v1) && (ldq * 2) % 16 == 0 &&
+                     (ldk * 2) % 16 == 0 && (ldv * 2) % 16 == 0;
+    if (!one) {
+        const int rc = madtp_attention_indexed(q0, k0, v0, kv_batch_index, out0, add_mask0, nullptr, nullptr, nullptr, B, H, Nq,
+                                               Nk, ldq, ldk, ldv, ldo, scale, io_dtype, stream);
+        if (rc) return rc;
+        return madtp_attention_indexed(q1, k1, v1, kv_batch_index, out1, add_mask1, nullptr, nullptr, nullptr, B, H, Nq, Nk, ldq,
+                                       ldk, ldv, ldo, scale, io_dtype, stream);
+    }
+    AttnArgs a;
+    a.q = (const char*)q0; a.k = (const char*)k0; a.v = (const char*)v0; a.out = (char*)out0; a.mask = add_mask0;
+    a.q2 = (const char*)q1; a.k2 = (const char*)k1; a.v2 = (const char*)v1; a.out2 = (char*)out1; a.mask2 = add_mask1;
+    a.pair = 1;
+    a.colsum = nullptr; a.p0 = nullptr; a.onorm = nullptr;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.nrt = (Nq + 15) / 16;
+    a.scale = scale;
+    a.kvidx = kv_batch_index;
+    return dispatch_nt_bf16<false>(a, (hipStream_t)stream);
 }
 
 #ifdef MADTP_TS_TIMING

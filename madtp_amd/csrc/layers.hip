@@ -369,20 +369,32 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
             if (both_here)
                 TRY(madtp_gemm_pair(enc0, enc1, w->ckv[0].w, w->ckv[1].w, w->ckv[0].b, w->ckv[1].b, s.kv, s.kv1, B * Nk,
                                     w->ckv[0].n, w->ckv[0].k, D, w->ckv[0].k, 2 * D, dt, dt, stream));
+            const char* kvp[2];
+            int ldkv[2];
             for (int br = 0; br < 2; ++br) {
                 const void* enc = br ? enc1 : enc0;
-                const float* em = w->variant_nlvr ? (br ? enc_mask1 : enc_mask0) : nullptr;
                 const char* kv = (const char*)(br ? kv_pre1 : kv_pre0);
+                ldkv[br] = (kv && kv_ld) ? kv_ld : 2 * D;
                 if (!kv) {
                     void* dst = br ? s.kv1 : s.kv;
                     if (!both_here) TRY(lin(enc, D, w->ckv[br], nullptr, 0, dst, 2 * D, B * Nk, dt, dt, MADTP_ACT_NONE, 1.f, stream));
                     kv = (const char*)dst;
                 }
-                const int ldkv = ((br ? kv_pre1 : kv_pre0) && kv_ld) ? kv_ld : 2 * D;
-                TRY(madtp_attention_indexed((const char*)s.q2 + (size_t)br * D * e, kv, kv + (size_t)D * e,
-                                            (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, (char*)s.cat + (size_t)br * D * e, em,
-                                            nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, 2 * D, ldkv, ldkv, 2 * D, w->scale,
-                                            dt, stream));
+                kvp[br] = kv;
+            }
+            const float* em0 = w->variant_nlvr ? enc_mask0 : nullptr;
+            const float* em1 = w->variant_nlvr ? enc_mask1 : nullptr;
+            if (ldkv[0] == ldkv[1] && (!kv_pre0) == (!kv_pre1)) {
+                // both branches in one launch ([c0|c1] side by side, ld 2D)
+                TRY(madtp_attention_pair(s.q2, (const char*)s.q2 + (size_t)D * e, kvp[0], kvp[1], kvp[0] + (size_t)D * e,
+                                         kvp[1] + (size_t)D * e, kv_pre0 ? kv_index : nullptr, s.cat, (char*)s.cat + (size_t)D * e,
+                                         em0, em1, B, w->heads, Lp, Nk, 2 * D, ldkv[0], ldkv[0], 2 * D, w->scale, dt, stream));
+            } else {
+                for (int br = 0; br < 2; ++br)
+                    TRY(madtp_attention_indexed((const char*)s.q2 + (size_t)br * D * e, kvp[br], kvp[br] + (size_t)D * e,
+                                                (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, (char*)s.cat + (size_t)br * D * e,
+                                                br ? em1 : em0, nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, 2 * D, ldkv[br],
+                                                ldkv[br], 2 * D, w->scale, dt, stream));
             }
             TRY(lin_ln(s.cat, 2 * D, w->cdense_fused, a32, w->fused_twin == 2 ? 1.f : 0.5f, w->ln_cross_g, w->ln_cross_b, s.att2,
                        dt == MADTP_BF16 ? s.attc : nullptr, M, dt, w->eps, s.part, stream));

@@ -67,6 +67,7 @@ _SIGS = {
                          + [c_void_p] * 5 + [c_int] + [c_void_p] * 9 + [c_int] + [c_void_p] * 3),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
     "madtp_gemm_pair": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_void_p]),
+    "madtp_attention_pair": (c_int, [c_void_p] * 11 + [c_int] * 8 + [c_float, c_int, c_void_p]),
     "madtp_query_att_ft_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
 }
@@ -257,6 +258,21 @@ def attention(q, k, v, B, H, Nq, Nk, scale, add_mask=None, scores=False):
                                   q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), _dt(q), _stream()),
            "madtp_attention")
     return out, side
+
+
+def attention_pair(q0, q1, k0, k1, v0, v1, B, H, Nq, Nk, scale, add_mask0=None, add_mask1=None):
+    """Two attention problems of identical shape (no score outputs) in one launch where the kernel allows -> (out0, out1)."""
+    for t in (q0, q1, k0, k1, v0, v1):
+        if not t.is_cuda or t.stride(1) != 1:
+            raise RuntimeError("attention operands must be GPU row-major views")
+    if q0.stride(0) != q1.stride(0) or k0.stride(0) != k1.stride(0) or v0.stride(0) != v1.stride(0):
+        raise RuntimeError("attention_pair: the two problems must share their leading dimensions")
+    out0 = torch.empty((B * Nq, H * 64), device=q0.device, dtype=q0.dtype)
+    out1 = torch.empty_like(out0)
+    _check(load().madtp_attention_pair(_p(q0), _p(q1), _p(k0), _p(k1), _p(v0), _p(v1), None, _p(out0), _p(out1), _p(add_mask0),
+                                       _p(add_mask1), B, H, Nq, Nk, q0.stride(0), k0.stride(0), v0.stride(0), out0.stride(0),
+                                       float(scale), _dt(q0), _stream()), "madtp_attention_pair")
+    return out0, out1
 
 
 def _ta_view(token_attn):

@@ -90,6 +90,23 @@ def test_gemm_wave_specialised(hip, M, N, K):
         assert torch.all(wide[:, :8] == 7.0) and torch.all(wide[:, 8 + N:] == 7.0)
 
 
+@pytest.mark.parametrize("dtype,Nq,Nk", [("bf16", 20, 84), ("bf16", 35, 190), ("bf16", 20, 577), ("f32", 20, 84)])
+def test_attention_pair(hip, dtype, Nq, Nk):
+    """madtp_attention_pair (one launch for bf16 / <= 256 keys, two launches otherwise) == two madtp_attention calls, with
+    different masks per branch and q / k|v given as column slices of fused projections."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    B, H, D = 5, 12, 768
+    q2 = _rand(B * Nq, 2 * D, seed=1).to(td).cuda()                      # [q0|q1]
+    kv0, kv1 = _rand(B * Nk, 2 * D, seed=2).to(td).cuda(), _rand(B * Nk, 2 * D, seed=3).to(td).cuda()  # [k|v] per branch
+    m0 = torch.zeros(B, Nk); m0[1, Nk // 2:] = -10000.0
+    m1 = torch.zeros(B, Nk); m1[3, 5:9] = -10000.0
+    m0, m1 = m0.cuda(), m1.cuda()
+    o0, o1 = hip.attention_pair(q2[:, :D], q2[:, D:], kv0[:, :D], kv1[:, :D], kv0[:, D:], kv1[:, D:], B, H, Nq, Nk, 0.125, m0, m1)
+    r0, _ = hip.attention(q2[:, :D], kv0[:, :D], kv0[:, D:], B, H, Nq, Nk, 0.125, add_mask=m0)
+    r1, _ = hip.attention(q2[:, D:], kv1[:, :D], kv1[:, D:], B, H, Nq, Nk, 0.125, add_mask=m1)
+    assert torch.equal(o0, r0) and torch.equal(o1, r1)
+
+
 @pytest.mark.parametrize("M,N,K", [(5120, 1536, 768), (5043, 1536, 768), (300, 256, 768)])
 def test_gemm_pair(hip, M, N, K):
     """madtp_gemm_pair: two problems in one wave-specialised launch (the first two shapes: 2 x 240 tiles, the second with a
