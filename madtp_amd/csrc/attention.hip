@@ -229,14 +229,19 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 //     per workgroup a 128-image batch of ~90-token sequences is only 256 workgroups - one wave per SIMD, every LDS /
 //     exp / cross-lane latency of the per-head chain exposed.  The two parity groups walk heads h = 0,2,4.. and 1,3,5..
 //     with their own K/V rings, two independent instruction streams per SIMD, and merge their head-max once at the end.
+//   * RB = 2 (scores variant, > 128 keys, HS = 1): the workgroup is 8 waves = TWO 64-row blocks on ONE K/V ring.  At 134 /
+//     197 keys a ring is 82 / 110 KiB, so only one workgroup fits a CU: with 64-row workgroups that is 4 waves per CU, 3-4
+//     workgroups per sample each re-reading the sample's K and V (310 MB at 197 tokens).  128 rows per workgroup halve
+//     the K/V traffic and put 8 waves on the CU.
 #ifdef MADTP_TS_TIMING
 __device__ long long g_attn_dbg[8];
 #define AT_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && it == 2) { __builtin_amdgcn_s_waitcnt(0); g_attn_dbg[i] = wall_clock64(); } } while (0)
 #else
 #define AT_MARK(i)
 #endif
-template <int NT, bool SCORES, int HS>
-__global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(AttnArgs a) {
+template <int NT, bool SCORES, int HS, int RB = 1>
+__global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void attn_bf16_kernel(AttnArgs a) {
+    static_assert(HS == 1 || RB == 1, "head-parity split and two row blocks are alternatives");
     constexpr int NKP = NT * 16;
     constexpr int NC = (NT + 1) / 2;          // 32-key chunks
     constexpr int VR = NC * 32;               // staged V rows (whole chunks)
@@ -245,7 +250,11 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave8 & 3, hp = wave8 >> 2;  // query-row tile within the workgroup, head parity group
+    const int wave = wave8 & 3;                    // query-row tile within its 64-row block
+    const int hp = HS == 2 ? wave8 >> 2 : 0;       // head parity group (HS = 2)
+    const int rb = RB == 2 ? wave8 >> 2 : 0;       // 64-row block within the workgroup (RB = 2)
+    constexpr int NSW = 4 * RB;                    // waves that stage one ring
+    const int swave = RB == 2 ? wave8 : wave;      // this wave's index among them
     char* const ring = smem + hp * 2 * STAGE;
     const int l16 = lane & 15, g = lane >> 4;
     int b = blockIdx.y;
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
         a.q = a.q2; a.k = a.k2; a.v = a.v2; a.out = a.out2; a.mask = a.mask2;
     }
     const int bkv = a.kvidx ? a.kvidx[b] : b;  // K/V block of this sample
-    const int rt = blockIdx.x * 4 + wave;
+    const int rt = (blockIdx.x * RB + rb) * 4 + wave;
     const int i0 = rt * 16;
     const bool active = i0 < a.Nq;
     const int irow = min(i0 + l16, a.Nq - 1);
@@ -281,11 +290,11 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
     const int sub = lane >> 3, pos = lane & 7;
     // per-lane source of every DMA instruction of this wave for head 0, computed ONCE (the 64-bit row arithmetic used to be
     // redone for each of the 6-14 instructions of every head); head h adds 128 bytes
-    constexpr int NDMA = ((NKP + VR) / 8 + 3) / 4;
+    constexpr int NDMA = ((NKP + VR) / 8 + NSW - 1) / NSW;
     const char* srcb[NDMA];
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
-        const int grp = wave + 4 * i;
+        const int grp = swave + NSW * i;
         const bool is_v = grp >= NKP / 8;
         int row = (is_v ? grp - NKP / 8 : grp) * 8 + sub;
         const int chunk = is_v ? (pos ^ (((row >> 1) & 3) << 1)) : (pos ^ (row & 7));
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(256 * HS, HS == 1 ? 2 : 1) void attn_bf16_kernel(At
         char* base = ring + st * STAGE;
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
-            const int grp = wave + 4 * i;
+            const int grp = swave + NSW * i;
             if (grp < (NKP + VR) / 8)
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(srcb[i] + h * 128), LDS_PTR(base + grp * 1024), 16, 0, 0);
         }
@@ -620,10 +629,11 @@ template <int NT, bool SCORES>
 int launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     constexpr int NC = (NT + 1) / 2;
     constexpr int HS = (SCORES && NT <= 8) ? 2 : 1;  // head-parity split: 4 rings must fit the 160 KiB of LDS
+    constexpr int RB = (SCORES && NT > 8) ? 2 : 1;   // two 64-row blocks per workgroup where only one ring fits a CU
     const size_t lds = (size_t)2 * HS * (NT * 16 + NC * 32) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_bf16_kernel<NT, SCORES, HS>,
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bf16_kernel<NT, SCORES, HS, RB>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -634,7 +644,8 @@ int launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
         gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
         if (gz > a.H) gz = a.H;
     }
-    hipLaunchKernelGGL((attn_bf16_kernel<NT, SCORES, HS>), dim3((a.Nq + 63) / 64, (!SCORES && a.pair) ? 2 * a.B : a.B, gz), dim3(256 * HS), lds, s, a);
+    hipLaunchKernelGGL((attn_bf16_kernel<NT, SCORES, HS, RB>), dim3((a.Nq + 64 * RB - 1) / (64 * RB), (!SCORES && a.pair) ? 2 * a.B : a.B, gz),
+                       dim3(256 * HS * RB), lds, s, a);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
