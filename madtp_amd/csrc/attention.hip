@@ -639,13 +639,17 @@ int launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
         attr_set = true;
     }
     int gz = 1;
+    size_t lds_used = lds;
     if (!SCORES) {
+        // cross-attention (few query rows per sample): below 512 workgroups every head gets its own workgroup - no head loop,
+        // so ONE ring stage is allocated and 2-6 workgroups share a CU (the two-stage ring of a 190-key problem is 98 KiB,
+        // one 4-wave workgroup per CU)
         const int wgs = ((a.Nq + 63) / 64) * a.B;
-        gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
-        if (gz > a.H) gz = a.H;
+        gz = wgs >= 512 ? 1 : a.H;
+        if (gz == a.H) lds_used = lds / 2;
     }
     hipLaunchKernelGGL((attn_bf16_kernel<NT, SCORES, HS, RB>), dim3((a.Nq + 64 * RB - 1) / (64 * RB), (!SCORES && a.pair) ? 2 * a.B : a.B, gz),
-                       dim3(256 * HS * RB), lds, s, a);
+                       dim3(256 * HS * RB), lds_used, s, a);
     MADTP_LAUNCH_CHECK();
     return 0;
 }

@@ -198,7 +198,7 @@ def _ref_attention(qkv, B, N, H, scale, mask=None):
     return o.transpose(1, 2).reshape(B * N, H * 64), p, colsum, p[:, :, 0, :], o.norm(dim=-1)
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 20, 12), (1, 1 + 16 * 4, 2), (2, 130, 12), (1, 256, 3), (2, 17, 1),
+@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 20, 12), (1, 1 + 16 * 4, 2), (2, 130, 12), (2, 180, 12), (1, 256, 3), (2, 17, 1),
                                    (1, 577, 12), (2, 901, 3), (1, 257, 2), (1, 1024, 1)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_self_attention_with_scores(hip, B, N, H, dtype):
