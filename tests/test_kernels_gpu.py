@@ -90,6 +90,22 @@ def test_gemm_wave_specialised(hip, M, N, K):
         assert torch.all(wide[:, :8] == 7.0) and torch.all(wide[:, 8 + N:] == 7.0)
 
 
+def test_gemm_wave_specialised_scalar_epilogue(hip):
+    """N = 100 (not a multiple of 8) on 60000 rows: the wave-specialised kernel with its scalar fallback epilogue (the shape of a
+    `x @ space_dict^T` product done as a plain GEMM), f32 and bf16 outputs, bias and residual."""
+    M, N, K = 60000, 100, 768
+    td = torch.bfloat16
+    a = _rand(M, K, seed=1).to(td).cuda()
+    w = _rand(N, K, seed=2, scale=0.05).to(td)
+    wp = _pad128(w.float()).to(td).cuda()
+    bias, res = _rand(N, seed=3).cuda(), _rand(M, N, seed=4).cuda()
+    core = a.double() @ w.cuda().double().t() + bias.double()
+    out = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
+    assert (out - (core.float() + res)).abs().max().item() < 1e-4 * max(1.0, core.abs().max().item())
+    out = hip.gemm(a, wp, bias, out_dtype=td, n=N)
+    assert (out.float() - core.float()).abs().max().item() < 1e-2 * max(1.0, core.abs().max().item())
+
+
 @pytest.mark.parametrize("dtype,Nq,Nk", [("bf16", 20, 84), ("bf16", 35, 190), ("bf16", 20, 577), ("f32", 20, 84)])
 def test_attention_pair(hip, dtype, Nq, Nk):
     """madtp_attention_pair (one launch for bf16 / <= 256 keys, two launches otherwise) == two madtp_attention calls, with
