@@ -92,7 +92,7 @@ def main():
     dist = torch.distributed if world > 1 else None
 
     from madtp_amd import build, harness, hip, runtime
-    if rank == 0 or not os.path.exists(build.LIB):
+    if rank == 0:  # one builder per node (the prebuilt .so normally travels with the snapshot: no-op); the others wait
         build.build(verbose=False)
     if dist is not None:
         dist.barrier()
