@@ -26,7 +26,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md.  f16x3: three f16 MFMA products per logical product, so the
+# roofline of the fp32-accurate GEMM in ALGORITHMIC flops (2MNK) is a third of the f16 dense peak.
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "f16x3": 2500.0 / 3.0}
+GEMM_DT = {"bf16": "bf16", "fp32": "f32", "f16x3": "f16s"}
 
 
 def load_calibration(batch, p=0.5):
@@ -75,7 +78,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3"])
+    ap.add_argument("--parity-steps", type=int, default=10, help="timed steps of the parity_mode leg (f16x3 precision)")
+    ap.add_argument("--parity-batch", type=int, default=0, help="samples of the index_match check (0 = --batch)")
     ap.add_argument("--batch", type=int, default=64, help="NLVR samples per GPU (2 images each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -144,21 +149,22 @@ def main():
     flops_sample = harness.nlvr_forward_flops(vit_lens, txt_lens)
     flops_full = harness.nlvr_forward_flops([197] * 12, [20] * 12)
 
-    cdt = torch.bfloat16 if args.precision == "bf16" else torch.float32
     roof = None
     if not args.no_gemm_events:
-        dt_name = "bf16" if args.precision == "bf16" else "f32"
+        dt_name = GEMM_DT[args.precision]
         ms_all, fl_all, cnt_all = gemm_summary(prof_rows, dt_name)
-        # dominant kernel: gemm_ws_kernel (bf16, M >= 4096) in the fast mode; gemm_kernel<float> in the parity mode
-        min_m = WS_MIN_M if args.precision == "bf16" else 0
+        # dominant kernel: gemm_ws_kernel (2-byte operand planes, M >= 4096) in the bf16 / f16x3 modes; gemm_kernel<float> in fp32
+        min_m = WS_MIN_M if args.precision != "fp32" else 0
         ms, fl, cnt = gemm_summary(prof_rows, dt_name, min_m)
         if ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
             pmc = pmc_traffic() if args.precision == "bf16" else None
             alg_bytes = sum(r["bytes"] for r in prof_rows if r["dtype"] == dt_name and r["M"] >= min_m)
-            kname = ("gemm_ws_kernel (all bf16 madtp_gemm launches with M >= 4096: ViT qkv/proj/fc1/fc2, cross-attention K/V)"
-                     if args.precision == "bf16" else "gemm_kernel<float> (madtp_gemm)")
+            kname = {"bf16": "gemm_ws_kernel (all bf16 madtp_gemm launches with M >= 4096: ViT qkv/proj/fc1/fc2, cross-attention K/V)",
+                     "f16x3": "gemm_ws_kernel<f16-split> (all madtp_gemm launches with M >= 4096; 3 f16 MFMA products per "
+                              "logical product: achieved/peak are in algorithmic 2MNK flops, peak = f16 dense / 3)",
+                     "fp32": "gemm_kernel<float> (madtp_gemm)"}[args.precision]
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": pmc.get("ws_hbm_bytes_per_launch") if pmc else None,
@@ -175,7 +181,8 @@ def main():
         "metric": "images/sec forward, BLIP-base NLVR2 p=0.5 b64; pruned-token index match",
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32", "f16x3": "f16x3 (fp32-accurate)"}[args.precision],
+        "data": "synthetic",
         "config": {"workload": "BLIP-base NLVR2 forward (BLIP_NLVR.forward(train=False)), p=0.5, 64 samples = 128 "
                                "images 224x224 + 20 text tokens per GPU, random-init weights",
                    "samples_per_gpu": args.batch, "images_per_gpu": 2 * args.batch, "temperature": T,
@@ -186,9 +193,35 @@ def main():
         "roofline": roof,
     }
 
+    if not args.no_parity:
+        # parity_mode leg: the SAME workload timed in the precision mode that carries the parity claim (f16x3: fp32-accurate
+        # GEMMs on the f16 MFMA, everything else the fp32 mode's kernels), same barrier / max-over-ranks protocol
+        pm = "f16x3"
+        with runtime.precision(pm), torch.no_grad():
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t2 = time.perf_counter()
+            for _ in range(args.parity_steps):
+                step()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            pel = time.perf_counter() - t2
+        pel = mdist.max_over_ranks(pel, device="cuda")
+        out["parity_mode"] = {"precision": pm, "value": round(images_per_step * args.parity_steps / pel, 1), "unit": "images/s",
+                              "ms_per_step": round(1e3 * pel / args.parity_steps, 3), "steps": args.parity_steps,
+                              "what": "same workload, every Linear as 3 f16 MFMA products of f16-split operands (fp32-accurate), "
+                                      "attention / LayerNorm / scores on the exact-f32 kernels; kept sets vs the oracle below"}
     if rank == 0 and world == 1:
         if not args.no_parity:
-            out["index_match"] = parity_report(model, harness, runtime, T, args.precision)
+            im = parity_report(model, harness, runtime, T, args.precision, B=args.parity_batch or args.batch)
+            out["index_match"] = im
+            out["parity_mode"]["index_match"] = im.get("f16x3")
+            out["parity_mode"]["index_match_batch"] = im["batch"]
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T)
     if rank == 0 and args.gemm_breakdown and not args.no_gemm_events:
@@ -217,18 +250,21 @@ def _match(mine, ref):
     return pairs, eq, jac
 
 
-def parity_report(model, harness, runtime, T, precision, B=8, seed=11):
-    """kept-token index match of the timed precision mode and of fp32 parity mode vs the CPU oracle on a small batch
-    (the oracle is the checker here, never the thing measured)."""
+def parity_report(model, harness, runtime, T, precision, B=64, seed=11):
+    """kept-token index match of the timed precision mode, the f16x3 mode and the fp32 mode vs the CPU oracle at the
+    HEADLINE batch (k = max_b count couples the samples of a batch, so a smaller batch is a different computation;
+    the oracle is the checker here, never the thing measured)."""
     from madtp_amd import specs
     from oracle import madtp_oracle as O
     images, text, targets = harness.nlvr_inputs(B, 224, 20, seed)
     W = specs.synth_weights(specs.blip_nlvr_shapes(224), 0)
     tr = {}
+    t_or0 = time.perf_counter()
     with torch.no_grad():
         ref_logits = O.blip_nlvr_forward(W, images.cpu(), text["input_ids"].cpu(), text["attention_mask"].cpu(), T, trace=tr)
-    rep = {"batch": B, "temperature": T, "oracle": "oracle/madtp_oracle.py (CPU fp32 restatement of the reference)"}
-    for mode in sorted({"fp32", precision}):
+    rep = {"batch": B, "temperature": T, "oracle": "oracle/madtp_oracle.py (CPU fp32 restatement of the reference)",
+           "oracle_forward_s": round(time.perf_counter() - t_or0, 2)}
+    for mode in sorted({"fp32", "f16x3", precision}):
         with runtime.precision(mode):
             logits, trace = harness.run_nlvr(model, images, text, targets, T)
         pairs = eq = 0
@@ -244,7 +280,7 @@ def parity_report(model, harness, runtime, T, precision, B=8, seed=11):
     with torch.no_grad():
         O.vit_forward(W, "visual_encoder.", images.cpu(), W["space_dict"], T, trace=vtr, layer_inputs=xs)
     venc = model.visual_encoder
-    for mode in sorted({"fp32", precision}):
+    for mode in sorted({"fp32", "f16x3", precision}):
         pairs = eq = 0
         jac = 0.0
         with runtime.precision(mode), torch.no_grad():

@@ -21,6 +21,11 @@ extern "C" {
 
 #define MADTP_F32 0
 #define MADTP_BF16 1
+/* f16-split operands of the fp32-accurate GEMM on the f16 MFMA ("f16x3" precision mode): an f32 matrix [R,K] stored as
+ * f16 planes side by side in a row - activations [P0 | P1] (2K f16 per row, P0 = f16(x), P1 = f16((x-P0) 2^11)), prepared
+ * weights [Q0 | Q1 | Q2] (3K f16 per row, scaled by the power of two in madtp_lin.w_scale); leading dimensions of such
+ * operands count f16 elements.  Written by madtp_split_f16 / the LayerNorm and GEMM epilogues, read by madtp_gemm. */
+#define MADTP_F16S 2
 
 #define MADTP_E_BADARG (-1)   /* null pointer / non-positive size                      */
 #define MADTP_E_SHAPE (-2)    /* shape outside what the kernel family supports          */
@@ -38,16 +43,18 @@ int madtp_abi_version(void);
 /* Human-readable name of a negative MADTP_E_* code. */
 const char* madtp_strerror(int code);
 
-/* C[M,N] = act(A[M,K] @ W[N,K]^T + bias[N]) * out_scale (+ residual[M,N])
+/* C[M,N] = act(acc_scale * (A[M,K] @ W[N,K]^T) + bias[N]) * out_scale (+ residual[M,N])
  * Replaces every nn.Linear on the path (aten::addmm): vit.py:31-35,77,92; med.py:153-171,246-250,312-329;
  * nlvr_encoder.py:259-266; models/utils.py:170 (x @ space_dict^T); blip_nlvr.py:57-61.
- * ab_dtype: dtype of A and W (F32 -> exact-f32 MFMA 16x16x4; BF16 -> MFMA 16x16x32 with f32 accumulate).
+ * ab_dtype: dtype of A and W (F32 -> exact-f32 MFMA 16x16x4; BF16 -> MFMA 16x16x32 with f32 accumulate; F16S -> the
+ * f16-split operands above: three f16 MFMA products per logical product, fp32-accurate; acc_scale = the weight's 2^-s).
  * W must be padded by the caller to a multiple of 128 rows (zero rows) - n_pad rows are read, N columns stored.
- * bias (f32, may be NULL), residual (f32 [M,ldr], may be NULL), C dtype c_dtype with leading dimension ldc.
- * K must be a multiple of 64 (bf16) / 32 (f32); lda, ldw in elements. */
+ * bias (f32, may be NULL), residual (f32 [M,ldr], may be NULL), C dtype c_dtype with leading dimension ldc
+ * (BF16 output needs BF16 operands, F16S output F16S operands; F32 output is always available).
+ * K must be a multiple of 64 (bf16, f16-split) / 32 (f32); lda, ldw in elements (f16 elements for F16S: >= 2K, >= 3K). */
 int madtp_gemm(const void* A, const void* W, const float* bias, const float* residual, void* C,
                int M, int N, int K, int lda, int ldw, int ldc, int ldr,
-               int ab_dtype, int c_dtype, int act, float out_scale, void* stream);
+               int ab_dtype, int c_dtype, int act, float acc_scale, float out_scale, void* stream);
 
 /* Split-K form for small-M projections (latency-bound at one workgroup per tile): part[s,M,N] (f32, contiguous) holds
  * the partial product of K range s; madtp_splitk_ln then computes
@@ -56,14 +63,16 @@ int madtp_gemm(const void* A, const void* W, const float* bias, const float* res
 int madtp_gemm_splitk(const void* A, const void* W, float* part, int M, int N, int K, int lda, int ldw, int splits,
                       int ab_dtype, void* stream);
 int madtp_splitk_ln(const float* part, int splits, const float* bias, const float* residual, const float* gamma,
-                    const float* beta, float* y32, void* ylp, int rows, int dim, float eps, float scale, void* stream);
+                    const float* beta, float* y32, void* ylp, int lp_dtype, int rows, int dim, float eps, float acc_scale,
+                    float scale, void* stream);
+/* (with acc_scale: y = LayerNorm(scale * (acc_scale * sum_s part[s] + bias) + residual); ylp in lp_dtype BF16 or F16S) */
 
 /* Two independent GEMMs of identical shape, leading dimensions and dtypes (C_i = A_i @ W_i^T + bias_i; bias0 and bias1 both
  * given or both NULL) in ONE launch when the shape runs on the wave-specialised bf16 kernel, two madtp_gemm launches otherwise.
  * Replaces the key/value nn.Linear pairs of the two cross-attention branches (nlvr_encoder.py:177-178 for self0 and self1). */
 int madtp_gemm_pair(const void* A0, const void* A1, const void* W0, const void* W1, const float* bias0, const float* bias1,
                     void* C0, void* C1, int M, int N, int K, int lda, int ldw, int ldc, int ab_dtype, int c_dtype,
-                    void* stream);
+                    float acc_scale0, float acc_scale1, void* stream);
 
 /* Optional profiling of madtp_gemm launches with HIP events recorded on the launch stream (bench.py roofline leg).
  * madtp_profile_begin() starts recording; madtp_profile_end() stops, waits for the events and writes one line per
@@ -72,9 +81,9 @@ int madtp_profile_begin(void);
 int madtp_profile_end(char* buf, int cap);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim (dim % 4 == 0, dim <= 1024); x is f32.
- * Writes y32 (f32, may be NULL) and/or ylp (bf16, may be NULL).
+ * Writes y32 (f32, may be NULL) and/or ylp (may be NULL; lp_dtype BF16: bf16 [rows,dim]; F16S: f16-split [rows,2*dim]).
  * vit.py:186,205,309 (eps 1e-6); med.py:79,249,328 (eps 1e-12); clip/model.py:160-166 (eps 1e-5). */
-int madtp_layernorm(const float* x, const float* gamma, const float* beta, float* y32, void* ylp,
+int madtp_layernorm(const float* x, const float* gamma, const float* beta, float* y32, void* ylp, int lp_dtype,
                     int rows, int dim, float eps, void* stream);
 
 /* im2col of non-overlapping patches for the patch-embedding GEMM (timm PatchEmbed Conv2d k=s=P, call site
@@ -86,9 +95,9 @@ int madtp_assemble_tokens(const float* patches, const float* cls, const float* p
                           int B, int np, int dim, void* stream);
 
 /* BERT embeddings: y = LayerNorm(word_emb[ids] + pos_emb[0..L))  (med.py:63-86 / nlvr_encoder.py:62-86).
- * ids int64 [B,L]; writes y32 (f32) and/or ylp (bf16). */
+ * ids int64 [B,L]; writes y32 (f32) and/or ylp (lp_dtype BF16 or F16S). */
 int madtp_bert_embed(const int64_t* ids, const float* word_emb, const float* pos_emb, const float* gamma,
-                     const float* beta, float* y32, void* ylp, int B, int L, int dim, float eps, void* stream);
+                     const float* beta, float* y32, void* ylp, int lp_dtype, int B, int L, int dim, float eps, void* stream);
 
 /* Multi-head attention core with the pruning-score side outputs.
  * q/k/v point at the first element of head 0 of token 0 for each operand; rows are tokens with row strides
@@ -166,7 +175,7 @@ int madtp_token_gather(const float* x, const int32_t* dst_pos, const float* merg
 /* The same with the following LayerNorm fused in (Block.norm2, vit.py:195): h32 and/or h_lp (compute dtype) receive
  * LayerNorm(y) row by row, bit-identical to madtp_layernorm(y); gamma == NULL: plain gather. */
 int madtp_token_gather_ln(const float* x, const int32_t* dst_pos, const float* merge_w, float* y, int B, int N, int k, int dim,
-                          const float* gamma, const float* beta, float eps, float* h32, void* h_lp, void* stream);
+                          const float* gamma, const float* beta, float eps, float* h32, void* h_lp, int lp_dtype, void* stream);
 
 /* Additive-mask compaction for the text encoders (nlvr_encoder.py:451-452,531-533; med.py:388-390,429-440):
  * out[b,0]=mask[b,0]; out[b,1+p] = mask[b,1+order[b,p]] for p in [0,k]  with order = indices_sort (NLVR, order2 = NULL);
@@ -211,6 +220,15 @@ int madtp_add_scale(const float* a, const float* b, float* out, float scale, siz
 /* f32 -> bf16 copy (weight preparation, activations entering a bf16 GEMM). */
 int madtp_cast_bf16(const float* src, void* dst, size_t n, void* stream);
 
+/* f32 [rows, K] (row stride ld_src) -> f16-split activation planes [rows, 2K] f16 (row stride ld_dst f16 elements):
+ * dst[r, c] = f16(x), dst[r, K + c] = f16((x - f16(x)) * 2^11).  Activations entering an F16S GEMM whose producer is not
+ * one of the fused epilogues (attention output, image tokens handed to the text encoder).  K % 4 == 0. */
+int madtp_split_f16(const float* src, int ld_src, void* dst, int ld_dst, int rows, int K, void* stream);
+
+/* Weight preparation for F16S GEMMs: w f32 [n, K] (row stride ldw) -> planes [Q0 | Q1 | Q2] f16 [n, 3K] of w * 2^s, with
+ * inv_scale = 2^s chosen by the caller as a power of two such that max|w| * 2^s <= 2^14 (madtp_lin.w_scale = 2^-s). */
+int madtp_split_f16_weight(const float* w, int ldw, void* dst, int n, int K, float inv_scale, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------------------
  * Layer-level entry points.  One call enqueues the kernel sequence of half a transformer layer (the host-side cut is
@@ -219,9 +237,10 @@ int madtp_cast_bf16(const float* src, void* dst, size_t n, void* stream);
  * Scratch comes from a caller-owned workspace of at least *_workspace() bytes (256-byte aligned base).
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct madtp_lin {
-    const void* w;  /* [n_pad, k] row-major, compute dtype */
+    const void* w;  /* [n_pad, k] row-major, compute dtype ([n_pad, 3k] f16 planes for MADTP_F16S) */
     const float* b; /* [n] or NULL */
     int n, k;
+    float w_scale;  /* accumulator scale of the prepared weight: 2^-s for F16S planes (w stored as w * 2^s), 1 otherwise */
 } madtp_lin;
 
 /* models/vit.py Block (:106-207): norm1, attn.qkv, attn.proj, norm2, mlp.fc1, mlp.fc2; also clip/model.py
@@ -230,7 +249,7 @@ typedef struct madtp_vit_block_w {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     float eps, scale; /* LayerNorm eps; attention scale head_dim^-0.5 */
     madtp_lin qkv, proj, fc1, fc2;
-    int heads, dim, dtype; /* dtype: MADTP_F32 (parity mode) or MADTP_BF16 (fast mode) */
+    int heads, dim, dtype; /* dtype: MADTP_F32 (parity mode), MADTP_F16S (fp32-accurate on the f16 MFMA) or MADTP_BF16 (fast mode) */
     int act;               /* MLP activation: MADTP_ACT_GELU_ERF (BLIP ViT) or MADTP_ACT_QUICK_GELU (CLIP) */
 } madtp_vit_block_w;
 

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import PreparedCache, compute_dtype, lin_of, require_gpu, as_f32_contig
+from .runtime import PreparedCache, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model
 
 
@@ -50,14 +50,7 @@ _KV_AHEAD = os.environ.get("MADTP_KV_AHEAD", "0") == "1"
 
 
 def _cast(x2d):
-    return x2d if compute_dtype() == torch.float32 else hip.cast_bf16(x2d)
-
-
-def _ln_dual(norm, x2d):
-    """post-LN: returns (f32 residual copy, compute-dtype GEMM operand)."""
-    bf = compute_dtype() == torch.bfloat16
-    y32, ybf = hip.layernorm(x2d, norm.weight, norm.bias, norm.eps, want_f32=True, want_bf16=bf)
-    return y32, (ybf if bf else y32)
+    return to_compute(x2d)
 
 
 class BertEmbeddings(nn.Module):
@@ -116,28 +109,6 @@ class BertSelfAttention(nn.Module):
     def save_cls_attn(self, c): self.cls_attn = c
     def get_cls_attn(self): return self.cls_attn
 
-    def run_self(self, hc2d, B, L, mask2d, want_scores):
-        """hc2d [B*L, 768] compute dtype -> (context [B*L,768] compute dtype, (key, value) views)."""
-        qkv = lin_of(self._cache, "qkv", [self.query, self.key, self.value])
-        C = self.all_head_size
-        y = hip.gemm(hc2d, qkv.w, qkv.b, n=qkv.n)
-        ctx, side = hip.attention(y[:, :C], y[:, C:2 * C], y[:, 2 * C:], B, self.num_attention_heads, L, L,
-                                  1.0 / math.sqrt(self.attention_head_size), add_mask=mask2d, scores=want_scores)
-        self.score_side = side
-        H, d = self.num_attention_heads, self.attention_head_size
-        kv = (y[:, C:2 * C].view(B, L, H, d).permute(0, 2, 1, 3), y[:, 2 * C:].view(B, L, H, d).permute(0, 2, 1, 3))
-        return ctx, kv
-
-    def run_cross(self, hc2d, B, L, enc_c2d, Nk, enc_mask2d):
-        q = lin_of(self._cache, "q", [self.query])
-        kv = lin_of(self._cache, "kv", [self.key, self.value])
-        C = self.all_head_size
-        qy = hip.gemm(hc2d, q.w, q.b, n=q.n)
-        kvy = hip.gemm(enc_c2d, kv.w, kv.b, n=kv.n)
-        ctx, _ = hip.attention(qy, kvy[:, :C], kvy[:, C:], B, self.num_attention_heads, L, Nk,
-                               1.0 / math.sqrt(self.attention_head_size), add_mask=enc_mask2d, scores=False)
-        return ctx
-
 
 class BertSelfOutput(nn.Module):
     """med.py:239-250; nlvr_encoder.py:240-271 (twin / merge)."""
@@ -158,27 +129,6 @@ class BertSelfOutput(nn.Module):
             self.merge = False
         self.twin = twin
         self._cache = PreparedCache()
-
-    def run(self, ctx, inp32):
-        """ctx: [M,768] (or a pair for twin) in the compute dtype; inp32: f32 residual -> (f32, compute dtype)."""
-        if self.twin:
-            d0 = lin_of(self._cache, "d0", [self.dense0])
-            d1 = lin_of(self._cache, "d1", [self.dense1])
-            if self.merge:  # nlvr_encoder.py:263-264: merge_layer(cat[dense0(c0), dense1(c1)])
-                mg = lin_of(self._cache, "mg", [self.merge_layer])
-                M = ctx[0].shape[0]
-                cat = torch.empty((M, 2 * d0.n), device=inp32.device, dtype=compute_dtype())
-                hip.gemm(ctx[0], d0.w, d0.b, n=d0.n, out=cat[:, :d0.n])
-                hip.gemm(ctx[1], d1.w, d1.b, n=d1.n, out=cat[:, d0.n:])
-                s = hip.gemm(cat, mg.w, mg.b, residual=inp32, out_dtype=torch.float32, n=mg.n)
-            else:  # :266 (h0+h1)/2, folded into the GEMM epilogues: 0.5*h0 + input, then 0.5*h1 + that
-                t = hip.gemm(ctx[0], d0.w, d0.b, residual=inp32, out_dtype=torch.float32, n=d0.n, out_scale=0.5)
-                s = hip.gemm(ctx[1], d1.w, d1.b, residual=t, out_dtype=torch.float32, n=d1.n, out_scale=0.5)
-        else:
-            d = lin_of(self._cache, "d", [self.dense])
-            s = hip.gemm(ctx, d.w, d.b, residual=inp32, out_dtype=torch.float32, n=d.n)
-        return _ln_dual(self.LayerNorm, s)
-
 
 def _fused_twin_output(co, fold_merge):
     """[W0 | W1] along K for the twin cross-attention output (nlvr_encoder.py:259-266).  Average layers: bias b0+b1,
@@ -358,7 +308,7 @@ class _BertLayerBase(nn.Module):
             w.ln_out_g, w.ln_out_b = self.output.LayerNorm.weight.data_ptr(), self.output.LayerNorm.bias.data_ptr()
             w.eps, w.scale = self.output.LayerNorm.eps, 1.0 / math.sqrt(sa.attention_head_size)
             w.heads, w.dim = sa.num_attention_heads, sa.all_head_size
-            w.dtype = hip.F32 if compute_dtype() == torch.float32 else hip.BF16
+            w.dtype = dtype_code()
             return (w, keep)
 
         return self._cache.get("w", params, build)[0]
@@ -399,8 +349,8 @@ class _BertLayerBase(nn.Module):
         # (fast mode: the bf16 copy of the layer output, emitted by the output LayerNorm, rides along on the returned tensor
         #  so the next layer does not cast its input again; it is only trusted for the very same, unmodified tensor)
         lp = getattr(hidden_states, "_madtp_lp", None)
-        if lp is not None and (lp[1] != hidden._version or hidden is not hidden_states or lp[0].shape != hidden.shape
-                               or compute_dtype() != torch.bfloat16):
+        if lp is not None and (lp[1] != hidden._version or hidden is not hidden_states or lp[0].shape[:-1] != hidden.shape[:-1]
+                               or compute_dtype() == torch.float32 or lp[0].dtype != compute_dtype()):
             lp = None
         y, mask_out, self.last_prune, ylp = hip.bert_layer(w, hidden, mask2d, token_attn, temperature if prune else 0, cross, enc0,
                                                            enc1, Nk, em0, em1, hidden_lp=lp[0] if lp else None,
@@ -441,12 +391,6 @@ class MedBertLayer(_BertLayerBase):
     """models/med.py BertLayer :332-467."""
     variant = "med"
 
-    def _cross(self, att32, attc, B, L, enc, enc_mask):
-        # med.py:197-199 ignores the encoder mask in cross-attention (`and not is_cross_attention`)
-        ca = self.crossattention
-        ctx = ca.self.run_cross(attc, B, L, self._enc_operand(enc), enc.shape[1], None)
-        return ca.output.run(ctx, att32)
-
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_value=None, output_attentions=False, mode=None, space_dict=None,
                 token_attn=None, reduce_num=0, temperature=0):
@@ -457,12 +401,6 @@ class MedBertLayer(_BertLayerBase):
 class NlvrBertLayer(_BertLayerBase):
     """models/nlvr_encoder.py BertLayer :385-559 (note the different positional order: space_dict is arg 3)."""
     variant = "nlvr"
-
-    def _cross(self, att32, attc, B, L, enc, enc_mask):
-        ca = self.crossattention
-        c0 = ca.self0.run_cross(attc, B, L, self._enc_operand(enc[0]), enc[0].shape[1], self._enc_mask2d(enc_mask[0]))
-        c1 = ca.self1.run_cross(attc, B, L, self._enc_operand(enc[1]), enc[1].shape[1], self._enc_mask2d(enc_mask[1]))
-        return ca.output.run([c0, c1], att32)
 
     def forward(self, hidden_states, attention_mask=None, space_dict=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_value=None, output_attentions=False, mode=None, token_attn=None,
@@ -555,7 +493,7 @@ class _BertEncoderBase(nn.Module):
                 sm = (ca.self0, ca.self1)[br] if ca.twin else ca.self
                 mods += [sm.key, sm.value]
             lin = lin_of(self._cache, ("kv_all", br), mods)
-            kvs.append(hip.gemm(self.layer[0]._enc_operand(enc), lin.w, lin.b, n=lin.n))
+            kvs.append(hip.gemm(self.layer[0]._enc_operand(enc), lin.w, lin.b, n=lin.n, out_dtype=attn_dtype()))
         return kvs, encs[0].shape[1], 2 * self.config.hidden_size
 
 
@@ -696,7 +634,7 @@ class EncoderKVCache:
         for l in bert_model.encoder.layer:
             sm = l.crossattention.self
             lin = lin_of(sm._cache, "kv", [sm.key, sm.value])
-            kv.append(hip.gemm(a, lin.w, lin.b, n=lin.n))
+            kv.append(hip.gemm(a, lin.w, lin.b, n=lin.n, out_dtype=attn_dtype()))  # the dtype the attention kernels read
         return EncoderKVCache(kv, Nk)
 
 

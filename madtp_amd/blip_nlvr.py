@@ -8,7 +8,7 @@ from torch import nn
 from . import hip
 from .bert import BertConfig
 from .nlvr_encoder import BertModel
-from .runtime import PreparedCache, compute_dtype, lin_of, require_gpu
+from .runtime import PreparedCache, compute_dtype, lin_of, require_gpu, to_compute
 from .vit import VisionTransformer
 
 ENC_TOKEN_ID = 30523  # tokenizer.enc_token_id ('[ENC]', models/blip.py:221-224)
@@ -88,7 +88,7 @@ class BLIP_NLVR(nn.Module):
         h = hidden_state.contiguous()
         l0 = lin_of(self._cache, "c0", [self.cls_head[0]])
         l2 = lin_of(self._cache, "c2", [self.cls_head[2]])
-        h = h if compute_dtype() == torch.float32 else hip.cast_bf16(h)
+        h = to_compute(h)
         h = hip.gemm(h, l0.w, l0.b, act=hip.ACT_RELU, n=l0.n)
         logits = hip.gemm(h, l2.w, l2.b, out_dtype=torch.float32, n=l2.n)  # :81
         for p in pending:

@@ -19,7 +19,7 @@ from .bert import BertConfig
 from .blip_nlvr import ENC_TOKEN_ID, create_vit
 from .bert import EncoderKVCache
 from .med import BertModel
-from .runtime import PreparedCache, compute_dtype, lin_of, require_gpu
+from .runtime import PreparedCache, compute_dtype, lin_of, require_gpu, to_compute
 
 
 class BLIP_Retrieval(nn.Module):
@@ -56,8 +56,7 @@ class BLIP_Retrieval(nn.Module):
     # ---- the small Linears of the evaluation path on the library GEMM ----
     def _linear(self, key, lin, x32):
         l = lin_of(self._cache, key, [lin])
-        a = x32 if compute_dtype() == torch.float32 else hip.cast_bf16(x32.contiguous())
-        return hip.gemm(a.contiguous(), l.w, l.b, out_dtype=torch.float32, n=l.n)
+        return hip.gemm(to_compute(x32.contiguous()), l.w, l.b, out_dtype=torch.float32, n=l.n)
 
     def project_image(self, cls_rows):
         return F.normalize(self._linear("vp", self.vision_proj, cls_rows), dim=-1)  # compress_retrieval_dtp.py:121-122

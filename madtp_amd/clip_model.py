@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import hip
-from .runtime import PreparedCache, compute_dtype, lin_of, prepare_linear, require_gpu, as_f32_contig
+from .runtime import PreparedCache, compute_dtype, dtype_code, lin_of, prepare_linear, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model
 
 
@@ -67,7 +67,7 @@ class ResidualAttentionBlock(nn.Module):
             w.eps, w.scale = self.ln_1.eps, (self.d_model // self.n_head) ** -0.5
             w.qkv, w.proj, w.fc1, w.fc2 = [hip.lin_struct(l) for l in lins]
             w.heads, w.dim = self.n_head, self.d_model
-            w.dtype = hip.F32 if compute_dtype() == torch.float32 else hip.BF16
+            w.dtype = dtype_code()
             w.act = hip.ACT_QUICK_GELU
             return (w, lins)
 
@@ -152,6 +152,5 @@ class VisionTransformer(nn.Module):
         cls, _ = hip.layernorm(cls, self.ln_post.weight, self.ln_post.bias, self.ln_post.eps)
         if self.proj is not None:  # x @ proj  :311-312
             pj = self._cache.get(("proj", cdt), [self.proj], lambda: prepare_linear([self.proj.t()], None, cdt))
-            a = cls if cdt == torch.float32 else hip.cast_bf16(cls)
-            cls = hip.gemm(a, pj.w, None, out_dtype=torch.float32, n=pj.n)
+            cls = hip.gemm(to_compute(cls), pj.w, None, out_dtype=torch.float32, n=pj.n)
         return cls, sd_img_ft_all

@@ -18,6 +18,31 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(
 typedef __bf16 hwbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 hwbf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// ---- f16-split ("x3") operands: fp32-accurate products on the f16 MFMA (dtype code MADTP_F16S) ---------------------------
+// An f32 matrix X[R, K] is stored as f16 planes side by side in one row.
+//   activations, 2 planes (row = [P0 | P1]: 2K f16 = the bytes of the f32 row):
+//       P0 = f16(x),  P1 = f16((x - P0) * 2^11)            ->  x = P0 + 2^-11 P1 to ~2^-24 relative (|x| < 65504)
+//   weights, pre-scaled per tensor by a power of two (w~ = w 2^s, max|w~| in (2^13, 2^14]), 3 planes (row = [Q0 | Q1 | Q2]):
+//       Q0 = f16(w~),  Q1 = f16(w~ - Q0),  Q2 = f16(Q0 2^-11)   (normal f16 numbers for every weight above 2^-17 of the maximum)
+// so that   x w~ = P0 Q1 + P1 Q2 + P0 Q0   (+ 2^-11 P1 Q1, dropped: < 2^-23 relative)
+// is THREE f16 MFMA products with exact partial products and f32 accumulation: 3/16 of the cost of the exact-f32 MFMA.
+constexpr float F16S_LO_SCALE = 2048.0f;  // 2^11
+__device__ __forceinline__ void split_f16x8(f32x4 a, f32x4 b, u32x4& p0, u32x4& p1) {
+    const f32x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const f16x8 h = __builtin_convertvector(v, f16x8);
+    const f32x8 r = (v - __builtin_convertvector(h, f32x8)) * F16S_LO_SCALE;  // v - h is exact in f32
+    const f16x8 l = __builtin_convertvector(r, f16x8);
+    p0 = __builtin_bit_cast(u32x4, h);
+    p1 = __builtin_bit_cast(u32x4, l);
+}
+__device__ __forceinline__ void split_f16x4(f32x4 v, f16x4& h, f16x4& l) {
+    h = __builtin_convertvector(v, f16x4);
+    l = __builtin_convertvector((v - __builtin_convertvector(h, f32x4)) * F16S_LO_SCALE, f16x4);
+}
 
 // round-to-nearest-even through the hardware converter (v_cvt_pk_bf16_f32 on gfx950)
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
@@ -172,8 +197,9 @@ __device__ __forceinline__ LnParams ln_params(const float* gamma, const float* b
     return p;
 }
 
+// ylp: row base of the low-precision copy - bf16 [dim], or (lp_f16s) the f16-split planes [P0 | P1] of 2*dim f16
 __device__ __forceinline__ void ln_store(const float4 (&v)[LN_MAX_CHUNKS], int lane, int dim, float mean, float rstd,
-                                         const LnParams& p, float* y32, bf16_t* ylp) {
+                                         const LnParams& p, float* y32, bf16_t* ylp, bool lp_f16s = false) {
 #pragma unroll
     for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
         const int col = (lane + 64 * c) * 4;
@@ -186,7 +212,14 @@ __device__ __forceinline__ void ln_store(const float4 (&v)[LN_MAX_CHUNKS], int l
         o.w = (v[c].w - mean) * rstd * gm.w + bt.w;
         if (y32) *(float4*)(y32 + col) = o;
         if (ylp) {
-            *(bf16x4*)(ylp + col) = pack_bf16x4((f32x4){o.x, o.y, o.z, o.w});
+            if (lp_f16s) {
+                f16x4 h, l;
+                split_f16x4((f32x4){o.x, o.y, o.z, o.w}, h, l);
+                *(f16x4*)(ylp + col) = h;
+                *(f16x4*)(ylp + dim + col) = l;
+            } else {
+                *(bf16x4*)(ylp + col) = pack_bf16x4((f32x4){o.x, o.y, o.z, o.w});
+            }
         }
     }
 }

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <map>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -34,7 +35,24 @@ struct GemmArgs {
     // madtp_gemm_pair (wave-specialised kernel only): a second problem of the same shape, tiles [ntm*ntn, 2*ntm*ntn)
     const char* A2; const char* W2; const float* bias2; void* C2; int pair;
     float out_scale;
+    float acc_scale;  // multiplies the raw accumulator before the bias: 2^-s of a pre-scaled f16-split weight, 1 otherwise
+    float acc_scale2; // the same for the second problem of a pair launch
 };
+
+// f16-split operands (common.h): the kernels walk the three plane products as ONE stream of 3 * K/64 slabs, small terms
+// first - pair p = slab / (K/64) multiplies activation plane x3_a_plane(p) with weight plane x3_w_plane(p).
+struct F16S {};  // operand tag of gemm_kernel<>
+__device__ __forceinline__ int x3_a_plane(int p) { return p == 1 ? 1 : 0; }                  // P0, P1, P0
+__device__ __forceinline__ int x3_w_plane(int p) { return p == 0 ? 1 : (p == 1 ? 2 : 0); }   // Q1, Q2, Q0
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// output modes of the epilogue
+constexpr int OM_F32 = 0, OM_BF16 = 1, OM_F16S = 2;
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
@@ -107,6 +125,7 @@ __device__ __forceinline__ float gelu_fast(float v) {
 }
 
 // compile-time activation: the epilogue is instantiated per activation code so it stays straight-line code
+// (LP_OUT here = the output is rounded to bf16 anyway: the cheap forms; f32 and f16-split outputs keep erff / expf)
 template <bool LP_OUT, int ACT>
 __device__ __forceinline__ float epi_act(float v) {
     if constexpr (ACT == MADTP_ACT_GELU_ERF) return LP_OUT ? gelu_fast(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
@@ -129,13 +148,13 @@ __device__ __forceinline__ int wfrag_row(int j, int rho) {
     return LP_OUT ? 32 * (j >> 1) + 8 * (rho >> 2) + 4 * (j & 1) + (rho & 3) : 16 * j + rho;
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 // HAS_RES: the residual is read by the epilogue itself (kernels that do not prefetch it into `res`); compile-time so
 // that the fast path below is straight-line code.
-template <bool LP_OUT, int ACT, bool HAS_RES, int FM, int FN, int BM, int BN, int RM, int RN>
+template <int OM, int ACT, bool HAS_RES, int FM, int FN, int BM, int BN, int RM, int RN>
 __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[FM][FN], const f32x4 (&res)[RM][RN],
                                          int m0, int n0, int wr, int wc, int l16, int grp4, size_t c_off) {
+    constexpr bool LP_OUT = OM != OM_F32;    // 8-consecutive-column fragment layout (wfrag_row<true>)
+    constexpr bool FAST_ACT = OM == OM_BF16;
     const bool c_bf16 = g.ldc < 0;
     const int ldc = c_bf16 ? -g.ldc : g.ldc;
             const int col_w = n0 + wc * (BN / 2);
@@ -210,16 +229,21 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[F
                             f32x4 v[NV];
 #pragma unroll
                             for (int u = 0; u < NV; ++u) {
-                                v[u] = acc[i][NV * jv + u] + bv[jv][u];
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[u][e] = epi_act<LP_OUT, ACT>(v[u][e]) * g.out_scale;
+                                for (int e = 0; e < 4; ++e)
+                                    v[u][e] = epi_act<FAST_ACT, ACT>(fmaf(acc[i][NV * jv + u][e], g.acc_scale, bv[jv][u][e])) * g.out_scale;
                                 if constexpr (RES_PREF && HAS_RES) v[u] += res[i][jv];
                                 if constexpr (RES_LOAD) v[u] += rv[ii][jv][u];
                             }
                             // rows past M fall outside the descriptor; columns past N are pushed outside it
                             const unsigned off = cok[jv] ? (unsigned)((16 * i + l16) * ldc + colv[jv]) * CSZ : 0x80000000u;
                             u32x4 bits;
-                            if constexpr (LP_OUT) bits = __builtin_bit_cast(u32x4, pack_bf16x8(v[0], v[1]));
+                            if constexpr (OM == OM_F16S) {
+                                // the two planes of the split output: P0 at column c, P1 at column N + c of the same row
+                                u32x4 lo_bits;
+                                split_f16x8(v[0], v[1], bits, lo_bits);
+                                __builtin_amdgcn_raw_buffer_store_b128(lo_bits, crsrc, cok[jv] ? off + (unsigned)g.N * 2u : off, 0, 0);
+                            } else if constexpr (OM == OM_BF16) bits = __builtin_bit_cast(u32x4, pack_bf16x8(v[0], v[1]));
                             else bits = __builtin_bit_cast(u32x4, v[0]);
                             __builtin_amdgcn_raw_buffer_store_b128(bits, crsrc, off, 0, 0);
                         }
@@ -238,18 +262,25 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[F
                         for (int i = 0; i < FM; ++i) {
                             const int row = m0 + wr * (BM / 2) + i * 16 + l16;
                             if (row >= g.M) continue;
-                            float v = epi_act<LP_OUT, ACT>(acc[i][j][r] + bv) * g.out_scale;
+                            float v = epi_act<FAST_ACT, ACT>(fmaf(acc[i][j][r], g.acc_scale, bv)) * g.out_scale;
                             if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
-                            if (c_bf16) ((bf16_t*)g.C)[(size_t)row * ldc + col] = f32_to_bf16(v);
-                            else ((float*)g.C)[(size_t)row * ldc + col] = v;
+                            const size_t ci = c_off + (size_t)row * ldc + col;  // c_off: the split-K partial slab of this slot
+                            if constexpr (OM == OM_F16S) {
+                                const _Float16 h = (_Float16)v;
+                                ((_Float16*)g.C)[ci] = h;
+                                ((_Float16*)g.C)[ci + g.N] = (_Float16)((v - (float)h) * F16S_LO_SCALE);
+                            } else if (c_bf16) ((bf16_t*)g.C)[ci] = f32_to_bf16(v);
+                            else ((float*)g.C)[ci] = v;
                         }
                     }
             }
 }
 
-template <typename T, bool LP_OUT, int BM, int BN, int STAGES>
+template <typename T, int OM, int BM, int BN, int STAGES>
 __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 1) void gemm_kernel(GemmArgs g) {
-    constexpr int ESZ = sizeof(T);
+    constexpr bool X3 = std::is_same<T, F16S>::value;  // f16-split operands: 3 plane products walked as one slab stream
+    constexpr bool LP_OUT = OM != OM_F32;
+    constexpr int ESZ = X3 ? 2 : (int)sizeof(T);
     constexpr int FM = BM / 32, FN = BN / 32;          // 16x16 fragments per wave (wave tile = BM/2 x BN/2)
     constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int PER = (BM + BN) / 32;                // LDS-DMA instructions per wave per slab
@@ -278,10 +309,9 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = g.K * ESZ / ROWB / S;  // slabs per slot
+    const int nkp = g.K * ESZ / ROWB;             // slabs per operand plane
+    const int nk = (X3 ? 3 : 1) * nkp / S;        // slabs per slot
     const int n_pad_max = g.ntn * BN - 1;
-    const bool c_bf16 = g.ldc < 0;  // sign bit of ldc carries the output dtype (see launcher)
-    const int ldc = c_bf16 ? -g.ldc : g.ldc;
 
     // LDS byte offsets of this lane's fragment rows (row*128) and their swizzle keys (row&7)
     int a_off[FM], a_key[FM], b_off[FN], b_key[FN];
@@ -313,8 +343,14 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
     auto issue_next = [&]() {
         if (issued < total_slabs && !(g.dbg & 2)) {
             char* st = smem + is_stage * STAGE_BYTES;
-            stage_tile<ESZ, BM>(g.A, im0, g.M - 1, g.lda, (ikb + is_kt) * ROWB, st, wave, lane);
-            stage_tile<ESZ, BN, LP_OUT>(g.W, in0, n_pad_max, g.ldw, (ikb + is_kt) * ROWB, st + A_BYTES, wave, lane);
+            int kba = (ikb + is_kt) * ROWB, kbw = kba;
+            if constexpr (X3) {
+                const int sl = ikb + is_kt, p = sl / nkp, kt = sl - p * nkp;
+                kba = (x3_a_plane(p) * g.K + kt * 64) * 2;
+                kbw = (x3_w_plane(p) * g.K + kt * 64) * 2;
+            }
+            stage_tile<ESZ, BM>(g.A, im0, g.M - 1, g.lda, kba, st, wave, lane);
+            stage_tile<ESZ, BN, LP_OUT>(g.W, in0, n_pad_max, g.ldw, kbw, st + A_BYTES, wave, lane);
         }
         ++issued;  // phantom slabs past the end keep the wait counts uniform (they issue nothing: see tail wait)
         if (++is_stage == STAGES) is_stage = 0;
@@ -376,7 +412,7 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
                     for (int i = 0; i < FM; ++i)
 #pragma unroll
                         for (int j = 0; j < FN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mfma_16x16x32<X3>(b[j], a[i], acc[i][j]);
                 } else {
                     f32x4 a[FM], b[FN];
 #pragma unroll
@@ -397,10 +433,10 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
         // ---- epilogue of tile (m0,n0): vectors straight from the accumulators ----
 #define EPI(ACT)                                                                                                  \
     if constexpr (LP_OUT) {                                                                                       \
-        epilogue<LP_OUT, ACT, false, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off);              \
+        epilogue<OM, ACT, false, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off);                  \
     } else {                                                                                                      \
-        if (g.residual) epilogue<LP_OUT, ACT, true, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off); \
-        else epilogue<LP_OUT, ACT, false, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off);         \
+        if (g.residual) epilogue<OM, ACT, true, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off);   \
+        else epilogue<OM, ACT, false, FM, FN, BM, BN>(g, acc, res, m0, n0, wr, wc, l16, grp4, c_off);             \
     }
         if (!((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {
             switch (g.act) {
@@ -456,8 +492,9 @@ __device__ __forceinline__ long long ws_now() {
 }
 #define WS_NOW() ws_now()
 #endif
-template <bool LP_OUT>
+template <bool X3, int OM>
 __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
+    constexpr bool LP_OUT = OM != OM_F32;
     constexpr int ESZ = 2, BM = 256, BN = 128, STAGES = 3, NCW = 8, NLW = 4;
     constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int PER = (BM + BN) / 8 / NLW;  // 1 KiB DMA instructions per loader wave per slab (12)
@@ -471,7 +508,8 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nk = g.K * ESZ / ROWB;
+    const int nkp = g.K * ESZ / ROWB;     // slabs per operand plane
+    const int nk = (X3 ? 3 : 1) * nkp;    // slabs per tile (f16-split: the three plane products back to back)
     const int my_slots = (nslots - lb + gl - 1) / gl;
     const long total_slabs = (long)my_slots * nk;
 
@@ -480,6 +518,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
         const int lw = wave - NCW, sub = lane >> 3;
         const int n_pad_max = g.ntn * BN - 1;
         int is_slot = lb, is_kt = 0, is_stage = 0;
+        int is_pair = 0, is_pk = 0;  // f16-split: plane pair of the next slab and its slab index within the plane
         long issued = 0;
         const char* srcp[PER];  // per-lane source of each DMA instruction at k = 0 of the current tile
         auto tile_ptrs = [&]() {
@@ -507,12 +546,23 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
         auto issue_next = [&]() {
             if (issued < total_slabs && !(g.dbg & 2)) {
                 char* st = smem + is_stage * STAGE_BYTES + lw * PER * 1024;
+                if constexpr (X3) {
+                    const int offa = (x3_a_plane(is_pair) * g.K + is_pk * 64) * 2, offw = (x3_w_plane(is_pair) * g.K + is_pk * 64) * 2;
 #pragma unroll
-                for (int q = 0; q < PER; ++q)
-                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(srcp[q] + is_kt * ROWB), LDS_PTR(st + q * 1024), 16, 0, 0);
+                    for (int q = 0; q < PER; ++q)
+                        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(srcp[q] + (lw * PER + q < BM / 8 ? offa : offw)),
+                                                         LDS_PTR(st + q * 1024), 16, 0, 0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < PER; ++q)
+                        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(srcp[q] + is_kt * ROWB), LDS_PTR(st + q * 1024), 16, 0, 0);
+                }
             }
             ++issued;
             if (++is_stage == STAGES) is_stage = 0;
+            if constexpr (X3) {
+                if (++is_pk == nkp) { is_pk = 0; if (++is_pair == 3) is_pair = 0; }
+            }
             if (++is_kt == nk) {
                 is_kt = 0;
                 is_slot += gl;
@@ -561,7 +611,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
     if (!(MADTP_WS_ABLATE & 4))                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(XB[j], XA[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_16x16x32<X3>(XB[j], XA[i], acc[i][j]);
 #ifdef MADTP_WS_TIMING
     long long ws_t_main = 0, ws_t_epi = 0, ws_tiles = 0;
     const long long ws_t_begin = WS_NOW();
@@ -579,7 +629,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[j], xa[i], zero4, 0, 0, 0);
+                    acc[i][j] = mfma_16x16x32<X3>(xb[j], xa[i], zero4);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): Y is in registers, this wave is done with the stage
             __builtin_amdgcn_sched_barrier(0);
@@ -613,13 +663,13 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
 #endif
         if (!((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {
             GemmArgs ge = g;  // (kernel arguments live in SGPRs: this is two scalar selects)
-            if (second) { ge.bias = g.bias2; ge.C = g.C2; }
+            if (second) { ge.bias = g.bias2; ge.C = g.C2; ge.acc_scale = g.acc_scale2; }
 #define EPI(ACT)                                                                                              \
     if constexpr (LP_OUT) {                                                                                   \
-        epilogue<LP_OUT, ACT, false, 4, 4, 128, 128>(ge, acc, res, m0, n0, wr, wc, l16, grp4, 0);              \
+        epilogue<OM, ACT, false, 4, 4, 128, 128>(ge, acc, res, m0, n0, wr, wc, l16, grp4, 0);                  \
     } else {                                                                                                  \
-        if (g.residual) epilogue<LP_OUT, ACT, true, 4, 4, 128, 128>(ge, acc, res, m0, n0, wr, wc, l16, grp4, 0); \
-        else epilogue<LP_OUT, ACT, false, 4, 4, 128, 128>(ge, acc, res, m0, n0, wr, wc, l16, grp4, 0);         \
+        if (g.residual) epilogue<OM, ACT, true, 4, 4, 128, 128>(ge, acc, res, m0, n0, wr, wc, l16, grp4, 0);   \
+        else epilogue<OM, ACT, false, 4, 4, 128, 128>(ge, acc, res, m0, n0, wr, wc, l16, grp4, 0);             \
     }
             switch (g.act) {
                 case MADTP_ACT_GELU_ERF: EPI(MADTP_ACT_GELU_ERF) break;
@@ -688,12 +738,12 @@ extern "C" int madtp_profile_end(char* buf, int cap) {
 }
 
 // second problem of a madtp_gemm_pair launch (same shape, leading dimensions and dtypes as the first)
-struct GemmPair { const void* A; const void* W; const float* bias; void* C; };
+struct GemmPair { const void* A; const void* W; const float* bias; void* C; float acc_scale; };
 constexpr int PAIR_UNSUPPORTED = 1000;  // internal: this shape does not run on the wave-specialised kernel
 
 static int gemm_launch(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
-                       int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float out_scale, int splitk,
-                       void* stream, const GemmPair* pair = nullptr);
+                       int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float acc_scale, float out_scale,
+                       int splitk, void* stream, const GemmPair* pair = nullptr);
 
 // Two independent GEMMs of identical shape (C_i = A_i @ W_i^T + bias_i) in ONE launch of the wave-specialised kernel: the
 // twin cross-attention branches of the NLVR text layers project their image tokens to [k|v] with two 240-tile problems, each
@@ -701,20 +751,22 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
 // Shapes the wave-specialised kernel does not take run as two madtp_gemm launches.
 extern "C" int madtp_gemm_pair(const void* A0, const void* A1, const void* W0, const void* W1, const float* bias0,
                                const float* bias1, void* C0, void* C1, int M, int N, int K, int lda, int ldw, int ldc,
-                               int ab_dtype, int c_dtype, void* stream) {
+                               int ab_dtype, int c_dtype, float acc_scale0, float acc_scale1, void* stream) {
     if (!A1 || !W1 || !C1 || (!bias0) != (!bias1)) return MADTP_E_BADARG;
-    const GemmPair p{A1, W1, bias1, C1};
-    int rc = gemm_launch(A0, W0, bias0, nullptr, C0, M, N, K, lda, ldw, ldc, 0, ab_dtype, c_dtype, MADTP_ACT_NONE, 1.f, 1, stream, &p);
+    const GemmPair p{A1, W1, bias1, C1, acc_scale1};
+    int rc = gemm_launch(A0, W0, bias0, nullptr, C0, M, N, K, lda, ldw, ldc, 0, ab_dtype, c_dtype, MADTP_ACT_NONE, acc_scale0, 1.f, 1,
+                         stream, &p);
     if (rc != PAIR_UNSUPPORTED) return rc;
-    rc = gemm_launch(A0, W0, bias0, nullptr, C0, M, N, K, lda, ldw, ldc, 0, ab_dtype, c_dtype, MADTP_ACT_NONE, 1.f, 1, stream);
+    rc = gemm_launch(A0, W0, bias0, nullptr, C0, M, N, K, lda, ldw, ldc, 0, ab_dtype, c_dtype, MADTP_ACT_NONE, acc_scale0, 1.f, 1, stream);
     if (rc) return rc;
-    return gemm_launch(A1, W1, bias1, nullptr, C1, M, N, K, lda, ldw, ldc, 0, ab_dtype, c_dtype, MADTP_ACT_NONE, 1.f, 1, stream);
+    return gemm_launch(A1, W1, bias1, nullptr, C1, M, N, K, lda, ldw, ldc, 0, ab_dtype, c_dtype, MADTP_ACT_NONE, acc_scale1, 1.f, 1,
+                       stream);
 }
 
 extern "C" int madtp_gemm(const void* A, const void* W, const float* bias, const float* residual, void* C,
                           int M, int N, int K, int lda, int ldw, int ldc, int ldr,
-                          int ab_dtype, int c_dtype, int act, float out_scale, void* stream) {
-    return gemm_launch(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, ab_dtype, c_dtype, act, out_scale, 1, stream);
+                          int ab_dtype, int c_dtype, int act, float acc_scale, float out_scale, void* stream) {
+    return gemm_launch(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, ab_dtype, c_dtype, act, acc_scale, out_scale, 1, stream);
 }
 
 // Split-K variant for small-M problems: part[s, M, N] (f32, contiguous) = A[:, Ks] @ W[:, Ks]^T for K range s of
@@ -722,25 +774,31 @@ extern "C" int madtp_gemm(const void* A, const void* W, const float* bias, const
 extern "C" int madtp_gemm_splitk(const void* A, const void* W, float* part, int M, int N, int K, int lda, int ldw, int splits,
                                  int ab_dtype, void* stream) {
     if (splits < 1) return MADTP_E_BADARG;
-    const int esz = ab_dtype == MADTP_BF16 ? 2 : 4;
-    if ((K * esz / ROWB) % splits) return MADTP_E_SHAPE;
-    return gemm_launch(A, W, nullptr, nullptr, part, M, N, K, lda, ldw, N, 0, ab_dtype, MADTP_F32, MADTP_ACT_NONE, 1.f, splits,
+    const int esz = ab_dtype == MADTP_F32 ? 4 : 2;
+    if (((ab_dtype == MADTP_F16S ? 3 : 1) * K * esz / ROWB) % splits) return MADTP_E_SHAPE;
+    return gemm_launch(A, W, nullptr, nullptr, part, M, N, K, lda, ldw, N, 0, ab_dtype, MADTP_F32, MADTP_ACT_NONE, 1.f, 1.f, splits,
                        stream);
 }
 
 static int gemm_launch(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
-                       int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float out_scale, int splitk,
-                       void* stream, const GemmPair* pair) {
+                       int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float acc_scale, float out_scale,
+                       int splitk, void* stream, const GemmPair* pair) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return MADTP_E_BADARG;
-    if (ab_dtype != MADTP_F32 && ab_dtype != MADTP_BF16) return MADTP_E_DTYPE;
-    if (c_dtype != MADTP_F32 && c_dtype != MADTP_BF16) return MADTP_E_DTYPE;
-    const int esz = ab_dtype == MADTP_BF16 ? 2 : 4;
+    if (ab_dtype != MADTP_F32 && ab_dtype != MADTP_BF16 && ab_dtype != MADTP_F16S) return MADTP_E_DTYPE;
+    if (c_dtype != MADTP_F32 && c_dtype != MADTP_BF16 && c_dtype != MADTP_F16S) return MADTP_E_DTYPE;
+    const bool x3 = ab_dtype == MADTP_F16S;
+    if (c_dtype == MADTP_F16S && !x3) return MADTP_E_DTYPE;  // the split epilogue exists on the f16-split kernels only
+    if (c_dtype == MADTP_BF16 && x3) return MADTP_E_DTYPE;
+    const int esz = ab_dtype == MADTP_F32 ? 4 : 2;
     if ((K * esz) % ROWB != 0) return MADTP_E_SHAPE;
     if (!aligned16(A) || !aligned16(W) || (lda * esz) % 16 || (ldw * esz) % 16) return MADTP_E_ALIGN;
-    if (lda < K || ldw < K || ldc < N || (residual && ldr < N)) return MADTP_E_SHAPE;
+    // f16-split operands: leading dimensions count f16 elements (2 planes of K per activation row, 3 per weight row)
+    if (lda < (x3 ? 2 : 1) * K || ldw < (x3 ? 3 : 1) * K || ldc < (c_dtype == MADTP_F16S ? 2 : 1) * N || (residual && ldr < N))
+        return MADTP_E_SHAPE;
     GemmArgs g;
     g.A = (const char*)A; g.W = (const char*)W; g.bias = bias; g.residual = residual; g.C = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.act = act; g.out_scale = out_scale;
+    g.acc_scale = acc_scale; g.acc_scale2 = pair ? pair->acc_scale : acc_scale;
     g.ldc = c_dtype == MADTP_BF16 ? -ldc : ldc;
     static int dbg = -1, force_cfg = -1;
     if (dbg < 0) { const char* e = getenv("MADTP_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
@@ -767,31 +825,31 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     int cfg = 0;
     const int t256 = ((M + 255) / 256) * ((N + 127) / 128);
     const bool big = M >= 4096 && t256 >= 200;
-    if (ab_dtype == MADTP_BF16 && !big) {
+    const bool lp16 = ab_dtype != MADTP_F32;  // 2-byte operand planes: bf16, or f16-split (three times the slab stream)
+    if (lp16 && !big) {
         const int t64 = ((M + 63) / 64) * ((N + 63) / 64) * splitk, t64x128 = ((M + 63) / 64) * ((N + 127) / 128) * splitk;
         if (t64 <= 768) cfg = 3;
         else if (t64x128 <= 768) cfg = 1;
     }
     // MADTP_GEMM_CFG=5 forces the wave-specialised kernel, 1..4 force a gemm_kernel variant (A/B measurements)
-    bool ws_ok = ab_dtype == MADTP_BF16 && splitk == 1 &&
+    bool ws_ok = lp16 && splitk == 1 &&
                  (force_cfg == 5 || (force_cfg == 0 && M >= 4096 && (big || cfg == 0)));
     if (pair) {
         static int pair_env = -1;  // MADTP_GEMM_PAIR=0: always two launches (A/B runs)
         if (pair_env < 0) { const char* e = getenv("MADTP_GEMM_PAIR"); pair_env = e ? atoi(e) : 1; }
-        ws_ok = pair_env && ab_dtype == MADTP_BF16 && force_cfg == 0 && M >= 4096 && 2 * t256 >= 200 && g.fast_epi &&
+        ws_ok = pair_env && lp16 && force_cfg == 0 && M >= 4096 && 2 * t256 >= 200 && g.fast_epi &&
                 aligned16(pair->A) && aligned16(pair->W) && aligned16(pair->C) && (!pair->bias || aligned16(pair->bias));
         if (!ws_ok) return PAIR_UNSUPPORTED;
         g.pair = 1; g.A2 = (const char*)pair->A; g.W2 = (const char*)pair->W; g.bias2 = pair->bias; g.C2 = pair->C;
     }
     if (force_cfg > 0 && force_cfg <= 4) cfg = force_cfg - 1;
     hipStream_t s = (hipStream_t)stream;
-    const bool lp = c_dtype == MADTP_BF16;
     GemmRecord rec;
     if (g_prof_on) {
         (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
         rec.flops = 2.0 * M * N * K; rec.dt = ab_dtype; rec.M = M; rec.N = N; rec.K = K;
         // algorithmic HBM bytes: A and W once, C once (x splits), bias, residual once
-        rec.bytes = (double)esz * ((double)M * K + (double)N * K) + (double)M * N * (c_dtype == MADTP_BF16 ? 2 : 4) * splitk +
+        rec.bytes = (double)esz * ((x3 ? 2.0 : 1.0) * M * K + (x3 ? 3.0 : 1.0) * N * K) + (double)M * N * (c_dtype == MADTP_BF16 ? 2 : 4) * splitk +
                     (bias ? 4.0 * N : 0.0) + (residual ? 4.0 * M * N : 0.0);
         if (pair) { rec.flops *= 2.0; rec.bytes *= 2.0; }  // two problems in this launch
         (void)hipEventRecord(rec.e0, s);
@@ -838,18 +896,27 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         const size_t lds = (size_t)3 * (256 + 128) * ROWB;
         static bool attr_ws = false;
         if (!attr_ws) {
-            hipError_t e1 = hipFuncSetAttribute((const void*)gemm_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipError_t e2 = hipFuncSetAttribute((const void*)gemm_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e1 != hipSuccess) return (int)e1;
-            if (e2 != hipSuccess) return (int)e2;
+            const void* fns[4] = {(const void*)gemm_ws_kernel<false, OM_BF16>, (const void*)gemm_ws_kernel<false, OM_F32>,
+                                  (const void*)gemm_ws_kernel<true, OM_F16S>, (const void*)gemm_ws_kernel<true, OM_F32>};
+            for (const void* fn : fns) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+            }
             attr_ws = true;
         }
-        if (lp) hipLaunchKernelGGL(gemm_ws_kernel<true>, dim3(grid), dim3(768), lds, s, g);
-        else hipLaunchKernelGGL(gemm_ws_kernel<false>, dim3(grid), dim3(768), lds, s, g);
+        if (x3) {
+            if (c_dtype == MADTP_F16S) hipLaunchKernelGGL((gemm_ws_kernel<true, OM_F16S>), dim3(grid), dim3(768), lds, s, g);
+            else hipLaunchKernelGGL((gemm_ws_kernel<true, OM_F32>), dim3(grid), dim3(768), lds, s, g);
+        } else {
+            if (c_dtype == MADTP_BF16) hipLaunchKernelGGL((gemm_ws_kernel<false, OM_BF16>), dim3(grid), dim3(768), lds, s, g);
+            else hipLaunchKernelGGL((gemm_ws_kernel<false, OM_F32>), dim3(grid), dim3(768), lds, s, g);
+        }
     } else if (ab_dtype == MADTP_BF16) {
-        if (lp) MADTP_DISPATCH_CFG(bf16_t, true); else MADTP_DISPATCH_CFG(bf16_t, false);
+        if (c_dtype == MADTP_BF16) MADTP_DISPATCH_CFG(bf16_t, OM_BF16); else MADTP_DISPATCH_CFG(bf16_t, OM_F32);
+    } else if (x3) {
+        if (c_dtype == MADTP_F16S) MADTP_DISPATCH_CFG(F16S, OM_F16S); else MADTP_DISPATCH_CFG(F16S, OM_F32);
     } else {
-        if (lp) MADTP_DISPATCH_CFG(float, true); else MADTP_DISPATCH_CFG(float, false);
+        if (c_dtype == MADTP_BF16) MADTP_DISPATCH_CFG(float, OM_BF16); else MADTP_DISPATCH_CFG(float, OM_F32);
     }
     if (g_prof_on) {
         (void)hipEventRecord(rec.e1, s);

@@ -19,7 +19,14 @@ struct Carver {
     bool fits() const { return !base || off <= cap; }
 };
 
+// bytes per logical element of an activation in compute dtype dt (F16S: two f16 planes = 4 bytes, like f32)
 inline size_t esz_of(int dt) { return dt == MADTP_BF16 ? 2 : 4; }
+// physical leading dimension of an operand with logical row length ld (f16-split rows hold 2 planes)
+inline int pld(int dt, int ld) { return dt == MADTP_F16S ? 2 * ld : ld; }
+// dtype the attention kernels run in: the f16-split mode keeps attention on the exact-f32 kernels (q/k/v/out f32)
+inline int attn_dt(int dt) { return dt == MADTP_F16S ? MADTP_F32 : dt; }
+// 128-byte K slabs a GEMM with operand dtype dt walks
+inline int slabs_of(int K, int dt) { return dt == MADTP_F32 ? K / 32 : (dt == MADTP_F16S ? 3 : 1) * K / 64; }
 
 #define TRY(call)                  \
     do {                           \
@@ -27,23 +34,32 @@ inline size_t esz_of(int dt) { return dt == MADTP_BF16 ? 2 : 4; }
         if (rc__ != 0) return rc__; \
     } while (0)
 
+// lda / ldc: LOGICAL row lengths (elements of the f32 matrix); split operands get their physical stride here
 inline int lin(const void* a, int lda, const madtp_lin& L, const float* residual, int ldr, void* c, int ldc, int M,
                int dt, int c_dt, int act, float scale, void* stream) {
-    return madtp_gemm(a, L.w, L.b, residual, c, M, L.n, L.k, lda, L.k, ldc, ldr, dt, c_dt, act, scale, stream);
+    return madtp_gemm(a, L.w, L.b, residual, c, M, L.n, L.k, pld(dt, lda), (dt == MADTP_F16S ? 3 : 1) * L.k, pld(c_dt, ldc), ldr,
+                      dt, c_dt, act, L.w_scale, scale, stream);
 }
 
 // LayerNorm into the compute dtype (and optionally an f32 copy)
 inline int ln_to(const float* x, const float* g, const float* b, float* y32, void* yc, int rows, int dim, float eps, int dt,
                  void* stream) {
-    if (dt == MADTP_F32) return madtp_layernorm(x, g, b, (float*)yc, nullptr, rows, dim, eps, stream);  // yc doubles as y32
-    return madtp_layernorm(x, g, b, y32, yc, rows, dim, eps, stream);
+    if (dt == MADTP_F32) return madtp_layernorm(x, g, b, (float*)yc, nullptr, MADTP_BF16, rows, dim, eps, stream);  // yc doubles as y32
+    return madtp_layernorm(x, g, b, y32, yc, dt, rows, dim, eps, stream);
+}
+
+// f32 [rows, dim] (contiguous rows of ld_src) -> the compute dtype's GEMM operand format (bf16 cast or f16 split)
+inline int to_lp(const float* src, int ld_src, void* dst, int rows, int dim, int dt, void* stream) {
+    if (dt == MADTP_F16S) return madtp_split_f16(src, ld_src, dst, 2 * dim, rows, dim, stream);
+    if (ld_src != dim) return MADTP_E_SHAPE;
+    return madtp_cast_bf16(src, dst, (size_t)rows * dim, stream);
 }
 
 // split-K factor for a small-M projection that feeds a LayerNorm: only when the tile count leaves most CUs idle and the
 // K loop is long enough that cutting it beats the extra partial traffic (S*M*N*4 bytes written and re-read)
 inline int choose_splits(int M, int N, int K, int dt) {
-    const int nk = (int)(K * esz_of(dt) / 128);
-    if (dt == MADTP_BF16 && M < 4096) {
+    const int nk = slabs_of(K, dt);
+    if (dt != MADTP_F32 && M < 4096) {
         // small bf16 problem: madtp_gemm runs it on 64x64 tiles, 3 workgroups per CU; split K while the grid still fits
         // one round (768 workgroups) and every split keeps >= 12 slabs
         const int t64 = ((M + 63) / 64) * ((N + 63) / 64);
@@ -64,12 +80,14 @@ inline int choose_splits(int M, int N, int K, int dt) {
 inline int lin_ln(const void* a, int lda, const madtp_lin& L, const float* residual, float scale, const float* gamma,
                   const float* beta, float* y32, void* ylp, int M, int dt, float eps, float* part, void* stream) {
     const int S = choose_splits(M, L.n, L.k, dt);
+    const int ldw = (dt == MADTP_F16S ? 3 : 1) * L.k;
     if (S > 1) {
-        TRY(madtp_gemm_splitk(a, L.w, part, M, L.n, L.k, lda, L.k, S, dt, stream));
-        return madtp_splitk_ln(part, S, L.b, residual, gamma, beta, y32, ylp, M, L.n, eps, scale, stream);
+        TRY(madtp_gemm_splitk(a, L.w, part, M, L.n, L.k, pld(dt, lda), ldw, S, dt, stream));
+        return madtp_splitk_ln(part, S, L.b, residual, gamma, beta, y32, ylp, dt, M, L.n, eps, L.w_scale, scale, stream);
     }
-    TRY(madtp_gemm(a, L.w, L.b, residual, part, M, L.n, L.k, lda, L.k, L.n, L.n, dt, MADTP_F32, MADTP_ACT_NONE, scale, stream));
-    return madtp_layernorm(part, gamma, beta, y32, ylp, M, L.n, eps, stream);
+    TRY(madtp_gemm(a, L.w, L.b, residual, part, M, L.n, L.k, pld(dt, lda), ldw, L.n, L.n, dt, MADTP_F32, MADTP_ACT_NONE, L.w_scale,
+                   scale, stream));
+    return madtp_layernorm(part, gamma, beta, y32, ylp, dt, M, L.n, eps, stream);
 }
 
 struct VitWs {
@@ -151,15 +169,19 @@ static int vit_attn_impl(const madtp_vit_block_w* w, const float* x, float* x_ou
     bool ok;
     VitWs s = vit_carve((char*)ws, ws_bytes, B, N, w->dim, w->fc1.n, w->heads, w->dtype, &ok);
     if (!ok) return MADTP_E_SHAPE;
-    const int M = B * N, D = w->dim, dt = w->dtype;
-    const size_t e = esz_of(dt);
+    const int M = B * N, D = w->dim, dt = w->dtype, adt = attn_dt(dt);
+    const size_t e = esz_of(adt);
     const bool prune = temperature > 0.f;
     if (prune && (!token_attn || !score || !threshold || !count)) return MADTP_E_BADARG;
     TRY(ln_to(x, w->ln1_g, w->ln1_b, nullptr, s.h, M, D, w->eps, dt, stream));
-    TRY(lin(s.h, D, w->qkv, nullptr, 0, s.qkv, 3 * D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+    TRY(lin(s.h, D, w->qkv, nullptr, 0, s.qkv, 3 * D, M, dt, adt, MADTP_ACT_NONE, 1.f, stream));
     const char* q = (const char*)s.qkv;
     TRY(madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.o, nullptr, prune ? s.colsum : nullptr, s.p0, s.onorm,
-                        B, w->heads, N, N, 3 * D, 3 * D, 3 * D, D, w->scale, dt, stream));
+                        B, w->heads, N, N, 3 * D, 3 * D, 3 * D, D, w->scale, adt, stream));
+    if (dt == MADTP_F16S) {  // the projection GEMM takes the attention output as f16 planes (s.h is free again)
+        TRY(to_lp((const float*)s.o, D, s.h, M, D, dt, stream));
+        s.o = s.h;
+    }
     if (prune && k_host) {
         // k = max_b count is delivered through pinned host memory.  token_score only needs the attention statistics, so it
         // is launched BEFORE the projection GEMM and the host waits for k while that GEMM runs.
@@ -206,7 +228,7 @@ extern "C" int madtp_vit_block_mlp(const madtp_vit_block_w* w, const float* x, f
         TRY(madtp_token_select(score, k, indices, indices_sort, s.dst_pos, s.merge_w, B, N - 1, stream));
         // gather + merge with norm2 fused in: the copying wave holds the row, so it emits LN(row) as well
         TRY(madtp_token_gather_ln(x, s.dst_pos, s.merge_w, s.xp, B, N, k, D, w->ln2_g, w->ln2_b, w->eps,
-                                  dt == MADTP_F32 ? (float*)s.h : nullptr, dt == MADTP_F32 ? nullptr : s.h, stream));
+                                  dt == MADTP_F32 ? (float*)s.h : nullptr, dt == MADTP_F32 ? nullptr : s.h, dt, stream));
         xr = s.xp;
         Np = k + 2;
     }
@@ -250,7 +272,7 @@ extern "C" int madtp_query_model(const float* x, const void* sd_w, const void* s
     } else {
         if (!sd_w) return MADTP_E_BADARG;
         TRY(madtp_gemm(x, sd_w, nullptr, nullptr, token_attn_full, B * N, kp, dim, dim, dim, kp, 0, MADTP_F32, MADTP_F32,
-                       MADTP_ACT_NONE, 1.f, stream));
+                       MADTP_ACT_NONE, 1.f, 1.f, stream));
     }
     if (att_ft)
         TRY(madtp_query_att_ft(token_attn_full + kp, kp, N * kp, K, x + dim, dim, N * dim, att_ft, inv_sqrt_sd, accumulate, B,
@@ -272,23 +294,27 @@ static int bert_attn_impl(const madtp_bert_layer_w* w, const float* hidden, cons
     bool ok;
     BertWs s = bert_carve((char*)ws, ws_bytes, B, L, Nk, w->dim, w->inter.n, w->heads, w->dtype, &ok);
     if (!ok) return MADTP_E_SHAPE;
-    const int M = B * L, D = w->dim, dt = w->dtype;
-    const size_t e = esz_of(dt);
+    const int M = B * L, D = w->dim, dt = w->dtype, adt = attn_dt(dt);
+    const size_t e = esz_of(adt);
     const bool prune = temperature > 0.f;
     if (prune && (!token_attn || !score || !threshold || !count || !mask2d)) return MADTP_E_BADARG;
     const void* hc = hidden;
-    if (dt == MADTP_BF16) {
-        if (hidden_lp) hc = hidden_lp;  // the previous layer's LayerNorm already emitted the bf16 copy
+    if (dt != MADTP_F32) {
+        if (hidden_lp) hc = hidden_lp;  // the previous layer's LayerNorm already emitted the compute-dtype copy
         else {
-            TRY(madtp_cast_bf16(hidden, s.hc, (size_t)M * D, stream));
+            TRY(to_lp(hidden, D, s.hc, M, D, dt, stream));
             hc = s.hc;
         }
     }
-    void* att_lp = dt == MADTP_BF16 ? s.attc : nullptr;  // bf16 copy of att for the second half (same workspace)
-    TRY(lin(hc, D, w->qkv, nullptr, 0, s.qkv, 3 * D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+    void* att_lp = dt != MADTP_F32 ? s.attc : nullptr;  // compute-dtype copy of att for the second half (same workspace)
+    TRY(lin(hc, D, w->qkv, nullptr, 0, s.qkv, 3 * D, M, dt, adt, MADTP_ACT_NONE, 1.f, stream));
     const char* q = (const char*)s.qkv;
     TRY(madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.ctx, mask2d, prune ? s.colsum : nullptr, s.p0, s.onorm,
-                        B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale, dt, stream));
+                        B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale, adt, stream));
+    if (dt == MADTP_F16S) {  // attention.output.dense takes the context as f16 planes (s.q is scratch of the second half)
+        TRY(to_lp((const float*)s.ctx, D, s.q, M, D, dt, stream));
+        s.ctx = s.q;
+    }
     if (prune && k_host) {  // as in the ViT block: score first, the output projection + LayerNorm run while the host waits
         int seq = 0;
         TRY(madtp_token_score_publish(s.colsum, (L + 15) / 16, s.p0, s.onorm, token_attn, ldt_row, ldt_batch, K, temperature,
@@ -332,8 +358,9 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
     bool ok;
     BertWs s = bert_carve((char*)ws, ws_bytes, B, L, Nk, w->dim, w->inter.n, w->heads, w->dtype, &ok);
     if (!ok) return MADTP_E_SHAPE;
-    const int D = w->dim, dt = w->dtype;
-    const size_t e = esz_of(dt);
+    const int D = w->dim, dt = w->dtype, adt = attn_dt(dt);
+    const size_t e = esz_of(adt);
+    const bool lpm = dt != MADTP_F32;  // a compute-dtype copy of the f32 activations feeds the GEMMs
     const float* a32 = att;
     const float* m2 = mask2d;
     int Lp = L;
@@ -353,8 +380,8 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
     (void)m2;  // the text-side padding mask only feeds the NEXT layer's self-attention
     const int M = B * Lp;
     const void* ac = a32;
-    if (dt == MADTP_BF16) {
-        if (!(att_lp_ready && k == 0)) TRY(madtp_cast_bf16(a32, s.attc, (size_t)M * D, stream));
+    if (lpm) {
+        if (!(att_lp_ready && k == 0)) TRY(to_lp(a32, D, s.attc, M, D, dt, stream));
         ac = s.attc;
     }
     if (cross_mode && w->cross) {
@@ -363,12 +390,13 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
         if (nbr == 2 && w->fused_twin) {
             // twin branches with fused projections: one q GEMM ([q0|q1], N = 2D), the two context tensors written
             // side by side ([c0|c1], ld 2D) and ONE output GEMM over K = 2D (dense0|dense1, merge_layer folded in)
-            TRY(lin(ac, D, w->cq_fused, nullptr, 0, s.q2, 2 * D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+            TRY(lin(ac, D, w->cq_fused, nullptr, 0, s.q2, 2 * D, M, dt, adt, MADTP_ACT_NONE, 1.f, stream));
             // [k|v] = enc @ [Wk|Wv]^T of BOTH branches in one launch (or read from the caller's cache of projected blocks)
             const bool both_here = !kv_pre0 && !kv_pre1 && w->ckv[0].n == w->ckv[1].n && w->ckv[0].k == w->ckv[1].k;
             if (both_here)
                 TRY(madtp_gemm_pair(enc0, enc1, w->ckv[0].w, w->ckv[1].w, w->ckv[0].b, w->ckv[1].b, s.kv, s.kv1, B * Nk,
-                                    w->ckv[0].n, w->ckv[0].k, D, w->ckv[0].k, 2 * D, dt, dt, stream));
+                                    w->ckv[0].n, w->ckv[0].k, pld(dt, D), (dt == MADTP_F16S ? 3 : 1) * w->ckv[0].k, 2 * D, dt, adt,
+                                    w->ckv[0].w_scale, w->ckv[1].w_scale, stream));
             const char* kvp[2];
             int ldkv[2];
             for (int br = 0; br < 2; ++br) {
@@ -377,7 +405,7 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
                 ldkv[br] = (kv && kv_ld) ? kv_ld : 2 * D;
                 if (!kv) {
                     void* dst = br ? s.kv1 : s.kv;
-                    if (!both_here) TRY(lin(enc, D, w->ckv[br], nullptr, 0, dst, 2 * D, B * Nk, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+                    if (!both_here) TRY(lin(enc, D, w->ckv[br], nullptr, 0, dst, 2 * D, B * Nk, dt, adt, MADTP_ACT_NONE, 1.f, stream));
                     kv = (const char*)dst;
                 }
                 kvp[br] = kv;
@@ -388,18 +416,23 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
                 // both branches in one launch ([c0|c1] side by side, ld 2D)
                 TRY(madtp_attention_pair(s.q2, (const char*)s.q2 + (size_t)D * e, kvp[0], kvp[1], kvp[0] + (size_t)D * e,
                                          kvp[1] + (size_t)D * e, kv_pre0 ? kv_index : nullptr, s.cat, (char*)s.cat + (size_t)D * e,
-                                         em0, em1, B, w->heads, Lp, Nk, 2 * D, ldkv[0], ldkv[0], 2 * D, w->scale, dt, stream));
+                                         em0, em1, B, w->heads, Lp, Nk, 2 * D, ldkv[0], ldkv[0], 2 * D, w->scale, adt, stream));
             } else {
                 for (int br = 0; br < 2; ++br)
                     TRY(madtp_attention_indexed((const char*)s.q2 + (size_t)br * D * e, kvp[br], kvp[br] + (size_t)D * e,
                                                 (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, (char*)s.cat + (size_t)br * D * e,
                                                 br ? em1 : em0, nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, 2 * D, ldkv[br],
-                                                ldkv[br], 2 * D, w->scale, dt, stream));
+                                                ldkv[br], 2 * D, w->scale, adt, stream));
             }
-            TRY(lin_ln(s.cat, 2 * D, w->cdense_fused, a32, w->fused_twin == 2 ? 1.f : 0.5f, w->ln_cross_g, w->ln_cross_b, s.att2,
-                       dt == MADTP_BF16 ? s.attc : nullptr, M, dt, w->eps, s.part, stream));
+            const void* catc = s.cat;
+            if (dt == MADTP_F16S) {  // [c0|c1] f32 -> f16 planes for the fused output GEMM (s.mid is free until the FFN)
+                TRY(to_lp((const float*)s.cat, 2 * D, s.mid, M, 2 * D, dt, stream));
+                catc = s.mid;
+            }
+            TRY(lin_ln(catc, 2 * D, w->cdense_fused, a32, w->fused_twin == 2 ? 1.f : 0.5f, w->ln_cross_g, w->ln_cross_b, s.att2,
+                       lpm ? s.attc : nullptr, M, dt, w->eps, s.part, stream));
             a32 = s.att2;
-            ac = dt == MADTP_BF16 ? (const void*)s.attc : (const void*)s.att2;
+            ac = lpm ? (const void*)s.attc : (const void*)s.att2;
             goto ffn;
         }
         void* cbuf[2] = {s.c0, s.c1};
@@ -407,37 +440,50 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
             const void* enc = br ? enc1 : enc0;
             // med.py:197-199 drops the encoder mask in cross-attention; nlvr_encoder.py:196-198 applies it
             const float* em = w->variant_nlvr ? (br ? enc_mask1 : enc_mask0) : nullptr;
-            TRY(lin(ac, D, w->cq[br], nullptr, 0, s.q, D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+            TRY(lin(ac, D, w->cq[br], nullptr, 0, s.q, D, M, dt, adt, MADTP_ACT_NONE, 1.f, stream));
             const char* kv = (const char*)(br ? kv_pre1 : kv_pre0);
             if (!kv) {
-                TRY(lin(enc, D, w->ckv[br], nullptr, 0, s.kv, 2 * D, B * Nk, dt, dt, MADTP_ACT_NONE, 1.f, stream));
+                TRY(lin(enc, D, w->ckv[br], nullptr, 0, s.kv, 2 * D, B * Nk, dt, adt, MADTP_ACT_NONE, 1.f, stream));
                 kv = (const char*)s.kv;
             }
             const int ldkv = ((br ? kv_pre1 : kv_pre0) && kv_ld) ? kv_ld : 2 * D;
             TRY(madtp_attention_indexed(s.q, kv, kv + (size_t)D * e, (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, cbuf[br], em,
-                                        nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, D, ldkv, ldkv, D, w->scale, dt, stream));
+                                        nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, D, ldkv, ldkv, D, w->scale, adt, stream));
+            if (dt == MADTP_F16S) {  // context f32 -> f16 planes for crossattention.output.dense (s.kv / s.kv1 are free now)
+                void* sp = br ? s.kv : s.kv1;  // (branch 1's K/V projection above reuses s.kv: branch 0's planes sit in s.kv1)
+                if ((size_t)M * D > (size_t)B * Nk * 2 * D) return MADTP_E_SHAPE;
+                TRY(to_lp((const float*)cbuf[br], D, sp, M, D, dt, stream));
+                cbuf[br] = sp;
+            }
         }
         if (nbr == 2) {
             if (w->has_merge) {  // nlvr_encoder.py:263-264
+                // [dense0(c0) | dense1(c1)] is written as f32 in the f16-split mode (the planes of a split matrix are
+                // separated by ITS row length, which two column-block writers of half the width cannot produce) and split once
+                const int cdt = dt == MADTP_F16S ? MADTP_F32 : dt;
                 char* cat = (char*)s.cat;
-                TRY(lin(s.c0, D, w->cdense[0], nullptr, 0, cat, 2 * D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
-                TRY(lin(s.c1, D, w->cdense[1], nullptr, 0, cat + (size_t)D * e, 2 * D, M, dt, dt, MADTP_ACT_NONE, 1.f, stream));
-                TRY(lin(s.cat, 2 * D, w->merge, a32, D, s.s, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
+                TRY(lin(cbuf[0], D, w->cdense[0], nullptr, 0, cat, 2 * D, M, dt, cdt, MADTP_ACT_NONE, 1.f, stream));
+                TRY(lin(cbuf[1], D, w->cdense[1], nullptr, 0, cat + (size_t)D * esz_of(cdt), 2 * D, M, dt, cdt, MADTP_ACT_NONE, 1.f, stream));
+                const void* catc = s.cat;
+                if (dt == MADTP_F16S) {
+                    TRY(to_lp((const float*)s.cat, 2 * D, s.mid, M, 2 * D, dt, stream));
+                    catc = s.mid;
+                }
+                TRY(lin(catc, 2 * D, w->merge, a32, D, s.s, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
             } else {  // :266 (h0+h1)/2 folded into the epilogues
-                TRY(lin(s.c0, D, w->cdense[0], a32, D, s.t, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 0.5f, stream));
-                TRY(lin(s.c1, D, w->cdense[1], s.t, D, s.s, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 0.5f, stream));
+                TRY(lin(cbuf[0], D, w->cdense[0], a32, D, s.t, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 0.5f, stream));
+                TRY(lin(cbuf[1], D, w->cdense[1], s.t, D, s.s, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 0.5f, stream));
             }
         } else {
-            TRY(lin(s.c0, D, w->cdense[0], a32, D, s.s, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
+            TRY(lin(cbuf[0], D, w->cdense[0], a32, D, s.s, D, M, dt, MADTP_F32, MADTP_ACT_NONE, 1.f, stream));
         }
-        TRY(madtp_layernorm(s.s, w->ln_cross_g, w->ln_cross_b, s.att2, dt == MADTP_BF16 ? s.attc : nullptr, M, D, w->eps,
-                            stream));
+        TRY(madtp_layernorm(s.s, w->ln_cross_g, w->ln_cross_b, s.att2, lpm ? s.attc : nullptr, dt, M, D, w->eps, stream));
         a32 = s.att2;
-        ac = dt == MADTP_BF16 ? (const void*)s.attc : (const void*)s.att2;
+        ac = lpm ? (const void*)s.attc : (const void*)s.att2;
     }
 ffn:
     TRY(lin(ac, D, w->inter, nullptr, 0, s.mid, w->inter.n, M, dt, dt, MADTP_ACT_GELU_ERF, 1.f, stream));
-    TRY(lin_ln(s.mid, w->inter.n, w->out, a32, 1.f, w->ln_out_g, w->ln_out_b, y, dt == MADTP_BF16 ? y_lp : nullptr, M, dt, w->eps,
+    TRY(lin_ln(s.mid, w->inter.n, w->out, a32, 1.f, w->ln_out_g, w->ln_out_b, y, lpm ? y_lp : nullptr, M, dt, w->eps,
                s.part, stream));
     return 0;
 }

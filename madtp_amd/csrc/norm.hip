@@ -3,12 +3,13 @@
 // of a row and consecutive waves cover consecutive rows (fully coalesced).  Roofline: HBM bandwidth,
 // algorithmic bytes per row = dim*4 read + dim*(4 and/or 2) written.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* y32, bf16_t* ylp,
-                                                        int rows, int dim, float eps) {
+                                                        int lp_mul, int rows, int dim, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -24,13 +25,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float mean, rstd;
     ln_row(v, n, dim, eps, mean, rstd);
     ln_store(v, lane, dim, mean, rstd, prm, y32 ? y32 + (size_t)row * dim : nullptr,
-             ylp ? ylp + (size_t)row * dim : nullptr);
+             ylp ? ylp + (size_t)row * dim * lp_mul : nullptr, lp_mul == 2);
 }
 
 __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ wemb,
                                                          const float* __restrict__ pemb, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* y32, bf16_t* ylp,
-                                                         int rows, int L, int dim, float eps) {
+                                                         int lp_mul, int rows, int L, int dim, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restri
     float mean, rstd;
     ln_row(v, n, dim, eps, mean, rstd);
     ln_store(v, lane, dim, mean, rstd, prm, y32 ? y32 + (size_t)row * dim : nullptr,
-             ylp ? ylp + (size_t)row * dim : nullptr);
+             ylp ? ylp + (size_t)row * dim * lp_mul : nullptr, lp_mul == 2);
 }
 
 // y = LayerNorm(scale * (sum_s part[s] + bias) + residual): the fixed-order reduction of split-K partials fused with the
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restri
 __global__ __launch_bounds__(256) void splitk_ln_kernel(const float* __restrict__ part, int S, size_t pstride,
                                                         const float* __restrict__ bias, const float* __restrict__ residual,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float* y32, bf16_t* ylp, int rows, int dim, float eps, float scale) {
+                                                        float* y32, bf16_t* ylp, int lp_mul, int rows, int dim, float eps,
+                                                        float acc_scale, float scale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -77,7 +79,10 @@ __global__ __launch_bounds__(256) void splitk_ln_kernel(const float* __restrict_
                 const float4 p = *(const float4*)(part + s * pstride + (size_t)row * dim + col);
                 a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
             }
-            if (bias) { const float4 b = *(const float4*)(bias + col); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            float4 b = make_float4(0, 0, 0, 0);
+            if (bias) b = *(const float4*)(bias + col);
+            // fmaf(a, 1, b) == a + b: the exact-f32 and bf16 paths are unchanged by the accumulator scale
+            a.x = fmaf(a.x, acc_scale, b.x); a.y = fmaf(a.y, acc_scale, b.y); a.z = fmaf(a.z, acc_scale, b.z); a.w = fmaf(a.w, acc_scale, b.w);
             a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
             if (residual) {
                 const float4 r = *(const float4*)(residual + (size_t)row * dim + col);
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256) void splitk_ln_kernel(const float* __restrict_
     float mean, rstd;
     ln_row(v, n, dim, eps, mean, rstd);
     ln_store(v, lane, dim, mean, rstd, prm, y32 ? y32 + (size_t)row * dim : nullptr,
-             ylp ? ylp + (size_t)row * dim : nullptr);
+             ylp ? ylp + (size_t)row * dim * lp_mul : nullptr, lp_mul == 2);
 }
 
 // one thread per 4 consecutive kx of one (b, patch, c, ky): reads 16 B of an image row, writes 16 B / 8 B
@@ -108,8 +113,16 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const int px = (int)(prow % g), py = (int)((prow / g) % g);
     const int b = (int)(prow / ((size_t)g * g));
     const float4 v = *(const float4*)(img + (((size_t)b * 3 + c) * S + (py * P + ky)) * S + px * P + kx);
-    T* o = cols + e;
-    o[0] = from_f32<T>(v.x); o[1] = from_f32<T>(v.y); o[2] = from_f32<T>(v.z); o[3] = from_f32<T>(v.w);
+    if constexpr (std::is_same<T, _Float16>::value) {  // f16-split planes [P0 | P1], row stride 2*kcols
+        f16x4 h, l;
+        split_f16x4((f32x4){v.x, v.y, v.z, v.w}, h, l);
+        _Float16* o = cols + prow * 2 * kcols + col;
+        *(f16x4*)o = h;
+        *(f16x4*)(o + kcols) = l;
+    } else {
+        T* o = cols + e;
+        o[0] = from_f32<T>(v.x); o[1] = from_f32<T>(v.y); o[2] = from_f32<T>(v.z); o[3] = from_f32<T>(v.w);
+    }
 }
 
 __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ patches, const float* __restrict__ cls,
@@ -134,6 +147,40 @@ __global__ __launch_bounds__(256) void add_scale_kernel(const float* __restrict_
     ((float4*)o)[i] = make_float4((x.x + y.x) * scale, (x.y + y.y) * scale, (x.z + y.z) * scale, (x.w + y.w) * scale);
 }
 
+// f32 [rows, K] -> f16-split activation planes [rows, 2K]; one thread per 4 consecutive columns
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ src, int ld_src, _Float16* __restrict__ dst,
+                                                        int ld_dst, int K4, size_t total4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const size_t row = i / K4;
+    const int col = (int)(i - row * K4) * 4;
+    const float4 v = *(const float4*)(src + row * ld_src + col);
+    f16x4 h, l;
+    split_f16x4((f32x4){v.x, v.y, v.z, v.w}, h, l);
+    _Float16* o = dst + row * ld_dst + col;
+    *(f16x4*)o = h;
+    *(f16x4*)(o + K4 * 4) = l;
+}
+
+// weight planes [Q0 | Q1 | Q2] of w * inv_scale (common.h): Q0 = f16(w~), Q1 = f16(w~ - Q0), Q2 = f16(Q0 * 2^-11)
+__global__ __launch_bounds__(256) void split_f16_weight_kernel(const float* __restrict__ w, int ldw, _Float16* __restrict__ dst,
+                                                               int K4, size_t total4, float inv_scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const size_t row = i / K4;
+    const int col = (int)(i - row * K4) * 4;
+    const float4 v4 = *(const float4*)(w + row * ldw + col);
+    const f32x4 v = (f32x4){v4.x, v4.y, v4.z, v4.w} * inv_scale;
+    const f16x4 q0 = __builtin_convertvector(v, f16x4);
+    const f32x4 q0f = __builtin_convertvector(q0, f32x4);
+    const f16x4 q1 = __builtin_convertvector(v - q0f, f16x4);
+    const f16x4 q2 = __builtin_convertvector(q0f * (1.0f / F16S_LO_SCALE), f16x4);
+    _Float16* o = dst + row * (size_t)(3 * K4 * 4) + col;
+    *(f16x4*)o = q0;
+    *(f16x4*)(o + K4 * 4) = q1;
+    *(f16x4*)(o + 2 * K4 * 4) = q2;
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
@@ -146,36 +193,43 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int madtp_layernorm(const float* x, const float* gamma, const float* beta, float* y32, void* ylp, int rows,
-                               int dim, float eps, void* stream) {
+static inline int lp_mul_of(int lp_dtype) { return lp_dtype == MADTP_F16S ? 2 : 1; }
+
+extern "C" int madtp_layernorm(const float* x, const float* gamma, const float* beta, float* y32, void* ylp, int lp_dtype,
+                               int rows, int dim, float eps, void* stream) {
     if (!x || !gamma || !beta || (!y32 && !ylp) || rows <= 0 || dim <= 0) return MADTP_E_BADARG;
+    if (ylp && lp_dtype != MADTP_BF16 && lp_dtype != MADTP_F16S) return MADTP_E_DTYPE;
     if (dim % 4 || dim > 256 * LN_MAX_CHUNKS) return MADTP_E_SHAPE;
     if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || (y32 && !aligned16(y32)) || (ylp && ((uintptr_t)ylp & 7)))
         return MADTP_E_ALIGN;
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y32,
-                       (bf16_t*)ylp, rows, dim, eps);
+                       (bf16_t*)ylp, lp_mul_of(lp_dtype), rows, dim, eps);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int madtp_splitk_ln(const float* part, int splits, const float* bias, const float* residual, const float* gamma,
-                               const float* beta, float* y32, void* ylp, int rows, int dim, float eps, float scale,
-                               void* stream) {
+                               const float* beta, float* y32, void* ylp, int lp_dtype, int rows, int dim, float eps,
+                               float acc_scale, float scale, void* stream) {
     if (!part || !gamma || !beta || (!y32 && !ylp) || rows <= 0 || dim <= 0 || splits < 1) return MADTP_E_BADARG;
+    if (ylp && lp_dtype != MADTP_BF16 && lp_dtype != MADTP_F16S) return MADTP_E_DTYPE;
     if (dim % 4 || dim > 256 * LN_MAX_CHUNKS) return MADTP_E_SHAPE;
     hipLaunchKernelGGL(splitk_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, splits,
-                       (size_t)rows * dim, bias, residual, gamma, beta, y32, (bf16_t*)ylp, rows, dim, eps, scale);
+                       (size_t)rows * dim, bias, residual, gamma, beta, y32, (bf16_t*)ylp, lp_mul_of(lp_dtype), rows, dim, eps,
+                       acc_scale, scale);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int madtp_bert_embed(const int64_t* ids, const float* word_emb, const float* pos_emb, const float* gamma,
-                                const float* beta, float* y32, void* ylp, int B, int L, int dim, float eps, void* stream) {
+                                const float* beta, float* y32, void* ylp, int lp_dtype, int B, int L, int dim, float eps,
+                                void* stream) {
     if (!ids || !word_emb || !pos_emb || !gamma || !beta || (!y32 && !ylp) || B <= 0 || L <= 0) return MADTP_E_BADARG;
+    if (ylp && lp_dtype != MADTP_BF16 && lp_dtype != MADTP_F16S) return MADTP_E_DTYPE;
     if (dim % 4 || dim > 256 * LN_MAX_CHUNKS) return MADTP_E_SHAPE;
     const int rows = B * L;
     hipLaunchKernelGGL(bert_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, word_emb, pos_emb,
-                       gamma, beta, y32, (bf16_t*)ylp, rows, L, dim, eps);
+                       gamma, beta, y32, (bf16_t*)ylp, lp_mul_of(lp_dtype), rows, L, dim, eps);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
@@ -189,6 +243,8 @@ extern "C" int madtp_patchify(const float* img, void* cols, int B, int S, int P,
         hipLaunchKernelGGL(patchify_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, img, (float*)cols, B, S, P, total4);
     else if (out_dtype == MADTP_BF16)
         hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)cols, B, S, P, total4);
+    else if (out_dtype == MADTP_F16S)
+        hipLaunchKernelGGL(patchify_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, img, (_Float16*)cols, B, S, P, total4);
     else
         return MADTP_E_DTYPE;
     MADTP_LAUNCH_CHECK();
@@ -223,7 +279,29 @@ extern "C" int madtp_cast_bf16(const float* src, void* dst, size_t n, void* stre
     return 0;
 }
 
-extern "C" int madtp_abi_version(void) { return 6; }
+extern "C" int madtp_split_f16(const float* src, int ld_src, void* dst, int ld_dst, int rows, int K, void* stream) {
+    if (!src || !dst || rows <= 0 || K <= 0) return MADTP_E_BADARG;
+    if (K % 4 || ld_src < K || ld_dst < 2 * K) return MADTP_E_SHAPE;
+    if (!aligned16(src) || ld_src % 4 || ((uintptr_t)dst & 7) || ld_dst % 4) return MADTP_E_ALIGN;
+    const size_t total4 = (size_t)rows * (K / 4);
+    hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                       (_Float16*)dst, ld_dst, K / 4, total4);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_split_f16_weight(const float* w, int ldw, void* dst, int n, int K, float inv_scale, void* stream) {
+    if (!w || !dst || n <= 0 || K <= 0 || !(inv_scale > 0.f)) return MADTP_E_BADARG;
+    if (K % 4 || ldw < K) return MADTP_E_SHAPE;
+    if (!aligned16(w) || ldw % 4 || ((uintptr_t)dst & 7)) return MADTP_E_ALIGN;
+    const size_t total4 = (size_t)n * (K / 4);
+    hipLaunchKernelGGL(split_f16_weight_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw,
+                       (_Float16*)dst, K / 4, total4, inv_scale);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_abi_version(void) { return 7; }
 
 extern "C" const char* madtp_strerror(int code) {
     switch (code) {

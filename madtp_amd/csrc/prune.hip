@@ -312,7 +312,8 @@ constexpr int GATHER_ROWS = 16;
 __global__ __launch_bounds__(256) void token_gather_kernel(const float* __restrict__ x, const int32_t* __restrict__ dst_pos,
                                                            const float* __restrict__ merge_w, float* __restrict__ y, int N,
                                                            int k, int dim4, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float eps, float* h32, bf16_t* hlp) {
+                                                           const float* __restrict__ beta, float eps, float* h32, bf16_t* hlp,
+                                                           int lp_mul) {
     __shared__ float4 part[4][256];  // dim <= 1024
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, n = N - 1, No = k + 2, dim = dim4 * 4;
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void token_gather_kernel(const float* __restri
         float mean, rstd;
         ln_row(v, nch, dim, eps, mean, rstd);
         const size_t off = ((size_t)b * No + dst) * dim;
-        ln_store(v, lane, dim, mean, rstd, prm, h32 ? h32 + off : nullptr, hlp ? hlp + off : nullptr);
+        ln_store(v, lane, dim, mean, rstd, prm, h32 ? h32 + off : nullptr, hlp ? hlp + off * lp_mul : nullptr, lp_mul == 2);
     };
     if ((int)blockIdx.x < (int)gridDim.x - 1) {
         for (int rr = wave; rr < GATHER_ROWS; rr += 4) {
@@ -1065,7 +1066,8 @@ extern "C" int madtp_token_select(const float* score, int k, int64_t* indices, i
 
 extern "C" int madtp_token_gather_ln(const float* x, const int32_t* dst_pos, const float* merge_w, float* y, int B, int N,
                                      int k, int dim, const float* gamma, const float* beta, float eps, float* h32, void* h_lp,
-                                     void* stream) {
+                                     int lp_dtype, void* stream) {
+    if (h_lp && lp_dtype != MADTP_BF16 && lp_dtype != MADTP_F16S) return MADTP_E_DTYPE;
     if (!x || !dst_pos || !merge_w || !y || B <= 0 || N < 2 || k < 1 || k > N - 1) return MADTP_E_BADARG;
     if (gamma && (!beta || (!h32 && !h_lp))) return MADTP_E_BADARG;
     if (dim % 4 || dim > 1024) return MADTP_E_SHAPE;
@@ -1073,14 +1075,14 @@ extern "C" int madtp_token_gather_ln(const float* x, const int32_t* dst_pos, con
         return MADTP_E_ALIGN;
     const int chunks = (N + GATHER_ROWS - 1) / GATHER_ROWS;
     hipLaunchKernelGGL(token_gather_kernel, dim3(chunks + 1, B), dim3(256), 0, (hipStream_t)stream, x, dst_pos, merge_w, y, N,
-                       k, dim / 4, gamma, beta, eps, h32, (bf16_t*)h_lp);
+                       k, dim / 4, gamma, beta, eps, h32, (bf16_t*)h_lp, lp_dtype == MADTP_F16S ? 2 : 1);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int madtp_token_gather(const float* x, const int32_t* dst_pos, const float* merge_w, float* y, int B, int N,
                                   int k, int dim, void* stream) {
-    return madtp_token_gather_ln(x, dst_pos, merge_w, y, B, N, k, dim, nullptr, nullptr, 0.f, nullptr, nullptr, stream);
+    return madtp_token_gather_ln(x, dst_pos, merge_w, y, B, N, k, dim, nullptr, nullptr, 0.f, nullptr, nullptr, MADTP_BF16, stream);
 }
 
 extern "C" int madtp_mask_gather(const float* mask, const int64_t* order, int ld_order, const int64_t* order2,

@@ -10,9 +10,9 @@ from ctypes import c_float, c_int, c_size_t, c_void_p
 
 import torch
 
-F32, BF16 = 0, 1
+F32, BF16, F16S = 0, 1, 2  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -22,20 +22,20 @@ _SIGS = {
     "madtp_strerror": (ctypes.c_char_p, [c_int]),
     "madtp_profile_begin": (c_int, []),
     "madtp_profile_end": (c_int, [ctypes.c_char_p, c_int]),
-    "madtp_gemm": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_int, c_int, c_int, c_float, c_void_p]),
+    "madtp_gemm": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "madtp_gemm_splitk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "madtp_splitk_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                c_float, c_float, c_void_p]),
-    "madtp_layernorm": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p]),
+    "madtp_splitk_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_float, c_float, c_float, c_void_p]),
+    "madtp_layernorm": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_float, c_void_p]),
     "madtp_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "madtp_assemble_tokens": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
-    "madtp_bert_embed": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_void_p]),
+    "madtp_bert_embed": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "madtp_attention": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float, c_int, c_void_p]),
     "madtp_token_score": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float]
                           + [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "madtp_token_select": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "madtp_token_gather": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
-    "madtp_token_gather_ln": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "madtp_token_gather_ln": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     "madtp_mask_gather": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "madtp_query_att_ft": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_int,
                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -66,16 +66,18 @@ _SIGS = {
     "madtp_bert_layer": (c_int, [c_void_p] * 7 + [c_size_t, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
                          + [c_void_p] * 5 + [c_int] + [c_void_p] * 9 + [c_int] + [c_void_p] * 3),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
-    "madtp_gemm_pair": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_void_p]),
+    "madtp_gemm_pair": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float, c_float, c_void_p]),
     "madtp_attention_pair": (c_int, [c_void_p] * 11 + [c_int] * 8 + [c_float, c_int, c_void_p]),
     "madtp_query_att_ft_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "madtp_split_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "madtp_split_f16_weight": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
 }
 
 
 
 class LinStruct(ctypes.Structure):
-    _fields_ = [("w", c_void_p), ("b", c_void_p), ("n", c_int), ("k", c_int)]
+    _fields_ = [("w", c_void_p), ("b", c_void_p), ("n", c_int), ("k", c_int), ("w_scale", c_float)]
 
 
 class VitBlockW(ctypes.Structure):
@@ -97,7 +99,8 @@ class BertLayerW(ctypes.Structure):
 
 def lin_struct(lin):
     """runtime.Lin -> LinStruct (the Lin object must stay alive while the struct is in use)."""
-    return LinStruct(lin.w.data_ptr(), 0 if lin.b is None else lin.b.data_ptr(), lin.n, lin.w.shape[1])
+    k = lin.w.shape[1] // 3 if lin.w.dtype == torch.float16 else lin.w.shape[1]
+    return LinStruct(lin.w.data_ptr(), 0 if lin.b is None else lin.b.data_ptr(), lin.n, k, w_scale_of(lin.w))
 
 
 _lib = None
@@ -143,11 +146,22 @@ def _stream():
 
 
 def _dt(t):
-    if t.dtype == torch.float32:
+    return dt_code(t.dtype)
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
         return F32
-    if t.dtype == torch.bfloat16:
+    if dtype == torch.bfloat16:
         return BF16
-    raise TypeError(f"unsupported dtype {t.dtype}")
+    if dtype == torch.float16:
+        return F16S
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def w_scale_of(w):
+    """accumulator scale of a prepared weight: 2^-s for f16-split planes (runtime.prepare_linear tags the tensor), else 1."""
+    return float(getattr(w, "_madtp_w_scale", 1.0))
 
 
 def _req(t, dtype=None, name="tensor"):
@@ -167,19 +181,22 @@ def gemm(a, w, bias=None, residual=None, out_dtype=None, act=ACT_NONE, n=None, o
     if not a.is_cuda or a.dim() != 2 or a.stride(1) != 1:
         raise RuntimeError("gemm: a must be a GPU row-major 2-D view (no CPU fallback)")
     M, K = a.shape
+    split = a.dtype == torch.float16  # f16-split planes: a is [M, 2K], w [Npad, 3K], a split output [M, 2n]
+    if split:
+        K //= 2
     n = n if n is not None else w.shape[0]
-    if w.shape[0] % 128 or w.shape[1] != K or a.dtype != w.dtype:
+    if w.shape[0] % 128 or w.shape[1] != (3 * K if split else K) or a.dtype != w.dtype:
         raise RuntimeError(f"gemm: bad weight {tuple(w.shape)} {w.dtype} for a {tuple(a.shape)} {a.dtype}")
     out_dtype = out_dtype or a.dtype
     if out is None:
-        out = torch.empty((M, n), device=a.device, dtype=out_dtype)
+        out = torch.empty((M, 2 * n if out_dtype == torch.float16 else n), device=a.device, dtype=out_dtype)
     ldr = residual.stride(0) if residual is not None else 0
     if residual is not None:
         _req(residual, torch.float32, "residual")
     if bias is not None:
         _req(bias, torch.float32, "bias")
     _check(load().madtp_gemm(_p(a), _p(w), _p(bias), _p(residual), _p(out), M, n, K, a.stride(0), w.stride(0),
-                             out.stride(0), ldr, _dt(a), _dt(out), act, float(out_scale), _stream()), "madtp_gemm")
+                             out.stride(0), ldr, _dt(a), _dt(out), act, w_scale_of(w), float(out_scale), _stream()), "madtp_gemm")
     return out
 
 
@@ -188,24 +205,37 @@ def gemm_pair(a0, a1, w0, w1, bias0, bias1, n, out_dtype=None):
     for t, name in ((a0, "a0"), (a1, "a1"), (w0, "w0"), (w1, "w1")):
         _req(t, name=name)
     M, K = a0.shape
+    if a0.dtype == torch.float16:
+        K //= 2
     if a1.shape != a0.shape or w1.shape != w0.shape or a0.stride(0) != a1.stride(0) or a0.dtype != w0.dtype:
         raise RuntimeError("gemm_pair: the two problems must have identical shapes and dtypes")
     out_dtype = out_dtype or a0.dtype
-    c0 = torch.empty((M, n), device=a0.device, dtype=out_dtype)
-    c1 = torch.empty((M, n), device=a0.device, dtype=out_dtype)
+    nc = 2 * n if out_dtype == torch.float16 else n
+    c0 = torch.empty((M, nc), device=a0.device, dtype=out_dtype)
+    c1 = torch.empty((M, nc), device=a0.device, dtype=out_dtype)
     _check(load().madtp_gemm_pair(_p(a0), _p(a1), _p(w0), _p(w1), _p(bias0), _p(bias1), _p(c0), _p(c1), M, n, K, a0.stride(0),
-                                  w0.stride(0), n, _dt(a0), _dt(c0), _stream()), "madtp_gemm_pair")
+                                  w0.stride(0), nc, _dt(a0), _dt(c0), w_scale_of(w0), w_scale_of(w1), _stream()), "madtp_gemm_pair")
     return c0, c1
 
 
-def layernorm(x, gamma, beta, eps, want_f32=True, want_bf16=False):
+def _lp_empty(shape, device, lp):
+    """buffer of the low-precision copy of an f32 [..., dim] tensor: bf16 [..., dim] or f16-split planes [..., 2*dim]."""
+    if lp == torch.float16:
+        return torch.empty(tuple(shape[:-1]) + (2 * shape[-1],), device=device, dtype=torch.float16)
+    return torch.empty(tuple(shape), device=device, dtype=torch.bfloat16)
+
+
+def layernorm(x, gamma, beta, eps, want_f32=True, want_bf16=False, lp=None):
+    """lp: torch.bfloat16 / torch.float16 (f16-split planes) selects the low-precision copy (want_bf16=True == lp=bf16)."""
     _req(x, torch.float32, "x")
+    _req(gamma, torch.float32, "LayerNorm weight"); _req(beta, torch.float32, "LayerNorm bias")
     dim = x.shape[-1]
     rows = x.numel() // dim
+    lp = lp or (torch.bfloat16 if want_bf16 else None)
     y32 = torch.empty_like(x) if want_f32 else None
-    ylp = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if want_bf16 else None
-    _check(load().madtp_layernorm(_p(x), _p(gamma), _p(beta), _p(y32), _p(ylp), rows, dim, float(eps), _stream()),
-           "madtp_layernorm")
+    ylp = _lp_empty(x.shape, x.device, lp) if lp is not None else None
+    _check(load().madtp_layernorm(_p(x), _p(gamma), _p(beta), _p(y32), _p(ylp), dt_code(lp) if lp is not None else BF16, rows,
+                                  dim, float(eps), _stream()), "madtp_layernorm")
     return y32, ylp
 
 
@@ -213,7 +243,8 @@ def patchify(img, patch, out_dtype):
     _req(img, torch.float32, "img")
     B, C, S, _ = img.shape
     g = S // patch
-    cols = torch.empty((B * g * g, C * patch * patch), device=img.device, dtype=out_dtype)
+    kc = C * patch * patch
+    cols = torch.empty((B * g * g, 2 * kc if out_dtype == torch.float16 else kc), device=img.device, dtype=out_dtype)
     _check(load().madtp_patchify(_p(img), _p(cols), B, S, patch, _dt(cols), _stream()), "madtp_patchify")
     return cols
 
@@ -226,14 +257,15 @@ def assemble_tokens(patches, cls, pos, B, np_):
     return x
 
 
-def bert_embed(ids, word_emb, pos_emb, gamma, beta, eps, want_bf16=False):
+def bert_embed(ids, word_emb, pos_emb, gamma, beta, eps, want_bf16=False, lp=None):
     _req(ids, torch.int64, "input_ids")
     B, L = ids.shape
     dim = word_emb.shape[1]
+    lp = lp or (torch.bfloat16 if want_bf16 else None)
     y32 = torch.empty((B, L, dim), device=ids.device, dtype=torch.float32)
-    ylp = torch.empty((B, L, dim), device=ids.device, dtype=torch.bfloat16) if want_bf16 else None
-    _check(load().madtp_bert_embed(_p(ids), _p(word_emb), _p(pos_emb), _p(gamma), _p(beta), _p(y32), _p(ylp), B, L, dim,
-                                   float(eps), _stream()), "madtp_bert_embed")
+    ylp = _lp_empty((B, L, dim), ids.device, lp) if lp is not None else None
+    _check(load().madtp_bert_embed(_p(ids), _p(word_emb), _p(pos_emb), _p(gamma), _p(beta), _p(y32), _p(ylp),
+                                   dt_code(lp) if lp is not None else BF16, B, L, dim, float(eps), _stream()), "madtp_bert_embed")
     return y32, ylp
 
 
@@ -318,15 +350,17 @@ def token_gather(x, dst_pos, merge_w, k):
     return y
 
 
-def token_gather_ln(x, dst_pos, merge_w, k, gamma, beta, eps, want_f32=True, want_bf16=True):
-    """token_gather with the following LayerNorm fused in -> (y, LN(y) f32 or None, LN(y) bf16 or None)."""
+def token_gather_ln(x, dst_pos, merge_w, k, gamma, beta, eps, want_f32=True, want_bf16=True, lp=None):
+    """token_gather with the following LayerNorm fused in -> (y, LN(y) f32 or None, LN(y) low-precision copy or None)."""
     _req(x, torch.float32, "x")
     B, N, dim = x.shape
+    lp = lp or (torch.bfloat16 if want_bf16 else None)
     y = torch.empty((B, k + 2, dim), device=x.device, dtype=torch.float32)
     h32 = torch.empty_like(y) if want_f32 else None
-    hlp = torch.empty(y.shape, device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    hlp = _lp_empty(y.shape, x.device, lp) if lp is not None else None
     _check(load().madtp_token_gather_ln(_p(x), _p(dst_pos), _p(merge_w), _p(y), B, N, k, dim, _p(gamma), _p(beta), float(eps),
-                                        _p(h32), _p(hlp), _stream()), "madtp_token_gather_ln")
+                                        _p(h32), _p(hlp), dt_code(lp) if lp is not None else BF16, _stream()),
+           "madtp_token_gather_ln")
     return y, h32, hlp
 
 
@@ -391,6 +425,32 @@ def cast_bf16(src):
     _req(src, torch.float32, "src")
     dst = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
     _check(load().madtp_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "madtp_cast_bf16")
+    return dst
+
+
+def split_f16(src):
+    """f32 [..., K] (rows contiguous) -> f16-split activation planes [..., 2K] (torch.float16) for an F16S GEMM."""
+    _req(src, torch.float32, "src")
+    K = src.shape[-1]
+    rows = src.numel() // K
+    dst = torch.empty(tuple(src.shape[:-1]) + (2 * K,), device=src.device, dtype=torch.float16)
+    _check(load().madtp_split_f16(_p(src), K, _p(dst), 2 * K, rows, K, _stream()), "madtp_split_f16")
+    return dst
+
+
+def split_f16_weight(w):
+    """f32 [n, K] -> ([n, 3K] f16 planes of w * 2^s, 2^-s) with max|w| * 2^s in (2^13, 2^14]."""
+    _req(w, torch.float32, "w")
+    n, K = w.shape
+    amax = float(w.abs().max())
+    s = 0
+    if amax > 0 and amax == amax and amax != float("inf"):
+        import math
+        s = 14 - math.ceil(math.log2(amax))
+        s = max(-100, min(100, s))
+    dst = torch.empty((n, 3 * K), device=w.device, dtype=torch.float16)
+    _check(load().madtp_split_f16_weight(_p(w), K, _p(dst), n, K, float(2.0 ** s), _stream()), "madtp_split_f16_weight")
+    dst._madtp_w_scale = float(2.0 ** -s)
     return dst
 
 
@@ -497,7 +557,9 @@ def bert_layer(wstruct, hidden, mask2d, token_attn, temperature, cross_mode, enc
     ybuf = torch.empty_like(hidden)
     k_out, k_used = ctypes.c_int(0), ctypes.c_int(0)
     dev = hidden.device
-    ylp = torch.empty(hidden.shape, device=dev, dtype=torch.bfloat16) if wstruct.dtype == BF16 else None
+    ylp = None
+    if wstruct.dtype != F32:  # compute-dtype copy of the layer output for the next layer (bf16, or f16-split planes)
+        ylp = _lp_empty(hidden.shape, dev, torch.float16 if wstruct.dtype == F16S else torch.bfloat16)
     if temperature > 0:
         tp, ldr, ldb, K = _ta_view(token_attn)
         score, thr, count, _ = prune_outputs(B, L - 1, dev)
@@ -515,7 +577,7 @@ def bert_layer(wstruct, hidden, mask2d, token_attn, temperature, cross_mode, enc
             k = k_used.value
             info.update(pruned=True, indices=_carve(idx, B, k), indices_sort=idx_sort)
             return (_carve(ybuf, B, k + 2, D), (_carve(mbuf, B, k + 2) if mbuf is not None else None), info,
-                    _carve(ylp, B, k + 2, D) if ylp is not None else None)
+                    _carve(ylp, B, k + 2, ylp.shape[-1]) if ylp is not None else None)
         return ybuf, None, info, ylp
     _check(lib.madtp_bert_layer(ctypes.byref(wstruct), _p(hidden), _p(mask2d), _p(att), _p(ybuf), 0, _p(ws), ws.numel(), B, L, Nk,
                                 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, int(cross_mode), _p(enc0), _p(enc1), _p(enc_mask0), _p(enc_mask1),
@@ -636,19 +698,23 @@ def profile_end():
     rows = []
     for line in buf.raw[:n].decode().splitlines():
         dt, M, N, K, c, ms, fl, by = line.split()
-        rows.append({"dtype": "bf16" if int(dt) == BF16 else "f32", "M": int(M), "N": int(N), "K": int(K),
+        rows.append({"dtype": {F32: "f32", BF16: "bf16", F16S: "f16s"}[int(dt)], "M": int(M), "N": int(N), "K": int(K),
                      "launches": int(c), "ms": float(ms), "flops": float(fl), "bytes": float(by)})
     return rows
 
 
-def gemm_splitk_ln(a, w, bias, residual, gamma, beta, eps, splits, n, scale=1.0, want_bf16=False):
-    """LayerNorm(scale*(a @ w^T + bias) + residual) via split-K partials; returns (y32, ybf16 or None)."""
+def gemm_splitk_ln(a, w, bias, residual, gamma, beta, eps, splits, n, scale=1.0, want_bf16=False, lp=None):
+    """LayerNorm(scale*(a @ w^T + bias) + residual) via split-K partials; returns (y32, low-precision copy or None)."""
     M, K = a.shape
+    if a.dtype == torch.float16:
+        K //= 2
+    lp = lp or (torch.bfloat16 if want_bf16 else None)
     part = torch.empty((splits, M, n), device=a.device, dtype=torch.float32)
     _check(load().madtp_gemm_splitk(_p(a), _p(w), _p(part), M, n, K, a.stride(0), w.stride(0), splits, _dt(a), _stream()),
            "madtp_gemm_splitk")
     y32 = torch.empty((M, n), device=a.device, dtype=torch.float32)
-    ylp = torch.empty((M, n), device=a.device, dtype=torch.bfloat16) if want_bf16 else None
-    _check(load().madtp_splitk_ln(_p(part), splits, _p(bias), _p(residual), _p(gamma), _p(beta), _p(y32), _p(ylp), M, n,
-                                  float(eps), float(scale), _stream()), "madtp_splitk_ln")
+    ylp = _lp_empty((M, n), a.device, lp) if lp is not None else None
+    _check(load().madtp_splitk_ln(_p(part), splits, _p(bias), _p(residual), _p(gamma), _p(beta), _p(y32), _p(ylp),
+                                  dt_code(lp) if lp is not None else BF16, M, n, float(eps), w_scale_of(w), float(scale), _stream()),
+           "madtp_splitk_ln")
     return y32, ylp

@@ -1,10 +1,16 @@
 """Host-side runtime shared by the module mirrors: precision mode, prepared-weight cache, small helpers.
 
 Precision modes (SURVEY.md section 7 "hard parts"):
-  "fp32" - parity mode: every GEMM runs on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32), activations f32.
-           Kept-token index sets match the fp32 reference eager path.
-  "bf16" - fast mode: GEMM operands are bf16 (f32 accumulate, MFMA 16x16x32), the residual stream, LayerNorm
-           statistics, softmax, the alignment logits x.sd^T and every pruning score stay f32.
+  "fp32"  - parity mode: every GEMM runs on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32), activations f32.
+            Kept-token index sets match the fp32 reference eager path.
+  "f16x3" - fp32-ACCURATE mode on the f16 MFMA: every Linear runs as three f16 MFMA products of f16-split operands
+            (csrc/common.h: x = P0 + 2^-11 P1, w 2^s = Q0 + Q1; exact partial products, f32 accumulation, ~2^-23
+            relative error per product - the rounding class of an f32 dot product) at 3/16 of the exact-f32 MFMA cost;
+            attention, LayerNorm, the alignment logits and all pruning scores are the fp32 mode's kernels.  Kept-token
+            sets match the reference like the fp32 mode (tests/test_model_parity_gpu.py); GEMM operands are torch.float16
+            tensors holding the planes side by side ([M, 2K] activations, [N, 3K] weights).
+  "bf16"  - fast mode: GEMM operands are bf16 (f32 accumulate, MFMA 16x16x32), the residual stream, LayerNorm
+            statistics, softmax, the alignment logits x.sd^T and every pruning score stay f32.
 """
 import threading
 
@@ -14,11 +20,13 @@ from . import hip
 
 _state = threading.local()
 _DEFAULT = "bf16"
+MODES = ("fp32", "f16x3", "bf16")
+_CDT = {"fp32": torch.float32, "f16x3": torch.float16, "bf16": torch.bfloat16}
 
 
 def set_precision(mode: str):
-    if mode not in ("fp32", "bf16"):
-        raise ValueError("precision must be 'fp32' or 'bf16'")
+    if mode not in MODES:
+        raise ValueError(f"precision must be one of {MODES}")
     _state.mode = mode
 
 
@@ -27,7 +35,27 @@ def get_precision() -> str:
 
 
 def compute_dtype():
-    return torch.float32 if get_precision() == "fp32" else torch.bfloat16
+    """torch dtype of the GEMM operands: float32, bfloat16, or float16 = f16-split planes (mode "f16x3")."""
+    return _CDT[get_precision()]
+
+
+def attn_dtype():
+    """dtype of q/k/v and the context of the attention kernels (the f16x3 mode keeps attention on the exact-f32 kernels)."""
+    return torch.bfloat16 if get_precision() == "bf16" else torch.float32
+
+
+def dtype_code():
+    """MADTP_F32 / MADTP_BF16 / MADTP_F16S of the current mode (the `dtype` field of the layer weight structs)."""
+    return hip.dt_code(compute_dtype())
+
+
+def to_compute(x):
+    """f32 [..., K] with contiguous rows -> the current mode's GEMM operand (itself, a bf16 copy, or f16-split planes)."""
+    cdt = compute_dtype()
+    if cdt == torch.float32:
+        return x
+    x = x if x.is_contiguous() else x.contiguous()
+    return hip.split_f16(x) if cdt == torch.float16 else hip.cast_bf16(x)
 
 
 class precision:
@@ -45,7 +73,8 @@ class precision:
 
 
 class Lin:
-    """A Linear prepared for madtp_gemm: weight padded to a multiple of 128 rows in the compute dtype, f32 bias."""
+    """A Linear prepared for madtp_gemm: weight padded to a multiple of 128 rows in the compute dtype (float16: the three
+    f16 planes of w * 2^s side by side, the tensor tagged with its accumulator scale 2^-s), f32 bias."""
     __slots__ = ("w", "b", "n")
 
     def __init__(self, w, b, n):
@@ -70,6 +99,8 @@ def prepare_linear(weights, biases, dtype):
     w = _pad_rows(w)
     if dtype == torch.bfloat16:
         w = hip.cast_bf16(w.contiguous())
+    elif dtype == torch.float16:
+        w = hip.split_f16_weight(w.contiguous())
     b = None
     if biases is not None and all(bb is not None for bb in biases):
         b = torch.cat([bb.detach().float() for bb in biases], 0).contiguous() if len(biases) > 1 \

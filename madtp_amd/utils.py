@@ -6,7 +6,7 @@ import torch
 from torch import nn
 
 from . import hip
-from .runtime import PreparedCache, compute_dtype, prepare_linear, require_gpu
+from .runtime import PreparedCache, compute_dtype, prepare_linear, require_gpu, to_compute
 
 
 def vector_gather(vectors, indices):
@@ -129,8 +129,7 @@ class Query_model(nn.Module):
             off = 1
             if rows is None:
                 rows, off = ft.float().contiguous().view(B * n, D), 0
-            a = rows if cdt == torch.float32 else hip.cast_bf16(rows.contiguous())
-            q = hip.gemm(a, qm.w, qm.b, out_dtype=torch.float32, n=qm.n).view(B, n + off, -1)
+            q = hip.gemm(to_compute(rows.contiguous()), qm.w, qm.b, out_dtype=torch.float32, n=qm.n).view(B, n + off, -1)
             if off == 1:
                 token_att, att_ft = hip.query_model(q, sdl.w, K, att_ft=acc_ft, want_att_ft=self.compute_att_ft,
                                                     sd_dim=self.att_dim, sd_split=split)

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import PreparedCache, compute_dtype, lin_of, require_gpu, as_f32_contig
+from .runtime import PreparedCache, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model, vector_gather  # noqa: F401  (re-exported like `from models.utils import *`)
 
 
@@ -45,8 +45,7 @@ class Mlp(nn.Module):
         require_gpu(x)
         shp = x.shape
         h = as_f32_contig(x).view(-1, shp[-1])
-        h = h if compute_dtype() == torch.float32 else hip.cast_bf16(h)
-        return self.run(h).view(*shp[:-1], -1)
+        return self.run(to_compute(h)).view(*shp[:-1], -1)
 
 
 class Attention(nn.Module):
@@ -93,10 +92,12 @@ class Attention(nn.Module):
         qkv = lin_of(self._cache, "qkv", [self.qkv])
         proj = lin_of(self._cache, "proj", [self.proj])
         C = self.dim
-        y = hip.gemm(h2d, qkv.w, qkv.b, n=qkv.n)  # [B*N, 3C]: q | k | v, head-major inside each (vit.py:77)
+        y = hip.gemm(h2d, qkv.w, qkv.b, n=qkv.n, out_dtype=attn_dtype())  # [B*N, 3C]: q | k | v, head-major (vit.py:77)
         o, side = hip.attention(y[:, :C], y[:, C:2 * C], y[:, 2 * C:], B, self.num_heads, N, N, self.scale,
                                 scores=want_scores)
         self.score_side = side
+        if o.dtype != compute_dtype():  # f16x3: the f32 context enters the projection as f16 planes
+            o = to_compute(o)
         return hip.gemm(o, proj.w, proj.b, residual=residual2d, out_dtype=torch.float32, n=proj.n)
 
     def forward(self, x, register_hook=False):
@@ -105,8 +106,7 @@ class Attention(nn.Module):
         require_gpu(x)
         B, N, C = x.shape
         h = as_f32_contig(x).view(B * N, C)
-        h = h if compute_dtype() == torch.float32 else hip.cast_bf16(h)
-        return self.run(h, B, N).view(B, N, C)
+        return self.run(to_compute(h), B, N).view(B, N, C)
 
 
 class Block(nn.Module):
@@ -126,9 +126,10 @@ class Block(nn.Module):
         self._cache = PreparedCache()
 
     def _ln(self, norm, x2d):
-        bf = compute_dtype() == torch.bfloat16
-        y32, ybf = hip.layernorm(x2d, norm.weight, norm.bias, norm.eps, want_f32=not bf, want_bf16=bf)
-        return ybf if bf else y32
+        cdt = compute_dtype()
+        lp = None if cdt == torch.float32 else cdt
+        y32, ylp = hip.layernorm(x2d, norm.weight, norm.bias, norm.eps, want_f32=lp is None, lp=lp)
+        return y32 if lp is None else ylp
 
     def Reduce_token(self, x, reduce_num=0, temperature=0, self_attn=None, cls_attn=None, token_attn=None):
         """vit.py:123-163.  `x` is the FULL token tensor [B,N,D] here (CLS included) - the kernels skip row 0 -
@@ -168,7 +169,7 @@ class Block(nn.Module):
             w.eps, w.scale = self.norm1.eps, self.attn.scale
             w.qkv, w.proj, w.fc1, w.fc2 = [hip.lin_struct(l) for l in lins]
             w.heads, w.dim = self.attn.num_heads, self.attn.dim
-            w.dtype = hip.F32 if compute_dtype() == torch.float32 else hip.BF16
+            w.dtype = dtype_code()
             w.act = hip.ACT_GELU
             return (w, lins)  # keep the prepared tensors alive next to the raw pointers
 

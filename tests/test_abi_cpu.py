@@ -41,10 +41,10 @@ def test_argument_validation_without_gpu(lib_path):
     # argument checks run on the host before any launch: usable as a no-GPU smoke of the error contract
     from madtp_amd import hip
     lib = hip.load()
-    assert lib.madtp_gemm(0, 0, 0, 0, 0, 1, 1, 64, 64, 64, 1, 0, 1, 1, 0, 1.0, 0) == -1      # null pointers
-    assert lib.madtp_gemm(16, 16, 0, 0, 16, 4, 4, 40, 40, 40, 4, 0, 1, 1, 0, 1.0, 0) == -2   # K*2 % 128 != 0
-    assert lib.madtp_gemm(16, 16, 0, 0, 16, 4, 4, 64, 64, 64, 4, 0, 7, 1, 0, 1.0, 0) == -3   # dtype
-    assert lib.madtp_gemm(8, 16, 0, 0, 16, 4, 4, 64, 64, 64, 4, 0, 1, 1, 0, 1.0, 0) == -4    # alignment
+    assert lib.madtp_gemm(0, 0, 0, 0, 0, 1, 1, 64, 64, 64, 1, 0, 1, 1, 0, 1.0, 1.0, 0) == -1      # null pointers
+    assert lib.madtp_gemm(16, 16, 0, 0, 16, 4, 4, 40, 40, 40, 4, 0, 1, 1, 0, 1.0, 1.0, 0) == -2   # K*2 % 128 != 0
+    assert lib.madtp_gemm(16, 16, 0, 0, 16, 4, 4, 64, 64, 64, 4, 0, 7, 1, 0, 1.0, 1.0, 0) == -3   # dtype
+    assert lib.madtp_gemm(8, 16, 0, 0, 16, 4, 4, 64, 64, 64, 4, 0, 1, 1, 0, 1.0, 1.0, 0) == -4    # alignment
     assert lib.madtp_token_select(16, 0, 16, 16, 16, 16, 2, 8, 0) == -2                       # k < 1
 
 

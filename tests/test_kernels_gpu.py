@@ -446,3 +446,109 @@ def test_small_elementwise(hip):
     a, b = _rand(8, 768, seed=50), _rand(8, 768, seed=51)
     assert torch.equal(hip.add_scale(a.cuda(), b.cuda(), 0.5).cpu(), (a + b) / 2)
     assert torch.equal(hip.cast_bf16(a.cuda()).cpu(), a.to(torch.bfloat16))
+
+
+# ---- f16-split ("f16x3") operands: fp32-accurate products on the f16 MFMA ------------------------------------------------
+def _unsplit(p, K):
+    """f16 planes [..., 2K] -> f32 value P0 + 2^-11 P1 (exact in f64)."""
+    return (p[..., :K].double() + p[..., K:].double() / 2048.0)
+
+
+def test_split_f16_roundtrip(hip):
+    """madtp_split_f16: P0 + 2^-11 P1 reproduces an f32 activation to ~2^-23 relative over 12 orders of magnitude;
+    madtp_split_f16_weight: (Q0 + Q1) * 2^-s reproduces the weight, Q2 = Q0 * 2^-11 exactly."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(257, 768, generator=g) * torch.exp(torch.randn(257, 768, generator=g) * 4.0)
+    x = x.clamp(-6.0e4, 6.0e4)
+    p = hip.split_f16(x.cuda())
+    assert p.dtype == torch.float16 and p.shape == (257, 1536)
+    back = _unsplit(p.cpu(), 768)
+    # error <= max(2^-23 |x|, 2^-36): relative while P1 is a normal f16 number, absolute (far below f32 resolution of O(1)
+    # activations) for entries under ~2^-13
+    err = (back - x.double()).abs()
+    assert (err <= torch.maximum(x.double().abs() * 2.0 ** -22, torch.tensor(2.0 ** -35, dtype=torch.float64))).all()
+    w = torch.randn(300, 768, generator=g) * 0.02 * torch.exp(torch.randn(300, 768, generator=g))
+    q = hip.split_f16_weight(w.cuda())
+    s = q._madtp_w_scale
+    assert math.log2(s) == round(math.log2(s)) and q.shape == (300, 3 * 768)
+    qc = q.cpu()
+    wb = (qc[:, :768].double() + qc[:, 768:1536].double()) * s
+    # relative to the tensor's scale: every weight above 2^-17 of the maximum keeps ~2^-22 relative accuracy
+    big = w.abs() > w.abs().max() * 2.0 ** -10
+    assert (((wb - w.double()).abs() / w.double().abs())[big]).max().item() < 2.0 ** -21
+    q0 = qc[:, :768].double()
+    assert torch.equal((q0 / 2048.0).to(torch.float16), qc[:, 1536:])
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (197, 768, 768), (300, 100, 768), (1000, 2304, 768), (130, 768, 3072),
+                                   (257, 2, 768), (10533, 768, 768), (10400, 2304, 768), (10533, 776, 3072)])
+def test_gemm_f16x3(hip, M, N, K):
+    """F16S GEMM vs a float64 matmul of the ORIGINAL f32 operands: the error must be in the rounding class of an f32 dot product
+    (the exact-f32 MFMA kernel is run on the same data as the yardstick), for the small-tile kernels and the wave-specialised
+    one (M >= 4096), with bias / activation / residual and with the split epilogue (F16S output feeding the next GEMM)."""
+    a = _rand(M, K, seed=1)
+    w = _rand(N, K, seed=2, scale=0.05)
+    bias = _rand(N, seed=3)
+    res = _rand(M, N, seed=4)
+    ag, bg, rg = a.cuda(), bias.cuda(), res.cuda()
+    ws = hip.split_f16_weight(_pad128(w).cuda())
+    asp = hip.split_f16(ag)
+    core = ag.double() @ w.cuda().double().t()
+    mag = (ag.double().abs() @ w.cuda().double().abs().t())  # sum |a||w|: the scale of the rounding error
+    out32 = hip.gemm(ag, _pad128(w).cuda(), bg, rg, out_dtype=torch.float32, n=N)
+    ref = (core + bg.double()).float() + rg
+    e32 = ((out32 - ref).abs().double() / mag).max().item()
+    out = hip.gemm(asp, ws, bg, rg, out_dtype=torch.float32, n=N)
+    e16 = ((out - ref).abs().double() / mag).max().item()
+    # f32 dot products of K terms err by ~1e-7 * sum|a||w| (cdna_hip_programming.md section 3); allow 3x the exact kernel + ulps
+    assert e16 < max(3.0 * e32, 3e-7), (e16, e32)
+    for act, fn in ((hip.ACT_GELU, F.gelu), (hip.ACT_RELU, F.relu), (hip.ACT_QUICK_GELU, lambda t: t * torch.sigmoid(1.702 * t))):
+        o = hip.gemm(asp, ws, bg, None, out_dtype=torch.float32, act=act, n=N, out_scale=0.5)
+        r = (fn(core + bg.double()) * 0.5).float()
+        assert ((o - r).abs().double() / mag.clamp_min(1.0)).max().item() < 1e-6, act
+    if N % 8 == 0:
+        # split output (the fused epilogue of fc1 / LayerNorm-free producers): planes of act(a w^T + b)
+        o = hip.gemm(asp, ws, bg, None, out_dtype=torch.float16, act=hip.ACT_GELU, n=N)
+        assert o.shape == (M, 2 * N)
+        r = F.gelu(core + bg.double())
+        assert ((_unsplit(o, N) - r).abs() / mag.clamp_min(1.0)).max().item() < 1e-6
+        # strided split output into a wider buffer: nothing outside the two planes is touched
+    # split-K partials + fused LayerNorm (the BERT projections)
+    if K % 256 == 0 and N % 4 == 0 and N <= 1024 and M <= 2000:
+        gamma, beta = 1.0 + 0.1 * _rand(N, seed=7).cuda(), 0.1 * _rand(N, seed=8).cuda()
+        y32, ylp = hip.gemm_splitk_ln(asp, ws, bg, rg, gamma, beta, 1e-12, 2, N, scale=0.5, lp=torch.float16)
+        r = F.layer_norm(((core + bg.double()) * 0.5 + rg.double()), (N,), gamma.double(), beta.double(), 1e-12)
+        assert (y32.double() - r).abs().max().item() < 2e-5
+        assert (_unsplit(ylp, N) - y32.double()).abs().max().item() < 1e-6
+
+
+def test_gemm_pair_f16x3(hip):
+    M, N, K = 5043, 1536, 768
+    a0, a1 = hip.split_f16(_rand(M, K, seed=1).cuda()), hip.split_f16(_rand(M, K, seed=2).cuda())
+    w0 = hip.split_f16_weight(_pad128(_rand(N, K, seed=3, scale=0.05)).cuda())
+    w1 = hip.split_f16_weight(_pad128(_rand(N, K, seed=4, scale=0.3)).cuda())  # a different power-of-two scale per problem
+    assert w0._madtp_w_scale != w1._madtp_w_scale
+    b0, b1 = _rand(N, seed=5).cuda(), _rand(N, seed=6).cuda()
+    c0, c1 = hip.gemm_pair(a0, a1, w0, w1, b0, b1, N, out_dtype=torch.float32)
+    assert torch.equal(c0, hip.gemm(a0, w0, b0, n=N, out_dtype=torch.float32))
+    assert torch.equal(c1, hip.gemm(a1, w1, b1, n=N, out_dtype=torch.float32))
+
+
+def test_f16s_producers(hip):
+    """LayerNorm / gather+LayerNorm / patchify / BERT embeddings emitting f16 planes == split of their f32 outputs."""
+    x = _rand(333, 768, seed=1).cuda()
+    gamma, beta = 1.0 + 0.1 * _rand(768, seed=2).cuda(), 0.1 * _rand(768, seed=3).cuda()
+    y32, ylp = hip.layernorm(x, gamma, beta, 1e-6, want_f32=True, lp=torch.float16)
+    assert torch.equal(ylp, hip.split_f16(y32))
+    img = _rand(2, 3, 64, 64, seed=4).cuda()
+    assert torch.equal(hip.patchify(img, 16, torch.float16), hip.split_f16(hip.patchify(img, 16, torch.float32)))
+    ids = torch.randint(0, 1000, (3, 20), generator=torch.Generator().manual_seed(5)).cuda()
+    wemb, pemb = _rand(1000, 768, seed=6).cuda(), _rand(64, 768, seed=7).cuda()
+    e32, elp = hip.bert_embed(ids, wemb, pemb, gamma, beta, 1e-12, lp=torch.float16)
+    assert torch.equal(elp, hip.split_f16(e32))
+    B, N, k = 3, 50, 30
+    xt = _rand(B, N, 768, seed=8).cuda()
+    score = torch.rand(B, N - 1, generator=torch.Generator().manual_seed(9)).cuda()
+    _, _, dst_pos, merge_w = hip.token_select(score, k)
+    y, h32, hlp = hip.token_gather_ln(xt, dst_pos, merge_w, k, gamma, beta, 1e-6, want_f32=True, lp=torch.float16)
+    assert torch.equal(hlp, hip.split_f16(h32))

@@ -13,6 +13,8 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "nlvr_*.npz")))
+# the two modes that carry the parity claim: exact-f32 MFMA, and the fp32-accurate f16-split GEMMs on the f16 MFMA
+EXACT_MODES = ["fp32", "f16x3"]
 
 
 @pytest.fixture(scope="module")
@@ -36,13 +38,14 @@ def _golden_sets(g, key, B2, n0):
     return harness.compose_ids(trace, n0)
 
 
+@pytest.mark.parametrize("mode", EXACT_MODES)
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c)[:-4] for c in CASES])
-def test_fp32_mode_matches_reference_fixture(env, path):
+def test_fp32_mode_matches_reference_fixture(env, path, mode):
     harness, runtime, model = env
     g = np.load(path)
     B, size, L, T, seed = int(g["B"]), int(g["size"]), int(g["L"]), float(g["temperature"]), int(g["seed"])
     images, text, targets = harness.nlvr_inputs(B, size, L, seed, pad_tail=int(g["pad_tail"]) if "pad_tail" in g.files else 0)
-    with runtime.precision("fp32"):
+    with runtime.precision(mode):
         logits, trace = harness.run_nlvr(model, images, text, targets, T)
     assert harness.token_lengths(trace["vit"], 197) == g["vit_lens"].tolist()
     assert harness.token_lengths(trace["text"], L) == g["txt_lens"].tolist()
@@ -56,8 +59,9 @@ def test_fp32_mode_matches_reference_fixture(env, path):
     assert np.abs(logits.cpu().numpy() - g["logits"]).max() < 1e-3
 
 
+@pytest.mark.parametrize("mode", EXACT_MODES)
 @pytest.mark.parametrize("B,T,seed", [(3, 2.0, 1), (2, 8.0, 2)])
-def test_fp32_mode_matches_oracle(env, B, T, seed):
+def test_fp32_mode_matches_oracle(env, B, T, seed, mode):
     """fresh seeds (new weights are NOT regenerated - inputs only), oracle computed on this box's CPU."""
     from madtp_amd import specs, synth
     from oracle import madtp_oracle as O
@@ -67,7 +71,7 @@ def test_fp32_mode_matches_oracle(env, B, T, seed):
     tr = {}
     with torch.no_grad():
         ref_logits = O.blip_nlvr_forward(W, images.cpu(), text["input_ids"].cpu(), text["attention_mask"].cpu(), T, trace=tr)
-    with runtime.precision("fp32"):
+    with runtime.precision(mode):
         logits, trace = harness.run_nlvr(model, images, text, targets, T)
     for side, n0 in (("vit", 196), ("text", 19)):
         mine = harness.compose_ids(trace[side], n0)
@@ -111,8 +115,9 @@ def test_module_error_behaviour(env):
 MED_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "med_*.npz")))
 
 
+@pytest.mark.parametrize("mode", EXACT_MODES)
 @pytest.mark.parametrize("path", MED_CASES, ids=[os.path.basename(c)[:-4] for c in MED_CASES])
-def test_med_bert_fp32_matches_reference_fixture(path):
+def test_med_bert_fp32_matches_reference_fixture(path, mode):
     """models/med.py BertModel mirror (text mode and multimodal mode, padded masks) vs the reference fixture."""
     from madtp_amd import build, hip, harness, runtime, specs
     from madtp_amd.med import BertConfig, BertModel
@@ -120,14 +125,14 @@ def test_med_bert_fp32_matches_reference_fixture(path):
     build.build(verbose=False)
     hip.load()
     g = np.load(path)
-    ids, att, enc, enc_att, sd, mode, T = med_inputs(g)
+    ids, att, enc, enc_att, sd, bert_mode, T = med_inputs(g)
     cfg = BertConfig.med_default()
     model = BertModel(cfg, add_pooling_layer=False)
     model.load_state_dict(specs.synth_weights(specs.bert_shapes("", "med"), int(g["seed"])), strict=False)
     model = model.eval().cuda()
-    with runtime.precision("fp32"), torch.no_grad():
+    with runtime.precision(mode), torch.no_grad():
         out, _ = model(ids.cuda(), attention_mask=att.cuda(), encoder_hidden_states=None if enc is None else enc.cuda(),
-                       encoder_attention_mask=None if enc_att is None else enc_att.cuda(), mode=mode,
+                       encoder_attention_mask=None if enc_att is None else enc_att.cuda(), mode=bert_mode,
                        space_dict=sd.cuda(), temperature=T)
     hid = out.last_hidden_state
     assert list(hid.shape) == g["hidden_shape"].tolist()
@@ -142,7 +147,7 @@ def test_med_bert_fp32_matches_reference_fixture(path):
     assert np.abs(hid[:, 0, :32].cpu().numpy() - g["hidden_cls"]).max() < 1e-3
     with runtime.precision("bf16"), torch.no_grad():
         outb, _ = model(ids.cuda(), attention_mask=att.cuda(), encoder_hidden_states=None if enc is None else enc.cuda(),
-                        encoder_attention_mask=None if enc_att is None else enc_att.cuda(), mode=mode,
+                        encoder_attention_mask=None if enc_att is None else enc_att.cuda(), mode=bert_mode,
                         space_dict=sd.cuda(), temperature=T)
     assert torch.isfinite(outb.last_hidden_state).all()
 
@@ -150,8 +155,9 @@ def test_med_bert_fp32_matches_reference_fixture(path):
 CLIP_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clip_*.npz")))
 
 
+@pytest.mark.parametrize("mode", EXACT_MODES)
 @pytest.mark.parametrize("path", CLIP_CASES, ids=[os.path.basename(c)[:-4] for c in CLIP_CASES])
-def test_clip_vision_fp32_matches_reference_fixture(path):
+def test_clip_vision_fp32_matches_reference_fixture(path, mode):
     """clip/model.py VisionTransformer/ResidualAttentionBlock mirror vs the reference fixture (row a14, config 4)."""
     from madtp_amd import build, hip, harness, runtime, specs, synth
     from madtp_amd.clip_model import VisionTransformer
@@ -166,7 +172,7 @@ def test_clip_vision_fp32_matches_reference_fixture(path):
     model = model.eval().cuda()
     images = synth.synth_images(B, size, seed).cuda()
     space_dict = synth.synth_tensor("space_dict", (100, 768), seed).cuda()
-    with runtime.precision("fp32"), torch.no_grad():
+    with runtime.precision(mode), torch.no_grad():
         feat, sd_ft = model(images, space_dict, T, 1)
     trace = [None if b.last_prune is None else {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.last_prune.items()}
              for b in model.transformer.resblocks]
@@ -188,8 +194,9 @@ def test_clip_vision_fp32_matches_reference_fixture(path):
 VIT_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vit*_b*.npz")))
 
 
+@pytest.mark.parametrize("mode", EXACT_MODES)
 @pytest.mark.parametrize("path", VIT_CASES, ids=[os.path.basename(c)[:-4] for c in VIT_CASES])
-def test_vit_large_image_fp32_matches_reference_fixture(path):
+def test_vit_large_image_fp32_matches_reference_fixture(path, mode):
     """VisionTransformer mirror at 384^2 (577 tokens) and 480^2 (901 tokens - BASELINE config 5, heaviest ragged
     compaction): long-sequence attention kernel + the same pruning kernels, vs the reference fixture."""
     from madtp_amd import build, hip, harness, runtime, specs, synth
@@ -204,7 +211,7 @@ def test_vit_large_image_fp32_matches_reference_fixture(path):
     images = synth.synth_images(B, size, seed).cuda()
     space_dict = synth.synth_tensor("space_dict", (100, 768), seed).cuda()
     n0 = (size // 16) ** 2
-    with runtime.precision("fp32"), torch.no_grad():
+    with runtime.precision(mode), torch.no_grad():
         out, sd_ft = model(images, space_dict=space_dict, temperature=T)
     trace = [None if b.last_prune is None else {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.last_prune.items()}
              for b in model.blocks]
@@ -225,7 +232,7 @@ def test_vit_large_image_fp32_matches_reference_fixture(path):
     assert (sd_b - sd_b2).abs().max().item() < 1e-4 * sd_b2.abs().max().item()
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "f16x3", "bf16"])
 def test_fused_layer_calls_equal_two_step(mode):
     """madtp_vit_block / madtp_bert_layer (one library call, k through pinned host memory, score launched before the
     projection) give bit-identical results to the half-layer entry points with the host decision made in Python."""
@@ -261,8 +268,9 @@ def test_fused_layer_calls_equal_two_step(mode):
 RETR_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "retr_*.npz")))
 
 
+@pytest.mark.parametrize("mode", EXACT_MODES)
 @pytest.mark.parametrize("path", RETR_CASES, ids=[os.path.basename(c)[:-4] for c in RETR_CASES])
-def test_retrieval_itm_reranking_matches_reference_fixture(path):
+def test_retrieval_itm_reranking_matches_reference_fixture(path, mode):
     """blip_retrieval.evaluate() mirror vs the score matrices the reference's own evaluate() produced:
     fp32 mode re-ranks the same candidates with the same scores (incl. the cross-batch CLS-repeat padding and the text-side
     pruning inside the k_test-pair multimodal batches); bf16 mode stays close; rank slicing (2 ranks) sums to the whole."""
@@ -277,7 +285,7 @@ def test_retrieval_itm_reranking_matches_reference_fixture(path):
     batches, ids, att = harness.retrieval_inputs(n_img, img_bs, n_txt, size, 35, seed, device="cuda")
     loader = harness.RetrievalLoader(batches, ids, att)
     cfg = {"k_test": k_test}
-    with runtime.precision("fp32"):
+    with runtime.precision(mode):
         i2t, t2i, _ = br.evaluate(model, loader, torch.device("cuda"), cfg, T)
         parts = [br.evaluate(model, loader, torch.device("cuda"), cfg, T, rank=r, world_size=2) for r in range(2)]
     for ours, ref in ((i2t, g["score_i2t"]), (t2i, g["score_t2i"])):
@@ -289,7 +297,7 @@ def test_retrieval_itm_reranking_matches_reference_fixture(path):
         assert np.array_equal(merged, full)
         assert not ((parts[0][k] != -100.0) & (parts[1][k] != -100.0)).any()
     # the K/V cache (images projected once per layer, attention indexes the cache) changes no bit of the scores
-    with runtime.precision("fp32"):
+    with runtime.precision(mode):
         n_i2t, n_t2i, _ = br.evaluate(model, loader, torch.device("cuda"), cfg, T, kv_cache=False)
     assert np.array_equal(n_i2t, i2t) and np.array_equal(n_t2i, t2i)
     with runtime.precision("bf16"):
