@@ -23,7 +23,7 @@ extern "C" {
 #define MADTP_BF16 1
 /* f16-split operands of the fp32-accurate GEMM on the f16 MFMA ("f16x3" precision mode): an f32 matrix [R,K] stored as
  * f16 planes side by side in a row - activations [P0 | P1] (2K f16 per row, P0 = f16(x), P1 = f16((x-P0) 2^11)), prepared
- * weights [Q0 | Q1 | Q2] (3K f16 per row, scaled by the power of two in madtp_lin.w_scale); leading dimensions of such
+ * weights [Q0 | Q1] (2K f16 per row, w 2^s = Q0 + Q1 with the power of two in madtp_lin.w_scale); leading dimensions of such
  * operands count f16 elements.  Written by madtp_split_f16 / the LayerNorm and GEMM epilogues, read by madtp_gemm. */
 #define MADTP_F16S 2
 
@@ -51,7 +51,7 @@ const char* madtp_strerror(int code);
  * W must be padded by the caller to a multiple of 128 rows (zero rows) - n_pad rows are read, N columns stored.
  * bias (f32, may be NULL), residual (f32 [M,ldr], may be NULL), C dtype c_dtype with leading dimension ldc
  * (BF16 output needs BF16 operands, F16S output F16S operands; F32 output is always available).
- * K must be a multiple of 64 (bf16, f16-split) / 32 (f32); lda, ldw in elements (f16 elements for F16S: >= 2K, >= 3K). */
+ * K must be a multiple of 64 (bf16, f16-split) / 32 (f32); lda, ldw in elements (f16 elements for F16S: both >= 2K). */
 int madtp_gemm(const void* A, const void* W, const float* bias, const float* residual, void* C,
                int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                int ab_dtype, int c_dtype, int act, float acc_scale, float out_scale, void* stream);
@@ -205,10 +205,13 @@ typedef struct madtp_att_ft_seg {
 int madtp_query_att_ft_multi(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float* stats_ws, float inv_sqrt_sd,
                              int accumulate, int B, int dim, void* stream);  /* stats_ws: nseg*B*256 floats of scratch */
 
-/* Fast-mode alignment logits out[M,128] = x[M,dim] @ sd^T with sd given as a bf16 hi/lo split ([128,dim] each, rows
- * beyond the dictionary size zero): x is split in registers and xh.sh + xl.sh + xh.sl runs on the bf16 MFMA
- * (~2^-16 relative error instead of bf16's 2^-9).  models/utils.py:170. */
-int madtp_align_logits(const float* x, const void* sd_hi, const void* sd_lo, float* out, int M, int dim, void* stream);
+/* Alignment logits out[M,128] = x[M,dim] @ sd^T with the dictionary given as two [128,dim] 2-byte planes (rows beyond the
+ * dictionary size zero) and x split in registers.  models/utils.py:170.
+ *   split_dtype MADTP_BF16 (fast mode): bf16 hi/lo planes, xh.sh + xl.sh + xh.sl on the bf16 MFMA (~2^-16 relative error);
+ *   split_dtype MADTP_F16S ("f16x3" mode): the f16 planes Q0 / Q1 of sd * 2^s, three f16 MFMA products (fp32-accurate,
+ *   see MADTP_F16S above), result scaled by out_scale = 2^-s. */
+int madtp_align_logits(const float* x, const void* sd_hi, const void* sd_lo, float* out, int M, int dim, int split_dtype,
+                       float out_scale, void* stream);
 
 /* vector_gather (models/utils.py:13-33): out[b,k,:] = vectors[b, indices[b,k], :]; f32 [B,L,D], int64 [B,K]. */
 int madtp_vector_gather(const float* vectors, const int64_t* indices, float* out, int B, int L, int K, int D,
@@ -225,7 +228,7 @@ int madtp_cast_bf16(const float* src, void* dst, size_t n, void* stream);
  * one of the fused epilogues (attention output, image tokens handed to the text encoder).  K % 4 == 0. */
 int madtp_split_f16(const float* src, int ld_src, void* dst, int ld_dst, int rows, int K, void* stream);
 
-/* Weight preparation for F16S GEMMs: w f32 [n, K] (row stride ldw) -> planes [Q0 | Q1 | Q2] f16 [n, 3K] of w * 2^s, with
+/* Weight preparation for F16S GEMMs: w f32 [n, K] (row stride ldw) -> planes [Q0 | Q1] f16 [n, 2K] of w * 2^s, with
  * inv_scale = 2^s chosen by the caller as a power of two such that max|w| * 2^s <= 2^14 (madtp_lin.w_scale = 2^-s). */
 int madtp_split_f16_weight(const float* w, int ldw, void* dst, int n, int K, float inv_scale, void* stream);
 
@@ -237,7 +240,7 @@ int madtp_split_f16_weight(const float* w, int ldw, void* dst, int n, int K, flo
  * Scratch comes from a caller-owned workspace of at least *_workspace() bytes (256-byte aligned base).
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct madtp_lin {
-    const void* w;  /* [n_pad, k] row-major, compute dtype ([n_pad, 3k] f16 planes for MADTP_F16S) */
+    const void* w;  /* [n_pad, k] row-major, compute dtype ([n_pad, 2k] f16 planes for MADTP_F16S) */
     const float* b; /* [n] or NULL */
     int n, k;
     float w_scale;  /* accumulator scale of the prepared weight: 2^-s for F16S planes (w stored as w * 2^s), 1 otherwise */
@@ -278,10 +281,11 @@ int madtp_vit_block(const madtp_vit_block_w* w, const float* x, float* x_attn, f
 /* Query_model.forward(return_token_att=True) (models/utils.py:147-183) over a contiguous token buffer x[B,N,dim]:
  * token_attn_full[B*N, 128] = x @ sd^T (exact-f32 MFMA; sd_w is f32 [128,dim], rows >= K zero); row b*N+1+t is patch t.
  * att_ft[B,K,dim] (+)= softmax_t(logits/sqrt(sd_dim)) @ x[:,1:]  (skipped when att_ft is NULL). */
-int madtp_query_model(const float* x, const void* sd_w, const void* sd_hi, const void* sd_lo, int K,
-                      float* token_attn_full, float* att_ft, float* stats_ws, int accumulate, float inv_sqrt_sd, int B, int N,
-                      int dim, void* stream);
-/* sd_hi/sd_lo != NULL selects the fast-mode kernels (bf16x3 logits, bf16 att_ft; att_ft then needs stats_ws = B*256 floats) */
+int madtp_query_model(const float* x, const void* sd_w, const void* sd_hi, const void* sd_lo, int split_dtype, float sd_scale,
+                      int K, float* token_attn_full, float* att_ft, float* stats_ws, int accumulate, float inv_sqrt_sd, int B,
+                      int N, int dim, void* stream);
+/* sd_hi/sd_lo != NULL selects madtp_align_logits for the logits (split_dtype / sd_scale as there); with split_dtype
+ * MADTP_BF16 att_ft also runs its bf16 kernel (needs stats_ws = B*256 floats), with MADTP_F16S it stays on the exact-f32 one */
 
 /* models/med.py BertLayer (:332-467) / models/nlvr_encoder.py BertLayer (:385-559) */
 typedef struct madtp_bert_layer_w {

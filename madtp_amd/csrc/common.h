@@ -26,9 +26,10 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // An f32 matrix X[R, K] is stored as f16 planes side by side in one row.
 //   activations, 2 planes (row = [P0 | P1]: 2K f16 = the bytes of the f32 row):
 //       P0 = f16(x),  P1 = f16((x - P0) * 2^11)            ->  x = P0 + 2^-11 P1 to ~2^-24 relative (|x| < 65504)
-//   weights, pre-scaled per tensor by a power of two (w~ = w 2^s, max|w~| in (2^13, 2^14]), 3 planes (row = [Q0 | Q1 | Q2]):
-//       Q0 = f16(w~),  Q1 = f16(w~ - Q0),  Q2 = f16(Q0 2^-11)   (normal f16 numbers for every weight above 2^-17 of the maximum)
-// so that   x w~ = P0 Q1 + P1 Q2 + P0 Q0   (+ 2^-11 P1 Q1, dropped: < 2^-23 relative)
+//   weights, pre-scaled per tensor by a power of two (w~ = w 2^s, max|w~| in (2^13, 2^14]), 2 planes (row = [Q0 | Q1]):
+//       Q0 = f16(w~),  Q1 = f16(w~ - Q0)     (Q0 2^-11, formed in registers by the GEMM, is a normal f16 number for every
+//                                              weight above 2^-17 of the tensor's maximum)
+// so that   x w~ = P0 Q1 + P0 Q0 + P1 (Q0 2^-11)   (+ 2^-11 P1 Q1, dropped: < 2^-23 relative)
 // is THREE f16 MFMA products with exact partial products and f32 accumulation: 3/16 of the cost of the exact-f32 MFMA.
 constexpr float F16S_LO_SCALE = 2048.0f;  // 2^11
 __device__ __forceinline__ void split_f16x8(f32x4 a, f32x4 b, u32x4& p0, u32x4& p1) {

@@ -39,11 +39,14 @@ struct GemmArgs {
     float acc_scale2; // the same for the second problem of a pair launch
 };
 
-// f16-split operands (common.h): the kernels walk the three plane products as ONE stream of 3 * K/64 slabs, small terms
-// first - pair p = slab / (K/64) multiplies activation plane x3_a_plane(p) with weight plane x3_w_plane(p).
+// f16-split operands (common.h).  The kernels walk K as a stream of 2 * K/64 slab steps: step 2t stages [P0 | Q1] of k-slab t,
+// step 2t+1 stages [P1 | Q0]; the three products of a k-slab are P0 Q1 (first step), P0 Q0 and P1 (Q0 2^-11) (second step, with
+// the P0 fragments kept in registers and Q0 scaled in registers): 96 MFMAs per 2 staged slab pairs instead of 96 per 3.
 struct F16S {};  // operand tag of gemm_kernel<>
-__device__ __forceinline__ int x3_a_plane(int p) { return p == 1 ? 1 : 0; }                  // P0, P1, P0
-__device__ __forceinline__ int x3_w_plane(int p) { return p == 0 ? 1 : (p == 1 ? 2 : 0); }   // Q1, Q2, Q0
+__device__ __forceinline__ bf16x8 x3_scale_lo(bf16x8 q) {  // Q0 * 2^-11 (v_pk_mul_f16; f16 denormals are kept)
+    const f16x8 v = __builtin_bit_cast(f16x8, q) * (_Float16)(1.0f / F16S_LO_SCALE);
+    return __builtin_bit_cast(bf16x8, v);
+}
 template <bool F16>
 __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
     if constexpr (F16)
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nkp = g.K * ESZ / ROWB;             // slabs per operand plane
-    const int nk = (X3 ? 3 : 1) * nkp / S;        // slabs per slot
+    const int nk = (X3 ? 2 : 1) * nkp / S;        // staged slab steps per slot (f16-split: [P0|Q1], [P1|Q0] per k-slab; nkp % S == 0)
     const int n_pad_max = g.ntn * BN - 1;
 
     // LDS byte offsets of this lane's fragment rows (row*128) and their swizzle keys (row&7)
@@ -345,9 +348,9 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
             char* st = smem + is_stage * STAGE_BYTES;
             int kba = (ikb + is_kt) * ROWB, kbw = kba;
             if constexpr (X3) {
-                const int sl = ikb + is_kt, p = sl / nkp, kt = sl - p * nkp;
-                kba = (x3_a_plane(p) * g.K + kt * 64) * 2;
-                kbw = (x3_w_plane(p) * g.K + kt * 64) * 2;
+                const int sl = ikb + is_kt, odd = sl & 1, kt = sl >> 1;
+                kba = (odd * g.K + kt * 64) * 2;
+                kbw = ((1 - odd) * g.K + kt * 64) * 2;
             }
             stage_tile<ESZ, BM>(g.A, im0, g.M - 1, g.lda, kba, st, wave, lane);
             stage_tile<ESZ, BN, LP_OUT>(g.W, in0, n_pad_max, g.ldw, kbw, st + A_BYTES, wave, lane);
@@ -371,6 +374,7 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
     // f32-output tiles carry the residual stream: its float4s are fetched two slabs before the epilogue so the HBM
     // latency hides under the last MFMAs instead of stalling the store phase.
     f32x4 res[LP_OUT ? 1 : FM][LP_OUT ? 1 : FN];
+    bf16x8 keep_p0[X3 ? 2 : 1][X3 ? FM : 1];  // f16-split: the P0 fragments of the even step, used again by the odd step
     const bool res_pref = !LP_OUT && g.residual && g.fast_epi;
     const int kt_pref = nk >= 2 ? nk - 2 : 0;
     while (true) {
@@ -408,11 +412,33 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
                     for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(sa + a_off[i] + ((chunk ^ a_key[i]) << 4));
 #pragma unroll
                     for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(sw + b_off[j] + ((chunk ^ b_key[j]) << 4));
+                    if constexpr (X3) {
+                        if ((kt & 1) == 0) {  // [P0 | Q1] (a slot starts on an even step): P0 Q1, keep P0
 #pragma unroll
-                    for (int i = 0; i < FM; ++i)
+                            for (int i = 0; i < FM; ++i) {
+                                keep_p0[kk][i] = a[i];
 #pragma unroll
-                        for (int j = 0; j < FN; ++j)
-                            acc[i][j] = mfma_16x16x32<X3>(b[j], a[i], acc[i][j]);
+                                for (int j = 0; j < FN; ++j) acc[i][j] = mfma_16x16x32<true>(b[j], a[i], acc[i][j]);
+                            }
+                        } else {              // [P1 | Q0]: P0 Q0 + P1 (Q0 2^-11)
+#pragma unroll
+                            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                                for (int j = 0; j < FN; ++j) acc[i][j] = mfma_16x16x32<true>(b[j], keep_p0[kk][i], acc[i][j]);
+#pragma unroll
+                            for (int j = 0; j < FN; ++j) b[j] = x3_scale_lo(b[j]);
+#pragma unroll
+                            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                                for (int j = 0; j < FN; ++j) acc[i][j] = mfma_16x16x32<true>(b[j], a[i], acc[i][j]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < FM; ++i)
+#pragma unroll
+                            for (int j = 0; j < FN; ++j)
+                                acc[i][j] = mfma_16x16x32<false>(b[j], a[i], acc[i][j]);
+                    }
                 } else {
                     f32x4 a[FM], b[FN];
 #pragma unroll
@@ -509,7 +535,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nkp = g.K * ESZ / ROWB;     // slabs per operand plane
-    const int nk = (X3 ? 3 : 1) * nkp;    // slabs per tile (f16-split: the three plane products back to back)
+    const int nk = (X3 ? 2 : 1) * nkp;    // staged slab steps per tile (f16-split: [P0|Q1], [P1|Q0] per k-slab)
     const int my_slots = (nslots - lb + gl - 1) / gl;
     const long total_slabs = (long)my_slots * nk;
 
@@ -518,7 +544,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
         const int lw = wave - NCW, sub = lane >> 3;
         const int n_pad_max = g.ntn * BN - 1;
         int is_slot = lb, is_kt = 0, is_stage = 0;
-        int is_pair = 0, is_pk = 0;  // f16-split: plane pair of the next slab and its slab index within the plane
+        int is_odd = 0, is_pk = 0;  // f16-split: parity of the next step ([P0|Q1] or [P1|Q0]) and its k-slab
         long issued = 0;
         const char* srcp[PER];  // per-lane source of each DMA instruction at k = 0 of the current tile
         auto tile_ptrs = [&]() {
@@ -547,7 +573,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             if (issued < total_slabs && !(g.dbg & 2)) {
                 char* st = smem + is_stage * STAGE_BYTES + lw * PER * 1024;
                 if constexpr (X3) {
-                    const int offa = (x3_a_plane(is_pair) * g.K + is_pk * 64) * 2, offw = (x3_w_plane(is_pair) * g.K + is_pk * 64) * 2;
+                    const int offa = (is_odd * g.K + is_pk * 64) * 2, offw = ((1 - is_odd) * g.K + is_pk * 64) * 2;
 #pragma unroll
                     for (int q = 0; q < PER; ++q)
                         __builtin_amdgcn_global_load_lds(GLOBAL_PTR(srcp[q] + (lw * PER + q < BM / 8 ? offa : offw)),
@@ -561,7 +587,8 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             ++issued;
             if (++is_stage == STAGES) is_stage = 0;
             if constexpr (X3) {
-                if (++is_pk == nkp) { is_pk = 0; if (++is_pair == 3) is_pair = 0; }
+                if (is_odd) { if (++is_pk == nkp) is_pk = 0; }
+                is_odd ^= 1;
             }
             if (++is_kt == nk) {
                 is_kt = 0;
@@ -618,6 +645,80 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
     long long ws_t0 = ws_t_begin;
 #endif
     for (int slot = lb; slot < nslots; slot += gl) {
+      if constexpr (X3) {
+        // f16-split: per k-slab two staged steps SA = [P0|Q1], SB = [P1|Q0] and six groups of 16 MFMAs,
+        //   G1 P0a Q1a   G2 P0b Q1b   G3 P0a Q0a   G4 P1a Q0a'   G5 P0b Q0b   G6 P1b Q0b'      (a / b: the two 32-deep halves, ' : * 2^-11)
+        // with every fragment read issued one group ahead of its first use, so at most four 4-fragment sets are live (as in the
+        // bf16 loop).  barrier(SB) sits between G1 and G2, barrier(next SA) between G5 and G6: all reads of a stage are complete
+        // (lgkmcnt(0)) before the barrier that lets the loaders overwrite it.
+#define X3_READ_A(R, ST, CH) _Pragma("unroll") for (int i = 0; i < 4; ++i) R[i] = *(const bf16x8*)((ST) + a_off[i] + ((((CH) + grp4) ^ a_key[i]) << 4));
+#define X3_READ_W(R, ST, CH) _Pragma("unroll") for (int i = 0; i < 4; ++i) R[i] = *(const bf16x8*)((ST) + b_off[i] + ((((CH) + grp4) ^ b_key[i]) << 4));
+#define X3_MFMA(RA, RW)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
+            acc[i][j] = mfma_16x16x32<true>(RW[j], RA[i], acc[i][j]);
+#define X3_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define X3_LGKM0() do { X3_FENCE(); __builtin_amdgcn_s_waitcnt(0xC07F); X3_FENCE(); } while (0)
+        bf16x8 p0a[4], p0b[4], q1a[4], q1b[4], q0[4], p1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = zero4;
+        {
+            const char* sA = smem + cur_stage * STAGE_BYTES;
+            __builtin_amdgcn_s_barrier();  // SA of the tile's first k-slab landed
+            X3_READ_A(p0a, sA, 0) X3_READ_W(q1a, sA, 0)
+        }
+        // (the last k-slab of a tile is peeled: a conditional re-read of p0a / q1a inside the loop would keep their old values
+        //  live across the whole body - two more fragment sets than the register budget of a 12-wave workgroup holds)
+#define X3_KSLAB(LAST)                                                                                                    \
+        {                                                                                                                 \
+            const char* sA = smem + cur_stage * STAGE_BYTES;                                                              \
+            if (++cur_stage == STAGES) cur_stage = 0;                                                                     \
+            const char* sB = smem + cur_stage * STAGE_BYTES;                                                              \
+            if (++cur_stage == STAGES) cur_stage = 0;                                                                     \
+            const char* sN = smem + cur_stage * STAGE_BYTES; /* SA of the next k-slab */                                  \
+            X3_READ_A(p0b, sA, 4) X3_READ_W(q1b, sA, 4)                                                                   \
+            X3_FENCE();                                                                                                   \
+            X3_MFMA(p0a, q1a) /* G1 */                                                                                    \
+            X3_LGKM0();                                                                                                   \
+            __builtin_amdgcn_s_barrier(); /* SB landed; every wave is done reading SA */                                  \
+            X3_READ_W(q0, sB, 0)                                                                                          \
+            X3_FENCE();                                                                                                   \
+            X3_MFMA(p0b, q1b) /* G2 */                                                                                    \
+            X3_FENCE();                                                                                                   \
+            X3_READ_A(p1, sB, 0)                                                                                          \
+            X3_FENCE();                                                                                                   \
+            X3_MFMA(p0a, q0) /* G3 */                                                                                     \
+            X3_FENCE();                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) q1a[i] = x3_scale_lo(q0[i]);                                    \
+            X3_READ_W(q0, sB, 4)                                                                                          \
+            X3_FENCE();                                                                                                   \
+            X3_MFMA(p1, q1a) /* G4 */                                                                                     \
+            X3_FENCE();                                                                                                   \
+            X3_READ_A(p1, sB, 4)                                                                                          \
+            X3_FENCE();                                                                                                   \
+            X3_MFMA(p0b, q0) /* G5 */                                                                                     \
+            X3_FENCE();                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) q1b[i] = x3_scale_lo(q0[i]);                                    \
+            X3_LGKM0();                                                                                                   \
+            if constexpr (!(LAST)) {                                                                                      \
+                __builtin_amdgcn_s_barrier(); /* next SA landed; every wave is done reading SB */                         \
+                X3_READ_A(p0a, sN, 0) X3_READ_W(q1a, sN, 0)                                                               \
+            }                                                                                                             \
+            X3_FENCE();                                                                                                   \
+            X3_MFMA(p1, q1b) /* G6 */                                                                                     \
+            X3_FENCE();                                                                                                   \
+        }
+        for (int kt = 0; kt + 1 < nkp; ++kt) X3_KSLAB(false)
+        X3_KSLAB(true)
+#undef X3_KSLAB
+#undef X3_READ_A
+#undef X3_READ_W
+#undef X3_MFMA
+#undef X3_FENCE
+#undef X3_LGKM0
+      } else {
         {   // first slab of the tile: accumulators start from zero, no Y pending
             constexpr bool first = true;
             const char* st = smem + cur_stage * STAGE_BYTES;
@@ -651,13 +752,14 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             if (++cur_stage == STAGES) cur_stage = 0;
         }
+        { MADTP_WS_MFMA(ya, yb) }
+      }
         int t = t0 + slot;
         const bool second = g.pair && t >= tiles1;
         if (second) t -= tiles1;
         int ctm, ctn;
         tile_mn(g, t, ctm, ctn);
         const int m0 = ctm * BM + grp * 128, n0 = ctn * BN;
-        { MADTP_WS_MFMA(ya, yb) }
 #ifdef MADTP_WS_TIMING
         { const long long now = WS_NOW(); ws_t_main += now - ws_t0; ws_t0 = now; }
 #endif
@@ -775,7 +877,7 @@ extern "C" int madtp_gemm_splitk(const void* A, const void* W, float* part, int 
                                  int ab_dtype, void* stream) {
     if (splits < 1) return MADTP_E_BADARG;
     const int esz = ab_dtype == MADTP_F32 ? 4 : 2;
-    if (((ab_dtype == MADTP_F16S ? 3 : 1) * K * esz / ROWB) % splits) return MADTP_E_SHAPE;
+    if ((K * esz / ROWB) % splits) return MADTP_E_SHAPE;  // (f16-split: every K range holds whole [P0|Q1],[P1|Q0] step pairs)
     return gemm_launch(A, W, nullptr, nullptr, part, M, N, K, lda, ldw, N, 0, ab_dtype, MADTP_F32, MADTP_ACT_NONE, 1.f, 1.f, splits,
                        stream);
 }
@@ -792,8 +894,8 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     const int esz = ab_dtype == MADTP_F32 ? 4 : 2;
     if ((K * esz) % ROWB != 0) return MADTP_E_SHAPE;
     if (!aligned16(A) || !aligned16(W) || (lda * esz) % 16 || (ldw * esz) % 16) return MADTP_E_ALIGN;
-    // f16-split operands: leading dimensions count f16 elements (2 planes of K per activation row, 3 per weight row)
-    if (lda < (x3 ? 2 : 1) * K || ldw < (x3 ? 3 : 1) * K || ldc < (c_dtype == MADTP_F16S ? 2 : 1) * N || (residual && ldr < N))
+    // f16-split operands: leading dimensions count f16 elements (2 planes of K per activation row and per weight row)
+    if (lda < (x3 ? 2 : 1) * K || ldw < (x3 ? 2 : 1) * K || ldc < (c_dtype == MADTP_F16S ? 2 : 1) * N || (residual && ldr < N))
         return MADTP_E_SHAPE;
     GemmArgs g;
     g.A = (const char*)A; g.W = (const char*)W; g.bias = bias; g.residual = residual; g.C = C;
@@ -843,13 +945,14 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         g.pair = 1; g.A2 = (const char*)pair->A; g.W2 = (const char*)pair->W; g.bias2 = pair->bias; g.C2 = pair->C;
     }
     if (force_cfg > 0 && force_cfg <= 4) cfg = force_cfg - 1;
+    if (x3 && cfg == 0) cfg = 1;  // f16-split: 64x128 tiles (the 128x128 variant would spill the kept P0 fragments)
     hipStream_t s = (hipStream_t)stream;
     GemmRecord rec;
     if (g_prof_on) {
         (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
         rec.flops = 2.0 * M * N * K; rec.dt = ab_dtype; rec.M = M; rec.N = N; rec.K = K;
         // algorithmic HBM bytes: A and W once, C once (x splits), bias, residual once
-        rec.bytes = (double)esz * ((x3 ? 2.0 : 1.0) * M * K + (x3 ? 3.0 : 1.0) * N * K) + (double)M * N * (c_dtype == MADTP_BF16 ? 2 : 4) * splitk +
+        rec.bytes = (double)esz * (x3 ? 2.0 : 1.0) * ((double)M * K + (double)N * K) + (double)M * N * (c_dtype == MADTP_BF16 ? 2 : 4) * splitk +
                     (bias ? 4.0 * N : 0.0) + (residual ? 4.0 * M * N : 0.0);
         if (pair) { rec.flops *= 2.0; rec.bytes *= 2.0; }  // two problems in this launch
         (void)hipEventRecord(rec.e0, s);

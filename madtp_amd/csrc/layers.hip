@@ -26,7 +26,7 @@ inline int pld(int dt, int ld) { return dt == MADTP_F16S ? 2 * ld : ld; }
 // dtype the attention kernels run in: the f16-split mode keeps attention on the exact-f32 kernels (q/k/v/out f32)
 inline int attn_dt(int dt) { return dt == MADTP_F16S ? MADTP_F32 : dt; }
 // 128-byte K slabs a GEMM with operand dtype dt walks
-inline int slabs_of(int K, int dt) { return dt == MADTP_F32 ? K / 32 : (dt == MADTP_F16S ? 3 : 1) * K / 64; }
+inline int slabs_of(int K, int dt) { return dt == MADTP_F32 ? K / 32 : K / 64; }  // (f16-split: k-slabs; 2 staged steps each)
 
 #define TRY(call)                  \
     do {                           \
@@ -37,7 +37,7 @@ inline int slabs_of(int K, int dt) { return dt == MADTP_F32 ? K / 32 : (dt == MA
 // lda / ldc: LOGICAL row lengths (elements of the f32 matrix); split operands get their physical stride here
 inline int lin(const void* a, int lda, const madtp_lin& L, const float* residual, int ldr, void* c, int ldc, int M,
                int dt, int c_dt, int act, float scale, void* stream) {
-    return madtp_gemm(a, L.w, L.b, residual, c, M, L.n, L.k, pld(dt, lda), (dt == MADTP_F16S ? 3 : 1) * L.k, pld(c_dt, ldc), ldr,
+    return madtp_gemm(a, L.w, L.b, residual, c, M, L.n, L.k, pld(dt, lda), (dt == MADTP_F16S ? 2 : 1) * L.k, pld(c_dt, ldc), ldr,
                       dt, c_dt, act, L.w_scale, scale, stream);
 }
 
@@ -64,8 +64,9 @@ inline int choose_splits(int M, int N, int K, int dt) {
         // one round (768 workgroups) and every split keeps >= 12 slabs
         const int t64 = ((M + 63) / 64) * ((N + 63) / 64);
         int best = 1;
+        const int steps = dt == MADTP_F16S ? 2 * nk : nk;  // staged slab steps of the K loop
         for (int sp = 2; sp <= 4; ++sp)
-            if (nk % sp == 0 && nk / sp >= 12 && t64 * sp <= 768) best = sp;
+            if (nk % sp == 0 && steps / sp >= 12 && t64 * sp <= 768) best = sp;
         return best;
     }
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
@@ -80,7 +81,7 @@ inline int choose_splits(int M, int N, int K, int dt) {
 inline int lin_ln(const void* a, int lda, const madtp_lin& L, const float* residual, float scale, const float* gamma,
                   const float* beta, float* y32, void* ylp, int M, int dt, float eps, float* part, void* stream) {
     const int S = choose_splits(M, L.n, L.k, dt);
-    const int ldw = (dt == MADTP_F16S ? 3 : 1) * L.k;
+    const int ldw = (dt == MADTP_F16S ? 2 : 1) * L.k;
     if (S > 1) {
         TRY(madtp_gemm_splitk(a, L.w, part, M, L.n, L.k, pld(dt, lda), ldw, S, dt, stream));
         return madtp_splitk_ln(part, S, L.b, residual, gamma, beta, y32, ylp, dt, M, L.n, eps, L.w_scale, scale, stream);
@@ -260,15 +261,16 @@ extern "C" int madtp_vit_block(const madtp_vit_block_w* w, const float* x, float
 
 // Query_model (models/utils.py:147-183) on the token buffer in place: logits of ALL rows of x (the CLS row is computed
 // and ignored) with the exact-f32 MFMA, then att_ft over the patch rows.
-extern "C" int madtp_query_model(const float* x, const void* sd_w, const void* sd_hi, const void* sd_lo, int K,
-                                 float* token_attn_full, float* att_ft, float* stats_ws, int accumulate, float inv_sqrt_sd,
-                                 int B, int N, int dim, void* stream) {
+extern "C" int madtp_query_model(const float* x, const void* sd_w, const void* sd_hi, const void* sd_lo, int split_dtype,
+                                 float sd_scale, int K, float* token_attn_full, float* att_ft, float* stats_ws, int accumulate,
+                                 float inv_sqrt_sd, int B, int N, int dim, void* stream) {
     if (!x || !token_attn_full || B <= 0 || N < 2) return MADTP_E_BADARG;
     const int kp = (K + 127) / 128 * 128;
-    const bool fast = sd_hi && sd_lo;
-    if (fast) {
+    const bool split = sd_hi && sd_lo;
+    const bool fast = split && split_dtype == MADTP_BF16;  // bf16 att_ft kernel as well
+    if (split) {
         if (kp != 128) return MADTP_E_SHAPE;
-        TRY(madtp_align_logits(x, sd_hi, sd_lo, token_attn_full, B * N, dim, stream));
+        TRY(madtp_align_logits(x, sd_hi, sd_lo, token_attn_full, B * N, dim, split_dtype, sd_scale, stream));
     } else {
         if (!sd_w) return MADTP_E_BADARG;
         TRY(madtp_gemm(x, sd_w, nullptr, nullptr, token_attn_full, B * N, kp, dim, dim, dim, kp, 0, MADTP_F32, MADTP_F32,
@@ -395,7 +397,7 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
             const bool both_here = !kv_pre0 && !kv_pre1 && w->ckv[0].n == w->ckv[1].n && w->ckv[0].k == w->ckv[1].k;
             if (both_here)
                 TRY(madtp_gemm_pair(enc0, enc1, w->ckv[0].w, w->ckv[1].w, w->ckv[0].b, w->ckv[1].b, s.kv, s.kv1, B * Nk,
-                                    w->ckv[0].n, w->ckv[0].k, pld(dt, D), (dt == MADTP_F16S ? 3 : 1) * w->ckv[0].k, 2 * D, dt, adt,
+                                    w->ckv[0].n, w->ckv[0].k, pld(dt, D), (dt == MADTP_F16S ? 2 : 1) * w->ckv[0].k, 2 * D, dt, adt,
                                     w->ckv[0].w_scale, w->ckv[1].w_scale, stream));
             const char* kvp[2];
             int ldkv[2];

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     *(f16x4*)(o + K4 * 4) = l;
 }
 
-// weight planes [Q0 | Q1 | Q2] of w * inv_scale (common.h): Q0 = f16(w~), Q1 = f16(w~ - Q0), Q2 = f16(Q0 * 2^-11)
+// weight planes [Q0 | Q1] of w * inv_scale (common.h): Q0 = f16(w~), Q1 = f16(w~ - Q0)
 __global__ __launch_bounds__(256) void split_f16_weight_kernel(const float* __restrict__ w, int ldw, _Float16* __restrict__ dst,
                                                                int K4, size_t total4, float inv_scale) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -174,11 +174,9 @@ __global__ __launch_bounds__(256) void split_f16_weight_kernel(const float* __re
     const f16x4 q0 = __builtin_convertvector(v, f16x4);
     const f32x4 q0f = __builtin_convertvector(q0, f32x4);
     const f16x4 q1 = __builtin_convertvector(v - q0f, f16x4);
-    const f16x4 q2 = __builtin_convertvector(q0f * (1.0f / F16S_LO_SCALE), f16x4);
-    _Float16* o = dst + row * (size_t)(3 * K4 * 4) + col;
+    _Float16* o = dst + row * (size_t)(2 * K4 * 4) + col;
     *(f16x4*)o = q0;
     *(f16x4*)(o + K4 * 4) = q1;
-    *(f16x4*)(o + 2 * K4 * 4) = q2;
 }
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {

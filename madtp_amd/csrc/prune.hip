@@ -826,9 +826,14 @@ __global__ __launch_bounds__(256, 1) void align_logits_kernel(const float* __res
 // slab.  The consumers never touch vector memory until their epilogue, so no HBM latency sits in the MFMA stream (the
 // register-prefetching kernel above loses ~7 us per launch to it).  x rows are swizzled with chunk ^= row&15 (256-byte rows
 // span all 64 banks), the dictionary with the GEMM swizzle.
+// F16 = true is the fp32-ACCURATE flavour (precision mode "f16x3"): the dictionary arrives as the f16 planes Q0 / Q1 of
+// sd * 2^s (common.h), x is split in registers into P0 = f16(x), P1 = f16((x - P0) 2^11), the three products
+// P0 Q0 + P0 Q1 + P1 (Q0 2^-11) run on the f16 MFMA and the accumulators are scaled by out_scale = 2^-s.
 constexpr int AW_XT = 64 * 256, AW_STAGE = AW_XT + 2 * AL_TILE;  // 16 KiB + 2 x 16 KiB
+template <bool F16>
 __global__ __launch_bounds__(768, 1) void align_ws_kernel(const float* __restrict__ x, const char* __restrict__ sd_hi,
-                                                          const char* __restrict__ sd_lo, float* __restrict__ out, int M, int dim) {
+                                                          const char* __restrict__ sd_lo, float* __restrict__ out, int M, int dim,
+                                                          float out_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGES = 3, PER = 12;  // 48 one-KiB DMA instructions per slab, 12 per loader wave
     const int tid = threadIdx.x, lane = tid & 63;
@@ -902,6 +907,30 @@ __global__ __launch_bounds__(768, 1) void align_ws_kernel(const float* __restric
                 bl[kk][j] = *(const bf16x8*)(sl + off);
             }
         bf16x8 ah[2], al[2];
+        if constexpr (F16) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 p0, p1;
+                split_f16x8(xa[kk][0], xa[kk][1], p0, p1);
+                ah[kk] = __builtin_bit_cast(bf16x8, p0);
+                al[kk] = __builtin_bit_cast(bf16x8, p1);
+            }
+            // per accumulator: P0 Q1, P0 Q0, P1 (Q0 2^-11)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bl[kk][j]), __builtin_bit_cast(f16x8, ah[kk]), acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bh[kk][j]), __builtin_bit_cast(f16x8, ah[kk]), acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f16x8 q2 = __builtin_bit_cast(f16x8, bh[kk][j]) * (_Float16)(1.0f / F16S_LO_SCALE);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q2, __builtin_bit_cast(f16x8, al[kk]), acc[j], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             ah[kk] = pack_bf16x8(xa[kk][0], xa[kk][1]);
@@ -923,12 +952,13 @@ __global__ __launch_bounds__(768, 1) void align_ws_kernel(const float* __restric
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[kk][j], ah[kk], acc[j], 0, 0, 0);
         }
+        }
     }
     const int m = row0 + xr;
     if (m < M) {
         float* o = out + (size_t)m * 128 + cw * 64 + 4 * g;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *(f32x4*)(o + 16 * j) = acc[j];
+        for (int j = 0; j < 4; ++j) *(f32x4*)(o + 16 * j) = F16 ? acc[j] * out_scale : acc[j];
     }
 }
 
@@ -1147,8 +1177,9 @@ extern "C" int madtp_vector_gather(const float* vectors, const int64_t* indices,
 }
 
 extern "C" int madtp_align_logits(const float* x, const void* sd_hi, const void* sd_lo, float* out, int M, int dim,
-                                  void* stream) {
+                                  int split_dtype, float out_scale, void* stream) {
     if (!x || !sd_hi || !sd_lo || !out || M <= 0) return MADTP_E_BADARG;
+    if (split_dtype != MADTP_BF16 && split_dtype != MADTP_F16S) return MADTP_E_DTYPE;
     if (dim % 128) return MADTP_E_SHAPE;
     if (!aligned16(x) || !aligned16(sd_hi) || !aligned16(sd_lo) || !aligned16(out)) return MADTP_E_ALIGN;
     constexpr int lds = AL_STAGES * 2 * AL_TILE;
@@ -1163,15 +1194,21 @@ extern "C" int madtp_align_logits(const float* x, const void* sd_hi, const void*
     }
     static int variant = -1;  // MADTP_ALIGN_KERNEL=1 selects the register-prefetching kernel (A/B measurements)
     if (variant < 0) { const char* e = getenv("MADTP_ALIGN_KERNEL"); variant = e ? atoi(e) : 0; }
-    if (variant == 0) {
+    if (variant == 0 || split_dtype == MADTP_F16S) {
         static bool attr_ws = false;
         if (!attr_ws) {
-            hipError_t e = hipFuncSetAttribute((const void*)align_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AW_STAGE);
-            if (e != hipSuccess) return (int)e;
+            for (const void* f : {(const void*)align_ws_kernel<false>, (const void*)align_ws_kernel<true>}) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AW_STAGE);
+                if (e != hipSuccess) return (int)e;
+            }
             attr_ws = true;
         }
-        hipLaunchKernelGGL(align_ws_kernel, dim3((M + 63) / 64), dim3(768), 3 * AW_STAGE, (hipStream_t)stream, x, (const char*)sd_hi,
-                           (const char*)sd_lo, out, M, dim);
+        if (split_dtype == MADTP_F16S)
+            hipLaunchKernelGGL(align_ws_kernel<true>, dim3((M + 63) / 64), dim3(768), 3 * AW_STAGE, (hipStream_t)stream, x,
+                               (const char*)sd_hi, (const char*)sd_lo, out, M, dim, out_scale);
+        else
+            hipLaunchKernelGGL(align_ws_kernel<false>, dim3((M + 63) / 64), dim3(768), 3 * AW_STAGE, (hipStream_t)stream, x,
+                               (const char*)sd_hi, (const char*)sd_lo, out, M, dim, 1.f);
         MADTP_LAUNCH_CHECK();
         return 0;
     }

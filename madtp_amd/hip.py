@@ -39,15 +39,15 @@ _SIGS = {
     "madtp_mask_gather": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "madtp_query_att_ft": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_int,
                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "madtp_align_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "madtp_align_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "madtp_vector_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "madtp_vit_block_workspace": (c_size_t, [c_int] * 6),
     "madtp_vit_block_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_int, c_int,
                                      c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "madtp_vit_block_mlp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
-    "madtp_query_model": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
-                                  c_int, c_int, c_int, c_void_p]),
+    "madtp_query_model": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_float, c_int, c_int, c_int, c_void_p]),
     "madtp_bert_layer_workspace": (c_size_t, [c_int] * 7),
     "madtp_bert_layer_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
                                       c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -99,7 +99,7 @@ class BertLayerW(ctypes.Structure):
 
 def lin_struct(lin):
     """runtime.Lin -> LinStruct (the Lin object must stay alive while the struct is in use)."""
-    k = lin.w.shape[1] // 3 if lin.w.dtype == torch.float16 else lin.w.shape[1]
+    k = lin.w.shape[1] // 2 if lin.w.dtype == torch.float16 else lin.w.shape[1]
     return LinStruct(lin.w.data_ptr(), 0 if lin.b is None else lin.b.data_ptr(), lin.n, k, w_scale_of(lin.w))
 
 
@@ -181,11 +181,11 @@ def gemm(a, w, bias=None, residual=None, out_dtype=None, act=ACT_NONE, n=None, o
     if not a.is_cuda or a.dim() != 2 or a.stride(1) != 1:
         raise RuntimeError("gemm: a must be a GPU row-major 2-D view (no CPU fallback)")
     M, K = a.shape
-    split = a.dtype == torch.float16  # f16-split planes: a is [M, 2K], w [Npad, 3K], a split output [M, 2n]
+    split = a.dtype == torch.float16  # f16-split planes: a is [M, 2K], w [Npad, 2K], a split output [M, 2n]
     if split:
         K //= 2
     n = n if n is not None else w.shape[0]
-    if w.shape[0] % 128 or w.shape[1] != (3 * K if split else K) or a.dtype != w.dtype:
+    if w.shape[0] % 128 or w.shape[1] != (2 * K if split else K) or a.dtype != w.dtype:
         raise RuntimeError(f"gemm: bad weight {tuple(w.shape)} {w.dtype} for a {tuple(a.shape)} {a.dtype}")
     out_dtype = out_dtype or a.dtype
     if out is None:
@@ -439,7 +439,7 @@ def split_f16(src):
 
 
 def split_f16_weight(w):
-    """f32 [n, K] -> ([n, 3K] f16 planes of w * 2^s, 2^-s) with max|w| * 2^s in (2^13, 2^14]."""
+    """f32 [n, K] -> [n, 2K] f16 planes [Q0 | Q1] of w * 2^s (max|w| * 2^s in (2^13, 2^14]); the tensor is tagged with 2^-s."""
     _req(w, torch.float32, "w")
     n, K = w.shape
     amax = float(w.abs().max())
@@ -448,7 +448,7 @@ def split_f16_weight(w):
         import math
         s = 14 - math.ceil(math.log2(amax))
         s = max(-100, min(100, s))
-    dst = torch.empty((n, 3 * K), device=w.device, dtype=torch.float16)
+    dst = torch.empty((n, 2 * K), device=w.device, dtype=torch.float16)
     _check(load().madtp_split_f16_weight(_p(w), K, _p(dst), n, K, float(2.0 ** s), _stream()), "madtp_split_f16_weight")
     dst._madtp_w_scale = float(2.0 ** -s)
     return dst
@@ -622,25 +622,31 @@ def vit_block_mlp(wstruct, x, k, score):
     return y, indices, indices_sort
 
 
-def align_logits(x2d, sd_hi, sd_lo):
+def align_logits(x2d, sd_hi, sd_lo, sd_scale=1.0):
+    """sd_hi / sd_lo: bf16 hi/lo planes (fast mode) or the f16 planes Q0 / Q1 of sd * 2^s with sd_scale = 2^-s (f16x3 mode)."""
     M, D = x2d.shape
     out = torch.empty((M, 128), device=x2d.device, dtype=torch.float32)
-    _check(load().madtp_align_logits(_p(x2d), _p(sd_hi), _p(sd_lo), _p(out), M, D, _stream()), "madtp_align_logits")
+    _check(load().madtp_align_logits(_p(x2d), _p(sd_hi), _p(sd_lo), _p(out), M, D, _dt(sd_hi), float(sd_scale), _stream()),
+           "madtp_align_logits")
     return out
 
 
 def query_model(x, sd_w, K, att_ft=None, want_att_ft=True, sd_dim=768, sd_split=None):
-    """x f32 [B,N,D] contiguous -> (token_attn view [B,N-1,K], att_ft).  sd_split=(hi,lo) bf16 selects fast mode."""
+    """x f32 [B,N,D] contiguous -> (token_attn view [B,N-1,K], att_ft).  sd_split=(hi, lo[, scale]): bf16 planes select the
+    fast mode (bf16x3 logits + bf16 att_ft), f16 planes of sd * 2^s (scale = 2^-s) the fp32-accurate f16x3 logits."""
     B, N, D = x.shape
     kp = sd_w.shape[0]
     full = torch.empty((B * N, kp), device=x.device, dtype=torch.float32)
     acc = 1 if att_ft is not None else 0
     if want_att_ft and att_ft is None:
         att_ft = torch.empty((B, K, D), device=x.device, dtype=torch.float32)
-    hi, lo = sd_split if sd_split is not None else (None, None)
-    ws = torch.empty(B * 256, device=x.device, dtype=torch.float32) if (want_att_ft and hi is not None) else None
-    _check(load().madtp_query_model(_p(x), _p(sd_w), _p(hi), _p(lo), K, _p(full), _p(att_ft) if want_att_ft else 0, _p(ws), acc,
-                                    1.0 / (sd_dim ** 0.5), B, N, D, _stream()), "madtp_query_model")
+    hi, lo = (sd_split[0], sd_split[1]) if sd_split is not None else (None, None)
+    sd_scale = sd_split[2] if sd_split is not None and len(sd_split) > 2 else 1.0
+    fast = hi is not None and hi.dtype == torch.bfloat16
+    ws = torch.empty(B * 256, device=x.device, dtype=torch.float32) if (want_att_ft and fast) else None
+    _check(load().madtp_query_model(_p(x), _p(sd_w), _p(hi), _p(lo), _dt(hi) if hi is not None else BF16, float(sd_scale), K,
+                                    _p(full), _p(att_ft) if want_att_ft else 0, _p(ws), acc, 1.0 / (sd_dim ** 0.5), B, N, D,
+                                    _stream()), "madtp_query_model")
     return full.view(B, N, kp)[:, 1:, :K], att_ft
 
 

@@ -118,6 +118,14 @@ class Query_model(nn.Module):
                 lo = hip.cast_bf16((sdl.w - hi.float()).contiguous())
                 return hi, lo
             split = self._cache.get(("sd_split", id(sd)), [sd], _split)
+        elif compute_dtype() == torch.float16 and sdl.w.shape[0] == 128:
+            # f16x3 mode: dictionary as the f16 planes Q0 / Q1 of sd * 2^s (+ the accumulator scale 2^-s): fp32-accurate logits
+            # from three f16 MFMA products, x split in registers (madtp_align_logits, split_dtype F16S)
+            def _split16():
+                q = hip.split_f16_weight(sdl.w)
+                d = sdl.w.shape[1]
+                return q[:, :d].contiguous(), q[:, d:].contiguous(), q._madtp_w_scale
+            split = self._cache.get(("sd_split16", id(sd)), [sd], _split16)
         if self.map_func:
             # CLIP: q = q_map(ft) (clip/model.py:188, models/utils.py:160-163).  Mapped over ALL rows of the token buffer
             # when ft is x[:,1:,:] of a contiguous tensor (the CLS row is computed and ignored), then the same
@@ -155,5 +163,6 @@ class Query_model(nn.Module):
         token_att = full.view(B, n + off, kp)[:, off:, :K]
         att_ft = acc_ft
         if self.compute_att_ft:
-            att_ft = hip.query_att_ft(token_att, ftq, out=acc_ft, sd_dim=self.att_dim, fast=split is not None)
+            att_ft = hip.query_att_ft(token_att, ftq, out=acc_ft, sd_dim=self.att_dim,
+                                      fast=split is not None and split[0].dtype == torch.bfloat16)
         return token_att, att_ft, sd
