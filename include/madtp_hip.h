@@ -31,6 +31,7 @@ extern "C" {
 #define MADTP_E_SHAPE (-2)    /* shape outside what the kernel family supports          */
 #define MADTP_E_DTYPE (-3)    /* unknown dtype code                                     */
 #define MADTP_E_ALIGN (-4)    /* pointer or leading dimension not 16-byte aligned       */
+#define MADTP_E_BUSY (-5)     /* every host hand-over slot of the device is pending (publish without wait) */
 
 /* activation codes of the GEMM epilogue */
 #define MADTP_ACT_NONE 0
@@ -143,15 +144,17 @@ int madtp_token_score(const float* colsum_part, int n_row_tiles, const float* p0
 /* Same launch, but k = max_b count is handed to the HOST: the last workgroup writes it to pinned host memory and the call
  * returns once it has arrived (*k_host).  This is the reference's one synchronisation per layer (`topk_num.item()`,
  * vit.py:145) without a device-to-host copy and a stream synchronisation; work queued on `stream` before the call has
- * completed when it returns.  Calls are serialised on a process-wide slot. */
+ * completed when it returns.  Each device has its own ring of 16 hand-over slots (pinned pair + ticket counter): calls on
+ * different devices, streams or host threads do not interfere, and no lock is held while waiting. */
 int madtp_token_score_sync(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
                            const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature,
                            float* score, float* threshold, int32_t* count, int32_t* k_host,
                            int B, int H, int N, void* stream);
 
-/* The same in two steps: _publish launches token_score with the host slot armed and takes the process-wide slot, _wait spins
- * until k has arrived and releases the slot (every _publish must be followed by exactly one _wait).  Kernels enqueued
- * between the two run while the host waits; the layer-level calls put the projection GEMM there. */
+/* The same in two steps: _publish claims a slot of the CURRENT device, launches token_score with it armed and returns its
+ * sequence number; _wait(seq) spins until k has arrived and frees the slot (a _publish that is never waited for leaks its
+ * slot: MADTP_E_BUSY after 16 such leaks, never a deadlock).  Kernels enqueued between the two run while the host waits; the
+ * layer-level calls put the projection GEMM there. */
 int madtp_token_score_publish(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
                               const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature,
                               float* score, float* threshold, int32_t* count, int B, int H, int N, int* seq_out,

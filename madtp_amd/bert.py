@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import PreparedCache, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
+from .runtime import PreparedCache, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model
 
 
@@ -274,7 +274,7 @@ class _BertLayerBase(nn.Module):
             w = hip.BertLayerW()
             w.qkv = L(sa._cache, "qkv", [sa.query, sa.key, sa.value])
             w.attn_out = L(ao._cache, "d", [ao.dense])
-            w.ln_att_g, w.ln_att_b = ao.LayerNorm.weight.data_ptr(), ao.LayerNorm.bias.data_ptr()
+            w.ln_att_g, w.ln_att_b = f32_ptr(ao.LayerNorm.weight, "LayerNorm parameter"), f32_ptr(ao.LayerNorm.bias, "LayerNorm parameter")
             w.cross, w.variant_nlvr, w.has_merge = 0, int(self.variant == "nlvr"), 0
             if has_cross:
                 ca = self.crossattention
@@ -302,10 +302,10 @@ class _BertLayerBase(nn.Module):
                     w.cq[0] = L(ca.self._cache, "q", [ca.self.query])
                     w.ckv[0] = L(ca.self._cache, "kv", [ca.self.key, ca.self.value])
                     w.cdense[0] = L(co._cache, "d", [co.dense])
-                w.ln_cross_g, w.ln_cross_b = co.LayerNorm.weight.data_ptr(), co.LayerNorm.bias.data_ptr()
+                w.ln_cross_g, w.ln_cross_b = f32_ptr(co.LayerNorm.weight, "LayerNorm parameter"), f32_ptr(co.LayerNorm.bias, "LayerNorm parameter")
             w.inter = L(self._cache, "inter", [self.intermediate.dense])
             w.out = L(self._cache, "out", [self.output.dense])
-            w.ln_out_g, w.ln_out_b = self.output.LayerNorm.weight.data_ptr(), self.output.LayerNorm.bias.data_ptr()
+            w.ln_out_g, w.ln_out_b = f32_ptr(self.output.LayerNorm.weight, "LayerNorm parameter"), f32_ptr(self.output.LayerNorm.bias, "LayerNorm parameter")
             w.eps, w.scale = self.output.LayerNorm.eps, 1.0 / math.sqrt(sa.attention_head_size)
             w.heads, w.dim = sa.num_attention_heads, sa.all_head_size
             w.dtype = dtype_code()
@@ -334,6 +334,10 @@ class _BertLayerBase(nn.Module):
         pre = self.__dict__.pop("_kv_pre", None)  # (kv cache of THIS layer, Nk, int32 index [B]) set by the encoder for this call
         if cross and pre is not None:
             Nk = pre[1]
+            # pre-projected K/V: the encoder tokens are not needed, their padding masks still are (nlvr_encoder.py:162,
+            # 193-195 applies encoder_attention_mask in cross-attention; med.py:197-199 drops it)
+            if self.variant == "nlvr" and encoder_attention_mask is not None:
+                em0, em1 = self._enc_mask2d(encoder_attention_mask[0]), self._enc_mask2d(encoder_attention_mask[1])
         elif cross:
             assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
             if self.variant == "nlvr":
@@ -565,6 +569,9 @@ class _BertModelBase(nn.Module):
              encoder_attention_mask, mode, inputs_embeds=None):
         if input_ids is not None and inputs_embeds is not None:
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+        if inputs_embeds is not None:
+            raise NotImplementedError("inputs_embeds (pre-embedded text WITHOUT the position embeddings / LayerNorm, "
+                                      "med.py:63-86) is not on the pruned forward path; pass input_ids or encoder_embeds")
         if input_ids is not None:
             batch_size, seq_length = input_ids.size()
             device = input_ids.device
@@ -599,6 +606,8 @@ class MedBertModel(_BertModelBase):
                 mode='multimodal', space_dict=None, temperature=0, encoder_kv_cache=None):
         """encoder_kv_cache (extension): an EncoderKVCache - the layers' cross-attention then reads the cached [k|v]
         projections of encoder block index[b] for sample b instead of projecting encoder_hidden_states (which may be None)."""
+        if position_ids is not None or head_mask is not None or past_key_values is not None or is_decoder:
+            raise NotImplementedError("position_ids / head_mask / past_key_values / is_decoder are off the pruned encoder path")
         emb, ext, enc_ext = self._run(input_ids, attention_mask, space_dict, temperature, encoder_embeds,
                                       encoder_hidden_states, encoder_attention_mask, mode, inputs_embeds)
         if encoder_kv_cache is not None:
@@ -646,6 +655,8 @@ class NlvrBertModel(_BertModelBase):
                 head_mask=None, inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_values=None, use_cache=None, output_attentions=None,
                 output_hidden_states=None, return_dict=None, is_decoder=False, mode='multimodal'):
+        if position_ids is not None or head_mask is not None or past_key_values is not None or is_decoder:
+            raise NotImplementedError("position_ids / head_mask / past_key_values / is_decoder are off the pruned encoder path")
         emb, ext, enc_ext = self._run(input_ids, attention_mask, space_dict, temperature, encoder_embeds,
                                       encoder_hidden_states, encoder_attention_mask, mode, inputs_embeds)
         out, sd_txt_ft = self.encoder(emb, attention_mask=ext, space_dict=space_dict, temperature=temperature,

@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import hip
-from .runtime import PreparedCache, compute_dtype, dtype_code, lin_of, prepare_linear, require_gpu, as_f32_contig, to_compute
+from .runtime import PreparedCache, f32_ptr, compute_dtype, dtype_code, lin_of, prepare_linear, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model
 
 
@@ -62,8 +62,8 @@ class ResidualAttentionBlock(nn.Module):
             lins = [lin_of(self._cache, "qkv", [_InProj(self.attn)]), lin_of(self._cache, "proj", [self.attn.out_proj]),
                     lin_of(self._cache, "fc1", [self.mlp.c_fc]), lin_of(self._cache, "fc2", [self.mlp.c_proj])]
             w = hip.VitBlockW()
-            w.ln1_g, w.ln1_b = self.ln_1.weight.data_ptr(), self.ln_1.bias.data_ptr()
-            w.ln2_g, w.ln2_b = self.ln_2.weight.data_ptr(), self.ln_2.bias.data_ptr()
+            w.ln1_g, w.ln1_b = f32_ptr(self.ln_1.weight, "LayerNorm parameter"), f32_ptr(self.ln_1.bias, "LayerNorm parameter")
+            w.ln2_g, w.ln2_b = f32_ptr(self.ln_2.weight, "LayerNorm parameter"), f32_ptr(self.ln_2.bias, "LayerNorm parameter")
             w.eps, w.scale = self.ln_1.eps, (self.d_model // self.n_head) ** -0.5
             w.qkv, w.proj, w.fc1, w.fc2 = [hip.lin_struct(l) for l in lins]
             w.heads, w.dim = self.n_head, self.d_model

@@ -631,13 +631,7 @@ int launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     constexpr int HS = (SCORES && NT <= 8) ? 2 : 1;  // head-parity split: 4 rings must fit the 160 KiB of LDS
     constexpr int RB = (SCORES && NT > 8) ? 2 : 1;   // two 64-row blocks per workgroup where only one ring fits a CU
     const size_t lds = (size_t)2 * HS * (NT * 16 + NC * 32) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_bf16_kernel<NT, SCORES, HS, RB>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    MADTP_ENSURE_MAX_LDS((attn_bf16_kernel<NT, SCORES, HS, RB>), lds);
     int gz = 1;
     size_t lds_used = lds;
     if (!SCORES) {
@@ -857,13 +851,7 @@ template <typename T, int NCH, bool SCORES>
 int launch_attn_large(const AttnArgs& a, hipStream_t s) {
     constexpr int RB = 64 * (int)sizeof(T) + 16;
     const size_t lds = (size_t)2 * 128 * RB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_large_kernel<T, NCH, SCORES>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    MADTP_ENSURE_MAX_LDS((attn_large_kernel<T, NCH, SCORES>), lds);
     int gz = 1;
     if (!SCORES) {
         const int wgs = ((a.Nq + 63) / 64) * a.B;
@@ -887,13 +875,7 @@ template <typename T, int NT, bool SCORES>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     constexpr int RB = 64 * (int)sizeof(T) + 16;
     const size_t lds = (size_t)2 * NT * 16 * RB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<T, NT, SCORES>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    MADTP_ENSURE_MAX_LDS((attn_kernel<T, NT, SCORES>), lds);
     int gz = 1;
     if (!SCORES) {  // cross-attention has few query rows: spread heads over workgroups
         const int wgs = ((a.Nq + 63) / 64) * a.B;

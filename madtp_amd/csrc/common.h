@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "../../include/madtp_hip.h"
 
@@ -152,6 +153,21 @@ __device__ __forceinline__ float row16_sum(float v) {
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE setting: each call site remembers the devices it has set it on
+// (bit per device ordinal), so a process that drives several GPUs configures every one of them.
+#define MADTP_ENSURE_MAX_LDS(FN, BYTES)                                                                                      \
+    do {                                                                                                                     \
+        static std::atomic<unsigned long long> done__{0};                                                                    \
+        int dev__ = 0;                                                                                                       \
+        (void)hipGetDevice(&dev__);                                                                                          \
+        const unsigned long long bit__ = 1ull << (dev__ & 63);                                                               \
+        if (!(done__.load(std::memory_order_acquire) & bit__)) {                                                             \
+            hipError_t e__ = hipFuncSetAttribute((const void*)(FN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)); \
+            if (e__ != hipSuccess) return (int)e__;                                                                          \
+            done__.fetch_or(bit__, std::memory_order_release);                                                               \
+        }                                                                                                                    \
+    } while (0)
 
 #define MADTP_LAUNCH_CHECK()                          \
     do {                                              \

@@ -965,13 +965,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         const int per_xcd = 32 * WGCU;                                                                                 \
         const int grid = 8 * (slots_max < per_xcd ? slots_max : per_xcd);                                              \
         const size_t lds = (size_t)(BM_ + BN_) * ROWB * ST_;                                                           \
-        static bool attr = false;                                                                                      \
-        if (!attr) {                                                                                                   \
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<TT, LP, BM_, BN_, ST_>,                        \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
-            if (e != hipSuccess) return (int)e;                                                                        \
-            attr = true;                                                                                               \
-        }                                                                                                              \
+        MADTP_ENSURE_MAX_LDS((gemm_kernel<TT, LP, BM_, BN_, ST_>), lds);                                               \
         hipLaunchKernelGGL((gemm_kernel<TT, LP, BM_, BN_, ST_>), dim3(grid), dim3(NTHREADS), lds, s, g);               \
     } while (0)
 #define MADTP_DISPATCH_CFG(TT, LP)                                             \
@@ -997,23 +991,17 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         const int slots_max = (g.ntm * g.ntn * (g.pair ? 2 : 1) + 7) / 8;
         const int grid = 8 * (slots_max < 32 ? slots_max : 32);
         const size_t lds = (size_t)3 * (256 + 128) * ROWB;
-        static bool attr_ws = false;
-        if (!attr_ws) {
-            const void* fns[4] = {(const void*)gemm_ws_kernel<false, OM_BF16>, (const void*)gemm_ws_kernel<false, OM_F32>,
-                                  (const void*)gemm_ws_kernel<true, OM_F16S>, (const void*)gemm_ws_kernel<true, OM_F32>};
-            for (const void* fn : fns) {
-                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return (int)e;
-            }
-            attr_ws = true;
-        }
+#define MADTP_LAUNCH_WS(X3_, OM_)                                                          \
+    do {                                                                                  \
+        MADTP_ENSURE_MAX_LDS((gemm_ws_kernel<X3_, OM_>), lds);                            \
+        hipLaunchKernelGGL((gemm_ws_kernel<X3_, OM_>), dim3(grid), dim3(768), lds, s, g); \
+    } while (0)
         if (x3) {
-            if (c_dtype == MADTP_F16S) hipLaunchKernelGGL((gemm_ws_kernel<true, OM_F16S>), dim3(grid), dim3(768), lds, s, g);
-            else hipLaunchKernelGGL((gemm_ws_kernel<true, OM_F32>), dim3(grid), dim3(768), lds, s, g);
+            if (c_dtype == MADTP_F16S) MADTP_LAUNCH_WS(true, OM_F16S); else MADTP_LAUNCH_WS(true, OM_F32);
         } else {
-            if (c_dtype == MADTP_BF16) hipLaunchKernelGGL((gemm_ws_kernel<false, OM_BF16>), dim3(grid), dim3(768), lds, s, g);
-            else hipLaunchKernelGGL((gemm_ws_kernel<false, OM_F32>), dim3(grid), dim3(768), lds, s, g);
+            if (c_dtype == MADTP_BF16) MADTP_LAUNCH_WS(false, OM_BF16); else MADTP_LAUNCH_WS(false, OM_F32);
         }
+#undef MADTP_LAUNCH_WS
     } else if (ab_dtype == MADTP_BF16) {
         if (c_dtype == MADTP_BF16) MADTP_DISPATCH_CFG(bf16_t, OM_BF16); else MADTP_DISPATCH_CFG(bf16_t, OM_F32);
     } else if (x3) {

@@ -308,6 +308,7 @@ extern "C" const char* madtp_strerror(int code) {
         case MADTP_E_SHAPE: return "unsupported shape";
         case MADTP_E_DTYPE: return "unknown dtype";
         case MADTP_E_ALIGN: return "pointer / leading dimension not 16-byte aligned";
+        case MADTP_E_BUSY: return "all host hand-over slots of the device are pending";
         default: return code > 0 ? "HIP launch error (hipError_t)" : "unknown error";
     }
 }

@@ -9,6 +9,7 @@
 // atomics, so results are run-to-run deterministic and independent of workgroup placement).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 #include <chrono>
 #include <mutex>
 #include <vector>
@@ -253,23 +254,34 @@ __global__ __launch_bounds__(256) void token_select_kernel(const float* __restri
                                                            int64_t* __restrict__ indices, int64_t* __restrict__ indices_sort,
                                                            int32_t* __restrict__ dst_pos, float* __restrict__ merge_w, int n) {
     __shared__ float s[MAXN];
+    __shared__ unsigned key_s[MAXN];
     __shared__ int rank_s[MAXN];
     __shared__ float red[4];
     __shared__ int wsum[4];
     __shared__ int base_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
-    for (int t = tid; t < n; t += 256) s[t] = score[(size_t)b * n + t];
+    // The ranking runs on an ORDER-PRESERVING integer key of the score, so it is a total order whatever the scores are: for
+    // ordinary numbers key(w) > key(v) <=> w > v (-0 is folded onto +0 first), and a NaN score (NaN / Inf upstream) ranks below
+    // everything instead of tying with every token - every rank 0..n-1 is produced exactly once, indices / indices_sort /
+    // dst_pos are always fully written permutations and no later kernel reads an uninitialised index.
+    for (int t = tid; t < n; t += 256) {
+        const float v = score[(size_t)b * n + t];
+        s[t] = v;
+        const unsigned u = __float_as_uint(v + 0.0f);
+        key_s[t] = (v != v) ? 0u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+    }
     if (tid == 0) base_s = 0;
     __syncthreads();
     // rank by counting: #tokens with a larger score (ties: lower index first) == position in a stable descending sort
     float dsum_l = 0.f;
     for (int t = tid; t < n; t += 256) {
         const float v = s[t];
+        const unsigned kv = key_s[t];
         int r = 0;
         for (int u = 0; u < n; ++u) {
-            const float w = s[u];
-            r += (w > v || (w == v && u < t)) ? 1 : 0;
+            const unsigned kw = key_s[u];
+            r += (kw > kv || (kw == kv && u < t)) ? 1 : 0;
         }
         rank_s[t] = r;
         indices_sort[(size_t)b * n + r] = t;
@@ -974,13 +986,7 @@ static int token_score_launch(const float* colsum_part, int n_row_tiles, const f
     const size_t stage_bytes = (size_t)(N - 1) * K * sizeof(float);
     const bool staged = K % 4 == 0 && ldt % 4 == 0 && ldb % 4 == 0 && aligned16(token_attn) && stage_bytes <= 140 * 1024;
     if (staged) {
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute((const void*)token_score_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               140 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr = true;
-        }
+        MADTP_ENSURE_MAX_LDS(token_score_kernel<true>, 140 * 1024);
         hipLaunchKernelGGL(token_score_kernel<true>, dim3(B), dim3(512), stage_bytes, (hipStream_t)stream, colsum_part,
                            n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N,
                            done_ctr, host_slot, seq);
@@ -1000,70 +1006,123 @@ extern "C" int madtp_token_score(const float* colsum_part, int n_row_tiles, cons
                               kmax, B, H, N, nullptr, nullptr, 0, stream);
 }
 
-// Host-visible batch maximum: process-wide pinned slot {k, sequence} + a device ticket counter (allocated on first use).
+// Host-visible batch maximum.  Per DEVICE a small ring of hand-over slots, each = {pinned host pair (k, sequence number),
+// device ticket counter}.  _publish claims a free slot of the current device under a short lock (never held across calls),
+// launches token_score with it armed and returns the sequence number, which names the slot; _wait spins on that slot and
+// frees it.  A caller that publishes and never waits leaks one slot (MADTP_E_BUSY once all are taken) instead of blocking
+// every later call; slots of different devices / streams never alias.
 namespace {
-struct HostSync {
-    int32_t* host = nullptr;      // pinned, device-accessible: [0] = k, [1] = sequence number of the launch that wrote it
-    int32_t* host_dev = nullptr;  // the same memory as the device sees it
+constexpr int SYNC_SLOTS = 16, SYNC_MAX_DEV = 64;
+struct SyncSlot {
+    int32_t* host = nullptr;      // pinned (portable, mapped): [0] = k, [1] = sequence number of the launch that wrote it
+    int32_t* host_dev = nullptr;  // the same memory as this device sees it
     int32_t* ctr = nullptr;       // device ticket counter (the last workgroup resets it)
+    bool busy = false;
     int seq = 0;
-    std::mutex mu;
 };
-HostSync g_sync;
-int host_sync_init() {
-    if (g_sync.host) return 0;
-    hipError_t e = hipHostMalloc((void**)&g_sync.host, 64, hipHostMallocMapped);
+struct DevSync {
+    std::mutex mu;
+    bool ready = false;
+    unsigned next_seq = 0;
+    SyncSlot slot[SYNC_SLOTS];
+};
+DevSync g_dev_sync[SYNC_MAX_DEV];
+
+int dev_sync_init(DevSync& d) {  // caller holds d.mu and has the device current
+    if (d.ready) return 0;
+    int32_t* host = nullptr;
+    hipError_t e = hipHostMalloc((void**)&host, SYNC_SLOTS * 64, hipHostMallocMapped | hipHostMallocPortable);
     if (e != hipSuccess) return (int)e;
-    g_sync.host[0] = 0; g_sync.host[1] = 0;
-    e = hipHostGetDevicePointer((void**)&g_sync.host_dev, g_sync.host, 0);
+    memset(host, 0, SYNC_SLOTS * 64);
+    int32_t* host_dev = nullptr;
+    e = hipHostGetDevicePointer((void**)&host_dev, host, 0);
     if (e != hipSuccess) return (int)e;
-    e = hipMalloc((void**)&g_sync.ctr, sizeof(int32_t));
+    int32_t* ctr = nullptr;
+    e = hipMalloc((void**)&ctr, SYNC_SLOTS * 64);
     if (e != hipSuccess) return (int)e;
-    return (int)hipMemset(g_sync.ctr, 0, sizeof(int32_t));
+    e = hipMemset(ctr, 0, SYNC_SLOTS * 64);
+    if (e != hipSuccess) return (int)e;
+    for (int i = 0; i < SYNC_SLOTS; ++i) {  // one 64-byte line per slot on both sides
+        d.slot[i].host = host + 16 * i;
+        d.slot[i].host_dev = host_dev + 16 * i;
+        d.slot[i].ctr = ctr + 16 * i;
+    }
+    d.ready = true;
+    return 0;
 }
+// sequence number handed to the caller: (device << 24) | (slot << 20) | 20-bit counter, never 0
+inline int pack_seq(int dev, int slot, unsigned n) { return (dev << 24) | (slot << 20) | (int)(n & 0xFFFFF); }
 }  // namespace
 
-// Two-step form used by the layer-level calls: publish = launch with the host slot armed (takes the process-wide slot);
-// wait = spin until the last workgroup has written k (releases the slot).  Work enqueued between the two calls runs on
-// the GPU while the host waits - the layers put the projection GEMM there, so the read-back costs no GPU idle time.
+// Two-step form used by the layer-level calls: publish = launch with a host slot armed; wait = spin until the last workgroup
+// has written k, then free the slot.  Work enqueued between the two calls runs on the GPU while the host waits - the layers
+// put the projection GEMM there, so the read-back costs no GPU idle time.
 extern "C" int madtp_token_score_publish(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
                                          const float* token_attn, int ldt, int ldb, int K, float temperature, float* score,
                                          float* threshold, int32_t* count, int B, int H, int N, int* seq_out, void* stream) {
     if (!seq_out) return MADTP_E_BADARG;
-    g_sync.mu.lock();
-    int rc = host_sync_init();
-    if (!rc) {
-        *seq_out = ++g_sync.seq;
-        rc = token_score_launch(colsum_part, n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count,
-                                nullptr, B, H, N, g_sync.ctr, g_sync.host_dev, *seq_out, stream);
+    int dev = 0;
+    hipError_t he = hipGetDevice(&dev);
+    if (he != hipSuccess) return (int)he;
+    if (dev < 0 || dev >= SYNC_MAX_DEV) return MADTP_E_SHAPE;
+    DevSync& d = g_dev_sync[dev];
+    int si = -1, seq = 0;
+    {
+        std::lock_guard<std::mutex> lk(d.mu);
+        const int rc = dev_sync_init(d);
+        if (rc) return rc;
+        for (int i = 0; i < SYNC_SLOTS && si < 0; ++i)
+            if (!d.slot[i].busy) si = i;
+        if (si < 0) return MADTP_E_BUSY;
+        if ((++d.next_seq & 0xFFFFF) == 0) ++d.next_seq;
+        seq = pack_seq(dev, si, d.next_seq);
+        d.slot[si].busy = true;
+        d.slot[si].seq = seq;
     }
-    if (rc) g_sync.mu.unlock();
-    return rc;
+    const int rc = token_score_launch(colsum_part, n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold,
+                                      count, nullptr, B, H, N, d.slot[si].ctr, d.slot[si].host_dev, seq, stream);
+    if (rc) {
+        std::lock_guard<std::mutex> lk(d.mu);
+        d.slot[si].busy = false;
+        return rc;
+    }
+    *seq_out = seq;
+    return 0;
 }
 
 extern "C" int madtp_token_score_wait(int seq, const int32_t* count, int B, int32_t* k_host, void* stream) {
-    if (!k_host || !count) { g_sync.mu.unlock(); return MADTP_E_BADARG; }
+    const int dev = (seq >> 24) & 0x3F, si = (seq >> 20) & 0xF;
+    if (!k_host || !count || seq == 0 || dev >= SYNC_MAX_DEV) return MADTP_E_BADARG;
+    DevSync& d = g_dev_sync[dev];
+    {
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (!d.ready || !d.slot[si].busy || d.slot[si].seq != seq) return MADTP_E_BADARG;  // not a pending publish
+    }
+    SyncSlot& sl = d.slot[si];
     int rc = 0;
     const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 0; __atomic_load_n(&g_sync.host[1], __ATOMIC_ACQUIRE) != seq; ++spins) {
+    for (unsigned spins = 0; __atomic_load_n(&sl.host[1], __ATOMIC_ACQUIRE) != seq; ++spins) {
         if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
-            // never signalled (failed launch / lost stream): fall back to the ordinary path so the error surfaces
+            // never signalled (failed launch / lost stream): fall back to the ordinary path so the error surfaces.  The ticket
+            // counter is reset only AFTER the stream has drained, so a late kernel cannot race the memset.
             hipError_t e = hipStreamSynchronize((hipStream_t)stream);
             std::vector<int32_t> h(B);
             if (e == hipSuccess) e = hipMemcpy(h.data(), count, sizeof(int32_t) * B, hipMemcpyDeviceToHost);
             if (e == hipSuccess) {
                 int m = 0;
                 for (int v : h) m = v > m ? v : m;
-                (void)hipMemset(g_sync.ctr, 0, sizeof(int32_t));
                 *k_host = m;
+                if (__atomic_load_n(&sl.host[1], __ATOMIC_ACQUIRE) != seq) e = hipMemset(sl.ctr, 0, sizeof(int32_t));
             }
             rc = (int)e;
-            g_sync.mu.unlock();
+            std::lock_guard<std::mutex> lk(d.mu);
+            sl.busy = false;
             return rc;
         }
     }
-    *k_host = __atomic_load_n(&g_sync.host[0], __ATOMIC_RELAXED);
-    g_sync.mu.unlock();
+    *k_host = __atomic_load_n(&sl.host[0], __ATOMIC_RELAXED);
+    std::lock_guard<std::mutex> lk(d.mu);
+    sl.busy = false;
     return 0;
 }
 
@@ -1183,26 +1242,14 @@ extern "C" int madtp_align_logits(const float* x, const void* sd_hi, const void*
     if (dim % 128) return MADTP_E_SHAPE;
     if (!aligned16(x) || !aligned16(sd_hi) || !aligned16(sd_lo) || !aligned16(out)) return MADTP_E_ALIGN;
     constexpr int lds = AL_STAGES * 2 * AL_TILE;
-    static bool attr = false;
-    if (!attr) {
-        for (const void* f : {(const void*)align_logits_kernel<12>, (const void*)align_logits_kernel<8>,
-                              (const void*)align_logits_kernel<0>}) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return (int)e;
-        }
-        attr = true;
-    }
+    MADTP_ENSURE_MAX_LDS(align_logits_kernel<12>, lds);
+    MADTP_ENSURE_MAX_LDS(align_logits_kernel<8>, lds);
+    MADTP_ENSURE_MAX_LDS(align_logits_kernel<0>, lds);
     static int variant = -1;  // MADTP_ALIGN_KERNEL=1 selects the register-prefetching kernel (A/B measurements)
     if (variant < 0) { const char* e = getenv("MADTP_ALIGN_KERNEL"); variant = e ? atoi(e) : 0; }
     if (variant == 0 || split_dtype == MADTP_F16S) {
-        static bool attr_ws = false;
-        if (!attr_ws) {
-            for (const void* f : {(const void*)align_ws_kernel<false>, (const void*)align_ws_kernel<true>}) {
-                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AW_STAGE);
-                if (e != hipSuccess) return (int)e;
-            }
-            attr_ws = true;
-        }
+        MADTP_ENSURE_MAX_LDS(align_ws_kernel<false>, 3 * AW_STAGE);
+        MADTP_ENSURE_MAX_LDS(align_ws_kernel<true>, 3 * AW_STAGE);
         if (split_dtype == MADTP_F16S)
             hipLaunchKernelGGL(align_ws_kernel<true>, dim3((M + 63) / 64), dim3(768), 3 * AW_STAGE, (hipStream_t)stream, x,
                                (const char*)sd_hi, (const char*)sd_lo, out, M, dim, out_scale);

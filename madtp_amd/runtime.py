@@ -112,6 +112,8 @@ class PreparedCache:
     """Per-module cache of prepared weights, invalidated when a parameter is modified in place, re-assigned,
     moved, or the precision mode changes (load_state_dict bumps Parameter._version)."""
 
+    MAX_ENTRIES = 32
+
     def __init__(self):
         self._store = {}
 
@@ -121,7 +123,10 @@ class PreparedCache:
         if hit is not None and hit[0] == sig:
             return hit[1]
         val = builder()
+        self._store.pop(key, None)
         self._store[key] = (sig, val)
+        while len(self._store) > self.MAX_ENTRIES:  # bounded: keys may embed id() of caller tensors (a fresh space_dict per call)
+            self._store.pop(next(iter(self._store)))
         return val
 
 
@@ -152,6 +157,15 @@ def require_gpu(t, name="input"):
         raise RuntimeError(f"{name} is on {t.device}: madtp_amd modules run only on an MI355X through the HIP "
                            "kernels (no CPU / eager fallback).  Use oracle/ for CPU checking.")
     return t
+
+
+def f32_ptr(p, name="parameter"):
+    """data_ptr() of a parameter the kernels read as contiguous f32 (LayerNorm gamma / beta): model.half() / .bfloat16() or a
+    non-contiguous parameter must fail loudly instead of being misread."""
+    if p.dtype != torch.float32 or not p.is_contiguous() or not p.is_cuda:
+        raise TypeError(f"{name}: the HIP kernels read it as a contiguous float32 GPU tensor, got {p.dtype} "
+                        f"{'contiguous' if p.is_contiguous() else 'strided'} on {p.device} - keep the module in float32")
+    return p.data_ptr()
 
 
 def as_f32_contig(t):

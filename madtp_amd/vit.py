@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import PreparedCache, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
+from .runtime import PreparedCache, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model, vector_gather  # noqa: F401  (re-exported like `from models.utils import *`)
 
 
@@ -164,8 +164,8 @@ class Block(nn.Module):
             lins = [lin_of(self.attn._cache, "qkv", [self.attn.qkv]), lin_of(self.attn._cache, "proj", [self.attn.proj]),
                     lin_of(self.mlp._cache, "fc1", [self.mlp.fc1]), lin_of(self.mlp._cache, "fc2", [self.mlp.fc2])]
             w = hip.VitBlockW()
-            w.ln1_g, w.ln1_b = self.norm1.weight.data_ptr(), self.norm1.bias.data_ptr()
-            w.ln2_g, w.ln2_b = self.norm2.weight.data_ptr(), self.norm2.bias.data_ptr()
+            w.ln1_g, w.ln1_b = f32_ptr(self.norm1.weight, "LayerNorm parameter"), f32_ptr(self.norm1.bias, "LayerNorm parameter")
+            w.ln2_g, w.ln2_b = f32_ptr(self.norm2.weight, "LayerNorm parameter"), f32_ptr(self.norm2.bias, "LayerNorm parameter")
             w.eps, w.scale = self.norm1.eps, self.attn.scale
             w.qkv, w.proj, w.fc1, w.fc2 = [hip.lin_struct(l) for l in lins]
             w.heads, w.dim = self.attn.num_heads, self.attn.dim

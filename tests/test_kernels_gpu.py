@@ -575,3 +575,71 @@ def test_align_logits_f16x3(hip):
     inner = x[:, 1:] @ sd.t()
     refa = torch.bmm(torch.softmax((inner / math.sqrt(D)).permute(0, 2, 1), -1), x[:, 1:])
     assert (ft.cpu() - refa).abs().max().item() < 2e-5 * max(1, refa.abs().max().item())  # att_ft stays on the exact-f32 kernel
+
+
+def test_token_select_nan_inf_scores_stay_memory_safe(hip):
+    """Scores containing NaN / +-Inf / -0 still give fully written permutations (a NaN tied with every token and
+    left index slots unwritten): NaNs rank last, every rank is produced exactly once, kept ids ascend."""
+    B, n, k = 4, 37, 20
+    g = torch.Generator().manual_seed(3)
+    score = torch.rand(B, n, generator=g)
+    score[0, 5] = float("nan"); score[0, 17] = float("nan")
+    score[1, :] = float("nan")
+    score[2, 3] = float("inf"); score[2, 4] = -float("inf"); score[2, 9] = -0.0; score[2, 10] = 0.0
+    idx, idx_sort, dst, mw = hip.token_select(score.cuda(), k)
+    idx, idx_sort, dst = idx.cpu(), idx_sort.cpu(), dst.cpu()
+    for b in range(B):
+        assert sorted(idx_sort[b].tolist()) == list(range(n)), b          # a permutation: nothing unwritten
+        kept = idx[b].tolist()
+        assert kept == sorted(kept) and len(set(kept)) == k and set(kept) == set(idx_sort[b, :k].tolist())
+        assert sorted(d for d in dst[b].tolist() if d >= 0) == list(range(k))
+    assert set(idx_sort[0, -2:].tolist()) == {5, 17}                      # NaNs rank below every number
+    assert idx_sort[1].tolist() == list(range(n))                         # all-NaN row: index order
+    assert idx_sort[2, 0].item() == 3 and idx_sort[2, -1].item() == 4     # +Inf first, -Inf last
+    p9, p10 = idx_sort[2].tolist().index(9), idx_sort[2].tolist().index(10)
+    assert p9 + 1 == p10                                                  # -0 == +0: a tie, lower index first
+    ref = torch.argsort(score[3], descending=True, stable=True)
+    assert idx_sort[3].tolist() == ref.tolist()
+
+
+def test_k_handover_slots(hip):
+    """madtp_token_score_publish / _wait: sequence numbers name per-device slots, a publish that is never waited for leaks one
+    slot and exhausting the ring returns MADTP_E_BUSY (-5) instead of blocking; waits may come in any order and from other
+    threads; a stale or repeated wait is rejected."""
+    import ctypes
+    import threading
+    lib = hip.load()
+    B, H, N, K = 3, 12, 50, 100
+    nrt = (N + 15) // 16
+    cs = torch.rand(B, nrt, N).cuda(); p0 = torch.rand(B, H, N).cuda(); on = torch.rand(B, H, N).cuda() + 0.1
+    ta = torch.randn(B, N - 1, K).cuda()
+    score = torch.empty(B, N - 1).cuda(); thr = torch.empty(B).cuda(); cnt = torch.empty(B, dtype=torch.int32).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def publish():
+        seq = ctypes.c_int(0)
+        rc = lib.madtp_token_score_publish(cs.data_ptr(), nrt, p0.data_ptr(), on.data_ptr(), ta.data_ptr(), K, (N - 1) * K, K, 2.0,
+                                           score.data_ptr(), thr.data_ptr(), cnt.data_ptr(), B, H, N, ctypes.byref(seq), st)
+        return rc, seq.value
+
+    def wait(seq):
+        k = ctypes.c_int32(-1)
+        rc = lib.madtp_token_score_wait(seq, cnt.data_ptr(), B, ctypes.byref(k), st)
+        return rc, k.value
+
+    _, _, _, k_ref = hip.token_score_sync((cs, p0, on), ta, 2.0, B, H, N)
+    seqs = []
+    for _ in range(16):
+        rc, seq = publish()
+        assert rc == 0 and seq != 0
+        seqs.append(seq)
+    assert len(set(seqs)) == 16
+    assert publish()[0] == -5                                   # ring exhausted: an error, not a deadlock
+    out = {}
+    ths = [threading.Thread(target=lambda s=s: out.__setitem__(s, wait(s))) for s in reversed(seqs)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    assert all(out[s] == (0, k_ref) for s in seqs)
+    assert wait(seqs[0])[0] == -1                               # already consumed
+    rc, seq = publish()
+    assert rc == 0 and wait(seq) == (0, k_ref)
+    assert int(cnt.max().item()) == k_ref
