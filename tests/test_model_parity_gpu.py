@@ -80,27 +80,19 @@ def test_fp32_mode_matches_oracle(env, B, T, seed, mode):
     assert (logits.cpu() - ref_logits).abs().max().item() < 1e-3
 
 
-def test_bf16_mode_close_to_oracle(env):
-    from madtp_amd import specs
-    from oracle import madtp_oracle as O
+@pytest.mark.parametrize("B,T", [(4, 2.0), (8, 8.612223847001898)])
+def test_bf16_mode_index_match_and_logits(env, B, T):
+    """bf16 fast mode vs the oracle: the per-layer decisions are sound (teacher-forced: every block fed the oracle's input),
+    the free-running sets stay close although one flipped token shifts k = max_b count for the whole batch, logits within
+    bf16 error.  Thresholds: about half the slack measured on MI355X (printed), so a regression that halves the match fails."""
+    from tests.parity_util import nlvr_index_match
     harness, runtime, model = env
-    B, T = 4, 2.0
-    images, text, targets = harness.nlvr_inputs(B, 224, 20, 3)
-    W = specs.synth_weights(specs.blip_nlvr_shapes(224), 0)
-    tr = {}
-    with torch.no_grad():
-        ref_logits = O.blip_nlvr_forward(W, images.cpu(), text["input_ids"].cpu(), text["attention_mask"].cpu(), T, trace=tr)
-    with runtime.precision("bf16"):
-        logits, trace = harness.run_nlvr(model, images, text, targets, T)
-    assert torch.isfinite(logits).all()
-    err = (logits.cpu() - ref_logits).abs().max().item()
-    # layer-0 kept sets see only bf16-rounded Q/K/V: they must agree almost everywhere
-    mine0 = harness.compose_ids(trace["vit"][:1], 196)[0]
-    ref0 = O.compose_ids(tr["vit"][:1], 196)[0]
-    jac = np.mean([len(a & b) / max(1, len(a | b)) for a, b in zip(mine0, ref0)])
-    print(f"bf16 fast mode: max|dlogit|={err:.4f} layer0 kept-set Jaccard={jac:.4f}")
-    assert err < 5e-2
-    assert jac > 0.9
+    rep = nlvr_index_match(model, T, ["bf16"], B=B, seed=3)["bf16"]
+    print(f"bf16 B={B} T={T:.2f}: {rep}")
+    assert rep["vit_layerwise_jaccard"] >= 0.998        # measured 0.9998 / 0.9994
+    assert rep["vit_layerwise_exact_match"] >= (0.975 if B <= 4 else 0.95)   # measured 0.989 / 0.974
+    assert rep["mean_jaccard"] >= 0.95                  # measured 0.984 / 0.979 (free running)
+    assert rep["max_abs_dlogit"] < 1.5e-2               # measured 0.005 / 0.006
 
 
 def test_module_error_behaviour(env):
@@ -149,7 +141,15 @@ def test_med_bert_fp32_matches_reference_fixture(path, mode):
         outb, _ = model(ids.cuda(), attention_mask=att.cuda(), encoder_hidden_states=None if enc is None else enc.cuda(),
                         encoder_attention_mask=None if enc_att is None else enc_att.cuda(), mode=bert_mode,
                         space_dict=sd.cuda(), temperature=T)
-    assert torch.isfinite(outb.last_hidden_state).all()
+    hb = outb.last_hidden_state
+    assert torch.isfinite(hb).all()
+    # the [ENC]/CLS row is the one every caller reads (itm_head, cls_head): bf16 GEMM error plus the occasional different kept
+    # token leave it close to the fp32-mode row (the other rows hold whichever tokens survived, in a mode-dependent order)
+    cb, cf = hb[:, 0, :].float(), hid[:, 0, :].float()
+    cos = torch.nn.functional.cosine_similarity(cb, cf, dim=-1).min().item()
+    errb = (cb - cf).abs().max().item()
+    print(f"MED bf16 vs fp32-mode CLS row: min cosine {cos:.5f}, max abs {errb:.4f} (|cls| max {cf.abs().max().item():.2f})")
+    assert cos > 0.99 and errb < 0.5   # measured 0.9969 / 0.29 on the 35 -> 7 token fixtures
 
 
 CLIP_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clip_*.npz")))
@@ -183,7 +183,9 @@ def test_clip_vision_fp32_matches_reference_fixture(path, mode):
     assert np.abs(sd_ft[:, :4, :16].cpu().numpy() - g["sd_ft_head"]).max() < 1e-2
     with runtime.precision("bf16"), torch.no_grad():
         fb, _ = model(images, space_dict, T, 1)
-    assert torch.isfinite(fb).all() and (fb.cpu() - torch.from_numpy(g["features"])).abs().max().item() < 0.25
+    errb = (fb.cpu() - torch.from_numpy(g["features"])).abs().max().item()
+    print(f"CLIP bf16 features: max abs err {errb:.4f} (|feat| max {np.abs(g['features']).max():.2f})")
+    assert torch.isfinite(fb).all() and errb < 0.1
     blk = model.transformer.resblocks[0]
     blk.attn_mask = torch.zeros(4, 4)
     with pytest.raises(NotImplementedError):
@@ -304,4 +306,10 @@ def test_retrieval_itm_reranking_matches_reference_fixture(path, mode):
         b_i2t, b_t2i, _ = br.evaluate(model, loader, torch.device("cuda"), cfg, T)
         c_i2t, c_t2i, _ = br.evaluate(model, loader, torch.device("cuda"), cfg, T, kv_cache=False)
     assert np.isfinite(b_i2t).all() and np.isfinite(b_t2i).all()
+    # bf16 re-ranks (almost) the same candidate sets and scores them within bf16 error of the reference
+    same = (b_i2t != -100.0) == (g["score_i2t"] != -100.0)
+    both = (b_i2t != -100.0) & (g["score_i2t"] != -100.0)
+    errb = np.abs(b_i2t - g["score_i2t"])[both].max()
+    print(f"retrieval bf16: candidate agreement {same.mean():.4f}, max |dscore| {errb:.4f}")
+    assert same.mean() > 0.95 and errb < 0.08   # measured 0.972 / 0.040
     assert np.array_equal(b_i2t, c_i2t) and np.array_equal(b_t2i, c_t2i)
