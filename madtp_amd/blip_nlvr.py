@@ -99,6 +99,9 @@ class BLIP_NLVR(nn.Module):
 
 def blip_nlvr(pretrained='', **kwargs):
     model = BLIP_NLVR(**kwargs)
-    if pretrained:
-        raise NotImplementedError("checkpoint loading: use model.load_state_dict(); key names match the reference")
+    if pretrained:  # blip_nlvr.py:122-128, load_checkpoint :130-159
+        from .checkpoint import load_checkpoint_nlvr
+        model, msg = load_checkpoint_nlvr(model, pretrained)
+        print("missing keys:")
+        print(msg.missing_keys)
     return model

@@ -70,8 +70,11 @@ class BLIP_Retrieval(nn.Module):
 
 def blip_retrieval(pretrained='', **kwargs):
     model = BLIP_Retrieval(**kwargs)
-    if pretrained:
-        raise NotImplementedError("checkpoint loading: use model.load_state_dict(strict=False); key names match the reference")
+    if pretrained:  # blip_retrieval.py (blip_retrieval) -> models/blip.py:254-278
+        from .checkpoint import load_checkpoint
+        model, msg = load_checkpoint(model, pretrained)
+        print("missing keys:")
+        print(msg.missing_keys)
     return model
 
 

@@ -1,0 +1,100 @@
+"""Drop-in installation ("drops into the compress_*_dtp.py scripts unchanged").
+
+    import madtp_amd.dropin as dropin
+    dropin.install("/path/to/MADTP")        # before the first `import models.*`
+    from models.blip_nlvr import blip_nlvr   # the REFERENCE's own, unmodified file ...
+    model = blip_nlvr(...)                   # ... now built from the MI355X mirrors of vit / med / nlvr_encoder / utils
+
+`install()` registers the mirrors under the reference's module names in sys.modules - `models.vit`, `models.med`,
+`models.nlvr_encoder`, `models.utils` - and leaves every other `models.*` module (blip.py, blip_nlvr.py, blip_retrieval.py,
+blip_vqa.py: pure glue) to be imported from the reference tree itself.  Names those glue files import that are off the
+pruned forward path (the text decoder `BertLMHeadModel`, the contrastive-loss helpers of models/utils.py) resolve to stubs
+that raise on use, so a training script fails loudly instead of silently running something else."""
+import importlib
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.modules.loss import _Loss
+
+_MIRRORS = ("vit", "med", "nlvr_encoder", "utils")
+
+
+def _off_path(name, what):
+    class _Stub(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            raise NotImplementedError(f"models.{what}.{name} is off the pruned forward path (training / decoding); "
+                                      "madtp_amd provides the evaluation forward only")
+    _Stub.__name__ = _Stub.__qualname__ = name
+    return _Stub
+
+
+def accuracy(output, target, topk=(1,)):
+    """models/utils.py:321-335 (metric helper used by the drivers)."""
+    maxk = max(topk)
+    _, pred = output.topk(maxk, 1, True, True)
+    pred = pred.t()
+    correct = pred.eq(target.view(1, -1).expand_as(pred))
+    return [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / target.size(0)) for k in topk]
+
+
+def _module(name, base, extra):
+    m = types.ModuleType(name)
+    m.__dict__.update({k: v for k, v in vars(base).items() if not k.startswith("__")})
+    m.__dict__.update(extra)
+    m.__doc__ = f"madtp_amd drop-in for the reference's {name} (mirror: {base.__name__})"
+    m.__madtp_mirror__ = base
+    return m
+
+
+def install(reference_root=None):
+    """Registers the mirrors as models.{vit,med,nlvr_encoder,utils}.  reference_root: directory that contains the reference's
+    `models/` package (needed unless `models` is already importable); it is put on sys.path like the drivers expect."""
+    if reference_root is not None:
+        reference_root = os.path.abspath(reference_root)
+        if reference_root not in sys.path:
+            sys.path.insert(0, reference_root)
+    for n in _MIRRORS:
+        full = f"models.{n}"
+        if full in sys.modules and not hasattr(sys.modules[full], "__madtp_mirror__"):
+            raise RuntimeError(f"{full} is already imported from {getattr(sys.modules[full], '__file__', '?')}: "
+                               "call madtp_amd.dropin.install() before the first `import models.*`")
+    pkg = sys.modules.get("models")
+    if pkg is None:
+        pkg = types.ModuleType("models")
+        roots = [os.path.join(p, "models") for p in ([reference_root] if reference_root else sys.path)
+                 if p and os.path.isdir(os.path.join(p, "models"))]
+        if not roots:
+            raise RuntimeError("cannot find the reference's `models/` package: pass reference_root")
+        pkg.__path__ = roots[:1]  # blip.py, blip_nlvr.py, ... are still imported from the reference tree
+        pkg.__package__ = "models"
+        sys.modules["models"] = pkg
+    extras = {
+        "vit": {},
+        "med": {"BertLMHeadModel": _off_path("BertLMHeadModel", "med")},
+        "nlvr_encoder": {},
+        # `from models.utils import *` in the reference also leaks that module's own imports; keep the same names available
+        "utils": {"torch": torch, "nn": nn, "np": np, "math": math, "F": F, "_Loss": _Loss,
+                  "device": torch.device("cuda" if torch.cuda.is_available() else "cpu"), "accuracy": accuracy,
+                  **{n: _off_path(n, "utils") for n in ("Sparsemax", "AllGather", "ClipInfoCELoss", "NT_Xent", "NT_Xent_gather")}},
+    }
+    try:
+        import einops
+        extras["utils"]["einops"] = einops
+    except ImportError:
+        pass
+    for n in _MIRRORS:
+        mod = _module(f"models.{n}", importlib.import_module(f"madtp_amd.{n}"), extras[n])
+        sys.modules[f"models.{n}"] = mod
+        setattr(pkg, n, mod)
+    return pkg
+
+
+def installed():
+    return all(hasattr(sys.modules.get(f"models.{n}"), "__madtp_mirror__") for n in _MIRRORS)

@@ -283,3 +283,20 @@ class VisionTransformer(nn.Module):
         B, N, D = x.shape
         y, _ = hip.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)  # :309
         return y, sd_img_ft_all
+
+
+def interpolate_pos_embed(pos_embed_checkpoint, visual_encoder):
+    """models/vit.py:398-422: bicubic resize of a checkpoint's position-embedding grid to this encoder's patch grid (the CLS
+    / extra tokens are kept); host-side weight preparation, run once per checkpoint load."""
+    embedding_size = pos_embed_checkpoint.shape[-1]
+    num_patches = visual_encoder.patch_embed.num_patches
+    num_extra_tokens = visual_encoder.pos_embed.shape[-2] - num_patches
+    orig_size = int((pos_embed_checkpoint.shape[-2] - num_extra_tokens) ** 0.5)
+    new_size = int(num_patches ** 0.5)
+    if orig_size == new_size:
+        return pos_embed_checkpoint
+    extra_tokens = pos_embed_checkpoint[:, :num_extra_tokens]
+    grid = pos_embed_checkpoint[:, num_extra_tokens:].reshape(-1, orig_size, orig_size, embedding_size).permute(0, 3, 1, 2)
+    grid = torch.nn.functional.interpolate(grid, size=(new_size, new_size), mode='bicubic', align_corners=False)
+    print('reshape position embedding from %d to %d' % (orig_size ** 2, new_size ** 2))
+    return torch.cat((extra_tokens, grid.permute(0, 2, 3, 1).flatten(1, 2)), dim=1)

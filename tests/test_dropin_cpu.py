@@ -1,0 +1,141 @@
+"""Drop-in boundary in the build container:
+  * madtp_amd.dropin.install() makes the REFERENCE's own, unmodified models/blip_nlvr.py / blip_retrieval.py construct on top
+    of the MI355X mirrors of models.{vit,med,nlvr_encoder,utils}; the resulting state_dict() keys and shapes equal the pure
+    reference model's (recorded in the golden fixtures by tools/make_golden.py);
+  * load_checkpoint semantics (models/blip.py:254-278, models/blip_nlvr.py:130-159): position-embedding interpolation equals
+    the reference's, twin-branch key duplication, shape filtering.
+The reference-importing tests are skipped where /root/reference is absent (the GPU box); the checkpoint tests run anywhere."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "models")), reason="reference tree not present")
+
+
+def _run(code):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(code)], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+@needs_ref
+def test_reference_blip_nlvr_constructs_on_the_mirrors():
+    out = _run(f"""
+        import sys, json, numpy as np
+        sys.path.insert(0, {ROOT!r} + "/tools")
+        import ref_shims
+        ref_shims.install(chdir=True, import_models=False)   # third-party stand-ins only (timm hub, tokenizer files ...)
+        import madtp_amd.dropin as dropin
+        dropin.install({REF!r})
+        import models.blip as blip                            # the reference's own glue files, unmodified
+        blip.init_tokenizer = lambda: ref_shims.FakeTokenizer()
+        import models.blip_nlvr as ref_nlvr
+        ref_nlvr.init_tokenizer = blip.init_tokenizer
+        assert ref_nlvr.__file__.startswith({REF!r}), ref_nlvr.__file__
+        import models.vit, models.med, models.nlvr_encoder, models.utils
+        import madtp_amd.vit, madtp_amd.bert
+        model = ref_nlvr.blip_nlvr(pretrained='', image_size=224, vit='base', evaluate=True, config=None)
+        assert type(model).__module__ == 'models.blip_nlvr'
+        assert isinstance(model.visual_encoder, madtp_amd.vit.VisionTransformer)
+        assert isinstance(model.text_encoder, madtp_amd.bert.NlvrBertModel)
+        sd = model.state_dict()
+        g = np.load({ROOT!r} + "/tests/golden/nlvr_b2_T1.npz", allow_pickle=False)
+        ref_keys = [str(k) for k in g["state_dict_keys"]]
+        mine = sorted(k for k in sd.keys())
+        missing = sorted(set(ref_keys) - set(mine)); extra = sorted(set(mine) - set(ref_keys))
+        print(json.dumps({{"n": len(mine), "missing": missing, "extra": extra}}))
+        """)
+    import json
+    rep = json.loads(out.strip().splitlines()[-1])
+    # buffers that only the reference registers (position_ids) may be absent; nothing else may differ
+    assert all("position_ids" in k for k in rep["missing"]), rep["missing"][:10]
+    assert all("position_ids" in k for k in rep["extra"]), rep["extra"][:10]
+    assert rep["n"] > 500
+
+
+@needs_ref
+def test_install_after_reference_import_is_refused():
+    _run(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r} + "/tools")
+        import ref_shims
+        ref_shims.install(chdir=True, import_models=True)    # imports the reference's own models.vit
+        import madtp_amd.dropin as dropin
+        try:
+            dropin.install({REF!r})
+        except RuntimeError as e:
+            assert "before the first" in str(e)
+        else:
+            raise SystemExit("install() after `import models.vit` must be refused")
+        """)
+
+
+@needs_ref
+def test_interpolate_pos_embed_equals_reference():
+    out = _run(f"""
+        import sys, torch
+        sys.path.insert(0, {ROOT!r} + "/tools")
+        import ref_shims
+        ref_shims.install(chdir=True, import_models=True)
+        import models.vit as ref_vit
+        from madtp_amd.vit import interpolate_pos_embed
+        class Enc:  # the two attributes the function reads
+            class patch_embed: num_patches = 576
+            pos_embed = torch.zeros(1, 577, 768)
+        torch.manual_seed(0)
+        ck = torch.randn(1, 197, 768)
+        a, b = ref_vit.interpolate_pos_embed(ck, Enc), interpolate_pos_embed(ck, Enc)
+        assert a.shape == (1, 577, 768) and torch.equal(a, b)
+        Enc.patch_embed.num_patches, Enc.pos_embed = 196, torch.zeros(1, 197, 768)
+        assert interpolate_pos_embed(ck, Enc) is ck
+        print("ok")
+        """)
+    assert "ok" in out
+
+
+def test_load_checkpoint_semantics(tmp_path):
+    """blip_nlvr(pretrained=path): pos-embed interpolation 14x14 -> 24x24, crossattention.self -> self0/self1 and
+    output.dense -> dense0/dense1 duplication, strict=False; blip.load_checkpoint: keys with a different shape are dropped."""
+    from madtp_amd.checkpoint import load_checkpoint, load_checkpoint_nlvr
+    from madtp_amd.vit import VisionTransformer, interpolate_pos_embed
+
+    class Tiny(torch.nn.Module):
+        def __init__(self, img):
+            super().__init__()
+            self.visual_encoder = VisionTransformer(img_size=img, patch_size=16, embed_dim=768, depth=1, num_heads=12, evaluate=True)
+            self.crossattention = torch.nn.ModuleDict({"self0": torch.nn.Linear(4, 4), "self1": torch.nn.Linear(4, 4)})
+            self.other = torch.nn.Linear(3, 3)
+    src = Tiny(224)
+    torch.manual_seed(1)
+    for p in src.parameters():
+        p.data.normal_()
+    sd = {k: v.clone() for k, v in src.state_dict().items() if "self0" not in k and "self1" not in k}
+    sd["crossattention.self.weight"] = torch.randn(4, 4)
+    sd["crossattention.self.bias"] = torch.randn(4)
+    path = os.path.join(tmp_path, "ck.pth")
+    torch.save({"model": sd, "temperature": 3.0}, path)
+    sd["other.weight"] = torch.randn(5, 5)                     # wrong shape: dropped by blip.load_checkpoint (second half)
+    dst = Tiny(384)
+    dst, msg = load_checkpoint_nlvr(dst, path)
+    got = dst.state_dict()
+    assert got["visual_encoder.pos_embed"].shape == (1, 577, 768)
+    assert torch.equal(got["visual_encoder.pos_embed"], interpolate_pos_embed(sd["visual_encoder.pos_embed"], dst.visual_encoder))
+    assert torch.equal(got["crossattention.self0.weight"], sd["crossattention.self.weight"])
+    assert torch.equal(got["crossattention.self1.bias"], sd["crossattention.self.bias"])
+    assert "crossattention.self.weight" in msg.unexpected_keys
+    dst2 = Tiny(384)
+    before = dst2.other.weight.clone()
+    sd2 = dict(sd); sd2.pop("crossattention.self.weight"); sd2.pop("crossattention.self.bias")
+    dst2, msg2 = load_checkpoint(dst2, {"model": sd2})
+    assert torch.equal(dst2.other.weight, before) and "other.weight" in msg2.missing_keys
+    assert dst2.state_dict()["visual_encoder.pos_embed"].shape == (1, 577, 768)
+    with pytest.raises(RuntimeError):
+        load_checkpoint(dst2, "https://example.com/x.pth")

@@ -82,7 +82,9 @@ class FakeTokenizer:
 _installed = False
 
 
-def install(chdir=True):
+def install(chdir=True, import_models=True):
+    """import_models=False: only the third-party stand-ins (used with madtp_amd.dropin, which must be installed BEFORE the
+    first `import models.*`)."""
     global _installed
     if _installed:
         return
@@ -214,6 +216,8 @@ def install(chdir=True):
     if chdir:
         os.chdir(REFERENCE_ROOT)  # (8) relative 'configs/med_config.json'
 
+    if not import_models:
+        return
     # (6) tokenizer: replace by-name copies after the modules are imported
     import models.blip as blip_mod
     blip_mod.init_tokenizer = lambda: FakeTokenizer()
