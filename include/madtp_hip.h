@@ -114,6 +114,14 @@ int madtp_attention(const void* q, const void* k, const void* v, void* out, cons
                     float* colsum_part, float* p0, float* onorm,
                     int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo,
                     float scale, int io_dtype, void* stream);
+/* madtp_attention with one more additive mask: mask_qk f32 [Nq, >=Nk] (row stride ld_mask_qk), shared by all samples and heads,
+ * added to the scaled scores next to add_mask - the causal attn_mask of CLIP's text tower (clip/model.py:466-472, applied as
+ * attn_mask[:L,:L] by the patched MultiheadAttention, clip/mock.py:309-310).  Nk <= 256. */
+int madtp_attention_qk_mask(const void* q, const void* k, const void* v, void* out, const float* add_mask,
+                            const float* mask_qk, int ld_mask_qk, float* colsum_part, float* p0, float* onorm,
+                            int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo,
+                            float scale, int io_dtype, void* stream);
+
 /* Cross-attention against a CACHE of encoder K/V blocks: sample b attends to block kv_batch_index[b] (int32 [B], device) of
  * k / v, i.e. rows kv_batch_index[b]*Nk .. +Nk-1 (NULL = block b, which is madtp_attention).  Lets many queries share the
  * projected K/V of one image (retrieval re-ranking) without copying them; no score side outputs. */
@@ -257,6 +265,8 @@ typedef struct madtp_vit_block_w {
     madtp_lin qkv, proj, fc1, fc2;
     int heads, dim, dtype; /* dtype: MADTP_F32 (parity mode), MADTP_F16S (fp32-accurate on the f16 MFMA) or MADTP_BF16 (fast mode) */
     int act;               /* MLP activation: MADTP_ACT_GELU_ERF (BLIP ViT) or MADTP_ACT_QUICK_GELU (CLIP) */
+    const float* attn_mask; /* optional additive [>=N, >=N] attention mask (CLIP text tower: causal), row stride ld_attn_mask */
+    int ld_attn_mask;
 } madtp_vit_block_w;
 
 size_t madtp_vit_block_workspace(int B, int N, int dim, int hidden, int heads, int dtype);

@@ -1,11 +1,15 @@
-"""Mirror of the reference's CLIP vision path with token pruning (clip/model.py: LayerNorm :158, QuickGELU :167,
-ResidualAttentionBlock :174-261, Transformer :264-272, VisionTransformer :275-313, with clip/mock.py's patched
-nn.MultiheadAttention): same constructor arguments, parameter names and forward() contracts - a block takes and returns the
-5-tuple (x[L,B,C], space_dict, temperature, sd_ft_all, max_keep).
+"""Mirror of the reference's CLIP with token pruning (clip/model.py: LayerNorm :158, QuickGELU :167, ResidualAttentionBlock
+:174-261, Transformer :264-272, VisionTransformer :275-313, CLIP :316-503 evaluation side, build_model :678-716, with
+clip/mock.py's patched nn.MultiheadAttention): same constructor arguments, parameter names and forward() contracts - a block
+takes and returns the 5-tuple (x[L,B,C], space_dict, temperature, sd_ft_all, max_keep).
 
-Scope: the VISION tower.  A block built with an attn_mask (the causal text tower)
-raises NotImplementedError - the text tower's positional causal mask / EOT read-out depend on the implementation-defined
-order of topk(sorted=False) and are tolerance-only in the survey.
+Both towers run (BASELINE config 4).  The text tower's blocks carry the causal attn_mask, applied as
+attn_mask[:L,:L] to the CURRENT (possibly pruned) sequence exactly as clip/mock.py:309-310 does.  One documented difference:
+the reference keeps pruned tokens in torch.topk(sorted=False)'s implementation-defined order, this path in ascending token
+order ("replicate a canonical order and document it").  In the vision tower the order is immaterial; in
+the text tower the positional mask and the read-out x[b, argmax(text[b])] (:501) see the order, so text features of PRUNED
+sequences are pinned by the oracle run with order="ascending" (oracle.clip_encode_text), and the oracle with
+order="reference" is pinned to the reference fixture.
 """
 from collections import OrderedDict
 
@@ -47,6 +51,7 @@ class ResidualAttentionBlock(nn.Module):
                                               ("c_proj", nn.Linear(d_model * 4, d_model))]))
         self.ln_2 = LayerNorm(d_model)
         self.attn_mask = attn_mask
+        self._mask_dev = None  # f32 GPU copy of attn_mask handed to the attention kernel
         self.query_model = Query_model(ft_dim=d_model, sd_dim=sd_dim, temperature=1, att_func_type='sparsemax',
                                        pool_type='max', map_func=True)
         self.n_head, self.d_model = n_head, d_model
@@ -69,15 +74,22 @@ class ResidualAttentionBlock(nn.Module):
             w.heads, w.dim = self.n_head, self.d_model
             w.dtype = dtype_code()
             w.act = hip.ACT_QUICK_GELU
-            return (w, lins)
+            keep = [lins]
+            if self.attn_mask is not None:  # :191-192 attention(): the mask follows x's device
+                dev = self.ln_1.weight.device
+                if self._mask_dev is None or self._mask_dev.device != dev:
+                    self._mask_dev = self.attn_mask.detach().to(device=dev, dtype=torch.float32).contiguous()
+                w.attn_mask, w.ld_attn_mask = self._mask_dev.data_ptr(), self._mask_dev.stride(0)
+                keep.append(self._mask_dev)
+            return (w, keep)
 
         return self._cache.get("w", params, build)[0]
 
     def forward(self, inputs):
         x, space_dict, temperature, sd_ft_all, max_keep = inputs  # x: (N, B, C)   clip/model.py:238
         require_gpu(x, "x")
-        if self.attn_mask is not None:
-            raise NotImplementedError("causal (text-tower) blocks are out of scope: vision tower only")
+        if self.attn_mask is not None and x.shape[0] > self.attn_mask.shape[0]:
+            raise ValueError(f"sequence of {x.shape[0]} tokens exceeds the {self.attn_mask.shape[0]}-token attention mask")
         xb = as_f32_contig(x.permute(1, 0, 2))  # (B, N, C); a no-op view when x came from the previous block
         B, N, C = xb.shape
         token_attn = None
@@ -93,7 +105,7 @@ class ResidualAttentionBlock(nn.Module):
             k = hip.batch_max_count(count)
             self.last_prune = {"k": k, "score": score, "threshold": thr, "count": count, "pruned": False,
                                "indices": None, "indices_sort": None}
-            if not (k <= max_keep or (N - 1 - k) <= 1):  # :220-221
+            if not (k <= int(max_keep) or (N - 1 - k) <= 1):  # :220-221 (max_keep is a 0-dim tensor on the text side, :492)
                 k_use = k
         y, indices, indices_sort = hip.vit_block_mlp(w, x_attn, k_use, score)  # :222-234, :260
         if k_use:
@@ -154,3 +166,105 @@ class VisionTransformer(nn.Module):
             pj = self._cache.get(("proj", cdt), [self.proj], lambda: prepare_linear([self.proj.t()], None, cdt))
             cls = hip.gemm(to_compute(cls), pj.w, None, out_dtype=torch.float32, n=pj.n)
         return cls, sd_img_ft_all
+
+
+class CLIP(nn.Module):
+    """clip/model.py:316-503, evaluation side: the towers, embeddings and projections with the reference's parameter names
+    (checkpoints load by key; the momentum copies `*_m` and the queues of :395-436 are training state and are not created -
+    load_state_dict(strict=False), as build_model :715 does, skips them), encode_image :482-483 and encode_text :485-503."""
+
+    def __init__(self, embed_dim: int, image_resolution: int, vision_layers, vision_width: int, vision_patch_size: int,
+                 context_length: int, vocab_size: int, transformer_width: int, transformer_heads: int,
+                 transformer_layers: int, evaluate: bool = True, config=None):
+        super().__init__()
+        self.context_length = context_length
+        self.sd_num = 100 if config is None else config['sd_num']
+        self.sd_dim = 768 if config is None else config['sd_dim']
+        self.space_dict = nn.Parameter(torch.randn(self.sd_num, self.sd_dim))
+        if isinstance(vision_layers, (tuple, list)):
+            raise NotImplementedError("ModifiedResNet vision towers (clip/model.py:94-155) are off the pruned ViT path")
+        self.visual = VisionTransformer(input_resolution=image_resolution, patch_size=vision_patch_size, width=vision_width,
+                                        layers=vision_layers, heads=vision_width // 64, output_dim=embed_dim, sd_dim=self.sd_dim)
+        self.transformer = Transformer(width=transformer_width, layers=transformer_layers, heads=transformer_heads,
+                                       attn_mask=self.build_attention_mask(), sd_dim=self.sd_dim)
+        self.vocab_size = vocab_size
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(self.context_length, transformer_width))
+        self.ln_final = LayerNorm(transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]) * 2.6592600369327779)  # log(1 / 0.07)
+        self.embed_dim = embed_dim
+        self.tokenize = None
+        self.vision_layers, self.transformer_layers = vision_layers, transformer_layers
+        self._cache = PreparedCache()
+        if not evaluate:
+            self.initialize_parameters()
+
+    def initialize_parameters(self):
+        """clip/model.py:438-464."""
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        proj_std = (self.transformer.width ** -0.5) * ((2 * self.transformer.layers) ** -0.5)
+        attn_std = self.transformer.width ** -0.5
+        fc_std = (2 * self.transformer.width) ** -0.5
+        for block in self.transformer.resblocks:
+            nn.init.normal_(block.attn.in_proj_weight, std=attn_std)
+            nn.init.normal_(block.attn.out_proj.weight, std=proj_std)
+            nn.init.normal_(block.mlp.c_fc.weight, std=fc_std)
+            nn.init.normal_(block.mlp.c_proj.weight, std=proj_std)
+        nn.init.normal_(self.text_projection, std=self.transformer.width ** -0.5)
+
+    def build_attention_mask(self):
+        """clip/model.py:466-472: additive causal mask, -inf above the diagonal."""
+        mask = torch.empty(self.context_length, self.context_length)
+        mask.fill_(float("-inf"))
+        mask.triu_(1)
+        return mask
+
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    def encode_image(self, image, space_dict=None, temperature=0):
+        return self.visual(image, space_dict=space_dict, temperature=temperature)  # :482-483
+
+    def encode_text(self, text, space_dict=None, temperature=0):
+        """:485-503.  -> (features [B, embed_dim], sd_txt_ft_all)"""
+        require_gpu(text, "text")
+        B, L = text.shape
+        # token + positional embeddings: an embedding-row gather and an add (the BERT kernel with its LayerNorm does not apply)
+        x = (self.token_embedding.weight[text] + self.positional_embedding[:L]).float().contiguous()  # :486-488
+        eot = text.argmax(dim=-1)
+        max_keep = eot.max() + 2  # :492
+        xs = x.permute(1, 0, 2)  # NLD -> LND (a view)
+        xs, _, _, sd_txt_ft_all, _ = self.transformer(xs, space_dict, temperature, None, max_keep)  # :493
+        xb = as_f32_contig(xs.permute(1, 0, 2))
+        rows = xb[torch.arange(B, device=xb.device), eot].contiguous()  # :501 (LayerNorm is row-wise: gather first)
+        rows, _ = hip.layernorm(rows, self.ln_final.weight, self.ln_final.bias, self.ln_final.eps)  # :497
+        cdt = compute_dtype()
+        pj = self._cache.get(("text_projection", cdt), [self.text_projection],
+                             lambda: prepare_linear([self.text_projection.t()], None, cdt))
+        return hip.gemm(to_compute(rows), pj.w, None, out_dtype=torch.float32, n=pj.n), sd_txt_ft_all
+
+
+def build_model(state_dict: dict, evaluate: bool = False, config=None):
+    """clip/model.py:678-716: geometry inferred from the checkpoint's tensor shapes (ViT towers), strict=False load.  The
+    reference casts weights to fp16 (convert_weights :653-675) and back to fp32 (clip/clip.py:148); here they stay fp32."""
+    if "visual.proj" not in state_dict:
+        raise NotImplementedError("ResNet CLIP checkpoints are off the pruned ViT path")
+    vision_width = state_dict["visual.conv1.weight"].shape[0]
+    vision_layers = len([k for k in state_dict.keys() if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    vision_patch_size = state_dict["visual.conv1.weight"].shape[-1]
+    grid_size = round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    image_resolution = vision_patch_size * grid_size
+    embed_dim = state_dict["text_projection"].shape[1]
+    context_length = state_dict["positional_embedding"].shape[0]
+    vocab_size = state_dict["token_embedding.weight"].shape[0]
+    transformer_width = state_dict["ln_final.weight"].shape[0]
+    transformer_heads = transformer_width // 64
+    transformer_layers = len(set(k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks")))
+    model = CLIP(embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size, context_length, vocab_size,
+                 transformer_width, transformer_heads, transformer_layers, evaluate, config)
+    sd = {k: v for k, v in state_dict.items() if k not in ("input_resolution", "context_length", "vocab_size")}
+    model.load_state_dict(sd, strict=False)
+    return model

@@ -29,6 +29,9 @@ struct AttnArgs {
     const int* kvidx;  // optional: sample b reads K/V block kvidx[b] (cross-attention against a cache of encoder K/V)
     // madtp_attention_pair (attn_bf16_kernel without scores only): a second problem of identical shape, blockIdx.y in [B, 2B)
     const char* q2; const char* k2; const char* v2; char* out2; const float* mask2; int pair;
+    // optional additive [Nq, Nk] mask shared by all samples and heads (CLIP's causal text mask, clip/mock.py:309-310): element
+    // (i, j) at mask_qk[i * ld_mqk + j]; folded into the per-lane key mask (a lane owns one query row)
+    const float* mask_qk; int ld_mqk;
 };
 
 template <typename T> __device__ __forceinline__ f32x4 load4(const char* p);
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int j = 16 * t + 4 * g + r;
             mk[t][r] = j < a.Nk ? (a.mask ? a.mask[(size_t)b * a.Nk + j] : 0.f) : -INFINITY;
+            if (a.mask_qk && j < a.Nk) mk[t][r] += a.mask_qk[(size_t)irow * a.ld_mqk + j];
         }
 
     for (int h = blockIdx.z; h < a.H; h += gridDim.z) {
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void a
         for (int r = 0; r < 4; ++r) {
             const int j = 16 * t + 4 * g + r;
             mk[t][r] = j < a.Nk ? (a.mask ? a.mask[(size_t)b * a.Nk + j] : 0.f) : -INFINITY;
+            if (a.mask_qk && j < a.Nk) mk[t][r] += a.mask_qk[(size_t)irow * a.ld_mqk + j];
         }
 
     // K_h and V_h are LDS-DMA'd (8 rows = 1 KiB per wave-instruction) into a 2-stage ring over the heads: the DMA of
@@ -908,10 +913,32 @@ extern "C" int madtp_attention(const void* q, const void* k, const void* v, void
                                    scale, io_dtype, stream);
 }
 
+static int attention_launch(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
+                            const float* add_mask, const float* mask_qk, int ld_mask_qk, float* colsum_part, float* p0,
+                            float* onorm, int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale,
+                            int io_dtype, void* stream);
+
 extern "C" int madtp_attention_indexed(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
                                        const float* add_mask, float* colsum_part, float* p0, float* onorm, int B, int H,
                                        int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale, int io_dtype,
                                        void* stream) {
+    return attention_launch(q, k, v, kv_batch_index, out, add_mask, nullptr, 0, colsum_part, p0, onorm, B, H, Nq, Nk, ldq, ldk,
+                            ldv, ldo, scale, io_dtype, stream);
+}
+
+extern "C" int madtp_attention_qk_mask(const void* q, const void* k, const void* v, void* out, const float* add_mask,
+                                       const float* mask_qk, int ld_mask_qk, float* colsum_part, float* p0, float* onorm, int B,
+                                       int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale, int io_dtype,
+                                       void* stream) {
+    if (mask_qk && (ld_mask_qk < Nk || Nk > 256)) return MADTP_E_SHAPE;  // the <= 256-key kernels carry the [Nq,Nk] mask
+    return attention_launch(q, k, v, nullptr, out, add_mask, mask_qk, ld_mask_qk, colsum_part, p0, onorm, B, H, Nq, Nk, ldq, ldk,
+                            ldv, ldo, scale, io_dtype, stream);
+}
+
+static int attention_launch(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
+                            const float* add_mask, const float* mask_qk, int ld_mask_qk, float* colsum_part, float* p0,
+                            float* onorm, int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale,
+                            int io_dtype, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
     if (kv_batch_index && colsum_part) return MADTP_E_BADARG;  // indexed K/V is a cross-attention feature
     if (io_dtype != MADTP_F32 && io_dtype != MADTP_BF16) return MADTP_E_DTYPE;
@@ -928,6 +955,7 @@ extern "C" int madtp_attention_indexed(const void* q, const void* k, const void*
     a.scale = scale;
     a.kvidx = kv_batch_index;
     a.pair = 0; a.q2 = a.k2 = a.v2 = nullptr; a.out2 = nullptr; a.mask2 = nullptr;
+    a.mask_qk = mask_qk; a.ld_mqk = ld_mask_qk;
     hipStream_t s = (hipStream_t)stream;
     const bool scores = colsum_part != nullptr;
     if (Nk > 256) {  // long sequences (384^2 / 480^2 images): two-pass kernel, exact-f32 MFMA in both modes
@@ -936,7 +964,7 @@ extern "C" int madtp_attention_indexed(const void* q, const void* k, const void*
     }
     if (io_dtype == MADTP_F32) return scores ? dispatch_nt<float, true>(a, s) : dispatch_nt<float, false>(a, s);
     if ((ldk * 2) % 16 || (ldv * 2) % 16) return MADTP_E_ALIGN;
-    if (scores && Nk <= 32) {  // short text sequences: one sample per workgroup, heads spread over the waves
+    if (scores && Nk <= 32 && !mask_qk) {  // short text sequences: one sample per workgroup, heads spread over the waves
         hipLaunchKernelGGL(attn_bf16_small_kernel, dim3(B), dim3(64 * SMALL_NW), 0, s, a);
         MADTP_LAUNCH_CHECK();
         return 0;
@@ -968,6 +996,7 @@ extern "C" int madtp_attention_pair(const void* q0, const void* q1, const void* 
     a.q = (const char*)q0; a.k = (const char*)k0; a.v = (const char*)v0; a.out = (char*)out0; a.mask = add_mask0;
     a.q2 = (const char*)q1; a.k2 = (const char*)k1; a.v2 = (const char*)v1; a.out2 = (char*)out1; a.mask2 = add_mask1;
     a.pair = 1;
+    a.mask_qk = nullptr; a.ld_mqk = 0;
     a.colsum = nullptr; a.p0 = nullptr; a.onorm = nullptr;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.nrt = (Nq + 15) / 16;

@@ -177,8 +177,9 @@ static int vit_attn_impl(const madtp_vit_block_w* w, const float* x, float* x_ou
     TRY(ln_to(x, w->ln1_g, w->ln1_b, nullptr, s.h, M, D, w->eps, dt, stream));
     TRY(lin(s.h, D, w->qkv, nullptr, 0, s.qkv, 3 * D, M, dt, adt, MADTP_ACT_NONE, 1.f, stream));
     const char* q = (const char*)s.qkv;
-    TRY(madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.o, nullptr, prune ? s.colsum : nullptr, s.p0, s.onorm,
-                        B, w->heads, N, N, 3 * D, 3 * D, 3 * D, D, w->scale, adt, stream));
+    TRY(madtp_attention_qk_mask(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.o, nullptr, w->attn_mask, w->ld_attn_mask,
+                                prune ? s.colsum : nullptr, s.p0, s.onorm, B, w->heads, N, N, 3 * D, 3 * D, 3 * D, D, w->scale, adt,
+                                stream));
     if (dt == MADTP_F16S) {  // the projection GEMM takes the attention output as f16 planes (s.h is free again)
         TRY(to_lp((const float*)s.o, D, s.h, M, D, dt, stream));
         s.o = s.h;

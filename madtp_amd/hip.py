@@ -31,6 +31,7 @@ _SIGS = {
     "madtp_assemble_tokens": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "madtp_bert_embed": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "madtp_attention": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float, c_int, c_void_p]),
+    "madtp_attention_qk_mask": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 3 + [c_int] * 8 + [c_float, c_int, c_void_p]),
     "madtp_token_score": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float]
                           + [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "madtp_token_select": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_void_p]),
@@ -84,7 +85,7 @@ class VitBlockW(ctypes.Structure):
     _fields_ = [("ln1_g", c_void_p), ("ln1_b", c_void_p), ("ln2_g", c_void_p), ("ln2_b", c_void_p),
                 ("eps", c_float), ("scale", c_float),
                 ("qkv", LinStruct), ("proj", LinStruct), ("fc1", LinStruct), ("fc2", LinStruct),
-                ("heads", c_int), ("dim", c_int), ("dtype", c_int), ("act", c_int)]
+                ("heads", c_int), ("dim", c_int), ("dtype", c_int), ("act", c_int), ("attn_mask", c_void_p), ("ld_attn_mask", c_int)]
 
 
 class BertLayerW(ctypes.Structure):
@@ -269,9 +270,9 @@ def bert_embed(ids, word_emb, pos_emb, gamma, beta, eps, want_bf16=False, lp=Non
     return y32, ylp
 
 
-def attention(q, k, v, B, H, Nq, Nk, scale, add_mask=None, scores=False):
+def attention(q, k, v, B, H, Nq, Nk, scale, add_mask=None, scores=False, mask_qk=None):
     """q,k,v: 2-D row views [B*N, >=H*64] (may be column slices of one fused projection).  Returns
-    (out[B*Nq, H*64], (colsum_part, p0, onorm) or None)."""
+    (out[B*Nq, H*64], (colsum_part, p0, onorm) or None).  mask_qk: optional additive f32 [>=Nq, >=Nk] mask (causal)."""
     for t in (q, k, v):
         if not t.is_cuda or t.stride(1) != 1:
             raise RuntimeError("attention operands must be GPU row-major views")
@@ -286,6 +287,12 @@ def attention(q, k, v, B, H, Nq, Nk, scale, add_mask=None, scores=False):
         side = (cs, p0, on)
     if add_mask is not None:
         _req(add_mask, torch.float32, "add_mask")
+    if mask_qk is not None:
+        _req(mask_qk, torch.float32, "mask_qk")
+        _check(load().madtp_attention_qk_mask(_p(q), _p(k), _p(v), _p(out), _p(add_mask), _p(mask_qk), mask_qk.stride(0), _p(cs),
+                                              _p(p0), _p(on), B, H, Nq, Nk, q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+                                              float(scale), _dt(q), _stream()), "madtp_attention_qk_mask")
+        return out, side
     _check(load().madtp_attention(_p(q), _p(k), _p(v), _p(out), _p(add_mask), _p(cs), _p(p0), _p(on), B, H, Nq, Nk,
                                   q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), _dt(q), _stream()),
            "madtp_attention")

@@ -130,6 +130,39 @@ def clip_vit_shapes(prefix="", img_size=224, patch=16, width=768, layers=12, out
     return sd
 
 
+def clip_text_shapes(prefix="", width=512, layers=12, ctx=77, vocab=49408, embed_dim=512, sd_dim=768):
+    """clip/model.py CLIP text side (:379-392): token / positional embeddings, the causal Transformer (:264-272) of
+    ResidualAttentionBlocks with their query_model.q_map, ln_final, text_projection."""
+    sd = OrderedDict()
+    sd[prefix + "token_embedding.weight"] = (vocab, width)
+    sd[prefix + "positional_embedding"] = (ctx, width)
+    sd[prefix + "text_projection"] = (width, embed_dim)
+    for i in range(layers):
+        p = f"{prefix}transformer.resblocks.{i}."
+        sd[p + "attn.in_proj_weight"] = (3 * width, width)
+        sd[p + "attn.in_proj_bias"] = (3 * width,)
+        _linear(sd, p + "attn.out_proj", width, width)
+        _ln(sd, p + "ln_1", width)
+        _linear(sd, p + "mlp.c_fc", 4 * width, width)
+        _linear(sd, p + "mlp.c_proj", width, 4 * width)
+        _ln(sd, p + "ln_2", width)
+        _linear(sd, p + "query_model.q_map.0", sd_dim, width)
+    _ln(sd, prefix + "ln_final", width)
+    return sd
+
+
+def clip_shapes(img_size=224, patch=16, vision_width=768, vision_layers=12, embed_dim=512, text_width=512, text_layers=12,
+                ctx=77, vocab=49408, sd_num=100, sd_dim=768):
+    """clip/model.py CLIP (ViT-B/16 geometry by default): visual.*, the text side, logit_scale, space_dict (the momentum
+    copies and queues of :395-436 are training state and are not part of the evaluation state dict)."""
+    sd = OrderedDict()
+    sd["space_dict"] = (sd_num, sd_dim)
+    sd["logit_scale"] = ()
+    sd.update(clip_vit_shapes("visual.", img_size, patch, vision_width, vision_layers, embed_dim, sd_dim))
+    sd.update(clip_text_shapes("", text_width, text_layers, ctx, vocab, embed_dim, sd_dim))
+    return sd
+
+
 def synth_weights(shapes, seed=0):
     """{key: tensor} from a shape spec using the deterministic generator."""
     import torch

@@ -91,6 +91,21 @@ def synth_images(n: int, size: int = 224, seed: int = 0) -> torch.Tensor:
     return torch.from_numpy(v.reshape(n, 3, size, size))
 
 
+def synth_clip_tokens(batch: int, ctx: int = 77, seed: int = 0, min_len: int = 6, max_len: int = 40, sot: int = 49406,
+                      eot: int = 49407) -> torch.Tensor:
+    """[batch, ctx] int64 CLIP-style token rows: SOT, `len_b` word ids in [1000, 40000), EOT (the highest id of the row -
+    clip/model.py:501 finds it with argmax), zero padding."""
+    h = hash_u32("clip_tokens", batch * ctx, seed).astype(np.int64)
+    ln = hash_u32("clip_lens", batch, seed).astype(np.int64)
+    ids = np.zeros((batch, ctx), dtype=np.int64)
+    for b in range(batch):
+        n = int(min_len + ln[b] % (max_len - min_len + 1))
+        ids[b, 0] = sot
+        ids[b, 1:1 + n] = 1000 + h[b * ctx:b * ctx + n] % 39000
+        ids[b, 1 + n] = eot
+    return torch.from_numpy(ids)
+
+
 def synth_token_ids(batch: int, length: int, seed: int = 0, lo: int = 1000, hi: int = 30000,
                     first_id=None) -> torch.Tensor:
     """[batch,length] int64 ids uniform in [lo,hi); position 0 optionally overwritten (the reference

@@ -152,7 +152,7 @@ def test_med_bert_fp32_matches_reference_fixture(path, mode):
     assert cos > 0.99 and errb < 0.5   # measured 0.9969 / 0.29 on the 35 -> 7 token fixtures
 
 
-CLIP_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clip_*.npz")))
+CLIP_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clip_vit_*.npz")))
 
 
 @pytest.mark.parametrize("mode", EXACT_MODES)
@@ -188,8 +188,8 @@ def test_clip_vision_fp32_matches_reference_fixture(path, mode):
     assert torch.isfinite(fb).all() and errb < 0.1
     blk = model.transformer.resblocks[0]
     blk.attn_mask = torch.zeros(4, 4)
-    with pytest.raises(NotImplementedError):
-        blk((torch.zeros(4, 1, 768, device="cuda"), None, 0, None, 1))
+    with pytest.raises(ValueError):  # a sequence longer than the block's attention mask
+        blk((torch.zeros(5, 1, 768, device="cuda"), None, 0, None, 1))
     blk.attn_mask = None
 
 
@@ -313,3 +313,65 @@ def test_retrieval_itm_reranking_matches_reference_fixture(path, mode):
     print(f"retrieval bf16: candidate agreement {same.mean():.4f}, max |dscore| {errb:.4f}")
     assert same.mean() > 0.95 and errb < 0.08   # measured 0.972 / 0.040
     assert np.array_equal(b_i2t, c_i2t) and np.array_equal(b_t2i, c_t2i)
+
+
+CLIP_FULL_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clip_full_*.npz")))
+
+
+@pytest.mark.parametrize("mode", EXACT_MODES)
+@pytest.mark.parametrize("path", CLIP_FULL_CASES, ids=[os.path.basename(c)[:-4] for c in CLIP_FULL_CASES])
+def test_clip_both_towers(path, mode):
+    """CLIP mirror (clip/model.py CLIP.encode_image / encode_text, BASELINE config 4) built by build_model() from a state dict:
+    vision tower vs the reference fixture (kept sets identical, features within 1e-3); causal text tower vs the oracle run in
+    the HIP path's canonical (ascending) token order - kept sets per layer identical, features within 1e-3 - and vs the
+    reference fixture where the order cannot matter yet (lengths, first pruned layer's kept set)."""
+    from madtp_amd import build, hip, harness, runtime, specs, synth
+    from madtp_amd import clip_model as cm
+    from oracle import madtp_oracle as O
+    build.build(verbose=False)
+    hip.load()
+    g = np.load(path)
+    B, size, T, seed = int(g["B"]), int(g["size"]), float(g["temperature"]), int(g["seed"])
+    W = specs.synth_weights(specs.clip_shapes(size), seed)
+    model = cm.build_model(dict(W), evaluate=True).eval().cuda()
+    assert model.transformer.width == 512 and model.context_length == 77 and model.visual.input_resolution == size
+    images = synth.synth_images(B, size, seed).cuda()
+    text = synth.synth_clip_tokens(B, 77, seed, int(g["min_len"]), int(g["max_len"]))
+    otr = []
+    with torch.no_grad():
+        ref_ft, ref_sd = O.clip_encode_text(W, text, W["space_dict"], T, order="ascending", trace=otr)
+
+    def traces(blocks):
+        return [None if b.last_prune is None else {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.last_prune.items()}
+                for b in blocks]
+
+    with runtime.precision(mode), torch.no_grad():
+        fi, sd_i = model.encode_image(images, model.space_dict, T)
+        vtr = traces(model.visual.transformer.resblocks)
+        ft, sd_t = model.encode_text(text.cuda(), model.space_dict, T)
+        ttr = traces(model.transformer.resblocks)
+    # vision tower == reference
+    assert harness.token_lengths(vtr, 197) == g["vit_lens"].tolist()
+    ref_v = [{"pruned": True, "indices": g[f"vit{l}_idx"]} if f"vit{l}_idx" in g.files else None for l in range(12)]
+    assert harness.compose_ids(vtr, 196) == harness.compose_ids(ref_v, 196)
+    assert np.abs(fi.cpu().numpy() - g["image_features"]).max() < 1e-3
+    # text tower == oracle in canonical order
+    assert harness.token_lengths(ttr, 77) == harness.token_lengths(otr, 77)
+    assert harness.compose_ids(ttr, 76) == O.compose_ids(otr, 76)
+    for l, info in enumerate(ttr):  # canonical order: kept ids ascend
+        if info is not None and info["pruned"]:
+            idx = info["indices"].numpy()
+            assert (np.diff(idx, axis=1) > 0).all()
+    assert (ft.cpu() - ref_ft).abs().max().item() < 1e-3
+    assert (sd_t.cpu() - ref_sd).abs().max().item() < 1e-3 * max(1.0, ref_sd.abs().max().item())
+    # ... and == reference up to the first pruned layer (same input there, so the same kept SET and the same k)
+    first = next(l for l in range(12) if f"txt{l}_idx" in g.files)
+    assert harness.token_lengths(ttr, 77)[: first + 1] == g["txt_lens"].tolist()[: first + 1]
+    assert (np.sort(ttr[first]["indices"].numpy(), 1) == np.sort(g[f"txt{first}_idx"], 1)).all()
+    with runtime.precision("bf16"), torch.no_grad():
+        fb, _ = model.encode_text(text.cuda(), model.space_dict, T)
+        ib, _ = model.encode_image(images, model.space_dict, T)
+    cos_t = torch.nn.functional.cosine_similarity(fb.float(), ft.float(), dim=-1).min().item()
+    cos_i = torch.nn.functional.cosine_similarity(ib.float(), fi.float(), dim=-1).min().item()
+    print(f"CLIP bf16 vs {mode}: min cosine text {cos_t:.4f} image {cos_i:.4f}")
+    assert cos_t > 0.98 and cos_i > 0.98

@@ -95,7 +95,7 @@ def test_oracle_med_matches_reference_fixture(path):
         assert (info["indices_sort"].numpy() == g[f"txt{l}_sort"]).all()
 
 
-CLIP_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clip_*.npz")))
+CLIP_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clip_vit_*.npz")))
 
 
 @pytest.mark.parametrize("path", CLIP_CASES, ids=[os.path.basename(c)[:-4] for c in CLIP_CASES])
@@ -192,3 +192,48 @@ def test_controller_matches_reference_rule_and_constant():
     # a toy plant: GFLOPs fall with T; the controller settles within one small step of the target
     log = C.run_controller(lambda T: 132.54 / (1.0 + 0.2 * T), 0.0, 0.5, 132.54, 60)
     assert abs(log[-1][2] - 66.27) < 1.5
+
+
+CLIP_FULL_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clip_full_*.npz")))
+
+
+@pytest.mark.parametrize("path", CLIP_FULL_CASES, ids=[os.path.basename(c)[:-4] for c in CLIP_FULL_CASES])
+def test_oracle_clip_full_matches_reference_fixture(path):
+    """clip/model.py CLIP.encode_image / encode_text (both towers; BASELINE config 4) recorded from the
+    reference's own CLIP: the oracle in order="reference" mode reproduces features, per-layer lengths and the kept indices IN
+    the reference's order (torch.topk(sorted=False) on the same machine); order="ascending" - the HIP path's canonical order -
+    keeps the same SETS at the first pruned layer and differs afterwards only through the positional mask / read-out."""
+    g = np.load(path)
+    B, size, T, seed = int(g["B"]), int(g["size"]), float(g["temperature"]), int(g["seed"])
+    shapes = specs.clip_shapes(size)
+    W = specs.synth_weights(shapes, seed)
+    ref_keys = {str(k) for k in g["state_dict_keys"]}
+    assert set(shapes.keys()) <= ref_keys
+    assert all(k.endswith("_m") or "_m." in k or "queue" in k for k in ref_keys - set(shapes.keys()))  # training state only
+    images = synth.synth_images(B, size, seed)
+    text = synth.synth_clip_tokens(B, 77, seed, int(g["min_len"]), int(g["max_len"]))
+    assert text.argmax(-1).tolist() == g["eot_pos"].tolist()
+    vtr, ttr = [], []
+    with torch.no_grad():
+        fi, sdi = O.clip_encode_image(W, images, W["space_dict"], T, trace=vtr)
+        ft, sdt = O.clip_encode_text(W, text, W["space_dict"], T, order="reference", trace=ttr)
+    assert np.abs(fi.numpy() - g["image_features"]).max() < 1e-4
+    assert np.abs(ft.numpy() - g["text_features"]).max() < 1e-4
+    assert np.abs(sdt[:, :4, :16].numpy() - g["sd_txt_head"]).max() < 1e-3
+    for key, tr, lens in (("vit", vtr, g["vit_lens"]), ("txt", ttr, g["txt_lens"])):
+        for l, info in enumerate(tr):
+            if f"{key}{l}_idx" not in g.files:
+                assert not info["pruned"]
+                continue
+            assert info["pruned"] and info["k"] + 2 == lens[l]
+            if key == "txt":
+                assert (info["indices"].numpy() == g[f"txt{l}_idx"]).all()  # same order as the reference on this machine
+            else:
+                assert (np.sort(info["indices"].numpy(), 1) == np.sort(g[f"vit{l}_idx"], 1)).all()
+    atr = []
+    with torch.no_grad():
+        fa, _ = O.clip_encode_text(W, text, W["space_dict"], T, order="ascending", trace=atr)
+    first = next(l for l, info in enumerate(ttr) if info["pruned"])
+    assert (np.sort(atr[first]["indices"].numpy(), 1) == np.sort(g[f"txt{first}_idx"], 1)).all()
+    assert [i["k"] if i["pruned"] else None for i in atr][: first + 1] == [i["k"] if i["pruned"] else None for i in ttr][: first + 1]
+    assert torch.isfinite(fa).all()

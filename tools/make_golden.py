@@ -201,6 +201,44 @@ def clip_case(name, B, temperature, seed=0, size=224):
     print(f"[{name}] T={temperature} vit_lens={lens}")
 
 
+def clip_full_case(name, B, temperature, seed=0, size=224, min_len=6, max_len=40):
+    """clip/model.py CLIP (ViT-B/16 geometry, text width 512 / 8 heads / 12 layers / ctx 77): the reference's own
+    encode_image / encode_text (compress_retrieval_clip_dtp.py:92,100 call sites) with clip/mock.py's patched MHA."""
+    import clip.mock  # noqa: F401
+    import clip.model as cm
+    from madtp_amd import specs
+    model = cm.CLIP(512, size, 12, 768, 16, 77, 49408, 512, 8, 12, True, None)
+    model.eval()
+    sd = specs.synth_weights(specs.clip_shapes(size), seed)
+    msg = model.load_state_dict(sd, strict=False)
+    assert not msg.unexpected_keys, msg.unexpected_keys
+    assert all(k.endswith("_m") or "_m." in k or "queue" in k for k in msg.missing_keys), msg.missing_keys[:8]
+    images = synth.synth_images(B, size, seed)
+    text = synth.synth_clip_tokens(B, 77, seed, min_len, max_len)
+    tap = GatherTap(cm)
+    hooks, vlens, tlens = [], [], []
+    for i, blk in enumerate(model.visual.transformer.resblocks):
+        hooks.append(blk.register_forward_pre_hook(lambda m, a, i=i: tap.set_tag(f"vit{i}")))
+        hooks.append(blk.register_forward_hook(lambda m, a, o: vlens.append(o[0].shape[0])))
+    for i, blk in enumerate(model.transformer.resblocks):
+        hooks.append(blk.register_forward_pre_hook(lambda m, a, i=i: tap.set_tag(f"txt{i}")))
+        hooks.append(blk.register_forward_hook(lambda m, a, o: tlens.append(o[0].shape[0])))
+    with torch.no_grad():
+        img_feat, sd_img = model.encode_image(images, model.space_dict, temperature)
+        txt_feat, sd_txt = model.encode_text(text, model.space_dict, temperature)
+    for h in hooks:
+        h.remove()
+    tap.restore()
+    rec = {"kind": "clip_full", "B": B, "size": size, "temperature": np.float64(temperature), "seed": seed,
+           "min_len": min_len, "max_len": max_len, "vit_lens": np.array(vlens), "txt_lens": np.array(tlens),
+           "image_features": img_feat.numpy(), "text_features": txt_feat.numpy(), "eot_pos": text.argmax(-1).numpy(),
+           "sd_img_head": sd_img[:, :4, :16].numpy(), "sd_txt_head": sd_txt[:, :4, :16].numpy(),
+           "state_dict_keys": np.array(sorted(k for k in model.state_dict().keys()))}
+    rec.update(tap.records)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] T={temperature} vit_lens={vlens} txt_lens={tlens} eot={text.argmax(-1).tolist()}")
+
+
 def retrieval_case(name, n_img, img_bs, n_txt, size, temperature, k_test, seed=0):
     """compress_retrieval_dtp.py evaluate() - the reference's own function, imported behind the shims - on a synthetic
     evaluation set: text features (text mode), image features with the cross-batch CLS-repeat padding, similarity
@@ -252,6 +290,8 @@ CASES = {
     "med_text_b3": lambda: med_case("med_text_b3", 3, 35, 0, 30.0, "text", pad_tail=3),
     "med_mm_b3": lambda: med_case("med_mm_b3", 3, 35, 50, 30.0, "multimodal", pad_tail=3),
     "clip_vit_b2": lambda: clip_case("clip_vit_b2", 2, 4.0),
+    "clip_full_b3_T4": lambda: clip_full_case("clip_full_b3_T4", 3, 4.0),
+    "clip_full_b3_T40": lambda: clip_full_case("clip_full_b3_T40", 3, 40.0, seed=1),
     "vit384_b2": lambda: vit_case("vit384_b2", 2, 384, 6.0),
     "vit480_b1": lambda: vit_case("vit480_b1", 1, 480, 6.0),
     "retr_i6_t12": lambda: retrieval_case("retr_i6_t12", 6, 3, 12, 224, 6.0, 4),
