@@ -452,9 +452,10 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
             const int ldkv = ((br ? kv_pre1 : kv_pre0) && kv_ld) ? kv_ld : 2 * D;
             TRY(madtp_attention_indexed(s.q, kv, kv + (size_t)D * e, (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, cbuf[br], em,
                                         nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, D, ldkv, ldkv, D, w->scale, adt, stream));
-            if (dt == MADTP_F16S) {  // context f32 -> f16 planes for crossattention.output.dense (s.kv / s.kv1 are free now)
-                void* sp = br ? s.kv : s.kv1;  // (branch 1's K/V projection above reuses s.kv: branch 0's planes sit in s.kv1)
-                if ((size_t)M * D > (size_t)B * Nk * 2 * D) return MADTP_E_SHAPE;
+            if (dt == MADTP_F16S) {  // context f32 -> f16 planes for crossattention.output.dense, in s.mid (free until the FFN;
+                                     // hidden >= 2*dim, so both branches fit side by side)
+                if (w->inter.n < 2 * D) return MADTP_E_SHAPE;
+                void* sp = (char*)s.mid + (size_t)br * M * D * esz_of(dt);
                 TRY(to_lp((const float*)cbuf[br], D, sp, M, D, dt, stream));
                 cbuf[br] = sp;
             }

@@ -107,6 +107,16 @@ def blip_retrieval_shapes(img_size=384, embed_dim=256):
     return sd
 
 
+def blip_vqa_shapes(img_size=480):
+    """models/blip_vqa.py BLIP_VQA.__init__ :15-55, encoder side: space_dict, visual_encoder, text_encoder (the answer decoder
+    `text_decoder` of :53-55 is off the pruned encoder path)."""
+    sd = OrderedDict()
+    sd["space_dict"] = (SD_NUM, D)
+    sd.update(vit_shapes("visual_encoder.", img_size))
+    sd.update(bert_shapes("text_encoder.", "med"))
+    return sd
+
+
 def clip_vit_shapes(prefix="", img_size=224, patch=16, width=768, layers=12, out_dim=512, sd_dim=768):
     """clip/model.py VisionTransformer (:275-313) with ResidualAttentionBlock (:174-261); ViT-B/16 geometry."""
     sd = OrderedDict()

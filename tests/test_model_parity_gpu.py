@@ -375,3 +375,46 @@ def test_clip_both_towers(path, mode):
     cos_i = torch.nn.functional.cosine_similarity(ib.float(), fi.float(), dim=-1).min().item()
     print(f"CLIP bf16 vs {mode}: min cosine text {cos_t:.4f} image {cos_i:.4f}")
     assert cos_t > 0.98 and cos_i > 0.98
+
+
+VQA_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vqa*.npz")))
+
+
+@pytest.mark.parametrize("mode", EXACT_MODES)
+@pytest.mark.parametrize("path", VQA_CASES, ids=[os.path.basename(c)[:-4] for c in VQA_CASES])
+def test_vqa_encoder_leg_matches_reference_fixture(path, mode):
+    """BLIP_VQA mirror, encoder leg (models/blip_vqa.py:59-64,118-125; BASELINE config 5: 480^2 images = 901 visual tokens,
+    MED multimodal encoder over the pruned image tokens) vs the fixture recorded from the reference's modules: kept sets of both
+    encoders identical, question states within 1e-3."""
+    from madtp_amd import build, hip, harness, runtime, specs
+    from madtp_amd.blip_vqa import BLIP_VQA
+    from tests.test_oracle_golden import vqa_inputs
+    build.build(verbose=False)
+    hip.load()
+    g = np.load(path)
+    T, L = float(g["temperature"]), int(g["L"])
+    model = BLIP_VQA(image_size=int(g["size"]), evaluate=True)
+    msg = model.load_state_dict(specs.synth_weights(specs.blip_vqa_shapes(int(g["size"])), int(g["seed"])), strict=False)
+    assert not msg.unexpected_keys and all("query_model" in k or "position_ids" in k for k in msg.missing_keys), msg
+    model = model.eval().cuda()
+    images, ids, att = vqa_inputs(g)
+    with runtime.precision(mode), torch.no_grad():
+        hid = model(images.cuda(), {"input_ids": ids.cuda(), "attention_mask": att.cuda()}, temperature=T, train=False)
+
+    def traces(layers):
+        return [None if l.last_prune is None else {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in l.last_prune.items()}
+                for l in layers]
+    vtr, ttr = traces(model.visual_encoder.blocks), traces(model.text_encoder.encoder.layer)
+    assert list(hid.shape) == g["hidden_shape"].tolist()
+    assert harness.token_lengths(vtr, 901) == g["vit_lens"].tolist()
+    assert harness.token_lengths(ttr, L) == g["txt_lens"].tolist()
+    for key, tr, n0 in (("vit", vtr, 900), ("txt", ttr, L - 1)):
+        ref = [{"pruned": True, "indices": g[f"{key}{l}_idx"][:, : tr[l]["k"]]} if f"{key}{l}_idx" in g.files else None
+               for l in range(12)]
+        assert harness.compose_ids(tr, n0) == harness.compose_ids(ref, n0), key
+    assert np.abs(hid[:, 0, :32].cpu().numpy() - g["hidden_cls"]).max() < 1e-3
+    with runtime.precision("bf16"), torch.no_grad():
+        hb = model(images.cuda(), {"input_ids": ids.cuda(), "attention_mask": att.cuda()}, temperature=T, train=False)
+    cos = torch.nn.functional.cosine_similarity(hb[:, 0, :].float(), hid[:, 0, :].float(), dim=-1).min().item()
+    print(f"VQA bf16 vs {mode} CLS row: min cosine {cos:.4f}")
+    assert torch.isfinite(hb).all() and cos > 0.97  # measured 0.9996 (T=6) / 0.981 (T=30: 901 -> 11 image tokens)

@@ -237,3 +237,41 @@ def test_oracle_clip_full_matches_reference_fixture(path):
     assert (np.sort(atr[first]["indices"].numpy(), 1) == np.sort(g[f"txt{first}_idx"], 1)).all()
     assert [i["k"] if i["pruned"] else None for i in atr][: first + 1] == [i["k"] if i["pruned"] else None for i in ttr][: first + 1]
     assert torch.isfinite(fa).all()
+
+
+VQA_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vqa*.npz")))
+
+
+def vqa_inputs(g):
+    from madtp_amd import harness
+    B, size, L, seed = int(g["B"]), int(g["size"]), int(g["L"]), int(g["seed"])
+    images = synth.synth_images(B, size, seed)
+    ids = synth.synth_token_ids(B, L, seed, first_id=None)
+    att = harness.padded_mask(B, L, int(g["pad_tail"]))
+    return images, ids, att
+
+
+@pytest.mark.parametrize("path", VQA_CASES, ids=[os.path.basename(c)[:-4] for c in VQA_CASES])
+def test_oracle_vqa_encoder_matches_reference_fixture(path):
+    """models/blip_vqa.py BLIP_VQA encoder leg (BASELINE config 5: 480^2 = 901 visual tokens): ViT + MED multimodal encoder."""
+    g = np.load(path)
+    T = float(g["temperature"])
+    shapes = specs.blip_vqa_shapes(int(g["size"]))
+    keys = {str(k) for k in g["state_dict_keys"]}
+    assert set(shapes.keys()) <= keys and all("position_ids" in k for k in keys - set(shapes.keys()))
+    W = specs.synth_weights(shapes, int(g["seed"]))
+    images, ids, att = vqa_inputs(g)
+    tr = {}
+    with torch.no_grad():
+        hid = O.blip_vqa_encoder_forward(W, images, ids, att, T, trace=tr)
+    assert list(hid.shape) == g["hidden_shape"].tolist()
+    assert np.abs(hid[:, 0, :32].numpy() - g["hidden_cls"]).max() < 1e-4
+    assert np.abs(tr["image_embeds"][:, 0, :16].numpy() - g["img_embeds_cls"]).max() < 1e-4
+    for key, trace, lens, n0 in (("vit", tr["vit"], g["vit_lens"], 901), ("txt", tr["text"], g["txt_lens"], int(g["L"]))):
+        for l, info in enumerate(trace):
+            if f"{key}{l}_idx" not in g.files:
+                assert info is None or not info["pruned"]
+                continue
+            assert info["pruned"] and info["k"] + 2 == lens[l]
+            ref = g[f"{key}{l}_idx"][:, : info["k"]]
+            assert (np.sort(info["indices"].numpy(), 1) == np.sort(ref, 1)).all()

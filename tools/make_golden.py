@@ -101,6 +101,55 @@ def nlvr_case(name, B, size, L, temperature, seed=0, pad_tail=0):
           f"({dt:.2f}s)")
 
 
+def vqa_case(name, B, size, L, temperature, seed=0, pad_tail=0):
+    """models/blip_vqa.py BLIP_VQA, encoder leg of forward(train=False) (:59-64, :118-125): the reference's own visual_encoder
+    and text_encoder (MED, multimodal mode) called exactly as those lines do; the answer decoder that follows is out of scope."""
+    import models.blip_vqa as bv
+    import models.vit as rvit
+    import models.med as rmed
+    ref_shims.patch_tokenizer(bv)
+    model = bv.BLIP_VQA(image_size=size, evaluate=True, config={"sd_num": 100, "sd_dim": 768, "batch_size_train": 16})
+    model.eval()
+    sd = synth.fill_state_dict(model, seed)
+    model.load_state_dict(sd, strict=True)
+    images = synth.synth_images(B, size, seed)
+    ids = synth.synth_token_ids(B, L, seed, first_id=None)
+    from madtp_amd import harness
+    att = harness.padded_mask(B, L, pad_tail)
+    tap_v, tap_t = GatherTap(rvit), GatherTap(rmed)
+    hooks, lens_v, lens_t = [], [], []
+    for i, blk in enumerate(model.visual_encoder.blocks):
+        hooks.append(blk.register_forward_pre_hook(lambda m, a, i=i: tap_v.set_tag(f"vit{i}")))
+        hooks.append(blk.register_forward_hook(lambda m, a, o: lens_v.append(o.shape[1])))
+    for i, lay in enumerate(model.text_encoder.encoder.layer):
+        hooks.append(lay.register_forward_pre_hook(lambda m, a, i=i: tap_t.set_tag(f"txt{i}")))
+        hooks.append(lay.register_forward_hook(lambda m, a, o: lens_t.append(o[0].shape[1])))
+    t0 = time.time()
+    with torch.no_grad():
+        image_embeds, sd_img_ft = model.visual_encoder(images, space_dict=model.space_dict, temperature=temperature)  # :59
+        image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long)  # :60
+        q_ids = ids.clone()
+        q_ids[:, 0] = model.tokenizer.enc_token_id  # :64
+        question_output = model.text_encoder(q_ids, attention_mask=att, encoder_hidden_states=image_embeds,
+                                             encoder_attention_mask=image_atts, return_dict=True,
+                                             space_dict=model.space_dict, temperature=temperature)[0]  # :118-124
+    dt = time.time() - t0
+    for h in hooks:
+        h.remove()
+    tap_v.restore()
+    tap_t.restore()
+    hid = question_output.last_hidden_state
+    enc_keys = sorted(k for k in sd.keys() if not k.startswith("text_decoder."))
+    out = {"kind": "vqa", "B": B, "size": size, "L": L, "temperature": np.float64(temperature), "seed": seed, "pad_tail": pad_tail,
+           "vit_lens": np.array(lens_v), "txt_lens": np.array(lens_t), "hidden_cls": hid[:, 0, :32].numpy(),
+           "hidden_shape": np.array(hid.shape), "img_embeds_cls": image_embeds[:, 0, :16].numpy(),
+           "state_dict_keys": np.array(enc_keys), "ref_seconds": dt, "threads": torch.get_num_threads()}
+    out.update({k: v for k, v in tap_v.records.items() if k.endswith("_idx")})
+    out.update(tap_t.records)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[{name}] size={size} T={temperature} vit_lens={lens_v} txt_lens={lens_t} ({dt:.1f}s)")
+
+
 def med_case(name, B, L, Nimg, temperature, mode, seed=0, pad_tail=0):
     """models/med.py BertModel (MED) stand-alone: text mode / multimodal mode with synthetic image tokens and an
     optional padded tail in attention_mask (exercises med.py:388-390 mask compaction)."""
@@ -289,6 +338,8 @@ CASES = {
     "nlvr_b3_T30_pad": lambda: nlvr_case("nlvr_b3_T30_pad", 3, 224, 35, 30.0, pad_tail=3),
     "med_text_b3": lambda: med_case("med_text_b3", 3, 35, 0, 30.0, "text", pad_tail=3),
     "med_mm_b3": lambda: med_case("med_mm_b3", 3, 35, 50, 30.0, "multimodal", pad_tail=3),
+    "vqa480_b2": lambda: vqa_case("vqa480_b2", 2, 480, 20, 6.0, pad_tail=2),
+    "vqa480_b2_T30": lambda: vqa_case("vqa480_b2_T30", 2, 480, 35, 30.0, seed=2, pad_tail=4),
     "clip_vit_b2": lambda: clip_case("clip_vit_b2", 2, 4.0),
     "clip_full_b3_T4": lambda: clip_full_case("clip_full_b3_T4", 3, 4.0),
     "clip_full_b3_T40": lambda: clip_full_case("clip_full_b3_T40", 3, 40.0, seed=1),
