@@ -2,23 +2,31 @@
 """Headline benchmark: images/sec of the pruned BLIP-base NLVR2 forward (BLIP_NLVR.forward(train=False) dataflow,
 reference models/blip_nlvr.py:63-100) at p=0.5, 64 samples (= 128 images) per GPU, bf16 GEMM operands, on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W --precision bf16|fp32 --batch 64]
+    python bench.py [--gpus N --steps K --warmup W --precision bf16|f16x3|fp32 --config nlvr|retrieval|clip|vqa --batch B]
 
-N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`:
-one process per GPU, batch sharded data-parallel (each rank owns 64 whole samples - both images of a pair stay on
-one rank), weights replicated, NO collective inside the forward (the path has no exchange step, SURVEY.md 8(e));
-RCCL is used only for the barrier and the MAX-reduction of the elapsed time.  Scaling is therefore "weak".
+--config selects one of BASELINE.json's GPU configurations (madtp_amd/workloads.py); the default is the one the metric is
+quoted on (config 2, NLVR2 b64).  N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N ...`: one process per GPU, batch sharded data-parallel (whole samples per rank - both images of an NLVR
+pair stay on one rank), weights replicated, NO collective inside the forward (the path has no exchange step, SURVEY.md
+8(e)); RCCL is used only for the barrier and the MAX-reduction of the elapsed time.  Scaling is "weak" (retrieval, whose
+BASELINE batch of 128 is a global one, is split over the ranks: "strong").
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     - the dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs of every GEMM launch in the timed
-                 region / the sum of their durations, measured live with HIP events on the launch stream.
-  cpu_baseline - oracle/ (the CPU restatement of the reference forward, kind "port") timed on this box's host
-                 cores on a bounded sample of the same workload (rank 0, N=1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline     - the dominant kernel (the MFMA GEMM): algorithmic FLOPs of its launches in the timed region / the sum of their
+                 durations, measured live with HIP events on the launch stream; `traffic` = HBM bytes per launch from two
+                 rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that THIS run starts on a 1-step copy of itself.
+  parity_mode  - the same workload timed in the precision mode that carries the parity claim ("f16x3": fp32-accurate GEMMs
+                 on the f16 MFMA) + index_match of every mode vs the CPU oracle at the headline batch.
+  cpu_baseline - oracle/ (the CPU restatement of the reference forward, kind "port") timed on this box's host cores on a
+                 bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -30,39 +38,13 @@ sys.path.insert(0, ROOT)
 # roofline of the fp32-accurate GEMM in ALGORITHMIC flops (2MNK) is a third of the f16 dense peak.
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "f16x3": 2500.0 / 3.0}
 GEMM_DT = {"bf16": "bf16", "fp32": "f32", "f16x3": "f16s"}
-
-
-def load_calibration(batch, p=0.5):
-    from madtp_amd import configs
-    return configs.temperature_for("nlvr", batch, p)
+WS_MIN_M = 4096  # madtp_gemm runs 2-byte-operand problems with M >= 4096 (and no split-K) on gemm_ws_kernel (csrc/gemm.hip)
+METRIC = "images/sec forward, BLIP-base NLVR2 p=0.5 b64; pruned-token index match"
 
 
 def gemm_summary(rows, dtype, min_m=0):
     sel = [r for r in rows if r["dtype"] == dtype and r["M"] >= min_m]
     return sum(r["ms"] for r in sel), sum(r["flops"] for r in sel), sum(r["launches"] for r in sel)
-
-
-WS_MIN_M = 4096  # madtp_gemm runs bf16 problems with M >= 4096 (and no split-K) on gemm_ws_kernel (csrc/gemm.hip)
-
-
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (collected and corrected
-    as MI355X_MICROARCH.md prescribes: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled on gfx950); produced
-    by tools/rocpd_pmc.py, see profiles/.  None when no such file is present."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_gemm_bf16.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        d = json.load(f)
-    # traffic of the dominant kernel alone: launch-weighted over gemm_ws_kernel<true> / <false>
-    fk = {k: v for k, v in d.get("per_kernel_fetch", {}).items() if "gemm_ws_kernel" in k}
-    wk = {k: v for k, v in d.get("per_kernel_write", {}).items() if "gemm_ws_kernel" in k}
-    n = sum(v["launches"] for v in fk.values())
-    if n:
-        fetch = sum(v["launches"] * v["kib_per_launch"] for v in fk.values()) / n
-        write = sum(v["launches"] * v["kib_per_launch"] for v in wk.values()) / max(1, sum(v["launches"] for v in wk.values()))
-        d["ws_hbm_bytes_per_launch"] = int((2 * fetch + write) * 1024)
-    return d
 
 
 def gemm_breakdown(rows, steps):
@@ -73,15 +55,62 @@ def gemm_breakdown(rows, steps):
     return "\n".join(out)
 
 
+def measure_traffic(args):
+    """HBM-side bytes per launch of the dominant kernel (gemm_ws_kernel), collected as MI355X_MICROARCH.md prescribes:
+    FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --pmc X --kernel-trace` passes over a 1-step run of this very command,
+    FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of 16-B/lane streams at 64 B; tools/pmc_calibrate.py confirmed the
+    factor for this kernel's access pattern in round 1).  -> dict or None (no rocprofv3 / a pass failed)."""
+    import sqlite3
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="madtp_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--config", args.config, "--precision", args.precision, "--steps", "1", "--warmup", "1", "--traffic", "off",
+                   "--no-cpu-baseline", "--no-parity", "--no-gemm-events"] + (["--batch", str(args.batch)] if args.batch else [])
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
+            if r.returncode != 0 or not dbs:
+                return None
+            c = sqlite3.connect(dbs[0])
+            rows = c.execute("select name, count(*), sum(counter_value) from pmc_events where counter_name=? group by name",
+                             (counter,)).fetchall()
+            n = sum(cnt for name, cnt, _ in rows if "gemm_ws_kernel" in name)
+            v = sum(val for name, _, val in rows if "gemm_ws_kernel" in name)
+            if not n:
+                return None
+            out[counter] = (n, v * 1024.0 / n)  # the counters are in KiB
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    f_n, f_b = out["FETCH_SIZE"]
+    w_n, w_b = out["WRITE_SIZE"]
+    return {"bytes_per_launch": int(2 * f_b + w_b), "fetch_size_raw_bytes_per_launch": int(f_b),
+            "write_size_bytes_per_launch": int(w_b), "launches_profiled": f_n,
+            "how": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace (separate passes) over a 1-step copy of the "
+                   "command, gemm_ws_kernel launches only; 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md)"}
+
+
 def main():
+    from madtp_amd import workloads
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3"])
+    ap.add_argument("--config", default="nlvr", choices=list(workloads.NAMES),
+                    help="BASELINE.json configuration (default: the headline)")
+    ap.add_argument("--batch", type=int, default=0, help="samples per GPU (0 = the configuration's BASELINE batch)")
+    ap.add_argument("--image-size", type=int, default=0, help="retrieval only: 224 (default) or 384")
     ap.add_argument("--parity-steps", type=int, default=10, help="timed steps of the parity_mode leg (f16x3 precision)")
-    ap.add_argument("--parity-batch", type=int, default=0, help="samples of the index_match check (0 = --batch)")
-    ap.add_argument("--batch", type=int, default=64, help="NLVR samples per GPU (2 images each)")
+    ap.add_argument("--parity-batch", type=int, default=0, help="samples of the index_match check (0 = --batch for nlvr, 8 else)")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "off"], help="roofline.traffic from live rocprofv3 --pmc passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
@@ -96,7 +125,7 @@ def main():
     mdist.init("nccl")  # "nccl" is RCCL on ROCm; no-op for a single process
     dist = torch.distributed if world > 1 else None
 
-    from madtp_amd import build, harness, hip, runtime
+    from madtp_amd import build, configs, hip, runtime
     if rank == 0:  # one builder per node (the prebuilt .so normally travels with the snapshot: no-op); the others wait
         build.build(verbose=False)
     if dist is not None:
@@ -105,12 +134,15 @@ def main():
     runtime.set_precision(args.precision)
     prof_rows = []
 
-    T, calib = load_calibration(args.batch, 0.5)
-    model = harness.build_nlvr(224, 0, "cuda")
-    images, text, targets = harness.nlvr_inputs(args.batch, 224, 20, seed=rank)  # resident in HBM before timing
+    w = workloads.get(args.config, **({"size": args.image_size} if (args.image_size and args.config == "retrieval") else {}))
+    strong = args.config == "retrieval" and not args.batch  # BASELINE config 3: a GLOBAL batch of 128 over the ranks
+    B = args.batch or (max(1, w.default_batch // world) if strong else w.default_batch)
+    T, calib = configs.temperature_for(args.config, args.batch or w.default_batch, w.p)
+    model = w.build("cuda")
+    inp = w.inputs(B, seed=rank)  # resident in HBM before timing
 
     def step():
-        return model(images, text, targets, temperature=T, train=False)
+        return w.step(model, inp, T)
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -121,12 +153,13 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            logits = step()
+            step()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        lens = w.lens(model)
         # Roofline leg: the SAME K steps once more with a HIP event pair around every madtp_gemm launch (recorded by
         # the library on the launch stream).  Kept out of the `value` region because ~180 event pairs per step
         # perturb it by ~10 % (measured); its own wall time is reported as instrumented_ms_per_step.
@@ -141,13 +174,9 @@ def main():
             prof_rows = hip.profile_end()
     elapsed = mdist.max_over_ranks(elapsed, device="cuda")
 
-    images_per_step = 2 * args.batch * world
+    images_per_step = w.images_per_sample * B * world
     value = images_per_step * args.steps / elapsed
-    _, trace = harness.run_nlvr(model, images, text, targets, T)
-    vit_lens = harness.token_lengths(trace["vit"], 197)
-    txt_lens = harness.token_lengths(trace["text"], 20)
-    flops_sample = harness.nlvr_forward_flops(vit_lens, txt_lens)
-    flops_full = harness.nlvr_forward_flops([197] * 12, [20] * 12)
+    flops_sample, flops_full = w.flops(lens), w.flops(None)
 
     roof = None
     if not args.no_gemm_events:
@@ -159,15 +188,17 @@ def main():
         if ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
-            pmc = pmc_traffic() if args.precision == "bf16" else None
             alg_bytes = sum(r["bytes"] for r in prof_rows if r["dtype"] == dt_name and r["M"] >= min_m)
             kname = {"bf16": "gemm_ws_kernel (all bf16 madtp_gemm launches with M >= 4096: ViT qkv/proj/fc1/fc2, cross-attention K/V)",
                      "f16x3": "gemm_ws_kernel<f16-split> (all madtp_gemm launches with M >= 4096; 3 f16 MFMA products per "
                               "logical product: achieved/peak are in algorithmic 2MNK flops, peak = f16 dense / 3)",
                      "fp32": "gemm_kernel<float> (madtp_gemm)"}[args.precision]
+            traffic = None
+            if args.traffic == "auto" and rank == 0 and world == 1 and args.precision != "fp32":
+                traffic = measure_traffic(args)
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1),
-                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": pmc.get("ws_hbm_bytes_per_launch") if pmc else None,
+                    "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
                     "algorithmic_bytes_per_launch": round(alg_bytes / cnt),
                     "launches_per_step": cnt // args.steps, "kernel_ms_per_step": round(ms / args.steps, 3),
                     "avg_launch_us": round(1e3 * ms / cnt, 2), "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
@@ -177,21 +208,22 @@ def main():
                                           "launches_per_step": cnt_all // args.steps,
                                           "ms_per_step": round(ms_all / args.steps, 3)}}
 
+    headline = args.config == "nlvr"
     out = {
-        "metric": "images/sec forward, BLIP-base NLVR2 p=0.5 b64; pruned-token index match",
+        "metric": METRIC if headline else f"images/sec forward, {args.config} configuration of BASELINE.json (p={w.p})",
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32", "f16x3": "f16x3 (fp32-accurate)"}[args.precision],
         "data": "synthetic",
-        "config": {"workload": "BLIP-base NLVR2 forward (BLIP_NLVR.forward(train=False)), p=0.5, 64 samples = 128 "
-                               "images 224x224 + 20 text tokens per GPU, random-init weights",
-                   "samples_per_gpu": args.batch, "images_per_gpu": 2 * args.batch, "temperature": T,
-                   "flops_ratio_vs_unpruned": round(flops_sample / flops_full, 4), "vit_tokens_per_layer": vit_lens,
-                   "text_tokens_per_layer": txt_lens, "parallelism": f"dp{world}"},
-        "samples_per_s": round(value / 2, 1),
-        "model_tflops": round(flops_sample * args.batch * world * args.steps / elapsed / 1e12, 1),
+        "config": {"workload": w.describe(B), "samples_per_gpu": B, "images_per_gpu": w.images_per_sample * B, "temperature": T,
+                   "p": w.p, "flops_ratio_vs_unpruned": round(flops_sample / flops_full, 4),
+                   "tokens_per_layer": lens, "calibrated_at_batch": calib.get("batch"), "parallelism": f"dp{world}"},
+        "samples_per_s": round(value / w.images_per_sample, 1),
+        "model_tflops": round(flops_sample * B * world * args.steps / elapsed / 1e12, 1),
         "roofline": roof,
     }
+    if headline:  # keys of the round-1 line, kept for the driver's records
+        out["config"]["vit_tokens_per_layer"], out["config"]["text_tokens_per_layer"] = lens["vit"], lens["text"]
 
     if not args.no_parity:
         # parity_mode leg: the SAME workload timed in the precision mode that carries the parity claim (f16x3: fp32-accurate
@@ -218,12 +250,17 @@ def main():
                                       "attention / LayerNorm / scores on the exact-f32 kernels; kept sets vs the oracle below"}
     if rank == 0 and world == 1:
         if not args.no_parity:
-            im = parity_report(model, harness, runtime, T, args.precision, B=args.parity_batch or args.batch)
+            modes = sorted({"fp32", "f16x3", args.precision})
+            if headline:
+                from tests.parity_util import nlvr_index_match
+                im = nlvr_index_match(model, T, modes, B=args.parity_batch or B, seed=11)
+            else:
+                im = generic_index_match(w, model, args.config, T, modes, args.parity_batch or 8)
             out["index_match"] = im
             out["parity_mode"]["index_match"] = im.get("f16x3")
             out["parity_mode"]["index_match_batch"] = im["batch"]
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(T)
+            out["cpu_baseline"] = cpu_baseline(args.config, w, T)
     if rank == 0 and args.gemm_breakdown and not args.no_gemm_events:
         print(gemm_breakdown(prof_rows, args.steps), file=sys.stderr, flush=True)
     if rank == 0:
@@ -233,34 +270,52 @@ def main():
         dist.destroy_process_group()
 
 
-def parity_report(model, harness, runtime, T, precision, B=64, seed=11):
-    """kept-token index match of the timed precision mode, the f16x3 mode and the fp32 mode vs the CPU oracle at the
-    HEADLINE batch (k = max_b count couples the samples of a batch, so a smaller batch is a different computation;
-    the oracle is the checker here, never the thing measured)."""
-    from tests.parity_util import nlvr_index_match
-    return nlvr_index_match(model, T, sorted({"fp32", "f16x3", precision}), B=B, seed=seed)
+def _flat(o):
+    if torch.is_tensor(o):
+        return [o.detach().float().cpu()]
+    return [t for x in o for t in _flat(x)]
 
 
-def cpu_baseline(T, B=8, budget_s=12.0):
+def generic_index_match(w, model, name, T, modes, B, seed=11):
+    """per-layer token counts and outputs of every precision mode vs the CPU oracle on B samples (the oracle is the checker
+    here; kept-SET equality per layer is asserted by the -m gpu tests on the reference fixtures)."""
+    from madtp_amd import runtime
+    from oracle import workloads as OW
+    size = getattr(w, "size", 224)
+    W = OW.weights(name, size)
+    t0 = time.perf_counter()
+    ref_out, ref_lens = OW.forward(name, W, B, T, seed, size)
+    rep = {"batch": B, "temperature": T, "oracle": "oracle/workloads.py -> oracle/madtp_oracle.py (CPU fp32 restatement)",
+           "oracle_forward_s": round(time.perf_counter() - t0, 2), "oracle_tokens_per_layer": ref_lens}
+    inp = w.inputs(B, seed)
+    for mode in modes:
+        with runtime.precision(mode), torch.no_grad():
+            out = w.step(model, inp, T)
+            lens = w.lens(model)
+        same = all(lens[k] == ref_lens[k] for k in lens)
+        outs, refs = _flat(out), _flat(ref_out)
+        err = max((a - b).abs().max().item() for a, b in zip(outs, refs)) if all(a.shape == b.shape for a, b in zip(outs, refs)) else None
+        rep[mode] = {"tokens_per_layer_equal": same, "max_abs_dout": None if err is None else round(err, 6)}
+    return rep
+
+
+def cpu_baseline(name, w, T, budget_s=12.0):
     """The CPU oracle (a port of the reference forward; the reference itself cannot travel to this box) timed on the
-    host cores: B=8 samples (16 images) of the same synthetic workload, repeated for ~budget_s seconds."""
-    from madtp_amd import specs, synth
-    from oracle import madtp_oracle as O
-    W = specs.synth_weights(specs.blip_nlvr_shapes(224), 0)
-    images = synth.synth_images(2 * B, 224, 0)
-    ids = synth.synth_token_ids(B, 20, 0)
-    att = torch.ones_like(ids)
-    with torch.no_grad():
-        O.blip_nlvr_forward(W, images, ids, att, T)  # warm-up
-        n, t0 = 0, time.perf_counter()
-        while True:
-            O.blip_nlvr_forward(W, images, ids, att, T)
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt > budget_s or n >= 50:
-                break
-    return {"value": round(2 * B * n / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} forwards of {B} samples ({2 * B} images 224x224 + 20 tokens), same weights/temperature, "
+    host cores: a small batch of the same synthetic workload, repeated for ~budget_s seconds."""
+    from oracle import workloads as OW
+    B = {"nlvr": 8, "retrieval": 8, "clip": 8, "vqa": 2}[name]
+    size = getattr(w, "size", 224)
+    W = OW.weights(name, size)
+    OW.forward(name, W, B, T, 0, size)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        OW.forward(name, W, B, T, 0, size)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    return {"value": round(w.images_per_sample * B * n / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} forwards of {B} samples ({w.images_per_sample * B} images) of the same workload, same weights/temperature, "
                       f"PyTorch CPU eager fp32 via oracle/madtp_oracle.py, {dt:.1f}s",
             "host_cpus": os.cpu_count()}
 
