@@ -868,6 +868,248 @@ int launch_attn_large(const AttnArgs& a, hipStream_t s) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 fast-mode kernel for long sequences (256 < Nk <= 1024).  Same two passes per head as attn_large_kernel (the head-max
+// of the NORMALISED probabilities needs a row's final max / sum before any probability can be compared across heads), but
+//   * S^T = K Q^T and O^T = V^T P^T run on the bf16 MFMA with the register layouts of attn_bf16_kernel (swapped products:
+//     a lane owns one query row, the softmax reductions are in-lane + two permlane steps, P feeds P.V without leaving the lane,
+//     V is consumed with ds_read_b64_tr_b16);
+//   * the 128-key chunks of K (pass A) and K|V (pass B) stream through a 2-stage LDS ring by LDS-DMA: the chunk after the
+//     current one - across pass and head boundaries - is in flight while the current one is computed, one barrier per chunk;
+//   * exp via v_exp_f32, one reciprocal per row.
+// The head-max stays in registers for all key tiles (NT x 4 floats per lane: 160 at 577 keys, 228 at 901), one wave per SIMD.
+// Work per (b, h): 6 Nq Nk 64 flop (Q K^T twice) on the bf16 MFMA; the bound is the VALU softmax work (2 exp per score).
+template <int NCH, bool SCORES>
+__global__ __launch_bounds__(256, 1) void attn_bf16_large_kernel(AttnArgs a) {
+    constexpr int CK = 128;                   // keys per chunk
+    constexpr int STAGE = 2 * CK * 128;       // K image (128-byte rows), then V image
+    constexpr int NT = NCH * 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int bkv = a.kvidx ? a.kvidx[b] : b;
+    const int rt = blockIdx.x * 4 + wave;
+    const int i0 = rt * 16;
+    const bool active = i0 < a.Nq;
+    const int irow = min(i0 + l16, a.Nq - 1);
+    const int nch = (a.Nk + CK - 1) / CK;
+
+    f32x4 pmax[SCORES ? NT : 1];
+    if constexpr (SCORES) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pmax[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // LDS-DMA of one chunk: 16 K and 16 V instructions of 8 rows (1 KiB) each, 4 + 4 per wave.  Swizzles on the SOURCE address
+    // as in attn_bf16_kernel: K chunk ^= row & 7, V chunk ^= 2 * ((row >> 1) & 3).  Rows >= Nk are clamped (their P is 0).
+    const int sub = lane >> 3, pos = lane & 7;
+    int lrow[4], koff[4], voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + sub;
+        lrow[i] = r;
+        koff[i] = (pos ^ (r & 7)) << 4;
+        voff[i] = (pos ^ (((r >> 1) & 3) << 1)) << 4;
+    }
+    auto stage = [&](int h, int c, bool with_v, int st) {
+        char* base = smem + st * STAGE + wave * 4 * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = min(c * CK + lrow[i], a.Nk - 1);
+            const size_t grow = (size_t)bkv * a.Nk + row;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a.k + (grow * a.ldk + h * 64) * 2 + koff[i]), LDS_PTR(base + i * 1024), 16, 0, 0);
+            if (with_v)
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a.v + (grow * a.ldv + h * 64) * 2 + voff[i]),
+                                                 LDS_PTR(base + CK * 128 + i * 1024), 16, 0, 0);
+        }
+    };
+    // S^T of one chunk (8 key tiles), scaled and masked; keys >= Nk -> -inf
+    auto scores = [&](const char* Ks, int c, const bf16x8 (&q)[2], f32x4 (&sc)[8]) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = 16 * t + l16;
+            const bf16x8 k0 = *(const bf16x8*)(Ks + row * 128 + (((0 + g) ^ (row & 7)) << 4));
+            const bf16x8 k1 = *(const bf16x8*)(Ks + row * 128 + (((4 + g) ^ (row & 7)) << 4));
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q[0], acc, 0, 0, 0);
+            sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q[1], acc, 0, 0, 0);
+        }
+        const int jb = c * CK + 4 * g;
+        if (a.mask) {
+            const float* mrow = a.mask + (size_t)b * a.Nk;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jb + 16 * t + r;
+                    sc[t][r] = j < a.Nk ? fmaf(sc[t][r], a.scale, mrow[j]) : -INFINITY;
+                }
+        } else if ((c + 1) * CK <= a.Nk) {  // full chunk: no bounds
+#pragma unroll
+            for (int t = 0; t < 8; ++t) sc[t] *= a.scale;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[t][r] = (jb + 16 * t + r) < a.Nk ? sc[t][r] * a.scale : -INFINITY;
+        }
+    };
+
+    const int hstep = gridDim.z;
+    int st = 0;
+    if ((int)blockIdx.z < a.H) stage(blockIdx.z, 0, false, 0);
+    for (int h = blockIdx.z; h < a.H; h += hstep) {
+        bf16x8 q[2];
+        {
+            const char* qp = a.q + (((size_t)b * a.Nq + irow) * a.ldq + h * 64) * 2 + g * 16;
+            q[0] = *(const bf16x8*)qp;
+            q[1] = *(const bf16x8*)(qp + 64);
+        }
+        // ---- pass A: row maximum and sum over all keys (online, exact at the end) ----
+        float m = -INFINITY, l = 0.f;
+#pragma nounroll
+        for (int c = 0; c < nch; ++c, st ^= 1) {
+            __syncthreads();  // chunk c landed (the barrier drains the DMA); the other stage is free again
+            if (c + 1 < nch) stage(h, c + 1, false, st ^ 1);
+            else stage(h, 0, true, st ^ 1);
+            if (!active) continue;
+            f32x4 sc[8];
+            scores(smem + st * STAGE, c, q, sc);
+            float cm = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cm = fmaxf(cm, sc[t][r]);
+            cm = rows4_max(cm);
+            const float mn = fmaxf(m, cm);  // chunk 0 always holds a valid key, so mn is finite
+            float cs = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs += __expf(sc[t][r] - mn);
+            cs = rows4_sum(cs);
+            l = l * __expf(m - mn) + cs;
+            m = mn;
+        }
+        const float inv = __builtin_amdgcn_rcpf(l);
+        // ---- pass B: probabilities, head-max, CLS row, P.V ----
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
+        for (int c = 0; c < nch; ++c, st ^= 1) {  // (a runtime loop: unrolled, the per-chunk DMA addresses get hoisted and spilled)
+            __syncthreads();
+            if (c + 1 < nch) stage(h, c + 1, true, st ^ 1);
+            else if (h + hstep < a.H) stage(h + hstep, 0, false, st ^ 1);
+            if (!active) continue;
+            const char* Ks = smem + st * STAGE;
+            const char* Vs = Ks + CK * 128;
+            f32x4 sc[8];
+            scores(Ks, c, q, sc);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[t][r] = __expf(sc[t][r] - m) * inv;
+            if constexpr (SCORES) {
+                // head-max of this chunk's 8 key tiles: pmax is indexed statically (registers), so the chunk selects a case
+#define PM_CASE(C)                                                                                      \
+    case C:                                                                                             \
+        if constexpr (C < NCH) {                                                                        \
+            _Pragma("unroll") for (int t = 0; t < 8; ++t)                                               \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r)                                           \
+                    pmax[(C < NCH ? C : 0) * 8 + t][r] = fmaxf(pmax[(C < NCH ? C : 0) * 8 + t][r], sc[t][r]); \
+        }                                                                                               \
+        break;
+                switch (c) { PM_CASE(0) PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7) default: break; }
+#undef PM_CASE
+                if (i0 == 0) {  // wave-uniform: the wave that owns query row 0
+                    if (l16 == 0) {
+                        float* dst = a.p0 + ((size_t)b * a.H + h) * a.Nk;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int j = c * CK + 16 * t + 4 * g + r;
+                                if (j < a.Nk) dst[j] = sc[t][r];
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {  // 32-key sub-chunks: key(k-slot group g, e) = 32cc + 16(e>>2) + 4g + (e&3)
+                const bf16x8 pa = pack_bf16x8(sc[2 * cc], sc[2 * cc + 1]);
+                const int vrow = 32 * cc + 4 * g + (l16 >> 2);
+                const int vkey = ((vrow >> 1) & 3) << 1;
+                const char* vr = Vs + vrow * 128 + 8 * (l16 & 1);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int p = ((2 * dt + ((l16 & 3) >> 1)) ^ vkey) << 4;
+                    const bf16x8 vb = cat_bf16x4(lds_read_tr16(vr + p), lds_read_tr16(vr + 16 * 128 + p));
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, o[dt], 0, 0, 0);  // O^T: row d = 4g+r, col i
+                }
+            }
+        }
+        if (active) {  // lane (i = l16, g) holds columns h*64 + 16dt + 4g .. +3 of row i
+            const int i = i0 + l16;
+            float n2 = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) n2 += o[dt][r] * o[dt][r];
+            if constexpr (SCORES) n2 = rows4_sum(n2);
+            if (i < a.Nq) {
+                bf16_t* orow = (bf16_t*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 2) + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + dt * 16) = pack_bf16x4(o[dt]);
+                if constexpr (SCORES)
+                    if (g == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
+            }
+        }
+    }
+    if constexpr (SCORES) {
+        if (active) {
+            const int i = i0 + l16;
+            const bool valid = i >= 1 && i < a.Nq;
+            float* dst = a.colsum + ((size_t)b * a.nrt + rt) * a.Nk;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = row16_sum(valid ? pmax[t][r] : 0.f);
+                    const int j = 16 * t + 4 * g + r;
+                    if (l16 == 0 && j < a.Nk) dst[j] = v;
+                }
+        }
+    }
+}
+
+template <int NCH, bool SCORES>
+int launch_attn_bf16_large(const AttnArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * 2 * 128 * 128;  // two stages of K|V chunk images
+    MADTP_ENSURE_MAX_LDS((attn_bf16_large_kernel<NCH, SCORES>), lds);
+    int gz = 1;
+    if (!SCORES) {  // cross-attention against a long image sequence: few query rows, spread the heads over workgroups
+        const int wgs = ((a.Nq + 63) / 64) * a.B;
+        gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
+        if (gz > a.H) gz = a.H;
+    }
+    hipLaunchKernelGGL((attn_bf16_large_kernel<NCH, SCORES>), dim3((a.Nq + 63) / 64, a.B, gz), dim3(256), lds, s, a);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool SCORES>
+int dispatch_bf16_large(const AttnArgs& a, hipStream_t s) {
+    const int nch = (a.Nk + 127) / 128;
+    if (nch <= 3) return launch_attn_bf16_large<3, SCORES>(a, s);
+    if (nch <= 5) return launch_attn_bf16_large<5, SCORES>(a, s);
+    if (nch <= 8) return launch_attn_bf16_large<8, SCORES>(a, s);
+    return MADTP_E_SHAPE;
+}
+
 template <typename T, bool SCORES>
 int dispatch_large(const AttnArgs& a, hipStream_t s) {
     const int nch = (a.Nk + 127) / 128;
@@ -958,9 +1200,12 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
     a.mask_qk = mask_qk; a.ld_mqk = ld_mask_qk;
     hipStream_t s = (hipStream_t)stream;
     const bool scores = colsum_part != nullptr;
-    if (Nk > 256) {  // long sequences (384^2 / 480^2 images): two-pass kernel, exact-f32 MFMA in both modes
+    if (Nk > 256) {  // long sequences (384^2 / 480^2 images): two-pass kernels
         if (io_dtype == MADTP_F32) return scores ? dispatch_large<float, true>(a, s) : dispatch_large<float, false>(a, s);
-        return scores ? dispatch_large<bf16_t, true>(a, s) : dispatch_large<bf16_t, false>(a, s);
+        static int large_env = -1;  // MADTP_ATTN_LARGE_F32=1: bf16 storage on the exact-f32 MFMA kernel (A/B runs)
+        if (large_env < 0) { const char* e = getenv("MADTP_ATTN_LARGE_F32"); large_env = e ? atoi(e) : 0; }
+        if (large_env) return scores ? dispatch_large<bf16_t, true>(a, s) : dispatch_large<bf16_t, false>(a, s);
+        return scores ? dispatch_bf16_large<true>(a, s) : dispatch_bf16_large<false>(a, s);  // fast mode: bf16 MFMA, LDS-DMA ring
     }
     if (io_dtype == MADTP_F32) return scores ? dispatch_nt<float, true>(a, s) : dispatch_nt<float, false>(a, s);
     if ((ldk * 2) % 16 || (ldv * 2) % 16) return MADTP_E_ALIGN;
