@@ -57,6 +57,13 @@ int madtp_gemm(const void* A, const void* W, const float* bias, const float* res
                int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                int ab_dtype, int c_dtype, int act, float acc_scale, float out_scale, void* stream);
 
+/* Benchmark / test hook: force the tile configuration of the following madtp_gemm launches of this process (0 = automatic
+ * dispatch (default), 1..4 = the 128x128 / 64x128 / 64x128x3 / 64x64 kernels, 5 = the wave-specialised 256x128 kernel,
+ * 6 = the 256x256 kernel; a configuration that cannot take a problem falls back to the automatic choice).  The environment
+ * variable MADTP_GEMM_CFG sets the initial value.  No reference counterpart (the reference has one GEMM: aten::addmm).
+ * Returns the previous value. */
+int madtp_gemm_set_config(int cfg);
+
 /* Split-K form for small-M projections (latency-bound at one workgroup per tile): part[s,M,N] (f32, contiguous) holds
  * the partial product of K range s; madtp_splitk_ln then computes
  *   y = LayerNorm(scale * (sum_s part[s] + bias) + residual)          (med.py:246-250,326-328; nlvr_encoder.py:259-271)

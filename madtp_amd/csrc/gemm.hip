@@ -147,13 +147,13 @@ __device__ __forceinline__ float epi_act(float v) {
 //             -> fragments (2jp, 2jp+1) give 8 consecutive columns = one 16-byte store, 64 B per row/instr
 // (which W row feeds which fragment row is only the LDS row a lane reads - free to choose.)
 template <bool LP_OUT>
-__device__ __forceinline__ int wfrag_row(int j, int rho) {
+__host__ __device__ __forceinline__ constexpr int wfrag_row(int j, int rho) {
     return LP_OUT ? 32 * (j >> 1) + 8 * (rho >> 2) + 4 * (j & 1) + (rho & 3) : 16 * j + rho;
 }
 
 // HAS_RES: the residual is read by the epilogue itself (kernels that do not prefetch it into `res`); compile-time so
 // that the fast path below is straight-line code.
-template <int OM, int ACT, bool HAS_RES, int FM, int FN, int BM, int BN, int RM, int RN>
+template <int OM, int ACT, bool HAS_RES, int FM, int FN, int BM, int BN, bool FAST_ONLY = false, int RM = 1, int RN = 1>
 __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[FM][FN], const f32x4 (&res)[RM][RN],
                                          int m0, int n0, int wr, int wc, int l16, int grp4, size_t c_off) {
     constexpr bool LP_OUT = OM != OM_F32;    // 8-consecutive-column fragment layout (wfrag_row<true>)
@@ -161,7 +161,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[F
     const bool c_bf16 = g.ldc < 0;
     const int ldc = c_bf16 ? -g.ldc : g.ldc;
             const int col_w = n0 + wc * (BN / 2);
-            if (g.fast_epi) {
+            if (FAST_ONLY || g.fast_epi) {
                 // The fast path is STRAIGHT-LINE code with every load (bias, residual) issued before the first store.
                 // gfx950 counts loads and stores in one in-order vmcnt and the compiler's s_waitcnt insertion is
                 // conservative at control-flow merges: with the old per-vector `if (row < M) { load residual; store }`
@@ -252,7 +252,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[F
                         }
                     }
                 }
-            } else {
+            } else if constexpr (!FAST_ONLY) {
                 // generic fallback (N or a leading dimension not a multiple of 8 elements, e.g. the 2-logit head)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
@@ -794,6 +794,181 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
 #undef MADTP_WS_MFMA
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 256x256 bf16 kernel ("sq"): one 512-thread workgroup per CU = 8 waves as 2 (M) x 4 (N), 128x64 outputs per wave
+// (8 x 4 MFMA 16x16x32 fragments = 128 f32 accumulators per lane), K walked in 64-deep slabs of 256 A rows + 256 W rows
+// (64 KiB) through a TWO-stage LDS ring.  Why next to the 256x128 wave-specialised kernel:
+//   * L2 -> LDS bytes per flop drop by a quarter (the 256x128 kernel's LDS-DMA stream alone needs as long as its MFMA
+//     stream: ~23 TB/s of L2 bandwidth chip-wide), LDS fragment reads per flop by a quarter as well (wave tile 128x64
+//     instead of 64x64);
+//   * the ViT shapes of the forward (M = 10.5k-25k rows, N = 768 / 2304 / 3072) quantise far better: N = 768 is 3 column
+//     tiles, so everything up to 21.7k rows is ONE round on 256 CUs where the 256x128 tiling needs two.
+// Every wave both loads and computes: per slab each wave issues 8 LDS-DMA instructions (buffer_load_dwordx4 ... lds: the
+// per-lane row offset in a VGPR, the K offset in an SGPR, rows past M dropped by the descriptor) for slab s+1 right after
+// barrier s, then runs 4 sub-phases of 16 MFMAs (k-step x 64-row half) whose fragment reads are issued one sub-phase
+// ahead; the last sub-phase of slab s executes after barrier s+1 from registers, under the first fragment reads of slab
+// s+1, so no ds_read latency is exposed at the barrier.  One s_barrier per slab; the only vmcnt wait sits at the END of a
+// slab (the DMA of the next slab was issued a whole slab earlier; a tile's output stores are a whole slab old as well).
+// MADTP_SQ_ABLATE (timing experiments only, results are wrong): bit 0 drops the steady-state LDS-DMA, bit 1 the MFMAs, bit 2 the
+// steady-state fragment reads.
+#ifndef MADTP_SQ_ABLATE
+#define MADTP_SQ_ABLATE 0
+#endif
+template <int OM>
+__global__ __launch_bounds__(512, 2) void gemm_sq_kernel(GemmArgs g) {
+    constexpr bool LP_OUT = OM != OM_F32;
+    constexpr int BM = 256, BN = 256, A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, gl = gridDim.x >> 3;
+    int t0, nslots;
+    xcd_tiles(g.ntm * g.ntn, xcd, t0, nslots);
+    if (lb >= nslots) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l16 = lane & 15, grp4 = lane >> 4;
+    const int nk = g.K / 64;
+    const int my_slots = (nslots - lb + gl - 1) / gl;
+    const int total_slabs = my_slots * nk;  // (32-bit on purpose: a 64-bit counter is compared on the VALU and spilled)
+
+    // ---- fragment addresses: one base per operand, the fragment index is an immediate offset (the swizzle key of a lane's
+    //      rows does not depend on the fragment: A rows 128 wr + 16 i + l16 have key l16 & 7, W rows see wfrag_row / swz_key)
+    const int key_a = l16 & 7;
+    const int rw0 = wc * 64 + wfrag_row<LP_OUT>(0, l16);
+    const int key_w = swz_key<LP_OUT>(rw0);
+    const int a_rd = (wr * 128 + l16) * ROWB + ((grp4 ^ key_a) << 4);            // k-step 0; k-step 1 = ^ 64
+    const int w_rd = A_BYTES + rw0 * ROWB + ((grp4 ^ key_w) << 4);
+    constexpr int WJ1 = (wfrag_row<LP_OUT>(1, 0) - wfrag_row<LP_OUT>(0, 0)) * ROWB;
+    constexpr int WJ2 = (wfrag_row<LP_OUT>(2, 0) - wfrag_row<LP_OUT>(0, 0)) * ROWB;
+    constexpr int WJ3 = (wfrag_row<LP_OUT>(3, 0) - wfrag_row<LP_OUT>(0, 0)) * ROWB;
+
+    // ---- LDS-DMA: stage image = A rows 0..255, then W rows 0..255 (128-byte rows, chunk ^= key(row)); instruction idx covers
+    //      rows 8 (idx & 31) .. +7 of A (idx < 32) or W; wave w issues idx = 8 w .. 8 w + 7, i.e. waves 0-3 load A, 4-7 load W
+    const bool ld_a = wave < 4;
+    const int sub = lane >> 3, pos = lane & 7;
+    const int npad = ((g.N + 127) / 128) * 128;  // W is padded to a multiple of 128 rows by the caller
+    const __amdgpu_buffer_rsrc_t rsrc = ld_a
+        ? __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (unsigned)((size_t)g.M * g.lda * 2), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (unsigned)((size_t)npad * g.ldw * 2), 0x00020000);
+    unsigned roff[8];  // per-lane source byte offset of each DMA instruction at k = 0 of the tile being staged
+    int is_slot = lb, is_kt = 0, is_stage = 0;
+    int issued = 0;
+    auto tile_offsets = [&]() {
+        const int t = t0 + is_slot;
+        const int r0 = ld_a ? (t / g.ntn) * BM : (t % g.ntn) * BN;
+        const unsigned ld2 = (unsigned)(ld_a ? g.lda : g.ldw) * 2u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = ((wave & 3) * 8 + q) * 8 + sub;                          // row within the A / W tile
+            const int key = ld_a ? (r & 7) : swz_key<LP_OUT>(r);
+            roff[q] = (unsigned)(r0 + r) * ld2 + (unsigned)((pos ^ key) << 4);     // rows past the matrix fall outside the descriptor
+        }
+    };
+    tile_offsets();
+    auto issue_next = [&]() {
+        if (issued < total_slabs && !((MADTP_SQ_ABLATE & 1) && issued > 0)) {
+            char* st = smem + is_stage * STAGE_BYTES + wave * 8 * 1024;
+            const int koff = is_kt * ROWB;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(st + q * 1024), 16, roff[q], koff, 0, 0);
+        }
+        ++issued;
+        is_stage ^= 1;
+        if (++is_kt == nk) {
+            is_kt = 0;
+            is_slot += gl;
+            if (issued < total_slabs) tile_offsets();
+        }
+    };
+
+    f32x4 acc[8][4];
+    bf16x8 alo0[4], ahi0[4], alo1[4], ahi1[4], b0[4], b1[4];
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 res[1][1];
+#define SQ_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define SQ_READ_A(R, KX, HALF)                                                              \
+    if (!(MADTP_SQ_ABLATE & 4) || slot == lb)                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
+        R[i] = *(const bf16x8*)(st + ((a_rd + ((HALF) * 4 + i) * 16 * ROWB) ^ (KX)));
+#define SQ_READ_W(R, KX)                                                                    \
+    if (!(MADTP_SQ_ABLATE & 4) || slot == lb) {                                             \
+    R[0] = *(const bf16x8*)(st + ((w_rd) ^ (KX)));                                          \
+    R[1] = *(const bf16x8*)(st + ((w_rd + WJ1) ^ (KX)));                                    \
+    R[2] = *(const bf16x8*)(st + ((w_rd + WJ2) ^ (KX)));                                    \
+    R[3] = *(const bf16x8*)(st + ((w_rd + WJ3) ^ (KX))); }
+#define SQ_MFMA(RA, RW, HALF)                                                               \
+    if (!(MADTP_SQ_ABLATE & 2))                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
+            acc[(HALF) * 4 + i][j] = mfma_16x16x32<false>(RW[j], RA[i], acc[(HALF) * 4 + i][j]);
+
+    issue_next();  // slab 0 -> stage 0
+    wait_vmcnt<0>();
+    int cur_stage = 0;
+    for (int slot = lb; slot < nslots; slot += gl) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = zero4;
+        // (the first slab of a tile is peeled: it has no pending sub-phase, and a conditional inside the loop body would be a
+        //  control-flow merge where the compiler's s_waitcnt insertion turns conservative)
+#define SQ_SLAB(FIRST)                                                                                                \
+        {                                                                                                             \
+            const char* st = smem + cur_stage * STAGE_BYTES;                                                          \
+            cur_stage ^= 1;                                                                                           \
+            __builtin_amdgcn_s_barrier(); /* slab landed for every wave; every wave finished reading the other stage */ \
+            issue_next();                                                                                             \
+            SQ_FENCE();                                                                                               \
+            SQ_READ_A(alo0, 0, 0) SQ_READ_W(b0, 0)                                                                    \
+            SQ_FENCE();                                                                                               \
+            if (!(FIRST)) { SQ_MFMA(ahi1, b1, 1) } /* last sub-phase of the previous slab, from registers */          \
+            SQ_FENCE();                                                                                               \
+            SQ_READ_A(ahi0, 0, 1)                                                                                     \
+            SQ_FENCE();                                                                                               \
+            SQ_MFMA(alo0, b0, 0)                                                                                      \
+            SQ_FENCE();                                                                                               \
+            SQ_READ_A(alo1, 64, 0) SQ_READ_W(b1, 64)                                                                  \
+            SQ_FENCE();                                                                                               \
+            SQ_MFMA(ahi0, b0, 1)                                                                                      \
+            SQ_FENCE();                                                                                               \
+            SQ_READ_A(ahi1, 64, 1)                                                                                    \
+            SQ_FENCE();                                                                                               \
+            SQ_MFMA(alo1, b1, 0)                                                                                      \
+            SQ_FENCE();                                                                                               \
+            __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): this wave is done reading the stage */                 \
+            wait_vmcnt<0>(); /* own DMA of the next slab landed (issued a slab ago); a tile's stores are a slab old */ \
+            SQ_FENCE();                                                                                               \
+        }
+        SQ_SLAB(true)
+        for (int kt = 1; kt < nk; ++kt) SQ_SLAB(false)
+#undef SQ_SLAB
+        { SQ_MFMA(ahi1, b1, 1) }
+        const int t = t0 + slot;
+        const int m0 = (t / g.ntn) * BM, n0 = (t % g.ntn) * BN + (wc >> 1) * 128;
+#define EPI(ACT)                                                                                                  \
+    if constexpr (LP_OUT) {                                                                                       \
+        epilogue<OM, ACT, false, 8, 4, 256, 128>(g, acc, res, m0, n0, wr, wc & 1, l16, grp4, 0);                   \
+    } else {                                                                                                      \
+        if (g.residual) epilogue<OM, ACT, true, 8, 4, 256, 128>(g, acc, res, m0, n0, wr, wc & 1, l16, grp4, 0);    \
+        else epilogue<OM, ACT, false, 8, 4, 256, 128>(g, acc, res, m0, n0, wr, wc & 1, l16, grp4, 0);              \
+    }
+        switch (g.act) {
+            case MADTP_ACT_GELU_ERF: EPI(MADTP_ACT_GELU_ERF) break;
+            case MADTP_ACT_QUICK_GELU: EPI(MADTP_ACT_QUICK_GELU) break;
+            case MADTP_ACT_RELU: EPI(MADTP_ACT_RELU) break;
+            default: EPI(MADTP_ACT_NONE) break;
+        }
+#undef EPI
+    }
+#undef SQ_FENCE
+#undef SQ_READ_A
+#undef SQ_READ_W
+#undef SQ_MFMA
+}
+
 #ifdef MADTP_WS_TIMING
 extern "C" int madtp_debug_read_ws_ts(long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ws_dbg), sizeof(long long) * 8);
@@ -846,6 +1021,24 @@ constexpr int PAIR_UNSUPPORTED = 1000;  // internal: this shape does not run on 
 static int gemm_launch(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
                        int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float acc_scale, float out_scale,
                        int splitk, void* stream, const GemmPair* pair = nullptr);
+
+// forced tile configuration (madtp_gemm_set_config / MADTP_GEMM_CFG): A/B measurements and the per-kernel tests
+static std::atomic<int> g_force_cfg{-1};
+static int gemm_force_cfg() {
+    int v = g_force_cfg.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("MADTP_GEMM_CFG");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v > 6) v = 0;
+        g_force_cfg.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+extern "C" int madtp_gemm_set_config(int cfg) {
+    const int prev = gemm_force_cfg();
+    g_force_cfg.store((cfg < 0 || cfg > 6) ? 0 : cfg, std::memory_order_relaxed);
+    return prev;
+}
 
 // Two independent GEMMs of identical shape (C_i = A_i @ W_i^T + bias_i) in ONE launch of the wave-specialised kernel: the
 // twin cross-attention branches of the NLVR text layers project their image tokens to [k|v] with two 240-tile problems, each
@@ -902,9 +1095,9 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.act = act; g.out_scale = out_scale;
     g.acc_scale = acc_scale; g.acc_scale2 = pair ? pair->acc_scale : acc_scale;
     g.ldc = c_dtype == MADTP_BF16 ? -ldc : ldc;
-    static int dbg = -1, force_cfg = -1;
+    static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("MADTP_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
-    if (force_cfg < 0) { const char* e = getenv("MADTP_GEMM_CFG"); force_cfg = e ? atoi(e) : 0; }
+    const int force_cfg = gemm_force_cfg();
     g.dbg = dbg;
     g.splitk = splitk;
     g.ngrp = 0;
@@ -975,7 +1168,31 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         else if (cfg == 2) MADTP_LAUNCH_GEMM(TT, LP, 64, 128, 3, 2);           \
         else MADTP_LAUNCH_GEMM(TT, LP, 64, 64, 3, 3);                          \
     } while (0)
-    if (ws_ok) {
+    // 256x256 kernel: bf16 operands, no split-K / pair.  Chosen when its round count times its per-tile cost (measured ~1.7x a
+    // 256x128 tile) beats the wave-specialised kernel's; MADTP_GEMM_CFG=6 forces it, MADTP_GEMM_SQ=0 turns it off (A/B runs).
+    bool sq_ok = false;
+    if (ab_dtype == MADTP_BF16 && splitk == 1 && !pair && (K % 64) == 0 &&
+        ((size_t)M + 255) * (size_t)lda * 2 < ((size_t)1 << 32) && ((size_t)N + 255) * (size_t)ldw * 2 < ((size_t)1 << 32)) {
+        static int sq_env = -1;
+        if (sq_env < 0) { const char* e = getenv("MADTP_GEMM_SQ"); sq_env = e ? atoi(e) : 1; }
+        const int t_sq = ((M + 255) / 256) * ((N + 255) / 256);
+        const float cost_sq = 1.7f * (float)((t_sq + 255) / 256), cost_ws = (float)((t256 + 255) / 256);
+        sq_ok = force_cfg == 6 || (force_cfg == 0 && sq_env && ws_ok && t_sq >= 100 && cost_sq < cost_ws);
+    }
+    if (sq_ok) {
+        g.ntm = (M + 255) / 256;
+        g.ntn = (N + 255) / 256;
+        const int slots_max = (g.ntm * g.ntn + 7) / 8;
+        const int grid = 8 * (slots_max < 32 ? slots_max : 32);
+        const size_t lds = (size_t)2 * (256 + 256) * ROWB;
+        if (c_dtype == MADTP_BF16) {
+            MADTP_ENSURE_MAX_LDS((gemm_sq_kernel<OM_BF16>), lds);
+            hipLaunchKernelGGL((gemm_sq_kernel<OM_BF16>), dim3(grid), dim3(512), lds, s, g);
+        } else {
+            MADTP_ENSURE_MAX_LDS((gemm_sq_kernel<OM_F32>), lds);
+            hipLaunchKernelGGL((gemm_sq_kernel<OM_F32>), dim3(grid), dim3(512), lds, s, g);
+        }
+    } else if (ws_ok) {
         // wave-specialised 256x128 kernel (one 12-wave workgroup per CU, 144 KiB LDS ring)
         g.ntm = (M + 255) / 256;
         g.ntn = (N + 127) / 128;

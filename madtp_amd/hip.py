@@ -12,7 +12,7 @@ import torch
 
 F32, BF16, F16S = 0, 1, 2  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -23,6 +23,7 @@ _SIGS = {
     "madtp_profile_begin": (c_int, []),
     "madtp_profile_end": (c_int, [ctypes.c_char_p, c_int]),
     "madtp_gemm": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_int, c_int, c_int, c_float, c_float, c_void_p]),
+    "madtp_gemm_set_config": (c_int, [c_int]),
     "madtp_gemm_splitk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "madtp_splitk_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_float, c_float, c_float, c_void_p]),
@@ -199,6 +200,19 @@ def gemm(a, w, bias=None, residual=None, out_dtype=None, act=ACT_NONE, n=None, o
     _check(load().madtp_gemm(_p(a), _p(w), _p(bias), _p(residual), _p(out), M, n, K, a.stride(0), w.stride(0),
                              out.stride(0), ldr, _dt(a), _dt(out), act, w_scale_of(w), float(out_scale), _stream()), "madtp_gemm")
     return out
+
+
+class gemm_config:
+    """context manager (tests / A-B benchmarks): force a madtp_gemm tile configuration, see madtp_gemm_set_config."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def __enter__(self):
+        self.prev = load().madtp_gemm_set_config(self.cfg)
+
+    def __exit__(self, *a):
+        load().madtp_gemm_set_config(self.prev)
 
 
 def gemm_pair(a0, a1, w0, w1, bias0, bias1, n, out_dtype=None):

@@ -90,6 +90,46 @@ def test_gemm_wave_specialised(hip, M, N, K):
         assert torch.all(wide[:, :8] == 7.0) and torch.all(wide[:, 8 + N:] == 7.0)
 
 
+@pytest.mark.parametrize("M,N,K", [(10533, 768, 768), (10533, 776, 768), (6000, 2304, 768), (10533, 768, 3072), (300, 100, 768),
+                                   (25216, 3072, 768)])
+@pytest.mark.parametrize("cfg", [6])
+def test_gemm_256x256(hip, M, N, K, cfg):
+    """gemm_sq_kernel (256x256 tiles, forced with madtp_gemm_set_config(6)): ragged last row tile, a last column tile with 8 / 4
+    valid columns, N below one tile (W rows past the 128-row padding are dropped by the buffer descriptor), every epilogue and
+    a strided output.  Reference: float64 matmul of the same bf16-rounded operands on the GPU."""
+    td = torch.bfloat16
+    a = _rand(M, K, seed=1).to(td).cuda()
+    w = _rand(N, K, seed=2, scale=0.05).to(td)
+    wp = _pad128(w.float()).to(td).cuda()
+    bias, res = _rand(N, seed=3).cuda(), _rand(M, N, seed=4).cuda()
+    core = a.double() @ w.cuda().double().t()
+    scale = max(1.0, core.abs().max().item())
+    with hip.gemm_config(cfg):
+        out = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
+        assert (out - ((core + bias.double()).float() + res)).abs().max().item() < 1e-4 * scale
+        out = hip.gemm(a, wp, bias, out_dtype=torch.float32, n=N, out_scale=0.5)
+        assert (out - ((core + bias.double()) * 0.5).float()).abs().max().item() < 1e-4 * scale
+        out = hip.gemm(a, wp, None, out_dtype=td, n=N)
+        assert (out.float() - core.float()).abs().max().item() < 1e-2 * scale
+        out = hip.gemm(a, wp, bias, out_dtype=td, act=hip.ACT_GELU, n=N)
+        assert (out.float() - F.gelu(core + bias.double()).float()).abs().max().item() < 1e-2 * scale
+        for odt in (torch.float32, td):
+            wide = torch.full((M, N + 24), 7.0, device="cuda", dtype=odt)
+            hip.gemm(a, wp, bias, out_dtype=odt, n=N, out=wide[:, 8:8 + N])
+            assert (wide[:, 8:8 + N].float() - (core + bias.double()).float()).abs().max().item() < 1e-2 * scale
+            assert torch.all(wide[:, :8] == 7.0) and torch.all(wide[:, 8 + N:] == 7.0)
+        # A as a column slice of a wider matrix (lda > K)
+        big = _rand(M, K + 128, seed=9).to(td).cuda()
+        out = hip.gemm(big[:, 64:64 + K], wp, bias, out_dtype=torch.float32, n=N)
+        ref = (big[:, 64:64 + K].double() @ w.cuda().double().t() + bias.double()).float()
+        assert (out - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    # the automatic dispatch gives the same values whichever kernel it picks (same k order per accumulator)
+    auto = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
+    with hip.gemm_config(cfg):
+        sq = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
+    assert (auto - sq).abs().max().item() < 1e-4 * scale
+
+
 def test_gemm_wave_specialised_scalar_epilogue(hip):
     """N = 100 (not a multiple of 8) on 60000 rows: the wave-specialised kernel with its scalar fallback epilogue (the shape of a
     `x @ space_dict^T` product done as a plain GEMM), f32 and bf16 outputs, bias and residual."""

@@ -6,7 +6,7 @@ from madtp_amd import build as b
 
 b.build()
 src, macro = {"align": ("prune.hip", "MADTP_AL_ABLATE"), "tstime": ("prune.hip", "MADTP_TS_TIMING"), "attime": ("attention.hip", "MADTP_TS_TIMING"),
-             "wstime": ("gemm.hip", "MADTP_WS_TIMING")}.get(
+             "wstime": ("gemm.hip", "MADTP_WS_TIMING"), "sq": ("gemm.hip", "MADTP_SQ_ABLATE")}.get(
     os.environ.get("ABLATE"), ("gemm.hip", "MADTP_WS_ABLATE"))
 for n in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]:
     o = os.path.join(b.LIBDIR, f"{src[:-4]}_abl{n}.o")

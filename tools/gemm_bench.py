@@ -15,6 +15,27 @@ if len(sys.argv) > 2 and sys.argv[2] == "small":
     shapes = [sh for sh in shapes if sh[0] <= 5120 or sh[1] == 128]
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
 print("dtype", dt, "MADTP_GEMM_DEBUG", os.environ.get("MADTP_GEMM_DEBUG"), "CFG", os.environ.get("MADTP_GEMM_CFG"))
+if len(sys.argv) > 2 and sys.argv[2] == "ab":  # 256x128 wave-specialised (cfg 5) vs 256x256 (cfg 6) vs automatic on the forward's ViT shapes
+    rows = [25216, 17152, 14208, 12288, 11776, 11136, 10752, 10496]
+    for M in rows:
+        for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
+            a = torch.randn(M, K, device="cuda").to(dt); w = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
+            bias = torch.randn(N, device="cuda"); res = torch.randn(M, N, device="cuda")
+            kw = dict(residual=res, out_dtype=torch.float32) if N == 768 else (dict(act=hip.ACT_GELU) if N == 3072 else {})
+            out = torch.empty(M, N, device="cuda", dtype=kw.get("out_dtype", dt))
+            line = f"M={M:6d} N={N:5d} K={K:5d}"
+            for cfg in (5, 6, 0):
+                with hip.gemm_config(cfg):
+                    for _ in range(3): hip.gemm(a, w, bias, n=N, out=out, **kw)
+                    torch.cuda.synchronize()
+                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20): hip.gemm(a, w, bias, n=N, out=out, **kw)
+                    e1.record(); torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 20
+                line += f"   cfg{cfg} {us:7.1f} us {2.0*M*N*K/us/1e6:7.1f} TF"
+            print(line, flush=True)
+    sys.exit(0)
 for M, N, K in shapes:
     if dt == torch.float32 and M * N * K > 4096**3: continue
     a = torch.randn(M, K, device="cuda").to(dt); w = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
