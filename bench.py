@@ -314,10 +314,40 @@ def cpu_baseline(name, w, T, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt > budget_s or n >= 50:
             break
-    return {"value": round(w.images_per_sample * B * n / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} forwards of {B} samples ({w.images_per_sample * B} images) of the same workload, same weights/temperature, "
-                      f"PyTorch CPU eager fp32 via oracle/madtp_oracle.py, {dt:.1f}s",
-            "host_cpus": os.cpu_count()}
+    rep = {"value": round(w.images_per_sample * B * n / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n} forwards of {B} samples ({w.images_per_sample * B} images) of the same workload, same weights/temperature, "
+                     f"PyTorch CPU eager fp32 via oracle/madtp_oracle.py, {dt:.1f}s",
+           "host_cpus": os.cpu_count()}
+    ref = reference_proper(name)
+    if ref:
+        rep["reference_proper"] = ref
+    return rep
+
+
+def reference_proper(name):
+    """The reference ITSELF (imported behind shims by tools/make_golden.py in the build container - it cannot travel to the GPU
+    box) timed while the golden fixtures were recorded: one forward per fixture, wall seconds and thread count stored in the
+    committed .npz.  A reported figure beside the port's, on different (container) cores - BASELINE.md section 3."""
+    import glob
+    import numpy as np
+    pat = {"nlvr": "nlvr_b*.npz", "retrieval": "med_mm_*.npz", "clip": "clip_full_*.npz", "vqa": "vqa_*.npz"}[name]
+    rows = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", pat))):
+        try:
+            g = np.load(path)
+            if "ref_seconds" not in g.files:
+                continue
+            B = int(g["B"]) if "B" in g.files else 0
+            imgs = B * (2 if name == "nlvr" else 1)
+            rows.append({"fixture": os.path.basename(path), "images": imgs, "seconds": round(float(g["ref_seconds"]), 3),
+                         "threads": int(g["threads"]) if "threads" in g.files else None,
+                         "images_per_s": round(imgs / float(g["ref_seconds"]), 2) if imgs else None})
+        except Exception:  # a fixture without the fields is simply not reported
+            continue
+    if not rows:
+        return None
+    return {"what": "the reference's own modules (CPU eager fp32, imported in the build container by tools/make_golden.py), one "
+                    "un-warmed forward per committed fixture", "fixtures": rows}
 
 
 if __name__ == "__main__":

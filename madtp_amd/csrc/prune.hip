@@ -249,6 +249,183 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     }
 }
 
+// Long sequences (the logits of a sample no longer fit the LDS: 577 / 901 tokens at 384^2 / 480^2 images) at small batches: one
+// workgroup per sample leaves most of the chip idle (VQA: 32 samples -> 32 of 256 CUs, 124 us per launch).  Here a sample is
+// split over G workgroups by DICTIONARY COLUMNS: every workgroup repeats the cheap per-token phase A (so it owns the complete
+// score vector I), runs the three softmax-over-tokens passes of phase B for its 128/G columns with 512/(128/G) token slices,
+// and publishes the minimum of its columns' sums; the last workgroup of the sample to arrive (agent-scope ticket) takes the
+// minimum over the G partial minima (exact, order-free), counts the survivors and takes part in the launch-wide ticket that
+// hands k to the host.  tick / part: per-sample scratch of the hand-over slot (zeroed once, every ticket resets itself).
+template <int G>
+__global__ __launch_bounds__(512) void token_score_split_kernel(const float* __restrict__ colsum, int nrt,
+                                                                const float* __restrict__ p0, const float* __restrict__ onorm,
+                                                                const float* __restrict__ ta, int ldt, int ldb, int K,
+                                                                float temperature, float* __restrict__ score,
+                                                                float* __restrict__ threshold, int32_t* __restrict__ count, int H, int N,
+                                                                int32_t* done_ctr, int32_t* host_slot, int seq, int32_t* tick,
+                                                                float* part) {
+    constexpr int KC = 128 / G, S = 512 / KC;  // columns per workgroup, token slices
+    __shared__ float I_s[MAXN];
+    __shared__ int last_s, lastg_s;
+    __shared__ float tw_s[MAXN];
+    __shared__ float red[8];
+    __shared__ float colred[S][KC];
+    __shared__ float colstat[KC];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = blockIdx.x, b = blockIdx.y, n = N - 1, nsamp = gridDim.y;
+    const float* ta_g = ta + (size_t)b * ldb;
+    auto TA = [&](int t, int c) -> float { return ta_g[(size_t)t * ldt + c]; };
+
+    // ---- phase A (identical in every workgroup of the sample): row max of the logits, four lanes per row, float4 reads
+    {
+        const int k4 = K >> 2, q = tid & 3;  // K % 4 == 0, ldt % 4 == 0, 16-byte aligned rows (launch condition)
+        for (int t = tid >> 2; t < n; t += 128) {
+            float m = -INFINITY;
+            for (int c = q; c < k4; c += 4) {
+                const float4 v = *(const float4*)(ta_g + (size_t)t * ldt + 4 * c);
+                m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+            }
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            if (q == 0) tw_s[t] = m;
+        }
+    }
+    __syncthreads();
+    constexpr int HMAX = 16, RMAX = 16;
+    float a_loc[2], c_loc[2], suma_l = 0.f, sumt_l = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = tid + u * 512;
+        a_loc[u] = 0.f; c_loc[u] = 0.f;
+        if (t < n) {
+            float a = 0.f, hs = 0.f, c = 0.f;
+            if (H <= HMAX && nrt <= RMAX) {
+                float on[HMAX], pz[HMAX], cs[RMAX];
+#pragma unroll
+                for (int h = 0; h < HMAX; ++h) {
+                    const size_t o = ((size_t)b * H + h) * N + t + 1;
+                    on[h] = h < H ? onorm[o] : 0.f;
+                    pz[h] = h < H ? p0[o] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) cs[r] = r < nrt ? colsum[((size_t)b * nrt + r) * N + t + 1] : 0.f;
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) if (r < nrt) a += cs[r];
+#pragma unroll
+                for (int h = 0; h < HMAX; ++h) if (h < H) hs += on[h];
+#pragma unroll
+                for (int h = 0; h < HMAX; ++h) if (h < H) c += pz[h] * (on[h] / (hs + 1e-8f));
+            } else {
+                for (int r = 0; r < nrt; ++r) a += colsum[((size_t)b * nrt + r) * N + t + 1];
+                for (int h = 0; h < H; ++h) hs += onorm[((size_t)b * H + h) * N + t + 1];
+                for (int h = 0; h < H; ++h) {
+                    const size_t o = ((size_t)b * H + h) * N + t + 1;
+                    c += p0[o] * (onorm[o] / (hs + 1e-8f));
+                }
+            }
+            a_loc[u] = a; c_loc[u] = c;
+            suma_l += a; sumt_l += tw_s[t];
+        }
+    }
+    const float suma = block_sum(suma_l, red, tid, 8);
+    const float sumt = block_sum(sumt_l, red, tid, 8);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = tid + u * 512;
+        if (t < n) {
+            const float aw = a_loc[u] / (suma + 1e-8f);
+            const float tw = tw_s[t] / (sumt + 1e-8f);
+            const float sc = (aw + tw + c_loc[u]) / 3.0f;  // vit.py:134
+            I_s[t] = sc;
+            if (g == 0) score[(size_t)b * n + t] = sc;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B on columns [g KC, (g+1) KC): softmax over tokens of token_attn / T (vit.py:137-139), S token slices
+    const int cl = tid % KC, slice = tid / KC, col = g * KC + cl;
+    const int t0 = (n * slice) / S, t1 = (n * (slice + 1)) / S;
+    const bool cval = col < K;
+    float m = -INFINITY;
+    if (cval) {
+#pragma unroll 8
+        for (int t = t0; t < t1; ++t) m = fmaxf(m, TA(t, col) / temperature);
+    }
+    colred[slice][cl] = m;
+    __syncthreads();
+    m = colred[0][cl];
+#pragma unroll
+    for (int s2 = 1; s2 < S; ++s2) m = fmaxf(m, colred[s2][cl]);
+    __syncthreads();
+    float se = 0.f;
+    if (cval) {
+#pragma unroll 8
+        for (int t = t0; t < t1; ++t) se += expf(TA(t, col) / temperature - m);
+    }
+    colred[slice][cl] = se;
+    __syncthreads();
+    float sum = colred[0][cl];
+#pragma unroll
+    for (int s2 = 1; s2 < S; ++s2) sum += colred[s2][cl];  // fixed order
+    __syncthreads();
+    float sw = 0.f;
+    if (cval) {
+#pragma unroll 8
+        for (int t = t0; t < t1; ++t) sw += (expf(TA(t, col) / temperature - m) / sum) * I_s[t];
+    }
+    colred[slice][cl] = sw;
+    __syncthreads();
+    if (tid < KC) {
+        float v = colred[0][tid];
+#pragma unroll
+        for (int s2 = 1; s2 < S; ++s2) v += colred[s2][tid];
+        colstat[tid] = (g * KC + tid) < K ? v : INFINITY;
+    }
+    __syncthreads();
+    float pm = INFINITY;
+    for (int k = lane; k < KC; k += 64) pm = fminf(pm, colstat[k]);
+    pm = wave_min(pm);
+    // ---- publish this workgroup's minimum, the last arriver of the sample finishes (MI355X_MICROARCH.md: agent-scope
+    //      release before the ticket, acquire after it, the partials read past the L1 with agent-scope atomic loads)
+    if (tid == 0) {
+        __hip_atomic_store(part + (size_t)b * G + g, pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        lastg_s = atomicAdd(tick + b, 1) == G - 1;
+    }
+    __syncthreads();
+    if (!lastg_s) return;
+    if (tid == 0) __threadfence();
+    __syncthreads();
+    float thr = INFINITY;
+#pragma unroll
+    for (int i = 0; i < G; ++i) thr = fminf(thr, __hip_atomic_load(part + (size_t)b * G + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    int cnt = 0;
+    for (int t = tid; t < n; t += 512) cnt += I_s[t] > thr ? 1 : 0;
+    const float total = block_sum((float)cnt, red, tid, 8);  // exact: counts <= 1024
+    if (tid == 0) {
+        tick[b] = 0;  // the scratch is clean again for the next launch on this slot
+        threshold[b] = thr;
+        count[b] = (int)total;
+        int last = 0;
+        if (done_ctr) {
+            __threadfence();
+            last = atomicAdd(done_ctr, 1) == nsamp - 1;
+        }
+        last_s = last;
+    }
+    if (!done_ctr) return;
+    __syncthreads();
+    if (!last_s) return;
+    int mloc = 0;
+    for (int i = tid; i < nsamp; i += 512) mloc = max(mloc, __hip_atomic_load(count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const int kk = (int)block_max_f((float)mloc, red, tid, 8);
+    if (tid == 0) {
+        *done_ctr = 0;
+        __hip_atomic_store(host_slot, kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_slot + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ----------------------------------------------------------------------------------------------- token_select
 __global__ __launch_bounds__(256) void token_select_kernel(const float* __restrict__ score, int k,
                                                            int64_t* __restrict__ indices, int64_t* __restrict__ indices_sort,
@@ -976,10 +1153,17 @@ __global__ __launch_bounds__(768, 1) void align_ws_kernel(const float* __restric
 
 }  // namespace
 
+constexpr int SPLIT_MAX_B = 1024, SPLIT_MAX_G = 8;  // per-slot scratch of token_score_split_kernel
+static bool split_enabled() {  // MADTP_TS_SPLIT=0: always one workgroup per sample (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MADTP_TS_SPLIT"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
 static int token_score_launch(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
                               const float* token_attn, int ldt, int ldb, int K, float temperature, float* score,
                               float* threshold, int32_t* count, int32_t* kmax, int B, int H, int N, int32_t* done_ctr,
-                              int32_t* host_slot, int seq, void* stream) {
+                              int32_t* host_slot, int seq, void* stream, int32_t* tick = nullptr, float* part = nullptr) {
     if (!colsum_part || !p0 || !onorm || !token_attn || !score || !threshold || !count) return MADTP_E_BADARG;
     if (B <= 0 || H <= 0 || N < 2 || n_row_tiles <= 0 || !(temperature > 0.f)) return MADTP_E_BADARG;
     if (N - 1 > MAXN || K > 128 || K <= 0 || ldt < K) return MADTP_E_SHAPE;
@@ -990,6 +1174,19 @@ static int token_score_launch(const float* colsum_part, int n_row_tiles, const f
         hipLaunchKernelGGL(token_score_kernel<true>, dim3(B), dim3(512), stage_bytes, (hipStream_t)stream, colsum_part,
                            n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N,
                            done_ctr, host_slot, seq);
+    } else if (tick && part && !kmax && B <= SPLIT_MAX_B && B <= 64 && K % 4 == 0 && ldt % 4 == 0 && ldb % 4 == 0 &&
+               aligned16(token_attn) && split_enabled()) {
+        // long sequence, small batch: G workgroups per sample (column split), so that the launch covers the chip (measured: VQA,
+        // 32 samples x 901 tokens, +6.5 % on the whole forward; at 128 samples the one-workgroup kernel already fills half the
+        // chip and the repeated phase A costs 2 %)
+        if (B <= 32)
+            hipLaunchKernelGGL(token_score_split_kernel<8>, dim3(8, B), dim3(512), 0, (hipStream_t)stream, colsum_part, n_row_tiles,
+                               p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, H, N, done_ctr, host_slot,
+                               seq, tick, part);
+        else
+            hipLaunchKernelGGL(token_score_split_kernel<4>, dim3(4, B), dim3(512), 0, (hipStream_t)stream, colsum_part, n_row_tiles,
+                               p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, H, N, done_ctr, host_slot,
+                               seq, tick, part);
     } else {
         hipLaunchKernelGGL(token_score_kernel<false>, dim3(B), dim3(512), 0, (hipStream_t)stream, colsum_part, n_row_tiles, p0,
                            onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N, done_ctr, host_slot,
@@ -1017,6 +1214,8 @@ struct SyncSlot {
     int32_t* host = nullptr;      // pinned (portable, mapped): [0] = k, [1] = sequence number of the launch that wrote it
     int32_t* host_dev = nullptr;  // the same memory as this device sees it
     int32_t* ctr = nullptr;       // device ticket counter (the last workgroup resets it)
+    int32_t* tick = nullptr;      // per-sample tickets of token_score_split_kernel [SPLIT_MAX_B] (self-resetting)
+    float* part = nullptr;        // per-sample partial minima [SPLIT_MAX_B, SPLIT_MAX_G]
     bool busy = false;
     int seq = 0;
 };
@@ -1042,10 +1241,18 @@ int dev_sync_init(DevSync& d) {  // caller holds d.mu and has the device current
     if (e != hipSuccess) return (int)e;
     e = hipMemset(ctr, 0, SYNC_SLOTS * 64);
     if (e != hipSuccess) return (int)e;
+    const size_t per_slot = (size_t)SPLIT_MAX_B * (1 + SPLIT_MAX_G) * 4;
+    char* scratch = nullptr;
+    e = hipMalloc((void**)&scratch, SYNC_SLOTS * per_slot);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(scratch, 0, SYNC_SLOTS * per_slot);
+    if (e != hipSuccess) return (int)e;
     for (int i = 0; i < SYNC_SLOTS; ++i) {  // one 64-byte line per slot on both sides
         d.slot[i].host = host + 16 * i;
         d.slot[i].host_dev = host_dev + 16 * i;
         d.slot[i].ctr = ctr + 16 * i;
+        d.slot[i].tick = (int32_t*)(scratch + i * per_slot);
+        d.slot[i].part = (float*)(scratch + i * per_slot + (size_t)SPLIT_MAX_B * 4);
     }
     d.ready = true;
     return 0;
@@ -1080,7 +1287,8 @@ extern "C" int madtp_token_score_publish(const float* colsum_part, int n_row_til
         d.slot[si].seq = seq;
     }
     const int rc = token_score_launch(colsum_part, n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold,
-                                      count, nullptr, B, H, N, d.slot[si].ctr, d.slot[si].host_dev, seq, stream);
+                                      count, nullptr, B, H, N, d.slot[si].ctr, d.slot[si].host_dev, seq, stream, d.slot[si].tick,
+                                      d.slot[si].part);
     if (rc) {
         std::lock_guard<std::mutex> lk(d.mu);
         d.slot[si].busy = false;
@@ -1112,7 +1320,10 @@ extern "C" int madtp_token_score_wait(int seq, const int32_t* count, int B, int3
                 int m = 0;
                 for (int v : h) m = v > m ? v : m;
                 *k_host = m;
-                if (__atomic_load_n(&sl.host[1], __ATOMIC_ACQUIRE) != seq) e = hipMemset(sl.ctr, 0, sizeof(int32_t));
+                if (__atomic_load_n(&sl.host[1], __ATOMIC_ACQUIRE) != seq) {
+                    e = hipMemset(sl.ctr, 0, sizeof(int32_t));
+                    if (e == hipSuccess) e = hipMemset(sl.tick, 0, sizeof(int32_t) * SPLIT_MAX_B);
+                }
             }
             rc = (int)e;
             std::lock_guard<std::mutex> lk(d.mu);

@@ -194,6 +194,36 @@ def test_controller_matches_reference_rule_and_constant():
     assert abs(log[-1][2] - 66.27) < 1.5
 
 
+def test_controller_ladders_of_every_driver():
+    """Each compress_*_dtp.py driver has its own step ladder (thresholds on |Cur - Target| -> step) and its own
+    calculate_temperature() search; spot values below are read off the reference sources (file:line in controller.py)."""
+    from madtp_amd import controller as C
+    tgt = 100.0
+    cases = {  # task -> [(Cur - Target, expected step)]
+        "retrieval": [(60, 0.5), (40, 0.3), (25, 0.2), (15, 0.1), (7, 0.05), (3, 0.02), (1, 0.01)],      # compress_retrieval_dtp.py:402-434
+        "retrieval_clip": [(60, 0.5), (40, 0.3), (25, 0.2), (15, 0.1), (7, 0.05), (3, 0.02), (1, 0.01)],  # compress_retrieval_clip_dtp.py:300-332
+        "caption": [(60, 0.5), (40, 0.3), (25, 0.2), (15, 0.1), (7, 0.05), (3, 0.02), (1, 0.01)],         # compress_caption_dtp.py:235-267
+        "vqa": [(60, 0.25), (40, 0.15), (15, 0.1), (7, 0.05), (3, 0.01), (1, 0.0)],                       # compress_vqa_dtp.py:245-268 (no else)
+        "nlvr": [(40, 1.0), (15, 0.5), (7, 0.25), (2, 0.1), (0.5, 0.01)],                                 # compress_nlvr_dtp.py:175-200
+    }
+    for task, rows in cases.items():
+        for d, step in rows:
+            assert abs(C.step_temperature(2.0, tgt + d, tgt, task) - (2.0 + step)) < 1e-12, (task, d)
+            assert abs(C.step_temperature(2.0, tgt - d, tgt, task) - (2.0 - step)) < 1e-12, (task, d)
+    assert C.ORI_GFLOPS["retrieval"] == 153.2 and C.ORI_GFLOPS["vqa"] == 186.1 and C.ORI_GFLOPS["retrieval_clip"] == 395.7
+    # calculate_temperature on a toy plant (GFLOPs fall with T): start value, first step and the stopping tolerance per driver
+    plant = lambda ori: (lambda T: ori / (1.0 + 0.15 * max(T, 0.0)))
+    for task, start, first, tol in (("retrieval", 0.0, 0.5, 10), ("caption", 1.0, 0.3, 10), ("retrieval_clip", 1.0, 0.5, 5),
+                                    ("vqa", 0.0, 0.5, 10)):
+        ori = C.ORI_GFLOPS[task]
+        seen = []
+        m = plant(ori)
+        cur, T = C.calculate_temperature(lambda t: (seen.append(t), m(t))[1], ori, ori * 0.5, task)
+        assert abs(seen[0] - (start + first)) < 1e-12, (task, seen[0])     # Cur - Target = ori / 2 picks the driver's first rung
+        assert abs(cur - ori * 0.5) <= tol + 1e-9 and cur == m(T), (task, cur, T)
+    # retrieval: |Cur - Target| = 76.6 -> +0.5; caption: 32.85 -> +0.3; clip: 197.85 -> +0.5; vqa: 93.05 -> +0.5
+
+
 CLIP_FULL_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clip_full_*.npz")))
 
 
