@@ -359,6 +359,50 @@ int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden, const flo
  * key|value weights stacked (the NLVR text encoder does that: 2 GEMMs per forward instead of 24).  Retrieval re-ranking
  * projects every image once per layer instead of once per (query, candidate) pair. */
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Encoder-level entry points: ONE call runs every layer of an encoder - the query model in front of
+ * each layer (vit.py:297-303 / med.py:513-524 / nlvr_encoder.py:608-613) and the layer itself - so the host side between two
+ * layers is a few lines of C instead of a return to Python (two FFI crossings, ~10 tensor allocations and ~40 us per layer:
+ * at 64 samples the text encoder's kernels run 5-18 us each and the GPU idled 15-25 us per layer waiting for the host).
+ * The per-layer host read of k = max_b count stays (the pruning rule is the reference's, vit.py:145-149); all buffers are
+ * caller-owned and sized for the UNPRUNED sequence, results of a pruned layer sit contiguously at the start of them.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct madtp_query_w {        /* models/utils.py Query_model operands, see madtp_query_model */
+    const void* sd_w;                 /* f32 [128, dim] dictionary (rows >= K zero) */
+    const void* sd_hi; const void* sd_lo; int split_dtype; float sd_scale;   /* optional split planes (madtp_align_logits) */
+    int K; float inv_sqrt_sd;
+    float* att_ft;                    /* [B,K,dim] running sum of the layers' att_ft, or NULL (not computed here) */
+    float* stats_ws;                  /* B*256 floats when att_ft runs its bf16 kernel, else NULL */
+} madtp_query_w;
+
+typedef struct madtp_layer_io {       /* buffers and results of one layer */
+    float* logits;                    /* [B*N_in, 128] logits of the layer's query model (token_attn = rows 1.. of each sample) */
+    float* x_attn;                    /* [B,N_in,dim]: ViT x + attn(norm1(x)); BERT attention_output */
+    float* y;                         /* [B,N_in,dim] layer output ([B,n_out,dim] contiguous when pruned) */
+    void* y_lp;                       /* BERT, compute dtype != f32: copy of y for the next layer (may be NULL) */
+    float* mask_out;                  /* BERT: [B,N_in] compacted additive mask (written when pruned) */
+    float* score; float* threshold; int32_t* count;       /* [B,N_in-1], [B], [B] (written when temperature > 0) */
+    int64_t* indices; int64_t* indices_sort;              /* [B,N_in-1] each; indices holds [B,k_used] when pruned */
+    int k_out, k_used, n_out;         /* RESULTS: max_b count, k applied (0 = not pruned), tokens per sample after the layer */
+} madtp_layer_io;
+
+/* VisionTransformer.forward's block loop (vit.py:292-305): for each layer the query model on x (skipped when q == NULL or
+ * temperature <= 0 ... see below) and Block.forward.  layers[l] as for madtp_vit_block; x0 [B,N0,dim] f32; ws: workspace of
+ * madtp_vit_block_workspace(B, N0, ...) bytes.  q == NULL: plain blocks (temperature ignored).  The output of the last layer
+ * is io[n_layers-1].y with io[n_layers-1].n_out tokens per sample (the final LayerNorm is the caller's, vit.py:309). */
+int madtp_vit_encoder(const madtp_vit_block_w* const* layers, int n_layers, const madtp_query_w* q, const float* x0,
+                      madtp_layer_io* io, void* ws, size_t ws_bytes, int B, int N0, float temperature, void* stream);
+
+/* BertEncoder.forward's layer loop (med.py:509-571 / nlvr_encoder.py:600-660): query model on the hidden states, then
+ * BertLayer.forward; the compacted mask and the compute-dtype copy of the output are handed from layer to layer.
+ * hidden0 [B,L0,dim] f32, hidden0_lp optional compute-dtype copy, mask0 additive [B,L0] (may be NULL when temperature <= 0);
+ * cross-attention operands as for madtp_bert_layer, kv_pre0 / kv_pre1: optional arrays of n_layers pointers. */
+int madtp_bert_encoder(const madtp_bert_layer_w* const* layers, int n_layers, const madtp_query_w* q, const float* hidden0,
+                       const void* hidden0_lp, const float* mask0, madtp_layer_io* io, void* ws, size_t ws_bytes, int B, int L0,
+                       int Nk, float temperature, int cross_mode, const void* enc0, const void* enc1, const float* enc_mask0,
+                       const float* enc_mask1, const void* const* kv_pre0, const void* const* kv_pre1, const int32_t* kv_index,
+                       int kv_ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

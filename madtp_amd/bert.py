@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import PreparedCache, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
+from .runtime import EncoderWeights, PreparedCache, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model
 
 
@@ -47,6 +47,8 @@ _ENC_STORE = []
 # instead of 24 x 17.8 us of GEMM, but the strided K/V rows cost the 24 cross-attention kernels 6.7 -> 8.1 us each and the two
 # chip-filling GEMMs no longer leave room for the vision encoder's deferred att_ft kernel on the auxiliary stream).
 _KV_AHEAD = os.environ.get("MADTP_KV_AHEAD", "0") == "1"
+# MADTP_ENCODER_CALL=0: one library call per BertLayer (and a return to Python between layers) instead of madtp_bert_encoder
+_ENCODER_CALL = os.environ.get("MADTP_ENCODER_CALL", "1") != "0"
 
 
 def _cast(x2d):
@@ -442,9 +444,14 @@ class _BertEncoderBase(nn.Module):
     def _run(self, hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states, encoder_attention_mask,
              mode, always_query):
         sd_txt_ft_all = None
+        cache = self.__dict__.pop("_kv_cache", None)  # EncoderKVCache for THIS call (MedBertModel.forward(encoder_kv_cache=...))
+        if _ENCODER_CALL and not _KV_AHEAD and all(type(l) is self.layer_cls for l in self.layer):
+            out = self._run_encoder_call(hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states,
+                                         encoder_attention_mask, mode, always_query, cache)
+            if out is not None:
+                return out
         defer = self.txt_query_model.deferred() if space_dict is not None else None
         reduce_num = int((hidden_states.shape[-2] - 1) // self.config.num_hidden_layers)
-        cache = self.__dict__.pop("_kv_cache", None)  # EncoderKVCache for THIS call (MedBertModel.forward(encoder_kv_cache=...))
         ahead = None
         if cache is None and mode == 'multimodal' and encoder_hidden_states is not None and _KV_AHEAD:
             ahead = self._project_encoder_tokens(encoder_hidden_states)
@@ -479,6 +486,87 @@ class _BertEncoderBase(nn.Module):
             sd_txt_ft_all = defer.finish()
         return _Out(hidden_states), sd_txt_ft_all
 
+
+    def _apply(self, fn, recurse=True):
+        self.__dict__.pop("_enc_weights", None)  # .to() / .half() may replace Parameter objects
+        return super()._apply(fn, recurse)
+
+    def _run_encoder_call(self, hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states,
+                          encoder_attention_mask, mode, always_query, cache):
+        """The layer loop of _run() as ONE library call (madtp_bert_encoder): the same kernels in the same order as the
+        per-layer path without the return to Python between layers.  None: fall back to the per-layer path."""
+        require_gpu(hidden_states, "hidden_states")
+        query = space_dict is not None or always_query
+        if query and space_dict is None:
+            raise TypeError("nlvr_encoder.BertEncoder calls txt_query_model unconditionally (:608): space_dict must be given")
+        hidden = as_f32_contig(hidden_states)
+        B, L, D = hidden.shape
+        mask2d = None
+        if attention_mask is not None:
+            if attention_mask.dim() != 4 or attention_mask.shape[2] != 1:
+                raise NotImplementedError("only padding masks [B,1,1,L] (encoder use) are supported")
+            mask2d = as_f32_contig(attention_mask[:, 0, 0, :])
+        t = temperature if space_dict is not None else 0
+        if t > 0 and mask2d is None:
+            raise ValueError("attention_mask is required when temperature > 0 (med.py:424)")
+        qargs, deferred = (None, False)
+        if query:
+            qargs, deferred = self.txt_query_model.encoder_args(space_dict, B, D, hidden.device)
+            if qargs is None:
+                return None
+        l0 = self.layer[0]
+        cross = mode == 'multimodal'
+        enc0 = enc1 = em0 = em1 = None
+        kv0 = kv1 = kv_index = None
+        Nk = 0
+        nlvr = self.layer_cls.variant == "nlvr"
+        if cross and cache is not None:
+            Nk, kv0, kv_index = cache.Nk, list(cache.kv), cache.index
+            if nlvr:
+                return None
+        elif cross:
+            assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
+            if nlvr:
+                Nk = encoder_hidden_states[0].shape[1]
+                enc0, enc1 = l0._enc_operand(encoder_hidden_states[0]), l0._enc_operand(encoder_hidden_states[1])
+                em0, em1 = l0._enc_mask2d(encoder_attention_mask[0]), l0._enc_mask2d(encoder_attention_mask[1])
+            else:
+                Nk = encoder_hidden_states.shape[1]
+                enc0 = l0._enc_operand(encoder_hidden_states)
+        lp = getattr(hidden_states, "_madtp_lp", None)
+        if lp is not None and (lp[1] != hidden._version or hidden is not hidden_states or lp[0].shape[:-1] != hidden.shape[:-1]
+                               or compute_dtype() == torch.float32 or lp[0].dtype != compute_dtype()):
+            lp = None
+        ew = self.__dict__.get("_enc_weights")
+        if ew is None:
+            ew = self.__dict__["_enc_weights"] = EncoderWeights()
+        ws = ew.get(list(self.layer))
+        kv_ld = 0
+        if kv0 is not None:
+            for tns in kv0:
+                if tns.stride(-1) != 1 or (kv_ld and kv_ld != tns.stride(0)):
+                    raise RuntimeError("encoder_kv_cache tensors must be row-major with one common row stride")
+                kv_ld = tns.stride(0)
+        run = hip.bert_encoder(ws, hidden, lp[0] if lp else None, mask2d, qargs, t, cross, enc0, enc1, Nk, em0, em1,
+                               kv_pre0=kv0, kv_pre1=kv1, kv_index=kv_index, kv_ld=kv_ld)
+        for l, layer in enumerate(self.layer):
+            layer.last_prune = run.info(l, t if query else 0)
+            layer.__dict__.pop("_kv_pre", None)
+        sd_txt_ft_all = None
+        qm = self.txt_query_model
+        if query and qm.compute_att_ft:
+            if deferred:
+                K = space_dict.shape[0]
+                segs = []
+                for l in range(len(self.layer)):
+                    n_in = run.n_in(l)
+                    xp = hidden.data_ptr() if l == 0 else run.ptr(l - 1, "y")
+                    segs.append((run.ptr(l, "logits") + 128 * 4, xp + D * 4, n_in - 1, 128, n_in * 128, D, n_in * D))
+                sd_txt_ft_all = hip.query_att_ft_multi_ptrs(segs, B, K, D, hidden.device, sd_dim=qm.att_dim)
+            else:
+                sd_txt_ft_all = qargs["att_ft"]
+        self._last_run = run
+        return _Out(run.output(len(self.layer) - 1)), sd_txt_ft_all
 
     def _project_encoder_tokens(self, encoder_hidden_states):
         """The cross-attention [k|v] projections of ALL layers in one GEMM per branch: the layers' fused key|value weights

@@ -522,3 +522,80 @@ extern "C" int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden
     return bert_rest_impl(w, att, mask2d, y, mask_out, ws, ws_bytes, B, L, *k_used, score, indices, indices_sort, cross_mode, enc0,
                           enc1, Nk, enc_mask0, enc_mask1, true, y_lp, kv_pre0, kv_pre1, kv_index, kv_ld, stream);
 }
+
+// ---- encoder-level entry points (include/madtp_hip.h): the layer loops of the two encoders in C --------------------------
+static int query_step(const madtp_query_w* q, const float* x, float* logits, int layer, int B, int N, int dim, void* stream) {
+    return madtp_query_model(x, q->sd_w, q->sd_hi, q->sd_lo, q->split_dtype, q->sd_scale, q->K, logits, q->att_ft, q->stats_ws,
+                             layer > 0 ? 1 : 0, q->inv_sqrt_sd, B, N, dim, stream);
+}
+
+extern "C" int madtp_vit_encoder(const madtp_vit_block_w* const* layers, int n_layers, const madtp_query_w* q, const float* x0,
+                                 madtp_layer_io* io, void* ws, size_t ws_bytes, int B, int N0, float temperature, void* stream) {
+    if (!layers || !io || !x0 || n_layers <= 0 || B <= 0 || N0 <= 0) return MADTP_E_BADARG;
+    const float* x = x0;
+    int N = N0;
+    const bool prune = q && temperature > 0.f;
+    const int kp = q ? (q->K + 127) / 128 * 128 : 0;
+    for (int l = 0; l < n_layers; ++l) {
+        madtp_layer_io& o = io[l];
+        const madtp_vit_block_w* w = layers[l];
+        if (!w || !o.x_attn || !o.y) return MADTP_E_BADARG;
+        if (q) {
+            if (!o.logits) return MADTP_E_BADARG;
+            TRY(query_step(q, x, o.logits, l, B, N, w->dim, stream));
+        }
+        int k_out = 0, k_used = 0;
+        if (prune)
+            TRY(madtp_vit_block(w, x, o.x_attn, o.y, ws, ws_bytes, B, N, o.logits + kp, kp, N * kp, q->K, temperature, o.score,
+                                o.threshold, o.count, o.indices, o.indices_sort, &k_out, &k_used, stream));
+        else
+            TRY(madtp_vit_block(w, x, o.x_attn, o.y, ws, ws_bytes, B, N, nullptr, 0, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr,
+                                nullptr, &k_out, &k_used, stream));
+        if (k_used > 0) N = k_used + 2;
+        o.k_out = k_out; o.k_used = k_used; o.n_out = N;
+        x = o.y;
+    }
+    return 0;
+}
+
+extern "C" int madtp_bert_encoder(const madtp_bert_layer_w* const* layers, int n_layers, const madtp_query_w* q, const float* hidden0,
+                                  const void* hidden0_lp, const float* mask0, madtp_layer_io* io, void* ws, size_t ws_bytes, int B,
+                                  int L0, int Nk, float temperature, int cross_mode, const void* enc0, const void* enc1,
+                                  const float* enc_mask0, const float* enc_mask1, const void* const* kv_pre0,
+                                  const void* const* kv_pre1, const int32_t* kv_index, int kv_ld, void* stream) {
+    if (!layers || !io || !hidden0 || n_layers <= 0 || B <= 0 || L0 <= 0) return MADTP_E_BADARG;
+    const float* h = hidden0;
+    const void* h_lp = hidden0_lp;
+    const float* mask = mask0;
+    int L = L0;
+    const bool prune = q && temperature > 0.f;
+    const int kp = q ? (q->K + 127) / 128 * 128 : 0;
+    for (int l = 0; l < n_layers; ++l) {
+        madtp_layer_io& o = io[l];
+        const madtp_bert_layer_w* w = layers[l];
+        if (!w || !o.x_attn || !o.y) return MADTP_E_BADARG;
+        if (q) {
+            if (!o.logits) return MADTP_E_BADARG;
+            TRY(query_step(q, h, o.logits, l, B, L, w->dim, stream));
+        }
+        int k_out = 0, k_used = 0;
+        const void* kv0 = kv_pre0 ? kv_pre0[l] : nullptr;
+        const void* kv1 = kv_pre1 ? kv_pre1[l] : nullptr;
+        if (prune)
+            TRY(madtp_bert_layer(w, h, mask, o.x_attn, o.y, o.mask_out, ws, ws_bytes, B, L, Nk, o.logits + kp, kp, L * kp, q->K,
+                                 temperature, o.score, o.threshold, o.count, o.indices, o.indices_sort, cross_mode, enc0, enc1,
+                                 enc_mask0, enc_mask1, h_lp, o.y_lp, kv0, kv1, kv_index, kv_ld, &k_out, &k_used, stream));
+        else
+            TRY(madtp_bert_layer(w, h, mask, o.x_attn, o.y, nullptr, ws, ws_bytes, B, L, Nk, nullptr, 0, 0, 0, 0.f, nullptr, nullptr,
+                                 nullptr, nullptr, nullptr, cross_mode, enc0, enc1, enc_mask0, enc_mask1, h_lp, o.y_lp, kv0, kv1,
+                                 kv_index, kv_ld, &k_out, &k_used, stream));
+        if (k_used > 0) {
+            L = k_used + 2;
+            if (mask) mask = o.mask_out;
+        }
+        o.k_out = k_out; o.k_used = k_used; o.n_out = L;
+        h = o.y;
+        h_lp = o.y_lp;
+    }
+    return 0;
+}

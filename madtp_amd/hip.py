@@ -12,7 +12,7 @@ import torch
 
 F32, BF16, F16S = 0, 1, 2  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -67,6 +67,10 @@ _SIGS = {
                         + [c_void_p] * 7 + [c_void_p]),
     "madtp_bert_layer": (c_int, [c_void_p] * 7 + [c_size_t, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
                          + [c_void_p] * 5 + [c_int] + [c_void_p] * 9 + [c_int] + [c_void_p] * 3),
+    "madtp_vit_encoder": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_float, c_void_p]),
+    "madtp_bert_encoder": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
+                                   c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_void_p]),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
     "madtp_gemm_pair": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float, c_float, c_void_p]),
     "madtp_attention_pair": (c_int, [c_void_p] * 11 + [c_int] * 8 + [c_float, c_int, c_void_p]),
@@ -97,6 +101,17 @@ class BertLayerW(ctypes.Structure):
                 ("ln_cross_g", c_void_p), ("ln_cross_b", c_void_p),
                 ("inter", LinStruct), ("out", LinStruct), ("ln_out_g", c_void_p), ("ln_out_b", c_void_p),
                 ("eps", c_float), ("scale", c_float), ("heads", c_int), ("dim", c_int), ("dtype", c_int)]
+
+
+class QueryW(ctypes.Structure):
+    _fields_ = [("sd_w", c_void_p), ("sd_hi", c_void_p), ("sd_lo", c_void_p), ("split_dtype", c_int), ("sd_scale", c_float),
+                ("K", c_int), ("inv_sqrt_sd", c_float), ("att_ft", c_void_p), ("stats_ws", c_void_p)]
+
+
+class LayerIO(ctypes.Structure):
+    _fields_ = [("logits", c_void_p), ("x_attn", c_void_p), ("y", c_void_p), ("y_lp", c_void_p), ("mask_out", c_void_p),
+                ("score", c_void_p), ("threshold", c_void_p), ("count", c_void_p), ("indices", c_void_p),
+                ("indices_sort", c_void_p), ("k_out", c_int), ("k_used", c_int), ("n_out", c_int)]
 
 
 def lin_struct(lin):
@@ -436,6 +451,19 @@ def query_att_ft_multi(pairs, out=None, sd_dim=768):
     return out
 
 
+def query_att_ft_multi_ptrs(segs_ptrs, B, K, dim, device, sd_dim=768):
+    """query_att_ft_multi from raw (token_attn ptr, ft ptr, n, ldt_row, ldt_batch, ldf_row, ldf_batch) tuples (the layers of an
+    encoder-level call: no tensor views are built)."""
+    segs = (AttFtSeg * len(segs_ptrs))()
+    for i, t in enumerate(segs_ptrs):
+        segs[i] = AttFtSeg(*t)
+    out = torch.empty((B, K, dim), device=device, dtype=torch.float32)
+    ws = torch.empty(len(segs_ptrs) * B * 256, device=device, dtype=torch.float32)
+    _check(load().madtp_query_att_ft_multi(segs, len(segs_ptrs), K, _p(out), _p(ws), 1.0 / (sd_dim ** 0.5), 0, B, dim, _stream()),
+           "madtp_query_att_ft_multi")
+    return out
+
+
 def add_scale(a, b, scale):
     out = torch.empty_like(a)
     _check(load().madtp_add_scale(_p(a), _p(b), _p(out), float(scale), a.numel(), _stream()), "madtp_add_scale")
@@ -745,3 +773,219 @@ def gemm_splitk_ln(a, w, bias, residual, gamma, beta, eps, splits, n, scale=1.0,
                                   dt_code(lp) if lp is not None else BF16, M, n, float(eps), w_scale_of(w), float(scale), _stream()),
            "madtp_splitk_ln")
     return y32, ylp
+
+
+# ---- encoder-level calls (madtp_vit_encoder / madtp_bert_encoder) ---------------------------------------------------------
+class LazyPruneInfo(dict):
+    """last_prune record of a layer run by an encoder-level call: the tensors (views of the call's one buffer) are only
+    created when the record is read - building ~70 views per forward eagerly would cost more host time than the call saved."""
+
+    def __init__(self, fill):
+        super().__init__()
+        self._fill_fn = fill
+
+    def _fill(self):
+        if self._fill_fn is not None:
+            fn, self._fill_fn = self._fill_fn, None
+            dict.update(self, fn())
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, d=None):
+        self._fill()
+        return dict.get(self, k, d)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __contains__(self, k):
+        self._fill()
+        return dict.__contains__(self, k)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+
+_ESZ = {torch.float32: 4, torch.int32: 4, torch.int64: 8, torch.bfloat16: 2, torch.float16: 2}
+
+
+_IO_NP = None
+_IO_LAYOUT = {}
+
+
+def _io_dtype():
+    """numpy mirror of LayerIO (same field order / offsets) so that a call's pointers are filled with one vector add."""
+    global _IO_NP
+    if _IO_NP is None:
+        import numpy as np
+        names = [f[0] for f in LayerIO._fields_]
+        fmts = ["u8"] * 10 + ["i4"] * 3
+        offs = [getattr(LayerIO, n).offset for n in names]
+        _IO_NP = np.dtype({"names": names, "formats": fmts, "offsets": offs, "itemsize": ctypes.sizeof(LayerIO)})
+    return _IO_NP
+
+
+class EncoderRun:
+    """Buffers and results of one encoder-level call: ONE device allocation carved per layer (sized for the unpruned sequence).
+    The per-layer offsets of a shape are computed once and cached; a call adds the buffer's base address to them."""
+    _FIELDS = ("logits", "x_attn", "y", "y_lp", "mask_out", "score", "threshold", "count", "indices", "indices_sort")
+
+    def __init__(self, n_layers, B, N0, D, device, want_logits, want_prune, want_mask, lp_dtype):
+        import numpy as np
+        self.n_layers, self.B, self.N0, self.D, self.lp_dtype = n_layers, B, N0, D, lp_dtype
+        key = (n_layers, B, N0, D, want_logits, want_prune, want_mask, lp_dtype)
+        lay = _IO_LAYOUT.get(key)
+        if lay is None:
+            lp_w = 0 if lp_dtype is None else (2 * D * 2 if lp_dtype == torch.float16 else D * 2)  # bytes per row of the lp copy
+            sizes = {"logits": B * N0 * 128 * 4 if want_logits else 0, "x_attn": B * N0 * D * 4, "y": B * N0 * D * 4,
+                     "y_lp": B * N0 * lp_w, "mask_out": B * N0 * 4 if want_mask else 0,
+                     "score": B * (N0 - 1) * 4 if want_prune else 0, "threshold": B * 4 if want_prune else 0,
+                     "count": B * 4 if want_prune else 0, "indices": B * (N0 - 1) * 8 if want_prune else 0,
+                     "indices_sort": B * (N0 - 1) * 8 if want_prune else 0}
+            # x_attn is scratch inside a layer: ONE buffer shared by all layers, placed behind the per-layer blocks
+            off, per = {}, 0
+            for f in self._FIELDS:
+                if f == "x_attn":
+                    continue
+                off[f] = per if sizes[f] else None
+                per += (sizes[f] + 255) // 256 * 256
+            xa = (sizes["x_attn"] + 255) // 256 * 256
+            rel = np.zeros((n_layers, 10), dtype=np.uint64)     # offsets relative to the aligned base; 0 rows masked below
+            present = np.zeros((10,), dtype=bool)
+            for j, f in enumerate(self._FIELDS):
+                if f == "x_attn":
+                    rel[:, j] = per * n_layers
+                    present[j] = True
+                elif off[f] is not None:
+                    rel[:, j] = np.arange(n_layers, dtype=np.uint64) * per + off[f]
+                    present[j] = True
+            lay = (off, per, per * n_layers + xa + 256, rel, present)
+            if len(_IO_LAYOUT) > 64:
+                _IO_LAYOUT.clear()
+            _IO_LAYOUT[key] = lay
+        self.off, self.per_layer, total, rel, present = lay
+        self.buf = torch.empty(total, dtype=torch.uint8, device=device)
+        ptr = self.buf.data_ptr()
+        base = (ptr + 255) // 256 * 256
+        self.base_off = base - ptr
+        self.io_np = np.zeros((n_layers,), dtype=_io_dtype())
+        ptrs = (rel + np.uint64(base)) * present.astype(np.uint64)
+        for j, f in enumerate(self._FIELDS):
+            self.io_np[f] = ptrs[:, j]
+        self.io_ptr = self.io_np.ctypes.data
+        self._n_out = None
+
+    def results(self):
+        """(k_out, k_used, n_out) lists, read once after the call."""
+        if self._n_out is None:
+            self._k_out = self.io_np["k_out"].tolist()
+            self._k_used = self.io_np["k_used"].tolist()
+            self._n_out = self.io_np["n_out"].tolist()
+        return self._k_out, self._k_used, self._n_out
+
+    def ptr(self, layer, field):
+        return int(self.io_np[field][layer])
+
+    def view(self, layer, field, dtype, *shape):
+        """tensor view of a layer's buffer (leading elements)."""
+        n = 1
+        for d in shape:
+            n *= d
+        if field == "x_attn":
+            start = self.base_off + self.per_layer * self.n_layers
+        else:
+            start = self.base_off + layer * self.per_layer + self.off[field]
+        return self.buf[start:start + n * _ESZ[dtype]].view(dtype).view(*shape)
+
+    def n_in(self, layer):
+        return self.N0 if layer == 0 else self.results()[2][layer - 1]
+
+    def info(self, layer, temperature):
+        """last_prune record of a layer (None when the layer ran without pruning scores)."""
+        if not temperature > 0:
+            return None
+        k_out, k_used_l, _ = self.results()
+        k, k_used, n = k_out[layer], k_used_l[layer], self.n_in(layer) - 1
+
+        def fill():
+            d = {"k": k, "score": self.view(layer, "score", torch.float32, self.B, n),
+                 "threshold": self.view(layer, "threshold", torch.float32, self.B),
+                 "count": self.view(layer, "count", torch.int32, self.B), "pruned": k_used > 0, "indices": None,
+                 "indices_sort": None}
+            if k_used > 0:
+                d["indices"] = self.view(layer, "indices", torch.int64, self.B, k_used)
+                d["indices_sort"] = self.view(layer, "indices_sort", torch.int64, self.B, n)
+            return d
+        return LazyPruneInfo(fill)
+
+    def output(self, layer):
+        return self.view(layer, "y", torch.float32, self.B, self.results()[2][layer], self.D)
+
+
+def _query_w(qargs):
+    """qargs: dict(sd_w, sd_hi, sd_lo, split_dtype, sd_scale, K, sd_dim, att_ft, stats_ws) -> (QueryW or None, keepalive)"""
+    if qargs is None:
+        return None
+    q = QueryW(_p(qargs["sd_w"]), _p(qargs.get("sd_hi")), _p(qargs.get("sd_lo")), qargs.get("split_dtype", BF16),
+               float(qargs.get("sd_scale", 1.0)), qargs["K"], 1.0 / (qargs["sd_dim"] ** 0.5), _p(qargs.get("att_ft")),
+               _p(qargs.get("stats_ws")))
+    return q
+
+
+def vit_encoder(weights, x, qargs, temperature):
+    """VisionTransformer's block loop in ONE library call.  weights: (list of VitBlockW, ctypes array of their addresses)
+    from runtime.EncoderWeights; x f32 [B,N,D] contiguous; qargs: query-model operands (see _query_w) or None.  -> EncoderRun."""
+    B, N, D = x.shape
+    lib = load()
+    wstructs, arr = weights
+    L = len(wstructs)
+    w0 = wstructs[0]
+    nbytes = lib.madtp_vit_block_workspace(B, N, w0.dim, w0.fc1.n, w0.heads, w0.dtype)
+    ws = workspace(nbytes, x.device)
+    prune = qargs is not None and temperature > 0
+    run = EncoderRun(L, B, N, D, x.device, qargs is not None, prune, False, None)
+    q = _query_w(qargs)
+    _check(lib.madtp_vit_encoder(arr, L, ctypes.byref(q) if q is not None else None, _p(x), run.io_ptr, _p(ws), ws.numel(), B, N,
+                                 float(temperature if prune else 0.0), _stream()), "madtp_vit_encoder")
+    run.keep = (x, wstructs, qargs)
+    return run
+
+
+def bert_encoder(weights, hidden, hidden_lp, mask2d, qargs, temperature, cross_mode, enc0, enc1, Nk, enc_mask0, enc_mask1,
+                 kv_pre0=None, kv_pre1=None, kv_index=None, kv_ld=0):
+    """BertEncoder's layer loop in ONE library call -> EncoderRun (y_lp of layer l: run.view(l, 'y_lp', ...))."""
+    B, Lq, D = hidden.shape
+    lib = load()
+    wstructs, arr = weights
+    L = len(wstructs)
+    w0 = wstructs[0]
+    nbytes = lib.madtp_bert_layer_workspace(B, Lq, Nk, w0.dim, w0.inter.n, w0.heads, w0.dtype)
+    ws = workspace(nbytes, hidden.device)
+    prune = qargs is not None and temperature > 0
+    lp_dtype = None if w0.dtype == F32 else (torch.float16 if w0.dtype == F16S else torch.bfloat16)
+    run = EncoderRun(L, B, Lq, D, hidden.device, qargs is not None, prune, mask2d is not None and prune, lp_dtype)
+    q = _query_w(qargs)
+    kv0 = (c_void_p * L)(*[_p(t) for t in kv_pre0]) if kv_pre0 is not None else None
+    kv1 = (c_void_p * L)(*[_p(t) for t in kv_pre1]) if kv_pre1 is not None else None
+    _check(lib.madtp_bert_encoder(arr, L, ctypes.byref(q) if q is not None else None, _p(hidden), _p(hidden_lp), _p(mask2d), run.io_ptr,
+                                  _p(ws), ws.numel(), B, Lq, Nk, float(temperature if prune else 0.0), int(cross_mode), _p(enc0),
+                                  _p(enc1), _p(enc_mask0), _p(enc_mask1), kv0, kv1, _p(kv_index), int(kv_ld), _stream()),
+           "madtp_bert_encoder")
+    run.keep = (hidden, hidden_lp, mask2d, wstructs, qargs, enc0, enc1, enc_mask0, enc_mask1, kv_pre0, kv_pre1, kv_index)
+    return run

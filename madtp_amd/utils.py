@@ -100,6 +100,41 @@ class Query_model(nn.Module):
             return DeferredAttFt(self.att_dim)
         return None
 
+    def _dictionary(self, sd):
+        """prepared dictionary operands: (f32 [128, dim] Lin, split planes or None)"""
+        sdl = self._cache.get(("sd", id(sd)), [sd], lambda: prepare_linear([sd], None, torch.float32))
+        split = None
+        if compute_dtype() == torch.bfloat16 and sdl.w.shape[0] == 128:
+            def _split():
+                hi = hip.cast_bf16(sdl.w)
+                lo = hip.cast_bf16((sdl.w - hi.float()).contiguous())
+                return hi, lo
+            split = self._cache.get(("sd_split", id(sd)), [sd], _split)
+        elif compute_dtype() == torch.float16 and sdl.w.shape[0] == 128:
+            def _split16():
+                q = hip.split_f16_weight(sdl.w)
+                d = sdl.w.shape[1]
+                return q[:, :d].contiguous(), q[:, d:].contiguous(), q._madtp_w_scale
+            split = self._cache.get(("sd_split16", id(sd)), [sd], _split16)
+        return sdl, split
+
+    def encoder_args(self, sd, B, dim, device):
+        """Operands of the query model for an encoder-level call (hip.vit_encoder / hip.bert_encoder): -> (qargs, deferred)
+        where deferred=True means att_ft is NOT accumulated by the call (fast mode: one launch over all layers afterwards).
+        None when this query model cannot run inside the encoder call (q_map)."""
+        if self.map_func:
+            return None, False
+        sdl, split = self._dictionary(sd)
+        K = sd.shape[0]
+        qa = {"sd_w": sdl.w, "K": K, "sd_dim": self.att_dim, "att_ft": None, "stats_ws": None}
+        if split is not None:
+            qa.update(sd_hi=split[0], sd_lo=split[1], split_dtype=hip.dt_code(split[0].dtype),
+                      sd_scale=split[2] if len(split) > 2 else 1.0)
+        deferred = self.compute_att_ft and split is not None and split[0].dtype == torch.bfloat16
+        if self.compute_att_ft and not deferred:
+            qa["att_ft"] = torch.empty((B, K, dim), device=device, dtype=torch.float32)
+        return qa, deferred
+
     def forward(self, ft, sd, mask=None, return_token_att=False, temperature=1, acc_ft=None, defer=None):
         """acc_ft (extension): running sum tensor to accumulate att_ft into (the encoders' `sd_ft_all += sd_ft`).
         defer (extension): a DeferredAttFt - att_ft is not computed here (returned as None) but summed by defer.finish()."""
@@ -109,23 +144,7 @@ class Query_model(nn.Module):
                                       "no reference call site on the pruned forward path uses it")
         B, n, D = ft.shape
         K = sd.shape[0]
-        sdl = self._cache.get(("sd", id(sd)), [sd], lambda: prepare_linear([sd], None, torch.float32))
-        split = None
-        if compute_dtype() == torch.bfloat16 and sdl.w.shape[0] == 128:
-            # fast mode: dictionary as a bf16 hi/lo pair for the split-precision logits kernel
-            def _split():
-                hi = hip.cast_bf16(sdl.w)
-                lo = hip.cast_bf16((sdl.w - hi.float()).contiguous())
-                return hi, lo
-            split = self._cache.get(("sd_split", id(sd)), [sd], _split)
-        elif compute_dtype() == torch.float16 and sdl.w.shape[0] == 128:
-            # f16x3 mode: dictionary as the f16 planes Q0 / Q1 of sd * 2^s (+ the accumulator scale 2^-s): fp32-accurate logits
-            # from three f16 MFMA products, x split in registers (madtp_align_logits, split_dtype F16S)
-            def _split16():
-                q = hip.split_f16_weight(sdl.w)
-                d = sdl.w.shape[1]
-                return q[:, :d].contiguous(), q[:, d:].contiguous(), q._madtp_w_scale
-            split = self._cache.get(("sd_split16", id(sd)), [sd], _split16)
+        sdl, split = self._dictionary(sd)  # fast mode: bf16 hi/lo planes; f16x3 mode: f16 planes Q0 / Q1 of sd * 2^s
         if self.map_func:
             # CLIP: q = q_map(ft) (clip/model.py:188, models/utils.py:160-163).  Mapped over ALL rows of the token buffer
             # when ft is x[:,1:,:] of a contiguous tensor (the CLS row is computed and ignored), then the same

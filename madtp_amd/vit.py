@@ -16,8 +16,12 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import PreparedCache, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
+from .runtime import EncoderWeights, PreparedCache, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model, vector_gather  # noqa: F401  (re-exported like `from models.utils import *`)
+
+import os as _os
+# MADTP_ENCODER_CALL=0: the per-layer path (one library call per Block / BertLayer) instead of the encoder-level calls (A/B runs)
+_ENCODER_CALL = _os.environ.get("MADTP_ENCODER_CALL", "1") != "0"
 
 
 class Mlp(nn.Module):
@@ -268,6 +272,10 @@ class VisionTransformer(nn.Module):
         token_num = x.shape[-2]
         reduce_num = int((token_num - 1) // self.depth)
         sd_img_ft_all = None
+        if register_blk == -1 and _ENCODER_CALL and all(type(b) is Block for b in self.blocks):
+            out = self._forward_encoder_call(x, space_dict, temperature, _pending)
+            if out is not None:
+                return out
         defer = self.img_query_model.deferred() if space_dict is not None else None
         for i, blk in enumerate(self.blocks):
             if space_dict is not None:
@@ -283,6 +291,66 @@ class VisionTransformer(nn.Module):
         B, N, D = x.shape
         y, _ = hip.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)  # :309
         return y, sd_img_ft_all
+
+
+def _vit_forward_encoder_call(self, x, space_dict, temperature, _pending):
+    """The block loop of forward() as ONE library call (madtp_vit_encoder): same kernels in the same order as the per-layer
+    path, without the return to Python between layers.  Returns None when the query model cannot run inside the call."""
+    B, N, D = x.shape
+    qm = self.img_query_model
+    qargs, deferred = (None, False)
+    if space_dict is not None:
+        qargs, deferred = qm.encoder_args(space_dict, B, D, x.device)
+        if qargs is None:
+            return None
+    ew = self.__dict__.get("_enc_weights")
+    if ew is None:
+        ew = self.__dict__["_enc_weights"] = EncoderWeights()
+    run = hip.vit_encoder(ew.get(list(self.blocks)), x, qargs, temperature if space_dict is not None else 0)
+    prune_t = temperature if (space_dict is not None and temperature > 0) else 0
+    for l, blk in enumerate(self.blocks):
+        blk.last_prune = run.info(l, prune_t)
+        blk.attn.score_side = None
+    sd_img_ft_all = None
+    if space_dict is not None and qm.compute_att_ft:
+        if deferred:  # fast mode: all layers' att_ft in one launch (on the auxiliary stream when the caller joins it later)
+            K = space_dict.shape[0]
+            segs, xin = [], x
+            for l in range(len(self.blocks)):
+                n_in = run.n_in(l)
+                lg = run.ptr(l, "logits")
+                xp = xin.data_ptr() if l == 0 else run.ptr(l - 1, "y")
+                segs.append((lg + 128 * 4, xp + D * 4, n_in - 1, 128, n_in * 128, D, n_in * D))
+
+            def launch():
+                return hip.query_att_ft_multi_ptrs(segs, B, K, D, x.device, sd_dim=qm.att_dim)
+            if _pending is None:
+                sd_img_ft_all = launch()
+            else:
+                from .runtime import side_stream
+                from .utils import _SideWork
+                main, side = torch.cuda.current_stream(), side_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    sd_img_ft_all = launch()
+                sd_img_ft_all.record_stream(main)
+                run.buf.record_stream(side)
+                _pending.append(_SideWork(side, (run, x)))
+        else:
+            sd_img_ft_all = qargs["att_ft"]
+    xo = run.output(len(self.blocks) - 1)
+    y, _ = hip.layernorm(xo, self.norm.weight, self.norm.bias, self.norm.eps)  # vit.py:309
+    self._last_run = run  # keeps the layers' buffers (and the lazily built last_prune views) alive until the next forward
+    return y, sd_img_ft_all
+
+
+def _vit_apply(self, fn, recurse=True):
+    self.__dict__.pop("_enc_weights", None)  # .to() / .half() may replace Parameter objects
+    return nn.Module._apply(self, fn, recurse)
+
+
+VisionTransformer._forward_encoder_call = _vit_forward_encoder_call
+VisionTransformer._apply = _vit_apply
 
 
 def interpolate_pos_embed(pos_embed_checkpoint, visual_encoder):

@@ -267,6 +267,42 @@ def test_fused_layer_calls_equal_two_step(mode):
                 assert info["pruned"] and torch.equal(info["indices"], idx) and torch.equal(info["indices_sort"], idx_sort)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "f16x3", "bf16"])
+def test_encoder_level_calls_equal_per_layer_path(mode, monkeypatch):
+    """madtp_vit_encoder / madtp_bert_encoder (one library call per encoder: the layer loop in C) give bit-identical results
+    to the per-layer path (one call per Block / BertLayer, Python in between): NLVR logits, every layer's pruning record, the
+    summed att_ft of both encoders; padded captions so that the text side prunes and compacts its mask as well."""
+    from madtp_amd import bert, build, harness, hip, runtime, vit
+    build.build(verbose=False)
+    hip.load()
+    model = harness.build_nlvr(224, 0, "cuda")
+    images, text, targets = harness.nlvr_inputs(3, 224, 35, seed=7, pad_tail=9)
+    results = []
+    for enc_call in (True, False):
+        monkeypatch.setattr(vit, "_ENCODER_CALL", enc_call)
+        monkeypatch.setattr(bert, "_ENCODER_CALL", enc_call)
+        with runtime.precision(mode):
+            logits, trace = harness.run_nlvr(model, images, text, targets, 30.0)
+        sd_img, sd_txt = model.last_sd_ft
+        torch.cuda.synchronize()
+        results.append((logits.clone(), trace, sd_img.clone(), sd_txt.clone()))
+    (la, ta, ia, xa), (lb, tb, ib, xb) = results
+    assert torch.equal(la, lb)
+    assert torch.equal(ia, ib) and torch.equal(xa, xb)
+    pruned_layers = 0
+    for side in ("vit", "text"):
+        for a, b in zip(ta[side], tb[side]):
+            assert (a is None) == (b is None)
+            if a is None:
+                continue
+            assert a["k"] == b["k"] and a["pruned"] == b["pruned"]
+            assert torch.equal(a["score"], b["score"]) and torch.equal(a["threshold"], b["threshold"]) and torch.equal(a["count"], b["count"])
+            if a["pruned"]:
+                pruned_layers += 1
+                assert torch.equal(a["indices"], b["indices"]) and torch.equal(a["indices_sort"], b["indices_sort"])
+    assert pruned_layers >= 6
+
+
 RETR_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "retr_*.npz")))
 
 
