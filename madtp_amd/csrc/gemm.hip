@@ -856,8 +856,9 @@ __global__ __launch_bounds__(512, 2) void gemm_sq_kernel(GemmArgs g) {
     int is_slot = lb, is_kt = 0, is_stage = 0;
     int issued = 0;
     auto tile_offsets = [&]() {
-        const int t = t0 + is_slot;
-        const int r0 = ld_a ? (t / g.ntn) * BM : (t % g.ntn) * BN;
+        int itm, itn;
+        tile_mn(g, t0 + is_slot, itm, itn);
+        const int r0 = ld_a ? itm * BM : itn * BN;
         const unsigned ld2 = (unsigned)(ld_a ? g.lda : g.ldw) * 2u;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -946,8 +947,9 @@ __global__ __launch_bounds__(512, 2) void gemm_sq_kernel(GemmArgs g) {
         for (int kt = 1; kt < nk; ++kt) SQ_SLAB(false)
 #undef SQ_SLAB
         { SQ_MFMA(ahi1, b1, 1) }
-        const int t = t0 + slot;
-        const int m0 = (t / g.ntn) * BM, n0 = (t % g.ntn) * BN + (wc >> 1) * 128;
+        int ctm, ctn;
+        tile_mn(g, t0 + slot, ctm, ctn);
+        const int m0 = ctm * BM, n0 = ctn * BN + (wc >> 1) * 128;
 #define EPI(ACT)                                                                                                  \
     if constexpr (LP_OUT) {                                                                                       \
         epilogue<OM, ACT, false, 8, 4, 256, 128>(g, acc, res, m0, n0, wr, wc & 1, l16, grp4, 0);                   \
@@ -1182,6 +1184,11 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     if (sq_ok) {
         g.ntm = (M + 255) / 256;
         g.ntn = (N + 255) / 256;
+        {
+            static int grp_env = -2;  // MADTP_GEMM_NGRP: column-group width of the tile order (0 / unset = row-panel major)
+            if (grp_env == -2) { const char* e = getenv("MADTP_GEMM_NGRP"); grp_env = e ? atoi(e) : 0; }
+            g.ngrp = (grp_env > 0 && grp_env < g.ntn) ? grp_env : 0;
+        }
         const int slots_max = (g.ntm * g.ntn + 7) / 8;
         const int grid = 8 * (slots_max < 32 ? slots_max : 32);
         const size_t lds = (size_t)2 * (256 + 256) * ROWB;
