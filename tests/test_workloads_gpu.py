@@ -43,3 +43,38 @@ def test_workload_matches_oracle_at_calibrated_temperature(name, B):
             assert torch.isfinite(a).all() and err < 0.15 * max(1.0, b.abs().max().item())
     # the analytic FLOP counter is consistent: pruned < unpruned, ratio in (0, 1)
     assert 0 < w.flops(lens) < w.flops(None)
+
+
+@pytest.mark.parametrize("name,task,B", [("nlvr", "retrieval", 8), ("clip", "retrieval_clip", 8)])
+def test_controller_closes_around_the_hip_forward(name, task, B):
+    """SURVEY 8(f) rank 3 on the GPU: the drivers' calculate_temperature() search (madtp_amd/controller.py, the ladder of the
+    named driver) with Cur_Gflops measured on the HIP forward itself - the analytic counter on the token counts the kernels
+    actually kept - converges to (1 - p) x the workload's unpruned GFLOPs within the driver's tolerance, and the per-epoch
+    controller started there stays inside one of its small steps of the target."""
+    from madtp_amd import build, controller as C, hip, runtime, workloads
+    build.build(verbose=False)
+    hip.load()
+    w = workloads.get(name)
+    model = w.build("cuda")
+    inp = w.inputs(B, 5)
+    full = C.workload_gflops(w, None)
+    target = full * (1 - w.p)
+    seen = []
+
+    def measure(T):
+        if T <= 0:
+            return full  # temperature 0 = no pruning (vit.py:192)
+        with runtime.precision("f16x3"), torch.no_grad():
+            w.step(model, inp, T)
+        g = C.workload_gflops(w, w.lens(model))
+        seen.append((T, g))
+        return g
+
+    tol = C.SEARCH[task][1]
+    # the drivers' figures are O(100) GFLOPs; rescale this workload's so that their absolute thresholds mean the same thing
+    scale = C.ORI_GFLOPS[task] / full
+    cur, T = C.calculate_temperature(lambda t: measure(t) * scale, full * scale, target * scale, task, max_iters=400)
+    assert abs(cur - target * scale) <= tol and T > 0, (cur, target * scale, T, seen[-3:])
+    assert len(seen) >= 3 and seen[-1][1] < 0.9 * full
+    log = C.run_controller(lambda t: measure(t) * scale, T, w.p, C.ORI_GFLOPS[task], 6, task)
+    assert all(abs(c - target * scale) <= 2 * tol for _, _, c in log), log
