@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 # roofline of the fp32-accurate GEMM in ALGORITHMIC flops (2MNK) is a third of the f16 dense peak.
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "f16x3": 2500.0 / 3.0}
 GEMM_DT = {"bf16": "bf16", "fp32": "f32", "f16x3": "f16s"}
-WS_MIN_M = 4096  # madtp_gemm runs 2-byte-operand problems with M >= 4096 (and no split-K) on gemm_ws_kernel (csrc/gemm.hip)
+WS_MIN_M = 4096  # madtp_gemm runs 2-byte-operand problems with M >= 4096 (and no split-K) on gemm_ws_kernel / gemm_sq_kernel (csrc/gemm.hip)
 METRIC = "images/sec forward, BLIP-base NLVR2 p=0.5 b64; pruned-token index match"
 
 
@@ -56,7 +56,7 @@ def gemm_breakdown(rows, steps):
 
 
 def measure_traffic(args):
-    """HBM-side bytes per launch of the dominant kernel (gemm_ws_kernel), collected as MI355X_MICROARCH.md prescribes:
+    """HBM-side bytes per launch of the dominant kernels (gemm_ws_kernel / gemm_sq_kernel), collected as MI355X_MICROARCH.md prescribes:
     FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --pmc X --kernel-trace` passes over a 1-step run of this very command,
     FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of 16-B/lane streams at 64 B; tools/pmc_calibrate.py confirmed the
     factor for this kernel's access pattern in round 1).  -> dict or None (no rocprofv3 / a pass failed)."""
@@ -80,8 +80,9 @@ def measure_traffic(args):
             c = sqlite3.connect(dbs[0])
             rows = c.execute("select name, count(*), sum(counter_value) from pmc_events where counter_name=? group by name",
                              (counter,)).fetchall()
-            n = sum(cnt for name, cnt, _ in rows if "gemm_ws_kernel" in name)
-            v = sum(val for name, _, val in rows if "gemm_ws_kernel" in name)
+            big = lambda name: "gemm_ws_kernel" in name or "gemm_sq_kernel" in name  # noqa: E731  (the two big-GEMM kernels)
+            n = sum(cnt for name, cnt, _ in rows if big(name))
+            v = sum(val for name, _, val in rows if big(name))
             if not n:
                 return None
             out[counter] = (n, v * 1024.0 / n)  # the counters are in KiB
@@ -94,7 +95,7 @@ def measure_traffic(args):
     return {"bytes_per_launch": int(2 * f_b + w_b), "fetch_size_raw_bytes_per_launch": int(f_b),
             "write_size_bytes_per_launch": int(w_b), "launches_profiled": f_n,
             "how": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace (separate passes) over a 1-step copy of the "
-                   "command, gemm_ws_kernel launches only; 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md)"}
+                   "command, gemm_ws_kernel + gemm_sq_kernel launches only; 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md)"}
 
 
 def main():
@@ -189,7 +190,7 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
             alg_bytes = sum(r["bytes"] for r in prof_rows if r["dtype"] == dt_name and r["M"] >= min_m)
-            kname = {"bf16": "gemm_ws_kernel (all bf16 madtp_gemm launches with M >= 4096: ViT qkv/proj/fc1/fc2, cross-attention K/V)",
+            kname = {"bf16": "gemm_ws_kernel + gemm_sq_kernel (all bf16 madtp_gemm launches with M >= 4096: ViT qkv/proj/fc1/fc2, cross-attention K/V; 256x128 wave-specialised or 256x256 tiles by round count)",
                      "f16x3": "gemm_ws_kernel<f16-split> (all madtp_gemm launches with M >= 4096; 3 f16 MFMA products per "
                               "logical product: achieved/peak are in algorithmic 2MNK flops, peak = f16 dense / 3)",
                      "fp32": "gemm_kernel<float> (madtp_gemm)"}[args.precision]

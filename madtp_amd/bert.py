@@ -72,8 +72,12 @@ class BertEmbeddings(nn.Module):
         if input_ids is None or position_ids is not None or past_key_values_length != 0:
             raise NotImplementedError("only the encoder use (input_ids, default positions) is on the pruned forward path")
         require_gpu(input_ids, "input_ids")
-        y32, _ = hip.bert_embed(input_ids.contiguous(), self.word_embeddings.weight, self.position_embeddings.weight,
-                                self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+        cdt = compute_dtype()
+        y32, ylp = hip.bert_embed(input_ids.contiguous(), self.word_embeddings.weight, self.position_embeddings.weight,
+                                  self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps,
+                                  lp=None if cdt == torch.float32 else cdt)
+        if ylp is not None:  # the first layer takes the compute-dtype copy from the embedding LayerNorm (no cast launch)
+            y32._madtp_lp = (ylp, y32._version)
         return y32
 
 
@@ -376,6 +380,10 @@ class _BertLayerBase(nn.Module):
         for src, ver, d, val in _ENC_STORE:
             if src is enc and ver == enc._version and d == dt:
                 return val
+        lp = getattr(enc, "_madtp_lp", None)  # compute-dtype copy emitted by the producer (the ViT's final LayerNorm)
+        if (lp is not None and lp[1] == enc._version and dt != torch.float32 and lp[0].dtype == dt and lp[0].is_contiguous()
+                and lp[0].shape[:-1] == enc.shape[:-1]):
+            return lp[0].view(-1, lp[0].shape[-1])
         e = as_f32_contig(enc)
         val = _cast(e.view(-1, e.shape[-1]))
         _ENC_STORE.append((enc, enc._version, dt, val))
@@ -566,7 +574,12 @@ class _BertEncoderBase(nn.Module):
             else:
                 sd_txt_ft_all = qargs["att_ft"]
         self._last_run = run
-        return _Out(run.output(len(self.layer) - 1)), sd_txt_ft_all
+        out = run.output(len(self.layer) - 1)
+        if run.lp_dtype is not None:  # compute-dtype copy of the last layer's output (emitted by its output LayerNorm)
+            nl = len(self.layer) - 1
+            out._madtp_lp = (run.view(nl, "y_lp", run.lp_dtype, B, out.shape[1], (2 * D if run.lp_dtype == torch.float16 else D)),
+                             out._version)
+        return _Out(out), sd_txt_ft_all
 
     def _project_encoder_tokens(self, encoder_hidden_states):
         """The cross-attention [k|v] projections of ALL layers in one GEMM per branch: the layers' fused key|value weights
@@ -648,6 +661,8 @@ class _BertModelBase(nn.Module):
         else:
             raise ValueError("Wrong shape for input_ids (shape {}) or attention_mask (shape {})".format(
                 input_shape, attention_mask.shape))
+        if not ext.dtype.is_floating_point:  # {0,1} masks: the same values (up to the sign of zero) in two launches instead of three
+            return torch.where(ext != 0, 0.0, -10000.0)
         return (1.0 - ext.to(torch.float32)) * -10000.0
 
     def invert_attention_mask(self, m):
@@ -673,7 +688,8 @@ class _BertModelBase(nn.Module):
         ext = self.get_extended_attention_mask(attention_mask, (batch_size, seq_length), device, False)
         if encoder_hidden_states is not None:
             if isinstance(encoder_hidden_states, list):
-                enc_ext = [self.invert_attention_mask(m) for m in encoder_attention_mask]
+                # (None entry: no padding in that image's tokens - the same values as an all-ones mask without its launches)
+                enc_ext = [None if m is None else self.invert_attention_mask(m) for m in encoder_attention_mask]
             elif encoder_attention_mask is None:
                 enc_ext = None
             else:

@@ -76,19 +76,27 @@ class BLIP_NLVR(nn.Module):
         pending = []
         image_embeds, sd_img_ft = self.visual_encoder(image, space_dict=self.space_dict, temperature=temperature,
                                                       _pending=pending)  # :64
-        image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
+        # :65 image_atts = ones: every image token is valid, so the cross-attention masks are all zero - passed as None (same
+        # values, without the six mask-building launches per forward)
         image0_embeds, image1_embeds = torch.split(image_embeds, targets.size(0))  # :67
+        lp = getattr(image_embeds, "_madtp_lp", None)
+        if lp is not None and lp[1] == image_embeds._version:  # the compute-dtype copy of the final LayerNorm, split alike
+            lp0, lp1 = torch.split(lp[0], targets.size(0))
+            image0_embeds._madtp_lp, image1_embeds._madtp_lp = (lp0, image0_embeds._version), (lp1, image1_embeds._version)
         ids, att = self._tokens(text, image.device)
         output, sd_txt_ft = self.text_encoder(ids, attention_mask=att,
                                               encoder_hidden_states=[image0_embeds, image1_embeds],
-                                              encoder_attention_mask=[image_atts[:image0_embeds.size(0)],
-                                                                      image_atts[image0_embeds.size(0):]],
+                                              encoder_attention_mask=[None, None],
                                               return_dict=True, space_dict=self.space_dict, temperature=temperature)
         hidden_state = output.last_hidden_state[:, 0, :]  # :80
-        h = hidden_state.contiguous()
         l0 = lin_of(self._cache, "c0", [self.cls_head[0]])
         l2 = lin_of(self._cache, "c2", [self.cls_head[2]])
-        h = to_compute(h)
+        lp = getattr(output.last_hidden_state, "_madtp_lp", None)
+        if (lp is not None and lp[1] == output.last_hidden_state._version and lp[0].dtype == compute_dtype()
+                and compute_dtype() == torch.bfloat16):
+            h = lp[0][:, 0, :]  # strided [B, dim] view of the compute-dtype copy: the GEMM reads the CLS rows in place
+        else:
+            h = to_compute(hidden_state.contiguous())
         h = hip.gemm(h, l0.w, l0.b, act=hip.ACT_RELU, n=l0.n)
         logits = hip.gemm(h, l2.w, l2.b, out_dtype=torch.float32, n=l2.n)  # :81
         for p in pending:

@@ -289,8 +289,7 @@ class VisionTransformer(nn.Module):
         if defer is not None and defer.pairs:
             sd_img_ft_all = defer.finish(_pending)
         B, N, D = x.shape
-        y, _ = hip.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)  # :309
-        return y, sd_img_ft_all
+        return _final_norm(self, x), sd_img_ft_all  # :309
 
 
 def _vit_forward_encoder_call(self, x, space_dict, temperature, _pending):
@@ -339,9 +338,20 @@ def _vit_forward_encoder_call(self, x, space_dict, temperature, _pending):
         else:
             sd_img_ft_all = qargs["att_ft"]
     xo = run.output(len(self.blocks) - 1)
-    y, _ = hip.layernorm(xo, self.norm.weight, self.norm.bias, self.norm.eps)  # vit.py:309
+    y = _final_norm(self, xo)  # vit.py:309
     self._last_run = run  # keeps the layers' buffers (and the lazily built last_prune views) alive until the next forward
     return y, sd_img_ft_all
+
+
+def _final_norm(self, x):
+    """vit.py:309; in the low-precision modes the LayerNorm also emits the compute-dtype copy of its output, which rides on the
+    returned tensor (`_madtp_lp`) for consumers that feed it to a GEMM (the text encoders' cross-attention K/V projections) -
+    they would otherwise cast the f32 image tokens again."""
+    cdt = compute_dtype()
+    y, ylp = hip.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps, lp=None if cdt == torch.float32 else cdt)
+    if ylp is not None:
+        y._madtp_lp = (ylp, y._version)
+    return y
 
 
 def _vit_apply(self, fn, recurse=True):
