@@ -47,8 +47,14 @@ _ENC_STORE = []
 # instead of 24 x 17.8 us of GEMM, but the strided K/V rows cost the 24 cross-attention kernels 6.7 -> 8.1 us each and the two
 # chip-filling GEMMs no longer leave room for the vision encoder's deferred att_ft kernel on the auxiliary stream).
 _KV_AHEAD = os.environ.get("MADTP_KV_AHEAD", "0") == "1"
-# MADTP_ENCODER_CALL=0: one library call per BertLayer (and a return to Python between layers) instead of madtp_bert_encoder
-_ENCODER_CALL = os.environ.get("MADTP_ENCODER_CALL", "1") != "0"
+# MADTP_ENCODER_CALL (see madtp_amd/vit.py): "auto" = madtp_bert_encoder for small batches only (up to ENCODER_CALL_MAX_SAMPLES
+# samples: the text side has ~20-35 rows per sample, so the criterion is the batch), "1" always, "0" one call per BertLayer
+_ENCODER_CALL = {"0": False, "1": True}.get(os.environ.get("MADTP_ENCODER_CALL", "auto"), "auto")
+ENCODER_CALL_MAX_SAMPLES = 32
+
+
+def _use_encoder_call(B, flag):
+    return (B <= ENCODER_CALL_MAX_SAMPLES) if flag == "auto" else bool(flag)
 
 
 def _cast(x2d):
@@ -453,7 +459,8 @@ class _BertEncoderBase(nn.Module):
              mode, always_query):
         sd_txt_ft_all = None
         cache = self.__dict__.pop("_kv_cache", None)  # EncoderKVCache for THIS call (MedBertModel.forward(encoder_kv_cache=...))
-        if _ENCODER_CALL and not _KV_AHEAD and all(type(l) is self.layer_cls for l in self.layer):
+        if (_use_encoder_call(hidden_states.shape[0], _ENCODER_CALL) and not _KV_AHEAD
+                and all(type(l) is self.layer_cls for l in self.layer)):
             out = self._run_encoder_call(hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states,
                                          encoder_attention_mask, mode, always_query, cache)
             if out is not None:
@@ -498,6 +505,20 @@ class _BertEncoderBase(nn.Module):
     def _apply(self, fn, recurse=True):
         self.__dict__.pop("_enc_weights", None)  # .to() / .half() may replace Parameter objects
         return super()._apply(fn, recurse)
+
+    def _encoder_weights(self):
+        ew = self.__dict__.get("_enc_weights")
+        if ew is None:
+            ew = self.__dict__["_enc_weights"] = EncoderWeights()
+        return ew.get(list(self.layer))
+
+    def prepare_encoder_call(self, batch=None):
+        """Optional hint (extension): validate / build the layers' weight structs NOW - a task model calls it before it runs
+        the vision encoder, so that the ~0.1 ms pass over this encoder's ~500 parameters overlaps GPU work instead of sitting
+        between the embedding kernel and the first layer.  Consumed by the next forward of this encoder."""
+        if (batch is None or _use_encoder_call(batch, _ENCODER_CALL)) and _ENCODER_CALL and not _KV_AHEAD \
+                and all(type(l) is self.layer_cls for l in self.layer):
+            self.__dict__["_prepared_weights"] = self._encoder_weights()
 
     def _run_encoder_call(self, hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states,
                           encoder_attention_mask, mode, always_query, cache):
@@ -545,10 +566,9 @@ class _BertEncoderBase(nn.Module):
         if lp is not None and (lp[1] != hidden._version or hidden is not hidden_states or lp[0].shape[:-1] != hidden.shape[:-1]
                                or compute_dtype() == torch.float32 or lp[0].dtype != compute_dtype()):
             lp = None
-        ew = self.__dict__.get("_enc_weights")
-        if ew is None:
-            ew = self.__dict__["_enc_weights"] = EncoderWeights()
-        ws = ew.get(list(self.layer))
+        ws = self.__dict__.pop("_prepared_weights", None)  # validated by prepare_encoder_call() earlier in this forward
+        if ws is None:
+            ws = self._encoder_weights()
         kv_ld = 0
         if kv0 is not None:
             for tns in kv0:

@@ -74,6 +74,8 @@ class BLIP_NLVR(nn.Module):
         # sd_img_ft only feeds the training loss (:86-96): its (fast-mode) sum over the layers runs on the auxiliary stream,
         # under the text encoder, and is joined before this forward returns
         pending = []
+        ids, att = self._tokens(text, image.device)  # (:68-69; before the vision encoder: host work that does not depend on it)
+        self.text_encoder.encoder.prepare_encoder_call(ids.shape[0])
         image_embeds, sd_img_ft = self.visual_encoder(image, space_dict=self.space_dict, temperature=temperature,
                                                       _pending=pending)  # :64
         # :65 image_atts = ones: every image token is valid, so the cross-attention masks are all zero - passed as None (same
@@ -83,7 +85,6 @@ class BLIP_NLVR(nn.Module):
         if lp is not None and lp[1] == image_embeds._version:  # the compute-dtype copy of the final LayerNorm, split alike
             lp0, lp1 = torch.split(lp[0], targets.size(0))
             image0_embeds._madtp_lp, image1_embeds._madtp_lp = (lp0, image0_embeds._version), (lp1, image1_embeds._version)
-        ids, att = self._tokens(text, image.device)
         output, sd_txt_ft = self.text_encoder(ids, attention_mask=att,
                                               encoder_hidden_states=[image0_embeds, image1_embeds],
                                               encoder_attention_mask=[None, None],

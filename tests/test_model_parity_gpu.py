@@ -270,7 +270,7 @@ def test_fused_layer_calls_equal_two_step(mode):
 @pytest.mark.parametrize("mode", ["fp32", "f16x3", "bf16"])
 def test_encoder_level_calls_equal_per_layer_path(mode, monkeypatch):
     """madtp_vit_encoder / madtp_bert_encoder (one library call per encoder: the layer loop in C) give bit-identical results
-    to the per-layer path (one call per Block / BertLayer, Python in between): NLVR logits, every layer's pruning record, the
+    to the per-layer path (one call per Block / BertLayer, Python in between; `_ENCODER_CALL` = True / False forces either): NLVR logits, every layer's pruning record, the
     summed att_ft of both encoders; padded captions so that the text side prunes and compacts its mask as well."""
     from madtp_amd import bert, build, harness, hip, runtime, vit
     build.build(verbose=False)
