@@ -877,10 +877,11 @@ int launch_attn_large(const AttnArgs& a, hipStream_t s) {
 //   * the 128-key chunks of K (pass A) and K|V (pass B) stream through a 2-stage LDS ring by LDS-DMA: the chunk after the
 //     current one - across pass and head boundaries - is in flight while the current one is computed, one barrier per chunk;
 //   * exp via v_exp_f32, one reciprocal per row.
-// The head-max stays in registers for all key tiles (NT x 4 floats per lane: 160 at 577 keys, 228 at 901), one wave per SIMD.
+// The head-max stays in registers for all key tiles as packed f16 pairs (NT x 2 registers per lane: 80 at 577 keys, 114 at 901),
+// two 4-wave workgroups per CU up to 640 keys (the 1024-key instantiation would spill at 256 registers and keeps one).
 // Work per (b, h): 6 Nq Nk 64 flop (Q K^T twice) on the bf16 MFMA; the bound is the VALU softmax work (2 exp per score).
 template <int NCH, bool SCORES>
-__global__ __launch_bounds__(256, 1) void attn_bf16_large_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (NCH <= 5 || !SCORES) ? 2 : 1) void attn_bf16_large_kernel(AttnArgs a) {
     constexpr int CK = 128;                   // keys per chunk
     constexpr int STAGE = 2 * CK * 128;       // K image (128-byte rows), then V image
     constexpr int NT = NCH * 8;
@@ -897,10 +898,14 @@ __global__ __launch_bounds__(256, 1) void attn_bf16_large_kernel(AttnArgs a) {
     const int irow = min(i0 + l16, a.Nq - 1);
     const int nch = (a.Nk + CK - 1) / CK;
 
-    f32x4 pmax[SCORES ? NT : 1];
+    // head-max of P for all key tiles, held as PACKED f16 pairs (probabilities <= 1: 2^-11 relative rounding, the column sums
+    // over ~N rows average it out; halves the registers of this array - 114 instead of 228 at 901 keys - so that two
+    // workgroups fit a CU, and the update is one v_pk_max_f16 per two values)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 pmax[SCORES ? NT : 1][2];
     if constexpr (SCORES) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) pmax[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t) { pmax[t][0] = (h2){0, 0}; pmax[t][1] = (h2){0, 0}; }
     }
 
     // LDS-DMA of one chunk: 16 K and 16 V instructions of 8 rows (1 KiB) each, 4 + 4 per wave.  Swizzles on the SOURCE address
@@ -1018,9 +1023,13 @@ __global__ __launch_bounds__(256, 1) void attn_bf16_large_kernel(AttnArgs a) {
 #define PM_CASE(C)                                                                                      \
     case C:                                                                                             \
         if constexpr (C < NCH) {                                                                        \
-            _Pragma("unroll") for (int t = 0; t < 8; ++t)                                               \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r)                                           \
-                    pmax[(C < NCH ? C : 0) * 8 + t][r] = fmaxf(pmax[(C < NCH ? C : 0) * 8 + t][r], sc[t][r]); \
+            _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                             \
+                constexpr int TT = (C < NCH ? C : 0) * 8;                                               \
+                const h2 lo = (h2){(_Float16)sc[t][0], (_Float16)sc[t][1]}; /* round-to-nearest: rtz would bias the column sums */                           \
+                const h2 hi = (h2){(_Float16)sc[t][2], (_Float16)sc[t][3]};                           \
+                pmax[TT + t][0] = __builtin_elementwise_max(pmax[TT + t][0], lo);                       \
+                pmax[TT + t][1] = __builtin_elementwise_max(pmax[TT + t][1], hi);                       \
+            }                                                                                           \
         }                                                                                               \
         break;
                 switch (c) { PM_CASE(0) PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7) default: break; }
@@ -1078,7 +1087,7 @@ __global__ __launch_bounds__(256, 1) void attn_bf16_large_kernel(AttnArgs a) {
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = row16_sum(valid ? pmax[t][r] : 0.f);
+                    const float v = row16_sum(valid ? (float)pmax[t][r >> 1][r & 1] : 0.f);
                     const int j = 16 * t + 4 * g + r;
                     if (l16 == 0 && j < a.Nk) dst[j] = v;
                 }
