@@ -212,7 +212,9 @@ int madtp_query_att_ft(const float* token_attn, int ldt_row, int ldt_batch, int 
 /* fast != 0: bf16-MFMA variant (fast mode), needs stats_ws = B*256 floats of scratch; 0: exact-f32 MFMA (stats_ws unused) */
 
 /* The encoders' running sum  sd_ft_all = sum over layers l of att_ft_l  (vit.py:297-303, nlvr_encoder.py:608-613) in ONE
- * launch (fast mode, bf16 MFMA): segment l is layer l's (token_attn, ft) pair with the strides of madtp_query_att_ft;
+ * launch: segment l is layer l's (token_attn, ft) pair with the strides of madtp_query_att_ft.  stats_ws != NULL (nseg*B*256
+ * floats): fast mode, bf16 MFMA; stats_ws == NULL: the exact-f32 arithmetic of madtp_query_att_ft(fast = 0) with the
+ * per-layer summation order kept, i.e. bit-identical to accumulating layer by layer (parity modes);
  * the [K,dim] block of a sample stays in registers across the segments and is written once.  The caller keeps every
  * layer's token buffer and logits alive until the stream has run this call. */
 typedef struct madtp_att_ft_seg {

@@ -748,6 +748,114 @@ constexpr int AB_TCH = 32, AB_WP = 144, AB_COLS = 128, AB_XP = AB_COLS + 16, AB_
 struct AttFtSeg { const float* ta; const float* ft; int n, ldt, ldb, ldf, ldfb; };
 struct AttFtSegs { AttFtSeg s[AB_MAXSEG]; int nseg; };
 
+// Parity-mode counterpart of the segment walk (exact-f32 MFMA, expf, true division - the arithmetic of query_att_ft_kernel):
+// per segment the block [K, 256] of the sample is accumulated from zero in one register set and then added to the running
+// sum in a second one, i.e. exactly the values `out += att_ft_l` produced layer by layer - without the read-modify-write of the
+// [B, K, dim] sum per layer and in one launch (it can run on the auxiliary stream like the fast-mode kernel).
+__global__ __launch_bounds__(256) void query_att_ft_exact_multi_kernel(AttFtSegs segs, int K, float* __restrict__ out,
+                                                                       float inv_sqrt_sd, int accumulate, int dim) {
+    __shared__ float mx[128], sm[128];
+    __shared__ float part[2][128];
+    __shared__ float wl[AF_TCHUNK * AF_KP];  // [t][c]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int d0 = blockIdx.x * 256 + wave * 64 + l16;
+    f32x4 tot[7][4];
+#pragma unroll
+    for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) tot[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int si = 0; si < segs.nseg; ++si) {
+        const AttFtSeg sg = segs.s[si];
+        const int n = sg.n, ldt = sg.ldt, ldf = sg.ldf;
+        const float* ta_b = sg.ta + (size_t)b * sg.ldb;
+        const float* xb = sg.ft + (size_t)b * sg.ldfb;
+        __syncthreads();
+        {
+            const int c = tid & 127, sl = tid >> 7;
+            const int t0 = sl ? n / 2 : 0, t1 = sl ? n : n / 2;
+            float m = -INFINITY;
+            if (c < K) {
+#pragma unroll 8
+                for (int t = t0; t < t1; ++t) m = fmaxf(m, ta_b[(size_t)t * ldt + c] * inv_sqrt_sd);
+            }
+            part[sl][c] = m;
+            __syncthreads();
+            m = fmaxf(part[0][c], part[1][c]);
+            __syncthreads();
+            float s = 0.f;
+            if (c < K) {
+#pragma unroll 8
+                for (int t = t0; t < t1; ++t) s += expf(ta_b[(size_t)t * ldt + c] * inv_sqrt_sd - m);
+            }
+            part[sl][c] = s;
+            __syncthreads();
+            if (tid < 128) { mx[tid] = m; sm[tid] = c < K ? part[0][c] + part[1][c] : 1.f; }
+            __syncthreads();
+        }
+        f32x4 acc[7][4];
+#pragma unroll
+        for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int tc = 0; tc < n; tc += AF_TCHUNK) {
+            const int tn = min(AF_TCHUNK, n - tc);
+            const int tn4 = (tn + 3) & ~3;
+            __syncthreads();
+            for (int idx = tid; idx < tn4 * AF_KP; idx += 256) {
+                const int t = idx / AF_KP, c = idx % AF_KP;
+                float w = 0.f;
+                if (t < tn && c < K) w = expf(ta_b[(size_t)(tc + t) * ldt + c] * inv_sqrt_sd - mx[c]) / sm[c];
+                wl[idx] = w;
+            }
+            __syncthreads();
+            for (int t4 = 0; t4 < tn; t4 += 4) {
+                const int t = t4 + g;
+                float xv[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) xv[nt] = t < tn ? xb[(size_t)(tc + t) * ldf + d0 + 16 * nt] : 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 7; ++mt) {
+                    const float w = wl[t * AF_KP + mt * 16 + l16];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xv[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        // running sum in layer order: the first segment of a non-accumulating call initialises it (x + 0 would also be exact,
+        // but -0 + 0 is not -0), later ones add - the same roundings as `out = out + att_ft_l` per layer
+        const bool first = si == 0 && !accumulate;
+#pragma unroll
+        for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) tot[mt][nt] = first ? acc[mt][nt] : tot[mt][nt] + acc[mt][nt];
+        if (si == 0 && accumulate) {  // continue a sum that already lives in `out`: out + att_ft_0 first
+#pragma unroll
+            for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = mt * 16 + g * 4 + r;
+                    if (c < K) {
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) tot[mt][nt][r] = out[((size_t)b * K + c) * dim + d0 + 16 * nt] + acc[mt][nt][r];
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = mt * 16 + g * 4 + r;
+            if (c < K) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) out[((size_t)b * K + c) * dim + d0 + 16 * nt] = tot[mt][nt][r];
+            }
+        }
+}
+
 // stats[(seg*B + b)*256 + c] = max_t logit*inv, [.. + 128 + c] = 1 / sum_t exp(logit*inv - max)  (0 for c >= K)
 __global__ __launch_bounds__(256) void att_ft_stats_kernel(AttFtSegs segs, int K, float inv_sqrt_sd, float* __restrict__ stats) {
     __shared__ __attribute__((aligned(16))) float part[AB_SL][128];
@@ -1451,8 +1559,25 @@ extern "C" int madtp_query_att_ft(const float* token_attn, int ldt, int ldb, int
 
 extern "C" int madtp_query_att_ft_multi(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float* stats_ws,
                                         float inv_sqrt_sd, int accumulate, int B, int dim, void* stream) {
-    if (!segs || !out || !stats_ws || nseg < 1 || B <= 0) return MADTP_E_BADARG;
+    if (!segs || !out || nseg < 1 || B <= 0) return MADTP_E_BADARG;
     if (K <= 0 || K > 112 || dim % AB_COLS) return MADTP_E_SHAPE;
+    if (!stats_ws) {  // parity modes: exact-f32 arithmetic, the per-layer summation order kept (see the kernel)
+        if (dim % 256) return MADTP_E_SHAPE;
+        for (int first = 0; first < nseg; first += AB_MAXSEG) {
+            AttFtSegs a;
+            a.nseg = nseg - first < AB_MAXSEG ? nseg - first : AB_MAXSEG;
+            for (int i = 0; i < a.nseg; ++i) {
+                const madtp_att_ft_seg& g = segs[first + i];
+                if (!g.token_attn || !g.ft || g.n < 1) return MADTP_E_BADARG;
+                if (g.ldt_row < K) return MADTP_E_SHAPE;
+                a.s[i] = AttFtSeg{g.token_attn, g.ft, g.n, g.ldt_row, g.ldt_batch, g.ldf_row, g.ldf_batch};
+            }
+            hipLaunchKernelGGL(query_att_ft_exact_multi_kernel, dim3(dim / 256, B), dim3(256), 0, (hipStream_t)stream, a, K, out,
+                               inv_sqrt_sd, (accumulate || first > 0) ? 1 : 0, dim);
+            MADTP_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     for (int first = 0; first < nseg; first += AB_MAXSEG) {
         AttFtSegs a;
         a.nseg = nseg - first < AB_MAXSEG ? nseg - first : AB_MAXSEG;

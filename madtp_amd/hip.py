@@ -432,9 +432,9 @@ class AttFtSeg(ctypes.Structure):
                 ("ldf_row", c_int), ("ldf_batch", c_int)]
 
 
-def query_att_ft_multi(pairs, out=None, sd_dim=768):
+def query_att_ft_multi(pairs, out=None, sd_dim=768, exact=False):
     """pairs: list of (token_attn [B,n,K] view, ft [B,n,dim] f32 view) of the layers of an encoder -> their summed att_ft
-    [B,K,dim] in one launch (fast mode)."""
+    [B,K,dim] in one launch (fast mode: bf16 MFMA; exact=True: the exact-f32 kernel, bit-identical to summing layer by layer)."""
     segs = (AttFtSeg * len(pairs))()
     for i, (ta, ft) in enumerate(pairs):
         fp, ldf, ldfb, dim = _ta_view(ft)
@@ -445,20 +445,20 @@ def query_att_ft_multi(pairs, out=None, sd_dim=768):
     if out is None:
         out = torch.empty((B, K, dim), device=pairs[0][1].device, dtype=torch.float32)
         acc = 0
-    ws = torch.empty(len(pairs) * B * 256, device=out.device, dtype=torch.float32)
+    ws = None if exact else torch.empty(len(pairs) * B * 256, device=out.device, dtype=torch.float32)
     _check(load().madtp_query_att_ft_multi(segs, len(pairs), K, _p(out), _p(ws), 1.0 / (sd_dim ** 0.5), acc, B, dim,
                                            _stream()), "madtp_query_att_ft_multi")
     return out
 
 
-def query_att_ft_multi_ptrs(segs_ptrs, B, K, dim, device, sd_dim=768):
+def query_att_ft_multi_ptrs(segs_ptrs, B, K, dim, device, sd_dim=768, exact=False):
     """query_att_ft_multi from raw (token_attn ptr, ft ptr, n, ldt_row, ldt_batch, ldf_row, ldf_batch) tuples (the layers of an
     encoder-level call: no tensor views are built)."""
     segs = (AttFtSeg * len(segs_ptrs))()
     for i, t in enumerate(segs_ptrs):
         segs[i] = AttFtSeg(*t)
     out = torch.empty((B, K, dim), device=device, dtype=torch.float32)
-    ws = torch.empty(len(segs_ptrs) * B * 256, device=device, dtype=torch.float32)
+    ws = None if exact else torch.empty(len(segs_ptrs) * B * 256, device=device, dtype=torch.float32)
     _check(load().madtp_query_att_ft_multi(segs, len(segs_ptrs), K, _p(out), _p(ws), 1.0 / (sd_dim ** 0.5), 0, B, dim, _stream()),
            "madtp_query_att_ft_multi")
     return out

@@ -39,8 +39,8 @@ class DeferredAttFt:
     only record their (logits, token rows) pair - both stay alive as ordinary tensors - and finish() sums all the
     layers' att_ft in ONE kernel (madtp_query_att_ft_multi) instead of a 39 MB read-modify-write per layer."""
 
-    def __init__(self, sd_dim):
-        self.pairs, self.sd_dim = [], sd_dim
+    def __init__(self, sd_dim, exact=False):
+        self.pairs, self.sd_dim, self.exact = [], sd_dim, exact
 
     def add(self, token_att, ft):
         self.pairs.append((token_att, ft))
@@ -51,14 +51,14 @@ class DeferredAttFt:
         if not self.pairs:
             return None
         if pending is None:
-            out = hip.query_att_ft_multi(self.pairs, sd_dim=self.sd_dim)
+            out = hip.query_att_ft_multi(self.pairs, sd_dim=self.sd_dim, exact=self.exact)
             self.pairs = []
             return out
         from .runtime import side_stream
         main, side = torch.cuda.current_stream(), side_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            out = hip.query_att_ft_multi(self.pairs, sd_dim=self.sd_dim)
+            out = hip.query_att_ft_multi(self.pairs, sd_dim=self.sd_dim, exact=self.exact)
         out.record_stream(main)
         pending.append(_SideWork(side, self.pairs))  # the handle keeps the layers' tensors alive until the wait
         self.pairs = []
@@ -94,10 +94,11 @@ class Query_model(nn.Module):
         self.compute_att_ft = True  # att_ft only feeds the training loss (blip_nlvr.py:86-96); eval callers may clear
 
     def deferred(self):
-        """A DeferredAttFt for an encoder loop, or None when att_ft must be produced per call (parity mode keeps the
-        reference's per-layer summation order; no q_map: the mapped q of CLIP is a per-layer temporary)."""
-        if compute_dtype() == torch.bfloat16 and self.compute_att_ft and not self.map_func:
-            return DeferredAttFt(self.att_dim)
+        """A DeferredAttFt for an encoder loop, or None when att_ft must be produced per call (no q_map: the mapped q of CLIP is
+        a per-layer temporary).  Fast mode: one bf16-MFMA launch over all layers; parity modes: one launch of the exact-f32 kernel
+        that keeps the reference's per-layer summation order (bit-identical to accumulating layer by layer)."""
+        if self.compute_att_ft and not self.map_func:
+            return DeferredAttFt(self.att_dim, exact=compute_dtype() != torch.bfloat16)
         return None
 
     def _dictionary(self, sd):
@@ -130,9 +131,10 @@ class Query_model(nn.Module):
         if split is not None:
             qa.update(sd_hi=split[0], sd_lo=split[1], split_dtype=hip.dt_code(split[0].dtype),
                       sd_scale=split[2] if len(split) > 2 else 1.0)
-        deferred = self.compute_att_ft and split is not None and split[0].dtype == torch.bfloat16
-        if self.compute_att_ft and not deferred:
-            qa["att_ft"] = torch.empty((B, K, dim), device=device, dtype=torch.float32)
+        # att_ft of all layers in ONE launch after the call ("bf16": fast-mode kernel, "exact": parity arithmetic and order)
+        deferred = False
+        if self.compute_att_ft:
+            deferred = "bf16" if (split is not None and split[0].dtype == torch.bfloat16) else "exact"
         return qa, deferred
 
     def forward(self, ft, sd, mask=None, return_token_att=False, temperature=1, acc_ft=None, defer=None):
@@ -168,7 +170,7 @@ class Query_model(nn.Module):
             ftq = ft
             if rows is not None:
                 # fast path: ft is x[:,1:,:] of a contiguous token buffer -> one C call (logits GEMM + att_ft)
-                want = self.compute_att_ft and not (defer is not None and split is not None)
+                want = self.compute_att_ft and not (defer is not None and (split is not None or defer.exact))
                 token_att, att_ft = hip.query_model(rows.view(B, n + 1, D), sdl.w, K, att_ft=acc_ft, want_att_ft=want,
                                                     sd_dim=self.att_dim, sd_split=split)
                 if self.compute_att_ft and not want:

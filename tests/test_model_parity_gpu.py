@@ -225,13 +225,24 @@ def test_vit_large_image_fp32_matches_reference_fixture(path, mode):
     with runtime.precision("bf16"), torch.no_grad():
         ob, sd_b = model(images, space_dict=space_dict, temperature=T)
     assert torch.isfinite(ob).all()
-    # fast mode sums the 12 layers' att_ft in one deferred launch: same result as the per-layer accumulate chain
+    # all modes sum the 12 layers' att_ft in one deferred launch after the last layer; forcing the per-layer path with the
+    # per-layer accumulate chain (`sd_ft_all += sd_ft`, vit.py:297-303) gives the same result: bit for bit in the parity modes
+    # (the exact kernel keeps the layer-by-layer summation order), to bf16-MFMA rounding in the fast mode
+    import madtp_amd.vit as vit_mod
+    saved = vit_mod._ENCODER_CALL
+    vit_mod._ENCODER_CALL = False
     model.img_query_model.deferred = lambda: None
-    with runtime.precision("bf16"), torch.no_grad():
-        ob2, sd_b2 = model(images, space_dict=space_dict, temperature=T)
-    del model.img_query_model.deferred
+    try:
+        with runtime.precision("bf16"), torch.no_grad():
+            ob2, sd_b2 = model(images, space_dict=space_dict, temperature=T)
+        with runtime.precision(mode), torch.no_grad():
+            out2, sd_ft2 = model(images, space_dict=space_dict, temperature=T)
+    finally:
+        del model.img_query_model.deferred
+        vit_mod._ENCODER_CALL = saved
     assert torch.equal(ob, ob2) and sd_b.shape == sd_ft.shape
     assert (sd_b - sd_b2).abs().max().item() < 1e-4 * sd_b2.abs().max().item()
+    assert torch.equal(out, out2) and torch.equal(sd_ft, sd_ft2)
 
 
 @pytest.mark.parametrize("mode", ["fp32", "f16x3", "bf16"])
