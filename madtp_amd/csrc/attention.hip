@@ -1147,6 +1147,7 @@ template <typename T, bool SCORES>
 int dispatch_nt(const AttnArgs& a, hipStream_t s) {
     const int nt = (a.Nk + 15) / 16;
     if (nt <= 4) return launch_attn<T, 4, SCORES>(a, s);
+    if (nt <= 6) return launch_attn<T, 6, SCORES>(a, s);  // 81-96 keys: nine of the twelve ViT layers of the headline workload
     if (nt <= 8) return launch_attn<T, 8, SCORES>(a, s);
     if (nt <= 10) return launch_attn<T, 10, SCORES>(a, s);
     if (nt <= 12) return launch_attn<T, 12, SCORES>(a, s);
