@@ -59,7 +59,8 @@ int madtp_gemm(const void* A, const void* W, const float* bias, const float* res
 
 /* Benchmark / test hook: force the tile configuration of the following madtp_gemm launches of this process (0 = automatic
  * dispatch (default), 1..4 = the 128x128 / 64x128 / 64x128x3 / 64x64 kernels, 5 = the wave-specialised 256x128 kernel,
- * 6 = the 256x256 kernel; a configuration that cannot take a problem falls back to the automatic choice).  The environment
+ * 6 = the 256x256 kernel, 7 = the wave-specialised kernel without its stream-K tail; a configuration that cannot take a
+ * problem falls back to the automatic choice).  The environment
  * variable MADTP_GEMM_CFG sets the initial value.  No reference counterpart (the reference has one GEMM: aten::addmm).
  * Returns the previous value. */
 int madtp_gemm_set_config(int cfg);

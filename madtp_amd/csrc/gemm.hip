@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <type_traits>
 #include <vector>
@@ -37,6 +38,9 @@ struct GemmArgs {
     float out_scale;
     float acc_scale;  // multiplies the raw accumulator before the bias: 2^-s of a pre-scaled f16-split weight, 1 otherwise
     float acc_scale2; // the same for the second problem of a pair launch
+    // stream-K tail of the wave-specialised kernel (sk_plan): partial accumulators [8 XCDs][32 units][8 waves][16][64 lanes] f32x4
+    // and the per-(tail tile, wave) tickets [8][16][8]; sk == 0: off
+    float* sk_ws; int* sk_tick; int sk;
 };
 
 // f16-split operands (common.h).  The kernels walk K as a stream of 2 * K/64 slab steps: step 2t stages [P0 | Q1] of k-slab t,
@@ -94,6 +98,20 @@ __device__ __forceinline__ void tile_mn(const GemmArgs& g, int t, int& tm, int& 
     const int grp = t / per, r = t - grp * per;
     const int gw = min(g.ngrp, g.ntn - grp * g.ngrp);
     tm = r / gw; tn = grp * g.ngrp + (r - tm * gw);
+}
+
+// Stream-K tail of a persistent kernel (the wave-specialised 256x128 one): an XCD's `nslots` tiles are `rounds` full rounds of
+// its `gl` workgroups plus `rem` tiles.  With rem <= gl/2 the last round would leave most CUs idle for a whole tile time (the
+// N = 768 GEMMs of the ViT layers at 11-14 k rows are 1.03-1.3 rounds), so each of the rem tiles is cut along K into `parts`
+// pieces run by `parts` workgroups; every consumer wave parks its 64x64 partial in the workspace and the LAST wave to arrive
+// (ticket per tile and wave position) sums the pieces in piece order - deterministic - and runs the epilogue.
+constexpr int SK_MAX_PARTS = 8;
+__host__ __device__ __forceinline__ int sk_parts(int rem, int gl, int nk) {
+    if (rem <= 0) return 0;
+    int p = gl / rem;
+    if (p > SK_MAX_PARTS) p = SK_MAX_PARTS;
+    if (p > nk / 2) p = nk / 2;  // at least two slabs per piece
+    return p >= 2 ? p : 0;
 }
 
 template <int ESZ, int ROWS, bool PERM = false>
@@ -530,22 +548,39 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
     int t0, nslots;
     const int tiles1 = g.ntm * g.ntn;
     xcd_tiles(g.pair ? 2 * tiles1 : tiles1, xcd, t0, nslots);
-    if (lb >= nslots) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nkp = g.K * ESZ / ROWB;     // slabs per operand plane
     const int nk = (X3 ? 2 : 1) * nkp;    // staged slab steps per tile (f16-split: [P0|Q1], [P1|Q0] per k-slab)
-    const int my_slots = (nslots - lb + gl - 1) / gl;
-    const long total_slabs = (long)my_slots * nk;
+    // work units of this workgroup: n_full whole tiles (slots lb, lb + gl, ...) and, with a stream-K tail, one K-piece
+    // [sk_k0, sk_k1) of tail tile sk_slot (sk_plan above; never on the f16-split kernel - its summation order is part of parity)
+    // (integer division runs on the VALU: readfirstlane puts the - uniform - results back into SGPRs)
+    int sk_p = 0, sk_rounds = 0;
+    if constexpr (!X3) {
+        if (g.sk) {
+            sk_rounds = __builtin_amdgcn_readfirstlane(nslots / gl);
+            sk_p = __builtin_amdgcn_readfirstlane(sk_parts(nslots - sk_rounds * gl, gl, nk));
+        }
+    }
+    const int n_full = __builtin_amdgcn_readfirstlane(sk_p ? sk_rounds : (lb < nslots ? (nslots - lb + gl - 1) / gl : 0));
+    const int sk_tile = __builtin_amdgcn_readfirstlane(sk_p ? lb / sk_p : 0);  // tail tile of this workgroup's piece
+    const bool has_tail = sk_p && lb < (nslots - sk_rounds * gl) * sk_p;
+    const int sk_slot = sk_rounds * gl + sk_tile, sk_part = lb - sk_tile * sk_p;
+    const int sk_k0 = __builtin_amdgcn_readfirstlane(has_tail ? sk_part * nk / sk_p : 0);
+    const int sk_k1 = __builtin_amdgcn_readfirstlane(has_tail ? (sk_part + 1) * nk / sk_p : 0);
+    const int n_units = n_full + (has_tail ? 1 : 0);
+    if (n_units == 0) return;
+    const int total_slabs = n_full * nk + (sk_k1 - sk_k0);
 
     if (wave >= NCW) {
         // ------------------------------------------ loader ------------------------------------------
         const int lw = wave - NCW, sub = lane >> 3;
         const int n_pad_max = g.ntn * BN - 1;
-        int is_slot = lb, is_kt = 0, is_stage = 0;
+        int is_unit = 0, is_stage = 0;
+        int is_slot = n_full ? lb : sk_slot, is_kt = n_full ? 0 : sk_k0, is_kend = n_full ? nk : sk_k1;
         int is_odd = 0, is_pk = 0;  // f16-split: parity of the next step ([P0|Q1] or [P1|Q0]) and its k-slab
-        long issued = 0;
+        int issued = 0;
         const char* srcp[PER];  // per-lane source of each DMA instruction at k = 0 of the current tile
         auto tile_ptrs = [&]() {
             int t = t0 + is_slot;
@@ -590,15 +625,15 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
                 if (is_odd) { if (++is_pk == nkp) is_pk = 0; }
                 is_odd ^= 1;
             }
-            if (++is_kt == nk) {
-                is_kt = 0;
-                is_slot += gl;
+            if (++is_kt == is_kend) {
+                if (++is_unit < n_full) { is_kt = 0; is_slot += gl; }
+                else { is_kt = sk_k0; is_kend = sk_k1; is_slot = sk_slot; }
                 if (issued < total_slabs) tile_ptrs();
             }
         };
         issue_next();
         issue_next();
-        for (long s = 0; s < total_slabs; ++s) {
+        for (int s = 0; s < total_slabs; ++s) {
             if (s + STAGES - 1 <= total_slabs) wait_vmcnt<(STAGES - 2) * PER>();
             else wait_vmcnt<0>();
             if (!(MADTP_WS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
@@ -644,7 +679,10 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
     const long long ws_t_begin = WS_NOW();
     long long ws_t0 = ws_t_begin;
 #endif
-    for (int slot = lb; slot < nslots; slot += gl) {
+    for (int unit = 0; unit < n_units; ++unit) {
+      const bool tail = unit == n_full;  // the K-piece of a stream-K tail tile
+      const int slot = tail ? sk_slot : lb + unit * gl;
+      const int nku = tail ? sk_k1 - sk_k0 : nk;
       if constexpr (X3) {
         // f16-split: per k-slab two staged steps SA = [P0|Q1], SB = [P1|Q0] and six groups of 16 MFMAs,
         //   G1 P0a Q1a   G2 P0b Q1b   G3 P0a Q0a   G4 P1a Q0a'   G5 P0b Q0b   G6 P1b Q0b'      (a / b: the two 32-deep halves, ' : * 2^-11)
@@ -736,7 +774,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             if (++cur_stage == STAGES) cur_stage = 0;
         }
-        for (int kt = 1; kt < nk; ++kt) {
+        for (int kt = 1; kt < nku; ++kt) {
             constexpr bool first = false;
             const char* st = smem + cur_stage * STAGE_BYTES;
             if (!(MADTP_WS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
@@ -753,6 +791,45 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             if (++cur_stage == STAGES) cur_stage = 0;
         }
         { MADTP_WS_MFMA(ya, yb) }
+        if (tail) {
+            // park this wave's 64x64 partial ([fragment][lane] f32x4: every store is one contiguous KiB), take the ticket of
+            // (tail tile, wave position); the last of the sk_p arrivals sums all pieces in piece order and goes on to the epilogue
+            f32x4* ws4 = (f32x4*)g.sk_ws;  // (uniform base + 32-bit element offsets: nothing 64-bit per lane stays live)
+            constexpr unsigned WAVE_STRIDE = 16 * 64, UNIT_STRIDE = NCW * WAVE_STRIDE;
+            unsigned in_unit = (unsigned)wave * WAVE_STRIDE + (unsigned)lane;
+            asm volatile("" : "+v"(in_unit));  // the addresses are built HERE: hoisted out of the tile loop they would be spilled
+            {
+                const unsigned mine = (unsigned)(xcd * 32 + lb) * UNIT_STRIDE + in_unit;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ws4[mine + (i * 4 + j) * 64] = acc[i][j];
+            }
+            // All pieces of a tile run on ONE XCD (same L2), so the hand-over needs no agent-scope fence - __threadfence() would
+            // write back and invalidate the whole L2 under the other workgroups' feet (measured: +60-90 us per launch).  It is the
+            // protocol the compiler emits for workgroup scope in threadgroup-split mode: the stores are complete in L2 once vmcnt
+            // reaches 0 (the vector L1 is write-through), the ticket is an L2 atomic, and the reader drops its CU's L1.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int* tk = g.sk_tick + (xcd * 16 + sk_tile) * NCW + wave;
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old != sk_p - 1) continue;
+            asm volatile("buffer_inv sc0" ::: "memory");
+            if (lane == 0) *tk = 0;  // clean for the next launch on this workspace
+            unsigned piece = (unsigned)(xcd * 32 + sk_tile * sk_p) * UNIT_STRIDE + in_unit;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = ws4[piece + (i * 4 + j) * 64];
+            for (int p = 1; p < sk_p; ++p) {
+                piece += UNIT_STRIDE;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += ws4[piece + (i * 4 + j) * 64];
+            }
+        }
       }
         int t = t0 + slot;
         const bool second = g.pair && t >= tiles1;
@@ -1031,14 +1108,14 @@ static int gemm_force_cfg() {
     if (v < 0) {
         const char* e = getenv("MADTP_GEMM_CFG");
         v = e ? atoi(e) : 0;
-        if (v < 0 || v > 6) v = 0;
+        if (v < 0 || v > 7) v = 0;
         g_force_cfg.store(v, std::memory_order_relaxed);
     }
     return v;
 }
 extern "C" int madtp_gemm_set_config(int cfg) {
     const int prev = gemm_force_cfg();
-    g_force_cfg.store((cfg < 0 || cfg > 6) ? 0 : cfg, std::memory_order_relaxed);
+    g_force_cfg.store((cfg < 0 || cfg > 7) ? 0 : cfg, std::memory_order_relaxed);
     return prev;
 }
 
@@ -1077,6 +1154,47 @@ extern "C" int madtp_gemm_splitk(const void* A, const void* W, float* part, int 
                        stream);
 }
 
+// Stream-K workspace of the wave-specialised kernel: one per (device, stream) - launches on one stream are ordered, launches
+// on different streams must not share partials - allocated on first use (32 MiB of partials + the tickets, zeroed once; every
+// ticket resets itself).  OFF by default (MADTP_GEMM_SK=1 turns it on; madtp_gemm_set_config(5) always uses it): on isolated
+// launches it wins 8-16 % on the K = 3072, N = 768 problems at 11-14 k rows, inside the forward - where that GEMM reads its
+// 75 MB operand and the f32 residual from HBM rather than from the Infinity Cache - the same launches take the same ~92 us with
+// and without it and the next GEMM loses ~3 us to the evicted lines (profiles/r02_gemm_sk_ab.txt).
+struct SkWorkspace { float* ws; int* tick; };
+static bool sk_enabled() {
+    static int sk_env = -1;
+    if (sk_env < 0) { const char* e = getenv("MADTP_GEMM_SK"); sk_env = e ? atoi(e) : 0; }
+    return sk_env != 0;
+}
+static bool sk_workspace(hipStream_t s, SkWorkspace& out) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, SkWorkspace> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = pool.find({dev, s});
+    if (it == pool.end()) {
+        constexpr size_t WS_BYTES = (size_t)8 * 32 * 8 * 16 * 64 * 16, TICK_BYTES = (size_t)8 * 16 * 8 * sizeof(int);
+        char* base = nullptr;
+        if (hipMalloc((void**)&base, WS_BYTES + TICK_BYTES) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipMemsetAsync(base + WS_BYTES, 0, TICK_BYTES, s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(base); return false; }
+        it = pool.emplace(std::make_pair(dev, s), SkWorkspace{(float*)base, (int*)(base + WS_BYTES)}).first;
+    }
+    out = it->second;
+    return true;
+}
+// Cost (in rounds of 256x128 tiles) of the wave-specialised kernel on t256 tiles.  The stream-K tail pays for K >= 2048 only
+// (measured, tools/gemm_bench.py ab / profiles/r02_gemm_sk_ab.txt): parking and re-reading the partials costs ~16 us per
+// launch, while the few tiles of a plain last round run ~25 % faster than in a full round (no contention), so with K = 768
+// (12 slabs, ~13 us per lone tile) the split loses 4-10 us and with K = 3072 it wins 6-14 us (M = 11-14 k rows, N = 768).
+constexpr int SK_MIN_SLABS = 32;
+static float ws_cost(int t256, int nk, bool sk) {
+    const int nsl = (t256 + 7) / 8, rounds = nsl / 32, rem = nsl - rounds * 32;
+    if (rem == 0) return (float)rounds;
+    const int parts = (sk && nk >= SK_MIN_SLABS) ? sk_parts(rem, 32, nk) : 0;
+    return (float)rounds + (parts ? 0.65f : 1.0f);
+}
+
 static int gemm_launch(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
                        int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float acc_scale, float out_scale,
                        int splitk, void* stream, const GemmPair* pair) {
@@ -1104,6 +1222,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     g.splitk = splitk;
     g.ngrp = 0;
     g.pair = 0; g.A2 = g.W2 = nullptr; g.bias2 = nullptr; g.C2 = nullptr;
+    g.sk = 0; g.sk_ws = nullptr; g.sk_tick = nullptr;
     // vector epilogue needs 16-byte aligned rows on every epilogue operand
     // (and, for the descriptor-bounded stores, a 256-row block of C below 2 GiB; bf16 output with an f32 residual has no
     // caller on the path and takes the scalar epilogue)
@@ -1130,7 +1249,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     }
     // MADTP_GEMM_CFG=5 forces the wave-specialised kernel, 1..4 force a gemm_kernel variant (A/B measurements)
     bool ws_ok = lp16 && splitk == 1 &&
-                 (force_cfg == 5 || (force_cfg == 0 && M >= 4096 && (big || cfg == 0)));
+                 (force_cfg == 5 || force_cfg == 7 || (force_cfg == 0 && M >= 4096 && (big || cfg == 0)));
     if (pair) {
         static int pair_env = -1;  // MADTP_GEMM_PAIR=0: always two launches (A/B runs)
         if (pair_env < 0) { const char* e = getenv("MADTP_GEMM_PAIR"); pair_env = e ? atoi(e) : 1; }
@@ -1173,12 +1292,15 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     // 256x256 kernel: bf16 operands, no split-K / pair.  Chosen when its round count times its per-tile cost (measured ~1.7x a
     // 256x128 tile) beats the wave-specialised kernel's; MADTP_GEMM_CFG=6 forces it, MADTP_GEMM_SQ=0 turns it off (A/B runs).
     bool sq_ok = false;
+    SkWorkspace skw{nullptr, nullptr};
+    const bool sk_on = ws_ok && !x3 && ab_dtype == MADTP_BF16 && (force_cfg == 5 || (force_cfg == 0 && sk_enabled() && K / 64 >= SK_MIN_SLABS)) &&
+                       sk_workspace(s, skw);
     if (ab_dtype == MADTP_BF16 && splitk == 1 && !pair && (K % 64) == 0 &&
         ((size_t)M + 255) * (size_t)lda * 2 < ((size_t)1 << 32) && ((size_t)N + 255) * (size_t)ldw * 2 < ((size_t)1 << 32)) {
         static int sq_env = -1;
         if (sq_env < 0) { const char* e = getenv("MADTP_GEMM_SQ"); sq_env = e ? atoi(e) : 1; }
         const int t_sq = ((M + 255) / 256) * ((N + 255) / 256);
-        const float cost_sq = 1.7f * (float)((t_sq + 255) / 256), cost_ws = (float)((t256 + 255) / 256);
+        const float cost_sq = 1.7f * (float)((t_sq + 255) / 256), cost_ws = ws_cost(t256, K / 64, sk_on);
         sq_ok = force_cfg == 6 || (force_cfg == 0 && sq_env && ws_ok && t_sq >= 100 && cost_sq < cost_ws);
     }
     if (sq_ok) {
@@ -1214,6 +1336,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         }
         const int slots_max = (g.ntm * g.ntn * (g.pair ? 2 : 1) + 7) / 8;
         const int grid = 8 * (slots_max < 32 ? slots_max : 32);
+        if (sk_on && grid == 256) { g.sk = 1; g.sk_ws = skw.ws; g.sk_tick = skw.tick; }
         const size_t lds = (size_t)3 * (256 + 128) * ROWB;
 #define MADTP_LAUNCH_WS(X3_, OM_)                                                          \
     do {                                                                                  \

@@ -130,6 +130,44 @@ def test_gemm_256x256(hip, M, N, K, cfg):
     assert (auto - sq).abs().max().item() < 1e-4 * scale
 
 
+@pytest.mark.parametrize("M,N,K", [(12288, 768, 3072),   # 288 tiles: one round + 4 tail tiles per XCD cut into 8 pieces
+                                   (14208, 768, 768),    # 336 tiles: 10 tail tiles per XCD, 3 pieces of 4 slabs
+                                   (25216, 768, 768),    # 594 tiles: two rounds + a tail of 2 pieces; XCDs with 10 and 11 tail tiles
+                                   (11000, 2304, 768),   # ragged last row tile inside a split tail tile
+                                   (8200, 1100, 1024)])   # uneven pieces (16 slabs in 5 pieces), N % 8 != 0: the scalar epilogue
+def test_gemm_stream_k_tail(hip, M, N, K):
+    """Stream-K tail of the wave-specialised kernel (madtp_gemm_set_config(5)) against the same kernel without it (7) and a
+    float64 product of the same bf16 operands: every epilogue, and repeated launches on one workspace (the tickets reset
+    themselves).  The pieces are summed in piece order, so two launches give identical bits."""
+    td = torch.bfloat16
+    a = _rand(M, K, seed=1).to(td).cuda()
+    w = _rand(N, K, seed=2, scale=0.05).to(td)
+    wp = _pad128(w.float()).to(td).cuda()
+    bias, res = _rand(N, seed=3).cuda(), _rand(M, N, seed=4).cuda()
+    core = a.double() @ w.cuda().double().t()
+    scale = max(1.0, core.abs().max().item())
+    with hip.gemm_config(7):
+        plain = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
+    with hip.gemm_config(5):
+        sk = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
+        assert (sk - ((core + bias.double()).float() + res)).abs().max().item() < 1e-4 * scale
+        assert (sk - plain).abs().max().item() < 2e-5 * scale
+        for _ in range(3):
+            again = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
+            assert torch.equal(again, sk)
+        out = hip.gemm(a, wp, bias, out_dtype=td, act=hip.ACT_GELU, n=N)
+        assert (out.float() - F.gelu(core + bias.double()).float()).abs().max().item() < 1e-2 * scale
+        out = hip.gemm(a, wp, None, out_dtype=td, n=N)
+        assert (out.float() - core.float()).abs().max().item() < 1e-2 * scale
+        # a second stream has its own workspace
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            other = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(other, sk)
+
+
 def test_gemm_wave_specialised_scalar_epilogue(hip):
     """N = 100 (not a multiple of 8) on 60000 rows: the wave-specialised kernel with its scalar fallback epilogue (the shape of a
     `x @ space_dict^T` product done as a plain GEMM), f32 and bf16 outputs, bias and residual."""

@@ -24,7 +24,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "ab":  # 256x128 wave-specialised (cfg 5
             kw = dict(residual=res, out_dtype=torch.float32) if N == 768 else (dict(act=hip.ACT_GELU) if N == 3072 else {})
             out = torch.empty(M, N, device="cuda", dtype=kw.get("out_dtype", dt))
             line = f"M={M:6d} N={N:5d} K={K:5d}"
-            for cfg in (5, 6, 0):
+            for cfg in (7, 5, 6, 0):  # 7: wave-specialised without the stream-K tail, 5: with it, 6: 256x256, 0: automatic
                 with hip.gemm_config(cfg):
                     for _ in range(3): hip.gemm(a, w, bias, n=N, out=out, **kw)
                     torch.cuda.synchronize()
@@ -34,6 +34,33 @@ if len(sys.argv) > 2 and sys.argv[2] == "ab":  # 256x128 wave-specialised (cfg 5
                     e1.record(); torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / 20
                 line += f"   cfg{cfg} {us:7.1f} us {2.0*M*N*K/us/1e6:7.1f} TF"
+            print(line, flush=True)
+    sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "lib":  # yardstick: the vendor library (torch -> hipBLASLt / rocBLAS) on the same shapes, plain bf16 out
+    import torch.nn.functional as F
+    rows = [25216, 12288, 10496]
+    for M in rows + [8192]:
+        for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)) if M != 8192 else ((8192, 8192),):
+            a = torch.randn(M, K, device="cuda").to(dt); w = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
+            bias = torch.randn(N, device="cuda")
+            out = torch.empty(M, N, device="cuda", dtype=dt)
+            lib_out = torch.empty(M, N, device="cuda", dtype=dt)
+            line = f"M={M:6d} N={N:5d} K={K:5d}"
+            def t(fn):
+                for _ in range(3): fn()
+                torch.cuda.synchronize()
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20): fn()
+                e1.record(); torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e3 / 20
+            us = t(lambda: hip.gemm(a, w, None, n=N, out=out))
+            line += f"   madtp {us:7.1f} us {2.0*M*N*K/us/1e6:7.1f} TF"
+            us = t(lambda: torch.matmul(a, w.t(), out=lib_out))
+            line += f"   library {us:7.1f} us {2.0*M*N*K/us/1e6:7.1f} TF"
+            wt = w.t().contiguous()
+            us = t(lambda: torch.matmul(a, wt, out=lib_out))
+            line += f"   library(NN) {us:7.1f} us {2.0*M*N*K/us/1e6:7.1f} TF"
             print(line, flush=True)
     sys.exit(0)
 for M, N, K in shapes:
