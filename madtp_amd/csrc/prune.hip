@@ -518,20 +518,39 @@ __global__ __launch_bounds__(256) void token_gather_kernel(const float* __restri
         ln_store(v, lane, dim, mean, rstd, prm, h32 ? h32 + off : nullptr, hlp ? hlp + off * lp_mul : nullptr, lp_mul == 2);
     };
     if ((int)blockIdx.x < (int)gridDim.x - 1) {
-        for (int rr = wave; rr < GATHER_ROWS; rr += 4) {
-            const int t = blockIdx.x * GATHER_ROWS + rr;  // source token incl. CLS
-            if (t >= N) break;
-            const int dst = t == 0 ? 0 : dst_pos[(size_t)b * n + t - 1] + 1;
-            if (dst <= 0 && t != 0) continue;
-            float4 v[LN_MAX_CHUNKS];
-            int nch = 0;
+        // A wave copies the source tokens t0 + wave + 4 i (i < 4).  The straightforward loop was a dependent chain per row
+        // (destination slot, then the row, then the LayerNorm reductions and stores): the four slots are fetched up front now
+        // and row i + 1 is in flight while row i is normalised and stored (same arithmetic per row: bit-identical).
+        constexpr int RPW = GATHER_ROWS / 4;
+        int dsts[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int t = blockIdx.x * GATHER_ROWS + wave + 4 * i;  // source token incl. CLS
+            dsts[i] = t >= N ? -1 : (t == 0 ? 0 : dst_pos[(size_t)b * n + t - 1] + 1);
+            if (t != 0 && dsts[i] <= 0) dsts[i] = -1;  // dropped (or past the end)
+        }
+        float4 v[2][LN_MAX_CHUNKS];
+        auto load_row = [&](float4 (&r)[LN_MAX_CHUNKS], int i) {
+            const int t = blockIdx.x * GATHER_ROWS + wave + 4 * i;
 #pragma unroll
             for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
                 const int cc = lane + 64 * c;
-                if (cc < dim4) { v[c] = xb[(size_t)t * dim4 + cc]; yb[(size_t)dst * dim4 + cc] = v[c]; nch = c + 1; }
-                else v[c] = make_float4(0, 0, 0, 0);
+                r[c] = (dsts[i] >= 0 && cc < dim4) ? xb[(size_t)t * dim4 + cc] : make_float4(0, 0, 0, 0);
             }
-            if (ln) ln_out(v, nch, dst);
+        };
+        const int nch = lane < dim4 ? (dim4 - lane + 63) / 64 : 0;  // chunks lane + 64 c < dim4 of this lane
+        load_row(v[0], 0);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            if (i + 1 < RPW) load_row(v[(i + 1) & 1], i + 1);
+            if (dsts[i] >= 0) {  // wave-uniform
+#pragma unroll
+                for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+                    const int cc = lane + 64 * c;
+                    if (cc < dim4) yb[(size_t)dsts[i] * dim4 + cc] = v[i & 1][c];
+                }
+                if (ln) ln_out(v[i & 1], nch, dsts[i]);
+            }
         }
     } else {
         // Merged token: wave w sums its dropped tokens t = w, w+4, .. in increasing order (the association of the result is fixed
