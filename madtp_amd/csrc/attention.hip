@@ -413,6 +413,10 @@ __global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void a
             const bf16x8 pa = pack_bf16x8(sc[2 * c], hi);
             // transpose read: lane 4r+q of the group addresses (key row r, columns 4q..4q+3), receives column l16.
             // key rows of this lane group: 32c + 4g + r (first read) and +16 (second); both have the same (row>>1)&3.
+            // (The compiler puts s_waitcnt vmcnt(0) in front of the first of these builtin reads - it cannot tell them from the
+            //  LDS-DMA targets - so P.V of head h waits for the K/V of head h+1 issued at the top of the iteration.  Inline-asm
+            //  reads as in attn_bf16_large_kernel remove the wait; measured neutral here (29.7 vs 28.7 us, the DMA has landed
+            //  by then) and the NT = 16 instantiation spills with the extra buffer, so the builtin stays.)
             const int vrow = 32 * c + 4 * g + (l16 >> 2);
             const int vkey = ((vrow >> 1) & 3) << 1;
             const char* vr = Vs + vrow * 128 + 8 * (l16 & 1);
@@ -880,8 +884,10 @@ int launch_attn_large(const AttnArgs& a, hipStream_t s) {
 // The head-max stays in registers for all key tiles as packed f16 pairs (NT x 2 registers per lane: 80 at 577 keys, 114 at 901),
 // two 4-wave workgroups per CU up to 640 keys (the 1024-key instantiation would spill at 256 registers and keeps one).
 // Work per (b, h): 6 Nq Nk 64 flop (Q K^T twice) on the bf16 MFMA; the bound is the VALU softmax work (2 exp per score).
-template <int NCH, bool SCORES>
-__global__ __launch_bounds__(256, (NCH <= 5 || !SCORES) ? 2 : 1) void attn_bf16_large_kernel(AttnArgs a) {
+// STG: stages of the chunk ring (2 is what launch_attn_bf16_large uses; 3 keeps two chunks in flight behind counted vmcnt waits
+// and was measured slower, see there).
+template <int NCH, bool SCORES, int STG>
+__global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) void attn_bf16_large_kernel(AttnArgs a) {
     constexpr int CK = 128;                   // keys per chunk
     constexpr int STAGE = 2 * CK * 128;       // K image (128-byte rows), then V image
     constexpr int NT = NCH * 8;
@@ -909,26 +915,42 @@ __global__ __launch_bounds__(256, (NCH <= 5 || !SCORES) ? 2 : 1) void attn_bf16_
     }
 
     // LDS-DMA of one chunk: 16 K and 16 V instructions of 8 rows (1 KiB) each, 4 + 4 per wave.  Swizzles on the SOURCE address
-    // as in attn_bf16_kernel: K chunk ^= row & 7, V chunk ^= 2 * ((row >> 1) & 3).  Rows >= Nk are clamped (their P is 0).
+    // as in attn_bf16_kernel: K chunk ^= row & 7, V chunk ^= 2 * ((row >> 1) & 3).  buffer_load ... lds: the per-lane part of
+    // the address (row within the chunk, swizzled 16-byte slot) is a constant VGPR offset, the step-dependent part (chunk, head)
+    // a scalar offset - no per-step address arithmetic on the VALU (it was ~150 of the ~450 instructions of a chunk step) - and
+    // rows >= Nk fall outside the sample's descriptor and read as zeros (their P is 0 / masked).
     const int sub = lane >> 3, pos = lane & 7;
-    int lrow[4], koff[4], voff[4];
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)(a.k + (size_t)bkv * a.Nk * a.ldk * 2), 0,
+                                                                          (unsigned)((size_t)a.Nk * a.ldk * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)(a.v + (size_t)bkv * a.Nk * a.ldv * 2), 0,
+                                                                          (unsigned)((size_t)a.Nk * a.ldv * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)(a.q + (size_t)b * a.Nq * a.ldq * 2), 0,
+                                                                          (unsigned)((size_t)a.Nq * a.ldq * 2), 0x00020000);
+    unsigned kro[4], vro[4], qro[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + sub;
-        lrow[i] = r;
-        koff[i] = (pos ^ (r & 7)) << 4;
-        voff[i] = (pos ^ (((r >> 1) & 3) << 1)) << 4;
+        kro[i] = (unsigned)r * (unsigned)a.ldk * 2u + (unsigned)((pos ^ (r & 7)) << 4);
+        vro[i] = (unsigned)r * (unsigned)a.ldv * 2u + (unsigned)((pos ^ (((r >> 1) & 3) << 1)) << 4);
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) qro[i] = (unsigned)(i0 + i * 8 + sub) * (unsigned)a.ldq * 2u + (unsigned)((pos ^ sub) << 4);
+    // Q rows of this wave (16 x 128 B per head) travel by LDS-DMA as well, into a wave-private 2 KiB image behind the ring (same
+    // swizzle as K), issued with the first K chunk of their head: a plain global load inside the chunk loops makes the compiler
+    // wait for vmcnt(0) at its first use - i.e. for every chunk DMA in flight - on each iteration.
+    char* const qimg = smem + STG * STAGE + wave * 2048;
+    auto stage_q = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, LDS_PTR(qimg + i * 1024), 16, qro[i], h * 128, 0, 0);
+    };
     auto stage = [&](int h, int c, bool with_v, int st) {
         char* base = smem + st * STAGE + wave * 4 * 1024;
+        const int sk = (c * CK * a.ldk + h * 64) * 2, sv = (c * CK * a.ldv + h * 64) * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = min(c * CK + lrow[i], a.Nk - 1);
-            const size_t grow = (size_t)bkv * a.Nk + row;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a.k + (grow * a.ldk + h * 64) * 2 + koff[i]), LDS_PTR(base + i * 1024), 16, 0, 0);
-            if (with_v)
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a.v + (grow * a.ldv + h * 64) * 2 + voff[i]),
-                                                 LDS_PTR(base + CK * 128 + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, LDS_PTR(base + i * 1024), 16, kro[i], sk, 0, 0);
+            if (with_v) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, LDS_PTR(base + CK * 128 + i * 1024), 16, vro[i], sv, 0, 0);
         }
     };
     // S^T of one chunk (8 key tiles), scaled and masked; keys >= Nk -> -inf
@@ -964,22 +986,47 @@ __global__ __launch_bounds__(256, (NCH <= 5 || !SCORES) ? 2 : 1) void attn_bf16_
     };
 
     const int hstep = gridDim.z;
-    int st = 0;
-    if ((int)blockIdx.z < a.H) stage(blockIdx.z, 0, false, 0);
+    // The chunk steps of this workgroup form one stream (head, pass A / B, chunk); the DMA of step s + STG - 1 is issued at step s.
+    // step_sync(): wait for the DMA of the current step (the STG - 2 younger ones may still fly: vmcnt counts 4 K instructions
+    // of a pass-A step, 8 K|V instructions of a pass-B step per wave; output stores issued in between only make the wait a
+    // little stricter), barrier (every wave is done with the stage that is overwritten next), issue.
+    int st = 0, is_st = 0, is_h = blockIdx.z, is_p = 0, is_c = 0;
+    auto issue = [&]() {
+        if (is_h < a.H) {
+            if (is_p == 0 && is_c == 0) stage_q(is_h);
+            stage(is_h, is_c, is_p == 1, is_st);
+        }
+        if (++is_st == STG) is_st = 0;
+        if (++is_c == nch) { is_c = 0; if (++is_p == 2) { is_p = 0; is_h += hstep; } }
+    };
+    auto step_sync = [&](int h, int p, int c) {
+        if constexpr (STG == 2) {
+            __syncthreads();  // chunk landed (the barrier drains the DMA); the other stage is free again
+        } else {
+            int nh = h, np = p, nc = c + 1;  // the step after the current one: its DMA stays in flight
+            if (nc == nch) { nc = 0; if (++np == 2) { np = 0; nh += hstep; } }
+            const int fly = nh < a.H ? (np ? 8 : (nc == 0 ? 6 : 4)) : 0;  // (+2: the Q rows ride with a head's first K chunk)
+            if (fly == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (fly == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (fly == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        issue();
+    };
+#pragma unroll
+    for (int i = 0; i < STG - 1; ++i) issue();
     for (int h = blockIdx.z; h < a.H; h += hstep) {
         bf16x8 q[2];
-        {
-            const char* qp = a.q + (((size_t)b * a.Nq + irow) * a.ldq + h * 64) * 2 + g * 16;
-            q[0] = *(const bf16x8*)qp;
-            q[1] = *(const bf16x8*)(qp + 64);
-        }
         // ---- pass A: row maximum and sum over all keys (online, exact at the end) ----
         float m = -INFINITY, l = 0.f;
 #pragma nounroll
-        for (int c = 0; c < nch; ++c, st ^= 1) {
-            __syncthreads();  // chunk c landed (the barrier drains the DMA); the other stage is free again
-            if (c + 1 < nch) stage(h, c + 1, false, st ^ 1);
-            else stage(h, 0, true, st ^ 1);
+        for (int c = 0; c < nch; ++c, st = (st + 1 == STG ? 0 : st + 1)) {
+            step_sync(h, 0, c);
+            if (c == 0) {  // the head's Q rows landed with this chunk
+                q[0] = *(const bf16x8*)(qimg + l16 * 128 + (((0 + g) ^ (l16 & 7)) << 4));
+                q[1] = *(const bf16x8*)(qimg + l16 * 128 + (((4 + g) ^ (l16 & 7)) << 4));
+            }
             if (!active) continue;
             f32x4 sc[8];
             scores(smem + st * STAGE, c, q, sc);
@@ -1005,10 +1052,8 @@ __global__ __launch_bounds__(256, (NCH <= 5 || !SCORES) ? 2 : 1) void attn_bf16_
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma nounroll
-        for (int c = 0; c < nch; ++c, st ^= 1) {  // (a runtime loop: unrolled, the per-chunk DMA addresses get hoisted and spilled)
-            __syncthreads();
-            if (c + 1 < nch) stage(h, c + 1, true, st ^ 1);
-            else if (h + hstep < a.H) stage(h + hstep, 0, false, st ^ 1);
+        for (int c = 0; c < nch; ++c, st = (st + 1 == STG ? 0 : st + 1)) {  // (a runtime loop: unrolled, the per-chunk DMA addresses get hoisted and spilled)
+            step_sync(h, 1, c);
             if (!active) continue;
             const char* Ks = smem + st * STAGE;
             const char* Vs = Ks + CK * 128;
@@ -1047,18 +1092,31 @@ __global__ __launch_bounds__(256, (NCH <= 5 || !SCORES) ? 2 : 1) void attn_bf16_
                     }
                 }
             }
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {  // 32-key sub-chunks: key(k-slot group g, e) = 32cc + 16(e>>2) + 4g + (e&3)
-                const bf16x8 pa = pack_bf16x8(sc[2 * cc], sc[2 * cc + 1]);
+            // 32-key sub-chunks: key(k-slot group g, e) = 32cc + 16(e>>2) + 4g + (e&3).  The transposing V reads are inline asm
+            // with their own lgkmcnt wait: through the builtin the compiler cannot tell them from the LDS-DMA targets and puts
+            // s_waitcnt vmcnt(0) in front of the first one - which would drain the chunks in flight on every step.
+            bf16x4 vt[2][8];
+            auto v_reads = [&](int cc, bf16x4 (&d)[8]) {
                 const int vrow = 32 * cc + 4 * g + (l16 >> 2);
                 const int vkey = ((vrow >> 1) & 3) << 1;
                 const char* vr = Vs + vrow * 128 + 8 * (l16 & 1);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const int p = ((2 * dt + ((l16 & 3) >> 1)) ^ vkey) << 4;
-                    const bf16x8 vb = cat_bf16x4(lds_read_tr16(vr + p), lds_read_tr16(vr + 16 * 128 + p));
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, o[dt], 0, 0, 0);  // O^T: row d = 4g+r, col i
+                    const unsigned ad = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(vr + (((2 * dt + ((l16 & 3) >> 1)) ^ vkey) << 4));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(d[2 * dt]) : "v"(ad) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(d[2 * dt + 1]) : "v"(ad) : "memory");
                 }
+            };
+            v_reads(0, vt[0]);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const bf16x8 pa = pack_bf16x8(sc[2 * cc], sc[2 * cc + 1]);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[cc & 1][0]), "+v"(vt[cc & 1][1]), "+v"(vt[cc & 1][2]), "+v"(vt[cc & 1][3]),
+                             "+v"(vt[cc & 1][4]), "+v"(vt[cc & 1][5]), "+v"(vt[cc & 1][6]), "+v"(vt[cc & 1][7]) :: "memory");
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat_bf16x4(vt[cc & 1][2 * dt], vt[cc & 1][2 * dt + 1]), pa, o[dt], 0, 0, 0);  // O^T: row d = 4g+r, col i
+                if (cc + 1 < 4) v_reads(cc + 1, vt[(cc + 1) & 1]);
             }
         }
         if (active) {  // lane (i = l16, g) holds columns h*64 + 16dt + 4g .. +3 of row i
@@ -1097,15 +1155,20 @@ __global__ __launch_bounds__(256, (NCH <= 5 || !SCORES) ? 2 : 1) void attn_bf16_
 
 template <int NCH, bool SCORES>
 int launch_attn_bf16_large(const AttnArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)2 * 2 * 128 * 128;  // two stages of K|V chunk images
-    MADTP_ENSURE_MAX_LDS((attn_bf16_large_kernel<NCH, SCORES>), lds);
     int gz = 1;
     if (!SCORES) {  // cross-attention against a long image sequence: few query rows, spread the heads over workgroups
         const int wgs = ((a.Nq + 63) / 64) * a.B;
         gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
         if (gz > a.H) gz = a.H;
     }
-    hipLaunchKernelGGL((attn_bf16_large_kernel<NCH, SCORES>), dim3((a.Nq + 63) / 64, a.B, gz), dim3(256), lds, s, a);
+    const dim3 grid((a.Nq + 63) / 64, a.B, gz);
+    // Two stages.  The three-stage ring (STG = 3: two chunks in flight behind counted vmcnt waits, 104 KiB, one workgroup per
+    // CU) was measured 4-8 % SLOWER at one workgroup per CU and 40 % slower where two would fit (tools/attn_large_bench.py): a
+    // chunk step of a lone wave is bound by its own dependent instruction stream (~1.85 us against ~1.2 us with two waves per
+    // SIMD), not by the DMA round trip.
+    const size_t lds = (size_t)2 * 2 * 128 * 128 + 4 * 2048;  // two stages of K|V chunk images + the waves' Q rows
+    MADTP_ENSURE_MAX_LDS((attn_bf16_large_kernel<NCH, SCORES, 2>), lds);
+    hipLaunchKernelGGL((attn_bf16_large_kernel<NCH, SCORES, 2>), grid, dim3(256), lds, s, a);
     MADTP_LAUNCH_CHECK();
     return 0;
 }

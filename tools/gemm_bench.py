@@ -17,6 +17,7 @@ dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.f
 print("dtype", dt, "MADTP_GEMM_DEBUG", os.environ.get("MADTP_GEMM_DEBUG"), "CFG", os.environ.get("MADTP_GEMM_CFG"))
 if len(sys.argv) > 2 and sys.argv[2] == "ab":  # 256x128 wave-specialised (cfg 5) vs 256x256 (cfg 6) vs automatic on the forward's ViT shapes
     rows = [25216, 17152, 14208, 12288, 11776, 11136, 10752, 10496]
+    if len(sys.argv) > 3 and sys.argv[3] == 'small_tiles': rows = [17152, 12288, 10752, 10496]
     for M in rows:
         for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
             a = torch.randn(M, K, device="cuda").to(dt); w = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
@@ -24,7 +25,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "ab":  # 256x128 wave-specialised (cfg 5
             kw = dict(residual=res, out_dtype=torch.float32) if N == 768 else (dict(act=hip.ACT_GELU) if N == 3072 else {})
             out = torch.empty(M, N, device="cuda", dtype=kw.get("out_dtype", dt))
             line = f"M={M:6d} N={N:5d} K={K:5d}"
-            for cfg in (7, 5, 6, 0):  # 7: wave-specialised without the stream-K tail, 5: with it, 6: 256x256, 0: automatic
+            for cfg in ((7, 1, 2, 3, 0) if (len(sys.argv) > 3 and sys.argv[3] == 'small_tiles') else (7, 5, 6, 0)):  # 7: wave-specialised without the stream-K tail, 5: with it, 6: 256x256, 0: automatic
                 with hip.gemm_config(cfg):
                     for _ in range(3): hip.gemm(a, w, bias, n=N, out=out, **kw)
                     torch.cuda.synchronize()
