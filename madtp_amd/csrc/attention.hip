@@ -83,21 +83,59 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             if (a.mask_qk && j < a.Nk) mk[t][r] += a.mask_qk[(size_t)irow * a.ld_mqk + j];
         }
 
+    // K_h / V_h go global -> registers -> LDS.  Up to 8 x 16 B per operand and thread (NT <= 8 in f32) the registers of head
+    // h + 1 are fetched right after head h's image is complete, so the loads fly under head h's MFMAs instead of sitting,
+    // with their full latency, between two barriers of every head (the arithmetic is untouched: bit-identical results).
+    constexpr int NLD = (NKP * CPR + 255) / 256;
+    constexpr bool PREFETCH = NLD <= 8;
+    uint4 kreg[PREFETCH ? NLD : 1], vreg[PREFETCH ? NLD : 1];
+    auto fetch = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CPR, c = idx % CPR;
+            kreg[i] = make_uint4(0, 0, 0, 0);
+            vreg[i] = make_uint4(0, 0, 0, 0);
+            if (idx < NKP * CPR && row < a.Nk) {
+                const size_t grow = (size_t)bkv * a.Nk + row;
+                kreg[i] = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * ESZ + c * 16);
+                vreg[i] = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * ESZ + c * 16);
+            }
+        }
+    };
+    if constexpr (PREFETCH) {
+        if ((int)blockIdx.z < a.H) fetch(blockIdx.z);
+    }
     for (int h = blockIdx.z; h < a.H; h += gridDim.z) {
         __syncthreads();
         // ---- stage K_h, V_h (zero rows beyond Nk: 0 * finite stays 0 in P.V) ----
-        for (int idx = tid; idx < NKP * CPR; idx += 256) {
-            const int row = idx / CPR, c = idx % CPR;
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if (row < a.Nk) {
-                const size_t grow = (size_t)bkv * a.Nk + row;
-                kv = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * ESZ + c * 16);
-                vv = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * ESZ + c * 16);
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = tid + 256 * i;
+                const int row = idx / CPR, c = idx % CPR;
+                if (idx < NKP * CPR) {
+                    *(uint4*)(Ks + row * RB + c * 16) = kreg[i];
+                    *(uint4*)(Vs + row * RB + c * 16) = vreg[i];
+                }
             }
-            *(uint4*)(Ks + row * RB + c * 16) = kv;
-            *(uint4*)(Vs + row * RB + c * 16) = vv;
+        } else {
+            for (int idx = tid; idx < NKP * CPR; idx += 256) {
+                const int row = idx / CPR, c = idx % CPR;
+                uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+                if (row < a.Nk) {
+                    const size_t grow = (size_t)bkv * a.Nk + row;
+                    kv = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * ESZ + c * 16);
+                    vv = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * ESZ + c * 16);
+                }
+                *(uint4*)(Ks + row * RB + c * 16) = kv;
+                *(uint4*)(Vs + row * RB + c * 16) = vv;
+            }
         }
         __syncthreads();
+        if constexpr (PREFETCH) {
+            if (h + (int)gridDim.z < a.H) fetch(h + gridDim.z);
+        }
         if (!active) continue;
 
         // ---- Q fragment: row i, d = 4*(4s+g)+e ----
@@ -1209,6 +1247,7 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
 template <typename T, bool SCORES>
 int dispatch_nt(const AttnArgs& a, hipStream_t s) {
     const int nt = (a.Nk + 15) / 16;
+    if (nt <= 2) return launch_attn<T, 2, SCORES>(a, s);  // <= 32 keys: the text encoder's self-attention (20-35 tokens)
     if (nt <= 4) return launch_attn<T, 4, SCORES>(a, s);
     if (nt <= 6) return launch_attn<T, 6, SCORES>(a, s);  // 81-96 keys: nine of the twelve ViT layers of the headline workload
     if (nt <= 8) return launch_attn<T, 8, SCORES>(a, s);
