@@ -18,7 +18,7 @@ from torch import nn
 
 from . import hip
 from .runtime import PreparedCache, f32_ptr, compute_dtype, dtype_code, lin_of, prepare_linear, require_gpu, as_f32_contig, to_compute
-from .utils import Query_model
+from .utils import DeferredAttFt, Query_model
 
 
 class LayerNorm(nn.LayerNorm):
@@ -94,7 +94,10 @@ class ResidualAttentionBlock(nn.Module):
         B, N, C = xb.shape
         token_attn = None
         if space_dict is not None:  # :239-245
-            token_attn, sd_ft_all, _ = self.query_model(xb[:, 1:, :], space_dict, return_token_att=True, acc_ft=sd_ft_all)
+            if isinstance(sd_ft_all, DeferredAttFt):  # Transformer.forward sums the blocks' att_ft in one launch at the end
+                token_attn, _, _ = self.query_model(xb[:, 1:, :], space_dict, return_token_att=True, defer=sd_ft_all)
+            else:
+                token_attn, sd_ft_all, _ = self.query_model(xb[:, 1:, :], space_dict, return_token_att=True, acc_ft=sd_ft_all)
         prune = space_dict is not None and temperature > 0
         w = self._weights()
         x_attn, po = hip.vit_block_attn(w, xb, token_attn, temperature if prune else 0)  # :247 + Reduce_token :196-218
@@ -123,7 +126,17 @@ class Transformer(nn.Module):
         self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask, sd_dim=sd_dim) for _ in range(layers)])
 
     def forward(self, x: torch.Tensor, space_dict=None, temperature=0, sd_ft_all=None, max_keep=1):
-        return self.resblocks((x, space_dict, temperature, sd_ft_all, max_keep))
+        # `sd_ft_all = sd_ft_all + sd_ft` of every block (clip/model.py:243-245) as ONE launch behind the last block when the
+        # sum starts here (sd_ft_all is None): the blocks record their (logits, mapped q) pairs in a DeferredAttFt that rides in
+        # the tuple's sd_ft_all slot (same values: fast mode one bf16-MFMA launch, parity modes the exact kernel in layer order)
+        defer = None
+        if space_dict is not None and sd_ft_all is None and len(self.resblocks) > 0 \
+                and all(isinstance(b, ResidualAttentionBlock) for b in self.resblocks):
+            defer = self.resblocks[0].query_model.deferred()
+        if defer is None:
+            return self.resblocks((x, space_dict, temperature, sd_ft_all, max_keep))
+        x, space_dict, temperature, d, max_keep = self.resblocks((x, space_dict, temperature, defer, max_keep))
+        return x, space_dict, temperature, (d.finish() if d.pairs else None), max_keep
 
 
 class VisionTransformer(nn.Module):

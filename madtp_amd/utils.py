@@ -94,10 +94,11 @@ class Query_model(nn.Module):
         self.compute_att_ft = True  # att_ft only feeds the training loss (blip_nlvr.py:86-96); eval callers may clear
 
     def deferred(self):
-        """A DeferredAttFt for an encoder loop, or None when att_ft must be produced per call (no q_map: the mapped q of CLIP is
-        a per-layer temporary).  Fast mode: one bf16-MFMA launch over all layers; parity modes: one launch of the exact-f32 kernel
-        that keeps the reference's per-layer summation order (bit-identical to accumulating layer by layer)."""
-        if self.compute_att_ft and not self.map_func:
+        """A DeferredAttFt for an encoder loop, or None when att_ft is not computed.  Fast mode: one bf16-MFMA launch over all
+        layers; parity modes: one launch of the exact-f32 kernel that keeps the reference's per-layer summation order
+        (bit-identical to accumulating layer by layer).  With a q_map (CLIP: every block has its own query model) the layers'
+        mapped q tensors are kept alive by the DeferredAttFt until that launch."""
+        if self.compute_att_ft:
             return DeferredAttFt(self.att_dim, exact=compute_dtype() != torch.bfloat16)
         return None
 
@@ -160,8 +161,12 @@ class Query_model(nn.Module):
                 rows, off = ft.float().contiguous().view(B * n, D), 0
             q = hip.gemm(to_compute(rows.contiguous()), qm.w, qm.b, out_dtype=torch.float32, n=qm.n).view(B, n + off, -1)
             if off == 1:
-                token_att, att_ft = hip.query_model(q, sdl.w, K, att_ft=acc_ft, want_att_ft=self.compute_att_ft,
+                want = self.compute_att_ft and defer is None
+                token_att, att_ft = hip.query_model(q, sdl.w, K, att_ft=acc_ft, want_att_ft=want,
                                                     sd_dim=self.att_dim, sd_split=split)
+                if self.compute_att_ft and not want:  # the mapped q stays alive in the DeferredAttFt until its one launch
+                    defer.add(token_att, q[:, 1:, :])
+                    return token_att, None, sd
                 return token_att, (att_ft if self.compute_att_ft else acc_ft), sd
             rows, ftq = q.view(B * n, -1), q
         else:
