@@ -301,6 +301,14 @@ int madtp_vit_block(const madtp_vit_block_w* w, const float* x, float* x_attn, f
                     float* threshold, int32_t* count, int64_t* indices, int64_t* indices_sort, int* k_out, int* k_used,
                     void* stream);
 
+/* The same with the pruning rule of CLIP's ResidualAttentionBlock (clip/model.py:220-221): the layer is pruned unless
+ * k <= max_keep or N-1-k <= 1 (the text tower passes max_keep = position of the EOT token + 2, :492; max_keep = 0 is
+ * madtp_vit_block).  As in madtp_vit_block the host read of k overlaps the projection GEMM. */
+int madtp_vit_block_keep(const madtp_vit_block_w* w, const float* x, float* x_attn, float* y, void* ws, size_t ws_bytes, int B, int N,
+                    const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature, float* score,
+                    float* threshold, int32_t* count, int64_t* indices, int64_t* indices_sort, int max_keep, int* k_out, int* k_used,
+                    void* stream);
+
 /* Query_model.forward(return_token_att=True) (models/utils.py:147-183) over a contiguous token buffer x[B,N,dim]:
  * token_attn_full[B*N, 128] = x @ sd^T (exact-f32 MFMA; sd_w is f32 [128,dim], rows >= K zero); row b*N+1+t is patch t.
  * att_ft[B,K,dim] (+)= softmax_t(logits/sqrt(sd_dim)) @ x[:,1:]  (skipped when att_ft is NULL). */

@@ -100,19 +100,9 @@ class ResidualAttentionBlock(nn.Module):
                 token_attn, sd_ft_all, _ = self.query_model(xb[:, 1:, :], space_dict, return_token_att=True, acc_ft=sd_ft_all)
         prune = space_dict is not None and temperature > 0
         w = self._weights()
-        x_attn, po = hip.vit_block_attn(w, xb, token_attn, temperature if prune else 0)  # :247 + Reduce_token :196-218
-        self.last_prune = None
-        k_use, score = 0, None
-        if prune:
-            score, thr, count, kmax = po
-            k = hip.batch_max_count(count)
-            self.last_prune = {"k": k, "score": score, "threshold": thr, "count": count, "pruned": False,
-                               "indices": None, "indices_sort": None}
-            if not (k <= int(max_keep) or (N - 1 - k) <= 1):  # :220-221 (max_keep is a 0-dim tensor on the text side, :492)
-                k_use = k
-        y, indices, indices_sort = hip.vit_block_mlp(w, x_attn, k_use, score)  # :222-234, :260
-        if k_use:
-            self.last_prune.update(pruned=True, indices=indices, indices_sort=indices_sort)
+        # :247 + Reduce_token :196-218 + :222-234, :260 in one library call: the host read of k overlaps the projection GEMM
+        # (max_keep is a 0-dim tensor on the text side, :492 - Transformer.forward converts it once)
+        y, self.last_prune = hip.vit_block(w, xb, token_attn, temperature if prune else 0, max_keep=int(max_keep))
         return y.permute(1, 0, 2), space_dict, temperature, sd_ft_all, max_keep
 
 
@@ -133,6 +123,8 @@ class Transformer(nn.Module):
         if space_dict is not None and sd_ft_all is None and len(self.resblocks) > 0 \
                 and all(isinstance(b, ResidualAttentionBlock) for b in self.resblocks):
             defer = self.resblocks[0].query_model.deferred()
+        if torch.is_tensor(max_keep):
+            max_keep = int(max_keep)  # one host read per tower instead of one per block
         if defer is None:
             return self.resblocks((x, space_dict, temperature, sd_ft_all, max_keep))
         x, space_dict, temperature, d, max_keep = self.resblocks((x, space_dict, temperature, defer, max_keep))

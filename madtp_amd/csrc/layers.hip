@@ -244,10 +244,10 @@ extern "C" int madtp_vit_block_mlp(const madtp_vit_block_w* w, const float* x, f
 // Whole Block.forward (vit.py:184-205) in one call: attention half, k = max_b count read on the host (the reference's one
 // synchronisation per layer, vit.py:145), the pruning rule of vit.py:148-149, MLP half launched straight away.
 // y has room for [B,N,dim], indices for [B,N-1]; on return *k_used > 0 means y is [B,k_used+2,dim] and indices [B,k_used].
-extern "C" int madtp_vit_block(const madtp_vit_block_w* w, const float* x, float* x_attn, float* y, void* ws, size_t ws_bytes,
-                               int B, int N, const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature,
-                               float* score, float* threshold, int32_t* count, int64_t* indices, int64_t* indices_sort,
-                               int* k_out, int* k_used, void* stream) {
+static int vit_block_impl(const madtp_vit_block_w* w, const float* x, float* x_attn, float* y, void* ws, size_t ws_bytes,
+                          int B, int N, const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature,
+                          float* score, float* threshold, int32_t* count, int64_t* indices, int64_t* indices_sort,
+                          int max_keep, int* k_out, int* k_used, void* stream) {
     if (!k_out || !k_used) return MADTP_E_BADARG;
     *k_out = 0; *k_used = 0;
     int32_t k = 0;
@@ -255,9 +255,27 @@ extern "C" int madtp_vit_block(const madtp_vit_block_w* w, const float* x, float
                       nullptr, temperature > 0.f ? &k : nullptr, stream));
     if (temperature > 0.f) {
         *k_out = k;
-        if (!(k < 1 || (N - 1 - k) <= 1)) *k_used = k;  // vit.py:148-149
+        // vit.py:148-149 `k < 1` is max_keep = 0; clip/model.py:220-221 `k <= max_keep`
+        if (!(k <= max_keep || (N - 1 - k) <= 1)) *k_used = k;
     }
     return madtp_vit_block_mlp(w, x_attn, y, ws, ws_bytes, B, N, *k_used, score, indices, indices_sort, stream);
+}
+
+extern "C" int madtp_vit_block(const madtp_vit_block_w* w, const float* x, float* x_attn, float* y, void* ws, size_t ws_bytes,
+                               int B, int N, const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature,
+                               float* score, float* threshold, int32_t* count, int64_t* indices, int64_t* indices_sort,
+                               int* k_out, int* k_used, void* stream) {
+    return vit_block_impl(w, x, x_attn, y, ws, ws_bytes, B, N, token_attn, ldt_row, ldt_batch, K, temperature, score, threshold,
+                          count, indices, indices_sort, 0, k_out, k_used, stream);
+}
+
+extern "C" int madtp_vit_block_keep(const madtp_vit_block_w* w, const float* x, float* x_attn, float* y, void* ws, size_t ws_bytes,
+                                    int B, int N, const float* token_attn, int ldt_row, int ldt_batch, int K, float temperature,
+                                    float* score, float* threshold, int32_t* count, int64_t* indices, int64_t* indices_sort,
+                                    int max_keep, int* k_out, int* k_used, void* stream) {
+    if (max_keep < 0) return MADTP_E_BADARG;
+    return vit_block_impl(w, x, x_attn, y, ws, ws_bytes, B, N, token_attn, ldt_row, ldt_batch, K, temperature, score, threshold,
+                          count, indices, indices_sort, max_keep, k_out, k_used, stream);
 }
 
 // Query_model (models/utils.py:147-183) on the token buffer in place: logits of ALL rows of x (the CLS row is computed

@@ -12,7 +12,7 @@ import torch
 
 F32, BF16, F16S = 0, 1, 2  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -65,6 +65,8 @@ _SIGS = {
     "madtp_attention_indexed": (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_float, c_int, c_void_p]),
     "madtp_vit_block": (c_int, [c_void_p] * 5 + [c_size_t, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
                         + [c_void_p] * 7 + [c_void_p]),
+    "madtp_vit_block_keep": (c_int, [c_void_p] * 5 + [c_size_t, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
+                             + [c_void_p] * 5 + [c_int] + [c_void_p] * 2 + [c_void_p]),
     "madtp_bert_layer": (c_int, [c_void_p] * 7 + [c_size_t, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
                          + [c_void_p] * 5 + [c_int] + [c_void_p] * 9 + [c_int] + [c_void_p] * 3),
     "madtp_vit_encoder": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_float, c_void_p]),
@@ -558,9 +560,10 @@ def _carve(buf, *shape):
     return buf.view(-1)[:n].view(*shape)
 
 
-def vit_block(wstruct, x, token_attn, temperature):
+def vit_block(wstruct, x, token_attn, temperature, max_keep=0):
     """Block.forward in ONE library call (attention half, host read of k, pruning rule, MLP half).
-    -> (y [B,N',D], info or None); info = dict(k, score, threshold, count, pruned, indices, indices_sort)."""
+    -> (y [B,N',D], info or None); info = dict(k, score, threshold, count, pruned, indices, indices_sort).
+    max_keep: CLIP's rule (clip/model.py:220-221: no pruning when k <= max_keep); 0 is the BLIP rule k < 1."""
     B, N, D = x.shape
     lib = load()
     nbytes = lib.madtp_vit_block_workspace(B, N, wstruct.dim, wstruct.fc1.n, wstruct.heads, wstruct.dtype)
@@ -573,9 +576,9 @@ def vit_block(wstruct, x, token_attn, temperature):
         score, thr, count, _ = prune_outputs(B, N - 1, x.device)
         idx = torch.empty((B, N - 1), device=x.device, dtype=torch.int64)
         idx_sort = torch.empty((B, N - 1), device=x.device, dtype=torch.int64)
-        _check(lib.madtp_vit_block(ctypes.byref(wstruct), _p(x), _p(x_attn), _p(ybuf), _p(ws), ws.numel(), B, N, tp, ldr, ldb, K,
-                                   float(temperature), _p(score), _p(thr), _p(count), _p(idx), _p(idx_sort),
-                                   ctypes.byref(k_out), ctypes.byref(k_used), _stream()), "madtp_vit_block")
+        _check(lib.madtp_vit_block_keep(ctypes.byref(wstruct), _p(x), _p(x_attn), _p(ybuf), _p(ws), ws.numel(), B, N, tp, ldr, ldb,
+                                        K, float(temperature), _p(score), _p(thr), _p(count), _p(idx), _p(idx_sort), int(max_keep),
+                                        ctypes.byref(k_out), ctypes.byref(k_used), _stream()), "madtp_vit_block_keep")
         info = {"k": k_out.value, "score": score, "threshold": thr, "count": count, "pruned": False, "indices": None,
                 "indices_sort": None}
         if k_used.value > 0:
