@@ -18,6 +18,9 @@
 // Roofline: MFMA f32 (157 TF) - 4*Nq*Nk*64 flops per (b,h); HBM traffic is q,k,v,out once (K/V re-reads by the
 // other query tiles of the same b hit L2).
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <stdlib.h>
 
 namespace {
 
@@ -32,6 +35,9 @@ struct AttnArgs {
     // optional additive [Nq, Nk] mask shared by all samples and heads (CLIP's causal text mask, clip/mock.py:309-310): element
     // (i, j) at mask_qk[i * ld_mqk + j]; folded into the per-lane key mask (a lane owns one query row)
     const float* mask_qk; int ld_mqk;
+    // attn_bf16_large_kernel with scores and gridDim.z == 2 (two head halves per row block): exchange area of the head-max
+    // [B * row blocks][2][4 waves][2 NT dwords][64 lanes] and one ticket per (row block, wave)
+    unsigned* hm_ws; int* hm_tick;
 };
 
 template <typename T> __device__ __forceinline__ f32x4 load4(const char* p);
@@ -1175,6 +1181,33 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
         }
     }
     if constexpr (SCORES) {
+        if (gridDim.z == 2) {
+            // Two workgroups share this row block, each with half of the heads (launch_attn_bf16_large: launches that would
+            // leave most SIMDs with one wave or none).  The head-max is a max - exact and order-free - so the halves are merged
+            // by whichever wave arrives second: agent-scope stores / loads (written through and read past the L2s: the two
+            // workgroups may sit on different XCDs) around one agent-scope ticket per (row block, wave).
+            const size_t slot = ((size_t)b * gridDim.x + blockIdx.x) * 4 + wave;
+            unsigned* mine = a.hm_ws + ((slot * 2 + blockIdx.z) * (2 * NT)) * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                __hip_atomic_store(mine + (2 * t) * 64, __builtin_bit_cast(unsigned, pmax[t][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + (2 * t + 1) * 64, __builtin_bit_cast(unsigned, pmax[t][1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores are complete (at memory scope) before the ticket
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(a.hm_tick + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old == 0) return;  // the other half writes the column sums
+            if (lane == 0) __hip_atomic_store(a.hm_tick + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned* theirs = a.hm_ws + ((slot * 2 + (1 - blockIdx.z)) * (2 * NT)) * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const unsigned u0 = __hip_atomic_load(theirs + (2 * t) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned u1 = __hip_atomic_load(theirs + (2 * t + 1) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pmax[t][0] = __builtin_elementwise_max(pmax[t][0], __builtin_bit_cast(h2, u0));
+                pmax[t][1] = __builtin_elementwise_max(pmax[t][1], __builtin_bit_cast(h2, u1));
+            }
+        }
         if (active) {
             const int i = i0 + l16;
             const bool valid = i >= 1 && i < a.Nq;
@@ -1191,13 +1224,44 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
     }
 }
 
+// Exchange area of the head split (one per device and stream, allocated on first use; the tickets reset themselves).
+struct HmWorkspace { unsigned* ws; int* tick; };
+constexpr int HM_MAX_WGS = 256, HM_MAX_NT = 40;
+static bool hm_workspace(hipStream_t s, HmWorkspace& out) {
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("MADTP_ATTN_HEAD_SPLIT"); env = e ? atoi(e) : 1; }
+    if (!env) return false;
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, HmWorkspace> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = pool.find({dev, s});
+    if (it == pool.end()) {
+        constexpr size_t WS_BYTES = (size_t)HM_MAX_WGS * 2 * 4 * (2 * HM_MAX_NT) * 64 * 4, TICK_BYTES = (size_t)HM_MAX_WGS * 4 * sizeof(int);
+        char* base = nullptr;
+        if (hipMalloc((void**)&base, WS_BYTES + TICK_BYTES) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipMemsetAsync(base + WS_BYTES, 0, TICK_BYTES, s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(base); return false; }
+        it = pool.emplace(std::make_pair(dev, s), HmWorkspace{(unsigned*)base, (int*)(base + WS_BYTES)}).first;
+    }
+    out = it->second;
+    return true;
+}
+
 template <int NCH, bool SCORES>
-int launch_attn_bf16_large(const AttnArgs& a, hipStream_t s) {
+int launch_attn_bf16_large(const AttnArgs& a_in, hipStream_t s) {
+    AttnArgs a = a_in;
     int gz = 1;
+    const int wgs = ((a.Nq + 63) / 64) * a.B;
     if (!SCORES) {  // cross-attention against a long image sequence: few query rows, spread the heads over workgroups
-        const int wgs = ((a.Nq + 63) / 64) * a.B;
         gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
         if (gz > a.H) gz = a.H;
+    } else if (NCH * 8 <= HM_MAX_NT && wgs <= HM_MAX_WGS && a.H % 2 == 0) {
+        // With scores a row block walks all heads (the head-max).  B x ceil(N/64) <= 256 workgroups of four waves leave the
+        // 1024 SIMDs with one wave or none (VQA: 32 x 7), each bound by its own dependent instruction stream: two workgroups
+        // per row block take half of the heads each and merge their head-max at the end (MADTP_ATTN_HEAD_SPLIT=0: off).
+        HmWorkspace hw;
+        if (hm_workspace(s, hw)) { gz = 2; a.hm_ws = hw.ws; a.hm_tick = hw.tick; }
     }
     const dim3 grid((a.Nq + 63) / 64, a.B, gz);
     // Two stages.  The three-stage ring (STG = 3: two chunks in flight behind counted vmcnt waits, 104 KiB, one workgroup per
@@ -1308,7 +1372,7 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
     a.nrt = (Nq + 15) / 16;
     a.scale = scale;
     a.kvidx = kv_batch_index;
-    a.pair = 0; a.q2 = a.k2 = a.v2 = nullptr; a.out2 = nullptr; a.mask2 = nullptr;
+    a.pair = 0; a.q2 = a.k2 = a.v2 = nullptr; a.out2 = nullptr; a.mask2 = nullptr; a.hm_ws = nullptr; a.hm_tick = nullptr;
     a.mask_qk = mask_qk; a.ld_mqk = ld_mask_qk;
     hipStream_t s = (hipStream_t)stream;
     const bool scores = colsum_part != nullptr;
@@ -1353,7 +1417,7 @@ extern "C" int madtp_attention_pair(const void* q0, const void* q1, const void* 
     a.q = (const char*)q0; a.k = (const char*)k0; a.v = (const char*)v0; a.out = (char*)out0; a.mask = add_mask0;
     a.q2 = (const char*)q1; a.k2 = (const char*)k1; a.v2 = (const char*)v1; a.out2 = (char*)out1; a.mask2 = add_mask1;
     a.pair = 1;
-    a.mask_qk = nullptr; a.ld_mqk = 0;
+    a.mask_qk = nullptr; a.ld_mqk = 0; a.hm_ws = nullptr; a.hm_tick = nullptr;
     a.colsum = nullptr; a.p0 = nullptr; a.onorm = nullptr;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.nrt = (Nq + 15) / 16;
