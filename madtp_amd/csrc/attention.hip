@@ -40,6 +40,30 @@ struct AttnArgs {
     unsigned* hm_ws; int* hm_tick;
 };
 
+// Exchange area of the head split (one per device and stream, allocated on first use; the tickets reset themselves).
+struct HmWorkspace { unsigned* ws; int* tick; };
+constexpr int HM_MAX_WGS = 256, HM_MAX_NT = 40;
+static bool hm_workspace(hipStream_t s, HmWorkspace& out) {
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("MADTP_ATTN_HEAD_SPLIT"); env = e ? atoi(e) : 1; }
+    if (!env) return false;
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, HmWorkspace> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = pool.find({dev, s});
+    if (it == pool.end()) {
+        constexpr size_t WS_BYTES = (size_t)HM_MAX_WGS * 2 * 4 * (2 * HM_MAX_NT) * 64 * 4, TICK_BYTES = (size_t)HM_MAX_WGS * 4 * sizeof(int);
+        char* base = nullptr;
+        if (hipMalloc((void**)&base, WS_BYTES + TICK_BYTES) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipMemsetAsync(base + WS_BYTES, 0, TICK_BYTES, s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(base); return false; }
+        it = pool.emplace(std::make_pair(dev, s), HmWorkspace{(unsigned*)base, (int*)(base + WS_BYTES)}).first;
+    }
+    out = it->second;
+    return true;
+}
+
 template <typename T> __device__ __forceinline__ f32x4 load4(const char* p);
 template <> __device__ __forceinline__ f32x4 load4<float>(const char* p) { return *(const f32x4*)p; }
 template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const char* p) {
@@ -244,6 +268,31 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     }
 
     if constexpr (SCORES) {
+        if (gridDim.z == 2) {
+            // two workgroups per row block, half of the heads each (launch_attn): the head-max halves are merged by the wave that
+            // arrives second - a max of the same f32 values, so the column sums are bit-identical to the one-workgroup launch
+            // (protocol: attn_bf16_large_kernel)
+            const size_t slot = ((size_t)b * gridDim.x + blockIdx.x) * 4 + wave;
+            unsigned* mine = a.hm_ws + ((slot * 2 + blockIdx.z) * (2 * HM_MAX_NT)) * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __hip_atomic_store(mine + (4 * t + r) * 64, __float_as_uint(pmax[t][r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(a.hm_tick + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old == 0) return;
+            if (lane == 0) __hip_atomic_store(a.hm_tick + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned* theirs = a.hm_ws + ((slot * 2 + (1 - blockIdx.z)) * (2 * HM_MAX_NT)) * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pmax[t][r] = fmaxf(pmax[t][r], __uint_as_float(__hip_atomic_load(theirs + (4 * t + r) * 64, __ATOMIC_RELAXED,
+                                                                                      __HIP_MEMORY_SCOPE_AGENT)));
+        }
         if (active) {
             const int i = i0 + l16;
             const bool valid = i >= 1 && i < a.Nq;
@@ -1187,7 +1236,7 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
             // by whichever wave arrives second: agent-scope stores / loads (written through and read past the L2s: the two
             // workgroups may sit on different XCDs) around one agent-scope ticket per (row block, wave).
             const size_t slot = ((size_t)b * gridDim.x + blockIdx.x) * 4 + wave;
-            unsigned* mine = a.hm_ws + ((slot * 2 + blockIdx.z) * (2 * NT)) * 64 + lane;
+            unsigned* mine = a.hm_ws + ((slot * 2 + blockIdx.z) * (2 * HM_MAX_NT)) * 64 + lane;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 __hip_atomic_store(mine + (2 * t) * 64, __builtin_bit_cast(unsigned, pmax[t][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1199,7 +1248,7 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
             old = __builtin_amdgcn_readfirstlane(old);
             if (old == 0) return;  // the other half writes the column sums
             if (lane == 0) __hip_atomic_store(a.hm_tick + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned* theirs = a.hm_ws + ((slot * 2 + (1 - blockIdx.z)) * (2 * NT)) * 64 + lane;
+            const unsigned* theirs = a.hm_ws + ((slot * 2 + (1 - blockIdx.z)) * (2 * HM_MAX_NT)) * 64 + lane;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const unsigned u0 = __hip_atomic_load(theirs + (2 * t) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1222,30 +1271,6 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
                 }
         }
     }
-}
-
-// Exchange area of the head split (one per device and stream, allocated on first use; the tickets reset themselves).
-struct HmWorkspace { unsigned* ws; int* tick; };
-constexpr int HM_MAX_WGS = 256, HM_MAX_NT = 40;
-static bool hm_workspace(hipStream_t s, HmWorkspace& out) {
-    static int env = -1;
-    if (env < 0) { const char* e = getenv("MADTP_ATTN_HEAD_SPLIT"); env = e ? atoi(e) : 1; }
-    if (!env) return false;
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, HmWorkspace> pool;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = pool.find({dev, s});
-    if (it == pool.end()) {
-        constexpr size_t WS_BYTES = (size_t)HM_MAX_WGS * 2 * 4 * (2 * HM_MAX_NT) * 64 * 4, TICK_BYTES = (size_t)HM_MAX_WGS * 4 * sizeof(int);
-        char* base = nullptr;
-        if (hipMalloc((void**)&base, WS_BYTES + TICK_BYTES) != hipSuccess) { (void)hipGetLastError(); return false; }
-        if (hipMemsetAsync(base + WS_BYTES, 0, TICK_BYTES, s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(base); return false; }
-        it = pool.emplace(std::make_pair(dev, s), HmWorkspace{(unsigned*)base, (int*)(base + WS_BYTES)}).first;
-    }
-    out = it->second;
-    return true;
 }
 
 template <int NCH, bool SCORES>
@@ -1293,15 +1318,21 @@ int dispatch_large(const AttnArgs& a, hipStream_t s) {
 }
 
 template <typename T, int NT, bool SCORES>
-int launch_attn(const AttnArgs& a, hipStream_t s) {
+int launch_attn(const AttnArgs& a_in, hipStream_t s) {
     constexpr int RB = 64 * (int)sizeof(T) + 16;
     const size_t lds = (size_t)2 * NT * 16 * RB;
     MADTP_ENSURE_MAX_LDS((attn_kernel<T, NT, SCORES>), lds);
     int gz = 1;
+    AttnArgs a = a_in;
+    const int wgs = ((a.Nq + 63) / 64) * a.B;
     if (!SCORES) {  // cross-attention has few query rows: spread heads over workgroups
-        const int wgs = ((a.Nq + 63) / 64) * a.B;
         gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
         if (gz > a.H) gz = a.H;
+    } else if (4 * NT <= 2 * HM_MAX_NT && wgs <= HM_MAX_WGS && a.H % 2 == 0) {
+        // with scores a row block walks all heads: a launch that leaves the SIMDs with one wave or none (128 images x 2 row
+        // blocks in the parity modes, 64 text samples) runs two workgroups per row block, half of the heads each
+        HmWorkspace hw;
+        if (hm_workspace(s, hw)) { gz = 2; a.hm_ws = hw.ws; a.hm_tick = hw.tick; }
     }
     hipLaunchKernelGGL((attn_kernel<T, NT, SCORES>), dim3((a.Nq + 63) / 64, a.B, gz), dim3(256), lds, s, a);
     MADTP_LAUNCH_CHECK();
