@@ -42,7 +42,7 @@ struct AttnArgs {
 
 // Exchange area of the head split (one per device and stream, allocated on first use; the tickets reset themselves).
 struct HmWorkspace { unsigned* ws; int* tick; };
-constexpr int HM_MAX_WGS = 256, HM_MAX_NT = 40;
+constexpr int HM_MAX_WGS = 384, HM_MAX_NT = 40;
 static bool hm_workspace(hipStream_t s, HmWorkspace& out) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("MADTP_ATTN_HEAD_SPLIT"); env = e ? atoi(e) : 1; }

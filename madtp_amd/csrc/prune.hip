@@ -427,14 +427,18 @@ __global__ __launch_bounds__(512) void token_score_split_kernel(const float* __r
 }
 
 // ----------------------------------------------------------------------------------------------- token_select
-__global__ __launch_bounds__(256) void token_select_kernel(const float* __restrict__ score, int k,
-                                                           int64_t* __restrict__ indices, int64_t* __restrict__ indices_sort,
-                                                           int32_t* __restrict__ dst_pos, float* __restrict__ merge_w, int n) {
+// NTHR threads per sample: 256, or 1024 for long sequences (the ranking is n^2 / NTHR compare steps per thread: 35 us at 900
+// tokens with 256 threads).  The sum of the dropped scores keeps the 256-thread association in both variants (same bits).
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void token_select_kernel(const float* __restrict__ score, int k,
+                                                            int64_t* __restrict__ indices, int64_t* __restrict__ indices_sort,
+                                                            int32_t* __restrict__ dst_pos, float* __restrict__ merge_w, int n) {
+    constexpr int NW = NTHR / 64;
     __shared__ float s[MAXN];
     __shared__ unsigned key_s[MAXN];
     __shared__ int rank_s[MAXN];
-    __shared__ float red[4];
-    __shared__ int wsum[4];
+    __shared__ float red[NW];
+    __shared__ int wsum[NW];
     __shared__ int base_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(256) void token_select_kernel(const float* __restri
     // ordinary numbers key(w) > key(v) <=> w > v (-0 is folded onto +0 first), and a NaN score (NaN / Inf upstream) ranks below
     // everything instead of tying with every token - every rank 0..n-1 is produced exactly once, indices / indices_sort /
     // dst_pos are always fully written permutations and no later kernel reads an uninitialised index.
-    for (int t = tid; t < n; t += 256) {
+    for (int t = tid; t < n; t += NTHR) {
         const float v = score[(size_t)b * n + t];
         s[t] = v;
         const unsigned u = __float_as_uint(v + 0.0f);
@@ -451,9 +455,7 @@ __global__ __launch_bounds__(256) void token_select_kernel(const float* __restri
     if (tid == 0) base_s = 0;
     __syncthreads();
     // rank by counting: #tokens with a larger score (ties: lower index first) == position in a stable descending sort
-    float dsum_l = 0.f;
-    for (int t = tid; t < n; t += 256) {
-        const float v = s[t];
+    for (int t = tid; t < n; t += NTHR) {
         const unsigned kv = key_s[t];
         int r = 0;
         for (int u = 0; u < n; ++u) {
@@ -462,11 +464,15 @@ __global__ __launch_bounds__(256) void token_select_kernel(const float* __restri
         }
         rank_s[t] = r;
         indices_sort[(size_t)b * n + r] = t;
-        if (r >= k) dsum_l += v;
     }
-    const float dsum = block_sum(dsum_l, red, tid, 4);  // sum of dropped scores (vit.py:158-159)
+    __syncthreads();
+    float dsum_l = 0.f;  // thread tid < 256 sums its tokens tid, tid + 256, ... in that order (the other threads add +0)
+    if (tid < 256)
+        for (int t = tid; t < n; t += 256)
+            if (rank_s[t] >= k) dsum_l += s[t];
+    const float dsum = block_sum(dsum_l, red, tid, NW);  // sum of dropped scores (vit.py:158-159)
     // stable compaction of kept tokens in ascending token order: ballot + popcount prefix per wave, serial over chunks
-    for (int c0 = 0; c0 < n; c0 += 256) {
+    for (int c0 = 0; c0 < n; c0 += NTHR) {
         const int t = c0 + tid;
         const bool keep = t < n && rank_s[t] < k;
         const unsigned long long bal = __ballot(keep);
@@ -486,7 +492,11 @@ __global__ __launch_bounds__(256) void token_select_kernel(const float* __restri
             }
         }
         __syncthreads();
-        if (tid == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < NW; ++w) tot += wsum[w];
+            base_s += tot;
+        }
         __syncthreads();
     }
 }
@@ -1524,8 +1534,12 @@ extern "C" int madtp_token_select(const float* score, int k, int64_t* indices, i
                                   float* merge_w, int B, int n, void* stream) {
     if (!score || !indices || !indices_sort || !dst_pos || !merge_w || B <= 0 || n <= 0) return MADTP_E_BADARG;
     if (k < 1 || k > n || n > MAXN) return MADTP_E_SHAPE;
-    hipLaunchKernelGGL(token_select_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, score, k, indices, indices_sort,
-                       dst_pos, merge_w, n);
+    if (n > 320)
+        hipLaunchKernelGGL(token_select_kernel<1024>, dim3(B), dim3(1024), 0, (hipStream_t)stream, score, k, indices, indices_sort,
+                           dst_pos, merge_w, n);
+    else
+        hipLaunchKernelGGL(token_select_kernel<256>, dim3(B), dim3(256), 0, (hipStream_t)stream, score, k, indices, indices_sort,
+                           dst_pos, merge_w, n);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
