@@ -293,7 +293,10 @@ def _ref_attention(qkv, B, N, H, scale, mask=None):
 
 
 @pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 20, 12), (1, 1 + 16 * 4, 2), (2, 130, 12), (2, 180, 12), (1, 256, 3), (2, 17, 1),
-                                   (1, 577, 12), (2, 901, 3), (1, 257, 2), (1, 1024, 1)])
+                                   (1, 577, 12), (2, 901, 3), (1, 257, 2), (1, 1024, 1),
+                                   # head split (two workgroups per row block, halves merged through the ticket) on many row
+                                   # blocks at once: 16 x 5 / 24 x 2 blocks, and an odd head count (no split)
+                                   (16, 320, 12), (24, 96, 12), (4, 300, 3)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_self_attention_with_scores(hip, B, N, H, dtype):
     td = torch.float32 if dtype == "f32" else torch.bfloat16
@@ -308,7 +311,8 @@ def test_self_attention_with_scores(hip, B, N, H, dtype):
         tol = 3e-5 if dtype == "f32" else 2e-2
         assert (out.float().cpu() - ro).abs().max().item() < tol * max(1, ro.abs().max().item())
         # f32 storage -> exact-f32 MFMA kernel; bf16 storage -> bf16-MFMA fast kernel (P rounded to bf16 for P.V)
-        assert (cs.sum(1).cpu() - rcol).abs().max().item() < (1e-4 if dtype == "f32" else 2e-4)
+        # (bf16 kernels: the head-max is held as f16 pairs, 2^-11 relative per value; the bound scales with the column mass)
+        assert (cs.sum(1).cpu() - rcol).abs().max().item() < (1e-4 if dtype == "f32" else 2e-4 * max(1.0, 0.5 * rcol.max().item()))
         assert (p0.cpu() - rp0).abs().max().item() < (1e-5 if dtype == "f32" else 2e-5)
         assert (on.cpu() - rn).abs().max().item() < (1e-4 if dtype == "f32" else 1e-2) * max(1, rn.max().item())
 
