@@ -41,6 +41,7 @@ struct GemmArgs {
     // stream-K tail of the wave-specialised kernel (sk_plan): partial accumulators [8 XCDs][32 units][8 waves][16][64 lanes] f32x4
     // and the per-(tail tile, wave) tickets [8][16][8]; sk == 0: off
     float* sk_ws; int* sk_tick; int sk;
+    int desc;  // gemm_kernel: both operands fit a 32-bit buffer descriptor -> descriptor-based LDS-DMA (no per-slab address arithmetic)
 };
 
 // f16-split operands (common.h).  The kernels walk K as a stream of 2 * K/64 slab steps: step 2t stages [P0 | Q1] of k-slab t,
@@ -112,6 +113,17 @@ __host__ __device__ __forceinline__ int sk_parts(int rem, int gl, int nk) {
     if (p > SK_MAX_PARTS) p = SK_MAX_PARTS;
     if (p > nk / 2) p = nk / 2;  // at least two slabs per piece
     return p >= 2 ? p : 0;
+}
+
+// The same with a buffer descriptor: NQ instructions of this wave, per-lane source offsets roff[] (row within the tile, swizzled
+// slot - constants of the kernel), scalar offset soff (tile origin + K position); rows past `bytes` read as zeros.
+// (A __device__ function on purpose: with these builtins inside the kernel's issue lambda the host pass of this compiler emits
+//  no launch stub for the kernel template.)
+template <int NQ>
+__device__ __forceinline__ void stage_tile_desc(const char* base, unsigned bytes, const unsigned* roff, int soff, char* lds) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + q * 1024), 16, roff[q], soff, 0, 0);
 }
 
 template <int ESZ, int ROWS, bool PERM = false>
@@ -361,17 +373,45 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
     int im0, in0, ikb;
     decode(is_slot, im0, in0, ikb);
     long issued = 0;
+    // Descriptor-based LDS-DMA (g.desc: both operands are below 4 GiB): the per-lane part of a DMA instruction's source - row
+    // within the tile, swizzled 16-byte slot - is a constant VGPR offset, tile origin and K position a scalar offset, and rows
+    // past the matrix fall outside the descriptor (they read as zeros; their outputs are never stored).  stage_tile() rebuilt
+    // the clamped 64-bit address of every instruction of every slab on the VALU: ~50 of the ~180 instructions of a 64x64 slab
+    // step, which at one wave per SIMD (the text encoder's small problems) is what bounds the K loop.
+    unsigned roff_a[BM / 32], roff_w[BN / 32];
+    {
+        const int sub = lane >> 3;
+#pragma unroll
+        for (int q = 0; q < BM / 32; ++q) {
+            const int r = (wave * (BM / 32) + q) * 8 + sub;
+            roff_a[q] = (unsigned)r * (unsigned)g.lda * ESZ + (unsigned)(((lane & 7) ^ swz_key<false>(r)) << 4);
+        }
+#pragma unroll
+        for (int q = 0; q < BN / 32; ++q) {
+            const int r = (wave * (BN / 32) + q) * 8 + sub;
+            roff_w[q] = (unsigned)r * (unsigned)g.ldw * ESZ + (unsigned)(((lane & 7) ^ swz_key<LP_OUT>(r)) << 4);
+        }
+    }
     auto issue_next = [&]() {
         if (issued < total_slabs && !(g.dbg & 2)) {
             char* st = smem + is_stage * STAGE_BYTES;
             int kba = (ikb + is_kt) * ROWB, kbw = kba;
-            if constexpr (X3) {
+            if (X3) {  // (a plain `if` on the constant: an `if constexpr` makes this lambda's body a dependent context that the
+                       //  compiler's HOST pass substitutes too - the descriptor builtins below then fail there, silently, and the
+                       //  kernel template gets no launch stub)
                 const int sl = ikb + is_kt, odd = sl & 1, kt = sl >> 1;
                 kba = (odd * g.K + kt * 64) * 2;
                 kbw = ((1 - odd) * g.K + kt * 64) * 2;
             }
-            stage_tile<ESZ, BM>(g.A, im0, g.M - 1, g.lda, kba, st, wave, lane);
-            stage_tile<ESZ, BN, LP_OUT>(g.W, in0, n_pad_max, g.ldw, kbw, st + A_BYTES, wave, lane);
+            if (g.desc) {
+                stage_tile_desc<BM / 32>(g.A, (unsigned)((size_t)g.M * g.lda * ESZ), roff_a, im0 * g.lda * ESZ + kba,
+                                         st + wave * (BM / 32) * 1024);
+                stage_tile_desc<BN / 32>(g.W, (unsigned)((size_t)(n_pad_max + 1) * g.ldw * ESZ), roff_w, in0 * g.ldw * ESZ + kbw,
+                                         st + A_BYTES + wave * (BN / 32) * 1024);
+            } else {
+                stage_tile<ESZ, BM>(g.A, im0, g.M - 1, g.lda, kba, st, wave, lane);
+                stage_tile<ESZ, BN, LP_OUT>(g.W, in0, n_pad_max, g.ldw, kbw, st + A_BYTES, wave, lane);
+            }
         }
         ++issued;  // phantom slabs past the end keep the wait counts uniform (they issue nothing: see tail wait)
         if (++is_stage == STAGES) is_stage = 0;
@@ -501,6 +541,7 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
             for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 }
+
 
 }  // namespace
 
@@ -1223,6 +1264,12 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     g.ngrp = 0;
     g.pair = 0; g.A2 = g.W2 = nullptr; g.bias2 = nullptr; g.C2 = nullptr;
     g.sk = 0; g.sk_ws = nullptr; g.sk_tick = nullptr;
+    {
+        static int desc_env = -1;  // MADTP_GEMM_DESC=0: gemm_kernel builds its LDS-DMA addresses per instruction (A/B runs)
+        if (desc_env < 0) { const char* e = getenv("MADTP_GEMM_DESC"); desc_env = e ? atoi(e) : 1; }
+        const size_t a_bytes = ((size_t)M + 127) * (size_t)lda * esz, w_bytes = ((size_t)N + 255) * (size_t)ldw * esz;
+        g.desc = desc_env && a_bytes < ((size_t)1 << 31) && w_bytes < ((size_t)1 << 31);
+    }
     // vector epilogue needs 16-byte aligned rows on every epilogue operand
     // (and, for the descriptor-bounded stores, a 256-row block of C below 2 GiB; bf16 output with an f32 residual has no
     // caller on the path and takes the scalar epilogue)
