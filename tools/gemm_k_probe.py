@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """madtp_gemm on the text encoder's problem sizes against K (runs on the GPU box).  Below ~10 us per call the loop is bound by the
 Python/ctypes launch path (a 1-slab problem takes the same 9.7 us as a 12-slab one), so only the long-K rows measure the kernel:
-48 slabs in 20.6 us = 0.43 us per 16 KiB slab = the ~38 GB/s LDS-DMA rate of a CU with one resident 64x64 workgroup."""
+48 slabs in 20.6 us = 0.43 us per 16 KiB slab step of a lone 64x64 workgroup (not a DMA limit: tools/probes/probe_stage_rate.hip)."""
 import os, sys, torch
 sys.path.insert(0, "/root/repo")
 from madtp_amd import hip
