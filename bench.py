@@ -126,8 +126,10 @@ def main():
     mdist.init("nccl")  # "nccl" is RCCL on ROCm; no-op for a single process
     dist = torch.distributed if world > 1 else None
 
+    if world > 1:  # each rank's host thread (k hand-over spin, launches) on its own cores, near its GPU
+        mdist.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device_index=local_rank)
     from madtp_amd import build, configs, hip, runtime
-    if rank == 0:  # one builder per node (the prebuilt .so normally travels with the snapshot: no-op); the others wait
+    if local_rank == 0:  # one builder per NODE (the prebuilt .so normally travels with the snapshot: no-op); the others wait
         build.build(verbose=False)
     if dist is not None:
         dist.barrier()
@@ -253,7 +255,7 @@ def main():
         if not args.no_parity:
             modes = sorted({"fp32", "f16x3", args.precision})
             if headline:
-                from tests.parity_util import nlvr_index_match
+                from oracle.index_match import nlvr_index_match
                 im = nlvr_index_match(model, T, modes, B=args.parity_batch or B, seed=11)
             else:
                 im = generic_index_match(w, model, args.config, T, modes, args.parity_batch or 8)

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import EncoderWeights, PreparedCache, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
+from .runtime import EncoderWeights, PreparedCache, param_epoch, get_precision, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model
 
 
@@ -266,7 +266,8 @@ class _BertLayerBase(nn.Module):
         # (walking the sub-modules costs ~0.1 ms per layer call - visible in the launch-bound small-batch regime) and
         # dropped by _apply() (.to / .half / ...), which may replace Parameter objects
         params = self.__dict__.get("_madtp_params")
-        if params is None:
+        if params is None or self.__dict__.get("_madtp_params_epoch") != param_epoch():
+            self.__dict__["_madtp_params_epoch"] = param_epoch()
             params = [sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias,
                       ao.dense.weight, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias, self.intermediate.dense.weight,
                       self.intermediate.dense.bias, self.output.dense.weight, self.output.dense.bias,
@@ -518,7 +519,7 @@ class _BertEncoderBase(nn.Module):
         between the embedding kernel and the first layer.  Consumed by the next forward of this encoder."""
         if (batch is None or _use_encoder_call(batch, _ENCODER_CALL)) and _ENCODER_CALL and not _KV_AHEAD \
                 and all(type(l) is self.layer_cls for l in self.layer):
-            self.__dict__["_prepared_weights"] = self._encoder_weights()
+            self.__dict__["_prepared_weights"] = (param_epoch(), get_precision(), self._encoder_weights())
 
     def _run_encoder_call(self, hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states,
                           encoder_attention_mask, mode, always_query, cache):
@@ -567,7 +568,9 @@ class _BertEncoderBase(nn.Module):
                                or compute_dtype() == torch.float32 or lp[0].dtype != compute_dtype()):
             lp = None
         ws = self.__dict__.pop("_prepared_weights", None)  # validated by prepare_encoder_call() earlier in this forward
-        if ws is None:
+        if ws is not None and ws[:2] == (param_epoch(), get_precision()):
+            ws = ws[2]
+        else:  # no hint, or parameters re-assigned / precision switched since the hint
             ws = self._encoder_weights()
         kv_ld = 0
         if kv0 is not None:

@@ -181,6 +181,98 @@ __host__ __device__ __forceinline__ constexpr int wfrag_row(int j, int rho) {
     return LP_OUT ? 32 * (j >> 1) + 8 * (rho >> 2) + 4 * (j & 1) + (rho & 3) : 16 * j + rho;
 }
 
+// ---- 32x32x16 fragments (gemm_ws_kernel<.., M32 = true>) ---------------------------------------------------------------
+// v_mfma_f32_32x32x16_bf16 does the work of two 16x16x32 instructions in one issue slot and runs the matrix pipe at its
+// full rate (32 cycles per instruction against 2 x ~17).  Operand lane map: lane l supplies fragment row l & 31 and the 8
+// consecutive k of 16-byte chunk (l >> 5) of the 16-deep k-step; C/D: column l & 31, rows (t & 3) + 8 (t >> 2) + 4 (l >> 5)
+// for register t.  With the operands swapped (D = Wfrag . Afrag^T) lane (l32 = l & 31, h = l >> 5) holds output row
+// 32 i + l32 and, per fragment (i, j), sixteen columns in four runs of four consecutive W-fragment rows 8 q + 4 h + e.
+//   f32 out : W-fragment row rho of fragment j is tile column 32 j + rho                 -> float4 per (i, j, q)
+//   bf16 out: W-fragment row rho is tile column 32 j + swap(bit 2, bit 3)(rho)           -> registers 8p..8p+7 are the 8
+//             consecutive columns 32 j + 16 p + 8 h .. +7 = one 16-byte store per (i, j, p)
+// LDS swizzle of the M32 stage image: a ds_read_b128 is serviced in 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}
+// (+32): the 16 rows of a group (same chunk) must fall on 16 different 16-byte slots of the 256-byte bank row, i.e. the
+// key must take all 8 values over the 8 even and over the 8 odd rows of a group - (r >> 1) & 7 does (the bf16-output row
+// permutation maps each group onto itself).  One key function for both operands.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__host__ __device__ __forceinline__ constexpr int swz_key32(int r) { return (r >> 1) & 7; }
+template <bool LP_OUT>
+__host__ __device__ __forceinline__ constexpr int wfrag_row32(int j, int rho) {
+    return 32 * j + (LP_OUT ? ((rho & ~12) | ((rho & 4) << 1) | ((rho & 8) >> 1)) : rho);
+}
+
+// epilogue of one consumer wave's 64x64 block held as 2x2 fragments of 32x32 (fast path only: the launcher keeps shapes
+// that need the scalar fallback on the 16x16 kernel).  Same structure as epilogue(): every load first, one wait, then
+// descriptor-bounded 16-byte stores; the f32 residual is fetched per 32-row fragment row.
+template <int OM, int ACT, bool HAS_RES>
+__device__ __forceinline__ void epilogue32(const GemmArgs& g, const f32x16 (&acc)[2][2], int row_t, int col_w, int l32, int h) {
+    constexpr bool LP_OUT = OM != OM_F32;
+    constexpr bool FAST_ACT = OM == OM_BF16;
+    constexpr int CSZ = LP_OUT ? 2 : 4;
+    constexpr int NJ = LP_OUT ? 2 : 4;   // column vectors per lane, fragment row and fragment column: p (8 columns) or q (4)
+    constexpr int NV = LP_OUT ? 2 : 1;   // float4s per column vector
+    const int ldc = g.ldc < 0 ? -g.ldc : g.ldc;
+    const int rows_valid = max(min(g.M - row_t, 64), 0);
+    const unsigned long long cb = (unsigned long long)((char*)g.C + (size_t)row_t * ldc * CSZ);
+    const unsigned cb_lo = __builtin_amdgcn_readfirstlane((unsigned)cb);
+    const unsigned cb_hi = __builtin_amdgcn_readfirstlane((unsigned)(cb >> 32));
+    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((unsigned long long)cb_hi << 32) | cb_lo), 0, __builtin_amdgcn_readfirstlane(rows_valid * ldc * CSZ), 0x00020000);
+    // one pass per fragment column j (32 output columns): its bias and - f32 residual stream - the residual of both fragment
+    // rows are fetched first, ONE wait, then the 2 x NJ stores: two exposed round trips per 64x64 block, 48 live load registers
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int colv[NJ];
+        bool cok[NJ];
+        f32x4 bv[NJ][NV];
+#pragma unroll
+        for (int jv = 0; jv < NJ; ++jv) {
+            colv[jv] = col_w + 32 * j + (LP_OUT ? 16 * jv + 8 * h : 8 * jv + 4 * h);
+            cok[jv] = colv[jv] < g.N;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) bv[jv][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (g.bias) {  // uniform; the unconditional wait below closes this diamond
+#pragma unroll
+            for (int jv = 0; jv < NJ; ++jv)
+#pragma unroll
+                for (int u = 0; u < NV; ++u) bv[jv][u] = *(const f32x4*)(g.bias + (cok[jv] ? colv[jv] : 0) + 4 * u);
+        }
+        f32x4 rv[HAS_RES ? 2 : 1][HAS_RES ? NJ : 1];
+        if constexpr (HAS_RES) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = min(row_t + 32 * i + l32, g.M - 1);
+#pragma unroll
+                for (int jv = 0; jv < NJ; ++jv)
+                    rv[i][jv] = *(const f32x4*)(g.residual + (size_t)row * g.ldr + (cok[jv] ? colv[jv] : 0));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) (the first one also covers the previous tile's stores, a main loop old)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jv = 0; jv < NJ; ++jv) {
+                const int t0 = LP_OUT ? 8 * jv : 4 * jv;  // first accumulator register of this column vector
+                f32x4 v[NV];
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[u][e] = epi_act<FAST_ACT, ACT>(fmaf(acc[i][j][t0 + 4 * u + e], g.acc_scale, bv[jv][u][e])) * g.out_scale;
+                    if constexpr (HAS_RES) v[u] += rv[i][jv];
+                }
+                const unsigned off = cok[jv] ? (unsigned)((32 * i + l32) * ldc + colv[jv]) * CSZ : 0x80000000u;
+                u32x4 bits;
+                if constexpr (OM == OM_BF16) bits = __builtin_bit_cast(u32x4, pack_bf16x8(v[0], v[1]));
+                else bits = __builtin_bit_cast(u32x4, v[0]);
+                __builtin_amdgcn_raw_buffer_store_b128(bits, crsrc, off, 0, 0);
+            }
+    }
+}
+
 // HAS_RES: the residual is read by the epilogue itself (kernels that do not prefetch it into `res`); compile-time so
 // that the fast path below is straight-line code.
 template <int OM, int ACT, bool HAS_RES, int FM, int FN, int BM, int BN, bool FAST_ONLY = false, int RM = 1, int RN = 1>
@@ -577,8 +669,9 @@ __device__ __forceinline__ long long ws_now() {
 }
 #define WS_NOW() ws_now()
 #endif
-template <bool X3, int OM>
+template <bool X3, int OM, bool M32 = false>
 __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
+    static_assert(!(X3 && M32), "the 32x32x16 consumer loop exists for the bf16 kernel only");
     constexpr bool LP_OUT = OM != OM_F32;
     constexpr int ESZ = 2, BM = 256, BN = 128, STAGES = 3, NCW = 8, NLW = 4;
     constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
@@ -637,7 +730,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
                 const int idx = lw * PER + q;                     // 8-row group of the stage image: A groups, then W groups
                 const bool is_a = idx < BM / 8;
                 const int r = (is_a ? idx : idx - BM / 8) * 8 + sub;  // row within the A / W tile
-                const int key = is_a ? (r & 7) : swz_key<LP_OUT>(r);
+                const int key = M32 ? swz_key32(r) : (is_a ? (r & 7) : swz_key<LP_OUT>(r));
                 int row = (is_a ? im0 : in0) + r;
                 const int lim = is_a ? g.M - 1 : n_pad_max;
                 row = row < lim ? row : lim;
@@ -685,6 +778,98 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
 
     // ------------------------------------------ consumer ------------------------------------------
     const int grp = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
+    if constexpr (M32) {
+        // 32x32x16 consumer loop: the wave's 64x64 block is 2x2 fragments of 32x32 (4 x 16 accumulators); a 64-deep slab is
+        // four 16-deep k-steps, read as two halves X (k-steps 0, 1) and Y (2, 3) of 4 A + 4 W fragments each - the same 16
+        // ds_read_b128 per slab as the 16x16x32 loop, half a slab ahead of the MFMAs that use them, but 16 MFMA issues per
+        // slab instead of 32.  No stream-K tail on this variant (g.sk == 0).
+        const int l32 = lane & 31, h = lane >> 5;
+        const int a_rd = (grp * 128 + wr * 64 + l32) * ROWB, a_k = swz_key32(l32);
+        const int rw = wc * 64 + wfrag_row32<LP_OUT>(0, l32);
+        const int w_rd = A_BYTES + rw * ROWB, w_k = swz_key32(rw);
+        f32x16 acc[2][2];
+        bf16x8 xa[4], xb[4], ya[4], yb[4];
+        int cur_stage = 0;
+#define WS32_READ(XA, XB, CH)                                                                      \
+    if (!(MADTP_WS_ABLATE & 1) || first)                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
+            XA[ks * 2 + i] = *(const bf16x8*)(st + a_rd + i * 32 * ROWB + ((((CH) + 2 * ks + h) ^ a_k) << 4)); \
+            XB[ks * 2 + i] = *(const bf16x8*)(st + w_rd + i * 32 * ROWB + ((((CH) + 2 * ks + h) ^ w_k) << 4)); \
+        }
+#define WS32_MFMA(XA, XB)                                                                          \
+    if (!(MADTP_WS_ABLATE & 4))                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                              \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(XB[ks * 2 + j], XA[ks * 2 + i], acc[i][j], 0, 0, 0);
+        for (int unit = 0; unit < n_units; ++unit) {
+            const int slot = lb + unit * gl;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+            {
+                constexpr bool first = true;
+                const char* st = smem + cur_stage * STAGE_BYTES;
+                if (!(MADTP_WS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
+                WS32_READ(xa, xb, 0)
+                WS32_READ(ya, yb, 4)
+                __builtin_amdgcn_sched_barrier(0);
+                WS32_MFMA(xa, xb)
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_sched_barrier(0);
+                if (++cur_stage == STAGES) cur_stage = 0;
+            }
+            for (int kt = 1; kt < nk; ++kt) {
+                constexpr bool first = false;
+                const char* st = smem + cur_stage * STAGE_BYTES;
+                if (!(MADTP_WS_ABLATE & 2)) __builtin_amdgcn_s_barrier();
+                WS32_READ(xa, xb, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                WS32_MFMA(ya, yb)
+                __builtin_amdgcn_sched_barrier(0);
+                WS32_READ(ya, yb, 4)
+                __builtin_amdgcn_sched_barrier(0);
+                WS32_MFMA(xa, xb)
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_sched_barrier(0);
+                if (++cur_stage == STAGES) cur_stage = 0;
+            }
+            { WS32_MFMA(ya, yb) }
+            int t = t0 + slot;
+            const bool second = g.pair && t >= tiles1;
+            if (second) t -= tiles1;
+            int ctm, ctn;
+            tile_mn(g, t, ctm, ctn);
+            const int row_t = ctm * BM + grp * 128 + wr * 64, col_w = ctn * BN + wc * 64;
+            if (!((g.dbg & 1) && acc[0][0][0] != 12345.678f)) {
+                GemmArgs ge = g;
+                if (second) { ge.bias = g.bias2; ge.C = g.C2; ge.acc_scale = g.acc_scale2; }
+#define EPI(ACT)                                                                                   \
+    if constexpr (LP_OUT) {                                                                        \
+        epilogue32<OM, ACT, false>(ge, acc, row_t, col_w, l32, h);                                  \
+    } else {                                                                                       \
+        if (g.residual) epilogue32<OM, ACT, true>(ge, acc, row_t, col_w, l32, h);                   \
+        else epilogue32<OM, ACT, false>(ge, acc, row_t, col_w, l32, h);                             \
+    }
+                switch (g.act) {
+                    case MADTP_ACT_GELU_ERF: EPI(MADTP_ACT_GELU_ERF) break;
+                    case MADTP_ACT_QUICK_GELU: EPI(MADTP_ACT_QUICK_GELU) break;
+                    case MADTP_ACT_RELU: EPI(MADTP_ACT_RELU) break;
+                    default: EPI(MADTP_ACT_NONE) break;
+                }
+#undef EPI
+            }
+        }
+#undef WS32_READ
+#undef WS32_MFMA
+        return;
+    }
     const int l16 = lane & 15, grp4 = lane >> 4;
     f32x4 acc[4][4];
     int a_off[4], a_key[4], b_off[4], b_key[4];
@@ -1149,14 +1334,14 @@ static int gemm_force_cfg() {
     if (v < 0) {
         const char* e = getenv("MADTP_GEMM_CFG");
         v = e ? atoi(e) : 0;
-        if (v < 0 || v > 7) v = 0;
+        if (v < 0 || v > 8) v = 0;
         g_force_cfg.store(v, std::memory_order_relaxed);
     }
     return v;
 }
 extern "C" int madtp_gemm_set_config(int cfg) {
     const int prev = gemm_force_cfg();
-    g_force_cfg.store((cfg < 0 || cfg > 7) ? 0 : cfg, std::memory_order_relaxed);
+    g_force_cfg.store((cfg < 0 || cfg > 8) ? 0 : cfg, std::memory_order_relaxed);
     return prev;
 }
 
@@ -1296,7 +1481,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     }
     // MADTP_GEMM_CFG=5 forces the wave-specialised kernel, 1..4 force a gemm_kernel variant (A/B measurements)
     bool ws_ok = lp16 && splitk == 1 &&
-                 (force_cfg == 5 || force_cfg == 7 || (force_cfg == 0 && M >= 4096 && (big || cfg == 0)));
+                 (force_cfg == 5 || force_cfg == 7 || force_cfg == 8 || (force_cfg == 0 && M >= 4096 && (big || cfg == 0)));
     if (pair) {
         static int pair_env = -1;  // MADTP_GEMM_PAIR=0: always two launches (A/B runs)
         if (pair_env < 0) { const char* e = getenv("MADTP_GEMM_PAIR"); pair_env = e ? atoi(e) : 1; }
@@ -1385,15 +1570,23 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         const int grid = 8 * (slots_max < 32 ? slots_max : 32);
         if (sk_on && grid == 256) { g.sk = 1; g.sk_ws = skw.ws; g.sk_tick = skw.tick; }
         const size_t lds = (size_t)3 * (256 + 128) * ROWB;
-#define MADTP_LAUNCH_WS(X3_, OM_)                                                          \
-    do {                                                                                  \
-        MADTP_ENSURE_MAX_LDS((gemm_ws_kernel<X3_, OM_>), lds);                            \
-        hipLaunchKernelGGL((gemm_ws_kernel<X3_, OM_>), dim3(grid), dim3(768), lds, s, g); \
+#define MADTP_LAUNCH_WS(X3_, OM_, M32_)                                                          \
+    do {                                                                                        \
+        MADTP_ENSURE_MAX_LDS((gemm_ws_kernel<X3_, OM_, M32_>), lds);                            \
+        hipLaunchKernelGGL((gemm_ws_kernel<X3_, OM_, M32_>), dim3(grid), dim3(768), lds, s, g); \
     } while (0)
+        // 32x32x16 consumer loop (bf16 operands, vector epilogue, no stream-K tail).  OFF by default - measured SLOWER than the
+        // 16x16x32 loop on every ViT shape of the forward (profiles/r03_gemm_m32_ab.txt: MFMA-only stream 1.57 vs 1.66 PF, whole
+        // kernel 623-837 vs 851-981 TF): MADTP_GEMM_M32=1 turns it on in the automatic dispatch, cfg 8 forces it (tests, A/B runs)
+        static int m32_env = -1;
+        if (m32_env < 0) { const char* e = getenv("MADTP_GEMM_M32"); m32_env = e ? atoi(e) : 0; }
+        const bool m32 = !x3 && g.fast_epi && !g.sk && (force_cfg == 8 || (force_cfg == 0 && m32_env));
         if (x3) {
-            if (c_dtype == MADTP_F16S) MADTP_LAUNCH_WS(true, OM_F16S); else MADTP_LAUNCH_WS(true, OM_F32);
+            if (c_dtype == MADTP_F16S) MADTP_LAUNCH_WS(true, OM_F16S, false); else MADTP_LAUNCH_WS(true, OM_F32, false);
+        } else if (m32) {
+            if (c_dtype == MADTP_BF16) MADTP_LAUNCH_WS(false, OM_BF16, true); else MADTP_LAUNCH_WS(false, OM_F32, true);
         } else {
-            if (c_dtype == MADTP_BF16) MADTP_LAUNCH_WS(false, OM_BF16); else MADTP_LAUNCH_WS(false, OM_F32);
+            if (c_dtype == MADTP_BF16) MADTP_LAUNCH_WS(false, OM_BF16, false); else MADTP_LAUNCH_WS(false, OM_F32, false);
         }
 #undef MADTP_LAUNCH_WS
     } else if (ab_dtype == MADTP_BF16) {

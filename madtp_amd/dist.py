@@ -22,6 +22,55 @@ def init(backend=None):
     return world, rank, local_rank
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(device_index):
+    """CPUs of the NUMA node the GPU hangs off (sysfs local_cpulist of its PCI function), or None when it cannot be read."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
+            cpus = _parse_cpulist(f.read())
+        return cpus or None
+    except Exception:
+        return None
+
+
+def pin_rank_to_cores(local_rank, local_world, device_index=None, cpus_of_gpu=None):
+    """Every rank's host thread spins on a pinned slot 24 times per forward (the k hand-over, csrc/prune.hip) and feeds ~300
+    launches: give each rank its own slice of host cores, on the NUMA node of ITS GPU when sysfs tells (ranks that share a
+    node split that node's cores among themselves), else an even split of the process's current affinity mask.  Returns the
+    CPU set chosen (also when sched_setaffinity is unavailable: empty set = nothing done)."""
+    if not hasattr(os, "sched_getaffinity") or local_world <= 1:
+        return set()
+    allowed = sorted(os.sched_getaffinity(0))
+    local = cpus_of_gpu if cpus_of_gpu is not None else (gpu_local_cpus(device_index) if device_index is not None else None)
+    pool = sorted(set(allowed) & set(local)) if local else []
+    if len(pool) >= 2 and len(pool) < len(allowed):
+        # ranks whose GPUs share this node: assume the usual even layout (local_world GPUs over the nodes that exist)
+        share = max(1, round(local_world * len(pool) / len(allowed)))
+        idx = local_rank % share
+        n = len(pool) // share
+        mine = pool[idx * n:(idx + 1) * n] if n else pool
+    else:
+        n = len(allowed) // local_world
+        mine = allowed[local_rank * n:(local_rank + 1) * n] if n else allowed
+    if mine:
+        try:
+            os.sched_setaffinity(0, mine)
+        except OSError:
+            return set()
+    return set(mine)
+
+
 def shard_range(n_samples, rank, world):
     """Contiguous split of `n_samples` NLVR samples; each sample's two images stay on the same rank
     (blip_nlvr.py:67 splits image_embeds by targets.size(0))."""

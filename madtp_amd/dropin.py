@@ -7,7 +7,11 @@
 
 `install()` registers the mirrors under the reference's module names in sys.modules - `models.vit`, `models.med`,
 `models.nlvr_encoder`, `models.utils` - and leaves every other `models.*` module (blip.py, blip_nlvr.py, blip_retrieval.py,
-blip_vqa.py: pure glue) to be imported from the reference tree itself.  Names those glue files import that are off the
+blip_vqa.py: pure glue) to be imported from the reference tree itself.  The CLIP driver (compress_retrieval_clip_dtp.py:21,
+262) goes `from clip import clip; clip.load(...)`: `clip.model` is registered as the mirror (madtp_amd.clip_model: `build_model`,
+`CLIP`) and `clip.mock` - the reference's import-time monkey-patch of torch.nn.MultiheadAttention
+(clip/mock.py:354-359), which the mirror's blocks do not use - as an empty module, while `clip.clip` (load / tokenize /
+_transform: host glue) and `clip.simple_tokenizer` are imported from the reference tree itself.  Names those glue files import that are off the
 pruned forward path (the text decoder `BertLMHeadModel`, the contrastive-loss helpers of models/utils.py) resolve to stubs
 that raise on use, so a training script fails loudly instead of silently running something else."""
 import importlib
@@ -93,6 +97,44 @@ def install(reference_root=None):
         mod = _module(f"models.{n}", importlib.import_module(f"madtp_amd.{n}"), extras[n])
         sys.modules[f"models.{n}"] = mod
         setattr(pkg, n, mod)
+    _install_clip(reference_root)
+    return pkg
+
+
+def _install_clip(reference_root):
+    """`clip` as a package whose `model` / `mock` sub-modules are ours and whose other files come from the reference tree
+    (clip/__init__.py itself is `from .clip import *; from . import mock`: the first half is done lazily by __getattr__ so
+    that installing does not import the tokenizer / torchvision glue).  Skipped when the tree has no clip/ directory."""
+    for full in ("clip", "clip.model", "clip.mock"):
+        if full in sys.modules and not hasattr(sys.modules[full], "__madtp_mirror__"):
+            raise RuntimeError(f"{full} is already imported from {getattr(sys.modules[full], '__file__', '?')}: "
+                               "call madtp_amd.dropin.install() before the first `import clip`")
+    roots = [os.path.join(p, "clip") for p in ([reference_root] if reference_root else sys.path)
+             if p and os.path.isfile(os.path.join(p, "clip", "clip.py"))]
+    if not roots:
+        return None
+    from . import clip_model
+    pkg = types.ModuleType("clip")
+    pkg.__path__ = roots[:1]
+    pkg.__package__ = "clip"
+    pkg.__madtp_mirror__ = clip_model
+    model = _module("clip.model", clip_model, {})
+    mock = types.ModuleType("clip.mock")
+    mock.__doc__ = "madtp_amd drop-in: the reference's MultiheadAttention monkey-patch is not needed by the mirror (no-op)"
+    mock.__madtp_mirror__ = clip_model
+
+    def _lazy(name):  # clip.load / clip.tokenize / clip.available_models re-exported as clip/__init__.py does
+        if name.startswith("__"):
+            raise AttributeError(name)
+        sub = importlib.import_module("clip.clip")
+        if name == "clip":
+            return sub
+        if name in getattr(sub, "__all__", ()):
+            return getattr(sub, name)
+        raise AttributeError(f"module 'clip' has no attribute {name!r}")
+    pkg.__getattr__ = _lazy
+    pkg.model, pkg.mock = model, mock
+    sys.modules["clip"], sys.modules["clip.model"], sys.modules["clip.mock"] = pkg, model, mock
     return pkg
 
 

@@ -11,10 +11,11 @@ MERGED_BASE = 100000
 
 def build_nlvr(image_size=224, seed=0, device="cuda"):
     """BLIP_NLVR mirror with the deterministic synthetic weights (same bits as the golden generator used)."""
-    model = BLIP_NLVR(image_size=image_size, evaluate=True)
-    sd = specs.synth_weights(specs.blip_nlvr_shapes(image_size), seed)
-    model.load_state_dict(sd, strict=True)
-    return model.eval().to(device)
+    model = BLIP_NLVR(image_size=image_size, evaluate=True).eval().to(device)
+    # generated ON the target device (same bits as the numpy generator, synth.uniform_pm1_torch): the ranks of a multi-GPU job
+    # do not queue for the host cores with 259 M hashes each
+    model.load_state_dict(specs.synth_weights(specs.blip_nlvr_shapes(image_size), seed, device=device), strict=True)
+    return model
 
 
 def padded_mask(B, L, pad_tail=0):
@@ -36,10 +37,10 @@ def nlvr_inputs(B, image_size=224, L=20, seed=0, device="cuda", pad_tail=0):
 def build_retrieval(image_size=224, seed=0, device="cuda"):
     """BLIP_Retrieval mirror with the deterministic synthetic weights (same bits as the golden generator used)."""
     from .blip_retrieval import BLIP_Retrieval
-    model = BLIP_Retrieval(image_size=image_size, evaluate=True)
-    msg = model.load_state_dict(specs.synth_weights(specs.blip_retrieval_shapes(image_size), seed), strict=False)
+    model = BLIP_Retrieval(image_size=image_size, evaluate=True).eval().to(device)
+    msg = model.load_state_dict(specs.synth_weights(specs.blip_retrieval_shapes(image_size), seed, device=device), strict=False)
     assert not msg.unexpected_keys and all("query_model" in k or "position_ids" in k for k in msg.missing_keys), msg
-    return model.eval().to(device)
+    return model
 
 
 class RetrievalLoader:

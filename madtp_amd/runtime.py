@@ -140,20 +140,39 @@ def lin_of(cache, key, linears, dtype=None):
                      lambda: prepare_linear([l.weight for l in linears], [l.bias for l in linears], dtype))
 
 
+# Parameter RE-ASSIGNMENT (`blk.mlp.fc1.weight = nn.Parameter(...)`, `load_state_dict(assign=True)`) replaces the Parameter
+# object, which the per-module lists of collected parameters below would keep missing (their signatures only see in-place
+# changes of the objects they hold).  torch calls this hook for every parameter registration in the process: the lists are
+# re-collected whenever the epoch moved.
+_PARAM_EPOCH = [0]
+
+
+def _on_parameter_registration(module, name, param):
+    _PARAM_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_on_parameter_registration)
+
+
+def param_epoch():
+    return _PARAM_EPOCH[0]
+
+
 class EncoderWeights:
     """The weight structs of all layers of an encoder for the encoder-level calls (hip.vit_encoder / hip.bert_encoder),
     revalidated per forward with ONE pass over the flattened parameter list (version counters and data pointers) instead of
     a PreparedCache lookup per layer - that was ~0.1 ms of host time in front of the first launch of an encoder."""
 
     def __init__(self):
-        self.flat, self.sig, self.val = None, None, None
+        self.flat, self.sig, self.val, self.epoch = None, None, None, -1
 
     def invalidate(self):
         self.flat = self.sig = self.val = None
 
     def get(self, layers):
         import ctypes
-        if self.flat is None:
+        if self.flat is None or self.epoch != _PARAM_EPOCH[0]:
+            self.epoch = _PARAM_EPOCH[0]
             for l in layers:
                 l._weights()  # (collects l._madtp_params)
             self.flat = [p for l in layers for p in l.__dict__["_madtp_params"]]

@@ -173,14 +173,14 @@ def clip_shapes(img_size=224, patch=16, vision_width=768, vision_layers=12, embe
     return sd
 
 
-def synth_weights(shapes, seed=0):
-    """{key: tensor} from a shape spec using the deterministic generator."""
+def synth_weights(shapes, seed=0, device=None):
+    """{key: tensor} from a shape spec using the deterministic generator (device: generate there - same bits, synth.py)."""
     import torch
     from . import synth
     out = {}
     for k, shp in shapes.items():
         if shp and shp[0] == "int64":
-            out[k] = torch.arange(shp[-1]).expand(shp[1:]).clone()
+            out[k] = torch.arange(shp[-1], device=device).expand(shp[1:]).clone()
         else:
-            out[k] = synth.synth_tensor(k, shp, seed)
+            out[k] = synth.synth_tensor(k, shp, seed, device=device)
     return out

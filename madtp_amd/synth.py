@@ -62,10 +62,32 @@ def _std_for(name: str, shape) -> tuple:
     return 0.0, 0.02  # trunc_normal_(std=.02) vit.py:266-270; BERT initializer_range 0.02
 
 
-def synth_tensor(name: str, shape, seed: int = 0, dtype=torch.float32) -> torch.Tensor:
+def uniform_pm1_torch(name: str, n: int, seed: int, device) -> torch.Tensor:
+    """uniform_pm1() evaluated with torch integer ops on `device` - the same bits: the 32-bit wrap-around products are the low
+    32 bits of int64 products (two's-complement overflow does not touch them), and every float step is one exactly-rounded
+    IEEE operation.  Lets each rank of a multi-GPU job generate its 259 M weights on its own GPU instead of on shared host
+    cores (tests/test_synth_cpu.py pins it to the numpy path)."""
+    M = 0xFFFFFFFF
+    x = torch.arange(n, dtype=torch.int64, device=device)
+    x = (x * 0x9E3779B9 + _fnv1a(name, seed)) & M
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & M
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & M
+    x = x ^ (x >> 16)
+    u = (x >> 8).to(torch.float32) * (1.0 / (1 << 24))
+    return (u - 0.5) * 2.0
+
+
+def synth_tensor(name: str, shape, seed: int = 0, dtype=torch.float32, device=None) -> torch.Tensor:
     shape = tuple(int(s) for s in shape)
     n = int(np.prod(shape)) if len(shape) else 1
     mean, std = _std_for(name, shape)
+    if device is not None and torch.device(device).type != "cpu":
+        v = uniform_pm1_torch(name, n, seed, device) * float(np.float32(std * _SQRT3))
+        if mean != 0.0:
+            v = v + float(np.float32(mean))
+        return v.reshape(shape).to(dtype)
     v = uniform_pm1(name, n, seed) * np.float32(std * _SQRT3)
     if mean != 0.0:
         v = v + np.float32(mean)

@@ -29,8 +29,8 @@ def full_rows_of(ft):
     if ft.dim() != 3 or ft.dtype != torch.float32:
         return None
     B, n, D = ft.shape
-    if ft.stride(2) != 1 or ft.stride(1) != D or ft.stride(0) != (n + 1) * D or ft.storage_offset() < D:
-        return None
+    if ft.stride(2) != 1 or ft.stride(1) != D or (B > 1 and ft.stride(0) != (n + 1) * D) or ft.storage_offset() < D:
+        return None  # (with one sample the batch stride is meaningless: a permuted (N,1,C) tensor reports stride(0) = C)
     return torch.as_strided(ft, (B * (n + 1), D), (D, 1), ft.storage_offset() - D)
 
 
@@ -128,6 +128,11 @@ class Query_model(nn.Module):
             return None, False
         sdl, split = self._dictionary(sd)
         K = sd.shape[0]
+        if sdl.w.shape[0] != 128:
+            # the encoder-level calls carve their per-layer logits slabs (and the deferred att_ft segments) at a row stride of
+            # 128 floats; a dictionary of more than 128 entries (padded to 256+) stays on the per-layer path, which sizes its
+            # logits as [rows, roundup(K, 128)]
+            return None, False
         qa = {"sd_w": sdl.w, "K": K, "sd_dim": self.att_dim, "att_ft": None, "stats_ws": None}
         if split is not None:
             qa.update(sd_hi=split[0], sd_lo=split[1], split_dtype=hip.dt_code(split[0].dtype),
@@ -188,6 +193,10 @@ class Query_model(nn.Module):
         full = hip.gemm(rows, sdl.w, n=kp)  # [rows, 128], zero weight rows beyond K
         token_att = full.view(B, n + off, kp)[:, off:, :K]
         att_ft = acc_ft
+        if self.compute_att_ft and defer is not None:
+            # (callers with a DeferredAttFt discard the returned att_ft: this layer's share must go through it as well)
+            defer.add(token_att, ftq[:, off:, :] if off else ftq)
+            return token_att, None, sd
         if self.compute_att_ft:
             att_ft = hip.query_att_ft(token_att, ftq, out=acc_ft, sd_dim=self.att_dim,
                                       fast=split is not None and split[0].dtype == torch.bfloat16)

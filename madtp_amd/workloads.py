@@ -128,6 +128,8 @@ class Retrieval(Workload):
         img_emb = model.project_image(img[:, 0, :])                                              # :121-122
         txt, _ = model.text_encoder(ids, attention_mask=att, mode='text', space_dict=sd, temperature=T)   # :101-103
         txt_emb = model.project_text(txt.last_hidden_state[:, 0, :])                             # :104
+        # the multimodal pass below overwrites the layers' last_prune: keep the text-mode records (references only, read by lens())
+        self._text_prune = [l.last_prune for l in model.text_encoder.encoder.layer]
         atts = torch.ones(img.shape[:-1], dtype=torch.long, device=img.device)
         mm, _ = model.text_encoder(ids_mm, attention_mask=att, encoder_hidden_states=img, encoder_attention_mask=atts,
                                    return_dict=True, space_dict=sd, temperature=T)               # :166-171 on matched pairs
@@ -135,14 +137,18 @@ class Retrieval(Workload):
 
     def lens(self, model):
         n0 = (self.size // 16) ** 2 + 1
-        return {"vit": harness.token_lengths(_traces(model.visual_encoder.blocks), n0),
-                "mm": harness.token_lengths(_traces(model.text_encoder.encoder.layer), self.L)}
+        out = {"vit": harness.token_lengths(_traces(model.visual_encoder.blocks), n0),
+               "mm": harness.token_lengths(_traces(model.text_encoder.encoder.layer), self.L)}
+        tp = getattr(self, "_text_prune", None)
+        if tp is not None:
+            out["text"] = harness.token_lengths([harness._cpu_info(i) for i in tp], self.L)
+        return out
 
     def flops(self, lens):
         n0 = (self.size // 16) ** 2 + 1
         if lens is None:
             lens = {"vit": [n0] * 12, "mm": [self.L] * 12, "text": [self.L] * 12}
-        txt = lens.get("text", lens["mm"])  # the text-mode pass prunes (almost) like the multimodal one; its lens are overwritten
+        txt = lens.get("text", lens["mm"])  # (step() keeps the text-mode pass's own records: Retrieval.lens()["text"])
         return vit_tower_flops(lens["vit"], n0) + med_flops(txt, self.L) + med_flops(lens["mm"], self.L, lens["vit"][-1])
 
     def describe(self, B):
@@ -156,10 +162,10 @@ class Vqa(Workload):
 
     def build(self, device="cuda"):
         from .blip_vqa import BLIP_VQA
-        model = BLIP_VQA(image_size=self.size, evaluate=True)
-        msg = model.load_state_dict(specs.synth_weights(specs.blip_vqa_shapes(self.size), 0), strict=False)
+        model = BLIP_VQA(image_size=self.size, evaluate=True).eval().to(device)
+        msg = model.load_state_dict(specs.synth_weights(specs.blip_vqa_shapes(self.size), 0, device=device), strict=False)
         assert not msg.unexpected_keys and all("query_model" in k or "position_ids" in k for k in msg.missing_keys), msg
-        return model.eval().to(device)
+        return model
 
     def inputs(self, B, seed=0, device="cuda"):
         images = synth.synth_images(B, self.size, seed).to(device)
@@ -171,8 +177,12 @@ class Vqa(Workload):
 
     def lens(self, model):
         n0 = (self.size // 16) ** 2 + 1
-        return {"vit": harness.token_lengths(_traces(model.visual_encoder.blocks), n0),
-                "mm": harness.token_lengths(_traces(model.text_encoder.encoder.layer), self.L)}
+        out = {"vit": harness.token_lengths(_traces(model.visual_encoder.blocks), n0),
+               "mm": harness.token_lengths(_traces(model.text_encoder.encoder.layer), self.L)}
+        tp = getattr(self, "_text_prune", None)
+        if tp is not None:
+            out["text"] = harness.token_lengths([harness._cpu_info(i) for i in tp], self.L)
+        return out
 
     def flops(self, lens):
         n0 = (self.size // 16) ** 2 + 1
@@ -191,7 +201,7 @@ class Clip(Workload):
 
     def build(self, device="cuda"):
         from .clip_model import build_model
-        return build_model(specs.synth_weights(specs.clip_shapes(self.size), 0), evaluate=True).eval().to(device)
+        return build_model(specs.synth_weights(specs.clip_shapes(self.size), 0, device=device), evaluate=True).eval().to(device)
 
     def inputs(self, B, seed=0, device="cuda"):
         return synth.synth_images(B, self.size, seed).to(device), synth.synth_clip_tokens(B, self.ctx, seed).to(device)

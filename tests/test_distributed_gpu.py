@@ -76,3 +76,42 @@ def test_world2_hip_forward_matches_per_shard_oracle(tmp_path, mode):
         assert (ref - res[r]["logits"]).abs().max().item() < 1e-3
         for side, n0 in (("vit", 196), ("text", 19)):
             assert res[r]["sets"][side] == O.compose_ids(tr[side], n0), f"rank {r} {side}: kept sets differ from the shard oracle"
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import numpy as np
+    from madtp_amd import dist as mdist
+    from madtp_amd.blip_retrieval import all_gather_scores, all_reduce_scores, rank_rows
+    torch.cuda.set_device(rank)
+    w, r, _ = mdist.init("nccl")  # RCCL: one device per rank
+    assert (w, r) == (world, rank)
+    assert mdist.max_over_ranks(1.0 + rank, device="cuda") == float(world)
+    assert mdist.sum_over_ranks([1.0, float(rank)], device="cuda") == [float(world), float(sum(range(world)))]
+    # config 3's one exchange (compress_retrieval_dtp.py:202-205): every rank filled its row slice of both score matrices
+    n_img, n_txt = 13, 31
+    full_i2t = np.arange(n_img * n_txt, dtype=np.float32).reshape(n_img, n_txt)
+    full_t2i = -np.arange(n_txt * n_img, dtype=np.float32).reshape(n_txt, n_img)
+    mine = []
+    for full in (full_i2t, full_t2i):
+        m = np.full_like(full, -100.0)
+        s, e = rank_rows(full.shape[0], rank, world)
+        m[s:e] = full[s:e]
+        mine.append(m)
+    a, b = all_gather_scores(mine[0], mine[1])
+    assert np.array_equal(a, full_i2t) and np.array_equal(b, full_t2i)
+    ra, rb = all_reduce_scores(mine[0], mine[1])   # the reference's SUM all-reduce: uniformly shifted by -100 (world - 1)
+    assert np.allclose(ra, full_i2t - 100.0 * (world - 1)) and np.allclose(rb, full_t2i - 100.0 * (world - 1))
+    mdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_reductions_and_score_gather():
+    """RCCL itself (backend "nccl", one device per rank) for the collectives the path uses: the MAX / SUM scalar reductions of
+    bench.py and the retrieval score-matrix exchange.  Needs >= 2 GPUs: skipped on the one-GPU test boxes, runs on a node."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL wants one device per rank)")
+    world = 2
+    mp.spawn(_nccl_worker, args=(world, _free_port(), ""), nprocs=world, join=True)

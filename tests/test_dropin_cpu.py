@@ -62,6 +62,82 @@ def test_reference_blip_nlvr_constructs_on_the_mirrors():
 
 
 @needs_ref
+def test_reference_clip_load_builds_the_mirror(tmp_path):
+    """compress_retrieval_clip_dtp.py:21,262: `from clip import clip; clip.load(name=<checkpoint>, evaluate=True, config=...)`
+    with the reference's own clip/clip.py -> build_model of the mirror; state-dict keys == the reference CLIP's (fixture)."""
+    out = _run(f"""
+        import sys, json, numpy as np, torch
+        sys.path.insert(0, {ROOT!r} + "/tools")
+        import ref_shims
+        ref_shims.install(chdir=True, import_models=False)
+        import madtp_amd.dropin as dropin
+        dropin.install({REF!r})
+        from clip import clip                                    # the reference's clip/clip.py, unmodified
+        assert clip.__file__.startswith({REF!r}), clip.__file__
+        import clip as clip_pkg, clip.model, clip.mock
+        import madtp_amd.clip_model as mirror
+        assert clip_pkg.model.build_model is mirror.build_model and clip.build_model is mirror.build_model
+        assert clip_pkg.load is clip.load and clip_pkg.tokenize is clip.tokenize   # clip/__init__.py: from .clip import *
+        from madtp_amd import specs
+        sd = specs.synth_weights(specs.clip_shapes(224), 0)
+        path = {str(tmp_path)!r} + "/clip_synth.pth"
+        torch.save({{"model": sd}}, path)
+        model, _ = clip.load(name=path, device="cpu", evaluate=True, config={{"sd_dim": 768, "sd_num": 100}})
+        assert type(model) is mirror.CLIP and isinstance(model.visual.transformer.resblocks[0], mirror.ResidualAttentionBlock)
+        g = np.load({ROOT!r} + "/tests/golden/clip_full_b3_T4.npz", allow_pickle=False)
+        ref_keys = [str(k) for k in g["state_dict_keys"]]
+        mine = sorted(model.state_dict().keys())
+        same_vals = all(torch.equal(model.state_dict()[k].float(), sd[k].float()) for k in sd if k in model.state_dict())
+        print(json.dumps({{"n": len(mine), "missing": sorted(set(ref_keys) - set(mine)), "extra": sorted(set(mine) - set(ref_keys)),
+                          "same_vals": same_vals}}))
+        """)
+    import json
+    rep = json.loads(out.strip().splitlines()[-1])
+    assert rep["missing"] == [] and rep["extra"] == [], (rep["missing"][:10], rep["extra"][:10])
+    assert rep["n"] > 300 and rep["same_vals"]
+
+
+@needs_ref
+@pytest.mark.parametrize("which", ["blip_retrieval", "blip_vqa"])
+def test_reference_blip_glue_constructs_on_the_mirrors(which):
+    """models/blip_retrieval.py / models/blip_vqa.py (the reference's own files) construct on the mirrors; state-dict keys of
+    the encoder side equal the reference model's (fixture key list).  blip_vqa's text DECODER (BertLMHeadModel) is the
+    rank_answer mirror of madtp_amd.bert (inference half of SURVEY 8(f) rank 4)."""
+    fixture = {"blip_retrieval": "retr_i6_t12", "blip_vqa": "vqa480_b2"}[which]
+    out = _run(f"""
+        import sys, json, numpy as np
+        sys.path.insert(0, {ROOT!r} + "/tools")
+        import ref_shims
+        ref_shims.install(chdir=True, import_models=False)
+        import madtp_amd.dropin as dropin
+        dropin.install({REF!r})
+        import models.blip as blip
+        blip.init_tokenizer = lambda: ref_shims.FakeTokenizer()
+        import models.{which} as ref_mod
+        ref_mod.init_tokenizer = blip.init_tokenizer
+        assert ref_mod.__file__.startswith({REF!r}), ref_mod.__file__
+        import madtp_amd.vit, madtp_amd.bert
+        if {which!r} == "blip_retrieval":
+            model = ref_mod.blip_retrieval(pretrained='', image_size=224, vit='base', evaluate=True, config={{"sd_dim": 768, "sd_num": 100}}, queue_size=16)
+        else:
+            model = ref_mod.blip_vqa(pretrained='', image_size=480, vit='base', evaluate=True, config={{"sd_dim": 768, "sd_num": 100}})
+        assert type(model).__module__ == 'models.{which}'
+        assert isinstance(model.visual_encoder, madtp_amd.vit.VisionTransformer)
+        assert isinstance(model.text_encoder, madtp_amd.bert.MedBertModel)
+        g = np.load({ROOT!r} + "/tests/golden/{fixture}.npz", allow_pickle=False)
+        ref_keys = [str(k) for k in g["state_dict_keys"]]
+        mine = sorted(model.state_dict().keys())
+        print(json.dumps({{"n": len(mine), "missing": sorted(set(ref_keys) - set(mine)), "extra": sorted(set(mine) - set(ref_keys))}}))
+        """)
+    import json
+    rep = json.loads(out.strip().splitlines()[-1])
+    ok = lambda k: "position_ids" in k  # noqa: E731  (buffers only the reference registers)
+    assert all(ok(k) for k in rep["missing"]), rep["missing"][:10]
+    assert all(ok(k) for k in rep["extra"]), rep["extra"][:10]
+    assert rep["n"] > 300
+
+
+@needs_ref
 def test_install_after_reference_import_is_refused():
     _run(f"""
         import sys

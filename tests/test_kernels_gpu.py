@@ -57,9 +57,12 @@ def test_gemm(hip, M, N, K, dtype):
     assert (out.float().cpu() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("cfg", [7, 8], ids=["mfma16x16x32", "mfma32x32x16"])
 @pytest.mark.parametrize("M,N,K", [(10533, 768, 768), (10533, 776, 768), (10400, 2304, 768), (10533, 768, 3072)])
-def test_gemm_wave_specialised(hip, M, N, K):
-    """Shapes that dispatch to gemm_ws_kernel (bf16, M >= 4096, >= 200 tiles of 256x128): ragged last row tile (M % 256 = 37),
+def test_gemm_wave_specialised(hip, M, N, K, cfg):
+    """Both consumer loops of gemm_ws_kernel (madtp_gemm_set_config 7: 16x16x32 fragments - what the dispatch uses; 8: the
+    32x32x16 fragments, kept opt-in: measured slower).
+    Shapes that dispatch to gemm_ws_kernel (bf16, M >= 4096, >= 200 tiles of 256x128): ragged last row tile (M % 256 = 37),
     a last column tile with 8 valid columns (N = 776), every epilogue (bias / GELU / f32 residual stream / bf16 out / scale)
     and an output that is a column slice of a wider buffer (ldc > N: the descriptor-bounded stores must not touch the rest).
     Reference: float64 matmul of the same bf16-rounded operands on the GPU."""
@@ -70,24 +73,25 @@ def test_gemm_wave_specialised(hip, M, N, K):
     bias, res = _rand(N, seed=3).cuda(), _rand(M, N, seed=4).cuda()
     core = a.double() @ w.cuda().double().t()
     scale = max(1.0, core.abs().max().item())
-    # f32 residual stream (proj / fc2)
-    out = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
-    ref = (core + bias.double()).float() + res
-    assert (out - ref).abs().max().item() < 1e-4 * scale
-    # f32 without residual, scaled
-    out = hip.gemm(a, wp, bias, out_dtype=torch.float32, n=N, out_scale=0.5)
-    assert (out - ((core + bias.double()) * 0.5).float()).abs().max().item() < 1e-4 * scale
-    # bf16 out (qkv) and GELU (fc1)
-    out = hip.gemm(a, wp, bias, out_dtype=td, n=N)
-    assert (out.float() - (core + bias.double()).float()).abs().max().item() < 1e-2 * scale
-    out = hip.gemm(a, wp, bias, out_dtype=td, act=hip.ACT_GELU, n=N)
-    assert (out.float() - F.gelu(core + bias.double()).float()).abs().max().item() < 1e-2 * scale
-    # strided output: columns [8, 8+N) of a wider buffer, the rest must stay untouched
-    for odt in (torch.float32, td):
-        wide = torch.full((M, N + 24), 7.0, device="cuda", dtype=odt)
-        hip.gemm(a, wp, bias, out_dtype=odt, n=N, out=wide[:, 8:8 + N])
-        assert (wide[:, 8:8 + N].float() - (core + bias.double()).float()).abs().max().item() < 1e-2 * scale
-        assert torch.all(wide[:, :8] == 7.0) and torch.all(wide[:, 8 + N:] == 7.0)
+    with hip.gemm_config(cfg):
+        # f32 residual stream (proj / fc2)
+        out = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
+        ref = (core + bias.double()).float() + res
+        assert (out - ref).abs().max().item() < 1e-4 * scale
+        # f32 without residual, scaled
+        out = hip.gemm(a, wp, bias, out_dtype=torch.float32, n=N, out_scale=0.5)
+        assert (out - ((core + bias.double()) * 0.5).float()).abs().max().item() < 1e-4 * scale
+        # bf16 out (qkv) and GELU (fc1)
+        out = hip.gemm(a, wp, bias, out_dtype=td, n=N)
+        assert (out.float() - (core + bias.double()).float()).abs().max().item() < 1e-2 * scale
+        out = hip.gemm(a, wp, bias, out_dtype=td, act=hip.ACT_GELU, n=N)
+        assert (out.float() - F.gelu(core + bias.double()).float()).abs().max().item() < 1e-2 * scale
+        # strided output: columns [8, 8+N) of a wider buffer, the rest must stay untouched
+        for odt in (torch.float32, td):
+            wide = torch.full((M, N + 24), 7.0, device="cuda", dtype=odt)
+            hip.gemm(a, wp, bias, out_dtype=odt, n=N, out=wide[:, 8:8 + N])
+            assert (wide[:, 8:8 + N].float() - (core + bias.double()).float()).abs().max().item() < 1e-2 * scale
+            assert torch.all(wide[:, :8] == 7.0) and torch.all(wide[:, 8 + N:] == 7.0)
 
 
 @pytest.mark.parametrize("M,N,K", [(10533, 768, 768), (10533, 776, 768), (6000, 2304, 768), (10533, 768, 3072), (300, 100, 768),

@@ -95,6 +95,42 @@ def test_bf16_mode_index_match_and_logits(env, B, T):
     assert rep["max_abs_dlogit"] < 1.5e-2               # measured 0.005 / 0.006
 
 
+def test_headline_batch_index_match(env):
+    """The claims of bench.py's index_match leg at the HEADLINE batch (64 samples = 128 images, calibrated T), asserted:
+    (a) the parity modes (fp32, f16x3) reproduce every kept set of the oracle and its logits within 1e-3;
+    (b) bf16: per-layer decisions sound (teacher-forced), free-running sets / logits within about half the measured slack
+        (MI355X, round 2: exact 0.17, Jaccard 0.68, teacher-forced exact 0.868 / Jaccard 0.998, |dlogit| 0.02), and the
+        count-flip report names the layer where k = max_b count first leaves the oracle's (the cascade's start);
+    (c) the batch-dependent GEMM dispatch (256x256 / 32x32x16 kernels vs the 16x16x32 wave-specialised one) adds no error:
+        the teacher-forced figures under madtp_gemm_set_config(7) are the same within noise."""
+    from madtp_amd import configs, hip
+    from oracle.index_match import nlvr_index_match
+    harness, runtime, model = env
+    T = configs.temperature_for("nlvr", 64, 0.5)[0]
+    rep = nlvr_index_match(model, T, ["fp32", "f16x3", "bf16"], B=64, seed=11, count_flips=True)
+    for mode in ("fp32", "f16x3"):
+        r = rep[mode]
+        print(f"{mode} B=64: {({k: v for k, v in r.items() if k != 'vit_count_flips'})}")
+        assert r["kept_set_exact_match"] == 1.0 and r["pruned_vs_unpruned_layers"] == [], r
+        assert r["max_abs_dlogit"] <= 1e-3, r
+        assert r["vit_layerwise_exact_match"] == 1.0
+        assert r["vit_count_flips"]["first_layer_k_differs"] is None
+    b = rep["bf16"]
+    print(f"bf16 B=64: {({k: v for k, v in b.items() if k != 'vit_count_flips'})}")
+    print("bf16 count flips:", b["vit_count_flips"])
+    assert b["vit_layerwise_jaccard"] >= 0.997 and b["vit_layerwise_exact_match"] >= 0.80
+    assert b["mean_jaccard"] >= 0.5 and b["max_abs_dlogit"] < 4e-2
+    # the free-running drop from B = 8 (Jaccard 0.96) is a cascade: it starts where k first differs
+    fl = b["vit_count_flips"]
+    if b["kept_set_exact_match"] < 0.5:
+        assert fl["first_layer_k_differs"] is not None
+    with hip.gemm_config(7):
+        b7 = nlvr_index_match(model, T, ["bf16"], B=64, seed=11)["bf16"]
+    print(f"bf16 B=64, 16x16x32 wave-specialised GEMM only: {b7}")
+    assert abs(b7["vit_layerwise_jaccard"] - b["vit_layerwise_jaccard"]) < 2e-3
+    assert abs(b7["vit_layerwise_exact_match"] - b["vit_layerwise_exact_match"]) < 0.05
+
+
 def test_module_error_behaviour(env):
     harness, runtime, model = env
     blk = model.visual_encoder.blocks[0]

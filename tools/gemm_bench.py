@@ -25,7 +25,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "ab":  # 256x128 wave-specialised (cfg 5
             kw = dict(residual=res, out_dtype=torch.float32) if N == 768 else (dict(act=hip.ACT_GELU) if N == 3072 else {})
             out = torch.empty(M, N, device="cuda", dtype=kw.get("out_dtype", dt))
             line = f"M={M:6d} N={N:5d} K={K:5d}"
-            for cfg in ((7, 1, 2, 3, 0) if (len(sys.argv) > 3 and sys.argv[3] == 'small_tiles') else (7, 5, 6, 0)):  # 7: wave-specialised without the stream-K tail, 5: with it, 6: 256x256, 0: automatic
+            for cfg in ((7, 1, 2, 3, 0) if (len(sys.argv) > 3 and sys.argv[3] == 'small_tiles') else (7, 8, 6, 0)):  # 7: wave-specialised, 16x16x32 MFMA; 8: wave-specialised, 32x32x16 MFMA; 6: 256x256; 0: automatic (5 = 7 + stream-K tail)
                 with hip.gemm_config(cfg):
                     for _ in range(3): hip.gemm(a, w, bias, n=N, out=out, **kw)
                     torch.cuda.synchronize()
