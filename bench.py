@@ -71,7 +71,7 @@ def measure_traffic(args):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
                    "--config", args.config, "--precision", args.precision, "--steps", "1", "--warmup", "1", "--traffic", "off",
-                   "--no-cpu-baseline", "--no-parity", "--no-gemm-events"] + (["--batch", str(args.batch)] if args.batch else [])
+                   "--no-cpu-baseline", "--no-parity", "--no-gemm-events", "--inflight", "1"] + (["--batch", str(args.batch)] if args.batch else [])
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
             dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--gemm-breakdown", action="store_true", help="per-shape GEMM time table on stderr")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("MADTP_INFLIGHT", "0")),
+                    help="forwards in flight per GPU (madtp_amd.pipeline: one host thread + HIP stream + model replica each; "
+                         "1 = the serial loop, 0 = the configuration's default).  The K timed steps are K whole forwards either way.")
     args = ap.parse_args()
 
     from madtp_amd import dist as mdist
@@ -138,6 +141,8 @@ def main():
     prof_rows = []
 
     w = workloads.get(args.config, **({"size": args.image_size} if (args.image_size and args.config == "retrieval") else {}))
+    if args.inflight <= 0:
+        args.inflight = w.default_inflight if args.precision == "bf16" else 1  # (the parity modes' kernels fill the chip)
     strong = args.config == "retrieval" and not args.batch  # BASELINE config 3: a GLOBAL batch of 128 over the ranks
     B = args.batch or (max(1, w.default_batch // world) if strong else w.default_batch)
     T, calib = configs.temperature_for(args.config, args.batch or w.default_batch, w.p)
@@ -147,16 +152,40 @@ def main():
     def step():
         return w.step(model, inp, T)
 
+    runner = None
+    if args.inflight > 1:
+        from madtp_amd.pipeline import InflightRunner
+        runner = InflightRunner(w, args.inflight, T, B, "cuda", seed0=rank * args.inflight,
+                                models=[model] + [w.build("cuda") for _ in range(args.inflight - 1)])
+        runner.inputs[0] = inp
+
+    def run_steps(n):  # n whole forwards: serial on the current stream, or spread over the in-flight workers
+        if runner is not None:
+            runner.run(n)
+        else:
+            for _ in range(n):
+                step()
+
+    single = None
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
+        if runner is not None:
+            runner.run(max(args.warmup, 3) * args.inflight)  # every replica prepares its weights, grows its workspace and its
+            #                                                  stream's allocator pool (>= 3 forwards per worker)
+            # the serial loop of the same K steps, for the record (latency of one forward; rounds 1-2 reported this as `value`)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            single = time.perf_counter() - ts
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        run_steps(args.steps)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -220,11 +249,17 @@ def main():
         "data": "synthetic",
         "config": {"workload": w.describe(B), "samples_per_gpu": B, "images_per_gpu": w.images_per_sample * B, "temperature": T,
                    "p": w.p, "flops_ratio_vs_unpruned": round(flops_sample / flops_full, 4),
-                   "tokens_per_layer": lens, "calibrated_at_batch": calib.get("batch"), "parallelism": f"dp{world}"},
+                   "tokens_per_layer": lens, "calibrated_at_batch": calib.get("batch"), "parallelism": f"dp{world}",
+                   "inflight_per_gpu": args.inflight},
         "samples_per_s": round(value / w.images_per_sample, 1),
         "model_tflops": round(flops_sample * B * world * args.steps / elapsed / 1e12, 1),
         "roofline": roof,
     }
+    if single is not None:
+        out["single_stream"] = {"value": round(w.images_per_sample * B * args.steps / single, 1), "unit": "images/s",
+                                "ms_per_forward": round(1e3 * single / args.steps, 3),
+                                "what": "the same K forwards one after the other on one stream (this rank; latency of a forward); "
+                                        f"`value` runs them {args.inflight} at a time on separate HIP streams (madtp_amd/pipeline.py)"}
     if headline:  # keys of the round-1 line, kept for the driver's records
         out["config"]["vit_tokens_per_layer"], out["config"]["text_tokens_per_layer"] = lens["vit"], lens["text"]
 
@@ -235,12 +270,13 @@ def main():
         with runtime.precision(pm), torch.no_grad():
             for _ in range(2):
                 step()
+            if runner is not None:
+                runner.run(2 * args.inflight)
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
             t2 = time.perf_counter()
-            for _ in range(args.parity_steps):
-                step()
+            run_steps(args.parity_steps)
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()

@@ -336,6 +336,11 @@ typedef struct madtp_bert_layer_w {
     const float *ln_out_g, *ln_out_b;
     float eps, scale;
     int heads, dim, dtype;
+    /* decoder layers (BertModel.forward(is_decoder=True), med.py:752-786: extended mask = causal[L,L] * padding[B,L]): the
+     * additive causal part, f32 [L, >= L] with row stride ld_self_mask_qk, shared by all samples and heads and added to the
+     * self-attention scores next to the padding mask (madtp_attention_qk_mask); NULL for encoder layers. */
+    const float* self_mask_qk;
+    int ld_self_mask_qk;
 } madtp_bert_layer_w;
 
 size_t madtp_bert_layer_workspace(int B, int L, int Nk, int dim, int hidden, int heads, int dtype);
@@ -413,6 +418,21 @@ int madtp_bert_encoder(const madtp_bert_layer_w* const* layers, int n_layers, co
                        int Nk, float temperature, int cross_mode, const void* enc0, const void* enc1, const float* enc_mask0,
                        const float* enc_mask1, const void* const* kv_pre0, const void* const* kv_pre1, const int32_t* kv_index,
                        int kv_ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Answer ranking with the teacher-forced decoder (inference half): models/med.py BertLMHeadModel
+ * :1036-1042 and models/blip_vqa.py rank_answer :166-172.  The decoder itself is madtp_bert_layer with self_mask_qk set, the
+ * LM head (med.py:616-657) is madtp_gemm (GELU) + madtp_layernorm + madtp_gemm over the vocabulary.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* loss[b] = sum over t < n_pred of the label-smoothed cross-entropy of row (b, t) of the prediction scores against
+ * labels[b, t + 1] (next-token prediction: shifted scores / labels, med.py:1038-1039; CrossEntropyLoss(reduction='none',
+ * label_smoothing) summed per sequence :1040-1042); labels == -100 contribute 0.  logits f32 [B*rows_per_seq, >= V] with row
+ * stride ld (row b*rows_per_seq + t), labels int64 [B, ld_labels], loss f32 [B]. */
+int madtp_lm_loss(const float* logits, int ld, int rows_per_seq, int n_pred, int V, const int64_t* labels, int ld_labels,
+                  float label_smoothing, float* loss, int B, void* stream);
+/* out[q, a] = softmax(logits[q, :V])[tok[a]]  (blip_vqa.py:170-171: F.softmax(logits, dim=1).index_select(1, answer_first_token));
+ * logits f32 [Q, >= V] with row stride ld, tok int64 [A], out f32 [Q, A]. */
+int madtp_token_prob(const float* logits, int ld, int V, const int64_t* tok, int A, float* out, int Q, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import EncoderWeights, PreparedCache, param_epoch, get_precision, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
+from .runtime import EncoderWeights, PreparedCache, param_epoch, get_precision, encoder_call_preference, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model
 
 
@@ -54,6 +54,8 @@ ENCODER_CALL_MAX_SAMPLES = 32
 
 
 def _use_encoder_call(B, flag):
+    if flag == "auto" and encoder_call_preference() is not None:
+        return bool(encoder_call_preference())
     return (B <= ENCODER_CALL_MAX_SAMPLES) if flag == "auto" else bool(flag)
 
 
@@ -333,11 +335,25 @@ class _BertLayerBase(nn.Module):
             raise NotImplementedError("decoder caching / attention outputs / head masks are off the pruned forward path")
         hidden = as_f32_contig(hidden_states)
         B, L, D = hidden.shape
-        mask2d = None
+        mask2d = causal = None
         if attention_mask is not None:
-            if attention_mask.dim() != 4 or attention_mask.shape[2] != 1:
-                raise NotImplementedError("only padding masks [B,1,1,L] (encoder use) are supported")
-            mask2d = as_f32_contig(attention_mask[:, 0, 0, :])
+            if attention_mask.dim() == 4 and attention_mask.shape[2] == L and attention_mask.shape[3] == L and L > 1:
+                # decoder mask (med.py:752-786): (1 - causal[L,L] * padding[B,L]) * -10000.  The kernels take the two factors
+                # as additive masks [B,L] + [L,L] (masked entries underflow to exactly 0 either way).  BertModel.forward attaches
+                # them; for a foreign tensor the padding part is the last query row (it sees every key causally) and the causal
+                # part sample 0's mask with its padding removed.
+                parts = getattr(attention_mask, "_madtp_causal", None)
+                if parts is None:
+                    mask2d = as_f32_contig(attention_mask[:, 0, L - 1, :])
+                    causal = as_f32_contig(attention_mask[0, 0] - mask2d[0][None, :])
+                else:
+                    mask2d, causal = parts
+                if temperature > 0:
+                    raise NotImplementedError("token pruning inside the causal decoder is not a reference code path")
+            elif attention_mask.dim() != 4 or attention_mask.shape[2] != 1:
+                raise NotImplementedError("only padding masks [B,1,1,L] and decoder masks [B,1,L,L] are supported")
+            else:
+                mask2d = as_f32_contig(attention_mask[:, 0, 0, :])
         prune = temperature > 0
         if prune and mask2d is None:
             raise ValueError("attention_mask is required when temperature > 0 (med.py:424)")
@@ -361,6 +377,9 @@ class _BertLayerBase(nn.Module):
                 Nk = encoder_hidden_states.shape[1]
                 enc0 = self._enc_operand(encoder_hidden_states)
         w = self._weights()
+        if causal is not None:  # a copy of the cached struct with this call's causal mask (kept alive by `causal` below)
+            w = hip.BertLayerW.from_buffer_copy(w)
+            w.self_mask_qk, w.ld_self_mask_qk = causal.data_ptr(), causal.stride(0)
         # one library call: self-attention + output LayerNorm, importance score / threshold / count (med.py:408-418,
         # 347-371), host read of k, [prune att + mask], cross-attention, FFN
         # (fast mode: the bf16 copy of the layer output, emitted by the output LayerNorm, rides along on the returned tensor
@@ -533,8 +552,10 @@ class _BertEncoderBase(nn.Module):
         B, L, D = hidden.shape
         mask2d = None
         if attention_mask is not None:
+            if attention_mask.dim() == 4 and attention_mask.shape[2] == L and L > 1:
+                return None  # decoder (causal) mask: the per-layer path carries it (madtp_bert_layer_w.self_mask_qk)
             if attention_mask.dim() != 4 or attention_mask.shape[2] != 1:
-                raise NotImplementedError("only padding masks [B,1,1,L] (encoder use) are supported")
+                raise NotImplementedError("only padding masks [B,1,1,L] and decoder masks [B,1,L,L] are supported")
             mask2d = as_f32_contig(attention_mask[:, 0, 0, :])
         t = temperature if space_dict is not None else 0
         if t > 0 and mask2d is None:
@@ -674,9 +695,16 @@ class _BertModelBase(nn.Module):
         return self.embeddings.word_embeddings
 
     def get_extended_attention_mask(self, attention_mask, input_shape=None, device=None, is_decoder=False):
-        """med.py:728-786 (encoder branch): (1 - m) * -10000 broadcast as [B,1,1,L]."""
-        if is_decoder:
-            raise NotImplementedError("causal (decoder) masks are off the pruned forward path")
+        """med.py:728-786: (1 - m) * -10000 broadcast as [B,1,1,L]; is_decoder (2-D mask): m = causal[L,L] * padding[B,L] as
+        [B,1,L,L] (:752-768), with its two additive factors attached for the layers' kernels (`_madtp_causal`)."""
+        if is_decoder and attention_mask.dim() == 2:
+            B, L = attention_mask.shape
+            ids = torch.arange(L, device=attention_mask.device)
+            causal = (ids[None, :] <= ids[:, None])                               # [L(query), L(key)]
+            pad = attention_mask != 0
+            ext = torch.where(causal[None, None, :, :] & pad[:, None, None, :], 0.0, -10000.0)
+            ext._madtp_causal = (torch.where(pad, 0.0, -10000.0).contiguous(), torch.where(causal, 0.0, -10000.0).contiguous())
+            return ext
         if attention_mask.dim() == 3:
             ext = attention_mask[:, None, :, :]
         elif attention_mask.dim() == 2:
@@ -692,7 +720,7 @@ class _BertModelBase(nn.Module):
         return self.get_extended_attention_mask(m)
 
     def _run(self, input_ids, attention_mask, space_dict, temperature, encoder_embeds, encoder_hidden_states,
-             encoder_attention_mask, mode, inputs_embeds=None):
+             encoder_attention_mask, mode, inputs_embeds=None, is_decoder=False):
         if input_ids is not None and inputs_embeds is not None:
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
         if inputs_embeds is not None:
@@ -708,7 +736,7 @@ class _BertModelBase(nn.Module):
             raise ValueError("You have to specify either input_ids or inputs_embeds or encoder_embeds")
         if attention_mask is None:
             attention_mask = torch.ones((batch_size, seq_length), device=device)
-        ext = self.get_extended_attention_mask(attention_mask, (batch_size, seq_length), device, False)
+        ext = self.get_extended_attention_mask(attention_mask, (batch_size, seq_length), device, is_decoder)
         if encoder_hidden_states is not None:
             if isinstance(encoder_hidden_states, list):
                 # (None entry: no padding in that image's tokens - the same values as an all-ones mask without its launches)
@@ -733,10 +761,13 @@ class MedBertModel(_BertModelBase):
                 mode='multimodal', space_dict=None, temperature=0, encoder_kv_cache=None):
         """encoder_kv_cache (extension): an EncoderKVCache - the layers' cross-attention then reads the cached [k|v]
         projections of encoder block index[b] for sample b instead of projecting encoder_hidden_states (which may be None)."""
-        if position_ids is not None or head_mask is not None or past_key_values is not None or is_decoder:
-            raise NotImplementedError("position_ids / head_mask / past_key_values / is_decoder are off the pruned encoder path")
+        if position_ids is not None or head_mask is not None or past_key_values is not None:
+            raise NotImplementedError("position_ids / head_mask / past_key_values (incremental decoding) are not implemented: the "
+                                      "decoder runs teacher-forced (rank_answer)")
+        if is_decoder and temperature > 0:
+            raise NotImplementedError("token pruning inside the causal decoder is not a reference code path")
         emb, ext, enc_ext = self._run(input_ids, attention_mask, space_dict, temperature, encoder_embeds,
-                                      encoder_hidden_states, encoder_attention_mask, mode, inputs_embeds)
+                                      encoder_hidden_states, encoder_attention_mask, mode, inputs_embeds, is_decoder)
         if encoder_kv_cache is not None:
             if self.encoder.layer_cls.variant != "med":
                 raise NotImplementedError("encoder_kv_cache is wired for the single-cross-attention (MED) layers")
@@ -772,6 +803,133 @@ class EncoderKVCache:
             lin = lin_of(sm._cache, "kv", [sm.key, sm.value])
             kv.append(hip.gemm(a, lin.w, lin.b, n=lin.n, out_dtype=attn_dtype()))  # the dtype the attention kernels read
         return EncoderKVCache(kv, Nk)
+
+
+class BertPredictionHeadTransform(nn.Module):
+    """med.py:616-631: dense, erf-GELU, LayerNorm."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        if config.hidden_act != "gelu":
+            raise ValueError("only the erf-GELU of med_config.json is implemented")
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+
+class BertLMPredictionHead(nn.Module):
+    """med.py:634-651: transform + decoder Linear(hidden -> vocab, bias=False) with the separate output bias linked to it."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.transform = BertPredictionHeadTransform(config)
+        self.decoder = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size))
+        self.decoder.bias = self.bias  # :648 (the same Parameter under both state-dict names)
+        self._cache = PreparedCache()
+
+
+class BertOnlyMLMHead(nn.Module):
+    """med.py:654-661."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.predictions = BertLMPredictionHead(config)
+
+
+VOCAB_PAD = 8  # the vocabulary GEMM writes ceil(V / 8) * 8 columns (30524 -> 30528): 16-byte vector stores on every row
+
+
+class _LMOut:
+    """CausalLMOutputWithCrossAttentions stand-in (med.py:1046-1060)."""
+
+    def __init__(self, loss, logits):
+        self.loss, self.logits = loss, logits
+        self.past_key_values = self.hidden_states = self.attentions = self.cross_attentions = None
+
+
+class BertLMHeadModel(nn.Module):
+    """models/med.py BertLMHeadModel :933-1094, teacher-forced use (labels / logits of whole sequences: BLIP_VQA.rank_answer,
+    blip_vqa.py:156-203).  Incremental decoding (past_key_values, generate / beam search) is not implemented."""
+
+    def __init__(self, config, sd_dim=768):
+        super().__init__()
+        self.config = config
+        self.bert = MedBertModel(config, add_pooling_layer=False, sd_dim=sd_dim)
+        self.cls = BertOnlyMLMHead(config)
+        if not getattr(config, "evaluate", True):
+            self.apply(self.bert._init_weights)
+        self.tie_weights()
+
+    def tie_weights(self):
+        """transformers PreTrainedModel.tie_weights (config.tie_word_embeddings, default True): the LM head's output embedding IS
+        the input embedding matrix (one Parameter under two state-dict names, as in every BLIP checkpoint)."""
+        if getattr(self.config, "tie_word_embeddings", True):
+            self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
+
+    def get_output_embeddings(self):
+        return self.cls.predictions.decoder
+
+    def set_output_embeddings(self, new_embeddings):
+        self.cls.predictions.decoder = new_embeddings
+
+    def _vocab_linear(self):
+        """decoder weight padded to 128 rows in the compute dtype + the output bias padded likewise, N = ceil(V / 8) * 8."""
+        from .runtime import Lin, prepare_linear
+        pr = self.cls.predictions
+
+        def build():
+            lin = prepare_linear([pr.decoder.weight], None, compute_dtype())
+            V = pr.decoder.weight.shape[0]
+            b = torch.zeros(lin.w.shape[0], device=pr.bias.device, dtype=torch.float32)
+            b[:V] = pr.bias.detach().float()
+            return Lin(lin.w, b, (V + VOCAB_PAD - 1) // VOCAB_PAD * VOCAB_PAD)
+        return pr._cache.get(("vocab", compute_dtype()), [pr.decoder.weight, pr.bias], build)
+
+    def prediction_scores(self, sequence_output):
+        """self.cls(sequence_output) med.py:1027: [B, L, D] f32 -> f32 view [B, L, V] of a [B, L, ceil(V/8)*8] buffer."""
+        pr = self.cls.predictions
+        B, L, D = sequence_output.shape
+        x = as_f32_contig(sequence_output).view(B * L, D)
+        tl = lin_of(pr._cache, "tdense", [pr.transform.dense])
+        h = hip.gemm(to_compute(x), tl.w, tl.b, out_dtype=torch.float32, act=hip.ACT_GELU, n=tl.n)
+        cdt = compute_dtype()
+        h32, hlp = hip.layernorm(h, pr.transform.LayerNorm.weight, pr.transform.LayerNorm.bias, pr.transform.LayerNorm.eps,
+                                 lp=None if cdt == torch.float32 else cdt)
+        vl = self._vocab_linear()
+        logits = hip.gemm(h32 if hlp is None else hlp, vl.w, vl.b, out_dtype=torch.float32, n=vl.n)
+        V = pr.decoder.weight.shape[0]
+        return logits.view(B, L, vl.n)[:, :, :V], logits.view(B, L, vl.n)
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, head_mask=None, inputs_embeds=None,
+                encoder_hidden_states=None, encoder_attention_mask=None, labels=None, past_key_values=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, return_dict=None, return_logits=False, is_decoder=True,
+                reduction='mean', mode='multimodal', space_dict=None, temperature=0, train=False, encoder_kv_cache=None):
+        """encoder_kv_cache (extension, as MedBertModel.forward): cached cross-attention [k|v] of the encoder states - sample b
+        attends to block index[b], so rank_answer does not tile / re-project the question states per candidate."""
+        if past_key_values is not None or use_cache or output_attentions or output_hidden_states:
+            raise NotImplementedError("incremental decoding / attention outputs are not implemented (teacher-forced forward only)")
+        outputs, sd_txt_ft = self.bert(input_ids, attention_mask=attention_mask, position_ids=position_ids, head_mask=head_mask,
+                                       inputs_embeds=inputs_embeds, encoder_hidden_states=encoder_hidden_states,
+                                       encoder_attention_mask=encoder_attention_mask, is_decoder=is_decoder, mode=mode,
+                                       space_dict=space_dict, temperature=temperature, encoder_kv_cache=encoder_kv_cache)
+        scores, padded = self.prediction_scores(outputs[0])
+        if return_logits:
+            return scores[:, :-1, :].contiguous()  # :1029-1030
+        lm_loss = None
+        if labels is not None:
+            # :1033-1042: shifted next-token cross-entropy, label_smoothing 0.1; per-sequence sums from one kernel
+            V = scores.shape[-1]
+            per_seq = hip.lm_loss(padded, labels.to(torch.int64).contiguous(), V, 0.1)
+            if reduction == 'none':
+                lm_loss = per_seq
+            elif reduction == 'sum':
+                lm_loss = per_seq.sum()
+            else:  # 'mean' over the non-ignored target tokens
+                lm_loss = per_seq.sum() / (labels[:, 1:] != -100).sum().clamp(min=1)
+        if not (return_dict if return_dict is not None else True):
+            return ((lm_loss, scores) if lm_loss is not None else (scores,))
+        out = _LMOut(lm_loss, scores)
+        return (out, sd_txt_ft) if train else out
 
 
 class NlvrBertModel(_BertModelBase):

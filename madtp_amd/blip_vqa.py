@@ -1,26 +1,26 @@
-"""Mirror of the reference's models/blip_vqa.py BLIP_VQA, encoder leg (BASELINE config 5: 480x480 images = 901 visual tokens,
-the heaviest ragged compaction): ViT on the image (:59), the MED text encoder in multimodal mode cross-attending to the pruned
-image tokens (:118-125).  Same constructor arguments and sub-module names (`visual_encoder`, `text_encoder`, `space_dict`:
-checkpoint keys) as the reference; the answer decoder `text_decoder` (BertLMHeadModel, :53-55) with rank_answer / beam search
-(:127-215) is out of scope (SURVEY.md 8 "out of scope": decoders), so forward(train=False) returns the encoder output the
-decoder would consume unless a decoder is attached by the caller."""
+"""Mirror of the reference's models/blip_vqa.py BLIP_VQA: the encoder leg (BASELINE config 5: 480x480 images = 901 visual
+tokens, the heaviest ragged compaction) - ViT on the image (:59), the MED text encoder in multimodal mode cross-attending to
+the pruned image tokens (:118-125) - and, with decoder=True, the answer decoder `text_decoder` (BertLMHeadModel, :53-55) run
+teacher-forced by rank_answer (:156-203; SURVEY.md 8(f) rank 4, inference half).  Same constructor arguments and sub-module
+names (checkpoint keys) as the reference.  Training and beam-search generation (:66-115, :127-148) are not implemented."""
 import os
 
 import torch
 from torch import nn
 
 from . import hip  # noqa: F401
-from .bert import BertConfig
-from .med import BertModel
+from .bert import BertConfig, EncoderKVCache
+from .med import BertLMHeadModel, BertModel
 from .runtime import require_gpu
 from .vit import VisionTransformer
 
 ENC_TOKEN_ID = 30523  # tokenizer.additional_special_tokens_ids[0] after init_tokenizer() (models/blip.py:219-225)
+PAD_TOKEN_ID = 0
 
 
 class BLIP_VQA(nn.Module):
     def __init__(self, med_config=None, image_size=480, vit='base', vit_grad_ckpt=False, vit_ckpt_layer=0, evaluate=True,
-                 config=None):
+                 config=None, decoder=True):
         super().__init__()
         if vit != 'base':
             raise NotImplementedError("the gfx950 kernels are tuned for ViT-B (768 wide, 12 heads)")
@@ -36,7 +36,12 @@ class BLIP_VQA(nn.Module):
         enc_cfg.encoder_width = 768
         enc_cfg.evaluate = evaluate
         self.text_encoder = BertModel(config=enc_cfg, add_pooling_layer=False, sd_dim=self.sd_dim)  # :51
-        self.text_decoder = None  # BertLMHeadModel in the reference (:55): off the pruned encoder path
+        # :53-55 (decoder=False, extension: the encoder-leg benchmark / fixtures skip its 137 M parameters)
+        self.text_decoder = None
+        if decoder:
+            dec_cfg = BertConfig.from_json_file(med_config) if isinstance(med_config, str) else BertConfig.med_default()
+            dec_cfg.evaluate = evaluate
+            self.text_decoder = BertLMHeadModel(config=dec_cfg, sd_dim=self.sd_dim)
         self.tokenizer = None     # callers pass {'input_ids', 'attention_mask'} tensors (max_length 35, :63)
 
     def _tokens(self, question, device):
@@ -66,7 +71,45 @@ class BLIP_VQA(nn.Module):
         question_states, _, _ = self.encode_question(image, question, temperature)
         if self.text_decoder is None:
             return question_states  # the tensor rank_answer / generate (:127-180) would consume
-        raise NotImplementedError("answer decoding (:127-215) is out of scope; attach your own decoder to `question_states`")
+        if inference != 'rank':
+            raise NotImplementedError("inference='generate' (beam search, :127-148) is not implemented; use inference='rank'")
+        a_ids = answer["input_ids"] if isinstance(answer, dict) else answer.input_ids
+        a_att = answer["attention_mask"] if isinstance(answer, dict) else answer.attention_mask
+        q_att = question["attention_mask"] if isinstance(question, dict) else question.attention_mask
+        return self.rank_answer(question_states, q_att.to(image.device), a_ids.to(image.device), a_att.to(image.device), k_test)  # :151-153
+
+    def rank_answer(self, question_states, question_atts, answer_ids, answer_atts, k, detail=None):
+        """blip_vqa.py:156-203.  Differences in HOW, not in what: the question states are projected to every decoder layer's
+        cross-attention [k|v] ONCE (EncoderKVCache) and candidate (q, j) reads block q in place - the reference tiles the
+        states k times (:186-187) and re-projects them in every layer; the first-token probabilities come from one kernel
+        (madtp_token_prob); the per-candidate sequence losses from madtp_lm_loss.  detail (optional dict): intermediate
+        tensors for the parity tests."""
+        require_gpu(question_states, "question_states")
+        dec = self.text_decoder
+        num_ques = question_states.size(0)
+        dev = question_states.device
+        cache = EncoderKVCache.build(dec.bert, question_states)
+        start_ids = answer_ids[0, 0].repeat(num_ques, 1)  # bos token :159
+        start = dec(start_ids, encoder_hidden_states=None, encoder_attention_mask=None, return_dict=True, reduction='none',
+                    encoder_kv_cache=cache.select(torch.arange(num_ques, device=dev)))  # :161-165
+        logits = start.logits[:, 0, :]  # first token's logit :166
+        answer_first_token = answer_ids[:, 1].contiguous()
+        prob_first_token = hip.token_prob(logits, answer_first_token, logits.shape[-1])  # softmax + index_select :170-171
+        topk_probs, topk_ids = prob_first_token.topk(k, dim=1)  # :172
+        flat = topk_ids.reshape(-1)
+        input_ids = answer_ids.index_select(0, flat)  # :175-181 ([num_ques * k, answer_len], question-major)
+        input_atts = answer_atts.index_select(0, flat)
+        targets_ids = input_ids.masked_fill(input_ids == PAD_TOKEN_ID, -100)  # :183
+        block = torch.arange(num_ques, device=dev).repeat_interleave(k)  # tile(question_states, 0, k) :186 as an index
+        out = dec(input_ids, attention_mask=input_atts, encoder_hidden_states=None, encoder_attention_mask=None,
+                  labels=targets_ids, return_dict=True, reduction='none', encoder_kv_cache=cache.select(block))  # :189-195
+        log_probs_sum = (-out.loss).view(num_ques, k)  # :197-198
+        max_topk_ids = log_probs_sum.argmax(dim=1)
+        max_ids = topk_ids[max_topk_ids >= 0, max_topk_ids]  # :200-201
+        if detail is not None:
+            detail.update(first_logits=logits, prob_first_token=prob_first_token, topk_ids=topk_ids, topk_probs=topk_probs,
+                          log_probs_sum=log_probs_sum)
+        return max_ids
 
 
 def blip_vqa(pretrained='', **kwargs):

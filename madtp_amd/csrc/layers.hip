@@ -330,8 +330,13 @@ static int bert_attn_impl(const madtp_bert_layer_w* w, const float* hidden, cons
     void* att_lp = dt != MADTP_F32 ? s.attc : nullptr;  // compute-dtype copy of att for the second half (same workspace)
     TRY(lin(hc, D, w->qkv, nullptr, 0, s.qkv, 3 * D, M, dt, adt, MADTP_ACT_NONE, 1.f, stream));
     const char* q = (const char*)s.qkv;
-    TRY(madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.ctx, mask2d, prune ? s.colsum : nullptr, s.p0, s.onorm,
-                        B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale, adt, stream));
+    if (w->self_mask_qk)  // decoder layer (BertModel(is_decoder=True), med.py:752-768): causal [L,L] mask next to the padding mask
+        TRY(madtp_attention_qk_mask(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.ctx, mask2d, w->self_mask_qk, w->ld_self_mask_qk,
+                                    prune ? s.colsum : nullptr, s.p0, s.onorm, B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale,
+                                    adt, stream));
+    else
+        TRY(madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.ctx, mask2d, prune ? s.colsum : nullptr, s.p0, s.onorm,
+                            B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale, adt, stream));
     if (dt == MADTP_F16S) {  // attention.output.dense takes the context as f16 planes (s.q is scratch of the second half)
         TRY(to_lp((const float*)s.ctx, D, s.q, M, D, dt, stream));
         s.ctx = s.q;

@@ -1,0 +1,105 @@
+// Answer ranking on the LM head's prediction scores (inference half):
+//   madtp_lm_loss    - models/med.py BertLMHeadModel.forward :1036-1042: label-smoothed next-token cross-entropy, summed per sequence
+//   madtp_token_prob - models/blip_vqa.py rank_answer :170-171: softmax probability of each candidate's first token
+// Both are HBM-bound row kernels over the vocabulary (V = 30524 f32 scores = 119 KiB per row): one 256-thread workgroup per
+// sequence / question, float4 loads, two passes per row (maximum + plain sum, then the exponential sum: the second pass reads
+// the row back from L2), wave-shuffle + LDS reductions in a fixed order (deterministic).
+// Algorithmic bytes: rows * V * 4 (scores read once from HBM), outputs negligible.
+#include "common.h"
+
+namespace {
+
+constexpr int LM_THREADS = 256;
+
+struct RowStats { float mx, sum_z, sum_e; };
+
+// block-wide reductions through a 4-entry LDS scratch (one slot per wave); every thread gets the result
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+}
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
+// max, sum of scores and sum of exp(score - max) of one row of V scores (row is 16-byte aligned, V need not be a multiple of 4)
+__device__ __forceinline__ RowStats row_stats(const float* row, int V, float* scratch) {
+    const int V4 = V >> 2, tid = threadIdx.x;
+    float mx = -INFINITY, sz = 0.f;
+    for (int i = tid; i < V4; i += LM_THREADS) {
+        const float4 v = ((const float4*)row)[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        sz += (v.x + v.y) + (v.z + v.w);
+    }
+    for (int i = (V4 << 2) + tid; i < V; i += LM_THREADS) { mx = fmaxf(mx, row[i]); sz += row[i]; }
+    mx = block_max(mx, scratch);
+    sz = block_sum(sz, scratch);
+    float se = 0.f;
+    for (int i = tid; i < V4; i += LM_THREADS) {
+        const float4 v = ((const float4*)row)[i];
+        se += (expf(v.x - mx) + expf(v.y - mx)) + (expf(v.z - mx) + expf(v.w - mx));
+    }
+    for (int i = (V4 << 2) + tid; i < V; i += LM_THREADS) se += expf(row[i] - mx);
+    se = block_sum(se, scratch);
+    return {mx, sz, se};
+}
+
+__global__ __launch_bounds__(LM_THREADS) void lm_loss_kernel(const float* logits, int ld, int rows_per_seq, int n_pred, int V,
+                                                             const int64_t* labels, int ld_labels, float eps, float* loss) {
+    __shared__ float scratch[4];
+    const int b = blockIdx.x;
+    float total = 0.f;
+    for (int t = 0; t < n_pred; ++t) {
+        const long long y = labels[(size_t)b * ld_labels + t + 1];
+        if (y < 0 || y >= V) continue;  // ignore_index (-100): the row contributes nothing (uniform across the workgroup)
+        const float* row = logits + ((size_t)b * rows_per_seq + t) * ld;
+        const RowStats st = row_stats(row, V, scratch);
+        const float lse = st.mx + logf(st.sum_e);
+        // CrossEntropyLoss(label_smoothing = eps): (1 - eps) * (-log p_y) + eps / V * sum_j (-log p_j)
+        const float nll = lse - row[y];
+        const float smooth = (float)V * lse - st.sum_z;
+        total += (1.0f - eps) * nll + (eps / (float)V) * smooth;
+    }
+    if (threadIdx.x == 0) loss[b] = total;
+}
+
+__global__ __launch_bounds__(LM_THREADS) void token_prob_kernel(const float* logits, int ld, int V, const int64_t* tok, int A,
+                                                                float* out) {
+    __shared__ float scratch[4];
+    const int q = blockIdx.x;
+    const float* row = logits + (size_t)q * ld;
+    const RowStats st = row_stats(row, V, scratch);
+    for (int a = threadIdx.x; a < A; a += LM_THREADS) {
+        const long long t = tok[a];
+        out[(size_t)q * A + a] = (t >= 0 && t < V) ? expf(row[t] - st.mx) / st.sum_e : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int madtp_lm_loss(const float* logits, int ld, int rows_per_seq, int n_pred, int V, const int64_t* labels,
+                             int ld_labels, float label_smoothing, float* loss, int B, void* stream) {
+    if (!logits || !labels || !loss || B <= 0 || V <= 0 || n_pred < 0 || n_pred > rows_per_seq || ld < V ||
+        ld_labels < n_pred + 1)
+        return MADTP_E_BADARG;
+    if (!aligned16(logits) || (ld & 3)) return MADTP_E_ALIGN;
+    hipLaunchKernelGGL(lm_loss_kernel, dim3(B), dim3(LM_THREADS), 0, (hipStream_t)stream, logits, ld, rows_per_seq, n_pred, V,
+                       labels, ld_labels, label_smoothing, loss);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_token_prob(const float* logits, int ld, int V, const int64_t* tok, int A, float* out, int Q, void* stream) {
+    if (!logits || !tok || !out || Q <= 0 || A <= 0 || V <= 0 || ld < V) return MADTP_E_BADARG;
+    if (!aligned16(logits) || (ld & 3)) return MADTP_E_ALIGN;
+    hipLaunchKernelGGL(token_prob_kernel, dim3(Q), dim3(LM_THREADS), 0, (hipStream_t)stream, logits, ld, V, tok, A, out);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}

@@ -12,8 +12,9 @@ blip_vqa.py: pure glue) to be imported from the reference tree itself.  The CLIP
 `CLIP`) and `clip.mock` - the reference's import-time monkey-patch of torch.nn.MultiheadAttention
 (clip/mock.py:354-359), which the mirror's blocks do not use - as an empty module, while `clip.clip` (load / tokenize /
 _transform: host glue) and `clip.simple_tokenizer` are imported from the reference tree itself.  Names those glue files import that are off the
-pruned forward path (the text decoder `BertLMHeadModel`, the contrastive-loss helpers of models/utils.py) resolve to stubs
-that raise on use, so a training script fails loudly instead of silently running something else."""
+pruned forward path (the contrastive-loss helpers of models/utils.py) resolve to stubs that raise on use, so a training script
+fails loudly instead of silently running something else; `models.med.BertLMHeadModel` is the teacher-forced decoder mirror
+(rank_answer; beam-search generation raises)."""
 import importlib
 import math
 import os
@@ -81,7 +82,7 @@ def install(reference_root=None):
         sys.modules["models"] = pkg
     extras = {
         "vit": {},
-        "med": {"BertLMHeadModel": _off_path("BertLMHeadModel", "med")},
+        "med": {},  # (BertLMHeadModel: the teacher-forced decoder mirror of madtp_amd.bert)
         "nlvr_encoder": {},
         # `from models.utils import *` in the reference also leaks that module's own imports; keep the same names available
         "utils": {"torch": torch, "nn": nn, "np": np, "math": math, "F": F, "_Loss": _Loss,

@@ -12,7 +12,7 @@ import torch
 
 F32, BF16, F16S = 0, 1, 2  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -80,6 +80,8 @@ _SIGS = {
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "madtp_split_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "madtp_split_f16_weight": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "madtp_lm_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p]),
+    "madtp_token_prob": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
 }
 
 
@@ -102,7 +104,8 @@ class BertLayerW(ctypes.Structure):
                 ("fused_twin", c_int), ("cq_fused", LinStruct), ("cdense_fused", LinStruct),
                 ("ln_cross_g", c_void_p), ("ln_cross_b", c_void_p),
                 ("inter", LinStruct), ("out", LinStruct), ("ln_out_g", c_void_p), ("ln_out_b", c_void_p),
-                ("eps", c_float), ("scale", c_float), ("heads", c_int), ("dim", c_int), ("dtype", c_int)]
+                ("eps", c_float), ("scale", c_float), ("heads", c_int), ("dim", c_int), ("dtype", c_int),
+                ("self_mask_qk", c_void_p), ("ld_self_mask_qk", c_int)]
 
 
 class QueryW(ctypes.Structure):
@@ -519,8 +522,9 @@ _WS = {}
 
 
 def workspace(nbytes, device):
-    """Grow-only scratch buffer per device (all kernels run in stream order, so layers can share it)."""
-    key = (device.type, device.index)
+    """Grow-only scratch buffer per (device, current stream): the kernels of one stream run in order, so its layers can share
+    it; forwards in flight on different streams (madtp_amd.pipeline) each get their own."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
@@ -743,6 +747,33 @@ def bert_layer_rest(wstruct, att, mask2d, k, score, cross_mode, enc0, enc1, Nk, 
                                      k, _p(score), _p(indices), _p(indices_sort), int(cross_mode), _p(enc0), _p(enc1), Nk,
                                      _p(enc_mask0), _p(enc_mask1), _stream()), "madtp_bert_layer_rest")
     return y, mask_out, indices, indices_sort
+
+
+def lm_loss(logits, labels, n_vocab, label_smoothing=0.1):
+    """med.py:1036-1042: logits f32 [B, L, >= n_vocab] (prediction scores of every position), labels int64 [B, L] (-100 =
+    ignored) -> loss f32 [B] = per-sequence sum of the label-smoothed next-token cross-entropy."""
+    _req(logits, torch.float32, "logits")
+    _req(labels, torch.int64, "labels")
+    B, L, ld = logits.shape
+    if not logits.is_contiguous() or not labels.is_contiguous() or tuple(labels.shape) != (B, L):
+        raise RuntimeError("lm_loss: logits [B,L,ld] and labels [B,L] must be contiguous")
+    out = torch.empty((B,), device=logits.device, dtype=torch.float32)
+    _check(load().madtp_lm_loss(_p(logits), ld, L, L - 1, int(n_vocab), _p(labels), L, float(label_smoothing), _p(out), B,
+                                _stream()), "madtp_lm_loss")
+    return out
+
+
+def token_prob(logits, tok, n_vocab):
+    """blip_vqa.py:170-171: softmax(logits[:, :n_vocab], dim=1).index_select(1, tok); logits f32 [Q, >= n_vocab] (rows may be
+    strided), tok int64 [A] -> f32 [Q, A]."""
+    _req(tok, torch.int64, "tok")
+    if not logits.is_cuda or logits.dtype != torch.float32 or logits.dim() != 2 or logits.stride(1) != 1:
+        raise RuntimeError("token_prob: logits must be a GPU f32 [Q, V] tensor with unit column stride (rows may be strided)")
+    Q, A = logits.shape[0], tok.shape[0]
+    out = torch.empty((Q, A), device=logits.device, dtype=torch.float32)
+    _check(load().madtp_token_prob(_p(logits), logits.stride(0), int(n_vocab), _p(tok), A, _p(out), Q, _stream()),
+           "madtp_token_prob")
+    return out
 
 
 def profile_begin():

@@ -1,0 +1,69 @@
+"""Several forwards in flight on ONE GPU (MI355X-first throughput design, no reference counterpart: the reference's eval loops
+run one batch at a time on the default stream, compress_nlvr_dtp.py:73-99).
+
+Why: the forward has two regimes.  The vision encoder's GEMMs fill all 256 CUs; the text encoder is ~170 dependent launches
+of 5-20 us on 1280 rows that leave most of the chip idle (a third of the step at the headline batch).  Consecutive batches
+are independent (k = max_b count couples samples only WITHIN a batch), so batch i+1's vision encoder can run under batch i's
+text encoder.  Each in-flight forward gets its own host thread, HIP stream, scratch workspace and model replica (same
+deterministic weights; per-module records such as `last_prune` stay private to a replica); the per-layer host read of k spins
+inside the library with the GIL released, the k hand-over slots are claimed per call (csrc/prune.hip), and no kernel of the
+path waits on another workgroup being resident, so concurrent streams cannot deadlock each other.
+Measured on MI355X (profiles/r03_inflight.txt, same box per line pair): NLVR2 headline 19.4-19.8 k -> 21.1-23.2 k images/s
+with two forwards in flight (three: slower - the vision encoders only share the CUs), retrieval 17.6 k -> 22.8-23.3 k,
+BLIP-VQA 3.3 k -> 3.9-4.3 k, CLIP (two chip-filling towers, nothing to hide) 17.6 k -> 13-15 k: bench.py takes 2 in flight
+except for CLIP.  Two details matter: (1) the workers run the encoder-level C entry points (madtp_vit_encoder /
+madtp_bert_encoder) - on the per-layer Python path their progress hinges on GIL hand-overs and the result swings between
+17 k and 22 k from run to run; (2) a host lock that keeps the workers' vision encoders from overlapping (forced
+anti-phase) was tried and dropped: no gain on NLVR, retrieval 22.8 k -> 14.5 k.
+"""
+import threading
+
+import torch
+
+
+class InflightRunner:
+    """n_inflight workers, each = (model replica, resident inputs, HIP stream, host thread).  run(steps) executes `steps` forwards
+    in total, step i on worker i % n, every worker's steps in order on its own stream; returns after all of them completed."""
+
+    def __init__(self, workload, n_inflight, temperature, batch, device="cuda", seed0=0, models=None):
+        self.w, self.T, self.n = workload, temperature, int(n_inflight)
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.models = list(models) if models is not None else [workload.build(self.device) for _ in range(self.n)]
+        self.inputs = [workload.inputs(batch, seed=seed0 + i) for i in range(self.n)]
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
+        self.errors = []
+        self.last = [None] * self.n  # output of each worker's most recent step
+
+    def _work(self, i, steps, mode):
+        try:
+            from . import runtime
+            runtime.set_precision(mode)  # the precision mode is thread-local state: the workers run the caller's
+            runtime.set_encoder_call_preference(True)  # layer loops in C: progress must not hinge on GIL hand-overs
+            torch.cuda.set_device(self.device)
+            with torch.cuda.stream(self.streams[i]), torch.no_grad():
+                for _ in range(steps):
+                    self.last[i] = self.w.step(self.models[i], self.inputs[i], self.T)
+            self.streams[i].synchronize()
+        except BaseException as e:  # surfaced by run()
+            self.errors.append(e)
+
+    def run(self, steps):
+        per = [steps // self.n + (1 if i < steps % self.n else 0) for i in range(self.n)]
+        main = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(main)
+        from . import runtime
+        mode = runtime.get_precision()
+        threads = [threading.Thread(target=self._work, args=(i, per[i], mode), name=f"madtp-inflight-{i}")
+                   for i in range(self.n) if per[i]]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for s in self.streams:
+            main.wait_stream(s)
+        if self.errors:
+            err, self.errors = self.errors[0], []
+            raise err

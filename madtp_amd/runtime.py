@@ -34,6 +34,17 @@ def get_precision() -> str:
     return getattr(_state, "mode", _DEFAULT)
 
 
+def set_encoder_call_preference(v):
+    """Thread-local override of MADTP_ENCODER_CALL's "auto" rule (None = no override).  The in-flight workers of
+    madtp_amd.pipeline set True: with several host threads the per-layer Python path makes the forwards' progress depend on GIL
+    hand-overs (measured: 17-22 k images/s from run to run), the encoder-level C loops hold no GIL (21-23 k)."""
+    _state.encoder_call = v
+
+
+def encoder_call_preference():
+    return getattr(_state, "encoder_call", None)
+
+
 def compute_dtype():
     """torch dtype of the GEMM operands: float32, bfloat16, or float16 = f16-split planes (mode "f16x3")."""
     return _CDT[get_precision()]
@@ -189,12 +200,14 @@ _SIDE = {}
 
 
 def side_stream(device=None):
-    """One auxiliary HIP stream per device for work the main stream does not depend on (the deferred att_ft sum of the
-    vision encoder runs there, under the text encoder's latency-bound kernels)."""
+    """One auxiliary HIP stream per (device, current main stream) for work the main stream does not depend on (the deferred
+    att_ft sum of the vision encoder runs there, under the text encoder's latency-bound kernels).  Keyed by the main stream so
+    that forwards in flight on different streams (madtp_amd.pipeline) do not serialise on one side stream."""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    if dev not in _SIDE:
-        _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return _SIDE[dev]
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
 
 
 def require_gpu(t, name="input"):

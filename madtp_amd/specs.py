@@ -107,13 +107,33 @@ def blip_retrieval_shapes(img_size=384, embed_dim=256):
     return sd
 
 
-def blip_vqa_shapes(img_size=480):
-    """models/blip_vqa.py BLIP_VQA.__init__ :15-55, encoder side: space_dict, visual_encoder, text_encoder (the answer decoder
-    `text_decoder` of :53-55 is off the pruned encoder path)."""
+def lm_head_shapes(prefix="text_decoder."):
+    """models/med.py BertLMHeadModel :933-947: `bert` (BertModel, no pooler) + `cls.predictions` (BertOnlyMLMHead :616-657)."""
+    sd = bert_shapes(prefix + "bert.", "med")
+    c = prefix + "cls.predictions."
+    sd[c + "bias"] = (VOCAB,)
+    _linear(sd, c + "transform.dense", D, D)
+    _ln(sd, c + "transform.LayerNorm")
+    _linear(sd, c + "decoder", VOCAB, D)
+    return sd
+
+
+# state-dict entries that alias ONE parameter in the reference (transformers ties the LM head to the input embeddings,
+# PreTrainedModel.tie_weights; BertLMPredictionHead links decoder.bias to its own bias, med.py:629-637): the synthetic
+# generator gives both names the same values, as any saved checkpoint has them
+TIED_KEYS = {"cls.predictions.decoder.weight": "bert.embeddings.word_embeddings.weight",
+             "cls.predictions.decoder.bias": "cls.predictions.bias"}
+
+
+def blip_vqa_shapes(img_size=480, decoder=False):
+    """models/blip_vqa.py BLIP_VQA.__init__ :15-55: space_dict, visual_encoder, text_encoder and - decoder=True - the answer
+    decoder `text_decoder` (:53-55) that rank_answer (:156-203) runs teacher-forced."""
     sd = OrderedDict()
     sd["space_dict"] = (SD_NUM, D)
     sd.update(vit_shapes("visual_encoder.", img_size))
     sd.update(bert_shapes("text_encoder.", "med"))
+    if decoder:
+        sd.update(lm_head_shapes("text_decoder."))
     return sd
 
 
@@ -183,4 +203,14 @@ def synth_weights(shapes, seed=0, device=None):
             out[k] = torch.arange(shp[-1], device=device).expand(shp[1:]).clone()
         else:
             out[k] = synth.synth_tensor(k, shp, seed, device=device)
+    tie_keys(out)
     return out
+
+
+def tie_keys(sd):
+    """give the aliased state-dict names of TIED_KEYS the values of their source entry (in place)."""
+    for k in list(sd.keys()):
+        for dst, src in TIED_KEYS.items():
+            if k.endswith(dst) and (k[:-len(dst)] + src) in sd:
+                sd[k] = sd[k[:-len(dst)] + src].clone()
+    return sd

@@ -138,3 +138,21 @@ def synth_token_ids(batch: int, length: int, seed: int = 0, lo: int = 1000, hi: 
     if first_id is not None:
         ids[:, 0] = first_id
     return ids
+
+
+def synth_answer_ids(n: int, length: int, seed: int = 0, bos: int = 30522, sep: int = 102, min_len: int = 1, max_len=None):
+    """(ids, attention_mask) [n, length] int64 of candidate answers as the VQA driver tokenises them
+    (compress_vqa_dtp.py: tokenizer(answer_list, padding='longest'); input_ids[:,0] = bos_token_id): [DEC], 1..max_len word
+    ids in [1000, 30000), [SEP], zero padding."""
+    max_len = length - 2 if max_len is None else max_len
+    h = hash_u32("answer_ids", n * length, seed).astype(np.int64)
+    ln = hash_u32("answer_lens", n, seed).astype(np.int64)
+    ids = np.zeros((n, length), dtype=np.int64)
+    att = np.zeros((n, length), dtype=np.int64)
+    for a in range(n):
+        m = int(min_len + ln[a] % (max_len - min_len + 1))
+        ids[a, 0] = bos
+        ids[a, 1:1 + m] = 1000 + h[a * length:a * length + m] % 29000
+        ids[a, 1 + m] = sep
+        att[a, :m + 2] = 1
+    return torch.from_numpy(ids), torch.from_numpy(att)

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import EncoderWeights, PreparedCache, param_epoch, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
+from .runtime import EncoderWeights, PreparedCache, param_epoch, encoder_call_preference, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model, vector_gather  # noqa: F401  (re-exported like `from models.utils import *`)
 
 import os as _os
@@ -31,6 +31,8 @@ ENCODER_CALL_MAX_ROWS = 8192
 
 def use_encoder_call(rows, flag=None):
     flag = _ENCODER_CALL if flag is None else flag
+    if flag == "auto" and encoder_call_preference() is not None:
+        return bool(encoder_call_preference())
     return (rows <= ENCODER_CALL_MAX_ROWS) if flag == "auto" else bool(flag)
 
 

@@ -66,6 +66,7 @@ class Workload:
     images_per_sample = 1
     default_batch = 64
     p = 0.5
+    default_inflight = 2  # forwards in flight per GPU in bench.py (madtp_amd/pipeline.py); measured per configuration
 
     def build(self, device="cuda"): raise NotImplementedError
     def inputs(self, B, seed=0, device="cuda"): raise NotImplementedError
@@ -129,7 +130,7 @@ class Retrieval(Workload):
         txt, _ = model.text_encoder(ids, attention_mask=att, mode='text', space_dict=sd, temperature=T)   # :101-103
         txt_emb = model.project_text(txt.last_hidden_state[:, 0, :])                             # :104
         # the multimodal pass below overwrites the layers' last_prune: keep the text-mode records (references only, read by lens())
-        self._text_prune = [l.last_prune for l in model.text_encoder.encoder.layer]
+        model.__dict__["_madtp_text_prune"] = [l.last_prune for l in model.text_encoder.encoder.layer]
         atts = torch.ones(img.shape[:-1], dtype=torch.long, device=img.device)
         mm, _ = model.text_encoder(ids_mm, attention_mask=att, encoder_hidden_states=img, encoder_attention_mask=atts,
                                    return_dict=True, space_dict=sd, temperature=T)               # :166-171 on matched pairs
@@ -139,7 +140,7 @@ class Retrieval(Workload):
         n0 = (self.size // 16) ** 2 + 1
         out = {"vit": harness.token_lengths(_traces(model.visual_encoder.blocks), n0),
                "mm": harness.token_lengths(_traces(model.text_encoder.encoder.layer), self.L)}
-        tp = getattr(self, "_text_prune", None)
+        tp = model.__dict__.get("_madtp_text_prune")
         if tp is not None:
             out["text"] = harness.token_lengths([harness._cpu_info(i) for i in tp], self.L)
         return out
@@ -162,7 +163,7 @@ class Vqa(Workload):
 
     def build(self, device="cuda"):
         from .blip_vqa import BLIP_VQA
-        model = BLIP_VQA(image_size=self.size, evaluate=True).eval().to(device)
+        model = BLIP_VQA(image_size=self.size, evaluate=True, decoder=False).eval().to(device)  # encoder leg (config 5)
         msg = model.load_state_dict(specs.synth_weights(specs.blip_vqa_shapes(self.size), 0, device=device), strict=False)
         assert not msg.unexpected_keys and all("query_model" in k or "position_ids" in k for k in msg.missing_keys), msg
         return model
@@ -179,7 +180,7 @@ class Vqa(Workload):
         n0 = (self.size // 16) ** 2 + 1
         out = {"vit": harness.token_lengths(_traces(model.visual_encoder.blocks), n0),
                "mm": harness.token_lengths(_traces(model.text_encoder.encoder.layer), self.L)}
-        tp = getattr(self, "_text_prune", None)
+        tp = model.__dict__.get("_madtp_text_prune")
         if tp is not None:
             out["text"] = harness.token_lengths([harness._cpu_info(i) for i in tp], self.L)
         return out
@@ -198,6 +199,7 @@ class Vqa(Workload):
 class Clip(Workload):
     name, default_batch, p = "clip", 128, 0.5
     size, ctx = 224, 77
+    default_inflight = 1  # both towers fill the chip: a second forward in flight only shares the CUs (17.6 k -> 13-15 k images/s)
 
     def build(self, device="cuda"):
         from .clip_model import build_model

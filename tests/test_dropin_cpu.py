@@ -72,11 +72,13 @@ def test_reference_clip_load_builds_the_mirror(tmp_path):
         ref_shims.install(chdir=True, import_models=False)
         import madtp_amd.dropin as dropin
         dropin.install({REF!r})
-        from clip import clip                                    # the reference's clip/clip.py, unmodified
+        from clip import clip                                    # the reference's clip/clip.py, unmodified (the driver's import)
         assert clip.__file__.startswith({REF!r}), clip.__file__
-        import clip as clip_pkg, clip.model, clip.mock
+        import sys as _s
+        clip_pkg = _s.modules["clip"]
         import madtp_amd.clip_model as mirror
-        assert clip_pkg.model.build_model is mirror.build_model and clip.build_model is mirror.build_model
+        assert _s.modules["clip.model"].build_model is mirror.build_model and clip.build_model is mirror.build_model
+        assert "clip.mock" in _s.modules
         assert clip_pkg.load is clip.load and clip_pkg.tokenize is clip.tokenize   # clip/__init__.py: from .clip import *
         from madtp_amd import specs
         sd = specs.synth_weights(specs.clip_shapes(224), 0)
@@ -93,7 +95,11 @@ def test_reference_clip_load_builds_the_mirror(tmp_path):
         """)
     import json
     rep = json.loads(out.strip().splitlines()[-1])
-    assert rep["missing"] == [] and rep["extra"] == [], (rep["missing"][:10], rep["extra"][:10])
+    # the mirror holds the EVALUATION state: the momentum copies (`*_m`, clip/model.py:398-427) and the queues (:429-437) of the
+    # reference only feed the training loss and are absent; a reference checkpoint's extra keys are ignored by strict=False
+    training_only = lambda k: k.split(".")[0].endswith("_m") or k.split(".")[0].endswith("_queue")  # noqa: E731
+    assert all(training_only(k) for k in rep["missing"]), [k for k in rep["missing"] if not training_only(k)][:10]
+    assert rep["extra"] == [], rep["extra"][:10]
     assert rep["n"] > 300 and rep["same_vals"]
 
 
@@ -132,8 +138,11 @@ def test_reference_blip_glue_constructs_on_the_mirrors(which):
     import json
     rep = json.loads(out.strip().splitlines()[-1])
     ok = lambda k: "position_ids" in k  # noqa: E731  (buffers only the reference registers)
+    # the fixture lists the evaluation-side keys; the reference's own glue class also builds its training state on the mirrors
+    # (momentum encoders, queues, temp: blip_retrieval.py:67-93) and, for VQA, the answer decoder
+    train = lambda k: k.split(".")[0].endswith(("_m", "_queue")) or k.split(".")[0] in ("temp", "text_decoder")  # noqa: E731
     assert all(ok(k) for k in rep["missing"]), rep["missing"][:10]
-    assert all(ok(k) for k in rep["extra"]), rep["extra"][:10]
+    assert all(ok(k) or train(k) for k in rep["extra"]), [k for k in rep["extra"] if not (ok(k) or train(k))][:10]
     assert rep["n"] > 300
 
 

@@ -758,3 +758,26 @@ def test_k_handover_slots(hip):
     rc, seq = publish()
     assert rc == 0 and wait(seq) == (0, k_ref)
     assert int(cnt.max().item()) == k_ref
+
+
+@pytest.mark.parametrize("B,L,V,ld", [(5, 7, 30524, 30528), (3, 2, 1000, 1000), (2, 9, 131, 132)])
+def test_lm_loss_and_token_prob(hip, B, L, V, ld):
+    """madtp_lm_loss vs F.cross_entropy(label_smoothing=0.1, reduction='none') on the shifted scores summed per sequence
+    (med.py:1036-1042) incl. ignored (-100) targets and a fully ignored sequence; madtp_token_prob vs softmax + index_select
+    (blip_vqa.py:170-171) on strided rows.  Padding columns [V, ld) hold garbage that must not be read."""
+    g = torch.Generator().manual_seed(B * 100 + L)
+    buf = torch.randn(B, L, ld, generator=g) * 3.0
+    buf[..., V:] = 1e9
+    labels = torch.randint(0, V, (B, L), generator=g)
+    labels[0, 2:] = -100
+    labels[-1, :] = -100
+    ref = F.cross_entropy(buf[:, :-1, :V].reshape(-1, V).double(), labels[:, 1:].reshape(-1), reduction="none", label_smoothing=0.1)
+    ref = ref.view(B, -1).sum(1).float()
+    out = hip.lm_loss(buf.cuda(), labels.cuda(), V, 0.1).cpu()
+    assert (out - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (out, ref)
+    assert out[-1].item() == 0.0
+    tok = torch.randint(0, V, (11,), generator=g)
+    rows = buf[:, 0, :].cuda()          # row stride L * ld
+    p = hip.token_prob(rows, tok.cuda(), V).cpu()
+    refp = torch.softmax(buf[:, 0, :V].double(), 1).index_select(1, tok).float()
+    assert (p - refp).abs().max().item() < 1e-6

@@ -460,7 +460,7 @@ def test_clip_both_towers(path, mode):
     assert cos_t > 0.98 and cos_i > 0.98
 
 
-VQA_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vqa*.npz")))
+VQA_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vqa[0-9]*.npz")))
 
 
 @pytest.mark.parametrize("mode", EXACT_MODES)
@@ -476,7 +476,7 @@ def test_vqa_encoder_leg_matches_reference_fixture(path, mode):
     hip.load()
     g = np.load(path)
     T, L = float(g["temperature"]), int(g["L"])
-    model = BLIP_VQA(image_size=int(g["size"]), evaluate=True)
+    model = BLIP_VQA(image_size=int(g["size"]), evaluate=True, decoder=False)
     msg = model.load_state_dict(specs.synth_weights(specs.blip_vqa_shapes(int(g["size"])), int(g["seed"])), strict=False)
     assert not msg.unexpected_keys and all("query_model" in k or "position_ids" in k for k in msg.missing_keys), msg
     model = model.eval().cuda()
@@ -501,3 +501,56 @@ def test_vqa_encoder_leg_matches_reference_fixture(path, mode):
     cos = torch.nn.functional.cosine_similarity(hb[:, 0, :].float(), hid[:, 0, :].float(), dim=-1).min().item()
     print(f"VQA bf16 vs {mode} CLS row: min cosine {cos:.4f}")
     assert torch.isfinite(hb).all() and cos > 0.97  # measured 0.9996 (T=6) / 0.981 (T=30: 901 -> 11 image tokens)
+
+
+VQA_RANK_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vqa_rank_*.npz")))
+
+
+@pytest.mark.parametrize("mode", EXACT_MODES + ["bf16"])
+@pytest.mark.parametrize("path", VQA_RANK_CASES, ids=[os.path.basename(c)[:-4] for c in VQA_RANK_CASES])
+def test_vqa_rank_answer_matches_reference_fixture(path, mode):
+    """SURVEY.md 8(f) rank 4, inference half: BLIP_VQA.forward(train=False, inference='rank') on the HIP path - encoder leg,
+    teacher-forced answer decoder (BertLMHeadModel: causal self-attention through madtp_bert_layer_w.self_mask_qk, LM head,
+    madtp_lm_loss) and rank_answer (madtp_token_prob, cached cross-attention K/V of the question states) - vs the fixture
+    recorded from the reference's own models/blip_vqa.py.  Parity modes: the same candidate sets, the same answers, first-token
+    probabilities within 1e-5 and sequence log-likelihoods within 1e-3 RELATIVE of the reference's; bf16: finite and close."""
+    from madtp_amd import build, hip, runtime, specs
+    from madtp_amd.blip_vqa import BLIP_VQA
+    from tests.test_oracle_golden import vqa_rank_inputs
+    build.build(verbose=False)
+    hip.load()
+    g = np.load(path)
+    T, k = float(g["temperature"]), int(g["k_test"])
+    model = BLIP_VQA(image_size=int(g["size"]), evaluate=True)
+    sd = specs.synth_weights(specs.blip_vqa_shapes(int(g["size"]), decoder=True), int(g["seed"]))
+    msg = model.load_state_dict(sd, strict=False)
+    assert not msg.unexpected_keys and all("query_model" in x or "position_ids" in x for x in msg.missing_keys), msg
+    dec = model.text_decoder
+    assert dec.cls.predictions.decoder.weight is dec.bert.embeddings.word_embeddings.weight   # tied (transformers tie_weights)
+    assert sorted(x for x in model.state_dict() if x.startswith("text_decoder.") and "position_ids" not in x) == \
+        sorted(str(x) for x in g["decoder_state_dict_keys"] if "position_ids" not in str(x))
+    model = model.eval().cuda()
+    images, ids, att, a_ids, a_att = vqa_rank_inputs(g)
+    det = {}
+    with runtime.precision(mode), torch.no_grad():
+        q = {"input_ids": ids.cuda(), "attention_mask": att.cuda()}
+        qs, _, _ = model.encode_question(images.cuda(), q, T)
+        max_ids = model.rank_answer(qs, att.cuda(), a_ids.cuda(), a_att.cuda(), k, detail=det)
+        again = model(images.cuda(), q, {"input_ids": a_ids.cuda(), "attention_mask": a_att.cuda()}, temperature=T, train=False,
+                      inference='rank', k_test=k)
+    assert torch.equal(max_ids, again)
+    lp, ref_lp = det["log_probs_sum"].cpu().numpy(), g["log_probs_sum"]
+    pf, ref_pf = det["prob_first_token"].cpu().numpy(), g["prob_first_token"]
+    if mode == "bf16":
+        assert np.isfinite(lp).all() and np.abs(pf - ref_pf).max() < 2e-4
+        print(f"bf16 rank_answer: max |d log-lik| {np.abs(np.sort(lp, 1) - np.sort(ref_lp, 1)).max():.3f}, answers {max_ids.tolist()} "
+              f"(reference {g['max_ids'].tolist()})")
+        return
+    assert np.abs(det["first_logits"][:, :64].cpu().numpy() - g["first_logits_sample"]).max() < 1e-3
+    assert np.abs(pf - ref_pf).max() < 1e-5
+    assert [sorted(r) for r in det["topk_ids"].tolist()] == [sorted(r) for r in g["topk_ids"].tolist()]
+    # same candidates possibly in another order: compare per (question, answer id)
+    mine = {(qi, int(a)): lp[qi, j] for qi in range(lp.shape[0]) for j, a in enumerate(det["topk_ids"][qi].tolist())}
+    ref = {(qi, int(a)): ref_lp[qi, j] for qi in range(ref_lp.shape[0]) for j, a in enumerate(g["topk_ids"][qi].tolist())}
+    assert max(abs(mine[x] - ref[x]) / max(1.0, abs(ref[x])) for x in ref) < 1e-3
+    assert max_ids.tolist() == g["max_ids"].tolist()

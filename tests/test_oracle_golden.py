@@ -269,7 +269,7 @@ def test_oracle_clip_full_matches_reference_fixture(path):
     assert torch.isfinite(fa).all()
 
 
-VQA_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vqa*.npz")))
+VQA_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vqa[0-9]*.npz")))
 
 
 def vqa_inputs(g):
@@ -305,3 +305,41 @@ def test_oracle_vqa_encoder_matches_reference_fixture(path):
             assert info["pruned"] and info["k"] + 2 == lens[l]
             ref = g[f"{key}{l}_idx"][:, : info["k"]]
             assert (np.sort(info["indices"].numpy(), 1) == np.sort(ref, 1)).all()
+
+
+VQA_RANK_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vqa_rank_*.npz")))
+
+
+def vqa_rank_inputs(g):
+    images, ids, att = vqa_inputs(g)
+    a_ids, a_att = synth.synth_answer_ids(int(g["n_answers"]), int(g["answer_len"]), int(g["seed"]))
+    return images, ids, att, a_ids, a_att
+
+
+@pytest.mark.parametrize("path", VQA_RANK_CASES, ids=[os.path.basename(c)[:-4] for c in VQA_RANK_CASES])
+def test_oracle_vqa_rank_answer_matches_reference_fixture(path):
+    """SURVEY.md 8(f) rank 4, inference half: BLIP_VQA.forward(train=False, inference='rank') of the reference - encoder leg,
+    teacher-forced answer decoder (models/med.py BertLMHeadModel) and rank_answer (blip_vqa.py:156-203) - recorded from the
+    reference's own modules: first-token probabilities, the k candidates per question, their sequence log-likelihoods and the
+    chosen answers."""
+    g = np.load(path)
+    T, k = float(g["temperature"]), int(g["k_test"])
+    shapes = specs.blip_vqa_shapes(int(g["size"]), decoder=True)
+    dec_keys = {str(x) for x in g["decoder_state_dict_keys"]}
+    mine = {x for x in shapes if x.startswith("text_decoder.")}
+    assert mine == dec_keys, (sorted(mine - dec_keys)[:5], sorted(dec_keys - mine)[:5])
+    W = specs.synth_weights(shapes, int(g["seed"]))
+    assert torch.equal(W["text_decoder.cls.predictions.decoder.weight"], W["text_decoder.bert.embeddings.word_embeddings.weight"])
+    images, ids, att, a_ids, a_att = vqa_rank_inputs(g)
+    tr, det = {}, {}
+    with torch.no_grad():
+        max_ids = O.blip_vqa_rank_forward(W, images, ids, att, a_ids, a_att, T, k, trace=tr, detail=det)
+    n0 = (int(g["size"]) // 16) ** 2 + 1
+    from madtp_amd import harness
+    assert harness.token_lengths(tr["vit"], n0) == g["vit_lens"].tolist()
+    assert harness.token_lengths(tr["text"], int(g["L"])) == g["txt_lens"].tolist()
+    assert np.abs(det["first_logits"][:, :64].numpy() - g["first_logits_sample"]).max() < 1e-4
+    assert np.abs(det["prob_first_token"].numpy() - g["prob_first_token"]).max() < 1e-6
+    assert det["topk_ids"].tolist() == g["topk_ids"].tolist()
+    assert np.abs(det["log_probs_sum"].numpy() - g["log_probs_sum"]).max() < 1e-3
+    assert max_ids.tolist() == g["max_ids"].tolist()

@@ -78,3 +78,28 @@ def test_controller_closes_around_the_hip_forward(name, task, B):
     assert len(seen) >= 3 and seen[-1][1] < 0.9 * full
     log = C.run_controller(lambda t: measure(t) * scale, T, w.p, C.ORI_GFLOPS[task], 6, task)
     assert all(abs(c - target * scale) <= 2 * tol for _, _, c in log), log
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name,B,mode", [("nlvr", 4, "fp32"), ("nlvr", 6, "bf16"), ("retrieval", 6, "f16x3")])
+def test_inflight_runner_equals_serial_forwards(name, B, mode):
+    """madtp_amd/pipeline.py: forwards in flight on separate host threads / HIP streams / model replicas give EXACTLY the
+    outputs of the same forwards run one after the other (same kernels, per-stream scratch, thread-local precision mode), also
+    when the steps of the workers interleave many times; the workers ran the encoder-level C entry points."""
+    from madtp_amd import build, configs, hip, runtime, workloads
+    from madtp_amd.pipeline import InflightRunner
+    build.build(verbose=False)
+    hip.load()
+    w = workloads.get(name)
+    T, _ = configs.temperature_for(name, w.default_batch, w.p)
+    with runtime.precision(mode), torch.no_grad():
+        runner = InflightRunner(w, 2, T, B, "cuda", seed0=7)
+        serial = [[t.clone() for t in _flat(w.step(runner.models[i], runner.inputs[i], T))] for i in range(2)]
+        lens = [w.lens(runner.models[i]) for i in range(2)]
+        for steps in (2, 7, 12):
+            runner.run(steps)
+            for i in range(2):
+                for a, b in zip(_flat(runner.last[i]), serial[i]):
+                    assert torch.equal(a, b), (steps, i, (a - b).abs().max().item())
+                assert w.lens(runner.models[i]) == lens[i]
+    assert runtime.get_precision() == "bf16"  # the caller's (default) mode is untouched outside the context

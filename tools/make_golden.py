@@ -332,6 +332,63 @@ def retrieval_case(name, n_img, img_bs, n_txt, size, temperature, k_test, seed=0
     print(f"[{name}] T={temperature} vit_out_lens={lens} i2t[0]={np.round(i2t[0], 3).tolist()} ({dt:.1f}s)")
 
 
+def vqa_rank_case(name, B, size, L, temperature, n_answers, answer_len, k_test, seed=0, pad_tail=0):
+    """models/blip_vqa.py BLIP_VQA.forward(train=False, inference='rank') (:57-64, :117-154) -> rank_answer (:156-203): the
+    reference's own encoder leg, answer decoder (models/med.py BertLMHeadModel, teacher-forced) and candidate ranking.  The LM
+    head's output embedding / bias are given the values of the entries they alias in any saved checkpoint (specs.TIED_KEYS):
+    the import shim turns transformers' tie_weights() into a no-op."""
+    import models.blip_vqa as bv
+    from madtp_amd import harness, specs
+    ref_shims.patch_tokenizer(bv)
+    model = bv.BLIP_VQA(image_size=size, evaluate=True, config={"sd_num": 100, "sd_dim": 768, "batch_size_train": 16})
+    model.eval()
+    sd = specs.tie_keys(synth.fill_state_dict(model, seed))
+    model.load_state_dict(sd, strict=True)
+    images = synth.synth_images(B, size, seed)
+    ids = synth.synth_token_ids(B, L, seed, first_id=None)
+    att = harness.padded_mask(B, L, pad_tail)
+    a_ids, a_att = synth.synth_answer_ids(n_answers, answer_len, seed)
+    calls = []
+    orig = model.text_decoder.forward
+
+    def tapped(*a, **k):
+        out = orig(*a, **k)
+        calls.append({"logits": out.logits.detach(), "loss": None if out.loss is None else out.loss.detach(),
+                      "input_ids": a[0].detach().clone()})
+        return out
+    model.text_decoder.forward = tapped
+    lens_v, lens_t, hooks = [], [], []
+    for blk in model.visual_encoder.blocks:
+        hooks.append(blk.register_forward_hook(lambda m, a, o: lens_v.append(o.shape[1])))
+    for lay in model.text_encoder.encoder.layer:
+        hooks.append(lay.register_forward_hook(lambda m, a, o: lens_t.append(o[0].shape[1])))
+    t0 = time.time()
+    with torch.no_grad():
+        max_ids = model(images, {"input_ids": ids, "attention_mask": att},
+                        ref_shims.FakeTokenizer._Batch({"input_ids": a_ids, "attention_mask": a_att}),
+                        temperature=temperature, train=False, inference='rank', k_test=k_test)
+    dt = time.time() - t0
+    for h in hooks:
+        h.remove()
+    model.text_decoder.forward = orig
+    first_logits = calls[0]["logits"][:, 0, :]
+    prob_first = torch.softmax(first_logits, dim=1).index_select(1, a_ids[:, 1])
+    topk_probs, topk_ids = prob_first.topk(k_test, dim=1)
+    assert torch.equal(calls[1]["input_ids"], torch.cat([a_ids.index_select(0, t) for t in topk_ids], 0))
+    log_probs_sum = (-calls[1]["loss"]).view(B, k_test)
+    dec_keys = sorted(k for k in sd.keys() if k.startswith("text_decoder."))
+    out = {"kind": "vqa_rank", "B": B, "size": size, "L": L, "temperature": np.float64(temperature), "seed": seed,
+           "pad_tail": pad_tail, "n_answers": n_answers, "answer_len": answer_len, "k_test": k_test,
+           "vit_lens": np.array(lens_v), "txt_lens": np.array(lens_t), "max_ids": max_ids.numpy(),
+           "topk_ids": topk_ids.numpy(), "topk_probs": topk_probs.numpy(), "prob_first_token": prob_first.numpy(),
+           "log_probs_sum": log_probs_sum.numpy(), "first_logits_sample": first_logits[:, :64].numpy(),
+           "first_logits_absmean": first_logits.abs().mean().numpy(),
+           "decoder_state_dict_keys": np.array(dec_keys), "ref_seconds": dt, "threads": torch.get_num_threads()}
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[{name}] T={temperature} vit_lens={lens_v} txt_lens={lens_t} max_ids={max_ids.tolist()} topk_ids={topk_ids.tolist()} "
+          f"log_probs_sum[0]={np.round(log_probs_sum[0].numpy(), 3).tolist()} ({dt:.1f}s)")
+
+
 CASES = {
     "nlvr_b2_T1": lambda: nlvr_case("nlvr_b2_T1", 2, 224, 20, 1.0),
     "nlvr_b2_T5": lambda: nlvr_case("nlvr_b2_T5", 2, 224, 20, 5.0),
@@ -340,6 +397,9 @@ CASES = {
     "med_mm_b3": lambda: med_case("med_mm_b3", 3, 35, 50, 30.0, "multimodal", pad_tail=3),
     "vqa480_b2": lambda: vqa_case("vqa480_b2", 2, 480, 20, 6.0, pad_tail=2),
     "vqa480_b2_T30": lambda: vqa_case("vqa480_b2_T30", 2, 480, 35, 30.0, seed=2, pad_tail=4),
+    "vqa_rank_b3": lambda: vqa_rank_case("vqa_rank_b3", 3, 224, 20, 6.0, n_answers=12, answer_len=7, k_test=4, pad_tail=2),
+    "vqa_rank_b2_T30": lambda: vqa_rank_case("vqa_rank_b2_T30", 2, 224, 35, 30.0, n_answers=9, answer_len=5, k_test=3, seed=2,
+                                             pad_tail=4),
     "clip_vit_b2": lambda: clip_case("clip_vit_b2", 2, 4.0),
     "clip_full_b3_T4": lambda: clip_full_case("clip_full_b3_T4", 3, 4.0),
     "clip_full_b3_T40": lambda: clip_full_case("clip_full_b3_T40", 3, 40.0, seed=1),
