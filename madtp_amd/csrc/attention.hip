@@ -310,6 +310,273 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// f16-split ("f16x3") flavour of the kernel above for the fp32-ACCURATE precision mode: same decomposition, f32 storage of
+// q / k / v / out, the same softmax arithmetic (separately rounded scale and mask, expf, true division) and the same score
+// side outputs - but both products run on the f16 MFMA as THREE products of f16-split operands (common.h):
+//     x = P0 + 2^-11 P1  (P0 = f16(x), P1 = f16((x - P0) 2^11))     x y = P0 Q0 + 2^-11 (P0 Q1 + P1 Q0)   (+ 2^-22 P1 Q1, dropped)
+// with exact partial products and f32 accumulation in two accumulators (hi: P0 Q0, lo: the two cross terms): the rounding
+// class of an f32 dot product at 3/16 of the exact-f32 MFMA's cost (v_mfma_f32_16x16x4_f32: 32 cycles per 16x16x4 step; the
+// f16 instruction does a 16x16x32 step in 16).  K_h and V_h are split WHILE they are staged (global f32 -> registers ->
+// two f16 planes in LDS, row pitch 160 B: conflict-free ds_read_b128 of the K fragments), Q and P are split in registers.
+// Register / operand layouts are those of attn_bf16_kernel: S^T = K Q^T (lane (i = l16, g) holds keys 16t + 4g + r of query
+// row i), P V with the k-slot <-> key permutation key(chunk c, g, e) = 32c + 16(e >> 2) + 4g + (e & 3) so that the A operand is
+// the lane's own eight probabilities and the B operand two transpose reads (ds_read_b64_tr_b16) of row-major V.
+template <int NT, bool SCORES>
+__global__ __launch_bounds__(256) void attn_f16s_kernel(AttnArgs a) {
+    constexpr int PITCH = NT <= 15 ? 160 : 144;  // bytes per 64-element f16 row (144: 2-way conflicts, what fits at 256 keys)
+    constexpr int NKP = NT * 16;                 // padded key count
+    constexpr int NC = (NT + 1) / 2;             // 32-key chunks of the P.V product
+    constexpr int VR = NC * 32;                  // V rows (whole chunks; rows >= NKP stay zero)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* K0 = smem;
+    char* K1 = K0 + NKP * PITCH;
+    char* V0 = K1 + NKP * PITCH;
+    char* V1 = V0 + VR * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int bkv = a.kvidx ? a.kvidx[b] : b;
+    const int rt = blockIdx.x * 4 + wave;
+    const int i0 = rt * 16;
+    const bool active = i0 < a.Nq;
+    const int irow = min(i0 + l16, a.Nq - 1);
+
+    f32x4 pmax[NT];
+    if constexpr (SCORES) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pmax[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 mk[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * t + 4 * g + r;
+            mk[t][r] = j < a.Nk ? (a.mask ? a.mask[(size_t)b * a.Nk + j] : 0.f) : -INFINITY;
+            if (a.mask_qk && j < a.Nk) mk[t][r] += a.mask_qk[(size_t)irow * a.ld_mqk + j];
+        }
+    if constexpr (VR > NKP) {  // the last chunk's missing key tile: zero V rows (their probabilities are zero as well), once
+        for (int idx = tid; idx < (VR - NKP) * (PITCH / 16); idx += 256) {
+            *(uint4*)(V0 + NKP * PITCH + idx * 16) = make_uint4(0, 0, 0, 0);
+            *(uint4*)(V1 + NKP * PITCH + idx * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+
+    // staging: thread chunk idx = (key row, 4 consecutive d) of K_h and V_h as f32, split into the two planes on the way to LDS;
+    // up to 8 chunks per operand the registers of head h + 1 are fetched under head h's MFMAs (as in attn_kernel)
+    constexpr int NLD = NT;  // NKP * 16 chunks / 256 threads
+    constexpr bool PREFETCH = NLD <= 8;
+    uint4 kreg[PREFETCH ? NLD : 1], vreg[PREFETCH ? NLD : 1];
+    auto fetch = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 4, c = idx & 15;
+            kreg[i] = make_uint4(0, 0, 0, 0);
+            vreg[i] = make_uint4(0, 0, 0, 0);
+            if (row < a.Nk) {
+                const size_t grow = (size_t)bkv * a.Nk + row;
+                kreg[i] = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * 4 + c * 16);
+                vreg[i] = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * 4 + c * 16);
+            }
+        }
+    };
+    auto put = [&](int idx, uint4 kv, uint4 vv) {
+        const int row = idx >> 4, c = idx & 15;
+        f16x4 h4, l4;
+        split_f16x4(__builtin_bit_cast(f32x4, kv), h4, l4);
+        *(f16x4*)(K0 + row * PITCH + c * 8) = h4;
+        *(f16x4*)(K1 + row * PITCH + c * 8) = l4;
+        split_f16x4(__builtin_bit_cast(f32x4, vv), h4, l4);
+        *(f16x4*)(V0 + row * PITCH + c * 8) = h4;
+        *(f16x4*)(V1 + row * PITCH + c * 8) = l4;
+    };
+    if constexpr (PREFETCH) {
+        if ((int)blockIdx.z < a.H) fetch(blockIdx.z);
+    }
+    constexpr float LO = 1.0f / F16S_LO_SCALE;
+    for (int h = blockIdx.z; h < a.H; h += gridDim.z) {
+        __syncthreads();
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) put(tid + 256 * i, kreg[i], vreg[i]);
+        } else {
+            for (int idx = tid; idx < NKP * 16; idx += 256) {
+                const int row = idx >> 4, c = idx & 15;
+                uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+                if (row < a.Nk) {
+                    const size_t grow = (size_t)bkv * a.Nk + row;
+                    kv = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * 4 + c * 16);
+                    vv = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * 4 + c * 16);
+                }
+                put(idx, kv, vv);
+            }
+        }
+        __syncthreads();
+        if constexpr (PREFETCH) {
+            if (h + (int)gridDim.z < a.H) fetch(h + gridDim.z);
+        }
+        if (!active) continue;
+
+        // ---- Q fragment (B operand of S^T = K Q^T): row i, k-slots of group g <-> d = 32 kk + 8g .. +7, split in registers ----
+        f16x8 qh[2], ql[2];
+        {
+            const char* qp = a.q + (((size_t)b * a.Nq + irow) * a.ldq + h * 64) * 4 + g * 32;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 p0, p1;
+                split_f16x8(*(const f32x4*)(qp + kk * 128), *(const f32x4*)(qp + kk * 128 + 16), p0, p1);
+                qh[kk] = __builtin_bit_cast(f16x8, p0);
+                ql[kk] = __builtin_bit_cast(f16x8, p1);
+            }
+        }
+
+        // ---- S^T = K Q^T: hi = K0 Q0, lo = K0 Q1 + K1 Q0, S = hi + 2^-11 lo ----
+        f32x4 sc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int off = (16 * t + l16) * PITCH + g * 16;
+            const f16x8 kh0 = *(const f16x8*)(K0 + off), kh1 = *(const f16x8*)(K0 + off + 64);
+            const f16x8 kl0 = *(const f16x8*)(K1 + off), kl1 = *(const f16x8*)(K1 + off + 64);
+            const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh0, qh[0], z, 0, 0, 0);
+            hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh1, qh[1], hi, 0, 0, 0);
+            f32x4 lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh0, ql[0], z, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh1, ql[1], lo, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl0, qh[0], lo, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl1, qh[1], lo, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[t][r] = fmaf(lo[r], LO, hi[r]);
+        }
+
+        // ---- softmax over keys: the parity arithmetic of attn_kernel ----
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = __fadd_rn(__fmul_rn(sc[t][r], a.scale), mk[t][r]);
+                sc[t][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = rows4_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = expf(sc[t][r] - m);
+                sc[t][r] = p;
+                sum += p;
+            }
+        sum = rows4_sum(sum);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = sc[t][r] / sum;
+                sc[t][r] = p;
+                if constexpr (SCORES) pmax[t][r] = fmaxf(pmax[t][r], p);
+            }
+        if constexpr (SCORES) {
+            if (i0 == 0 && l16 == 0) {  // CLS row of this batch element
+                float* dst = a.p0 + ((size_t)b * a.H + h) * a.Nk;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * t + 4 * g + r;
+                        if (j < a.Nk) dst[j] = sc[t][r];
+                    }
+            }
+        }
+
+        // ---- O^T = V^T P^T: hi = V0 P0, lo = V0 P1 + V1 P0 ----
+        f32x4 oh[4], ol[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { oh[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ol[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f32x4 t1 = (2 * c + 1 < NT) ? sc[2 * c + 1 < NT ? 2 * c + 1 : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            u32x4 pp0, pp1;
+            split_f16x8(sc[2 * c], t1, pp0, pp1);
+            const f16x8 ph = __builtin_bit_cast(f16x8, pp0), pl = __builtin_bit_cast(f16x8, pp1);
+            // transpose read: lane 4r + q of a 16-lane group addresses (key row r, columns 4q .. 4q+3) and receives column l16
+            const int voff = (32 * c + 4 * g + (l16 >> 2)) * PITCH + 8 * (l16 & 3);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 vh = cat_bf16x4(lds_read_tr16(V0 + voff + dt * 32), lds_read_tr16(V0 + voff + 16 * PITCH + dt * 32));
+                const bf16x8 vl = cat_bf16x4(lds_read_tr16(V1 + voff + dt * 32), lds_read_tr16(V1 + voff + 16 * PITCH + dt * 32));
+                oh[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh), ph, oh[dt], 0, 0, 0);
+                ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh), pl, ol[dt], 0, 0, 0);
+                ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vl), ph, ol[dt], 0, 0, 0);
+            }
+        }
+
+        // ---- write O: lane (i = l16, g) holds columns h*64 + 16 dt + 4g .. +3 of row i (16-byte stores), row norms ----
+        {
+            const int i = i0 + l16;
+            f32x4 o[4];
+            float n2 = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[dt][r] = fmaf(ol[dt][r], LO, oh[dt][r]);
+                    n2 += o[dt][r] * o[dt][r];
+                }
+            if constexpr (SCORES) n2 = rows4_sum(n2);
+            if (i < a.Nq) {
+                float* orow = (float*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 4) + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) *(f32x4*)(orow + dt * 16) = o[dt];
+                if constexpr (SCORES)
+                    if (g == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
+            }
+        }
+    }
+
+    if constexpr (SCORES) {
+        if (gridDim.z == 2) {  // two workgroups per row block, half of the heads each: exact head-max merge (attn_kernel)
+            const size_t slot = ((size_t)b * gridDim.x + blockIdx.x) * 4 + wave;
+            unsigned* mine = a.hm_ws + ((slot * 2 + blockIdx.z) * (2 * HM_MAX_NT)) * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __hip_atomic_store(mine + (4 * t + r) * 64, __float_as_uint(pmax[t][r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(a.hm_tick + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old == 0) return;
+            if (lane == 0) __hip_atomic_store(a.hm_tick + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned* theirs = a.hm_ws + ((slot * 2 + (1 - blockIdx.z)) * (2 * HM_MAX_NT)) * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pmax[t][r] = fmaxf(pmax[t][r], __uint_as_float(__hip_atomic_load(theirs + (4 * t + r) * 64, __ATOMIC_RELAXED,
+                                                                                      __HIP_MEMORY_SCOPE_AGENT)));
+        }
+        if (active) {
+            const int i = i0 + l16;
+            const bool valid = i >= 1 && i < a.Nq;
+            float* dst = a.colsum + ((size_t)b * a.nrt + rt) * a.Nk;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = row16_sum(valid ? pmax[t][r] : 0.f);
+                    const int j = 16 * t + 4 * g + r;
+                    if (l16 == 0 && j < a.Nk) dst[j] = v;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // bf16 fast-mode kernel: same decomposition and register layouts, but both products run on the bf16 MFMA
 // (v_mfma_f32_16x16x32_bf16, f32 accumulate); softmax and all score reductions stay f32.
 //   * K_h is DMA'd into LDS as 128-byte rows with the 16-B chunk index XOR (row&7) (swizzle on the source address),
@@ -1339,6 +1606,39 @@ int launch_attn(const AttnArgs& a_in, hipStream_t s) {
     return 0;
 }
 
+template <int NT, bool SCORES>
+int launch_attn_f16s(const AttnArgs& a_in, hipStream_t s) {
+    constexpr int PITCH = NT <= 15 ? 160 : 144;
+    const size_t lds = (size_t)(2 * NT * 16 + 2 * ((NT + 1) / 2) * 32) * PITCH;
+    MADTP_ENSURE_MAX_LDS((attn_f16s_kernel<NT, SCORES>), lds);
+    int gz = 1;
+    AttnArgs a = a_in;
+    const int wgs = ((a.Nq + 63) / 64) * a.B;
+    if (!SCORES) {
+        gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
+        if (gz > a.H) gz = a.H;
+    } else if (4 * NT <= 2 * HM_MAX_NT && wgs <= HM_MAX_WGS && a.H % 2 == 0) {
+        HmWorkspace hw;
+        if (hm_workspace(s, hw)) { gz = 2; a.hm_ws = hw.ws; a.hm_tick = hw.tick; }
+    }
+    hipLaunchKernelGGL((attn_f16s_kernel<NT, SCORES>), dim3((a.Nq + 63) / 64, a.B, gz), dim3(256), lds, s, a);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool SCORES>
+int dispatch_nt_f16s(const AttnArgs& a, hipStream_t s) {
+    const int nt = (a.Nk + 15) / 16;
+    if (nt <= 2) return launch_attn_f16s<2, SCORES>(a, s);
+    if (nt <= 4) return launch_attn_f16s<4, SCORES>(a, s);
+    if (nt <= 6) return launch_attn_f16s<6, SCORES>(a, s);
+    if (nt <= 8) return launch_attn_f16s<8, SCORES>(a, s);
+    if (nt <= 10) return launch_attn_f16s<10, SCORES>(a, s);
+    if (nt <= 13) return launch_attn_f16s<13, SCORES>(a, s);
+    if (nt <= 16) return launch_attn_f16s<16, SCORES>(a, s);
+    return MADTP_E_SHAPE;
+}
+
 template <typename T, bool SCORES>
 int dispatch_nt(const AttnArgs& a, hipStream_t s) {
     const int nt = (a.Nk + 15) / 16;
@@ -1390,7 +1690,15 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
                             int io_dtype, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
     if (kv_batch_index && colsum_part) return MADTP_E_BADARG;  // indexed K/V is a cross-attention feature
-    if (io_dtype != MADTP_F32 && io_dtype != MADTP_BF16) return MADTP_E_DTYPE;
+    // io_dtype MADTP_F16S: f32 storage, products as three f16 MFMA products of f16-split operands (the f16x3 precision mode)
+    if (io_dtype != MADTP_F32 && io_dtype != MADTP_BF16 && io_dtype != MADTP_F16S) return MADTP_E_DTYPE;
+    bool f16s = io_dtype == MADTP_F16S;
+    if (f16s) {
+        static int f16s_env = -1;  // MADTP_ATTN_F16S=0: the f16x3 mode keeps its attention on the exact-f32 MFMA kernels (A/B runs)
+        if (f16s_env < 0) { const char* e = getenv("MADTP_ATTN_F16S"); f16s_env = e ? atoi(e) : 1; }
+        f16s = f16s_env != 0;
+        io_dtype = MADTP_F32;
+    }
     if (colsum_part && (!p0 || !onorm || Nq != Nk)) return MADTP_E_BADARG;
     const int esz = io_dtype == MADTP_BF16 ? 2 : 4;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (ldq * esz) % 16 || (ldk * esz) % 16 || (ldv * esz) % 16)
@@ -1414,6 +1722,8 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
         if (large_env) return scores ? dispatch_large<bf16_t, true>(a, s) : dispatch_large<bf16_t, false>(a, s);
         return scores ? dispatch_bf16_large<true>(a, s) : dispatch_bf16_large<false>(a, s);  // fast mode: bf16 MFMA, LDS-DMA ring
     }
+    if (f16s && (ldo * 4) % 16 == 0 && aligned16(out))
+        return scores ? dispatch_nt_f16s<true>(a, s) : dispatch_nt_f16s<false>(a, s);
     if (io_dtype == MADTP_F32) return scores ? dispatch_nt<float, true>(a, s) : dispatch_nt<float, false>(a, s);
     if ((ldk * 2) % 16 || (ldv * 2) % 16) return MADTP_E_ALIGN;
     if (scores && Nk <= 32 && !mask_qk) {  // short text sequences: one sample per workgroup, heads spread over the waves

@@ -25,6 +25,8 @@ inline size_t esz_of(int dt) { return dt == MADTP_BF16 ? 2 : 4; }
 inline int pld(int dt, int ld) { return dt == MADTP_F16S ? 2 * ld : ld; }
 // dtype the attention kernels run in: the f16-split mode keeps attention on the exact-f32 kernels (q/k/v/out f32)
 inline int attn_dt(int dt) { return dt == MADTP_F16S ? MADTP_F32 : dt; }
+// io_dtype of the madtp_attention* calls: the f16x3 mode keeps f32 STORAGE (attn_dt) but asks for the f16-split products
+inline int attn_io(int dt) { return dt == MADTP_F16S ? MADTP_F16S : dt; }
 // 128-byte K slabs a GEMM with operand dtype dt walks
 inline int slabs_of(int K, int dt) { return dt == MADTP_F32 ? K / 32 : K / 64; }  // (f16-split: k-slabs; 2 staged steps each)
 
@@ -178,7 +180,7 @@ static int vit_attn_impl(const madtp_vit_block_w* w, const float* x, float* x_ou
     TRY(lin(s.h, D, w->qkv, nullptr, 0, s.qkv, 3 * D, M, dt, adt, MADTP_ACT_NONE, 1.f, stream));
     const char* q = (const char*)s.qkv;
     TRY(madtp_attention_qk_mask(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.o, nullptr, w->attn_mask, w->ld_attn_mask,
-                                prune ? s.colsum : nullptr, s.p0, s.onorm, B, w->heads, N, N, 3 * D, 3 * D, 3 * D, D, w->scale, adt,
+                                prune ? s.colsum : nullptr, s.p0, s.onorm, B, w->heads, N, N, 3 * D, 3 * D, 3 * D, D, w->scale, attn_io(dt),
                                 stream));
     if (dt == MADTP_F16S) {  // the projection GEMM takes the attention output as f16 planes (s.h is free again)
         TRY(to_lp((const float*)s.o, D, s.h, M, D, dt, stream));
@@ -333,10 +335,10 @@ static int bert_attn_impl(const madtp_bert_layer_w* w, const float* hidden, cons
     if (w->self_mask_qk)  // decoder layer (BertModel(is_decoder=True), med.py:752-768): causal [L,L] mask next to the padding mask
         TRY(madtp_attention_qk_mask(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.ctx, mask2d, w->self_mask_qk, w->ld_self_mask_qk,
                                     prune ? s.colsum : nullptr, s.p0, s.onorm, B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale,
-                                    adt, stream));
+                                    attn_io(dt), stream));
     else
         TRY(madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.ctx, mask2d, prune ? s.colsum : nullptr, s.p0, s.onorm,
-                            B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale, adt, stream));
+                            B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale, attn_io(dt), stream));
     if (dt == MADTP_F16S) {  // attention.output.dense takes the context as f16 planes (s.q is scratch of the second half)
         TRY(to_lp((const float*)s.ctx, D, s.q, M, D, dt, stream));
         s.ctx = s.q;
@@ -442,13 +444,13 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
                 // both branches in one launch ([c0|c1] side by side, ld 2D)
                 TRY(madtp_attention_pair(s.q2, (const char*)s.q2 + (size_t)D * e, kvp[0], kvp[1], kvp[0] + (size_t)D * e,
                                          kvp[1] + (size_t)D * e, kv_pre0 ? kv_index : nullptr, s.cat, (char*)s.cat + (size_t)D * e,
-                                         em0, em1, B, w->heads, Lp, Nk, 2 * D, ldkv[0], ldkv[0], 2 * D, w->scale, adt, stream));
+                                         em0, em1, B, w->heads, Lp, Nk, 2 * D, ldkv[0], ldkv[0], 2 * D, w->scale, attn_io(dt), stream));
             } else {
                 for (int br = 0; br < 2; ++br)
                     TRY(madtp_attention_indexed((const char*)s.q2 + (size_t)br * D * e, kvp[br], kvp[br] + (size_t)D * e,
                                                 (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, (char*)s.cat + (size_t)br * D * e,
                                                 br ? em1 : em0, nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, 2 * D, ldkv[br],
-                                                ldkv[br], 2 * D, w->scale, adt, stream));
+                                                ldkv[br], 2 * D, w->scale, attn_io(dt), stream));
             }
             const void* catc = s.cat;
             if (dt == MADTP_F16S) {  // [c0|c1] f32 -> f16 planes for the fused output GEMM (s.mid is free until the FFN)
@@ -474,7 +476,7 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
             }
             const int ldkv = ((br ? kv_pre1 : kv_pre0) && kv_ld) ? kv_ld : 2 * D;
             TRY(madtp_attention_indexed(s.q, kv, kv + (size_t)D * e, (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, cbuf[br], em,
-                                        nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, D, ldkv, ldkv, D, w->scale, adt, stream));
+                                        nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, D, ldkv, ldkv, D, w->scale, attn_io(dt), stream));
             if (dt == MADTP_F16S) {  // context f32 -> f16 planes for crossattention.output.dense, in s.mid (free until the FFN;
                                      // hidden >= 2*dim, so both branches fit side by side)
                 if (w->inter.n < 2 * D) return MADTP_E_SHAPE;

@@ -19,8 +19,14 @@ def build_nlvr(image_size=224, seed=0, device="cuda"):
 
 
 def padded_mask(B, L, pad_tail=0):
-    """attention_mask [B,L] of ones with a zero tail of b % (pad_tail+1) tokens in sample b (padded captions)."""
+    """attention_mask [B,L] of ones with a zero tail of b % (pad_tail+1) tokens in sample b (padded captions); pad_tail may also
+    be a list of per-sample tail lengths (ragged captions: a short one next to a full-length one)."""
     att = torch.ones(B, L, dtype=torch.long)
+    if isinstance(pad_tail, (list, tuple)):
+        for b, n in enumerate(pad_tail):
+            if n:
+                att[b, L - int(n):] = 0
+        return att
     if pad_tail:
         for b in range(B):
             att[b, L - (b % (pad_tail + 1)):] = 0

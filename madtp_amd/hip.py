@@ -304,9 +304,10 @@ def bert_embed(ids, word_emb, pos_emb, gamma, beta, eps, want_bf16=False, lp=Non
     return y32, ylp
 
 
-def attention(q, k, v, B, H, Nq, Nk, scale, add_mask=None, scores=False, mask_qk=None):
+def attention(q, k, v, B, H, Nq, Nk, scale, add_mask=None, scores=False, mask_qk=None, split=False):
     """q,k,v: 2-D row views [B*N, >=H*64] (may be column slices of one fused projection).  Returns
-    (out[B*Nq, H*64], (colsum_part, p0, onorm) or None).  mask_qk: optional additive f32 [>=Nq, >=Nk] mask (causal)."""
+    (out[B*Nq, H*64], (colsum_part, p0, onorm) or None).  mask_qk: optional additive f32 [>=Nq, >=Nk] mask (causal).
+    split (f32 operands only): the products as three f16 MFMA products of f16-split operands (precision mode "f16x3")."""
     for t in (q, k, v):
         if not t.is_cuda or t.stride(1) != 1:
             raise RuntimeError("attention operands must be GPU row-major views")
@@ -321,14 +322,15 @@ def attention(q, k, v, B, H, Nq, Nk, scale, add_mask=None, scores=False, mask_qk
         side = (cs, p0, on)
     if add_mask is not None:
         _req(add_mask, torch.float32, "add_mask")
+    io = F16S if (split and q.dtype == torch.float32) else _dt(q)
     if mask_qk is not None:
         _req(mask_qk, torch.float32, "mask_qk")
         _check(load().madtp_attention_qk_mask(_p(q), _p(k), _p(v), _p(out), _p(add_mask), _p(mask_qk), mask_qk.stride(0), _p(cs),
                                               _p(p0), _p(on), B, H, Nq, Nk, q.stride(0), k.stride(0), v.stride(0), out.stride(0),
-                                              float(scale), _dt(q), _stream()), "madtp_attention_qk_mask")
+                                              float(scale), io, _stream()), "madtp_attention_qk_mask")
         return out, side
     _check(load().madtp_attention(_p(q), _p(k), _p(v), _p(out), _p(add_mask), _p(cs), _p(p0), _p(on), B, H, Nq, Nk,
-                                  q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), _dt(q), _stream()),
+                                  q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), io, _stream()),
            "madtp_attention")
     return out, side
 

@@ -110,7 +110,7 @@ class Attention(nn.Module):
         C = self.dim
         y = hip.gemm(h2d, qkv.w, qkv.b, n=qkv.n, out_dtype=attn_dtype())  # [B*N, 3C]: q | k | v, head-major (vit.py:77)
         o, side = hip.attention(y[:, :C], y[:, C:2 * C], y[:, 2 * C:], B, self.num_heads, N, N, self.scale,
-                                scores=want_scores)
+                                scores=want_scores, split=compute_dtype() == torch.float16)
         self.score_side = side
         if o.dtype != compute_dtype():  # f16x3: the f32 context enters the projection as f16 planes
             o = to_compute(o)

@@ -126,7 +126,10 @@ def test_reference_blip_glue_constructs_on_the_mirrors(which):
         if {which!r} == "blip_retrieval":
             model = ref_mod.blip_retrieval(pretrained='', image_size=224, vit='base', evaluate=True, config={{"sd_dim": 768, "sd_num": 100}}, queue_size=16)
         else:
-            model = ref_mod.blip_vqa(pretrained='', image_size=480, vit='base', evaluate=True, config={{"sd_dim": 768, "sd_num": 100}})
+            model = ref_mod.blip_vqa(pretrained='', image_size=480, vit='base', evaluate=True,
+                                     config={{"sd_dim": 768, "sd_num": 100, "batch_size_train": 16}})
+            import madtp_amd.bert as mb
+            assert isinstance(model.text_decoder, mb.BertLMHeadModel)   # the teacher-forced decoder mirror (rank_answer)
         assert type(model).__module__ == 'models.{which}'
         assert isinstance(model.visual_encoder, madtp_amd.vit.VisionTransformer)
         assert isinstance(model.text_encoder, madtp_amd.bert.MedBertModel)

@@ -781,3 +781,44 @@ def test_lm_loss_and_token_prob(hip, B, L, V, ld):
     p = hip.token_prob(rows, tok.cuda(), V).cpu()
     refp = torch.softmax(buf[:, 0, :V].double(), 1).index_select(1, tok).float()
     assert (p - refp).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 20, 12), (1, 65, 2), (2, 130, 12), (2, 82, 12), (1, 256, 3), (2, 17, 1),
+                                   (16, 96, 12), (24, 96, 12), (4, 241, 3)])
+def test_attention_f16_split_products(hip, B, N, H):
+    """attn_f16s_kernel (io_dtype MADTP_F16S: f32 storage, QK^T and P.V as three f16 MFMA products of f16-split operands - the
+    f16x3 precision mode) against a float64 reference: its error stays within 3x the exact-f32 MFMA kernel's on the same
+    inputs (the rounding class of an f32 dot product - the criterion of test_gemm_f16x3), for the context and every score
+    side output, with and without a padding mask, incl. the head-split launches (<= 384 row blocks) and a [N,N] causal mask."""
+    qkv = _rand(B * N, 3 * H * 64, seed=20)
+    mask = (torch.rand(B, N, generator=torch.Generator().manual_seed(3)) > 0.8).float() * -10000.0
+    mask[:, 0] = 0
+    causal = torch.where(torch.arange(N)[None, :] <= torch.arange(N)[:, None], 0.0, -10000.0).contiguous()
+    qd = qkv.cuda()
+    q, k, v = qd[:, : H * 64], qd[:, H * 64: 2 * H * 64], qd[:, 2 * H * 64:]
+    for m, mqk in ((None, None), (mask, None), (None, causal)):
+        kw = dict(add_mask=None if m is None else m.cuda(), scores=True, mask_qk=None if mqk is None else mqk.cuda())
+        ex_o, (ex_cs, ex_p0, ex_on) = hip.attention(q, k, v, B, H, N, N, 0.125, **kw)
+        sp_o, (sp_cs, sp_p0, sp_on) = hip.attention(q, k, v, B, H, N, N, 0.125, split=True, **kw)
+        if mqk is None:
+            ro, rp, rcol, rp0, rn = _ref_attention(qkv.double(), B, N, H, 0.125, m)
+        else:
+            ro, rp, rcol, rp0, rn = _ref_attention_causal(qkv.double(), B, N, H, 0.125, causal)
+        for name, ex, sp, ref in (("out", ex_o, sp_o, ro), ("colsum", ex_cs.sum(1), sp_cs.sum(1), rcol), ("p0", ex_p0, sp_p0, rp0),
+                                  ("onorm", ex_on, sp_on, rn)):
+            e_ex = (ex.double().cpu() - ref).abs().max().item()
+            e_sp = (sp.double().cpu() - ref).abs().max().item()
+            assert e_sp <= 3.0 * e_ex + 2e-7 * max(1.0, ref.abs().max().item()), (name, e_sp, e_ex)
+    # the split kernel is deterministic
+    again, _ = hip.attention(q, k, v, B, H, N, N, 0.125, split=True, scores=True)
+    first, _ = hip.attention(q, k, v, B, H, N, N, 0.125, split=True, scores=True)
+    assert torch.equal(again, first)
+
+
+def _ref_attention_causal(qkv, B, N, H, scale, causal):
+    q, k, v = qkv.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * scale + causal.double()[None, None]
+    p = s.softmax(-1)
+    o = p @ v
+    colsum = p[:, :, 1:, :].max(1)[0].sum(1)
+    return o.transpose(1, 2).reshape(B * N, H * 64), p, colsum, p[:, :, 0, :], o.norm(dim=-1)

@@ -343,3 +343,62 @@ def test_oracle_vqa_rank_answer_matches_reference_fixture(path):
     assert det["topk_ids"].tolist() == g["topk_ids"].tolist()
     assert np.abs(det["log_probs_sum"].numpy() - g["log_probs_sum"]).max() < 1e-3
     assert max_ids.tolist() == g["max_ids"].tolist()
+
+
+NLVR_PAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "nlvrpad_*.npz")))
+
+
+def nlvr_pad_layers(g):
+    """Text layers of a ragged-caption fixture at which some sample's top-(k+1) (nlvr_encoder.py:452: indices_sort[:, :k+1])
+    contains a PADDED position - from the recorded `indices_sort` / lengths alone, following the mask compaction rule."""
+    from madtp_amd import harness
+    B, L = int(g["B"]), int(g["L"])
+    mask = harness.padded_mask(B, L, g["pad_list"].tolist()).numpy()
+    layers = []
+    for l in range(12):
+        if f"txt{l}_sort" not in g.files:
+            continue
+        k = int(g["txt_lens"][l]) - 2
+        srt = g[f"txt{l}_sort"][:, :k + 1]
+        picked = np.take_along_axis(mask[:, 1:], srt, axis=1)
+        if (picked == 0).any():
+            layers.append(l)
+        mask = np.concatenate([mask[:, :1], picked], axis=1)
+    return layers
+
+
+@pytest.mark.parametrize("path", NLVR_PAD_CASES, ids=[os.path.basename(c)[:-4] for c in NLVR_PAD_CASES])
+def test_oracle_nlvr_pad_inside_topk_fixture(path):
+    """nlvr_encoder.py:440-452 with ragged captions: k = max_b count comes from the long caption, the short ones keep PADDED
+    tokens inside their top-(k+1), and the reference pairs tokens in topk(sorted=False) order with mask entries in SORTED order.
+    The oracle in text_order="reference" reproduces the recording (same torch build: kept sets of every layer, logits); in
+    text_order="ascending" - the HIP path's canonical pairing - the kept SETS still agree up to and including the first layer
+    with a pad inside the top-(k+1) (the pairing only acts on the layers after it)."""
+    from madtp_amd import harness
+    g = np.load(path)
+    B, size, L, T, seed = int(g["B"]), int(g["size"]), int(g["L"]), float(g["temperature"]), int(g["seed"])
+    W = specs.synth_weights(specs.blip_nlvr_shapes(size), seed)
+    images, ids = synth.synth_images(2 * B, size, seed), synth.synth_token_ids(B, L, seed)
+    att = harness.padded_mask(B, L, g["pad_list"].tolist())
+    pad_layers = nlvr_pad_layers(g)
+    assert pad_layers, "the fixture must exercise the pad-inside-top-(k+1) case"
+    first = pad_layers[0]
+    tr_ref, tr_asc = {}, {}
+    with torch.no_grad():
+        logits = O.blip_nlvr_forward(W, images, ids, att, T, trace=tr_ref, text_order="reference")
+        logits_asc = O.blip_nlvr_forward(W, images, ids, att, T, trace=tr_asc, text_order="ascending")
+    assert np.abs(logits.numpy() - g["logits"]).max() < 1e-5
+    for l, info in enumerate(tr_ref["text"]):
+        if f"txt{l}_idx" not in g.files:
+            assert not info["pruned"]
+            continue
+        assert info["pruned"] and info["k"] + 2 == g["txt_lens"][l]
+        assert (info["indices"].numpy() == g[f"txt{l}_idx"]).all()       # this build's topk(sorted=False) order
+        assert (info["indices_sort"].numpy() == g[f"txt{l}_sort"]).all()
+    ref_sets, asc_sets = harness.compose_ids(tr_ref["text"], L - 1), harness.compose_ids(tr_asc["text"], L - 1)
+    for l in range(first + 1):
+        assert asc_sets[l] == ref_sets[l], l
+    differ = [l for l in range(12) if asc_sets[l] != ref_sets[l]]
+    print(f"pads inside top-(k+1) at text layers {pad_layers}; ascending-order pairing differs from this build's at layers "
+          f"{differ}; |dlogit| {np.abs(logits_asc.numpy() - logits.numpy()).max():.4f}")
+    assert all(l > first for l in differ)

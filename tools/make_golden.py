@@ -58,7 +58,7 @@ class GatherTap:
         self.module.vector_gather = self.orig
 
 
-def nlvr_case(name, B, size, L, temperature, seed=0, pad_tail=0):
+def nlvr_case(name, B, size, L, temperature, seed=0, pad_tail=0, pad_list=None):
     import models.blip_nlvr as bn
     import models.vit as rvit
     import models.nlvr_encoder as rnl
@@ -70,7 +70,7 @@ def nlvr_case(name, B, size, L, temperature, seed=0, pad_tail=0):
     images = synth.synth_images(2 * B, size, seed)
     ids = synth.synth_token_ids(B, L, seed, first_id=None)
     from madtp_amd import harness
-    text = {"input_ids": ids, "attention_mask": harness.padded_mask(B, L, pad_tail)}
+    text = {"input_ids": ids, "attention_mask": harness.padded_mask(B, L, pad_list if pad_list is not None else pad_tail)}
     tap_v, tap_t = GatherTap(rvit), GatherTap(rnl)
     hooks = []
     lens_v, lens_t = [], []
@@ -94,6 +94,8 @@ def nlvr_case(name, B, size, L, temperature, seed=0, pad_tail=0):
            "logits": logits.numpy(), "vit_lens": np.array(lens_v), "txt_lens": np.array(lens_t),
            "img_embeds_cls": feats["img"][:, 0, :16].numpy(), "img_embeds_absmean": feats["img"].abs().mean().numpy(),
            "state_dict_keys": np.array(sorted(sd.keys())), "ref_seconds": dt, "threads": torch.get_num_threads()}
+    if pad_list is not None:
+        out["pad_list"] = np.array(pad_list)
     out.update(tap_v.records)
     out.update(tap_t.records)
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
@@ -393,6 +395,9 @@ CASES = {
     "nlvr_b2_T1": lambda: nlvr_case("nlvr_b2_T1", 2, 224, 20, 1.0),
     "nlvr_b2_T5": lambda: nlvr_case("nlvr_b2_T5", 2, 224, 20, 5.0),
     "nlvr_b3_T30_pad": lambda: nlvr_case("nlvr_b3_T30_pad", 3, 224, 35, 30.0, pad_tail=3),
+    # ragged captions (0 / 14 / 26 padded positions of 35): k = max_b count is set by the long caption, so the short ones keep
+    # PADDED tokens inside their top-(k+1) - the token / mask pairing of nlvr_encoder.py:440-452 is exercised
+    "nlvrpad_b3_T12": lambda: nlvr_case("nlvrpad_b3_T12", 3, 224, 35, 12.0, seed=0, pad_list=[0, 14, 26]),
     "med_text_b3": lambda: med_case("med_text_b3", 3, 35, 0, 30.0, "text", pad_tail=3),
     "med_mm_b3": lambda: med_case("med_mm_b3", 3, 35, 50, 30.0, "multimodal", pad_tail=3),
     "vqa480_b2": lambda: vqa_case("vqa480_b2", 2, 480, 20, 6.0, pad_tail=2),
