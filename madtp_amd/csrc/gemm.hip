@@ -1327,6 +1327,21 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
                        int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float acc_scale, float out_scale,
                        int splitk, void* stream, const GemmPair* pair = nullptr);
 
+// Workgroups per XCD of the two big-GEMM kernels (default 32 = one persistent workgroup per CU walking its share of the tiles).
+// A larger cap gives every workgroup fewer tiles (>= tiles / 8: one tile each) - the launch then frees CUs tile by tile, which
+// lets the small kernels of ANOTHER stream in between (madtp_amd/pipeline.py) at the price of the cross-tile pipelining.
+static std::atomic<int> g_wg_per_xcd{-1};
+static int gemm_wg_per_xcd() {
+    int v = g_wg_per_xcd.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("MADTP_GEMM_WG_PER_XCD");
+        v = e ? atoi(e) : 32;
+        if (v < 1) v = 32;
+        g_wg_per_xcd.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 // forced tile configuration (madtp_gemm_set_config / MADTP_GEMM_CFG): A/B measurements and the per-kernel tests
 static std::atomic<int> g_force_cfg{-1};
 static int gemm_force_cfg() {
@@ -1544,7 +1559,8 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
             g.ngrp = (grp_env > 0 && grp_env < g.ntn) ? grp_env : 0;
         }
         const int slots_max = (g.ntm * g.ntn + 7) / 8;
-        const int grid = 8 * (slots_max < 32 ? slots_max : 32);
+        const int cap = gemm_wg_per_xcd();
+        const int grid = 8 * (slots_max < cap ? slots_max : cap);
         const size_t lds = (size_t)2 * (256 + 256) * ROWB;
         if (c_dtype == MADTP_BF16) {
             MADTP_ENSURE_MAX_LDS((gemm_sq_kernel<OM_BF16>), lds);
@@ -1567,7 +1583,8 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
             g.ngrp = (on && G < g.ntn) ? G : 0;
         }
         const int slots_max = (g.ntm * g.ntn * (g.pair ? 2 : 1) + 7) / 8;
-        const int grid = 8 * (slots_max < 32 ? slots_max : 32);
+        const int cap = gemm_wg_per_xcd();
+        const int grid = 8 * (slots_max < cap ? slots_max : cap);
         if (sk_on && grid == 256) { g.sk = 1; g.sk_ws = skw.ws; g.sk_tick = skw.tick; }
         const size_t lds = (size_t)3 * (256 + 128) * ROWB;
 #define MADTP_LAUNCH_WS(X3_, OM_, M32_)                                                          \

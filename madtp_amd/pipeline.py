@@ -32,7 +32,12 @@ class InflightRunner:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.models = list(models) if models is not None else [workload.build(self.device) for _ in range(self.n)]
         self.inputs = [workload.inputs(batch, seed=seed0 + i) for i in range(self.n)]
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
+        import os
+        # stream priorities: worker 0 high, the others normal (MADTP_INFLIGHT_PRIO="p0,p1,..." overrides).  Measured at the headline
+        # (profiles/r03_inflight.txt (e)): equal priorities 20.9-22.2 k images/s, (high, normal) 22.7-22.8 k on the same box - with
+        # one stream preferred the two forwards settle into a stable interleave instead of contending kernel by kernel
+        prio = [int(x) for x in os.environ.get("MADTP_INFLIGHT_PRIO", "-1").split(",") if x.strip()]
+        self.streams = [torch.cuda.Stream(device=self.device, priority=(prio[i] if i < len(prio) else 0)) for i in range(self.n)]
         self.errors = []
         self.last = [None] * self.n  # output of each worker's most recent step
 
