@@ -1216,6 +1216,242 @@ __global__ __launch_bounds__(256, 1) void attn_large_kernel(AttnArgs a) {
     }
 }
 
+// f16-split flavour of attn_large_kernel for the f16x3 precision mode (see attn_f16s_kernel): the same two passes and the same
+// softmax arithmetic, S^T = K Q^T and O^T = V^T P^T as three f16 MFMA products of f16-split operands.  A 128-key chunk is staged
+// as two f16 planes per operand (160-byte rows, 80 KiB for K and V); all eight 16-byte pieces of a thread are loaded before the
+// first is split and stored, so their latencies overlap.
+template <int NCH, bool SCORES>
+__global__ __launch_bounds__(256, 1) void attn_large_f16s_kernel(AttnArgs a) {  // (two per CU would fit the LDS, not the head-max registers)
+    constexpr int PITCH = 160;
+    constexpr int CK = 128;
+    constexpr int NT = NCH * 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* K0 = smem;
+    char* K1 = K0 + CK * PITCH;
+    char* V0 = K1 + CK * PITCH;
+    char* V1 = V0 + CK * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int bkv = a.kvidx ? a.kvidx[b] : b;
+    const int rt = blockIdx.x * 4 + wave;
+    const int i0 = rt * 16;
+    const bool active = i0 < a.Nq;
+    const int irow = min(i0 + l16, a.Nq - 1);
+    constexpr float LO = 1.0f / F16S_LO_SCALE;
+
+    f32x4 pmax[SCORES ? NT : 1];
+    if constexpr (SCORES) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pmax[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    auto stage = [&](int h, int c, bool with_v) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // four pieces per operand in flight at a time (register budget)
+            uint4 kr[4], vr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * (4 * half + i), row = idx >> 4, ch = idx & 15, j = c * CK + row;
+                kr[i] = make_uint4(0, 0, 0, 0);
+                vr[i] = make_uint4(0, 0, 0, 0);
+                if (j < a.Nk) {
+                    const size_t grow = (size_t)bkv * a.Nk + j;
+                    kr[i] = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * 4 + ch * 16);
+                    if (with_v) vr[i] = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * 4 + ch * 16);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * (4 * half + i), row = idx >> 4, ch = idx & 15;
+                f16x4 h4, l4;
+                split_f16x4(__builtin_bit_cast(f32x4, kr[i]), h4, l4);
+                *(f16x4*)(K0 + row * PITCH + ch * 8) = h4;
+                *(f16x4*)(K1 + row * PITCH + ch * 8) = l4;
+                if (with_v) {
+                    split_f16x4(__builtin_bit_cast(f32x4, vr[i]), h4, l4);
+                    *(f16x4*)(V0 + row * PITCH + ch * 8) = h4;
+                    *(f16x4*)(V1 + row * PITCH + ch * 8) = l4;
+                }
+            }
+        }
+    };
+    // S^T for the 8 tiles of one chunk (scale and mask applied as in attn_large_kernel, keys beyond Nk -> -inf)
+    auto scores = [&](int c, const f16x8 (&qh)[2], const f16x8 (&ql)[2], f32x4 (&sc)[8]) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int off = (16 * t + l16) * PITCH + g * 16;
+            const f16x8 kh0 = *(const f16x8*)(K0 + off), kh1 = *(const f16x8*)(K0 + off + 64);
+            const f16x8 kl0 = *(const f16x8*)(K1 + off), kl1 = *(const f16x8*)(K1 + off + 64);
+            const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh0, qh[0], z, 0, 0, 0);
+            hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh1, qh[1], hi, 0, 0, 0);
+            f32x4 lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh0, ql[0], z, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh1, ql[1], lo, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl0, qh[0], lo, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl1, qh[1], lo, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = c * CK + 16 * t + 4 * g + r;
+                float v = fmaf(lo[r], LO, hi[r]) * a.scale;
+                if (a.mask && j < a.Nk) v += a.mask[(size_t)b * a.Nk + j];
+                sc[t][r] = j < a.Nk ? v : -INFINITY;
+            }
+        }
+    };
+
+    for (int h = blockIdx.z; h < a.H; h += gridDim.z) {
+        f16x8 qh[2], ql[2];
+        {
+            const char* qp = a.q + (((size_t)b * a.Nq + irow) * a.ldq + h * 64) * 4 + g * 32;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 p0, p1;
+                split_f16x8(*(const f32x4*)(qp + kk * 128), *(const f32x4*)(qp + kk * 128 + 16), p0, p1);
+                qh[kk] = __builtin_bit_cast(f16x8, p0);
+                ql[kk] = __builtin_bit_cast(f16x8, p1);
+            }
+        }
+        // ---- pass A: row statistics ----
+        float m = -INFINITY, l = 0.f;
+        for (int c = 0; c < NCH; ++c) {
+            if (c * CK >= a.Nk) break;
+            __syncthreads();
+            stage(h, c, false);
+            __syncthreads();
+            if (!active) continue;
+            f32x4 sc[8];
+            scores(c, qh, ql, sc);
+            float cm = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cm = fmaxf(cm, sc[t][r]);
+            cm = rows4_max(cm);
+            const float mn = fmaxf(m, cm);
+            float cs = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs += expf(sc[t][r] - mn);
+            cs = rows4_sum(cs);
+            l = l * expf(m - mn) + cs;
+            m = mn;
+        }
+        // ---- pass B: probabilities, head-max, O^T = V^T P^T ----
+        f32x4 oh[4], ol[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { oh[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ol[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c * CK < a.Nk) {  // block-uniform
+                __syncthreads();
+                stage(h, c, true);
+                __syncthreads();
+                if (active) {
+                    f32x4 sc[8];
+                    scores(c, qh, ql, sc);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = expf(sc[t][r] - m) / l;
+                            sc[t][r] = p;
+                            if constexpr (SCORES) pmax[c * 8 + t][r] = fmaxf(pmax[c * 8 + t][r], p);
+                        }
+                    }
+                    if constexpr (SCORES) {
+                        if (i0 == 0 && l16 == 0) {
+                            float* dst = a.p0 + ((size_t)b * a.H + h) * a.Nk;
+#pragma unroll
+                            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int j = c * CK + 16 * t + 4 * g + r;
+                                    if (j < a.Nk) dst[j] = sc[t][r];
+                                }
+                        }
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {  // 32-key sub-chunks of the staged chunk
+                        u32x4 pp0, pp1;
+                        split_f16x8(sc[2 * cc], sc[2 * cc + 1], pp0, pp1);
+                        const f16x8 ph = __builtin_bit_cast(f16x8, pp0), pl = __builtin_bit_cast(f16x8, pp1);
+                        const int voff = (32 * cc + 4 * g + (l16 >> 2)) * PITCH + 8 * (l16 & 3);
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            const bf16x8 vh = cat_bf16x4(lds_read_tr16(V0 + voff + dt * 32), lds_read_tr16(V0 + voff + 16 * PITCH + dt * 32));
+                            const bf16x8 vl = cat_bf16x4(lds_read_tr16(V1 + voff + dt * 32), lds_read_tr16(V1 + voff + 16 * PITCH + dt * 32));
+                            oh[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh), ph, oh[dt], 0, 0, 0);
+                            ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vh), pl, ol[dt], 0, 0, 0);
+                            ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vl), ph, ol[dt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        if (active) {
+            const int i = i0 + l16;
+            f32x4 o[4];
+            float n2 = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[dt][r] = fmaf(ol[dt][r], LO, oh[dt][r]);
+                    n2 += o[dt][r] * o[dt][r];
+                }
+            if constexpr (SCORES) n2 = rows4_sum(n2);
+            if (i < a.Nq) {
+                float* orow = (float*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 4) + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) *(f32x4*)(orow + dt * 16) = o[dt];
+                if constexpr (SCORES)
+                    if (g == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
+            }
+        }
+    }
+    if constexpr (SCORES) {
+        if (active) {
+            const int i = i0 + l16;
+            const bool valid = i >= 1 && i < a.Nq;
+            float* dst = a.colsum + ((size_t)b * a.nrt + rt) * a.Nk;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = row16_sum(valid ? pmax[t][r] : 0.f);
+                    const int j = 16 * t + 4 * g + r;
+                    if (l16 == 0 && j < a.Nk) dst[j] = v;
+                }
+        }
+    }
+}
+
+template <int NCH, bool SCORES>
+int launch_attn_large_f16s(const AttnArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)4 * 128 * 160;
+    MADTP_ENSURE_MAX_LDS((attn_large_f16s_kernel<NCH, SCORES>), lds);
+    int gz = 1;
+    if (!SCORES) {
+        const int wgs = ((a.Nq + 63) / 64) * a.B;
+        gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
+        if (gz > a.H) gz = a.H;
+    }
+    hipLaunchKernelGGL((attn_large_f16s_kernel<NCH, SCORES>), dim3((a.Nq + 63) / 64, a.B, gz), dim3(256), lds, s, a);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool SCORES>
+int dispatch_large_f16s(const AttnArgs& a, hipStream_t s) {
+    const int nch = (a.Nk + 127) / 128;
+    if (nch <= 5) return launch_attn_large_f16s<5, SCORES>(a, s);
+    if (nch <= 8) return launch_attn_large_f16s<8, SCORES>(a, s);
+    return MADTP_E_SHAPE;
+}
+
 template <typename T, int NCH, bool SCORES>
 int launch_attn_large(const AttnArgs& a, hipStream_t s) {
     constexpr int RB = 64 * (int)sizeof(T) + 16;
@@ -1716,6 +1952,8 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
     hipStream_t s = (hipStream_t)stream;
     const bool scores = colsum_part != nullptr;
     if (Nk > 256) {  // long sequences (384^2 / 480^2 images): two-pass kernels
+        if (f16s && (ldo * 4) % 16 == 0 && aligned16(out))
+            return scores ? dispatch_large_f16s<true>(a, s) : dispatch_large_f16s<false>(a, s);
         if (io_dtype == MADTP_F32) return scores ? dispatch_large<float, true>(a, s) : dispatch_large<float, false>(a, s);
         static int large_env = -1;  // MADTP_ATTN_LARGE_F32=1: bf16 storage on the exact-f32 MFMA kernel (A/B runs)
         if (large_env < 0) { const char* e = getenv("MADTP_ATTN_LARGE_F32"); large_env = e ? atoi(e) : 0; }

@@ -784,9 +784,10 @@ def test_lm_loss_and_token_prob(hip, B, L, V, ld):
 
 
 @pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 20, 12), (1, 65, 2), (2, 130, 12), (2, 82, 12), (1, 256, 3), (2, 17, 1),
-                                   (16, 96, 12), (24, 96, 12), (4, 241, 3)])
+                                   (16, 96, 12), (24, 96, 12), (4, 241, 3),
+                                   (1, 577, 12), (2, 901, 3), (1, 257, 2), (1, 1024, 1)])   # attn_large_f16s_kernel
 def test_attention_f16_split_products(hip, B, N, H):
-    """attn_f16s_kernel (io_dtype MADTP_F16S: f32 storage, QK^T and P.V as three f16 MFMA products of f16-split operands - the
+    """attn_f16s_kernel / attn_large_f16s_kernel (io_dtype MADTP_F16S: f32 storage, QK^T and P.V as three f16 MFMA products of f16-split operands - the
     f16x3 precision mode) against a float64 reference: its error stays within 3x the exact-f32 MFMA kernel's on the same
     inputs (the rounding class of an f32 dot product - the criterion of test_gemm_f16x3), for the context and every score
     side output, with and without a padding mask, incl. the head-split launches (<= 384 row blocks) and a [N,N] causal mask."""
@@ -797,6 +798,8 @@ def test_attention_f16_split_products(hip, B, N, H):
     qd = qkv.cuda()
     q, k, v = qd[:, : H * 64], qd[:, H * 64: 2 * H * 64], qd[:, 2 * H * 64:]
     for m, mqk in ((None, None), (mask, None), (None, causal)):
+        if mqk is not None and N > 256:
+            continue  # the [N,N] mask operand belongs to the <= 256-key kernels
         kw = dict(add_mask=None if m is None else m.cuda(), scores=True, mask_qk=None if mqk is None else mqk.cuda())
         ex_o, (ex_cs, ex_p0, ex_on) = hip.attention(q, k, v, B, H, N, N, 0.125, **kw)
         sp_o, (sp_cs, sp_p0, sp_on) = hip.attention(q, k, v, B, H, N, N, 0.125, split=True, **kw)

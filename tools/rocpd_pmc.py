@@ -9,8 +9,12 @@ import sys
 
 def per_kernel(db, counter):
     c = sqlite3.connect(db)
-    rows = c.execute("select name, count(*), sum(counter_value), sum(duration) from pmc_events where counter_name=? "
-                     "group by name", (counter,)).fetchall()
+    # (dispatches in front of the first forward - model construction, the on-device weight generator - are left out)
+    cols = [r[1] for r in c.execute("pragma table_info(pmc_events)").fetchall()]
+    key = "start" if "start" in cols else "dispatch_id"
+    t0 = c.execute(f"select min({key}) from pmc_events where name like '%patchify%'").fetchone()[0] or 0
+    rows = c.execute(f"select name, count(*), sum(counter_value), sum(duration) from pmc_events where counter_name=? and {key} >= ? "
+                     "group by name", (counter, t0)).fetchall()
     return {r[0]: (r[1], r[2], r[3]) for r in rows}
 
 

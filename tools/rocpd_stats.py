@@ -6,8 +6,11 @@ import sys
 
 db = sys.argv[1]
 c = sqlite3.connect(db)
+# kernels in front of the first forward (patchify_kernel opens one) are model construction - e.g. the ~10 k integer launches of the
+# on-device synthetic weight generator - and are left out
+t0 = c.execute("select min(start) from kernels where name like '%patchify%'").fetchone()[0] or 0
 rows = c.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 "
-                 "from kernels group by name order by 3 desc").fetchall()
+                 "from kernels where start >= ? group by name order by 3 desc", (t0,)).fetchall()
 tot = sum(r[2] for r in rows)
 for h in sys.argv[2:]:
     print("# " + h)
