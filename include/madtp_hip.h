@@ -225,6 +225,11 @@ typedef struct madtp_att_ft_seg {
 } madtp_att_ft_seg;
 int madtp_query_att_ft_multi(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float* stats_ws, float inv_sqrt_sd,
                              int accumulate, int B, int dim, void* stream);  /* stats_ws: nseg*B*256 floats of scratch */
+/* The same sum in the "f16x3" precision mode: token rows and softmax weights (expf, true division) as f16-split planes, three
+ * f16 MFMA products per tile (the rounding class of the exact-f32 kernel; att_ft only feeds the training loss, vit.py:300-303,
+ * no pruning decision depends on it).  stats_ws (nseg*B*256 floats) is required. */
+int madtp_query_att_ft_multi_split(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float* stats_ws, float inv_sqrt_sd,
+                                   int accumulate, int B, int dim, void* stream);
 
 /* Alignment logits out[M,128] = x[M,dim] @ sd^T with the dictionary given as two [128,dim] 2-byte planes (rows beyond the
  * dictionary size zero) and x split in registers.  models/utils.py:170.

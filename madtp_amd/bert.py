@@ -614,7 +614,7 @@ class _BertEncoderBase(nn.Module):
                     n_in = run.n_in(l)
                     xp = hidden.data_ptr() if l == 0 else run.ptr(l - 1, "y")
                     segs.append((run.ptr(l, "logits") + 128 * 4, xp + D * 4, n_in - 1, 128, n_in * 128, D, n_in * D))
-                sd_txt_ft_all = hip.query_att_ft_multi_ptrs(segs, B, K, D, hidden.device, sd_dim=qm.att_dim, exact=deferred == "exact")
+                sd_txt_ft_all = hip.query_att_ft_multi_ptrs(segs, B, K, D, hidden.device, sd_dim=qm.att_dim, exact={"exact": True, "split": "split"}.get(deferred, False))
             else:
                 sd_txt_ft_all = qargs["att_ft"]
         self._last_run = run

@@ -768,7 +768,7 @@ __global__ __launch_bounds__(256) void query_att_ft_kernel(const float* __restri
 // read-modified-written (B*K*dim f32 = 39 MB at B=128) after every layer.
 // Two kernels: att_ft_stats_kernel (grid nseg x B) computes the softmax statistics of every (segment, sample) - the
 // maximum and 1/sum over tokens of each dictionary column, two passes with four independent float4 loads in flight per
-// thread; query_att_ft_bf16_kernel then streams ALL 32-token chunks of the sample's segments as one sequence: the next
+// thread; query_att_ft_mma_kernel then streams ALL 32-token chunks of the sample's segments as one sequence: the next
 // chunk's logits and token rows are fetched into registers while the current one is multiplied, converted (softmax weight /
 // bf16) into one of two LDS buffers, one barrier per chunk.
 // Workgroup = one sample x 128 output columns (wave w: columns [32w, 32w+32), 2 MFMA column tiles): 6 x B workgroups of
@@ -886,6 +886,8 @@ __global__ __launch_bounds__(256) void query_att_ft_exact_multi_kernel(AttFtSegs
 }
 
 // stats[(seg*B + b)*256 + c] = max_t logit*inv, [.. + 128 + c] = 1 / sum_t exp(logit*inv - max)  (0 for c >= K)
+// EXACT (the f16-split att_ft of the f16x3 mode): expf, and the SUM itself is stored (the weights are then true quotients)
+template <bool EXACT>
 __global__ __launch_bounds__(256) void att_ft_stats_kernel(AttFtSegs segs, int K, float inv_sqrt_sd, float* __restrict__ stats) {
     __shared__ __attribute__((aligned(16))) float part[AB_SL][128];
     __shared__ __attribute__((aligned(16))) float mx[128];
@@ -926,7 +928,7 @@ __global__ __launch_bounds__(256) void att_ft_stats_kernel(AttFtSegs segs, int K
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sum[e] += __expf(v[u][e] * inv_sqrt_sd - mc[e]);
+                for (int e = 0; e < 4; ++e) sum[e] += EXACT ? expf(v[u][e] * inv_sqrt_sd - mc[e]) : __expf(v[u][e] * inv_sqrt_sd - mc[e]);
         }
     }
     if (sl < AB_SL) *(f32x4*)(&part[sl][c4]) = sum;
@@ -937,27 +939,38 @@ __global__ __launch_bounds__(256) void att_ft_stats_kernel(AttFtSegs segs, int K
         for (int q = 0; q < AB_SL; ++q) ss += part[q][tid];
         float* o = stats + ((size_t)si * gridDim.y + b) * 256;
         o[tid] = tid < K ? mx[tid] : 0.f;
-        o[128 + tid] = tid < K ? 1.0f / ss : 0.f;  // weight 0 for the padding columns K..127
+        // fast: 1 / sum (weight 0 for the padding columns K..127); exact: the sum itself (the kernel zeroes the padding columns)
+        o[128 + tid] = EXACT ? (tid < K ? ss : 1.f) : (tid < K ? 1.0f / ss : 0.f);
     }
 }
 
-__global__ __launch_bounds__(256, 3) void query_att_ft_bf16_kernel(AttFtSegs segs, int K, const float* __restrict__ stats,
-                                                                   float* __restrict__ out, float inv_sqrt_sd, int accumulate,
-                                                                   int dim) {
-    __shared__ __attribute__((aligned(16))) float st[AB_MAXSEG][256];  // per segment: max[128] | 1/sum[128]
-    __shared__ __attribute__((aligned(16))) bf16_t Wt[2][AB_TCH * AB_WP];
-    __shared__ __attribute__((aligned(16))) bf16_t Xs[2][AB_TCH * AB_XP];
+// SPLIT = false: the fast mode's kernel (bf16 operands, __expf, reciprocal sums).  SPLIT = true: the f16x3 mode's - token rows and
+// softmax weights (expf, true division) as f16-split planes, three f16 MFMA products per (weight tile, column tile) in two
+// accumulator sets (hi, cross terms), out = hi + 2^-11 lo: the rounding class of the exact-f32 kernel at a fraction of its time
+// (that one issues its token-row loads right in front of the MFMAs that use them: 1.2 ms per ViT encoder at the headline batch).
+template <bool SPLIT>
+__global__ __launch_bounds__(256, SPLIT ? 1 : 3) void query_att_ft_mma_kernel(AttFtSegs segs, int K, const float* __restrict__ stats,
+                                                                              float* __restrict__ out, float inv_sqrt_sd,
+                                                                              int accumulate, int dim) {
+    constexpr int NP = SPLIT ? 2 : 1;  // operand planes
+    extern __shared__ __attribute__((aligned(16))) char smem_af[];
+    float (*st)[256] = (float (*)[256])smem_af;                                     // per segment: max[128] | 1/sum or sum [128]
+    bf16_t* const Wt = (bf16_t*)(smem_af + AB_MAXSEG * 256 * 4);                    // [2 buffers][NP planes][AB_TCH * AB_WP]
+    bf16_t* const Xs = Wt + 2 * NP * AB_TCH * AB_WP;                                // [2 buffers][NP planes][AB_TCH * AB_XP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, g = lane >> 4;
     const int b = blockIdx.y, B = gridDim.y;
     const int dblk = blockIdx.x * AB_COLS;
     const int K4 = (K + 3) & ~3;  // logits are read as float4s: columns K..K4-1 exist (row pitch >= K4) and get weight 0
-    f32x4 acc[7][AB_NT];
+    f32x4 acc[7][AB_NT], acl[SPLIT ? 7 : 1][AB_NT];
 #pragma unroll
     for (int mt = 0; mt < 7; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < AB_NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < AB_NT; ++nt) {
+            acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (SPLIT) acl[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     int nchunks = 0;
     for (int si = 0; si < segs.nseg; ++si) {
         st[si][tid] = stats[((size_t)si * B + b) * 256 + tid];
@@ -985,19 +998,39 @@ __global__ __launch_bounds__(256, 3) void query_att_ft_bf16_kernel(AttFtSegs seg
         f_tc += AB_TCH;
         if (f_tc >= n) { f_tc = 0; ++f_si; }
     };
-    auto commit = [&](int buf) {  // registers -> LDS: bf16 token rows, softmax weights (exp(-inf) = 0 pads)
+    auto commit = [&](int buf) {  // registers -> LDS: token rows and softmax weights (exp(-inf) = 0 pads) in the operand format
+        bf16_t* const xs = Xs + buf * NP * AB_TCH * AB_XP;
+        bf16_t* const wt = Wt + buf * NP * AB_TCH * AB_WP;
 #pragma unroll
-        for (int i = 0; i < XL; ++i)
-            *(bf16x4*)(&Xs[buf][(tid / XC4 + (256 / XC4) * i) * AB_XP + (tid % XC4) * 4]) = pack_bf16x4(xr[i]);
+        for (int i = 0; i < XL; ++i) {
+            const int o = (tid / XC4 + (256 / XC4) * i) * AB_XP + (tid % XC4) * 4;
+            if constexpr (SPLIT) {
+                f16x4 h4, l4;
+                split_f16x4(xr[i], h4, l4);
+                *(f16x4*)(xs + o) = h4;
+                *(f16x4*)(xs + AB_TCH * AB_XP + o) = l4;
+            } else {
+                *(bf16x4*)(xs + o) = pack_bf16x4(xr[i]);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i, t = idx / 28, c4 = (idx % 28) * 4;
             if (idx < AB_TCH * 28) {
                 const f32x4 mc = *(const f32x4*)(&st[r_si][c4]), sc = *(const f32x4*)(&st[r_si][128 + c4]);
                 f32x4 w;
+                if constexpr (SPLIT) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = __expf(lr[i][e] * inv_sqrt_sd - mc[e]) * sc[e];
-                *(bf16x4*)(&Wt[buf][t * AB_WP + c4]) = pack_bf16x4(w);
+                    for (int e = 0; e < 4; ++e) w[e] = c4 + e < K ? expf(lr[i][e] * inv_sqrt_sd - mc[e]) / sc[e] : 0.f;
+                    f16x4 h4, l4;
+                    split_f16x4(w, h4, l4);
+                    *(f16x4*)(wt + t * AB_WP + c4) = h4;
+                    *(f16x4*)(wt + AB_TCH * AB_WP + t * AB_WP + c4) = l4;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = __expf(lr[i][e] * inv_sqrt_sd - mc[e]) * sc[e];
+                    *(bf16x4*)(wt + t * AB_WP + c4) = pack_bf16x4(w);
+                }
             }
         }
     };
@@ -1011,23 +1044,34 @@ __global__ __launch_bounds__(256, 3) void query_att_ft_bf16_kernel(AttFtSegs seg
             commit((ch + 1) & 1);  // that buffer's readers finished before the barrier that ended chunk ch-1
             if (ch + 2 < nchunks) fetch();
         }
-        const bf16_t* xs = Xs[ch & 1];
-        const bf16_t* wt = Wt[ch & 1];
+        const bf16_t* xs = Xs + (ch & 1) * NP * AB_TCH * AB_XP;
+        const bf16_t* wt = Wt + (ch & 1) * NP * AB_TCH * AB_WP;
         // lane 4r+q of a 16-lane group addresses (token row r, columns 4q..4q+3); k slots 8g..8g+7 = two reads
         const int trow = 8 * g + (l16 >> 2), cpart = 4 * (l16 & 3);
-        bf16x8 xf[AB_NT];
+        bf16x8 xf[AB_NT], xl[SPLIT ? AB_NT : 1];
 #pragma unroll
         for (int nt = 0; nt < AB_NT; ++nt) {
             const bf16_t* p = xs + trow * AB_XP + wave * (16 * AB_NT) + nt * 16 + cpart;
             xf[nt] = cat_bf16x4(lds_read_tr16(p), lds_read_tr16(p + 4 * AB_XP));
+            if constexpr (SPLIT) xl[nt] = cat_bf16x4(lds_read_tr16(p + AB_TCH * AB_XP), lds_read_tr16(p + AB_TCH * AB_XP + 4 * AB_XP));
         }
 #pragma unroll
         for (int mt = 0; mt < 7; ++mt) {
             const bf16_t* p = wt + trow * AB_WP + mt * 16 + cpart;
             const bf16x8 wf = cat_bf16x4(lds_read_tr16(p), lds_read_tr16(p + 4 * AB_WP));
+            if constexpr (SPLIT) {
+                const bf16x8 wl = cat_bf16x4(lds_read_tr16(p + AB_TCH * AB_WP), lds_read_tr16(p + AB_TCH * AB_WP + 4 * AB_WP));
 #pragma unroll
-            for (int nt = 0; nt < AB_NT; ++nt)  // operands swapped: lane (c = l16, g) ends up with 4 consecutive d
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[nt], wf, acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < AB_NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xf[nt]), __builtin_bit_cast(f16x8, wf), acc[mt][nt], 0, 0, 0);
+                    acl[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xf[nt]), __builtin_bit_cast(f16x8, wl), acl[mt][nt], 0, 0, 0);
+                    acl[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xl[nt]), __builtin_bit_cast(f16x8, wf), acl[mt][nt], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < AB_NT; ++nt)  // operands swapped: lane (c = l16, g) ends up with 4 consecutive d
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[nt], wf, acc[mt][nt], 0, 0, 0);
+            }
         }
         lds_barrier();
     }
@@ -1040,9 +1084,14 @@ __global__ __launch_bounds__(256, 3) void query_att_ft_bf16_kernel(AttFtSegs seg
 #pragma unroll
         for (int nt = 0; nt < AB_NT; ++nt) {
             f32x4* o = (f32x4*)(orow + 16 * nt);
-            *o = accumulate ? *o + acc[mt][nt] : acc[mt][nt];
+            f32x4 v = acc[mt][nt];
+            if constexpr (SPLIT) v += acl[mt][nt] * (1.0f / F16S_LO_SCALE);
+            *o = accumulate ? *o + v : v;
         }
     }
+}
+constexpr size_t att_ft_mma_lds(bool split) {
+    return (size_t)AB_MAXSEG * 256 * 4 + (size_t)2 * (split ? 2 : 1) * AB_TCH * (AB_WP + AB_XP) * 2;
 }
 
 // ------------------------------------------------------------------------------------- alignment logits (bf16 x 3)
@@ -1590,8 +1639,22 @@ extern "C" int madtp_query_att_ft(const float* token_attn, int ldt, int ldb, int
     return 0;
 }
 
+static int att_ft_multi_impl(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float* stats_ws, float inv_sqrt_sd,
+                             int accumulate, int B, int dim, bool split, void* stream);
+
 extern "C" int madtp_query_att_ft_multi(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float* stats_ws,
                                         float inv_sqrt_sd, int accumulate, int B, int dim, void* stream) {
+    return att_ft_multi_impl(segs, nseg, K, out, stats_ws, inv_sqrt_sd, accumulate, B, dim, false, stream);
+}
+
+extern "C" int madtp_query_att_ft_multi_split(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float* stats_ws,
+                                              float inv_sqrt_sd, int accumulate, int B, int dim, void* stream) {
+    if (!stats_ws) return MADTP_E_BADARG;
+    return att_ft_multi_impl(segs, nseg, K, out, stats_ws, inv_sqrt_sd, accumulate, B, dim, true, stream);
+}
+
+static int att_ft_multi_impl(const madtp_att_ft_seg* segs, int nseg, int K, float* out, float* stats_ws, float inv_sqrt_sd,
+                             int accumulate, int B, int dim, bool split, void* stream) {
     if (!segs || !out || nseg < 1 || B <= 0) return MADTP_E_BADARG;
     if (K <= 0 || K > 112 || dim % AB_COLS) return MADTP_E_SHAPE;
     if (!stats_ws) {  // parity modes: exact-f32 arithmetic, the per-layer summation order kept (see the kernel)
@@ -1623,9 +1686,18 @@ extern "C" int madtp_query_att_ft_multi(const madtp_att_ft_seg* segs, int nseg, 
             a.s[i] = AttFtSeg{g.token_attn, g.ft, g.n, g.ldt_row, g.ldt_batch, g.ldf_row, g.ldf_batch};
         }
         float* stats = stats_ws + (size_t)first * B * 256;
-        hipLaunchKernelGGL(att_ft_stats_kernel, dim3(a.nseg, B), dim3(256), 0, (hipStream_t)stream, a, K, inv_sqrt_sd, stats);
-        hipLaunchKernelGGL(query_att_ft_bf16_kernel, dim3(dim / AB_COLS, B), dim3(256), 0, (hipStream_t)stream, a, K, stats, out,
-                           inv_sqrt_sd, (accumulate || first > 0) ? 1 : 0, dim);
+        const int acc_flag = (accumulate || first > 0) ? 1 : 0;
+        if (split) {
+            MADTP_ENSURE_MAX_LDS(query_att_ft_mma_kernel<true>, att_ft_mma_lds(true));
+            hipLaunchKernelGGL(att_ft_stats_kernel<true>, dim3(a.nseg, B), dim3(256), 0, (hipStream_t)stream, a, K, inv_sqrt_sd, stats);
+            hipLaunchKernelGGL(query_att_ft_mma_kernel<true>, dim3(dim / AB_COLS, B), dim3(256), att_ft_mma_lds(true),
+                               (hipStream_t)stream, a, K, stats, out, inv_sqrt_sd, acc_flag, dim);
+        } else {
+            MADTP_ENSURE_MAX_LDS(query_att_ft_mma_kernel<false>, att_ft_mma_lds(false));
+            hipLaunchKernelGGL(att_ft_stats_kernel<false>, dim3(a.nseg, B), dim3(256), 0, (hipStream_t)stream, a, K, inv_sqrt_sd, stats);
+            hipLaunchKernelGGL(query_att_ft_mma_kernel<false>, dim3(dim / AB_COLS, B), dim3(256), att_ft_mma_lds(false),
+                               (hipStream_t)stream, a, K, stats, out, inv_sqrt_sd, acc_flag, dim);
+        }
         MADTP_LAUNCH_CHECK();
     }
     return 0;

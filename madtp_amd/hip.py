@@ -77,6 +77,7 @@ _SIGS = {
     "madtp_gemm_pair": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float, c_float, c_void_p]),
     "madtp_attention_pair": (c_int, [c_void_p] * 11 + [c_int] * 8 + [c_float, c_int, c_void_p]),
     "madtp_query_att_ft_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
+    "madtp_query_att_ft_multi_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "madtp_split_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "madtp_split_f16_weight": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
@@ -441,7 +442,8 @@ class AttFtSeg(ctypes.Structure):
 
 def query_att_ft_multi(pairs, out=None, sd_dim=768, exact=False):
     """pairs: list of (token_attn [B,n,K] view, ft [B,n,dim] f32 view) of the layers of an encoder -> their summed att_ft
-    [B,K,dim] in one launch (fast mode: bf16 MFMA; exact=True: the exact-f32 kernel, bit-identical to summing layer by layer)."""
+    [B,K,dim] in one launch (fast mode: bf16 MFMA; exact=True: the exact-f32 kernel, bit-identical to summing layer by layer;
+    exact="split": f16-split operands on the f16 MFMA - the f16x3 mode)."""
     segs = (AttFtSeg * len(pairs))()
     for i, (ta, ft) in enumerate(pairs):
         fp, ldf, ldfb, dim = _ta_view(ft)
@@ -452,9 +454,9 @@ def query_att_ft_multi(pairs, out=None, sd_dim=768, exact=False):
     if out is None:
         out = torch.empty((B, K, dim), device=pairs[0][1].device, dtype=torch.float32)
         acc = 0
-    ws = None if exact else torch.empty(len(pairs) * B * 256, device=out.device, dtype=torch.float32)
-    _check(load().madtp_query_att_ft_multi(segs, len(pairs), K, _p(out), _p(ws), 1.0 / (sd_dim ** 0.5), acc, B, dim,
-                                           _stream()), "madtp_query_att_ft_multi")
+    ws = None if exact is True else torch.empty(len(pairs) * B * 256, device=out.device, dtype=torch.float32)
+    fn = load().madtp_query_att_ft_multi_split if exact == "split" else load().madtp_query_att_ft_multi
+    _check(fn(segs, len(pairs), K, _p(out), _p(ws), 1.0 / (sd_dim ** 0.5), acc, B, dim, _stream()), "madtp_query_att_ft_multi")
     return out
 
 
@@ -465,9 +467,9 @@ def query_att_ft_multi_ptrs(segs_ptrs, B, K, dim, device, sd_dim=768, exact=Fals
     for i, t in enumerate(segs_ptrs):
         segs[i] = AttFtSeg(*t)
     out = torch.empty((B, K, dim), device=device, dtype=torch.float32)
-    ws = None if exact else torch.empty(len(segs_ptrs) * B * 256, device=device, dtype=torch.float32)
-    _check(load().madtp_query_att_ft_multi(segs, len(segs_ptrs), K, _p(out), _p(ws), 1.0 / (sd_dim ** 0.5), 0, B, dim, _stream()),
-           "madtp_query_att_ft_multi")
+    ws = None if exact is True else torch.empty(len(segs_ptrs) * B * 256, device=device, dtype=torch.float32)
+    fn = load().madtp_query_att_ft_multi_split if exact == "split" else load().madtp_query_att_ft_multi
+    _check(fn(segs, len(segs_ptrs), K, _p(out), _p(ws), 1.0 / (sd_dim ** 0.5), 0, B, dim, _stream()), "madtp_query_att_ft_multi")
     return out
 
 

@@ -99,7 +99,8 @@ class Query_model(nn.Module):
         (bit-identical to accumulating layer by layer).  With a q_map (CLIP: every block has its own query model) the layers'
         mapped q tensors are kept alive by the DeferredAttFt until that launch."""
         if self.compute_att_ft:
-            return DeferredAttFt(self.att_dim, exact=compute_dtype() != torch.bfloat16)
+            cdt = compute_dtype()  # fp32: the exact-f32 kernel in layer order; f16x3: f16-split operands; bf16: the fast kernel
+            return DeferredAttFt(self.att_dim, exact=True if cdt == torch.float32 else ("split" if cdt == torch.float16 else False))
         return None
 
     def _dictionary(self, sd):
@@ -140,7 +141,8 @@ class Query_model(nn.Module):
         # att_ft of all layers in ONE launch after the call ("bf16": fast-mode kernel, "exact": parity arithmetic and order)
         deferred = False
         if self.compute_att_ft:
-            deferred = "bf16" if (split is not None and split[0].dtype == torch.bfloat16) else "exact"
+            deferred = "bf16" if (split is not None and split[0].dtype == torch.bfloat16) else \
+                ("split" if compute_dtype() == torch.float16 else "exact")
         return qa, deferred
 
     def forward(self, ft, sd, mask=None, return_token_att=False, temperature=1, acc_ft=None, defer=None):

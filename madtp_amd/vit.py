@@ -345,7 +345,7 @@ def _vit_forward_encoder_call(self, x, space_dict, temperature, _pending, prep):
                 segs.append((lg + 128 * 4, xp + D * 4, n_in - 1, 128, n_in * 128, D, n_in * D))
 
             def launch():
-                return hip.query_att_ft_multi_ptrs(segs, B, K, D, x.device, sd_dim=qm.att_dim, exact=deferred == "exact")
+                return hip.query_att_ft_multi_ptrs(segs, B, K, D, x.device, sd_dim=qm.att_dim, exact={"exact": True, "split": "split"}.get(deferred, False))
             if _pending is None:
                 sd_img_ft_all = launch()
             else:

@@ -521,6 +521,33 @@ def test_query_att_ft_multi_segment(hip):
     assert (out2 - out - part).abs().max().item() < 1e-4 * scale
 
 
+def test_query_att_ft_multi_f16_split(hip):
+    """madtp_query_att_ft_multi_split (the f16x3 mode's att_ft: f16-split token rows and softmax weights, three f16 MFMA products)
+    against float64: within 3x the error of the exact-f32 kernel on the same segments (ragged token counts, > 16 segments),
+    accumulate form included."""
+    B, D, K = 3, 768, 100
+    sd = _rand(K, D, seed=81)
+    sdp = _pad128(sd).cuda()
+    pairs, ref = [], 0
+    for li, N in enumerate([150, 131, 64, 65, 33, 2, 20] + [17] * 12):
+        x = _rand(B, N, D, seed=90 + li)
+        xd = x.cuda()
+        tav = hip.gemm(xd.view(B * N, D), sdp, n=128).view(B, N, 128)[:, 1:, :K]     # exact-f32 logits, row pitch 128
+        pairs.append((tav, xd[:, 1:, :]))
+        inner = tav.double().cpu()
+        ref = ref + torch.bmm(torch.softmax((inner / math.sqrt(D)).permute(0, 2, 1), -1), x[:, 1:].double())
+    exact = hip.query_att_ft_multi(pairs, exact=True)
+    split = hip.query_att_ft_multi(pairs, exact="split")
+    e_ex = (exact.double().cpu() - ref).abs().max().item()
+    e_sp = (split.double().cpu() - ref).abs().max().item()
+    print(f"att_ft vs float64: exact-f32 kernel {e_ex:.3e}, f16-split kernel {e_sp:.3e}")
+    assert e_sp <= 3.0 * e_ex + 2e-7 * max(1.0, ref.abs().max().item()), (e_sp, e_ex)
+    out2 = hip.query_att_ft_multi(pairs[:3], out=split.clone(), exact="split")
+    part = hip.query_att_ft_multi(pairs[:3], exact="split")
+    assert (out2 - split - part).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(hip.query_att_ft_multi(pairs, exact="split"), split)   # deterministic
+
+
 def test_fast_mode_alignment_and_att_ft(hip):
     """bf16x3 split-precision logits (~2^-16 relative) and the bf16-MFMA att_ft."""
     B, N, D, K = 3, 150, 768, 100

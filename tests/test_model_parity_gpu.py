@@ -262,8 +262,9 @@ def test_vit_large_image_fp32_matches_reference_fixture(path, mode):
         ob, sd_b = model(images, space_dict=space_dict, temperature=T)
     assert torch.isfinite(ob).all()
     # all modes sum the 12 layers' att_ft in one deferred launch after the last layer; forcing the per-layer path with the
-    # per-layer accumulate chain (`sd_ft_all += sd_ft`, vit.py:297-303) gives the same result: bit for bit in the parity modes
-    # (the exact kernel keeps the layer-by-layer summation order), to bf16-MFMA rounding in the fast mode
+    # per-layer accumulate chain (`sd_ft_all += sd_ft`, vit.py:297-303) gives the same result: bit for bit in the fp32 mode (the
+    # exact kernel keeps the layer-by-layer summation order), to f32 rounding in the f16x3 mode (its deferred launch runs f16-split
+    # products, the per-layer chain the exact-f32 kernel), to bf16-MFMA rounding in the fast mode
     import madtp_amd.vit as vit_mod
     saved = vit_mod._ENCODER_CALL
     vit_mod._ENCODER_CALL = False
@@ -278,7 +279,11 @@ def test_vit_large_image_fp32_matches_reference_fixture(path, mode):
         vit_mod._ENCODER_CALL = saved
     assert torch.equal(ob, ob2) and sd_b.shape == sd_ft.shape
     assert (sd_b - sd_b2).abs().max().item() < 1e-4 * sd_b2.abs().max().item()
-    assert torch.equal(out, out2) and torch.equal(sd_ft, sd_ft2)
+    assert torch.equal(out, out2)
+    if mode == "fp32":
+        assert torch.equal(sd_ft, sd_ft2)
+    else:
+        assert (sd_ft - sd_ft2).abs().max().item() < 2e-6 * max(1.0, sd_ft2.abs().max().item())
 
 
 @pytest.mark.parametrize("mode", ["fp32", "f16x3", "bf16"])

@@ -14,9 +14,10 @@ d=json.load(open("gpurun_out/${TAG}_bench_$C.json")); r=d.get("roofline") or {};
 print("$C", d["value"], d["ms_per_step"], (d.get("single_stream") or {}).get("value"), "frac", r.get("frac"), "traffic", r.get("traffic"), "parity", p.get("value"), (p.get("index_match") or {}))
 PY
 done
+python tools/retrieval_bench.py --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_retrieval_evaluate.json; cut -c1-300 gpurun_out/${TAG}_retrieval_evaluate.json
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for spec in "nlvr bf16" "nlvr f16x3" "vqa bf16" "retrieval bf16" "clip bf16"; do
+for spec in "nlvr bf16" "nlvr f16x3" "vqa bf16" "vqa f16x3" "retrieval bf16" "clip bf16"; do
   set -- $spec; C=$1; P=$2; T=${C}_${P}
   CMD="bench.py --config $C --precision $P --inflight 1 --steps 5 --warmup 2 --traffic off --no-cpu-baseline --no-parity --no-gemm-events"
   rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$T -o p -- python $R/$CMD > $R/gpurun_out/prof_$T.log 2>&1
