@@ -9,6 +9,10 @@ Precision modes (SURVEY.md section 7 "hard parts"):
             attention, LayerNorm, the alignment logits and all pruning scores are the fp32 mode's kernels.  Kept-token
             sets match the reference like the fp32 mode (tests/test_model_parity_gpu.py); GEMM operands are torch.float16
             tensors holding the planes side by side ([M, 2K] activations, [N, 3K] weights).
+            RANGE: the activation planes carry no prescale (weights get a power of two), so a GEMM input must stay inside the
+            f16 range: |x| >= 65504 becomes inf (then NaN) and |x| below ~6e-5 loses relative accuracy.  The BLIP / CLIP
+            activations on this path (LayerNorm outputs, GELU(fc1), attention contexts, CLIP's q_map inputs) are O(1e-3 .. 1e2);
+            a model whose residual stream leaves that range has to run in the "fp32" mode, which has no such limit.
   "bf16"  - fast mode: GEMM operands are bf16 (f32 accumulate, MFMA 16x16x32), the residual stream, LayerNorm
             statistics, softmax, the alignment logits x.sd^T and every pruning score stay f32.
 """

@@ -103,8 +103,14 @@ class Query_model(nn.Module):
             return DeferredAttFt(self.att_dim, exact=True if cdt == torch.float32 else ("split" if cdt == torch.float16 else False))
         return None
 
+    MAX_ENTRIES = 128  # the pruning kernels keep one dictionary row per lane pair (token_score: K <= 128; att_ft: K <= 112)
+
     def _dictionary(self, sd):
         """prepared dictionary operands: (f32 [128, dim] Lin, split planes or None)"""
+        if sd.shape[0] > self.MAX_ENTRIES:
+            raise NotImplementedError(
+                f"space_dict with {sd.shape[0]} entries: the HIP pruning kernels hold at most {self.MAX_ENTRIES} dictionary "
+                "entries (112 when att_ft is computed); every reference config uses sd_num = 100 (configs/*.yaml)")
         sdl = self._cache.get(("sd", id(sd)), [sd], lambda: prepare_linear([sd], None, torch.float32))
         split = None
         if compute_dtype() == torch.bfloat16 and sdl.w.shape[0] == 128:

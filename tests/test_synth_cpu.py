@@ -50,3 +50,15 @@ def test_pin_rank_to_cores_splits_the_mask():
     finally:
         os.sched_setaffinity(0, before)
     assert mdist._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+
+
+def test_query_model_rejects_dictionaries_the_kernels_cannot_hold():
+    """the encoder-level calls carve their logits slabs at 128 floats per row; a space dictionary of
+    more than 128 entries must fail loudly before any kernel runs (reference configs: sd_num = 100)."""
+    import pytest
+    from madtp_amd.utils import Query_model
+    qm = Query_model(ft_dim=768, sd_dim=768)
+    with pytest.raises(NotImplementedError, match="128"):
+        qm._dictionary(torch.randn(200, 768))
+    with pytest.raises(NotImplementedError, match="128"):
+        qm.encoder_args(torch.randn(200, 768), 2, 768, "cpu")
