@@ -23,8 +23,8 @@ def _free_port():
 def _worker(rank, world, port, out_dir):
     os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
-    torch.set_num_threads(2)
-    from madtp_amd import specs, synth
+    torch.set_num_threads(4)
+    from madtp_amd import synth
     from oracle import madtp_oracle as O
     w, r, _ = mdist.init("gloo")
     assert (w, r) == (world, rank)
@@ -36,7 +36,7 @@ def _worker(rank, world, port, out_dir):
     lo, hi = mdist.shard_range(B, rank, world)
     assert img_s.shape[0] == 2 * (hi - lo) and torch.equal(img_s[: hi - lo], images[lo:hi])
     assert torch.equal(img_s[hi - lo:], images[B + lo:B + hi])
-    W = specs.synth_weights(specs.blip_nlvr_shapes(224), 0)
+    W = torch.load(os.path.join(out_dir, "weights.pt"), mmap=True, weights_only=True)  # generated once by the parent (~15 s)
     with torch.no_grad():
         logits = O.blip_nlvr_forward(W, img_s, ids_s, att_s, T)
     mdist.barrier()
@@ -64,17 +64,18 @@ def test_shard_range_covers_batch():
 def test_world2_gloo_sharded_forward_matches_per_shard_oracle(tmp_path):
     world = 2
     port = _free_port()
+    from madtp_amd import specs, synth
+    W = specs.synth_weights(specs.blip_nlvr_shapes(224), 0)
+    torch.save(W, os.path.join(tmp_path, "weights.pt"))
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
     # every rank saw the same gathered logits, in global sample order
     assert torch.equal(res[0]["all"], res[1]["all"])
     assert torch.equal(res[0]["all"], torch.cat([res[0]["logits"], res[1]["logits"]]))
     # per-shard parity: re-run each shard standalone in this process
-    from madtp_amd import specs, synth
     from oracle import madtp_oracle as O
     images = synth.synth_images(6, 224, 7)
     ids = synth.synth_token_ids(3, 12, 7)
-    W = specs.synth_weights(specs.blip_nlvr_shapes(224), 0)
     for r in range(world):
         lo, hi = res[r]["range"]
         img = torch.cat([images[lo:hi], images[3 + lo:3 + hi]])
@@ -86,11 +87,11 @@ def test_world2_gloo_sharded_forward_matches_per_shard_oracle(tmp_path):
 def _retrieval_worker(rank, world, port, out_dir):
     os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
-    torch.set_num_threads(2)
-    from madtp_amd import blip_retrieval as br, harness, specs
+    torch.set_num_threads(4)
+    from madtp_amd import blip_retrieval as br, harness
     from oracle import madtp_oracle as O
     mdist.init("gloo")
-    W = specs.synth_weights(specs.blip_retrieval_shapes(224), 0)
+    W = torch.load(os.path.join(out_dir, "weights.pt"), mmap=True, weights_only=True)  # generated once by the parent
     batches, ids, att = harness.retrieval_inputs(3, 2, 4, 224, 35, 0)
     with torch.no_grad():
         i2t, t2i = O.retrieval_evaluate(W, batches, ids, att, 6.0, 2, rank=rank, world=world)
@@ -110,9 +111,10 @@ def test_retrieval_rank_slices_and_all_reduce(tmp_path):
     from madtp_amd import harness, specs
     from oracle import madtp_oracle as O
     world = 2
+    W = specs.synth_weights(specs.blip_retrieval_shapes(224), 0)
+    torch.save(W, os.path.join(str(tmp_path), "weights.pt"))
     mp.spawn(_retrieval_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     outs = [torch.load(os.path.join(str(tmp_path), f"retr{r}.pt"), weights_only=False) for r in range(world)]
-    W = specs.synth_weights(specs.blip_retrieval_shapes(224), 0)
     batches, ids, att = harness.retrieval_inputs(3, 2, 4, 224, 35, 0)
     torch.set_num_threads(4)
     with torch.no_grad():

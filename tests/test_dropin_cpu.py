@@ -33,6 +33,7 @@ def test_reference_blip_nlvr_constructs_on_the_mirrors():
         sys.path.insert(0, {ROOT!r} + "/tools")
         import ref_shims
         ref_shims.install(chdir=True, import_models=False)   # third-party stand-ins only (timm hub, tokenizer files ...)
+        ref_shims.fast_init()                                # keys / shapes only: skip the random initialisers
         import madtp_amd.dropin as dropin
         dropin.install({REF!r})
         import models.blip as blip                            # the reference's own glue files, unmodified
@@ -70,6 +71,7 @@ def test_reference_clip_load_builds_the_mirror(tmp_path):
         sys.path.insert(0, {ROOT!r} + "/tools")
         import ref_shims
         ref_shims.install(chdir=True, import_models=False)
+        ref_shims.fast_init()
         import madtp_amd.dropin as dropin
         dropin.install({REF!r})
         from clip import clip                                    # the reference's clip/clip.py, unmodified (the driver's import)
@@ -81,7 +83,8 @@ def test_reference_clip_load_builds_the_mirror(tmp_path):
         assert "clip.mock" in _s.modules
         assert clip_pkg.load is clip.load and clip_pkg.tokenize is clip.tokenize   # clip/__init__.py: from .clip import *
         from madtp_amd import specs
-        sd = specs.synth_weights(specs.clip_shapes(224), 0)
+        # (any values do: the check is that load() copies them into the mirror; the deterministic generator takes ~10 s here)
+        sd = {{k: torch.full(tuple(shape), 1e-3 * (i % 97 + 1)) for i, (k, shape) in enumerate(specs.clip_shapes(224).items())}}
         path = {str(tmp_path)!r} + "/clip_synth.pth"
         torch.save({{"model": sd}}, path)
         model, _ = clip.load(name=path, device="cpu", evaluate=True, config={{"sd_dim": 768, "sd_num": 100}})
@@ -115,6 +118,7 @@ def test_reference_blip_glue_constructs_on_the_mirrors(which):
         sys.path.insert(0, {ROOT!r} + "/tools")
         import ref_shims
         ref_shims.install(chdir=True, import_models=False)
+        ref_shims.fast_init()
         import madtp_amd.dropin as dropin
         dropin.install({REF!r})
         import models.blip as blip

@@ -226,3 +226,21 @@ def install(chdir=True, import_models=True):
 def patch_tokenizer(module):
     """models.blip_nlvr & co. did `from models.blip import init_tokenizer` - rebind the local name."""
     module.init_tokenizer = lambda: FakeTokenizer()
+
+
+def fast_init():
+    """Construct-only tests: make the random initialisers no-ops (nn.Linear / nn.Embedding / nn.LayerNorm defaults, the
+    reference's `_init_weights`: `normal_`, `trunc_normal_`, `kaiming_uniform_` ...).  Building BLIP / CLIP at full size on
+    8 CPU cores spends minutes in those; the tests that use this only compare state-dict keys and shapes."""
+    same = lambda t, *a, **k: t  # noqa: E731
+    for name in ("normal_", "uniform_", "trunc_normal_", "kaiming_uniform_", "kaiming_normal_", "xavier_uniform_",
+                 "xavier_normal_", "constant_", "zeros_", "ones_", "orthogonal_"):
+        if hasattr(torch.nn.init, name):
+            setattr(torch.nn.init, name, same)
+    for name in ("normal_", "uniform_", "trunc_normal_"):
+        if hasattr(torch.Tensor, name):
+            setattr(torch.Tensor, name, same)
+    torch.randn = lambda *size, **k: torch.zeros(*size, **{kk: v for kk, v in k.items() if kk in ("dtype", "device")})
+    import timm.models.layers as tl  # the stand-in module installed by install()
+    if hasattr(tl, "trunc_normal_"):
+        tl.trunc_normal_ = same
