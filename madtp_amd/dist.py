@@ -44,6 +44,9 @@ def gpu_local_cpus(device_index):
         return None
 
 
+MIN_CORES_PER_RANK = 4  # bench.py runs two in-flight worker threads next to the main thread
+
+
 def pin_rank_to_cores(local_rank, local_world, device_index=None, cpus_of_gpu=None):
     """Every rank's host thread spins on a pinned slot 24 times per forward (the k hand-over, csrc/prune.hip) and feeds ~300
     launches: give each rank its own slice of host cores, on the NUMA node of ITS GPU when sysfs tells (ranks that share a
@@ -63,6 +66,8 @@ def pin_rank_to_cores(local_rank, local_world, device_index=None, cpus_of_gpu=No
     else:
         n = len(allowed) // local_world
         mine = allowed[local_rank * n:(local_rank + 1) * n] if n else allowed
+    if len(mine) < MIN_CORES_PER_RANK:
+        return set()  # a slice this small would make the rank's own threads (main + in-flight workers) contend: leave it to the OS
     if mine:
         try:
             os.sched_setaffinity(0, mine)

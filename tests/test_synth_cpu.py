@@ -29,10 +29,15 @@ def test_pin_rank_to_cores_splits_the_mask():
     if not hasattr(os, "sched_getaffinity"):
         return
     before = os.sched_getaffinity(0)
+    min_cores = mdist.MIN_CORES_PER_RANK
     try:
         allowed = sorted(before)
         if len(allowed) < 2:
             return
+        # a slice smaller than the rank's own thread count is not applied (main thread + two in-flight workers)
+        mdist.MIN_CORES_PER_RANK = len(allowed)
+        assert mdist.pin_rank_to_cores(0, 2) == set() and os.sched_getaffinity(0) == before
+        mdist.MIN_CORES_PER_RANK = 1
         sets = []
         for r in range(2):
             os.sched_setaffinity(0, before)
@@ -49,6 +54,7 @@ def test_pin_rank_to_cores_splits_the_mask():
         assert os.sched_getaffinity(0) == before
     finally:
         os.sched_setaffinity(0, before)
+        mdist.MIN_CORES_PER_RANK = min_cores
     assert mdist._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
 
 
