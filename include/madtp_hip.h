@@ -438,6 +438,16 @@ int madtp_lm_loss(const float* logits, int ld, int rows_per_seq, int n_pred, int
 /* out[q, a] = softmax(logits[q, :V])[tok[a]]  (blip_vqa.py:170-171: F.softmax(logits, dim=1).index_select(1, answer_first_token));
  * logits f32 [Q, >= V] with row stride ld, tok int64 [A], out f32 [Q, A]. */
 int madtp_token_prob(const float* logits, int ld, int V, const int64_t* tok, int A, float* out, int Q, void* stream);
+/* Candidate selection of one beam-search step (transformers 4.15 generation_utils.py `beam_search`, the search behind
+ * text_decoder.generate(num_beams=...) at models/blip_vqa.py:134-140 and models/blip.py:189-196):
+ *   score[b, j * V + t] = log_softmax(logits[b * num_beams + j, :V])[t] + beam_scores[b * num_beams + j]   (t == suppress_token: -inf,
+ *   the MinLengthLogitsProcessor's treatment of EOS below min_length; -1 = none)
+ *   out_scores / out_index [B, n_top] = the n_top (= 2 * num_beams) best of the num_beams * V candidates of item b in descending
+ *   order (ties: the lower flat index j * V + t first; fewer than n_top finite candidates: index -1, score -inf).
+ * logits f32 [B * num_beams, >= V] with row stride ld (the LM head's scores at the last position), beam_scores f32
+ * [B * num_beams]; num_beams <= 8, n_top <= 16. */
+int madtp_beam_topk(const float* logits, int ld, int V, const float* beam_scores, int num_beams, int n_top, int suppress_token,
+                    float* out_scores, int32_t* out_index, int B, void* stream);
 
 #ifdef __cplusplus
 }

@@ -849,7 +849,8 @@ class _LMOut:
 
 class BertLMHeadModel(nn.Module):
     """models/med.py BertLMHeadModel :933-1094, teacher-forced use (labels / logits of whole sequences: BLIP_VQA.rank_answer,
-    blip_vqa.py:156-203).  Incremental decoding (past_key_values, generate / beam search) is not implemented."""
+    blip_vqa.py:156-203) and beam-search generation (`generate`, madtp_amd/generation.py; no past_key_values: every step re-runs the
+    prefix)."""
 
     def __init__(self, config, sd_dim=768):
         super().__init__()
@@ -930,6 +931,44 @@ class BertLMHeadModel(nn.Module):
             return ((lm_loss, scores) if lm_loss is not None else (scores,))
         out = _LMOut(lm_loss, scores)
         return (out, sd_txt_ft) if train else out
+
+
+    def generate(self, input_ids, max_length=20, min_length=0, num_beams=1, eos_token_id=None, pad_token_id=None,
+                 repetition_penalty=1.0, length_penalty=1.0, early_stopping=False, do_sample=False, encoder_hidden_states=None,
+                 encoder_attention_mask=None, **unused):
+        """The beam-search use of transformers' `generate` at the reference's call sites (models/blip_vqa.py:134-140,
+        models/blip.py:189-196): input_ids [B, t0] prompt, encoder_hidden_states ALREADY repeated num_beams times per item
+        ([B * num_beams, N, D], as the reference passes them) -> int64 [B, <= max_length].  Every step runs the decoder over the
+        whole prefix (med.py prepare_inputs_for_generation :1071-1089: attention_mask = ones, is_decoder=True); the encoder
+        states are projected to every layer's cross-attention [k|v] ONCE per item and beam j of item b reads block b.
+        encoder_attention_mask is accepted and ignored: MED cross-attention drops the encoder mask (med.py:197-199)."""
+        if do_sample:
+            raise NotImplementedError("nucleus sampling (models/blip.py:175-186) is not implemented: beam search only")
+        if num_beams < 2:
+            raise NotImplementedError("greedy search: the reference's call sites use num_beams = 3")
+        if eos_token_id is None or pad_token_id is None or encoder_hidden_states is None:
+            raise ValueError("generate: eos_token_id, pad_token_id and encoder_hidden_states are required")
+        from . import generation
+        require_gpu(encoder_hidden_states, "encoder_hidden_states")
+        dev = encoder_hidden_states.device
+        B = input_ids.shape[0]
+        if encoder_hidden_states.shape[0] != B * num_beams:
+            raise ValueError("generate: encoder_hidden_states must hold num_beams copies per prompt (repeat_interleave, "
+                             "as models/blip_vqa.py:128 / models/blip.py:165 pass them)")
+        cache = EncoderKVCache.build(self.bert, encoder_hidden_states[::num_beams].contiguous())
+        sel = cache.select(torch.arange(B, device=dev).repeat_interleave(num_beams))
+        V = self.cls.predictions.decoder.weight.shape[0]
+
+        def step(ids):
+            outputs, _ = self.bert(ids, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                                   is_decoder=True, mode='multimodal', encoder_kv_cache=sel)
+            _, padded = self.prediction_scores(outputs[0][:, -1:, :].contiguous())
+            return padded[:, 0, :]
+        prompt = input_ids.to(dev).to(torch.int64).repeat_interleave(num_beams, dim=0)
+        with torch.no_grad():
+            return generation.beam_search(step, prompt, num_beams, max_length, min_length, eos_token_id, pad_token_id, V,
+                                          repetition_penalty=repetition_penalty, length_penalty=length_penalty,
+                                          early_stopping=early_stopping)
 
 
 class NlvrBertModel(_BertModelBase):

@@ -16,6 +16,8 @@ from .vit import VisionTransformer
 
 ENC_TOKEN_ID = 30523  # tokenizer.additional_special_tokens_ids[0] after init_tokenizer() (models/blip.py:219-225)
 PAD_TOKEN_ID = 0
+BOS_TOKEN_ID = 30522  # tokenizer.bos_token_id ("[DEC]", models/blip.py:222)
+SEP_TOKEN_ID = 102  # tokenizer.sep_token_id of bert-base-uncased
 
 
 class BLIP_VQA(nn.Module):
@@ -71,8 +73,20 @@ class BLIP_VQA(nn.Module):
         question_states, _, _ = self.encode_question(image, question, temperature)
         if self.text_decoder is None:
             return question_states  # the tensor rank_answer / generate (:127-180) would consume
+        if inference == 'generate':  # :127-147 (the reference decodes the ids to strings with its tokenizer, :143-146)
+            num_beams = 3
+            qs = question_states.repeat_interleave(num_beams, dim=0)  # :128
+            qa = torch.ones(qs.size()[:-1], dtype=torch.long, device=qs.device)  # :129
+            bos_ids = torch.full((image.size(0), 1), fill_value=BOS_TOKEN_ID, device=image.device)  # :132
+            outputs = self.text_decoder.generate(input_ids=bos_ids, max_length=10, min_length=1, num_beams=num_beams,
+                                                 eos_token_id=SEP_TOKEN_ID, pad_token_id=PAD_TOKEN_ID,
+                                                 encoder_hidden_states=qs, encoder_attention_mask=qa)  # :134-140
+            tok = getattr(self, "tokenizer", None)
+            if tok is not None and hasattr(tok, "decode"):
+                return [tok.decode(o, skip_special_tokens=True) for o in outputs]
+            return outputs
         if inference != 'rank':
-            raise NotImplementedError("inference='generate' (beam search, :127-148) is not implemented; use inference='rank'")
+            raise ValueError("inference must be 'rank' or 'generate'")
         a_ids = answer["input_ids"] if isinstance(answer, dict) else answer.input_ids
         a_att = answer["attention_mask"] if isinstance(answer, dict) else answer.attention_mask
         q_att = question["attention_mask"] if isinstance(question, dict) else question.attention_mask

@@ -1,6 +1,7 @@
 // Answer ranking on the LM head's prediction scores (inference half):
 //   madtp_lm_loss    - models/med.py BertLMHeadModel.forward :1036-1042: label-smoothed next-token cross-entropy, summed per sequence
 //   madtp_token_prob - models/blip_vqa.py rank_answer :170-171: softmax probability of each candidate's first token
+//   madtp_beam_topk  - the candidate selection of text_decoder.generate(num_beams=..) (models/blip_vqa.py:134, models/blip.py:189)
 // Both are HBM-bound row kernels over the vocabulary (V = 30524 f32 scores = 119 KiB per row): one 256-thread workgroup per
 // sequence / question, float4 loads, two passes per row (maximum + plain sum, then the exponential sum: the second pass reads
 // the row back from L2), wave-shuffle + LDS reductions in a fixed order (deterministic).
@@ -82,7 +83,91 @@ __global__ __launch_bounds__(LM_THREADS) void token_prob_kernel(const float* log
     }
 }
 
+// Beam-search candidate selection (transformers 4.15 generation_utils.py beam_search: log_softmax of the last-position scores,
+// + the running beam score, view [B, num_beams * V], topk(2 * num_beams) sorted; models/blip_vqa.py:134, models/blip.py:189).
+// One workgroup per batch item: log-sum-exp of its num_beams rows (row_stats), then every thread scans a strided share of the
+// num_beams * V candidates keeping its n_top best in its own LDS slice, then n_top rounds of a block-wide arg-max (ties: the
+// lower flat index) emit the winners in descending order.  HBM-bound: num_beams * V * 4 bytes per item, read twice from L2/HBM.
+constexpr int BT_MAX_TOP = 16, BT_MAX_BEAMS = 8;
+
+__global__ __launch_bounds__(LM_THREADS) void beam_topk_kernel(const float* logits, int ld, int V, const float* beam_scores,
+                                                               int num_beams, int n_top, int suppress, float* out_scores,
+                                                               int32_t* out_index) {
+    __shared__ float scratch[4];
+    __shared__ float lse_s[BT_MAX_BEAMS];
+    __shared__ float c_val[LM_THREADS * BT_MAX_TOP];
+    __shared__ int c_idx[LM_THREADS * BT_MAX_TOP];
+    __shared__ float w_val[4];
+    __shared__ int w_idx[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int j = 0; j < num_beams; ++j) {
+        const RowStats st = row_stats(logits + ((size_t)b * num_beams + j) * ld, V, scratch);
+        if (tid == 0) lse_s[j] = st.mx + logf(st.sum_e);
+    }
+    __syncthreads();
+    float* mv = c_val + tid * BT_MAX_TOP;
+    int* mi = c_idx + tid * BT_MAX_TOP;
+    for (int q = 0; q < n_top; ++q) { mv[q] = -INFINITY; mi[q] = 0x7fffffff; }
+    float cur_min = -INFINITY;
+    int min_pos = 0, filled = 0;
+    for (int j = 0; j < num_beams; ++j) {
+        const float* row = logits + ((size_t)b * num_beams + j) * ld;
+        const float add = beam_scores[b * num_beams + j], lse = lse_s[j];
+        for (int t = tid; t < V; t += LM_THREADS) {
+            float v = (row[t] - lse) + add;
+            if (t == suppress) v = -INFINITY;
+            if (!(v > -INFINITY)) continue;  // -inf and NaN never become candidates
+            if (filled < n_top) {
+                mv[filled] = v; mi[filled] = j * V + t; ++filled;
+                if (filled == n_top) {
+                    cur_min = mv[0]; min_pos = 0;
+                    for (int q = 1; q < n_top; ++q) if (mv[q] < cur_min) { cur_min = mv[q]; min_pos = q; }
+                }
+            } else if (v > cur_min) {
+                mv[min_pos] = v; mi[min_pos] = j * V + t;
+                cur_min = mv[0]; min_pos = 0;
+                for (int q = 1; q < n_top; ++q) if (mv[q] < cur_min) { cur_min = mv[q]; min_pos = q; }
+            }
+        }
+    }
+    for (int r = 0; r < n_top; ++r) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int q = 0; q < n_top; ++q)
+            if (mv[q] > bv || (mv[q] == bv && mi[q] < bi)) { bv = mv[q]; bi = mi[q]; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { w_val[tid >> 6] = bv; w_idx[tid >> 6] = bi; }
+        __syncthreads();
+        bv = w_val[0]; bi = w_idx[0];
+        for (int w = 1; w < 4; ++w)
+            if (w_val[w] > bv || (w_val[w] == bv && w_idx[w] < bi)) { bv = w_val[w]; bi = w_idx[w]; }
+        if (tid == 0) {
+            out_scores[(size_t)b * n_top + r] = bv;
+            out_index[(size_t)b * n_top + r] = bi == 0x7fffffff ? -1 : bi;
+        }
+        for (int q = 0; q < n_top; ++q)
+            if (mi[q] == bi && bi != 0x7fffffff) { mv[q] = -INFINITY; mi[q] = 0x7fffffff; }
+    }
+}
+
 }  // namespace
+
+extern "C" int madtp_beam_topk(const float* logits, int ld, int V, const float* beam_scores, int num_beams, int n_top,
+                               int suppress_token, float* out_scores, int32_t* out_index, int B, void* stream) {
+    if (!logits || !beam_scores || !out_scores || !out_index || B <= 0 || V <= 0 || ld < V) return MADTP_E_BADARG;
+    if (num_beams < 1 || num_beams > BT_MAX_BEAMS || n_top < 1 || n_top > BT_MAX_TOP || (long long)num_beams * V > 0x7ffffffeLL)
+        return MADTP_E_SHAPE;
+    if (!aligned16(logits) || (ld & 3)) return MADTP_E_ALIGN;
+    hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(LM_THREADS), 0, (hipStream_t)stream, logits, ld, V, beam_scores, num_beams,
+                       n_top, suppress_token, out_scores, out_index);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int madtp_lm_loss(const float* logits, int ld, int rows_per_seq, int n_pred, int V, const int64_t* labels,
                              int ld_labels, float label_smoothing, float* loss, int B, void* stream) {

@@ -1,0 +1,110 @@
+"""Beam-search decoding for the BLIP text decoder: the `text_decoder.generate(num_beams=...)` call sites of the reference
+(models/blip_vqa.py:134-140, models/blip.py:189-196).  The search itself is transformers 4.15's (environment.yml:266, a
+dependency that is not vendored in the reference): generation_utils.py `beam_search` + generation_beam_search.py
+`BeamSearchScorer` / `BeamHypotheses` + `MinLengthLogitsProcessor`; oracle/madtp_oracle.py::beam_search restates it for the tests.
+
+Split of work: per step the decoder runs over the whole prefix of every live beam (no KV cache of the self-attention: answers /
+captions are <= 10 / 30 tokens), the LM head at the last position only; `madtp_beam_topk` (csrc/lmhead.hip) does the
+log-softmax, the beam-score addition, the EOS suppression below min_length and the top-2k selection over num_beams * V
+candidates per item on the GPU; the 2 * num_beams winners per item come to the host (one small copy per step - the search is
+inherently sequential in the step) where the hypothesis book-keeping runs, as it does in the library."""
+import torch
+
+from . import hip
+
+
+class BeamHypotheses:
+    """generation_beam_search.py BeamHypotheses (4.15): score = sum_logprobs / len(hyp) ** length_penalty."""
+
+    def __init__(self, num_beams, length_penalty, early_stopping):
+        self.num_beams, self.length_penalty, self.early_stopping = num_beams, length_penalty, early_stopping
+        self.beams, self.worst_score = [], 1e9
+
+    def __len__(self):
+        return len(self.beams)
+
+    def add(self, hyp, sum_logprobs):
+        score = sum_logprobs / (len(hyp) ** self.length_penalty)
+        if len(self) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, hyp))
+            if len(self) > self.num_beams:
+                ranked = sorted([(s, idx) for idx, (s, _) in enumerate(self.beams)])
+                del self.beams[ranked[0][1]]
+                self.worst_score = ranked[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs, cur_len):
+        if len(self) < self.num_beams:
+            return False
+        if self.early_stopping:
+            return True
+        return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
+
+
+def beam_search(step_fn, input_ids, num_beams, max_length, min_length, eos_token_id, pad_token_id, n_vocab,
+                repetition_penalty=1.0, length_penalty=1.0, early_stopping=False):
+    """step_fn(input_ids [B * num_beams, t] on the GPU) -> f32 last-position scores [B * num_beams, >= n_vocab] (GPU, unit column
+    stride); input_ids: the prompt already repeated num_beams times per item.  -> int64 [B, <= max_length] on the GPU."""
+    if repetition_penalty != 1.0:
+        raise NotImplementedError("repetition_penalty != 1.0: the reference's beam-search call sites pass 1.0 "
+                                  "(models/blip.py:161,195; compress_caption_dtp.py evaluate)")
+    dev = input_ids.device
+    n, cur_len = input_ids.shape
+    B = n // num_beams
+    hyps = [BeamHypotheses(num_beams, length_penalty, early_stopping) for _ in range(B)]
+    done = [False] * B
+    beam_scores = torch.zeros((B, num_beams), dtype=torch.float32)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    ids_host = input_ids.cpu()
+    while True:
+        logits = step_fn(input_ids)
+        suppress = eos_token_id if (min_length is not None and min_length > -1 and cur_len < min_length) else -1
+        sc, ix = hip.beam_topk(logits, beam_scores.to(dev), num_beams, n_vocab, suppress_token=suppress)
+        sc, ix = sc.cpu(), ix.cpu().to(torch.int64)
+        next_indices, next_tokens = ix // n_vocab, ix % n_vocab
+        nb_scores = torch.zeros((B, num_beams), dtype=torch.float32)
+        nb_tokens = torch.zeros((B, num_beams), dtype=torch.int64)
+        nb_rows = torch.zeros((B, num_beams), dtype=torch.int64)
+        for b in range(B):
+            if done[b]:
+                nb_tokens[b, :] = pad_token_id
+                continue
+            slot = 0
+            for rank in range(2 * num_beams):
+                if int(ix[b, rank]) < 0:
+                    continue
+                tok, s, row = int(next_tokens[b, rank]), float(sc[b, rank]), b * num_beams + int(next_indices[b, rank])
+                if tok == eos_token_id:
+                    if rank >= num_beams:
+                        continue
+                    hyps[b].add(ids_host[row].tolist(), s)
+                else:
+                    nb_scores[b, slot], nb_tokens[b, slot], nb_rows[b, slot] = s, tok, row
+                    slot += 1
+                if slot == num_beams:
+                    break
+            if slot < num_beams:
+                raise RuntimeError("beam search: fewer than num_beams open continuations among the 2 * num_beams candidates")
+            done[b] = done[b] or hyps[b].is_done(float(sc[b].max()), cur_len)
+        beam_scores = nb_scores.view(-1)
+        ids_host = torch.cat([ids_host[nb_rows.view(-1), :], nb_tokens.view(-1, 1)], dim=-1)
+        input_ids = ids_host.to(dev)
+        cur_len += 1
+        if all(done) or cur_len >= max_length:
+            break
+    for b in range(B):
+        if done[b]:
+            continue
+        for j in range(num_beams):
+            row = b * num_beams + j
+            hyps[b].add(ids_host[row].tolist(), float(beam_scores[row]))
+    best = [sorted(h.beams, key=lambda x: x[0])[-1][1] for h in hyps]
+    lens = [len(h) for h in best]
+    out = torch.full((B, min(max(lens) + 1, max_length)), pad_token_id, dtype=torch.int64)
+    for b, h in enumerate(best):
+        out[b, :lens[b]] = torch.tensor(h, dtype=torch.int64)
+        if lens[b] < max_length:
+            out[b, lens[b]] = eos_token_id
+    return out.to(dev)

@@ -12,7 +12,7 @@ import torch
 
 F32, BF16, F16S = 0, 1, 2  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -83,6 +83,7 @@ _SIGS = {
     "madtp_split_f16_weight": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
     "madtp_lm_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p]),
     "madtp_token_prob": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "madtp_beam_topk": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
 }
 
 
@@ -778,6 +779,25 @@ def token_prob(logits, tok, n_vocab):
     _check(load().madtp_token_prob(_p(logits), logits.stride(0), int(n_vocab), _p(tok), A, _p(out), Q, _stream()),
            "madtp_token_prob")
     return out
+
+
+def beam_topk(logits, beam_scores, num_beams, n_vocab, n_top=None, suppress_token=-1):
+    """One beam-search step's candidate selection (include/madtp_hip.h madtp_beam_topk): logits f32 [B * num_beams, >= n_vocab]
+    (rows may be strided), beam_scores f32 [B * num_beams] -> (scores f32 [B, n_top], flat index int32 [B, n_top] = beam * V + token),
+    descending, n_top = 2 * num_beams by default."""
+    _req(beam_scores, torch.float32, "beam_scores")
+    if not logits.is_cuda or logits.dtype != torch.float32 or logits.dim() != 2 or logits.stride(1) != 1:
+        raise RuntimeError("beam_topk: logits must be a GPU f32 [rows, V] tensor with unit column stride (rows may be strided)")
+    rows = logits.shape[0]
+    if rows % num_beams or beam_scores.numel() != rows:
+        raise ValueError("beam_topk: logits rows / beam_scores must be batch * num_beams long")
+    B = rows // num_beams
+    n_top = 2 * num_beams if n_top is None else int(n_top)
+    sc = torch.empty((B, n_top), device=logits.device, dtype=torch.float32)
+    ix = torch.empty((B, n_top), device=logits.device, dtype=torch.int32)
+    _check(load().madtp_beam_topk(_p(logits), logits.stride(0), int(n_vocab), _p(beam_scores), int(num_beams), n_top,
+                                  int(suppress_token), _p(sc), _p(ix), B, _stream()), "madtp_beam_topk")
+    return sc, ix
 
 
 def profile_begin():

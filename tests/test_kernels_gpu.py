@@ -810,6 +810,37 @@ def test_lm_loss_and_token_prob(hip, B, L, V, ld):
     assert (p - refp).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("B,nb,V,ld", [(3, 3, 30524, 30528), (2, 2, 37, 40), (5, 3, 1000, 1000), (1, 8, 131, 132)])
+def test_beam_topk(hip, B, nb, V, ld):
+    """madtp_beam_topk vs torch: topk(2 * num_beams) of (log_softmax(logits) + beam_scores) over the num_beams * V candidates of
+    every item (transformers 4.15 beam_search), with the EOS suppression of MinLengthLogitsProcessor, on strided rows whose
+    padding columns hold garbage, incl. the -1e9 start scores of beams 1.. and a row of all-equal logits (ties -> lower index)."""
+    g = torch.Generator().manual_seed(B * 10 + nb)
+    buf = torch.randn(B * nb, 2, ld, generator=g) * 2.0
+    buf[..., V:] = 1e9
+    buf[-1, 0, :V] = 0.25                                   # ties
+    bs = torch.randn(B * nb, generator=g)
+    bs.view(B, nb)[0, 1:] = -1e9                            # first step of an item
+    rows = buf[:, 0, :].cuda()                              # row stride 2 * ld
+    for suppress in (-1, 5):
+        sc, ix = hip.beam_topk(rows, bs.cuda(), nb, V, suppress_token=suppress)
+        lp = torch.log_softmax(buf[:, 0, :V].double(), -1)
+        if suppress >= 0:
+            lp[:, suppress] = -float("inf")
+        tot = (lp + bs.double()[:, None]).view(B, nb * V)
+        rs, ri = tot.topk(2 * nb, dim=1)
+        assert (sc.cpu().double() - rs).abs().max().item() < 1e-4 * max(1.0, rs[rs > -1e8].abs().max().item())
+        mine = ix.cpu().long()
+        for b in range(B):   # same candidates; order may differ only between numerically tied scores
+            assert sorted(mine[b].tolist()) == sorted(ri[b].tolist()) or \
+                (tot[b, mine[b]] - rs[b]).abs().max().item() < 1e-5
+        assert (sc[:, :-1] >= sc[:, 1:]).all()
+    # all-equal row: the winners of the last item's last beam come in ascending index order
+    sc, ix = hip.beam_topk(rows[-nb:], torch.zeros(nb).cuda() - torch.arange(nb).cuda() * 100.0, nb, V)
+    if nb == 1:
+        assert ix[0].tolist() == list(range(2))
+
+
 @pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 20, 12), (1, 65, 2), (2, 130, 12), (2, 82, 12), (1, 256, 3), (2, 17, 1),
                                    (16, 96, 12), (24, 96, 12), (4, 241, 3),
                                    (1, 577, 12), (2, 901, 3), (1, 257, 2), (1, 1024, 1)])   # attn_large_f16s_kernel

@@ -561,6 +561,84 @@ def test_vqa_rank_answer_matches_reference_fixture(path, mode):
     assert max_ids.tolist() == g["max_ids"].tolist()
 
 
+def test_generation_beam_search_equals_oracle_on_toy_models():
+    """madtp_amd.generation.beam_search (madtp_beam_topk + the host-side hypothesis book-keeping) against oracle.beam_search
+    (transformers 4.15 restated) on first-order toy language models with random tables: EOS frequent enough that hypotheses
+    finish at every length, min_length in play, items finishing at different steps (padding), the hand-worked cases of
+    tests/test_oracle_golden.py included."""
+    from madtp_amd import build, generation, hip
+    from oracle import madtp_oracle as O
+    from tests.test_oracle_golden import TOY, toy_lm
+    build.build(verbose=False)
+    hip.load()
+
+    def gpu_lm(table, ld):
+        lt = torch.full((len(table), ld), 1e9)
+        lt[:, :len(table[0])] = torch.log(torch.tensor(table, dtype=torch.float32))
+        lt = lt.cuda()
+        return lambda ids: lt[ids[:, -1]]
+    out = generation.beam_search(gpu_lm(TOY, 8), torch.tensor([[2], [2], [4], [4]]).cuda(), 2, 6, 0, 1, 0, 5)
+    assert out.tolist() == [[2, 3, 1], [4, 1, 0]]
+    gen = torch.Generator().manual_seed(5)
+    n_eos = 0
+    for trial in range(24):
+        V = [11, 37, 200][trial % 3]
+        nb = 2 + trial % 3
+        B = 1 + trial % 4
+        table = torch.rand(V, V, generator=gen) ** 4 + 1e-4
+        table[:, 1] *= (2.0 + 6.0 * torch.rand(V, generator=gen)) * (V / 11.0)   # EOS competitive
+        table = (table / table.sum(1, keepdim=True)).tolist()
+        prompt = torch.randint(2, V, (B, 1 + trial % 2), generator=gen).repeat_interleave(nb, dim=0)
+        kw = dict(num_beams=nb, max_length=4 + trial % 5, min_length=trial % 3, eos_token_id=1, pad_token_id=0)
+        ref = O.beam_search(toy_lm(table), prompt, **kw)
+        mine = generation.beam_search(gpu_lm(table, (V + 3) // 4 * 4), prompt.cuda(), kw["num_beams"], kw["max_length"],
+                                      kw["min_length"], 1, 0, V)
+        assert mine.cpu().tolist() == ref.tolist(), (trial, mine.tolist(), ref.tolist())
+        n_eos += int((ref == 1).any())
+    assert n_eos >= 8   # the finishing rules were exercised
+
+
+VQA_GEN_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vqa_gen_*.npz")))
+
+
+@pytest.mark.parametrize("mode", EXACT_MODES + ["bf16"])
+@pytest.mark.parametrize("path", VQA_GEN_CASES, ids=[os.path.basename(c)[:-4] for c in VQA_GEN_CASES])
+def test_vqa_generate_matches_oracle_and_reference_fixture(path, mode):
+    """BLIP_VQA.forward(train=False, inference='generate') on the HIP path (blip_vqa.py:127-147: encoder leg, question states
+    cached as cross-attention K/V per item, three beams, max_length 10, min_length 1, decoder over the whole prefix per step,
+    LM head at the last position, madtp_beam_topk) vs the oracle's restatement on the same inputs - identical token sequences in
+    the parity modes, also where [SEP] is biased into the candidate set (hypotheses finish early) - and vs the sequences the
+    reference itself produced where no finished hypothesis decides (see tests/test_oracle_golden.py)."""
+    from madtp_amd import build, hip, runtime, specs
+    from madtp_amd.blip_vqa import BLIP_VQA
+    from oracle import madtp_oracle as O
+    from tests.test_oracle_golden import VQA_GEN_COMPARABLE, vqa_gen_weights, vqa_inputs
+    build.build(verbose=False)
+    hip.load()
+    g = np.load(path)
+    name = os.path.basename(path)[:-4]
+    T = float(g["temperature"])
+    W = vqa_gen_weights(g)
+    model = BLIP_VQA(image_size=int(g["size"]), evaluate=True)
+    msg = model.load_state_dict(W, strict=False)
+    assert not msg.unexpected_keys, msg
+    model = model.eval().cuda()
+    images, ids, att = vqa_inputs(g)
+    with runtime.precision(mode), torch.no_grad():
+        out = model(images.cuda(), {"input_ids": ids.cuda(), "attention_mask": att.cuda()}, None, temperature=T, train=False,
+                    inference='generate')
+    out = out.cpu()
+    assert out.shape[0] == int(g["B"]) and out.shape[1] <= 10 and (out[:, 0] == 30522).all()
+    if mode == "bf16":
+        print(f"bf16 generate {name}: {out.tolist()}")
+        return
+    with torch.no_grad():
+        ref = O.blip_vqa_generate_forward(W, images, ids, att, T)
+    assert out.tolist() == ref.tolist(), (out.tolist(), ref.tolist())
+    for b in VQA_GEN_COMPARABLE[name]:
+        assert out[b].tolist() == g["sequences"][b].tolist()[:out.shape[1]]
+
+
 NLVR_PAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "nlvrpad_*.npz")))
 
 

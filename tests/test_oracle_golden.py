@@ -328,7 +328,7 @@ def test_oracle_vqa_rank_answer_matches_reference_fixture(path):
     dec_keys = {str(x) for x in g["decoder_state_dict_keys"]}
     mine = {x for x in shapes if x.startswith("text_decoder.")}
     assert mine == dec_keys, (sorted(mine - dec_keys)[:5], sorted(dec_keys - mine)[:5])
-    W = specs.synth_weights(shapes, int(g["seed"]))
+    W = vqa_decoder_weights(int(g["size"]), int(g["seed"]))
     assert torch.equal(W["text_decoder.cls.predictions.decoder.weight"], W["text_decoder.bert.embeddings.word_embeddings.weight"])
     images, ids, att, a_ids, a_att = vqa_rank_inputs(g)
     tr, det = {}, {}
@@ -402,3 +402,93 @@ def test_oracle_nlvr_pad_inside_topk_fixture(path):
     print(f"pads inside top-(k+1) at text layers {pad_layers}; ascending-order pairing differs from this build's at layers "
           f"{differ}; |dlogit| {np.abs(logits_asc.numpy() - logits.numpy()).max():.4f}")
     assert all(l > first for l in differ)
+
+
+# ---- beam-search generation (inference half; transformers 4.15 restated in oracle.beam_search) --------
+VQA_GEN_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vqa_gen_*.npz")))
+# items of a fixture whose winner ran to max_length on both sides (no finished hypothesis is involved in the choice): the
+# recording was made under transformers 5.15, whose re-implemented search scores FINISHED hypotheses differently from 4.15
+VQA_GEN_COMPARABLE = {"vqa_gen_b2": [0, 1], "vqa_gen_b3_T30_eos": [1]}
+
+
+import functools
+
+
+@functools.lru_cache(maxsize=3)
+def vqa_decoder_weights(size, seed):
+    """(generated once per session and shared by the rank / generate tests: ~360 M values, 15-20 s)"""
+    return specs.synth_weights(specs.blip_vqa_shapes(size, decoder=True), seed)
+
+
+def vqa_gen_weights(g):
+    W = dict(vqa_decoder_weights(int(g["size"]), int(g["seed"])))  # shallow copy: only the two bias entries are replaced
+    b = W["text_decoder.cls.predictions.bias"].clone()
+    b[102] += float(g["eos_bias"])
+    W["text_decoder.cls.predictions.bias"] = b
+    return specs.tie_keys(W)
+
+
+@pytest.mark.parametrize("path", VQA_GEN_CASES, ids=[os.path.basename(c)[:-4] for c in VQA_GEN_CASES])
+def test_oracle_vqa_generate_matches_reference_fixture(path):
+    """BLIP_VQA.forward(train=False, inference='generate') of the reference (blip_vqa.py:127-147) recorded with its own modules:
+    the first step's six best accumulated log-probabilities of every item (log-softmax + top-2k) and - where no finished
+    hypothesis decides - the generated sequences."""
+    g = np.load(path)
+    name = os.path.basename(path)[:-4]
+    images, ids, att = vqa_inputs(g)
+    tr = []
+    with torch.no_grad():
+        seq = O.blip_vqa_generate_forward(vqa_gen_weights(g), images, ids, att, float(g["temperature"]), num_beams=int(g["num_beams"]),
+                                          max_length=int(g["max_length"]), min_length=int(g["min_length"]), beam_trace=tr)
+    nb = int(g["num_beams"])
+    assert np.abs(tr[0]["next_scores"].numpy() - g["first_log_probs_top"][::nb]).max() < 1e-4
+    ref = g["sequences"]
+    for b in VQA_GEN_COMPARABLE[name]:
+        assert seq[b].tolist() == ref[b].tolist()[:seq.shape[1]], (b, seq[b].tolist(), ref[b].tolist())
+    # the decoder inputs of the reference's second step = the beams the first step kept (same rule in both library versions)
+    step1 = g["step_input_ids"][1][:, :2]
+    mine = torch.cat([torch.full((step1.shape[0], 1), O.BOS_TOKEN_ID), tr[0]["beam_tokens"].view(-1, 1)], 1).numpy()
+    live = [r for r in range(step1.shape[0]) if (r // nb) in VQA_GEN_COMPARABLE[name]]
+    assert np.array_equal(mine[live], step1[live])
+
+
+def toy_lm(table):
+    """step_fn of a first-order toy language model: next-token LOG-probabilities depend on the last token only."""
+    lt = torch.log(torch.tensor(table, dtype=torch.float32))
+    return lambda ids: lt[ids[:, -1]]
+
+
+TOY = [[0.2, 0.2, 0.2, 0.2, 0.2],            # after [PAD] (rows of finished items)
+       [0.2, 0.2, 0.2, 0.2, 0.2],            # after EOS (never expanded)
+       [0.01, 0.05, 0.04, 0.5, 0.4],         # after 2
+       [0.001, 0.9, 0.05, 0.03, 0.019],      # after 3
+       [0.001, 0.8, 0.1, 0.06, 0.039]]       # after 4
+
+
+def test_beam_search_hypothesis_bookkeeping_hand_worked():
+    """transformers 4.15 BeamSearchScorer / BeamHypotheses on a 5-token toy model (0 = PAD, 1 = EOS), worked by hand:
+    item 0 (prompt [2]): step 1 finishes [2,3] (-0.798 / 2 = -0.399) and [2,4] (-1.139 / 2 = -0.570); not done, because the best
+      candidate could still reach -0.798 / 2 > -0.570; step 2's best open candidate is -3.912 / 3 = -1.304 < -0.570 -> done;
+      answer [2,3,EOS].
+    item 1 (prompt [4]): EOS is the best first candidate -> hypothesis [4] (-0.223 / 1); step 1 finishes [4,3] (-2.918 / 2) and
+      the heuristic closes the item (worst finished == best possible); answer [4,EOS] padded to the batch length."""
+    prompt = torch.tensor([[2], [2], [4], [4]])
+    out = O.beam_search(toy_lm(TOY), prompt, num_beams=2, max_length=6, min_length=0, eos_token_id=1, pad_token_id=0)
+    assert out.tolist() == [[2, 3, 1], [4, 1, 0]]
+    # min_length = 2 forbids the EOS directly after the one-token prompt: item 1 must open with its best non-EOS token
+    out = O.beam_search(toy_lm(TOY), prompt, num_beams=2, max_length=6, min_length=2, eos_token_id=1, pad_token_id=0)
+    assert out[1].tolist()[:2] == [4, 2] and out[0].tolist()[:3] == [2, 3, 1]
+
+
+def test_beam_search_length_normalisation_and_eos_rank_rule():
+    """max_length = 3: [2,3]+EOS finishes with -1.204 / 2 = -0.602, the open beam [2,4,2] ends with -1.309 / 3 = -0.436 and wins
+    (sum_logprobs / len ** 1.0); an EOS that ranks below the top num_beams candidates is not a hypothesis."""
+    table = [[0.2] * 5, [0.2] * 5,
+             [0.0001, 0.15, 0.0499, 0.5, 0.3],
+             [0.0001, 0.6, 0.2999, 0.06, 0.04],
+             [0.0001, 0.05, 0.9, 0.03, 0.0199]]
+    tr = []
+    out = O.beam_search(toy_lm(table), torch.tensor([[2], [2]]), num_beams=2, max_length=3, min_length=0, eos_token_id=1,
+                        pad_token_id=0, trace=tr)
+    assert out.tolist() == [[2, 4, 2]]
+    assert tr[0]["next_tokens"][0].tolist()[:3] == [3, 4, 1] and tr[0]["beam_tokens"].tolist() == [3, 4]  # EOS third: skipped

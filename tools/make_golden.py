@@ -391,7 +391,71 @@ def vqa_rank_case(name, B, size, L, temperature, n_answers, answer_len, k_test, 
           f"log_probs_sum[0]={np.round(log_probs_sum[0].numpy(), 3).tolist()} ({dt:.1f}s)")
 
 
+def vqa_gen_case(name, B, size, L, temperature, eos_bias, seed=0, pad_tail=0):
+    """models/blip_vqa.py BLIP_VQA.forward(train=False, inference='generate') (:117-147): the reference's encoder leg and its
+    `text_decoder.generate(num_beams=3, max_length=10, min_length=1)` call, run under the installed transformers 5.15 with the
+    shims of ref_shims.enable_generate().  eos_bias is added to the LM head's bias of [SEP] (and its tied alias): with random
+    weights [SEP] never ranks among the 6 candidates otherwise and no hypothesis would ever finish before max_length.
+    NOTE the search is 5.15's re-implementation: finished hypotheses are normalised by (length incl. EOS - prompt length) where
+    4.15 (the reference's pinned version) divides by the length without the EOS, prompt included - the same number for this
+    one-token prompt - but a beam that reaches max_length is scored / (max_length - 1) instead of / max_length, and the
+    early-stop heuristic differs.  Recorded: the sequences and the per-step decoder inputs (which beams were expanded)."""
+    import models.blip_vqa as bv
+    from madtp_amd import harness, specs
+    ref_shims.patch_tokenizer(bv)
+    ref_shims.enable_generate()
+    model = bv.BLIP_VQA(image_size=size, evaluate=True, config={"sd_num": 100, "sd_dim": 768, "batch_size_train": 16})
+    model.eval()
+    sd = synth.fill_state_dict(model, seed)
+    sd["text_decoder.cls.predictions.bias"][102] += eos_bias
+    sd = specs.tie_keys(sd)
+    model.load_state_dict(sd, strict=True)
+    images = synth.synth_images(B, size, seed)
+    ids = synth.synth_token_ids(B, L, seed, first_id=None)
+    att = harness.padded_mask(B, L, pad_tail)
+    steps = []
+    orig = model.text_decoder.forward
+
+    import functools
+
+    @functools.wraps(orig)  # (generate() validates model_kwargs against forward's signature)
+    def tapped(*a, **k):
+        out = orig(*a, **k)
+        inp = k.get("input_ids", a[0] if a else None)
+        steps.append({"input_ids": inp.detach().clone(), "last_logits": out.logits[:, -1, :].detach().clone()})
+        return out
+    model.text_decoder.forward = tapped
+    raw = []
+    gen = model.text_decoder.generate
+
+    def tapped_gen(*a, **k):
+        out = gen(*a, **k)
+        raw.append(out.detach().clone())
+        return out
+    model.text_decoder.generate = tapped_gen
+    t0 = time.time()
+    with torch.no_grad():
+        answers = model(images, {"input_ids": ids, "attention_mask": att}, None, temperature=temperature, train=False,
+                        inference='generate')
+    dt = time.time() - t0
+    seqs = raw[0]
+    T = max(s["input_ids"].shape[1] for s in steps)
+    step_ids = np.zeros((len(steps), steps[0]["input_ids"].shape[0], T), dtype=np.int64)
+    for i, s_ in enumerate(steps):
+        step_ids[i, :, :s_["input_ids"].shape[1]] = s_["input_ids"].numpy()
+    out = {"kind": "vqa_gen", "B": B, "size": size, "L": L, "temperature": np.float64(temperature), "seed": seed,
+           "pad_tail": pad_tail, "eos_bias": np.float64(eos_bias), "num_beams": 3, "max_length": 10, "min_length": 1,
+           "sequences": seqs.numpy(), "step_input_ids": step_ids, "step_lens": np.array([s_["input_ids"].shape[1] for s_ in steps]),
+           "first_logits_sample": steps[0]["last_logits"][:, :64].numpy(),
+           "first_log_probs_top": torch.log_softmax(steps[0]["last_logits"], -1).topk(6, dim=1)[0].numpy(),
+           "transformers_version": np.array(__import__("transformers").__version__), "ref_seconds": dt}
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[{name}] T={temperature} eos_bias={eos_bias} sequences={seqs.tolist()} steps={len(steps)} ({dt:.1f}s)")
+
+
 CASES = {
+    "vqa_gen_b2": lambda: vqa_gen_case("vqa_gen_b2", 2, 224, 12, 0.0, 0.0),
+    "vqa_gen_b3_T30_eos": lambda: vqa_gen_case("vqa_gen_b3_T30_eos", 3, 224, 16, 30.0, 2.2, seed=1, pad_tail=3),
     "nlvr_b2_T1": lambda: nlvr_case("nlvr_b2_T1", 2, 224, 20, 1.0),
     "nlvr_b2_T5": lambda: nlvr_case("nlvr_b2_T5", 2, 224, 20, 5.0),
     "nlvr_b3_T30_pad": lambda: nlvr_case("nlvr_b3_T30_pad", 3, 224, 35, 30.0, pad_tail=3),

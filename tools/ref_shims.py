@@ -244,3 +244,27 @@ def fast_init():
     import timm.models.layers as tl  # the stand-in module installed by install()
     if hasattr(tl, "trunc_normal_"):
         tl.trunc_normal_ = same
+
+
+def enable_generate():
+    """Make the reference's `text_decoder.generate(...)` call sites (models/blip_vqa.py:134, models/blip.py:177,189) runnable
+    under the installed transformers (5.x): (a) since 4.50 `PreTrainedModel` no longer inherits `GenerationMixin`, so it is
+    appended to the bases of the reference's own `BertLMHeadModel`; (b) 5.x repeats EVERY tensor in model_kwargs num_beams times,
+    4.15's `_expand_inputs_for_generation` only input_ids / attention_mask / token_type_ids (the reference pre-expands
+    encoder_hidden_states itself, blip_vqa.py:128) - restated here; (c) FakeTokenizer.decode returns the ids.
+    The SEARCH that then runs is the installed library's re-implementation, not 4.15's (see oracle/madtp_oracle.py)."""
+    from transformers.generation import GenerationMixin
+    import models.med as med
+    if GenerationMixin not in med.BertLMHeadModel.__mro__:
+        med.BertLMHeadModel.__bases__ = med.BertLMHeadModel.__bases__ + (GenerationMixin,)
+
+    def _expand_415(expand_size=1, is_encoder_decoder=False, input_ids=None, **model_kwargs):
+        if expand_size > 1:
+            if input_ids is not None:
+                input_ids = input_ids.repeat_interleave(expand_size, dim=0)
+            for k in ("attention_mask", "token_type_ids"):
+                if model_kwargs.get(k) is not None:
+                    model_kwargs[k] = model_kwargs[k].repeat_interleave(expand_size, dim=0)
+        return input_ids, model_kwargs
+    GenerationMixin._expand_inputs_for_generation = staticmethod(_expand_415)
+    FakeTokenizer.decode = lambda self, ids, skip_special_tokens=True: [int(t) for t in ids]
