@@ -2,7 +2,7 @@
 tokens, the heaviest ragged compaction) - ViT on the image (:59), the MED text encoder in multimodal mode cross-attending to
 the pruned image tokens (:118-125) - and, with decoder=True, the answer decoder `text_decoder` (BertLMHeadModel, :53-55) run
 teacher-forced by rank_answer (:156-203; SURVEY.md 8(f) rank 4, inference half).  Same constructor arguments and sub-module
-names (checkpoint keys) as the reference.  Training and beam-search generation (:66-115, :127-148) are not implemented."""
+names (checkpoint keys) as the reference.  Beam-search generation (inference="generate", :127-147) goes through BertLMHeadModel.generate (madtp_amd/generation.py); training (:66-115) is not implemented."""
 import os
 
 import torch

@@ -125,6 +125,15 @@ TIED_KEYS = {"cls.predictions.decoder.weight": "bert.embeddings.word_embeddings.
              "cls.predictions.decoder.bias": "cls.predictions.bias"}
 
 
+def blip_decoder_shapes(img_size=384):
+    """models/blip.py BLIP_Decoder.__init__ :71-109: space_dict, visual_encoder, text_decoder (BertLMHeadModel)."""
+    sd = OrderedDict()
+    sd["space_dict"] = (SD_NUM, D)
+    sd.update(vit_shapes("visual_encoder.", img_size))
+    sd.update(lm_head_shapes("text_decoder."))
+    return sd
+
+
 def blip_vqa_shapes(img_size=480, decoder=False):
     """models/blip_vqa.py BLIP_VQA.__init__ :15-55: space_dict, visual_encoder, text_encoder and - decoder=True - the answer
     decoder `text_decoder` (:53-55) that rank_answer (:156-203) runs teacher-forced."""

@@ -231,3 +231,40 @@ def test_load_checkpoint_semantics(tmp_path):
     assert dst2.state_dict()["visual_encoder.pos_embed"].shape == (1, 577, 768)
     with pytest.raises(RuntimeError):
         load_checkpoint(dst2, "https://example.com/x.pth")
+
+
+@needs_ref
+def test_reference_blip_decoder_constructs_on_the_mirrors():
+    """models/blip.py BLIP_Decoder (the captioning model of compress_caption_dtp.py; the reference's own file) constructs on the
+    mirrors: state-dict keys equal the reference model's, and its `self.text_decoder.generate(...)` call site (:189-196) resolves
+    to the beam search of madtp_amd.bert.BertLMHeadModel with the keyword arguments the reference passes."""
+    out = _run(f"""
+        import sys, json, inspect, numpy as np
+        sys.path.insert(0, {ROOT!r} + "/tools")
+        import ref_shims
+        ref_shims.install(chdir=True, import_models=False)
+        ref_shims.fast_init()
+        import madtp_amd.dropin as dropin
+        dropin.install({REF!r})
+        import models.blip as blip
+        blip.init_tokenizer = lambda: ref_shims.FakeTokenizer()
+        assert blip.__file__.startswith({REF!r}), blip.__file__
+        import madtp_amd.vit, madtp_amd.bert as mb
+        model = blip.blip_decoder(pretrained='', image_size=224, vit='base', evaluate=True, config={{"sd_dim": 768, "sd_num": 100}})
+        assert type(model).__module__ == 'models.blip' and model.prompt_length == 4
+        assert isinstance(model.visual_encoder, madtp_amd.vit.VisionTransformer)
+        assert isinstance(model.text_decoder, mb.BertLMHeadModel)
+        params = set(inspect.signature(model.text_decoder.generate).parameters)
+        need = {{"input_ids", "max_length", "min_length", "num_beams", "eos_token_id", "pad_token_id", "repetition_penalty",
+                 "encoder_hidden_states", "encoder_attention_mask"}}
+        g = np.load({ROOT!r} + "/tests/golden/cap_gen_b2_T6.npz", allow_pickle=False)
+        ref_keys = [str(k) for k in g["state_dict_keys"]]
+        mine = sorted(model.state_dict().keys())
+        print(json.dumps({{"n": len(mine), "missing": sorted(set(ref_keys) - set(mine)), "extra": sorted(set(mine) - set(ref_keys)),
+                          "generate_args_missing": sorted(need - params)}}))
+        """)
+    import json
+    rep = json.loads(out.strip().splitlines()[-1])
+    assert all("position_ids" in k for k in rep["missing"]), rep["missing"][:10]
+    assert all("position_ids" in k for k in rep["extra"]), rep["extra"][:10]
+    assert rep["generate_args_missing"] == [] and rep["n"] > 300

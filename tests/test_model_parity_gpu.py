@@ -639,6 +639,43 @@ def test_vqa_generate_matches_oracle_and_reference_fixture(path, mode):
         assert out[b].tolist() == g["sequences"][b].tolist()[:out.shape[1]]
 
 
+CAP_GEN_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "cap_gen_*.npz")))
+
+
+@pytest.mark.parametrize("mode", EXACT_MODES + ["bf16"])
+@pytest.mark.parametrize("path", CAP_GEN_CASES, ids=[os.path.basename(c)[:-4] for c in CAP_GEN_CASES])
+def test_caption_generate_matches_reference_fixture(path, mode):
+    """BLIP_Decoder.generate(sample=False, num_beams=3) on the HIP path (models/blip.py:161-196, the evaluation call of
+    compress_caption_dtp.py:86): pruned ViT, image tokens cached as cross-attention K/V per image, beam search over the MED
+    decoder - the token sequences the reference itself generated (parity modes), the pruned ViT's token counts included."""
+    from madtp_amd import build, hip, runtime, synth
+    from madtp_amd.blip import BLIP_Decoder
+    from tests.test_oracle_golden import cap_gen_weights
+    build.build(verbose=False)
+    hip.load()
+    g = np.load(path)
+    model = BLIP_Decoder(image_size=int(g["size"]), evaluate=True)
+    msg = model.load_state_dict(cap_gen_weights(g), strict=False)
+    assert not msg.unexpected_keys and all("query_model" in x or "position_ids" in x for x in msg.missing_keys), msg
+    assert sorted(k for k in model.state_dict() if "position_ids" not in k) == \
+        sorted(str(k) for k in g["state_dict_keys"] if "position_ids" not in str(k))
+    model = model.eval().cuda()
+    images = synth.synth_images(int(g["B"]), int(g["size"]), int(g["seed"]))
+    with runtime.precision(mode), torch.no_grad():
+        out = model.generate(images.cuda(), sample=False, num_beams=int(g["num_beams"]), max_length=int(g["max_length"]),
+                             min_length=int(g["min_length"]), temperature=float(g["temperature"]))
+    out = out.cpu()
+    if mode == "bf16":
+        assert out.shape[0] == int(g["B"]) and out[:, :4].tolist() == g["sequences"][:, :4].tolist()
+        print(f"bf16 caption ids: {out.tolist()}")
+        return
+    from madtp_amd import harness
+    vtr = [None if b.last_prune is None else {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.last_prune.items()}
+           for b in model.visual_encoder.blocks]
+    assert harness.token_lengths(vtr, (int(g["size"]) // 16) ** 2 + 1) == g["vit_lens"].tolist()
+    assert out.tolist() == g["sequences"].tolist()
+
+
 NLVR_PAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "nlvrpad_*.npz")))
 
 

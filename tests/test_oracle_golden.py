@@ -492,3 +492,36 @@ def test_beam_search_length_normalisation_and_eos_rank_rule():
                         pad_token_id=0, trace=tr)
     assert out.tolist() == [[2, 4, 2]]
     assert tr[0]["next_tokens"][0].tolist()[:3] == [3, 4, 1] and tr[0]["beam_tokens"].tolist() == [3, 4]  # EOS third: skipped
+
+
+CAP_GEN_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "cap_gen_*.npz")))
+
+
+def cap_gen_weights(g):
+    W = specs.synth_weights(specs.blip_decoder_shapes(int(g["size"])), int(g["seed"]))
+    W["text_decoder.cls.predictions.bias"][102] += float(g["eos_bias"])
+    return specs.tie_keys(W)
+
+
+@pytest.mark.parametrize("path", CAP_GEN_CASES, ids=[os.path.basename(c)[:-4] for c in CAP_GEN_CASES])
+def test_oracle_caption_generate_matches_reference_fixture(path):
+    """models/blip.py BLIP_Decoder.generate(sample=False, num_beams=3) (:161-196; compress_caption_dtp.py:86) recorded from the
+    reference's own modules: state-dict keys, the pruned ViT's token counts, the prompt ids, the beams kept after the first step
+    and the generated sequences (both fixtures: the winner is the same under the 4.15 and the 5.15 scoring of finished
+    hypotheses - in cap_gen_b3_T30_eos every item closes with [SEP] right at min_length)."""
+    g = np.load(path)
+    shapes = specs.blip_decoder_shapes(int(g["size"]))
+    assert set(shapes) == {str(k) for k in g["state_dict_keys"]}
+    images = synth.synth_images(int(g["B"]), int(g["size"]), int(g["seed"]))
+    tr, vt = [], []
+    with torch.no_grad():
+        seq = O.blip_decoder_generate_forward(cap_gen_weights(g), images, float(g["temperature"]), num_beams=int(g["num_beams"]),
+                                              max_length=int(g["max_length"]), min_length=int(g["min_length"]), beam_trace=tr,
+                                              trace=vt)
+    from madtp_amd import harness
+    assert harness.token_lengths(vt, (int(g["size"]) // 16) ** 2 + 1) == g["vit_lens"].tolist()
+    assert g["prompt_input_ids"][0].tolist() == [O.BOS_TOKEN_ID] + list(O.CAPTION_PROMPT_IDS[1:-1])
+    if float(g["eos_bias"]) == 0.0:
+        assert np.abs(tr[0]["next_scores"].numpy() - g["first_log_probs_top"][::int(g["num_beams"])]).max() < 1e-4
+    assert np.array_equal(g["second_step_input_ids"][:, -1], tr[0]["beam_tokens"].numpy())
+    assert seq.tolist() == g["sequences"].tolist()

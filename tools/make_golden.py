@@ -453,7 +453,63 @@ def vqa_gen_case(name, B, size, L, temperature, eos_bias, seed=0, pad_tail=0):
     print(f"[{name}] T={temperature} eos_bias={eos_bias} sequences={seqs.tolist()} steps={len(steps)} ({dt:.1f}s)")
 
 
+def cap_gen_case(name, B, size, temperature, eos_bias, max_length, min_length, seed=0):
+    """models/blip.py BLIP_Decoder.generate(sample=False, num_beams=3, ...) (:161-202, the evaluation call of
+    compress_caption_dtp.py:86) of the reference's own modules, under the shims / caveats of vqa_gen_case (the search that runs
+    is transformers 5.15's; with the 4-token prompt its finished-hypothesis normalisation differs from 4.15's)."""
+    import models.blip as blip
+    from madtp_amd import specs
+    ref_shims.patch_tokenizer(blip)
+    ref_shims.enable_generate()
+    model = blip.BLIP_Decoder(image_size=size, evaluate=True, config={"sd_num": 100, "sd_dim": 768})
+    model.eval()
+    sd = synth.fill_state_dict(model, seed)
+    sd["text_decoder.cls.predictions.bias"][102] += eos_bias
+    sd = specs.tie_keys(sd)
+    model.load_state_dict(sd, strict=True)
+    images = synth.synth_images(B, size, seed)
+    steps, raw = [], []
+    orig = model.text_decoder.forward
+    import functools
+
+    @functools.wraps(orig)
+    def tapped(*a, **k):
+        out = orig(*a, **k)
+        inp = k.get("input_ids", a[0] if a else None)
+        steps.append({"input_ids": inp.detach().clone(), "last_logits": out.logits[:, -1, :].detach().clone()})
+        return out
+    model.text_decoder.forward = tapped
+    gen = model.text_decoder.generate
+
+    def tapped_gen(*a, **k):
+        out = gen(*a, **k)
+        raw.append(out.detach().clone())
+        return out
+    model.text_decoder.generate = tapped_gen
+    lens_v, hooks = [], []
+    for blk in model.visual_encoder.blocks:
+        hooks.append(blk.register_forward_hook(lambda m, a, o: lens_v.append(o.shape[1])))
+    t0 = time.time()
+    with torch.no_grad():
+        model.generate(images, sample=False, num_beams=3, max_length=max_length, min_length=min_length, temperature=temperature)
+    dt = time.time() - t0
+    for h in hooks:
+        h.remove()
+    seqs = raw[0]
+    keys = sorted(sd.keys())
+    out = {"kind": "cap_gen", "B": B, "size": size, "temperature": np.float64(temperature), "seed": seed,
+           "eos_bias": np.float64(eos_bias), "num_beams": 3, "max_length": max_length, "min_length": min_length,
+           "sequences": seqs.numpy(), "vit_lens": np.array(lens_v), "prompt_input_ids": steps[0]["input_ids"].numpy(),
+           "first_log_probs_top": torch.log_softmax(steps[0]["last_logits"], -1).topk(6, dim=1)[0].numpy(),
+           "second_step_input_ids": steps[1]["input_ids"].numpy(), "state_dict_keys": np.array(keys),
+           "transformers_version": np.array(__import__("transformers").__version__), "ref_seconds": dt}
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[{name}] T={temperature} eos_bias={eos_bias} vit_lens={lens_v} sequences={seqs.tolist()} steps={len(steps)} ({dt:.1f}s)")
+
+
 CASES = {
+    "cap_gen_b2_T6": lambda: cap_gen_case("cap_gen_b2_T6", 2, 224, 6.0, 0.0, 12, 5),
+    "cap_gen_b3_T30_eos": lambda: cap_gen_case("cap_gen_b3_T30_eos", 3, 224, 30.0, 2.4, 12, 5, seed=1),
     "vqa_gen_b2": lambda: vqa_gen_case("vqa_gen_b2", 2, 224, 12, 0.0, 0.0),
     "vqa_gen_b3_T30_eos": lambda: vqa_gen_case("vqa_gen_b3_T30_eos", 3, 224, 16, 30.0, 2.2, seed=1, pad_tail=3),
     "nlvr_b2_T1": lambda: nlvr_case("nlvr_b2_T1", 2, 224, 20, 1.0),

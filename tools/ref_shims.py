@@ -73,9 +73,17 @@ class FakeTokenizer:
         def to(self, device):
             return FakeTokenizer._Batch({k: v.to(device) for k, v in self.items()})
 
+    # the one string the reference tokenises itself: BLIP_Decoder's prompt (models/blip.py:109,170); bert-base-uncased ids
+    STRINGS = {'a picture of ': [101, 1037, 3861, 1997, 102]}
+
     def __call__(self, text, **kw):
         if isinstance(text, dict):
             return FakeTokenizer._Batch({k: v.clone() for k, v in text.items()})
+        if isinstance(text, str) and text in self.STRINGS:
+            return FakeTokenizer._Batch({"input_ids": list(self.STRINGS[text])})
+        if isinstance(text, (list, tuple)) and all(t in self.STRINGS for t in text):
+            ids = torch.tensor([self.STRINGS[t] for t in text], dtype=torch.long)
+            return FakeTokenizer._Batch({"input_ids": ids, "attention_mask": torch.ones_like(ids)})
         raise TypeError("FakeTokenizer expects {'input_ids','attention_mask'} tensors")
 
 
