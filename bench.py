@@ -109,7 +109,9 @@ def main():
                     help="BASELINE.json configuration (default: the headline)")
     ap.add_argument("--batch", type=int, default=0, help="samples per GPU (0 = the configuration's BASELINE batch)")
     ap.add_argument("--image-size", type=int, default=0, help="retrieval only: 224 (default) or 384")
-    ap.add_argument("--parity-steps", type=int, default=10, help="timed steps of the parity_mode leg (f16x3 precision)")
+    ap.add_argument("--parity-steps", type=int, default=30, help="timed steps of the parity_mode leg (f16x3 precision)")
+    ap.add_argument("--parity-inflight", type=int, default=3, help="forwards in flight in the parity_mode leg (when the headline "
+                    "leg runs more than one in flight)")
     ap.add_argument("--parity-batch", type=int, default=0, help="samples of the index_match check (0 = --batch for nlvr, 8 else)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "off"], help="roofline.traffic from live rocprofv3 --pmc passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -155,13 +157,15 @@ def main():
     runner = None
     if args.inflight > 1:
         from madtp_amd.pipeline import InflightRunner
-        runner = InflightRunner(w, args.inflight, T, B, "cuda", seed0=rank * args.inflight,
-                                models=[model] + [w.build("cuda") for _ in range(args.inflight - 1)])
+        # one runner for both legs: the headline uses the first args.inflight workers, the parity_mode leg args.parity_inflight
+        n_slots = args.inflight if args.no_parity else max(args.inflight, args.parity_inflight)
+        runner = InflightRunner(w, n_slots, T, B, "cuda", seed0=rank * n_slots,
+                                models=[model] + [w.build("cuda") for _ in range(n_slots - 1)])
         runner.inputs[0] = inp
 
     def run_steps(n):  # n whole forwards: serial on the current stream, or spread over the in-flight workers
         if runner is not None:
-            runner.run(n)
+            runner.run(n, workers=args.inflight)
         else:
             for _ in range(n):
                 step()
@@ -171,7 +175,7 @@ def main():
         for _ in range(args.warmup):
             step()
         if runner is not None:
-            runner.run(max(args.warmup, 3) * args.inflight)  # every replica prepares its weights, grows its workspace and its
+            runner.run(max(args.warmup, 3) * args.inflight, workers=args.inflight)  # every replica prepares its weights, grows its workspace and its
             #                                                  stream's allocator pool (>= 3 forwards per worker)
             # the serial loop of the same K steps, for the record (latency of one forward; rounds 1-2 reported this as `value`)
             torch.cuda.synchronize()
@@ -267,16 +271,22 @@ def main():
         # parity_mode leg: the SAME workload timed in the precision mode that carries the parity claim (f16x3: fp32-accurate
         # GEMMs on the f16 MFMA, everything else the fp32 mode's kernels), same barrier / max-over-ranks protocol
         pm = "f16x3"
+        # three forwards in flight where the headline takes two: the parity mode's kernels are longer, its host-side gaps the
+        # same (measured, NLVR: 9.2 k serial, 10.4 k with two, 10.9 k with three, 10.5 k with four in flight)
+        pn = runner.n if runner is not None else 1
         with runtime.precision(pm), torch.no_grad():
             for _ in range(2):
                 step()
             if runner is not None:
-                runner.run(2 * args.inflight)
+                runner.run(3 * pn, workers=pn)
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
             t2 = time.perf_counter()
-            run_steps(args.parity_steps)
+            if runner is not None:
+                runner.run(args.parity_steps, workers=pn)
+            else:
+                run_steps(args.parity_steps)
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
@@ -285,6 +295,7 @@ def main():
         pel = mdist.max_over_ranks(pel, device="cuda")
         out["parity_mode"] = {"precision": pm, "value": round(images_per_step * args.parity_steps / pel, 1), "unit": "images/s",
                               "ms_per_step": round(1e3 * pel / args.parity_steps, 3), "steps": args.parity_steps,
+                              "inflight_per_gpu": pn,
                               "what": "same workload, every Linear as 3 f16 MFMA products of f16-split operands (fp32-accurate), "
                                       "attention / LayerNorm / scores on the exact-f32 kernels; kept sets vs the oracle below"}
     if rank == 0 and world == 1:

@@ -102,4 +102,10 @@ def test_inflight_runner_equals_serial_forwards(name, B, mode):
                 for a, b in zip(_flat(runner.last[i]), serial[i]):
                     assert torch.equal(a, b), (steps, i, (a - b).abs().max().item())
                 assert w.lens(runner.models[i]) == lens[i]
+        # a subset of the slots (bench.py: headline on two, parity mode on three workers of ONE runner): the idle slot keeps its output
+        keep = [t.clone() for t in _flat(runner.last[1])]
+        runner.last[0] = None
+        runner.run(3, workers=1)
+        assert all(torch.equal(a, b) for a, b in zip(_flat(runner.last[0]), serial[0]))
+        assert all(torch.equal(a, b) for a, b in zip(_flat(runner.last[1]), keep))
     assert runtime.get_precision() == "bf16"  # the caller's (default) mode is untouched outside the context
