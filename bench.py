@@ -102,7 +102,7 @@ def main():
     from madtp_amd import workloads
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=24)  # a multiple of the 2 / 3 forwards in flight: equal shares per worker
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3"])
     ap.add_argument("--config", default="nlvr", choices=list(workloads.NAMES),
@@ -144,7 +144,7 @@ def main():
 
     w = workloads.get(args.config, **({"size": args.image_size} if (args.image_size and args.config == "retrieval") else {}))
     if args.inflight <= 0:
-        args.inflight = w.default_inflight if args.precision == "bf16" else 1  # (the parity modes' kernels fill the chip)
+        args.inflight = w.default_inflight  # (a --precision f16x3 / fp32 run: 9.2 k serial, 10.4 / 10.9 k with two / three in flight)
     strong = args.config == "retrieval" and not args.batch  # BASELINE config 3: a GLOBAL batch of 128 over the ranks
     B = args.batch or (max(1, w.default_batch // world) if strong else w.default_batch)
     T, calib = configs.temperature_for(args.config, args.batch or w.default_batch, w.p)

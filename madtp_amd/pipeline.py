@@ -8,13 +8,15 @@ text encoder.  Each in-flight forward gets its own host thread, HIP stream, scra
 deterministic weights; per-module records such as `last_prune` stay private to a replica); the per-layer host read of k spins
 inside the library with the GIL released, the k hand-over slots are claimed per call (csrc/prune.hip), and no kernel of the
 path waits on another workgroup being resident, so concurrent streams cannot deadlock each other.
-Measured on MI355X (profiles/r03_inflight.txt, same box per line pair): NLVR2 headline 19.4-19.8 k -> 21.1-23.2 k images/s
-with two forwards in flight (three: slower - the vision encoders only share the CUs), retrieval 17.6 k -> 22.8-23.3 k,
-BLIP-VQA 3.3 k -> 3.9-4.3 k, CLIP (two chip-filling towers, nothing to hide) 17.6 k -> 13-15 k: bench.py takes 2 in flight
-except for CLIP.  Two details matter: (1) the workers run the encoder-level C entry points (madtp_vit_encoder /
-madtp_bert_encoder) - on the per-layer Python path their progress hinges on GIL hand-overs and the result swings between
-17 k and 22 k from run to run; (2) a host lock that keeps the workers' vision encoders from overlapping (forced
-anti-phase) was tried and dropped: no gain on NLVR, retrieval 22.8 k -> 14.5 k.
+Measured on MI355X (profiles/r03_inflight.txt, same box per line group; final figures in (i)): NLVR2 headline 19-20 k serial
+-> 22.6-23.1 k images/s with two and 23.8-24.2 k with THREE forwards in flight (four: 21.6-22.5 k), retrieval 17.5 k -> 27.2 k
+with three, BLIP-VQA 3.3 k -> 4.7 k with three, CLIP (two chip-filling towers) 17.1-18.0 k -> 15.9-22.8 k with two from run to run
+(three: 15 k): bench.py takes 3 in flight, 1 for CLIP.  Three details matter: (1) the workers run the encoder-level C entry points
+(madtp_vit_encoder / madtp_bert_encoder) - on the per-layer Python path their progress hinges on GIL hand-overs and the result
+swings between 17 k and 22 k from run to run; (2) worker 0's stream has HIGH priority, the others normal: with equal
+priorities three in flight give 20.7 k (the forwards contend kernel by kernel), with one preferred stream 24 k; (3) a host lock
+that keeps the workers' vision encoders from overlapping (forced anti-phase) was tried and dropped: no gain on NLVR, retrieval
+22.8 k -> 14.5 k.
 """
 import threading
 

@@ -66,7 +66,9 @@ class Workload:
     images_per_sample = 1
     default_batch = 64
     p = 0.5
-    default_inflight = 2  # forwards in flight per GPU in bench.py (madtp_amd/pipeline.py); measured per configuration
+    # forwards in flight per GPU in bench.py (madtp_amd/pipeline.py); measured per configuration with worker 0 on a high-priority
+    # stream (profiles/r03_inflight.txt (i)): NLVR 22.6-23.1 k with two, 23.8-24.2 k with three, 21.6-22.5 k with four
+    default_inflight = 3
 
     def build(self, device="cuda"): raise NotImplementedError
     def inputs(self, B, seed=0, device="cuda"): raise NotImplementedError
@@ -199,7 +201,7 @@ class Vqa(Workload):
 class Clip(Workload):
     name, default_batch, p = "clip", 128, 0.5
     size, ctx = 224, 77
-    default_inflight = 1  # both towers fill the chip: a second forward in flight only shares the CUs (17.6 k -> 13-15 k images/s)
+    default_inflight = 1  # both towers fill the chip: 17.1-18.0 k serial; two in flight gave 15.9 k to 22.8 k from run to run, three 15 k
 
     def build(self, device="cuda"):
         from .clip_model import build_model
