@@ -102,15 +102,15 @@ def main():
     from madtp_amd import workloads
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)  # a multiple of the 2 / 3 forwards in flight: equal shares per worker
+    ap.add_argument("--steps", type=int, default=48)  # a multiple of the 2 / 3 / 4 forwards in flight (equal shares per worker; 12 forwards each: the ramp-up and the tail of the pipeline stay small)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3"])
     ap.add_argument("--config", default="nlvr", choices=list(workloads.NAMES),
                     help="BASELINE.json configuration (default: the headline)")
     ap.add_argument("--batch", type=int, default=0, help="samples per GPU (0 = the configuration's BASELINE batch)")
     ap.add_argument("--image-size", type=int, default=0, help="retrieval only: 224 (default) or 384")
-    ap.add_argument("--parity-steps", type=int, default=30, help="timed steps of the parity_mode leg (f16x3 precision)")
-    ap.add_argument("--parity-inflight", type=int, default=3, help="forwards in flight in the parity_mode leg (when the headline "
+    ap.add_argument("--parity-steps", type=int, default=32, help="timed steps of the parity_mode leg (f16x3 precision)")
+    ap.add_argument("--parity-inflight", type=int, default=4, help="forwards in flight in the parity_mode leg (when the headline "
                     "leg runs more than one in flight)")
     ap.add_argument("--parity-batch", type=int, default=0, help="samples of the index_match check (0 = --batch for nlvr, 8 else)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "off"], help="roofline.traffic from live rocprofv3 --pmc passes")
@@ -271,8 +271,7 @@ def main():
         # parity_mode leg: the SAME workload timed in the precision mode that carries the parity claim (f16x3: fp32-accurate
         # GEMMs on the f16 MFMA, everything else the fp32 mode's kernels), same barrier / max-over-ranks protocol
         pm = "f16x3"
-        # three forwards in flight where the headline takes two: the parity mode's kernels are longer, its host-side gaps the
-        # same (measured, NLVR: 9.2 k serial, 10.4 k with two, 10.9 k with three, 10.5 k with four in flight)
+        # (measured, NLVR f16x3: 9.2 k serial, 10.4 k with two, 10.9 k with three, 11.3 k with four forwards in flight)
         pn = runner.n if runner is not None else 1
         with runtime.precision(pm), torch.no_grad():
             for _ in range(2):

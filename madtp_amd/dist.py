@@ -44,7 +44,7 @@ def gpu_local_cpus(device_index):
         return None
 
 
-MIN_CORES_PER_RANK = 4  # bench.py runs two in-flight worker threads next to the main thread
+MIN_CORES_PER_RANK = 6  # bench.py runs four in-flight worker threads next to the main thread
 
 
 def pin_rank_to_cores(local_rank, local_world, device_index=None, cpus_of_gpu=None):

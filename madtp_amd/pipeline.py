@@ -11,9 +11,10 @@ path waits on another workgroup being resident, so concurrent streams cannot dea
 Measured on MI355X (profiles/r03_inflight.txt, same box per line group; final figures in (i)): NLVR2 headline 19-20 k serial
 -> 22.6-23.1 k images/s with two and 23.8-24.2 k with THREE forwards in flight (four: 21.6-22.5 k), retrieval 17.5 k -> 27.2 k
 with three, BLIP-VQA 3.3 k -> 4.7 k with three, CLIP (two chip-filling towers) 17.1-18.0 k -> 15.9-22.8 k with two from run to run
-(three: 15 k): bench.py takes 3 in flight, 1 for CLIP.  Three details matter: (1) the workers run the encoder-level C entry points
+(three: 15 k): (final: FOUR in flight, two of them on high-priority streams: NLVR 25.1-25.5 k, retrieval 27.5-29.0 k, VQA 4.75 k)
+bench.py takes 4 in flight, 1 for CLIP.  Three details matter: (1) the workers run the encoder-level C entry points
 (madtp_vit_encoder / madtp_bert_encoder) - on the per-layer Python path their progress hinges on GIL hand-overs and the result
-swings between 17 k and 22 k from run to run; (2) worker 0's stream has HIGH priority, the others normal: with equal
+swings between 17 k and 22 k from run to run; (2) half of the workers' streams have HIGH priority, the others normal: with equal
 priorities three in flight give 20.7 k (the forwards contend kernel by kernel), with one preferred stream 24 k; (3) a host lock
 that keeps the workers' vision encoders from overlapping (forced anti-phase) was tried and dropped: no gain on NLVR, retrieval
 22.8 k -> 14.5 k.
@@ -35,10 +36,16 @@ class InflightRunner:
         self.models = list(models) if models is not None else [workload.build(self.device) for _ in range(self.n)]
         self.inputs = [workload.inputs(batch, seed=seed0 + i) for i in range(self.n)]
         import os
-        # stream priorities: worker 0 high, the others normal (MADTP_INFLIGHT_PRIO="p0,p1,..." overrides).  Measured at the headline
-        # (profiles/r03_inflight.txt (e)): equal priorities 20.9-22.2 k images/s, (high, normal) 22.7-22.8 k on the same box - with
-        # one stream preferred the two forwards settle into a stable interleave instead of contending kernel by kernel
-        prio = [int(x) for x in os.environ.get("MADTP_INFLIGHT_PRIO", "-1").split(",") if x.strip()]
+        # stream priorities: the first n // 2 workers (at least one) HIGH, the others normal (HIP has these two levels;
+        # MADTP_INFLIGHT_PRIO="p0,p1,..." overrides).  Measured at the headline (profiles/r03_inflight.txt (e), (i), (j)): with equal
+        # priorities the forwards contend kernel by kernel (three in flight: 20.7 k images/s), with preferred streams they settle
+        # into a stable interleave: two (h,n) 22.6-23.1 k, three (h,n,n) 23.8-24.5 k, four (h,h,n,n) 25.1-25.5 k, four (h,n,n,n)
+        # 21.6-22.5 k, five (h,h,n,n,n) 24.1-24.3 k, six (h,h,h,n,n,n) 22.0 k
+        env = os.environ.get("MADTP_INFLIGHT_PRIO", "")
+        if env.strip():
+            prio = [int(x) for x in env.split(",") if x.strip()]
+        else:
+            prio = [-1] * max(1, self.n // 2)
         self.streams = [torch.cuda.Stream(device=self.device, priority=(prio[i] if i < len(prio) else 0)) for i in range(self.n)]
         self.errors = []
         self.last = [None] * self.n  # output of each worker's most recent step

@@ -66,9 +66,10 @@ class Workload:
     images_per_sample = 1
     default_batch = 64
     p = 0.5
-    # forwards in flight per GPU in bench.py (madtp_amd/pipeline.py); measured per configuration with worker 0 on a high-priority
-    # stream (profiles/r03_inflight.txt (i)): NLVR 22.6-23.1 k with two, 23.8-24.2 k with three, 21.6-22.5 k with four
-    default_inflight = 3
+    # forwards in flight per GPU in bench.py (madtp_amd/pipeline.py: half of the workers on high-priority streams); measured per
+    # configuration (profiles/r03_inflight.txt (i), (j)): NLVR 22.6-23.1 k with two, 23.8-24.5 k with three, 25.1-25.5 k with four,
+    # 24.1-24.3 k with five
+    default_inflight = 4
 
     def build(self, device="cuda"): raise NotImplementedError
     def inputs(self, B, seed=0, device="cuda"): raise NotImplementedError
