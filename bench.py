@@ -127,12 +127,18 @@ def main():
     world, rank, local_rank = mdist.env_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    mdist.init("nccl")  # "nccl" is RCCL on ROCm; no-op for a single process
+    # MADTP_BENCH_ONE_GPU=1 (rehearsal on a one-GPU box: tools/bench_rehearsal.sh): all ranks share GPU 0 and reduce over gloo -
+    # RCCL refuses two ranks on one device - so that the multi-rank code path of this file runs on hardware before the driver's
+    # 8-GPU run; the figures of such a run mean nothing.
+    one_gpu = world > 1 and os.environ.get("MADTP_BENCH_ONE_GPU") == "1"
+    gpu_index = 0 if one_gpu else local_rank
+    red_dev = "cpu" if one_gpu else "cuda"
+    torch.cuda.set_device(gpu_index)
+    mdist.init("gloo" if one_gpu else "nccl")  # "nccl" is RCCL on ROCm; no-op for a single process
     dist = torch.distributed if world > 1 else None
 
     if world > 1:  # each rank's host thread (k hand-over spin, launches) on its own cores, near its GPU
-        mdist.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device_index=local_rank)
+        mdist.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device_index=gpu_index)
     from madtp_amd import build, configs, hip, runtime
     if local_rank == 0:  # one builder per NODE (the prebuilt .so normally travels with the snapshot: no-op); the others wait
         build.build(verbose=False)
@@ -208,7 +214,7 @@ def main():
             torch.cuda.synchronize()
             instr_elapsed = time.perf_counter() - t1
             prof_rows = hip.profile_end()
-    elapsed = mdist.max_over_ranks(elapsed, device="cuda")
+    elapsed = mdist.max_over_ranks(elapsed, device=red_dev)
 
     images_per_step = w.images_per_sample * B * world
     value = images_per_step * args.steps / elapsed
@@ -291,7 +297,7 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             pel = time.perf_counter() - t2
-        pel = mdist.max_over_ranks(pel, device="cuda")
+        pel = mdist.max_over_ranks(pel, device=red_dev)
         out["parity_mode"] = {"precision": pm, "value": round(images_per_step * args.parity_steps / pel, 1), "unit": "images/s",
                               "ms_per_step": round(1e3 * pel / args.parity_steps, 3), "steps": args.parity_steps,
                               "inflight_per_gpu": pn,
