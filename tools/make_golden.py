@@ -512,6 +512,7 @@ CASES = {
     "cap_gen_b3_T30_eos": lambda: cap_gen_case("cap_gen_b3_T30_eos", 3, 224, 30.0, 2.4, 12, 5, seed=1),
     "vqa_gen_b2": lambda: vqa_gen_case("vqa_gen_b2", 2, 224, 12, 0.0, 0.0),
     "vqa_gen_b3_T30_eos": lambda: vqa_gen_case("vqa_gen_b3_T30_eos", 3, 224, 16, 30.0, 2.2, seed=1, pad_tail=3),
+    "vqa_gen_b4_eos26": lambda: vqa_gen_case("vqa_gen_b4_eos26", 4, 224, 12, 0.0, 2.6, seed=2),
     "nlvr_b2_T1": lambda: nlvr_case("nlvr_b2_T1", 2, 224, 20, 1.0),
     "nlvr_b2_T5": lambda: nlvr_case("nlvr_b2_T5", 2, 224, 20, 5.0),
     "nlvr_b3_T30_pad": lambda: nlvr_case("nlvr_b3_T30_pad", 3, 224, 35, 30.0, pad_tail=3),
