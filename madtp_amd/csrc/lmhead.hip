@@ -15,40 +15,52 @@ constexpr int LM_THREADS = 256;
 struct RowStats { float mx, sum_z, sum_e; };
 
 // block-wide reductions through a 4-entry LDS scratch (one slot per wave); every thread gets the result
+template <int NT = LM_THREADS>
 __device__ __forceinline__ float block_max(float v, float* scratch) {
     v = wave_max(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
-    return fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    float r = scratch[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) r = fmaxf(r, scratch[w]);
+    return r;
 }
+template <int NT = LM_THREADS>
 __device__ __forceinline__ float block_sum(float v, float* scratch) {
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    if constexpr (NT == 256) return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);  // (the order lm_loss was pinned with)
+    float r = scratch[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) r += scratch[w];
+    return r;
 }
 
 // max, sum of scores and sum of exp(score - max) of one row of V scores (row is 16-byte aligned, V need not be a multiple of 4)
+template <int NT = LM_THREADS>
 __device__ __forceinline__ RowStats row_stats(const float* row, int V, float* scratch) {
     const int V4 = V >> 2, tid = threadIdx.x;
     float mx = -INFINITY, sz = 0.f;
-    for (int i = tid; i < V4; i += LM_THREADS) {
+#pragma unroll 8
+    for (int i = tid; i < V4; i += NT) {
         const float4 v = ((const float4*)row)[i];
         mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
         sz += (v.x + v.y) + (v.z + v.w);
     }
-    for (int i = (V4 << 2) + tid; i < V; i += LM_THREADS) { mx = fmaxf(mx, row[i]); sz += row[i]; }
-    mx = block_max(mx, scratch);
-    sz = block_sum(sz, scratch);
+    for (int i = (V4 << 2) + tid; i < V; i += NT) { mx = fmaxf(mx, row[i]); sz += row[i]; }
+    mx = block_max<NT>(mx, scratch);
+    sz = block_sum<NT>(sz, scratch);
     float se = 0.f;
-    for (int i = tid; i < V4; i += LM_THREADS) {
+#pragma unroll 8
+    for (int i = tid; i < V4; i += NT) {
         const float4 v = ((const float4*)row)[i];
         se += (expf(v.x - mx) + expf(v.y - mx)) + (expf(v.z - mx) + expf(v.w - mx));
     }
-    for (int i = (V4 << 2) + tid; i < V; i += LM_THREADS) se += expf(row[i] - mx);
-    se = block_sum(se, scratch);
+    for (int i = (V4 << 2) + tid; i < V; i += NT) se += expf(row[i] - mx);
+    se = block_sum<NT>(se, scratch);
     return {mx, sz, se};
 }
 
@@ -88,32 +100,36 @@ __global__ __launch_bounds__(LM_THREADS) void token_prob_kernel(const float* log
 // One workgroup per batch item: log-sum-exp of its num_beams rows (row_stats), then every thread scans a strided share of the
 // num_beams * V candidates keeping its n_top best in its own LDS slice, then n_top rounds of a block-wide arg-max (ties: the
 // lower flat index) emit the winners in descending order.  HBM-bound: num_beams * V * 4 bytes per item, read twice from L2/HBM.
-constexpr int BT_MAX_TOP = 16, BT_MAX_BEAMS = 8;
+// 1024 threads per item: the launch has only B workgroups (32 for a caption batch), so the memory-level parallelism has to come
+// from inside the workgroup - with 256 threads and one float4 in flight per thread the same kernel took 197 us per step.
+constexpr int BT_MAX_TOP = 16, BT_MAX_BEAMS = 8, BT_THREADS = 1024;
 
-__global__ __launch_bounds__(LM_THREADS) void beam_topk_kernel(const float* logits, int ld, int V, const float* beam_scores,
+__global__ __launch_bounds__(BT_THREADS) void beam_topk_kernel(const float* logits, int ld, int V, const float* beam_scores,
                                                                int num_beams, int n_top, int suppress, float* out_scores,
                                                                int32_t* out_index) {
-    __shared__ float scratch[4];
+    __shared__ float scratch[BT_THREADS / 64];
     __shared__ float lse_s[BT_MAX_BEAMS];
-    __shared__ float c_val[LM_THREADS * BT_MAX_TOP];
-    __shared__ int c_idx[LM_THREADS * BT_MAX_TOP];
-    __shared__ float w_val[4];
-    __shared__ int w_idx[4];
+    extern __shared__ __attribute__((aligned(16))) char bt_dyn[];  // [BT_THREADS][n_top] values, then [BT_THREADS][n_top] indices
+    float* c_val = (float*)bt_dyn;
+    int* c_idx = (int*)(c_val + BT_THREADS * n_top);
+    __shared__ float w_val[BT_THREADS / 64];
+    __shared__ int w_idx[BT_THREADS / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int j = 0; j < num_beams; ++j) {
-        const RowStats st = row_stats(logits + ((size_t)b * num_beams + j) * ld, V, scratch);
+        const RowStats st = row_stats<BT_THREADS>(logits + ((size_t)b * num_beams + j) * ld, V, scratch);
         if (tid == 0) lse_s[j] = st.mx + logf(st.sum_e);
     }
     __syncthreads();
-    float* mv = c_val + tid * BT_MAX_TOP;
-    int* mi = c_idx + tid * BT_MAX_TOP;
+    float* mv = c_val + tid * n_top;
+    int* mi = c_idx + tid * n_top;
     for (int q = 0; q < n_top; ++q) { mv[q] = -INFINITY; mi[q] = 0x7fffffff; }
     float cur_min = -INFINITY;
     int min_pos = 0, filled = 0;
     for (int j = 0; j < num_beams; ++j) {
         const float* row = logits + ((size_t)b * num_beams + j) * ld;
         const float add = beam_scores[b * num_beams + j], lse = lse_s[j];
-        for (int t = tid; t < V; t += LM_THREADS) {
+#pragma unroll 4
+        for (int t = tid; t < V; t += BT_THREADS) {
             float v = (row[t] - lse) + add;
             if (t == suppress) v = -INFINITY;
             if (!(v > -INFINITY)) continue;  // -inf and NaN never become candidates
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(LM_THREADS) void beam_topk_kernel(const float* logi
         if ((tid & 63) == 0) { w_val[tid >> 6] = bv; w_idx[tid >> 6] = bi; }
         __syncthreads();
         bv = w_val[0]; bi = w_idx[0];
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < BT_THREADS / 64; ++w)
             if (w_val[w] > bv || (w_val[w] == bv && w_idx[w] < bi)) { bv = w_val[w]; bi = w_idx[w]; }
         if (tid == 0) {
             out_scores[(size_t)b * n_top + r] = bv;
@@ -163,8 +179,9 @@ extern "C" int madtp_beam_topk(const float* logits, int ld, int V, const float* 
     if (num_beams < 1 || num_beams > BT_MAX_BEAMS || n_top < 1 || n_top > BT_MAX_TOP || (long long)num_beams * V > 0x7ffffffeLL)
         return MADTP_E_SHAPE;
     if (!aligned16(logits) || (ld & 3)) return MADTP_E_ALIGN;
-    hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(LM_THREADS), 0, (hipStream_t)stream, logits, ld, V, beam_scores, num_beams,
-                       n_top, suppress_token, out_scores, out_index);
+    MADTP_ENSURE_MAX_LDS(beam_topk_kernel, BT_THREADS * BT_MAX_TOP * 8);
+    hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(BT_THREADS), (size_t)BT_THREADS * n_top * 8, (hipStream_t)stream, logits, ld, V,
+                       beam_scores, num_beams, n_top, suppress_token, out_scores, out_index);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
