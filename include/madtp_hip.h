@@ -64,6 +64,12 @@ int madtp_gemm(const void* A, const void* W, const float* bias, const float* res
  * variable MADTP_GEMM_CFG sets the initial value.  No reference counterpart (the reference has one GEMM: aten::addmm).
  * Returns the previous value. */
 int madtp_gemm_set_config(int cfg);
+/* Scheduling hint for the automatic dispatch: the relative per-round cost of a 256x256 tile against a 256x128 tile (default
+ * 1.7 = an isolated launch; a caller that keeps several forwards in flight on the GPU lowers it - the other streams fill
+ * sparse last rounds, so the more efficient tile wins more often).  cost <= 0 restores the default (MADTP_GEMM_SQ_COST or
+ * 1.7).  Process-wide; results do not depend on it (same arithmetic per output element in both kernels).  Returns the previous
+ * value.  No reference counterpart. */
+float madtp_gemm_set_sq_cost(float cost);
 
 /* Split-K form for small-M projections (latency-bound at one workgroup per tile): part[s,M,N] (f32, contiguous) holds
  * the partial product of K range s; madtp_splitk_ln then computes

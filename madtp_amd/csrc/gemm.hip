@@ -1354,6 +1354,27 @@ static int gemm_force_cfg() {
     }
     return v;
 }
+// Per-round cost of a 256x256 tile relative to a 256x128 tile in the dispatch rule below.  1.7 is what an isolated launch
+// measures (the rule then counts rounds).  With several forwards in flight on one GPU the tail of a sparse last round is filled
+// by the other streams' kernels, so the round count matters less than the per-flop efficiency of the tile (the 256x256 tile
+// reads half the LDS bytes per MFMA): madtp_amd/pipeline.py lowers the cost to 0.9 while its workers run - measured NLVR
+// 25.2 -> 25.7 k images/s with four in flight, but 20.1 -> 19.2 k on the serial loop, which keeps 1.7.
+static std::atomic<float> g_sq_cost{-1.f};
+static float gemm_sq_cost() {
+    float v = g_sq_cost.load(std::memory_order_relaxed);
+    if (v <= 0.f) {
+        const char* e = getenv("MADTP_GEMM_SQ_COST");
+        v = e ? (float)atof(e) : 1.7f;
+        if (!(v > 0.f)) v = 1.7f;
+        g_sq_cost.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+extern "C" float madtp_gemm_set_sq_cost(float cost) {
+    const float prev = gemm_sq_cost();
+    g_sq_cost.store(cost > 0.f ? cost : -1.f, std::memory_order_relaxed);
+    return prev;
+}
 extern "C" int madtp_gemm_set_config(int cfg) {
     const int prev = gemm_force_cfg();
     g_force_cfg.store((cfg < 0 || cfg > 8) ? 0 : cfg, std::memory_order_relaxed);
@@ -1547,7 +1568,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         static int sq_env = -1;
         if (sq_env < 0) { const char* e = getenv("MADTP_GEMM_SQ"); sq_env = e ? atoi(e) : 1; }
         const int t_sq = ((M + 255) / 256) * ((N + 255) / 256);
-        const float cost_sq = 1.7f * (float)((t_sq + 255) / 256), cost_ws = ws_cost(t256, K / 64, sk_on);
+        const float cost_sq = gemm_sq_cost() * (float)((t_sq + 255) / 256), cost_ws = ws_cost(t256, K / 64, sk_on);
         sq_ok = force_cfg == 6 || (force_cfg == 0 && sq_env && ws_ok && t_sq >= 100 && cost_sq < cost_ws);
     }
     if (sq_ok) {

@@ -47,6 +47,10 @@ class InflightRunner:
         else:
             prio = [-1] * max(1, self.n // 2)
         self.streams = [torch.cuda.Stream(device=self.device, priority=(prio[i] if i < len(prio) else 0)) for i in range(self.n)]
+        # GEMM dispatch hint while the workers run (hip.gemm_set_sq_cost; per workload, measured): None = leave the default
+        self.sq_cost = getattr(workload, "inflight_sq_cost", None)
+        if os.environ.get("MADTP_INFLIGHT_SQ_COST"):  # A/B runs: "0" = no hint
+            self.sq_cost = float(os.environ["MADTP_INFLIGHT_SQ_COST"]) or None
         self.errors = []
         self.last = [None] * self.n  # output of each worker's most recent step
 
@@ -76,10 +80,18 @@ class InflightRunner:
         mode = runtime.get_precision()
         threads = [threading.Thread(target=self._work, args=(i, per[i], mode), name=f"madtp-inflight-{i}")
                    for i in range(self.n) if per[i]]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        prev_cost = None
+        if self.sq_cost and len(threads) > 1:
+            from . import hip
+            prev_cost = hip.gemm_set_sq_cost(self.sq_cost)
+        try:
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            if prev_cost is not None:
+                hip.gemm_set_sq_cost(prev_cost)
         for s in self.streams:
             main.wait_stream(s)
         if self.errors:
