@@ -70,6 +70,11 @@ int madtp_gemm_set_config(int cfg);
  * 1.7).  Process-wide; results do not depend on it (same arithmetic per output element in both kernels).  Returns the previous
  * value.  No reference counterpart. */
 float madtp_gemm_set_sq_cost(float cost);
+/* Second scheduling hint of the same kind: the tile configuration of the SMALL problems (fewer than 200 tiles of 256x128, e.g.
+ * the 1280-row GEMMs of the text encoders): -1 = automatic (the smallest tile that fits one round: lowest latency of a lone
+ * launch), 0 = 128x128, 1 = 64x128, 2 = 64x128 with three stages, 3 = 64x64.  A caller with several forwards in flight sets 0
+ * (fewer operand re-reads: less CU time per launch).  Process-wide; results do not depend on it.  Returns the previous value. */
+int madtp_gemm_set_small_tile(int cfg);
 
 /* Split-K form for small-M projections (latency-bound at one workgroup per tile): part[s,M,N] (f32, contiguous) holds
  * the partial product of K range s; madtp_splitk_ln then computes

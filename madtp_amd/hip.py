@@ -12,7 +12,7 @@ import torch
 
 F32, BF16, F16S = 0, 1, 2  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -25,6 +25,7 @@ _SIGS = {
     "madtp_gemm": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "madtp_gemm_set_config": (c_int, [c_int]),
     "madtp_gemm_set_sq_cost": (c_float, [c_float]),
+    "madtp_gemm_set_small_tile": (c_int, [c_int]),
     "madtp_gemm_splitk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "madtp_splitk_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_float, c_float, c_float, c_void_p]),
@@ -242,6 +243,11 @@ def gemm_set_sq_cost(cost):
     """madtp_gemm_set_sq_cost (include/madtp_hip.h): dispatch hint for callers that keep several forwards in flight; cost <= 0
     restores the default.  -> previous value."""
     return float(load().madtp_gemm_set_sq_cost(float(cost)))
+
+
+def gemm_set_small_tile(cfg):
+    """madtp_gemm_set_small_tile (include/madtp_hip.h): tile configuration of the small problems, -1 = automatic.  -> previous."""
+    return int(load().madtp_gemm_set_small_tile(int(cfg)))
 
 
 def gemm_pair(a0, a1, w0, w1, bias0, bias1, n, out_dtype=None):

@@ -49,8 +49,12 @@ class InflightRunner:
         self.streams = [torch.cuda.Stream(device=self.device, priority=(prio[i] if i < len(prio) else 0)) for i in range(self.n)]
         # GEMM dispatch hint while the workers run (hip.gemm_set_sq_cost; per workload, measured): None = leave the default
         self.sq_cost = getattr(workload, "inflight_sq_cost", None)
+        self.small_tile = getattr(workload, "inflight_small_tile", None)
         if os.environ.get("MADTP_INFLIGHT_SQ_COST"):  # A/B runs: "0" = no hint
             self.sq_cost = float(os.environ["MADTP_INFLIGHT_SQ_COST"]) or None
+        if os.environ.get("MADTP_INFLIGHT_SMALL_TILE"):  # A/B runs: "-1" = no hint
+            self.small_tile = int(os.environ["MADTP_INFLIGHT_SMALL_TILE"])
+            self.small_tile = None if self.small_tile < 0 else self.small_tile
         self.errors = []
         self.last = [None] * self.n  # output of each worker's most recent step
 
@@ -80,10 +84,13 @@ class InflightRunner:
         mode = runtime.get_precision()
         threads = [threading.Thread(target=self._work, args=(i, per[i], mode), name=f"madtp-inflight-{i}")
                    for i in range(self.n) if per[i]]
-        prev_cost = None
-        if self.sq_cost and len(threads) > 1:
-            from . import hip
-            prev_cost = hip.gemm_set_sq_cost(self.sq_cost)
+        from . import hip
+        prev_cost = prev_small = None
+        if len(threads) > 1:  # dispatch hints for a GPU shared by several forwards (include/madtp_hip.h); results do not change
+            if self.sq_cost:
+                prev_cost = hip.gemm_set_sq_cost(self.sq_cost)
+            if self.small_tile is not None:
+                prev_small = hip.gemm_set_small_tile(self.small_tile)
         try:
             for t in threads:
                 t.start()
@@ -92,6 +99,8 @@ class InflightRunner:
         finally:
             if prev_cost is not None:
                 hip.gemm_set_sq_cost(prev_cost)
+            if prev_small is not None:
+                hip.gemm_set_small_tile(prev_small)
         for s in self.streams:
             main.wait_stream(s)
         if self.errors:

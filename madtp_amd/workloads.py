@@ -73,6 +73,9 @@ class Workload:
     # GEMM dispatch hint while several forwards are in flight (include/madtp_hip.h madtp_gemm_set_sq_cost); measured with four
     # in flight: NLVR 25.2 -> 25.7 k images/s, VQA 4.77 -> 4.87 k, retrieval 29.4 -> 28.4 k (keeps the default)
     inflight_sq_cost = 0.9
+    # ... and the 128x128 tile for the small problems (madtp_gemm_set_small_tile): NLVR 25.5 -> 26.2 k, retrieval 28.5 -> 30.4 k,
+    # VQA 4.81 -> 4.85 k with four in flight
+    inflight_small_tile = 0
 
     def build(self, device="cuda"): raise NotImplementedError
     def inputs(self, B, seed=0, device="cuda"): raise NotImplementedError
