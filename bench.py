@@ -73,9 +73,10 @@ def measure_traffic(args):
                    "--config", args.config, "--precision", args.precision, "--steps", "1", "--warmup", "1", "--traffic", "off",
                    "--no-cpu-baseline", "--no-parity", "--no-gemm-events", "--inflight", "1"] + (["--batch", str(args.batch)] if args.batch else [])
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=int(os.environ.get("MADTP_TRAFFIC_TIMEOUT", "150")))
             dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
             if r.returncode != 0 or not dbs:
+                print(f"[bench] traffic pass {counter}: rc {r.returncode}, {len(dbs)} result files; stderr tail: {r.stderr[-600:]}", file=sys.stderr)
                 return None
             c = sqlite3.connect(dbs[0])
             rows = c.execute("select name, count(*), sum(counter_value) from pmc_events where counter_name=? group by name",
@@ -86,7 +87,8 @@ def measure_traffic(args):
             if not n:
                 return None
             out[counter] = (n, v * 1024.0 / n)  # the counters are in KiB
-    except Exception:
+    except Exception as e:
+        print(f"[bench] traffic passes failed: {e!r}", file=sys.stderr)
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -127,6 +129,14 @@ def main():
     world, rank, local_rank = mdist.env_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    # roofline.traffic comes from two rocprofv3 --pmc passes over a one-step copy of this command (measure_traffic).  They run
+    # FIRST, before this process touches the GPU: launched after the in-flight legs (four streams, two of them high-priority,
+    # still alive in this process) the profiled child hung in about every second run until its timeout (profiles/README.md).
+    pre_traffic = None
+    if (args.traffic == "auto" and rank == 0 and world == 1 and args.precision != "fp32" and not args.no_gemm_events):
+        from madtp_amd import build as _build
+        _build.build(verbose=False)
+        pre_traffic = measure_traffic(args)
     # MADTP_BENCH_ONE_GPU=1 (rehearsal on a one-GPU box: tools/bench_rehearsal.sh): all ranks share GPU 0 and reduce over gloo -
     # RCCL refuses two ranks on one device - so that the multi-rank code path of this file runs on hardware before the driver's
     # 8-GPU run; the figures of such a run mean nothing.
@@ -235,9 +245,7 @@ def main():
                      "f16x3": "gemm_ws_kernel<f16-split> (all madtp_gemm launches with M >= 4096; 3 f16 MFMA products per "
                               "logical product: achieved/peak are in algorithmic 2MNK flops, peak = f16 dense / 3)",
                      "fp32": "gemm_kernel<float> (madtp_gemm)"}[args.precision]
-            traffic = None
-            if args.traffic == "auto" and rank == 0 and world == 1 and args.precision != "fp32":
-                traffic = measure_traffic(args)
+            traffic = pre_traffic
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1),
                     "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
