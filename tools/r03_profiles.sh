@@ -27,7 +27,7 @@ for spec in "nlvr bf16" "nlvr f16x3" "vqa bf16" "vqa f16x3" "retrieval bf16" "cl
   rm -rf $R/gpurun_out/prof_$T
 done
 # two forwards in flight: who overlaps whom
-rocprofv3 --kernel-trace -d $R/gpurun_out/prof_inflight -o p -- python $R/bench.py --inflight 2 --steps 10 --warmup 2 --traffic off --no-cpu-baseline --no-parity --no-gemm-events > $R/gpurun_out/prof_inflight.log 2>&1
+rocprofv3 --kernel-trace -d $R/gpurun_out/prof_inflight -o p -- python $R/bench.py --steps 24 --warmup 3 --traffic off --no-cpu-baseline --no-parity --no-gemm-events > $R/gpurun_out/prof_inflight.log 2>&1
 python $R/tools/rocpd_overlap.py $(find $R/gpurun_out/prof_inflight -name "*_results.db" | head -1) 400 0.8 > $R/gpurun_out/${TAG}_inflight_overlap.txt
 rm -rf $R/gpurun_out/prof_inflight
 # HBM-side counters per kernel (separate passes, MI355X_MICROARCH.md)
