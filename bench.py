@@ -268,7 +268,10 @@ def main():
         "config": {"workload": w.describe(B), "samples_per_gpu": B, "images_per_gpu": w.images_per_sample * B, "temperature": T,
                    "p": w.p, "flops_ratio_vs_unpruned": round(flops_sample / flops_full, 4),
                    "tokens_per_layer": lens, "calibrated_at_batch": calib.get("batch"), "parallelism": f"dp{world}",
-                   "inflight_per_gpu": args.inflight},
+                   "inflight_per_gpu": args.inflight,
+                   "inflight_high_priority_streams": (max(1, runner.n // 2) if runner is not None else 0),
+                   "gemm_dispatch_hints_while_in_flight": ({"sq_cost": runner.sq_cost, "small_tile": runner.small_tile}
+                                                           if runner is not None else None)},
         "samples_per_s": round(value / w.images_per_sample, 1),
         "model_tflops": round(flops_sample * B * world * args.steps / elapsed / 1e12, 1),
         "roofline": roof,
