@@ -104,7 +104,7 @@ def main():
     from madtp_amd import workloads
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)  # a multiple of the 2 / 3 / 4 forwards in flight (equal shares per worker; 12 forwards each: the ramp-up and the tail of the pipeline stay small)
+    ap.add_argument("--steps", type=int, default=96)  # a multiple of the 2 / 3 / 4 forwards in flight (equal shares per worker; 24 forwards each: the ramp-up and the tail of the pipeline cost 24 steps ~5 %, 48 ~3 %, 96 ~1.5 % of the 192-step figure)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3"])
     ap.add_argument("--config", default="nlvr", choices=list(workloads.NAMES),
