@@ -207,10 +207,14 @@ def main():
         t0 = time.perf_counter()
         run_steps(args.steps)
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0  # this rank's K steps, before it waits for the others
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        hl_high = runner.n_high if runner is not None else 0  # high-priority streams among the workers the headline leg used
+        weight_bytes = sum(p.numel() * p.element_size() for p in model.parameters())
+        hbm_alloc = torch.cuda.max_memory_allocated()  # every replica's weights (f32 + prepared compute-dtype copies), inputs, workspaces
         lens = w.lens(model)
         # Roofline leg: the SAME K steps once more with a HIP event pair around every madtp_gemm launch (recorded by
         # the library on the launch stream).  Kept out of the `value` region because ~180 event pairs per step
@@ -225,6 +229,7 @@ def main():
             instr_elapsed = time.perf_counter() - t1
             prof_rows = hip.profile_end()
     elapsed = mdist.max_over_ranks(elapsed, device=red_dev)
+    own_max, own_min = mdist.max_over_ranks(own, device=red_dev), mdist.min_over_ranks(own, device=red_dev)
 
     images_per_step = w.images_per_sample * B * world
     value = images_per_step * args.steps / elapsed
@@ -269,13 +274,28 @@ def main():
                    "p": w.p, "flops_ratio_vs_unpruned": round(flops_sample / flops_full, 4),
                    "tokens_per_layer": lens, "calibrated_at_batch": calib.get("batch"), "parallelism": f"dp{world}",
                    "inflight_per_gpu": args.inflight,
-                   "inflight_high_priority_streams": (max(1, runner.n // 2) if runner is not None else 0),
+                   "inflight_high_priority_streams": (hl_high if runner is not None else 0),
+                   "model_replicas_resident": (runner.n if runner is not None else 1),
+                   "weight_bytes_per_replica": weight_bytes, "hbm_bytes_allocated": hbm_alloc,
                    "gemm_dispatch_hints_while_in_flight": ({"sq_cost": runner.sq_cost, "small_tile": runner.small_tile}
                                                            if runner is not None else None)},
+        "per_rank_ms_per_step": {"min": round(1e3 * own_min / args.steps, 3), "max": round(1e3 * own_max / args.steps, 3),
+                                 "what": "each rank's own K steps, clocked before the closing barrier (stragglers show as max >> min)"},
         "samples_per_s": round(value / w.images_per_sample, 1),
         "model_tflops": round(flops_sample * B * world * args.steps / elapsed / 1e12, 1),
         "roofline": roof,
     }
+    # First-class companions of `value`: `value` is THROUGHPUT with args.inflight independent forwards in flight on one
+    # GPU (args.inflight model replicas); the reference's eval loop runs one batch at a time (compress_nlvr_dtp.py:73-99), which is
+    # `serial_value` / `ms_per_forward` here.  ms_per_step = elapsed / steps is the pipeline's issue interval, not a latency.
+    if single is not None:
+        out["serial_value"] = round(w.images_per_sample * B * world * args.steps / single, 1)
+        out["ms_per_forward"] = round(1e3 * single / args.steps, 3)
+        out["ms_per_forward_in_flight"] = round(1e3 * elapsed * args.inflight / args.steps, 3)
+    else:
+        out["serial_value"] = out["value"]
+        out["ms_per_forward"] = out["ms_per_step"]
+        out["ms_per_forward_in_flight"] = out["ms_per_step"]
     if single is not None:
         out["single_stream"] = {"value": round(w.images_per_sample * B * args.steps / single, 1), "unit": "images/s",
                                 "ms_per_forward": round(1e3 * single / args.steps, 3),

@@ -106,6 +106,15 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def min_over_ranks(value, device="cpu"):
+    """MIN all-reduce of a python float (the fastest rank's own time in the timed region: max - min shows stragglers)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())
+
+
 def sum_over_ranks(values, device="cpu"):
     if not dist.is_initialized():
         return [float(v) for v in values]

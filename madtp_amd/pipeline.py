@@ -24,6 +24,40 @@ import threading
 import torch
 
 
+# The GEMM dispatch hints are process-wide state of the library (include/madtp_hip.h): runners that overlap in time share ONE
+# setting - the first one in sets it and remembers the previous values, the last one out restores them (a nested or concurrent
+# runner neither re-applies its own hints nor restores stale ones).
+_hint_lock = threading.Lock()
+_hint_depth = 0
+_hint_prev = (None, None)
+
+
+def _hints_enter(sq_cost, small_tile):
+    global _hint_depth, _hint_prev
+    from . import hip
+    with _hint_lock:
+        if _hint_depth == 0:
+            prev_cost = hip.gemm_set_sq_cost(sq_cost) if sq_cost else None
+            prev_small = hip.gemm_set_small_tile(small_tile) if small_tile is not None else None
+            _hint_prev = (prev_cost, prev_small)
+        _hint_depth += 1
+    return True
+
+
+def _hints_exit():
+    global _hint_depth, _hint_prev
+    from . import hip
+    with _hint_lock:
+        _hint_depth -= 1
+        if _hint_depth == 0:
+            prev_cost, prev_small = _hint_prev
+            if prev_cost is not None:
+                hip.gemm_set_sq_cost(prev_cost)
+            if prev_small is not None:
+                hip.gemm_set_small_tile(prev_small)
+            _hint_prev = (None, None)
+
+
 class InflightRunner:
     """n_inflight workers, each = (model replica, resident inputs, HIP stream, host thread).  run(steps) executes `steps` forwards
     in total, step i on worker i % n, every worker's steps in order on its own stream; returns after all of them completed."""
@@ -41,12 +75,14 @@ class InflightRunner:
         # priorities the forwards contend kernel by kernel (three in flight: 20.7 k images/s), with preferred streams they settle
         # into a stable interleave: two (h,n) 22.6-23.1 k, three (h,n,n) 23.8-24.5 k, four (h,h,n,n) 25.1-25.5 k, four (h,n,n,n)
         # 21.6-22.5 k, five (h,h,n,n,n) 24.1-24.3 k, six (h,h,h,n,n,n) 22.0 k
+        # The split follows the number of workers a run() actually uses (the first workers // 2 of THEM are high), so every slot
+        # owns one stream of each level and run() picks.
         env = os.environ.get("MADTP_INFLIGHT_PRIO", "")
-        if env.strip():
-            prio = [int(x) for x in env.split(",") if x.strip()]
-        else:
-            prio = [-1] * max(1, self.n // 2)
-        self.streams = [torch.cuda.Stream(device=self.device, priority=(prio[i] if i < len(prio) else 0)) for i in range(self.n)]
+        self.prio_env = [int(x) for x in env.split(",") if x.strip()] if env.strip() else None
+        self._by_prio = [dict() for _ in range(self.n)]  # slot -> {priority: stream}, created on first use (a run() with all n
+        #                                                   workers creates exactly n streams, as many as are in use)
+        self.streams = [None] * self.n                    # the streams of the most recent run(), by worker
+        self.n_high = 0
         # GEMM dispatch hint while the workers run (hip.gemm_set_sq_cost; per workload, measured): None = leave the default
         self.sq_cost = getattr(workload, "inflight_sq_cost", None)
         self.small_tile = getattr(workload, "inflight_small_tile", None)
@@ -56,6 +92,7 @@ class InflightRunner:
             self.small_tile = int(os.environ["MADTP_INFLIGHT_SMALL_TILE"])
             self.small_tile = None if self.small_tile < 0 else self.small_tile
         self.errors = []
+        self.stop = threading.Event()  # set by the first worker that fails: the others stop at their next step
         self.last = [None] * self.n  # output of each worker's most recent step
 
     def _work(self, i, steps, mode):
@@ -66,10 +103,13 @@ class InflightRunner:
             torch.cuda.set_device(self.device)
             with torch.cuda.stream(self.streams[i]), torch.no_grad():
                 for _ in range(steps):
+                    if self.stop.is_set():
+                        break
                     self.last[i] = self.w.step(self.models[i], self.inputs[i], self.T)
             self.streams[i].synchronize()
         except BaseException as e:  # surfaced by run()
             self.errors.append(e)
+            self.stop.set()
 
     def run(self, steps, workers=None):
         """workers (optional): use only the first `workers` of the n in-flight slots (bench.py times the headline with two and
@@ -78,30 +118,34 @@ class InflightRunner:
         n = self.n if workers is None else max(1, min(int(workers), self.n))
         per = [steps // n + (1 if i < steps % n else 0) if i < n else 0 for i in range(self.n)]
         main = torch.cuda.current_stream(self.device)
-        for s in self.streams:
+        if self.prio_env is not None:
+            high = [i < len(self.prio_env) and self.prio_env[i] < 0 for i in range(self.n)]
+        else:
+            high = [i < max(1, n // 2) for i in range(self.n)]
+        for i in range(n):
+            pr = -1 if high[i] else 0
+            if pr not in self._by_prio[i]:
+                self._by_prio[i][pr] = torch.cuda.Stream(device=self.device, priority=pr)
+            self.streams[i] = self._by_prio[i][pr]
+        self.n_high = sum(1 for i in range(n) if high[i])
+        self.stop.clear()
+        used = [self.streams[i] for i in range(n)]
+        for s in used:
             s.wait_stream(main)
         from . import runtime
         mode = runtime.get_precision()
         threads = [threading.Thread(target=self._work, args=(i, per[i], mode), name=f"madtp-inflight-{i}")
                    for i in range(self.n) if per[i]]
-        from . import hip
-        prev_cost = prev_small = None
-        if len(threads) > 1:  # dispatch hints for a GPU shared by several forwards (include/madtp_hip.h); results do not change
-            if self.sq_cost:
-                prev_cost = hip.gemm_set_sq_cost(self.sq_cost)
-            if self.small_tile is not None:
-                prev_small = hip.gemm_set_small_tile(self.small_tile)
+        hinted = len(threads) > 1 and _hints_enter(self.sq_cost, self.small_tile)
         try:
             for t in threads:
                 t.start()
             for t in threads:
                 t.join()
         finally:
-            if prev_cost is not None:
-                hip.gemm_set_sq_cost(prev_cost)
-            if prev_small is not None:
-                hip.gemm_set_small_tile(prev_small)
-        for s in self.streams:
+            if hinted:
+                _hints_exit()
+        for s in used:
             main.wait_stream(s)
         if self.errors:
             err, self.errors = self.errors[0], []

@@ -44,6 +44,7 @@ def _worker(rank, world, port, out_dir):
     assert allv.shape == (B, 2)
     t = mdist.max_over_ranks(1.0 + rank)
     assert t == float(world)
+    assert mdist.min_over_ranks(1.0 + rank) == 1.0
     assert mdist.sum_over_ranks([hi - lo, 1.0]) == [float(B), float(world)]
     torch.save({"logits": logits, "all": allv, "range": (lo, hi)}, os.path.join(out_dir, f"r{rank}.pt"))
     mdist.barrier()

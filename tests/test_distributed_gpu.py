@@ -88,6 +88,7 @@ def _nccl_worker(rank, world, port, out_dir):
     w, r, _ = mdist.init("nccl")  # RCCL: one device per rank
     assert (w, r) == (world, rank)
     assert mdist.max_over_ranks(1.0 + rank, device="cuda") == float(world)
+    assert mdist.min_over_ranks(1.0 + rank, device="cuda") == 1.0
     assert mdist.sum_over_ranks([1.0, float(rank)], device="cuda") == [float(world), float(sum(range(world)))]
     # config 3's one exchange (compress_retrieval_dtp.py:202-205): every rank filled its row slice of both score matrices
     n_img, n_txt = 13, 31
@@ -107,11 +108,33 @@ def _nccl_worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
+def _nccl_single_rank_worker(rank, port):
+    os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from madtp_amd import dist as mdist
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", init_method="env://", world_size=1, rank=0)
+    assert dist.get_backend() == "nccl"
+    assert mdist.max_over_ranks(3.5, device="cuda") == 3.5 and mdist.min_over_ranks(3.5, device="cuda") == 3.5
+    assert mdist.sum_over_ranks([1.0, 2.0], device="cuda") == [1.0, 2.0]
+    logits = torch.arange(10, dtype=torch.float32, device="cuda").reshape(5, 2)
+    assert torch.equal(mdist.gather_logits(logits), logits)
+    t = torch.full((1 << 20,), 2.0, device="cuda")   # a 4 MB all-reduce through the RCCL ring code path
+    dist.all_reduce(t)
+    assert float(t[0]) == 2.0 and float(t[-1]) == 2.0
+    mdist.barrier()
+    dist.destroy_process_group()
+
+
 @pytest.mark.timeout(600)
 def test_rccl_reductions_and_score_gather():
     """RCCL itself (backend "nccl", one device per rank) for the collectives the path uses: the MAX / SUM scalar reductions of
     bench.py and the retrieval score-matrix exchange.  Needs >= 2 GPUs: skipped on the one-GPU test boxes, runs on a node."""
     if torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs (RCCL wants one device per rank)")
+        # one-GPU form: RCCL refuses two ranks on one device, so the communicator has ONE rank - librccl is loaded, the
+        # communicator is created and the all_reduce (MAX / MIN / SUM) / all_gather / barrier calls of the path run through it
+        mp.spawn(_nccl_single_rank_worker, args=(_free_port(),), nprocs=1, join=True)
+        return
     world = 2
     mp.spawn(_nccl_worker, args=(world, _free_port(), ""), nprocs=world, join=True)

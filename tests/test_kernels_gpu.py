@@ -96,9 +96,11 @@ def test_gemm_wave_specialised(hip, M, N, K, cfg):
 
 @pytest.mark.parametrize("M,N,K", [(10533, 768, 768), (10533, 776, 768), (6000, 2304, 768), (10533, 768, 3072), (300, 100, 768),
                                    (25216, 3072, 768)])
-@pytest.mark.parametrize("cfg", [6])
+@pytest.mark.parametrize("cfg", [6, 9], ids=["lockstep", "pingpong"])
 def test_gemm_256x256(hip, M, N, K, cfg):
-    """gemm_sq_kernel (256x256 tiles, forced with madtp_gemm_set_config(6)): ragged last row tile, a last column tile with 8 / 4
+    """gemm_sq_kernel (256x256 tiles, forced with madtp_gemm_set_config(6)) and gemm_pp_kernel (the same tile with the
+    two-wave-row ping-pong main loop, config 9; repeated launches must give identical bits - a race between the run-ahead
+    LDS-DMA stream and the fragment reads would not): ragged last row tile, a last column tile with 8 / 4
     valid columns, N below one tile (W rows past the 128-row padding are dropped by the buffer descriptor), every epilogue and
     a strided output.  Reference: float64 matmul of the same bf16-rounded operands on the GPU."""
     td = torch.bfloat16
@@ -132,6 +134,13 @@ def test_gemm_256x256(hip, M, N, K, cfg):
     with hip.gemm_config(cfg):
         sq = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
     assert (auto - sq).abs().max().item() < 1e-4 * scale
+    if cfg == 9:
+        with hip.gemm_config(6):
+            lock = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
+        assert torch.equal(lock, sq)  # same k order per accumulator as the lockstep kernel
+        with hip.gemm_config(9):
+            for _ in range(20):
+                assert torch.equal(hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N), sq)
 
 
 @pytest.mark.parametrize("M,N,K", [(12288, 768, 3072),   # 288 tiles: one round + 4 tail tiles per XCD cut into 8 pieces

@@ -25,7 +25,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "ab":  # 256x128 wave-specialised (cfg 5
             kw = dict(residual=res, out_dtype=torch.float32) if N == 768 else (dict(act=hip.ACT_GELU) if N == 3072 else {})
             out = torch.empty(M, N, device="cuda", dtype=kw.get("out_dtype", dt))
             line = f"M={M:6d} N={N:5d} K={K:5d}"
-            for cfg in ((7, 1, 2, 3, 0) if (len(sys.argv) > 3 and sys.argv[3] == 'small_tiles') else (7, 8, 6, 0)):  # 7: wave-specialised, 16x16x32 MFMA; 8: wave-specialised, 32x32x16 MFMA; 6: 256x256; 0: automatic (5 = 7 + stream-K tail)
+            for cfg in ((7, 1, 2, 3, 0) if (len(sys.argv) > 3 and sys.argv[3] == 'small_tiles') else (7, 6, 9, 0)):  # 9: 256x256 ping-pong; 7: wave-specialised, 16x16x32 MFMA; 8: wave-specialised, 32x32x16 MFMA; 6: 256x256; 0: automatic (5 = 7 + stream-K tail)
                 with hip.gemm_config(cfg):
                     for _ in range(3): hip.gemm(a, w, bias, n=N, out=out, **kw)
                     torch.cuda.synchronize()
@@ -36,6 +36,29 @@ if len(sys.argv) > 2 and sys.argv[2] == "ab":  # 256x128 wave-specialised (cfg 5
                 us = e0.elapsed_time(e1) * 1e3 / 20
                 line += f"   cfg{cfg} {us:7.1f} us {2.0*M*N*K/us/1e6:7.1f} TF"
             print(line, flush=True)
+    sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "cube":  # long-K yardstick: 4096^3 / 8192^3, every big-tile kernel and the vendor library, random operands
+    for M in (4096, 8192):
+        a = torch.randn(M, M, device="cuda").to(dt); w = (torch.randn(M, M, device="cuda") * 0.05).to(dt)
+        out = torch.empty(M, M, device="cuda", dtype=dt); lib_out = torch.empty(M, M, device="cuda", dtype=dt)
+        def t(fn, reps=10):
+            for _ in range(3): fn()
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps): fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / reps
+        line = f"M=N=K={M}"
+        for rnd in range(2):
+            for cfg in (7, 6, 9):
+                with hip.gemm_config(cfg):
+                    us = t(lambda: hip.gemm(a, w, None, n=M, out=out))
+                line += f"   cfg{cfg} {us:8.1f} us {2.0*M*M*M/us/1e6:7.1f} TF"
+            us = t(lambda: torch.matmul(a, w.t(), out=lib_out))
+            line += f"   library {us:8.1f} us {2.0*M*M*M/us/1e6:7.1f} TF |"
+        print(line, flush=True)
+        print("   max|pp - lib| =", (out.float() - lib_out.float()).abs().max().item(), flush=True)
     sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "lib":  # yardstick: the vendor library (torch -> hipBLASLt / rocBLAS) on the same shapes, plain bf16 out
     import torch.nn.functional as F
