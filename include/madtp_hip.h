@@ -460,6 +460,49 @@ int madtp_token_prob(const float* logits, int ld, int V, const int64_t* tok, int
 int madtp_beam_topk(const float* logits, int ld, int V, const float* beam_scores, int num_beams, int n_top, int suppress_token,
                     float* out_scores, int32_t* out_index, int B, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Backward of the pruned ViT block (first half; csrc/backward.hip): the pieces of loss.backward()
+ * through models/vit.py Block.forward (:183-207) that are not a GEMM.  fp32 arithmetic, fixed-order reductions.  The GEMMs
+ * (dgrad = dY W, wgrad = dY^T X) are madtp_gemm (MADTP_F32) on operands transposed by madtp_transpose_pad.  Orchestrated by
+ * madtp_amd/backward.py (torch.autograd.Function around Block.forward).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* dst[c, r] = src[r, c] (r < R, c < C), zero elsewhere of dst [Cp, Rp] (row stride ld_dst >= Rp): GEMM operands of the
+ * backward need K contiguous (nn.Linear layout) and padded (K % 32 == 0, 128-row weight padding). */
+int madtp_transpose_pad(const float* src, int ld_src, int R, int C, float* dst, int ld_dst, int Rp, int Cp, void* stream);
+/* out[c] = sum_r dy[r, c]: bias gradients (nn.Linear, LayerNorm beta).  part_ws: 64 * N floats of scratch. */
+int madtp_colsum(const float* dy, int ld, int M, int N, float* out, float* part_ws, void* stream);
+/* g = act(u) (g != NULL) and / or du = dg * act'(u) (du != NULL): Mlp's GELU (vit.py:34) and its derivative; n % 4 == 0. */
+int madtp_act_fwd_bwd(const float* u, const float* dg, float* g, float* du, size_t n, int act, void* stream);
+/* LayerNorm backward (vit.py:186,205 norm1 / norm2): dx = dLN(x)^T dy (+ add, the residual branch's gradient, may be NULL);
+ * dgamma / dbeta (may be NULL).  ws: 2 * rows + 64 * dim floats. */
+int madtp_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* add, float* dx, float* dgamma,
+                        float* dbeta, float* ws, int rows, int dim, float eps, void* stream);
+/* Backward of madtp_token_gather (vit.py:153-161, values only - `indices` carry no gradient): dy [B,k+2,dim] ->
+ * dx [B,N,dim] (kept token: its row of dy; dropped token: merge_w * dy[b,k+1]; CLS: dy[b,0]) and
+ * dw [B,N-1] = <dy[b,k+1], x[b,1+t]> for dropped tokens (0 for kept): the gradient of the merge weights. */
+int madtp_token_gather_bwd(const float* dy, const float* x, const int32_t* dst_pos, const float* merge_w, float* dx, float* dw,
+                           int B, int N, int k, int dim, void* stream);
+/* Backward of the importance score as far as autograd follows it in the reference (vit.py:126-134, :95-101): from dw (above)
+ * through w = I / (sum_dropped I + 1e-8), I = (self_attn_w + token_attn_w + cls_attn) / 3 to
+ *   da [B,N]          gradient of a_j = sum_{i>=1} max_h P[b,h,i,j] (un-normalised; da[b,0] = 0)
+ *   dp0 [B,H,N]       gradient of P[b,h,0,j]
+ *   dnrm_scale [B,H,N] gradient of ||attn_out[b,h,j,:]|| divided by that norm (d attn_out += dnrm_scale * attn_out)
+ *   dtoken_attn [B,N-1,K] dense gradient of the alignment logits (one non-zero per row: the row maximum)
+ * Inputs as produced by madtp_attention / madtp_token_score / madtp_token_select in the forward. */
+int madtp_token_score_bwd(const float* dw, const float* score, const int32_t* dst_pos, const float* merge_w,
+                          const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
+                          const float* token_attn, int ldt_row, int ldt_batch, int K, float* da, float* dp0, float* dnrm_scale,
+                          float* dtoken_attn, int B, int H, int N, void* stream);
+/* Softmax-attention backward with recomputed probabilities (vit.py:81-91) plus the score terms above:
+ *   dP[h,i,j] = dout_i . v_j + [i == 0, j >= 1] dp0[h,j] + [i >= 1, j >= 1, h == argmax_h' P[h',i,j]] da[j]
+ *   dS = P (dP - rowsum(P dP)); dq = scale dS k; dk = scale dS^T q; dv = P^T dout      (dout += dnrm_scale * out first)
+ * q/k/v/dq/dk/dv: f32, rows b*N+i, head h at columns [64h, 64h+64) of each base pointer (slices of the fused qkv buffer).
+ * ws: madtp_attention_bwd_workspace(B,H,N) bytes (P and dS [B,H,N,N] f32 + the head arg-max [B,N,N]).  N <= 1024. */
+size_t madtp_attention_bwd_workspace(int B, int H, int N);
+int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, const float* dout, int ldo, const float* out,
+                        int ldout, const float* dnrm_scale, const float* da, const float* dp0, float* dq, float* dk, float* dv,
+                        int ldd, void* ws, size_t ws_bytes, int B, int H, int N, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

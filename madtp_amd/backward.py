@@ -1,0 +1,236 @@
+"""Backward of the pruned ViT block (first half): what `loss.backward()` does through
+models/vit.py Block.forward (:183-207) in the reference's compression training (compress_nlvr_dtp.py:46-58, loss_fdt
+blip_nlvr.py:84-98), as hand-written gfx950 kernels behind a torch.autograd.Function.
+
+Scope of this round: ONE block, fp32 ("parity") arithmetic, gradient-checked against the reference's own .grad
+(tests/golden/vit_block_grad_b2.npz) and autograd through the CPU oracle.  PyTorch is plumbing (buffers, the autograd graph
+edge); every arithmetic op is a kernel of csrc/backward.hip or madtp_gemm:
+  * dgrad  dX = dY W      -> madtp_gemm(dY, W^T)          (exact-f32 MFMA; W^T by madtp_transpose_pad)
+  * wgrad  dW = dY^T X    -> madtp_gemm(dY^T, X^T)        (both operands transposed and zero-padded to 32 rows of M)
+  * bias / LayerNorm parameter gradients: fixed-order column reductions
+  * attention backward with recomputed probabilities, gather/merge backward, importance-score backward (the merge weights
+    w = I / (sum_dropped I + 1e-8) carry gradient into the attention probabilities and the alignment logits; the top-k
+    INDICES do not, exactly as torch.topk in vit.py:153-155).
+The forward's intermediates are recomputed here from (x, token_attn) with the forward's own kernels and the forward's pruning
+decision k (activation recomputation: nothing but the two inputs is kept alive between forward and backward).
+"""
+import torch
+
+from . import hip
+from .hip import _check, _p, _stream, load
+
+
+def _pad(n, m):
+    return (n + m - 1) // m * m
+
+
+def transpose_pad(src, rows_pad, cols_pad):
+    """src f32 [R, C] (row-major view, unit column stride) -> [cols_pad, rows_pad] with dst[c, r] = src[r, c], zero padding."""
+    R, C = src.shape
+    dst = torch.empty((cols_pad, rows_pad), device=src.device, dtype=torch.float32)
+    _check(load().madtp_transpose_pad(_p(src), src.stride(0), R, C, _p(dst), rows_pad, rows_pad, cols_pad, _stream()),
+           "madtp_transpose_pad")
+    return dst
+
+
+def dgrad(dy, weight):
+    """dX[M, K] = dY[M, N] @ W[N, K] (nn.Linear weight layout)."""
+    N, K = weight.shape
+    wt = transpose_pad(weight, N, _pad(K, 128))  # [Kpad, N]: the GEMM's "weight" with K' = N contiguous
+    return hip.gemm(dy, wt, n=K, out_dtype=torch.float32)
+
+
+def wgrad(dy, x):
+    """dW[N, K] = dY[M, N]^T @ X[M, K]."""
+    M, N = dy.shape
+    K = x.shape[1]
+    Mp = _pad(M, 32)
+    dyt = transpose_pad(dy, Mp, N)             # [N, Mp]
+    xt = transpose_pad(x, Mp, _pad(K, 128))    # [Kpad, Mp]
+    return hip.gemm(dyt, xt, n=K, out_dtype=torch.float32)
+
+
+def colsum(dy):
+    M, N = dy.shape
+    out = torch.empty((N,), device=dy.device, dtype=torch.float32)
+    part = torch.empty((64 * N,), device=dy.device, dtype=torch.float32)
+    _check(load().madtp_colsum(_p(dy), dy.stride(0), M, N, _p(out), _p(part), _stream()), "madtp_colsum")
+    return out
+
+
+def act_fwd(u, act):
+    g = torch.empty_like(u)
+    _check(load().madtp_act_fwd_bwd(_p(u), None, _p(g), None, u.numel(), act, _stream()), "madtp_act_fwd_bwd")
+    return g
+
+
+def act_bwd(u, dg, act):
+    du = torch.empty_like(u)
+    _check(load().madtp_act_fwd_bwd(_p(u), _p(dg), None, _p(du), u.numel(), act, _stream()), "madtp_act_fwd_bwd")
+    return du
+
+
+def layernorm_bwd(x2d, gamma, dy2d, eps, add=None):
+    rows, dim = x2d.shape
+    dx = torch.empty_like(x2d)
+    dgamma = torch.empty((dim,), device=x2d.device, dtype=torch.float32)
+    dbeta = torch.empty_like(dgamma)
+    ws = torch.empty((2 * rows + 64 * dim,), device=x2d.device, dtype=torch.float32)
+    _check(load().madtp_layernorm_bwd(_p(x2d), _p(gamma), _p(dy2d), _p(add), _p(dx), _p(dgamma), _p(dbeta), _p(ws), rows, dim,
+                                      float(eps), _stream()), "madtp_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def token_gather_bwd(dy, x_attn, dst_pos, merge_w, k):
+    B, N, dim = x_attn.shape
+    dx = torch.empty_like(x_attn)
+    dw = torch.empty((B, N - 1), device=x_attn.device, dtype=torch.float32)
+    _check(load().madtp_token_gather_bwd(_p(dy), _p(x_attn), _p(dst_pos), _p(merge_w), _p(dx), _p(dw), B, N, k, dim, _stream()),
+           "madtp_token_gather_bwd")
+    return dx, dw
+
+
+def token_score_bwd(dw, score, dst_pos, merge_w, side, token_attn, B, H, N):
+    cs, p0, on = side
+    tp, ldr, ldb, K = hip._ta_view(token_attn)
+    dev = dw.device
+    da = torch.empty((B, N), device=dev, dtype=torch.float32)
+    dp0 = torch.empty((B, H, N), device=dev, dtype=torch.float32)
+    dnrm = torch.empty((B, H, N), device=dev, dtype=torch.float32)
+    dta = torch.empty((B, N - 1, K), device=dev, dtype=torch.float32)
+    _check(load().madtp_token_score_bwd(_p(dw), _p(score), _p(dst_pos), _p(merge_w), _p(cs), cs.shape[1], _p(p0), _p(on), tp, ldr,
+                                        ldb, K, _p(da), _p(dp0), _p(dnrm), _p(dta), B, H, N, _stream()), "madtp_token_score_bwd")
+    return da, dp0, dnrm, dta
+
+
+def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None):
+    """qkv f32 [B*N, 3*H*64] (fused projection), dout / out [B*N, H*64] -> dqkv [B*N, 3*H*64]."""
+    D = H * 64
+    dqkv = torch.empty_like(qkv)
+    lib = load()
+    nbytes = lib.madtp_attention_bwd_workspace(B, H, N)
+    ws = torch.empty((nbytes,), device=qkv.device, dtype=torch.uint8)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
+    _check(lib.madtp_attention_bwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(dout), dout.stride(0), _p(out), out.stride(0), _p(dnrm),
+                                   _p(da), _p(dp0), _p(dq), _p(dk), _p(dv), dqkv.stride(0), _p(ws), nbytes, B, H, N, float(scale),
+                                   _stream()), "madtp_attention_bwd")
+    return dqkv
+
+
+def _f32_lin(linear):
+    """(weight padded to 128 rows, bias) of an nn.Linear for the exact-f32 GEMM."""
+    w = linear.weight.detach()
+    n = w.shape[0]
+    npad = _pad(n, 128)
+    if npad != n:
+        wp = torch.zeros((npad, w.shape[1]), device=w.device, dtype=torch.float32)
+        wp[:n] = w
+        w = wp
+    return w.contiguous(), (None if linear.bias is None else linear.bias.detach().contiguous())
+
+
+def vit_block_backward(blk, x, token_attn, temperature, k, dy):
+    """Gradients of Block.forward (vit.py:183-207) at (x [B,N,D], token_attn [B,N-1,K]) for the output gradient dy
+    [B,N',D], with the forward's pruning decision k (0 = the layer was not pruned).  Returns
+    (dx, dtoken_attn or None, {parameter name: grad})."""
+    B, N, D = x.shape
+    H, scale = blk.attn.num_heads, blk.attn.scale
+    M = B * N
+    eps1, eps2 = blk.norm1.eps, blk.norm2.eps
+    x2 = x.reshape(M, D)
+    # ---- recompute the forward (fp32 kernels, the forward's own) ----
+    h1, _ = hip.layernorm(x2, blk.norm1.weight.detach(), blk.norm1.bias.detach(), eps1)
+    wq, bq = _f32_lin(blk.attn.qkv)
+    wp, bp = _f32_lin(blk.attn.proj)
+    w1, b1 = _f32_lin(blk.mlp.fc1)
+    w2, b2 = _f32_lin(blk.mlp.fc2)
+    qkv = hip.gemm(h1, wq, bq, n=3 * D, out_dtype=torch.float32)
+    out, side = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, scale, scores=k > 0)
+    x_attn = hip.gemm(out, wp, bp, residual=x2, n=D, out_dtype=torch.float32)
+    if k > 0:
+        score, _, _, _ = hip.token_score(side, token_attn, temperature, B, H, N)
+        _, _, dst_pos, merge_w = hip.token_select(score, k)
+        y0 = hip.token_gather(x_attn.view(B, N, D), dst_pos, merge_w, k)
+    else:
+        y0 = x_attn.view(B, N, D)
+    N2 = y0.shape[1]
+    M2 = B * N2
+    y02 = y0.reshape(M2, D)
+    h2, _ = hip.layernorm(y02, blk.norm2.weight.detach(), blk.norm2.bias.detach(), eps2)
+    F = blk.mlp.fc1.weight.shape[0]
+    u = hip.gemm(h2, w1, b1, n=F, out_dtype=torch.float32)
+    g = act_fwd(u, hip.ACT_GELU)
+    # ---- backward ----
+    grads = {}
+    dy2 = dy.reshape(M2, D).contiguous().float()
+    dg = dgrad(dy2, blk.mlp.fc2.weight.detach())               # y = y0 + g W2^T + b2
+    grads["mlp.fc2.weight"], grads["mlp.fc2.bias"] = wgrad(dy2, g), colsum(dy2)
+    du = act_bwd(u, dg, hip.ACT_GELU)
+    dh2 = dgrad(du, blk.mlp.fc1.weight.detach())
+    grads["mlp.fc1.weight"], grads["mlp.fc1.bias"] = wgrad(du, h2), colsum(du)
+    dy0, grads["norm2.weight"], grads["norm2.bias"] = layernorm_bwd(y02, blk.norm2.weight.detach(), dh2, eps2, add=dy2)
+    dta = None
+    dnrm = da = dp0 = None
+    if k > 0:
+        dx_attn, dw = token_gather_bwd(dy0.view(B, N2, D), x_attn.view(B, N, D), dst_pos, merge_w, k)
+        da, dp0, dnrm, dta = token_score_bwd(dw, score, dst_pos, merge_w, side, token_attn, B, H, N)
+        dxa2 = dx_attn.view(M, D)
+    else:
+        dxa2 = dy0
+    dout = dgrad(dxa2, blk.attn.proj.weight.detach())          # x_attn = x + out Wp^T + bp
+    grads["attn.proj.weight"], grads["attn.proj.bias"] = wgrad(dxa2, out), colsum(dxa2)
+    dqkv = attention_bwd(qkv, dout, out, B, H, N, scale, dnrm, da, dp0)
+    dh1 = dgrad(dqkv, blk.attn.qkv.weight.detach())
+    grads["attn.qkv.weight"] = wgrad(dqkv, h1)
+    if blk.attn.qkv.bias is not None:
+        grads["attn.qkv.bias"] = colsum(dqkv)
+    dx2, grads["norm1.weight"], grads["norm1.bias"] = layernorm_bwd(x2, blk.norm1.weight.detach(), dh1, eps1, add=dxa2)
+    return dx2.view(B, N, D), dta, grads
+
+
+_PARAM_ORDER = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+                "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+
+
+def _params_of(blk):
+    return [blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.attn.proj.bias,
+            blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias]
+
+
+class VitBlockFunction(torch.autograd.Function):
+    """Block.forward with a hand-written backward.  Inputs after (blk, temperature): x, token_attn (or None), then the block's 12
+    parameters in _PARAM_ORDER (passed so that autograd routes their gradients; the kernels read them from the module)."""
+
+    @staticmethod
+    def forward(ctx, blk, temperature, x, token_attn, *params):
+        prune = temperature > 0
+        y, info = hip.vit_block(blk._weights(), x, token_attn, temperature if prune else 0)
+        blk.last_prune = info
+        ctx.blk, ctx.temperature = blk, float(temperature)
+        ctx.k = int(info["indices"].shape[1]) if (info is not None and info.get("pruned")) else 0
+        ctx.save_for_backward(x, token_attn if token_attn is not None else x.new_empty(0))
+        ctx.has_ta = token_attn is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ta = ctx.saved_tensors
+        ta = ta if ctx.has_ta else None
+        with torch.no_grad():
+            dx, dta, grads = vit_block_backward(ctx.blk, x, ta, ctx.temperature, ctx.k, dy)
+        pg = [grads.get(name) for name in _PARAM_ORDER]
+        if ctx.has_ta and dta is None:
+            dta = torch.zeros_like(ta)
+        return (None, None, dx, dta if ctx.has_ta else None) + tuple(pg)
+
+
+def block_forward_with_grad(blk, x, temperature, token_attn):
+    """Block.forward under autograd (called by madtp_amd.vit.Block.forward when gradients are required)."""
+    from . import runtime
+    if runtime.get_precision() != "fp32":
+        raise NotImplementedError("the block backward is built for the fp32 precision mode (runtime.precision('fp32')); "
+                                  f"current mode: {runtime.get_precision()}")
+    if token_attn is not None and not token_attn.is_contiguous():
+        token_attn = token_attn.contiguous()
+    return VitBlockFunction.apply(blk, temperature, x, token_attn, *_params_of(blk))

@@ -1,0 +1,548 @@
+// Backward of the pruned ViT block (first half): the kernels behind Block.forward's gradient
+// (reference: loss.backward() in compress_nlvr_dtp.py:46-58 through models/vit.py:75-103 Attention.forward, :123-163
+// Reduce_token and :183-207 Block.forward).  fp32 ("parity") arithmetic throughout; every reduction runs in a fixed order, so
+// repeated calls give identical bits.
+//
+// What autograd differentiates in the reference, and therefore here:
+//   * the two residual branches (LayerNorm, Linear, erf-GELU, softmax attention);
+//   * the pruning step's VALUES: x_topk = gather(x, indices) and x_combine = sum_dropped w_t x_t with
+//     w_t = I_t / (sum_dropped I + 1e-8) - `indices` (topk) carry no gradient, the merge weights do: through
+//     Importance_score = (self_attn_w + token_attn_w + cls_attn) / 3 they reach the attention probabilities (head-max column
+//     mass, vit.py:126-128; CLS row x head-diversity weights, :95-101) and the alignment logits (row max, :131-132);
+//   * nothing through the temperature softmax / threshold / count (only compared, :137-145).
+// The GEMMs of the backward (dgrad = dY W, wgrad = dY^T X) run on madtp_gemm's exact-f32 MFMA kernel with operands
+// transposed by madtp_transpose_pad; this file holds everything else.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;  // head dim
+
+// fixed-order block sum over 256 threads (4 waves): wave butterfly, then the four partials in wave order
+__device__ __forceinline__ float block_sum256(float v, float* red /* >= 4 floats of LDS */) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- dst[c, r] = src[r, c] for r < R, c < C; zero elsewhere of dst[Cp, Rp] ---------------------------------------------
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ src, int ld_src, int R, int C,
+                                                            float* __restrict__ dst, int ld_dst, int Rp, int Cp) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = r0 + ty + 8 * q, c = c0 + tx;
+        tile[ty + 8 * q][tx] = (r < R && c < C) ? src[(size_t)r * ld_src + c] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = c0 + ty + 8 * q, r = r0 + tx;
+        if (c < Cp && r < Rp) dst[(size_t)c * ld_dst + r] = tile[tx][ty + 8 * q];
+    }
+}
+
+// ---- column reductions: out[c] = sum_r f(r, c); XHAT: f = dy * (x - mean_r) * rstd_r (LayerNorm gamma grad), else f = dy --
+// stage 1: grid (ceil(N/64), P): block (64 columns x 4 row lanes), rows r = chunk start + lane, +4, ... in order;
+// stage 2: the P partials of a column in order.
+template <bool XHAT>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ dy, int ld, const float* __restrict__ x,
+                                                         int ldx, const float* __restrict__ stats, int M, int N, int rows_per,
+                                                         float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const int r_begin = blockIdx.y * rows_per, r_end = min(M, r_begin + rows_per);
+    float s = 0.f;
+    if (c < N)
+        for (int r = r_begin + sub; r < r_end; r += 4) {
+            float v = dy[(size_t)r * ld + c];
+            if constexpr (XHAT) v *= (x[(size_t)r * ldx + c] - stats[2 * r]) * stats[2 * r + 1];
+            s += v;
+        }
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && c < N) part[(size_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void col_reduce_final_kernel(const float* __restrict__ part, int P, int N, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(size_t)p * N + c];
+    out[c] = s;
+}
+
+// ---- activations -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_grad(float u, int act) {
+    switch (act) {
+        case MADTP_ACT_GELU_ERF: {
+            const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+            return cdf + u * 0.39894228040143267794f * expf(-0.5f * u * u);
+        }
+        case MADTP_ACT_QUICK_GELU: {
+            const float s = 1.0f / (1.0f + expf(-1.702f * u));
+            return s + 1.702f * u * s * (1.0f - s);
+        }
+        case MADTP_ACT_RELU: return u > 0.f ? 1.0f : 0.0f;
+        default: return 1.0f;
+    }
+}
+__device__ __forceinline__ float act_val(float v, int act) {
+    switch (act) {
+        case MADTP_ACT_GELU_ERF: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case MADTP_ACT_QUICK_GELU: return v / (1.0f + expf(-1.702f * v));
+        case MADTP_ACT_RELU: return fmaxf(v, 0.0f);
+        default: return v;
+    }
+}
+// g = act(u) (g != NULL) and / or du = dg * act'(u) (dg, du != NULL)
+__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ u, const float* __restrict__ dg, float* __restrict__ g,
+                                                  float* __restrict__ du, size_t n4, int act) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 uv = ((const float4*)u)[i];
+    if (g) ((float4*)g)[i] = make_float4(act_val(uv.x, act), act_val(uv.y, act), act_val(uv.z, act), act_val(uv.w, act));
+    if (du) {
+        const float4 d = ((const float4*)dg)[i];
+        ((float4*)du)[i] = make_float4(d.x * act_grad(uv.x, act), d.y * act_grad(uv.y, act), d.z * act_grad(uv.z, act), d.w * act_grad(uv.w, act));
+    }
+}
+
+// ---- LayerNorm backward, one wave per row: dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma (+ add) -----------
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dy, const float* __restrict__ add,
+                                                            float* __restrict__ dx, float* __restrict__ stats, int rows, int dim,
+                                                            float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = (dim / 4 - lane + 63) / 64;
+    float4 v[LN_MAX_CHUNKS], gd[LN_MAX_CHUNKS];
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+        if (c < nchunk) {
+            const int col = (lane + 64 * c) * 4;
+            v[c] = *(const float4*)(x + (size_t)row * dim + col);
+            const float4 d = *(const float4*)(dy + (size_t)row * dim + col), gm = *(const float4*)(gamma + col);
+            gd[c] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+        }
+    float mean, rstd;
+    ln_row(v, nchunk, dim, eps, mean, rstd);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+        if (c < nchunk) {
+            s1 += (gd[c].x + gd[c].y) + (gd[c].z + gd[c].w);
+            s2 += (gd[c].x * (v[c].x - mean) + gd[c].y * (v[c].y - mean)) + (gd[c].z * (v[c].z - mean) + gd[c].w * (v[c].w - mean));
+        }
+    const float c1 = wave_sum(s1) / (float)dim, c2 = wave_sum(s2) * rstd / (float)dim;  // mean(g), mean(g xhat)
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+        if (c < nchunk) {
+            const int col = (lane + 64 * c) * 4;
+            float4 o;
+            o.x = rstd * (gd[c].x - c1 - (v[c].x - mean) * rstd * c2);
+            o.y = rstd * (gd[c].y - c1 - (v[c].y - mean) * rstd * c2);
+            o.z = rstd * (gd[c].z - c1 - (v[c].z - mean) * rstd * c2);
+            o.w = rstd * (gd[c].w - c1 - (v[c].w - mean) * rstd * c2);
+            if (add) {
+                const float4 a = *(const float4*)(add + (size_t)row * dim + col);
+                o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+            }
+            *(float4*)(dx + (size_t)row * dim + col) = o;
+        }
+    if (lane == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+// ---- gather / merge backward (vit.py:153-161): one wave per row of dx [B, N, dim] ------------------------------------
+//   dx[b,0] = dy[b,0]; kept t: dx[b,1+t] = dy[b,1+dst_pos]; dropped t: dx[b,1+t] = merge_w[b,t] dy[b,k+1],
+//   dw[b,t] = <dy[b,k+1], x[b,1+t]> (0 for kept tokens)
+__global__ __launch_bounds__(256) void token_gather_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const int32_t* __restrict__ dst_pos, const float* __restrict__ merge_w,
+                                                               float* __restrict__ dx, float* __restrict__ dw, int B, int N, int k,
+                                                               int dim) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)B * N) return;
+    const int b = (int)(row / N), tok = (int)(row % N);
+    const float* dyb = dy + (size_t)b * (k + 2) * dim;
+    float* o = dx + (size_t)row * dim;
+    if (tok == 0) {
+        for (int c = lane * 4; c < dim; c += 256) *(float4*)(o + c) = *(const float4*)(dyb + c);
+        return;
+    }
+    const int t = tok - 1, dp = dst_pos[(size_t)b * (N - 1) + t];
+    if (dp >= 0) {
+        const float* s = dyb + (size_t)(1 + dp) * dim;
+        for (int c = lane * 4; c < dim; c += 256) *(float4*)(o + c) = *(const float4*)(s + c);
+        if (lane == 0) dw[(size_t)b * (N - 1) + t] = 0.f;
+    } else {
+        const float w = merge_w[(size_t)b * (N - 1) + t];
+        const float* s = dyb + (size_t)(k + 1) * dim;
+        const float* xr = x + (size_t)row * dim;
+        float acc = 0.f;
+        for (int c = lane * 4; c < dim; c += 256) {
+            const float4 d = *(const float4*)(s + c), xv = *(const float4*)(xr + c);
+            *(float4*)(o + c) = make_float4(w * d.x, w * d.y, w * d.z, w * d.w);
+            acc += (d.x * xv.x + d.y * xv.y) + (d.z * xv.z + d.w * xv.w);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) dw[(size_t)b * (N - 1) + t] = acc;
+    }
+}
+
+// ---- importance-score backward (vit.py:126-134 + :95-101), one workgroup per sample -----------------------------------
+// in : dw [B,n] (grad of the merge weights), score [B,n], dst_pos, merge_w, colsum_part [B,nrt,N], p0 [B,H,N], onorm [B,H,N],
+//      token_attn (strided [B,n,K])
+// out: da [B,N] (grad of the UN-normalised head-max column mass a_j, j >= 1; da[b,0] = 0), dp0 [B,H,N] (grad of P[b,h,0,j]),
+//      dnrm_scale [B,H,N] (grad of ||out[b,h,j,:]|| divided by that norm: d out += dnrm_scale * out), dta [B,n,K] dense
+__global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ score,
+                                                        const int32_t* __restrict__ dst_pos, const float* __restrict__ merge_w,
+                                                        const float* __restrict__ colsum_part, int nrt, const float* __restrict__ p0,
+                                                        const float* __restrict__ onorm, const float* __restrict__ ta, int ldt_row,
+                                                        int ldt_batch, int K, float* __restrict__ da, float* __restrict__ dp0,
+                                                        float* __restrict__ dnrm_scale, float* __restrict__ dta, int H, int N) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, n = N - 1, tid = threadIdx.x;
+    const float* cs = colsum_part + (size_t)b * nrt * N;
+    // pass 1: sums
+    float sS = 0.f, sC = 0.f, sA = 0.f, sT = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        const size_t bj = (size_t)b * n + j;
+        if (dst_pos[bj] < 0) { sS += score[bj]; sC += dw[bj] * merge_w[bj]; }
+        float a = 0.f;
+        for (int rt = 0; rt < nrt; ++rt) a += cs[(size_t)rt * N + 1 + j];
+        sA += a;
+        const float* row = ta + (size_t)b * ldt_batch + (size_t)j * ldt_row;
+        float m = row[0];
+        for (int c = 1; c < K; ++c) m = fmaxf(m, row[c]);
+        sT += m;
+    }
+    const float S = block_sum256(sS, red), Cw = block_sum256(sC, red), SA = block_sum256(sA, red), ST = block_sum256(sT, red);
+    const float invS = 1.0f / (S + 1e-8f), invA = 1.0f / (SA + 1e-8f), invT = 1.0f / (ST + 1e-8f);
+    // pass 2: coupling terms of the two normalisations: ca = sum_j g_j a_j/(SA+eps), ct likewise
+    float sca = 0.f, sct = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        const size_t bj = (size_t)b * n + j;
+        const float g = dst_pos[bj] < 0 ? (dw[bj] - Cw) * invS * (1.0f / 3.0f) : 0.f;
+        float a = 0.f;
+        for (int rt = 0; rt < nrt; ++rt) a += cs[(size_t)rt * N + 1 + j];
+        const float* row = ta + (size_t)b * ldt_batch + (size_t)j * ldt_row;
+        float m = row[0];
+        for (int c = 1; c < K; ++c) m = fmaxf(m, row[c]);
+        sca += g * a * invA;
+        sct += g * m * invT;
+    }
+    const float CA = block_sum256(sca, red), CT = block_sum256(sct, red);
+    if (tid == 0) da[(size_t)b * N] = 0.f;
+    for (int h = tid; h < H; h += 256) { dp0[((size_t)b * H + h) * N] = 0.f; dnrm_scale[((size_t)b * H + h) * N] = 0.f; }
+    for (int j = tid; j < n; j += 256) {
+        const size_t bj = (size_t)b * n + j;
+        const float g = dst_pos[bj] < 0 ? (dw[bj] - Cw) * invS * (1.0f / 3.0f) : 0.f;
+        da[(size_t)b * N + 1 + j] = (g - CA) * invA;
+        // alignment logits: gradient lands on the row maximum (first maximum, as torch.max)
+        const float* row = ta + (size_t)b * ldt_batch + (size_t)j * ldt_row;
+        float m = row[0];
+        int am = 0;
+        for (int c = 1; c < K; ++c)
+            if (row[c] > m) { m = row[c]; am = c; }
+        float* drow = dta + ((size_t)b * n + j) * K;
+        const float dt = (g - CT) * invT;
+        for (int c = 0; c < K; ++c) drow[c] = c == am ? dt : 0.f;
+        // cls_attn[j] = sum_h P[h,0,j] hi[h,j], hi = nr_h / (sum_h nr_h + eps)
+        float sn = 0.f;
+        for (int h = 0; h < H; ++h) sn += onorm[((size_t)b * H + h) * N + 1 + j];
+        const float invN = 1.0f / (sn + 1e-8f);
+        float cc = 0.f;
+        for (int h = 0; h < H; ++h) {
+            const size_t o = ((size_t)b * H + h) * N + 1 + j;
+            cc += g * p0[o] * onorm[o] * invN;
+        }
+        for (int h = 0; h < H; ++h) {
+            const size_t o = ((size_t)b * H + h) * N + 1 + j;
+            const float nr = onorm[o];
+            dp0[o] = g * nr * invN;
+            const float dnr = (g * p0[o] - cc) * invN;
+            dnrm_scale[o] = nr > 0.f ? dnr / nr : 0.f;
+        }
+    }
+}
+
+// ---- attention backward ---------------------------------------------------------------------------------------------
+// q/k/v: rows (b*N + i) of a [B*N, ld] f32 matrix, head h at columns [h*64, h*64+64) of each operand's base pointer.
+struct AttnBwdArgs {
+    const float *q, *k, *v; int ld;      // forward operands
+    const float* dout; int ldo;          // grad of the attention output [B*N, H*64]
+    const float* out; int ldout;         // forward attention output (for the norm term), may be NULL with dnrm_scale
+    const float* dnrm_scale;             // [B,H,N] or NULL
+    const float* da;                     // [B,N] or NULL: grad of a_j = sum_{i>=1} max_h P[h,i,j]
+    const float* dp0;                    // [B,H,N] or NULL: grad of P[h,0,j]
+    float* P; float* dS;                 // scratch [B,H,N,N] each
+    unsigned char* hm;                   // scratch [B,N,N]: argmax_h P[b,h,i,j]
+    float *dq, *dk, *dv; int ldd;        // outputs, same layout as q/k/v
+    int B, H, N; float scale;
+};
+
+// P[b,h,i,:] = softmax_j(scale q_i . k_j) for 16 query rows per workgroup
+__global__ __launch_bounds__(256) void attn_probs_kernel(AttnBwdArgs a) {
+    extern __shared__ float sm[];
+    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, i0 = blockIdx.y * 16, N = a.N, tid = threadIdx.x;
+    float* Qs = sm;                 // [16][64]
+    float* S = sm + 16 * HD;        // [16][N]
+    for (int e = tid; e < 16 * HD; e += 256) {
+        const int r = e >> 6, d = e & 63, i = min(i0 + r, N - 1);
+        Qs[e] = a.q[(size_t)(b * N + i) * a.ld + h * HD + d];
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += 256) {
+        float kr[HD];
+        const float* kp = a.k + (size_t)(b * N + j) * a.ld + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) { const float4 t = *(const float4*)(kp + d); kr[d] = t.x; kr[d + 1] = t.y; kr[d + 2] = t.z; kr[d + 3] = t.w; }
+        for (int r = 0; r < 16; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) s = fmaf(Qs[r * HD + d], kr[d], s);
+            S[r * N + j] = s * a.scale;
+        }
+    }
+    __syncthreads();
+    const int r = tid >> 4, l = tid & 15;  // 16 lanes per row
+    float m = -INFINITY;
+    for (int j = l; j < N; j += 16) m = fmaxf(m, S[r * N + j]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float sum = 0.f;
+    for (int j = l; j < N; j += 16) { const float e = expf(S[r * N + j] - m); S[r * N + j] = e; sum += e; }
+    sum = row16_sum(sum);
+    if (i0 + r < N) {
+        float* Pr = a.P + ((size_t)bh * N + i0 + r) * N;
+        for (int j = l; j < N; j += 16) Pr[j] = S[r * N + j] / sum;
+    }
+}
+
+// hm[b,i,j] = argmax_h P[b,h,i,j] (first maximum)
+__global__ __launch_bounds__(256) void attn_headmax_kernel(AttnBwdArgs a) {
+    const int b = blockIdx.x, i = blockIdx.y, N = a.N;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        float m = a.P[(((size_t)b * a.H) * N + i) * N + j];
+        int am = 0;
+        for (int h = 1; h < a.H; ++h) {
+            const float p = a.P[(((size_t)b * a.H + h) * N + i) * N + j];
+            if (p > m) { m = p; am = h; }
+        }
+        a.hm[((size_t)b * N + i) * N + j] = (unsigned char)am;
+    }
+}
+
+// rows pass: dP = dO V^T (+ score terms), dS = P (dP - rowsum(P dP)), dQ = scale dS K
+__global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdArgs a) {
+    extern __shared__ float sm[];
+    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, i0 = blockIdx.y * 16, N = a.N, tid = threadIdx.x;
+    float* dOs = sm;                  // [16][64]
+    float* Ps = sm + 16 * HD;         // [16][N]
+    float* Ds = Ps + 16 * N;          // [16][N]: dP, then dS
+    for (int e = tid; e < 16 * HD; e += 256) {
+        const int r = e >> 6, d = e & 63, i = i0 + r;
+        float v = 0.f;
+        if (i < N) {
+            v = a.dout[(size_t)(b * N + i) * a.ldo + h * HD + d];
+            if (a.dnrm_scale) v += a.dnrm_scale[((size_t)b * a.H + h) * N + i] * a.out[(size_t)(b * N + i) * a.ldout + h * HD + d];
+        }
+        dOs[e] = v;
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += 256) {
+        float vr[HD];
+        const float* vp = a.v + (size_t)(b * N + j) * a.ld + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) { const float4 t = *(const float4*)(vp + d); vr[d] = t.x; vr[d + 1] = t.y; vr[d + 2] = t.z; vr[d + 3] = t.w; }
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + r;
+            float dp = 0.f, p = 0.f;
+            if (i < N) {
+#pragma unroll
+                for (int d = 0; d < HD; ++d) dp = fmaf(dOs[r * HD + d], vr[d], dp);
+                p = a.P[((size_t)bh * N + i) * N + j];
+                if (j >= 1) {
+                    if (i == 0) { if (a.dp0) dp += a.dp0[((size_t)b * a.H + h) * N + j]; }
+                    else if (a.da && a.hm[((size_t)b * N + i) * N + j] == h) dp += a.da[(size_t)b * N + j];
+                }
+            }
+            Ps[r * N + j] = p;
+            Ds[r * N + j] = dp;
+        }
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 4, l = tid & 15;
+        float dsum = 0.f;
+        for (int j = l; j < N; j += 16) dsum += Ps[r * N + j] * Ds[r * N + j];
+        dsum = row16_sum(dsum);
+        for (int j = l; j < N; j += 16) {
+            const float ds = Ps[r * N + j] * (Ds[r * N + j] - dsum);
+            Ds[r * N + j] = ds;
+            if (i0 + r < N) a.dS[((size_t)bh * N + i0 + r) * N + j] = ds;
+        }
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 4, dq = (tid & 15) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < N; ++j) {
+            const float ds = Ds[r * N + j];
+            const float4 kv = *(const float4*)(a.k + (size_t)(b * N + j) * a.ld + h * HD + dq);
+            acc.x = fmaf(ds, kv.x, acc.x); acc.y = fmaf(ds, kv.y, acc.y); acc.z = fmaf(ds, kv.z, acc.z); acc.w = fmaf(ds, kv.w, acc.w);
+        }
+        if (i0 + r < N)
+            *(float4*)(a.dq + (size_t)(b * N + i0 + r) * a.ldd + h * HD + dq) =
+                make_float4(acc.x * a.scale, acc.y * a.scale, acc.z * a.scale, acc.w * a.scale);
+    }
+}
+
+// columns pass: dV_j = sum_i P_ij dO_i, dK_j = scale sum_i dS_ij Q_i for 16 keys per workgroup
+__global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnBwdArgs a) {
+    __shared__ float Pt[16][17], St[16][17], Qt[16][HD], Ot[16][HD];
+    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, j0 = blockIdx.y * 16, N = a.N, tid = threadIdx.x;
+    const int c = tid >> 4, dq = (tid & 15) * 4;
+    float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), dk = dv;
+    for (int i0 = 0; i0 < N; i0 += 16) {
+        __syncthreads();
+        {
+            const int r = tid >> 4, cc = tid & 15, i = i0 + r, j = j0 + cc;
+            const bool ok = i < N && j < N;
+            Pt[r][cc] = ok ? a.P[((size_t)bh * N + i) * N + j] : 0.f;
+            St[r][cc] = ok ? a.dS[((size_t)bh * N + i) * N + j] : 0.f;
+        }
+        for (int e = tid; e < 16 * HD; e += 256) {
+            const int r = e >> 6, d = e & 63, i = i0 + r;
+            float qv = 0.f, ov = 0.f;
+            if (i < N) {
+                qv = a.q[(size_t)(b * N + i) * a.ld + h * HD + d];
+                ov = a.dout[(size_t)(b * N + i) * a.ldo + h * HD + d];
+                if (a.dnrm_scale) ov += a.dnrm_scale[((size_t)b * a.H + h) * N + i] * a.out[(size_t)(b * N + i) * a.ldout + h * HD + d];
+            }
+            Qt[r][d] = qv;
+            Ot[r][d] = ov;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = Pt[r][c], ds = St[r][c];
+            const float4 o = *(const float4*)&Ot[r][dq], qv = *(const float4*)&Qt[r][dq];
+            dv.x = fmaf(p, o.x, dv.x); dv.y = fmaf(p, o.y, dv.y); dv.z = fmaf(p, o.z, dv.z); dv.w = fmaf(p, o.w, dv.w);
+            dk.x = fmaf(ds, qv.x, dk.x); dk.y = fmaf(ds, qv.y, dk.y); dk.z = fmaf(ds, qv.z, dk.z); dk.w = fmaf(ds, qv.w, dk.w);
+        }
+    }
+    if (j0 + c < N) {
+        *(float4*)(a.dv + (size_t)(b * N + j0 + c) * a.ldd + h * HD + dq) = dv;
+        *(float4*)(a.dk + (size_t)(b * N + j0 + c) * a.ldd + h * HD + dq) =
+            make_float4(dk.x * a.scale, dk.y * a.scale, dk.z * a.scale, dk.w * a.scale);
+    }
+}
+
+}  // namespace
+
+extern "C" int madtp_transpose_pad(const float* src, int ld_src, int R, int C, float* dst, int ld_dst, int Rp, int Cp, void* stream) {
+    if (!src || !dst || R <= 0 || C <= 0 || Rp < R || Cp < C || ld_src < C || ld_dst < Rp) return MADTP_E_BADARG;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((Rp + 31) / 32, (Cp + 31) / 32), dim3(256), 0, (hipStream_t)stream, src, ld_src, R, C,
+                       dst, ld_dst, Rp, Cp);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+static int col_reduce(const float* dy, int ld, const float* x, int ldx, const float* stats, int M, int N, float* out, float* part,
+                      hipStream_t s) {
+    const int P = M >= 4096 ? 64 : (M >= 256 ? 16 : 1);
+    const int rows_per = (M + P - 1) / P;
+    if (x) hipLaunchKernelGGL(col_reduce_kernel<true>, dim3((N + 63) / 64, P), dim3(256), 0, s, dy, ld, x, ldx, stats, M, N, rows_per, part);
+    else hipLaunchKernelGGL(col_reduce_kernel<false>, dim3((N + 63) / 64, P), dim3(256), 0, s, dy, ld, x, ldx, stats, M, N, rows_per, part);
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, P, N, out);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_colsum(const float* dy, int ld, int M, int N, float* out, float* part_ws, void* stream) {
+    if (!dy || !out || !part_ws || M <= 0 || N <= 0 || ld < N) return MADTP_E_BADARG;
+    return col_reduce(dy, ld, nullptr, 0, nullptr, M, N, out, part_ws, (hipStream_t)stream);
+}
+
+extern "C" int madtp_act_fwd_bwd(const float* u, const float* dg, float* g, float* du, size_t n, int act, void* stream) {
+    if (!u || (!g && !du) || (du && !dg) || n == 0 || (n & 3)) return MADTP_E_BADARG;
+    if (!aligned16(u) || (g && !aligned16(g)) || (du && (!aligned16(du) || !aligned16(dg)))) return MADTP_E_ALIGN;
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(act_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, dg, g, du, n4, act);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* add, float* dx, float* dgamma,
+                                   float* dbeta, float* ws, int rows, int dim, float eps, void* stream) {
+    if (!x || !gamma || !dy || !dx || !ws || rows <= 0 || dim <= 0) return MADTP_E_BADARG;
+    if (dim % 4 || dim > 256 * LN_MAX_CHUNKS) return MADTP_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    float* stats = ws;                       // [rows, 2]
+    float* part = ws + (size_t)2 * rows;     // [64, dim]
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, dy, add, dx, stats, rows, dim, eps);
+    MADTP_LAUNCH_CHECK();
+    if (dgamma) { const int rc = col_reduce(dy, dim, x, dim, stats, rows, dim, dgamma, part, s); if (rc) return rc; }
+    if (dbeta) { const int rc = col_reduce(dy, dim, nullptr, 0, nullptr, rows, dim, dbeta, part, s); if (rc) return rc; }
+    return 0;
+}
+
+extern "C" int madtp_token_gather_bwd(const float* dy, const float* x, const int32_t* dst_pos, const float* merge_w, float* dx,
+                                      float* dw, int B, int N, int k, int dim, void* stream) {
+    if (!dy || !x || !dst_pos || !merge_w || !dx || !dw || B <= 0 || N < 3 || k < 1 || k > N - 1 || dim <= 0 || dim % 4) return MADTP_E_BADARG;
+    const long rows = (long)B * N;
+    hipLaunchKernelGGL(token_gather_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy, x, dst_pos,
+                       merge_w, dx, dw, B, N, k, dim);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_token_score_bwd(const float* dw, const float* score, const int32_t* dst_pos, const float* merge_w,
+                                     const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
+                                     const float* token_attn, int ldt_row, int ldt_batch, int K, float* da, float* dp0,
+                                     float* dnrm_scale, float* dtoken_attn, int B, int H, int N, void* stream) {
+    if (!dw || !score || !dst_pos || !merge_w || !colsum_part || !p0 || !onorm || !token_attn || !da || !dp0 || !dnrm_scale ||
+        !dtoken_attn || B <= 0 || H <= 0 || N < 3 || K <= 0)
+        return MADTP_E_BADARG;
+    hipLaunchKernelGGL(score_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dw, score, dst_pos, merge_w, colsum_part,
+                       n_row_tiles, p0, onorm, token_attn, ldt_row, ldt_batch, K, da, dp0, dnrm_scale, dtoken_attn, H, N);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t madtp_attention_bwd_workspace(int B, int H, int N) {
+    const size_t pn = (size_t)B * H * N * N * sizeof(float);
+    return 2 * pn + (((size_t)B * N * N + 255) & ~(size_t)255);
+}
+
+extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, const float* dout, int ldo,
+                                   const float* out, int ldout, const float* dnrm_scale, const float* da, const float* dp0,
+                                   float* dq, float* dk, float* dv, int ldd, void* ws, size_t ws_bytes, int B, int H, int N,
+                                   float scale, void* stream) {
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || !ws || B <= 0 || H <= 0 || N <= 0) return MADTP_E_BADARG;
+    if (dnrm_scale && !out) return MADTP_E_BADARG;
+    if (N > 1024) return MADTP_E_SHAPE;  // the row kernels keep 16 x N score rows in LDS (2 x 64 KiB at N = 1024)
+    if (ws_bytes < madtp_attention_bwd_workspace(B, H, N)) return MADTP_E_BADARG;
+    if (ld % 4 || ldd % 4 || !aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv)) return MADTP_E_ALIGN;
+    AttnBwdArgs a;
+    a.q = q; a.k = k; a.v = v; a.ld = ld; a.dout = dout; a.ldo = ldo; a.out = out; a.ldout = ldout; a.dnrm_scale = dnrm_scale;
+    a.da = da; a.dp0 = dp0; a.dq = dq; a.dk = dk; a.dv = dv; a.ldd = ldd; a.B = B; a.H = H; a.N = N; a.scale = scale;
+    const size_t pn = (size_t)B * H * N * N;
+    a.P = (float*)ws; a.dS = a.P + pn; a.hm = (unsigned char*)(a.dS + pn);
+    hipStream_t s = (hipStream_t)stream;
+    const int nrt = (N + 15) / 16;
+    const size_t lds_p = (size_t)(16 * HD + 16 * N) * sizeof(float), lds_r = (size_t)(16 * HD + 32 * N) * sizeof(float);
+    MADTP_ENSURE_MAX_LDS(attn_probs_kernel, lds_p);
+    MADTP_ENSURE_MAX_LDS(attn_bwd_rows_kernel, lds_r);
+    hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, nrt), dim3(256), lds_p, s, a);
+    if (da) hipLaunchKernelGGL(attn_headmax_kernel, dim3(B, N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(B * H, nrt), dim3(256), lds_r, s, a);
+    hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(B * H, nrt), dim3(256), 0, s, a);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}

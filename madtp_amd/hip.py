@@ -12,7 +12,7 @@ import torch
 
 F32, BF16, F16S = 0, 1, 2  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -86,6 +86,17 @@ _SIGS = {
     "madtp_lm_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p]),
     "madtp_token_prob": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "madtp_beam_topk": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    # backward of the pruned ViT block (csrc/backward.hip)
+    "madtp_transpose_pad": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "madtp_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "madtp_act_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "madtp_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_void_p]),
+    "madtp_token_gather_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
+    "madtp_token_score_bwd": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4
+                              + [c_int, c_int, c_int, c_void_p]),
+    "madtp_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "madtp_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 6
+                            + [c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_float, c_void_p]),
 }
 
 

@@ -201,6 +201,15 @@ class Block(nn.Module):
         prune = temperature > 0
         if prune and token_attn is None:
             raise ValueError("temperature > 0 requires token_attn (the reference fails in Reduce_token as well)")
+        if torch.is_grad_enabled():
+            # training / compression (compress_nlvr_dtp.py:46-58): Block.forward under autograd with the hand-written backward of
+            # madtp_amd/backward.py (fp32 precision mode).  An input that asks for a gradient in another mode fails loudly;
+            # parameters that merely have requires_grad = True (the nn.Module default) do not force the autograd path there.
+            wants = x.requires_grad or (token_attn is not None and token_attn.requires_grad)
+            from .runtime import get_precision
+            if wants or (get_precision() == "fp32" and any(p.requires_grad for p in self.parameters())):
+                from .backward import block_forward_with_grad
+                return block_forward_with_grad(self, x, temperature if prune else 0, token_attn)
         w = self._weights()
         # one library call: x = x + attn(norm1(x)), importance score / threshold / count (vit.py:186-190,125-145), the host
         # read of k = max_b count (vit.py:145), [top-k, gather, merge] and x = x + mlp(norm2(x)) (vit.py:153-161,195-205)

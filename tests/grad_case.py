@@ -1,0 +1,55 @@
+"""Shared by the CPU oracle test and the GPU test of the block backward: rebuilds the inputs of a vit_block_grad_* fixture
+(tools/make_golden.py::vit_block_grad_case) from the deterministic generators and the CPU oracle."""
+import numpy as np
+import torch
+
+from madtp_amd import specs, synth
+from oracle import madtp_oracle as O
+
+
+def grad_sample_index(numel, n=1024):
+    return (np.arange(min(n, numel), dtype=np.int64) * 7919) % numel
+
+
+def build(g):
+    """g: loaded fixture -> dict(W, prefix, x, token_attn, T, G, layer)."""
+    B, size, T, seed, layer = int(g["B"]), int(g["size"]), float(g["temperature"]), int(g["seed"]), int(g["layer"])
+    W = specs.synth_weights(specs.vit_shapes("", size), seed)
+    images = synth.synth_images(B, size, seed)
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed)
+    layer_inputs = []
+    with torch.no_grad():
+        O.vit_forward(W, "", images, space_dict, T, depth=layer + 1, layer_inputs=layer_inputs)
+        x = layer_inputs[layer]
+        token_attn, _ = O.query_model(x[:, 1:, :], space_dict)
+    out_shape = tuple(int(v) for v in g["out_shape"])
+    G = torch.from_numpy(synth.uniform_pm1("grad_out", int(np.prod(out_shape)), seed).reshape(out_shape))
+    return {"W": W, "prefix": f"blocks.{layer}.", "x": x, "token_attn": token_attn.contiguous(), "T": T, "G": G, "layer": layer}
+
+
+def check_against_fixture(g, grads, rtol, what):
+    """grads: {name: tensor}; compares norm, sum and the sampled entries of every recorded gradient."""
+    names = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample")]
+    assert names, "fixture holds no gradients"
+    for name in names:
+        t = grads[name].detach().float().cpu().reshape(-1)
+        ref = torch.from_numpy(g[f"g_{name}_sample"])
+        got = t[torch.from_numpy(grad_sample_index(t.numel()))]
+        scale = max(float(ref.abs().max()), 1e-12)
+        err = float((got - ref).abs().max()) / scale
+        assert err < rtol, f"{what}: grad {name}: sampled entries differ by {err:.3e} of their maximum (tolerance {rtol})"
+        nrm = float(t.double().norm())
+        assert abs(nrm - float(g[f"g_{name}_norm"])) <= rtol * max(float(g[f"g_{name}_norm"]), 1e-12), f"{what}: |grad {name}|"
+
+
+def permute_G(G, ref_indices, own_indices):
+    """The reference keeps tokens in torch.topk(sorted=False)'s order, the HIP path in ascending token order:
+    row 1 + p of the block output is token own_indices[b, p] here and token ref_indices[b, p] there.  Returns G re-ordered so that
+    every TOKEN receives the upstream gradient it gets in the reference (CLS row and merged-token row stay in place)."""
+    out = G.clone()
+    B, k = ref_indices.shape
+    for b in range(B):
+        pos = {int(t): p for p, t in enumerate(ref_indices[b])}
+        for p in range(k):
+            out[b, 1 + p] = G[b, 1 + pos[int(own_indices[b, p])]]
+    return out

@@ -1,0 +1,145 @@
+"""Backward of the pruned ViT block on a real MI355X (first half): the hand-written HIP backward
+(madtp_amd/backward.py + csrc/backward.hip, fp32 precision mode) against
+  * the reference's own .grad (tests/golden/vit_block_grad_*.npz, recorded from models/vit.py by tools/make_golden.py),
+  * autograd through the CPU oracle on the same inputs (full tensors),
+with the tolerance SURVEY/VERDICT name: 1e-3 relative to each gradient's largest entry; and the single kernels against torch."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vit_block_grad_*.npz")))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from madtp_amd import build, hip as h
+    build.build(verbose=False)
+    h.load()
+    assert torch.cuda.is_available()
+    return h
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _rel(a, b):
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+
+
+def test_transpose_colsum_act(hip):
+    from madtp_amd import backward as bw
+    x = _rand(197, 100, seed=1).cuda()
+    t = bw.transpose_pad(x, 224, 128)
+    assert t.shape == (128, 224) and torch.equal(t[:100, :197], x.t()) and float(t[100:].abs().max()) == 0 and float(t[:, 197:].abs().max()) == 0
+    y = _rand(5000, 776, seed=2).cuda()
+    assert _rel(bw.colsum(y).cpu(), y.double().sum(0).float().cpu()) < 1e-5
+    assert torch.equal(bw.colsum(y), bw.colsum(y))  # fixed-order reduction
+    u, dg = _rand(300, 3072, seed=3).cuda(), _rand(300, 3072, seed=4).cuda()
+    ur = u.clone().requires_grad_(True)
+    g = F.gelu(ur)
+    g.backward(dg)
+    assert _rel(bw.act_fwd(u, hip.ACT_GELU), g.detach()) < 1e-6 and _rel(bw.act_bwd(u, dg, hip.ACT_GELU), ur.grad) < 1e-5
+
+
+def test_dgrad_wgrad(hip):
+    from madtp_amd import backward as bw
+    M, N, K = 394, 2304, 768
+    dy, x, w = _rand(M, N, seed=1).cuda(), _rand(M, K, seed=2).cuda(), _rand(N, K, seed=3, scale=0.05).cuda()
+    assert _rel(bw.dgrad(dy, w), (dy.double() @ w.double()).float()) < 1e-5
+    assert _rel(bw.wgrad(dy, x), (dy.double().t() @ x.double()).float()) < 1e-5
+
+
+def test_layernorm_bwd(hip):
+    from madtp_amd import backward as bw
+    rows, dim = 1001, 768
+    x, dy, add = _rand(rows, dim, seed=1).cuda(), _rand(rows, dim, seed=2).cuda(), _rand(rows, dim, seed=3).cuda()
+    gamma, beta = (1 + 0.1 * _rand(dim, seed=4)).cuda(), _rand(dim, seed=5).cuda()
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    F.layer_norm(xr, (dim,), gr, br, 1e-6).backward(dy)
+    dx, dgamma, dbeta = bw.layernorm_bwd(x, gamma, dy, 1e-6, add=add)
+    assert _rel(dx, xr.grad + add) < 1e-5 and _rel(dgamma, gr.grad) < 1e-5 and _rel(dbeta, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,N", [(2, 197), (3, 50), (1, 300)])
+def test_attention_bwd_plain(hip, B, N):
+    """softmax attention backward with recomputed probabilities vs torch autograd (no score terms)."""
+    from madtp_amd import backward as bw
+    H, D = 12, 768
+    qkv = _rand(B * N, 3 * D, seed=1, scale=0.5).cuda()
+    dout = _rand(B * N, D, seed=2).cuda()
+    r = qkv.clone().requires_grad_(True)
+    q, k, v = [t.reshape(B, N, H, 64).permute(0, 2, 1, 3) for t in (r[:, :D], r[:, D:2 * D], r[:, 2 * D:])]
+    p = ((q @ k.transpose(-2, -1)) * 0.125).softmax(-1)
+    o = (p @ v).transpose(1, 2).reshape(B * N, D)
+    o.backward(dout)
+    dqkv = bw.attention_bwd(qkv, dout, o.detach().contiguous(), B, H, N, 0.125)
+    assert _rel(dqkv, r.grad) < 2e-5
+    assert torch.equal(dqkv, bw.attention_bwd(qkv, dout, o.detach().contiguous(), B, H, N, 0.125))
+
+
+@pytest.mark.parametrize("path", GRAD_CASES, ids=[os.path.basename(c)[:-4] for c in GRAD_CASES])
+def test_block_backward_matches_reference_grads(hip, path):
+    from madtp_amd import runtime, vit
+    from oracle import madtp_oracle as O
+    from tests import grad_case
+    g = np.load(path)
+    c = grad_case.build(g)
+    blk = vit.Block(768, 12, qkv_bias=True, norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6))
+    blk.load_state_dict({k[len(c["prefix"]):]: v for k, v in c["W"].items() if k.startswith(c["prefix"])}, strict=True)
+    blk = blk.cuda()
+    x = c["x"].cuda().requires_grad_(True)
+    ta = c["token_attn"].cuda().requires_grad_(True)
+    with runtime.precision("fp32"):
+        y = blk(x, False, 0, c["T"], ta)
+        assert tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
+        info = blk.last_prune
+        for b in range(x.shape[0]):
+            assert {int(v) for v in info["indices"][b]} == {int(v) for v in g["blk_idx"][b]}, "kept set differs from the reference"
+        # same upstream gradient per TOKEN as in the recording (the two paths order the kept tokens differently)
+        G = grad_case.permute_G(c["G"], g["blk_idx"], info["indices"].cpu().numpy())
+        (y * G.cuda()).sum().backward()
+    grads = {"x": x.grad, "token_attn": ta.grad}
+    grads.update({k: p.grad for k, p in blk.named_parameters()})
+    # (1) the reference's own gradients (sampled entries, norms)
+    grad_case.check_against_fixture(g, grads, 1e-3, "HIP backward vs reference")
+    # (2) autograd through the CPU oracle, every entry
+    ref, _, oinfo = O.vit_block_grads(c["W"], c["prefix"], c["x"], c["token_attn"], c["T"], c["G"])
+    assert np.array_equal(oinfo["indices"].numpy(), g["blk_idx"]), "the oracle keeps the recording's token order on this box"
+    for name, r in ref.items():
+        e = _rel(grads[name].cpu(), r)
+        assert e < 1e-3, f"grad {name}: {e:.3e} of its maximum"
+    # the alignment-logit gradient has one entry per token row, at the row maximum
+    nz = (ta.grad != 0).sum(-1)
+    assert int(nz.max()) <= 1
+    # not pruned (temperature 0): the plain residual-block backward
+    x2 = c["x"].cuda().requires_grad_(True)
+    for p in blk.parameters():
+        p.grad = None
+    G2 = torch.from_numpy(np.random.RandomState(0).uniform(-1, 1, size=tuple(c["x"].shape)).astype(np.float32))
+    with runtime.precision("fp32"):
+        y2 = blk(x2, False, 0, 0, None)
+        (y2 * G2.cuda()).sum().backward()
+    Wl = {k: v for k, v in c["W"].items() if k.startswith(c["prefix"])}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in Wl.items()}
+    xl = c["x"].clone().requires_grad_(True)
+    yo, _ = O.vit_block(leaves, c["prefix"], xl, 0, None)
+    (yo * G2).sum().backward()
+    assert _rel(x2.grad.cpu(), xl.grad) < 1e-3
+    for k, p in blk.named_parameters():
+        assert _rel(p.grad.cpu(), leaves[c["prefix"] + k].grad) < 1e-3, k
+
+
+def test_block_backward_needs_fp32_mode(hip):
+    from madtp_amd import runtime, vit
+    blk = vit.Block(768, 12, qkv_bias=True).cuda()
+    x = torch.randn(1, 20, 768, device="cuda", requires_grad=True)
+    with runtime.precision("bf16"), pytest.raises(NotImplementedError):
+        blk(x)

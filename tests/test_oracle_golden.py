@@ -535,3 +535,23 @@ def test_oracle_caption_generate_matches_reference_fixture(path):
         seq5 = O.blip_decoder_generate_forward(cap_gen_weights(g), images, float(g["temperature"]), num_beams=int(g["num_beams"]),
                                                max_length=int(g["max_length"]), min_length=int(g["min_length"]), library="5.15")
     assert seq5.tolist() == g["sequences"].tolist()
+
+
+GRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vit_block_grad_*.npz")))
+
+
+@pytest.mark.parametrize("path", GRAD_CASES, ids=[os.path.basename(c)[:-4] for c in GRAD_CASES])
+def test_oracle_block_backward_matches_reference_grads(path):
+    """autograd through oracle.vit_block == the reference's own .grad of models/vit.py Block.forward (x,
+    token_attn and all 12 parameters), recorded by tools/make_golden.py::vit_block_grad_case.  Pins the checker of the HIP
+    backward (tests/test_backward_gpu.py)."""
+    from tests import grad_case
+    g = np.load(path)
+    c = grad_case.build(g)
+    assert np.allclose(c["x"][:, :2, :8].numpy(), g["x_head"], atol=0, rtol=0), "block input differs from the recording"
+    assert np.allclose(c["token_attn"][:, :2, :8].numpy(), g["ta_head"], rtol=1e-6, atol=1e-6)
+    grads, y, info = O.vit_block_grads(c["W"], c["prefix"], c["x"], c["token_attn"], c["T"], c["G"])
+    assert tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
+    assert {int(v) for v in info["indices"][0]} == {int(v) for v in g["blk_idx"][0]}
+    assert np.allclose(y[:, :3, :16].numpy(), g["y_head"], rtol=1e-5, atol=1e-6)
+    grad_case.check_against_fixture(g, grads, 2e-5, "oracle autograd vs reference")

@@ -223,6 +223,55 @@ def vit_case(name, B, size, temperature, seed=0):
     print(f"[{name}] size={size} T={temperature} vit_lens={lens}")
 
 
+def grad_sample_index(numel, n=1024):
+    """deterministic sample positions of a flattened gradient tensor (shared with tests/test_oracle_golden.py and the GPU test)"""
+    return (np.arange(min(n, numel), dtype=np.int64) * 7919) % numel
+
+
+def vit_block_grad_case(name, B, size, temperature, layer=0, seed=0):
+    """the reference's OWN autograd through models/vit.py Block.forward for one layer.  The block
+    input x and the query model's token_attn are captured from a no-grad forward of the reference VisionTransformer (pre-hook of
+    block `layer`, cloned before Reduce_token divides token_attn in place, vit.py:137), then block `layer` runs again alone with
+    x and token_attn as leaves and loss = sum(y * G); recorded: the pruning decision, and of every gradient (x, token_attn, the 12
+    parameters) its L2 norm, its sum and 1024 sampled entries (grad_sample_index) - data only."""
+    import models.vit as rvit
+    from madtp_amd import specs
+    model = rvit.VisionTransformer(img_size=size, patch_size=16, embed_dim=768, depth=12, num_heads=12, evaluate=True, sd_dim=768)
+    model.eval()
+    model.load_state_dict(specs.synth_weights(specs.vit_shapes("", size), seed), strict=True)
+    images = synth.synth_images(B, size, seed)
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed)
+    cap = {}
+    blk = model.blocks[layer]
+    h = blk.register_forward_pre_hook(lambda m, a: cap.update(x=a[0].detach().clone(), ta=a[4].detach().clone()))
+    with torch.no_grad():
+        model(images, space_dict=space_dict, temperature=temperature)
+    h.remove()
+    x = cap["x"].clone().requires_grad_(True)
+    ta = cap["ta"].clone().requires_grad_(True)
+    tap = GatherTap(rvit)
+    tap.set_tag("blk")
+    for p_ in blk.parameters():
+        p_.grad = None
+    y = blk(x, False, 0, temperature, ta * 1.0)   # (ta * 1.0: the block divides its argument in place; keep the leaf intact)
+    tap.restore()
+    G = torch.from_numpy(synth.uniform_pm1("grad_out", y.numel(), seed).reshape(tuple(y.shape)))
+    (y * G).sum().backward()
+    rec = {"kind": "vit_block_grad", "B": B, "size": size, "temperature": np.float64(temperature), "seed": seed, "layer": layer,
+           "out_shape": np.array(y.shape), "y_head": y.detach()[:, :3, :16].numpy(), "blk_idx": tap.records["blk_idx"],
+           "x_head": cap["x"][:, :2, :8].numpy(), "ta_head": cap["ta"][:, :2, :8].numpy()}
+    grads = {"x": x.grad, "token_attn": ta.grad}
+    grads.update({k: v.grad for k, v in blk.named_parameters()})
+    for k, g in grads.items():
+        flat = g.detach().reshape(-1)
+        idx = grad_sample_index(flat.numel())
+        rec[f"g_{k}_sample"] = flat[torch.from_numpy(idx)].numpy()
+        rec[f"g_{k}_norm"] = np.float64(flat.double().norm().item())
+        rec[f"g_{k}_sum"] = np.float64(flat.double().sum().item())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] layer {layer} T={temperature} out {tuple(y.shape)} |dx| {rec['g_x_norm']:.4e} |dta| {rec['g_token_attn_norm']:.4e}")
+
+
 def clip_case(name, B, temperature, seed=0, size=224):
     """clip/model.py VisionTransformer (ViT-B/16 geometry) with clip/mock.py's patched MultiheadAttention."""
     import clip.mock  # noqa: F401  (monkey-patches torch.nn.MultiheadAttention, as the reference does on import)
@@ -533,6 +582,10 @@ CASES = {
     "vit480_b1": lambda: vit_case("vit480_b1", 1, 480, 6.0),
     "retr_i6_t12": lambda: retrieval_case("retr_i6_t12", 6, 3, 12, 224, 6.0, 4),
     "retr_384_i4_t6": lambda: retrieval_case("retr_384_i4_t6", 4, 2, 6, 384, 4.0, 3, seed=1),
+    # backward of one pruned ViT block: the reference's own .grad (layer 0 at T = 5: 196 -> ~133 kept + 1 merged token; layer 3
+    # at the same temperature enters with an already pruned sequence of 101 tokens; margins of every pruning decision on the way are >= 8e-5 relative, far above f32 rounding)
+    "vit_block_grad_b2": lambda: vit_block_grad_case("vit_block_grad_b2", 2, 224, 5.0, layer=0),
+    "vit_block_grad_b2_l3": lambda: vit_block_grad_case("vit_block_grad_b2_l3", 2, 224, 5.0, layer=3),
 }
 
 if __name__ == "__main__":
