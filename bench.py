@@ -36,8 +36,8 @@ sys.path.insert(0, ROOT)
 
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md.  f16x3: three f16 MFMA products per logical product, so the
 # roofline of the fp32-accurate GEMM in ALGORITHMIC flops (2MNK) is a third of the f16 dense peak.
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "f16x3": 2500.0 / 3.0}
-GEMM_DT = {"bf16": "bf16", "fp32": "f32", "f16x3": "f16s"}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "fp32": 157.3, "f16x3": 2500.0 / 3.0}
+GEMM_DT = {"bf16": "bf16", "f16": "f16", "fp32": "f32", "f16x3": "f16s"}
 WS_MIN_M = 4096  # madtp_gemm runs 2-byte-operand problems with M >= 4096 (and no split-K) on gemm_ws_kernel / gemm_sq_kernel (csrc/gemm.hip)
 METRIC = "images/sec forward, BLIP-base NLVR2 p=0.5 b64; pruned-token index match"
 
@@ -81,7 +81,7 @@ def measure_traffic(args):
             c = sqlite3.connect(dbs[0])
             rows = c.execute("select name, count(*), sum(counter_value) from pmc_events where counter_name=? group by name",
                              (counter,)).fetchall()
-            big = lambda name: "gemm_ws_kernel" in name or "gemm_sq_kernel" in name  # noqa: E731  (the two big-GEMM kernels)
+            big = lambda name: "gemm_ws_kernel" in name or "gemm_sq_kernel" in name or "gemm_pp_kernel" in name  # noqa: E731  (the big-GEMM kernels)
             n = sum(cnt for name, cnt, _ in rows if big(name))
             v = sum(val for name, _, val in rows if big(name))
             if not n:
@@ -97,7 +97,7 @@ def measure_traffic(args):
     return {"bytes_per_launch": int(2 * f_b + w_b), "fetch_size_raw_bytes_per_launch": int(f_b),
             "write_size_bytes_per_launch": int(w_b), "launches_profiled": f_n,
             "how": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace (separate passes) over a 1-step copy of the "
-                   "command, gemm_ws_kernel + gemm_sq_kernel launches only; 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md)"}
+                   "command, gemm_ws_kernel + gemm_pp_kernel (+ gemm_sq_kernel) launches only; 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md)"}
 
 
 def main():
@@ -106,7 +106,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)  # a multiple of the 2 / 3 / 4 forwards in flight (equal shares per worker; 24 forwards each: the ramp-up and the tail of the pipeline cost 24 steps ~5 %, 48 ~3 %, 96 ~1.5 % of the 192-step figure)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3"])
+    ap.add_argument("--precision", default="f16", choices=["bf16", "f16", "fp32", "f16x3"],
+                    help="fast modes: f16 (default since round 4: IEEE f16 operands on the f16 MFMA - the bf16 mode's kernels and speed "
+                         "within 2 %, 0.94 instead of 0.17 of the kept sets identical to the fp32 oracle at the headline batch) or bf16 "
+                         "(BASELINE.json config 2's dtype); parity modes: f16x3, fp32")
     ap.add_argument("--config", default="nlvr", choices=list(workloads.NAMES),
                     help="BASELINE.json configuration (default: the headline)")
     ap.add_argument("--batch", type=int, default=0, help="samples per GPU (0 = the configuration's BASELINE batch)")
@@ -246,7 +249,8 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
             alg_bytes = sum(r["bytes"] for r in prof_rows if r["dtype"] == dt_name and r["M"] >= min_m)
-            kname = {"bf16": "gemm_ws_kernel + gemm_sq_kernel (all bf16 madtp_gemm launches with M >= 4096: ViT qkv/proj/fc1/fc2, cross-attention K/V; 256x128 wave-specialised or 256x256 tiles by round count)",
+            kname = {"f16": "gemm_ws_kernel + gemm_pp_kernel on IEEE f16 operands (v_mfma_f32_16x16x32_f16; all madtp_gemm launches with M >= 4096)",
+                     "bf16": "gemm_ws_kernel + gemm_pp_kernel (all bf16 madtp_gemm launches with M >= 4096: ViT qkv/proj/fc1/fc2, cross-attention K/V; 256x128 wave-specialised or 256x256 ping-pong tiles by round count)",
                      "f16x3": "gemm_ws_kernel<f16-split> (all madtp_gemm launches with M >= 4096; 3 f16 MFMA products per "
                               "logical product: achieved/peak are in algorithmic 2MNK flops, peak = f16 dense / 3)",
                      "fp32": "gemm_kernel<float> (madtp_gemm)"}[args.precision]
@@ -268,7 +272,7 @@ def main():
         "metric": METRIC if headline else f"images/sec forward, {args.config} configuration of BASELINE.json (p={w.p})",
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
-        "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32", "f16x3": "f16x3 (fp32-accurate)"}[args.precision],
+        "vs_baseline": None, "dtype": {"bf16": "bf16", "f16": "f16", "fp32": "f32", "f16x3": "f16x3 (fp32-accurate)"}[args.precision],
         "data": "synthetic",
         "config": {"workload": w.describe(B), "samples_per_gpu": B, "images_per_gpu": w.images_per_sample * B, "temperature": T,
                    "p": w.p, "flops_ratio_vs_unpruned": round(flops_sample / flops_full, 4),
@@ -336,7 +340,7 @@ def main():
                                       "attention / LayerNorm / scores on the exact-f32 kernels; kept sets vs the oracle below"}
     if rank == 0 and world == 1:
         if not args.no_parity:
-            modes = sorted({"fp32", "f16x3", args.precision})
+            modes = sorted({"fp32", "f16x3", "bf16", "f16", args.precision})
             if headline:
                 from oracle.index_match import nlvr_index_match
                 im = nlvr_index_match(model, T, modes, B=args.parity_batch or B, seed=11)

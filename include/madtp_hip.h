@@ -26,12 +26,18 @@ extern "C" {
  * weights [Q0 | Q1] (2K f16 per row, w 2^s = Q0 + Q1 with the power of two in madtp_lin.w_scale); leading dimensions of such
  * operands count f16 elements.  Written by madtp_split_f16 / the LayerNorm and GEMM epilogues, read by madtp_gemm. */
 #define MADTP_F16S 2
+/* plain IEEE f16 operands on the f16 MFMA (the "f16" fast precision mode, round 4): the storage layout, shapes and kernels of
+ * MADTP_BF16 with 11 significand bits instead of 8 at the same MFMA rate (v_mfma_f32_16x16x32_f16); accepted wherever
+ * MADTP_BF16 is, unless an entry point says otherwise.  Range: |x| < 65504 - producers raise the range flag
+ * (madtp_range_status) instead of handing on an infinity. */
+#define MADTP_F16 3
 
 #define MADTP_E_BADARG (-1)   /* null pointer / non-positive size                      */
 #define MADTP_E_SHAPE (-2)    /* shape outside what the kernel family supports          */
 #define MADTP_E_DTYPE (-3)    /* unknown dtype code                                     */
 #define MADTP_E_ALIGN (-4)    /* pointer or leading dimension not 16-byte aligned       */
 #define MADTP_E_BUSY (-5)     /* every host hand-over slot of the device is pending (publish without wait) */
+#define MADTP_E_RANGE (-6)    /* a value left the f16 range in an f16 precision mode (madtp_range_status)   */
 
 /* activation codes of the GEMM epilogue */
 #define MADTP_ACT_NONE 0
@@ -259,6 +265,16 @@ int madtp_add_scale(const float* a, const float* b, float* out, float scale, siz
 
 /* f32 -> bf16 copy (weight preparation, activations entering a bf16 GEMM). */
 int madtp_cast_bf16(const float* src, void* dst, size_t n, void* stream);
+/* f32 -> 2-byte copy in the element format lp_dtype (MADTP_BF16 or MADTP_F16), scaled by `scale` first (f16 weights are stored
+ * as w * 2^s so that small weights stay clear of the f16 subnormals; the GEMM's acc_scale 2^-s undoes it). */
+int madtp_cast_lp(const float* src, void* dst, size_t n, int lp_dtype, float scale, void* stream);
+
+/* Range flag of the f16 formats (MADTP_F16S planes and MADTP_F16 operands): a producer kernel (madtp_split_f16, the LayerNorm /
+ * GEMM / attention epilogues that emit f16) that meets a value outside the f16 range (|x| >= 65504 or NaN) sets a sticky flag in
+ * pinned host memory instead of silently handing an infinity on (which the next GEMM would turn into NaNs).  Returns the flag
+ * (0 = clean) after the work queued on `stream` so far has completed, and clears it when `reset` != 0.  The layer-level entry
+ * points check it with their host read of k and return MADTP_E_RANGE. */
+int madtp_range_status(int reset, void* stream);
 
 /* f32 [rows, K] (row stride ld_src) -> f16-split activation planes [rows, 2K] f16 (row stride ld_dst f16 elements):
  * dst[r, c] = f16(x), dst[r, K + c] = f16((x - f16(x)) * 2^11).  Activations entering an F16S GEMM whose producer is not

@@ -64,6 +64,12 @@ static bool hm_workspace(hipStream_t s, HmWorkspace& out) {
     return true;
 }
 
+// 16x16x32 MFMA of the fast modes' 2-byte operands: bf16 (MADTP_BF16) or IEEE f16 (MADTP_F16), f32 accumulate
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_lp(bf16x8 a, bf16x8 b, f32x4 c, int, int, int) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 template <typename T> __device__ __forceinline__ f32x4 load4(const char* p);
 template <> __device__ __forceinline__ f32x4 load4<float>(const char* p) { return *(const f32x4*)p; }
 template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const char* p) {
@@ -603,7 +609,7 @@ __device__ long long g_attn_dbg[8];
 #else
 #define AT_MARK(i)
 #endif
-template <int NT, bool SCORES, int HS, int RB = 1>
+template <int NT, bool SCORES, int HS, int RB = 1, bool F16 = false>
 __global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void attn_bf16_kernel(AttnArgs a) {
     static_assert(HS == 1 || RB == 1, "head-parity split and two row blocks are alternatives");
     constexpr int NKP = NT * 16;
@@ -714,8 +720,8 @@ __global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void a
             const bf16x8 k0 = *(const bf16x8*)(Ks + row * 128 + (((0 + g) ^ (row & 7)) << 4));
             const bf16x8 k1 = *(const bf16x8*)(Ks + row * 128 + (((4 + g) ^ (row & 7)) << 4));
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q[0], acc, 0, 0, 0);
-            sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q[1], acc, 0, 0, 0);
+            acc = mfma_lp<F16>(k0, q[0], acc, 0, 0, 0);
+            sc[t] = mfma_lp<F16>(k1, q[1], acc, 0, 0, 0);
         }
         AT_MARK(3);
         // ---- softmax over keys (lane holds j = 16t+4g+r of row i) ----
@@ -770,7 +776,7 @@ __global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void a
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const f32x4 hi = (2 * c + 1 < NT) ? sc[2 * c + 1 < NT ? 2 * c + 1 : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
-            const bf16x8 pa = pack_bf16x8(sc[2 * c], hi);
+            const bf16x8 pa = pack_lp8<F16>(sc[2 * c], hi);
             // transpose read: lane 4r+q of the group addresses (key row r, columns 4q..4q+3), receives column l16.
             // key rows of this lane group: 32c + 4g + r (first read) and +16 (second); both have the same (row>>1)&3.
             // (The compiler puts s_waitcnt vmcnt(0) in front of the first of these builtin reads - it cannot tell them from the
@@ -784,7 +790,7 @@ __global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void a
             for (int dt = 0; dt < 4; ++dt) {
                 const int p = ((2 * dt + ((l16 & 3) >> 1)) ^ vkey) << 4;
                 const bf16x8 vb = cat_bf16x4(lds_read_tr16(vr + p), lds_read_tr16(vr + 16 * 128 + p));
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, o[dt], 0, 0, 0);  // O^T: row d = 4g+r, col i
+                o[dt] = mfma_lp<F16>(vb, pa, o[dt], 0, 0, 0);  // O^T: row d = 4g+r, col i
             }
         }
         AT_MARK(5);
@@ -802,7 +808,7 @@ __global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void a
             if (i < a.Nq) {
                 bf16_t* orow = (bf16_t*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 2) + 4 * g;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + dt * 16) = pack_bf16x4(o[dt]);
+                for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + dt * 16) = pack_lp4<F16>(o[dt]);
                 if constexpr (SCORES)
                     if (g == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
             }
@@ -851,6 +857,7 @@ __global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void a
 // SMALL_NW waves per workgroup: with 12 heads every wave owns exactly one head (a head is a ~3 us dependent chain; four
 // waves walking three heads each made the kernel three chains long).
 constexpr int SMALL_NW = 12;
+template <bool F16>
 __global__ __launch_bounds__(64 * SMALL_NW, 1) void attn_bf16_small_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char vbuf[SMALL_NW][32 * 128];
     __shared__ float pm[SMALL_NW][2][2][64][4];  // [wave][row tile][key tile][lane][r]
@@ -909,8 +916,8 @@ __global__ __launch_bounds__(64 * SMALL_NW, 1) void attn_bf16_small_kernel(AttnA
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], q0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], q1, acc, 0, 0, 0);
+                acc = mfma_lp<F16>(kf[t][0], q0, acc, 0, 0, 0);
+                acc = mfma_lp<F16>(kf[t][1], q1, acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = fmaf(acc[r], a.scale, mk[t][r]);
@@ -944,7 +951,7 @@ __global__ __launch_bounds__(64 * SMALL_NW, 1) void attn_bf16_small_kernel(AttnA
                     }
             }
             // O^T = V^T P^T (operands swapped): lane (i = l16, g) gets columns 16dt + 4g .. +3 of row i
-            const bf16x8 pa = pack_bf16x8(sc[0], sc[1]);
+            const bf16x8 pa = pack_lp8<F16>(sc[0], sc[1]);
             const int vrow = 4 * g + (l16 >> 2);
             const int vkey = ((vrow >> 1) & 3) << 1;
             const char* vr = Vs + vrow * 128 + 8 * (l16 & 1);
@@ -954,7 +961,7 @@ __global__ __launch_bounds__(64 * SMALL_NW, 1) void attn_bf16_small_kernel(AttnA
             for (int dt = 0; dt < 4; ++dt) {
                 const int p = ((2 * dt + ((l16 & 3) >> 1)) ^ vkey) << 4;
                 const bf16x8 vb = cat_bf16x4(lds_read_tr16(vr + p), lds_read_tr16(vr + 16 * 128 + p));
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                o[dt] = mfma_lp<F16>(vb, pa, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) n2 += o[dt][r] * o[dt][r];
             }
@@ -963,7 +970,7 @@ __global__ __launch_bounds__(64 * SMALL_NW, 1) void attn_bf16_small_kernel(AttnA
             if (i < N) {
                 bf16_t* orow = (bf16_t*)(a.out + (((size_t)b * N + i) * a.ldo + h * 64) * 2) + 4 * g;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + dt * 16) = pack_bf16x4(o[dt]);
+                for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + dt * 16) = pack_lp4<F16>(o[dt]);
                 if (g == 0) a.onorm[((size_t)b * a.H + h) * N + i] = sqrtf(n2);
             }
         }
@@ -994,13 +1001,13 @@ __global__ __launch_bounds__(64 * SMALL_NW, 1) void attn_bf16_small_kernel(AttnA
     }
 }
 
-template <int NT, bool SCORES>
+template <int NT, bool SCORES, bool F16>
 int launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
     constexpr int NC = (NT + 1) / 2;
     constexpr int HS = (SCORES && NT <= 8) ? 2 : 1;  // head-parity split: 4 rings must fit the 160 KiB of LDS
     constexpr int RB = (SCORES && NT > 8) ? 2 : 1;   // two 64-row blocks per workgroup where only one ring fits a CU
     const size_t lds = (size_t)2 * HS * (NT * 16 + NC * 32) * 128;
-    MADTP_ENSURE_MAX_LDS((attn_bf16_kernel<NT, SCORES, HS, RB>), lds);
+    MADTP_ENSURE_MAX_LDS((attn_bf16_kernel<NT, SCORES, HS, RB, F16>), lds);
     int gz = 1;
     size_t lds_used = lds;
     if (!SCORES) {
@@ -1011,22 +1018,22 @@ int launch_attn_bf16(const AttnArgs& a, hipStream_t s) {
         gz = wgs >= 512 ? 1 : a.H;
         if (gz == a.H) lds_used = lds / 2;
     }
-    hipLaunchKernelGGL((attn_bf16_kernel<NT, SCORES, HS, RB>), dim3((a.Nq + 64 * RB - 1) / (64 * RB), (!SCORES && a.pair) ? 2 * a.B : a.B, gz),
+    hipLaunchKernelGGL((attn_bf16_kernel<NT, SCORES, HS, RB, F16>), dim3((a.Nq + 64 * RB - 1) / (64 * RB), (!SCORES && a.pair) ? 2 * a.B : a.B, gz),
                        dim3(256 * HS * RB), lds_used, s, a);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
 
-template <bool SCORES>
+template <bool SCORES, bool F16 = false>
 int dispatch_nt_bf16(const AttnArgs& a, hipStream_t s) {
     const int nt = (a.Nk + 15) / 16;
-    if (nt <= 4) return launch_attn_bf16<4, SCORES>(a, s);
-    if (nt <= 6) return launch_attn_bf16<6, SCORES>(a, s);
-    if (nt <= 8) return launch_attn_bf16<8, SCORES>(a, s);
-    if (nt <= 10) return launch_attn_bf16<10, SCORES>(a, s);
-    if (nt <= 12) return launch_attn_bf16<12, SCORES>(a, s);
-    if (nt <= 13) return launch_attn_bf16<13, SCORES>(a, s);
-    if (nt <= 16) return launch_attn_bf16<16, SCORES>(a, s);
+    if (nt <= 4) return launch_attn_bf16<4, SCORES, F16>(a, s);
+    if (nt <= 6) return launch_attn_bf16<6, SCORES, F16>(a, s);
+    if (nt <= 8) return launch_attn_bf16<8, SCORES, F16>(a, s);
+    if (nt <= 10) return launch_attn_bf16<10, SCORES, F16>(a, s);
+    if (nt <= 12) return launch_attn_bf16<12, SCORES, F16>(a, s);
+    if (nt <= 13) return launch_attn_bf16<13, SCORES, F16>(a, s);
+    if (nt <= 16) return launch_attn_bf16<16, SCORES, F16>(a, s);
     return MADTP_E_SHAPE;
 }
 
@@ -1482,7 +1489,7 @@ int launch_attn_large(const AttnArgs& a, hipStream_t s) {
 // Work per (b, h): 6 Nq Nk 64 flop (Q K^T twice) on the bf16 MFMA; the bound is the VALU softmax work (2 exp per score).
 // STG: stages of the chunk ring (2 is what launch_attn_bf16_large uses; 3 keeps two chunks in flight behind counted vmcnt waits
 // and was measured slower, see there).
-template <int NCH, bool SCORES, int STG>
+template <int NCH, bool SCORES, int STG, bool F16 = false>
 __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) void attn_bf16_large_kernel(AttnArgs a) {
     constexpr int CK = 128;                   // keys per chunk
     constexpr int STAGE = 2 * CK * 128;       // K image (128-byte rows), then V image
@@ -1557,8 +1564,8 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
             const bf16x8 k0 = *(const bf16x8*)(Ks + row * 128 + (((0 + g) ^ (row & 7)) << 4));
             const bf16x8 k1 = *(const bf16x8*)(Ks + row * 128 + (((4 + g) ^ (row & 7)) << 4));
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q[0], acc, 0, 0, 0);
-            sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q[1], acc, 0, 0, 0);
+            acc = mfma_lp<F16>(k0, q[0], acc, 0, 0, 0);
+            sc[t] = mfma_lp<F16>(k1, q[1], acc, 0, 0, 0);
         }
         const int jb = c * CK + 4 * g;
         if (a.mask) {
@@ -1706,12 +1713,12 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
             v_reads(0, vt[0]);
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                const bf16x8 pa = pack_bf16x8(sc[2 * cc], sc[2 * cc + 1]);
+                const bf16x8 pa = pack_lp8<F16>(sc[2 * cc], sc[2 * cc + 1]);
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[cc & 1][0]), "+v"(vt[cc & 1][1]), "+v"(vt[cc & 1][2]), "+v"(vt[cc & 1][3]),
                              "+v"(vt[cc & 1][4]), "+v"(vt[cc & 1][5]), "+v"(vt[cc & 1][6]), "+v"(vt[cc & 1][7]) :: "memory");
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat_bf16x4(vt[cc & 1][2 * dt], vt[cc & 1][2 * dt + 1]), pa, o[dt], 0, 0, 0);  // O^T: row d = 4g+r, col i
+                    o[dt] = mfma_lp<F16>(cat_bf16x4(vt[cc & 1][2 * dt], vt[cc & 1][2 * dt + 1]), pa, o[dt], 0, 0, 0);  // O^T: row d = 4g+r, col i
                 if (cc + 1 < 4) v_reads(cc + 1, vt[(cc + 1) & 1]);
             }
         }
@@ -1726,7 +1733,7 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
             if (i < a.Nq) {
                 bf16_t* orow = (bf16_t*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 2) + 4 * g;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + dt * 16) = pack_bf16x4(o[dt]);
+                for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + dt * 16) = pack_lp4<F16>(o[dt]);
                 if constexpr (SCORES)
                     if (g == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
             }
@@ -1776,7 +1783,7 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
     }
 }
 
-template <int NCH, bool SCORES>
+template <int NCH, bool SCORES, bool F16>
 int launch_attn_bf16_large(const AttnArgs& a_in, hipStream_t s) {
     AttnArgs a = a_in;
     int gz = 1;
@@ -1797,18 +1804,18 @@ int launch_attn_bf16_large(const AttnArgs& a_in, hipStream_t s) {
     // chunk step of a lone wave is bound by its own dependent instruction stream (~1.85 us against ~1.2 us with two waves per
     // SIMD), not by the DMA round trip.
     const size_t lds = (size_t)2 * 2 * 128 * 128 + 4 * 2048;  // two stages of K|V chunk images + the waves' Q rows
-    MADTP_ENSURE_MAX_LDS((attn_bf16_large_kernel<NCH, SCORES, 2>), lds);
-    hipLaunchKernelGGL((attn_bf16_large_kernel<NCH, SCORES, 2>), grid, dim3(256), lds, s, a);
+    MADTP_ENSURE_MAX_LDS((attn_bf16_large_kernel<NCH, SCORES, 2, F16>), lds);
+    hipLaunchKernelGGL((attn_bf16_large_kernel<NCH, SCORES, 2, F16>), grid, dim3(256), lds, s, a);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
 
-template <bool SCORES>
+template <bool SCORES, bool F16 = false>
 int dispatch_bf16_large(const AttnArgs& a, hipStream_t s) {
     const int nch = (a.Nk + 127) / 128;
-    if (nch <= 3) return launch_attn_bf16_large<3, SCORES>(a, s);
-    if (nch <= 5) return launch_attn_bf16_large<5, SCORES>(a, s);
-    if (nch <= 8) return launch_attn_bf16_large<8, SCORES>(a, s);
+    if (nch <= 3) return launch_attn_bf16_large<3, SCORES, F16>(a, s);
+    if (nch <= 5) return launch_attn_bf16_large<5, SCORES, F16>(a, s);
+    if (nch <= 8) return launch_attn_bf16_large<8, SCORES, F16>(a, s);
     return MADTP_E_SHAPE;
 }
 
@@ -1927,8 +1934,9 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
     if (kv_batch_index && colsum_part) return MADTP_E_BADARG;  // indexed K/V is a cross-attention feature
     // io_dtype MADTP_F16S: f32 storage, products as three f16 MFMA products of f16-split operands (the f16x3 precision mode)
-    if (io_dtype != MADTP_F32 && io_dtype != MADTP_BF16 && io_dtype != MADTP_F16S) return MADTP_E_DTYPE;
+    if (io_dtype != MADTP_F32 && io_dtype != MADTP_BF16 && io_dtype != MADTP_F16S && io_dtype != MADTP_F16) return MADTP_E_DTYPE;
     bool f16s = io_dtype == MADTP_F16S;
+    const bool f16 = io_dtype == MADTP_F16;  // plain f16 operands: the bf16 kernels on the f16 MFMA
     if (f16s) {
         static int f16s_env = -1;  // MADTP_ATTN_F16S=0: the f16x3 mode keeps its attention on the exact-f32 MFMA kernels (A/B runs)
         if (f16s_env < 0) { const char* e = getenv("MADTP_ATTN_F16S"); f16s_env = e ? atoi(e) : 1; }
@@ -1936,7 +1944,7 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
         io_dtype = MADTP_F32;
     }
     if (colsum_part && (!p0 || !onorm || Nq != Nk)) return MADTP_E_BADARG;
-    const int esz = io_dtype == MADTP_BF16 ? 2 : 4;
+    const int esz = (io_dtype == MADTP_BF16 || f16) ? 2 : 4;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (ldq * esz) % 16 || (ldk * esz) % 16 || (ldv * esz) % 16)
         return MADTP_E_ALIGN;
     if (Nk > 1024) return MADTP_E_SHAPE;
@@ -1957,6 +1965,7 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
         if (io_dtype == MADTP_F32) return scores ? dispatch_large<float, true>(a, s) : dispatch_large<float, false>(a, s);
         static int large_env = -1;  // MADTP_ATTN_LARGE_F32=1: bf16 storage on the exact-f32 MFMA kernel (A/B runs)
         if (large_env < 0) { const char* e = getenv("MADTP_ATTN_LARGE_F32"); large_env = e ? atoi(e) : 0; }
+        if (f16) return scores ? dispatch_bf16_large<true, true>(a, s) : dispatch_bf16_large<false, true>(a, s);
         if (large_env) return scores ? dispatch_large<bf16_t, true>(a, s) : dispatch_large<bf16_t, false>(a, s);
         return scores ? dispatch_bf16_large<true>(a, s) : dispatch_bf16_large<false>(a, s);  // fast mode: bf16 MFMA, LDS-DMA ring
     }
@@ -1965,10 +1974,12 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
     if (io_dtype == MADTP_F32) return scores ? dispatch_nt<float, true>(a, s) : dispatch_nt<float, false>(a, s);
     if ((ldk * 2) % 16 || (ldv * 2) % 16) return MADTP_E_ALIGN;
     if (scores && Nk <= 32 && !mask_qk) {  // short text sequences: one sample per workgroup, heads spread over the waves
-        hipLaunchKernelGGL(attn_bf16_small_kernel, dim3(B), dim3(64 * SMALL_NW), 0, s, a);
+        if (f16) hipLaunchKernelGGL(attn_bf16_small_kernel<true>, dim3(B), dim3(64 * SMALL_NW), 0, s, a);
+        else hipLaunchKernelGGL(attn_bf16_small_kernel<false>, dim3(B), dim3(64 * SMALL_NW), 0, s, a);
         MADTP_LAUNCH_CHECK();
         return 0;
     }
+    if (f16) return scores ? dispatch_nt_bf16<true, true>(a, s) : dispatch_nt_bf16<false, true>(a, s);
     return scores ? dispatch_nt_bf16<true>(a, s) : dispatch_nt_bf16<false>(a, s);
 }
 
@@ -1982,7 +1993,7 @@ extern "C" int madtp_attention_pair(const void* q0, const void* q1, const void* 
     if (!q0 || !q1 || !k0 || !k1 || !v0 || !v1 || !out0 || !out1 || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
     static int pair_env = -1;  // MADTP_ATTN_PAIR=0: always two launches (A/B runs)
     if (pair_env < 0) { const char* e = getenv("MADTP_ATTN_PAIR"); pair_env = e ? atoi(e) : 1; }
-    const bool one = pair_env && io_dtype == MADTP_BF16 && Nk <= 256 && (!add_mask0) == (!add_mask1) && aligned16(q0) &&
+    const bool one = pair_env && (io_dtype == MADTP_BF16 || io_dtype == MADTP_F16) && Nk <= 256 && (!add_mask0) == (!add_mask1) && aligned16(q0) &&
                      aligned16(q1) && aligned16(k0) && aligned16(k1) && aligned16(v0) && aligned16(v1) && (ldq * 2) % 16 == 0 &&
                      (ldk * 2) % 16 == 0 && (ldv * 2) % 16 == 0;
     if (!one) {
@@ -2002,6 +2013,7 @@ extern "C" int madtp_attention_pair(const void* q0, const void* q1, const void* 
     a.nrt = (Nq + 15) / 16;
     a.scale = scale;
     a.kvidx = kv_batch_index;
+    if (io_dtype == MADTP_F16) return dispatch_nt_bf16<false, true>(a, (hipStream_t)stream);
     return dispatch_nt_bf16<false>(a, (hipStream_t)stream);
 }
 

@@ -58,6 +58,41 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(f32x4 lo, f32x4 hi) {
 __device__ __forceinline__ bf16x4 pack_bf16x4(f32x4 v) {
     return __builtin_bit_cast(bf16x4, __builtin_convertvector(v, hwbf16x4));
 }
+// ---- plain f16 operands (dtype code MADTP_F16): the 2-byte storage of the bf16 kernels with IEEE half elements ------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// (pairwise: one v_cvt_pk_f16_f32 - round to nearest even - per two values; the 8-wide convertvector came out as a scalar
+//  v_cvt_f16_f32 per value plus packing)
+__device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2));
+}
+__device__ __forceinline__ bf16x8 pack_f16x8(f32x4 lo, f32x4 hi) {
+    const u32x4 r = {pack_f16x2(lo[0], lo[1]), pack_f16x2(lo[2], lo[3]), pack_f16x2(hi[0], hi[1]), pack_f16x2(hi[2], hi[3])};
+    return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ bf16x4 pack_f16x4(f32x4 v) {
+    const u32x2 r = {pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3])};
+    return __builtin_bit_cast(bf16x4, r);
+}
+template <bool F16> __device__ __forceinline__ bf16x8 pack_lp8(f32x4 lo, f32x4 hi) { return F16 ? pack_f16x8(lo, hi) : pack_bf16x8(lo, hi); }
+template <bool F16> __device__ __forceinline__ bf16x4 pack_lp4(f32x4 v) { return F16 ? pack_f16x4(v) : pack_bf16x4(v); }
+// Range flag of the f16 formats (include/madtp_hip.h madtp_range_status): producers OR "not (|v| < 65520)" - true for NaN and for
+// everything that rounds to an f16 infinity - over the values they convert and store 1 to the flag when it is set.
+int* madtp_internal_range_flag();  // host side: device-visible pointer to the pinned flag (norm.hip)
+__device__ __forceinline__ bool f16_range_bad(float v) { return !(fabsf(v) < 65520.0f); }
+__device__ __forceinline__ bool f16_range_bad(f32x4 v) {
+    return f16_range_bad(v[0]) | f16_range_bad(v[1]) | f16_range_bad(v[2]) | f16_range_bad(v[3]);
+}
+__device__ __forceinline__ void f16_range_raise(int* flag, bool bad) {
+    if (flag && bad) *(volatile int*)flag = 1;
+}
+// the cheap form for register-resident tiles (GEMM epilogues): running maximum of |v| (one v_max per value), tested once.  A NaN
+// does not survive fmaxf - but a NaN in a GEMM output needs a non-finite operand, whose own producer has raised the flag.
+__device__ __forceinline__ float f16_range_acc(float mx, f32x4 v) {
+    mx = fmaxf(fmaxf(mx, fabsf(v[0])), fabsf(v[1]));  // (v_max3_f32 with |.| source modifiers)
+    return fmaxf(fmaxf(mx, fabsf(v[2])), fabsf(v[3]));
+}
 
 // ds_read_b64_tr_b16: within each 16-lane group, lane 4r+q supplies the LDS address of the 8-byte piece (row r, columns
 // 4q..4q+3) of a 4x16 bf16 block and lane i receives column i of that block (rows 0..3) - verified on MI355X with
@@ -215,8 +250,10 @@ __device__ __forceinline__ LnParams ln_params(const float* gamma, const float* b
 }
 
 // ylp: row base of the low-precision copy - bf16 [dim], or (lp_f16s) the f16-split planes [P0 | P1] of 2*dim f16
+// lp_fmt: MADTP_BF16 / MADTP_F16S (split planes) / MADTP_F16 (plain f16); range_flag: see f16_range_raise
 __device__ __forceinline__ void ln_store(const float4 (&v)[LN_MAX_CHUNKS], int lane, int dim, float mean, float rstd,
-                                         const LnParams& p, float* y32, bf16_t* ylp, bool lp_f16s = false) {
+                                         const LnParams& p, float* y32, bf16_t* ylp, int lp_fmt = MADTP_BF16, int* range_flag = nullptr) {
+    bool bad = false;
 #pragma unroll
     for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
         const int col = (lane + 64 * c) * 4;
@@ -229,16 +266,22 @@ __device__ __forceinline__ void ln_store(const float4 (&v)[LN_MAX_CHUNKS], int l
         o.w = (v[c].w - mean) * rstd * gm.w + bt.w;
         if (y32) *(float4*)(y32 + col) = o;
         if (ylp) {
-            if (lp_f16s) {
+            if (lp_fmt == MADTP_F16S) {
                 f16x4 h, l;
                 split_f16x4((f32x4){o.x, o.y, o.z, o.w}, h, l);
                 *(f16x4*)(ylp + col) = h;
                 *(f16x4*)(ylp + dim + col) = l;
+                bad |= f16_range_bad((f32x4){o.x, o.y, o.z, o.w});
+            } else if (lp_fmt == MADTP_F16) {
+                *(bf16x4*)(ylp + col) = pack_f16x4((f32x4){o.x, o.y, o.z, o.w});
+                bad |= f16_range_bad((f32x4){o.x, o.y, o.z, o.w});
             } else {
                 *(bf16x4*)(ylp + col) = pack_bf16x4((f32x4){o.x, o.y, o.z, o.w});
             }
         }
     }
+    f16_range_raise(range_flag, bad);
 }
+__host__ __device__ static inline int lp_row_mul(int lp_fmt) { return lp_fmt == MADTP_F16S ? 2 : 1; }  // row width of the lp copy in units of dim
 
 

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
                         for (int i = 0; i < FM; ++i)
 #pragma unroll
                             for (int j = 0; j < FN; ++j)
-                                acc[i][j] = mfma_16x16x32<false>(b[j], a[i], acc[i][j]);
+                                acc[i][j] = mfma_16x16x32<std::is_same<T, F16P>::value>(b[j], a[i], acc[i][j]);
                     }
                 } else {
                     f32x4 a[FM], b[FN];
@@ -297,9 +297,11 @@ __device__ __forceinline__ long long ws_now() {
 }
 #define WS_NOW() ws_now()
 #endif
-template <bool X3, int OM, bool M32 = false>
+template <bool X3, int OM, bool M32 = false, bool F16 = false>
 __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
     static_assert(!(X3 && M32), "the 32x32x16 consumer loop exists for the bf16 kernel only");
+    static_assert(!(F16 && (X3 || M32)), "plain f16 operands run the 16x16x32 consumer loop");
+    constexpr bool MF16 = X3 || F16;  // which 16x16x32 MFMA: f16 (split planes or plain f16 operands) or bf16
     constexpr bool LP_OUT = OM != OM_F32;
     constexpr int ESZ = 2, BM = 256, BN = 128, STAGES = 3, NCW = 8, NLW = 4;
     constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
     if (!(MADTP_WS_ABLATE & 4))                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
-            acc[i][j] = mfma_16x16x32<X3>(XB[j], XA[i], acc[i][j]);
+            acc[i][j] = mfma_16x16x32<MF16>(XB[j], XA[i], acc[i][j]);
 #ifdef MADTP_WS_TIMING
     long long ws_t_main = 0, ws_t_epi = 0, ws_tiles = 0;
     const long long ws_t_begin = WS_NOW();
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(768, 1) void gemm_ws_kernel(GemmArgs g) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = mfma_16x16x32<X3>(xb[j], xa[i], zero4);
+                    acc[i][j] = mfma_16x16x32<MF16>(xb[j], xa[i], zero4);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): Y is in registers, this wave is done with the stage
             __builtin_amdgcn_sched_barrier(0);
@@ -910,7 +912,7 @@ extern "C" int madtp_debug_read_ws_ts(long long* out) {
 #endif
 
 // gemm_pp.hip: the ping-pong 256x256 kernel lives in its own translation unit (args = const GemmArgs*)
-__attribute__((visibility("hidden"))) int madtp_gemm_pp_launch(const void* args, int out_bf16, int f16, int grid, void* stream);
+__attribute__((visibility("hidden"))) int madtp_gemm_pp_launch(const void* args, int out_lp, int f16, int grid, void* stream);
 
 // ---- optional HIP-event profiling of every GEMM launch (bench.py's roofline leg) -----------------------------------
 namespace {
@@ -1113,11 +1115,13 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
                        int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float acc_scale, float out_scale,
                        int splitk, void* stream, const GemmPair* pair) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return MADTP_E_BADARG;
-    if (ab_dtype != MADTP_F32 && ab_dtype != MADTP_BF16 && ab_dtype != MADTP_F16S) return MADTP_E_DTYPE;
-    if (c_dtype != MADTP_F32 && c_dtype != MADTP_BF16 && c_dtype != MADTP_F16S) return MADTP_E_DTYPE;
+    if (ab_dtype != MADTP_F32 && ab_dtype != MADTP_BF16 && ab_dtype != MADTP_F16S && ab_dtype != MADTP_F16) return MADTP_E_DTYPE;
+    if (c_dtype != MADTP_F32 && c_dtype != MADTP_BF16 && c_dtype != MADTP_F16S && c_dtype != MADTP_F16) return MADTP_E_DTYPE;
     const bool x3 = ab_dtype == MADTP_F16S;
+    const bool f16 = ab_dtype == MADTP_F16;  // plain f16 operands: the bf16 kernels' instantiations on the f16 MFMA
     if (c_dtype == MADTP_F16S && !x3) return MADTP_E_DTYPE;  // the split epilogue exists on the f16-split kernels only
-    if (c_dtype == MADTP_BF16 && x3) return MADTP_E_DTYPE;
+    if (c_dtype == MADTP_BF16 && (x3 || f16)) return MADTP_E_DTYPE;  // a 2-byte output of 2-byte operands has their element format
+    if (c_dtype == MADTP_F16 && !f16) return MADTP_E_DTYPE;
     const int esz = ab_dtype == MADTP_F32 ? 4 : 2;
     if ((K * esz) % ROWB != 0) return MADTP_E_SHAPE;
     if (!aligned16(A) || !aligned16(W) || (lda * esz) % 16 || (ldw * esz) % 16) return MADTP_E_ALIGN;
@@ -1128,7 +1132,8 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     g.A = (const char*)A; g.W = (const char*)W; g.bias = bias; g.residual = residual; g.C = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.act = act; g.out_scale = out_scale;
     g.acc_scale = acc_scale; g.acc_scale2 = pair ? pair->acc_scale : acc_scale;
-    g.ldc = c_dtype == MADTP_BF16 ? -ldc : ldc;
+    g.ldc = (c_dtype == MADTP_BF16 || c_dtype == MADTP_F16) ? -ldc : ldc;  // negative: a 2-byte output (scalar fallback epilogue)
+    g.range_flag = (c_dtype == MADTP_F16S || c_dtype == MADTP_F16) ? madtp_internal_range_flag() : nullptr;
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("MADTP_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
     const int force_cfg = gemm_force_cfg();
@@ -1147,7 +1152,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     // (and, for the descriptor-bounded stores, a 256-row block of C below 2 GiB; bf16 output with an f32 residual has no
     // caller on the path and takes the scalar epilogue)
     g.fast_epi = (N % 8 == 0) && (ldc % 8 == 0) && aligned16(C) && (!bias || aligned16(bias)) &&
-                 (!residual || (aligned16(residual) && ldr % 4 == 0 && c_dtype != MADTP_BF16)) &&
+                 (!residual || (aligned16(residual) && ldr % 4 == 0 && c_dtype != MADTP_BF16 && c_dtype != MADTP_F16)) &&
                  (size_t)ldc * 256 * 4 < ((size_t)1 << 31);
     // tile configuration (MADTP_GEMM_CFG=1..4 forces one of the gemm_kernel variants for A/B measurements):
     //   0: 128x128, 2-stage ring, 2 workgroups/CU  - default, and the f32 path
@@ -1191,7 +1196,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
         rec.flops = 2.0 * M * N * K; rec.dt = ab_dtype; rec.M = M; rec.N = N; rec.K = K;
         // algorithmic HBM bytes: A and W once, C once (x splits), bias, residual once
-        rec.bytes = (double)esz * (x3 ? 2.0 : 1.0) * ((double)M * K + (double)N * K) + (double)M * N * (c_dtype == MADTP_BF16 ? 2 : 4) * splitk +
+        rec.bytes = (double)esz * (x3 ? 2.0 : 1.0) * ((double)M * K + (double)N * K) + (double)M * N * ((c_dtype == MADTP_BF16 || c_dtype == MADTP_F16) ? 2 : 4) * splitk +
                     (bias ? 4.0 * N : 0.0) + (residual ? 4.0 * M * N : 0.0);
         if (pair) { rec.flops *= 2.0; rec.bytes *= 2.0; }  // two problems in this launch
         (void)hipEventRecord(rec.e0, s);
@@ -1220,7 +1225,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     SkWorkspace skw{nullptr, nullptr};
     const bool sk_on = ws_ok && !x3 && ab_dtype == MADTP_BF16 && (force_cfg == 5 || (force_cfg == 0 && sk_enabled() && K / 64 >= SK_MIN_SLABS)) &&
                        sk_workspace(s, skw);
-    if (ab_dtype == MADTP_BF16 && splitk == 1 && !pair && (K % 64) == 0 &&
+    if ((ab_dtype == MADTP_BF16 || f16) && splitk == 1 && !pair && (K % 64) == 0 &&
         ((size_t)M + 255) * (size_t)lda * 2 < ((size_t)1 << 32) && ((size_t)N + 255) * (size_t)ldw * 2 < ((size_t)1 << 32)) {
         static int sq_env = -1;
         if (sq_env < 0) { const char* e = getenv("MADTP_GEMM_SQ"); sq_env = e ? atoi(e) : 1; }
@@ -1232,10 +1237,11 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         if (pp_env < 0) { const char* e = getenv("MADTP_GEMM_PP"); pp_env = e ? atoi(e) : 1; }
         const bool pp_can = (K % 128) == 0;
         pp_ok = pp_can && (force_cfg == 9 || (force_cfg == 0 && pp_env));
+        const bool sq_allowed = sq_env && (!f16 || pp_ok);  // plain f16 operands: the 256x256 tile exists as the ping-pong kernel only
         float unit = gemm_sq_cost();
         if (pp_ok && unit > 1.5f) unit = 1.5f;
         const float cost_sq = unit * (float)((t_sq + 255) / 256), cost_ws = ws_cost(t256, K / 64, sk_on);
-        sq_ok = force_cfg == 6 || (force_cfg == 9 && pp_can) || (force_cfg == 0 && sq_env && ws_ok && t_sq >= 100 && cost_sq < cost_ws);
+        sq_ok = (force_cfg == 6 && !f16) || (force_cfg == 9 && pp_can) || (force_cfg == 0 && sq_allowed && ws_ok && t_sq >= 100 && cost_sq < cost_ws);
         pp_ok = pp_ok && sq_ok;
     }
     if (sq_ok) {
@@ -1255,7 +1261,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         const int grid = 8 * (slots_max < cap ? slots_max : cap);
         const size_t lds = (size_t)2 * (256 + 256) * ROWB;
         if (pp_ok) {
-            const int rc = madtp_gemm_pp_launch(&g, c_dtype == MADTP_BF16, 0, grid, s);
+            const int rc = madtp_gemm_pp_launch(&g, c_dtype != MADTP_F32, f16 ? 1 : 0, grid, s);
             if (rc) return rc;
         } else if (c_dtype == MADTP_BF16) {
             MADTP_ENSURE_MAX_LDS((gemm_sq_kernel<OM_BF16>), lds);
@@ -1282,18 +1288,20 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         const int grid = 8 * (slots_max < cap ? slots_max : cap);
         if (sk_on && grid == 256) { g.sk = 1; g.sk_ws = skw.ws; g.sk_tick = skw.tick; }
         const size_t lds = (size_t)3 * (256 + 128) * ROWB;
-#define MADTP_LAUNCH_WS(X3_, OM_, M32_)                                                          \
-    do {                                                                                        \
-        MADTP_ENSURE_MAX_LDS((gemm_ws_kernel<X3_, OM_, M32_>), lds);                            \
-        hipLaunchKernelGGL((gemm_ws_kernel<X3_, OM_, M32_>), dim3(grid), dim3(768), lds, s, g); \
+#define MADTP_LAUNCH_WS(X3_, OM_, M32_, ...)                                                                  \
+    do {                                                                                                     \
+        MADTP_ENSURE_MAX_LDS((gemm_ws_kernel<X3_, OM_, M32_ __VA_OPT__(,) __VA_ARGS__>), lds);                \
+        hipLaunchKernelGGL((gemm_ws_kernel<X3_, OM_, M32_ __VA_OPT__(,) __VA_ARGS__>), dim3(grid), dim3(768), lds, s, g); \
     } while (0)
         // 32x32x16 consumer loop (bf16 operands, vector epilogue, no stream-K tail).  OFF by default - measured SLOWER than the
         // 16x16x32 loop on every ViT shape of the forward (profiles/r03_gemm_m32_ab.txt: MFMA-only stream 1.57 vs 1.66 PF, whole
         // kernel 623-837 vs 851-981 TF): MADTP_GEMM_M32=1 turns it on in the automatic dispatch, cfg 8 forces it (tests, A/B runs)
         static int m32_env = -1;
         if (m32_env < 0) { const char* e = getenv("MADTP_GEMM_M32"); m32_env = e ? atoi(e) : 0; }
-        const bool m32 = !x3 && g.fast_epi && !g.sk && (force_cfg == 8 || (force_cfg == 0 && m32_env));
-        if (x3) {
+        const bool m32 = !x3 && !f16 && g.fast_epi && !g.sk && (force_cfg == 8 || (force_cfg == 0 && m32_env));
+        if (f16) {
+            if (c_dtype == MADTP_F16) MADTP_LAUNCH_WS(false, OM_F16, false, true); else MADTP_LAUNCH_WS(false, OM_F32, false, true);
+        } else if (x3) {
             if (c_dtype == MADTP_F16S) MADTP_LAUNCH_WS(true, OM_F16S, false); else MADTP_LAUNCH_WS(true, OM_F32, false);
         } else if (m32) {
             if (c_dtype == MADTP_BF16) MADTP_LAUNCH_WS(false, OM_BF16, true); else MADTP_LAUNCH_WS(false, OM_F32, true);
@@ -1303,6 +1311,8 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
 #undef MADTP_LAUNCH_WS
     } else if (ab_dtype == MADTP_BF16) {
         if (c_dtype == MADTP_BF16) MADTP_DISPATCH_CFG(bf16_t, OM_BF16); else MADTP_DISPATCH_CFG(bf16_t, OM_F32);
+    } else if (f16) {
+        if (c_dtype == MADTP_F16) MADTP_DISPATCH_CFG(F16P, OM_F16); else MADTP_DISPATCH_CFG(F16P, OM_F32);
     } else if (x3) {
         if (c_dtype == MADTP_F16S) MADTP_DISPATCH_CFG(F16S, OM_F16S); else MADTP_DISPATCH_CFG(F16S, OM_F32);
     } else {

@@ -22,7 +22,9 @@ struct GemmArgs {
     // and the per-(tail tile, wave) tickets [8][16][8]; sk == 0: off
     float* sk_ws; int* sk_tick; int sk;
     int desc;  // gemm_kernel: both operands fit a 32-bit buffer descriptor -> descriptor-based LDS-DMA (no per-slab address arithmetic)
+    int* range_flag;  // f16 outputs (OM_F16S / OM_F16): the pinned range flag (common.h), else unused
 };
+struct F16P { unsigned short bits; };  // operand tag of gemm_kernel<>: plain f16 elements (MADTP_F16) on the f16 MFMA
 
 // f16-split operands (common.h).  The kernels walk K as a stream of 2 * K/64 slab steps: step 2t stages [P0 | Q1] of k-slab t,
 // step 2t+1 stages [P1 | Q0]; the three products of a k-slab are P0 Q1 (first step), P0 Q0 and P1 (Q0 2^-11) (second step, with
@@ -40,7 +42,7 @@ __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 // output modes of the epilogue
-constexpr int OM_F32 = 0, OM_BF16 = 1, OM_F16S = 2;
+constexpr int OM_F32 = 0, OM_BF16 = 1, OM_F16S = 2, OM_F16 = 3;  // OM_F16: plain f16 output (operands MADTP_F16)
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
@@ -187,7 +189,7 @@ __host__ __device__ __forceinline__ constexpr int wfrag_row32(int j, int rho) {
 template <int OM, int ACT, bool HAS_RES>
 __device__ __forceinline__ void epilogue32(const GemmArgs& g, const f32x16 (&acc)[2][2], int row_t, int col_w, int l32, int h) {
     constexpr bool LP_OUT = OM != OM_F32;
-    constexpr bool FAST_ACT = OM == OM_BF16;
+    constexpr bool FAST_ACT = OM == OM_BF16 || OM == OM_F16;
     constexpr int CSZ = LP_OUT ? 2 : 4;
     constexpr int NJ = LP_OUT ? 2 : 4;   // column vectors per lane, fragment row and fragment column: p (8 columns) or q (4)
     constexpr int NV = LP_OUT ? 2 : 1;   // float4s per column vector
@@ -247,6 +249,7 @@ __device__ __forceinline__ void epilogue32(const GemmArgs& g, const f32x16 (&acc
                 const unsigned off = cok[jv] ? (unsigned)((32 * i + l32) * ldc + colv[jv]) * CSZ : 0x80000000u;
                 u32x4 bits;
                 if constexpr (OM == OM_BF16) bits = __builtin_bit_cast(u32x4, pack_bf16x8(v[0], v[1]));
+                else if constexpr (OM == OM_F16) bits = __builtin_bit_cast(u32x4, pack_f16x8(v[0], v[1]));
                 else bits = __builtin_bit_cast(u32x4, v[0]);
                 __builtin_amdgcn_raw_buffer_store_b128(bits, crsrc, off, 0, 0);
             }
@@ -259,7 +262,7 @@ template <int OM, int ACT, bool HAS_RES, int FM, int FN, int BM, int BN, bool FA
 __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[FM][FN], const f32x4 (&res)[RM][RN],
                                          int m0, int n0, int wr, int wc, int l16, int grp4, size_t c_off) {
     constexpr bool LP_OUT = OM != OM_F32;    // 8-consecutive-column fragment layout (wfrag_row<true>)
-    constexpr bool FAST_ACT = OM == OM_BF16;
+    constexpr bool FAST_ACT = OM == OM_BF16 || OM == OM_F16;
     const bool c_bf16 = g.ldc < 0;
     const int ldc = c_bf16 ? -g.ldc : g.ldc;
             const int col_w = n0 + wc * (BN / 2);
@@ -275,6 +278,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[F
                 constexpr int NV = LP_OUT ? 2 : 1;        // float4s per column vector
                 constexpr int CSZ = LP_OUT ? 2 : 4;
                 constexpr bool RES_PREF = !LP_OUT && RM == FM;
+                float range_mx = 0.f;  // f16 outputs: a value outside the f16 range raises the range flag (f16_range_acc)
                 const int row_t = m0 + wr * (BM / 2);  // first row of this wave's 64-row (BM/2) block: wave-uniform
                 const int rows_valid = max(min(g.M - row_t, BM / 2), 0);
                 const unsigned long long cb = (unsigned long long)((char*)g.C + (c_off + (size_t)((g.dbg & 8) ? (row_t & 127) : row_t) * ldc) * CSZ);  // dbg 8: timing experiment, all tiles store to the first 128 rows (L2-resident)
@@ -348,12 +352,18 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[F
                                 u32x4 lo_bits;
                                 split_f16x8(v[0], v[1], bits, lo_bits);
                                 __builtin_amdgcn_raw_buffer_store_b128(lo_bits, crsrc, cok[jv] ? off + (unsigned)g.N * 2u : off, 0, 0);
+                                range_mx = f16_range_acc(f16_range_acc(range_mx, v[0]), v[1]);
                             } else if constexpr (OM == OM_BF16) bits = __builtin_bit_cast(u32x4, pack_bf16x8(v[0], v[1]));
+                            else if constexpr (OM == OM_F16) {
+                                bits = __builtin_bit_cast(u32x4, pack_f16x8(v[0], v[1]));
+                                range_mx = f16_range_acc(f16_range_acc(range_mx, v[0]), v[1]);
+                            }
                             else bits = __builtin_bit_cast(u32x4, v[0]);
                             __builtin_amdgcn_raw_buffer_store_b128(bits, crsrc, off, 0, 0);
                         }
                     }
                 }
+                if constexpr (OM == OM_F16S || OM == OM_F16) f16_range_raise(g.range_flag, !(range_mx < 65520.0f));
             } else if constexpr (!FAST_ONLY) {
                 // generic fallback (N or a leading dimension not a multiple of 8 elements, e.g. the 2-logit head)
 #pragma unroll
@@ -374,6 +384,10 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[F
                                 const _Float16 h = (_Float16)v;
                                 ((_Float16*)g.C)[ci] = h;
                                 ((_Float16*)g.C)[ci + g.N] = (_Float16)((v - (float)h) * F16S_LO_SCALE);
+                                f16_range_raise(g.range_flag, f16_range_bad(v));
+                            } else if constexpr (OM == OM_F16) {
+                                ((_Float16*)g.C)[ci] = (_Float16)v;
+                                f16_range_raise(g.range_flag, f16_range_bad(v));
                             } else if (c_bf16) ((bf16_t*)g.C)[ci] = f32_to_bf16(v);
                             else ((float*)g.C)[ci] = v;
                         }

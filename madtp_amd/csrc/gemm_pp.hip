@@ -222,34 +222,35 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
 }
 
 // launcher called by gemm.hip's dispatch (args points at its GemmArgs, same definition from gemm_device.h)
-__attribute__((visibility("hidden"))) int madtp_gemm_pp_launch(const void* args, int out_bf16, int f16, int grid, void* stream) {
+__attribute__((visibility("hidden"))) int madtp_gemm_pp_launch(const void* args, int out_lp, int f16, int grid, void* stream) {
     const GemmArgs& g = *(const GemmArgs*)args;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)8 * 128 * ROWB;
-    if (f16) return MADTP_E_DTYPE;
-    static int abl = -1;  // MADTP_PP_ABLATE: timing experiments (bf16 output only; see ABL above)
+    static int abl = -1;  // MADTP_PP_ABLATE: timing experiments (bf16 operands and output only; see ABL above)
     if (abl < 0) { const char* e = getenv("MADTP_PP_ABLATE"); abl = e ? atoi(e) : 0; }
-#define PP_LAUNCH(OM_, ABL_)                                                                              \
+#define PP_LAUNCH(OM_, F16_, ABL_)                                                                        \
     do {                                                                                                  \
-        MADTP_ENSURE_MAX_LDS((gemm_pp_kernel<OM_, false, ABL_>), lds);                                     \
-        hipLaunchKernelGGL((gemm_pp_kernel<OM_, false, ABL_>), dim3(grid), dim3(512), lds, s, g);          \
+        MADTP_ENSURE_MAX_LDS((gemm_pp_kernel<OM_, F16_, ABL_>), lds);                                      \
+        hipLaunchKernelGGL((gemm_pp_kernel<OM_, F16_, ABL_>), dim3(grid), dim3(512), lds, s, g);           \
     } while (0)
-    if (out_bf16) {
+    if (f16) {  // out_lp: a 2-byte output in the operands' element format
+        if (out_lp) PP_LAUNCH(OM_F16, true, 0); else PP_LAUNCH(OM_F32, true, 0);
+    } else if (out_lp) {
         switch (abl) {
 #ifdef MADTP_PP_ABLATIONS
-            case 1: PP_LAUNCH(OM_BF16, 1); break;
-            case 2: PP_LAUNCH(OM_BF16, 2); break;
-            case 3: PP_LAUNCH(OM_BF16, 3); break;
-            case 4: PP_LAUNCH(OM_BF16, 4); break;
-            case 5: PP_LAUNCH(OM_BF16, 5); break;
-            case 6: PP_LAUNCH(OM_BF16, 6); break;
-            case 8: PP_LAUNCH(OM_BF16, 8); break;
-            case 16: PP_LAUNCH(OM_BF16, 16); break;
+            case 1: PP_LAUNCH(OM_BF16, false, 1); break;
+            case 2: PP_LAUNCH(OM_BF16, false, 2); break;
+            case 3: PP_LAUNCH(OM_BF16, false, 3); break;
+            case 4: PP_LAUNCH(OM_BF16, false, 4); break;
+            case 5: PP_LAUNCH(OM_BF16, false, 5); break;
+            case 6: PP_LAUNCH(OM_BF16, false, 6); break;
+            case 8: PP_LAUNCH(OM_BF16, false, 8); break;
+            case 16: PP_LAUNCH(OM_BF16, false, 16); break;
 #endif
-            default: PP_LAUNCH(OM_BF16, 0); break;
+            default: PP_LAUNCH(OM_BF16, false, 0); break;
         }
     } else {
-        PP_LAUNCH(OM_F32, 0);
+        PP_LAUNCH(OM_F32, false, 0);
     }
 #undef PP_LAUNCH
     return 0;

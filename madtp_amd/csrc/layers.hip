@@ -20,7 +20,7 @@ struct Carver {
 };
 
 // bytes per logical element of an activation in compute dtype dt (F16S: two f16 planes = 4 bytes, like f32)
-inline size_t esz_of(int dt) { return dt == MADTP_BF16 ? 2 : 4; }
+inline size_t esz_of(int dt) { return (dt == MADTP_BF16 || dt == MADTP_F16) ? 2 : 4; }
 // physical leading dimension of an operand with logical row length ld (f16-split rows hold 2 planes)
 inline int pld(int dt, int ld) { return dt == MADTP_F16S ? 2 * ld : ld; }
 // dtype the attention kernels run in: the f16-split mode keeps attention on the exact-f32 kernels (q/k/v/out f32)
@@ -54,7 +54,7 @@ inline int ln_to(const float* x, const float* g, const float* b, float* y32, voi
 inline int to_lp(const float* src, int ld_src, void* dst, int rows, int dim, int dt, void* stream) {
     if (dt == MADTP_F16S) return madtp_split_f16(src, ld_src, dst, 2 * dim, rows, dim, stream);
     if (ld_src != dim) return MADTP_E_SHAPE;
-    return madtp_cast_bf16(src, dst, (size_t)rows * dim, stream);
+    return madtp_cast_lp(src, dst, (size_t)rows * dim, dt, 1.0f, stream);
 }
 
 // split-K factor for a small-M projection that feeds a LayerNorm: only when the tile count leaves most CUs idle and the

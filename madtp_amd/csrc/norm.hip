@@ -6,10 +6,11 @@
 #include <type_traits>
 
 namespace {
+struct F16Plain { unsigned short bits; };  // element tag: plain f16 (MADTP_F16)
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* y32, bf16_t* ylp,
-                                                        int lp_mul, int rows, int dim, float eps) {
+                                                        int lp_fmt, int* range_flag, int rows, int dim, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -25,13 +26,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float mean, rstd;
     ln_row(v, n, dim, eps, mean, rstd);
     ln_store(v, lane, dim, mean, rstd, prm, y32 ? y32 + (size_t)row * dim : nullptr,
-             ylp ? ylp + (size_t)row * dim * lp_mul : nullptr, lp_mul == 2);
+             ylp ? ylp + (size_t)row * dim * lp_row_mul(lp_fmt) : nullptr, lp_fmt, range_flag);
 }
 
 __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ wemb,
                                                          const float* __restrict__ pemb, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* y32, bf16_t* ylp,
-                                                         int lp_mul, int rows, int L, int dim, float eps) {
+                                                         int lp_fmt, int* range_flag, int rows, int L, int dim, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restri
     float mean, rstd;
     ln_row(v, n, dim, eps, mean, rstd);
     ln_store(v, lane, dim, mean, rstd, prm, y32 ? y32 + (size_t)row * dim : nullptr,
-             ylp ? ylp + (size_t)row * dim * lp_mul : nullptr, lp_mul == 2);
+             ylp ? ylp + (size_t)row * dim * lp_row_mul(lp_fmt) : nullptr, lp_fmt, range_flag);
 }
 
 // y = LayerNorm(scale * (sum_s part[s] + bias) + residual): the fixed-order reduction of split-K partials fused with the
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restri
 __global__ __launch_bounds__(256) void splitk_ln_kernel(const float* __restrict__ part, int S, size_t pstride,
                                                         const float* __restrict__ bias, const float* __restrict__ residual,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float* y32, bf16_t* ylp, int lp_mul, int rows, int dim, float eps,
+                                                        float* y32, bf16_t* ylp, int lp_fmt, int* range_flag, int rows, int dim, float eps,
                                                         float acc_scale, float scale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void splitk_ln_kernel(const float* __restrict_
     float mean, rstd;
     ln_row(v, n, dim, eps, mean, rstd);
     ln_store(v, lane, dim, mean, rstd, prm, y32 ? y32 + (size_t)row * dim : nullptr,
-             ylp ? ylp + (size_t)row * dim * lp_mul : nullptr, lp_mul == 2);
+             ylp ? ylp + (size_t)row * dim * lp_row_mul(lp_fmt) : nullptr, lp_fmt, range_flag);
 }
 
 // one thread per 4 consecutive kx of one (b, patch, c, ky): reads 16 B of an image row, writes 16 B / 8 B
@@ -119,6 +120,8 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
         _Float16* o = cols + prow * 2 * kcols + col;
         *(f16x4*)o = h;
         *(f16x4*)(o + kcols) = l;
+    } else if constexpr (std::is_same<T, F16Plain>::value) {  // plain f16 (MADTP_F16)
+        *(bf16x4*)((bf16_t*)cols + e) = pack_f16x4((f32x4){v.x, v.y, v.z, v.w});
     } else {
         T* o = cols + e;
         o[0] = from_f32<T>(v.x); o[1] = from_f32<T>(v.y); o[2] = from_f32<T>(v.z); o[3] = from_f32<T>(v.w);
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void add_scale_kernel(const float* __restrict_
 
 // f32 [rows, K] -> f16-split activation planes [rows, 2K]; one thread per 4 consecutive columns
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ src, int ld_src, _Float16* __restrict__ dst,
-                                                        int ld_dst, int K4, size_t total4) {
+                                                        int ld_dst, int K4, size_t total4, int* range_flag) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
     const size_t row = i / K4;
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     _Float16* o = dst + row * ld_dst + col;
     *(f16x4*)o = h;
     *(f16x4*)(o + K4 * 4) = l;
+    f16_range_raise(range_flag, f16_range_bad((f32x4){v.x, v.y, v.z, v.w}));  // P0 would be an infinity: flag it (madtp_range_status)
 }
 
 // weight planes [Q0 | Q1] of w * inv_scale (common.h): Q0 = f16(w~), Q1 = f16(w~ - Q0)
@@ -189,19 +193,58 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     }
 }
 
+// f32 -> 2-byte elements (bf16 or plain f16) of src * scale
+template <bool F16>
+__global__ __launch_bounds__(256) void cast_lp_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n, float scale,
+                                                      int* range_flag) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n) {
+        const float4 v4 = *(const float4*)(src + i);
+        const f32x4 v = (f32x4){v4.x, v4.y, v4.z, v4.w} * scale;
+        *(bf16x4*)(dst + i) = pack_lp4<F16>(v);
+        if constexpr (F16) f16_range_raise(range_flag, f16_range_bad(v));
+    } else {
+        for (size_t j = i; j < n; ++j) {
+            const float v = src[j] * scale;
+            if constexpr (F16) { ((_Float16*)dst)[j] = (_Float16)v; f16_range_raise(range_flag, f16_range_bad(v)); }
+            else dst[j] = f32_to_bf16(v);
+        }
+    }
+}
+
 }  // namespace
 
-static inline int lp_mul_of(int lp_dtype) { return lp_dtype == MADTP_F16S ? 2 : 1; }
+static inline bool lp_dtype_ok(int d) { return d == MADTP_BF16 || d == MADTP_F16S || d == MADTP_F16; }
+
+// The f16 range flag: one int of pinned (host-coherent) memory per process, written by device kernels, read by the host.
+int* madtp_internal_range_flag() {
+    static int* flag = [] {
+        int* p = nullptr;
+        if (hipHostMalloc((void**)&p, 64, hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return (int*)nullptr; }
+        *p = 0;
+        return p;
+    }();
+    return flag;
+}
+extern "C" int madtp_range_status(int reset, void* stream) {
+    int* f = madtp_internal_range_flag();
+    if (!f) return 0;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) (void)hipGetLastError();
+    const int v = *(volatile int*)f;
+    if (reset) *(volatile int*)f = 0;
+    return v;
+}
 
 extern "C" int madtp_layernorm(const float* x, const float* gamma, const float* beta, float* y32, void* ylp, int lp_dtype,
                                int rows, int dim, float eps, void* stream) {
     if (!x || !gamma || !beta || (!y32 && !ylp) || rows <= 0 || dim <= 0) return MADTP_E_BADARG;
-    if (ylp && lp_dtype != MADTP_BF16 && lp_dtype != MADTP_F16S) return MADTP_E_DTYPE;
+    if (ylp && !lp_dtype_ok(lp_dtype)) return MADTP_E_DTYPE;
     if (dim % 4 || dim > 256 * LN_MAX_CHUNKS) return MADTP_E_SHAPE;
     if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || (y32 && !aligned16(y32)) || (ylp && ((uintptr_t)ylp & 7)))
         return MADTP_E_ALIGN;
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y32,
-                       (bf16_t*)ylp, lp_mul_of(lp_dtype), rows, dim, eps);
+                       (bf16_t*)ylp, lp_dtype, madtp_internal_range_flag(), rows, dim, eps);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
@@ -210,10 +253,10 @@ extern "C" int madtp_splitk_ln(const float* part, int splits, const float* bias,
                                const float* beta, float* y32, void* ylp, int lp_dtype, int rows, int dim, float eps,
                                float acc_scale, float scale, void* stream) {
     if (!part || !gamma || !beta || (!y32 && !ylp) || rows <= 0 || dim <= 0 || splits < 1) return MADTP_E_BADARG;
-    if (ylp && lp_dtype != MADTP_BF16 && lp_dtype != MADTP_F16S) return MADTP_E_DTYPE;
+    if (ylp && !lp_dtype_ok(lp_dtype)) return MADTP_E_DTYPE;
     if (dim % 4 || dim > 256 * LN_MAX_CHUNKS) return MADTP_E_SHAPE;
     hipLaunchKernelGGL(splitk_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, splits,
-                       (size_t)rows * dim, bias, residual, gamma, beta, y32, (bf16_t*)ylp, lp_mul_of(lp_dtype), rows, dim, eps,
+                       (size_t)rows * dim, bias, residual, gamma, beta, y32, (bf16_t*)ylp, lp_dtype, madtp_internal_range_flag(), rows, dim, eps,
                        acc_scale, scale);
     MADTP_LAUNCH_CHECK();
     return 0;
@@ -223,11 +266,11 @@ extern "C" int madtp_bert_embed(const int64_t* ids, const float* word_emb, const
                                 const float* beta, float* y32, void* ylp, int lp_dtype, int B, int L, int dim, float eps,
                                 void* stream) {
     if (!ids || !word_emb || !pos_emb || !gamma || !beta || (!y32 && !ylp) || B <= 0 || L <= 0) return MADTP_E_BADARG;
-    if (ylp && lp_dtype != MADTP_BF16 && lp_dtype != MADTP_F16S) return MADTP_E_DTYPE;
+    if (ylp && !lp_dtype_ok(lp_dtype)) return MADTP_E_DTYPE;
     if (dim % 4 || dim > 256 * LN_MAX_CHUNKS) return MADTP_E_SHAPE;
     const int rows = B * L;
     hipLaunchKernelGGL(bert_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, word_emb, pos_emb,
-                       gamma, beta, y32, (bf16_t*)ylp, lp_mul_of(lp_dtype), rows, L, dim, eps);
+                       gamma, beta, y32, (bf16_t*)ylp, lp_dtype, madtp_internal_range_flag(), rows, L, dim, eps);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
@@ -241,6 +284,8 @@ extern "C" int madtp_patchify(const float* img, void* cols, int B, int S, int P,
         hipLaunchKernelGGL(patchify_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, img, (float*)cols, B, S, P, total4);
     else if (out_dtype == MADTP_BF16)
         hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)cols, B, S, P, total4);
+    else if (out_dtype == MADTP_F16)
+        hipLaunchKernelGGL(patchify_kernel<F16Plain>, grid, dim3(256), 0, (hipStream_t)stream, img, (F16Plain*)cols, B, S, P, total4);
     else if (out_dtype == MADTP_F16S)
         hipLaunchKernelGGL(patchify_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, img, (_Float16*)cols, B, S, P, total4);
     else
@@ -269,6 +314,20 @@ extern "C" int madtp_add_scale(const float* a, const float* b, float* out, float
     return 0;
 }
 
+extern "C" int madtp_cast_lp(const float* src, void* dst, size_t n, int lp_dtype, float scale, void* stream) {
+    if (!src || !dst || n == 0) return MADTP_E_BADARG;
+    if (!aligned16(src) || (((uintptr_t)dst) & 7u)) return MADTP_E_ALIGN;
+    const dim3 grid((unsigned)(((n + 3) / 4 + 255) / 256));
+    if (lp_dtype == MADTP_BF16)
+        hipLaunchKernelGGL(cast_lp_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n, scale, (int*)nullptr);
+    else if (lp_dtype == MADTP_F16)
+        hipLaunchKernelGGL(cast_lp_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n, scale, madtp_internal_range_flag());
+    else
+        return MADTP_E_DTYPE;
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int madtp_cast_bf16(const float* src, void* dst, size_t n, void* stream) {
     if (!src || !dst || n == 0) return MADTP_E_BADARG;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
@@ -283,7 +342,7 @@ extern "C" int madtp_split_f16(const float* src, int ld_src, void* dst, int ld_d
     if (!aligned16(src) || ld_src % 4 || ((uintptr_t)dst & 7) || ld_dst % 4) return MADTP_E_ALIGN;
     const size_t total4 = (size_t)rows * (K / 4);
     hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
-                       (_Float16*)dst, ld_dst, K / 4, total4);
+                       (_Float16*)dst, ld_dst, K / 4, total4, madtp_internal_range_flag());
     MADTP_LAUNCH_CHECK();
     return 0;
 }
@@ -299,7 +358,7 @@ extern "C" int madtp_split_f16_weight(const float* w, int ldw, void* dst, int n,
     return 0;
 }
 
-extern "C" int madtp_abi_version(void) { return 15; }
+extern "C" int madtp_abi_version(void) { return 16; }
 
 extern "C" const char* madtp_strerror(int code) {
     switch (code) {
@@ -309,6 +368,7 @@ extern "C" const char* madtp_strerror(int code) {
         case MADTP_E_DTYPE: return "unknown dtype";
         case MADTP_E_ALIGN: return "pointer / leading dimension not 16-byte aligned";
         case MADTP_E_BUSY: return "all host hand-over slots of the device are pending";
+        case MADTP_E_RANGE: return "a value left the f16 range (|x| >= 65504 or NaN) in an f16 precision mode - use the fp32 / bf16 mode for this model";
         default: return code > 0 ? "HIP launch error (hipError_t)" : "unknown error";
     }
 }

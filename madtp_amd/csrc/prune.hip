@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void token_gather_kernel(const float* __restri
                                                            const float* __restrict__ merge_w, float* __restrict__ y, int N,
                                                            int k, int dim4, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float* h32, bf16_t* hlp,
-                                                           int lp_mul) {
+                                                           int lp_fmt, int* range_flag) {
     __shared__ float4 part[4][256];  // dim <= 1024
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, n = N - 1, No = k + 2, dim = dim4 * 4;
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void token_gather_kernel(const float* __restri
         float mean, rstd;
         ln_row(v, nch, dim, eps, mean, rstd);
         const size_t off = ((size_t)b * No + dst) * dim;
-        ln_store(v, lane, dim, mean, rstd, prm, h32 ? h32 + off : nullptr, hlp ? hlp + off * lp_mul : nullptr, lp_mul == 2);
+        ln_store(v, lane, dim, mean, rstd, prm, h32 ? h32 + off : nullptr, hlp ? hlp + off * lp_row_mul(lp_fmt) : nullptr, lp_fmt, range_flag);
     };
     if ((int)blockIdx.x < (int)gridDim.x - 1) {
         // A wave copies the source tokens t0 + wave + 4 i (i < 4).  The straightforward loop was a dependent chain per row
@@ -1557,9 +1557,15 @@ extern "C" int madtp_token_score_wait(int seq, const int32_t* count, int B, int3
         }
     }
     *k_host = __atomic_load_n(&sl.host[0], __ATOMIC_RELAXED);
-    std::lock_guard<std::mutex> lk(d.mu);
-    sl.busy = false;
-    return 0;
+    {
+        std::lock_guard<std::mutex> lk(d.mu);
+        sl.busy = false;
+    }
+    // the f16 range flag (madtp_range_status): kernels of this layer that ran before token_score have long completed, so a value
+    // that left the f16 range in an f16 precision mode surfaces here, at the layer's one host synchronisation, as an error code
+    // instead of NaNs further down (sticky until madtp_range_status(reset = 1))
+    const int* rf = madtp_internal_range_flag();
+    return (rf && *(const volatile int*)rf) ? MADTP_E_RANGE : 0;
 }
 
 extern "C" int madtp_token_score_sync(const float* colsum_part, int n_row_tiles, const float* p0, const float* onorm,
@@ -1596,7 +1602,7 @@ extern "C" int madtp_token_select(const float* score, int k, int64_t* indices, i
 extern "C" int madtp_token_gather_ln(const float* x, const int32_t* dst_pos, const float* merge_w, float* y, int B, int N,
                                      int k, int dim, const float* gamma, const float* beta, float eps, float* h32, void* h_lp,
                                      int lp_dtype, void* stream) {
-    if (h_lp && lp_dtype != MADTP_BF16 && lp_dtype != MADTP_F16S) return MADTP_E_DTYPE;
+    if (h_lp && lp_dtype != MADTP_BF16 && lp_dtype != MADTP_F16S && lp_dtype != MADTP_F16) return MADTP_E_DTYPE;
     if (!x || !dst_pos || !merge_w || !y || B <= 0 || N < 2 || k < 1 || k > N - 1) return MADTP_E_BADARG;
     if (gamma && (!beta || (!h32 && !h_lp))) return MADTP_E_BADARG;
     if (dim % 4 || dim > 1024) return MADTP_E_SHAPE;
@@ -1604,7 +1610,7 @@ extern "C" int madtp_token_gather_ln(const float* x, const int32_t* dst_pos, con
         return MADTP_E_ALIGN;
     const int chunks = (N + GATHER_ROWS - 1) / GATHER_ROWS;
     hipLaunchKernelGGL(token_gather_kernel, dim3(chunks + 1, B), dim3(256), 0, (hipStream_t)stream, x, dst_pos, merge_w, y, N,
-                       k, dim / 4, gamma, beta, eps, h32, (bf16_t*)h_lp, lp_dtype == MADTP_F16S ? 2 : 1);
+                       k, dim / 4, gamma, beta, eps, h32, (bf16_t*)h_lp, lp_dtype, madtp_internal_range_flag());
     MADTP_LAUNCH_CHECK();
     return 0;
 }

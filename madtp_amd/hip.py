@@ -10,9 +10,10 @@ from ctypes import c_float, c_int, c_size_t, c_void_p
 
 import torch
 
-F32, BF16, F16S = 0, 1, 2  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
+F32, BF16, F16S, F16 = 0, 1, 2, 3  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
+#                                    F16: plain IEEE f16 operands (the "f16" fast mode), see set_lp_format below
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -81,6 +82,8 @@ _SIGS = {
     "madtp_query_att_ft_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "madtp_query_att_ft_multi_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "madtp_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "madtp_cast_lp": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_float, c_void_p]),
+    "madtp_range_status": (c_int, [c_int, c_void_p]),
     "madtp_split_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "madtp_split_f16_weight": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
     "madtp_lm_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p]),
@@ -168,9 +171,14 @@ def load(path=None):
     return lib
 
 
+E_RANGE = -6
+
+
 def _check(code, what):
     if code != 0:
         msg = load().madtp_strerror(code).decode()
+        if code == E_RANGE:
+            load().madtp_range_status(1, None)  # the flag is sticky: clear it so that the process can go on in another mode
         raise RuntimeError(f"{what} failed: {msg} (code {code})")
 
 
@@ -182,6 +190,31 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Element format of the fast modes' 2-byte operands.  PyTorch is plumbing here (it never does arithmetic on these buffers), and
+# the two fast modes share every shape, stride and buffer size - so both keep their operands in torch.bfloat16-TYPED containers
+# and the element FORMAT (bf16, or IEEE f16 in the "f16" mode) travels as the dtype code of the C-ABI (MADTP_BF16 / MADTP_F16),
+# chosen by the thread's precision mode (runtime.set_precision -> set_lp_format).  Do not .float() such a tensor in the "f16"
+# mode: use lp_to_f32().
+import threading as _threading
+
+_lp_state = _threading.local()
+
+
+def set_lp_format(code):
+    _lp_state.fmt = BF16 if code != F16 else F16
+
+
+def lp_format():
+    return getattr(_lp_state, "fmt", BF16)
+
+
+def lp_to_f32(t):
+    """a 2-byte operand container (see above) -> f32 values, in the current thread's element format"""
+    if t.dtype == torch.bfloat16 and lp_format() == F16:
+        return t.view(torch.float16).float()
+    return t.float()
+
+
 def _dt(t):
     return dt_code(t.dtype)
 
@@ -190,7 +223,7 @@ def dt_code(dtype):
     if dtype == torch.float32:
         return F32
     if dtype == torch.bfloat16:
-        return BF16
+        return lp_format()
     if dtype == torch.float16:
         return F16S
     raise TypeError(f"unsupported dtype {dtype}")
@@ -504,11 +537,46 @@ def add_scale(a, b, scale):
     return out
 
 
-def cast_bf16(src):
+def cast_bf16(src, scale=1.0):
+    """f32 -> the fast modes' 2-byte operand (bf16, or f16 in the "f16" mode: lp_format()), of src * scale"""
+    _req(src, torch.float32, "src")
+    dst = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
+    _check(load().madtp_cast_lp(_p(src), _p(dst), src.numel(), lp_format(), float(scale), _stream()), "madtp_cast_lp")
+    return dst
+
+
+def cast_bf16_plain(src):
+    """f32 -> bf16, whatever the thread's 2-byte element format: the alignment dictionary's hi / lo planes (madtp_align_logits
+    splits x.sd^T into bf16 products in BOTH fast modes)."""
     _req(src, torch.float32, "src")
     dst = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
     _check(load().madtp_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "madtp_cast_bf16")
     return dst
+
+
+def split_code(t):
+    """split_dtype of alignment-dictionary planes: float16 = the f16 planes of the f16x3 mode, bfloat16 = bf16 hi / lo planes"""
+    return F16S if t.dtype == torch.float16 else BF16
+
+
+def cast_lp_weight(w):
+    """Prepared weight of a fast mode: bf16 cast, or - "f16" mode - f16 of w * 2^s with max|w| * 2^s in (2^13, 2^14] (small
+    weights stay clear of the f16 subnormals; the tensor is tagged with the accumulator scale 2^-s like the split planes)."""
+    if lp_format() != F16:
+        return cast_bf16(w)
+    amax = float(w.abs().max())
+    s = 0
+    if amax > 0 and amax == amax and amax != float("inf"):
+        import math
+        s = max(-100, min(100, 14 - math.ceil(math.log2(amax))))
+    dst = cast_bf16(w, scale=2.0 ** s)
+    dst._madtp_w_scale = float(2.0 ** -s)
+    return dst
+
+
+def range_status(reset=True):
+    """madtp_range_status: 1 when a producer kernel met a value outside the f16 range since the last reset (f16 modes)."""
+    return int(load().madtp_range_status(1 if reset else 0, _stream()))
 
 
 def split_f16(src):
@@ -711,7 +779,7 @@ def align_logits(x2d, sd_hi, sd_lo, sd_scale=1.0):
     """sd_hi / sd_lo: bf16 hi/lo planes (fast mode) or the f16 planes Q0 / Q1 of sd * 2^s with sd_scale = 2^-s (f16x3 mode)."""
     M, D = x2d.shape
     out = torch.empty((M, 128), device=x2d.device, dtype=torch.float32)
-    _check(load().madtp_align_logits(_p(x2d), _p(sd_hi), _p(sd_lo), _p(out), M, D, _dt(sd_hi), float(sd_scale), _stream()),
+    _check(load().madtp_align_logits(_p(x2d), _p(sd_hi), _p(sd_lo), _p(out), M, D, split_code(sd_hi), float(sd_scale), _stream()),
            "madtp_align_logits")
     return out
 
@@ -729,7 +797,7 @@ def query_model(x, sd_w, K, att_ft=None, want_att_ft=True, sd_dim=768, sd_split=
     sd_scale = sd_split[2] if sd_split is not None and len(sd_split) > 2 else 1.0
     fast = hi is not None and hi.dtype == torch.bfloat16
     ws = torch.empty(B * 256, device=x.device, dtype=torch.float32) if (want_att_ft and fast) else None
-    _check(load().madtp_query_model(_p(x), _p(sd_w), _p(hi), _p(lo), _dt(hi) if hi is not None else BF16, float(sd_scale), K,
+    _check(load().madtp_query_model(_p(x), _p(sd_w), _p(hi), _p(lo), split_code(hi) if hi is not None else BF16, float(sd_scale), K,
                                     _p(full), _p(att_ft) if want_att_ft else 0, _p(ws), acc, 1.0 / (sd_dim ** 0.5), B, N, D,
                                     _stream()), "madtp_query_model")
     return full.view(B, N, kp)[:, 1:, :K], att_ft
@@ -835,7 +903,7 @@ def profile_end():
     rows = []
     for line in buf.raw[:n].decode().splitlines():
         dt, M, N, K, c, ms, fl, by = line.split()
-        rows.append({"dtype": {F32: "f32", BF16: "bf16", F16S: "f16s"}[int(dt)], "M": int(M), "N": int(N), "K": int(K),
+        rows.append({"dtype": {F32: "f32", BF16: "bf16", F16S: "f16s", F16: "f16"}[int(dt)], "M": int(M), "N": int(N), "K": int(K),
                      "launches": int(c), "ms": float(ms), "flops": float(fl), "bytes": float(by)})
     return rows
 

@@ -15,6 +15,11 @@ Precision modes (SURVEY.md section 7 "hard parts"):
             a model whose residual stream leaves that range has to run in the "fp32" mode, which has no such limit.
   "bf16"  - fast mode: GEMM operands are bf16 (f32 accumulate, MFMA 16x16x32), the residual stream, LayerNorm
             statistics, softmax, the alignment logits x.sd^T and every pruning score stay f32.
+  "f16"   - the same fast mode with IEEE f16 operands (round 4): identical kernels, layouts and MFMA rate
+            (v_mfma_f32_16x16x32_f16), 11 significand bits instead of 8.  Weights are stored as w * 2^s (accumulator scale 2^-s)
+            like the split planes; activations carry no prescale, so the RANGE note of "f16x3" applies - but a value that leaves
+            the f16 range raises the library's range flag (MADTP_E_RANGE at the layer's host read of k, hip.range_status())
+            instead of turning into NaNs.  Operands live in torch.bfloat16-typed containers (hip.set_lp_format).
 """
 import threading
 
@@ -24,14 +29,15 @@ from . import hip
 
 _state = threading.local()
 _DEFAULT = "bf16"
-MODES = ("fp32", "f16x3", "bf16")
-_CDT = {"fp32": torch.float32, "f16x3": torch.float16, "bf16": torch.bfloat16}
+MODES = ("fp32", "f16x3", "bf16", "f16")
+_CDT = {"fp32": torch.float32, "f16x3": torch.float16, "bf16": torch.bfloat16, "f16": torch.bfloat16}  # "f16": a 2-byte container
 
 
 def set_precision(mode: str):
     if mode not in MODES:
         raise ValueError(f"precision must be one of {MODES}")
     _state.mode = mode
+    hip.set_lp_format(hip.F16 if mode == "f16" else hip.BF16)
 
 
 def get_precision() -> str:
@@ -56,7 +62,7 @@ def compute_dtype():
 
 def attn_dtype():
     """dtype of q/k/v and the context of the attention kernels (the f16x3 mode keeps attention on the exact-f32 kernels)."""
-    return torch.bfloat16 if get_precision() == "bf16" else torch.float32
+    return torch.bfloat16 if get_precision() in ("bf16", "f16") else torch.float32
 
 
 def dtype_code():
@@ -113,7 +119,7 @@ def prepare_linear(weights, biases, dtype):
     n = w.shape[0]
     w = _pad_rows(w)
     if dtype == torch.bfloat16:
-        w = hip.cast_bf16(w.contiguous())
+        w = hip.cast_lp_weight(w.contiguous())
     elif dtype == torch.float16:
         w = hip.split_f16_weight(w.contiguous())
     b = None

@@ -115,8 +115,8 @@ class Query_model(nn.Module):
         split = None
         if compute_dtype() == torch.bfloat16 and sdl.w.shape[0] == 128:
             def _split():
-                hi = hip.cast_bf16(sdl.w)
-                lo = hip.cast_bf16((sdl.w - hi.float()).contiguous())
+                hi = hip.cast_bf16_plain(sdl.w)  # (bf16 planes in both fast modes: the logits kernel splits x into bf16 too)
+                lo = hip.cast_bf16_plain((sdl.w - hi.float()).contiguous())
                 return hi, lo
             split = self._cache.get(("sd_split", id(sd)), [sd], _split)
         elif compute_dtype() == torch.float16 and sdl.w.shape[0] == 128:
@@ -142,7 +142,7 @@ class Query_model(nn.Module):
             return None, False
         qa = {"sd_w": sdl.w, "K": K, "sd_dim": self.att_dim, "att_ft": None, "stats_ws": None}
         if split is not None:
-            qa.update(sd_hi=split[0], sd_lo=split[1], split_dtype=hip.dt_code(split[0].dtype),
+            qa.update(sd_hi=split[0], sd_lo=split[1], split_dtype=hip.split_code(split[0]),
                       sd_scale=split[2] if len(split) > 2 else 1.0)
         # att_ft of all layers in ONE launch after the call ("bf16": fast-mode kernel, "exact": parity arithmetic and order)
         deferred = False

@@ -892,3 +892,92 @@ def _ref_attention_causal(qkv, B, N, H, scale, causal):
     o = p @ v
     colsum = p[:, :, 1:, :].max(1)[0].sum(1)
     return o.transpose(1, 2).reshape(B * N, H * 64), p, colsum, p[:, :, 0, :], o.norm(dim=-1)
+
+
+# ---- the "f16" fast precision mode (plain IEEE f16 operands on the f16 MFMA, MADTP_F16) ---------------------------------------
+@pytest.mark.parametrize("M,N,K", [(197, 768, 768), (1000, 2304, 768), (10533, 768, 768), (10400, 2304, 768), (10533, 768, 3072),
+                                   (257, 2, 768)])
+def test_gemm_f16_operands(hip, M, N, K):
+    """MADTP_F16 operands through every GEMM kernel family (small tiles, wave-specialised 256x128, ping-pong 256x256) and every
+    epilogue: against a float64 product of the same f16-rounded operands (f32 output: accumulation error only; f16 output: one
+    f16 rounding, 2^-11 relative), with the weight pre-scale 2^s of the prepared weights undone by the accumulator scale."""
+    from madtp_amd import runtime
+    a = _rand(M, K, seed=1).cuda()
+    w = _rand(N, K, seed=2, scale=0.05)
+    bias, res = _rand(N, seed=3).cuda(), _rand(M, N, seed=4).cuda()
+    with runtime.precision("f16"):
+        ad = hip.cast_bf16(a)
+        wd = hip.cast_lp_weight(_pad128(w).cuda())
+        assert hip.w_scale_of(wd) < 1.0  # |w| <= 0.25: stored as w * 2^s
+        ar = hip.lp_to_f32(ad).double()
+        wr = (hip.lp_to_f32(wd)[:N].double() * hip.w_scale_of(wd))
+        core = ar @ wr.t()
+        scale = max(1.0, core.abs().max().item())
+        out = hip.gemm(ad, wd, bias, res, out_dtype=torch.float32, n=N)
+        assert (out - ((core + bias.double()).float() + res)).abs().max().item() < 1e-4 * scale
+        out = hip.gemm(ad, wd, bias, out_dtype=torch.bfloat16, act=hip.ACT_GELU, n=N)  # (a 2-byte container: f16 elements here)
+        ref = F.gelu(core + bias.double()).float()
+        assert (hip.lp_to_f32(out) - ref).abs().max().item() < 1.5e-3 * scale
+        out = hip.gemm(ad, wd, None, out_dtype=torch.bfloat16, n=N)
+        assert (hip.lp_to_f32(out) - core.float()).abs().max().item() < 1e-3 * scale
+    # the same problem in the bf16 mode is 8x coarser: the f16 operands carry three more significand bits
+    with runtime.precision("bf16"):
+        ob = hip.gemm(hip.cast_bf16(a), hip.cast_lp_weight(_pad128(w).cuda()), None, out_dtype=torch.float32, n=N)
+    exact = a.double() @ w.cuda().double().t()
+    with runtime.precision("f16"):
+        of = hip.gemm(ad, wd, None, out_dtype=torch.float32, n=N)
+    if M * N > 4096:
+        assert (of - exact.float()).abs().mean().item() < 0.25 * (ob - exact.float()).abs().mean().item()
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 20, 12), (2, 130, 12), (1, 577, 12), (16, 320, 12)])
+def test_self_attention_f16_operands(hip, B, N, H):
+    from madtp_amd import runtime
+    qkv = _rand(B * N, 3 * H * 64, seed=20)
+    with runtime.precision("f16"):
+        qd = hip.cast_bf16(qkv.cuda())
+        out, (cs, p0, on) = hip.attention(qd[:, : H * 64], qd[:, H * 64: 2 * H * 64], qd[:, 2 * H * 64:], B, H, N, N, 0.125, scores=True)
+        qr = hip.lp_to_f32(qd).cpu()
+        ro, rp, rcol, rp0, rn = _ref_attention(qr, B, N, H, 0.125, None)
+        assert (hip.lp_to_f32(out).cpu() - ro).abs().max().item() < 3e-3 * max(1, ro.abs().max().item())   # bf16 kernels: 2e-2
+        assert (p0.cpu() - rp0).abs().max().item() < 2e-5
+        assert (on.cpu() - rn).abs().max().item() < 2e-3 * max(1, rn.max().item())
+
+
+def test_f16_range_flag(hip):
+    """A value outside the f16 range must surface as an error, not as NaNs: the producers of f16 planes /
+    f16 operands raise the library's range flag; the layer-level calls turn it into MADTP_E_RANGE at their host read of k."""
+    from madtp_amd import runtime
+    assert hip.range_status() == 0
+    x = _rand(64, 768, seed=1).cuda()
+    hip.split_f16(x)
+    assert hip.range_status() == 0
+    x[:, 5] *= 1e5  # one channel far outside the f16 range
+    hip.split_f16(x)
+    assert hip.range_status() == 1 and hip.range_status() == 0  # reported once, then cleared
+    with runtime.precision("f16"):
+        hip.cast_bf16(x)
+        assert hip.range_status() == 1
+        big = hip.gemm(hip.cast_bf16(_rand(300, 768, seed=2).cuda() * 40), hip.cast_lp_weight(_pad128(_rand(768, 768, seed=3)).cuda() * 90),
+                       None, out_dtype=torch.bfloat16, n=768)   # outputs ~ 40 * 90 * sqrt(768) = 1e5
+        assert hip.range_status() == 1 and not torch.isfinite(hip.lp_to_f32(big)).all()
+    g, b = torch.ones(768, device="cuda"), torch.zeros(768, device="cuda")
+    hip.layernorm(x, g * 1e5, b, 1e-6, want_f32=False, lp=torch.float16)
+    assert hip.range_status() == 1
+
+
+def test_f16_modes_range_error_in_a_block(hip):
+    """model level: one LayerNorm channel scaled to 1e5 makes norm1's output leave the f16 range - the block call fails with the
+    range error in both f16 modes instead of returning NaNs, and the fp32 mode still runs."""
+    from madtp_amd import runtime, vit
+    blk = vit.Block(768, 12, qkv_bias=True).cuda()
+    x = _rand(2, 50, 768, seed=1).cuda()
+    ta = _rand(2, 49, 100, seed=2).cuda()
+    with torch.no_grad():
+        blk.norm1.weight[7] = 1e5
+        for mode in ("f16x3", "f16"):
+            with runtime.precision(mode), pytest.raises(RuntimeError, match="f16 range"):
+                blk(x, False, 0, 1.0, ta.clone())
+            assert hip.range_status() == 0
+        with runtime.precision("fp32"):
+            assert torch.isfinite(blk(x, False, 0, 1.0, ta.clone())).all()
