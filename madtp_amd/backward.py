@@ -3,7 +3,7 @@ models/vit.py Block.forward (:183-207) in the reference's compression training (
 blip_nlvr.py:84-98), as hand-written gfx950 kernels behind a torch.autograd.Function.
 
 Scope of this round: ONE block, fp32 ("parity") arithmetic, gradient-checked against the reference's own .grad
-(tests/golden/vit_block_grad_b2.npz) and autograd through the CPU oracle.  PyTorch is plumbing (buffers, the autograd graph
+(tests/golden/blockgrad_b2.npz) and autograd through the CPU oracle.  PyTorch is plumbing (buffers, the autograd graph
 edge); every arithmetic op is a kernel of csrc/backward.hip or madtp_gemm:
   * dgrad  dX = dY W      -> madtp_gemm(dY, W^T)          (exact-f32 MFMA; W^T by madtp_transpose_pad)
   * wgrad  dW = dY^T X    -> madtp_gemm(dY^T, X^T)        (both operands transposed and zero-padded to 32 rows of M)

@@ -1,4 +1,4 @@
-"""Shared by the CPU oracle test and the GPU test of the block backward: rebuilds the inputs of a vit_block_grad_* fixture
+"""Shared by the CPU oracle test and the GPU test of the block backward: rebuilds the inputs of a blockgrad_* fixture
 (tools/make_golden.py::vit_block_grad_case) from the deterministic generators and the CPU oracle."""
 import numpy as np
 import torch

@@ -1,6 +1,6 @@
 """Backward of the pruned ViT block on a real MI355X (first half): the hand-written HIP backward
 (madtp_amd/backward.py + csrc/backward.hip, fp32 precision mode) against
-  * the reference's own .grad (tests/golden/vit_block_grad_*.npz, recorded from models/vit.py by tools/make_golden.py),
+  * the reference's own .grad (tests/golden/blockgrad_*.npz, recorded from models/vit.py by tools/make_golden.py),
   * autograd through the CPU oracle on the same inputs (full tensors),
 with the tolerance SURVEY/VERDICT name: 1e-3 relative to each gradient's largest entry; and the single kernels against torch."""
 import glob
@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vit_block_grad_*.npz")))
+GRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "blockgrad_*.npz")))
 
 
 @pytest.fixture(scope="module")

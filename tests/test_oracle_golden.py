@@ -537,7 +537,7 @@ def test_oracle_caption_generate_matches_reference_fixture(path):
     assert seq5.tolist() == g["sequences"].tolist()
 
 
-GRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "vit_block_grad_*.npz")))
+GRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "blockgrad_*.npz")))
 
 
 @pytest.mark.parametrize("path", GRAD_CASES, ids=[os.path.basename(c)[:-4] for c in GRAD_CASES])

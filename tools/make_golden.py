@@ -584,8 +584,8 @@ CASES = {
     "retr_384_i4_t6": lambda: retrieval_case("retr_384_i4_t6", 4, 2, 6, 384, 4.0, 3, seed=1),
     # backward of one pruned ViT block: the reference's own .grad (layer 0 at T = 5: 196 -> ~133 kept + 1 merged token; layer 3
     # at the same temperature enters with an already pruned sequence of 101 tokens; margins of every pruning decision on the way are >= 8e-5 relative, far above f32 rounding)
-    "vit_block_grad_b2": lambda: vit_block_grad_case("vit_block_grad_b2", 2, 224, 5.0, layer=0),
-    "vit_block_grad_b2_l3": lambda: vit_block_grad_case("vit_block_grad_b2_l3", 2, 224, 5.0, layer=3),
+    "blockgrad_b2": lambda: vit_block_grad_case("blockgrad_b2", 2, 224, 5.0, layer=0),
+    "blockgrad_b2_l3": lambda: vit_block_grad_case("blockgrad_b2_l3", 2, 224, 5.0, layer=3),
 }
 
 if __name__ == "__main__":
