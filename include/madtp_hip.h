@@ -441,6 +441,18 @@ typedef struct madtp_layer_io {       /* buffers and results of one layer */
 int madtp_vit_encoder(const madtp_vit_block_w* const* layers, int n_layers, const madtp_query_w* q, const float* x0,
                       madtp_layer_io* io, void* ws, size_t ws_bytes, int B, int N0, float temperature, void* stream);
 
+/* The same loop WITHOUT the per-layer host read of k (device-side lengths).  token_score leaves each
+ * layer's decision - k = max_b count, the k applied under vit.py:148-149, the next layer's token count - in a device-side record
+ * and every later kernel (top-k select, gather + norm2, the GEMMs' M, the next layer's LayerNorm / alignment logits / attention N)
+ * reads its size from there, with grids, key-tile instantiations and buffers sized for the unpruned sequence; the whole encoder
+ * is enqueued ahead and the host reads the records ONCE at the end (io[l].k_out / k_used / n_out).  Results are bit-identical to
+ * madtp_vit_encoder.  For the launch-bound regime: B * N0 < 4096 token rows and N0 <= 256 (MADTP_E_SHAPE otherwise); q and
+ * temperature > 0 are required, q->att_ft must be NULL (the caller sums att_ft after the call, when the token counts are known);
+ * dims_dev: (n_layers + 2) * 4 int32 of device scratch, dims_host: (n_layers + 1) * 4 int32 of host memory. */
+int madtp_vit_encoder_async(const madtp_vit_block_w* const* layers, int n_layers, const madtp_query_w* q, const float* x0,
+                            madtp_layer_io* io, void* ws, size_t ws_bytes, int B, int N0, float temperature, int32_t* dims_dev,
+                            int32_t* dims_host, void* stream);
+
 /* BertEncoder.forward's layer loop (med.py:509-571 / nlvr_encoder.py:600-660): query model on the hidden states, then
  * BertLayer.forward; the compacted mask and the compute-dtype copy of the output are handed from layer to layer.
  * hidden0 [B,L0,dim] f32, hidden0_lp optional compute-dtype copy, mask0 additive [B,L0] (may be NULL when temperature <= 0);

@@ -18,6 +18,7 @@
 // Roofline: MFMA f32 (157 TF) - 4*Nq*Nk*64 flops per (b,h); HBM traffic is q,k,v,out once (K/V re-reads by the
 // other query tiles of the same b hit L2).
 #include "common.h"
+#include "internal.h"
 #include <map>
 #include <mutex>
 #include <stdlib.h>
@@ -38,7 +39,15 @@ struct AttnArgs {
     // attn_bf16_large_kernel with scores and gridDim.z == 2 (two head halves per row block): exchange area of the head-max
     // [B * row blocks][2][4 waves][2 NT dwords][64 lanes] and one ticket per (row block, wave)
     unsigned* hm_ws; int* hm_tick;
+    // sync-free encoder path (self-attention): Nq = Nk = *n_dev tokens per sample, read by the kernel; the launch geometry and the
+    // key-tile instantiation are the host's worst case (the unpruned sequence)
+    const int32_t* n_dev;
 };
+#define ATTN_DEV_DIMS(a)                                   \
+    if ((a).n_dev) {                                       \
+        (a).Nq = (a).Nk = *(a).n_dev;                      \
+        (a).nrt = ((a).Nq + 15) / 16;                      \
+    }
 
 // Exchange area of the head split (one per device and stream, allocated on first use; the tickets reset themselves).
 struct HmWorkspace { unsigned* ws; int* tick; };
@@ -85,6 +94,7 @@ template <> __device__ __forceinline__ float load1<bf16_t>(const char* p) { retu
 
 template <typename T, int NT, bool SCORES>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+    ATTN_DEV_DIMS(a)
     constexpr int ESZ = sizeof(T);
     constexpr int RB = 64 * ESZ + 16;        // LDS row pitch in bytes (pad one 16-B slot)
     constexpr int CPR = 64 * ESZ / 16;       // 16-byte chunks per row
@@ -329,6 +339,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 // the lane's own eight probabilities and the B operand two transpose reads (ds_read_b64_tr_b16) of row-major V.
 template <int NT, bool SCORES>
 __global__ __launch_bounds__(256) void attn_f16s_kernel(AttnArgs a) {
+    ATTN_DEV_DIMS(a)
     constexpr int PITCH = NT <= 15 ? 160 : 144;  // bytes per 64-element f16 row (144: 2-way conflicts, what fits at 256 keys)
     constexpr int NKP = NT * 16;                 // padded key count
     constexpr int NC = (NT + 1) / 2;             // 32-key chunks of the P.V product
@@ -611,6 +622,7 @@ __device__ long long g_attn_dbg[8];
 #endif
 template <int NT, bool SCORES, int HS, int RB = 1, bool F16 = false>
 __global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void attn_bf16_kernel(AttnArgs a) {
+    ATTN_DEV_DIMS(a)
     static_assert(HS == 1 || RB == 1, "head-parity split and two row blocks are alternatives");
     constexpr int NKP = NT * 16;
     constexpr int NC = (NT + 1) / 2;          // 32-key chunks
@@ -1908,7 +1920,15 @@ extern "C" int madtp_attention(const void* q, const void* k, const void* v, void
 static int attention_launch(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
                             const float* add_mask, const float* mask_qk, int ld_mask_qk, float* colsum_part, float* p0,
                             float* onorm, int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale,
-                            int io_dtype, void* stream);
+                            int io_dtype, void* stream, const int32_t* n_dev = nullptr);
+
+int madtp_i_attention(const void* q, const void* k, const void* v, void* out, float* colsum_part, float* p0, float* onorm, int B,
+                      int H, int N, int ldq, int ldk, int ldv, int ldo, float scale, int io_dtype, const int32_t* n_dev,
+                      void* stream) {
+    if (N > 256) return MADTP_E_SHAPE;  // the two-pass long-sequence kernels keep host-side lengths
+    return attention_launch(q, k, v, nullptr, out, nullptr, nullptr, 0, colsum_part, p0, onorm, B, H, N, N, ldq, ldk, ldv, ldo, scale,
+                            io_dtype, stream, n_dev);
+}
 
 extern "C" int madtp_attention_indexed(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
                                        const float* add_mask, float* colsum_part, float* p0, float* onorm, int B, int H,
@@ -1930,7 +1950,7 @@ extern "C" int madtp_attention_qk_mask(const void* q, const void* k, const void*
 static int attention_launch(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
                             const float* add_mask, const float* mask_qk, int ld_mask_qk, float* colsum_part, float* p0,
                             float* onorm, int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale,
-                            int io_dtype, void* stream) {
+                            int io_dtype, void* stream, const int32_t* n_dev) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
     if (kv_batch_index && colsum_part) return MADTP_E_BADARG;  // indexed K/V is a cross-attention feature
     // io_dtype MADTP_F16S: f32 storage, products as three f16 MFMA products of f16-split operands (the f16x3 precision mode)
@@ -1957,6 +1977,7 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
     a.kvidx = kv_batch_index;
     a.pair = 0; a.q2 = a.k2 = a.v2 = nullptr; a.out2 = nullptr; a.mask2 = nullptr; a.hm_ws = nullptr; a.hm_tick = nullptr;
     a.mask_qk = mask_qk; a.ld_mqk = ld_mask_qk;
+    a.n_dev = n_dev;
     hipStream_t s = (hipStream_t)stream;
     const bool scores = colsum_part != nullptr;
     if (Nk > 256) {  // long sequences (384^2 / 480^2 images): two-pass kernels
@@ -1973,7 +1994,7 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
         return scores ? dispatch_nt_f16s<true>(a, s) : dispatch_nt_f16s<false>(a, s);
     if (io_dtype == MADTP_F32) return scores ? dispatch_nt<float, true>(a, s) : dispatch_nt<float, false>(a, s);
     if ((ldk * 2) % 16 || (ldv * 2) % 16) return MADTP_E_ALIGN;
-    if (scores && Nk <= 32 && !mask_qk) {  // short text sequences: one sample per workgroup, heads spread over the waves
+    if (scores && Nk <= 32 && !mask_qk && !n_dev) {  // short text sequences: one sample per workgroup, heads spread over the waves
         if (f16) hipLaunchKernelGGL(attn_bf16_small_kernel<true>, dim3(B), dim3(64 * SMALL_NW), 0, s, a);
         else hipLaunchKernelGGL(attn_bf16_small_kernel<false>, dim3(B), dim3(64 * SMALL_NW), 0, s, a);
         MADTP_LAUNCH_CHECK();
@@ -2007,7 +2028,7 @@ extern "C" int madtp_attention_pair(const void* q0, const void* q1, const void* 
     a.q = (const char*)q0; a.k = (const char*)k0; a.v = (const char*)v0; a.out = (char*)out0; a.mask = add_mask0;
     a.q2 = (const char*)q1; a.k2 = (const char*)k1; a.v2 = (const char*)v1; a.out2 = (char*)out1; a.mask2 = add_mask1;
     a.pair = 1;
-    a.mask_qk = nullptr; a.ld_mqk = 0; a.hm_ws = nullptr; a.hm_tick = nullptr;
+    a.mask_qk = nullptr; a.ld_mqk = 0; a.hm_ws = nullptr; a.hm_tick = nullptr; a.n_dev = nullptr;
     a.colsum = nullptr; a.p0 = nullptr; a.onorm = nullptr;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.nrt = (Nq + 15) / 16;

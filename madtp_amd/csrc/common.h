@@ -204,6 +204,22 @@ __device__ __forceinline__ float row16_sum(float v) {
         }                                                                                                                    \
     } while (0)
 
+// ---- device-side token counts (the sync-free encoder path; layers.hip madtp_vit_encoder_async) --------
+// A kernel that takes a DevN reads the size it names from DEVICE memory when p != nullptr: value = mul * p[0] + add, written by an
+// earlier kernel of the same stream (token_score publishes the layer's k and the next layer's token count).  Launch geometry and
+// buffers are sized by the host for the worst case (the unpruned sequence); workgroups past the actual size exit or idle.
+struct DevN { const int32_t* p; int mul, add; };
+__host__ __device__ __forceinline__ int devn(const DevN& d, int host_value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return d.p ? d.mul * *d.p + d.add : host_value;
+#else
+    return host_value;
+#endif
+}
+// per-layer record of the device-side pruning decision: dims[l] = {tokens per sample entering layer l, k = max_b count of the
+// layer, k applied (0 = not pruned), tokens per sample leaving it}
+constexpr int DIMS_STRIDE = 4;
+
 #define MADTP_LAUNCH_CHECK()                          \
     do {                                              \
         hipError_t e__ = hipGetLastError();           \

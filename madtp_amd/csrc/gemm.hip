@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "gemm_device.h"
+#include "internal.h"
 
 namespace {
 
@@ -38,6 +39,10 @@ __global__ __launch_bounds__(NTHREADS, (BM + BN) * ROWB * STAGES <= 65536 ? 2 : 
     constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int PER = (BM + BN) / 32;                // LDS-DMA instructions per wave per slab
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (g.m_dev) {  // device-side row count: the grid was sized for the host's (worst-case) M
+        g.M = g.m_mul * *g.m_dev;
+        g.ntm = (g.M + BM - 1) / BM;
+    }
 
     // Persistent, XCD-aware tile schedule: block b runs on XCD b%8 (observed dispatch rule; only speed depends on
     // it); XCD x owns the tile range of xcd_tiles() and its workgroups walk it round-robin.
@@ -959,7 +964,7 @@ constexpr int PAIR_UNSUPPORTED = 1000;  // internal: this shape does not run on 
 
 static int gemm_launch(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
                        int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float acc_scale, float out_scale,
-                       int splitk, void* stream, const GemmPair* pair = nullptr);
+                       int splitk, void* stream, const GemmPair* pair = nullptr, DevN m_dev = DevN{nullptr, 0, 0});
 
 // Workgroups per XCD of the two big-GEMM kernels (default 32 = one persistent workgroup per CU walking its share of the tiles).
 // A larger cap gives every workgroup fewer tiles (>= tiles / 8: one tile each) - the launch then frees CUs tile by tile, which
@@ -1111,9 +1116,15 @@ static float ws_cost(int t256, int nk, bool sk) {
     return (float)rounds + (parts ? 0.65f : 1.0f);
 }
 
+int madtp_i_gemm(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K, int lda, int ldw,
+                 int ldc, int ldr, int ab_dtype, int c_dtype, int act, float acc_scale, float out_scale, DevN m_dev, void* stream) {
+    return gemm_launch(A, W, bias, residual, C, M, N, K, lda, ldw, ldc, ldr, ab_dtype, c_dtype, act, acc_scale, out_scale, 1, stream, nullptr,
+                       m_dev);
+}
+
 static int gemm_launch(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
                        int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float acc_scale, float out_scale,
-                       int splitk, void* stream, const GemmPair* pair) {
+                       int splitk, void* stream, const GemmPair* pair, DevN m_dev) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return MADTP_E_BADARG;
     if (ab_dtype != MADTP_F32 && ab_dtype != MADTP_BF16 && ab_dtype != MADTP_F16S && ab_dtype != MADTP_F16) return MADTP_E_DTYPE;
     if (c_dtype != MADTP_F32 && c_dtype != MADTP_BF16 && c_dtype != MADTP_F16S && c_dtype != MADTP_F16) return MADTP_E_DTYPE;
@@ -1142,6 +1153,8 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     g.ngrp = 0;
     g.pair = 0; g.A2 = g.W2 = nullptr; g.bias2 = nullptr; g.C2 = nullptr;
     g.sk = 0; g.sk_ws = nullptr; g.sk_tick = nullptr;
+    g.m_dev = m_dev.p; g.m_mul = m_dev.mul;
+    if (m_dev.p && (M >= 4096 || pair || splitk != 1)) return MADTP_E_SHAPE;  // device-side M: the small-tile kernels only
     {
         static int desc_env = -1;  // MADTP_GEMM_DESC=0: gemm_kernel builds its LDS-DMA addresses per instruction (A/B runs)
         if (desc_env < 0) { const char* e = getenv("MADTP_GEMM_DESC"); desc_env = e ? atoi(e) : 1; }

@@ -23,6 +23,7 @@ struct GemmArgs {
     float* sk_ws; int* sk_tick; int sk;
     int desc;  // gemm_kernel: both operands fit a 32-bit buffer descriptor -> descriptor-based LDS-DMA (no per-slab address arithmetic)
     int* range_flag;  // f16 outputs (OM_F16S / OM_F16): the pinned range flag (common.h), else unused
+    const int32_t* m_dev; int m_mul;  // gemm_kernel: M = m_mul * *m_dev, read by the kernel (sync-free encoder path, common.h DevN)
 };
 struct F16P { unsigned short bits; };  // operand tag of gemm_kernel<>: plain f16 elements (MADTP_F16) on the f16 MFMA
 

@@ -1,0 +1,31 @@
+// Library-internal launchers shared between the translation units (hidden visibility: not part of the C-ABI).  The *_i_* forms are
+// the public entry points plus a DevN (common.h): a size read from device memory by the kernel itself - the sync-free encoder path.
+#pragma once
+#include "common.h"
+
+#define MADTP_INTERNAL __attribute__((visibility("hidden")))
+
+MADTP_INTERNAL int madtp_i_layernorm(const float* x, const float* gamma, const float* beta, float* y32, void* ylp, int lp_dtype,
+                                     int rows, int dim, float eps, DevN rows_dev, void* stream);
+MADTP_INTERNAL int madtp_i_split_f16(const float* src, int ld_src, void* dst, int ld_dst, int rows, int K, DevN rows_dev, void* stream);
+// madtp_gemm with M = m_dev (small-tile kernels only: the worst-case M must stay below 4096 rows)
+MADTP_INTERNAL int madtp_i_gemm(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
+                                int lda, int ldw, int ldc, int ldr, int ab_dtype, int c_dtype, int act, float acc_scale,
+                                float out_scale, DevN m_dev, void* stream);
+// madtp_attention (self-attention with the score side outputs) with Nq = Nk = n_dev tokens per sample
+MADTP_INTERNAL int madtp_i_attention(const void* q, const void* k, const void* v, void* out, float* colsum_part, float* p0,
+                                     float* onorm, int B, int H, int N, int ldq, int ldk, int ldv, int ldo, float scale,
+                                     int io_dtype, const int32_t* n_dev, void* stream);
+// token_score on n_dev tokens (token_attn = rows 1.. of a [B * n, ldt] logits buffer: batch stride n * ldt); the last workgroup
+// writes the layer's decision to dims_l[1..3] and the next layer's token count to dims_l[DIMS_STRIDE] (BLIP rule vit.py:148-149)
+MADTP_INTERNAL int madtp_i_token_score_dev(const float* colsum_part, const float* p0, const float* onorm, const float* logits, int ldt,
+                                           int K, float temperature, float* score, float* threshold, int32_t* count, int B, int H,
+                                           int N_max, int32_t* dims_l, int32_t* ticket, void* stream);
+// token_select / token_gather_ln with n, k (k == 0: identity - nothing is pruned, the gather copies every token) from dims_l
+MADTP_INTERNAL int madtp_i_token_select_dev(const float* score, int64_t* indices, int64_t* indices_sort, int32_t* dst_pos,
+                                            float* merge_w, int B, int n_max, const int32_t* dims_l, void* stream);
+MADTP_INTERNAL int madtp_i_token_gather_ln_dev(const float* x, const int32_t* dst_pos, const float* merge_w, float* y, int B, int N_max,
+                                               int dim, const float* gamma, const float* beta, float eps, float* h32, void* h_lp,
+                                               int lp_dtype, const int32_t* dims_l, void* stream);
+MADTP_INTERNAL int madtp_i_align_logits(const float* x, const void* sd_hi, const void* sd_lo, float* out, int M, int dim, int split_dtype,
+                                        float out_scale, DevN m_dev, void* stream);

@@ -5,6 +5,7 @@
 // return.  The only host<->device round trip of a layer stays where the reference has it: the read-back of
 // k = max_b count between the two halves (vit.py:145 `.item()`).
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -581,6 +582,86 @@ extern "C" int madtp_vit_encoder(const madtp_vit_block_w* const* layers, int n_l
         x = o.y;
     }
     return 0;
+}
+
+// VisionTransformer.forward's block loop WITHOUT the per-layer host read of k (include/madtp_hip.h):
+// token_score's last workgroup leaves the layer's decision in a device-side record (dims[l] = {N_l, k, k applied, N_{l+1}}) and
+// every later kernel of the stream - top-k select, gather + norm2, the MLP GEMMs' M, the next layer's LayerNorm / alignment
+// logits / qkv GEMM / attention - reads its size from there; grids, key-tile instantiations and buffers are the unpruned case's.
+// The arithmetic per element is that of the per-layer path (same kernels, same k order, same reduction trees).
+static int lin_dev(const void* a, int lda, const madtp_lin& L, const float* residual, int ldr, void* c, int ldc, int M_max, int dt,
+                   int c_dt, int act, DevN m, void* stream) {
+    return madtp_i_gemm(a, L.w, L.b, residual, c, M_max, L.n, L.k, pld(dt, lda), (dt == MADTP_F16S ? 2 : 1) * L.k, pld(c_dt, ldc), ldr, dt,
+                        c_dt, act, L.w_scale, 1.f, m, stream);
+}
+
+extern "C" int madtp_vit_encoder_async(const madtp_vit_block_w* const* layers, int n_layers, const madtp_query_w* q, const float* x0,
+                                       madtp_layer_io* io, void* ws, size_t ws_bytes, int B, int N0, float temperature,
+                                       int32_t* dims_dev, int32_t* dims_host, void* stream) {
+    if (!layers || !io || !x0 || !q || !dims_dev || !dims_host || n_layers <= 0 || B <= 0 || N0 < 3) return MADTP_E_BADARG;
+    if (!(temperature > 0.f) || q->att_ft) return MADTP_E_BADARG;  // (att_ft: the caller's deferred sum, after this call)
+    if ((long)B * N0 >= 4096 || N0 > 256) return MADTP_E_SHAPE;   // small-tile GEMMs and the <= 256-key attention kernels only
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nrec = (size_t)(n_layers + 1) * DIMS_STRIDE;
+    int32_t* ticket = dims_dev + nrec;  // token_score's arrival counter (resets itself)
+    hipError_t he = hipMemsetAsync(dims_dev, 0, (nrec + 4) * sizeof(int32_t), s);
+    if (he == hipSuccess) he = hipMemsetD32Async((hipDeviceptr_t)dims_dev, N0, 1, s);
+    if (he != hipSuccess) return (int)he;
+    const int kp = (q->K + 127) / 128 * 128;
+    const bool split = q->sd_hi && q->sd_lo;
+    if (split && kp != 128) return MADTP_E_SHAPE;
+    const float* x = x0;
+    const int Mmax = B * N0;
+    for (int l = 0; l < n_layers; ++l) {
+        madtp_layer_io& o = io[l];
+        const madtp_vit_block_w* w = layers[l];
+        if (!w || !o.x_attn || !o.y || !o.logits || !o.score || !o.threshold || !o.count || !o.indices || !o.indices_sort || w->attn_mask)
+            return MADTP_E_BADARG;
+        bool ok;
+        VitWs v = vit_carve((char*)ws, ws_bytes, B, N0, w->dim, w->fc1.n, w->heads, w->dtype, &ok);
+        if (!ok) return MADTP_E_SHAPE;
+        const int D = w->dim, dt = w->dtype, adt = attn_dt(dt);
+        const size_t e = esz_of(adt);
+        int32_t* dl = dims_dev + (size_t)l * DIMS_STRIDE;
+        const DevN m_in{dl, B, 0}, m_out{dl + DIMS_STRIDE, B, 0};
+        // query model (models/utils.py:170): logits of all rows of x
+        if (split) TRY(madtp_i_align_logits(x, q->sd_hi, q->sd_lo, o.logits, Mmax, D, q->split_dtype, q->sd_scale, m_in, stream));
+        else TRY(madtp_i_gemm(x, q->sd_w, nullptr, nullptr, o.logits, Mmax, kp, D, D, D, kp, 0, MADTP_F32, MADTP_F32, MADTP_ACT_NONE, 1.f,
+                              1.f, m_in, stream));
+        // attention half (vit_attn_impl)
+        if (dt == MADTP_F32) TRY(madtp_i_layernorm(x, w->ln1_g, w->ln1_b, (float*)v.h, nullptr, MADTP_BF16, Mmax, D, w->eps, m_in, stream));
+        else TRY(madtp_i_layernorm(x, w->ln1_g, w->ln1_b, nullptr, v.h, dt, Mmax, D, w->eps, m_in, stream));
+        TRY(lin_dev(v.h, D, w->qkv, nullptr, 0, v.qkv, 3 * D, Mmax, dt, adt, MADTP_ACT_NONE, m_in, stream));
+        const char* qp = (const char*)v.qkv;
+        TRY(madtp_i_attention(qp, qp + (size_t)D * e, qp + (size_t)2 * D * e, v.o, v.colsum, v.p0, v.onorm, B, w->heads, N0, 3 * D, 3 * D,
+                              3 * D, D, w->scale, attn_io(dt), dl, stream));
+        void* attn_o = v.o;
+        if (dt == MADTP_F16S) {
+            TRY(madtp_i_split_f16((const float*)v.o, D, v.h, 2 * D, Mmax, D, m_in, stream));
+            attn_o = v.h;
+        }
+        TRY(madtp_i_token_score_dev(v.colsum, v.p0, v.onorm, o.logits, kp, q->K, temperature, o.score, o.threshold, o.count, B, w->heads,
+                                    N0, dl, ticket, stream));
+        TRY(lin_dev(attn_o, D, w->proj, x, D, o.x_attn, D, Mmax, dt, MADTP_F32, MADTP_ACT_NONE, m_in, stream));
+        // pruning + MLP half (madtp_vit_block_mlp); a layer that is not pruned runs the gather as a copy (+ norm2)
+        TRY(madtp_i_token_select_dev(o.score, o.indices, o.indices_sort, v.dst_pos, v.merge_w, B, N0 - 1, dl, stream));
+        TRY(madtp_i_token_gather_ln_dev(o.x_attn, v.dst_pos, v.merge_w, v.xp, B, N0, D, w->ln2_g, w->ln2_b, w->eps,
+                                        dt == MADTP_F32 ? (float*)v.h : nullptr, dt == MADTP_F32 ? nullptr : v.h, dt, dl, stream));
+        TRY(lin_dev(v.h, D, w->fc1, nullptr, 0, v.mid, w->fc1.n, Mmax, dt, dt, w->act, m_out, stream));
+        TRY(lin_dev(v.mid, w->fc1.n, w->fc2, v.xp, D, o.y, D, Mmax, dt, MADTP_F32, MADTP_ACT_NONE, m_out, stream));
+        x = o.y;
+    }
+    // the ONE host read of the call: every layer's decision, for the output shapes and the layers' pruning records
+    he = hipMemcpyAsync(dims_host, dims_dev, nrec * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (he == hipSuccess) he = hipStreamSynchronize(s);
+    if (he != hipSuccess) return (int)he;
+    for (int l = 0; l < n_layers; ++l) {
+        io[l].k_out = dims_host[l * DIMS_STRIDE + 1];
+        io[l].k_used = dims_host[l * DIMS_STRIDE + 2];
+        io[l].n_out = dims_host[l * DIMS_STRIDE + 3];
+    }
+    const int* rf = madtp_internal_range_flag();
+    return (rf && *(const volatile int*)rf) ? MADTP_E_RANGE : 0;
 }
 
 extern "C" int madtp_bert_encoder(const madtp_bert_layer_w* const* layers, int n_layers, const madtp_query_w* q, const float* hidden0,

@@ -3,6 +3,7 @@
 // of a row and consecutive waves cover consecutive rows (fully coalesced).  Roofline: HBM bandwidth,
 // algorithmic bytes per row = dim*4 read + dim*(4 and/or 2) written.
 #include "common.h"
+#include "internal.h"
 #include <type_traits>
 
 namespace {
@@ -10,9 +11,10 @@ struct F16Plain { unsigned short bits; };  // element tag: plain f16 (MADTP_F16)
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* y32, bf16_t* ylp,
-                                                        int lp_fmt, int* range_flag, int rows, int dim, float eps) {
+                                                        int lp_fmt, int* range_flag, int rows_h, int dim, float eps, DevN rows_dev) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rows = devn(rows_dev, rows_h);
     if (row >= rows) return;
     const float* xr = x + (size_t)row * dim;
     const LnParams prm = ln_params(gamma, beta, lane, dim);
@@ -152,8 +154,9 @@ __global__ __launch_bounds__(256) void add_scale_kernel(const float* __restrict_
 
 // f32 [rows, K] -> f16-split activation planes [rows, 2K]; one thread per 4 consecutive columns
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ src, int ld_src, _Float16* __restrict__ dst,
-                                                        int ld_dst, int K4, size_t total4, int* range_flag) {
+                                                        int ld_dst, int K4, size_t total4_h, int* range_flag, DevN rows_dev) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total4 = rows_dev.p ? (size_t)devn(rows_dev, 0) * K4 : total4_h;
     if (i >= total4) return;
     const size_t row = i / K4;
     const int col = (int)(i - row * K4) * 4;
@@ -238,13 +241,17 @@ extern "C" int madtp_range_status(int reset, void* stream) {
 
 extern "C" int madtp_layernorm(const float* x, const float* gamma, const float* beta, float* y32, void* ylp, int lp_dtype,
                                int rows, int dim, float eps, void* stream) {
+    return madtp_i_layernorm(x, gamma, beta, y32, ylp, lp_dtype, rows, dim, eps, DevN{nullptr, 0, 0}, stream);
+}
+int madtp_i_layernorm(const float* x, const float* gamma, const float* beta, float* y32, void* ylp, int lp_dtype, int rows, int dim,
+                      float eps, DevN rows_dev, void* stream) {
     if (!x || !gamma || !beta || (!y32 && !ylp) || rows <= 0 || dim <= 0) return MADTP_E_BADARG;
     if (ylp && !lp_dtype_ok(lp_dtype)) return MADTP_E_DTYPE;
     if (dim % 4 || dim > 256 * LN_MAX_CHUNKS) return MADTP_E_SHAPE;
     if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || (y32 && !aligned16(y32)) || (ylp && ((uintptr_t)ylp & 7)))
         return MADTP_E_ALIGN;
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y32,
-                       (bf16_t*)ylp, lp_dtype, madtp_internal_range_flag(), rows, dim, eps);
+                       (bf16_t*)ylp, lp_dtype, madtp_internal_range_flag(), rows, dim, eps, rows_dev);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
@@ -337,12 +344,15 @@ extern "C" int madtp_cast_bf16(const float* src, void* dst, size_t n, void* stre
 }
 
 extern "C" int madtp_split_f16(const float* src, int ld_src, void* dst, int ld_dst, int rows, int K, void* stream) {
+    return madtp_i_split_f16(src, ld_src, dst, ld_dst, rows, K, DevN{nullptr, 0, 0}, stream);
+}
+int madtp_i_split_f16(const float* src, int ld_src, void* dst, int ld_dst, int rows, int K, DevN rows_dev, void* stream) {
     if (!src || !dst || rows <= 0 || K <= 0) return MADTP_E_BADARG;
     if (K % 4 || ld_src < K || ld_dst < 2 * K) return MADTP_E_SHAPE;
     if (!aligned16(src) || ld_src % 4 || ((uintptr_t)dst & 7) || ld_dst % 4) return MADTP_E_ALIGN;
     const size_t total4 = (size_t)rows * (K / 4);
     hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
-                       (_Float16*)dst, ld_dst, K / 4, total4, madtp_internal_range_flag());
+                       (_Float16*)dst, ld_dst, K / 4, total4, madtp_internal_range_flag(), rows_dev);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
@@ -358,7 +368,7 @@ extern "C" int madtp_split_f16_weight(const float* w, int ldw, void* dst, int n,
     return 0;
 }
 
-extern "C" int madtp_abi_version(void) { return 16; }
+extern "C" int madtp_abi_version(void) { return 17; }
 
 extern "C" const char* madtp_strerror(int code) {
     switch (code) {

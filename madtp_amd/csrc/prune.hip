@@ -8,6 +8,7 @@
 // coalesced row reads, wave shuffle reductions, ballot/popcount prefix sums, fixed reduction orders (no float
 // atomics, so results are run-to-run deterministic and independent of workgroup placement).
 #include "common.h"
+#include "internal.h"
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
@@ -60,7 +61,13 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
                                                           const float* __restrict__ ta, int ldt_g, int ldb, int K, float temperature,
                                                           float* __restrict__ score, float* __restrict__ threshold,
                                                           int32_t* __restrict__ count, int32_t* __restrict__ kmax, int H,
-                                                          int N, int32_t* done_ctr, int32_t* host_slot, int seq) {
+                                                          int N, int32_t* done_ctr, int32_t* host_slot, int seq,
+                                                          int32_t* dims_l = nullptr) {
+    if (dims_l) {  // sync-free encoder path: the token count comes from the device-side record of this layer (common.h DevN)
+        N = dims_l[0];
+        nrt = (N + 15) / 16;
+        ldb = N * ldt_g;  // token_attn = rows 1.. of each sample of a dense [B * N, ldt] logits buffer
+    }
     __shared__ float I_s[MAXN];
     __shared__ int last_s;
     __shared__ float tw_s[MAXN];
@@ -244,8 +251,19 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     const int kk = (int)block_max_f((float)mloc, red, tid, 8);  // exact: counts <= 1024
     if (tid == 0) {
         *done_ctr = 0;
-        __hip_atomic_store(host_slot, kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(host_slot + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (dims_l) {
+            // the layer's decision stays on the device: k, the k applied under the BLIP rule (vit.py:148-149: no pruning when
+            // k < 1 or N - 1 - k <= 1) and the next layer's token count; later kernels of the stream read them (kernel boundary)
+            const int k_used = (kk < 1 || (N - 1 - kk) <= 1) ? 0 : kk;
+            dims_l[1] = kk;
+            dims_l[2] = k_used;
+            dims_l[3] = k_used ? k_used + 2 : N;
+            dims_l[DIMS_STRIDE] = k_used ? k_used + 2 : N;
+        }
+        if (host_slot) {
+            __hip_atomic_store(host_slot, kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_slot + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -432,7 +450,12 @@ __global__ __launch_bounds__(512) void token_score_split_kernel(const float* __r
 template <int NTHR>
 __global__ __launch_bounds__(NTHR) void token_select_kernel(const float* __restrict__ score, int k,
                                                             int64_t* __restrict__ indices, int64_t* __restrict__ indices_sort,
-                                                            int32_t* __restrict__ dst_pos, float* __restrict__ merge_w, int n) {
+                                                            int32_t* __restrict__ dst_pos, float* __restrict__ merge_w, int n,
+                                                            const int32_t* dims_l = nullptr) {
+    // sync-free encoder path: n and k from the layer's device-side record; k == 0 there means "not pruned" (vit.py:148-149): the
+    // kernel then writes the identity map (every token kept in place, no merge weights) for the gather that follows
+    bool ident = false;
+    if (dims_l) { n = dims_l[0] - 1; k = dims_l[2]; ident = k == 0; }
     constexpr int NW = NTHR / 64;
     __shared__ float s[MAXN];
     __shared__ unsigned key_s[MAXN];
@@ -474,7 +497,7 @@ __global__ __launch_bounds__(NTHR) void token_select_kernel(const float* __restr
     // stable compaction of kept tokens in ascending token order: ballot + popcount prefix per wave, serial over chunks
     for (int c0 = 0; c0 < n; c0 += NTHR) {
         const int t = c0 + tid;
-        const bool keep = t < n && rank_s[t] < k;
+        const bool keep = t < n && (ident || rank_s[t] < k);
         const unsigned long long bal = __ballot(keep);
         const int before = __popcll(bal & ((1ull << lane) - 1ull));
         if (lane == 0) wsum[wave] = __popcll(bal);
@@ -483,7 +506,7 @@ __global__ __launch_bounds__(NTHR) void token_select_kernel(const float* __restr
         for (int w = 0; w < wave; ++w) off += wsum[w];
         if (t < n) {
             if (keep) {
-                indices[(size_t)b * k + off + before] = t;
+                if (!ident) indices[(size_t)b * k + off + before] = t;
                 dst_pos[(size_t)b * n + t] = off + before;
                 merge_w[(size_t)b * n + t] = 0.f;
             } else {
@@ -512,10 +535,12 @@ __global__ __launch_bounds__(256) void token_gather_kernel(const float* __restri
                                                            const float* __restrict__ merge_w, float* __restrict__ y, int N,
                                                            int k, int dim4, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float* h32, bf16_t* hlp,
-                                                           int lp_fmt, int* range_flag) {
+                                                           int lp_fmt, int* range_flag, const int32_t* dims_l = nullptr) {
     __shared__ float4 part[4][256];  // dim <= 1024
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, n = N - 1, No = k + 2, dim = dim4 * 4;
+    bool ident = false;  // sync-free encoder path: N, k from the device-side record; k == 0: not pruned, every token is copied
+    if (dims_l) { N = dims_l[0]; k = dims_l[2]; ident = k == 0; }
+    const int b = blockIdx.y, n = N - 1, No = ident ? N : k + 2, dim = dim4 * 4;
     const float4* xb = (const float4*)x + (size_t)b * N * dim4;
     float4* yb = (float4*)y + (size_t)b * No * dim4;
     const bool ln = gamma != nullptr;
@@ -562,7 +587,7 @@ __global__ __launch_bounds__(256) void token_gather_kernel(const float* __restri
                 if (ln) ln_out(v[i & 1], nch, dsts[i]);
             }
         }
-    } else {
+    } else if (!ident) {
         // Merged token: wave w sums its dropped tokens t = w, w+4, .. in increasing order (the association of the result is fixed
         // by that).  The straightforward loop was a chain of dependent loads per token (weight / position, then the row): ~1 us
         // per token, 49 (224 at 901 tokens) iterations per wave - the longest workgroup of the launch.  Now each wave first
@@ -1111,8 +1136,10 @@ constexpr int AL_ROWB = 128, AL_TILE = 128 * AL_ROWB, AL_STAGES = 3;
 template <int NK>
 __global__ __launch_bounds__(256, 1) void align_logits_kernel(const float* __restrict__ x, const char* __restrict__ sd_hi,
                                                               const char* __restrict__ sd_lo, float* __restrict__ out, int M,
-                                                              int dim) {
+                                                              int dim, DevN m_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // AL_STAGES x (hi tile, lo tile) = 96 KiB
+    M = devn(m_dev, M);
+    if ((int)blockIdx.x * 64 >= M) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, g = lane >> 4;
@@ -1247,8 +1274,10 @@ constexpr int AW_XT = 64 * 256, AW_STAGE = AW_XT + 2 * AL_TILE;  // 16 KiB + 2 x
 template <bool F16>
 __global__ __launch_bounds__(768, 1) void align_ws_kernel(const float* __restrict__ x, const char* __restrict__ sd_hi,
                                                           const char* __restrict__ sd_lo, float* __restrict__ out, int M, int dim,
-                                                          float out_scale) {
+                                                          float out_scale, DevN m_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    M = devn(m_dev, M);
+    if ((int)blockIdx.x * 64 >= M) return;
     constexpr int STAGES = 3, PER = 12;  // 48 one-KiB DMA instructions per slab, 12 per loader wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1585,6 +1614,54 @@ extern "C" int madtp_debug_read_ts(long long* out) {
 }
 #endif
 
+// ---- sync-free encoder path (internal.h): the same kernels with their sizes read from the layer's device-side record ----
+int madtp_i_token_score_dev(const float* colsum_part, const float* p0, const float* onorm, const float* logits, int ldt, int K,
+                            float temperature, float* score, float* threshold, int32_t* count, int B, int H, int N_max,
+                            int32_t* dims_l, int32_t* ticket, void* stream) {
+    if (!colsum_part || !p0 || !onorm || !logits || !score || !threshold || !count || !dims_l || !ticket) return MADTP_E_BADARG;
+    if (B <= 0 || H <= 0 || N_max < 2 || !(temperature > 0.f)) return MADTP_E_BADARG;
+    if (N_max - 1 > MAXN || K > 128 || K <= 0 || ldt < K) return MADTP_E_SHAPE;
+    const size_t stage_bytes = (size_t)(N_max - 1) * K * sizeof(float);
+    const bool staged = K % 4 == 0 && ldt % 4 == 0 && aligned16(logits) && stage_bytes <= 140 * 1024;
+    const float* ta = logits + ldt;  // row 0 of every sample is the CLS token
+    if (staged) {  // (the same kernel variant as the host-side path takes at any n <= N_max - 1: same arithmetic)
+        MADTP_ENSURE_MAX_LDS(token_score_kernel<true>, 140 * 1024);
+        hipLaunchKernelGGL(token_score_kernel<true>, dim3(B), dim3(512), stage_bytes, (hipStream_t)stream, colsum_part,
+                           (N_max + 15) / 16, p0, onorm, ta, ldt, N_max * ldt, K, temperature, score, threshold, count,
+                           (int32_t*)nullptr, H, N_max, ticket, (int32_t*)nullptr, 0, dims_l);
+    } else {
+        hipLaunchKernelGGL(token_score_kernel<false>, dim3(B), dim3(512), 0, (hipStream_t)stream, colsum_part, (N_max + 15) / 16, p0,
+                           onorm, ta, ldt, N_max * ldt, K, temperature, score, threshold, count, (int32_t*)nullptr, H, N_max, ticket,
+                           (int32_t*)nullptr, 0, dims_l);
+    }
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+int madtp_i_token_select_dev(const float* score, int64_t* indices, int64_t* indices_sort, int32_t* dst_pos, float* merge_w, int B,
+                             int n_max, const int32_t* dims_l, void* stream) {
+    if (!score || !indices || !indices_sort || !dst_pos || !merge_w || !dims_l || B <= 0 || n_max <= 0) return MADTP_E_BADARG;
+    if (n_max > 320) return MADTP_E_SHAPE;  // (the 1024-thread variant of long sequences keeps host-side sizes)
+    hipLaunchKernelGGL(token_select_kernel<256>, dim3(B), dim3(256), 0, (hipStream_t)stream, score, 0, indices, indices_sort, dst_pos,
+                       merge_w, n_max, dims_l);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+int madtp_i_token_gather_ln_dev(const float* x, const int32_t* dst_pos, const float* merge_w, float* y, int B, int N_max, int dim,
+                                const float* gamma, const float* beta, float eps, float* h32, void* h_lp, int lp_dtype,
+                                const int32_t* dims_l, void* stream) {
+    if (h_lp && lp_dtype != MADTP_BF16 && lp_dtype != MADTP_F16S && lp_dtype != MADTP_F16) return MADTP_E_DTYPE;
+    if (!x || !dst_pos || !merge_w || !y || !dims_l || B <= 0 || N_max < 2) return MADTP_E_BADARG;
+    if (gamma && (!beta || (!h32 && !h_lp))) return MADTP_E_BADARG;
+    if (dim % 4 || dim > 1024) return MADTP_E_SHAPE;
+    const int chunks = (N_max + GATHER_ROWS - 1) / GATHER_ROWS;
+    hipLaunchKernelGGL(token_gather_kernel, dim3(chunks + 1, B), dim3(256), 0, (hipStream_t)stream, x, dst_pos, merge_w, y, N_max, 0,
+                       dim / 4, gamma, beta, eps, h32, (bf16_t*)h_lp, lp_dtype, madtp_internal_range_flag(), dims_l);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int madtp_token_select(const float* score, int k, int64_t* indices, int64_t* indices_sort, int32_t* dst_pos,
                                   float* merge_w, int B, int n, void* stream) {
     if (!score || !indices || !indices_sort || !dst_pos || !merge_w || B <= 0 || n <= 0) return MADTP_E_BADARG;
@@ -1723,6 +1800,10 @@ extern "C" int madtp_vector_gather(const float* vectors, const int64_t* indices,
 
 extern "C" int madtp_align_logits(const float* x, const void* sd_hi, const void* sd_lo, float* out, int M, int dim,
                                   int split_dtype, float out_scale, void* stream) {
+    return madtp_i_align_logits(x, sd_hi, sd_lo, out, M, dim, split_dtype, out_scale, DevN{nullptr, 0, 0}, stream);
+}
+int madtp_i_align_logits(const float* x, const void* sd_hi, const void* sd_lo, float* out, int M, int dim, int split_dtype,
+                         float out_scale, DevN m_dev, void* stream) {
     if (!x || !sd_hi || !sd_lo || !out || M <= 0) return MADTP_E_BADARG;
     if (split_dtype != MADTP_BF16 && split_dtype != MADTP_F16S) return MADTP_E_DTYPE;
     if (dim % 128) return MADTP_E_SHAPE;
@@ -1738,16 +1819,16 @@ extern "C" int madtp_align_logits(const float* x, const void* sd_hi, const void*
         MADTP_ENSURE_MAX_LDS(align_ws_kernel<true>, 3 * AW_STAGE);
         if (split_dtype == MADTP_F16S)
             hipLaunchKernelGGL(align_ws_kernel<true>, dim3((M + 63) / 64), dim3(768), 3 * AW_STAGE, (hipStream_t)stream, x,
-                               (const char*)sd_hi, (const char*)sd_lo, out, M, dim, out_scale);
+                               (const char*)sd_hi, (const char*)sd_lo, out, M, dim, out_scale, m_dev);
         else
             hipLaunchKernelGGL(align_ws_kernel<false>, dim3((M + 63) / 64), dim3(768), 3 * AW_STAGE, (hipStream_t)stream, x,
-                               (const char*)sd_hi, (const char*)sd_lo, out, M, dim, 1.f);
+                               (const char*)sd_hi, (const char*)sd_lo, out, M, dim, 1.f, m_dev);
         MADTP_LAUNCH_CHECK();
         return 0;
     }
     auto kern = dim == 768 ? align_logits_kernel<12> : dim == 512 ? align_logits_kernel<8> : align_logits_kernel<0>;
     hipLaunchKernelGGL(kern, dim3((M + 63) / 64), dim3(256), lds, (hipStream_t)stream, x, (const char*)sd_hi,
-                       (const char*)sd_lo, out, M, dim);
+                       (const char*)sd_lo, out, M, dim, m_dev);
     MADTP_LAUNCH_CHECK();
     return 0;
 }

@@ -13,7 +13,7 @@ import torch
 F32, BF16, F16S, F16 = 0, 1, 2, 3  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 #                                    F16: plain IEEE f16 operands (the "f16" fast mode), see set_lp_format below
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -73,6 +73,8 @@ _SIGS = {
     "madtp_bert_layer": (c_int, [c_void_p] * 7 + [c_size_t, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float]
                          + [c_void_p] * 5 + [c_int] + [c_void_p] * 9 + [c_int] + [c_void_p] * 3),
     "madtp_vit_encoder": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_float, c_void_p]),
+    "madtp_vit_encoder_async": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_float, c_void_p,
+                                         c_void_p, c_void_p]),
     "madtp_bert_encoder": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
                                    c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                    c_void_p]),
@@ -1098,7 +1100,7 @@ def _query_w(qargs):
     return q
 
 
-def vit_encoder(weights, x, qargs, temperature):
+def vit_encoder(weights, x, qargs, temperature, sync_free=False):
     """VisionTransformer's block loop in ONE library call.  weights: (list of VitBlockW, ctypes array of their addresses)
     from runtime.EncoderWeights; x f32 [B,N,D] contiguous; qargs: query-model operands (see _query_w) or None.  -> EncoderRun."""
     B, N, D = x.shape
@@ -1111,10 +1113,25 @@ def vit_encoder(weights, x, qargs, temperature):
     prune = qargs is not None and temperature > 0
     run = EncoderRun(L, B, N, D, x.device, qargs is not None, prune, False, None)
     q = _query_w(qargs)
+    if sync_free:
+        # device-side lengths: the whole encoder is enqueued without a host read of k; one read of the layers' records at the end
+        if not vit_encoder_sync_free_ok(B, N, prune, qargs):
+            raise RuntimeError("sync-free encoder call: needs pruning with a deferred att_ft, B * N < 4096 token rows and N <= 256")
+        dims_dev = torch.empty(((L + 2) * 4,), device=x.device, dtype=torch.int32)
+        dims_host = (ctypes.c_int32 * ((L + 1) * 4))()
+        _check(lib.madtp_vit_encoder_async(arr, L, ctypes.byref(q), _p(x), run.io_ptr, _p(ws), ws.numel(), B, N, float(temperature),
+                                           _p(dims_dev), ctypes.addressof(dims_host), _stream()), "madtp_vit_encoder_async")
+        run.keep = (x, wstructs, qargs, dims_dev, dims_host)
+        return run
     _check(lib.madtp_vit_encoder(arr, L, ctypes.byref(q) if q is not None else None, _p(x), run.io_ptr, _p(ws), ws.numel(), B, N,
                                  float(temperature if prune else 0.0), _stream()), "madtp_vit_encoder")
     run.keep = (x, wstructs, qargs)
     return run
+
+
+def vit_encoder_sync_free_ok(B, N, prune, qargs):
+    """shapes / options madtp_vit_encoder_async takes (the launch-bound regime: small-tile GEMMs, <= 256-key attention)"""
+    return bool(prune and qargs is not None and qargs.get("att_ft") is None and B * N < 4096 and 3 <= N <= 256)
 
 
 def bert_encoder(weights, hidden, hidden_lp, mask2d, qargs, temperature, cross_mode, enc0, enc1, Nk, enc_mask0, enc_mask1,

@@ -27,6 +27,7 @@ import os as _os
 # path spreads its host work under the previous layer's kernels).
 _ENCODER_CALL = {"0": False, "1": True}.get(_os.environ.get("MADTP_ENCODER_CALL", "auto"), "auto")
 ENCODER_CALL_MAX_ROWS = 8192
+_SYNC_FREE = _os.environ.get("MADTP_ENCODER_SYNC_FREE", "1") != "0"
 
 
 def use_encoder_call(rows, flag=None):
@@ -337,8 +338,11 @@ def _vit_forward_encoder_call(self, x, space_dict, temperature, _pending, prep):
     B, N, D = x.shape
     qm = self.img_query_model
     weights, qargs, deferred = prep
-    run = hip.vit_encoder(weights, x, qargs, temperature if space_dict is not None else 0)
     prune_t = temperature if (space_dict is not None and temperature > 0) else 0
+    # device-side lengths (madtp_vit_encoder_async): no host read of k between the layers - taken in the launch-bound regime it is
+    # built for (B * N < 4096 token rows, N <= 256, deferred att_ft); MADTP_ENCODER_SYNC_FREE=0 keeps the per-layer hand-over of k
+    sync_free = _SYNC_FREE and hip.vit_encoder_sync_free_ok(B, N, prune_t > 0, qargs)
+    run = hip.vit_encoder(weights, x, qargs, temperature if space_dict is not None else 0, sync_free=sync_free)
     for l, blk in enumerate(self.blocks):
         blk.last_prune = run.info(l, prune_t)
         blk.attn.score_side = None

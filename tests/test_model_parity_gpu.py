@@ -375,6 +375,45 @@ def test_encoder_level_calls_equal_per_layer_path(mode, monkeypatch):
     assert pruned_layers >= 6
 
 
+@pytest.mark.parametrize("mode", ["fp32", "f16x3", "bf16", "f16"])
+@pytest.mark.parametrize("B,T,size", [(3, 30.0, 224), (1, 5.0, 224), (8, 8.6, 224), (2, 0.02, 48), (2, 3.0, 64)])
+def test_sync_free_vit_encoder_equals_host_k_paths(mode, B, T, size, monkeypatch):
+    """SURVEY 8(f) rank 2, device-side lengths: madtp_vit_encoder_async (the whole ViT enqueued without a host read of k - every
+    kernel takes its token count from the device-side record token_score leaves) against madtp_vit_encoder (k handed to the host
+    per layer) and the per-layer path: bit-identical encoder output, att_ft sum and pruning records (scores, thresholds, counts,
+    kept indices, full sort order) in all precision modes; the 48 x 48 and 64 x 64 images (10 / 17 tokens) drive layers into the
+    not-pruned branch of vit.py:148-149 (k >= n - 1: the sync-free path then runs its gather as a copy)."""
+    from madtp_amd import build, harness, hip, runtime, vit
+    build.build(verbose=False)
+    hip.load()
+    model = harness.build_nlvr(224, 0, "cuda")
+    images, _, _ = harness.nlvr_inputs(B, 224, 20, seed=5)
+    images = images[:, :, :size, :size].contiguous()
+    venc = model.visual_encoder
+    outs = []
+    for enc_call, sync_free in ((False, False), (True, False), (True, True)):
+        monkeypatch.setattr(vit, "_ENCODER_CALL", enc_call)
+        monkeypatch.setattr(vit, "_SYNC_FREE", sync_free)
+        with runtime.precision(mode), torch.no_grad():
+            y, sd = venc(images[:B], space_dict=model.space_dict, temperature=T)
+            recs = [dict(blk.last_prune.items()) if blk.last_prune is not None else None for blk in venc.blocks]
+        torch.cuda.synchronize()
+        outs.append((y.clone(), sd.clone(), [None if r is None else {k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()} for r in recs]))
+    ref = outs[0]
+    pruned = unpruned = 0
+    for y, sd, recs in outs[1:]:
+        assert y.shape == ref[0].shape and torch.equal(y, ref[0]) and torch.equal(sd, ref[1])
+        for a, b in zip(recs, ref[2]):
+            assert a["k"] == b["k"] and a["pruned"] == b["pruned"]
+            assert torch.equal(a["score"], b["score"]) and torch.equal(a["threshold"], b["threshold"]) and torch.equal(a["count"], b["count"])
+            if a["pruned"]:
+                pruned += 1
+                assert torch.equal(a["indices"], b["indices"]) and torch.equal(a["indices_sort"], b["indices_sort"])
+            else:
+                unpruned += 1
+    assert (unpruned > 0) if size < 224 else (pruned >= 12)
+
+
 RETR_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "retr_*.npz")))
 
 
