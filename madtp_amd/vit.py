@@ -27,7 +27,12 @@ import os as _os
 # path spreads its host work under the previous layer's kernels).
 _ENCODER_CALL = {"0": False, "1": True}.get(_os.environ.get("MADTP_ENCODER_CALL", "auto"), "auto")
 ENCODER_CALL_MAX_ROWS = 8192
-_SYNC_FREE = _os.environ.get("MADTP_ENCODER_SYNC_FREE", "1") != "0"
+# MADTP_ENCODER_SYNC_FREE=1: the encoder-level call without a host read of k (madtp_vit_encoder_async, device-side lengths).
+# Bit-identical to the host-k paths (tests/test_model_parity_gpu.py) but measured SLOWER where it applies (profiles/
+# r04_latency_table_*.txt: ViT alone at 1 / 16 images 1.92 / 2.28 ms against 1.43 / 1.77 ms): the host read of k already hides
+# under the projection GEMM, while the sync-free kernels run the unpruned sequence's grids and key-tile instantiations
+# (attention at 82 tokens on the 13-tile kernel).  Off by default; it is the form to capture in a graph / enqueue ahead.
+_SYNC_FREE = _os.environ.get("MADTP_ENCODER_SYNC_FREE", "0") == "1"
 
 
 def use_encoder_call(rows, flag=None):
@@ -339,8 +344,8 @@ def _vit_forward_encoder_call(self, x, space_dict, temperature, _pending, prep):
     qm = self.img_query_model
     weights, qargs, deferred = prep
     prune_t = temperature if (space_dict is not None and temperature > 0) else 0
-    # device-side lengths (madtp_vit_encoder_async): no host read of k between the layers - taken in the launch-bound regime it is
-    # built for (B * N < 4096 token rows, N <= 256, deferred att_ft); MADTP_ENCODER_SYNC_FREE=0 keeps the per-layer hand-over of k
+    # device-side lengths (madtp_vit_encoder_async): no host read of k between the layers (opt-in, see _SYNC_FREE above; shapes:
+    # B * N < 4096 token rows, N <= 256, deferred att_ft)
     sync_free = _SYNC_FREE and hip.vit_encoder_sync_free_ok(B, N, prune_t > 0, qargs)
     run = hip.vit_encoder(weights, x, qargs, temperature if space_dict is not None else 0, sync_free=sync_free)
     for l, blk in enumerate(self.blocks):
