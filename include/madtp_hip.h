@@ -487,6 +487,13 @@ int madtp_token_prob(const float* logits, int ld, int V, const int64_t* tok, int
  * [B * num_beams]; num_beams <= 8, n_top <= 16. */
 int madtp_beam_topk(const float* logits, int ld, int V, const float* beam_scores, int num_beams, int n_top, int suppress_token,
                     float* out_scores, int32_t* out_index, int B, void* stream);
+/* The same with the library's RepetitionPenaltyLogitsProcessor in front (generate(repetition_penalty=...), models/blip.py:161,
+ * 195): a token that already occurs in row (b, j) of prev_ids int64 [B * num_beams, ld_prev] (the beams' sequences so far,
+ * prompt included, cur_len columns) has its log-probability lp replaced by lp < 0 ? lp * penalty : lp / penalty - beam_search
+ * of transformers 4.15 runs the processors on the log-softmax scores - before the beam score is added. */
+int madtp_beam_topk_penalty(const float* logits, int ld, int V, const float* beam_scores, int num_beams, int n_top,
+                            int suppress_token, const int64_t* prev_ids, int ld_prev, int cur_len, float repetition_penalty,
+                            float* out_scores, int32_t* out_index, int B, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Backward of the pruned ViT block (first half; csrc/backward.hip): the pieces of loss.backward()
@@ -526,6 +533,10 @@ int madtp_token_score_bwd(const float* dw, const float* score, const int32_t* ds
  *   dS = P (dP - rowsum(P dP)); dq = scale dS k; dk = scale dS^T q; dv = P^T dout      (dout += dnrm_scale * out first)
  * q/k/v/dq/dk/dv: f32, rows b*N+i, head h at columns [64h, 64h+64) of each base pointer (slices of the fused qkv buffer).
  * ws: madtp_attention_bwd_workspace(B,H,N) bytes (P and dS [B,H,N,N] f32 + the head arg-max [B,N,N]).  N <= 1024. */
+/* The attention map itself, P[b,h,i,j] = softmax_j(scale q_i . k_j) as f32 [B,H,N,N] (vit.py:81-83 `self.save_attention_map(attn)`):
+ * the forward never materialises it; Attention.get_attention_map() of the mirror recomputes it on demand from the layer's input
+ * (q / k: f32 row views as in madtp_attention_bwd). */
+int madtp_attention_probs(const float* q, const float* k, int ld, float* P, int B, int H, int N, float scale, void* stream);
 size_t madtp_attention_bwd_workspace(int B, int H, int N);
 int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, const float* dout, int ldo, const float* out,
                         int ldout, const float* dnrm_scale, const float* da, const float* dp0, float* dq, float* dk, float* dv,

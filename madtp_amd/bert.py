@@ -944,6 +944,18 @@ class BertLMHeadModel(nn.Module):
         encoder_attention_mask is accepted and ignored: MED cross-attention drops the encoder mask (med.py:197-199)."""
         if do_sample:
             raise NotImplementedError("nucleus sampling (models/blip.py:175-186) is not implemented: beam search only")
+        # keyword arguments of transformers' generate that would change the result must not be dropped silently
+        for key, val in unused.items():
+            if key == "num_return_sequences" and val == 1:
+                continue
+            if key in ("top_p", "top_k", "temperature") and not do_sample:  # sampling-only knobs
+                continue
+            if key == "use_cache":
+                continue
+            if key == "attention_mask" and (val is None or bool((val != 0).all())):
+                continue  # an all-ones prompt mask is the default prepare_inputs_for_generation builds (med.py:1075-1077)
+            raise TypeError(f"generate(): unsupported argument {key}={val!r} (beam search of the reference's call sites only: "
+                            "num_beams, max_length, min_length, eos / pad ids, repetition_penalty, length_penalty, early_stopping)")
         if num_beams < 2:
             raise NotImplementedError("greedy search: the reference's call sites use num_beams = 3")
         if eos_token_id is None or pad_token_id is None or encoder_hidden_states is None:
@@ -955,6 +967,10 @@ class BertLMHeadModel(nn.Module):
         if encoder_hidden_states.shape[0] != B * num_beams:
             raise ValueError("generate: encoder_hidden_states must hold num_beams copies per prompt (repeat_interleave, "
                              "as models/blip_vqa.py:128 / models/blip.py:165 pass them)")
+        ehs = encoder_hidden_states.reshape(B, num_beams, *encoder_hidden_states.shape[1:])
+        if not bool((ehs == ehs[:, :1]).all()):
+            raise ValueError("generate: the num_beams copies of an item's encoder_hidden_states differ - they are projected once "
+                             "per item here (the reference repeats ONE image num_beams times, models/blip.py:165)")
         cache = EncoderKVCache.build(self.bert, encoder_hidden_states[::num_beams].contiguous())
         sel = cache.select(torch.arange(B, device=dev).repeat_interleave(num_beams))
         V = self.cls.predictions.decoder.weight.shape[0]

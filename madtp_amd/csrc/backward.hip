@@ -515,6 +515,19 @@ extern "C" int madtp_token_score_bwd(const float* dw, const float* score, const 
     return 0;
 }
 
+extern "C" int madtp_attention_probs(const float* q, const float* k, int ld, float* P, int B, int H, int N, float scale, void* stream) {
+    if (!q || !k || !P || B <= 0 || H <= 0 || N <= 0) return MADTP_E_BADARG;
+    if (N > 1024) return MADTP_E_SHAPE;
+    if (ld % 4 || !aligned16(q) || !aligned16(k)) return MADTP_E_ALIGN;
+    AttnBwdArgs a = {};
+    a.q = q; a.k = k; a.ld = ld; a.P = P; a.B = B; a.H = H; a.N = N; a.scale = scale;
+    const size_t lds_p = (size_t)(16 * HD + 16 * N) * sizeof(float);
+    MADTP_ENSURE_MAX_LDS(attn_probs_kernel, lds_p);
+    hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, (N + 15) / 16), dim3(256), lds_p, (hipStream_t)stream, a);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t madtp_attention_bwd_workspace(int B, int H, int N) {
     const size_t pn = (size_t)B * H * N * N * sizeof(float);
     return 2 * pn + (((size_t)B * N * N + 255) & ~(size_t)255);

@@ -356,15 +356,17 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x4 (&acc)[F
                                 range_mx = f16_range_acc(f16_range_acc(range_mx, v[0]), v[1]);
                             } else if constexpr (OM == OM_BF16) bits = __builtin_bit_cast(u32x4, pack_bf16x8(v[0], v[1]));
                             else if constexpr (OM == OM_F16) {
+                                // (no range accumulation here: an f16 output that overflows turns the next f32-output GEMM's
+                                //  result into inf / NaN, which the LayerNorm behind it flags - f16_range_bad is true for NaN -
+                                //  still inside the forward; the 64 extra VALU per lane cost the 60 us launches 2-3 %)
                                 bits = __builtin_bit_cast(u32x4, pack_f16x8(v[0], v[1]));
-                                range_mx = f16_range_acc(f16_range_acc(range_mx, v[0]), v[1]);
                             }
                             else bits = __builtin_bit_cast(u32x4, v[0]);
                             __builtin_amdgcn_raw_buffer_store_b128(bits, crsrc, off, 0, 0);
                         }
                     }
                 }
-                if constexpr (OM == OM_F16S || OM == OM_F16) f16_range_raise(g.range_flag, !(range_mx < 65520.0f));
+                if constexpr (OM == OM_F16S) f16_range_raise(g.range_flag, !(range_mx < 65520.0f));
             } else if constexpr (!FAST_ONLY) {
                 // generic fallback (N or a leading dimension not a multiple of 8 elements, e.g. the 2-logit head)
 #pragma unroll

@@ -106,7 +106,8 @@ constexpr int BT_MAX_TOP = 16, BT_MAX_BEAMS = 8, BT_THREADS = 1024;
 
 __global__ __launch_bounds__(BT_THREADS) void beam_topk_kernel(const float* logits, int ld, int V, const float* beam_scores,
                                                                int num_beams, int n_top, int suppress, float* out_scores,
-                                                               int32_t* out_index) {
+                                                               int32_t* out_index, const int64_t* prev_ids, int ld_prev,
+                                                               int cur_len, float penalty) {
     __shared__ float scratch[BT_THREADS / 64];
     __shared__ float lse_s[BT_MAX_BEAMS];
     extern __shared__ __attribute__((aligned(16))) char bt_dyn[];  // [BT_THREADS][n_top] values, then [BT_THREADS][n_top] indices
@@ -115,6 +116,20 @@ __global__ __launch_bounds__(BT_THREADS) void beam_topk_kernel(const float* logi
     __shared__ float w_val[BT_THREADS / 64];
     __shared__ int w_idx[BT_THREADS / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
+    // RepetitionPenaltyLogitsProcessor (transformers 4.15, applied by beam_search to the LOG-PROBABILITIES): tokens already in a
+    // beam's sequence (prompt included) get lp < 0 ? lp * penalty : lp / penalty.  One bit per (beam row, token) in LDS.
+    unsigned* seen = (unsigned*)(c_idx + BT_THREADS * n_top);  // [num_beams][(V + 31) / 32] when prev_ids != NULL
+    const int vw = (V + 31) / 32;
+    if (prev_ids) {
+        for (int i = tid; i < num_beams * vw; i += BT_THREADS) seen[i] = 0u;
+        __syncthreads();
+        for (int i = tid; i < num_beams * cur_len; i += BT_THREADS) {
+            const int j = i / cur_len, c = i - j * cur_len;
+            const long long t = prev_ids[((size_t)b * num_beams + j) * ld_prev + c];
+            if (t >= 0 && t < V) atomicOr(&seen[j * vw + (int)(t >> 5)], 1u << (t & 31));
+        }
+        __syncthreads();
+    }
     for (int j = 0; j < num_beams; ++j) {
         const RowStats st = row_stats<BT_THREADS>(logits + ((size_t)b * num_beams + j) * ld, V, scratch);
         if (tid == 0) lse_s[j] = st.mx + logf(st.sum_e);
@@ -130,7 +145,9 @@ __global__ __launch_bounds__(BT_THREADS) void beam_topk_kernel(const float* logi
         const float add = beam_scores[b * num_beams + j], lse = lse_s[j];
 #pragma unroll 4
         for (int t = tid; t < V; t += BT_THREADS) {
-            float v = (row[t] - lse) + add;
+            float lp = row[t] - lse;
+            if (prev_ids && ((seen[j * vw + (t >> 5)] >> (t & 31)) & 1u)) lp = lp < 0.f ? lp * penalty : lp / penalty;
+            float v = lp + add;
             if (t == suppress) v = -INFINITY;
             if (!(v > -INFINITY)) continue;  // -inf and NaN never become candidates
             if (filled < n_top) {
@@ -173,17 +190,35 @@ __global__ __launch_bounds__(BT_THREADS) void beam_topk_kernel(const float* logi
 
 }  // namespace
 
-extern "C" int madtp_beam_topk(const float* logits, int ld, int V, const float* beam_scores, int num_beams, int n_top,
-                               int suppress_token, float* out_scores, int32_t* out_index, int B, void* stream) {
+static int beam_topk_launch(const float* logits, int ld, int V, const float* beam_scores, int num_beams, int n_top,
+                            int suppress_token, float* out_scores, int32_t* out_index, int B, const int64_t* prev_ids, int ld_prev,
+                            int cur_len, float penalty, void* stream) {
     if (!logits || !beam_scores || !out_scores || !out_index || B <= 0 || V <= 0 || ld < V) return MADTP_E_BADARG;
     if (num_beams < 1 || num_beams > BT_MAX_BEAMS || n_top < 1 || n_top > BT_MAX_TOP || (long long)num_beams * V > 0x7ffffffeLL)
         return MADTP_E_SHAPE;
     if (!aligned16(logits) || (ld & 3)) return MADTP_E_ALIGN;
-    MADTP_ENSURE_MAX_LDS(beam_topk_kernel, BT_THREADS * BT_MAX_TOP * 8);
-    hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(BT_THREADS), (size_t)BT_THREADS * n_top * 8, (hipStream_t)stream, logits, ld, V,
-                       beam_scores, num_beams, n_top, suppress_token, out_scores, out_index);
+    if (prev_ids && (cur_len < 1 || ld_prev < cur_len || !(penalty > 0.f))) return MADTP_E_BADARG;
+    const size_t lds = (size_t)BT_THREADS * n_top * 8 + (prev_ids ? (size_t)num_beams * ((V + 31) / 32) * 4 : 0);
+    if (lds > 150 * 1024) return MADTP_E_SHAPE;  // (the kernel's static LDS comes on top)
+    MADTP_ENSURE_MAX_LDS(beam_topk_kernel, 150 * 1024);
+    hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(BT_THREADS), lds, (hipStream_t)stream, logits, ld, V, beam_scores, num_beams,
+                       n_top, suppress_token, out_scores, out_index, prev_ids, ld_prev, cur_len, penalty);
     MADTP_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int madtp_beam_topk(const float* logits, int ld, int V, const float* beam_scores, int num_beams, int n_top,
+                               int suppress_token, float* out_scores, int32_t* out_index, int B, void* stream) {
+    return beam_topk_launch(logits, ld, V, beam_scores, num_beams, n_top, suppress_token, out_scores, out_index, B, nullptr, 0, 0, 1.f,
+                            stream);
+}
+
+extern "C" int madtp_beam_topk_penalty(const float* logits, int ld, int V, const float* beam_scores, int num_beams, int n_top,
+                                       int suppress_token, const int64_t* prev_ids, int ld_prev, int cur_len, float repetition_penalty,
+                                       float* out_scores, int32_t* out_index, int B, void* stream) {
+    if (!prev_ids) return MADTP_E_BADARG;
+    return beam_topk_launch(logits, ld, V, beam_scores, num_beams, n_top, suppress_token, out_scores, out_index, B, prev_ids, ld_prev,
+                            cur_len, repetition_penalty, stream);
 }
 
 extern "C" int madtp_lm_loss(const float* logits, int ld, int rows_per_seq, int n_pred, int V, const int64_t* labels,

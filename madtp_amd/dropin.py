@@ -14,7 +14,7 @@ blip_vqa.py: pure glue) to be imported from the reference tree itself.  The CLIP
 _transform: host glue) and `clip.simple_tokenizer` are imported from the reference tree itself.  Names those glue files import that are off the
 pruned forward path (the contrastive-loss helpers of models/utils.py) resolve to stubs that raise on use, so a training script
 fails loudly instead of silently running something else; `models.med.BertLMHeadModel` is the teacher-forced decoder mirror
-(rank_answer; beam-search generation raises)."""
+(rank_answer and beam-search `generate`; nucleus sampling raises)."""
 import importlib
 import math
 import os

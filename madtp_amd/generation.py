@@ -46,9 +46,6 @@ def beam_search(step_fn, input_ids, num_beams, max_length, min_length, eos_token
                 repetition_penalty=1.0, length_penalty=1.0, early_stopping=False):
     """step_fn(input_ids [B * num_beams, t] on the GPU) -> f32 last-position scores [B * num_beams, >= n_vocab] (GPU, unit column
     stride); input_ids: the prompt already repeated num_beams times per item.  -> int64 [B, <= max_length] on the GPU."""
-    if repetition_penalty != 1.0:
-        raise NotImplementedError("repetition_penalty != 1.0: the reference's beam-search call sites pass 1.0 "
-                                  "(models/blip.py:161,195; compress_caption_dtp.py evaluate)")
     dev = input_ids.device
     n, cur_len = input_ids.shape
     B = n // num_beams
@@ -61,7 +58,9 @@ def beam_search(step_fn, input_ids, num_beams, max_length, min_length, eos_token
     while True:
         logits = step_fn(input_ids)
         suppress = eos_token_id if (min_length is not None and min_length > -1 and cur_len < min_length) else -1
-        sc, ix = hip.beam_topk(logits, beam_scores.to(dev), num_beams, n_vocab, suppress_token=suppress)
+        sc, ix = hip.beam_topk(logits, beam_scores.to(dev), num_beams, n_vocab, suppress_token=suppress,
+                               prev_ids=input_ids.contiguous() if repetition_penalty != 1.0 else None,
+                               repetition_penalty=repetition_penalty)
         sc, ix = sc.cpu(), ix.cpu().to(torch.int64)
         next_indices, next_tokens = ix // n_vocab, ix % n_vocab
         nb_scores = torch.zeros((B, num_beams), dtype=torch.float32)

@@ -13,7 +13,7 @@ import torch
 F32, BF16, F16S, F16 = 0, 1, 2, 3  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 #                                    F16: plain IEEE f16 operands (the "f16" fast mode), see set_lp_format below
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -91,6 +91,8 @@ _SIGS = {
     "madtp_lm_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p]),
     "madtp_token_prob": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "madtp_beam_topk": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "madtp_beam_topk_penalty": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p,
+                                         c_void_p, c_int, c_void_p]),
     # backward of the pruned ViT block (csrc/backward.hip)
     "madtp_transpose_pad": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "madtp_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -99,6 +101,7 @@ _SIGS = {
     "madtp_token_gather_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
     "madtp_token_score_bwd": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4
                               + [c_int, c_int, c_int, c_void_p]),
+    "madtp_attention_probs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "madtp_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
     "madtp_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 6
                             + [c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_float, c_void_p]),
@@ -394,6 +397,18 @@ def attention(q, k, v, B, H, Nq, Nk, scale, add_mask=None, scores=False, mask_qk
                                   q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), io, _stream()),
            "madtp_attention")
     return out, side
+
+
+def attention_probs(q, k, B, H, N, scale):
+    """P = softmax(scale q k^T) f32 [B, H, N, N] from f32 row views q, k [B*N, >= H*64] (madtp_attention_probs)."""
+    for t in (q, k):
+        if not t.is_cuda or t.dtype != torch.float32 or t.stride(1) != 1:
+            raise RuntimeError("attention_probs operands must be GPU f32 row-major views")
+    if q.stride(0) != k.stride(0):
+        raise RuntimeError("attention_probs: q and k must share their leading dimension")
+    P = torch.empty((B, H, N, N), device=q.device, dtype=torch.float32)
+    _check(load().madtp_attention_probs(_p(q), _p(k), q.stride(0), _p(P), B, H, N, float(scale), _stream()), "madtp_attention_probs")
+    return P
 
 
 def attention_pair(q0, q1, k0, k1, v0, v1, B, H, Nq, Nk, scale, add_mask0=None, add_mask1=None):
@@ -875,7 +890,7 @@ def token_prob(logits, tok, n_vocab):
     return out
 
 
-def beam_topk(logits, beam_scores, num_beams, n_vocab, n_top=None, suppress_token=-1):
+def beam_topk(logits, beam_scores, num_beams, n_vocab, n_top=None, suppress_token=-1, prev_ids=None, repetition_penalty=1.0):
     """One beam-search step's candidate selection (include/madtp_hip.h madtp_beam_topk): logits f32 [B * num_beams, >= n_vocab]
     (rows may be strided), beam_scores f32 [B * num_beams] -> (scores f32 [B, n_top], flat index int32 [B, n_top] = beam * V + token),
     descending, n_top = 2 * num_beams by default."""
@@ -889,6 +904,12 @@ def beam_topk(logits, beam_scores, num_beams, n_vocab, n_top=None, suppress_toke
     n_top = 2 * num_beams if n_top is None else int(n_top)
     sc = torch.empty((B, n_top), device=logits.device, dtype=torch.float32)
     ix = torch.empty((B, n_top), device=logits.device, dtype=torch.int32)
+    if prev_ids is not None and repetition_penalty != 1.0:  # RepetitionPenaltyLogitsProcessor on the beams' sequences so far
+        _req(prev_ids, torch.int64, "prev_ids")
+        _check(load().madtp_beam_topk_penalty(_p(logits), logits.stride(0), int(n_vocab), _p(beam_scores), int(num_beams), n_top,
+                                              int(suppress_token), _p(prev_ids), prev_ids.stride(0), prev_ids.shape[1],
+                                              float(repetition_penalty), _p(sc), _p(ix), B, _stream()), "madtp_beam_topk_penalty")
+        return sc, ix
     _check(load().madtp_beam_topk(_p(logits), logits.stride(0), int(n_vocab), _p(beam_scores), int(num_beams), n_top,
                                   int(suppress_token), _p(sc), _p(ix), B, _stream()), "madtp_beam_topk")
     return sc, ix

@@ -7,8 +7,9 @@ Differences a caller can observe (documented in INTEGRATION.md):
   * kept tokens come out in ascending token order (the reference's topk(sorted=False) order is implementation
     defined; attention is permutation-equivariant so downstream values agree to f32 rounding);
   * `token_attn` is not divided by the temperature in place (vit.py:137 mutates the caller's tensor);
-  * the [B,H,N,N] attention map is never materialised: get_attention_map() returns None unless
-    Attention.keep_attention_map is set (slow debug path is not provided in this round).
+  * the [B,H,N,N] attention map is never materialised by the forward: get_attention_map() returns None unless
+    Attention.keep_attention_map is set, in which case it is recomputed on demand (exact-f32) from the layer's input;
+    register_hook=True (gradient hooks on the map, Grad-CAM) still raises.
 """
 from functools import partial
 
@@ -90,6 +91,11 @@ class Attention(nn.Module):
         self.cls_attn = None
         self.score_side = None  # (colsum_part, p0, onorm) of the last call - consumed by Block.Reduce_token
         self._cache = PreparedCache()
+        # vit.py:57-73, 83: the reference stores the [B,H,N,N] map of every call.  The kernels never materialise it; with
+        # keep_attention_map = True the layer remembers its (normalised) input instead and get_attention_map() recomputes the map
+        # on demand - exact-f32 arithmetic whatever the precision mode (q, k from an f32 GEMM, madtp_attention_probs).
+        self.keep_attention_map = False
+        self._map_input = None
 
     def save_attn_gradients(self, attn_gradients):
         self.attn_gradients = attn_gradients
@@ -101,6 +107,13 @@ class Attention(nn.Module):
         self.attention_map = attention_map
 
     def get_attention_map(self):
+        if self.attention_map is None and self.keep_attention_map and self._map_input is not None:
+            h32, B, N = self._map_input  # LayerNorm output of the last call, f32 [B*N, dim]
+            with torch.no_grad():
+                qk = lin_of(self._cache, "qkv", [self.qkv], torch.float32)
+                y = hip.gemm(h32, qk.w, qk.b, n=qk.n, out_dtype=torch.float32)
+                C = self.dim
+                self.attention_map = hip.attention_probs(y[:, :C], y[:, C:2 * C], B, self.num_heads, N, self.scale)
         return self.attention_map
 
     def save_cls_attn(self, cls_attn):
@@ -207,6 +220,10 @@ class Block(nn.Module):
         prune = temperature > 0
         if prune and token_attn is None:
             raise ValueError("temperature > 0 requires token_attn (the reference fails in Reduce_token as well)")
+        if self.attn.keep_attention_map:  # get_attention_map() support (see Attention.__init__)
+            self.attn.attention_map = None
+            self.attn._map_input = (hip.layernorm(x.detach().view(B * N, D), self.norm1.weight.detach(), self.norm1.bias.detach(),
+                                                  self.norm1.eps)[0], B, N)
         if torch.is_grad_enabled():
             # training / compression (compress_nlvr_dtp.py:46-58): Block.forward under autograd with the hand-written backward of
             # madtp_amd/backward.py (fp32 precision mode).  An input that asks for a gradient in another mode fails loudly;
@@ -297,7 +314,8 @@ class VisionTransformer(nn.Module):
         B = x.shape[0]
         enc_prep = None
         if (register_blk == -1 and use_encoder_call(B * (self.patch_embed.num_patches + 1), _ENCODER_CALL)
-                and all(type(b) is Block for b in self.blocks)):
+                and all(type(b) is Block and not b.attn.keep_attention_map for b in self.blocks)
+                and not (torch.is_grad_enabled() and x.requires_grad)):
             # host-only preparation of the encoder-level call FIRST (weight structs, query-model operands): it then overlaps
             # the tail of whatever the GPU is still running instead of sitting between the patch embedding and the first layer
             enc_prep = self._encoder_call_prep(x, space_dict)

@@ -959,8 +959,13 @@ def test_f16_range_flag(hip):
         hip.cast_bf16(x)
         assert hip.range_status() == 1
         big = hip.gemm(hip.cast_bf16(_rand(300, 768, seed=2).cuda() * 40), hip.cast_lp_weight(_pad128(_rand(768, 768, seed=3)).cuda() * 90),
-                       None, out_dtype=torch.bfloat16, n=768)   # outputs ~ 40 * 90 * sqrt(768) = 1e5
-        assert hip.range_status() == 1 and not torch.isfinite(hip.lp_to_f32(big)).all()
+                       None, out_dtype=torch.bfloat16, n=768)   # outputs ~ 40 * 90 * sqrt(768) = 1e5: infinities in the f16 output
+        assert not torch.isfinite(hip.lp_to_f32(big)).all()
+        # the vector epilogue of an f16-output GEMM does not test its values (cost); the overflow is caught by the LayerNorm behind
+        # the next f32-output GEMM, i.e. still inside the layer
+        nxt = hip.gemm(big, hip.cast_lp_weight(_pad128(_rand(768, 768, seed=4, scale=0.05)).cuda()), None, out_dtype=torch.float32, n=768)
+        hip.layernorm(nxt, torch.ones(768, device="cuda"), torch.zeros(768, device="cuda"), 1e-6, want_f32=False, lp=torch.bfloat16)
+        assert hip.range_status() == 1
     g, b = torch.ones(768, device="cuda"), torch.zeros(768, device="cuda")
     hip.layernorm(x, g * 1e5, b, 1e-6, want_f32=False, lp=torch.float16)
     assert hip.range_status() == 1
@@ -981,3 +986,22 @@ def test_f16_modes_range_error_in_a_block(hip):
             assert hip.range_status() == 0
         with runtime.precision("fp32"):
             assert torch.isfinite(blk(x, False, 0, 1.0, ta.clone())).all()
+
+
+def test_attention_map_accessor(hip):
+    """Block.attn.get_attention_map() (vit.py:57-73, 83): None by default (the kernels never materialise P); with
+    keep_attention_map = True the [B,H,N,N] map of the last call, recomputed on demand in exact f32 - against torch on the same
+    weights, in a fast precision mode as well."""
+    from madtp_amd import runtime, vit
+    blk = vit.Block(768, 12, qkv_bias=True).cuda()
+    x = _rand(2, 50, 768, seed=1).cuda()
+    with torch.no_grad(), runtime.precision("f16"):
+        blk(x)
+        assert blk.attn.get_attention_map() is None
+        blk.attn.keep_attention_map = True
+        blk(x)
+        P = blk.attn.get_attention_map()
+    h = F.layer_norm(x, (768,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+    qkv = F.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias).reshape(2, 50, 3, 12, 64).permute(2, 0, 3, 1, 4)
+    ref = ((qkv[0] @ qkv[1].transpose(-2, -1)) * blk.attn.scale).softmax(-1)
+    assert P.shape == (2, 12, 50, 50) and (P - ref).abs().max().item() < 2e-6

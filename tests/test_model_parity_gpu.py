@@ -649,10 +649,13 @@ def test_generation_beam_search_equals_oracle_on_toy_models():
         table = (table / table.sum(1, keepdim=True)).tolist()
         prompt = torch.randint(2, V, (B, 1 + trial % 2), generator=gen).repeat_interleave(nb, dim=0)
         kw = dict(num_beams=nb, max_length=4 + trial % 5, min_length=trial % 3, eos_token_id=1, pad_token_id=0)
-        ref = O.beam_search(toy_lm(table), prompt, **kw)
+        # every other trial with the library's repetition penalty (generate(repetition_penalty=...), models/blip.py:161,195):
+        # tokens already in a beam's sequence have their log-probability scaled (madtp_beam_topk_penalty)
+        rp = [1.0, 1.3, 0.8, 2.0][trial % 4]
+        ref = O.beam_search(toy_lm(table), prompt, repetition_penalty=rp, **kw)
         mine = generation.beam_search(gpu_lm(table, (V + 3) // 4 * 4), prompt.cuda(), kw["num_beams"], kw["max_length"],
-                                      kw["min_length"], 1, 0, V)
-        assert mine.cpu().tolist() == ref.tolist(), (trial, mine.tolist(), ref.tolist())
+                                      kw["min_length"], 1, 0, V, repetition_penalty=rp)
+        assert mine.cpu().tolist() == ref.tolist(), (trial, rp, mine.tolist(), ref.tolist())
         n_eos += int((ref == 1).any())
     assert n_eos >= 8   # the finishing rules were exercised
 

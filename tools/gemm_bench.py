@@ -3,8 +3,10 @@
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from madtp_amd import hip
+from madtp_amd import hip, runtime
 hip.load()
+if os.environ.get("MADTP_PRECISION"):  # "f16": the same 2-byte containers hold IEEE f16 (random bits either way for timing)
+    runtime.set_precision(os.environ["MADTP_PRECISION"])
 shapes = [(25216, 2304, 768), (25216, 768, 768), (25216, 3072, 768), (25216, 768, 3072),
           (10496, 2304, 768), (10496, 768, 768), (10496, 3072, 768), (10496, 768, 3072),
           (5120, 1536, 768), (1280, 2304, 768), (1280, 768, 768), (1280, 3072, 768), (1280, 768, 3072), (1280, 768, 1536),
