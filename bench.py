@@ -430,6 +430,7 @@ def reference_proper(name):
             B = int(g["B"]) if "B" in g.files else 0
             imgs = B * (2 if name == "nlvr" else 1)
             rows.append({"fixture": os.path.basename(path), "images": imgs, "seconds": round(float(g["ref_seconds"]), 3),
+                         "warm_median_of": (int(len(g["ref_seconds_runs"])) if "ref_seconds_runs" in g.files else 1),
                          "threads": int(g["threads"]) if "threads" in g.files else None,
                          "images_per_s": round(imgs / float(g["ref_seconds"]), 2) if imgs else None})
         except Exception:  # a fixture without the fields is simply not reported
@@ -437,7 +438,8 @@ def reference_proper(name):
     if not rows:
         return None
     return {"what": "the reference's own modules (CPU eager fp32, imported in the build container by tools/make_golden.py), one "
-                    "un-warmed forward per committed fixture", "fixtures": rows}
+                    "forward per committed fixture: the median of 5 warm runs where the fixture records it (ref_seconds_runs), else one un-warmed "
+                    "call", "fixtures": rows}
 
 
 if __name__ == "__main__":
