@@ -773,3 +773,9 @@ def test_nlvr_pad_inside_topk_pairing(env, path, mode):
         for l in range(first + 1):
             assert mine[l] == rec[l], l
         assert harness.token_lengths(trace["vit"], 197) == g["vit_lens"].tolist()
+        if len(nlvr_pad_layers(g)) == 1:
+            # pads inside the top-(k+1) at ONE layer only (nlvrpad_b3_T20_one): there the ascending pairing mis-pairs nothing and
+            # neither does the recording's order (tests/test_oracle_golden.py prints the slots) - the reference's OWN result is
+            # reproduced: every layer's kept sets and the recorded logits
+            assert mine == rec
+            assert np.abs(logits.cpu().numpy() - g["logits"]).max() < 1e-3

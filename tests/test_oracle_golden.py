@@ -402,6 +402,34 @@ def test_oracle_nlvr_pad_inside_topk_fixture(path):
     print(f"pads inside top-(k+1) at text layers {pad_layers}; ascending-order pairing differs from this build's at layers "
           f"{differ}; |dlogit| {np.abs(logits_asc.numpy() - logits.numpy()).max():.4f}")
     assert all(l > first for l in differ)
+    # What exactly differs AT the pad layer (stated slot by slot): both pairings take the compacted mask by RANK (indices_sort[:, :k+1],
+    # nlvr_encoder.py:452), so the mask vector handed to the next layer is the SAME; the kept token SET is the same; only the
+    # permutation of the kept tokens under that mask differs (torch.topk(sorted=False)'s order there, ascending token order here),
+    # i.e. WHICH kept token sits under a -10000 entry.
+    ref_i, asc_i = tr_ref["text"][first], tr_asc["text"][first]
+    k = ref_i["k"]
+    in_mask = harness.padded_mask(B, L, g["pad_list"].tolist())
+    for l in range(first):  # layers before the first pad layer that pruned: follow the mask compaction
+        if tr_ref["text"][l]["pruned"]:
+            srt = tr_ref["text"][l]["indices_sort"][:, : tr_ref["text"][l]["k"] + 1]
+            in_mask = torch.cat([in_mask[:, :1], torch.gather(in_mask[:, 1:], 1, srt)], 1)
+    pad_in = in_mask[:, 1:] == 0                                      # padded positions (attention mask 0) of the layer input, per token
+    by_rank = torch.gather(pad_in, 1, ref_i["indices_sort"][:, :k])   # the -10000 pattern of slots 0..k-1 (both pairings)
+    assert torch.equal(ref_i["indices_sort"], asc_i["indices_sort"])
+    under_ref = torch.gather(pad_in, 1, ref_i["indices"])             # is the token in slot p a padded one? (reference order)
+    under_asc = torch.gather(pad_in, 1, asc_i["indices"])
+    slots_ref = [(by_rank[b] != under_ref[b]).nonzero().flatten().tolist() for b in range(B)]
+    slots_asc = [(by_rank[b] != under_asc[b]).nonzero().flatten().tolist() for b in range(B)]
+    print(f"layer {first}: slots whose mask entry does not belong to the token in them - reference order {slots_ref}, ascending "
+          f"order {slots_asc}")
+    for b in range(B):
+        if int(g["pad_list"][b]) == 0:      # the unpadded caption has no -10000 entry at all: nothing to mis-pair
+            assert slots_ref[b] == [] and slots_asc[b] == []
+        assert len(slots_ref[b]) % 2 == 0 and len(slots_asc[b]) % 2 == 0  # mis-pairings come in (real under -10000, pad under 0) pairs
+    if len(pad_layers) == 1:
+        # single-layer fixture: the number of kept padded tokens is the same in both pairings (same SET); bounded by the pads present
+        for b in range(B):
+            assert int(under_ref[b].sum()) == int(under_asc[b].sum()) <= int(g["pad_list"][b])
 
 
 # ---- beam-search generation (inference half; transformers 4.15 restated in oracle.beam_search) --------

@@ -580,6 +580,9 @@ CASES = {
     # ragged captions (0 / 14 / 26 padded positions of 35): k = max_b count is set by the long caption, so the short ones keep
     # PADDED tokens inside their top-(k+1) - the token / mask pairing of nlvr_encoder.py:440-452 is exercised
     "nlvrpad_b3_T12": lambda: nlvr_case("nlvrpad_b3_T12", 3, 224, 35, 12.0, seed=0, pad_list=[0, 14, 26]),
+    # the same edge at ONE text layer only (layer 4, the first one that prunes; 0 / 1 / 2 padded positions): what differs from
+    # the recording can be stated slot by slot (tests)
+    "nlvrpad_b3_T20_one": lambda: nlvr_case("nlvrpad_b3_T20_one", 3, 224, 35, 20.0, seed=0, pad_list=[0, 1, 2]),
     "med_text_b3": lambda: med_case("med_text_b3", 3, 35, 0, 30.0, "text", pad_tail=3),
     "med_mm_b3": lambda: med_case("med_mm_b3", 3, 35, 50, 30.0, "multimodal", pad_tail=3),
     "vqa480_b2": lambda: vqa_case("vqa480_b2", 2, 480, 20, 6.0, pad_tail=2),
