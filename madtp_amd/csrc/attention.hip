@@ -51,7 +51,7 @@ struct AttnArgs {
 
 // Exchange area of the head split (one per device and stream, allocated on first use; the tickets reset themselves).
 struct HmWorkspace { unsigned* ws; int* tick; };
-constexpr int HM_MAX_WGS = 384, HM_MAX_NT = 40;
+constexpr int HM_MAX_WGS = 384, HM_MAX_NT = 40, HM_MAX_GZ = 4;  // (attn_bf16_large_kernel splits the heads over up to 4 workgroups)
 static bool hm_workspace(hipStream_t s, HmWorkspace& out) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("MADTP_ATTN_HEAD_SPLIT"); env = e ? atoi(e) : 1; }
@@ -63,7 +63,7 @@ static bool hm_workspace(hipStream_t s, HmWorkspace& out) {
     std::lock_guard<std::mutex> lk(mu);
     auto it = pool.find({dev, s});
     if (it == pool.end()) {
-        constexpr size_t WS_BYTES = (size_t)HM_MAX_WGS * 2 * 4 * (2 * HM_MAX_NT) * 64 * 4, TICK_BYTES = (size_t)HM_MAX_WGS * 4 * sizeof(int);
+        constexpr size_t WS_BYTES = (size_t)HM_MAX_WGS * HM_MAX_GZ * 4 * (2 * HM_MAX_NT) * 64 * 4, TICK_BYTES = (size_t)HM_MAX_WGS * 4 * sizeof(int);
         char* base = nullptr;
         if (hipMalloc((void**)&base, WS_BYTES + TICK_BYTES) != hipSuccess) { (void)hipGetLastError(); return false; }
         if (hipMemsetAsync(base + WS_BYTES, 0, TICK_BYTES, s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(base); return false; }
@@ -663,7 +663,9 @@ __global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void a
             const int j = 16 * t + 4 * g + r;
             mk[t][r] = j < a.Nk ? (a.mask ? a.mask[(size_t)b * a.Nk + j] : 0.f) : -INFINITY;
             if (a.mask_qk && j < a.Nk) mk[t][r] += a.mask_qk[(size_t)irow * a.ld_mqk + j];
+            mk[t][r] *= 1.44269504088896341f;  // the softmax runs in log2 units: exp2(c2 s + mk - max), no multiply inside expf
         }
+    const float c2 = a.scale * 1.44269504088896341f;
 
     // K_h and V_h are LDS-DMA'd (8 rows = 1 KiB per wave-instruction) into a 2-stage ring over the heads: the DMA of
     // head h+1 is in flight while head h is computed.  Swizzles live on the SOURCE address (the DMA destination is
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void a
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = fmaf(sc[t][r], a.scale, mk[t][r]);
+                const float v = fmaf(sc[t][r], c2, mk[t][r]);
                 sc[t][r] = v;
                 m = fmaxf(m, v);
             }
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void a
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(sc[t][r] - m);
+                const float p = __builtin_amdgcn_exp2f(sc[t][r] - m);
                 sc[t][r] = p;
                 sum += p;
             }
@@ -1498,7 +1500,8 @@ int launch_attn_large(const AttnArgs& a, hipStream_t s) {
 //   * exp via v_exp_f32, one reciprocal per row.
 // The head-max stays in registers for all key tiles as packed f16 pairs (NT x 2 registers per lane: 80 at 577 keys, 114 at 901),
 // two 4-wave workgroups per CU up to 640 keys (the 1024-key instantiation would spill at 256 registers and keeps one).
-// Work per (b, h): 6 Nq Nk 64 flop (Q K^T twice) on the bf16 MFMA; the bound is the VALU softmax work (2 exp per score).
+// Work per (b, h): 6 Nq Nk 64 flop (Q K^T twice) on the bf16 MFMA; the bound is the VALU softmax work (2 exp per score, each
+// one fma + v_exp_f32 on the unscaled score, see scores()).
 // STG: stages of the chunk ring (2 is what launch_attn_bf16_large uses; 3 keeps two chunks in flight behind counted vmcnt waits
 // and was measured slower, see there).
 template <int NCH, bool SCORES, int STG, bool F16 = false>
@@ -1568,7 +1571,8 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
             if (with_v) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, LDS_PTR(base + CK * 128 + i * 1024), 16, vro[i], sv, 0, 0);
         }
     };
-    // S^T of one chunk (8 key tiles), scaled and masked; keys >= Nk -> -inf
+    const float c2 = a.scale * 1.44269504088896341f, inv_scale = 1.f / a.scale;
+    // S^T of one chunk (8 key tiles), unscaled (see below), masked; keys >= Nk -> -inf
     auto scores = [&](const char* Ks, int c, const bf16x8 (&q)[2], f32x4 (&sc)[8]) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -1579,6 +1583,10 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
             acc = mfma_lp<F16>(k0, q[0], acc, 0, 0, 0);
             sc[t] = mfma_lp<F16>(k1, q[1], acc, 0, 0, 0);
         }
+        // The scores stay UNSCALED: exp(scale s - max) is evaluated as exp2(fma(s, c2, off)) with c2 = scale log2(e) and a per-row
+        // offset (pass A: -c2 max; pass B: -(c2 max + log2 sum), which normalises as well) - one fma + one v_exp_f32 per score
+        // instead of scale, subtract, the log2(e) multiply of expf, v_exp_f32 and the 1 / sum multiply: the VALU softmax work
+        // is this kernel's bound.  An additive mask joins in units of 1 / scale.
         const int jb = c * CK + 4 * g;
         if (a.mask) {
             const float* mrow = a.mask + (size_t)b * a.Nk;
@@ -1587,19 +1595,15 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = jb + 16 * t + r;
-                    sc[t][r] = j < a.Nk ? fmaf(sc[t][r], a.scale, mrow[j]) : -INFINITY;
+                    sc[t][r] = j < a.Nk ? fmaf(mrow[j], inv_scale, sc[t][r]) : -INFINITY;
                 }
-        } else if ((c + 1) * CK <= a.Nk) {  // full chunk: no bounds
-#pragma unroll
-            for (int t = 0; t < 8; ++t) sc[t] *= a.scale;
-        } else {
+        } else if ((c + 1) * CK > a.Nk) {  // (a full chunk needs no bounds)
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sc[t][r] = (jb + 16 * t + r) < a.Nk ? sc[t][r] * a.scale : -INFINITY;
+                for (int r = 0; r < 4; ++r) sc[t][r] = (jb + 16 * t + r) < a.Nk ? sc[t][r] : -INFINITY;
         }
     };
-
     const int hstep = gridDim.z;
     // The chunk steps of this workgroup form one stream (head, pass A / B, chunk); the DMA of step s + STG - 1 is issued at step s.
     // step_sync(): wait for the DMA of the current step (the STG - 2 younger ones may still fly: vmcnt counts 4 K instructions
@@ -1651,17 +1655,18 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cm = fmaxf(cm, sc[t][r]);
             cm = rows4_max(cm);
-            const float mn = fmaxf(m, cm);  // chunk 0 always holds a valid key, so mn is finite
+            const float mn = fmaxf(m, cm);  // chunk 0 always holds a valid key, so mn is finite (m, mn: unscaled)
+            const float off = -mn * c2;
             float cs = 0.f;
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cs += __expf(sc[t][r] - mn);
+                for (int r = 0; r < 4; ++r) cs += __builtin_amdgcn_exp2f(fmaf(sc[t][r], c2, off));
             cs = rows4_sum(cs);
-            l = l * __expf(m - mn) + cs;
+            l = l * __builtin_amdgcn_exp2f((m - mn) * c2) + cs;
             m = mn;
         }
-        const float inv = __builtin_amdgcn_rcpf(l);
+        const float poff = -(m * c2 + __builtin_amdgcn_logf(l));  // P = exp2(c2 s + poff): normalised
         // ---- pass B: probabilities, head-max, CLS row, P.V ----
         f32x4 o[4];
 #pragma unroll
@@ -1677,7 +1682,7 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sc[t][r] = __expf(sc[t][r] - m) * inv;
+                for (int r = 0; r < 4; ++r) sc[t][r] = __builtin_amdgcn_exp2f(fmaf(sc[t][r], c2, poff));
             if constexpr (SCORES) {
                 // head-max of this chunk's 8 key tiles: pmax is indexed statically (registers), so the chunk selects a case
 #define PM_CASE(C)                                                                                      \
@@ -1752,13 +1757,15 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
         }
     }
     if constexpr (SCORES) {
-        if (gridDim.z == 2) {
-            // Two workgroups share this row block, each with half of the heads (launch_attn_bf16_large: launches that would
-            // leave most SIMDs with one wave or none).  The head-max is a max - exact and order-free - so the halves are merged
-            // by whichever wave arrives second: agent-scope stores / loads (written through and read past the L2s: the two
-            // workgroups may sit on different XCDs) around one agent-scope ticket per (row block, wave).
+        if (gridDim.z >= 2) {
+            // gridDim.z workgroups (2..4) share this row block, each with a share of the heads (launch_attn_bf16_large: launches
+            // that would leave most SIMDs with one wave or none, or whose round count a finer split lowers).  The head-max is a max
+            // - exact and order-free - so the shares are merged by whichever wave arrives LAST: agent-scope stores / loads (written
+            // through and read past the L2s: the workgroups may sit on different XCDs) around one agent-scope ticket per (row
+            // block, wave).
+            const int G = gridDim.z;
             const size_t slot = ((size_t)b * gridDim.x + blockIdx.x) * 4 + wave;
-            unsigned* mine = a.hm_ws + ((slot * 2 + blockIdx.z) * (2 * HM_MAX_NT)) * 64 + lane;
+            unsigned* mine = a.hm_ws + ((slot * HM_MAX_GZ + blockIdx.z) * (2 * HM_MAX_NT)) * 64 + lane;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 __hip_atomic_store(mine + (2 * t) * 64, __builtin_bit_cast(unsigned, pmax[t][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1768,15 +1775,18 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
             int old = 0;
             if (lane == 0) old = __hip_atomic_fetch_add(a.hm_tick + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             old = __builtin_amdgcn_readfirstlane(old);
-            if (old == 0) return;  // the other half writes the column sums
+            if (old != G - 1) return;  // the last arriver writes the column sums
             if (lane == 0) __hip_atomic_store(a.hm_tick + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned* theirs = a.hm_ws + ((slot * 2 + (1 - blockIdx.z)) * (2 * HM_MAX_NT)) * 64 + lane;
+            for (int z = 0; z < G; ++z) {
+                if (z == (int)blockIdx.z) continue;
+                const unsigned* theirs = a.hm_ws + ((slot * HM_MAX_GZ + z) * (2 * HM_MAX_NT)) * 64 + lane;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const unsigned u0 = __hip_atomic_load(theirs + (2 * t) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned u1 = __hip_atomic_load(theirs + (2 * t + 1) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pmax[t][0] = __builtin_elementwise_max(pmax[t][0], __builtin_bit_cast(h2, u0));
-                pmax[t][1] = __builtin_elementwise_max(pmax[t][1], __builtin_bit_cast(h2, u1));
+                for (int t = 0; t < NT; ++t) {
+                    const unsigned u0 = __hip_atomic_load(theirs + (2 * t) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned u1 = __hip_atomic_load(theirs + (2 * t + 1) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pmax[t][0] = __builtin_elementwise_max(pmax[t][0], __builtin_bit_cast(h2, u0));
+                    pmax[t][1] = __builtin_elementwise_max(pmax[t][1], __builtin_bit_cast(h2, u1));
+                }
             }
         }
         if (active) {
@@ -1805,10 +1815,24 @@ int launch_attn_bf16_large(const AttnArgs& a_in, hipStream_t s) {
         if (gz > a.H) gz = a.H;
     } else if (NCH * 8 <= HM_MAX_NT && wgs <= HM_MAX_WGS && a.H % 2 == 0) {
         // With scores a row block walks all heads (the head-max).  B x ceil(N/64) <= 256 workgroups of four waves leave the
-        // 1024 SIMDs with one wave or none (VQA: 32 x 7), each bound by its own dependent instruction stream: two workgroups
-        // per row block take half of the heads each and merge their head-max at the end (MADTP_ATTN_HEAD_SPLIT=0: off).
+        // 1024 SIMDs with one wave or none (VQA: 32 x 7), each bound by its own dependent instruction stream: 2..4 workgroups
+        // per row block take a share of the heads each and merge their head-max at the end (MADTP_ATTN_HEAD_SPLIT=0: off).
+        // The split that minimises rounds x heads per workgroup (512 workgroup slots at two per CU, 256 at one): e.g. 32 samples
+        // x 605 keys = 320 row blocks: 2 groups = 640 workgroups = 2 rounds x 6 heads, 3 groups = 960 = 2 rounds x 4 heads.
         HmWorkspace hw;
-        if (hm_workspace(s, hw)) { gz = 2; a.hm_ws = hw.ws; a.hm_tick = hw.tick; }
+        if (hm_workspace(s, hw)) {
+            const int cap = 256 * ((NCH <= 5) ? 2 : 1);
+            int best = 2, best_cost = 1 << 30;
+            for (int z = 2; z <= HM_MAX_GZ; ++z) {
+                if (a.H % z) continue;
+                const int cost = ((wgs * z + cap - 1) / cap) * (a.H / z);
+                if (cost < best_cost) { best_cost = cost; best = z; }
+            }
+            static int gz_env = -1;  // MADTP_ATTN_HEAD_GROUPS=2..4 forces the split (A/B runs)
+            if (gz_env < 0) { const char* e = getenv("MADTP_ATTN_HEAD_GROUPS"); gz_env = e ? atoi(e) : 0; }
+            if (gz_env >= 2 && gz_env <= HM_MAX_GZ && a.H % gz_env == 0) best = gz_env;
+            gz = best; a.hm_ws = hw.ws; a.hm_tick = hw.tick;
+        }
     }
     const dim3 grid((a.Nq + 63) / 64, a.B, gz);
     // Two stages.  The three-stage ring (STG = 3: two chunks in flight behind counted vmcnt waits, 104 KiB, one workgroup per
