@@ -145,11 +145,33 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
 #pragma unroll
                 for (int h = 0; h < HMAX; ++h) if (h < H) c += pz[h] * (on[h] / (hs + 1e-8f));
             } else {
-                for (int r = 0; r < nrt; ++r) a += colsum[((size_t)b * nrt + r) * N + t + 1];
-                for (int h = 0; h < H; ++h) hs += onorm[((size_t)b * H + h) * N + t + 1];
-                for (int h = 0; h < H; ++h) {
-                    const size_t o = ((size_t)b * H + h) * N + t + 1;
-                    c += p0[o] * (onorm[o] / (hs + 1e-8f));
+                // long sequences (nrt = 38..57 row tiles at 605..901 tokens): the same sums in the same order, with the loads of
+                // sixteen row tiles requested before the first add (one load per dependent add was ~60 L2 round trips per token)
+                for (int r0 = 0; r0 < nrt; r0 += RMAX) {
+                    float cs[RMAX];
+#pragma unroll
+                    for (int r = 0; r < RMAX; ++r) cs[r] = r0 + r < nrt ? colsum[((size_t)b * nrt + r0 + r) * N + t + 1] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < RMAX; ++r) if (r0 + r < nrt) a += cs[r];
+                }
+                if (H <= HMAX) {
+                    float on[HMAX], pz[HMAX];
+#pragma unroll
+                    for (int h = 0; h < HMAX; ++h) {
+                        const size_t o = ((size_t)b * H + h) * N + t + 1;
+                        on[h] = h < H ? onorm[o] : 0.f;
+                        pz[h] = h < H ? p0[o] : 0.f;
+                    }
+#pragma unroll
+                    for (int h = 0; h < HMAX; ++h) if (h < H) hs += on[h];
+#pragma unroll
+                    for (int h = 0; h < HMAX; ++h) if (h < H) c += pz[h] * (on[h] / (hs + 1e-8f));
+                } else {
+                    for (int h = 0; h < H; ++h) hs += onorm[((size_t)b * H + h) * N + t + 1];
+                    for (int h = 0; h < H; ++h) {
+                        const size_t o = ((size_t)b * H + h) * N + t + 1;
+                        c += p0[o] * (onorm[o] / (hs + 1e-8f));
+                    }
                 }
             }
             a_loc[u] = a; c_loc[u] = c;
@@ -292,17 +314,33 @@ __global__ __launch_bounds__(512) void token_score_split_kernel(const float* __r
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = blockIdx.x, b = blockIdx.y, n = N - 1, nsamp = gridDim.y;
     const float* ta_g = ta + (size_t)b * ldb;
-    auto TA = [&](int t, int c) -> float { return ta_g[(size_t)t * ldt + c]; };
-
-    // ---- phase A (identical in every workgroup of the sample): row max of the logits, four lanes per row, float4 reads
+    // this workgroup's KC columns of the sample's logits, staged once ([n][KC] f32: <= 57 KiB at 901 tokens and G = 8) - the three
+    // softmax passes of phase B then read LDS instead of walking 64-byte pieces of global rows three times
+    extern __shared__ __attribute__((aligned(16))) float cols_s[];
+    auto TA = [&](int t, int c) -> float { return cols_s[t * KC + (c - g * KC)]; };
     {
-        const int k4 = K >> 2, q = tid & 3;  // K % 4 == 0, ldt % 4 == 0, 16-byte aligned rows (launch condition)
+        constexpr int C4 = KC / 4;
+        for (int idx = tid; idx < n * C4; idx += 512) {
+            const int t = idx / C4, c = (idx - t * C4) * 4;
+            if (g * KC + c < K)  // K % 4 == 0: a float4 is inside the row or not at all
+                *(float4*)(cols_s + t * KC + c) = *(const float4*)(ta_g + (size_t)t * ldt + g * KC + c);
+        }
+    }
+
+    // ---- phase A (identical in every workgroup of the sample): row max of the logits, four lanes per row, float4 reads (all of
+    //      a lane's <= 8 loads of a row are requested before the first max)
+    {
+        const int k4 = K >> 2, q = tid & 3;  // K % 4 == 0, ldt % 4 == 0, 16-byte aligned rows (launch condition); K <= 128
         for (int t = tid >> 2; t < n; t += 128) {
-            float m = -INFINITY;
-            for (int c = q; c < k4; c += 4) {
-                const float4 v = *(const float4*)(ta_g + (size_t)t * ldt + 4 * c);
-                m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = q + 4 * i;
+                v[i] = c < k4 ? *(const float4*)(ta_g + (size_t)t * ldt + 4 * c) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
             }
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m = fmaxf(fmaxf(m, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
             m = fmaxf(m, __shfl_xor(m, 1));
             m = fmaxf(m, __shfl_xor(m, 2));
             if (q == 0) tw_s[t] = m;
@@ -334,11 +372,33 @@ __global__ __launch_bounds__(512) void token_score_split_kernel(const float* __r
 #pragma unroll
                 for (int h = 0; h < HMAX; ++h) if (h < H) c += pz[h] * (on[h] / (hs + 1e-8f));
             } else {
-                for (int r = 0; r < nrt; ++r) a += colsum[((size_t)b * nrt + r) * N + t + 1];
-                for (int h = 0; h < H; ++h) hs += onorm[((size_t)b * H + h) * N + t + 1];
-                for (int h = 0; h < H; ++h) {
-                    const size_t o = ((size_t)b * H + h) * N + t + 1;
-                    c += p0[o] * (onorm[o] / (hs + 1e-8f));
+                // long sequences (nrt = 38..57 row tiles at 605..901 tokens): the same sums in the same order, with the loads of
+                // sixteen row tiles requested before the first add (one load per dependent add was ~60 L2 round trips per token)
+                for (int r0 = 0; r0 < nrt; r0 += RMAX) {
+                    float cs[RMAX];
+#pragma unroll
+                    for (int r = 0; r < RMAX; ++r) cs[r] = r0 + r < nrt ? colsum[((size_t)b * nrt + r0 + r) * N + t + 1] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < RMAX; ++r) if (r0 + r < nrt) a += cs[r];
+                }
+                if (H <= HMAX) {
+                    float on[HMAX], pz[HMAX];
+#pragma unroll
+                    for (int h = 0; h < HMAX; ++h) {
+                        const size_t o = ((size_t)b * H + h) * N + t + 1;
+                        on[h] = h < H ? onorm[o] : 0.f;
+                        pz[h] = h < H ? p0[o] : 0.f;
+                    }
+#pragma unroll
+                    for (int h = 0; h < HMAX; ++h) if (h < H) hs += on[h];
+#pragma unroll
+                    for (int h = 0; h < HMAX; ++h) if (h < H) c += pz[h] * (on[h] / (hs + 1e-8f));
+                } else {
+                    for (int h = 0; h < H; ++h) hs += onorm[((size_t)b * H + h) * N + t + 1];
+                    for (int h = 0; h < H; ++h) {
+                        const size_t o = ((size_t)b * H + h) * N + t + 1;
+                        c += p0[o] * (onorm[o] / (hs + 1e-8f));
+                    }
                 }
             }
             a_loc[u] = a; c_loc[u] = c;
@@ -1433,12 +1493,14 @@ static int token_score_launch(const float* colsum_part, int n_row_tiles, const f
         // long sequence, small batch: G workgroups per sample (column split), so that the launch covers the chip (measured: VQA,
         // 32 samples x 901 tokens, +6.5 % on the whole forward; at 128 samples the one-workgroup kernel already fills half the
         // chip and the repeated phase A costs 2 %)
+        MADTP_ENSURE_MAX_LDS(token_score_split_kernel<8>, (size_t)MAXN * 16 * sizeof(float));
+        MADTP_ENSURE_MAX_LDS(token_score_split_kernel<4>, (size_t)MAXN * 32 * sizeof(float));
         if (B <= 32)
-            hipLaunchKernelGGL(token_score_split_kernel<8>, dim3(8, B), dim3(512), 0, (hipStream_t)stream, colsum_part, n_row_tiles,
+            hipLaunchKernelGGL(token_score_split_kernel<8>, dim3(8, B), dim3(512), (size_t)(N - 1) * 16 * sizeof(float), (hipStream_t)stream, colsum_part, n_row_tiles,
                                p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, H, N, done_ctr, host_slot,
                                seq, tick, part);
         else
-            hipLaunchKernelGGL(token_score_split_kernel<4>, dim3(4, B), dim3(512), 0, (hipStream_t)stream, colsum_part, n_row_tiles,
+            hipLaunchKernelGGL(token_score_split_kernel<4>, dim3(4, B), dim3(512), (size_t)(N - 1) * 32 * sizeof(float), (hipStream_t)stream, colsum_part, n_row_tiles,
                                p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, H, N, done_ctr, host_slot,
                                seq, tick, part);
     } else {
