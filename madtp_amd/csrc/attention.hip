@@ -893,8 +893,10 @@ __global__ __launch_bounds__(64 * SMALL_NW, 1) void attn_bf16_small_kernel(AttnA
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = 16 * t + 4 * g + r;
-            mk[t][r] = j < N ? (a.mask ? a.mask[(size_t)b * N + j] : 0.f) : -INFINITY;
+            mk[t][r] = (j < N ? (a.mask ? a.mask[(size_t)b * N + j] : 0.f) : -INFINITY) * 1.44269504088896341f;
         }
+    const float c2 = a.scale * 1.44269504088896341f;  // log2 units, the same arithmetic as attn_bf16_kernel (bit-identical results:
+                                                      // the sync-free encoder runs that kernel where this one serves the host-k path)
 
     for (int h = wave; h < a.H; h += SMALL_NW) {
         // V_h rows -> private LDS (row-major 128-byte rows, chunk ^= 2*((row>>1)&3) as in the general kernel)
@@ -934,7 +936,7 @@ __global__ __launch_bounds__(64 * SMALL_NW, 1) void attn_bf16_small_kernel(AttnA
                 acc = mfma_lp<F16>(kf[t][1], q1, acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = fmaf(acc[r], a.scale, mk[t][r]);
+                    const float v = fmaf(acc[r], c2, mk[t][r]);
                     acc[r] = v;
                     m = fmaxf(m, v);
                 }
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(64 * SMALL_NW, 1) void attn_bf16_small_kernel(AttnA
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { sc[t][r] = __expf(sc[t][r] - m); sum += sc[t][r]; }
+                for (int r = 0; r < 4; ++r) { sc[t][r] = __builtin_amdgcn_exp2f(sc[t][r] - m); sum += sc[t][r]; }
             sum = rows4_sum(sum);
             const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
@@ -1514,9 +1516,14 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, g = lane >> 4;
+    // (A 1-D grid that puts all row blocks / head groups of a sample on ONE XCD - so that its K and V are fetched by one L2 only -
+    //  was measured SLOWER: 140 -> 164 us at 605 keys, 650 -> 785 us at 901: the 64 resident workgroups of an XCD then walk the
+    //  same K/V lines at the same time.  The round-robin 3-D grid interleaves the samples on every XCD.)
+    const int nrb = gridDim.x, ngz = gridDim.z;
+    const int blk_x = blockIdx.x, blk_z = blockIdx.z;
     const int b = blockIdx.y;
     const int bkv = a.kvidx ? a.kvidx[b] : b;
-    const int rt = blockIdx.x * 4 + wave;
+    const int rt = blk_x * 4 + wave;
     const int i0 = rt * 16;
     const bool active = i0 < a.Nq;
     const int irow = min(i0 + l16, a.Nq - 1);
@@ -1604,12 +1611,12 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
                 for (int r = 0; r < 4; ++r) sc[t][r] = (jb + 16 * t + r) < a.Nk ? sc[t][r] : -INFINITY;
         }
     };
-    const int hstep = gridDim.z;
+    const int hstep = ngz;
     // The chunk steps of this workgroup form one stream (head, pass A / B, chunk); the DMA of step s + STG - 1 is issued at step s.
     // step_sync(): wait for the DMA of the current step (the STG - 2 younger ones may still fly: vmcnt counts 4 K instructions
     // of a pass-A step, 8 K|V instructions of a pass-B step per wave; output stores issued in between only make the wait a
     // little stricter), barrier (every wave is done with the stage that is overwritten next), issue.
-    int st = 0, is_st = 0, is_h = blockIdx.z, is_p = 0, is_c = 0;
+    int st = 0, is_st = 0, is_h = blk_z, is_p = 0, is_c = 0;
     auto issue = [&]() {
         if (is_h < a.H) {
             if (is_p == 0 && is_c == 0) stage_q(is_h);
@@ -1635,7 +1642,7 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
     };
 #pragma unroll
     for (int i = 0; i < STG - 1; ++i) issue();
-    for (int h = blockIdx.z; h < a.H; h += hstep) {
+    for (int h = blk_z; h < a.H; h += hstep) {
         bf16x8 q[2];
         // ---- pass A: row maximum and sum over all keys (online, exact at the end) ----
         float m = -INFINITY, l = 0.f;
@@ -1757,15 +1764,15 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
         }
     }
     if constexpr (SCORES) {
-        if (gridDim.z >= 2) {
+        if (ngz >= 2) {
             // gridDim.z workgroups (2..4) share this row block, each with a share of the heads (launch_attn_bf16_large: launches
             // that would leave most SIMDs with one wave or none, or whose round count a finer split lowers).  The head-max is a max
             // - exact and order-free - so the shares are merged by whichever wave arrives LAST: agent-scope stores / loads (written
             // through and read past the L2s: the workgroups may sit on different XCDs) around one agent-scope ticket per (row
             // block, wave).
-            const int G = gridDim.z;
-            const size_t slot = ((size_t)b * gridDim.x + blockIdx.x) * 4 + wave;
-            unsigned* mine = a.hm_ws + ((slot * HM_MAX_GZ + blockIdx.z) * (2 * HM_MAX_NT)) * 64 + lane;
+            const int G = ngz;
+            const size_t slot = ((size_t)b * nrb + blk_x) * 4 + wave;
+            unsigned* mine = a.hm_ws + ((slot * HM_MAX_GZ + blk_z) * (2 * HM_MAX_NT)) * 64 + lane;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 __hip_atomic_store(mine + (2 * t) * 64, __builtin_bit_cast(unsigned, pmax[t][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1778,7 +1785,7 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
             if (old != G - 1) return;  // the last arriver writes the column sums
             if (lane == 0) __hip_atomic_store(a.hm_tick + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int z = 0; z < G; ++z) {
-                if (z == (int)blockIdx.z) continue;
+                if (z == blk_z) continue;
                 const unsigned* theirs = a.hm_ws + ((slot * HM_MAX_GZ + z) * (2 * HM_MAX_NT)) * 64 + lane;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {

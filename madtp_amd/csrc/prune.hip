@@ -297,13 +297,13 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
 // minimum over the G partial minima (exact, order-free), counts the survivors and takes part in the launch-wide ticket that
 // hands k to the host.  tick / part: per-sample scratch of the hand-over slot (zeroed once, every ticket resets itself).
 template <int G>
-__global__ __launch_bounds__(512) void token_score_split_kernel(const float* __restrict__ colsum, int nrt,
+__global__ __launch_bounds__(512, 2) void token_score_split_kernel(const float* __restrict__ colsum, int nrt,
                                                                 const float* __restrict__ p0, const float* __restrict__ onorm,
                                                                 const float* __restrict__ ta, int ldt, int ldb, int K,
                                                                 float temperature, float* __restrict__ score,
                                                                 float* __restrict__ threshold, int32_t* __restrict__ count, int H, int N,
                                                                 int32_t* done_ctr, int32_t* host_slot, int seq, int32_t* tick,
-                                                                float* part) {
+                                                                float* part, int nsamp) {
     constexpr int KC = 128 / G, S = 512 / KC;  // columns per workgroup, token slices
     __shared__ float I_s[MAXN];
     __shared__ int last_s, lastg_s;
@@ -312,8 +312,20 @@ __global__ __launch_bounds__(512) void token_score_split_kernel(const float* __r
     __shared__ float colred[S][KC];
     __shared__ float colstat[KC];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int g = blockIdx.x, b = blockIdx.y, n = N - 1, nsamp = gridDim.y;
+    // The G workgroups of a sample share its logits and attention statistics, so they sit on ONE XCD (workgroup id % 8 is the
+    // XCD: sample b lives on XCD b % 8, its workgroups are that XCD's slots (b / 8) G .. + G - 1).  With the sample's workgroups
+    // dealt round-robin over the XCDs every L2 fetched every sample (8 x 11.5 MB through the fabric at 32 x 901 tokens: the row
+    // max alone ran 17 us at ~5 TB/s of fabric traffic).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int g = slot % G, b = (slot / G) * 8 + xcd, n = N - 1;
+    if (b >= nsamp) return;
     const float* ta_g = ta + (size_t)b * ldb;
+#ifdef MADTP_TS_TIMING
+#define TSS_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_ts_dbg[i] = wall_clock64(); } while (0)
+#else
+#define TSS_MARK(i)
+#endif
+    TSS_MARK(0);
     // this workgroup's KC columns of the sample's logits, staged once ([n][KC] f32: <= 57 KiB at 901 tokens and G = 8) - the three
     // softmax passes of phase B then read LDS instead of walking 64-byte pieces of global rows three times
     extern __shared__ __attribute__((aligned(16))) float cols_s[];
@@ -327,84 +339,95 @@ __global__ __launch_bounds__(512) void token_score_split_kernel(const float* __r
         }
     }
 
+    TSS_MARK(1);
     // ---- phase A (identical in every workgroup of the sample): row max of the logits, four lanes per row, float4 reads (all of
     //      a lane's <= 8 loads of a row are requested before the first max)
     {
-        const int k4 = K >> 2, q = tid & 3;  // K % 4 == 0, ldt % 4 == 0, 16-byte aligned rows (launch condition); K <= 128
-        for (int t = tid >> 2; t < n; t += 128) {
-            float4 v[8];
+        // eight lanes per row, four float4 per lane (K <= 128), 64 rows per pass and EIGHT passes requested at once (32 loads per
+        // lane in flight: the sample's 360 KB at 901 tokens are two round trips instead of one per 128 rows - the row max was a
+        // third of this kernel).  max is exact and order-free.
+        const int k4 = K >> 2, q = tid & 7;  // K % 4 == 0, ldt % 4 == 0, 16-byte aligned rows (launch condition)
+        for (int tb = tid >> 3; tb < n; tb += 512) {
+            float4 v[8][4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = q + 4 * i;
-                v[i] = c < k4 ? *(const float4*)(ta_g + (size_t)t * ldt + 4 * c) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            for (int ps = 0; ps < 8; ++ps) {
+                const int t = tb + 64 * ps;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = q + 8 * i;
+                    v[ps][i] = (t < n && c < k4) ? *(const float4*)(ta_g + (size_t)t * ldt + 4 * c)
+                                                 : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                }
             }
-            float m = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) m = fmaxf(fmaxf(m, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
-            m = fmaxf(m, __shfl_xor(m, 1));
-            m = fmaxf(m, __shfl_xor(m, 2));
-            if (q == 0) tw_s[t] = m;
+            for (int ps = 0; ps < 8; ++ps) {
+                const int t = tb + 64 * ps;
+                float m = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m = fmaxf(fmaxf(m, fmaxf(v[ps][i].x, v[ps][i].y)), fmaxf(v[ps][i].z, v[ps][i].w));
+                m = fmaxf(m, __shfl_xor(m, 1));
+                m = fmaxf(m, __shfl_xor(m, 2));
+                m = fmaxf(m, __shfl_xor(m, 4));
+                if (q == 0 && t < n) tw_s[t] = m;
+            }
         }
     }
     __syncthreads();
-    constexpr int HMAX = 16, RMAX = 16;
-    float a_loc[2], c_loc[2], suma_l = 0.f, sumt_l = 0.f;
+    TSS_MARK(2);
+    // a = column mass of head-max attention, c = head-diversity weighted CLS attention (as in token_score_kernel: the same sums in
+    // the same order).  Every load of BOTH tokens of a thread is requested before the first add - clamped indices instead of
+    // predicates: straight-line code, no waits at control-flow merges - in batches of 32 row tiles (nrt = 38..57 here).
+    constexpr int HMAX = 16, RB = 32;
+    float a_loc[2] = {0.f, 0.f}, c_loc[2] = {0.f, 0.f}, suma_l = 0.f, sumt_l = 0.f;
+    const int tt[2] = {min(tid, n - 1), min(tid + 512, n - 1)};
+    for (int r0 = 0; r0 < nrt; r0 += RB) {
+        float cs[2][RB];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) cs[u][r] = colsum[((size_t)b * nrt + min(r0 + r, nrt - 1)) * N + tt[u] + 1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) if (r0 + r < nrt) a_loc[u] += cs[u][r];
+    }
+    if (H <= HMAX) {
+        float on[2][HMAX], pz[2][HMAX];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int h = 0; h < HMAX; ++h) {
+                const size_t o = ((size_t)b * H + min(h, H - 1)) * N + tt[u] + 1;
+                on[u][h] = onorm[o];
+                pz[u][h] = p0[o];
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float hs = 0.f, c = 0.f;
+#pragma unroll
+            for (int h = 0; h < HMAX; ++h) if (h < H) hs += on[u][h];
+#pragma unroll
+            for (int h = 0; h < HMAX; ++h) if (h < H) c += pz[u][h] * (on[u][h] / (hs + 1e-8f));
+            c_loc[u] = c;
+        }
+    } else {
+        for (int u = 0; u < 2; ++u) {
+            float hs = 0.f, c = 0.f;
+            for (int h = 0; h < H; ++h) hs += onorm[((size_t)b * H + h) * N + tt[u] + 1];
+            for (int h = 0; h < H; ++h) {
+                const size_t o = ((size_t)b * H + h) * N + tt[u] + 1;
+                c += p0[o] * (onorm[o] / (hs + 1e-8f));
+            }
+            c_loc[u] = c;
+        }
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int t = tid + u * 512;
-        a_loc[u] = 0.f; c_loc[u] = 0.f;
-        if (t < n) {
-            float a = 0.f, hs = 0.f, c = 0.f;
-            if (H <= HMAX && nrt <= RMAX) {
-                float on[HMAX], pz[HMAX], cs[RMAX];
-#pragma unroll
-                for (int h = 0; h < HMAX; ++h) {
-                    const size_t o = ((size_t)b * H + h) * N + t + 1;
-                    on[h] = h < H ? onorm[o] : 0.f;
-                    pz[h] = h < H ? p0[o] : 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < RMAX; ++r) cs[r] = r < nrt ? colsum[((size_t)b * nrt + r) * N + t + 1] : 0.f;
-#pragma unroll
-                for (int r = 0; r < RMAX; ++r) if (r < nrt) a += cs[r];
-#pragma unroll
-                for (int h = 0; h < HMAX; ++h) if (h < H) hs += on[h];
-#pragma unroll
-                for (int h = 0; h < HMAX; ++h) if (h < H) c += pz[h] * (on[h] / (hs + 1e-8f));
-            } else {
-                // long sequences (nrt = 38..57 row tiles at 605..901 tokens): the same sums in the same order, with the loads of
-                // sixteen row tiles requested before the first add (one load per dependent add was ~60 L2 round trips per token)
-                for (int r0 = 0; r0 < nrt; r0 += RMAX) {
-                    float cs[RMAX];
-#pragma unroll
-                    for (int r = 0; r < RMAX; ++r) cs[r] = r0 + r < nrt ? colsum[((size_t)b * nrt + r0 + r) * N + t + 1] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < RMAX; ++r) if (r0 + r < nrt) a += cs[r];
-                }
-                if (H <= HMAX) {
-                    float on[HMAX], pz[HMAX];
-#pragma unroll
-                    for (int h = 0; h < HMAX; ++h) {
-                        const size_t o = ((size_t)b * H + h) * N + t + 1;
-                        on[h] = h < H ? onorm[o] : 0.f;
-                        pz[h] = h < H ? p0[o] : 0.f;
-                    }
-#pragma unroll
-                    for (int h = 0; h < HMAX; ++h) if (h < H) hs += on[h];
-#pragma unroll
-                    for (int h = 0; h < HMAX; ++h) if (h < H) c += pz[h] * (on[h] / (hs + 1e-8f));
-                } else {
-                    for (int h = 0; h < H; ++h) hs += onorm[((size_t)b * H + h) * N + t + 1];
-                    for (int h = 0; h < H; ++h) {
-                        const size_t o = ((size_t)b * H + h) * N + t + 1;
-                        c += p0[o] * (onorm[o] / (hs + 1e-8f));
-                    }
-                }
-            }
-            a_loc[u] = a; c_loc[u] = c;
-            suma_l += a; sumt_l += tw_s[t];
-        }
+        if (t < n) { suma_l += a_loc[u]; sumt_l += tw_s[t]; }
+        else { a_loc[u] = 0.f; c_loc[u] = 0.f; }
     }
+    TSS_MARK(3);
     const float suma = block_sum(suma_l, red, tid, 8);
     const float sumt = block_sum(sumt_l, red, tid, 8);
 #pragma unroll
@@ -420,14 +443,21 @@ __global__ __launch_bounds__(512) void token_score_split_kernel(const float* __r
     }
     __syncthreads();
 
+    TSS_MARK(4);
     // ---- phase B on columns [g KC, (g+1) KC): softmax over tokens of token_attn / T (vit.py:137-139), S token slices
     const int cl = tid % KC, slice = tid / KC, col = g * KC + cl;
     const int t0 = (n * slice) / S, t1 = (n * (slice + 1)) / S;
     const bool cval = col < K;
+    // (the LDS copy is private to this workgroup and element [t][col] is only touched by this thread: x / T and then
+    //  exp(x / T - max) overwrite it in place - each pass's arithmetic is unchanged, it just is not repeated by the next)
     float m = -INFINITY;
     if (cval) {
 #pragma unroll 8
-        for (int t = t0; t < t1; ++t) m = fmaxf(m, TA(t, col) / temperature);
+        for (int t = t0; t < t1; ++t) {
+            const float v = TA(t, col) / temperature;
+            cols_s[t * KC + cl] = v;
+            m = fmaxf(m, v);
+        }
     }
     colred[slice][cl] = m;
     __syncthreads();
@@ -438,7 +468,11 @@ __global__ __launch_bounds__(512) void token_score_split_kernel(const float* __r
     float se = 0.f;
     if (cval) {
 #pragma unroll 8
-        for (int t = t0; t < t1; ++t) se += expf(TA(t, col) / temperature - m);
+        for (int t = t0; t < t1; ++t) {
+            const float e = expf(cols_s[t * KC + cl] - m);
+            cols_s[t * KC + cl] = e;
+            se += e;
+        }
     }
     colred[slice][cl] = se;
     __syncthreads();
@@ -449,7 +483,7 @@ __global__ __launch_bounds__(512) void token_score_split_kernel(const float* __r
     float sw = 0.f;
     if (cval) {
 #pragma unroll 8
-        for (int t = t0; t < t1; ++t) sw += (expf(TA(t, col) / temperature - m) / sum) * I_s[t];
+        for (int t = t0; t < t1; ++t) sw += (cols_s[t * KC + cl] / sum) * I_s[t];
     }
     colred[slice][cl] = sw;
     __syncthreads();
@@ -460,6 +494,7 @@ __global__ __launch_bounds__(512) void token_score_split_kernel(const float* __r
         colstat[tid] = (g * KC + tid) < K ? v : INFINITY;
     }
     __syncthreads();
+    TSS_MARK(5);
     float pm = INFINITY;
     for (int k = lane; k < KC; k += 64) pm = fminf(pm, colstat[k]);
     pm = wave_min(pm);
@@ -471,6 +506,7 @@ __global__ __launch_bounds__(512) void token_score_split_kernel(const float* __r
         lastg_s = atomicAdd(tick + b, 1) == G - 1;
     }
     __syncthreads();
+    TSS_MARK(6);
     if (!lastg_s) return;
     if (tid == 0) __threadfence();
     __syncthreads();
@@ -1496,13 +1532,13 @@ static int token_score_launch(const float* colsum_part, int n_row_tiles, const f
         MADTP_ENSURE_MAX_LDS(token_score_split_kernel<8>, (size_t)MAXN * 16 * sizeof(float));
         MADTP_ENSURE_MAX_LDS(token_score_split_kernel<4>, (size_t)MAXN * 32 * sizeof(float));
         if (B <= 32)
-            hipLaunchKernelGGL(token_score_split_kernel<8>, dim3(8, B), dim3(512), (size_t)(N - 1) * 16 * sizeof(float), (hipStream_t)stream, colsum_part, n_row_tiles,
+            hipLaunchKernelGGL(token_score_split_kernel<8>, dim3(8 * ((B + 7) / 8) * 8), dim3(512), (size_t)(N - 1) * 16 * sizeof(float), (hipStream_t)stream, colsum_part, n_row_tiles,
                                p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, H, N, done_ctr, host_slot,
-                               seq, tick, part);
+                               seq, tick, part, B);
         else
-            hipLaunchKernelGGL(token_score_split_kernel<4>, dim3(4, B), dim3(512), (size_t)(N - 1) * 32 * sizeof(float), (hipStream_t)stream, colsum_part, n_row_tiles,
+            hipLaunchKernelGGL(token_score_split_kernel<4>, dim3(8 * ((B + 7) / 8) * 4), dim3(512), (size_t)(N - 1) * 32 * sizeof(float), (hipStream_t)stream, colsum_part, n_row_tiles,
                                p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, H, N, done_ctr, host_slot,
-                               seq, tick, part);
+                               seq, tick, part, B);
     } else {
         hipLaunchKernelGGL(token_score_kernel<false>, dim3(B), dim3(512), 0, (hipStream_t)stream, colsum_part, n_row_tiles, p0,
                            onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N, done_ctr, host_slot,

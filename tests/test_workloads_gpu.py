@@ -1,6 +1,6 @@
 """One -m gpu test per BASELINE configuration at its CALIBRATED temperature (madtp_amd/configs.py): the workload of bench.py
 --config X (madtp_amd/workloads.py) on a small batch vs the CPU oracle's forward of the same workload (oracle/workloads.py):
-identical per-layer token counts in the fp32 and f16x3 modes, outputs within 1e-3; bf16 stays close."""
+identical per-layer token counts in the fp32 and f16x3 modes, outputs within 1e-3; f16 stays close, bf16 in the neighbourhood."""
 import pytest
 import torch
 
@@ -34,13 +34,17 @@ def test_workload_matches_oracle_at_calibrated_temperature(name, B):
             assert lens[k] == ref_lens[k], (mode, k, lens[k], ref_lens[k])
         for a, b in zip(_flat(out), _flat(ref_out)):
             assert a.shape == b.shape and (a - b).abs().max().item() < 1e-3, (mode, (a - b).abs().max().item())
-    with runtime.precision("bf16"), torch.no_grad():
-        outb = w.step(model, inp, T)
-    for a, b in zip(_flat(outb), _flat(ref_out)):
-        if a.shape == b.shape:
-            err = (a - b).abs().max().item()
-            print(f"{name} bf16: max |dout| {err:.4f} (|out| max {b.abs().max().item():.3f})")
-            assert torch.isfinite(a).all() and err < 0.15 * max(1.0, b.abs().max().item())
+    # fast modes: no bit-exact claim (a rounding difference can flip a token decision, and the sequence lengths - hence the
+    # outputs - then differ from the oracle's from that layer on); f16 (11 significand bits) stays close, bf16 (8 bits) in the
+    # neighbourhood.  At the benchmark batch the decision-level agreement is measured by bench.py's index_match block.
+    for mode, tol in (("f16", 0.05), ("bf16", 0.35)):
+        with runtime.precision(mode), torch.no_grad():
+            outb = w.step(model, inp, T)
+        for a, b in zip(_flat(outb), _flat(ref_out)):
+            if a.shape == b.shape:
+                err = (a - b).abs().max().item()
+                print(f"{name} {mode}: max |dout| {err:.4f} (|out| max {b.abs().max().item():.3f})")
+                assert torch.isfinite(a).all() and err < tol * max(1.0, b.abs().max().item()), (mode, err)
     # the analytic FLOP counter is consistent: pruned < unpruned, ratio in (0, 1)
     assert 0 < w.flops(lens) < w.flops(None)
 

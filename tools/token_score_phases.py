@@ -16,3 +16,17 @@ for B, N in ((128, 97), (128, 197), (64, 20)):
     lib.madtp_debug_read_ts(out)
     t = list(out)[:7]
     print(f"B={B} N={N}: " + " ".join(f"{(t[i + 1] - t[i]) * 10}ns" for i in range(6)), " total", (t[6] - t[0]) * 10, "ns")
+
+# long sequences: token_score_split_kernel (workgroup (0, 0)): staging issue | row max | per-token terms | sums + I | phase B | publish
+for B, N in ((32, 901), (32, 605), (32, 430)):
+    H, K = 12, 100
+    nrt = (N + 15) // 16
+    cs = torch.rand(B, nrt, N, device="cuda"); p0 = torch.rand(B, H, N, device="cuda"); on = torch.rand(B, H, N, device="cuda")
+    ta = torch.randn(B, N, 128, device="cuda")[:, 1:, :K]
+    for _ in range(3):
+        hip.token_score_sync((cs, p0, on), ta, 5.0, B, H, N)
+    torch.cuda.synchronize()
+    out = (ctypes.c_longlong * 16)()
+    lib.madtp_debug_read_ts(out)
+    t = list(out)[:7]
+    print(f"split B={B} N={N}: " + " ".join(f"{(t[i + 1] - t[i]) * 10}ns" for i in range(6)), " total", (t[6] - t[0]) * 10, "ns")
