@@ -269,6 +269,14 @@ int madtp_cast_bf16(const float* src, void* dst, size_t n, void* stream);
  * as w * 2^s so that small weights stay clear of the f16 subnormals; the GEMM's acc_scale 2^-s undoes it). */
 int madtp_cast_lp(const float* src, void* dst, size_t n, int lp_dtype, float scale, void* stream);
 
+/* Score arithmetic of the FAST precision modes (bf16 / f16): with on != 0 `madtp_token_score*` and the layer / encoder calls run
+ * the softmax over tokens of vit.py:137-139 in log2 units with the hardware exp2 and one reciprocal per dictionary column instead
+ * of two IEEE divisions and a precise expf per logit (that phase is VALU-bound: 10 of 17 us at 197 tokens).  The parity modes
+ * (fp32, f16x3) keep on = 0: their arithmetic is the reference's.  Process-wide, set together with the precision mode
+ * (madtp_amd/runtime.py); only the one-workgroup-per-sample kernel (token logits resident in LDS) has the fast form.  Returns
+ * the previous value.  No reference counterpart. */
+int madtp_set_score_fast(int on);
+
 /* Range flag of the f16 formats (MADTP_F16S planes and MADTP_F16 operands): a producer kernel (madtp_split_f16, the LayerNorm /
  * GEMM / attention epilogues that emit f16) that meets a value outside the f16 range (|x| >= 65504 or NaN) sets a sticky flag in
  * pinned host memory instead of silently handing an infinity on (which the next GEMM would turn into NaNs).  Returns the flag

@@ -36,7 +36,12 @@ def transpose_pad(src, rows_pad, cols_pad):
 def dgrad(dy, weight):
     """dX[M, K] = dY[M, N] @ W[N, K] (nn.Linear weight layout)."""
     N, K = weight.shape
-    wt = transpose_pad(weight, N, _pad(K, 128))  # [Kpad, N]: the GEMM's "weight" with K' = N contiguous
+    Np = _pad(N, 32)  # the GEMM's reduction length (f32 slabs of 32): zero columns for e.g. the 100 dictionary columns
+    if Np != N:
+        dyp = torch.zeros((dy.shape[0], Np), device=dy.device, dtype=torch.float32)
+        dyp[:, :N] = dy
+        dy = dyp
+    wt = transpose_pad(weight, Np, _pad(K, 128))  # [Kpad, Np]: the GEMM's "weight" with K' = N contiguous
     return hip.gemm(dy, wt, n=K, out_dtype=torch.float32)
 
 
@@ -234,3 +239,108 @@ def block_forward_with_grad(blk, x, temperature, token_attn):
     if token_attn is not None and not token_attn.is_contiguous():
         token_attn = token_attn.contiguous()
     return VitBlockFunction.apply(blk, temperature, x, token_attn, *_params_of(blk))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The whole pruned ViT under autograd (fp32 mode): patch embedding + CLS / position (vit.py:283-289), the query model's logits
+# (models/utils.py:165-166), the twelve blocks (VitBlockFunction) and the final LayerNorm (vit.py:309).  sd_img_ft_all - the
+# second output of VisionTransformer.forward, consumed by the training drivers' alignment loss - is returned WITHOUT a graph
+# (its softmax-over-tokens backward is not built yet); gradients flow from the image tokens.
+
+class PatchTokensFunction(torch.autograd.Function):
+    """x = cat(cls, conv(img)) + pos_embed[:, :N] (vit.py:283-289; conv = im2col + GEMM, madtp_amd.vit.PatchEmbed).
+    Gradients for the projection weight / bias, cls_token and pos_embed; none for the image."""
+
+    @staticmethod
+    def forward(ctx, vit, img, w, b, cls, pos):
+        patches, np_ = vit.patch_embed.run(img)
+        B = img.shape[0]
+        x = hip.assemble_tokens(patches, cls, pos, B, np_)
+        ctx.vit, ctx.np_, ctx.patch = vit, np_, vit.patch_embed.patch_size[0]
+        ctx.has_b = b is not None
+        ctx.save_for_backward(img, w, pos)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        img, w, pos = ctx.saved_tensors
+        B, N, D = dx.shape
+        with torch.no_grad():
+            dx = dx.contiguous().float()
+            dtok = colsum(dx.view(B, N * D)).view(N, D)          # sum over the batch: d pos_embed[:, :N] (row 0 = d cls_token too)
+            dpos = torch.zeros_like(pos)
+            dpos[0, :N] = dtok
+            dcls = dtok[0].reshape(1, 1, D).clone()
+            dpatch = dx[:, 1:, :].reshape(B * ctx.np_, D).contiguous()
+            cols = hip.patchify(img.contiguous().float(), ctx.patch, torch.float32)
+            dw = wgrad(dpatch, cols).view_as(w)
+            db = colsum(dpatch) if ctx.has_b else None
+        return None, None, dw, db, dcls, dpos
+
+
+class QueryLogitsFunction(torch.autograd.Function):
+    """token_att = ft @ sd^T (models/utils.py:165-166, raw logits) on the exact-f32 GEMM; ft2d [M, D], sd [K, D]."""
+
+    @staticmethod
+    def forward(ctx, ft2d, sd):
+        K = sd.shape[0]
+        kp = _pad(K, 128)
+        w = sd.detach()
+        if kp != K:
+            w = torch.zeros((kp, sd.shape[1]), device=sd.device, dtype=torch.float32)
+            w[:K] = sd.detach()
+        ctx.save_for_backward(ft2d, sd)
+        return hip.gemm(ft2d.contiguous(), w.contiguous(), None, n=K, out_dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, dl):
+        ft2d, sd = ctx.saved_tensors
+        with torch.no_grad():
+            dl = dl.contiguous().float()
+            dft = dgrad(dl, sd.detach()) if ctx.needs_input_grad[0] else None
+            dsd = wgrad(dl, ft2d.contiguous()) if ctx.needs_input_grad[1] else None
+        return dft, dsd
+
+
+class LayerNormFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        ctx.eps = float(eps)
+        ctx.save_for_backward(x, gamma)
+        y, _ = hip.layernorm(x.contiguous(), gamma.detach(), beta.detach(), eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        D = x.shape[-1]
+        with torch.no_grad():
+            dx, dg, db = layernorm_bwd(x.reshape(-1, D).contiguous(), gamma.detach(), dy.reshape(-1, D).contiguous().float(), ctx.eps)
+        return dx.view_as(x), dg, db, None
+
+
+def vit_forward_with_grad(vit, img, space_dict, temperature):
+    """VisionTransformer.forward (vit.py:281-310) under autograd -> (x, sd_img_ft_all); called by madtp_amd.vit when gradients
+    are required in the fp32 mode."""
+    from . import runtime
+    if runtime.get_precision() != "fp32":
+        raise NotImplementedError("the ViT backward is built for the fp32 precision mode (runtime.precision('fp32')); "
+                                  f"current mode: {runtime.get_precision()}")
+    if img.requires_grad:
+        raise NotImplementedError("gradients with respect to the image are not built (the drivers never ask for them)")
+    pe = vit.patch_embed.proj
+    x = PatchTokensFunction.apply(vit, img, pe.weight, pe.bias, vit.cls_token, vit.pos_embed)
+    token_num = x.shape[-2]
+    reduce_num = int((token_num - 1) // vit.depth)
+    sd_all = None
+    for blk in vit.blocks:
+        if space_dict is not None:
+            B, N, D = x.shape
+            with torch.no_grad():  # :297-303, the running att_ft sum: values only (see the note above)
+                _, sd_all, _ = vit.img_query_model(x.detach()[:, 1:, :], space_dict.detach(), return_token_att=True, acc_ft=sd_all)
+            ft2d = x[:, 1:, :].reshape(B * (N - 1), D)
+            token_attn = QueryLogitsFunction.apply(ft2d, space_dict).view(B, N - 1, -1)
+            x = blk(x, False, reduce_num, temperature, token_attn)  # :304 (Block.forward routes to VitBlockFunction)
+        else:
+            x = blk(x, False)
+    return LayerNormFunction.apply(x, vit.norm.weight, vit.norm.bias, vit.norm.eps), sd_all

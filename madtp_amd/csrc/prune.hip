@@ -11,6 +11,7 @@
 #include "internal.h"
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <vector>
@@ -55,7 +56,10 @@ __device__ long long g_ts_dbg[16];
 #else
 #define TS_MARK(i)
 #endif
-template <bool STAGED>
+// FAST (fast precision modes only, madtp_set_score_fast): phase B in log2 units with v_exp_f32 and one reciprocal per column
+// instead of two IEEE divisions and a precise expf per logit - phase B is VALU-bound (10 of 17 us at 197 tokens) and the parity
+// modes' arithmetic (FAST = false) has to stay what the reference computes.
+template <bool STAGED, bool FAST = false>
 __global__ __launch_bounds__(512) void token_score_kernel(const float* __restrict__ colsum, int nrt,
                                                           const float* __restrict__ p0, const float* __restrict__ onorm,
                                                           const float* __restrict__ ta, int ldt_g, int ldb, int K, float temperature,
@@ -203,10 +207,11 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     //  so x/T and then exp(x/T - max) overwrite it in place - the arithmetic of each pass is unchanged, it just is not
     //  repeated by the next one)
     float m = -INFINITY;
+    const float c2 = 1.44269504088896341f / temperature;  // FAST: logits in log2 units
     if (cval) {
 #pragma unroll 8
         for (int t = t0; t < t1; ++t) {
-            const float v = TA(t, col) / temperature;
+            const float v = (FAST && STAGED) ? TA(t, col) * c2 : TA(t, col) / temperature;
             if constexpr (STAGED) ta_s[t * K + col] = v;
             m = fmaxf(m, v);
         }
@@ -220,7 +225,8 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
 #pragma unroll 8
         for (int t = t0; t < t1; ++t) {
             float e;
-            if constexpr (STAGED) { e = expf(ta_s[t * K + col] - m); ta_s[t * K + col] = e; }
+            if constexpr (FAST && STAGED) { e = __builtin_amdgcn_exp2f(ta_s[t * K + col] - m); ta_s[t * K + col] = e; }
+            else if constexpr (STAGED) { e = expf(ta_s[t * K + col] - m); ta_s[t * K + col] = e; }
             else e = expf(TA(t, col) / temperature - m);
             se += e;
         }
@@ -231,10 +237,16 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     __syncthreads();
     float sw = 0.f;
     if (cval) {
+        if constexpr (FAST && STAGED) {
 #pragma unroll 8
-        for (int t = t0; t < t1; ++t) {
-            const float e = STAGED ? ta_s[t * K + col] : expf(TA(t, col) / temperature - m);
-            sw += (e / sum) * I_s[t];
+            for (int t = t0; t < t1; ++t) sw = fmaf(ta_s[t * K + col], I_s[t], sw);
+            sw *= __builtin_amdgcn_rcpf(sum);
+        } else {
+#pragma unroll 8
+            for (int t = t0; t < t1; ++t) {
+                const float e = STAGED ? ta_s[t * K + col] : expf(TA(t, col) / temperature - m);
+                sw += (e / sum) * I_s[t];
+            }
         }
     }
     colred[slice][col] = sw;
@@ -1504,6 +1516,12 @@ __global__ __launch_bounds__(768, 1) void align_ws_kernel(const float* __restric
 }  // namespace
 
 constexpr int SPLIT_MAX_B = 1024, SPLIT_MAX_G = 8;  // per-slot scratch of token_score_split_kernel
+// Score arithmetic of the fast precision modes (token_score_kernel<.., FAST>): a process-wide switch like the GEMM hints, set by
+// the caller together with its precision mode (madtp_amd/runtime.py).  -> previous value.
+static std::atomic<int> g_score_fast{0};
+static bool score_fast() { return g_score_fast.load(std::memory_order_relaxed) != 0; }
+extern "C" int madtp_set_score_fast(int on) { return g_score_fast.exchange(on ? 1 : 0, std::memory_order_relaxed); }
+
 static bool split_enabled() {  // MADTP_TS_SPLIT=0: always one workgroup per sample (A/B runs)
     static int v = -1;
     if (v < 0) { const char* e = getenv("MADTP_TS_SPLIT"); v = e ? atoi(e) : 1; }
@@ -1520,10 +1538,17 @@ static int token_score_launch(const float* colsum_part, int n_row_tiles, const f
     const size_t stage_bytes = (size_t)(N - 1) * K * sizeof(float);
     const bool staged = K % 4 == 0 && ldt % 4 == 0 && ldb % 4 == 0 && aligned16(token_attn) && stage_bytes <= 140 * 1024;
     if (staged) {
-        MADTP_ENSURE_MAX_LDS(token_score_kernel<true>, 140 * 1024);
-        hipLaunchKernelGGL(token_score_kernel<true>, dim3(B), dim3(512), stage_bytes, (hipStream_t)stream, colsum_part,
-                           n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N,
-                           done_ctr, host_slot, seq);
+        if (score_fast()) {
+            MADTP_ENSURE_MAX_LDS((token_score_kernel<true, true>), 140 * 1024);
+            hipLaunchKernelGGL((token_score_kernel<true, true>), dim3(B), dim3(512), stage_bytes, (hipStream_t)stream, colsum_part,
+                               n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N,
+                               done_ctr, host_slot, seq);
+        } else {
+            MADTP_ENSURE_MAX_LDS(token_score_kernel<true>, 140 * 1024);
+            hipLaunchKernelGGL(token_score_kernel<true>, dim3(B), dim3(512), stage_bytes, (hipStream_t)stream, colsum_part,
+                               n_row_tiles, p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N,
+                               done_ctr, host_slot, seq);
+        }
     } else if (tick && part && !kmax && B <= SPLIT_MAX_B && B <= 64 && K % 4 == 0 && ldt % 4 == 0 && ldb % 4 == 0 &&
                aligned16(token_attn) && split_enabled()) {
         // long sequence, small batch: G workgroups per sample (column split), so that the launch covers the chip (measured: VQA,
@@ -1723,10 +1748,17 @@ int madtp_i_token_score_dev(const float* colsum_part, const float* p0, const flo
     const bool staged = K % 4 == 0 && ldt % 4 == 0 && aligned16(logits) && stage_bytes <= 140 * 1024;
     const float* ta = logits + ldt;  // row 0 of every sample is the CLS token
     if (staged) {  // (the same kernel variant as the host-side path takes at any n <= N_max - 1: same arithmetic)
-        MADTP_ENSURE_MAX_LDS(token_score_kernel<true>, 140 * 1024);
-        hipLaunchKernelGGL(token_score_kernel<true>, dim3(B), dim3(512), stage_bytes, (hipStream_t)stream, colsum_part,
-                           (N_max + 15) / 16, p0, onorm, ta, ldt, N_max * ldt, K, temperature, score, threshold, count,
-                           (int32_t*)nullptr, H, N_max, ticket, (int32_t*)nullptr, 0, dims_l);
+        if (score_fast()) {
+            MADTP_ENSURE_MAX_LDS((token_score_kernel<true, true>), 140 * 1024);
+            hipLaunchKernelGGL((token_score_kernel<true, true>), dim3(B), dim3(512), stage_bytes, (hipStream_t)stream, colsum_part,
+                               (N_max + 15) / 16, p0, onorm, ta, ldt, N_max * ldt, K, temperature, score, threshold, count,
+                               (int32_t*)nullptr, H, N_max, ticket, (int32_t*)nullptr, 0, dims_l);
+        } else {
+            MADTP_ENSURE_MAX_LDS(token_score_kernel<true>, 140 * 1024);
+            hipLaunchKernelGGL(token_score_kernel<true>, dim3(B), dim3(512), stage_bytes, (hipStream_t)stream, colsum_part,
+                               (N_max + 15) / 16, p0, onorm, ta, ldt, N_max * ldt, K, temperature, score, threshold, count,
+                               (int32_t*)nullptr, H, N_max, ticket, (int32_t*)nullptr, 0, dims_l);
+        }
     } else {
         hipLaunchKernelGGL(token_score_kernel<false>, dim3(B), dim3(512), 0, (hipStream_t)stream, colsum_part, (N_max + 15) / 16, p0,
                            onorm, ta, ldt, N_max * ldt, K, temperature, score, threshold, count, (int32_t*)nullptr, H, N_max, ticket,

@@ -13,7 +13,7 @@ import torch
 F32, BF16, F16S, F16 = 0, 1, 2, 3  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 #                                    F16: plain IEEE f16 operands (the "f16" fast mode), see set_lp_format below
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -27,6 +27,7 @@ _SIGS = {
     "madtp_gemm_set_config": (c_int, [c_int]),
     "madtp_gemm_set_sq_cost": (c_float, [c_float]),
     "madtp_gemm_set_small_tile": (c_int, [c_int]),
+    "madtp_set_score_fast": (c_int, [c_int]),
     "madtp_gemm_splitk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "madtp_splitk_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_float, c_float, c_float, c_void_p]),
@@ -173,6 +174,7 @@ def load(path=None):
     if v != ABI_VERSION:
         raise RuntimeError(f"libmadtp_hip ABI {v} != binding {ABI_VERSION}; rebuild")
     _lib = lib
+    lib.madtp_set_score_fast(_score_fast)
     return lib
 
 
@@ -292,6 +294,19 @@ def gemm_set_sq_cost(cost):
     """madtp_gemm_set_sq_cost (include/madtp_hip.h): dispatch hint for callers that keep several forwards in flight; cost <= 0
     restores the default.  -> previous value."""
     return float(load().madtp_gemm_set_sq_cost(float(cost)))
+
+
+_score_fast = 0  # (madtp_amd.runtime sets it with the precision mode, its default included)
+
+
+def set_score_fast(on):
+    """madtp_set_score_fast (include/madtp_hip.h): fast-mode arithmetic of token_score's softmax over tokens.  Remembered
+    until the library is loaded (setting a precision mode must not need the library).  -> previous."""
+    global _score_fast
+    prev, _score_fast = _score_fast, 1 if on else 0
+    if _lib is not None:
+        _lib.madtp_set_score_fast(_score_fast)
+    return prev
 
 
 def gemm_set_small_tile(cfg):

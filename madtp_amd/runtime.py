@@ -21,6 +21,7 @@ Precision modes (SURVEY.md section 7 "hard parts"):
             the f16 range raises the library's range flag (MADTP_E_RANGE at the layer's host read of k, hip.range_status())
             instead of turning into NaNs.  Operands live in torch.bfloat16-typed containers (hip.set_lp_format).
 """
+import os
 import threading
 
 import torch
@@ -38,6 +39,11 @@ def set_precision(mode: str):
         raise ValueError(f"precision must be one of {MODES}")
     _state.mode = mode
     hip.set_lp_format(hip.F16 if mode == "f16" else hip.BF16)
+    hip.set_score_fast(mode in ("bf16", "f16") and _SCORE_FAST)  # process-wide, like the element format: the modes of concurrent threads agree
+
+
+_SCORE_FAST = os.environ.get("MADTP_SCORE_FAST", "1") != "0"  # A/B switch: the fast modes on the reference score arithmetic
+hip.set_score_fast(_DEFAULT in ("bf16", "f16") and _SCORE_FAST)  # (remembered by the binding until the library is loaded)
 
 
 def get_precision() -> str:

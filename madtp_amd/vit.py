@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import EncoderWeights, PreparedCache, param_epoch, encoder_call_preference, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
+from .runtime import EncoderWeights, PreparedCache, param_epoch, get_precision, encoder_call_preference, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model, vector_gather  # noqa: F401  (re-exported like `from models.utils import *`)
 
 import os as _os
@@ -312,6 +312,12 @@ class VisionTransformer(nn.Module):
         """_pending (extension used by BLIP_NLVR): a list - the fast-mode sum of the layers' att_ft then runs on the
         auxiliary stream and the caller makes its stream wait (handle.sync()) before sd_img_ft_all is consumed."""
         B = x.shape[0]
+        if (torch.is_grad_enabled() and register_blk == -1 and get_precision() == "fp32" and type(self) is VisionTransformer
+                and (any(p.requires_grad for p in self.parameters()) or (space_dict is not None and space_dict.requires_grad))):
+            # training / compression use (SURVEY 8(f) rank 4): every stage of the forward as an autograd.Function around the same
+            # kernels (madtp_amd/backward.py); inference callers run under torch.no_grad() as the reference's evaluate() does
+            from .backward import vit_forward_with_grad
+            return vit_forward_with_grad(self, x, space_dict, temperature)
         enc_prep = None
         if (register_blk == -1 and use_encoder_call(B * (self.patch_embed.num_patches + 1), _ENCODER_CALL)
                 and all(type(b) is Block and not b.attn.keep_attention_map for b in self.blocks)

@@ -34,7 +34,7 @@ def check_against_fixture(g, grads, rtol, what):
     for name in names:
         t = grads[name].detach().float().cpu().reshape(-1)
         ref = torch.from_numpy(g[f"g_{name}_sample"])
-        got = t[torch.from_numpy(grad_sample_index(t.numel()))]
+        got = t[torch.from_numpy(grad_sample_index(t.numel(), int(g["nsample"]) if "nsample" in g.files else 1024))]
         scale = max(float(ref.abs().max()), 1e-12)
         err = float((got - ref).abs().max()) / scale
         assert err < rtol, f"{what}: grad {name}: sampled entries differ by {err:.3e} of their maximum (tolerance {rtol})"
@@ -53,3 +53,11 @@ def permute_G(G, ref_indices, own_indices):
         for p in range(k):
             out[b, 1 + p] = G[b, 1 + pos[int(own_indices[b, p])]]
     return out
+
+
+def vit_loss_vectors(g):
+    """(g, h) of oracle.vit_loss for a encgrad_* fixture (tools/make_golden.py::vit_grad_case)."""
+    from madtp_amd import synth as S
+    B, seed = int(g["B"]), int(g["seed"])
+    return (torch.from_numpy(S.uniform_pm1("vitgrad_g", B * 768, seed).reshape(B, 768)),
+            torch.from_numpy(S.uniform_pm1("vitgrad_h", B * 768, seed).reshape(B, 768)))

@@ -143,3 +143,48 @@ def test_block_backward_needs_fp32_mode(hip):
     x = torch.randn(1, 20, 768, device="cuda", requires_grad=True)
     with runtime.precision("bf16"), pytest.raises(NotImplementedError):
         blk(x)
+
+
+VITGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "encgrad_*.npz")))
+
+
+@pytest.mark.parametrize("path", VITGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in VITGRAD_CASES])
+def test_vit_backward_matches_reference_grads(hip, path):
+    """The whole pruned ViT under autograd (madtp_amd/backward.py::vit_forward_with_grad: patch embedding + CLS / position, the
+    query model's logits, twelve VitBlockFunctions, final LayerNorm; fp32 mode) against the reference's own .grad of
+    models/vit.py VisionTransformer.forward for all 150 parameters and space_dict (tests/golden/encgrad_*.npz), loss =
+    oracle.vit_loss on the image tokens (token-order invariant).  Tolerance 1e-3 of each gradient's largest entry; the per-layer
+    kept sets must equal the recording (otherwise the gradients are not comparable)."""
+    from madtp_amd import runtime, synth
+    from oracle import madtp_oracle as O
+    from tests import grad_case
+    g = np.load(path)
+    B, size, T, seed = int(g["B"]), int(g["size"]), float(g["temperature"]), int(g["seed"])
+    from madtp_amd import specs, vit as mvit
+    venc = mvit.VisionTransformer(img_size=size, patch_size=16, embed_dim=768, depth=12, num_heads=12, evaluate=True, sd_dim=768)
+    venc.load_state_dict(specs.synth_weights(specs.vit_shapes("", size), seed), strict=True)
+    venc = venc.cuda().eval()
+    for p_ in venc.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    images = synth.synth_images(B, size, seed).cuda()
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed).cuda().requires_grad_(True)
+    gv, hv = [t.cuda() for t in grad_case.vit_loss_vectors(g)]
+    with runtime.precision("fp32"):
+        y, sd_all = venc(images, space_dict=space_dict, temperature=T)
+        assert y.requires_grad and tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
+        # kept sets as ORIGINAL patch ids (the two sides order a layer's tokens differently, SURVEY.md section 7)
+        from madtp_amd import harness
+        n0 = (size // 16) ** 2
+        ref_trace = [{"pruned": True, "indices": g[f"vit{i}_idx"]} if f"vit{i}_idx" in g.files else None for i in range(12)]
+        own_trace = [None if blk.last_prune is None or not blk.last_prune.get("pruned") else
+                     {"pruned": True, "indices": blk.last_prune["indices"].cpu()} for blk in venc.blocks]
+        assert harness.compose_ids(own_trace, n0) == harness.compose_ids(ref_trace, n0), "kept sets differ from the recording"
+        assert abs(float(y.detach().double().norm()) - float(g["y_norm"])) < 1e-4 * float(g["y_norm"])
+        O.vit_loss(y, gv, hv).backward()
+    assert sd_all is not None and not sd_all.requires_grad
+    grads = {k: v.grad for k, v in venc.named_parameters() if v.grad is not None}
+    grads["space_dict"] = space_dict.grad
+    missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]
+    assert not missing, f"no gradient produced for {missing[:5]}"
+    grad_case.check_against_fixture(g, grads, 1e-3, "HIP ViT backward vs reference")

@@ -17,6 +17,7 @@ def hip():
     build.build(verbose=False)
     h.load()
     assert torch.cuda.is_available()
+    h.set_score_fast(0)  # kernel tests check the reference arithmetic; the fast modes' form has its own test below
     return h
 
 
@@ -417,6 +418,29 @@ def test_token_score_select_gather(hip, B, N, T):
         mg = hip.mask_gather(m2.cuda(), idx_sort, k)
         ref_m = torch.cat([m2[:, :1], torch.gather(m2[:, 1:], 1, order[:, : k + 1])], 1)
         assert torch.equal(mg.cpu(), ref_m)
+
+
+@pytest.mark.parametrize("B,N,T", [(4, 197, 1.0), (5, 131, 10.0), (2, 20, 3.0)])
+def test_token_score_fast_arithmetic(hip, B, N, T):
+    """madtp_set_score_fast: the fast modes' softmax over tokens (log2 units, hardware exp2, one reciprocal per column) against the
+    reference arithmetic of the same kernel: same scores (phase A is shared), thresholds within float noise, counts equal wherever
+    no score sits within that noise of the threshold."""
+    H, K = 12, 100
+    g = torch.Generator().manual_seed(77)
+    nrt = (N + 15) // 16
+    side = tuple(torch.rand(*shp, generator=g).cuda() for shp in ((B, nrt, N), (B, H, N), (B, H, N)))
+    ta = torch.randn(B, N - 1, K, generator=g).cuda() * 3.0
+    exact = hip.token_score(side, ta, T, B, H, N)
+    assert hip.set_score_fast(1) == 0
+    try:
+        fast = hip.token_score(side, ta, T, B, H, N)
+    finally:
+        assert hip.set_score_fast(0) == 1
+    assert torch.equal(fast[0], exact[0])
+    assert (fast[1] - exact[1]).abs().max().item() < 2e-6 * exact[1].abs().max().item() + 1e-9
+    margin = (exact[0] - exact[1][:, None]).abs().min(1)[0]
+    safe = margin > 1e-6 * exact[1].abs()
+    assert safe.any() and torch.equal(fast[2][safe], exact[2][safe])
 
 
 @pytest.mark.parametrize("B,N", [(1, 20), (7, 131), (130, 81)])

@@ -576,10 +576,37 @@ def test_oracle_block_backward_matches_reference_grads(path):
     from tests import grad_case
     g = np.load(path)
     c = grad_case.build(g)
-    assert np.allclose(c["x"][:, :2, :8].numpy(), g["x_head"], atol=0, rtol=0), "block input differs from the recording"
-    assert np.allclose(c["token_attn"][:, :2, :8].numpy(), g["ta_head"], rtol=1e-6, atol=1e-6)
+    # (layer 0's input is the patch embedding; deeper inputs went through `layer` blocks of CPU matmuls whose summation order
+    #  depends on the thread count of the moment: float noise, not bits)
+    assert np.allclose(c["x"][:, :2, :8].numpy(), g["x_head"], rtol=2e-5, atol=2e-6), "block input differs from the recording"
+    assert np.allclose(c["token_attn"][:, :2, :8].numpy(), g["ta_head"], rtol=2e-5, atol=1e-4)
     grads, y, info = O.vit_block_grads(c["W"], c["prefix"], c["x"], c["token_attn"], c["T"], c["G"])
     assert tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
     assert {int(v) for v in info["indices"][0]} == {int(v) for v in g["blk_idx"][0]}
     assert np.allclose(y[:, :3, :16].numpy(), g["y_head"], rtol=1e-5, atol=1e-6)
     grad_case.check_against_fixture(g, grads, 2e-5, "oracle autograd vs reference")
+
+
+VITGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "encgrad_*.npz")))
+
+
+@pytest.mark.parametrize("path", VITGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in VITGRAD_CASES])
+def test_oracle_vit_backward_matches_reference_grads(path):
+    """SURVEY 8(f) rank 4, the whole encoder: autograd through oracle.vit_forward == the reference's own .grad of
+    models/vit.py VisionTransformer.forward (all 150 parameters + space_dict; loss oracle.vit_loss on the image tokens), recorded
+    by tools/make_golden.py::vit_grad_case.  Pins the checker of the HIP path's ViT backward (tests/test_backward_gpu.py)."""
+    from madtp_amd import specs, synth
+    from tests import grad_case
+    g = np.load(path)
+    B, size, T, seed = int(g["B"]), int(g["size"]), float(g["temperature"]), int(g["seed"])
+    W = specs.synth_weights(specs.vit_shapes("", size), seed)
+    images = synth.synth_images(B, size, seed)
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed)
+    gv, hv = grad_case.vit_loss_vectors(g)
+    grads, y, trace = O.vit_grads(W, "", images, space_dict, T, gv, hv)
+    assert tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
+    assert abs(float(y.double().norm()) - float(g["y_norm"])) < 1e-5 * float(g["y_norm"])
+    for i, t in enumerate(trace):
+        if f"vit{i}_idx" in g.files:
+            assert [set(r.tolist()) for r in t["indices"]] == [set(r.tolist()) for r in g[f"vit{i}_idx"]], f"layer {i} kept sets"
+    grad_case.check_against_fixture(g, grads, 5e-5, "oracle autograd vs reference (whole ViT)")

@@ -284,6 +284,50 @@ def vit_block_grad_case(name, B, size, temperature, layer=0, seed=0):
     print(f"[{name}] layer {layer} T={temperature} out {tuple(y.shape)} |dx| {rec['g_x_norm']:.4e} |dta| {rec['g_token_attn_norm']:.4e}")
 
 
+def vit_grad_case(name, B, size, temperature, seed=0, nsample=256):
+    """SURVEY 8(f) rank 4 (backward), the whole encoder: the reference's OWN autograd through models/vit.py
+    VisionTransformer.forward (12 pruned blocks, query-model logits, patch embedding, final LayerNorm) with every parameter and
+    space_dict as leaves, loss = oracle.vit_loss(y, g, h) (token-order invariant).  Recorded: per-layer lengths and kept sets, the
+    output's head, and of every gradient its L2 norm, sum and `nsample` sampled entries (grad_sample_index) - data only."""
+    import models.vit as rvit
+    from madtp_amd import specs
+    from oracle import madtp_oracle as O
+    model = rvit.VisionTransformer(img_size=size, patch_size=16, embed_dim=768, depth=12, num_heads=12, evaluate=True, sd_dim=768)
+    model.eval()
+    model.load_state_dict(specs.synth_weights(specs.vit_shapes("", size), seed), strict=True)
+    images = synth.synth_images(B, size, seed)
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed).clone().requires_grad_(True)
+    g = torch.from_numpy(synth.uniform_pm1("vitgrad_g", B * 768, seed).reshape(B, 768))
+    h = torch.from_numpy(synth.uniform_pm1("vitgrad_h", B * 768, seed).reshape(B, 768))
+    tap = GatherTap(rvit)
+    hooks, lens = [], []
+    for i, blk in enumerate(model.blocks):
+        hooks.append(blk.register_forward_pre_hook(lambda m, a, i=i: tap.set_tag(f"vit{i}")))
+        hooks.append(blk.register_forward_hook(lambda m, a, o: lens.append(o.shape[1])))
+    for p_ in model.parameters():
+        p_.grad = None
+    y, _ = model(images, space_dict=space_dict, temperature=temperature)
+    for hk in hooks:
+        hk.remove()
+    tap.restore()
+    O.vit_loss(y, g, h).backward()
+    rec = {"kind": "vit_grad", "B": B, "size": size, "temperature": np.float64(temperature), "seed": seed, "nsample": nsample,
+           "vit_lens": np.array(lens), "out_shape": np.array(y.shape), "y_norm": np.float64(y.detach().double().norm().item()),
+           "loss": np.float64(O.vit_loss(y.detach().double(), g.double(), h.double()).item())}
+    rec.update(tap.records)
+    grads = {"space_dict": space_dict.grad}
+    grads.update({k: v.grad for k, v in model.named_parameters() if v.grad is not None})
+    for k, gr in grads.items():
+        flat = gr.detach().reshape(-1)
+        idx = grad_sample_index(flat.numel(), nsample)
+        rec[f"g_{k}_sample"] = flat[torch.from_numpy(idx)].numpy()
+        rec[f"g_{k}_norm"] = np.float64(flat.double().norm().item())
+        rec[f"g_{k}_sum"] = np.float64(flat.double().sum().item())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] T={temperature} lens {lens} {len(grads)} gradients, |d space_dict| {rec['g_space_dict_norm']:.4e} "
+          f"|d pos_embed| {rec['g_pos_embed_norm']:.4e}")
+
+
 def clip_case(name, B, temperature, seed=0, size=224):
     """clip/model.py VisionTransformer (ViT-B/16 geometry) with clip/mock.py's patched MultiheadAttention."""
     import clip.mock  # noqa: F401  (monkey-patches torch.nn.MultiheadAttention, as the reference does on import)
@@ -601,6 +645,7 @@ CASES = {
     # at the same temperature enters with an already pruned sequence of 101 tokens; margins of every pruning decision on the way are >= 8e-5 relative, far above f32 rounding)
     "blockgrad_b2": lambda: vit_block_grad_case("blockgrad_b2", 2, 224, 5.0, layer=0),
     "blockgrad_b2_l3": lambda: vit_block_grad_case("blockgrad_b2_l3", 2, 224, 5.0, layer=3),
+    "encgrad_b2_s96": lambda: vit_grad_case("encgrad_b2_s96", 2, 96, 5.0),
 }
 
 if __name__ == "__main__":
