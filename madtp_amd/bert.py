@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import EncoderWeights, PreparedCache, param_epoch, get_precision, encoder_call_preference, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
+from .runtime import EncoderWeights, PreparedCache, param_epoch, own_modules, get_precision, encoder_call_preference, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model
 
 
@@ -270,6 +270,7 @@ class _BertLayerBase(nn.Module):
         params = self.__dict__.get("_madtp_params")
         if params is None or self.__dict__.get("_madtp_params_epoch") != param_epoch():
             self.__dict__["_madtp_params_epoch"] = param_epoch()
+            own_modules(self)
             params = [sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias,
                       ao.dense.weight, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias, self.intermediate.dense.weight,
                       self.intermediate.dense.bias, self.output.dense.weight, self.output.dense.bias,

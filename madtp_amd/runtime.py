@@ -23,6 +23,7 @@ Precision modes (SURVEY.md section 7 "hard parts"):
 """
 import os
 import threading
+import weakref
 
 import torch
 
@@ -167,18 +168,34 @@ def lin_of(cache, key, linears, dtype=None):
                      lambda: prepare_linear([l.weight for l in linears], [l.bias for l in linears], dtype))
 
 
-# Parameter RE-ASSIGNMENT (`blk.mlp.fc1.weight = nn.Parameter(...)`, `load_state_dict(assign=True)`) replaces the Parameter
-# object, which the per-module lists of collected parameters below would keep missing (their signatures only see in-place
-# changes of the objects they hold).  torch calls this hook for every parameter registration in the process: the lists are
-# re-collected whenever the epoch moved.
+# Parameter RE-ASSIGNMENT (`blk.mlp.fc1.weight = nn.Parameter(...)`, `load_state_dict(assign=True)`) or a replaced sub-module
+# (`blk.mlp.fc1 = nn.Linear(...)`) swaps the Parameter objects, which the per-module lists of collected parameters below would
+# keep missing (their signatures only see in-place changes of the objects they hold).  torch calls these hooks for EVERY
+# registration in the process, so they only count registrations ON modules of a mirror model that has collected its parameters
+# (own_modules(), called where a layer collects its list): a host application that builds other modules per request, or on
+# another thread, does not make the layers re-walk their parameters.
 _PARAM_EPOCH = [0]
+_OWNED = weakref.WeakSet()
+
+
+def own_modules(root):
+    """Marks root and its sub-modules as holders of collected parameters (see above)."""
+    for m in root.modules():
+        _OWNED.add(m)
 
 
 def _on_parameter_registration(module, name, param):
-    _PARAM_EPOCH[0] += 1
+    if module in _OWNED:
+        _PARAM_EPOCH[0] += 1
+
+
+def _on_module_registration(module, name, submodule):
+    if module in _OWNED:
+        _PARAM_EPOCH[0] += 1
 
 
 torch.nn.modules.module.register_module_parameter_registration_hook(_on_parameter_registration)
+torch.nn.modules.module.register_module_module_registration_hook(_on_module_registration)
 
 
 def param_epoch():

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import EncoderWeights, PreparedCache, param_epoch, get_precision, encoder_call_preference, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
+from .runtime import EncoderWeights, PreparedCache, param_epoch, own_modules, get_precision, encoder_call_preference, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model, vector_gather  # noqa: F401  (re-exported like `from models.utils import *`)
 
 import os as _os
@@ -191,6 +191,7 @@ class Block(nn.Module):
         params = self.__dict__.get("_madtp_params")  # collected once per module, dropped by _apply() (see bert.py)
         if params is None or self.__dict__.get("_madtp_params_epoch") != param_epoch():
             self.__dict__["_madtp_params_epoch"] = param_epoch()
+            own_modules(self)
             params = [self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.attn.qkv.weight,
                       self.attn.qkv.bias, self.attn.proj.weight, self.attn.proj.bias, self.mlp.fc1.weight,
                       self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias]

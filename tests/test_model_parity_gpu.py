@@ -779,3 +779,33 @@ def test_nlvr_pad_inside_topk_pairing(env, path, mode):
             # reproduced: every layer's kept sets and the recorded logits
             assert mine == rec
             assert np.abs(logits.cpu().numpy() - g["logits"]).max() < 1e-3
+
+
+def test_block_sees_reassigned_parameters_and_replaced_submodules():
+    """The collected parameter lists behind Block._weights() follow a re-assigned Parameter and a replaced sub-module (the
+    registration hooks of madtp_amd.runtime, filtered to modules that have collected their lists)."""
+    from madtp_amd import build, hip, runtime, vit
+    build.build(verbose=False)
+    hip.load()
+    torch.manual_seed(0)
+    blk = vit.Block(768, 12, qkv_bias=True).cuda().eval()
+    x = torch.randn(2, 50, 768, device="cuda")
+    with runtime.precision("fp32"), torch.no_grad():
+        y0 = blk(x).clone()
+        blk.mlp.fc1.weight = torch.nn.Parameter(torch.zeros_like(blk.mlp.fc1.weight))   # re-assignment, not an in-place change
+        y1 = blk(x).clone()
+        fresh = torch.nn.Linear(3072, 768).cuda()
+        blk.mlp.fc2 = fresh                                                               # replaced sub-module
+        y2 = blk(x).clone()
+        torch.nn.Linear(8, 8)                                                             # unrelated module: no effect
+        y3 = blk(x).clone()
+    assert not torch.equal(y0, y1) and not torch.equal(y1, y2) and torch.equal(y2, y3)
+    # fc1.weight = 0: mlp(x) = fc2(gelu(fc1.bias)) for every token
+    with torch.no_grad():
+        hb = torch.nn.functional.gelu(blk.mlp.fc1.bias)
+        delta = fresh(hb)
+    with runtime.precision("fp32"), torch.no_grad():
+        blk.mlp.fc2 = torch.nn.Linear(3072, 768).cuda()
+        torch.nn.init.zeros_(blk.mlp.fc2.weight); torch.nn.init.zeros_(blk.mlp.fc2.bias)
+        y_attn = blk(x).clone()                                                           # mlp contributes exactly 0
+    assert (y2 - (y_attn + delta)).abs().max().item() < 1e-4
