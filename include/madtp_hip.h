@@ -541,6 +541,14 @@ int madtp_token_score_bwd(const float* dw, const float* score, const int32_t* ds
  *   dS = P (dP - rowsum(P dP)); dq = scale dS k; dk = scale dS^T q; dv = P^T dout      (dout += dnrm_scale * out first)
  * q/k/v/dq/dk/dv: f32, rows b*N+i, head h at columns [64h, 64h+64) of each base pointer (slices of the fused qkv buffer).
  * ws: madtp_attention_bwd_workspace(B,H,N) bytes (P and dS [B,H,N,N] f32 + the head arg-max [B,N,N]).  N <= 1024. */
+/* Backward of the query model's att_ft branch (models/utils.py:174-178: W = softmax over tokens of inner / sqrt(sd_dim), att_ft =
+ * W q), the part of VisionTransformer.forward's second output (vit.py:297-303, consumed by the training drivers' alignment loss).
+ * Given dA = d att_ft [B,K,D]: dinner[B,n,K] += W (q dA^T - sum_n W q dA^T) / sqrt(sd_dim), dq[B,n,D] += W^T dA.  inner, dinner: dense
+ * [B,n,K] (dinner usually already holds the gradient that reaches the logits through token_attn); q, dq: dense [B,n,D]; ws: B*K*n
+ * floats.  n <= 1024, K <= 128, D <= 1024.  Exact f32, fixed summation order. */
+int madtp_att_ft_bwd(const float* inner, const float* q, const float* dA, float inv_sqrt_d, float* dinner, float* dq, float* ws,
+                     int B, int n, int K, int D, void* stream);
+
 /* The attention map itself, P[b,h,i,j] = softmax_j(scale q_i . k_j) as f32 [B,H,N,N] (vit.py:81-83 `self.save_attention_map(attn)`):
  * the forward never materialises it; Attention.get_attention_map() of the mirror recomputes it on demand from the layer's input
  * (q / k: f32 row views as in madtp_attention_bwd). */

@@ -2,8 +2,9 @@
 models/vit.py Block.forward (:183-207) in the reference's compression training (compress_nlvr_dtp.py:46-58, loss_fdt
 blip_nlvr.py:84-98), as hand-written gfx950 kernels behind a torch.autograd.Function.
 
-Scope of this round: ONE block, fp32 ("parity") arithmetic, gradient-checked against the reference's own .grad
-(tests/golden/blockgrad_b2.npz) and autograd through the CPU oracle.  PyTorch is plumbing (buffers, the autograd graph
+Scope: the block (VitBlockFunction) and, at the end of this file, the whole VisionTransformer.forward (both outputs), fp32
+("parity") arithmetic, gradient-checked against the reference's own .grad (tests/golden/blockgrad_*.npz, encgrad_*.npz) and
+autograd through the CPU oracle.  PyTorch is plumbing (buffers, the autograd graph
 edge); every arithmetic op is a kernel of csrc/backward.hip or madtp_gemm:
   * dgrad  dX = dY W      -> madtp_gemm(dY, W^T)          (exact-f32 MFMA; W^T by madtp_transpose_pad)
   * wgrad  dW = dY^T X    -> madtp_gemm(dY^T, X^T)        (both operands transposed and zero-padded to 32 rows of M)
@@ -14,6 +15,8 @@ edge); every arithmetic op is a kernel of csrc/backward.hip or madtp_gemm:
 The forward's intermediates are recomputed here from (x, token_attn) with the forward's own kernels and the forward's pruning
 decision k (activation recomputation: nothing but the two inputs is kept alive between forward and backward).
 """
+import math
+
 import torch
 
 from . import hip
@@ -243,9 +246,9 @@ def block_forward_with_grad(blk, x, temperature, token_attn):
 
 # ---------------------------------------------------------------------------------------------------------------------------
 # The whole pruned ViT under autograd (fp32 mode): patch embedding + CLS / position (vit.py:283-289), the query model's logits
-# (models/utils.py:165-166), the twelve blocks (VitBlockFunction) and the final LayerNorm (vit.py:309).  sd_img_ft_all - the
-# second output of VisionTransformer.forward, consumed by the training drivers' alignment loss - is returned WITHOUT a graph
-# (its softmax-over-tokens backward is not built yet); gradients flow from the image tokens.
+# and att_ft (models/utils.py:165-178), the twelve blocks (VitBlockFunction) and the final LayerNorm (vit.py:309).  Both outputs
+# of VisionTransformer.forward carry a graph: the image tokens and sd_img_ft_all (the sum of the layers' att_ft, consumed by the
+# training drivers' alignment loss).
 
 class PatchTokensFunction(torch.autograd.Function):
     """x = cat(cls, conv(img)) + pos_embed[:, :N] (vit.py:283-289; conv = im2col + GEMM, madtp_amd.vit.PatchEmbed).
@@ -278,28 +281,47 @@ class PatchTokensFunction(torch.autograd.Function):
         return None, None, dw, db, dcls, dpos
 
 
-class QueryLogitsFunction(torch.autograd.Function):
-    """token_att = ft @ sd^T (models/utils.py:165-166, raw logits) on the exact-f32 GEMM; ft2d [M, D], sd [K, D]."""
+def att_ft_bwd(inner, q, dA, sd_dim, dinner, dq):
+    """madtp_att_ft_bwd: adds the att_ft branch's gradient to dinner [B,n,K] and dq [B,n,D] (both dense f32, in place)."""
+    B, n, K = inner.shape
+    D = q.shape[-1]
+    ws = torch.empty((B * K * n,), device=inner.device, dtype=torch.float32)
+    _check(load().madtp_att_ft_bwd(_p(inner), _p(q), _p(dA), 1.0 / math.sqrt(sd_dim), _p(dinner), _p(dq), _p(ws), B, n, K, D, _stream()),
+           "madtp_att_ft_bwd")
+
+
+class QueryModelFunction(torch.autograd.Function):
+    """Query_model.forward(return_token_att=True) (models/utils.py:147-183, no q_map): x [B,N,D] (row 0 = CLS, not used), sd [K,D] ->
+    (token_att [B,N-1,K] raw logits, att_ft [B,K,D]).  Forward = the inference path's own kernels (madtp_amd.utils.Query_model);
+    backward: the logits' gradient (from token_attn's use in the blocks and from att_ft's softmax over tokens) goes through dgrad /
+    wgrad on the exact-f32 GEMM, plus the direct att_ft term W^T dA for the tokens."""
 
     @staticmethod
-    def forward(ctx, ft2d, sd):
-        K = sd.shape[0]
-        kp = _pad(K, 128)
-        w = sd.detach()
-        if kp != K:
-            w = torch.zeros((kp, sd.shape[1]), device=sd.device, dtype=torch.float32)
-            w[:K] = sd.detach()
-        ctx.save_for_backward(ft2d, sd)
-        return hip.gemm(ft2d.contiguous(), w.contiguous(), None, n=K, out_dtype=torch.float32)
+    def forward(ctx, qm, x, sd):
+        ta, att_ft, _ = qm(x[:, 1:, :], sd, return_token_att=True)
+        ta = ta.contiguous()
+        ctx.save_for_backward(x, sd, ta)
+        ctx.sd_dim = qm.att_dim
+        return ta, att_ft.clone()
 
     @staticmethod
-    def backward(ctx, dl):
-        ft2d, sd = ctx.saved_tensors
+    def backward(ctx, dta, datt):
+        x, sd, ta = ctx.saved_tensors
+        B, N, D = x.shape
+        n, K = N - 1, sd.shape[0]
         with torch.no_grad():
-            dl = dl.contiguous().float()
-            dft = dgrad(dl, sd.detach()) if ctx.needs_input_grad[0] else None
-            dsd = wgrad(dl, ft2d.contiguous()) if ctx.needs_input_grad[1] else None
-        return dft, dsd
+            ft = x[:, 1:, :].contiguous()
+            dinner = dta.contiguous().float().clone() if dta is not None else torch.zeros_like(ta)
+            dq = torch.zeros_like(ft)
+            if datt is not None:
+                att_ft_bwd(ta, ft, datt.contiguous().float(), ctx.sd_dim, dinner, dq)
+            d2 = dinner.view(B * n, K)
+            dx = None
+            if ctx.needs_input_grad[1]:
+                dx = torch.zeros_like(x)
+                dx[:, 1:, :] = dgrad(d2, sd.detach()).view(B, n, D) + dq
+            dsd = wgrad(d2, ft.view(B * n, D)) if ctx.needs_input_grad[2] else None
+        return None, dx, dsd
 
 
 class LayerNormFunction(torch.autograd.Function):
@@ -335,11 +357,8 @@ def vit_forward_with_grad(vit, img, space_dict, temperature):
     sd_all = None
     for blk in vit.blocks:
         if space_dict is not None:
-            B, N, D = x.shape
-            with torch.no_grad():  # :297-303, the running att_ft sum: values only (see the note above)
-                _, sd_all, _ = vit.img_query_model(x.detach()[:, 1:, :], space_dict.detach(), return_token_att=True, acc_ft=sd_all)
-            ft2d = x[:, 1:, :].reshape(B * (N - 1), D)
-            token_attn = QueryLogitsFunction.apply(ft2d, space_dict).view(B, N - 1, -1)
+            token_attn, sd_ft = QueryModelFunction.apply(vit.img_query_model, x, space_dict)  # :297-298
+            sd_all = sd_ft if sd_all is None else sd_all + sd_ft                              # :300-303
             x = blk(x, False, reduce_num, temperature, token_attn)  # :304 (Block.forward routes to VitBlockFunction)
         else:
             x = blk(x, False)

@@ -443,6 +443,83 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnBwdArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ att_ft backward
+// Query_model (models/utils.py:170-178):  W[b,k,:] = softmax_n(inner[b,:,k] / sqrt(sd_dim)),  att_ft[b,k,:] = sum_n W[b,k,n] q[b,n,:].
+// Given dA = d att_ft:  dW[k,n] = <dA[k,:], q[n,:]>,  dS[k,n] = W (dW - sum_n W dW) / sqrt(sd_dim)  (added to d inner[b,n,k]),
+// dq[n,:] += sum_k W[k,n] dA[k,:].  Exact f32, fixed summation orders.
+// kernel 1: one workgroup per (dictionary column k, sample b); W is written to ws for kernel 2.
+constexpr int AF_MAXN = 1024;
+__global__ __launch_bounds__(256) void att_ft_bwd_logits_kernel(const float* __restrict__ inner, const float* __restrict__ q,
+                                                                const float* __restrict__ dA, float inv_sqrt_d,
+                                                                float* __restrict__ dinner, float* __restrict__ Wws, int n, int K, int D) {
+    __shared__ float w_s[AF_MAXN], dw_s[AF_MAXN], red[8];
+    extern __shared__ float da_s[];  // [D]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = blockIdx.x, b = blockIdx.y;
+    const float* in_b = inner + (size_t)b * n * K;
+    for (int d = tid; d < D; d += 256) da_s[d] = dA[((size_t)b * K + k) * D + d];
+    float m = -INFINITY;
+    for (int t = tid; t < n; t += 256) { const float v = in_b[(size_t)t * K + k] * inv_sqrt_d; w_s[t] = v; m = fmaxf(m, v); }
+    m = wave_max(m);
+    __syncthreads();
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float z = 0.f;
+    for (int t = tid; t < n; t += 256) { const float e = expf(w_s[t] - m); w_s[t] = e; z += e; }
+    const float Z = block_sum256(z, red);
+    // dW[n] = <dA[k,:], q[n,:]>: a wave per token row, lanes over d
+    const float* q_b = q + (size_t)b * n * D;
+    for (int t = wave; t < n; t += 4) {
+        float acc = 0.f;
+        for (int d = lane; d < D; d += 64) acc = fmaf(da_s[d], q_b[(size_t)t * D + d], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) dw_s[t] = acc;
+    }
+    __syncthreads();
+    float c = 0.f;
+    for (int t = tid; t < n; t += 256) { const float w = w_s[t] / Z; w_s[t] = w; c = fmaf(w, dw_s[t], c); }
+    const float C = block_sum256(c, red);
+    for (int t = tid; t < n; t += 256) {
+        const float w = w_s[t];
+        dinner[((size_t)b * n + t) * K + k] += w * (dw_s[t] - C) * inv_sqrt_d;
+        Wws[((size_t)b * K + k) * n + t] = w;
+    }
+}
+// kernel 2: dq[b,n,:] += sum_k W[b,k,n] dA[b,k,:]; one workgroup per (8 token rows, sample), a thread per 1/256 of D
+__global__ __launch_bounds__(256) void att_ft_bwd_q_kernel(const float* __restrict__ Wws, const float* __restrict__ dA,
+                                                           float* __restrict__ dq, int n, int K, int D) {
+    constexpr int R = 8, DMAX = 4;  // D <= 1024
+    __shared__ float w_s[R][128];
+    const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * R;
+    for (int i = tid; i < R * K; i += 256) {
+        const int r = i / K, k = i - r * K;
+        w_s[r][k] = t0 + r < n ? Wws[((size_t)b * K + k) * n + t0 + r] : 0.f;
+    }
+    __syncthreads();
+    float acc[R][DMAX];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < DMAX; ++j) acc[r][j] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        float a[DMAX];
+#pragma unroll
+        for (int j = 0; j < DMAX; ++j) { const int d = tid + 256 * j; a[j] = d < D ? dA[((size_t)b * K + k) * D + d] : 0.f; }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < DMAX; ++j) acc[r][j] = fmaf(w_s[r][k], a[j], acc[r][j]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (t0 + r < n)
+#pragma unroll
+            for (int j = 0; j < DMAX; ++j) { const int d = tid + 256 * j; if (d < D) dq[((size_t)b * n + t0 + r) * D + d] += acc[r][j]; }
+}
+
 }  // namespace
 
 extern "C" int madtp_transpose_pad(const float* src, int ld_src, int R, int C, float* dst, int ld_dst, int Rp, int Cp, void* stream) {
@@ -556,6 +633,21 @@ extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* 
     if (da) hipLaunchKernelGGL(attn_headmax_kernel, dim3(B, N), dim3(256), 0, s, a);
     hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(B * H, nrt), dim3(256), lds_r, s, a);
     hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(B * H, nrt), dim3(256), 0, s, a);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// d att_ft -> (d inner += ..., d q += ...), see att_ft_bwd_logits_kernel.  inner / dinner: dense [B, n, K]; q / dq: dense [B, n, D];
+// dA: [B, K, D]; ws: B K n floats.  inv_sqrt_d = 1 / sqrt(sd_dim) (models/utils.py:174).
+extern "C" int madtp_att_ft_bwd(const float* inner, const float* q, const float* dA, float inv_sqrt_d, float* dinner, float* dq,
+                                float* ws, int B, int n, int K, int D, void* stream) {
+    if (!inner || !q || !dA || !dinner || !dq || !ws || B <= 0 || n <= 0 || K <= 0 || D <= 0) return MADTP_E_BADARG;
+    if (n > AF_MAXN || K > 128 || D > 1024) return MADTP_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(att_ft_bwd_logits_kernel, dim3(K, B), dim3(256), (size_t)D * sizeof(float), s, inner, q, dA, inv_sqrt_d, dinner, ws, n, K, D);
+    MADTP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(att_ft_bwd_q_kernel, dim3((n + 7) / 8, B), dim3(256), 0, s, ws, dA, dq, n, K, D);
     MADTP_LAUNCH_CHECK();
     return 0;
 }

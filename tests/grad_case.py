@@ -59,5 +59,6 @@ def vit_loss_vectors(g):
     """(g, h) of oracle.vit_loss for a encgrad_* fixture (tools/make_golden.py::vit_grad_case)."""
     from madtp_amd import synth as S
     B, seed = int(g["B"]), int(g["seed"])
+    a = torch.from_numpy(S.uniform_pm1("vitgrad_a", B * 100 * 768, seed).reshape(B, 100, 768)) if "loss_has_sd_all" in g.files else None
     return (torch.from_numpy(S.uniform_pm1("vitgrad_g", B * 768, seed).reshape(B, 768)),
-            torch.from_numpy(S.uniform_pm1("vitgrad_h", B * 768, seed).reshape(B, 768)))
+            torch.from_numpy(S.uniform_pm1("vitgrad_h", B * 768, seed).reshape(B, 768)), a)

@@ -85,6 +85,26 @@ def test_attention_bwd_plain(hip, B, N):
     assert torch.equal(dqkv, bw.attention_bwd(qkv, dout, o.detach().contiguous(), B, H, N, 0.125))
 
 
+@pytest.mark.parametrize("B,n", [(3, 50), (2, 196), (1, 300)])
+def test_att_ft_bwd(hip, B, n):
+    """madtp_att_ft_bwd vs torch autograd through models/utils.py:174-178 (softmax over tokens of inner / sqrt(d), W q); the kernel
+    ADDS to the gradients it is given."""
+    import math
+    from madtp_amd import backward as bw
+    K, D = 100, 768
+    q, sd, dA = _rand(B, n, D, seed=1).cuda(), _rand(K, D, seed=2, scale=0.3).cuda(), _rand(B, K, D, seed=3).cuda()
+    qr, ir = q.clone().requires_grad_(True), (q @ sd.t()).clone().requires_grad_(True)
+    w = torch.softmax((ir / math.sqrt(D)).permute(0, 2, 1), dim=-1)
+    (torch.bmm(w, qr) * dA).sum().backward()
+    dinner0, dq0 = _rand(B, n, K, seed=4).cuda(), _rand(B, n, D, seed=5).cuda()
+    dinner, dq = dinner0.clone(), dq0.clone()
+    bw.att_ft_bwd(ir.detach().contiguous(), q, dA, D, dinner, dq)
+    assert _rel(dinner - dinner0, ir.grad) < 2e-5 and _rel(dq - dq0, qr.grad) < 2e-5
+    d2, q2 = dinner0.clone(), dq0.clone()
+    bw.att_ft_bwd(ir.detach().contiguous(), q, dA, D, d2, q2)
+    assert torch.equal(d2, dinner) and torch.equal(q2, dq)  # fixed summation order
+
+
 @pytest.mark.parametrize("path", GRAD_CASES, ids=[os.path.basename(c)[:-4] for c in GRAD_CASES])
 def test_block_backward_matches_reference_grads(hip, path):
     from madtp_amd import runtime, vit
@@ -169,7 +189,7 @@ def test_vit_backward_matches_reference_grads(hip, path):
         p_.grad = None
     images = synth.synth_images(B, size, seed).cuda()
     space_dict = synth.synth_tensor("space_dict", (100, 768), seed).cuda().requires_grad_(True)
-    gv, hv = [t.cuda() for t in grad_case.vit_loss_vectors(g)]
+    gv, hv, av = [t.cuda() for t in grad_case.vit_loss_vectors(g)]
     with runtime.precision("fp32"):
         y, sd_all = venc(images, space_dict=space_dict, temperature=T)
         assert y.requires_grad and tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
@@ -181,8 +201,8 @@ def test_vit_backward_matches_reference_grads(hip, path):
                      {"pruned": True, "indices": blk.last_prune["indices"].cpu()} for blk in venc.blocks]
         assert harness.compose_ids(own_trace, n0) == harness.compose_ids(ref_trace, n0), "kept sets differ from the recording"
         assert abs(float(y.detach().double().norm()) - float(g["y_norm"])) < 1e-4 * float(g["y_norm"])
-        O.vit_loss(y, gv, hv).backward()
-    assert sd_all is not None and not sd_all.requires_grad
+        assert sd_all.requires_grad and abs(float(sd_all.detach().double().norm()) - float(g["sd_all_norm"])) < 1e-4 * float(g["sd_all_norm"])
+        (O.vit_loss(y, gv, hv) + (sd_all * av).sum()).backward()   # both outputs of the forward enter the loss
     grads = {k: v.grad for k, v in venc.named_parameters() if v.grad is not None}
     grads["space_dict"] = space_dict.grad
     missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]

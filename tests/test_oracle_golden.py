@@ -602,8 +602,8 @@ def test_oracle_vit_backward_matches_reference_grads(path):
     W = specs.synth_weights(specs.vit_shapes("", size), seed)
     images = synth.synth_images(B, size, seed)
     space_dict = synth.synth_tensor("space_dict", (100, 768), seed)
-    gv, hv = grad_case.vit_loss_vectors(g)
-    grads, y, trace = O.vit_grads(W, "", images, space_dict, T, gv, hv)
+    gv, hv, av = grad_case.vit_loss_vectors(g)
+    grads, y, trace = O.vit_grads(W, "", images, space_dict, T, gv, hv, a=av)
     assert tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
     assert abs(float(y.double().norm()) - float(g["y_norm"])) < 1e-5 * float(g["y_norm"])
     for i, t in enumerate(trace):

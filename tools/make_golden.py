@@ -287,7 +287,7 @@ def vit_block_grad_case(name, B, size, temperature, layer=0, seed=0):
 def vit_grad_case(name, B, size, temperature, seed=0, nsample=256):
     """SURVEY 8(f) rank 4 (backward), the whole encoder: the reference's OWN autograd through models/vit.py
     VisionTransformer.forward (12 pruned blocks, query-model logits, patch embedding, final LayerNorm) with every parameter and
-    space_dict as leaves, loss = oracle.vit_loss(y, g, h) (token-order invariant).  Recorded: per-layer lengths and kept sets, the
+    space_dict as leaves, loss = oracle.vit_loss(y, g, h) (token-order invariant) + sum(sd_img_ft_all * a).  Recorded: per-layer lengths and kept sets, the
     output's head, and of every gradient its L2 norm, sum and `nsample` sampled entries (grad_sample_index) - data only."""
     import models.vit as rvit
     from madtp_amd import specs
@@ -306,13 +306,15 @@ def vit_grad_case(name, B, size, temperature, seed=0, nsample=256):
         hooks.append(blk.register_forward_hook(lambda m, a, o: lens.append(o.shape[1])))
     for p_ in model.parameters():
         p_.grad = None
-    y, _ = model(images, space_dict=space_dict, temperature=temperature)
+    a = torch.from_numpy(synth.uniform_pm1("vitgrad_a", B * 100 * 768, seed).reshape(B, 100, 768))
+    y, sd_all = model(images, space_dict=space_dict, temperature=temperature)
     for hk in hooks:
         hk.remove()
     tap.restore()
-    O.vit_loss(y, g, h).backward()
+    (O.vit_loss(y, g, h) + (sd_all * a).sum()).backward()   # both outputs of VisionTransformer.forward enter the loss
     rec = {"kind": "vit_grad", "B": B, "size": size, "temperature": np.float64(temperature), "seed": seed, "nsample": nsample,
            "vit_lens": np.array(lens), "out_shape": np.array(y.shape), "y_norm": np.float64(y.detach().double().norm().item()),
+           "sd_all_norm": np.float64(sd_all.detach().double().norm().item()), "loss_has_sd_all": 1,
            "loss": np.float64(O.vit_loss(y.detach().double(), g.double(), h.double()).item())}
     rec.update(tap.records)
     grads = {"space_dict": space_dict.grad}
