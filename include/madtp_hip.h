@@ -552,9 +552,10 @@ int madtp_att_ft_bwd(const float* inner, const float* q, const float* dA, float 
 /* The attention map itself, P[b,h,i,j] = softmax_j(scale q_i . k_j) as f32 [B,H,N,N] (vit.py:81-83 `self.save_attention_map(attn)`):
  * the forward never materialises it; Attention.get_attention_map() of the mirror recomputes it on demand from the layer's input
  * (q / k: f32 row views as in madtp_attention_bwd). */
-int madtp_attention_probs(const float* q, const float* k, int ld, float* P, int B, int H, int N, float scale, void* stream);
+int madtp_attention_probs(const float* q, const float* k, int ld, const float* key_mask, float* P, int B, int H, int N, float scale,
+                          void* stream);  /* key_mask: additive [B,N] over the keys (BERT padding mask, med.py:197-199) or NULL */
 size_t madtp_attention_bwd_workspace(int B, int H, int N);
-int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, const float* dout, int ldo, const float* out,
+int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, const float* key_mask, const float* dout, int ldo, const float* out,
                         int ldout, const float* dnrm_scale, const float* da, const float* dp0, float* dq, float* dk, float* dv,
                         int ldd, void* ws, size_t ws_bytes, int B, int H, int N, float scale, void* stream);
 

@@ -36,8 +36,8 @@ def transpose_pad(src, rows_pad, cols_pad):
     return dst
 
 
-def dgrad(dy, weight):
-    """dX[M, K] = dY[M, N] @ W[N, K] (nn.Linear weight layout)."""
+def dgrad(dy, weight, residual=None):
+    """dX[M, K] = dY[M, N] @ W[N, K] (nn.Linear weight layout) [+ residual[M, K]: the other branch of a residual connection]."""
     N, K = weight.shape
     Np = _pad(N, 32)  # the GEMM's reduction length (f32 slabs of 32): zero columns for e.g. the 100 dictionary columns
     if Np != N:
@@ -45,7 +45,7 @@ def dgrad(dy, weight):
         dyp[:, :N] = dy
         dy = dyp
     wt = transpose_pad(weight, Np, _pad(K, 128))  # [Kpad, Np]: the GEMM's "weight" with K' = N contiguous
-    return hip.gemm(dy, wt, n=K, out_dtype=torch.float32)
+    return hip.gemm(dy, wt, n=K, out_dtype=torch.float32, residual=residual)
 
 
 def wgrad(dy, x):
@@ -111,8 +111,9 @@ def token_score_bwd(dw, score, dst_pos, merge_w, side, token_attn, B, H, N):
     return da, dp0, dnrm, dta
 
 
-def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None):
-    """qkv f32 [B*N, 3*H*64] (fused projection), dout / out [B*N, H*64] -> dqkv [B*N, 3*H*64]."""
+def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None, key_mask=None):
+    """qkv f32 [B*N, 3*H*64] (fused projection), dout / out [B*N, H*64] -> dqkv [B*N, 3*H*64].  key_mask: additive f32 [B,N]
+    over the keys (the BERT layers' padding mask) or None."""
     D = H * 64
     dqkv = torch.empty_like(qkv)
     lib = load()
@@ -120,7 +121,7 @@ def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None):
     ws = torch.empty((nbytes,), device=qkv.device, dtype=torch.uint8)
     q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
     dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
-    _check(lib.madtp_attention_bwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(dout), dout.stride(0), _p(out), out.stride(0), _p(dnrm),
+    _check(lib.madtp_attention_bwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(key_mask), _p(dout), dout.stride(0), _p(out), out.stride(0), _p(dnrm),
                                    _p(da), _p(dp0), _p(dq), _p(dk), _p(dv), dqkv.stride(0), _p(ws), nbytes, B, H, N, float(scale),
                                    _stream()), "madtp_attention_bwd")
     return dqkv
@@ -242,6 +243,131 @@ def block_forward_with_grad(blk, x, temperature, token_attn):
     if token_attn is not None and not token_attn.is_contiguous():
         token_attn = token_attn.contiguous()
     return VitBlockFunction.apply(blk, temperature, x, token_attn, *_params_of(blk))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# MED text layer (models/med.py BertLayer.forward :393-462 in mode 'text'): self-attention with the padding mask, output
+# LayerNorm, Reduce_token on the post-LN tokens (:345-391 - the same importance score and merge rule as the ViT block), FFN with
+# post-LayerNorm.  Same recipe as vit_block_backward: recompute the forward from (hidden, token_attn) with the forward's own fp32
+# kernels and the forward's k, then walk the graph backwards.
+
+_MED_PARAMS = ("attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight", "attention.self.key.bias",
+               "attention.self.value.weight", "attention.self.value.bias", "attention.output.dense.weight",
+               "attention.output.dense.bias", "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias",
+               "intermediate.dense.weight", "intermediate.dense.bias", "output.dense.weight", "output.dense.bias",
+               "output.LayerNorm.weight", "output.LayerNorm.bias")
+
+
+def _med_params_of(layer):
+    mods = dict(layer.named_parameters())
+    return [mods[n] for n in _MED_PARAMS]
+
+
+def med_text_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy):
+    """Gradients of the MED BertLayer in mode 'text' at (hidden [B,L,D], token_attn [B,L-1,K]) for the output gradient dy
+    [B,L',D]; mask2d: additive key mask [B,L] or None; k: the forward's pruning decision (0 = not pruned).  Returns
+    (dhidden, dtoken_attn or None, {parameter name: grad})."""
+    B, L, D = hidden.shape
+    sa, so = layer.attention.self, layer.attention.output
+    H, scale = sa.num_attention_heads, 1.0 / math.sqrt(sa.attention_head_size)
+    M = B * L
+    h2 = hidden.reshape(M, D)
+    # ---- recompute the forward ----
+    wqkv = torch.cat([sa.query.weight.detach(), sa.key.weight.detach(), sa.value.weight.detach()], 0).contiguous()  # [3D, D]
+    bqkv = torch.cat([sa.query.bias.detach(), sa.key.bias.detach(), sa.value.bias.detach()], 0).contiguous()
+    wo, bo = _f32_lin(so.dense)
+    wi, bi = _f32_lin(layer.intermediate.dense)
+    wout, bout = _f32_lin(layer.output.dense)
+    qkv = hip.gemm(h2, wqkv, bqkv, n=3 * D, out_dtype=torch.float32)
+    ctx, side = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, L, L, scale, add_mask=mask2d, scores=k > 0)
+    a0 = hip.gemm(ctx, wo, bo, residual=h2, n=D, out_dtype=torch.float32)
+    ao, _ = hip.layernorm(a0, so.LayerNorm.weight.detach(), so.LayerNorm.bias.detach(), so.LayerNorm.eps)
+    if k > 0:
+        score, _, _, _ = hip.token_score(side, token_attn, temperature, B, H, L)
+        _, _, dst_pos, merge_w = hip.token_select(score, k)
+        y0 = hip.token_gather(ao.view(B, L, D), dst_pos, merge_w, k)
+    else:
+        y0 = ao.view(B, L, D)
+    L2 = y0.shape[1]
+    M2 = B * L2
+    y02 = y0.reshape(M2, D)
+    F = layer.intermediate.dense.weight.shape[0]
+    u = hip.gemm(y02, wi, bi, n=F, out_dtype=torch.float32)
+    gl = act_fwd(u, hip.ACT_GELU)
+    f0 = hip.gemm(gl, wout, bout, residual=y02, n=D, out_dtype=torch.float32)
+    # ---- backward ----
+    grads = {}
+    ln2 = layer.output.LayerNorm
+    dy2 = dy.reshape(M2, D).contiguous().float()
+    df0, grads["output.LayerNorm.weight"], grads["output.LayerNorm.bias"] = layernorm_bwd(f0, ln2.weight.detach(), dy2, ln2.eps)
+    dgl = dgrad(df0, layer.output.dense.weight.detach())
+    grads["output.dense.weight"], grads["output.dense.bias"] = wgrad(df0, gl), colsum(df0)
+    du = act_bwd(u, dgl, hip.ACT_GELU)
+    dy0 = dgrad(du, layer.intermediate.dense.weight.detach(), residual=df0)   # f0 = y0 + ffn(y0)
+    grads["intermediate.dense.weight"], grads["intermediate.dense.bias"] = wgrad(du, y02), colsum(du)
+    dta = dnrm = da = dp0 = None
+    if k > 0:
+        dao3, dw = token_gather_bwd(dy0.view(B, L2, D), ao.view(B, L, D), dst_pos, merge_w, k)
+        da, dp0, dnrm, dta = token_score_bwd(dw, score, dst_pos, merge_w, side, token_attn, B, H, L)
+        dao = dao3.view(M, D)
+    else:
+        dao = dy0
+    ln1 = so.LayerNorm
+    da0, grads["attention.output.LayerNorm.weight"], grads["attention.output.LayerNorm.bias"] = layernorm_bwd(
+        a0, ln1.weight.detach(), dao.contiguous(), ln1.eps)
+    dctx = dgrad(da0, so.dense.weight.detach())                               # a0 = hidden + ctx Wo^T + bo
+    grads["attention.output.dense.weight"], grads["attention.output.dense.bias"] = wgrad(da0, ctx), colsum(da0)
+    dqkv = attention_bwd(qkv, dctx, ctx, B, H, L, scale, dnrm, da, dp0, key_mask=mask2d)
+    dh = dgrad(dqkv, wqkv, residual=da0)
+    gw, gb = wgrad(dqkv, h2), colsum(dqkv)
+    for i, nm in enumerate(("query", "key", "value")):
+        grads[f"attention.self.{nm}.weight"] = gw[i * D:(i + 1) * D]
+        grads[f"attention.self.{nm}.bias"] = gb[i * D:(i + 1) * D]
+    return dh.view(B, L, D), dta, grads
+
+
+class MedTextLayerFunction(torch.autograd.Function):
+    """MED BertLayer.forward in mode 'text' with a hand-written backward.  Inputs after (layer, temperature, mask2d): hidden,
+    token_attn (or None), then the layer's 16 parameters in _MED_PARAMS order.  Returns (layer output, new additive mask [B,L'])."""
+
+    @staticmethod
+    def forward(ctx, layer, temperature, mask2d, hidden, token_attn, *params):
+        prune = temperature > 0
+        y, mask_out, info, _ = hip.bert_layer(layer._weights(), hidden, mask2d, token_attn, temperature if prune else 0, False,
+                                              None, None, 0, None, None)
+        layer.last_prune = info
+        ctx.layer, ctx.temperature = layer, float(temperature)
+        ctx.k = int(info["indices"].shape[1]) if (info is not None and info.get("pruned")) else 0
+        ctx.has_ta = token_attn is not None
+        ctx.has_mask = mask2d is not None
+        ctx.save_for_backward(hidden, token_attn if token_attn is not None else hidden.new_empty(0),
+                              mask2d if mask2d is not None else hidden.new_empty(0))
+        if mask_out is None:
+            mask_out = mask2d if mask2d is not None else hidden.new_zeros((hidden.shape[0], y.shape[1]))
+        ctx.mark_non_differentiable(mask_out)
+        return y, mask_out
+
+    @staticmethod
+    def backward(ctx, dy, _dmask):
+        hidden, ta, mask2d = ctx.saved_tensors
+        ta = ta if ctx.has_ta else None
+        with torch.no_grad():
+            dh, dta, grads = med_text_layer_backward(ctx.layer, hidden, mask2d if ctx.has_mask else None, ta, ctx.temperature, ctx.k, dy)
+        if ctx.has_ta and dta is None:
+            dta = torch.zeros_like(ta)
+        return (None, None, None, dh, dta if ctx.has_ta else None) + tuple(grads.get(n) for n in _MED_PARAMS)
+
+
+def med_text_layer_forward_with_grad(layer, hidden, mask2d, temperature, token_attn):
+    """MED BertLayer (mode 'text') under autograd -> (output, new additive mask [B,L'] or None); fp32 mode only."""
+    from . import runtime
+    if runtime.get_precision() != "fp32":
+        raise NotImplementedError("the BERT layer backward is built for the fp32 precision mode (runtime.precision('fp32')); "
+                                  f"current mode: {runtime.get_precision()}")
+    if token_attn is not None and not token_attn.is_contiguous():
+        token_attn = token_attn.contiguous()
+    y, mask_out = MedTextLayerFunction.apply(layer, temperature, mask2d, hidden, token_attn, *_med_params_of(layer))
+    return y, (mask_out if mask2d is not None else None)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

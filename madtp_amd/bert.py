@@ -359,6 +359,16 @@ class _BertLayerBase(nn.Module):
         if prune and mask2d is None:
             raise ValueError("attention_mask is required when temperature > 0 (med.py:424)")
         cross = mode == 'multimodal'
+        if (torch.is_grad_enabled() and not cross and causal is None and self.variant == "med" and get_precision() == "fp32"
+                and (hidden.requires_grad or (token_attn is not None and token_attn.requires_grad)
+                     or any(p.requires_grad for p in self.parameters()))):
+            # training / compression use: the text-mode MED layer as an autograd.Function around the same
+            # kernels (madtp_amd/backward.py); cross-attention layers and the NLVR variant have no backward yet
+            from .backward import med_text_layer_forward_with_grad
+            y, mask_out = med_text_layer_forward_with_grad(self, hidden, mask2d, temperature if prune else 0, token_attn)
+            if mask_out is not None:
+                attention_mask = mask_out[:, None, None, :]
+            return (y, None, attention_mask)
         enc0 = enc1 = em0 = em1 = None
         Nk = 0
         pre = self.__dict__.pop("_kv_pre", None)  # (kv cache of THIS layer, Nk, int32 index [B]) set by the encoder for this call

@@ -283,6 +283,7 @@ struct AttnBwdArgs {
     unsigned char* hm;                   // scratch [B,N,N]: argmax_h P[b,h,i,j]
     float *dq, *dk, *dv; int ldd;        // outputs, same layout as q/k/v
     int B, H, N; float scale;
+    const float* key_mask;               // [B,N] additive key mask (BERT padding mask, med.py:197-199) or NULL
 };
 
 // P[b,h,i,:] = softmax_j(scale q_i . k_j) for 16 query rows per workgroup
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(AttnBwdArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int d = 0; d < HD; ++d) s = fmaf(Qs[r * HD + d], kr[d], s);
-            S[r * N + j] = s * a.scale;
+            S[r * N + j] = a.key_mask ? fmaf(s, a.scale, a.key_mask[(size_t)b * N + j]) : s * a.scale;
         }
     }
     __syncthreads();
@@ -592,12 +593,13 @@ extern "C" int madtp_token_score_bwd(const float* dw, const float* score, const 
     return 0;
 }
 
-extern "C" int madtp_attention_probs(const float* q, const float* k, int ld, float* P, int B, int H, int N, float scale, void* stream) {
+extern "C" int madtp_attention_probs(const float* q, const float* k, int ld, const float* key_mask, float* P, int B, int H, int N,
+                                     float scale, void* stream) {
     if (!q || !k || !P || B <= 0 || H <= 0 || N <= 0) return MADTP_E_BADARG;
     if (N > 1024) return MADTP_E_SHAPE;
     if (ld % 4 || !aligned16(q) || !aligned16(k)) return MADTP_E_ALIGN;
     AttnBwdArgs a = {};
-    a.q = q; a.k = k; a.ld = ld; a.P = P; a.B = B; a.H = H; a.N = N; a.scale = scale;
+    a.q = q; a.k = k; a.ld = ld; a.P = P; a.B = B; a.H = H; a.N = N; a.scale = scale; a.key_mask = key_mask;
     const size_t lds_p = (size_t)(16 * HD + 16 * N) * sizeof(float);
     MADTP_ENSURE_MAX_LDS(attn_probs_kernel, lds_p);
     hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, (N + 15) / 16), dim3(256), lds_p, (hipStream_t)stream, a);
@@ -610,7 +612,7 @@ extern "C" size_t madtp_attention_bwd_workspace(int B, int H, int N) {
     return 2 * pn + (((size_t)B * N * N + 255) & ~(size_t)255);
 }
 
-extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, const float* dout, int ldo,
+extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, const float* key_mask, const float* dout, int ldo,
                                    const float* out, int ldout, const float* dnrm_scale, const float* da, const float* dp0,
                                    float* dq, float* dk, float* dv, int ldd, void* ws, size_t ws_bytes, int B, int H, int N,
                                    float scale, void* stream) {
@@ -622,6 +624,7 @@ extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* 
     AttnBwdArgs a;
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.dout = dout; a.ldo = ldo; a.out = out; a.ldout = ldout; a.dnrm_scale = dnrm_scale;
     a.da = da; a.dp0 = dp0; a.dq = dq; a.dk = dk; a.dv = dv; a.ldd = ldd; a.B = B; a.H = H; a.N = N; a.scale = scale;
+    a.key_mask = key_mask;
     const size_t pn = (size_t)B * H * N * N;
     a.P = (float*)ws; a.dS = a.P + pn; a.hm = (unsigned char*)(a.dS + pn);
     hipStream_t s = (hipStream_t)stream;

@@ -13,7 +13,7 @@ import torch
 F32, BF16, F16S, F16 = 0, 1, 2, 3  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 #                                    F16: plain IEEE f16 operands (the "f16" fast mode), see set_lp_format below
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -102,10 +102,10 @@ _SIGS = {
     "madtp_token_gather_bwd": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
     "madtp_token_score_bwd": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4
                               + [c_int, c_int, c_int, c_void_p]),
-    "madtp_attention_probs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "madtp_attention_probs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "madtp_att_ft_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "madtp_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
-    "madtp_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 6
+    "madtp_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 6
                             + [c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_float, c_void_p]),
 }
 
@@ -415,15 +415,15 @@ def attention(q, k, v, B, H, Nq, Nk, scale, add_mask=None, scores=False, mask_qk
     return out, side
 
 
-def attention_probs(q, k, B, H, N, scale):
-    """P = softmax(scale q k^T) f32 [B, H, N, N] from f32 row views q, k [B*N, >= H*64] (madtp_attention_probs)."""
+def attention_probs(q, k, B, H, N, scale, key_mask=None):
+    """P = softmax(scale q k^T [+ key_mask[b, j]]) f32 [B, H, N, N] from f32 row views q, k [B*N, >= H*64] (madtp_attention_probs)."""
     for t in (q, k):
         if not t.is_cuda or t.dtype != torch.float32 or t.stride(1) != 1:
             raise RuntimeError("attention_probs operands must be GPU f32 row-major views")
     if q.stride(0) != k.stride(0):
         raise RuntimeError("attention_probs: q and k must share their leading dimension")
     P = torch.empty((B, H, N, N), device=q.device, dtype=torch.float32)
-    _check(load().madtp_attention_probs(_p(q), _p(k), q.stride(0), _p(P), B, H, N, float(scale), _stream()), "madtp_attention_probs")
+    _check(load().madtp_attention_probs(_p(q), _p(k), q.stride(0), _p(key_mask), _p(P), B, H, N, float(scale), _stream()), "madtp_attention_probs")
     return P
 
 

@@ -208,3 +208,40 @@ def test_vit_backward_matches_reference_grads(hip, path):
     missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]
     assert not missing, f"no gradient produced for {missing[:5]}"
     grad_case.check_against_fixture(g, grads, 1e-3, "HIP ViT backward vs reference")
+
+
+MEDGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "medgrad_*.npz")))
+
+
+@pytest.mark.parametrize("path", MEDGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in MEDGRAD_CASES])
+def test_med_text_layer_backward_matches_reference_grads(hip, path):
+    """The MED BertLayer in mode 'text' under autograd (madtp_amd/backward.py::MedTextLayerFunction: masked self-attention, output
+    LayerNorm, Reduce_token on the post-LN tokens, FFN; fp32 mode) against the reference's own .grad of models/med.py
+    BertLayer.forward (hidden, token_attn, the layer's 16 parameters; tests/golden/medgrad_*.npz, ragged padding masks) and against
+    autograd through the CPU oracle on every entry.  Loss = oracle.vit_loss on the layer output (token-order invariant)."""
+    from madtp_amd import med, runtime
+    from oracle import madtp_oracle as O
+    from tests import grad_case
+    g = np.load(path)
+    c = grad_case.build_med(g)
+    layer = grad_case.build_med_layer(c)
+    hidden = c["hidden"].cuda().requires_grad_(True)
+    ta = c["token_attn"].cuda().requires_grad_(True)
+    mask = c["add_mask"].cuda()
+    gv, hv = c["g"].cuda(), c["h"].cuda()
+    with runtime.precision("fp32"):
+        out = layer(hidden, mask, None, None, None, None, False, mode="text", token_attn=ta, reduce_num=0, temperature=c["T"])
+        y, mask_out = out[0], out[-1]
+        assert y.requires_grad and tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
+        assert abs(float(y.detach().double().norm()) - float(g["y_norm"])) < 1e-4 * float(g["y_norm"])
+        assert sorted(mask_out[:, 0, 0, :].cpu().reshape(-1).tolist()) == sorted(g["mask_out"].reshape(-1).tolist())
+        O.vit_loss(y, gv, hv).backward()
+    grads = {"hidden": hidden.grad, "token_attn": ta.grad}
+    grads.update({k: p.grad for k, p in layer.named_parameters() if p.grad is not None})
+    grad_case.check_against_fixture(g, grads, 1e-3, "HIP MED layer backward vs reference")
+    ref, yo, _, _ = O.bert_layer_grads(c["W"], c["prefix"], c["hidden"], c["add_mask"], c["T"], c["token_attn"], c["g"], c["h"],
+                                       layer_num=c["layer"])
+    for name, r in ref.items():
+        scale = ref[name[:-8] + "query.bias"] if name.endswith("key.bias") else r   # (a key bias has no true gradient: noise)
+        e = float((grads[name].cpu() - r).abs().max()) / max(float(scale.abs().max()), 1e-12)
+        assert e < 1e-3, f"grad {name}: {e:.3e} of its maximum"

@@ -610,3 +610,23 @@ def test_oracle_vit_backward_matches_reference_grads(path):
         if f"vit{i}_idx" in g.files:
             assert [set(r.tolist()) for r in t["indices"]] == [set(r.tolist()) for r in g[f"vit{i}_idx"]], f"layer {i} kept sets"
     grad_case.check_against_fixture(g, grads, 5e-5, "oracle autograd vs reference (whole ViT)")
+
+
+MEDGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "medgrad_*.npz")))
+
+
+@pytest.mark.parametrize("path", MEDGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in MEDGRAD_CASES])
+def test_oracle_med_layer_backward_matches_reference_grads(path):
+    """SURVEY 8(f) rank 4, text side: autograd through oracle.bert_layer (mode 'text', pruned) == the reference's own .grad of
+    models/med.py BertLayer.forward (hidden, token_attn, 16 parameters), recorded by tools/make_golden.py::med_layer_grad_case."""
+    from tests import grad_case
+    g = np.load(path)
+    c = grad_case.build_med(g)
+    assert np.allclose(c["hidden"][:, :2, :8].numpy(), g["h_head"], rtol=2e-5, atol=2e-6), "layer input differs from the recording"
+    assert np.allclose(c["token_attn"][:, :2, :8].numpy(), g["ta_head"], rtol=2e-5, atol=1e-4)
+    grads, y, mask_out, info = O.bert_layer_grads(c["W"], c["prefix"], c["hidden"], c["add_mask"], c["T"], c["token_attn"],
+                                                  c["g"], c["h"], layer_num=c["layer"])
+    assert tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
+    assert abs(float(y.double().norm()) - float(g["y_norm"])) < 1e-5 * float(g["y_norm"])
+    assert np.array_equal(mask_out[:, 0, 0, :].numpy(), g["mask_out"])
+    grad_case.check_against_fixture(g, grads, 5e-5, "oracle autograd vs reference (MED text layer)")

@@ -206,6 +206,68 @@ def med_case(name, B, L, Nimg, temperature, mode, seed=0, pad_tail=0):
     print(f"[{name}] T={temperature} mode={mode} txt_lens={lens}")
 
 
+def med_layer_grad_case(name, B, L, temperature, layer=0, seed=0, pad_tail=0, nsample=512):
+    """SURVEY 8(f) rank 4 (backward), text side: the reference's OWN autograd through models/med.py BertLayer.forward (mode
+    'text': self-attention with the padding mask, output LayerNorm, Reduce_token on the post-LN tokens, FFN) for one layer.  The
+    layer's input, additive mask and token_attn are captured from a no-grad forward of the reference BertModel (pre-hook of layer
+    `layer`, token_attn cloned before Reduce_token divides it in place, med.py:360), then the layer runs again alone with
+    hidden_states and token_attn as leaves and loss = oracle.vit_loss(out, g, h) (token-order invariant).  Recorded: the pruning
+    decision and of every gradient (hidden, token_attn, the layer's 16 parameters) its L2 norm, sum and sampled entries."""
+    import models.med as rmed
+    from madtp_amd import specs
+    from oracle import madtp_oracle as O
+    cfg = rmed.BertConfig.from_json_file("configs/med_config.json")
+    cfg.encoder_width = 768
+    cfg.evaluate = True
+    model = rmed.BertModel(config=cfg, add_pooling_layer=False)
+    model.eval()
+    msg = model.load_state_dict(specs.synth_weights(specs.bert_shapes("", "med"), seed), strict=False)
+    assert not msg.unexpected_keys
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed)
+    ids = synth.synth_token_ids(B, L, seed + 1)
+    att = torch.ones_like(ids)
+    if pad_tail:
+        for b in range(B):
+            att[b, L - (b % (pad_tail + 1)):] = 0
+    cap = {}
+    lay = model.encoder.layer[layer]
+    hk = lay.register_forward_pre_hook(lambda m, a, kw: cap.update(h=a[0].detach().clone(), mask=a[1].detach().clone(),
+                                                                    ta=kw["token_attn"].detach().clone()), with_kwargs=True)
+    with torch.no_grad():
+        model(ids, attention_mask=att, return_dict=True, mode="text", space_dict=space_dict, temperature=temperature)
+    hk.remove()
+    hid = cap["h"].clone().requires_grad_(True)
+    ta = cap["ta"].clone().requires_grad_(True)
+    tap = GatherTap(rmed)
+    tap.set_tag("lay")
+    for p_ in lay.parameters():
+        p_.grad = None
+    out = lay(hid, cap["mask"], None, None, None, None, False, mode="text", space_dict=space_dict, token_attn=ta * 1.0,
+              reduce_num=0, temperature=temperature)
+    tap.restore()
+    y = out[0]
+    g = torch.from_numpy(synth.uniform_pm1("vitgrad_g", B * 768, seed).reshape(B, 768))
+    h = torch.from_numpy(synth.uniform_pm1("vitgrad_h", B * 768, seed).reshape(B, 768))
+    O.vit_loss(y, g, h).backward()
+    rec = {"kind": "med_layer_grad", "B": B, "L": L, "temperature": np.float64(temperature), "seed": seed, "layer": layer,
+           "pad_tail": pad_tail, "nsample": nsample, "out_shape": np.array(y.shape),
+           "y_norm": np.float64(y.detach().double().norm().item()), "mask_out": out[-1].detach()[:, 0, 0, :].numpy(),
+           "h_head": cap["h"][:, :2, :8].numpy(), "ta_head": cap["ta"][:, :2, :8].numpy()}
+    rec.update(tap.records)
+    grads = {"hidden": hid.grad, "token_attn": ta.grad}
+    grads.update({k: v.grad for k, v in lay.named_parameters() if v.grad is not None})
+    assert ta.grad is not None and y.shape[1] < L, f"layer not pruned at T={temperature}: output {tuple(y.shape)}"
+    for k, gr in grads.items():
+        flat = gr.detach().reshape(-1)
+        idx = grad_sample_index(flat.numel(), nsample)
+        rec[f"g_{k}_sample"] = flat[torch.from_numpy(idx)].numpy()
+        rec[f"g_{k}_norm"] = np.float64(flat.double().norm().item())
+        rec[f"g_{k}_sum"] = np.float64(flat.double().sum().item())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] layer {layer} T={temperature} out {tuple(y.shape)} {len(grads)} gradients: {sorted(grads)[:4]}... "
+          f"|dh| {rec['g_hidden_norm']:.4e} |dta| {rec['g_token_attn_norm']:.4e} records {sorted(tap.records)}")
+
+
 def vit_case(name, B, size, temperature, seed=0):
     """models/vit.py VisionTransformer stand-alone at a large image size (384 -> 577 tokens: retrieval/NLVR yaml
     configs; 480 -> 901 tokens: configs/vqa.yaml)."""
@@ -648,6 +710,8 @@ CASES = {
     "blockgrad_b2": lambda: vit_block_grad_case("blockgrad_b2", 2, 224, 5.0, layer=0),
     "blockgrad_b2_l3": lambda: vit_block_grad_case("blockgrad_b2_l3", 2, 224, 5.0, layer=3),
     "encgrad_b2_s96": lambda: vit_grad_case("encgrad_b2_s96", 2, 96, 5.0),
+    "medgrad_b3_l0": lambda: med_layer_grad_case("medgrad_b3_l0", 3, 35, 30.0, layer=0, pad_tail=3),
+    "medgrad_b3_l3": lambda: med_layer_grad_case("medgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
 }
 
 if __name__ == "__main__":
