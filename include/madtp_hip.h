@@ -541,6 +541,14 @@ int madtp_token_score_bwd(const float* dw, const float* score, const int32_t* ds
  *   dS = P (dP - rowsum(P dP)); dq = scale dS k; dk = scale dS^T q; dv = P^T dout      (dout += dnrm_scale * out first)
  * q/k/v/dq/dk/dv: f32, rows b*N+i, head h at columns [64h, 64h+64) of each base pointer (slices of the fused qkv buffer).
  * ws: madtp_attention_bwd_workspace(B,H,N) bytes (P and dS [B,H,N,N] f32 + the head arg-max [B,N,N]).  N <= 1024. */
+/* Cross-attention backward (med.py:143-236 with encoder_hidden_states; nlvr_encoder.py:142-237): Nq text queries against Nk
+ * encoder tokens, softmax probabilities recomputed, no score terms.  q [B*Nq, ldq], k / v [B*Nk, ldkv] (e.g. the halves of a fused
+ * [k|v] projection), dout [B*Nq, ldo] -> dq [B*Nq, lddq], dk / dv [B*Nk, lddkv]; key_mask additive [B,Nk] or NULL; exact f32. */
+size_t madtp_attention_bwd_cross_workspace(int B, int H, int Nq, int Nk);
+int madtp_attention_bwd_cross(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* key_mask,
+                              const float* dout, int ldo, float* dq, int lddq, float* dk, float* dv, int lddkv, void* ws,
+                              size_t ws_bytes, int B, int H, int Nq, int Nk, float scale, void* stream);
+
 /* Backward of the query model's att_ft branch (models/utils.py:174-178: W = softmax over tokens of inner / sqrt(sd_dim), att_ft =
  * W q), the part of VisionTransformer.forward's second output (vit.py:297-303, consumed by the training drivers' alignment loss).
  * Given dA = d att_ft [B,K,D]: dinner[B,n,K] += W (q dA^T - sum_n W q dA^T) / sqrt(sd_dim), dq[B,n,D] += W^T dA.  inner, dinner: dense

@@ -127,6 +127,23 @@ def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None, 
     return dqkv
 
 
+def attention_bwd_cross(q, kv, dout, B, H, Nq, Nk, scale, key_mask=None):
+    """Cross-attention backward: q f32 [B*Nq, D], kv f32 [B*Nk, 2D] (fused [k|v] projection of the encoder tokens), dout [B*Nq, D]
+    -> (dq [B*Nq, D], dkv [B*Nk, 2D])."""
+    D = H * 64
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    lib = load()
+    nbytes = lib.madtp_attention_bwd_cross_workspace(B, H, Nq, Nk)
+    ws = torch.empty((nbytes,), device=q.device, dtype=torch.uint8)
+    k, v = kv[:, :D], kv[:, D:]
+    dk, dv = dkv[:, :D], dkv[:, D:]
+    _check(lib.madtp_attention_bwd_cross(_p(q), q.stride(0), _p(k), _p(v), kv.stride(0), _p(key_mask), _p(dout), dout.stride(0),
+                                         _p(dq), dq.stride(0), _p(dk), _p(dv), dkv.stride(0), _p(ws), nbytes, B, H, Nq, Nk,
+                                         float(scale), _stream()), "madtp_attention_bwd_cross")
+    return dq, dkv
+
+
 def _f32_lin(linear):
     """(weight padded to 128 rows, bias) of an nn.Linear for the exact-f32 GEMM."""
     w = linear.weight.detach()
@@ -246,9 +263,9 @@ def block_forward_with_grad(blk, x, temperature, token_attn):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# MED text layer (models/med.py BertLayer.forward :393-462 in mode 'text'): self-attention with the padding mask, output
-# LayerNorm, Reduce_token on the post-LN tokens (:345-391 - the same importance score and merge rule as the ViT block), FFN with
-# post-LayerNorm.  Same recipe as vit_block_backward: recompute the forward from (hidden, token_attn) with the forward's own fp32
+# MED layer (models/med.py BertLayer.forward :393-462): self-attention with the padding mask, output LayerNorm, Reduce_token on
+# the post-LN tokens (:345-391 - the same importance score and merge rule as the ViT block), in mode 'multimodal' cross-attention
+# to the image tokens, FFN with post-LayerNorm.  Same recipe as vit_block_backward: recompute the forward from (hidden, token_attn) with the forward's own fp32
 # kernels and the forward's k, then walk the graph backwards.
 
 _MED_PARAMS = ("attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight", "attention.self.key.bias",
@@ -256,17 +273,22 @@ _MED_PARAMS = ("attention.self.query.weight", "attention.self.query.bias", "atte
                "attention.output.dense.bias", "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias",
                "intermediate.dense.weight", "intermediate.dense.bias", "output.dense.weight", "output.dense.bias",
                "output.LayerNorm.weight", "output.LayerNorm.bias")
+_MED_CROSS_PARAMS = ("crossattention.self.query.weight", "crossattention.self.query.bias", "crossattention.self.key.weight",
+                     "crossattention.self.key.bias", "crossattention.self.value.weight", "crossattention.self.value.bias",
+                     "crossattention.output.dense.weight", "crossattention.output.dense.bias",
+                     "crossattention.output.LayerNorm.weight", "crossattention.output.LayerNorm.bias")
 
 
-def _med_params_of(layer):
+def _med_params_of(layer, cross):
     mods = dict(layer.named_parameters())
-    return [mods[n] for n in _MED_PARAMS]
+    return [mods[n] for n in (_MED_PARAMS + _MED_CROSS_PARAMS if cross else _MED_PARAMS)]
 
 
-def med_text_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy):
-    """Gradients of the MED BertLayer in mode 'text' at (hidden [B,L,D], token_attn [B,L-1,K]) for the output gradient dy
-    [B,L',D]; mask2d: additive key mask [B,L] or None; k: the forward's pruning decision (0 = not pruned).  Returns
-    (dhidden, dtoken_attn or None, {parameter name: grad})."""
+def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, enc=None):
+    """Gradients of the MED BertLayer (med.py:393-462) at (hidden [B,L,D], token_attn [B,L-1,K]) for the output gradient dy
+    [B,L',D]; mask2d: additive key mask [B,L] or None; k: the forward's pruning decision (0 = not pruned); enc [B,Nk,Denc]: the
+    encoder tokens of mode 'multimodal' (cross-attention between the pruning step and the FFN; MED ignores the encoder mask,
+    med.py:197-199) or None for mode 'text'.  Returns (dhidden, dtoken_attn or None, denc or None, {parameter name: grad})."""
     B, L, D = hidden.shape
     sa, so = layer.attention.self, layer.attention.output
     H, scale = sa.num_attention_heads, 1.0 / math.sqrt(sa.attention_head_size)
@@ -291,10 +313,25 @@ def med_text_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, d
     L2 = y0.shape[1]
     M2 = B * L2
     y02 = y0.reshape(M2, D)
+    if enc is not None:
+        ca, co = layer.crossattention.self, layer.crossattention.output
+        Nk, De = enc.shape[1], enc.shape[2]
+        enc2 = enc.reshape(B * Nk, De).contiguous().float()
+        wcq, bcq = _f32_lin(ca.query)
+        wckv = torch.cat([ca.key.weight.detach(), ca.value.weight.detach()], 0).contiguous()  # [2D, Denc]
+        bckv = torch.cat([ca.key.bias.detach(), ca.value.bias.detach()], 0).contiguous()
+        wcd, bcd = _f32_lin(co.dense)
+        cq = hip.gemm(y02, wcq, bcq, n=D, out_dtype=torch.float32)
+        ckv = hip.gemm(enc2, wckv, bckv, n=2 * D, out_dtype=torch.float32)
+        cctx, _ = hip.attention(cq, ckv[:, :D], ckv[:, D:], B, H, L2, Nk, scale)
+        c0 = hip.gemm(cctx, wcd, bcd, residual=y02, n=D, out_dtype=torch.float32)
+        x2, _ = hip.layernorm(c0, co.LayerNorm.weight.detach(), co.LayerNorm.bias.detach(), co.LayerNorm.eps)
+    else:
+        x2 = y02
     F = layer.intermediate.dense.weight.shape[0]
-    u = hip.gemm(y02, wi, bi, n=F, out_dtype=torch.float32)
+    u = hip.gemm(x2, wi, bi, n=F, out_dtype=torch.float32)
     gl = act_fwd(u, hip.ACT_GELU)
-    f0 = hip.gemm(gl, wout, bout, residual=y02, n=D, out_dtype=torch.float32)
+    f0 = hip.gemm(gl, wout, bout, residual=x2, n=D, out_dtype=torch.float32)
     # ---- backward ----
     grads = {}
     ln2 = layer.output.LayerNorm
@@ -303,8 +340,24 @@ def med_text_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, d
     dgl = dgrad(df0, layer.output.dense.weight.detach())
     grads["output.dense.weight"], grads["output.dense.bias"] = wgrad(df0, gl), colsum(df0)
     du = act_bwd(u, dgl, hip.ACT_GELU)
-    dy0 = dgrad(du, layer.intermediate.dense.weight.detach(), residual=df0)   # f0 = y0 + ffn(y0)
-    grads["intermediate.dense.weight"], grads["intermediate.dense.bias"] = wgrad(du, y02), colsum(du)
+    dx2 = dgrad(du, layer.intermediate.dense.weight.detach(), residual=df0)   # f0 = x2 + ffn(x2)
+    grads["intermediate.dense.weight"], grads["intermediate.dense.bias"] = wgrad(du, x2), colsum(du)
+    denc = None
+    if enc is not None:
+        dc0, grads["crossattention.output.LayerNorm.weight"], grads["crossattention.output.LayerNorm.bias"] = layernorm_bwd(
+            c0, co.LayerNorm.weight.detach(), dx2, co.LayerNorm.eps)
+        dcctx = dgrad(dc0, co.dense.weight.detach())                          # c0 = y0 + cctx Wd^T + bd
+        grads["crossattention.output.dense.weight"], grads["crossattention.output.dense.bias"] = wgrad(dc0, cctx), colsum(dc0)
+        dcq, dckv = attention_bwd_cross(cq, ckv, dcctx, B, H, L2, Nk, scale)
+        dy0 = dgrad(dcq, ca.query.weight.detach(), residual=dc0)
+        grads["crossattention.self.query.weight"], grads["crossattention.self.query.bias"] = wgrad(dcq, y02), colsum(dcq)
+        denc = dgrad(dckv, wckv).view(B, Nk, De)
+        gw, gb = wgrad(dckv, enc2), colsum(dckv)
+        for i, nm in enumerate(("key", "value")):
+            grads[f"crossattention.self.{nm}.weight"] = gw[i * D:(i + 1) * D]
+            grads[f"crossattention.self.{nm}.bias"] = gb[i * D:(i + 1) * D]
+    else:
+        dy0 = dx2
     dta = dnrm = da = dp0 = None
     if k > 0:
         dao3, dw = token_gather_bwd(dy0.view(B, L2, D), ao.view(B, L, D), dst_pos, merge_w, k)
@@ -323,25 +376,29 @@ def med_text_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, d
     for i, nm in enumerate(("query", "key", "value")):
         grads[f"attention.self.{nm}.weight"] = gw[i * D:(i + 1) * D]
         grads[f"attention.self.{nm}.bias"] = gb[i * D:(i + 1) * D]
-    return dh.view(B, L, D), dta, grads
+    return dh.view(B, L, D), dta, denc, grads
 
 
-class MedTextLayerFunction(torch.autograd.Function):
-    """MED BertLayer.forward in mode 'text' with a hand-written backward.  Inputs after (layer, temperature, mask2d): hidden,
-    token_attn (or None), then the layer's 16 parameters in _MED_PARAMS order.  Returns (layer output, new additive mask [B,L'])."""
+class MedLayerFunction(torch.autograd.Function):
+    """MED BertLayer.forward (modes 'text' and 'multimodal') with a hand-written backward.  Inputs after (layer, temperature,
+    mask2d): hidden, token_attn (or None), enc (encoder tokens [B,Nk,Denc] or None), then the layer's parameters in _MED_PARAMS
+    (+ _MED_CROSS_PARAMS) order.  Returns (layer output, new additive mask [B,L'])."""
 
     @staticmethod
-    def forward(ctx, layer, temperature, mask2d, hidden, token_attn, *params):
+    def forward(ctx, layer, temperature, mask2d, hidden, token_attn, enc, *params):
         prune = temperature > 0
-        y, mask_out, info, _ = hip.bert_layer(layer._weights(), hidden, mask2d, token_attn, temperature if prune else 0, False,
-                                              None, None, 0, None, None)
+        cross = enc is not None
+        enc2 = enc.reshape(-1, enc.shape[-1]).contiguous().float() if cross else None
+        y, mask_out, info, _ = hip.bert_layer(layer._weights(), hidden, mask2d, token_attn, temperature if prune else 0, cross,
+                                              enc2, None, enc.shape[1] if cross else 0, None, None)
         layer.last_prune = info
-        ctx.layer, ctx.temperature = layer, float(temperature)
+        ctx.layer, ctx.temperature, ctx.cross = layer, float(temperature), cross
         ctx.k = int(info["indices"].shape[1]) if (info is not None and info.get("pruned")) else 0
         ctx.has_ta = token_attn is not None
         ctx.has_mask = mask2d is not None
-        ctx.save_for_backward(hidden, token_attn if token_attn is not None else hidden.new_empty(0),
-                              mask2d if mask2d is not None else hidden.new_empty(0))
+        e = hidden.new_empty(0)
+        ctx.save_for_backward(hidden, token_attn if token_attn is not None else e, mask2d if mask2d is not None else e,
+                              enc if cross else e)
         if mask_out is None:
             mask_out = mask2d if mask2d is not None else hidden.new_zeros((hidden.shape[0], y.shape[1]))
         ctx.mark_non_differentiable(mask_out)
@@ -349,24 +406,27 @@ class MedTextLayerFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dmask):
-        hidden, ta, mask2d = ctx.saved_tensors
+        hidden, ta, mask2d, enc = ctx.saved_tensors
         ta = ta if ctx.has_ta else None
         with torch.no_grad():
-            dh, dta, grads = med_text_layer_backward(ctx.layer, hidden, mask2d if ctx.has_mask else None, ta, ctx.temperature, ctx.k, dy)
+            dh, dta, denc, grads = med_layer_backward(ctx.layer, hidden, mask2d if ctx.has_mask else None, ta, ctx.temperature,
+                                                      ctx.k, dy, enc if ctx.cross else None)
         if ctx.has_ta and dta is None:
             dta = torch.zeros_like(ta)
-        return (None, None, None, dh, dta if ctx.has_ta else None) + tuple(grads.get(n) for n in _MED_PARAMS)
+        names = _MED_PARAMS + _MED_CROSS_PARAMS if ctx.cross else _MED_PARAMS
+        return (None, None, None, dh, dta if ctx.has_ta else None, denc) + tuple(grads.get(n) for n in names)
 
 
-def med_text_layer_forward_with_grad(layer, hidden, mask2d, temperature, token_attn):
-    """MED BertLayer (mode 'text') under autograd -> (output, new additive mask [B,L'] or None); fp32 mode only."""
+def med_layer_forward_with_grad(layer, hidden, mask2d, temperature, token_attn, enc=None):
+    """MED BertLayer under autograd -> (output, new additive mask [B,L'] or None); enc: the encoder tokens of mode 'multimodal'
+    (a tensor of the autograd graph - the image tokens - or None for mode 'text'); fp32 mode only."""
     from . import runtime
     if runtime.get_precision() != "fp32":
         raise NotImplementedError("the BERT layer backward is built for the fp32 precision mode (runtime.precision('fp32')); "
                                   f"current mode: {runtime.get_precision()}")
     if token_attn is not None and not token_attn.is_contiguous():
         token_attn = token_attn.contiguous()
-    y, mask_out = MedTextLayerFunction.apply(layer, temperature, mask2d, hidden, token_attn, *_med_params_of(layer))
+    y, mask_out = MedLayerFunction.apply(layer, temperature, mask2d, hidden, token_attn, enc, *_med_params_of(layer, enc is not None))
     return y, (mask_out if mask2d is not None else None)
 
 

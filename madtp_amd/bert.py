@@ -359,13 +359,18 @@ class _BertLayerBase(nn.Module):
         if prune and mask2d is None:
             raise ValueError("attention_mask is required when temperature > 0 (med.py:424)")
         cross = mode == 'multimodal'
-        if (torch.is_grad_enabled() and not cross and causal is None and self.variant == "med" and get_precision() == "fp32"
+        if (torch.is_grad_enabled() and causal is None and self.variant == "med" and get_precision() == "fp32"
                 and (hidden.requires_grad or (token_attn is not None and token_attn.requires_grad)
+                     or (cross and encoder_hidden_states is not None and encoder_hidden_states.requires_grad)
                      or any(p.requires_grad for p in self.parameters()))):
-            # training / compression use: the text-mode MED layer as an autograd.Function around the same
-            # kernels (madtp_amd/backward.py); cross-attention layers and the NLVR variant have no backward yet
-            from .backward import med_text_layer_forward_with_grad
-            y, mask_out = med_text_layer_forward_with_grad(self, hidden, mask2d, temperature if prune else 0, token_attn)
+            # training / compression use: the MED layer as an autograd.Function around the same kernels
+            # (madtp_amd/backward.py); the NLVR variant (twin cross-attention) has no backward yet
+            from .backward import med_layer_forward_with_grad
+            self.__dict__.pop("_kv_pre", None)
+            if cross:
+                assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
+            y, mask_out = med_layer_forward_with_grad(self, hidden, mask2d, temperature if prune else 0, token_attn,
+                                                      encoder_hidden_states if cross else None)
             if mask_out is not None:
                 attention_mask = mask_out[:, None, None, :]
             return (y, None, attention_mask)

@@ -282,24 +282,26 @@ struct AttnBwdArgs {
     float* P; float* dS;                 // scratch [B,H,N,N] each
     unsigned char* hm;                   // scratch [B,N,N]: argmax_h P[b,h,i,j]
     float *dq, *dk, *dv; int ldd;        // outputs, same layout as q/k/v
-    int B, H, N; float scale;
-    const float* key_mask;               // [B,N] additive key mask (BERT padding mask, med.py:197-199) or NULL
+    int B, H, N; float scale;            // N = Nq (query rows per sample)
+    const float* key_mask;               // [B,Nk] additive key mask (BERT padding mask, med.py:197-199) or NULL
+    int Nk; int ldk; int lddk;           // keys per sample, leading dimension of k / v and of dk / dv (cross-attention: the keys
+                                         // come from another sequence and projection; self-attention: Nk = N, ldk = ld, lddk = ldd)
 };
 
 // P[b,h,i,:] = softmax_j(scale q_i . k_j) for 16 query rows per workgroup
 __global__ __launch_bounds__(256) void attn_probs_kernel(AttnBwdArgs a) {
     extern __shared__ float sm[];
-    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, i0 = blockIdx.y * 16, N = a.N, tid = threadIdx.x;
+    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, i0 = blockIdx.y * 16, NQ = a.N, N = a.Nk, tid = threadIdx.x;
     float* Qs = sm;                 // [16][64]
-    float* S = sm + 16 * HD;        // [16][N]
+    float* S = sm + 16 * HD;        // [16][Nk]
     for (int e = tid; e < 16 * HD; e += 256) {
-        const int r = e >> 6, d = e & 63, i = min(i0 + r, N - 1);
-        Qs[e] = a.q[(size_t)(b * N + i) * a.ld + h * HD + d];
+        const int r = e >> 6, d = e & 63, i = min(i0 + r, NQ - 1);
+        Qs[e] = a.q[(size_t)(b * NQ + i) * a.ld + h * HD + d];
     }
     __syncthreads();
     for (int j = tid; j < N; j += 256) {
         float kr[HD];
-        const float* kp = a.k + (size_t)(b * N + j) * a.ld + h * HD;
+        const float* kp = a.k + (size_t)(b * N + j) * a.ldk + h * HD;
 #pragma unroll
         for (int d = 0; d < HD; d += 4) { const float4 t = *(const float4*)(kp + d); kr[d] = t.x; kr[d + 1] = t.y; kr[d + 2] = t.z; kr[d + 3] = t.w; }
         for (int r = 0; r < 16; ++r) {
@@ -318,8 +320,8 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(AttnBwdArgs a) {
     float sum = 0.f;
     for (int j = l; j < N; j += 16) { const float e = expf(S[r * N + j] - m); S[r * N + j] = e; sum += e; }
     sum = row16_sum(sum);
-    if (i0 + r < N) {
-        float* Pr = a.P + ((size_t)bh * N + i0 + r) * N;
+    if (i0 + r < NQ) {
+        float* Pr = a.P + ((size_t)bh * NQ + i0 + r) * N;
         for (int j = l; j < N; j += 16) Pr[j] = S[r * N + j] / sum;
     }
 }
@@ -341,32 +343,32 @@ __global__ __launch_bounds__(256) void attn_headmax_kernel(AttnBwdArgs a) {
 // rows pass: dP = dO V^T (+ score terms), dS = P (dP - rowsum(P dP)), dQ = scale dS K
 __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdArgs a) {
     extern __shared__ float sm[];
-    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, i0 = blockIdx.y * 16, N = a.N, tid = threadIdx.x;
+    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, i0 = blockIdx.y * 16, NQ = a.N, N = a.Nk, tid = threadIdx.x;
     float* dOs = sm;                  // [16][64]
     float* Ps = sm + 16 * HD;         // [16][N]
     float* Ds = Ps + 16 * N;          // [16][N]: dP, then dS
     for (int e = tid; e < 16 * HD; e += 256) {
         const int r = e >> 6, d = e & 63, i = i0 + r;
         float v = 0.f;
-        if (i < N) {
-            v = a.dout[(size_t)(b * N + i) * a.ldo + h * HD + d];
-            if (a.dnrm_scale) v += a.dnrm_scale[((size_t)b * a.H + h) * N + i] * a.out[(size_t)(b * N + i) * a.ldout + h * HD + d];
+        if (i < NQ) {
+            v = a.dout[(size_t)(b * NQ + i) * a.ldo + h * HD + d];
+            if (a.dnrm_scale) v += a.dnrm_scale[((size_t)b * a.H + h) * NQ + i] * a.out[(size_t)(b * NQ + i) * a.ldout + h * HD + d];
         }
         dOs[e] = v;
     }
     __syncthreads();
     for (int j = tid; j < N; j += 256) {
         float vr[HD];
-        const float* vp = a.v + (size_t)(b * N + j) * a.ld + h * HD;
+        const float* vp = a.v + (size_t)(b * N + j) * a.ldk + h * HD;
 #pragma unroll
         for (int d = 0; d < HD; d += 4) { const float4 t = *(const float4*)(vp + d); vr[d] = t.x; vr[d + 1] = t.y; vr[d + 2] = t.z; vr[d + 3] = t.w; }
         for (int r = 0; r < 16; ++r) {
             const int i = i0 + r;
             float dp = 0.f, p = 0.f;
-            if (i < N) {
+            if (i < NQ) {
 #pragma unroll
                 for (int d = 0; d < HD; ++d) dp = fmaf(dOs[r * HD + d], vr[d], dp);
-                p = a.P[((size_t)bh * N + i) * N + j];
+                p = a.P[((size_t)bh * NQ + i) * N + j];
                 if (j >= 1) {
                     if (i == 0) { if (a.dp0) dp += a.dp0[((size_t)b * a.H + h) * N + j]; }
                     else if (a.da && a.hm[((size_t)b * N + i) * N + j] == h) dp += a.da[(size_t)b * N + j];
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdArgs a) {
         for (int j = l; j < N; j += 16) {
             const float ds = Ps[r * N + j] * (Ds[r * N + j] - dsum);
             Ds[r * N + j] = ds;
-            if (i0 + r < N) a.dS[((size_t)bh * N + i0 + r) * N + j] = ds;
+            if (i0 + r < NQ) a.dS[((size_t)bh * NQ + i0 + r) * N + j] = ds;
         }
     }
     __syncthreads();
@@ -394,11 +396,11 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdArgs a) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = 0; j < N; ++j) {
             const float ds = Ds[r * N + j];
-            const float4 kv = *(const float4*)(a.k + (size_t)(b * N + j) * a.ld + h * HD + dq);
+            const float4 kv = *(const float4*)(a.k + (size_t)(b * N + j) * a.ldk + h * HD + dq);
             acc.x = fmaf(ds, kv.x, acc.x); acc.y = fmaf(ds, kv.y, acc.y); acc.z = fmaf(ds, kv.z, acc.z); acc.w = fmaf(ds, kv.w, acc.w);
         }
-        if (i0 + r < N)
-            *(float4*)(a.dq + (size_t)(b * N + i0 + r) * a.ldd + h * HD + dq) =
+        if (i0 + r < NQ)
+            *(float4*)(a.dq + (size_t)(b * NQ + i0 + r) * a.ldd + h * HD + dq) =
                 make_float4(acc.x * a.scale, acc.y * a.scale, acc.z * a.scale, acc.w * a.scale);
     }
 }
@@ -406,24 +408,24 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdArgs a) {
 // columns pass: dV_j = sum_i P_ij dO_i, dK_j = scale sum_i dS_ij Q_i for 16 keys per workgroup
 __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnBwdArgs a) {
     __shared__ float Pt[16][17], St[16][17], Qt[16][HD], Ot[16][HD];
-    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, j0 = blockIdx.y * 16, N = a.N, tid = threadIdx.x;
+    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, j0 = blockIdx.y * 16, NQ = a.N, N = a.Nk, tid = threadIdx.x;
     const int c = tid >> 4, dq = (tid & 15) * 4;
     float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), dk = dv;
-    for (int i0 = 0; i0 < N; i0 += 16) {
+    for (int i0 = 0; i0 < NQ; i0 += 16) {
         __syncthreads();
         {
             const int r = tid >> 4, cc = tid & 15, i = i0 + r, j = j0 + cc;
-            const bool ok = i < N && j < N;
-            Pt[r][cc] = ok ? a.P[((size_t)bh * N + i) * N + j] : 0.f;
-            St[r][cc] = ok ? a.dS[((size_t)bh * N + i) * N + j] : 0.f;
+            const bool ok = i < NQ && j < N;
+            Pt[r][cc] = ok ? a.P[((size_t)bh * NQ + i) * N + j] : 0.f;
+            St[r][cc] = ok ? a.dS[((size_t)bh * NQ + i) * N + j] : 0.f;
         }
         for (int e = tid; e < 16 * HD; e += 256) {
             const int r = e >> 6, d = e & 63, i = i0 + r;
             float qv = 0.f, ov = 0.f;
-            if (i < N) {
-                qv = a.q[(size_t)(b * N + i) * a.ld + h * HD + d];
-                ov = a.dout[(size_t)(b * N + i) * a.ldo + h * HD + d];
-                if (a.dnrm_scale) ov += a.dnrm_scale[((size_t)b * a.H + h) * N + i] * a.out[(size_t)(b * N + i) * a.ldout + h * HD + d];
+            if (i < NQ) {
+                qv = a.q[(size_t)(b * NQ + i) * a.ld + h * HD + d];
+                ov = a.dout[(size_t)(b * NQ + i) * a.ldo + h * HD + d];
+                if (a.dnrm_scale) ov += a.dnrm_scale[((size_t)b * a.H + h) * NQ + i] * a.out[(size_t)(b * NQ + i) * a.ldout + h * HD + d];
             }
             Qt[r][d] = qv;
             Ot[r][d] = ov;
@@ -438,8 +440,8 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnBwdArgs a) {
         }
     }
     if (j0 + c < N) {
-        *(float4*)(a.dv + (size_t)(b * N + j0 + c) * a.ldd + h * HD + dq) = dv;
-        *(float4*)(a.dk + (size_t)(b * N + j0 + c) * a.ldd + h * HD + dq) =
+        *(float4*)(a.dv + (size_t)(b * N + j0 + c) * a.lddk + h * HD + dq) = dv;
+        *(float4*)(a.dk + (size_t)(b * N + j0 + c) * a.lddk + h * HD + dq) =
             make_float4(dk.x * a.scale, dk.y * a.scale, dk.z * a.scale, dk.w * a.scale);
     }
 }
@@ -600,6 +602,7 @@ extern "C" int madtp_attention_probs(const float* q, const float* k, int ld, con
     if (ld % 4 || !aligned16(q) || !aligned16(k)) return MADTP_E_ALIGN;
     AttnBwdArgs a = {};
     a.q = q; a.k = k; a.ld = ld; a.P = P; a.B = B; a.H = H; a.N = N; a.scale = scale; a.key_mask = key_mask;
+    a.Nk = N; a.ldk = ld;
     const size_t lds_p = (size_t)(16 * HD + 16 * N) * sizeof(float);
     MADTP_ENSURE_MAX_LDS(attn_probs_kernel, lds_p);
     hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, (N + 15) / 16), dim3(256), lds_p, (hipStream_t)stream, a);
@@ -624,7 +627,7 @@ extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* 
     AttnBwdArgs a;
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.dout = dout; a.ldo = ldo; a.out = out; a.ldout = ldout; a.dnrm_scale = dnrm_scale;
     a.da = da; a.dp0 = dp0; a.dq = dq; a.dk = dk; a.dv = dv; a.ldd = ldd; a.B = B; a.H = H; a.N = N; a.scale = scale;
-    a.key_mask = key_mask;
+    a.key_mask = key_mask; a.Nk = N; a.ldk = ld; a.lddk = ldd;
     const size_t pn = (size_t)B * H * N * N;
     a.P = (float*)ws; a.dS = a.P + pn; a.hm = (unsigned char*)(a.dS + pn);
     hipStream_t s = (hipStream_t)stream;
@@ -640,6 +643,37 @@ extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* 
     return 0;
 }
 
+
+// Cross-attention backward (med.py:143-236 with encoder_hidden_states: Nq text queries against Nk encoder tokens, no score terms):
+// q [B*Nq, ldq], k / v [B*Nk, ldkv] (e.g. the two halves of a fused [k|v] projection of the encoder tokens), dout [B*Nq, ldo] ->
+// dq [B*Nq, lddq], dk / dv [B*Nk, lddkv].  key_mask: additive [B,Nk] or NULL (MED ignores the encoder mask, nlvr_encoder applies
+// it).  ws: 2 * B*H*Nq*Nk floats.  Nq, Nk <= 1024.
+extern "C" size_t madtp_attention_bwd_cross_workspace(int B, int H, int Nq, int Nk) {
+    return 2 * (size_t)B * H * Nq * Nk * sizeof(float);
+}
+extern "C" int madtp_attention_bwd_cross(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* key_mask,
+                                         const float* dout, int ldo, float* dq, int lddq, float* dk, float* dv, int lddkv, void* ws,
+                                         size_t ws_bytes, int B, int H, int Nq, int Nk, float scale, void* stream) {
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || !ws || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
+    if (Nq > 1024 || Nk > 1024) return MADTP_E_SHAPE;
+    if (ws_bytes < madtp_attention_bwd_cross_workspace(B, H, Nq, Nk)) return MADTP_E_BADARG;
+    if (ldq % 4 || ldkv % 4 || lddq % 4 || lddkv % 4 || !aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(dq) ||
+        !aligned16(dk) || !aligned16(dv)) return MADTP_E_ALIGN;
+    AttnBwdArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.ld = ldq; a.ldk = ldkv; a.dout = dout; a.ldo = ldo; a.dq = dq; a.dk = dk; a.dv = dv;
+    a.ldd = lddq; a.lddk = lddkv; a.B = B; a.H = H; a.N = Nq; a.Nk = Nk; a.scale = scale; a.key_mask = key_mask;
+    const size_t pn = (size_t)B * H * Nq * Nk;
+    a.P = (float*)ws; a.dS = a.P + pn;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds_p = (size_t)(16 * HD + 16 * Nk) * sizeof(float), lds_r = (size_t)(16 * HD + 32 * Nk) * sizeof(float);
+    MADTP_ENSURE_MAX_LDS(attn_probs_kernel, lds_p);
+    MADTP_ENSURE_MAX_LDS(attn_bwd_rows_kernel, lds_r);
+    hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, (Nq + 15) / 16), dim3(256), lds_p, s, a);
+    hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(B * H, (Nq + 15) / 16), dim3(256), lds_r, s, a);
+    hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(B * H, (Nk + 15) / 16), dim3(256), 0, s, a);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
 
 // d att_ft -> (d inner += ..., d q += ...), see att_ft_bwd_logits_kernel.  inner / dinner: dense [B, n, K]; q / dq: dense [B, n, D];
 // dA: [B, K, D]; ws: B K n floats.  inv_sqrt_d = 1 / sqrt(sd_dim) (models/utils.py:174).

@@ -87,16 +87,18 @@ def build_med(g):
         for b in range(B):
             att[b, L - (b % (pad_tail + 1)):] = 0
     add_mask = O.extended_mask(att)
+    mode = str(g["mode"]) if "mode" in g.files else "text"
+    enc = synth.synth_tensor("image_embeds", (B, int(g["Nimg"]), 768), seed).mul(25.0) if mode == "multimodal" else None
     with torch.no_grad():
         hidden = O.bert_embeddings(W, "embeddings.", ids)
         for l in range(layer):
             ta, _ = O.query_model(hidden[:, 1:, :], space_dict)
-            hidden, add_mask, _ = O.bert_layer(W, f"encoder.layer.{l}.", hidden, add_mask, T, ta, None, None, "text", l, "med")
+            hidden, add_mask, _ = O.bert_layer(W, f"encoder.layer.{l}.", hidden, add_mask, T, ta, enc, None, mode, l, "med")
         token_attn, _ = O.query_model(hidden[:, 1:, :], space_dict)
     gv = torch.from_numpy(synth.uniform_pm1("vitgrad_g", B * 768, seed).reshape(B, 768))
     hv = torch.from_numpy(synth.uniform_pm1("vitgrad_h", B * 768, seed).reshape(B, 768))
     return {"W": W, "prefix": f"encoder.layer.{layer}.", "hidden": hidden, "add_mask": add_mask, "token_attn": token_attn.contiguous(),
-            "T": T, "g": gv, "h": hv, "layer": layer}
+            "T": T, "g": gv, "h": hv, "layer": layer, "enc": enc, "mode": mode}
 
 
 def build_med_layer(c):

@@ -85,6 +85,29 @@ def test_attention_bwd_plain(hip, B, N):
     assert torch.equal(dqkv, bw.attention_bwd(qkv, dout, o.detach().contiguous(), B, H, N, 0.125))
 
 
+@pytest.mark.parametrize("B,Nq,Nk", [(2, 35, 197), (3, 20, 50), (1, 7, 577)])
+def test_attention_bwd_cross(hip, B, Nq, Nk):
+    """cross-attention backward (Nq queries against Nk keys of another sequence, fused [k|v] projection, optional key mask) vs
+    torch autograd."""
+    from madtp_amd import backward as bw
+    H, D = 12, 768
+    q, kv, dout = _rand(B * Nq, D, seed=1, scale=0.5).cuda(), _rand(B * Nk, 2 * D, seed=2, scale=0.5).cuda(), _rand(B * Nq, D, seed=3).cuda()
+    mask = torch.zeros(B, Nk)
+    mask[:, Nk - 3:] = -10000.0
+    for km in (None, mask.cuda()):
+        qr, kvr = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+        qh = qr.reshape(B, Nq, H, 64).permute(0, 2, 1, 3)
+        kh = kvr[:, :D].reshape(B, Nk, H, 64).permute(0, 2, 1, 3)
+        vh = kvr[:, D:].reshape(B, Nk, H, 64).permute(0, 2, 1, 3)
+        sc = (qh @ kh.transpose(-2, -1)) * 0.125
+        if km is not None:
+            sc = sc + km[:, None, None, :]
+        o = (sc.softmax(-1) @ vh).transpose(1, 2).reshape(B * Nq, D)
+        o.backward(dout)
+        dq, dkv = bw.attention_bwd_cross(q, kv, dout, B, H, Nq, Nk, 0.125, key_mask=km)
+        assert _rel(dq, qr.grad) < 2e-5 and _rel(dkv, kvr.grad) < 2e-5
+
+
 @pytest.mark.parametrize("B,n", [(3, 50), (2, 196), (1, 300)])
 def test_att_ft_bwd(hip, B, n):
     """madtp_att_ft_bwd vs torch autograd through models/utils.py:174-178 (softmax over tokens of inner / sqrt(d), W q); the kernel
@@ -214,7 +237,7 @@ MEDGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "medgrad_
 
 
 @pytest.mark.parametrize("path", MEDGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in MEDGRAD_CASES])
-def test_med_text_layer_backward_matches_reference_grads(hip, path):
+def test_med_layer_backward_matches_reference_grads(hip, path):
     """The MED BertLayer in mode 'text' under autograd (madtp_amd/backward.py::MedTextLayerFunction: masked self-attention, output
     LayerNorm, Reduce_token on the post-LN tokens, FFN; fp32 mode) against the reference's own .grad of models/med.py
     BertLayer.forward (hidden, token_attn, the layer's 16 parameters; tests/golden/medgrad_*.npz, ragged padding masks) and against
@@ -229,18 +252,22 @@ def test_med_text_layer_backward_matches_reference_grads(hip, path):
     ta = c["token_attn"].cuda().requires_grad_(True)
     mask = c["add_mask"].cuda()
     gv, hv = c["g"].cuda(), c["h"].cuda()
+    enc = c["enc"].cuda().requires_grad_(True) if c["enc"] is not None else None
+    enc_mask = torch.zeros(enc.shape[0], 1, 1, enc.shape[1], device="cuda") if enc is not None else None
     with runtime.precision("fp32"):
-        out = layer(hidden, mask, None, None, None, None, False, mode="text", token_attn=ta, reduce_num=0, temperature=c["T"])
+        out = layer(hidden, mask, None, enc, enc_mask, None, False, mode=c["mode"], token_attn=ta, reduce_num=0, temperature=c["T"])
         y, mask_out = out[0], out[-1]
         assert y.requires_grad and tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
         assert abs(float(y.detach().double().norm()) - float(g["y_norm"])) < 1e-4 * float(g["y_norm"])
         assert sorted(mask_out[:, 0, 0, :].cpu().reshape(-1).tolist()) == sorted(g["mask_out"].reshape(-1).tolist())
         O.vit_loss(y, gv, hv).backward()
     grads = {"hidden": hidden.grad, "token_attn": ta.grad}
+    if enc is not None:
+        grads["enc"] = enc.grad
     grads.update({k: p.grad for k, p in layer.named_parameters() if p.grad is not None})
     grad_case.check_against_fixture(g, grads, 1e-3, "HIP MED layer backward vs reference")
     ref, yo, _, _ = O.bert_layer_grads(c["W"], c["prefix"], c["hidden"], c["add_mask"], c["T"], c["token_attn"], c["g"], c["h"],
-                                       layer_num=c["layer"])
+                                       layer_num=c["layer"], enc=c["enc"])
     for name, r in ref.items():
         scale = ref[name[:-8] + "query.bias"] if name.endswith("key.bias") else r   # (a key bias has no true gradient: noise)
         e = float((grads[name].cpu() - r).abs().max()) / max(float(scale.abs().max()), 1e-12)

@@ -625,7 +625,7 @@ def test_oracle_med_layer_backward_matches_reference_grads(path):
     assert np.allclose(c["hidden"][:, :2, :8].numpy(), g["h_head"], rtol=2e-5, atol=2e-6), "layer input differs from the recording"
     assert np.allclose(c["token_attn"][:, :2, :8].numpy(), g["ta_head"], rtol=2e-5, atol=1e-4)
     grads, y, mask_out, info = O.bert_layer_grads(c["W"], c["prefix"], c["hidden"], c["add_mask"], c["T"], c["token_attn"],
-                                                  c["g"], c["h"], layer_num=c["layer"])
+                                                  c["g"], c["h"], layer_num=c["layer"], enc=c["enc"])
     assert tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
     assert abs(float(y.double().norm()) - float(g["y_norm"])) < 1e-5 * float(g["y_norm"])
     assert np.array_equal(mask_out[:, 0, 0, :].numpy(), g["mask_out"])

@@ -206,9 +206,10 @@ def med_case(name, B, L, Nimg, temperature, mode, seed=0, pad_tail=0):
     print(f"[{name}] T={temperature} mode={mode} txt_lens={lens}")
 
 
-def med_layer_grad_case(name, B, L, temperature, layer=0, seed=0, pad_tail=0, nsample=512):
+def med_layer_grad_case(name, B, L, temperature, layer=0, seed=0, pad_tail=0, nsample=512, mode="text", Nimg=0):
     """SURVEY 8(f) rank 4 (backward), text side: the reference's OWN autograd through models/med.py BertLayer.forward (mode
-    'text': self-attention with the padding mask, output LayerNorm, Reduce_token on the post-LN tokens, FFN) for one layer.  The
+    'text': self-attention with the padding mask, output LayerNorm, Reduce_token on the post-LN tokens, FFN; mode 'multimodal':
+    cross-attention to synthetic image tokens between the pruning step and the FFN, the tokens a leaf as well) for one layer.  The
     layer's input, additive mask and token_attn are captured from a no-grad forward of the reference BertModel (pre-hook of layer
     `layer`, token_attn cloned before Reduce_token divides it in place, med.py:360), then the layer runs again alone with
     hidden_states and token_attn as leaves and loss = oracle.vit_loss(out, g, h) (token-order invariant).  Recorded: the pruning
@@ -233,16 +234,21 @@ def med_layer_grad_case(name, B, L, temperature, layer=0, seed=0, pad_tail=0, ns
     lay = model.encoder.layer[layer]
     hk = lay.register_forward_pre_hook(lambda m, a, kw: cap.update(h=a[0].detach().clone(), mask=a[1].detach().clone(),
                                                                     ta=kw["token_attn"].detach().clone()), with_kwargs=True)
+    enc = synth.synth_tensor("image_embeds", (B, Nimg, 768), seed).mul(25.0) if mode == "multimodal" else None
+    enc_att = torch.ones(B, Nimg, dtype=torch.long) if enc is not None else None
     with torch.no_grad():
-        model(ids, attention_mask=att, return_dict=True, mode="text", space_dict=space_dict, temperature=temperature)
+        model(ids, attention_mask=att, encoder_hidden_states=enc, encoder_attention_mask=enc_att, return_dict=True, mode=mode,
+              space_dict=space_dict, temperature=temperature)
     hk.remove()
     hid = cap["h"].clone().requires_grad_(True)
     ta = cap["ta"].clone().requires_grad_(True)
+    encl = enc.clone().requires_grad_(True) if enc is not None else None
+    enc_mask = model.invert_attention_mask(enc_att) if enc is not None else None
     tap = GatherTap(rmed)
     tap.set_tag("lay")
     for p_ in lay.parameters():
         p_.grad = None
-    out = lay(hid, cap["mask"], None, None, None, None, False, mode="text", space_dict=space_dict, token_attn=ta * 1.0,
+    out = lay(hid, cap["mask"], None, encl, enc_mask, None, False, mode=mode, space_dict=space_dict, token_attn=ta * 1.0,
               reduce_num=0, temperature=temperature)
     tap.restore()
     y = out[0]
@@ -250,11 +256,13 @@ def med_layer_grad_case(name, B, L, temperature, layer=0, seed=0, pad_tail=0, ns
     h = torch.from_numpy(synth.uniform_pm1("vitgrad_h", B * 768, seed).reshape(B, 768))
     O.vit_loss(y, g, h).backward()
     rec = {"kind": "med_layer_grad", "B": B, "L": L, "temperature": np.float64(temperature), "seed": seed, "layer": layer,
-           "pad_tail": pad_tail, "nsample": nsample, "out_shape": np.array(y.shape),
+           "pad_tail": pad_tail, "nsample": nsample, "out_shape": np.array(y.shape), "mode": mode, "Nimg": Nimg,
            "y_norm": np.float64(y.detach().double().norm().item()), "mask_out": out[-1].detach()[:, 0, 0, :].numpy(),
            "h_head": cap["h"][:, :2, :8].numpy(), "ta_head": cap["ta"][:, :2, :8].numpy()}
     rec.update(tap.records)
     grads = {"hidden": hid.grad, "token_attn": ta.grad}
+    if encl is not None:
+        grads["enc"] = encl.grad
     grads.update({k: v.grad for k, v in lay.named_parameters() if v.grad is not None})
     assert ta.grad is not None and y.shape[1] < L, f"layer not pruned at T={temperature}: output {tuple(y.shape)}"
     for k, gr in grads.items():
@@ -712,6 +720,7 @@ CASES = {
     "encgrad_b2_s96": lambda: vit_grad_case("encgrad_b2_s96", 2, 96, 5.0),
     "medgrad_b3_l0": lambda: med_layer_grad_case("medgrad_b3_l0", 3, 35, 30.0, layer=0, pad_tail=3),
     "medgrad_b3_l3": lambda: med_layer_grad_case("medgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
+    "medgrad_mm_b3_l3": lambda: med_layer_grad_case("medgrad_mm_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3, mode="multimodal", Nimg=50),
 }
 
 if __name__ == "__main__":
