@@ -279,21 +279,69 @@ _MED_CROSS_PARAMS = ("crossattention.self.query.weight", "crossattention.self.qu
                      "crossattention.output.LayerNorm.weight", "crossattention.output.LayerNorm.bias")
 
 
+def _nlvr_cross_params(layer):
+    names = []
+    for br in ("self0", "self1"):
+        for nm in ("query", "key", "value"):
+            names += [f"crossattention.{br}.{nm}.weight", f"crossattention.{br}.{nm}.bias"]
+    names += ["crossattention.output.dense0.weight", "crossattention.output.dense0.bias", "crossattention.output.dense1.weight",
+              "crossattention.output.dense1.bias"]
+    if layer.crossattention.output.merge:
+        names += ["crossattention.output.merge_layer.weight", "crossattention.output.merge_layer.bias"]
+    return tuple(names + ["crossattention.output.LayerNorm.weight", "crossattention.output.LayerNorm.bias"])
+
+
+def _layer_param_names(layer, cross):
+    if not cross:
+        return _MED_PARAMS
+    return _MED_PARAMS + (_nlvr_cross_params(layer) if layer.variant == "nlvr" else _MED_CROSS_PARAMS)
+
+
 def _med_params_of(layer, cross):
     mods = dict(layer.named_parameters())
-    return [mods[n] for n in (_MED_PARAMS + _MED_CROSS_PARAMS if cross else _MED_PARAMS)]
+    return [mods[n] for n in _layer_param_names(layer, cross)]
 
 
-def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, enc=None):
-    """Gradients of the MED BertLayer (med.py:393-462) at (hidden [B,L,D], token_attn [B,L-1,K]) for the output gradient dy
-    [B,L',D]; mask2d: additive key mask [B,L] or None; k: the forward's pruning decision (0 = not pruned); enc [B,Nk,Denc]: the
-    encoder tokens of mode 'multimodal' (cross-attention between the pruning step and the FFN; MED ignores the encoder mask,
-    med.py:197-199) or None for mode 'text'.  Returns (dhidden, dtoken_attn or None, denc or None, {parameter name: grad})."""
+def _cross_branch_fwd(sm, y02, enc2, B, H, L2, Nk, scale, key_mask):
+    """One cross-attention branch (BertSelfAttention with encoder_hidden_states): -> (cq, ckv, cctx, wckv)."""
+    D = H * 64
+    wcq, bcq = _f32_lin(sm.query)
+    wckv = torch.cat([sm.key.weight.detach(), sm.value.weight.detach()], 0).contiguous()  # [2D, Denc]
+    bckv = torch.cat([sm.key.bias.detach(), sm.value.bias.detach()], 0).contiguous()
+    cq = hip.gemm(y02, wcq, bcq, n=D, out_dtype=torch.float32)
+    ckv = hip.gemm(enc2, wckv, bckv, n=2 * D, out_dtype=torch.float32)
+    cctx, _ = hip.attention(cq, ckv[:, :D], ckv[:, D:], B, H, L2, Nk, scale, add_mask=key_mask)
+    return cq, ckv, cctx, wckv
+
+
+def _cross_branch_bwd(prefix, sm, grads, dcctx, cq, ckv, wckv, y02, enc2, B, H, L2, Nk, scale, key_mask, dy0_acc):
+    """Backward of one cross-attention branch; -> (dy0_acc + its contribution to the layer tokens, d encoder tokens [B*Nk, Denc])."""
+    D = H * 64
+    dcq, dckv = attention_bwd_cross(cq, ckv, dcctx, B, H, L2, Nk, scale, key_mask=key_mask)
+    dy0 = dgrad(dcq, sm.query.weight.detach(), residual=dy0_acc)
+    grads[prefix + "query.weight"], grads[prefix + "query.bias"] = wgrad(dcq, y02), colsum(dcq)
+    denc = dgrad(dckv, wckv)
+    gw, gb = wgrad(dckv, enc2), colsum(dckv)
+    for i, nm in enumerate(("key", "value")):
+        grads[prefix + nm + ".weight"] = gw[i * D:(i + 1) * D]
+        grads[prefix + nm + ".bias"] = gb[i * D:(i + 1) * D]
+    return dy0, denc
+
+
+def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, enc=None, enc_masks=None):
+    """Gradients of a BertLayer - MED (med.py:393-462) or NLVR (nlvr_encoder.py:484-554) - at (hidden [B,L,D], token_attn
+    [B,L-1,K]) for the output gradient dy [B,L',D]; mask2d: additive key mask [B,L] or None; k: the forward's pruning decision
+    (0 = not pruned).  enc: None (mode 'text'), the encoder tokens [B,Nk,Denc] (MED, mode 'multimodal': one cross-attention between
+    the pruning step and the FFN, encoder mask ignored, med.py:197-199) or a list of two (NLVR: twin branches self0 / self1 whose
+    outputs are averaged, or merged by merge_layer from layer 6 on, nlvr_encoder.py:259-266; enc_masks: their additive key masks
+    [B,Nk] or None, applied as nlvr_encoder.py:196-198 does).  Returns (dhidden, dtoken_attn or None, denc (None / tensor / list),
+    {parameter name: grad})."""
     B, L, D = hidden.shape
     sa, so = layer.attention.self, layer.attention.output
     H, scale = sa.num_attention_heads, 1.0 / math.sqrt(sa.attention_head_size)
     M = B * L
     h2 = hidden.reshape(M, D)
+    twin = isinstance(enc, (list, tuple))
     # ---- recompute the forward ----
     wqkv = torch.cat([sa.query.weight.detach(), sa.key.weight.detach(), sa.value.weight.detach()], 0).contiguous()  # [3D, D]
     bqkv = torch.cat([sa.query.bias.detach(), sa.key.bias.detach(), sa.value.bias.detach()], 0).contiguous()
@@ -314,17 +362,27 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
     M2 = B * L2
     y02 = y0.reshape(M2, D)
     if enc is not None:
-        ca, co = layer.crossattention.self, layer.crossattention.output
-        Nk, De = enc.shape[1], enc.shape[2]
-        enc2 = enc.reshape(B * Nk, De).contiguous().float()
-        wcq, bcq = _f32_lin(ca.query)
-        wckv = torch.cat([ca.key.weight.detach(), ca.value.weight.detach()], 0).contiguous()  # [2D, Denc]
-        bckv = torch.cat([ca.key.bias.detach(), ca.value.bias.detach()], 0).contiguous()
-        wcd, bcd = _f32_lin(co.dense)
-        cq = hip.gemm(y02, wcq, bcq, n=D, out_dtype=torch.float32)
-        ckv = hip.gemm(enc2, wckv, bckv, n=2 * D, out_dtype=torch.float32)
-        cctx, _ = hip.attention(cq, ckv[:, :D], ckv[:, D:], B, H, L2, Nk, scale)
-        c0 = hip.gemm(cctx, wcd, bcd, residual=y02, n=D, out_dtype=torch.float32)
+        ca, co = layer.crossattention, layer.crossattention.output
+        encs = list(enc) if twin else [enc]
+        sms = [ca.self0, ca.self1] if twin else [ca.self]
+        ems = list(enc_masks) if (twin and enc_masks is not None) else [None] * len(encs)
+        Nk, De = encs[0].shape[1], encs[0].shape[2]
+        enc2s = [e.reshape(B * Nk, De).contiguous().float() for e in encs]
+        br = [_cross_branch_fwd(sm, y02, e2, B, H, L2, Nk, scale, em) for sm, e2, em in zip(sms, enc2s, ems)]
+        if twin:
+            w0, b0 = _f32_lin(co.dense0)
+            w1, b1 = _f32_lin(co.dense1)
+            d0 = hip.gemm(br[0][2], w0, b0, n=D, out_dtype=torch.float32)
+            d1 = hip.gemm(br[1][2], w1, b1, n=D, out_dtype=torch.float32)
+            if co.merge:
+                d01 = torch.cat([d0, d1], 1).contiguous()  # (a copy: the operand layout of merge_layer)
+                wm, bm = _f32_lin(co.merge_layer)
+                c0 = hip.gemm(d01, wm, bm, residual=y02, n=D, out_dtype=torch.float32)
+            else:
+                c0 = (d0 + d1) * 0.5 + y02
+        else:
+            wcd, bcd = _f32_lin(co.dense)
+            c0 = hip.gemm(br[0][2], wcd, bcd, residual=y02, n=D, out_dtype=torch.float32)
         x2, _ = hip.layernorm(c0, co.LayerNorm.weight.detach(), co.LayerNorm.bias.detach(), co.LayerNorm.eps)
     else:
         x2 = y02
@@ -344,18 +402,33 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
     grads["intermediate.dense.weight"], grads["intermediate.dense.bias"] = wgrad(du, x2), colsum(du)
     denc = None
     if enc is not None:
-        dc0, grads["crossattention.output.LayerNorm.weight"], grads["crossattention.output.LayerNorm.bias"] = layernorm_bwd(
-            c0, co.LayerNorm.weight.detach(), dx2, co.LayerNorm.eps)
-        dcctx = dgrad(dc0, co.dense.weight.detach())                          # c0 = y0 + cctx Wd^T + bd
-        grads["crossattention.output.dense.weight"], grads["crossattention.output.dense.bias"] = wgrad(dc0, cctx), colsum(dc0)
-        dcq, dckv = attention_bwd_cross(cq, ckv, dcctx, B, H, L2, Nk, scale)
-        dy0 = dgrad(dcq, ca.query.weight.detach(), residual=dc0)
-        grads["crossattention.self.query.weight"], grads["crossattention.self.query.bias"] = wgrad(dcq, y02), colsum(dcq)
-        denc = dgrad(dckv, wckv).view(B, Nk, De)
-        gw, gb = wgrad(dckv, enc2), colsum(dckv)
-        for i, nm in enumerate(("key", "value")):
-            grads[f"crossattention.self.{nm}.weight"] = gw[i * D:(i + 1) * D]
-            grads[f"crossattention.self.{nm}.bias"] = gb[i * D:(i + 1) * D]
+        P = "crossattention."
+        dc0, grads[P + "output.LayerNorm.weight"], grads[P + "output.LayerNorm.bias"] = layernorm_bwd(
+            c0, co.LayerNorm.weight.detach(), dx2, co.LayerNorm.eps)          # c0 = y0 + combine(branches)
+        if twin:
+            if co.merge:
+                dd01 = dgrad(dc0, co.merge_layer.weight.detach())             # [M2, 2D]
+                grads[P + "output.merge_layer.weight"], grads[P + "output.merge_layer.bias"] = wgrad(dc0, d01), colsum(dc0)
+                dds = [dd01[:, :D].contiguous(), dd01[:, D:].contiguous()]
+            else:
+                half = dc0 * 0.5
+                dds = [half, half]
+            dy0, dencs = dc0, []
+            for i, (sm, dd) in enumerate(zip(sms, dds)):
+                dn = (co.dense0, co.dense1)[i]
+                cq, ckv, cctx, wckv = br[i]
+                dcctx = dgrad(dd, dn.weight.detach())
+                grads[P + f"output.dense{i}.weight"], grads[P + f"output.dense{i}.bias"] = wgrad(dd, cctx), colsum(dd)
+                dy0, de = _cross_branch_bwd(P + f"self{i}.", sm, grads, dcctx, cq, ckv, wckv, y02, enc2s[i], B, H, L2, Nk, scale,
+                                            ems[i], dy0)
+                dencs.append(de.view(B, Nk, De))
+            denc = dencs
+        else:
+            cq, ckv, cctx, wckv = br[0]
+            dcctx = dgrad(dc0, co.dense.weight.detach())
+            grads[P + "output.dense.weight"], grads[P + "output.dense.bias"] = wgrad(dc0, cctx), colsum(dc0)
+            dy0, de = _cross_branch_bwd(P + "self.", sms[0], grads, dcctx, cq, ckv, wckv, y02, enc2s[0], B, H, L2, Nk, scale, None, dc0)
+            denc = de.view(B, Nk, De)
     else:
         dy0 = dx2
     dta = dnrm = da = dp0 = None
@@ -380,25 +453,29 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
 
 
 class MedLayerFunction(torch.autograd.Function):
-    """MED BertLayer.forward (modes 'text' and 'multimodal') with a hand-written backward.  Inputs after (layer, temperature,
-    mask2d): hidden, token_attn (or None), enc (encoder tokens [B,Nk,Denc] or None), then the layer's parameters in _MED_PARAMS
-    (+ _MED_CROSS_PARAMS) order.  Returns (layer output, new additive mask [B,L'])."""
+    """BertLayer.forward (MED: modes 'text' / 'multimodal'; NLVR: twin cross-attention) with a hand-written backward.  Inputs after
+    (layer, temperature, mask2d, enc_masks): hidden, token_attn (or None), enc0, enc1 (encoder tokens [B,Nk,Denc] or None; MED uses
+    enc0 only), then the layer's parameters in _layer_param_names order.  Returns (layer output, new additive mask [B,L'])."""
 
     @staticmethod
-    def forward(ctx, layer, temperature, mask2d, hidden, token_attn, enc, *params):
+    def forward(ctx, layer, temperature, mask2d, enc_masks, hidden, token_attn, enc0, enc1, *params):
         prune = temperature > 0
-        cross = enc is not None
-        enc2 = enc.reshape(-1, enc.shape[-1]).contiguous().float() if cross else None
+        cross = enc0 is not None
+        twin = enc1 is not None
+        flat = lambda e: e.reshape(-1, e.shape[-1]).contiguous().float()
+        em = enc_masks if enc_masks is not None else (None, None)
         y, mask_out, info, _ = hip.bert_layer(layer._weights(), hidden, mask2d, token_attn, temperature if prune else 0, cross,
-                                              enc2, None, enc.shape[1] if cross else 0, None, None)
+                                              flat(enc0) if cross else None, flat(enc1) if twin else None,
+                                              enc0.shape[1] if cross else 0, em[0] if twin else None, em[1] if twin else None)
         layer.last_prune = info
-        ctx.layer, ctx.temperature, ctx.cross = layer, float(temperature), cross
+        ctx.layer, ctx.temperature, ctx.cross, ctx.twin = layer, float(temperature), cross, twin
         ctx.k = int(info["indices"].shape[1]) if (info is not None and info.get("pruned")) else 0
         ctx.has_ta = token_attn is not None
         ctx.has_mask = mask2d is not None
+        ctx.enc_masks = em if twin else None
         e = hidden.new_empty(0)
         ctx.save_for_backward(hidden, token_attn if token_attn is not None else e, mask2d if mask2d is not None else e,
-                              enc if cross else e)
+                              enc0 if cross else e, enc1 if twin else e)
         if mask_out is None:
             mask_out = mask2d if mask2d is not None else hidden.new_zeros((hidden.shape[0], y.shape[1]))
         ctx.mark_non_differentiable(mask_out)
@@ -406,27 +483,33 @@ class MedLayerFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dmask):
-        hidden, ta, mask2d, enc = ctx.saved_tensors
+        hidden, ta, mask2d, enc0, enc1 = ctx.saved_tensors
         ta = ta if ctx.has_ta else None
+        enc = ([enc0, enc1] if ctx.twin else enc0) if ctx.cross else None
         with torch.no_grad():
             dh, dta, denc, grads = med_layer_backward(ctx.layer, hidden, mask2d if ctx.has_mask else None, ta, ctx.temperature,
-                                                      ctx.k, dy, enc if ctx.cross else None)
+                                                      ctx.k, dy, enc, ctx.enc_masks)
         if ctx.has_ta and dta is None:
             dta = torch.zeros_like(ta)
-        names = _MED_PARAMS + _MED_CROSS_PARAMS if ctx.cross else _MED_PARAMS
-        return (None, None, None, dh, dta if ctx.has_ta else None, denc) + tuple(grads.get(n) for n in names)
+        de0, de1 = (denc if ctx.twin else (denc, None)) if ctx.cross else (None, None)
+        return (None, None, None, None, dh, dta if ctx.has_ta else None, de0, de1) + tuple(
+            grads.get(n) for n in _layer_param_names(ctx.layer, ctx.cross))
 
 
-def med_layer_forward_with_grad(layer, hidden, mask2d, temperature, token_attn, enc=None):
-    """MED BertLayer under autograd -> (output, new additive mask [B,L'] or None); enc: the encoder tokens of mode 'multimodal'
-    (a tensor of the autograd graph - the image tokens - or None for mode 'text'); fp32 mode only."""
+def med_layer_forward_with_grad(layer, hidden, mask2d, temperature, token_attn, enc=None, enc_masks=None):
+    """BertLayer (MED or NLVR) under autograd -> (output, new additive mask [B,L'] or None); enc: the encoder tokens of mode
+    'multimodal' (MED: a tensor; NLVR: a list of two, with enc_masks their additive key masks [B,Nk] or None) or None for mode
+    'text'; fp32 mode only."""
     from . import runtime
     if runtime.get_precision() != "fp32":
         raise NotImplementedError("the BERT layer backward is built for the fp32 precision mode (runtime.precision('fp32')); "
                                   f"current mode: {runtime.get_precision()}")
     if token_attn is not None and not token_attn.is_contiguous():
         token_attn = token_attn.contiguous()
-    y, mask_out = MedLayerFunction.apply(layer, temperature, mask2d, hidden, token_attn, enc, *_med_params_of(layer, enc is not None))
+    twin = isinstance(enc, (list, tuple))
+    e0, e1 = (enc[0], enc[1]) if twin else (enc, None)
+    y, mask_out = MedLayerFunction.apply(layer, temperature, mask2d, enc_masks if twin else None, hidden, token_attn, e0, e1,
+                                         *_med_params_of(layer, enc is not None))
     return y, (mask_out if mask2d is not None else None)
 
 

@@ -359,21 +359,29 @@ class _BertLayerBase(nn.Module):
         if prune and mask2d is None:
             raise ValueError("attention_mask is required when temperature > 0 (med.py:424)")
         cross = mode == 'multimodal'
-        if (torch.is_grad_enabled() and causal is None and self.variant == "med" and get_precision() == "fp32"
-                and (hidden.requires_grad or (token_attn is not None and token_attn.requires_grad)
-                     or (cross and encoder_hidden_states is not None and encoder_hidden_states.requires_grad)
-                     or any(p.requires_grad for p in self.parameters()))):
-            # training / compression use: the MED layer as an autograd.Function around the same kernels
-            # (madtp_amd/backward.py); the NLVR variant (twin cross-attention) has no backward yet
-            from .backward import med_layer_forward_with_grad
-            self.__dict__.pop("_kv_pre", None)
-            if cross:
-                assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
-            y, mask_out = med_layer_forward_with_grad(self, hidden, mask2d, temperature if prune else 0, token_attn,
-                                                      encoder_hidden_states if cross else None)
-            if mask_out is not None:
-                attention_mask = mask_out[:, None, None, :]
-            return (y, None, attention_mask)
+        if torch.is_grad_enabled() and causal is None and get_precision() == "fp32":
+            encs = (list(encoder_hidden_states) if isinstance(encoder_hidden_states, (list, tuple)) else [encoder_hidden_states]) \
+                if (cross and encoder_hidden_states is not None) else []
+            if (hidden.requires_grad or (token_attn is not None and token_attn.requires_grad) or any(e.requires_grad for e in encs)
+                    or any(p.requires_grad for p in self.parameters())):
+                # training / compression use: the layer as an autograd.Function around the same kernels
+                # (madtp_amd/backward.py)
+                from .backward import med_layer_forward_with_grad
+                self.__dict__.pop("_kv_pre", None)
+                if cross:
+                    assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
+                enc_arg = enc_masks = None
+                if cross and self.variant == "nlvr":
+                    enc_arg = [as_f32_contig(e) for e in encoder_hidden_states]
+                    if encoder_attention_mask is not None:
+                        enc_masks = (self._enc_mask2d(encoder_attention_mask[0]), self._enc_mask2d(encoder_attention_mask[1]))
+                elif cross:
+                    enc_arg = encoder_hidden_states
+                y, mask_out = med_layer_forward_with_grad(self, hidden, mask2d, temperature if prune else 0, token_attn, enc_arg,
+                                                          enc_masks)
+                if mask_out is not None:
+                    attention_mask = mask_out[:, None, None, :]
+                return (y, None, attention_mask)
         enc0 = enc1 = em0 = em1 = None
         Nk = 0
         pre = self.__dict__.pop("_kv_pre", None)  # (kv cache of THIS layer, Nk, int32 index [B]) set by the encoder for this call

@@ -111,3 +111,42 @@ def build_med_layer(c):
         p.requires_grad_(True)
         p.grad = None
     return layer
+
+
+def build_nlvr(g):
+    """Inputs of an nlvrgrad_* fixture (tools/make_golden.py::nlvr_layer_grad_case) rebuilt from the deterministic generators and
+    the CPU oracle: -> dict(W, prefix, hidden, add_mask, token_attn, T, g, h, layer, enc [2 tensors], enc_mask [2 x [B,1,1,Nk]])."""
+    B, L, T, seed, layer, pad_tail, Nimg = (int(g["B"]), int(g["L"]), float(g["temperature"]), int(g["seed"]), int(g["layer"]),
+                                            int(g["pad_tail"]), int(g["Nimg"]))
+    W = specs.synth_weights(specs.bert_shapes("", "nlvr"), seed)
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed)
+    ids = synth.synth_token_ids(B, L, seed + 1)
+    att = torch.ones_like(ids)
+    if pad_tail:
+        for b in range(B):
+            att[b, L - (b % (pad_tail + 1)):] = 0
+    add_mask = O.extended_mask(att)
+    enc = [synth.synth_tensor(f"image_embeds{i}", (B, Nimg, 768), seed).mul(25.0) for i in range(2)]
+    enc_mask = [torch.zeros(B, 1, 1, Nimg) for _ in range(2)]
+    with torch.no_grad():
+        hidden = O.bert_embeddings(W, "embeddings.", ids)
+        for l in range(layer):
+            ta, _ = O.query_model(hidden[:, 1:, :], space_dict)
+            hidden, add_mask, _ = O.bert_layer(W, f"encoder.layer.{l}.", hidden, add_mask, T, ta, enc, enc_mask, "multimodal", l, "nlvr")
+        token_attn, _ = O.query_model(hidden[:, 1:, :], space_dict)
+    gv = torch.from_numpy(synth.uniform_pm1("vitgrad_g", B * 768, seed).reshape(B, 768))
+    hv = torch.from_numpy(synth.uniform_pm1("vitgrad_h", B * 768, seed).reshape(B, 768))
+    return {"W": W, "prefix": f"encoder.layer.{layer}.", "hidden": hidden, "add_mask": add_mask, "token_attn": token_attn.contiguous(),
+            "T": T, "g": gv, "h": hv, "layer": layer, "enc": enc, "enc_mask": enc_mask, "mode": "multimodal"}
+
+
+def build_nlvr_layer(c):
+    """The mirror NLVR BertLayer of a build_nlvr() case with the case's weights, on the GPU, parameters requiring grad."""
+    from madtp_amd.nlvr_encoder import BertConfig, BertModel
+    model = BertModel(BertConfig.med_default(), add_pooling_layer=False)
+    model.load_state_dict(c["W"], strict=False)
+    layer = model.encoder.layer[c["layer"]].cuda().eval()
+    for p in layer.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    return layer

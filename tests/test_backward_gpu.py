@@ -272,3 +272,42 @@ def test_med_layer_backward_matches_reference_grads(hip, path):
         scale = ref[name[:-8] + "query.bias"] if name.endswith("key.bias") else r   # (a key bias has no true gradient: noise)
         e = float((grads[name].cpu() - r).abs().max()) / max(float(scale.abs().max()), 1e-12)
         assert e < 1e-3, f"grad {name}: {e:.3e} of its maximum"
+
+
+NLVRGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "nlvrgrad_*.npz")))
+
+
+@pytest.mark.parametrize("path", NLVRGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in NLVRGRAD_CASES])
+def test_nlvr_layer_backward_matches_reference_grads(hip, path):
+    """The NLVR BertLayer (the headline model's text layer: twin cross-attention to the two images' tokens, averaged below layer 6,
+    merged by merge_layer from layer 6 on) under autograd against the reference's own .grad of models/nlvr_encoder.py
+    BertLayer.forward (hidden, token_attn, both image sequences, all parameters; tests/golden/nlvrgrad_*.npz) and against autograd
+    through the CPU oracle on every entry."""
+    from madtp_amd import runtime
+    from oracle import madtp_oracle as O
+    from tests import grad_case
+    g = np.load(path)
+    c = grad_case.build_nlvr(g)
+    layer = grad_case.build_nlvr_layer(c)
+    hidden = c["hidden"].cuda().requires_grad_(True)
+    ta = c["token_attn"].cuda().requires_grad_(True)
+    mask = c["add_mask"].cuda()
+    enc = [e.cuda().requires_grad_(True) for e in c["enc"]]
+    enc_mask = [m.cuda() for m in c["enc_mask"]]
+    gv, hv = c["g"].cuda(), c["h"].cuda()
+    with runtime.precision("fp32"):
+        out = layer(hidden, mask, None, None, enc, enc_mask, None, False, mode="multimodal", token_attn=ta, reduce_num=0,
+                    temperature=c["T"])
+        y = out[0]
+        assert y.requires_grad and tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
+        assert abs(float(y.detach().double().norm()) - float(g["y_norm"])) < 1e-4 * float(g["y_norm"])
+        O.vit_loss(y, gv, hv).backward()
+    grads = {"hidden": hidden.grad, "token_attn": ta.grad, "enc0": enc[0].grad, "enc1": enc[1].grad}
+    grads.update({k: p.grad for k, p in layer.named_parameters() if p.grad is not None})
+    grad_case.check_against_fixture(g, grads, 1e-3, "HIP NLVR layer backward vs reference")
+    ref, _, _, _ = O.bert_layer_grads(c["W"], c["prefix"], c["hidden"], c["add_mask"], c["T"], c["token_attn"], c["g"], c["h"],
+                                      layer_num=c["layer"], variant="nlvr", enc=c["enc"], enc_mask=c["enc_mask"])
+    for name, r in ref.items():
+        scale = ref[name[:-8] + "query.bias"] if name.endswith("key.bias") else r   # (a key bias has no true gradient: noise)
+        e = float((grads[name].cpu() - r).abs().max()) / max(float(scale.abs().max()), 1e-12)
+        assert e < 1e-3, f"grad {name}: {e:.3e} of its maximum"

@@ -630,3 +630,24 @@ def test_oracle_med_layer_backward_matches_reference_grads(path):
     assert abs(float(y.double().norm()) - float(g["y_norm"])) < 1e-5 * float(g["y_norm"])
     assert np.array_equal(mask_out[:, 0, 0, :].numpy(), g["mask_out"])
     grad_case.check_against_fixture(g, grads, 5e-5, "oracle autograd vs reference (MED text layer)")
+
+
+NLVRGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "nlvrgrad_*.npz")))
+
+
+@pytest.mark.parametrize("path", NLVRGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in NLVRGRAD_CASES])
+def test_oracle_nlvr_layer_backward_matches_reference_grads(path):
+    """SURVEY 8(f) rank 4, the headline's text layer: autograd through oracle.bert_layer (variant 'nlvr', twin cross-attention,
+    average below layer 6 / merge_layer from 6 on) == the reference's own .grad of models/nlvr_encoder.py BertLayer.forward (hidden,
+    token_attn, both image sequences, 36 / 38 parameters), recorded by tools/make_golden.py::nlvr_layer_grad_case."""
+    from tests import grad_case
+    g = np.load(path)
+    c = grad_case.build_nlvr(g)
+    assert np.allclose(c["hidden"][:, :2, :8].numpy(), g["h_head"], rtol=2e-5, atol=2e-6), "layer input differs from the recording"
+    assert np.allclose(c["token_attn"][:, :2, :8].numpy(), g["ta_head"], rtol=2e-5, atol=1e-4)
+    grads, y, mask_out, info = O.bert_layer_grads(c["W"], c["prefix"], c["hidden"], c["add_mask"], c["T"], c["token_attn"],
+                                                  c["g"], c["h"], layer_num=c["layer"], variant="nlvr", enc=c["enc"],
+                                                  enc_mask=c["enc_mask"])
+    assert tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
+    assert abs(float(y.double().norm()) - float(g["y_norm"])) < 1e-5 * float(g["y_norm"])
+    grad_case.check_against_fixture(g, grads, 5e-5, "oracle autograd vs reference (NLVR layer)")

@@ -276,6 +276,73 @@ def med_layer_grad_case(name, B, L, temperature, layer=0, seed=0, pad_tail=0, ns
           f"|dh| {rec['g_hidden_norm']:.4e} |dta| {rec['g_token_attn_norm']:.4e} records {sorted(tap.records)}")
 
 
+def nlvr_layer_grad_case(name, B, L, temperature, layer, seed=0, pad_tail=0, nsample=384, Nimg=40):
+    """SURVEY 8(f) rank 4 (backward), the headline's text layer: the reference's OWN autograd through models/nlvr_encoder.py
+    BertLayer.forward (mode 'multimodal': masked self-attention, output LayerNorm, Reduce_token, TWIN cross-attention to two image
+    token sequences - averaged below layer 6, merged by merge_layer from layer 6 on - FFN).  The layer's inputs are captured from a
+    no-grad forward of the reference BertModel; the layer then runs alone with hidden_states, token_attn and both image sequences as
+    leaves, loss = oracle.vit_loss(out, g, h)."""
+    import models.nlvr_encoder as rnl
+    import models.med as rmed
+    from madtp_amd import specs
+    from oracle import madtp_oracle as O
+    cfg = rmed.BertConfig.from_json_file("configs/med_config.json")
+    cfg.encoder_width = 768
+    cfg.evaluate = True
+    model = rnl.BertModel(config=cfg, add_pooling_layer=False)
+    model.eval()
+    msg = model.load_state_dict(specs.synth_weights(specs.bert_shapes("", "nlvr"), seed), strict=False)
+    assert not msg.unexpected_keys, msg
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed)
+    ids = synth.synth_token_ids(B, L, seed + 1)
+    att = torch.ones_like(ids)
+    if pad_tail:
+        for b in range(B):
+            att[b, L - (b % (pad_tail + 1)):] = 0
+    encs = [synth.synth_tensor(f"image_embeds{i}", (B, Nimg, 768), seed).mul(25.0) for i in range(2)]
+    enc_atts = [torch.ones(B, Nimg, dtype=torch.long) for _ in range(2)]
+    cap = {}
+    lay = model.encoder.layer[layer]
+    hk = lay.register_forward_pre_hook(lambda m, a, kw: cap.update(h=a[0].detach().clone(), mask=a[1].detach().clone(),
+                                                                    emask=[t.detach().clone() for t in a[5]],
+                                                                    ta=kw["token_attn"].detach().clone()), with_kwargs=True)
+    with torch.no_grad():
+        model(ids, attention_mask=att, encoder_hidden_states=encs, encoder_attention_mask=enc_atts, return_dict=True,
+              mode="multimodal", space_dict=space_dict, temperature=temperature)
+    hk.remove()
+    hid = cap["h"].clone().requires_grad_(True)
+    ta = cap["ta"].clone().requires_grad_(True)
+    encl = [e.clone().requires_grad_(True) for e in encs]
+    tap = GatherTap(rnl)
+    tap.set_tag("lay")
+    for p_ in lay.parameters():
+        p_.grad = None
+    out = lay(hid, cap["mask"], space_dict, None, encl, cap["emask"], None, False, mode="multimodal", token_attn=ta * 1.0,
+              reduce_num=0, temperature=temperature)
+    tap.restore()
+    y = out[0]
+    g = torch.from_numpy(synth.uniform_pm1("vitgrad_g", B * 768, seed).reshape(B, 768))
+    h = torch.from_numpy(synth.uniform_pm1("vitgrad_h", B * 768, seed).reshape(B, 768))
+    O.vit_loss(y, g, h).backward()
+    rec = {"kind": "nlvr_layer_grad", "B": B, "L": L, "temperature": np.float64(temperature), "seed": seed, "layer": layer,
+           "pad_tail": pad_tail, "nsample": nsample, "out_shape": np.array(y.shape), "Nimg": Nimg,
+           "y_norm": np.float64(y.detach().double().norm().item()), "mask_out": out[-1].detach()[:, 0, 0, :].numpy(),
+           "h_head": cap["h"][:, :2, :8].numpy(), "ta_head": cap["ta"][:, :2, :8].numpy()}
+    rec.update(tap.records)
+    grads = {"hidden": hid.grad, "token_attn": ta.grad, "enc0": encl[0].grad, "enc1": encl[1].grad}
+    grads.update({k: v.grad for k, v in lay.named_parameters() if v.grad is not None})
+    assert ta.grad is not None and y.shape[1] < L, f"layer not pruned at T={temperature}: output {tuple(y.shape)}"
+    for k, gr in grads.items():
+        flat = gr.detach().reshape(-1)
+        idx = grad_sample_index(flat.numel(), nsample)
+        rec[f"g_{k}_sample"] = flat[torch.from_numpy(idx)].numpy()
+        rec[f"g_{k}_norm"] = np.float64(flat.double().norm().item())
+        rec[f"g_{k}_sum"] = np.float64(flat.double().sum().item())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] layer {layer} T={temperature} out {tuple(y.shape)} {len(grads)} gradients |dh| {rec['g_hidden_norm']:.4e} "
+          f"|denc0| {rec['g_enc0_norm']:.4e} records {sorted(tap.records)}")
+
+
 def vit_case(name, B, size, temperature, seed=0):
     """models/vit.py VisionTransformer stand-alone at a large image size (384 -> 577 tokens: retrieval/NLVR yaml
     configs; 480 -> 901 tokens: configs/vqa.yaml)."""
@@ -720,6 +787,8 @@ CASES = {
     "encgrad_b2_s96": lambda: vit_grad_case("encgrad_b2_s96", 2, 96, 5.0),
     "medgrad_b3_l0": lambda: med_layer_grad_case("medgrad_b3_l0", 3, 35, 30.0, layer=0, pad_tail=3),
     "medgrad_b3_l3": lambda: med_layer_grad_case("medgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
+    "nlvrgrad_b3_l3": lambda: nlvr_layer_grad_case("nlvrgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
+    "nlvrgrad_b3_l7": lambda: nlvr_layer_grad_case("nlvrgrad_b3_l7", 3, 35, 30.0, layer=7, pad_tail=3),
     "medgrad_mm_b3_l3": lambda: med_layer_grad_case("medgrad_mm_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3, mode="multimodal", Nimg=50),
 }
 
