@@ -632,3 +632,85 @@ def vit_forward_with_grad(vit, img, space_dict, temperature):
         else:
             x = blk(x, False)
     return LayerNormFunction.apply(x, vit.norm.weight, vit.norm.bias, vit.norm.eps), sd_all
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The text side and the task head under autograd (fp32 mode): embeddings, the encoder's layer loop (query model + layer
+# Functions), a Linear with activation - what BLIP_NLVR.forward needs besides the ViT for loss.backward() on its logits.
+
+class EmbeddingsFunction(torch.autograd.Function):
+    """BertEmbeddings.forward (med.py:63-86, absolute positions): LayerNorm(word[ids] + pos[:L]).  Gradients for the two tables and
+    the LayerNorm; the word table's is a scatter-add over the ids (index_add_)."""
+
+    @staticmethod
+    def forward(ctx, ids, word, pos, gamma, beta, eps):
+        y, _ = hip.bert_embed(ids.contiguous(), word, pos, gamma, beta, eps)
+        ctx.eps = float(eps)
+        ctx.save_for_backward(ids, word, pos, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, word, pos, gamma = ctx.saved_tensors
+        B, L = ids.shape
+        D = word.shape[1]
+        with torch.no_grad():
+            e = (word.detach()[ids] + pos.detach()[:L]).reshape(B * L, D).contiguous()   # the LayerNorm's input, recomputed
+            de, dg, db = layernorm_bwd(e, gamma.detach(), dy.reshape(B * L, D).contiguous().float(), ctx.eps)
+            dpos = torch.zeros_like(pos)
+            dpos[:L] = colsum(de.view(B, L * D)).view(L, D)
+            dword = torch.zeros_like(word).index_add_(0, ids.reshape(-1), de)
+        return None, dword, dpos, dg, db, None
+
+
+class LinearFunction(torch.autograd.Function):
+    """y = act(x W^T + b) on the exact-f32 GEMM (x [M,K], W [N,K])."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        N = w.shape[0]
+        wp = w.detach()
+        if _pad(N, 128) != N:
+            wp = torch.zeros((_pad(N, 128), w.shape[1]), device=w.device, dtype=torch.float32)
+            wp[:N] = w.detach()
+        x = x.contiguous().float()
+        u = hip.gemm(x, wp.contiguous(), None if b is None else b.detach().contiguous(), n=N, out_dtype=torch.float32)
+        ctx.act, ctx.has_b = act, b is not None
+        ctx.save_for_backward(x, w, u)
+        return act_fwd(u, act) if act != hip.ACT_NONE else u
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, u = ctx.saved_tensors
+        with torch.no_grad():
+            dy = dy.contiguous().float()
+            du = act_bwd(u, dy, ctx.act) if ctx.act != hip.ACT_NONE else dy
+            dx = dgrad(du, w.detach()) if ctx.needs_input_grad[0] else None
+            dw = wgrad(du, x) if ctx.needs_input_grad[1] else None
+            db = colsum(du) if ctx.has_b else None
+        return dx, dw, db, None
+
+
+def bert_encoder_forward_with_grad(enc, hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states,
+                                   encoder_attention_mask, mode, always_query):
+    """The layer loop of BertEncoder.forward (med.py:509-571 / nlvr_encoder.py:600-660) under autograd: the text query model as a
+    QueryModelFunction, the layers route themselves to MedLayerFunction.  -> (hidden_states, attention_mask, sd_txt_ft_all)."""
+    sd_all = None
+    reduce_num = int((hidden_states.shape[-2] - 1) // enc.config.num_hidden_layers)
+    for layer_module in enc.layer:
+        layer_module.__dict__.pop("_kv_pre", None)
+        token_attn = None
+        if space_dict is not None or always_query:
+            if space_dict is None:
+                raise TypeError("nlvr_encoder.BertEncoder calls txt_query_model unconditionally (:608): space_dict must be given")
+            token_attn, sd_ft = QueryModelFunction.apply(enc.txt_query_model, hidden_states, space_dict)
+            sd_all = sd_ft if sd_all is None else sd_all + sd_ft
+        t = temperature if space_dict is not None else 0
+        if enc.layer_cls.variant == "nlvr":
+            outs = layer_module(hidden_states, attention_mask, space_dict, None, encoder_hidden_states, encoder_attention_mask, None,
+                                False, mode=mode, token_attn=token_attn, reduce_num=reduce_num, temperature=t)
+        else:
+            outs = layer_module(hidden_states, attention_mask, None, encoder_hidden_states, encoder_attention_mask, None, False,
+                                mode=mode, space_dict=space_dict, token_attn=token_attn, reduce_num=reduce_num, temperature=t)
+        hidden_states, attention_mask = outs[0], outs[-1]
+    return hidden_states, attention_mask, sd_all

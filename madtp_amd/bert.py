@@ -80,6 +80,10 @@ class BertEmbeddings(nn.Module):
         if input_ids is None or position_ids is not None or past_key_values_length != 0:
             raise NotImplementedError("only the encoder use (input_ids, default positions) is on the pruned forward path")
         require_gpu(input_ids, "input_ids")
+        if torch.is_grad_enabled() and get_precision() == "fp32" and any(p.requires_grad for p in self.parameters()):
+            from .backward import EmbeddingsFunction  # training use: gradients for the two tables and the LayerNorm
+            return EmbeddingsFunction.apply(input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
+                                            self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
         cdt = compute_dtype()
         y32, ylp = hip.bert_embed(input_ids.contiguous(), self.word_embeddings.weight, self.position_embeddings.weight,
                                   self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps,
@@ -503,6 +507,16 @@ class _BertEncoderBase(nn.Module):
              mode, always_query):
         sd_txt_ft_all = None
         cache = self.__dict__.pop("_kv_cache", None)  # EncoderKVCache for THIS call (MedBertModel.forward(encoder_kv_cache=...))
+        if torch.is_grad_enabled() and get_precision() == "fp32" and cache is None:
+            encs = [] if encoder_hidden_states is None else (list(encoder_hidden_states) if isinstance(encoder_hidden_states, (list, tuple))
+                                                              else [encoder_hidden_states])
+            if (hidden_states.requires_grad or (space_dict is not None and space_dict.requires_grad)
+                    or any(e.requires_grad for e in encs) or any(p.requires_grad for p in self.parameters())):
+                from .backward import bert_encoder_forward_with_grad  # (the layer loop under autograd)
+                self.__dict__.pop("_prepared_weights", None)
+                h, _, sd_all = bert_encoder_forward_with_grad(self, hidden_states, attention_mask, space_dict, temperature,
+                                                              encoder_hidden_states, encoder_attention_mask, mode, always_query)
+                return _Out(h), sd_all
         if (_use_encoder_call(hidden_states.shape[0], _ENCODER_CALL) and not _KV_AHEAD
                 and all(type(l) is self.layer_cls for l in self.layer)):
             out = self._run_encoder_call(hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states,

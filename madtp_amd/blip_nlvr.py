@@ -90,6 +90,15 @@ class BLIP_NLVR(nn.Module):
                                               encoder_attention_mask=[None, None],
                                               return_dict=True, space_dict=self.space_dict, temperature=temperature)
         hidden_state = output.last_hidden_state[:, 0, :]  # :80
+        if torch.is_grad_enabled() and hidden_state.requires_grad:
+            # training use (fp32 mode, madtp_amd/backward.py): the head as two autograd Linears on the exact-f32 GEMM
+            from .backward import LinearFunction
+            h = LinearFunction.apply(hidden_state.contiguous(), self.cls_head[0].weight, self.cls_head[0].bias, hip.ACT_RELU)
+            logits = LinearFunction.apply(h, self.cls_head[2].weight, self.cls_head[2].bias, hip.ACT_NONE)
+            for p in pending:
+                p.sync()
+            self.last_sd_ft = (sd_img_ft, sd_txt_ft)
+            return logits
         l0 = lin_of(self._cache, "c0", [self.cls_head[0]])
         l2 = lin_of(self._cache, "c2", [self.cls_head[2]])
         lp = getattr(output.last_hidden_state, "_madtp_lp", None)

@@ -311,3 +311,36 @@ def test_nlvr_layer_backward_matches_reference_grads(hip, path):
         scale = ref[name[:-8] + "query.bias"] if name.endswith("key.bias") else r   # (a key bias has no true gradient: noise)
         e = float((grads[name].cpu() - r).abs().max()) / max(float(scale.abs().max()), 1e-12)
         assert e < 1e-3, f"grad {name}: {e:.3e} of its maximum"
+
+
+MODELGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "modelgrad_nlvr_*.npz")))
+
+
+@pytest.mark.parametrize("path", MODELGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in MODELGRAD_CASES])
+def test_nlvr_model_backward_matches_reference_grads(hip, path):
+    """loss.backward() through the headline model on the HIP path (BLIP_NLVR.forward(train=False) in the fp32 mode with grad mode
+    on: pruned ViT on both images, BERT embeddings, twelve NLVR layers with twin cross-attention, cls_head - every stage an
+    autograd.Function of madtp_amd/backward.py) against the reference's own .grad of models/blip_nlvr.py for all 579 parameters
+    (space_dict included), loss = sum(logits * c).  The per-layer token counts must equal the recording."""
+    from madtp_amd import harness, runtime, synth
+    from tests import grad_case
+    g = np.load(path)
+    B, size, L, T, seed = int(g["B"]), int(g["size"]), int(g["L"]), float(g["temperature"]), int(g["seed"])
+    model = harness.build_nlvr(size, seed, "cuda")
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    images, text, targets = harness.nlvr_inputs(B, size, L, seed, "cuda", pad_tail=int(g["pad_tail"]))
+    c = torch.from_numpy(synth.uniform_pm1("nlvrgrad_c", B * 2, seed).reshape(B, 2)).cuda()
+    with runtime.precision("fp32"):
+        logits = model(images, text, targets, temperature=T, train=False)
+        assert logits.requires_grad and (logits.detach().cpu() - torch.from_numpy(g["logits"])).abs().max().item() < 1e-4
+        trace = {"vit": [harness._cpu_info(b.last_prune) for b in model.visual_encoder.blocks],
+                 "text": [harness._cpu_info(l.last_prune) for l in model.text_encoder.encoder.layer]}
+        assert harness.token_lengths(trace["vit"], (size // 16) ** 2 + 1) == g["vit_lens"].tolist()
+        assert harness.token_lengths(trace["text"], L) == g["txt_lens"].tolist()
+        (logits * c).sum().backward()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]
+    assert not missing, f"no gradient produced for {len(missing)} tensors, e.g. {missing[:5]}"
+    grad_case.check_against_fixture(g, grads, 1e-3, "HIP BLIP_NLVR backward vs reference")

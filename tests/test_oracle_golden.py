@@ -651,3 +651,27 @@ def test_oracle_nlvr_layer_backward_matches_reference_grads(path):
     assert tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
     assert abs(float(y.double().norm()) - float(g["y_norm"])) < 1e-5 * float(g["y_norm"])
     grad_case.check_against_fixture(g, grads, 5e-5, "oracle autograd vs reference (NLVR layer)")
+
+
+MODELGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "modelgrad_nlvr_*.npz")))
+
+
+@pytest.mark.parametrize("path", MODELGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in MODELGRAD_CASES])
+def test_oracle_nlvr_model_backward_matches_reference_grads(path):
+    """SURVEY 8(f) rank 4, the headline model end to end: autograd through oracle.blip_nlvr_forward == the reference's own .grad
+    of models/blip_nlvr.py BLIP_NLVR.forward(train=False) for all 579 parameters (space_dict included), loss = sum(logits * c);
+    recorded by tools/make_golden.py::nlvr_model_grad_case.  Pins the checker of the HIP path's model-level backward."""
+    from madtp_amd import specs, synth, harness
+    from tests import grad_case
+    g = np.load(path)
+    B, size, L, T, seed = int(g["B"]), int(g["size"]), int(g["L"]), float(g["temperature"]), int(g["seed"])
+    W = specs.synth_weights(specs.blip_nlvr_shapes(size), seed)
+    images = synth.synth_images(2 * B, size, seed)
+    ids = synth.synth_token_ids(B, L, seed)
+    att = harness.padded_mask(B, L, int(g["pad_tail"]))
+    c = torch.from_numpy(synth.uniform_pm1("nlvrgrad_c", B * 2, seed).reshape(B, 2))
+    grads, logits, trace = O.blip_nlvr_grads(W, images, ids, att, T, c)
+    assert np.abs(logits.numpy() - g["logits"]).max() < 1e-5
+    assert harness.token_lengths(trace["vit"], (size // 16) ** 2 + 1) == g["vit_lens"].tolist()
+    assert harness.token_lengths(trace["text"], L) == g["txt_lens"].tolist()
+    grad_case.check_against_fixture(g, grads, 1e-4, "oracle autograd vs reference (BLIP_NLVR)")

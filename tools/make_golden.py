@@ -115,6 +115,53 @@ def nlvr_case(name, B, size, L, temperature, seed=0, pad_tail=0, pad_list=None):
           f"({dt:.2f}s)")
 
 
+def nlvr_model_grad_case(name, B, size, L, temperature, seed=0, pad_tail=0, nsample=128):
+    """SURVEY 8(f) rank 4 (backward), the headline model end to end: the reference's OWN autograd through
+    models/blip_nlvr.py BLIP_NLVR.forward(train=False) - pruned ViT on both images, BERT embeddings, twelve NLVR layers with twin
+    cross-attention, cls_head - with every parameter (space_dict included) as a leaf and loss = sum(logits * c).  Recorded: per-layer
+    lengths, the logits, and of every gradient its L2 norm, sum and `nsample` sampled entries."""
+    import models.blip_nlvr as bn
+    import models.vit as rvit
+    import models.nlvr_encoder as rnl
+    ref_shims.patch_tokenizer(bn)
+    model = bn.BLIP_NLVR(image_size=size, evaluate=True, config={"sd_num": 100, "sd_dim": 768, "batch_size_train": 16})
+    model.eval()
+    sd = synth.fill_state_dict(model, seed)
+    model.load_state_dict(sd, strict=True)
+    images = synth.synth_images(2 * B, size, seed)
+    ids = synth.synth_token_ids(B, L, seed, first_id=None)
+    from madtp_amd import harness
+    text = {"input_ids": ids, "attention_mask": harness.padded_mask(B, L, pad_tail)}
+    lens_v, lens_t, hooks = [], [], []
+    for blk in model.visual_encoder.blocks:
+        hooks.append(blk.register_forward_hook(lambda m, a, o: lens_v.append(o.shape[1])))
+    for lay in model.text_encoder.encoder.layer:
+        hooks.append(lay.register_forward_hook(lambda m, a, o: lens_t.append(o[0].shape[1])))
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    logits = model(images, text, torch.zeros(B, dtype=torch.long), temperature=temperature, train=False)
+    for h in hooks:
+        h.remove()
+    c = torch.from_numpy(synth.uniform_pm1("nlvrgrad_c", B * 2, seed).reshape(B, 2))
+    (logits * c).sum().backward()
+    rec = {"kind": "nlvr_model_grad", "B": B, "size": size, "L": L, "temperature": np.float64(temperature), "seed": seed,
+           "pad_tail": pad_tail, "nsample": nsample, "logits": logits.detach().numpy(), "vit_lens": np.array(lens_v),
+           "txt_lens": np.array(lens_t)}
+    n = 0
+    for k, v in model.named_parameters():
+        if v.grad is None:
+            continue
+        flat = v.grad.detach().reshape(-1)
+        idx = grad_sample_index(flat.numel(), nsample)
+        rec[f"g_{k}_sample"] = flat[torch.from_numpy(idx)].numpy()
+        rec[f"g_{k}_norm"] = np.float64(flat.double().norm().item())
+        n += 1
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] T={temperature} vit_lens={lens_v} txt_lens={lens_t} logits={logits.detach().numpy().round(4).tolist()} "
+          f"{n} gradients")
+
+
 def vqa_case(name, B, size, L, temperature, seed=0, pad_tail=0):
     """models/blip_vqa.py BLIP_VQA, encoder leg of forward(train=False) (:59-64, :118-125): the reference's own visual_encoder
     and text_encoder (MED, multimodal mode) called exactly as those lines do; the answer decoder that follows is out of scope."""
@@ -787,6 +834,7 @@ CASES = {
     "encgrad_b2_s96": lambda: vit_grad_case("encgrad_b2_s96", 2, 96, 5.0),
     "medgrad_b3_l0": lambda: med_layer_grad_case("medgrad_b3_l0", 3, 35, 30.0, layer=0, pad_tail=3),
     "medgrad_b3_l3": lambda: med_layer_grad_case("medgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
+    "modelgrad_nlvr_b2": lambda: nlvr_model_grad_case("modelgrad_nlvr_b2", 2, 96, 35, 30.0, pad_tail=0, nsample=64),
     "nlvrgrad_b3_l3": lambda: nlvr_layer_grad_case("nlvrgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
     "nlvrgrad_b3_l7": lambda: nlvr_layer_grad_case("nlvrgrad_b3_l7", 3, 35, 30.0, layer=7, pad_tail=3),
     "medgrad_mm_b3_l3": lambda: med_layer_grad_case("medgrad_mm_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3, mode="multimodal", Nimg=50),
