@@ -65,9 +65,27 @@ class BLIP_NLVR(nn.Module):
         ids[:, 0] = ENC_TOKEN_ID  # :69
         return ids, att.to(device)
 
+    def _losses(self, prediction, targets, temperature, sd_img_ft, sd_txt_ft):
+        """blip_nlvr.py:84-98: (loss_ori, loss_fdt) = (cross-entropy of the two-way prediction, CosineEmbeddingLoss between the
+        l2-normalised dictionary features of the image pair (averaged) and of the text).  The two loss heads are a few torch ops
+        on [B,2] and [100 B, sd_dim] tensors - everything upstream of them is the HIP path and its autograd.Functions."""
+        import torch.nn.functional as F
+        loss_ori = F.cross_entropy(prediction, targets)
+        loss_fdt = loss_ori
+        if temperature != 0 and sd_img_ft is not None and sd_txt_ft is not None:
+            sd_img0_ft, sd_img1_ft = torch.split(sd_img_ft, targets.size(0))
+            sd_img = (sd_img0_ft + sd_img1_ft) / 2
+            sd_img = sd_img / (sd_img.norm(dim=-1, keepdim=True) + 1e-10)
+            sd_txt = sd_txt_ft / (sd_txt_ft.norm(dim=-1, keepdim=True) + 1e-10)
+            sd_img, sd_txt = sd_img.reshape(-1, self.sd_dim), sd_txt.reshape(-1, self.sd_dim)
+            labels = torch.ones(sd_img.shape[0], device=sd_txt.device).long()
+            loss_fdt = F.cosine_embedding_loss(sd_img, sd_txt, labels)
+        return loss_ori, loss_fdt
+
     def forward(self, image, text, targets, temperature=0, train=True):
-        if train:
-            raise NotImplementedError("training losses / backward are out of scope of the pruned forward path")
+        """blip_nlvr.py:63-100.  train=True returns (loss_ori, loss_fdt) as the reference does; the dropout / DropPath of the
+        reference's training mode are not built (the mirror modules have none), so this is the reference's training forward with
+        model.eval() semantics - what its gradients are checked against.  Gradients need the fp32 precision mode."""
         require_gpu(image, "image")
         self.visual_encoder.img_query_model.compute_att_ft = self.compute_sd_ft
         self.text_encoder.encoder.txt_query_model.compute_att_ft = self.compute_sd_ft
@@ -98,7 +116,7 @@ class BLIP_NLVR(nn.Module):
             for p in pending:
                 p.sync()
             self.last_sd_ft = (sd_img_ft, sd_txt_ft)
-            return logits
+            return self._losses(logits, targets, temperature, sd_img_ft, sd_txt_ft) if train else logits
         l0 = lin_of(self._cache, "c0", [self.cls_head[0]])
         l2 = lin_of(self._cache, "c2", [self.cls_head[2]])
         lp = getattr(output.last_hidden_state, "_madtp_lp", None)
@@ -112,7 +130,7 @@ class BLIP_NLVR(nn.Module):
         for p in pending:
             p.sync()
         self.last_sd_ft = (sd_img_ft, sd_txt_ft)
-        return logits
+        return self._losses(logits, targets, temperature, sd_img_ft, sd_txt_ft) if train else logits
 
 
 def blip_nlvr(pretrained='', **kwargs):

@@ -344,3 +344,41 @@ def test_nlvr_model_backward_matches_reference_grads(hip, path):
     missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]
     assert not missing, f"no gradient produced for {len(missing)} tensors, e.g. {missing[:5]}"
     grad_case.check_against_fixture(g, grads, 1e-3, "HIP BLIP_NLVR backward vs reference")
+
+
+TRAINSTEP_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "trainstep_nlvr_*.npz")))
+
+
+@pytest.mark.parametrize("path", TRAINSTEP_CASES, ids=[os.path.basename(c)[:-4] for c in TRAINSTEP_CASES])
+def test_nlvr_training_step_matches_reference(hip, path):
+    """One compression training step of the headline model on the HIP path (compress_nlvr_dtp.py:52-56): BLIP_NLVR.forward(
+    train=True) -> (loss_ori, loss_fdt), loss = loss_ori + 0.1 loss_fdt, backward - both losses and the gradients of all 579
+    parameters against the reference's own (model.eval(): the mirror has no dropout); then three AdamW steps on the same batch
+    lower the loss (the optimizer is torch's, on the parameters' .grad)."""
+    from madtp_amd import harness, runtime
+    from tests import grad_case
+    g = np.load(path)
+    B, size, L, T, seed = int(g["B"]), int(g["size"]), int(g["L"]), float(g["temperature"]), int(g["seed"])
+    model = harness.build_nlvr(size, seed, "cuda")
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    images, text, _ = harness.nlvr_inputs(B, size, L, seed, "cuda", pad_tail=int(g["pad_tail"]))
+    targets = (torch.arange(B) % 2).cuda()
+    with runtime.precision("fp32"):
+        lo, lf = model(images, text, targets, temperature=T, train=True)
+        assert abs(float(lo.detach()) - float(g["loss_ori"])) < 1e-4 and abs(float(lf.detach()) - float(g["loss_fdt"])) < 1e-4
+        (lo + 0.1 * lf).backward()
+        grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        grad_case.check_against_fixture(g, grads, 1e-3, "HIP training step vs reference")
+        opt = torch.optim.AdamW(model.parameters(), lr=2e-5, weight_decay=0.05)
+        losses = [float((lo + 0.1 * lf).detach())]
+        opt.step()
+        for _ in range(3):
+            opt.zero_grad()
+            lo, lf = model(images, text, targets, temperature=T, train=True)
+            loss = lo + 0.1 * lf
+            losses.append(float(loss.detach()))
+            loss.backward()
+            opt.step()
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -675,3 +675,24 @@ def test_oracle_nlvr_model_backward_matches_reference_grads(path):
     assert harness.token_lengths(trace["vit"], (size // 16) ** 2 + 1) == g["vit_lens"].tolist()
     assert harness.token_lengths(trace["text"], L) == g["txt_lens"].tolist()
     grad_case.check_against_fixture(g, grads, 1e-4, "oracle autograd vs reference (BLIP_NLVR)")
+
+
+TRAINSTEP_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "trainstep_nlvr_*.npz")))
+
+
+@pytest.mark.parametrize("path", TRAINSTEP_CASES, ids=[os.path.basename(c)[:-4] for c in TRAINSTEP_CASES])
+def test_oracle_nlvr_training_step_matches_reference(path):
+    """The reference's compression training step (compress_nlvr_dtp.py:52-56: loss_ori + 0.1 loss_fdt from
+    BLIP_NLVR.forward(train=True), blip_nlvr.py:84-98; model.eval(), i.e. without dropout): both losses and the gradients of all
+    579 parameters, oracle autograd vs the recording of tools/make_golden.py::nlvr_model_grad_case(train=True)."""
+    from madtp_amd import specs, synth, harness
+    from tests import grad_case
+    g = np.load(path)
+    B, size, L, T, seed = int(g["B"]), int(g["size"]), int(g["L"]), float(g["temperature"]), int(g["seed"])
+    W = specs.synth_weights(specs.blip_nlvr_shapes(size), seed)
+    images = synth.synth_images(2 * B, size, seed)
+    ids = synth.synth_token_ids(B, L, seed)
+    att = harness.padded_mask(B, L, int(g["pad_tail"]))
+    grads, lo, lf = O.blip_nlvr_train_grads(W, images, ids, att, torch.arange(B) % 2, T)
+    assert abs(float(lo) - float(g["loss_ori"])) < 1e-5 and abs(float(lf) - float(g["loss_fdt"])) < 1e-5
+    grad_case.check_against_fixture(g, grads, 1e-4, "oracle training step vs reference")

@@ -115,7 +115,7 @@ def nlvr_case(name, B, size, L, temperature, seed=0, pad_tail=0, pad_list=None):
           f"({dt:.2f}s)")
 
 
-def nlvr_model_grad_case(name, B, size, L, temperature, seed=0, pad_tail=0, nsample=128):
+def nlvr_model_grad_case(name, B, size, L, temperature, seed=0, pad_tail=0, nsample=128, train=False):
     """SURVEY 8(f) rank 4 (backward), the headline model end to end: the reference's OWN autograd through
     models/blip_nlvr.py BLIP_NLVR.forward(train=False) - pruned ViT on both images, BERT embeddings, twelve NLVR layers with twin
     cross-attention, cls_head - with every parameter (space_dict included) as a leaf and loss = sum(logits * c).  Recorded: per-layer
@@ -140,14 +140,24 @@ def nlvr_model_grad_case(name, B, size, L, temperature, seed=0, pad_tail=0, nsam
     for p_ in model.parameters():
         p_.requires_grad_(True)
         p_.grad = None
-    logits = model(images, text, torch.zeros(B, dtype=torch.long), temperature=temperature, train=False)
+    targets = torch.arange(B, dtype=torch.long) % 2
+    if train:
+        # the reference's training step (compress_nlvr_dtp.py:52-56) in model.eval() (no dropout / DropPath: deterministic):
+        # loss = loss_ori + 0.1 * loss_fdt (cross-entropy + cosine embedding loss of the dictionary features, blip_nlvr.py:84-98)
+        loss_ori, loss_fdt = model(images, text, targets, temperature=temperature, train=True)
+        logits = torch.zeros(B, 2)
+        (loss_ori + 0.1 * loss_fdt).backward()
+    else:
+        logits = model(images, text, targets, temperature=temperature, train=False)
+        c = torch.from_numpy(synth.uniform_pm1("nlvrgrad_c", B * 2, seed).reshape(B, 2))
+        (logits * c).sum().backward()
     for h in hooks:
         h.remove()
-    c = torch.from_numpy(synth.uniform_pm1("nlvrgrad_c", B * 2, seed).reshape(B, 2))
-    (logits * c).sum().backward()
     rec = {"kind": "nlvr_model_grad", "B": B, "size": size, "L": L, "temperature": np.float64(temperature), "seed": seed,
            "pad_tail": pad_tail, "nsample": nsample, "logits": logits.detach().numpy(), "vit_lens": np.array(lens_v),
-           "txt_lens": np.array(lens_t)}
+           "txt_lens": np.array(lens_t), "train": int(train)}
+    if train:
+        rec["loss_ori"], rec["loss_fdt"] = np.float64(loss_ori.item()), np.float64(loss_fdt.item())
     n = 0
     for k, v in model.named_parameters():
         if v.grad is None:
@@ -834,6 +844,7 @@ CASES = {
     "encgrad_b2_s96": lambda: vit_grad_case("encgrad_b2_s96", 2, 96, 5.0),
     "medgrad_b3_l0": lambda: med_layer_grad_case("medgrad_b3_l0", 3, 35, 30.0, layer=0, pad_tail=3),
     "medgrad_b3_l3": lambda: med_layer_grad_case("medgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
+    "trainstep_nlvr_b2": lambda: nlvr_model_grad_case("trainstep_nlvr_b2", 2, 96, 35, 30.0, pad_tail=0, nsample=64, train=True),
     "modelgrad_nlvr_b2": lambda: nlvr_model_grad_case("modelgrad_nlvr_b2", 2, 96, 35, 30.0, pad_tail=0, nsample=64),
     "nlvrgrad_b3_l3": lambda: nlvr_layer_grad_case("nlvrgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
     "nlvrgrad_b3_l7": lambda: nlvr_layer_grad_case("nlvrgrad_b3_l7", 3, 35, 30.0, layer=7, pad_tail=3),
