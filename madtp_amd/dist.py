@@ -137,3 +137,40 @@ def gather_logits(logits):
     outs = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(outs, pad)
     return torch.cat([o[: int(k.item())] for o, k in zip(outs, ns)], dim=0)
+
+
+def allreduce_gradients(parameters, bucket_bytes=256 << 20, average=True):
+    """The exchange step of data-parallel TRAINING (the reference wraps the model in DistributedDataParallel,
+    compress_nlvr_dtp.py:251-253): sums (averages) the .grad of `parameters` over the ranks with bucketed all-reduces - gradients
+    are flattened into buckets of up to bucket_bytes in parameter order, one all-reduce per bucket (RCCL over xGMI is per-link
+    bound: few large messages), and copied back.  Parameters without a gradient on this rank (a layer that did not run) take part
+    with zeros so that every rank issues the same collectives.  Returns the number of buckets.  No-op for world size 1."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    params = [p for p in parameters if p.requires_grad]
+    buckets, cur, cur_bytes = [], [], 0
+    for p in params:
+        nbytes = p.numel() * p.element_size()
+        if cur and (cur_bytes + nbytes > bucket_bytes or p.dtype != cur[0].dtype or p.device != cur[0].device):
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(p)
+        cur_bytes += nbytes
+    if cur:
+        buckets.append(cur)
+    for b in buckets:
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if average:
+            flat /= world
+        o = 0
+        for p in b:
+            n = p.numel()
+            g = flat[o:o + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            o += n
+    return len(buckets)

@@ -136,3 +136,44 @@ def test_retrieval_rank_slices_and_all_reduce(tmp_path):
         for r, o in enumerate(outs):
             assert np.array_equal(gat[own[r]], o[key].numpy()[own[r]])
         assert np.array_equal(gat != -100.0, done) and np.allclose(gat[done], full[done], atol=1e-4)
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    mdist.init("gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+    extra = torch.nn.Linear(4, 4)  # runs on rank 0 only: the other rank has no gradient for it
+    x, y = torch.randn(8, 16), torch.randn(8, 4)
+    lo, hi = mdist.shard_range(8, rank, world)
+    out = model(x[lo:hi])
+    if rank == 0:
+        out = out + 0.0 * extra(out).sum()
+    ((out - y[lo:hi]) ** 2).mean().backward()
+    params = list(model.parameters()) + list(extra.parameters())
+    nb = mdist.allreduce_gradients(params, bucket_bytes=1024)  # small buckets: several collectives
+    torch.save({"grads": [p.grad.clone() for p in params], "buckets": nb}, os.path.join(out_dir, f"grad{rank}.pt"))
+    mdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_allreduce_gradients_equals_full_batch(tmp_path):
+    """The exchange step of data-parallel training (madtp_amd.dist.allreduce_gradients, the DDP all-reduce of
+    compress_nlvr_dtp.py:251-253 as bucketed collectives): with the batch sharded over two gloo ranks and a mean loss per shard, the
+    averaged gradients equal the full-batch gradients on every rank, a parameter that has a gradient on one rank only included."""
+    world = 2
+    mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), f"grad{r}.pt"), weights_only=False) for r in range(world)]
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+    extra = torch.nn.Linear(4, 4)
+    x, y = torch.randn(8, 16), torch.randn(8, 4)
+    ((model(x) - y) ** 2).mean().backward()
+    ref = [p.grad for p in model.parameters()]
+    assert outs[0]["buckets"] == outs[1]["buckets"] and outs[0]["buckets"] >= 2
+    for r in range(world):
+        for a, b in zip(outs[r]["grads"][:len(ref)], ref):
+            assert (a - b).abs().max().item() < 1e-6
+        for a, b in zip(outs[r]["grads"][len(ref):], outs[0]["grads"][len(ref):]):
+            assert torch.equal(a, b)   # the rank-0-only layer: the same (averaged) gradient everywhere
