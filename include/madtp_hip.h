@@ -563,7 +563,9 @@ int madtp_att_ft_bwd(const float* inner, const float* q, const float* dA, float 
 int madtp_attention_probs(const float* q, const float* k, int ld, const float* key_mask, float* P, int B, int H, int N, float scale,
                           void* stream);  /* key_mask: additive [B,N] over the keys (BERT padding mask, med.py:197-199) or NULL */
 size_t madtp_attention_bwd_workspace(int B, int H, int N);
-int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, const float* key_mask, const float* dout, int ldo, const float* out,
+int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, const float* key_mask, const float* mask_qk,
+                        int ld_mqk, /* mask_qk: additive [N, ld_mqk] over (query, key) pairs - the decoder's causal mask - or NULL */
+                        const float* dout, int ldo, const float* out,
                         int ldout, const float* dnrm_scale, const float* da, const float* dp0, float* dq, float* dk, float* dv,
                         int ldd, void* ws, size_t ws_bytes, int B, int H, int N, float scale, void* stream);
 

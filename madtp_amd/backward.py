@@ -111,7 +111,7 @@ def token_score_bwd(dw, score, dst_pos, merge_w, side, token_attn, B, H, N):
     return da, dp0, dnrm, dta
 
 
-def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None, key_mask=None):
+def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None, key_mask=None, mask_qk=None):
     """qkv f32 [B*N, 3*H*64] (fused projection), dout / out [B*N, H*64] -> dqkv [B*N, 3*H*64].  key_mask: additive f32 [B,N]
     over the keys (the BERT layers' padding mask) or None."""
     D = H * 64
@@ -121,7 +121,8 @@ def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None, 
     ws = torch.empty((nbytes,), device=qkv.device, dtype=torch.uint8)
     q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
     dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
-    _check(lib.madtp_attention_bwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(key_mask), _p(dout), dout.stride(0), _p(out), out.stride(0), _p(dnrm),
+    _check(lib.madtp_attention_bwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(key_mask), _p(mask_qk),
+                                   mask_qk.stride(0) if mask_qk is not None else 0, _p(dout), dout.stride(0), _p(out), out.stride(0), _p(dnrm),
                                    _p(da), _p(dp0), _p(dq), _p(dk), _p(dv), dqkv.stride(0), _p(ws), nbytes, B, H, N, float(scale),
                                    _stream()), "madtp_attention_bwd")
     return dqkv
@@ -328,7 +329,7 @@ def _cross_branch_bwd(prefix, sm, grads, dcctx, cq, ckv, wckv, y02, enc2, B, H, 
     return dy0, denc
 
 
-def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, enc=None, enc_masks=None):
+def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, enc=None, enc_masks=None, causal=None):
     """Gradients of a BertLayer - MED (med.py:393-462) or NLVR (nlvr_encoder.py:484-554) - at (hidden [B,L,D], token_attn
     [B,L-1,K]) for the output gradient dy [B,L',D]; mask2d: additive key mask [B,L] or None; k: the forward's pruning decision
     (0 = not pruned).  enc: None (mode 'text'), the encoder tokens [B,Nk,Denc] (MED, mode 'multimodal': one cross-attention between
@@ -349,7 +350,8 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
     wi, bi = _f32_lin(layer.intermediate.dense)
     wout, bout = _f32_lin(layer.output.dense)
     qkv = hip.gemm(h2, wqkv, bqkv, n=3 * D, out_dtype=torch.float32)
-    ctx, side = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, L, L, scale, add_mask=mask2d, scores=k > 0)
+    ctx, side = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, L, L, scale, add_mask=mask2d, scores=k > 0,
+                              mask_qk=causal)   # causal [L,L]: the decoder's mask (med.py:752-786), never together with pruning
     a0 = hip.gemm(ctx, wo, bo, residual=h2, n=D, out_dtype=torch.float32)
     ao, _ = hip.layernorm(a0, so.LayerNorm.weight.detach(), so.LayerNorm.bias.detach(), so.LayerNorm.eps)
     if k > 0:
@@ -443,7 +445,7 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
         a0, ln1.weight.detach(), dao.contiguous(), ln1.eps)
     dctx = dgrad(da0, so.dense.weight.detach())                               # a0 = hidden + ctx Wo^T + bo
     grads["attention.output.dense.weight"], grads["attention.output.dense.bias"] = wgrad(da0, ctx), colsum(da0)
-    dqkv = attention_bwd(qkv, dctx, ctx, B, H, L, scale, dnrm, da, dp0, key_mask=mask2d)
+    dqkv = attention_bwd(qkv, dctx, ctx, B, H, L, scale, dnrm, da, dp0, key_mask=mask2d, mask_qk=causal)
     dh = dgrad(dqkv, wqkv, residual=da0)
     gw, gb = wgrad(dqkv, h2), colsum(dqkv)
     for i, nm in enumerate(("query", "key", "value")):
@@ -458,13 +460,18 @@ class MedLayerFunction(torch.autograd.Function):
     enc0 only), then the layer's parameters in _layer_param_names order.  Returns (layer output, new additive mask [B,L'])."""
 
     @staticmethod
-    def forward(ctx, layer, temperature, mask2d, enc_masks, hidden, token_attn, enc0, enc1, *params):
+    def forward(ctx, layer, temperature, mask2d, enc_masks, causal, hidden, token_attn, enc0, enc1, *params):
         prune = temperature > 0
         cross = enc0 is not None
         twin = enc1 is not None
         flat = lambda e: e.reshape(-1, e.shape[-1]).contiguous().float()
         em = enc_masks if enc_masks is not None else (None, None)
-        y, mask_out, info, _ = hip.bert_layer(layer._weights(), hidden, mask2d, token_attn, temperature if prune else 0, cross,
+        w = layer._weights()
+        if causal is not None:  # a copy of the cached struct with this call's causal mask (as BertLayer._forward does)
+            w = hip.BertLayerW.from_buffer_copy(w)
+            w.self_mask_qk, w.ld_self_mask_qk = causal.data_ptr(), causal.stride(0)
+        ctx.causal = causal
+        y, mask_out, info, _ = hip.bert_layer(w, hidden, mask2d, token_attn, temperature if prune else 0, cross,
                                               flat(enc0) if cross else None, flat(enc1) if twin else None,
                                               enc0.shape[1] if cross else 0, em[0] if twin else None, em[1] if twin else None)
         layer.last_prune = info
@@ -488,15 +495,15 @@ class MedLayerFunction(torch.autograd.Function):
         enc = ([enc0, enc1] if ctx.twin else enc0) if ctx.cross else None
         with torch.no_grad():
             dh, dta, denc, grads = med_layer_backward(ctx.layer, hidden, mask2d if ctx.has_mask else None, ta, ctx.temperature,
-                                                      ctx.k, dy, enc, ctx.enc_masks)
+                                                      ctx.k, dy, enc, ctx.enc_masks, ctx.causal)
         if ctx.has_ta and dta is None:
             dta = torch.zeros_like(ta)
         de0, de1 = (denc if ctx.twin else (denc, None)) if ctx.cross else (None, None)
-        return (None, None, None, None, dh, dta if ctx.has_ta else None, de0, de1) + tuple(
+        return (None, None, None, None, None, dh, dta if ctx.has_ta else None, de0, de1) + tuple(
             grads.get(n) for n in _layer_param_names(ctx.layer, ctx.cross))
 
 
-def med_layer_forward_with_grad(layer, hidden, mask2d, temperature, token_attn, enc=None, enc_masks=None):
+def med_layer_forward_with_grad(layer, hidden, mask2d, temperature, token_attn, enc=None, enc_masks=None, causal=None):
     """BertLayer (MED or NLVR) under autograd -> (output, new additive mask [B,L'] or None); enc: the encoder tokens of mode
     'multimodal' (MED: a tensor; NLVR: a list of two, with enc_masks their additive key masks [B,Nk] or None) or None for mode
     'text'; fp32 mode only."""
@@ -508,7 +515,7 @@ def med_layer_forward_with_grad(layer, hidden, mask2d, temperature, token_attn, 
         token_attn = token_attn.contiguous()
     twin = isinstance(enc, (list, tuple))
     e0, e1 = (enc[0], enc[1]) if twin else (enc, None)
-    y, mask_out = MedLayerFunction.apply(layer, temperature, mask2d, enc_masks if twin else None, hidden, token_attn, e0, e1,
+    y, mask_out = MedLayerFunction.apply(layer, temperature, mask2d, enc_masks if twin else None, causal, hidden, token_attn, e0, e1,
                                          *_med_params_of(layer, enc is not None))
     return y, (mask_out if mask2d is not None else None)
 

@@ -363,7 +363,7 @@ class _BertLayerBase(nn.Module):
         if prune and mask2d is None:
             raise ValueError("attention_mask is required when temperature > 0 (med.py:424)")
         cross = mode == 'multimodal'
-        if torch.is_grad_enabled() and causal is None and get_precision() == "fp32":
+        if torch.is_grad_enabled() and get_precision() == "fp32":
             encs = (list(encoder_hidden_states) if isinstance(encoder_hidden_states, (list, tuple)) else [encoder_hidden_states]) \
                 if (cross and encoder_hidden_states is not None) else []
             if (hidden.requires_grad or (token_attn is not None and token_attn.requires_grad) or any(e.requires_grad for e in encs)
@@ -382,8 +382,8 @@ class _BertLayerBase(nn.Module):
                 elif cross:
                     enc_arg = encoder_hidden_states
                 y, mask_out = med_layer_forward_with_grad(self, hidden, mask2d, temperature if prune else 0, token_attn, enc_arg,
-                                                          enc_masks)
-                if mask_out is not None:
+                                                          enc_masks, causal)
+                if mask_out is not None and causal is None:
                     attention_mask = mask_out[:, None, None, :]
                 return (y, None, attention_mask)
         enc0 = enc1 = em0 = em1 = None
@@ -951,6 +951,29 @@ class BertLMHeadModel(nn.Module):
                                        inputs_embeds=inputs_embeds, encoder_hidden_states=encoder_hidden_states,
                                        encoder_attention_mask=encoder_attention_mask, is_decoder=is_decoder, mode=mode,
                                        space_dict=space_dict, temperature=temperature, encoder_kv_cache=encoder_kv_cache)
+        if torch.is_grad_enabled() and get_precision() == "fp32" and outputs[0].requires_grad:
+            # training use: the LM head as autograd Functions on the exact-f32 GEMM, the label-smoothed
+            # next-token cross-entropy of :1033-1042 as torch ops on the [B (L-1), V] scores
+            from .backward import LayerNormFunction, LinearFunction
+            import torch.nn.functional as F
+            pr = self.cls.predictions
+            B, L, D = outputs[0].shape
+            h = LinearFunction.apply(outputs[0].reshape(B * L, D), pr.transform.dense.weight, pr.transform.dense.bias, hip.ACT_GELU)
+            h = LayerNormFunction.apply(h, pr.transform.LayerNorm.weight, pr.transform.LayerNorm.bias, pr.transform.LayerNorm.eps)
+            scores = LinearFunction.apply(h, pr.decoder.weight, pr.bias, hip.ACT_NONE).view(B, L, -1)
+            if return_logits:
+                return scores[:, :-1, :].contiguous()
+            lm_loss = None
+            if labels is not None:
+                V = scores.shape[-1]
+                lm_loss = F.cross_entropy(scores[:, :-1, :].reshape(-1, V), labels[:, 1:].reshape(-1).to(torch.int64),
+                                          reduction=reduction, label_smoothing=0.1)
+                if reduction == 'none':
+                    lm_loss = lm_loss.view(B, -1).sum(1)
+            if not (return_dict if return_dict is not None else True):
+                return ((lm_loss, scores) if lm_loss is not None else (scores,))
+            out = _LMOut(lm_loss, scores)
+            return (out, sd_txt_ft) if train else out
         scores, padded = self.prediction_scores(outputs[0])
         if return_logits:
             return scores[:, :-1, :].contiguous()  # :1029-1030

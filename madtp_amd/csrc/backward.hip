@@ -284,6 +284,7 @@ struct AttnBwdArgs {
     float *dq, *dk, *dv; int ldd;        // outputs, same layout as q/k/v
     int B, H, N; float scale;            // N = Nq (query rows per sample)
     const float* key_mask;               // [B,Nk] additive key mask (BERT padding mask, med.py:197-199) or NULL
+    const float* mask_qk; int ld_mqk;    // [N, ld_mqk] additive mask over (query, key) pairs (the decoder's causal mask) or NULL
     int Nk; int ldk; int lddk;           // keys per sample, leading dimension of k / v and of dk / dv (cross-attention: the keys
                                          // come from another sequence and projection; self-attention: Nk = N, ldk = ld, lddk = ldd)
 };
@@ -308,7 +309,9 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(AttnBwdArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int d = 0; d < HD; ++d) s = fmaf(Qs[r * HD + d], kr[d], s);
-            S[r * N + j] = a.key_mask ? fmaf(s, a.scale, a.key_mask[(size_t)b * N + j]) : s * a.scale;
+            float sv = a.key_mask ? fmaf(s, a.scale, a.key_mask[(size_t)b * N + j]) : s * a.scale;
+            if (a.mask_qk) sv += a.mask_qk[(size_t)min(i0 + r, NQ - 1) * a.ld_mqk + j];
+            S[r * N + j] = sv;
         }
     }
     __syncthreads();
@@ -602,7 +605,7 @@ extern "C" int madtp_attention_probs(const float* q, const float* k, int ld, con
     if (ld % 4 || !aligned16(q) || !aligned16(k)) return MADTP_E_ALIGN;
     AttnBwdArgs a = {};
     a.q = q; a.k = k; a.ld = ld; a.P = P; a.B = B; a.H = H; a.N = N; a.scale = scale; a.key_mask = key_mask;
-    a.Nk = N; a.ldk = ld;
+    a.Nk = N; a.ldk = ld; a.mask_qk = nullptr; a.ld_mqk = 0;
     const size_t lds_p = (size_t)(16 * HD + 16 * N) * sizeof(float);
     MADTP_ENSURE_MAX_LDS(attn_probs_kernel, lds_p);
     hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, (N + 15) / 16), dim3(256), lds_p, (hipStream_t)stream, a);
@@ -615,7 +618,8 @@ extern "C" size_t madtp_attention_bwd_workspace(int B, int H, int N) {
     return 2 * pn + (((size_t)B * N * N + 255) & ~(size_t)255);
 }
 
-extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, const float* key_mask, const float* dout, int ldo,
+extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, const float* key_mask, const float* mask_qk,
+                                   int ld_mqk, const float* dout, int ldo,
                                    const float* out, int ldout, const float* dnrm_scale, const float* da, const float* dp0,
                                    float* dq, float* dk, float* dv, int ldd, void* ws, size_t ws_bytes, int B, int H, int N,
                                    float scale, void* stream) {
@@ -627,7 +631,7 @@ extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* 
     AttnBwdArgs a;
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.dout = dout; a.ldo = ldo; a.out = out; a.ldout = ldout; a.dnrm_scale = dnrm_scale;
     a.da = da; a.dp0 = dp0; a.dq = dq; a.dk = dk; a.dv = dv; a.ldd = ldd; a.B = B; a.H = H; a.N = N; a.scale = scale;
-    a.key_mask = key_mask; a.Nk = N; a.ldk = ld; a.lddk = ldd;
+    a.key_mask = key_mask; a.Nk = N; a.ldk = ld; a.lddk = ldd; a.mask_qk = mask_qk; a.ld_mqk = ld_mqk;
     const size_t pn = (size_t)B * H * N * N;
     a.P = (float*)ws; a.dS = a.P + pn; a.hm = (unsigned char*)(a.dS + pn);
     hipStream_t s = (hipStream_t)stream;

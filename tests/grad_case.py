@@ -150,3 +150,16 @@ def build_nlvr_layer(c):
         p.requires_grad_(True)
         p.grad = None
     return layer
+
+
+def build_decoder(g):
+    """Inputs of a decgrad_* fixture (tools/make_golden.py::decoder_grad_case): -> dict(W, ids, att, labels, enc, enc_att, w)."""
+    B, L, Nq, seed, pad_tail = int(g["B"]), int(g["L"]), int(g["Nq"]), int(g["seed"]), int(g["pad_tail"])
+    W = specs.tie_keys(specs.synth_weights(specs.lm_head_shapes(""), seed))
+    ids = synth.synth_token_ids(B, L, seed + 3)
+    att = torch.ones_like(ids)
+    for b in range(B):
+        att[b, L - (b % (pad_tail + 1)):] = 0
+    return {"W": W, "ids": ids, "att": att, "labels": ids.masked_fill(att == 0, -100),
+            "enc": synth.synth_tensor("question_states", (B, Nq, 768), seed), "enc_att": torch.ones(B, Nq, dtype=torch.long),
+            "w": torch.from_numpy(g["weights"])}

@@ -696,3 +696,19 @@ def test_oracle_nlvr_training_step_matches_reference(path):
     grads, lo, lf = O.blip_nlvr_train_grads(W, images, ids, att, torch.arange(B) % 2, T)
     assert abs(float(lo) - float(g["loss_ori"])) < 1e-5 and abs(float(lf) - float(g["loss_fdt"])) < 1e-5
     grad_case.check_against_fixture(g, grads, 1e-4, "oracle training step vs reference")
+
+
+DECGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "decgrad_*.npz")))
+
+
+@pytest.mark.parametrize("path", DECGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in DECGRAD_CASES])
+def test_oracle_decoder_backward_matches_reference_grads(path):
+    """SURVEY 8(f) rank 4, the answer decoder's training forward (blip_vqa.py:101-113 -> med.py BertLMHeadModel.forward with
+    labels, reduction='none'): per-sequence losses and the gradients of all 321 decoder parameters + the question states, oracle
+    autograd vs the recording of tools/make_golden.py::decoder_grad_case (tied output embedding: one leaf under two names)."""
+    from tests import grad_case
+    g = np.load(path)
+    c = grad_case.build_decoder(g)
+    grads, loss = O.bert_lm_grads(c["W"], "", c["ids"], c["att"], c["enc"], c["enc_att"], c["labels"], c["w"])
+    assert np.abs(loss.numpy() - g["loss"]).max() < 1e-4 * np.abs(g["loss"]).max()
+    grad_case.check_against_fixture(g, grads, 1e-4, "oracle autograd vs reference (decoder)")

@@ -692,6 +692,53 @@ def vqa_rank_case(name, B, size, L, temperature, n_answers, answer_len, k_test, 
           f"log_probs_sum[0]={np.round(log_probs_sum[0].numpy(), 3).tolist()} ({dt:.1f}s)")
 
 
+def decoder_grad_case(name, B, L, Nq, seed=0, pad_tail=2, nsample=128):
+    """SURVEY 8(f) rank 4 (backward), the answer / caption decoder: the reference's OWN autograd through models/med.py
+    BertLMHeadModel.forward as blip_vqa.py:101-113 trains it - teacher-forced answers with a padded tail, labels = ids with the
+    padding set to -100, cross-attention to question states [B,Nq,768] (a leaf as well), reduction='none', loss =
+    sum(weights * per-sequence loss) / B.  Recorded: the per-sequence losses and of every gradient its norm and sampled entries."""
+    import models.med as rmed
+    from madtp_amd import specs
+    cfg = rmed.BertConfig.from_json_file("configs/med_config.json")
+    cfg.encoder_width = 768
+    cfg.evaluate = True
+    model = rmed.BertLMHeadModel(config=cfg)
+    model.eval()
+    sd = specs.tie_keys(synth.fill_state_dict(model, seed))
+    model.load_state_dict(sd, strict=True)
+    model.cls.predictions.decoder.weight = model.bert.embeddings.word_embeddings.weight   # (the shim makes tie_weights a no-op)
+    ids = synth.synth_token_ids(B, L, seed + 3)
+    att = torch.ones_like(ids)
+    for b in range(B):
+        att[b, L - (b % (pad_tail + 1)):] = 0
+    labels = ids.masked_fill(att == 0, -100)
+    enc = synth.synth_tensor("question_states", (B, Nq, 768), seed).clone().requires_grad_(True)
+    enc_att = torch.ones(B, Nq, dtype=torch.long)
+    w = torch.tensor([1.0, 0.5, 2.0, 1.5][:B])
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    out = model(ids, attention_mask=att, encoder_hidden_states=enc, encoder_attention_mask=enc_att, labels=labels,
+                return_dict=True, reduction='none')
+    ((w * out.loss).sum() / B).backward()
+    rec = {"kind": "decoder_grad", "B": B, "L": L, "Nq": Nq, "seed": seed, "pad_tail": pad_tail, "nsample": nsample,
+           "loss": out.loss.detach().numpy(), "weights": w.numpy()}
+    grads = {"enc": enc.grad}
+    seen = set()
+    for k, v in model.named_parameters():
+        if v.grad is not None and id(v) not in seen:
+            seen.add(id(v))
+            grads[k] = v.grad
+    for k, gr in grads.items():
+        flat = gr.detach().reshape(-1)
+        idx = grad_sample_index(flat.numel(), nsample)
+        rec[f"g_{k}_sample"] = flat[torch.from_numpy(idx)].numpy()
+        rec[f"g_{k}_norm"] = np.float64(flat.double().norm().item())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] loss={out.loss.detach().numpy().round(4).tolist()} {len(grads)} gradients "
+          f"|d word_embeddings| {rec['g_bert.embeddings.word_embeddings.weight_norm']:.4e} |d enc| {rec['g_enc_norm']:.4e}")
+
+
 def vqa_gen_case(name, B, size, L, temperature, eos_bias, seed=0, pad_tail=0):
     """models/blip_vqa.py BLIP_VQA.forward(train=False, inference='generate') (:117-147): the reference's encoder leg and its
     `text_decoder.generate(num_beams=3, max_length=10, min_length=1)` call, run under the installed transformers 5.15 with the
@@ -844,6 +891,7 @@ CASES = {
     "encgrad_b2_s96": lambda: vit_grad_case("encgrad_b2_s96", 2, 96, 5.0),
     "medgrad_b3_l0": lambda: med_layer_grad_case("medgrad_b3_l0", 3, 35, 30.0, layer=0, pad_tail=3),
     "medgrad_b3_l3": lambda: med_layer_grad_case("medgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
+    "decgrad_b3": lambda: decoder_grad_case("decgrad_b3", 3, 8, 12),
     "trainstep_nlvr_b2": lambda: nlvr_model_grad_case("trainstep_nlvr_b2", 2, 96, 35, 30.0, pad_tail=0, nsample=64, train=True),
     "modelgrad_nlvr_b2": lambda: nlvr_model_grad_case("modelgrad_nlvr_b2", 2, 96, 35, 30.0, pad_tail=0, nsample=64),
     "nlvrgrad_b3_l3": lambda: nlvr_layer_grad_case("nlvrgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
