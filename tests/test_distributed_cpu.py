@@ -117,9 +117,13 @@ def test_retrieval_rank_slices_and_all_reduce(tmp_path):
     mp.spawn(_retrieval_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     outs = [torch.load(os.path.join(str(tmp_path), f"retr{r}.pt"), weights_only=False) for r in range(world)]
     batches, ids, att = harness.retrieval_inputs(3, 2, 4, 224, 35, 0)
-    torch.set_num_threads(4)
-    with torch.no_grad():
-        full_i2t, full_t2i = O.retrieval_evaluate(W, batches, ids, att, 6.0, 2)
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(4)  # (the workers' thread count: the same reduction splits as the ranks used)
+    try:
+        with torch.no_grad():
+            full_i2t, full_t2i = O.retrieval_evaluate(W, batches, ids, att, 6.0, 2)
+    finally:
+        torch.set_num_threads(prev_threads)  # later test modules of this process keep the machine's thread count
     for key, full in (("i2t", full_i2t.numpy()), ("t2i", full_t2i.numpy())):
         own = [(o[key].numpy() != -100.0) for o in outs]
         assert not (own[0] & own[1]).any() and np.array_equal(own[0] | own[1], full != -100.0)
