@@ -69,7 +69,7 @@ class BLIP_VQA(nn.Module):
     def forward(self, image, question, answer=None, temperature=0, train=True, n=None, weights=None, inference='rank',
                 k_test=128):
         if train:
-            raise NotImplementedError("BLIP_VQA training (answer decoder loss, :66-115) is out of scope: evaluation forward only")
+            return self._train_forward(image, question, answer, temperature, n, weights)
         question_states, _, _ = self.encode_question(image, question, temperature)
         if self.text_decoder is None:
             return question_states  # the tensor rank_answer / generate (:127-180) would consume
@@ -91,6 +91,36 @@ class BLIP_VQA(nn.Module):
         a_att = answer["attention_mask"] if isinstance(answer, dict) else answer.attention_mask
         q_att = question["attention_mask"] if isinstance(question, dict) else question.attention_mask
         return self.rank_answer(question_states, q_att.to(image.device), a_ids.to(image.device), a_att.to(image.device), k_test)  # :151-153
+
+    def _train_forward(self, image, question, answer, temperature, n, weights):
+        """blip_vqa.py:66-115: (loss_vqa, loss_fdt).  answer: {'input_ids', 'attention_mask'} of all answers (n[b] per question, in
+        question order; position 0 is set to the BOS id as :72 does), weights: one per answer.  The answer decoder runs
+        teacher-forced on the question states repeated n[b] times; loss_fdt is the cosine embedding loss of the l2-normalised
+        dictionary features (:102-113).  Gradients need the fp32 precision mode (madtp_amd/backward.py); the reference's dropout is
+        not built (model.eval() semantics)."""
+        import torch.nn.functional as F
+        if self.text_decoder is None:
+            raise RuntimeError("BLIP_VQA(decoder=False) has no answer decoder to train")
+        question_states, _, (sd_img_ft, sd_txt_ft) = self.encode_question(image, question, temperature)
+        dev = image.device
+        a_ids = (answer["input_ids"] if isinstance(answer, dict) else answer.input_ids).to(dev).clone()
+        a_att = (answer["attention_mask"] if isinstance(answer, dict) else answer.attention_mask).to(dev)
+        q_att = (question["attention_mask"] if isinstance(question, dict) else question.attention_mask).to(dev)
+        a_ids[:, 0] = BOS_TOKEN_ID  # :72
+        targets = a_ids.masked_fill(a_ids == PAD_TOKEN_ID, -100)  # :73
+        rep = torch.repeat_interleave(torch.arange(len(n), device=dev), torch.as_tensor(list(n), device=dev))
+        qs = question_states.index_select(0, rep)  # :84-90 (each question's states n[b] times)
+        qa = q_att.index_select(0, rep)
+        out = self.text_decoder(a_ids, attention_mask=a_att, encoder_hidden_states=qs, encoder_attention_mask=qa, labels=targets,
+                                return_dict=True, reduction='none')  # :92-99
+        loss_vqa = (torch.as_tensor(weights, device=dev, dtype=torch.float32) * out.loss).sum() / image.size(0)  # :101-102
+        loss_fdt = loss_vqa
+        if temperature != 0 and sd_img_ft is not None and sd_txt_ft is not None:
+            si = sd_img_ft / (sd_img_ft.norm(dim=-1, keepdim=True) + 1e-10)
+            st = sd_txt_ft / (sd_txt_ft.norm(dim=-1, keepdim=True) + 1e-10)
+            si, st = si.reshape(-1, self.sd_dim), st.reshape(-1, self.sd_dim)
+            loss_fdt = F.cosine_embedding_loss(si, st, torch.ones(si.shape[0], device=dev).long())
+        return loss_vqa, loss_fdt
 
     def rank_answer(self, question_states, question_atts, answer_ids, answer_atts, k, detail=None):
         """blip_vqa.py:156-203.  Differences in HOW, not in what: the question states are projected to every decoder layer's

@@ -163,3 +163,15 @@ def build_decoder(g):
     return {"W": W, "ids": ids, "att": att, "labels": ids.masked_fill(att == 0, -100),
             "enc": synth.synth_tensor("question_states", (B, Nq, 768), seed), "enc_att": torch.ones(B, Nq, dtype=torch.long),
             "w": torch.from_numpy(g["weights"])}
+
+
+def build_vqa_train(g):
+    """Inputs of a trainstep_vqa_* fixture (tools/make_golden.py::vqa_train_case)."""
+    from madtp_amd import harness
+    B, size, L, seed = int(g["B"]), int(g["size"]), int(g["L"]), int(g["seed"])
+    n_list = [int(v) for v in g["n_list"]]
+    a_ids, a_att = synth.synth_answer_ids(sum(n_list), int(g["answer_len"]), seed)
+    return {"W": specs.tie_keys(specs.synth_weights(specs.blip_vqa_shapes(size, decoder=True), seed)),
+            "images": synth.synth_images(B, size, seed), "ids": synth.synth_token_ids(B, L, seed),
+            "att": harness.padded_mask(B, L, int(g["pad_tail"])), "a_ids": a_ids, "a_att": a_att, "n_list": n_list,
+            "weights": torch.from_numpy(g["weights"]), "T": float(g["temperature"])}

@@ -422,3 +422,42 @@ def test_decoder_backward_matches_reference_grads(hip, path):
     missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]
     assert not missing, f"no gradient produced for {len(missing)} tensors, e.g. {missing[:5]}"
     grad_case.check_against_fixture(g, grads, 1e-3, "HIP decoder backward vs reference")
+
+
+VQATRAIN_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "trainstep_vqa_*.npz")))
+
+
+@pytest.mark.parametrize("path", VQATRAIN_CASES, ids=[os.path.basename(c)[:-4] for c in VQATRAIN_CASES])
+def test_vqa_training_step_matches_reference(hip, path):
+    """One training step of BLIP_VQA on the HIP path (blip_vqa.py:57-115: pruned ViT, question encoder = MED in mode 'multimodal'
+    with text pruning, answer decoder teacher-forced on the question states repeated n[b] times; loss_vqa + 0.1 loss_fdt) in the
+    fp32 mode: both losses and the gradients of all 788 parameters against the reference's own."""
+    from madtp_amd import runtime
+    from madtp_amd.blip_vqa import BLIP_VQA
+    from tests import grad_case
+    g = np.load(path)
+    c = grad_case.build_vqa_train(g)
+    model = BLIP_VQA(image_size=int(g["size"]), evaluate=True, decoder=True)
+    msg = model.load_state_dict(c["W"], strict=False)
+    assert not msg.unexpected_keys, msg.unexpected_keys[:5]
+    model.text_decoder.tie_weights()
+    model = model.cuda().eval()
+    model.text_decoder.tie_weights()
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    with runtime.precision("fp32"):
+        lv, lf = model(c["images"].cuda(), {"input_ids": c["ids"].cuda(), "attention_mask": c["att"].cuda()},
+                       {"input_ids": c["a_ids"].cuda(), "attention_mask": c["a_att"].cuda()}, temperature=c["T"], train=True,
+                       n=c["n_list"], weights=c["weights"])
+        assert abs(float(lv.detach()) - float(g["loss_vqa"])) < 1e-3 * float(g["loss_vqa"])
+        assert abs(float(lf.detach()) - float(g["loss_fdt"])) < 1e-4
+        (lv + 0.1 * lf).backward()
+    grads, seen = {}, set()
+    for k, p_ in model.named_parameters():
+        if p_.grad is not None and id(p_) not in seen:
+            seen.add(id(p_))
+            grads[k] = p_.grad
+    missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]
+    assert not missing, f"no gradient produced for {len(missing)} tensors, e.g. {missing[:5]}"
+    grad_case.check_against_fixture(g, grads, 1e-3, "HIP VQA training step vs reference")

@@ -712,3 +712,19 @@ def test_oracle_decoder_backward_matches_reference_grads(path):
     grads, loss = O.bert_lm_grads(c["W"], "", c["ids"], c["att"], c["enc"], c["enc_att"], c["labels"], c["w"])
     assert np.abs(loss.numpy() - g["loss"]).max() < 1e-4 * np.abs(g["loss"]).max()
     grad_case.check_against_fixture(g, grads, 1e-4, "oracle autograd vs reference (decoder)")
+
+
+VQATRAIN_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "trainstep_vqa_*.npz")))
+
+
+@pytest.mark.parametrize("path", VQATRAIN_CASES, ids=[os.path.basename(c)[:-4] for c in VQATRAIN_CASES])
+def test_oracle_vqa_training_step_matches_reference(path):
+    """The reference's BLIP_VQA training step (blip_vqa.py:57-115, loss_vqa + 0.1 loss_fdt; model.eval()): both losses and the
+    gradients of all 788 parameters, oracle autograd vs the recording of tools/make_golden.py::vqa_train_case."""
+    from tests import grad_case
+    g = np.load(path)
+    c = grad_case.build_vqa_train(g)
+    grads, lv, lf = O.blip_vqa_train_grads(c["W"], c["images"], c["ids"], c["att"], c["a_ids"], c["a_att"], c["n_list"],
+                                           c["weights"], c["T"])
+    assert abs(float(lv) - float(g["loss_vqa"])) < 1e-4 * float(g["loss_vqa"]) and abs(float(lf) - float(g["loss_fdt"])) < 1e-5
+    grad_case.check_against_fixture(g, grads, 1e-4, "oracle VQA training step vs reference")

@@ -739,6 +739,57 @@ def decoder_grad_case(name, B, L, Nq, seed=0, pad_tail=2, nsample=128):
           f"|d word_embeddings| {rec['g_bert.embeddings.word_embeddings.weight_norm']:.4e} |d enc| {rec['g_enc_norm']:.4e}")
 
 
+def vqa_train_case(name, B, size, L, temperature, n_list, answer_len, seed=0, pad_tail=1, nsample=48):
+    """SURVEY 8(f) rank 4 (backward), the second task model end to end: the reference's OWN training step of models/blip_vqa.py
+    BLIP_VQA.forward(train=True) (:66-115; model.eval(): no dropout) - pruned ViT, question encoder (MED, multimodal, pruned), answer
+    decoder teacher-forced on the question states repeated n[b] times, loss = loss_vqa + 0.1 loss_fdt - with every parameter a leaf.
+    Recorded: both losses, per-layer lengths, and of every gradient its norm and sampled entries."""
+    import models.blip_vqa as bv
+    from madtp_amd import harness, specs
+    ref_shims.patch_tokenizer(bv)
+    model = bv.BLIP_VQA(image_size=size, evaluate=True, config={"sd_num": 100, "sd_dim": 768, "batch_size_train": 16})
+    model.eval()
+    sd = specs.tie_keys(synth.fill_state_dict(model, seed))
+    model.load_state_dict(sd, strict=True)
+    model.text_decoder.cls.predictions.decoder.weight = model.text_decoder.bert.embeddings.word_embeddings.weight
+    images = synth.synth_images(B, size, seed)
+    ids = synth.synth_token_ids(B, L, seed, first_id=None)
+    att = harness.padded_mask(B, L, pad_tail)
+    a_ids, a_att = synth.synth_answer_ids(sum(n_list), answer_len, seed)
+    weights = torch.tensor([0.6, 0.4, 1.0, 0.7, 0.3][:sum(n_list)])
+    lens_v, lens_t, hooks = [], [], []
+    for blk in model.visual_encoder.blocks:
+        hooks.append(blk.register_forward_hook(lambda m, a, o: lens_v.append(o.shape[1])))
+    for lay in model.text_encoder.encoder.layer:
+        hooks.append(lay.register_forward_hook(lambda m, a, o: lens_t.append(o[0].shape[1])))
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    loss_vqa, loss_fdt = model(images, {"input_ids": ids, "attention_mask": att},
+                               ref_shims.FakeTokenizer._Batch({"input_ids": a_ids, "attention_mask": a_att}),
+                               temperature=temperature, train=True, n=list(n_list), weights=weights)
+    for h in hooks:
+        h.remove()
+    (loss_vqa + 0.1 * loss_fdt).backward()
+    rec = {"kind": "vqa_train", "B": B, "size": size, "L": L, "temperature": np.float64(temperature), "seed": seed,
+           "pad_tail": pad_tail, "nsample": nsample, "n_list": np.array(n_list), "answer_len": answer_len, "weights": weights.numpy(),
+           "loss_vqa": np.float64(loss_vqa.item()), "loss_fdt": np.float64(loss_fdt.item()), "vit_lens": np.array(lens_v),
+           "txt_lens": np.array(lens_t)}
+    seen, n = set(), 0
+    for k, v in model.named_parameters():
+        if v.grad is None or id(v) in seen:
+            continue
+        seen.add(id(v))
+        flat = v.grad.detach().reshape(-1)
+        idx = grad_sample_index(flat.numel(), nsample)
+        rec[f"g_{k}_sample"] = flat[torch.from_numpy(idx)].numpy()
+        rec[f"g_{k}_norm"] = np.float64(flat.double().norm().item())
+        n += 1
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] T={temperature} vit_lens={lens_v} txt_lens={lens_t} loss_vqa={loss_vqa.item():.4f} loss_fdt={loss_fdt.item():.4f} "
+          f"{n} gradients")
+
+
 def vqa_gen_case(name, B, size, L, temperature, eos_bias, seed=0, pad_tail=0):
     """models/blip_vqa.py BLIP_VQA.forward(train=False, inference='generate') (:117-147): the reference's encoder leg and its
     `text_decoder.generate(num_beams=3, max_length=10, min_length=1)` call, run under the installed transformers 5.15 with the
@@ -891,6 +942,7 @@ CASES = {
     "encgrad_b2_s96": lambda: vit_grad_case("encgrad_b2_s96", 2, 96, 5.0),
     "medgrad_b3_l0": lambda: med_layer_grad_case("medgrad_b3_l0", 3, 35, 30.0, layer=0, pad_tail=3),
     "medgrad_b3_l3": lambda: med_layer_grad_case("medgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
+    "trainstep_vqa_b2": lambda: vqa_train_case("trainstep_vqa_b2", 2, 96, 20, 20.0, [2, 1], 6),
     "decgrad_b3": lambda: decoder_grad_case("decgrad_b3", 3, 8, 12),
     "trainstep_nlvr_b2": lambda: nlvr_model_grad_case("trainstep_nlvr_b2", 2, 96, 35, 30.0, pad_tail=0, nsample=64, train=True),
     "modelgrad_nlvr_b2": lambda: nlvr_model_grad_case("modelgrad_nlvr_b2", 2, 96, 35, 30.0, pad_tail=0, nsample=64),
