@@ -46,8 +46,31 @@ class BLIP_Decoder(nn.Module):
         self.prompt_length = len(self.prompt_ids) - 1 if self.prompt_ids else None  # :109
 
     def forward(self, image, caption, temperature=0, train=False):
-        raise NotImplementedError("BLIP_Decoder.forward is the captioning LOSS (models/blip.py:111-158): training is out of "
-                                  "scope; evaluation goes through generate() (compress_caption_dtp.py:86)")
+        """models/blip.py:111-158.  caption: {'input_ids', 'attention_mask'} tensors (or a list of strings with a tokenizer
+        attached); train=True -> (loss_lm, loss_fdt) - the decoder is not given space_dict, so sd_txt_ft is None and loss_fdt IS
+        loss_lm (:146-147) - train=False -> the decoder's output object.  Gradients need the fp32 precision mode."""
+        require_gpu(image, "image")
+        image_embeds, _ = self.visual_encoder(image, space_dict=self.space_dict, temperature=temperature)  # :112
+        image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)  # :113
+        if isinstance(caption, dict) or hasattr(caption, "input_ids"):
+            ids = (caption["input_ids"] if isinstance(caption, dict) else caption.input_ids).to(image.device).clone()
+            att = (caption["attention_mask"] if isinstance(caption, dict) else caption.attention_mask).to(image.device)
+        elif self.tokenizer is not None:
+            t = self.tokenizer(caption, padding='longest', truncation=True, max_length=40, return_tensors="pt")  # :115
+            ids, att = t.input_ids.to(image.device).clone(), t.attention_mask.to(image.device)
+        else:
+            raise TypeError("pass {'input_ids','attention_mask'} tensors or set model.tokenizer (no vocabulary offline)")
+        ids[:, 0] = BOS_TOKEN_ID  # :117
+        if self.prompt_length is None:
+            raise TypeError("prompt_length is unknown for this prompt: set model.prompt_length (= tokens of the prompt - 1, :109)")
+        targets = ids.masked_fill(ids == PAD_TOKEN_ID, -100)  # :119
+        targets[:, :self.prompt_length] = -100  # :120
+        if not train:
+            return self.text_decoder(ids, attention_mask=att, encoder_hidden_states=image_embeds,
+                                     encoder_attention_mask=image_atts, labels=None, return_dict=True)  # :136-146
+        out = self.text_decoder(ids, attention_mask=att, encoder_hidden_states=image_embeds, encoder_attention_mask=image_atts,
+                                labels=targets, return_dict=True)  # :123-132 (reduction 'mean')
+        return out.loss, out.loss  # :133, :147: no text-side dictionary features -> loss_fdt = loss_lm
 
     def _prompt(self, B, device):
         if self.tokenizer is not None:

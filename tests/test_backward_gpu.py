@@ -461,3 +461,41 @@ def test_vqa_training_step_matches_reference(hip, path):
     missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]
     assert not missing, f"no gradient produced for {len(missing)} tensors, e.g. {missing[:5]}"
     grad_case.check_against_fixture(g, grads, 1e-3, "HIP VQA training step vs reference")
+
+
+CAPTRAIN_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "trainstep_cap_*.npz")))
+
+
+@pytest.mark.parametrize("path", CAPTRAIN_CASES, ids=[os.path.basename(c)[:-4] for c in CAPTRAIN_CASES])
+def test_caption_training_step_matches_reference(hip, path):
+    """One training step of the caption model on the HIP path (BLIP_Decoder.forward(train=True), models/blip.py:111-158: pruned ViT
+    + decoder teacher-forced on the caption, prompt and padding masked out of the targets) in the fp32 mode: loss_lm and the
+    gradients of all 472 parameters against the reference's own."""
+    from madtp_amd import runtime, specs, synth
+    from madtp_amd.blip import BLIP_Decoder
+    from tests import grad_case
+    g = np.load(path)
+    B, size, seed = int(g["B"]), int(g["size"]), int(g["seed"])
+    model = BLIP_Decoder(image_size=size, evaluate=True)
+    msg = model.load_state_dict(specs.tie_keys(specs.synth_weights(specs.blip_decoder_shapes(size), seed)), strict=False)
+    assert not msg.unexpected_keys, msg.unexpected_keys[:5]
+    model = model.cuda().eval()
+    model.text_decoder.tie_weights()
+    assert model.prompt_length == int(g["prompt_length"])
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    with runtime.precision("fp32"):
+        lm, lf = model(synth.synth_images(B, size, seed).cuda(), {"input_ids": torch.from_numpy(g["ids"]).cuda(),
+                                                                  "attention_mask": torch.from_numpy(g["att"]).cuda()},
+                       temperature=float(g["temperature"]), train=True)
+        assert abs(float(lm.detach()) - float(g["loss_lm"])) < 1e-3 * float(g["loss_lm"])
+        (lm + 0.1 * lf).backward()
+    grads, seen = {}, set()
+    for k, p_ in model.named_parameters():
+        if p_.grad is not None and id(p_) not in seen:
+            seen.add(id(p_))
+            grads[k] = p_.grad
+    missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]
+    assert not missing, f"no gradient produced for {len(missing)} tensors, e.g. {missing[:5]}"
+    grad_case.check_against_fixture(g, grads, 1e-3, "HIP caption training step vs reference")

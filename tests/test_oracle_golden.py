@@ -728,3 +728,21 @@ def test_oracle_vqa_training_step_matches_reference(path):
                                            c["weights"], c["T"])
     assert abs(float(lv) - float(g["loss_vqa"])) < 1e-4 * float(g["loss_vqa"]) and abs(float(lf) - float(g["loss_fdt"])) < 1e-5
     grad_case.check_against_fixture(g, grads, 1e-4, "oracle VQA training step vs reference")
+
+
+CAPTRAIN_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "trainstep_cap_*.npz")))
+
+
+@pytest.mark.parametrize("path", CAPTRAIN_CASES, ids=[os.path.basename(c)[:-4] for c in CAPTRAIN_CASES])
+def test_oracle_caption_training_step_matches_reference(path):
+    """The reference's BLIP_Decoder training step (models/blip.py:111-158; model.eval()): loss_lm and the gradients of all 472
+    parameters, oracle autograd vs the recording of tools/make_golden.py::cap_train_case."""
+    from madtp_amd import specs, synth
+    from tests import grad_case
+    g = np.load(path)
+    B, size, seed = int(g["B"]), int(g["size"]), int(g["seed"])
+    W = specs.tie_keys(specs.synth_weights(specs.blip_decoder_shapes(size), seed))
+    grads, loss = O.blip_decoder_train_grads(W, synth.synth_images(B, size, seed), torch.from_numpy(g["ids"]), torch.from_numpy(g["att"]),
+                                             float(g["temperature"]), int(g["prompt_length"]))
+    assert abs(float(loss) - float(g["loss_lm"])) < 1e-4 * float(g["loss_lm"])
+    grad_case.check_against_fixture(g, grads, 1e-4, "oracle caption training step vs reference")

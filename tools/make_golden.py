@@ -790,6 +790,56 @@ def vqa_train_case(name, B, size, L, temperature, n_list, answer_len, seed=0, pa
           f"{n} gradients")
 
 
+def cap_train_case(name, B, size, L, temperature, seed=0, nsample=48):
+    """SURVEY 8(f) rank 4 (backward), the caption model: the reference's OWN training step of models/blip.py
+    BLIP_Decoder.forward(train=True) (:111-158; model.eval()) - pruned ViT, decoder teacher-forced on the caption (prompt positions
+    and padding masked out of the targets), loss = loss_lm + 0.1 loss_fdt with loss_fdt = loss_lm (no text-side dictionary
+    features) - with every parameter a leaf."""
+    import models.blip as blip
+    from madtp_amd import specs
+    ref_shims.patch_tokenizer(blip)
+    model = blip.BLIP_Decoder(image_size=size, evaluate=True, config={"sd_num": 100, "sd_dim": 768})
+    model.eval()
+    sd = specs.tie_keys(synth.fill_state_dict(model, seed))
+    model.load_state_dict(sd, strict=True)
+    model.text_decoder.cls.predictions.decoder.weight = model.text_decoder.bert.embeddings.word_embeddings.weight
+    images = synth.synth_images(B, size, seed)
+    ids = synth.synth_token_ids(B, L, seed + 5)
+    ids[:, :4] = torch.tensor([101, 1037, 3861, 1997])   # "[CLS] a picture of" - the prompt every caption starts with
+    att = torch.ones_like(ids)
+    for b in range(B):
+        if b % 2:
+            ids[b, L - 3] = 102
+            ids[b, L - 2:] = 0
+            att[b, L - 2:] = 0
+    lens_v, hooks = [], []
+    for blk in model.visual_encoder.blocks:
+        hooks.append(blk.register_forward_hook(lambda m, a, o: lens_v.append(o.shape[1])))
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    loss_lm, loss_fdt = model(images, {"input_ids": ids.clone(), "attention_mask": att}, temperature=temperature, train=True)
+    for h in hooks:
+        h.remove()
+    (loss_lm + 0.1 * loss_fdt).backward()
+    rec = {"kind": "cap_train", "B": B, "size": size, "L": L, "temperature": np.float64(temperature), "seed": seed,
+           "nsample": nsample, "loss_lm": np.float64(loss_lm.item()), "loss_fdt": np.float64(loss_fdt.item()),
+           "vit_lens": np.array(lens_v), "prompt_length": int(model.prompt_length), "ids": ids.numpy(), "att": att.numpy()}
+    seen, n = set(), 0
+    for k, v in model.named_parameters():
+        if v.grad is None or id(v) in seen:
+            continue
+        seen.add(id(v))
+        flat = v.grad.detach().reshape(-1)
+        idx = grad_sample_index(flat.numel(), nsample)
+        rec[f"g_{k}_sample"] = flat[torch.from_numpy(idx)].numpy()
+        rec[f"g_{k}_norm"] = np.float64(flat.double().norm().item())
+        n += 1
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] T={temperature} vit_lens={lens_v} loss_lm={loss_lm.item():.4f} loss_fdt={loss_fdt.item():.4f} "
+          f"prompt_length={model.prompt_length} {n} gradients")
+
+
 def vqa_gen_case(name, B, size, L, temperature, eos_bias, seed=0, pad_tail=0):
     """models/blip_vqa.py BLIP_VQA.forward(train=False, inference='generate') (:117-147): the reference's encoder leg and its
     `text_decoder.generate(num_beams=3, max_length=10, min_length=1)` call, run under the installed transformers 5.15 with the
@@ -942,6 +992,7 @@ CASES = {
     "encgrad_b2_s96": lambda: vit_grad_case("encgrad_b2_s96", 2, 96, 5.0),
     "medgrad_b3_l0": lambda: med_layer_grad_case("medgrad_b3_l0", 3, 35, 30.0, layer=0, pad_tail=3),
     "medgrad_b3_l3": lambda: med_layer_grad_case("medgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
+    "trainstep_cap_b2": lambda: cap_train_case("trainstep_cap_b2", 2, 96, 12, 20.0),
     "trainstep_vqa_b2": lambda: vqa_train_case("trainstep_vqa_b2", 2, 96, 20, 20.0, [2, 1], 6),
     "decgrad_b3": lambda: decoder_grad_case("decgrad_b3", 3, 8, 12),
     "trainstep_nlvr_b2": lambda: nlvr_model_grad_case("trainstep_nlvr_b2", 2, 96, 35, 30.0, pad_tail=0, nsample=64, train=True),
