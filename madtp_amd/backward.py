@@ -157,23 +157,68 @@ def _f32_lin(linear):
     return w.contiguous(), (None if linear.bias is None else linear.bias.detach().contiguous())
 
 
-def vit_block_backward(blk, x, token_attn, temperature, k, dy):
-    """Gradients of Block.forward (vit.py:183-207) at (x [B,N,D], token_attn [B,N-1,K]) for the output gradient dy
-    [B,N',D], with the forward's pruning decision k (0 = the layer was not pruned).  Returns
-    (dx, dtoken_attn or None, {parameter name: grad})."""
+def _f32_wb(w, b):
+    """(weight padded to 128 rows, bias) of a Linear given as tensors, for the exact-f32 GEMM."""
+    w = w.detach()
+    n = w.shape[0]
+    npad = _pad(n, 128)
+    if npad != n:
+        wp = torch.zeros((npad, w.shape[1]), device=w.device, dtype=torch.float32)
+        wp[:n] = w
+        w = wp
+    return w.contiguous(), (None if b is None else b.detach().contiguous())
+
+
+class _BlockParts:
+    """The modules / tensors of a pruned ViT block under one set of names: BLIP's Block (models/vit.py:106-207) and CLIP's
+    ResidualAttentionBlock (clip/model.py:174-261: fused in_proj, QuickGELU, LayerNorm eps 1e-5) run the same layer call."""
+
+    def __init__(self, blk):
+        if hasattr(blk, "ln_1"):  # CLIP
+            self.norm1, self.norm2 = blk.ln_1, blk.ln_2
+            self.qkv_w, self.qkv_b = blk.attn.in_proj_weight, blk.attn.in_proj_bias
+            self.proj, self.fc1, self.fc2 = blk.attn.out_proj, blk.mlp.c_fc, blk.mlp.c_proj
+            self.H, self.scale, self.act = blk.n_head, (blk.d_model // blk.n_head) ** -0.5, hip.ACT_QUICK_GELU
+            self.names = {"norm1": "ln_1", "norm2": "ln_2", "qkv_w": "attn.in_proj_weight", "qkv_b": "attn.in_proj_bias",
+                          "proj": "attn.out_proj", "fc1": "mlp.c_fc", "fc2": "mlp.c_proj"}
+        else:
+            self.norm1, self.norm2 = blk.norm1, blk.norm2
+            self.qkv_w, self.qkv_b = blk.attn.qkv.weight, blk.attn.qkv.bias
+            self.proj, self.fc1, self.fc2 = blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2
+            self.H, self.scale, self.act = blk.attn.num_heads, blk.attn.scale, hip.ACT_GELU
+            self.names = {"norm1": "norm1", "norm2": "norm2", "qkv_w": "attn.qkv.weight", "qkv_b": "attn.qkv.bias",
+                          "proj": "attn.proj", "fc1": "mlp.fc1", "fc2": "mlp.fc2"}
+
+    def order(self):
+        n = self.names
+        return (n["norm1"] + ".weight", n["norm1"] + ".bias", n["qkv_w"], n["qkv_b"], n["proj"] + ".weight", n["proj"] + ".bias",
+                n["norm2"] + ".weight", n["norm2"] + ".bias", n["fc1"] + ".weight", n["fc1"] + ".bias", n["fc2"] + ".weight",
+                n["fc2"] + ".bias")
+
+    def params(self):
+        return [self.norm1.weight, self.norm1.bias, self.qkv_w, self.qkv_b, self.proj.weight, self.proj.bias, self.norm2.weight,
+                self.norm2.bias, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias]
+
+
+def vit_block_backward(blk, x, token_attn, temperature, k, dy, mask_qk=None):
+    """Gradients of Block.forward (vit.py:183-207; clip/model.py:236-261 for CLIP's block) at (x [B,N,D], token_attn [B,N-1,K])
+    for the output gradient dy [B,N',D], with the forward's pruning decision k (0 = the layer was not pruned); mask_qk: the
+    additive [N,N] attention mask of CLIP's text tower or None.  Returns (dx, dtoken_attn or None, {parameter name: grad})."""
+    P = _BlockParts(blk)
+    nm = P.names
     B, N, D = x.shape
-    H, scale = blk.attn.num_heads, blk.attn.scale
+    H, scale = P.H, P.scale
     M = B * N
-    eps1, eps2 = blk.norm1.eps, blk.norm2.eps
+    eps1, eps2 = P.norm1.eps, P.norm2.eps
     x2 = x.reshape(M, D)
     # ---- recompute the forward (fp32 kernels, the forward's own) ----
-    h1, _ = hip.layernorm(x2, blk.norm1.weight.detach(), blk.norm1.bias.detach(), eps1)
-    wq, bq = _f32_lin(blk.attn.qkv)
-    wp, bp = _f32_lin(blk.attn.proj)
-    w1, b1 = _f32_lin(blk.mlp.fc1)
-    w2, b2 = _f32_lin(blk.mlp.fc2)
+    h1, _ = hip.layernorm(x2, P.norm1.weight.detach(), P.norm1.bias.detach(), eps1)
+    wq, bq = _f32_wb(P.qkv_w, P.qkv_b)
+    wp, bp = _f32_lin(P.proj)
+    w1, b1 = _f32_lin(P.fc1)
+    w2, b2 = _f32_lin(P.fc2)
     qkv = hip.gemm(h1, wq, bq, n=3 * D, out_dtype=torch.float32)
-    out, side = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, scale, scores=k > 0)
+    out, side = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, scale, scores=k > 0, mask_qk=mask_qk)
     x_attn = hip.gemm(out, wp, bp, residual=x2, n=D, out_dtype=torch.float32)
     if k > 0:
         score, _, _, _ = hip.token_score(side, token_attn, temperature, B, H, N)
@@ -184,19 +229,19 @@ def vit_block_backward(blk, x, token_attn, temperature, k, dy):
     N2 = y0.shape[1]
     M2 = B * N2
     y02 = y0.reshape(M2, D)
-    h2, _ = hip.layernorm(y02, blk.norm2.weight.detach(), blk.norm2.bias.detach(), eps2)
-    F = blk.mlp.fc1.weight.shape[0]
+    h2, _ = hip.layernorm(y02, P.norm2.weight.detach(), P.norm2.bias.detach(), eps2)
+    F = P.fc1.weight.shape[0]
     u = hip.gemm(h2, w1, b1, n=F, out_dtype=torch.float32)
-    g = act_fwd(u, hip.ACT_GELU)
+    g = act_fwd(u, P.act)
     # ---- backward ----
     grads = {}
     dy2 = dy.reshape(M2, D).contiguous().float()
-    dg = dgrad(dy2, blk.mlp.fc2.weight.detach())               # y = y0 + g W2^T + b2
-    grads["mlp.fc2.weight"], grads["mlp.fc2.bias"] = wgrad(dy2, g), colsum(dy2)
-    du = act_bwd(u, dg, hip.ACT_GELU)
-    dh2 = dgrad(du, blk.mlp.fc1.weight.detach())
-    grads["mlp.fc1.weight"], grads["mlp.fc1.bias"] = wgrad(du, h2), colsum(du)
-    dy0, grads["norm2.weight"], grads["norm2.bias"] = layernorm_bwd(y02, blk.norm2.weight.detach(), dh2, eps2, add=dy2)
+    dg = dgrad(dy2, P.fc2.weight.detach())               # y = y0 + g W2^T + b2
+    grads[nm["fc2"] + ".weight"], grads[nm["fc2"] + ".bias"] = wgrad(dy2, g), colsum(dy2)
+    du = act_bwd(u, dg, P.act)
+    dh2 = dgrad(du, P.fc1.weight.detach())
+    grads[nm["fc1"] + ".weight"], grads[nm["fc1"] + ".bias"] = wgrad(du, h2), colsum(du)
+    dy0, grads[nm["norm2"] + ".weight"], grads[nm["norm2"] + ".bias"] = layernorm_bwd(y02, P.norm2.weight.detach(), dh2, eps2, add=dy2)
     dta = None
     dnrm = da = dp0 = None
     if k > 0:
@@ -205,34 +250,26 @@ def vit_block_backward(blk, x, token_attn, temperature, k, dy):
         dxa2 = dx_attn.view(M, D)
     else:
         dxa2 = dy0
-    dout = dgrad(dxa2, blk.attn.proj.weight.detach())          # x_attn = x + out Wp^T + bp
-    grads["attn.proj.weight"], grads["attn.proj.bias"] = wgrad(dxa2, out), colsum(dxa2)
-    dqkv = attention_bwd(qkv, dout, out, B, H, N, scale, dnrm, da, dp0)
-    dh1 = dgrad(dqkv, blk.attn.qkv.weight.detach())
-    grads["attn.qkv.weight"] = wgrad(dqkv, h1)
-    if blk.attn.qkv.bias is not None:
-        grads["attn.qkv.bias"] = colsum(dqkv)
-    dx2, grads["norm1.weight"], grads["norm1.bias"] = layernorm_bwd(x2, blk.norm1.weight.detach(), dh1, eps1, add=dxa2)
+    dout = dgrad(dxa2, P.proj.weight.detach())          # x_attn = x + out Wp^T + bp
+    grads[nm["proj"] + ".weight"], grads[nm["proj"] + ".bias"] = wgrad(dxa2, out), colsum(dxa2)
+    dqkv = attention_bwd(qkv, dout, out, B, H, N, scale, dnrm, da, dp0, mask_qk=mask_qk)
+    dh1 = dgrad(dqkv, P.qkv_w.detach())
+    grads[nm["qkv_w"]] = wgrad(dqkv, h1)
+    if P.qkv_b is not None:
+        grads[nm["qkv_b"]] = colsum(dqkv)
+    dx2, grads[nm["norm1"] + ".weight"], grads[nm["norm1"] + ".bias"] = layernorm_bwd(x2, P.norm1.weight.detach(), dh1, eps1, add=dxa2)
     return dx2.view(B, N, D), dta, grads
 
 
-_PARAM_ORDER = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
-                "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
-
-
-def _params_of(blk):
-    return [blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.attn.proj.bias,
-            blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias]
-
-
 class VitBlockFunction(torch.autograd.Function):
-    """Block.forward with a hand-written backward.  Inputs after (blk, temperature): x, token_attn (or None), then the block's 12
-    parameters in _PARAM_ORDER (passed so that autograd routes their gradients; the kernels read them from the module)."""
+    """Block.forward (BLIP Block or CLIP ResidualAttentionBlock) with a hand-written backward.  Inputs after (blk, temperature,
+    max_keep): x, token_attn (or None), then the block's 12 parameters in _BlockParts.order() (passed so that autograd routes
+    their gradients; the kernels read them from the module)."""
 
     @staticmethod
-    def forward(ctx, blk, temperature, x, token_attn, *params):
+    def forward(ctx, blk, temperature, max_keep, x, token_attn, *params):
         prune = temperature > 0
-        y, info = hip.vit_block(blk._weights(), x, token_attn, temperature if prune else 0)
+        y, info = hip.vit_block(blk._weights(), x, token_attn, temperature if prune else 0, max_keep=max_keep)
         blk.last_prune = info
         ctx.blk, ctx.temperature = blk, float(temperature)
         ctx.k = int(info["indices"].shape[1]) if (info is not None and info.get("pruned")) else 0
@@ -244,15 +281,18 @@ class VitBlockFunction(torch.autograd.Function):
     def backward(ctx, dy):
         x, ta = ctx.saved_tensors
         ta = ta if ctx.has_ta else None
+        mask = getattr(ctx.blk, "_mask_dev", None) if getattr(ctx.blk, "attn_mask", None) is not None else None
+        if mask is not None:
+            mask = mask[:x.shape[1], :x.shape[1]]
         with torch.no_grad():
-            dx, dta, grads = vit_block_backward(ctx.blk, x, ta, ctx.temperature, ctx.k, dy)
-        pg = [grads.get(name) for name in _PARAM_ORDER]
+            dx, dta, grads = vit_block_backward(ctx.blk, x, ta, ctx.temperature, ctx.k, dy, mask_qk=mask)
+        pg = [grads.get(name) for name in _BlockParts(ctx.blk).order()]
         if ctx.has_ta and dta is None:
             dta = torch.zeros_like(ta)
-        return (None, None, dx, dta if ctx.has_ta else None) + tuple(pg)
+        return (None, None, None, dx, dta if ctx.has_ta else None) + tuple(pg)
 
 
-def block_forward_with_grad(blk, x, temperature, token_attn):
+def block_forward_with_grad(blk, x, temperature, token_attn, max_keep=0):
     """Block.forward under autograd (called by madtp_amd.vit.Block.forward when gradients are required)."""
     from . import runtime
     if runtime.get_precision() != "fp32":
@@ -260,7 +300,7 @@ def block_forward_with_grad(blk, x, temperature, token_attn):
                                   f"current mode: {runtime.get_precision()}")
     if token_attn is not None and not token_attn.is_contiguous():
         token_attn = token_attn.contiguous()
-    return VitBlockFunction.apply(blk, temperature, x, token_attn, *_params_of(blk))
+    return VitBlockFunction.apply(blk, temperature, max_keep, x, token_attn, *_BlockParts(blk).params())
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -567,37 +607,49 @@ def att_ft_bwd(inner, q, dA, sd_dim, dinner, dq):
 
 
 class QueryModelFunction(torch.autograd.Function):
-    """Query_model.forward(return_token_att=True) (models/utils.py:147-183, no q_map): x [B,N,D] (row 0 = CLS, not used), sd [K,D] ->
-    (token_att [B,N-1,K] raw logits, att_ft [B,K,D]).  Forward = the inference path's own kernels (madtp_amd.utils.Query_model);
+    """Query_model.forward(return_token_att=True) (models/utils.py:147-183): x [B,N,D] (row 0 = CLS, not used), sd [K,Dsd] ->
+    (token_att [B,N-1,K] raw logits, att_ft [B,K,Dsd]); with a q_map (CLIP, map_func=True: q = Linear(ft) before the logits,
+    :160-163) its weight and bias follow as inputs.  Forward = the inference path's own kernels (madtp_amd.utils.Query_model);
     backward: the logits' gradient (from token_attn's use in the blocks and from att_ft's softmax over tokens) goes through dgrad /
-    wgrad on the exact-f32 GEMM, plus the direct att_ft term W^T dA for the tokens."""
+    wgrad on the exact-f32 GEMM, plus the direct att_ft term W^T dA for the (mapped) tokens."""
 
     @staticmethod
-    def forward(ctx, qm, x, sd):
+    def forward(ctx, qm, x, sd, *qmap):
         ta, att_ft, _ = qm(x[:, 1:, :], sd, return_token_att=True)
         ta = ta.contiguous()
-        ctx.save_for_backward(x, sd, ta)
-        ctx.sd_dim = qm.att_dim
-        return ta, att_ft.clone()
+        ctx.save_for_backward(x, sd, ta, *qmap)
+        ctx.sd_dim, ctx.has_map = qm.att_dim, len(qmap) > 0
+        return ta, (att_ft.clone() if att_ft is not None else x.new_zeros((x.shape[0], sd.shape[0], sd.shape[1])))
 
     @staticmethod
     def backward(ctx, dta, datt):
-        x, sd, ta = ctx.saved_tensors
+        x, sd, ta = ctx.saved_tensors[:3]
         B, N, D = x.shape
         n, K = N - 1, sd.shape[0]
         with torch.no_grad():
             ft = x[:, 1:, :].contiguous()
+            if ctx.has_map:
+                wm, bm = ctx.saved_tensors[3], ctx.saved_tensors[4]
+                wmp, bmp = _f32_wb(wm, bm)
+                q = hip.gemm(ft.view(B * n, D), wmp, bmp, n=wm.shape[0], out_dtype=torch.float32).view(B, n, -1)
+            else:
+                q = ft
             dinner = dta.contiguous().float().clone() if dta is not None else torch.zeros_like(ta)
-            dq = torch.zeros_like(ft)
+            dq = torch.zeros_like(q)
             if datt is not None:
-                att_ft_bwd(ta, ft, datt.contiguous().float(), ctx.sd_dim, dinner, dq)
+                att_ft_bwd(ta, q, datt.contiguous().float(), ctx.sd_dim, dinner, dq)
             d2 = dinner.view(B * n, K)
+            dq2 = dgrad(d2, sd.detach(), residual=dq.view(B * n, -1))
+            dsd = wgrad(d2, q.reshape(B * n, -1)) if ctx.needs_input_grad[2] else None
+            gmap = ()
+            if ctx.has_map:
+                gmap = (wgrad(dq2, ft.view(B * n, D)), colsum(dq2))
+                dq2 = dgrad(dq2, wm.detach())
             dx = None
             if ctx.needs_input_grad[1]:
                 dx = torch.zeros_like(x)
-                dx[:, 1:, :] = dgrad(d2, sd.detach()).view(B, n, D) + dq
-            dsd = wgrad(d2, ft.view(B * n, D)) if ctx.needs_input_grad[2] else None
-        return None, dx, dsd
+                dx[:, 1:, :] = dq2.view(B, n, D)
+        return (None, dx, dsd) + gmap
 
 
 class LayerNormFunction(torch.autograd.Function):

@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from . import hip
-from .runtime import PreparedCache, f32_ptr, compute_dtype, dtype_code, lin_of, prepare_linear, require_gpu, as_f32_contig, to_compute
+from .runtime import PreparedCache, get_precision, f32_ptr, compute_dtype, dtype_code, lin_of, prepare_linear, require_gpu, as_f32_contig, to_compute
 from .utils import DeferredAttFt, Query_model
 
 
@@ -92,6 +92,23 @@ class ResidualAttentionBlock(nn.Module):
             raise ValueError(f"sequence of {x.shape[0]} tokens exceeds the {self.attn_mask.shape[0]}-token attention mask")
         xb = as_f32_contig(x.permute(1, 0, 2))  # (B, N, C); a no-op view when x came from the previous block
         B, N, C = xb.shape
+        if torch.is_grad_enabled() and get_precision() == "fp32" and (
+                xb.requires_grad or (space_dict is not None and space_dict.requires_grad) or any(p.requires_grad for p in self.parameters())):
+            # training use: the block as autograd Functions around the same kernels (madtp_amd/backward.py);
+            # sd_ft_all (the running att_ft sum, :241-245) carries a graph as well
+            from .backward import QueryModelFunction, block_forward_with_grad
+            token_attn = None
+            if space_dict is not None:
+                if isinstance(sd_ft_all, DeferredAttFt):
+                    sd_ft_all = None
+                qmap = self.query_model.q_map[0]
+                token_attn, sd_ft = QueryModelFunction.apply(self.query_model, xb, space_dict, qmap.weight, qmap.bias)
+                sd_ft_all = sd_ft if sd_ft_all is None else sd_ft_all + sd_ft
+            prune = space_dict is not None and temperature > 0
+            if self.attn_mask is not None:
+                self._weights()  # (makes the f32 device copy of the mask the backward reads)
+            y = block_forward_with_grad(self, xb, temperature if prune else 0, token_attn, max_keep=int(max_keep))
+            return y.permute(1, 0, 2), space_dict, temperature, sd_ft_all, max_keep
         token_attn = None
         if space_dict is not None:  # :239-245
             if isinstance(sd_ft_all, DeferredAttFt):  # Transformer.forward sums the blocks' att_ft in one launch at the end
@@ -128,6 +145,8 @@ class Transformer(nn.Module):
         if defer is None:
             return self.resblocks((x, space_dict, temperature, sd_ft_all, max_keep))
         x, space_dict, temperature, d, max_keep = self.resblocks((x, space_dict, temperature, defer, max_keep))
+        if not isinstance(d, DeferredAttFt):  # the blocks ran under autograd and summed their att_ft themselves
+            return x, space_dict, temperature, d, max_keep
         return x, space_dict, temperature, (d.finish() if d.pairs else None), max_keep
 
 

@@ -175,3 +175,25 @@ def build_vqa_train(g):
             "images": synth.synth_images(B, size, seed), "ids": synth.synth_token_ids(B, L, seed),
             "att": harness.padded_mask(B, L, int(g["pad_tail"])), "a_ids": a_ids, "a_att": a_att, "n_list": n_list,
             "weights": torch.from_numpy(g["weights"]), "T": float(g["temperature"])}
+
+
+def build_clip_block(g):
+    """Inputs of a clipgrad_* fixture (tools/make_golden.py::clip_block_grad_case): the block input x [B,N,C] (batch first) from the
+    CPU oracle's forward of the preceding blocks."""
+    B, size, T, seed, layer = int(g["B"]), int(g["size"]), float(g["temperature"]), int(g["seed"]), int(g["layer"])
+    W = specs.synth_weights(specs.clip_vit_shapes("", size), seed)
+    images = synth.synth_images(B, size, seed)
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed)
+    import torch.nn.functional as F
+    with torch.no_grad():  # clip/model.py:292-303 up to block `layer`
+        x = F.conv2d(images, W["conv1.weight"], None, stride=16)
+        x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+        x = torch.cat([W["class_embedding"] + torch.zeros(x.shape[0], 1, x.shape[-1]), x], dim=1) + W["positional_embedding"]
+        x = O.layer_norm(x, W["ln_pre.weight"], W["ln_pre.bias"], 1e-5)
+        for i in range(layer):
+            x, _, _ = O.clip_block(W, f"transformer.resblocks.{i}.", x, space_dict, T, int(g["max_keep"]))
+    return {"W": W, "images": images, "space_dict": space_dict, "T": T, "layer": layer, "x": x, "max_keep": int(g["max_keep"]),
+            "prefix": f"transformer.resblocks.{layer}.",
+            "g": torch.from_numpy(synth.uniform_pm1("vitgrad_g", B * 768, seed).reshape(B, 768)),
+            "h": torch.from_numpy(synth.uniform_pm1("vitgrad_h", B * 768, seed).reshape(B, 768)),
+            "a": torch.from_numpy(synth.uniform_pm1("vitgrad_a", B * 100 * 768, seed).reshape(B, 100, 768))}

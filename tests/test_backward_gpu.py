@@ -499,3 +499,38 @@ def test_caption_training_step_matches_reference(hip, path):
     missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]
     assert not missing, f"no gradient produced for {len(missing)} tensors, e.g. {missing[:5]}"
     grad_case.check_against_fixture(g, grads, 1e-3, "HIP caption training step vs reference")
+
+
+CLIPGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clipgrad_*.npz")))
+
+
+@pytest.mark.parametrize("path", CLIPGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in CLIPGRAD_CASES])
+def test_clip_block_backward_matches_reference_grads(hip, path):
+    """CLIP's ResidualAttentionBlock (clip/model.py:174-261: fused in_proj, QuickGELU, the block's own query model with q_map, the
+    k <= max_keep rule) under autograd in the fp32 mode - the block backward of the BLIP ViT behind a parameter adapter,
+    QueryModelFunction with the mapped tokens - against the reference's own .grad (x, space_dict, 14 parameters; sd_ft_all enters
+    the loss too)."""
+    from madtp_amd import clip_model, runtime
+    from oracle import madtp_oracle as O
+    from tests import grad_case
+    g = np.load(path)
+    c = grad_case.build_clip_block(g)
+    blk = clip_model.ResidualAttentionBlock(768, 12, None, sd_dim=768)
+    pre = c["prefix"]
+    blk.load_state_dict({k[len(pre):]: v for k, v in c["W"].items() if k.startswith(pre)}, strict=True)
+    blk = blk.cuda().eval()
+    for p_ in blk.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    x = c["x"].permute(1, 0, 2).contiguous().cuda().requires_grad_(True)   # (N, B, C) as the reference passes it
+    sd = c["space_dict"].cuda().requires_grad_(True)
+    with runtime.precision("fp32"):
+        y, _, _, sd_ft, _ = blk((x, sd, c["T"], None, c["max_keep"]))
+        yb = y.permute(1, 0, 2)
+        assert tuple(yb.shape) == tuple(int(v) for v in g["out_shape"])
+        assert abs(float(yb.detach().double().norm()) - float(g["y_norm"])) < 1e-4 * float(g["y_norm"])
+        assert abs(float(sd_ft.detach().double().norm()) - float(g["sd_ft_norm"])) < 1e-4 * float(g["sd_ft_norm"])
+        (O.vit_loss(yb, c["g"].cuda(), c["h"].cuda()) + (sd_ft * c["a"].cuda()).sum()).backward()
+    grads = {"x": x.grad.permute(1, 0, 2).contiguous(), "space_dict": sd.grad}
+    grads.update({k: p_.grad for k, p_ in blk.named_parameters() if p_.grad is not None})
+    grad_case.check_against_fixture(g, grads, 1e-3, "HIP CLIP block backward vs reference")

@@ -746,3 +746,21 @@ def test_oracle_caption_training_step_matches_reference(path):
                                              float(g["temperature"]), int(g["prompt_length"]))
     assert abs(float(loss) - float(g["loss_lm"])) < 1e-4 * float(g["loss_lm"])
     grad_case.check_against_fixture(g, grads, 1e-4, "oracle caption training step vs reference")
+
+
+CLIPGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clipgrad_*.npz")))
+
+
+@pytest.mark.parametrize("path", CLIPGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in CLIPGRAD_CASES])
+def test_oracle_clip_block_backward_matches_reference_grads(path):
+    """SURVEY 8(f) rank 4, CLIP: autograd through oracle.clip_block == the reference's own .grad of clip/model.py
+    ResidualAttentionBlock.forward (x, space_dict, the block's 12 parameters and its query model's q_map), recorded by
+    tools/make_golden.py::clip_block_grad_case."""
+    from tests import grad_case
+    g = np.load(path)
+    c = grad_case.build_clip_block(g)
+    assert np.allclose(c["x"][:, :2, :8].numpy(), g["x_head"], rtol=2e-5, atol=2e-6)
+    grads, y, sd_ft, info = O.clip_block_grads(c["W"], c["prefix"], c["x"], c["space_dict"], c["T"], c["max_keep"], c["g"], c["h"], c["a"])
+    assert tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
+    assert abs(float(y.double().norm()) - float(g["y_norm"])) < 1e-5 * float(g["y_norm"])
+    grad_case.check_against_fixture(g, grads, 5e-5, "oracle autograd vs reference (CLIP block)")

@@ -553,6 +553,57 @@ def clip_case(name, B, temperature, seed=0, size=224):
     print(f"[{name}] T={temperature} vit_lens={lens}")
 
 
+def clip_block_grad_case(name, B, temperature, layer, seed=0, size=96, nsample=512):
+    """SURVEY 8(f) rank 4 (backward), CLIP: the reference's OWN autograd through clip/model.py ResidualAttentionBlock.forward (with
+    clip/mock.py's patched MultiheadAttention) for one block of the vision tower.  The block's input tuple is captured from a
+    no-grad forward of the reference VisionTransformer; the block then runs alone with x [N,B,C] and space_dict as leaves and
+    sd_ft_all = None, loss = oracle.vit_loss on the output tokens (order invariant) + sum(sd_ft * a).  The block owns its query
+    model (q_map: a Linear in front of the logits), whose parameters are recorded too."""
+    import clip.mock  # noqa: F401
+    import clip.model as cm
+    from madtp_amd import specs
+    from oracle import madtp_oracle as O
+    model = cm.VisionTransformer(input_resolution=size, patch_size=16, width=768, layers=12, heads=12, output_dim=512, sd_dim=768)
+    model.eval()
+    model.load_state_dict(specs.synth_weights(specs.clip_vit_shapes("", size), seed), strict=True)
+    images = synth.synth_images(B, size, seed)
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed)
+    cap = {}
+    blk = model.transformer.resblocks[layer]
+    hk = blk.register_forward_pre_hook(lambda m, a: cap.update(x=a[0][0].detach().clone(), max_keep=a[0][4]))
+    with torch.no_grad():
+        model(images, space_dict, temperature, 1)
+    hk.remove()
+    x = cap["x"].clone().requires_grad_(True)
+    sdl = space_dict.clone().requires_grad_(True)
+    tap = GatherTap(cm)
+    tap.set_tag("blk")
+    for p_ in blk.parameters():
+        p_.grad = None
+    y, _, _, sd_ft, _ = blk((x, sdl, temperature, None, cap["max_keep"]))
+    tap.restore()
+    yb = y.permute(1, 0, 2)
+    g = torch.from_numpy(synth.uniform_pm1("vitgrad_g", B * 768, seed).reshape(B, 768))
+    h = torch.from_numpy(synth.uniform_pm1("vitgrad_h", B * 768, seed).reshape(B, 768))
+    a = torch.from_numpy(synth.uniform_pm1("vitgrad_a", B * 100 * 768, seed).reshape(B, 100, 768))
+    (O.vit_loss(yb, g, h) + (sd_ft * a).sum()).backward()
+    rec = {"kind": "clip_block_grad", "B": B, "size": size, "temperature": np.float64(temperature), "seed": seed, "layer": layer,
+           "nsample": nsample, "max_keep": int(cap["max_keep"]), "out_shape": np.array(yb.shape),
+           "y_norm": np.float64(yb.detach().double().norm().item()), "x_head": cap["x"].permute(1, 0, 2)[:, :2, :8].numpy(),
+           "sd_ft_norm": np.float64(sd_ft.detach().double().norm().item())}
+    rec.update(tap.records)
+    grads = {"x": x.grad.permute(1, 0, 2).contiguous(), "space_dict": sdl.grad}
+    grads.update({k: v.grad for k, v in blk.named_parameters() if v.grad is not None})
+    for k, gr in grads.items():
+        flat = gr.detach().reshape(-1)
+        idx = grad_sample_index(flat.numel(), nsample)
+        rec[f"g_{k}_sample"] = flat[torch.from_numpy(idx)].numpy()
+        rec[f"g_{k}_norm"] = np.float64(flat.double().norm().item())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] layer {layer} T={temperature} in {tuple(cap['x'].shape)} out {tuple(y.shape)} {len(grads)} gradients: "
+          f"{sorted(grads)} records {sorted(tap.records)}")
+
+
 def clip_full_case(name, B, temperature, seed=0, size=224, min_len=6, max_len=40):
     """clip/model.py CLIP (ViT-B/16 geometry, text width 512 / 8 heads / 12 layers / ctx 77): the reference's own
     encode_image / encode_text (compress_retrieval_clip_dtp.py:92,100 call sites) with clip/mock.py's patched MHA."""
@@ -992,6 +1043,7 @@ CASES = {
     "encgrad_b2_s96": lambda: vit_grad_case("encgrad_b2_s96", 2, 96, 5.0),
     "medgrad_b3_l0": lambda: med_layer_grad_case("medgrad_b3_l0", 3, 35, 30.0, layer=0, pad_tail=3),
     "medgrad_b3_l3": lambda: med_layer_grad_case("medgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
+    "clipgrad_b2_l1": lambda: clip_block_grad_case("clipgrad_b2_l1", 2, 4.0, layer=1),
     "trainstep_cap_b2": lambda: cap_train_case("trainstep_cap_b2", 2, 96, 12, 20.0),
     "trainstep_vqa_b2": lambda: vqa_train_case("trainstep_vqa_b2", 2, 96, 20, 20.0, [2, 1], 6),
     "decgrad_b3": lambda: decoder_grad_case("decgrad_b3", 3, 8, 12),
