@@ -282,8 +282,7 @@ class VitBlockFunction(torch.autograd.Function):
         x, ta = ctx.saved_tensors
         ta = ta if ctx.has_ta else None
         mask = getattr(ctx.blk, "_mask_dev", None) if getattr(ctx.blk, "attn_mask", None) is not None else None
-        if mask is not None:
-            mask = mask[:x.shape[1], :x.shape[1]]
+        # (the full [ctx, ctx] mask: the kernels read its leading [N, N] corner through the row stride, clip/mock.py:309-310)
         with torch.no_grad():
             dx, dta, grads = vit_block_backward(ctx.blk, x, ta, ctx.temperature, ctx.k, dy, mask_qk=mask)
         pg = [grads.get(name) for name in _BlockParts(ctx.blk).order()]

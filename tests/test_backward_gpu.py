@@ -534,3 +534,35 @@ def test_clip_block_backward_matches_reference_grads(hip, path):
     grads = {"x": x.grad.permute(1, 0, 2).contiguous(), "space_dict": sd.grad}
     grads.update({k: p_.grad for k, p_ in blk.named_parameters() if p_.grad is not None})
     grad_case.check_against_fixture(g, grads, 1e-3, "HIP CLIP block backward vs reference")
+
+
+CLIPTEXTGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "cliptextgrad_*.npz")))
+
+
+@pytest.mark.parametrize("path", CLIPTEXTGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in CLIPTEXTGRAD_CASES])
+def test_clip_text_block_backward_matches_reference_grads(hip, path):
+    """A block of CLIP's text tower (width 512, 8 heads, causal attn_mask applied as mask[:N,:N]) under autograd: the causal mask
+    together with the pruning score terms in the attention backward, against the reference's own .grad."""
+    from madtp_amd import clip_model, runtime
+    from oracle import madtp_oracle as O
+    from tests import grad_case
+    from tests.test_oracle_golden import _clip_text_block_case
+    g = np.load(path)
+    c = _clip_text_block_case(g)
+    blk = clip_model.ResidualAttentionBlock(512, 8, c["mask"], sd_dim=768)
+    blk.load_state_dict({k[2:]: v for k, v in c["W"].items()}, strict=True)
+    blk = blk.cuda().eval()
+    for p_ in blk.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    x = c["x"].permute(1, 0, 2).contiguous().cuda().requires_grad_(True)
+    sd = c["space_dict"].cuda().requires_grad_(True)
+    with runtime.precision("fp32"):
+        y, _, _, sd_ft, _ = blk((x, sd, c["T"], None, c["max_keep"]))
+        yb = y.permute(1, 0, 2)
+        assert tuple(yb.shape) == tuple(int(v) for v in g["out_shape"])
+        assert abs(float(yb.detach().double().norm()) - float(g["y_norm"])) < 1e-4 * float(g["y_norm"])
+        (O.vit_loss(yb, c["g"].cuda(), c["h"].cuda()) + (sd_ft * c["a"].cuda()).sum()).backward()
+    grads = {"x": x.grad.permute(1, 0, 2).contiguous(), "space_dict": sd.grad}
+    grads.update({k: p_.grad for k, p_ in blk.named_parameters() if p_.grad is not None})
+    grad_case.check_against_fixture(g, grads, 1e-3, "HIP CLIP text block backward vs reference")

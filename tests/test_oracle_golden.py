@@ -764,3 +764,42 @@ def test_oracle_clip_block_backward_matches_reference_grads(path):
     assert tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
     assert abs(float(y.double().norm()) - float(g["y_norm"])) < 1e-5 * float(g["y_norm"])
     grad_case.check_against_fixture(g, grads, 5e-5, "oracle autograd vs reference (CLIP block)")
+
+
+CLIPTEXTGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "cliptextgrad_*.npz")))
+
+
+def _clip_text_block_case(g):
+    from madtp_amd import synth
+    B, N, seed = int(g["B"]), int(g["N"]), int(g["seed"])
+    names = ["ln_1.weight", "ln_1.bias", "ln_2.weight", "ln_2.bias", "attn.in_proj_weight", "attn.in_proj_bias",
+             "attn.out_proj.weight", "attn.out_proj.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias",
+             "query_model.q_map.0.weight", "query_model.q_map.0.bias"]
+    shapes = {"ln_1.weight": (512,), "ln_1.bias": (512,), "ln_2.weight": (512,), "ln_2.bias": (512,),
+              "attn.in_proj_weight": (1536, 512), "attn.in_proj_bias": (1536,), "attn.out_proj.weight": (512, 512),
+              "attn.out_proj.bias": (512,), "mlp.c_fc.weight": (2048, 512), "mlp.c_fc.bias": (2048,), "mlp.c_proj.weight": (512, 2048),
+              "mlp.c_proj.bias": (512,), "query_model.q_map.0.weight": (768, 512), "query_model.q_map.0.bias": (768,)}
+    W = {"b." + k: synth.synth_tensor("clip_text_block." + k, shapes[k], seed) for k in names}
+    mask = torch.empty(77, 77).fill_(float("-inf")).triu_(1)
+    return {"W": W, "mask": mask, "x": synth.synth_tensor("clip_text_x", (N, B, 512), seed).permute(1, 0, 2).contiguous(),
+            "space_dict": synth.synth_tensor("space_dict", (100, 768), seed), "T": float(g["temperature"]), "max_keep": int(g["max_keep"]),
+            "g": torch.from_numpy(synth.uniform_pm1("vitgrad_g", B * 512, seed).reshape(B, 512)),
+            "h": torch.from_numpy(synth.uniform_pm1("vitgrad_h", B * 512, seed).reshape(B, 512)),
+            "a": torch.from_numpy(synth.uniform_pm1("vitgrad_a", B * 100 * 768, seed).reshape(B, 100, 768))}
+
+
+@pytest.mark.parametrize("path", CLIPTEXTGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in CLIPTEXTGRAD_CASES])
+def test_oracle_clip_text_block_backward_matches_reference_grads(path):
+    """CLIP text-tower block (width 512, 8 heads, causal mask): oracle autograd == the reference's own .grad
+    (tools/make_golden.py::clip_text_block_grad_case)."""
+    from tests import grad_case
+    g = np.load(path)
+    c = _clip_text_block_case(g)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in c["W"].items()}
+    xl, sl = c["x"].clone().requires_grad_(True), c["space_dict"].clone().requires_grad_(True)
+    y, sd_ft, info = O.clip_block(leaves, "b.", xl, sl, c["T"], c["max_keep"], num_heads=8, attn_mask=c["mask"])
+    (O.vit_loss(y, c["g"], c["h"]) + (sd_ft * c["a"]).sum()).backward()
+    assert tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
+    grads = {"x": xl.grad, "space_dict": sl.grad}
+    grads.update({k[2:]: v.grad for k, v in leaves.items()})
+    grad_case.check_against_fixture(g, grads, 5e-5, "oracle autograd vs reference (CLIP text block)")

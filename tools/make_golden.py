@@ -604,6 +604,44 @@ def clip_block_grad_case(name, B, temperature, layer, seed=0, size=96, nsample=5
           f"{sorted(grads)} records {sorted(tap.records)}")
 
 
+def clip_text_block_grad_case(name, B, N, temperature, max_keep, seed=0, nsample=512):
+    """As clip_block_grad_case for a block of CLIP's TEXT tower (width 512, 8 heads, causal attn_mask [77,77] applied as
+    mask[:N,:N], clip/mock.py:309-310): a stand-alone reference ResidualAttentionBlock with synthetic weights on a synthetic token
+    tensor x [N,B,512] - exercises the causal mask together with the pruning score terms in the attention backward."""
+    import clip.mock  # noqa: F401
+    import clip.model as cm
+    from oracle import madtp_oracle as O
+    mask = torch.empty(77, 77).fill_(float("-inf")).triu_(1)   # CLIP.build_attention_mask (clip/model.py:383-389)
+    blk = cm.ResidualAttentionBlock(512, 8, mask, sd_dim=768)
+    blk.eval()
+    blk.load_state_dict(synth.fill_state_dict(blk, seed, prefix="clip_text_block."), strict=True)
+    x = synth.synth_tensor("clip_text_x", (N, B, 512), seed).clone().requires_grad_(True)
+    sdl = synth.synth_tensor("space_dict", (100, 768), seed).clone().requires_grad_(True)
+    tap = GatherTap(cm)
+    tap.set_tag("blk")
+    y, _, _, sd_ft, _ = blk((x, sdl, temperature, None, max_keep))
+    tap.restore()
+    yb = y.permute(1, 0, 2)
+    g = torch.from_numpy(synth.uniform_pm1("vitgrad_g", B * 512, seed).reshape(B, 512))
+    h = torch.from_numpy(synth.uniform_pm1("vitgrad_h", B * 512, seed).reshape(B, 512))
+    a = torch.from_numpy(synth.uniform_pm1("vitgrad_a", B * 100 * 768, seed).reshape(B, 100, 768))
+    (O.vit_loss(yb, g, h) + (sd_ft * a).sum()).backward()
+    assert yb.shape[1] < N, f"block not pruned at T={temperature}: {tuple(yb.shape)}"
+    rec = {"kind": "clip_text_block_grad", "B": B, "N": N, "temperature": np.float64(temperature), "seed": seed, "nsample": nsample,
+           "max_keep": int(max_keep), "out_shape": np.array(yb.shape), "y_norm": np.float64(yb.detach().double().norm().item()),
+           "sd_ft_norm": np.float64(sd_ft.detach().double().norm().item())}
+    rec.update(tap.records)
+    grads = {"x": x.grad.permute(1, 0, 2).contiguous(), "space_dict": sdl.grad}
+    grads.update({k: v.grad for k, v in blk.named_parameters() if v.grad is not None})
+    for k, gr in grads.items():
+        flat = gr.detach().reshape(-1)
+        idx = grad_sample_index(flat.numel(), nsample)
+        rec[f"g_{k}_sample"] = flat[torch.from_numpy(idx)].numpy()
+        rec[f"g_{k}_norm"] = np.float64(flat.double().norm().item())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] T={temperature} in ({N},{B},512) out {tuple(y.shape)} {len(grads)} gradients")
+
+
 def clip_full_case(name, B, temperature, seed=0, size=224, min_len=6, max_len=40):
     """clip/model.py CLIP (ViT-B/16 geometry, text width 512 / 8 heads / 12 layers / ctx 77): the reference's own
     encode_image / encode_text (compress_retrieval_clip_dtp.py:92,100 call sites) with clip/mock.py's patched MHA."""
@@ -1043,6 +1081,7 @@ CASES = {
     "encgrad_b2_s96": lambda: vit_grad_case("encgrad_b2_s96", 2, 96, 5.0),
     "medgrad_b3_l0": lambda: med_layer_grad_case("medgrad_b3_l0", 3, 35, 30.0, layer=0, pad_tail=3),
     "medgrad_b3_l3": lambda: med_layer_grad_case("medgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
+    "cliptextgrad_b2": lambda: clip_text_block_grad_case("cliptextgrad_b2", 2, 24, 3.0, 4),
     "clipgrad_b2_l1": lambda: clip_block_grad_case("clipgrad_b2_l1", 2, 4.0, layer=1),
     "trainstep_cap_b2": lambda: cap_train_case("trainstep_cap_b2", 2, 96, 12, 20.0),
     "trainstep_vqa_b2": lambda: vqa_train_case("trainstep_vqa_b2", 2, 96, 20, 20.0, [2, 1], 6),
