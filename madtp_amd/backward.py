@@ -772,3 +772,55 @@ def bert_encoder_forward_with_grad(enc, hidden_states, attention_mask, space_dic
                                 mode=mode, space_dict=space_dict, token_attn=token_attn, reduce_num=reduce_num, temperature=t)
         hidden_states, attention_mask = outs[0], outs[-1]
     return hidden_states, attention_mask, sd_all
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CLIP's vision tower (clip/model.py:275-313) under autograd: conv1 (no bias) + class / positional embedding, ln_pre, the blocks
+# (they route themselves to VitBlockFunction / QueryModelFunction), ln_post on the class token, x @ proj.
+
+class ClipPatchTokensFunction(torch.autograd.Function):
+    """tok = cat(class_embedding, conv1(img)) + positional_embedding (clip/model.py:293-297; conv1 = im2col + GEMM)."""
+
+    @staticmethod
+    def forward(ctx, img, w, cls, pos, patch):
+        cols = hip.patchify(img, patch, torch.float32)
+        wp, _ = _f32_wb(w.reshape(w.shape[0], -1), None)
+        patches = hip.gemm(cols, wp, None, out_dtype=torch.float32, n=w.shape[0])
+        B = img.shape[0]
+        ctx.np_, ctx.patch = patches.shape[0] // B, patch
+        ctx.save_for_backward(img, w)
+        return hip.assemble_tokens(patches, cls.detach().contiguous(), pos.detach().contiguous(), B, ctx.np_)
+
+    @staticmethod
+    def backward(ctx, dx):
+        img, w = ctx.saved_tensors
+        B, N, D = dx.shape
+        with torch.no_grad():
+            dx = dx.contiguous().float()
+            dpos = colsum(dx.view(B, N * D)).view(N, D)
+            dcls = dpos[0].clone()
+            dpatch = dx[:, 1:, :].reshape(B * ctx.np_, D).contiguous()
+            cols = hip.patchify(img, ctx.patch, torch.float32)
+            dw = wgrad(dpatch, cols).view_as(w)
+        return None, dw, dcls, dpos, None
+
+
+def clip_vision_forward_with_grad(vt, img, space_dict, temperature, max_keep):
+    """clip.model.VisionTransformer.forward under autograd -> (features [B, output_dim], sd_img_ft_all); fp32 mode."""
+    from . import runtime
+    if runtime.get_precision() != "fp32":
+        raise NotImplementedError("the CLIP backward is built for the fp32 precision mode (runtime.precision('fp32')); "
+                                  f"current mode: {runtime.get_precision()}")
+    tok = ClipPatchTokensFunction.apply(img, vt.conv1.weight, vt.class_embedding, vt.positional_embedding, vt.patch_size)
+    tok = LayerNormFunction.apply(tok, vt.ln_pre.weight, vt.ln_pre.bias, vt.ln_pre.eps)
+    xs = tok.permute(1, 0, 2)
+    sd_all = None
+    if space_dict is not None:
+        xs, _, _, sd_all, _ = vt.transformer(xs, space_dict, temperature, None, max_keep)
+    else:
+        xs = vt.transformer(xs)[0]
+    cls = xs.permute(1, 0, 2)[:, 0, :].contiguous()
+    cls = LayerNormFunction.apply(cls, vt.ln_post.weight, vt.ln_post.bias, vt.ln_post.eps)
+    if vt.proj is not None:
+        cls = LinearFunction.apply(cls, vt.proj.t().contiguous(), None, hip.ACT_NONE)  # x @ proj (:311-312)
+    return cls, sd_all

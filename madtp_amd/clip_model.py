@@ -171,6 +171,10 @@ class VisionTransformer(nn.Module):
     def forward(self, x: torch.Tensor, space_dict=None, temperature=0, max_keep=1):
         img = as_f32_contig(require_gpu(x, "image"))
         B = img.shape[0]
+        if torch.is_grad_enabled() and get_precision() == "fp32" and (
+                (space_dict is not None and space_dict.requires_grad) or any(p.requires_grad for p in self.parameters())):
+            from .backward import clip_vision_forward_with_grad  # (the tower under autograd)
+            return clip_vision_forward_with_grad(self, img, space_dict, temperature, max_keep)
         cdt = compute_dtype()
         conv = self._cache.get(("conv", cdt), [self.conv1.weight], lambda: prepare_linear([self.conv1.weight], None, cdt))
         cols = hip.patchify(img, self.patch_size, cdt)

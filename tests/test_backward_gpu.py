@@ -566,3 +566,43 @@ def test_clip_text_block_backward_matches_reference_grads(hip, path):
     grads = {"x": x.grad.permute(1, 0, 2).contiguous(), "space_dict": sd.grad}
     grads.update({k: p_.grad for k, p_ in blk.named_parameters() if p_.grad is not None})
     grad_case.check_against_fixture(g, grads, 1e-3, "HIP CLIP text block backward vs reference")
+
+
+CLIPVITGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clipvitgrad_*.npz")))
+
+
+@pytest.mark.parametrize("path", CLIPVITGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in CLIPVITGRAD_CASES])
+def test_clip_vision_backward_matches_reference_grads(hip, path):
+    """CLIP's vision tower (encode_image) under autograd on the HIP path: conv1 + class / positional embedding, ln_pre, twelve
+    pruned blocks with their own query models, ln_post, proj - features, per-layer lengths and the gradients of all 176 parameters
+    + space_dict against the reference's own."""
+    from madtp_amd import clip_model, runtime
+    from tests import grad_case
+    from tests.test_oracle_golden import _clip_vit_case
+    g = np.load(path)
+    c = _clip_vit_case(g)
+    vt = clip_model.VisionTransformer(input_resolution=int(g["size"]), patch_size=16, width=768, layers=12, heads=12, output_dim=512,
+                                      sd_dim=768)
+    vt.load_state_dict(c["W"], strict=True)
+    vt = vt.cuda().eval()
+    for p_ in vt.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    sd = c["space_dict"].cuda().requires_grad_(True)
+    with runtime.precision("fp32"):
+        feat, sd_all = vt(c["images"].cuda(), sd, c["T"], 1)
+        assert feat.requires_grad and (feat.detach().cpu() - torch.from_numpy(g["features"])).abs().max().item() < 1e-4
+        lens = [int(b.last_prune["indices"].shape[1]) + 2 if (b.last_prune and b.last_prune.get("pruned")) else None
+                for b in vt.transformer.resblocks]
+        n = (int(g["size"]) // 16) ** 2 + 1
+        got = []
+        for v in lens:
+            n = v if v is not None else n
+            got.append(n)
+        assert got == g["vit_lens"].tolist()
+        ((feat * c["c"].cuda()).sum() + (sd_all * c["a"].cuda()).sum()).backward()
+    grads = {k: p_.grad for k, p_ in vt.named_parameters() if p_.grad is not None}
+    grads["space_dict"] = sd.grad
+    missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]
+    assert not missing, f"no gradient produced for {missing[:5]}"
+    grad_case.check_against_fixture(g, grads, 1e-3, "HIP CLIP vision tower backward vs reference")

@@ -803,3 +803,27 @@ def test_oracle_clip_text_block_backward_matches_reference_grads(path):
     grads = {"x": xl.grad, "space_dict": sl.grad}
     grads.update({k[2:]: v.grad for k, v in leaves.items()})
     grad_case.check_against_fixture(g, grads, 5e-5, "oracle autograd vs reference (CLIP text block)")
+
+
+CLIPVITGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clipvitgrad_*.npz")))
+
+
+def _clip_vit_case(g):
+    from madtp_amd import specs, synth
+    B, size, seed = int(g["B"]), int(g["size"]), int(g["seed"])
+    return {"W": specs.synth_weights(specs.clip_vit_shapes("", size), seed), "images": synth.synth_images(B, size, seed),
+            "space_dict": synth.synth_tensor("space_dict", (100, 768), seed), "T": float(g["temperature"]),
+            "c": torch.from_numpy(synth.uniform_pm1("clipgrad_c", B * 512, seed).reshape(B, 512)),
+            "a": torch.from_numpy(synth.uniform_pm1("vitgrad_a", B * 100 * 768, seed).reshape(B, 100, 768))}
+
+
+@pytest.mark.parametrize("path", CLIPVITGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in CLIPVITGRAD_CASES])
+def test_oracle_clip_vision_backward_matches_reference_grads(path):
+    """CLIP's vision tower end to end: oracle autograd == the reference's own .grad of clip/model.py VisionTransformer.forward
+    (176 parameters + space_dict; tools/make_golden.py::clip_vit_grad_case)."""
+    from tests import grad_case
+    g = np.load(path)
+    c = _clip_vit_case(g)
+    grads, feat, trace = O.clip_vision_grads(c["W"], "", c["images"], c["space_dict"], c["T"], c["c"], c["a"])
+    assert np.abs(feat.numpy() - g["features"]).max() < 1e-5
+    grad_case.check_against_fixture(g, grads, 1e-4, "oracle autograd vs reference (CLIP vision tower)")

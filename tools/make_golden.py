@@ -604,6 +604,43 @@ def clip_block_grad_case(name, B, temperature, layer, seed=0, size=96, nsample=5
           f"{sorted(grads)} records {sorted(tap.records)}")
 
 
+def clip_vit_grad_case(name, B, temperature, seed=0, size=96, nsample=192):
+    """SURVEY 8(f) rank 4 (backward), CLIP's vision tower end to end: the reference's OWN autograd through clip/model.py
+    VisionTransformer.forward (conv1, class / positional embedding, ln_pre, twelve pruned blocks each with its own query model,
+    ln_post, proj) with every parameter and space_dict as leaves, loss = sum(features * c) + sum(sd_img_ft_all * a)."""
+    import clip.mock  # noqa: F401
+    import clip.model as cm
+    from madtp_amd import specs
+    model = cm.VisionTransformer(input_resolution=size, patch_size=16, width=768, layers=12, heads=12, output_dim=512, sd_dim=768)
+    model.eval()
+    model.load_state_dict(specs.synth_weights(specs.clip_vit_shapes("", size), seed), strict=True)
+    images = synth.synth_images(B, size, seed)
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed).clone().requires_grad_(True)
+    lens, hooks = [], []
+    for blk in model.transformer.resblocks:
+        hooks.append(blk.register_forward_hook(lambda m, a, o: lens.append(o[0].shape[0])))
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    feat, sd_all = model(images, space_dict, temperature, 1)
+    for h in hooks:
+        h.remove()
+    c = torch.from_numpy(synth.uniform_pm1("clipgrad_c", B * 512, seed).reshape(B, 512))
+    a = torch.from_numpy(synth.uniform_pm1("vitgrad_a", B * 100 * 768, seed).reshape(B, 100, 768))
+    ((feat * c).sum() + (sd_all * a).sum()).backward()
+    rec = {"kind": "clip_vit_grad", "B": B, "size": size, "temperature": np.float64(temperature), "seed": seed, "nsample": nsample,
+           "vit_lens": np.array(lens), "features": feat.detach().numpy(), "sd_all_norm": np.float64(sd_all.detach().double().norm().item())}
+    grads = {"space_dict": space_dict.grad}
+    grads.update({k: v.grad for k, v in model.named_parameters() if v.grad is not None})
+    for k, gr in grads.items():
+        flat = gr.detach().reshape(-1)
+        idx = grad_sample_index(flat.numel(), nsample)
+        rec[f"g_{k}_sample"] = flat[torch.from_numpy(idx)].numpy()
+        rec[f"g_{k}_norm"] = np.float64(flat.double().norm().item())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] T={temperature} lens {lens} {len(grads)} gradients")
+
+
 def clip_text_block_grad_case(name, B, N, temperature, max_keep, seed=0, nsample=512):
     """As clip_block_grad_case for a block of CLIP's TEXT tower (width 512, 8 heads, causal attn_mask [77,77] applied as
     mask[:N,:N], clip/mock.py:309-310): a stand-alone reference ResidualAttentionBlock with synthetic weights on a synthetic token
@@ -1081,6 +1118,7 @@ CASES = {
     "encgrad_b2_s96": lambda: vit_grad_case("encgrad_b2_s96", 2, 96, 5.0),
     "medgrad_b3_l0": lambda: med_layer_grad_case("medgrad_b3_l0", 3, 35, 30.0, layer=0, pad_tail=3),
     "medgrad_b3_l3": lambda: med_layer_grad_case("medgrad_b3_l3", 3, 35, 30.0, layer=3, pad_tail=3),
+    "clipvitgrad_b2": lambda: clip_vit_grad_case("clipvitgrad_b2", 2, 4.0),
     "cliptextgrad_b2": lambda: clip_text_block_grad_case("cliptextgrad_b2", 2, 24, 3.0, 4),
     "clipgrad_b2_l1": lambda: clip_block_grad_case("clipgrad_b2_l1", 2, 4.0, layer=1),
     "trainstep_cap_b2": lambda: cap_train_case("trainstep_cap_b2", 2, 96, 12, 20.0),
