@@ -87,6 +87,9 @@ class BLIP_NLVR(nn.Module):
         reference's training mode are not built (the mirror modules have none), so this is the reference's training forward with
         model.eval() semantics - what its gradients are checked against.  Gradients need the fp32 precision mode."""
         require_gpu(image, "image")
+        if train:
+            from .runtime import warn_no_dropout
+            warn_no_dropout(self)
         self.visual_encoder.img_query_model.compute_att_ft = self.compute_sd_ft
         self.text_encoder.encoder.txt_query_model.compute_att_ft = self.compute_sd_ft
         # sd_img_ft only feeds the training loss (:86-96): its (fast-mode) sum over the layers runs on the auxiliary stream,

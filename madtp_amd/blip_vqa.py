@@ -99,6 +99,8 @@ class BLIP_VQA(nn.Module):
         dictionary features (:102-113).  Gradients need the fp32 precision mode (madtp_amd/backward.py); the reference's dropout is
         not built (model.eval() semantics)."""
         import torch.nn.functional as F
+        from .runtime import warn_no_dropout
+        warn_no_dropout(self)
         if self.text_decoder is None:
             raise RuntimeError("BLIP_VQA(decoder=False) has no answer decoder to train")
         question_states, _, (sd_img_ft, sd_txt_ft) = self.encode_question(image, question, temperature)

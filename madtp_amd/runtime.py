@@ -263,3 +263,17 @@ def as_f32_contig(t):
     if t.dtype != torch.float32:
         t = t.float()
     return t if t.is_contiguous() else t.contiguous()
+
+
+_WARNED_DROPOUT = [False]
+
+
+def warn_no_dropout(module):
+    """The training forwards (BLIP_NLVR / BLIP_VQA / BLIP_Decoder with train=True) run the reference's graph WITHOUT its stochastic
+    regularisers: the mirror modules carry nn.Dropout members for state-dict / constructor compatibility, but the kernels have no
+    dropout and the ViT no DropPath.  In module.train() mode that differs from the reference (which drops with p = 0.1): say so once."""
+    if module.training and not _WARNED_DROPOUT[0]:
+        import warnings
+        _WARNED_DROPOUT[0] = True
+        warnings.warn("madtp_amd: train=True runs without dropout / DropPath (not built); gradients are those of the reference in "
+                      "model.eval() mode", RuntimeWarning, stacklevel=3)
