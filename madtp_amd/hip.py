@@ -840,14 +840,10 @@ def query_model(x, sd_w, K, att_ft=None, want_att_ft=True, sd_dim=768, sd_split=
 
 
 def bert_layer_attn(wstruct, hidden, mask2d, token_attn, temperature, Nk):
+    """First half of a BERT layer (madtp_bert_layer_attn: self-attention + output LayerNorm + importance score) for callers with
+    their own pruning rule -> (attention_output, (score, threshold, count, kmax) or None)."""
     B, L, D = hidden.shape
     lib = load()
-    kv_ld = 0
-    for t in kv_pre:  # cached [k|v] rows may be column slices of a wider projection (all layers side by side)
-        if t is not None:
-            if t.stride(-1) != 1 or (kv_ld and kv_ld != t.stride(0)):
-                raise RuntimeError("bert_layer: kv_pre tensors must be row-major with one common row stride")
-            kv_ld = t.stride(0)
     nbytes = lib.madtp_bert_layer_workspace(B, L, Nk, wstruct.dim, wstruct.inter.n, wstruct.heads, wstruct.dtype)
     ws = workspace(nbytes, hidden.device)
     att = torch.empty_like(hidden)
