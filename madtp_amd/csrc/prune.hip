@@ -555,11 +555,43 @@ __global__ __launch_bounds__(512, 2) void token_score_split_kernel(const float* 
 // ----------------------------------------------------------------------------------------------- token_select
 // NTHR threads per sample: 256, or 1024 for long sequences (the ranking is n^2 / NTHR compare steps per thread: 35 us at 900
 // tokens with 256 threads).  The sum of the dropped scores keeps the 256-thread association in both variants (same bits).
+// Long sequences (n > 320: 577 / 901 tokens) at small batches: the n^2 ranking of one sample on ONE workgroup was 20 us of
+// VALU work on 32 of 256 CUs (VQA).  token_rank_kernel spreads it: a workgroup ranks 64 tokens, four lanes per token (each counts a
+// quarter of the other tokens, two quad shuffles add up), grid (ceil(n / 64), B); the ranks go to `rank_out` [B, n] (the caller
+// passes dst_pos, which token_select_kernel overwrites afterwards) and indices_sort is scattered here.  Same keys, same tie rule:
+// the same permutation as the in-kernel ranking.
+__global__ __launch_bounds__(256) void token_rank_kernel(const float* __restrict__ score, int64_t* __restrict__ indices_sort,
+                                                         int32_t* __restrict__ rank_out, int n) {
+    __shared__ unsigned key_s[MAXN];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    for (int t = tid; t < n; t += 256) {
+        const float v = score[(size_t)b * n + t];
+        const unsigned u = __float_as_uint(v + 0.0f);
+        key_s[t] = (v != v) ? 0u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+    }
+    __syncthreads();
+    const int t = blockIdx.x * 64 + (tid >> 2), q = tid & 3;
+    const bool ok = t < n;
+    const unsigned kv = ok ? key_s[t] : 0u;
+    int r = 0;
+    if (ok)
+        for (int u = q; u < n; u += 4) {
+            const unsigned kw = key_s[u];
+            r += (kw > kv || (kw == kv && u < t)) ? 1 : 0;
+        }
+    r += __shfl_xor(r, 1);
+    r += __shfl_xor(r, 2);
+    if (ok && q == 0) {
+        rank_out[(size_t)b * n + t] = r;
+        indices_sort[(size_t)b * n + r] = t;
+    }
+}
+
 template <int NTHR>
 __global__ __launch_bounds__(NTHR) void token_select_kernel(const float* __restrict__ score, int k,
                                                             int64_t* __restrict__ indices, int64_t* __restrict__ indices_sort,
                                                             int32_t* __restrict__ dst_pos, float* __restrict__ merge_w, int n,
-                                                            const int32_t* dims_l = nullptr) {
+                                                            const int32_t* dims_l = nullptr, bool ranked = false) {
     // sync-free encoder path: n and k from the layer's device-side record; k == 0 there means "not pruned" (vit.py:148-149): the
     // kernel then writes the identity map (every token kept in place, no merge weights) for the gather that follows
     bool ident = false;
@@ -586,7 +618,12 @@ __global__ __launch_bounds__(NTHR) void token_select_kernel(const float* __restr
     if (tid == 0) base_s = 0;
     __syncthreads();
     // rank by counting: #tokens with a larger score (ties: lower index first) == position in a stable descending sort
+    // (ranked: token_rank_kernel did it and left the ranks in dst_pos - read them all before anything below overwrites dst_pos)
     for (int t = tid; t < n; t += NTHR) {
+        if (ranked) {
+            rank_s[t] = dst_pos[(size_t)b * n + t];
+            continue;
+        }
         const unsigned kv = key_s[t];
         int r = 0;
         for (int u = 0; u < n; ++u) {
@@ -1792,11 +1829,22 @@ int madtp_i_token_gather_ln_dev(const float* x, const int32_t* dst_pos, const fl
     return 0;
 }
 
+static bool rank_split_enabled() {  // MADTP_RANK_SPLIT=0: the one-workgroup ranking at every length (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MADTP_RANK_SPLIT"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
 extern "C" int madtp_token_select(const float* score, int k, int64_t* indices, int64_t* indices_sort, int32_t* dst_pos,
                                   float* merge_w, int B, int n, void* stream) {
     if (!score || !indices || !indices_sort || !dst_pos || !merge_w || B <= 0 || n <= 0) return MADTP_E_BADARG;
     if (k < 1 || k > n || n > MAXN) return MADTP_E_SHAPE;
-    if (n > 320)
+    if (n > 320 && B <= 64 && rank_split_enabled()) {
+        // long sequences at small batches: the ranking on ceil(n / 64) workgroups per sample, then compaction + merge weights
+        hipLaunchKernelGGL(token_rank_kernel, dim3((n + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, score, indices_sort, dst_pos, n);
+        hipLaunchKernelGGL(token_select_kernel<256>, dim3(B), dim3(256), 0, (hipStream_t)stream, score, k, indices, indices_sort,
+                           dst_pos, merge_w, n, (const int32_t*)nullptr, true);
+    } else if (n > 320)
         hipLaunchKernelGGL(token_select_kernel<1024>, dim3(B), dim3(1024), 0, (hipStream_t)stream, score, k, indices, indices_sort,
                            dst_pos, merge_w, n);
     else
