@@ -12,9 +12,12 @@ blip_vqa.py: pure glue) to be imported from the reference tree itself.  The CLIP
 `CLIP`) and `clip.mock` - the reference's import-time monkey-patch of torch.nn.MultiheadAttention
 (clip/mock.py:354-359), which the mirror's blocks do not use - as an empty module, while `clip.clip` (load / tokenize /
 _transform: host glue) and `clip.simple_tokenizer` are imported from the reference tree itself.  Names those glue files import that are off the
-pruned forward path (the contrastive-loss helpers of models/utils.py) resolve to stubs that raise on use, so a training script
-fails loudly instead of silently running something else; `models.med.BertLMHeadModel` is the teacher-forced decoder mirror
-(rank_answer and beam-search `generate`; nucleus sampling raises)."""
+pruned forward path (the contrastive-loss helpers of models/utils.py) resolve to stubs that raise on use, so a script that needs
+them (retrieval / CLIP training: momentum encoders, queues) fails loudly instead of silently running something else;
+`models.med.BertLMHeadModel` is the decoder mirror (teacher-forced with or without labels, rank_answer, beam-search `generate`;
+nucleus sampling raises).  Since round 4 the mirrors build an autograd graph in the fp32 precision mode when grad mode is on
+(madtp_amd/backward.py), so the NLVR / VQA / caption glue files' `forward(train=True)` - whose loss heads are plain torch code in
+the reference's own files - can be back-propagated through; the mirrors have no dropout / DropPath."""
 import importlib
 import math
 import os
