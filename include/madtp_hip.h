@@ -273,7 +273,8 @@ int madtp_cast_lp(const float* src, void* dst, size_t n, int lp_dtype, float sca
  * the softmax over tokens of vit.py:137-139 in log2 units with the hardware exp2 and one reciprocal per dictionary column instead
  * of two IEEE divisions and a precise expf per logit (that phase is VALU-bound: 10 of 17 us at 197 tokens).  The parity modes
  * (fp32, f16x3) keep on = 0: their arithmetic is the reference's.  Process-wide, set together with the precision mode
- * (madtp_amd/runtime.py); only the one-workgroup-per-sample kernel (token logits resident in LDS) has the fast form.  Returns
+ * (madtp_amd/runtime.py); the LDS-resident kernels (one workgroup per sample, and the column-split one for long sequences) have
+ * the fast form, the global-memory fallback does not.  Returns
  * the previous value.  No reference counterpart. */
 int madtp_set_score_fast(int on);
 

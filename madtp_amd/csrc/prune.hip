@@ -308,7 +308,7 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
 // and publishes the minimum of its columns' sums; the last workgroup of the sample to arrive (agent-scope ticket) takes the
 // minimum over the G partial minima (exact, order-free), counts the survivors and takes part in the launch-wide ticket that
 // hands k to the host.  tick / part: per-sample scratch of the hand-over slot (zeroed once, every ticket resets itself).
-template <int G>
+template <int G, bool FAST = false>
 __global__ __launch_bounds__(512, 2) void token_score_split_kernel(const float* __restrict__ colsum, int nrt,
                                                                 const float* __restrict__ p0, const float* __restrict__ onorm,
                                                                 const float* __restrict__ ta, int ldt, int ldb, int K,
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void token_score_split_kernel(const float* 
     if (cval) {
 #pragma unroll 8
         for (int t = t0; t < t1; ++t) {
-            const float v = TA(t, col) / temperature;
+            const float v = FAST ? TA(t, col) * (1.44269504088896341f / temperature) : TA(t, col) / temperature;  // (FAST: log2 units)
             cols_s[t * KC + cl] = v;
             m = fmaxf(m, v);
         }
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void token_score_split_kernel(const float* 
     if (cval) {
 #pragma unroll 8
         for (int t = t0; t < t1; ++t) {
-            const float e = expf(cols_s[t * KC + cl] - m);
+            const float e = FAST ? __builtin_amdgcn_exp2f(cols_s[t * KC + cl] - m) : expf(cols_s[t * KC + cl] - m);
             cols_s[t * KC + cl] = e;
             se += e;
         }
@@ -494,8 +494,14 @@ __global__ __launch_bounds__(512, 2) void token_score_split_kernel(const float* 
     __syncthreads();
     float sw = 0.f;
     if (cval) {
+        if constexpr (FAST) {
 #pragma unroll 8
-        for (int t = t0; t < t1; ++t) sw += (cols_s[t * KC + cl] / sum) * I_s[t];
+            for (int t = t0; t < t1; ++t) sw = fmaf(cols_s[t * KC + cl], I_s[t], sw);
+            sw *= __builtin_amdgcn_rcpf(sum);
+        } else {
+#pragma unroll 8
+            for (int t = t0; t < t1; ++t) sw += (cols_s[t * KC + cl] / sum) * I_s[t];
+        }
     }
     colred[slice][cl] = sw;
     __syncthreads();
@@ -1591,16 +1597,17 @@ static int token_score_launch(const float* colsum_part, int n_row_tiles, const f
         // long sequence, small batch: G workgroups per sample (column split), so that the launch covers the chip (measured: VQA,
         // 32 samples x 901 tokens, +6.5 % on the whole forward; at 128 samples the one-workgroup kernel already fills half the
         // chip and the repeated phase A costs 2 %)
-        MADTP_ENSURE_MAX_LDS(token_score_split_kernel<8>, (size_t)MAXN * 16 * sizeof(float));
-        MADTP_ENSURE_MAX_LDS(token_score_split_kernel<4>, (size_t)MAXN * 32 * sizeof(float));
-        if (B <= 32)
-            hipLaunchKernelGGL(token_score_split_kernel<8>, dim3(8 * ((B + 7) / 8) * 8), dim3(512), (size_t)(N - 1) * 16 * sizeof(float), (hipStream_t)stream, colsum_part, n_row_tiles,
-                               p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, H, N, done_ctr, host_slot,
-                               seq, tick, part, B);
-        else
-            hipLaunchKernelGGL(token_score_split_kernel<4>, dim3(8 * ((B + 7) / 8) * 4), dim3(512), (size_t)(N - 1) * 32 * sizeof(float), (hipStream_t)stream, colsum_part, n_row_tiles,
-                               p0, onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, H, N, done_ctr, host_slot,
-                               seq, tick, part, B);
+#define TS_SPLIT_LAUNCH(G_, FAST_)                                                                                                          \
+    do {                                                                                                                                   \
+        MADTP_ENSURE_MAX_LDS((token_score_split_kernel<G_, FAST_>), (size_t)MAXN * (128 / G_) * sizeof(float));                             \
+        hipLaunchKernelGGL((token_score_split_kernel<G_, FAST_>), dim3(8 * ((B + 7) / 8) * G_), dim3(512),                                  \
+                           (size_t)(N - 1) * (128 / G_) * sizeof(float), (hipStream_t)stream, colsum_part, n_row_tiles, p0, onorm,        \
+                           token_attn, ldt, ldb, K, temperature, score, threshold, count, H, N, done_ctr, host_slot, seq, tick, part, B); \
+    } while (0)
+        const bool fast = score_fast();  // (the fast precision modes' score arithmetic, madtp_set_score_fast)
+        if (B <= 32) { if (fast) TS_SPLIT_LAUNCH(8, true); else TS_SPLIT_LAUNCH(8, false); }
+        else { if (fast) TS_SPLIT_LAUNCH(4, true); else TS_SPLIT_LAUNCH(4, false); }
+#undef TS_SPLIT_LAUNCH
     } else {
         hipLaunchKernelGGL(token_score_kernel<false>, dim3(B), dim3(512), 0, (hipStream_t)stream, colsum_part, n_row_tiles, p0,
                            onorm, token_attn, ldt, ldb, K, temperature, score, threshold, count, kmax, H, N, done_ctr, host_slot,
