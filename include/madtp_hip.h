@@ -568,7 +568,9 @@ int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, 
                         int ld_mqk, /* mask_qk: additive [N, ld_mqk] over (query, key) pairs - the decoder's causal mask - or NULL */
                         const float* dout, int ldo, const float* out,
                         int ldout, const float* dnrm_scale, const float* da, const float* dp0, float* dq, float* dk, float* dv,
-                        int ldd, void* ws, size_t ws_bytes, int B, int H, int N, float scale, void* stream);
+                        int ldd, void* ws, size_t ws_bytes,
+                        float* dp_out, /* [B,H,N,N] or NULL: the gradient of the attention probabilities (vit.py:189 register_hook) */
+                        int B, int H, int N, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -111,7 +111,7 @@ def token_score_bwd(dw, score, dst_pos, merge_w, side, token_attn, B, H, N):
     return da, dp0, dnrm, dta
 
 
-def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None, key_mask=None, mask_qk=None):
+def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None, key_mask=None, mask_qk=None, dp_out=None):
     """qkv f32 [B*N, 3*H*64] (fused projection), dout / out [B*N, H*64] -> dqkv [B*N, 3*H*64].  key_mask: additive f32 [B,N]
     over the keys (the BERT layers' padding mask) or None."""
     D = H * 64
@@ -123,7 +123,7 @@ def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None, 
     dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
     _check(lib.madtp_attention_bwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(key_mask), _p(mask_qk),
                                    mask_qk.stride(0) if mask_qk is not None else 0, _p(dout), dout.stride(0), _p(out), out.stride(0), _p(dnrm),
-                                   _p(da), _p(dp0), _p(dq), _p(dk), _p(dv), dqkv.stride(0), _p(ws), nbytes, B, H, N, float(scale),
+                                   _p(da), _p(dp0), _p(dq), _p(dk), _p(dv), dqkv.stride(0), _p(ws), nbytes, _p(dp_out), B, H, N, float(scale),
                                    _stream()), "madtp_attention_bwd")
     return dqkv
 
@@ -200,7 +200,7 @@ class _BlockParts:
                 self.norm2.bias, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias]
 
 
-def vit_block_backward(blk, x, token_attn, temperature, k, dy, mask_qk=None):
+def vit_block_backward(blk, x, token_attn, temperature, k, dy, mask_qk=None, dp_out=None):
     """Gradients of Block.forward (vit.py:183-207; clip/model.py:236-261 for CLIP's block) at (x [B,N,D], token_attn [B,N-1,K])
     for the output gradient dy [B,N',D], with the forward's pruning decision k (0 = the layer was not pruned); mask_qk: the
     additive [N,N] attention mask of CLIP's text tower or None.  Returns (dx, dtoken_attn or None, {parameter name: grad})."""
@@ -252,7 +252,7 @@ def vit_block_backward(blk, x, token_attn, temperature, k, dy, mask_qk=None):
         dxa2 = dy0
     dout = dgrad(dxa2, P.proj.weight.detach())          # x_attn = x + out Wp^T + bp
     grads[nm["proj"] + ".weight"], grads[nm["proj"] + ".bias"] = wgrad(dxa2, out), colsum(dxa2)
-    dqkv = attention_bwd(qkv, dout, out, B, H, N, scale, dnrm, da, dp0, mask_qk=mask_qk)
+    dqkv = attention_bwd(qkv, dout, out, B, H, N, scale, dnrm, da, dp0, mask_qk=mask_qk, dp_out=dp_out)
     dh1 = dgrad(dqkv, P.qkv_w.detach())
     grads[nm["qkv_w"]] = wgrad(dqkv, h1)
     if P.qkv_b is not None:
@@ -283,8 +283,16 @@ class VitBlockFunction(torch.autograd.Function):
         ta = ta if ctx.has_ta else None
         mask = getattr(ctx.blk, "_mask_dev", None) if getattr(ctx.blk, "attn_mask", None) is not None else None
         # (the full [ctx, ctx] mask: the kernels read its leading [N, N] corner through the row stride, clip/mock.py:309-310)
+        dp_out = None
+        att = getattr(ctx.blk, "attn", None)
+        if getattr(att, "_hook_attn_gradients", False):  # Block.forward(register_hook=True): vit.py:88-90, the Grad-CAM hook
+            att._hook_attn_gradients = False
+            B_, N_ = x.shape[0], x.shape[1]
+            dp_out = torch.empty((B_, att.num_heads, N_, N_), device=x.device, dtype=torch.float32)
         with torch.no_grad():
-            dx, dta, grads = vit_block_backward(ctx.blk, x, ta, ctx.temperature, ctx.k, dy, mask_qk=mask)
+            dx, dta, grads = vit_block_backward(ctx.blk, x, ta, ctx.temperature, ctx.k, dy, mask_qk=mask, dp_out=dp_out)
+        if dp_out is not None:
+            att.save_attn_gradients(dp_out)
         pg = [grads.get(name) for name in _BlockParts(ctx.blk).order()]
         if ctx.has_ta and dta is None:
             dta = torch.zeros_like(ta)
@@ -668,7 +676,7 @@ class LayerNormFunction(torch.autograd.Function):
         return dx.view_as(x), dg, db, None
 
 
-def vit_forward_with_grad(vit, img, space_dict, temperature):
+def vit_forward_with_grad(vit, img, space_dict, temperature, register_blk=-1):
     """VisionTransformer.forward (vit.py:281-310) under autograd -> (x, sd_img_ft_all); called by madtp_amd.vit when gradients
     are required in the fp32 mode."""
     from . import runtime
@@ -682,13 +690,13 @@ def vit_forward_with_grad(vit, img, space_dict, temperature):
     token_num = x.shape[-2]
     reduce_num = int((token_num - 1) // vit.depth)
     sd_all = None
-    for blk in vit.blocks:
+    for i, blk in enumerate(vit.blocks):
         if space_dict is not None:
             token_attn, sd_ft = QueryModelFunction.apply(vit.img_query_model, x, space_dict)  # :297-298
             sd_all = sd_ft if sd_all is None else sd_all + sd_ft                              # :300-303
-            x = blk(x, False, reduce_num, temperature, token_attn)  # :304 (Block.forward routes to VitBlockFunction)
+            x = blk(x, register_blk == i, reduce_num, temperature, token_attn)  # :304 (Block.forward routes to VitBlockFunction)
         else:
-            x = blk(x, False)
+            x = blk(x, register_blk == i)
     return LayerNormFunction.apply(x, vit.norm.weight, vit.norm.bias, vit.norm.eps), sd_all
 
 

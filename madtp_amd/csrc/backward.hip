@@ -285,6 +285,7 @@ struct AttnBwdArgs {
     int B, H, N; float scale;            // N = Nq (query rows per sample)
     const float* key_mask;               // [B,Nk] additive key mask (BERT padding mask, med.py:197-199) or NULL
     const float* mask_qk; int ld_mqk;    // [N, ld_mqk] additive mask over (query, key) pairs (the decoder's causal mask) or NULL
+    float* dp_out;                       // [B,H,N,Nk] or NULL: the gradient of the attention probabilities themselves (Grad-CAM hook)
     int Nk; int ldk; int lddk;           // keys per sample, leading dimension of k / v and of dk / dv (cross-attention: the keys
                                          // come from another sequence and projection; self-attention: Nk = N, ldk = ld, lddk = ldd)
 };
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdArgs a) {
             }
             Ps[r * N + j] = p;
             Ds[r * N + j] = dp;
+            if (a.dp_out && i < NQ) a.dp_out[((size_t)bh * NQ + i) * N + j] = dp;
         }
     }
     __syncthreads();
@@ -621,8 +623,8 @@ extern "C" size_t madtp_attention_bwd_workspace(int B, int H, int N) {
 extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, const float* key_mask, const float* mask_qk,
                                    int ld_mqk, const float* dout, int ldo,
                                    const float* out, int ldout, const float* dnrm_scale, const float* da, const float* dp0,
-                                   float* dq, float* dk, float* dv, int ldd, void* ws, size_t ws_bytes, int B, int H, int N,
-                                   float scale, void* stream) {
+                                   float* dq, float* dk, float* dv, int ldd, void* ws, size_t ws_bytes, float* dp_out, int B, int H,
+                                   int N, float scale, void* stream) {
     if (!q || !k || !v || !dout || !dq || !dk || !dv || !ws || B <= 0 || H <= 0 || N <= 0) return MADTP_E_BADARG;
     if (dnrm_scale && !out) return MADTP_E_BADARG;
     if (N > 1024) return MADTP_E_SHAPE;  // the row kernels keep 16 x N score rows in LDS (2 x 64 KiB at N = 1024)
@@ -631,7 +633,7 @@ extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* 
     AttnBwdArgs a;
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.dout = dout; a.ldo = ldo; a.out = out; a.ldout = ldout; a.dnrm_scale = dnrm_scale;
     a.da = da; a.dp0 = dp0; a.dq = dq; a.dk = dk; a.dv = dv; a.ldd = ldd; a.B = B; a.H = H; a.N = N; a.scale = scale;
-    a.key_mask = key_mask; a.Nk = N; a.ldk = ld; a.lddk = ldd; a.mask_qk = mask_qk; a.ld_mqk = ld_mqk;
+    a.key_mask = key_mask; a.Nk = N; a.ldk = ld; a.lddk = ldd; a.mask_qk = mask_qk; a.ld_mqk = ld_mqk; a.dp_out = dp_out;
     const size_t pn = (size_t)B * H * N * N;
     a.P = (float*)ws; a.dS = a.P + pn; a.hm = (unsigned char*)(a.dS + pn);
     hipStream_t s = (hipStream_t)stream;

@@ -9,7 +9,8 @@ Differences a caller can observe (documented in INTEGRATION.md):
   * `token_attn` is not divided by the temperature in place (vit.py:137 mutates the caller's tensor);
   * the [B,H,N,N] attention map is never materialised by the forward: get_attention_map() returns None unless
     Attention.keep_attention_map is set, in which case it is recomputed on demand (exact-f32) from the layer's input;
-    register_hook=True (gradient hooks on the map, Grad-CAM) still raises.
+    register_hook=True (gradient hooks on the map, Grad-CAM): the block's backward leaves the gradient of the attention
+    probabilities in get_attn_gradients() (fp32 mode, grad mode on).
 """
 from functools import partial
 
@@ -107,7 +108,7 @@ class Attention(nn.Module):
         self.attention_map = attention_map
 
     def get_attention_map(self):
-        if self.attention_map is None and self.keep_attention_map and self._map_input is not None:
+        if self.attention_map is None and self._map_input is not None:  # (set by keep_attention_map or register_hook=True)
             h32, B, N = self._map_input  # LayerNorm output of the last call, f32 [B*N, dim]
             with torch.no_grad():
                 qk = lin_of(self._cache, "qkv", [self.qkv], torch.float32)
@@ -214,11 +215,23 @@ class Block(nn.Module):
 
     def forward(self, x, register_hook=False, reduce_num=0, temperature=0, token_attn=None):
         require_gpu(x, "x")
-        if register_hook:
-            raise NotImplementedError("register_hook needs the materialised attention map (Grad-CAM path, out of scope)")
         x = as_f32_contig(x)
         B, N, D = x.shape
         prune = temperature > 0
+        if register_hook:
+            # vit.py:88-90 (Grad-CAM): the attention map is saved and its gradient captured.  Here: the map is recomputed on request
+            # (get_attention_map(), f32) and the block's backward leaves d loss / d attention-probabilities [B,H,N,N] in
+            # get_attn_gradients() - which needs the autograd path, i.e. grad mode on and the fp32 precision mode.
+            from .runtime import get_precision as _gp
+            if not (torch.is_grad_enabled() and _gp() == "fp32"):
+                raise NotImplementedError("register_hook=True captures attention gradients in the block's backward: it needs grad "
+                                          "mode on and runtime.precision('fp32')")
+            self.attn._hook_attn_gradients = True
+            self.attn.attention_map = None
+            self.attn._map_input = (hip.layernorm(x.detach().view(B * N, D), self.norm1.weight.detach(), self.norm1.bias.detach(),
+                                                  self.norm1.eps)[0], B, N)
+            from .backward import block_forward_with_grad
+            return block_forward_with_grad(self, x, temperature if prune else 0, token_attn)
         if prune and token_attn is None:
             raise ValueError("temperature > 0 requires token_attn (the reference fails in Reduce_token as well)")
         if self.attn.keep_attention_map:  # get_attention_map() support (see Attention.__init__)
@@ -313,12 +326,12 @@ class VisionTransformer(nn.Module):
         """_pending (extension used by BLIP_NLVR): a list - the fast-mode sum of the layers' att_ft then runs on the
         auxiliary stream and the caller makes its stream wait (handle.sync()) before sd_img_ft_all is consumed."""
         B = x.shape[0]
-        if (torch.is_grad_enabled() and register_blk == -1 and get_precision() == "fp32" and type(self) is VisionTransformer
+        if (torch.is_grad_enabled() and get_precision() == "fp32" and type(self) is VisionTransformer
                 and (any(p.requires_grad for p in self.parameters()) or (space_dict is not None and space_dict.requires_grad))):
             # training / compression use (SURVEY 8(f) rank 4): every stage of the forward as an autograd.Function around the same
             # kernels (madtp_amd/backward.py); inference callers run under torch.no_grad() as the reference's evaluate() does
             from .backward import vit_forward_with_grad
-            return vit_forward_with_grad(self, x, space_dict, temperature)
+            return vit_forward_with_grad(self, x, space_dict, temperature, register_blk)
         enc_prep = None
         if (register_blk == -1 and use_encoder_call(B * (self.patch_embed.num_patches + 1), _ENCODER_CALL)
                 and all(type(b) is Block and not b.attn.keep_attention_map for b in self.blocks)

@@ -606,3 +606,71 @@ def test_clip_vision_backward_matches_reference_grads(hip, path):
     missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]
     assert not missing, f"no gradient produced for {missing[:5]}"
     grad_case.check_against_fixture(g, grads, 1e-3, "HIP CLIP vision tower backward vs reference")
+
+
+def test_register_hook_captures_attention_gradients(hip):
+    """Block.forward(register_hook=True) (vit.py:88-90, 189: the Grad-CAM hook on the attention map): after loss.backward() the
+    block's get_attn_gradients() holds d loss / d attention-probabilities [B,H,N,N] and get_attention_map() the probabilities -
+    against torch autograd through the CPU oracle's block with the probabilities retained (pruned block: the score terms of the
+    merge weights are part of that gradient)."""
+    from madtp_amd import runtime, vit
+    from oracle import madtp_oracle as O
+    from tests import grad_case
+    g = np.load(GRAD_CASES[0])
+    c = grad_case.build(g)
+    blk = vit.Block(768, 12, qkv_bias=True, norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6))
+    blk.load_state_dict({k[len(c["prefix"]):]: v for k, v in c["W"].items() if k.startswith(c["prefix"])}, strict=True)
+    blk = blk.cuda()
+    x = c["x"].cuda().requires_grad_(True)
+    ta = c["token_attn"].cuda()
+    with runtime.precision("fp32"):
+        y = blk(x, True, 0, c["T"], ta)
+        G = grad_case.permute_G(c["G"], g["blk_idx"], blk.last_prune["indices"].cpu().numpy())
+        (y * G.cuda()).sum().backward()
+    dP, P = blk.attn.get_attn_gradients(), blk.attn.get_attention_map()
+    B, N = x.shape[0], x.shape[1]
+    assert tuple(dP.shape) == (B, 12, N, N) and tuple(P.shape) == (B, 12, N, N)
+    # reference: autograd through the oracle's block with the softmax output retained
+    kept = {}
+    orig = O.vit_attention
+
+    def tapped(W, p, xx, num_heads=12):
+        out = orig(W, p, xx, num_heads)
+        probs = [t for t in out if torch.is_tensor(t) and t.dim() == 4][0]
+        probs.retain_grad()
+        kept["P"] = probs
+        return out
+    O.vit_attention = tapped
+    try:
+        Wl = {k: v.clone().requires_grad_(True) for k, v in c["W"].items() if k.startswith(c["prefix"])}
+        xl = c["x"].clone().requires_grad_(True)
+        yo, _ = O.vit_block(Wl, c["prefix"], xl, c["T"], c["token_attn"].clone())
+        (yo * c["G"]).sum().backward()
+    finally:
+        O.vit_attention = orig
+    assert _rel(P.cpu(), kept["P"].detach()) < 1e-5
+    assert _rel(dP.cpu(), kept["P"].grad) < 1e-3
+    # outside the autograd path the hook cannot work: loud error
+    with runtime.precision("bf16"), pytest.raises(NotImplementedError):
+        blk(x.detach(), True, 0, c["T"], ta)
+
+
+def test_vit_register_blk_routes_the_hook(hip):
+    """VisionTransformer.forward(register_blk=i) (vit.py:281, 304): block i - and only block i - captures its attention gradients."""
+    from madtp_amd import runtime, specs, synth, vit as mvit
+    venc = mvit.VisionTransformer(img_size=96, patch_size=16, embed_dim=768, depth=12, num_heads=12, evaluate=True, sd_dim=768)
+    venc.load_state_dict(specs.synth_weights(specs.vit_shapes("", 96), 0), strict=True)
+    venc = venc.cuda().eval()
+    images = synth.synth_images(2, 96, 0).cuda()
+    sd = synth.synth_tensor("space_dict", (100, 768), 0).cuda().requires_grad_(True)
+    with runtime.precision("fp32"):
+        y, _ = venc(images, register_blk=2, space_dict=sd, temperature=5.0)
+        y.square().sum().backward()
+    for i, blk in enumerate(venc.blocks):
+        gA = blk.attn.get_attn_gradients()
+        if i == 2:
+            n_in = 37 if i == 0 else int(venc.blocks[i - 1].last_prune["indices"].shape[1]) + 2
+            assert gA is not None and tuple(gA.shape) == (2, 12, n_in, n_in) and torch.isfinite(gA).all() and float(gA.abs().max()) > 0
+            assert tuple(blk.attn.get_attention_map().shape) == tuple(gA.shape)
+        else:
+            assert gA is None
