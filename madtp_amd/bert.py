@@ -363,7 +363,9 @@ class _BertLayerBase(nn.Module):
         if prune and mask2d is None:
             raise ValueError("attention_mask is required when temperature > 0 (med.py:424)")
         cross = mode == 'multimodal'
-        if torch.is_grad_enabled() and get_precision() == "fp32":
+        # (a call that arrives with a pre-projected K/V cache - rank_answer / teacher-forced decoding against an EncoderKVCache -
+        #  has no encoder tokens to differentiate through: it is an inference call whatever the parameters' requires_grad says)
+        if torch.is_grad_enabled() and get_precision() == "fp32" and "_kv_pre" not in self.__dict__:
             encs = (list(encoder_hidden_states) if isinstance(encoder_hidden_states, (list, tuple)) else [encoder_hidden_states]) \
                 if (cross and encoder_hidden_states is not None) else []
             if (hidden.requires_grad or (token_attn is not None and token_attn.requires_grad) or any(e.requires_grad for e in encs)
@@ -371,7 +373,6 @@ class _BertLayerBase(nn.Module):
                 # training / compression use: the layer as an autograd.Function around the same kernels
                 # (madtp_amd/backward.py)
                 from .backward import med_layer_forward_with_grad
-                self.__dict__.pop("_kv_pre", None)
                 if cross:
                     assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
                 enc_arg = enc_masks = None

@@ -110,7 +110,8 @@ def test_f16_mode_index_match_and_logits(env, B, T):
     # (B = 4: every set identical, |dlogit| 1.5e-4; B = 8: an early flip cascades, Jaccard 0.96) - so only the logits of a run
     # whose sets all match are bounded tightly.
     assert f["vit_layerwise_jaccard"] >= 0.9995 and f["vit_layerwise_exact_match"] >= b["vit_layerwise_exact_match"]
-    assert f["mean_jaccard"] >= 0.9 and f["max_abs_dlogit"] < 4e-2
+    # |dlogit|: the measured slack (MI355X, rounds 4-5: 1.5e-4 at B = 4, <= 6e-3 at B = 8 where an early flip cascades), times two
+    assert f["mean_jaccard"] >= 0.9 and f["max_abs_dlogit"] < 1.2e-2
     if f["kept_set_exact_match"] == 1.0:
         assert f["max_abs_dlogit"] < 1e-3
 
@@ -603,6 +604,13 @@ def test_vqa_rank_answer_matches_reference_fixture(path, mode):
         again = model(images.cuda(), q, {"input_ids": a_ids.cuda(), "attention_mask": a_att.cuda()}, temperature=T, train=False,
                       inference='rank', k_test=k)
     assert torch.equal(max_ids, again)
+    if mode == "fp32":
+        # grad mode ON (a caller that forgot no_grad; parameters carry requires_grad=True by default): rank_answer runs against the
+        # cached K/V of the question states - an inference call, not the autograd route (it raised AssertionError)
+        with runtime.precision(mode):
+            with torch.no_grad():
+                qs2, _, _ = model.encode_question(images.cuda(), q, T)
+            assert torch.equal(model.rank_answer(qs2, att.cuda(), a_ids.cuda(), a_att.cuda(), k), max_ids)
     lp, ref_lp = det["log_probs_sum"].cpu().numpy(), g["log_probs_sum"]
     pf, ref_pf = det["prob_first_token"].cpu().numpy(), g["prob_first_token"]
     if mode == "bf16":
