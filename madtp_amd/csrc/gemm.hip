@@ -917,7 +917,8 @@ extern "C" int madtp_debug_read_ws_ts(long long* out) {
 #endif
 
 // gemm_pp.hip: the ping-pong 256x256 kernel lives in its own translation unit (args = const GemmArgs*)
-__attribute__((visibility("hidden"))) int madtp_gemm_pp_launch(const void* args, int out_lp, int f16, int grid, void* stream);
+__attribute__((visibility("hidden"))) int madtp_gemm_pp_launch(const void* args, int om, int mode, int rows, int grid, void* stream);
+#include "gemm_table.h"  // per-shape kernel choice of the big problems, measured (tools/gemm_autotune.py)
 
 // ---- optional HIP-event profiling of every GEMM launch (bench.py's roofline leg) -----------------------------------
 namespace {
@@ -988,7 +989,7 @@ static int gemm_force_cfg() {
     if (v < 0) {
         const char* e = getenv("MADTP_GEMM_CFG");
         v = e ? atoi(e) : 0;
-        if (v < 0 || v > 9) v = 0;
+        if (v < 0 || v > 10) v = 0;
         g_force_cfg.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -999,6 +1000,7 @@ static int gemm_force_cfg() {
 // reads half the LDS bytes per MFMA): madtp_amd/pipeline.py lowers the cost to 0.9 while its workers run - measured NLVR
 // 25.2 -> 25.7 k images/s with four in flight, but 20.1 -> 19.2 k on the serial loop, which keeps 1.7.
 static std::atomic<float> g_sq_cost{-1.f};
+static std::atomic<int> g_sq_cost_hinted{0};  // a caller's hint is in force (madtp_gemm_set_sq_cost): the measured table steps aside
 static float gemm_sq_cost() {
     float v = g_sq_cost.load(std::memory_order_relaxed);
     if (v <= 0.f) {
@@ -1032,11 +1034,12 @@ extern "C" int madtp_gemm_set_small_tile(int cfg) {
 extern "C" float madtp_gemm_set_sq_cost(float cost) {
     const float prev = gemm_sq_cost();
     g_sq_cost.store(cost > 0.f ? cost : -1.f, std::memory_order_relaxed);
+    g_sq_cost_hinted.store(cost > 0.f && cost != 1.7f ? 1 : 0, std::memory_order_relaxed);
     return prev;
 }
 extern "C" int madtp_gemm_set_config(int cfg) {
     const int prev = gemm_force_cfg();
-    g_force_cfg.store((cfg < 0 || cfg > 9) ? 0 : cfg, std::memory_order_relaxed);
+    g_force_cfg.store((cfg < 0 || cfg > 10) ? 0 : cfg, std::memory_order_relaxed);
     return prev;
 }
 
@@ -1235,30 +1238,53 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     // 256x256 kernel: bf16 operands, no split-K / pair.  Chosen when its round count times its per-tile cost (measured ~1.7x a
     // 256x128 tile) beats the wave-specialised kernel's; MADTP_GEMM_CFG=6 forces it, MADTP_GEMM_SQ=0 turns it off (A/B runs).
     bool sq_ok = false, pp_ok = false;
+    int pp_rows = 256;  // tile height of the ping-pong kernel: 256, or 192 (gemm_pp.hip FA = 3)
     SkWorkspace skw{nullptr, nullptr};
     const bool sk_on = ws_ok && !x3 && ab_dtype == MADTP_BF16 && (force_cfg == 5 || (force_cfg == 0 && sk_enabled() && K / 64 >= SK_MIN_SLABS)) &&
                        sk_workspace(s, skw);
-    if ((ab_dtype == MADTP_BF16 || f16) && splitk == 1 && !pair && (K % 64) == 0 &&
+    if (lp16 && splitk == 1 && !pair && (K % 64) == 0 &&
         ((size_t)M + 255) * (size_t)lda * 2 < ((size_t)1 << 32) && ((size_t)N + 255) * (size_t)ldw * 2 < ((size_t)1 << 32)) {
         static int sq_env = -1;
         if (sq_env < 0) { const char* e = getenv("MADTP_GEMM_SQ"); sq_env = e ? atoi(e) : 1; }
-        const int t_sq = ((M + 255) / 256) * ((N + 255) / 256);
+        const int t_sq = ((M + 255) / 256) * ((N + 255) / 256), t_192 = ((M + 191) / 192) * ((N + 255) / 256);
         // the ping-pong main loop (gemm_pp_kernel, gemm_pp.hip) needs an even slab count; MADTP_GEMM_PP=0 keeps the lockstep kernel
-        // (A/B runs), cfg 9 forces it, cfg 6 forces the lockstep kernel.  Its tile costs ~1.5 tiles of 256x128 (lockstep: 1.7) -
-        // profiles/r04_gemm_pp_ab.txt; a caller's sq_cost hint (several forwards in flight) applies to both.
+        // (A/B runs), cfg 9 forces its 256-row tile, cfg 10 its 192-row tile, cfg 6 forces the lockstep kernel.  Its tile costs
+        // ~1.5 tiles of 256x128 (lockstep: 1.7) - profiles/r04_gemm_pp_ab.txt; a caller's sq_cost hint (several forwards in flight)
+        // applies to both.  Plain f16 and f16-split operands: the 256-column tile exists as the ping-pong kernel only.
         static int pp_env = -1;
         if (pp_env < 0) { const char* e = getenv("MADTP_GEMM_PP"); pp_env = e ? atoi(e) : 1; }
         const bool pp_can = (K % 128) == 0;
-        pp_ok = pp_can && (force_cfg == 9 || (force_cfg == 0 && pp_env));
-        const bool sq_allowed = sq_env && (!f16 || pp_ok);  // plain f16 operands: the 256x256 tile exists as the ping-pong kernel only
+        pp_ok = pp_can && (force_cfg == 9 || force_cfg == 10 || (force_cfg == 0 && pp_env));
+        const bool sq_allowed = sq_env && ((!f16 && !x3) || pp_ok);
         float unit = gemm_sq_cost();
         if (pp_ok && unit > 1.5f) unit = 1.5f;
-        const float cost_sq = unit * (float)((t_sq + 255) / 256), cost_ws = ws_cost(t256, K / 64, sk_on);
-        sq_ok = (force_cfg == 6 && !f16) || (force_cfg == 9 && pp_can) || (force_cfg == 0 && sq_allowed && ws_ok && t_sq >= 100 && cost_sq < cost_ws);
+        // Choice for an automatic launch: (1) the measured table (gemm_table.h: per (operand class, N, K, output) and 64-row bucket
+        // of M the fastest of {wave-specialised 256x128, ping-pong 256x256, ping-pong 192x256} on an idle MI355X; MADTP_GEMM_TABLE=0
+        // turns it off; it steps aside while a caller's in-flight hint is in force), else (2) the round-count cost model.
+        static int tab_env = -1;
+        if (tab_env < 0) { const char* e = getenv("MADTP_GEMM_TABLE"); tab_env = e ? atoi(e) : 1; }
+        int choice = -1;  // 0 wave-specialised, 1 ping-pong / lockstep 256x256, 2 ping-pong 192x256
+        if (force_cfg == 6 && !f16 && !x3) choice = 1;
+        else if (force_cfg == 9 && pp_can) choice = 1;
+        else if (force_cfg == 10 && pp_can) choice = 2;
+        else if (force_cfg == 0 && sq_allowed && ws_ok) {
+            if (pp_ok && tab_env && (tab_env == 2 || !g_sq_cost_hinted.load(std::memory_order_relaxed)))
+                choice = gemm_table_lookup(x3, M, N, K, c_dtype == MADTP_F32);
+            if (choice < 0) {
+                const float cost_ws = ws_cost(t256, K / 64, sk_on);
+                const float cost_sq = t_sq >= 100 ? unit * (float)((t_sq + 255) / 256) : 1e9f;
+                // a 192-row tile: 3/4 of the MFMAs of a 256-row one behind the same barriers and 7/8 of its DMA stream (measured ~0.8)
+                const float cost_192 = (pp_ok && t_192 >= 100) ? 0.8f * unit * (float)((t_192 + 255) / 256) : 1e9f;
+                choice = (cost_192 < cost_sq && cost_192 < cost_ws) ? 2 : (cost_sq < cost_ws ? 1 : 0);
+            }
+        }
+        sq_ok = choice >= 1;
         pp_ok = pp_ok && sq_ok;
+        if (choice == 2) pp_rows = 192;
+        if (sq_ok && !pp_ok && (f16 || x3)) sq_ok = false;  // (no lockstep instantiation for these operand formats)
     }
     if (sq_ok) {
-        g.ntm = (M + 255) / 256;
+        g.ntm = (M + pp_rows - 1) / pp_rows;
         g.ntn = (N + 255) / 256;
         {
             // MADTP_GEMM_NGRP: column-group width of the tile order (0 = row-panel major; unset = row-panel major up to 15 column
@@ -1274,7 +1300,8 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         const int grid = 8 * (slots_max < cap ? slots_max : cap);
         const size_t lds = (size_t)2 * (256 + 256) * ROWB;
         if (pp_ok) {
-            const int rc = madtp_gemm_pp_launch(&g, c_dtype != MADTP_F32, f16 ? 1 : 0, grid, s);
+            const int om = c_dtype == MADTP_F32 ? OM_F32 : (c_dtype == MADTP_F16S ? OM_F16S : (c_dtype == MADTP_F16 ? OM_F16 : OM_BF16));
+            const int rc = madtp_gemm_pp_launch(&g, om, x3 ? 2 : (f16 ? 1 : 0), pp_rows, grid, s);
             if (rc) return rc;
         } else if (c_dtype == MADTP_BF16) {
             MADTP_ENSURE_MAX_LDS((gemm_sq_kernel<OM_BF16>), lds);

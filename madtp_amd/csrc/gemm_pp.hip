@@ -24,12 +24,25 @@
 //     next tile's first 7 half-tiles fly during the epilogue) and past the workgroup's last tile (rows beyond M read as
 //     zeros through the descriptor, nobody reads those slots).
 // K must be a multiple of 128 (an even slab count: ring slots are compile-time constants in a body of two slabs).
+//
+// Round 5, two generalisations of the same loop (the ring, the phase order and every hazard argument above are unchanged):
+//   * FA = A fragments per half of a wave's rows: 4 = the 256-row tile, 3 = a 192 x 256 tile (wave block 96 x 64, phases of 12
+//     MFMAs).  The half-tile IMAGE keeps its 128 row slots of 128 B - the wave rows' halves sit at slots 0 and 64 - and the
+//     16 (4 - FA) unused slots of each half are fetched from beyond the descriptor (zeros, no traffic): fragment addresses, ring
+//     slots, DMA instruction counts (so the counted vmcnt) are those of FA = 4.  What it buys is the round count of the
+//     N = 768 launches at 11-16 k rows (M = 12288: 144 tiles of 256 x 256 on 256 CUs -> 192 tiles of 192 x 256).
+//   * MODE 2 = f16-split operands (common.h: x = P0 + 2^-11 P1, w 2^s = Q0 + Q1): a k-slab is THREE slabs of the stream,
+//     (P0, Q1), (P0, Q0), (P1, Q0 2^-11) - plane offsets on the scalar side of the descriptor loads, Q0 2^-11 formed in registers
+//     (v_pk_mul_f16 on the 8 W fragment registers per half, behind the phase's lgkmcnt wait) - accumulated in that order into
+//     the same accumulators.  P0 and Q0 are staged twice (L2 -> LDS bytes per MFMA = the plain kernel's).
 // ABL (timing experiments only, results are wrong unless 0 or 8/16): bit 0 no steady-state LDS-DMA, bit 1 no MFMAs, bit 2 no
 // steady-state fragment reads, bit 3 the DMA issue moves from the read part to the head of the MFMA part, bit 4 no s_setprio.
-template <int OM, bool F16, int ABL = 0>
+template <int OM, int MODE, int FA = 4, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
+    static_assert(FA == 4 || FA == 3, "256- or 192-row tiles");
+    constexpr bool X3 = MODE == 2, F16 = MODE != 0;
     constexpr bool LP_OUT = OM != OM_F32;
-    constexpr int BM = 256, BN = 256, HT = 128 * ROWB;  // half-tile bytes
+    constexpr int BM = 64 * FA, BN = 256, HT = 128 * ROWB;  // half-tile bytes (128 row slots, 32 FA of them used by A halves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, gl = gridDim.x >> 3;
@@ -40,7 +53,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int nk = g.K / 64;
+    const int nkp = g.K / 64;  // k-slabs per operand plane
 
     // ---- fragment read addresses inside a half-tile image (128 rows of 128 B, 16-byte chunk index ^= key(row)) ----
     // A fragment i: row wr 64 + l16 + 16 i, key l16 & 7; W fragment jj: row rw0 + (wfrag_row(1,0) - wfrag_row(0,0)) jj.
@@ -67,6 +80,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (unsigned)((size_t)npad * g.ldw * 2), 0x00020000);
     unsigned va[2][2], vw[2][2];  // [half][q]: per-lane source byte offsets at k = 0 of the tile the stream is in
     int is_slot = lb, is_koff = 0;
+    const int plane_b = g.K * 2;                  // bytes from a row's first plane to its second (f16-split rows: [P0 | P1], [Q0 | Q1])
+    int is_s = 0;                                 // f16-split: which of the k-slab's three products the stream is in
+    int is_offa = 0, is_offw = X3 ? plane_b : 0;  // scalar byte offsets of the stream's current slab: (P0, Q1) first
     auto tile_offsets = [&]() {
         int tm, tn;
         tile_mn(g, t0 + is_slot, tm, tn);
@@ -78,35 +94,44 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         for (int q = 0; q < 2; ++q) {
             const int R = (2 * wave + q) * 8 + sub8;  // row of the half-tile image
             const unsigned ca = (unsigned)((pos ^ (R & 7)) << 4), cw = (unsigned)((pos ^ swz_key<LP_OUT>(R)) << 4);
-            const unsigned rowa = (unsigned)(tm * BM + (R >> 6) * 128 + (R & 63)), roww = (unsigned)(tn * BN + (R >> 5) * 64 + (R & 31));
-            va[0][q] = rowa * lda2 + ca;
-            va[1][q] = (rowa + 64u) * lda2 + ca;
+            const unsigned rowa = (unsigned)(tm * BM + (R >> 6) * (32 * FA) + (R & 63)), roww = (unsigned)(tn * BN + (R >> 5) * 64 + (R & 31));
+            const bool a_ok = FA == 4 || (R & 63) < 16 * FA;  // unused row slots of a 192-row tile: beyond the descriptor -> zeros
+            va[0][q] = a_ok ? rowa * lda2 + ca : 0x80000000u;
+            va[1][q] = a_ok ? (rowa + 16u * FA) * lda2 + ca : 0x80000000u;
             vw[0][q] = roww * ldw2 + cw;
             vw[1][q] = (roww + 32u) * ldw2 + cw;
         }
     };
     tile_offsets();
     bool steady = false;
-#define PP_ISSUE(RS, V, SLOT)                                                                                     \
+#define PP_ISSUE(RS, V, SLOT, OFF)                                                                                \
     if (!(ABL & 1) || !steady) {                                                                                  \
         char* d__ = smem + (SLOT) * HT + wave * 2048;                                                             \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, LDS_PTR(d__), 16, V[0], is_koff, 0, 0);                       \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, LDS_PTR(d__ + 1024), 16, V[1], is_koff, 0, 0);                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, LDS_PTR(d__), 16, V[0], OFF, 0, 0);                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, LDS_PTR(d__ + 1024), 16, V[1], OFF, 0, 0);                    \
     }
-#define PP_NEXT_SLAB()                                                  \
-    do {                                                                \
-        is_koff += ROWB;                                                \
-        if (is_koff == nk * ROWB) { is_koff = 0; is_slot += gl; tile_offsets(); } \
+#define PP_ISSUE_A(V, SLOT) PP_ISSUE(rs_a, V, SLOT, is_offa)
+#define PP_ISSUE_W(V, SLOT) PP_ISSUE(rs_w, V, SLOT, is_offw)
+    // the stream moves on to its next slab: the next k-slab - or, f16-split, the next product of this k-slab - or the next tile
+#define PP_NEXT_SLAB()                                                                         \
+    do {                                                                                       \
+        if (!X3 || ++is_s == 3) {                                                              \
+            is_s = 0;                                                                          \
+            is_koff += ROWB;                                                                   \
+            if (is_koff == nkp * ROWB) { is_koff = 0; is_slot += gl; tile_offsets(); }         \
+        }                                                                                      \
+        is_offa = is_koff + ((X3 && is_s == 2) ? plane_b : 0);                                 \
+        is_offw = is_koff + ((X3 && is_s == 0) ? plane_b : 0);                                 \
     } while (0)
 
-    f32x4 acc[8][4];
-    bf16x8 a0[4][2], a1[4][2], b0[2][2], b1[2][2];
+    f32x4 acc[2 * FA][4];
+    bf16x8 a0[FA][2], a1[FA][2], b0[2][2], b1[2][2];
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 res[1][1];
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define PP_READ_A(R, P, IDX)                                                                   \
     if (!(ABL & 4) || !steady)                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+    _Pragma("unroll") for (int i = 0; i < FA; ++i) {                                           \
         R[i][0] = *(const bf16x8*)(ab[P][0] + (IDX) * HT + i * 16 * ROWB);                     \
         R[i][1] = *(const bf16x8*)(ab[P][1] + (IDX) * HT + i * 16 * ROWB);                     \
     }
@@ -119,11 +144,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
 #define PP_MFMA(RA, RW, SA, SB)                                                                \
     if (!(ABL & 2))                                                                            \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                          \
+        _Pragma("unroll") for (int i = 0; i < FA; ++i)                                         \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                      \
-                acc[(SA) * 4 + i][(SB) * 2 + j] = mfma_16x16x32<F16>(RW[j][ks], RA[i][ks], acc[(SA) * 4 + i][(SB) * 2 + j]);
-    // one phase: READS, ISSUE run beside the other wave row's MFMAs; the MFMAs beside its reads
-#define PP_PHASE(READS, ISSUE, MFMAS)                                                          \
+                acc[(SA) * FA + i][(SB) * 2 + j] = mfma_16x16x32<F16>(RW[j][ks], RA[i][ks], acc[(SA) * FA + i][(SB) * 2 + j]);
+    // f16-split, third product of a k-slab: W fragments Q0 -> Q0 2^-11 (behind the lgkmcnt wait that completes their reads)
+#define PP_SCALE_W(R, ON)                                                                      \
+    if constexpr (X3 && (ON))                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) { R[j][0] = x3_scale_lo(R[j][0]); R[j][1] = x3_scale_lo(R[j][1]); }
+    // one phase: READS, ISSUE run beside the other wave row's MFMAs; the MFMAs (behind PRE, register-only work) beside its reads
+#define PP_PHASE(READS, ISSUE, PRE, MFMAS)                                                     \
     {                                                                                          \
         READS                                                                                  \
         PP_FENCE();                                                                            \
@@ -137,6 +166,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         PP_FENCE();                                                                            \
         __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */                                   \
         PP_FENCE();                                                                            \
+        PRE                                                                                    \
+        PP_FENCE();                                                                            \
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_setprio(1);                              \
         MFMAS                                                                                  \
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_setprio(0);                              \
@@ -146,16 +177,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
     }
     // slab of parity P: ring slots 4 P + {0: B0, 1: A0, 2: A1, 3: B1}; the stream issues B1 of the next slab, then B0, A0, A1 of
     // the slab after it (slot parity P again)
-#define PP_SLAB(P)                                                                                                          \
-    PP_PHASE(PP_READ_A(a0, P, 1), PP_ISSUE(rs_w, vw[1], 4 * ((P) ^ 1) + 3); PP_NEXT_SLAB();, PP_MFMA(a0, b0, 0, 0))          \
-    PP_PHASE(PP_READ_A(a1, P, 2), PP_ISSUE(rs_w, vw[0], 4 * (P) + 0);, PP_MFMA(a1, b0, 1, 0))                                \
-    PP_PHASE(PP_READ_W(b1, P, 3), PP_ISSUE(rs_a, va[0], 4 * (P) + 1);, PP_MFMA(a1, b1, 1, 1))                                \
-    PP_PHASE(PP_READ_W(b0, (P) ^ 1, 0), PP_ISSUE(rs_a, va[1], 4 * (P) + 2);, PP_MFMA(a0, b1, 0, 1))
+    // (SC: this slab is the third product of an f16-split k-slab - its W fragments are scaled by 2^-11 where they are first used)
+#define PP_SLAB(P, SC)                                                                                                              \
+    PP_PHASE(PP_READ_A(a0, P, 1), PP_ISSUE_W(vw[1], 4 * ((P) ^ 1) + 3); PP_NEXT_SLAB();, PP_SCALE_W(b0, SC), PP_MFMA(a0, b0, 0, 0))   \
+    PP_PHASE(PP_READ_A(a1, P, 2), PP_ISSUE_W(vw[0], 4 * (P) + 0);, , PP_MFMA(a1, b0, 1, 0))                                          \
+    PP_PHASE(PP_READ_W(b1, P, 3), PP_ISSUE_A(va[0], 4 * (P) + 1);, PP_SCALE_W(b1, SC), PP_MFMA(a1, b1, 1, 1))                        \
+    PP_PHASE(PP_READ_W(b0, (P) ^ 1, 0), PP_ISSUE_A(va[1], 4 * (P) + 2);, , PP_MFMA(a0, b1, 0, 1))
 
     // ---- prologue: half-tiles 0..6 (slab 0 whole, slab 1 without its B1), then b0 of slab 0 ----
-    PP_ISSUE(rs_w, vw[0], 0); PP_ISSUE(rs_a, va[0], 1); PP_ISSUE(rs_a, va[1], 2); PP_ISSUE(rs_w, vw[1], 3);
+    PP_ISSUE_W(vw[0], 0); PP_ISSUE_A(va[0], 1); PP_ISSUE_A(va[1], 2); PP_ISSUE_W(vw[1], 3);
     PP_NEXT_SLAB();
-    PP_ISSUE(rs_w, vw[0], 4); PP_ISSUE(rs_a, va[0], 5); PP_ISSUE(rs_a, va[1], 6);
+    PP_ISSUE_W(vw[0], 4); PP_ISSUE_A(va[0], 5); PP_ISSUE_A(va[1], 6);
     PP_FENCE();
     wait_vmcnt<10>();  // half-tiles 0 and 1 of this wave
     __builtin_amdgcn_s_barrier();
@@ -176,12 +208,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): slot 0 is re-staged from phase 1 on
         PP_FENCE();
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 2 * FA; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = zero4;
-        for (int kt = 0; kt < nk; kt += 2) {
-            PP_SLAB(0)
-            PP_SLAB(1)
+        for (int kt = 0; kt < nkp; kt += 2) {
+            if constexpr (X3) {  // two k-slabs = six slabs of the stream: (P0,Q1) (P0,Q0) (P1,Q0') (P0,Q1) (P0,Q0) (P1,Q0')
+                PP_SLAB(0, false)
+                PP_SLAB(1, false)
+                PP_SLAB(0, true)
+                PP_SLAB(1, false)
+                PP_SLAB(0, false)
+                PP_SLAB(1, true)
+            } else {
+                PP_SLAB(0, false)
+                PP_SLAB(1, false)
+            }
             steady = true;
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with the other row's last barrier
@@ -197,10 +238,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         const int l16e = lne & 15, grp4e = lne >> 4;
 #define EPI(ACT)                                                                                                  \
     if constexpr (LP_OUT) {                                                                                       \
-        epilogue<OM, ACT, false, 8, 4, 256, 128>(g, acc, res, m0, n0, wr, wc & 1, l16e, grp4e, 0);                 \
+        epilogue<OM, ACT, false, 2 * FA, 4, BM, 128>(g, acc, res, m0, n0, wr, wc & 1, l16e, grp4e, 0);             \
     } else {                                                                                                      \
-        if (g.residual) epilogue<OM, ACT, true, 8, 4, 256, 128>(g, acc, res, m0, n0, wr, wc & 1, l16e, grp4e, 0);  \
-        else epilogue<OM, ACT, false, 8, 4, 256, 128>(g, acc, res, m0, n0, wr, wc & 1, l16e, grp4e, 0);            \
+        if (g.residual) epilogue<OM, ACT, true, 2 * FA, 4, BM, 128>(g, acc, res, m0, n0, wr, wc & 1, l16e, grp4e, 0); \
+        else epilogue<OM, ACT, false, 2 * FA, 4, BM, 128>(g, acc, res, m0, n0, wr, wc & 1, l16e, grp4e, 0);        \
     }
         switch (g.act) {
             case MADTP_ACT_GELU_ERF: EPI(MADTP_ACT_GELU_ERF) break;
@@ -213,6 +254,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
     wait_vmcnt<0>();  // the run-ahead half-tiles past the last tile: land before the LDS is released
 #undef PP_SLAB
 #undef PP_PHASE
+#undef PP_SCALE_W
+#undef PP_ISSUE_A
+#undef PP_ISSUE_W
 #undef PP_MFMA
 #undef PP_READ_W
 #undef PP_READ_A
@@ -222,36 +266,45 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
 }
 
 // launcher called by gemm.hip's dispatch (args points at its GemmArgs, same definition from gemm_device.h)
-__attribute__((visibility("hidden"))) int madtp_gemm_pp_launch(const void* args, int out_lp, int f16, int grid, void* stream) {
+//   om: OM_F32 / OM_BF16 / OM_F16 / OM_F16S;  mode: 0 bf16, 1 f16, 2 f16-split operands;  rows: 256 or 192 (tile height)
+__attribute__((visibility("hidden"))) int madtp_gemm_pp_launch(const void* args, int om, int mode, int rows, int grid, void* stream) {
     const GemmArgs& g = *(const GemmArgs*)args;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)8 * 128 * ROWB;
-    static int abl = -1;  // MADTP_PP_ABLATE: timing experiments (bf16 operands and output only; see ABL above)
+    static int abl = -1;  // MADTP_PP_ABLATE: timing experiments (bf16 operands and output, 256-row tile only; see ABL above)
     if (abl < 0) { const char* e = getenv("MADTP_PP_ABLATE"); abl = e ? atoi(e) : 0; }
-#define PP_LAUNCH(OM_, F16_, ABL_)                                                                        \
-    do {                                                                                                  \
-        MADTP_ENSURE_MAX_LDS((gemm_pp_kernel<OM_, F16_, ABL_>), lds);                                      \
-        hipLaunchKernelGGL((gemm_pp_kernel<OM_, F16_, ABL_>), dim3(grid), dim3(512), lds, s, g);           \
+#define PP_LAUNCH(OM_, MODE_, FA_, ABL_)                                                                        \
+    do {                                                                                                        \
+        MADTP_ENSURE_MAX_LDS((gemm_pp_kernel<OM_, MODE_, FA_, ABL_>), lds);                                      \
+        hipLaunchKernelGGL((gemm_pp_kernel<OM_, MODE_, FA_, ABL_>), dim3(grid), dim3(512), lds, s, g);           \
     } while (0)
-    if (f16) {  // out_lp: a 2-byte output in the operands' element format
-        if (out_lp) PP_LAUNCH(OM_F16, true, 0); else PP_LAUNCH(OM_F32, true, 0);
-    } else if (out_lp) {
-        switch (abl) {
+#define PP_ROWS(OM_, MODE_)                                                                                     \
+    do { if (rows == 192) PP_LAUNCH(OM_, MODE_, 3, 0); else PP_LAUNCH(OM_, MODE_, 4, 0); } while (0)
+    if (rows != 256 && rows != 192) return MADTP_E_BADARG;
+    if (mode == 2) {
+        if (om == OM_F16S) PP_ROWS(OM_F16S, 2); else if (om == OM_F32) PP_ROWS(OM_F32, 2); else return MADTP_E_DTYPE;
+    } else if (mode == 1) {
+        if (om == OM_F16) PP_ROWS(OM_F16, 1); else if (om == OM_F32) PP_ROWS(OM_F32, 1); else return MADTP_E_DTYPE;
+    } else if (om == OM_BF16) {
+        switch (rows == 256 ? abl : 0) {
 #ifdef MADTP_PP_ABLATIONS
-            case 1: PP_LAUNCH(OM_BF16, false, 1); break;
-            case 2: PP_LAUNCH(OM_BF16, false, 2); break;
-            case 3: PP_LAUNCH(OM_BF16, false, 3); break;
-            case 4: PP_LAUNCH(OM_BF16, false, 4); break;
-            case 5: PP_LAUNCH(OM_BF16, false, 5); break;
-            case 6: PP_LAUNCH(OM_BF16, false, 6); break;
-            case 8: PP_LAUNCH(OM_BF16, false, 8); break;
-            case 16: PP_LAUNCH(OM_BF16, false, 16); break;
+            case 1: PP_LAUNCH(OM_BF16, 0, 4, 1); break;
+            case 2: PP_LAUNCH(OM_BF16, 0, 4, 2); break;
+            case 3: PP_LAUNCH(OM_BF16, 0, 4, 3); break;
+            case 4: PP_LAUNCH(OM_BF16, 0, 4, 4); break;
+            case 5: PP_LAUNCH(OM_BF16, 0, 4, 5); break;
+            case 6: PP_LAUNCH(OM_BF16, 0, 4, 6); break;
+            case 8: PP_LAUNCH(OM_BF16, 0, 4, 8); break;
+            case 16: PP_LAUNCH(OM_BF16, 0, 4, 16); break;
 #endif
-            default: PP_LAUNCH(OM_BF16, false, 0); break;
+            default: PP_ROWS(OM_BF16, 0); break;
         }
+    } else if (om == OM_F32) {
+        PP_ROWS(OM_F32, 0);
     } else {
-        PP_LAUNCH(OM_F32, false, 0);
+        return MADTP_E_DTYPE;
     }
+#undef PP_ROWS
 #undef PP_LAUNCH
     return 0;
 }

@@ -97,9 +97,10 @@ def test_gemm_wave_specialised(hip, M, N, K, cfg):
 
 @pytest.mark.parametrize("M,N,K", [(10533, 768, 768), (10533, 776, 768), (6000, 2304, 768), (10533, 768, 3072), (300, 100, 768),
                                    (25216, 3072, 768)])
-@pytest.mark.parametrize("cfg", [6, 9], ids=["lockstep", "pingpong"])
+@pytest.mark.parametrize("cfg", [6, 9, 10], ids=["lockstep", "pingpong", "pingpong192"])
 def test_gemm_256x256(hip, M, N, K, cfg):
-    """gemm_sq_kernel (256x256 tiles, forced with madtp_gemm_set_config(6)) and gemm_pp_kernel (the same tile with the
+    """(cfg 10, round 5: the ping-pong kernel on 192 x 256 tiles - gemm_pp.hip FA = 3 - same checks, ragged last 192-row tile.)
+    gemm_sq_kernel (256x256 tiles, forced with madtp_gemm_set_config(6)) and gemm_pp_kernel (the same tile with the
     two-wave-row ping-pong main loop, config 9; repeated launches must give identical bits - a race between the run-ahead
     LDS-DMA stream and the fragment reads would not): ragged last row tile, a last column tile with 8 / 4
     valid columns, N below one tile (W rows past the 128-row padding are dropped by the buffer descriptor), every epilogue and
@@ -135,11 +136,11 @@ def test_gemm_256x256(hip, M, N, K, cfg):
     with hip.gemm_config(cfg):
         sq = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
     assert (auto - sq).abs().max().item() < 1e-4 * scale
-    if cfg == 9:
+    if cfg in (9, 10):
         with hip.gemm_config(6):
             lock = hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N)
         assert torch.equal(lock, sq)  # same k order per accumulator as the lockstep kernel
-        with hip.gemm_config(9):
+        with hip.gemm_config(cfg):
             for _ in range(20):
                 assert torch.equal(hip.gemm(a, wp, bias, res, out_dtype=torch.float32, n=N), sq)
 
@@ -695,6 +696,46 @@ def test_gemm_f16x3(hip, M, N, K):
         assert (_unsplit(ylp, N) - y32.double()).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("cfg", [9, 10], ids=["pingpong", "pingpong192"])
+@pytest.mark.parametrize("M,N,K", [(10533, 768, 768), (10400, 2304, 768), (10533, 776, 3072), (12288, 3072, 768)])
+def test_gemm_f16x3_pingpong(hip, M, N, K, cfg):
+    """Round 5: f16-split operands on gemm_pp_kernel<.., MODE 2, ..> (a k-slab as three slabs of the ping-pong stream: (P0,Q1),
+    (P0,Q0), (P1,Q0 2^-11)) on both tile heights, against a float64 product of the ORIGINAL f32 operands with the exact-f32 MFMA
+    kernel as the yardstick (the criterion of test_gemm_f16x3), every epilogue incl. the split output, ragged last row / column
+    tiles, repeated launches bit-identical (a race of the run-ahead DMA stream would not be), and within f32 rounding of the
+    wave-specialised f16-split kernel."""
+    a = _rand(M, K, seed=1)
+    w = _rand(N, K, seed=2, scale=0.05)
+    ag, bg, rg = a.cuda(), _rand(N, seed=3).cuda(), _rand(M, N, seed=4).cuda()
+    ws = hip.split_f16_weight(_pad128(w).cuda())
+    asp = hip.split_f16(ag)
+    core = ag.double() @ w.cuda().double().t()
+    mag = (ag.double().abs() @ w.cuda().double().abs().t())
+    out32 = hip.gemm(ag, _pad128(w).cuda(), bg, rg, out_dtype=torch.float32, n=N)
+    ref = (core + bg.double()).float() + rg
+    e32 = ((out32 - ref).abs().double() / mag).max().item()
+    with hip.gemm_config(7):
+        ws_out = hip.gemm(asp, ws, bg, rg, out_dtype=torch.float32, n=N)
+    with hip.gemm_config(cfg):
+        out = hip.gemm(asp, ws, bg, rg, out_dtype=torch.float32, n=N)
+        e16 = ((out - ref).abs().double() / mag).max().item()
+        assert e16 < max(3.0 * e32, 3e-7), (e16, e32)
+        assert ((out - ws_out).abs().double() / mag).max().item() < 3e-7
+        for _ in range(10):
+            assert torch.equal(hip.gemm(asp, ws, bg, rg, out_dtype=torch.float32, n=N), out)
+        o = hip.gemm(asp, ws, bg, None, out_dtype=torch.float32, act=hip.ACT_GELU, n=N, out_scale=0.5)
+        r = (F.gelu(core + bg.double()) * 0.5).float()
+        assert ((o - r).abs().double() / mag.clamp_min(1.0)).max().item() < 1e-6
+        if N % 8 == 0:
+            o = hip.gemm(asp, ws, bg, None, out_dtype=torch.float16, act=hip.ACT_GELU, n=N)
+            assert o.shape == (M, 2 * N)
+            r = F.gelu(core + bg.double())
+            assert ((_unsplit(o, N) - r).abs() / mag.clamp_min(1.0)).max().item() < 1e-6
+            with hip.gemm_config(7):
+                assert ((_unsplit(hip.gemm(asp, ws, bg, None, out_dtype=torch.float16, act=hip.ACT_GELU, n=N), N) - _unsplit(o, N)).abs()
+                        / mag.clamp_min(1.0)).max().item() < 3e-7
+
+
 def test_gemm_pair_f16x3(hip):
     M, N, K = 5043, 1536, 768
     a0, a1 = hip.split_f16(_rand(M, K, seed=1).cuda()), hip.split_f16(_rand(M, K, seed=2).cuda())
@@ -944,6 +985,15 @@ def test_gemm_f16_operands(hip, M, N, K):
         assert (hip.lp_to_f32(out) - ref).abs().max().item() < 1.5e-3 * scale
         out = hip.gemm(ad, wd, None, out_dtype=torch.bfloat16, n=N)
         assert (hip.lp_to_f32(out) - core.float()).abs().max().item() < 1e-3 * scale
+        if M >= 4096:  # every big-tile kernel family on f16 operands: wave-specialised, ping-pong 256x256, ping-pong 192x256
+            auto = hip.gemm(ad, wd, bias, res, out_dtype=torch.float32, n=N)
+            for cfg in (7, 9, 10):
+                with hip.gemm_config(cfg):
+                    o = hip.gemm(ad, wd, bias, res, out_dtype=torch.float32, n=N)
+                    assert (o - ((core + bias.double()).float() + res)).abs().max().item() < 1e-4 * scale, cfg
+                    assert (o - auto).abs().max().item() < 1e-4 * scale
+                    o = hip.gemm(ad, wd, bias, out_dtype=torch.bfloat16, act=hip.ACT_GELU, n=N)
+                    assert (hip.lp_to_f32(o) - ref).abs().max().item() < 1.5e-3 * scale, cfg
     # the same problem in the bf16 mode is 8x coarser: the f16 operands carry three more significand bits
     with runtime.precision("bf16"):
         ob = hip.gemm(hip.cast_bf16(a), hip.cast_lp_weight(_pad128(w).cuda()), None, out_dtype=torch.float32, n=N)

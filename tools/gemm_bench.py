@@ -18,7 +18,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "small":
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
 print("dtype", dt, "MADTP_GEMM_DEBUG", os.environ.get("MADTP_GEMM_DEBUG"), "CFG", os.environ.get("MADTP_GEMM_CFG"))
 if len(sys.argv) > 2 and sys.argv[2] == "ab":  # 256x128 wave-specialised (cfg 5) vs 256x256 (cfg 6) vs automatic on the forward's ViT shapes
-    rows = [25216, 17152, 14208, 12288, 11776, 11136, 10752, 10496]
+    rows = [25216, 17152, 14336, 12416, 12288, 11776, 11136, 10752, 10496]  # the headline forward's row counts (128 images x tokens per layer) + 12288
     if len(sys.argv) > 3 and sys.argv[3] == 'small_tiles': rows = [17152, 12288, 10752, 10496]
     for M in rows:
         for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
@@ -27,7 +27,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "ab":  # 256x128 wave-specialised (cfg 5
             kw = dict(residual=res, out_dtype=torch.float32) if N == 768 else (dict(act=hip.ACT_GELU) if N == 3072 else {})
             out = torch.empty(M, N, device="cuda", dtype=kw.get("out_dtype", dt))
             line = f"M={M:6d} N={N:5d} K={K:5d}"
-            for cfg in ((7, 1, 2, 3, 0) if (len(sys.argv) > 3 and sys.argv[3] == 'small_tiles') else (7, 6, 9, 0)):  # 9: 256x256 ping-pong; 7: wave-specialised, 16x16x32 MFMA; 8: wave-specialised, 32x32x16 MFMA; 6: 256x256; 0: automatic (5 = 7 + stream-K tail)
+            for cfg in ((7, 1, 2, 3, 0) if (len(sys.argv) > 3 and sys.argv[3] == "small_tiles") else (7, 9, 10, 0)):  # 9: 256x256 ping-pong; 7: wave-specialised, 16x16x32 MFMA; 8: wave-specialised, 32x32x16 MFMA; 6: 256x256; 0: automatic (5 = 7 + stream-K tail)
                 with hip.gemm_config(cfg):
                     for _ in range(3): hip.gemm(a, w, bias, n=N, out=out, **kw)
                     torch.cuda.synchronize()
