@@ -1181,7 +1181,13 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     // the 4480 x 768 GEMMs of a 128-pair re-ranking batch (108 tiles), which run better on 420 64x128 tiles.
     int cfg = 0;
     const int t256 = ((M + 255) / 256) * ((N + 127) / 128);
-    const bool big = M >= 4096 && t256 >= 200;
+    // Thresholds of the big-tile kernels (persistent 256-row tiles): M >= 4096 and most of the chip covered - what a lone launch
+    // wants (latency).  MADTP_GEMM_BIG_MIN_M / _TILES lower them (experiments with several forwards in flight, where a launch's
+    // CU time counts and a 1280-row problem on 45 efficient tiles costs a third of the CU time of 720 small ones).
+    static int big_min_m = -1, big_min_t = -1;
+    if (big_min_m < 0) { const char* e = getenv("MADTP_GEMM_BIG_MIN_M"); big_min_m = e ? atoi(e) : 4096; if (big_min_m < 256) big_min_m = 256; }
+    if (big_min_t < 0) { const char* e = getenv("MADTP_GEMM_BIG_MIN_TILES"); big_min_t = e ? atoi(e) : 200; if (big_min_t < 1) big_min_t = 1; }
+    const bool big = !m_dev.p && M >= big_min_m && t256 >= big_min_t;
     const bool lp16 = ab_dtype != MADTP_F32;  // 2-byte operand planes: bf16, or f16-split (three times the slab stream)
     if (lp16 && !big) {
         const int t64 = ((M + 63) / 64) * ((N + 63) / 64) * splitk, t64x128 = ((M + 63) / 64) * ((N + 127) / 128) * splitk;
@@ -1195,11 +1201,11 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     }
     // MADTP_GEMM_CFG=5 forces the wave-specialised kernel, 1..4 force a gemm_kernel variant (A/B measurements)
     bool ws_ok = lp16 && splitk == 1 &&
-                 (force_cfg == 5 || force_cfg == 7 || force_cfg == 8 || (force_cfg == 0 && M >= 4096 && (big || auto_cfg == 0)));
+                 (force_cfg == 5 || force_cfg == 7 || force_cfg == 8 || (force_cfg == 0 && !m_dev.p && M >= big_min_m && (big || (auto_cfg == 0 && M >= 4096))));
     if (pair) {
         static int pair_env = -1;  // MADTP_GEMM_PAIR=0: always two launches (A/B runs)
         if (pair_env < 0) { const char* e = getenv("MADTP_GEMM_PAIR"); pair_env = e ? atoi(e) : 1; }
-        ws_ok = pair_env && lp16 && force_cfg == 0 && M >= 4096 && 2 * t256 >= 200 && g.fast_epi &&
+        ws_ok = pair_env && lp16 && force_cfg == 0 && M >= big_min_m && 2 * t256 >= big_min_t && g.fast_epi &&
                 aligned16(pair->A) && aligned16(pair->W) && aligned16(pair->C) && (!pair->bias || aligned16(pair->bias));
         if (!ws_ok) return PAIR_UNSUPPORTED;
         g.pair = 1; g.A2 = (const char*)pair->A; g.W2 = (const char*)pair->W; g.bias2 = pair->bias; g.C2 = pair->C;
@@ -1209,7 +1215,10 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     hipStream_t s = (hipStream_t)stream;
     GemmRecord rec;
     if (g_prof_on) {
-        (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
+        // timing-only events: no system-scope fence when they complete (hipEventDisableSystemFence: "can improve the accuracy of timing
+        // measurements by avoiding the cost of cache writeback and invalidation, and the performance impact of those actions on the
+        // execution of following work") - the un-instrumented forward has no such fences between its kernels either
+        (void)hipEventCreateWithFlags(&rec.e0, hipEventDisableSystemFence); (void)hipEventCreateWithFlags(&rec.e1, hipEventDisableSystemFence);
         rec.flops = 2.0 * M * N * K; rec.dt = ab_dtype; rec.M = M; rec.N = N; rec.K = K;
         // algorithmic HBM bytes: A and W once, C once (x splits), bias, residual once
         rec.bytes = (double)esz * (x3 ? 2.0 : 1.0) * ((double)M * K + (double)N * K) + (double)M * N * ((c_dtype == MADTP_BF16 || c_dtype == MADTP_F16) ? 2 : 4) * splitk +
@@ -1272,9 +1281,9 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
                 choice = gemm_table_lookup(x3, M, N, K, c_dtype == MADTP_F32);
             if (choice < 0) {
                 const float cost_ws = ws_cost(t256, K / 64, sk_on);
-                const float cost_sq = t_sq >= 100 ? unit * (float)((t_sq + 255) / 256) : 1e9f;
+                const float cost_sq = 2 * t_sq >= big_min_t ? unit * (float)((t_sq + 255) / 256) : 1e9f;
                 // a 192-row tile: 3/4 of the MFMAs of a 256-row one behind the same barriers and 7/8 of its DMA stream (measured ~0.8)
-                const float cost_192 = (pp_ok && t_192 >= 100) ? 0.8f * unit * (float)((t_192 + 255) / 256) : 1e9f;
+                const float cost_192 = (pp_ok && 2 * t_192 >= big_min_t) ? 0.8f * unit * (float)((t_192 + 255) / 256) : 1e9f;
                 choice = (cost_192 < cost_sq && cost_192 < cost_ws) ? 2 : (cost_sq < cost_ws ? 1 : 0);
             }
         }
