@@ -971,7 +971,10 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
 // A larger cap gives every workgroup fewer tiles (>= tiles / 8: one tile each) - the launch then frees CUs tile by tile, which
 // lets the small kernels of ANOTHER stream in between (madtp_amd/pipeline.py) at the price of the cross-tile pipelining.
 static std::atomic<int> g_wg_per_xcd{-1};
+static thread_local int t_wg_cap = 0;  // per-thread override for the launches of one library call (madtp_internal_gemm_wg_cap)
+int madtp_internal_gemm_wg_cap(int cap) { const int prev = t_wg_cap; t_wg_cap = cap > 0 ? cap : 0; return prev; }
 static int gemm_wg_per_xcd() {
+    if (t_wg_cap > 0) return t_wg_cap;
     int v = g_wg_per_xcd.load(std::memory_order_relaxed);
     if (v < 0) {
         const char* e = getenv("MADTP_GEMM_WG_PER_XCD");
@@ -1211,6 +1214,9 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         g.pair = 1; g.A2 = (const char*)pair->A; g.W2 = (const char*)pair->W; g.bias2 = pair->bias; g.C2 = pair->C;
     }
     if (force_cfg > 0 && force_cfg <= 4) cfg = force_cfg - 1;
+    // (round 5, measured and dropped: "deep ring" variants of the small tiles - 64x64 x 6 stages / 64x128 x 5, one workgroup per CU,
+    //  five / four slabs in flight - are no faster on the text encoder's 1280-row problems (768x768: 11.7 vs 11.8 us, and 24 vs 13.5 us
+    //  where the tiles need three rounds): their ~10 us are launch ramp, first-touch latency and drain, not the K loop)
     if (x3 && cfg == 0) cfg = 1;  // f16-split: 64x128 tiles (the 128x128 variant would spill the kept P0 fragments)
     hipStream_t s = (hipStream_t)stream;
     GemmRecord rec;
@@ -1244,6 +1250,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         else if (cfg == 2) MADTP_LAUNCH_GEMM(TT, LP, 64, 128, 3, 2);           \
         else MADTP_LAUNCH_GEMM(TT, LP, 64, 64, 3, 3);                          \
     } while (0)
+
     // 256x256 kernel: bf16 operands, no split-K / pair.  Chosen when its round count times its per-tile cost (measured ~1.7x a
     // 256x128 tile) beats the wave-specialised kernel's; MADTP_GEMM_CFG=6 forces it, MADTP_GEMM_SQ=0 turns it off (A/B runs).
     bool sq_ok = false, pp_ok = false;

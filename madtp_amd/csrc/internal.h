@@ -29,3 +29,7 @@ MADTP_INTERNAL int madtp_i_token_gather_ln_dev(const float* x, const int32_t* ds
                                                int lp_dtype, const int32_t* dims_l, void* stream);
 MADTP_INTERNAL int madtp_i_align_logits(const float* x, const void* sd_hi, const void* sd_lo, float* out, int M, int dim, int split_dtype,
                                         float out_scale, DevN m_dev, void* stream);
+// Workgroups per XCD of the big-GEMM kernels for the following launches of THIS thread (0 = the process-wide setting); returns the
+// previous value.  The encoder call's side-stream K/V projections run on part of the chip so that the latency-bound text kernels
+// of the main stream keep finding free CUs.
+MADTP_INTERNAL int madtp_internal_gemm_wg_cap(int cap);

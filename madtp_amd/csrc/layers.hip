@@ -6,6 +6,9 @@
 // k = max_b count between the two halves (vit.py:145 `.item()`).
 #include "common.h"
 #include "internal.h"
+#include <stdlib.h>
+#include <map>
+#include <mutex>
 
 namespace {
 
@@ -664,6 +667,58 @@ extern "C" int madtp_vit_encoder_async(const madtp_vit_block_w* const* layers, i
     return (rf && *(const volatile int*)rf) ? MADTP_E_RANGE : 0;
 }
 
+// ---- cross-attention K/V of the image tokens on a SIDE stream (round 5) ------------------------------------------------------
+// The twin cross-attention layers project the two images' tokens to [k|v] with one pair GEMM per layer (12 x ~31 us at the
+// headline batch: the only chip-filling launches of the text encoder, whose other ~150 kernels are latency-bound chains on 1280
+// rows).  Those projections depend on the vision encoder's output only, so the encoder-level call enqueues all of them on a side
+// stream of its own (one per (device, caller stream); event-ordered behind the caller's stream on entry, one completion event
+// per layer) into a library-owned buffer, and layer l of the caller's stream waits for event l and reads its K/V from there
+// (the kv_pre path of madtp_bert_layer: same kernel, same operands, same bits).
+// OFF by default (MADTP_KV_SIDE=1 turns it on): measured at the headline batch (profiles/r05_kv_side_ab.txt, same box, two rounds)
+// the serial forward gains 2 % with the side GEMMs on half the chip (19.05 -> 19.43 k images/s; nothing with a chip-filling side
+// GEMM - the persistent 256-row tiles leave the text kernels no CU to start on - and the per-layer Python path is still ahead at
+// 19.68 k), while four forwards in flight LOSE 4 % (26.3 -> 25.1 k: eight streams contend kernel by kernel).
+namespace {
+constexpr int KV_SIDE_MAX_LAYERS = 32;
+struct KvSide {
+    hipStream_t side = nullptr;
+    hipEvent_t ready = nullptr, done[KV_SIDE_MAX_LAYERS] = {};
+    char* buf = nullptr;
+    size_t cap = 0;
+};
+std::mutex g_kv_side_mu;
+std::map<std::pair<int, hipStream_t>, KvSide> g_kv_side;
+
+bool kv_side_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MADTP_KV_SIDE"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
+// -> nullptr when the side resources cannot be had (the caller falls back to the in-layer projections)
+KvSide* kv_side_get(hipStream_t main, size_t bytes, int n_layers) {
+    int dev = 0;
+    if (n_layers > KV_SIDE_MAX_LAYERS || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_kv_side_mu);
+    KvSide& k = g_kv_side[{dev, main}];
+    if (!k.side) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&k.side, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); k.side = nullptr; return nullptr; }
+        bool ok = hipEventCreateWithFlags(&k.ready, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < KV_SIDE_MAX_LAYERS; ++i) ok = hipEventCreateWithFlags(&k.done[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); return nullptr; }
+    }
+    if (k.cap < bytes) {
+        // grow-only; the old buffer may still be read by kernels in flight on the caller's stream: free it behind them
+        if (k.buf) { (void)hipStreamSynchronize(main); (void)hipStreamSynchronize(k.side); (void)hipFree(k.buf); k.buf = nullptr; k.cap = 0; }
+        if (hipMalloc((void**)&k.buf, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        k.cap = bytes;
+    }
+    return &k;
+}
+}  // namespace
+
 extern "C" int madtp_bert_encoder(const madtp_bert_layer_w* const* layers, int n_layers, const madtp_query_w* q, const float* hidden0,
                                   const void* hidden0_lp, const float* mask0, madtp_layer_io* io, void* ws, size_t ws_bytes, int B,
                                   int L0, int Nk, float temperature, int cross_mode, const void* enc0, const void* enc1,
@@ -676,6 +731,42 @@ extern "C" int madtp_bert_encoder(const madtp_bert_layer_w* const* layers, int n
     int L = L0;
     const bool prune = q && temperature > 0.f;
     const int kp = q ? (q->K + 127) / 128 * 128 : 0;
+    // twin cross-attention without a caller-side K/V cache: all layers' [k|v] projections of the image tokens go to the side stream
+    KvSide* side = nullptr;
+    size_t kv_bytes = 0;
+    if (cross_mode && enc0 && enc1 && !kv_pre0 && !kv_pre1 && Nk > 0 && kv_side_enabled()) {
+        bool twin = true;
+        for (int l = 0; l < n_layers && twin; ++l) {
+            const madtp_bert_layer_w* w = layers[l];
+            twin = w && w->cross == 2 && w->fused_twin && w->ckv[0].n == w->ckv[1].n && w->ckv[0].k == w->ckv[1].k &&
+                   w->ckv[0].n == 2 * w->dim && w->dtype == layers[0]->dtype && w->dim == layers[0]->dim;
+        }
+        if (twin) {
+            const int D = layers[0]->dim, dt = layers[0]->dtype, adt = attn_dt(dt);
+            kv_bytes = (((size_t)B * Nk * 2 * D * esz_of(adt)) + 255) & ~(size_t)255;
+            side = kv_side_get((hipStream_t)stream, 2 * kv_bytes * n_layers, n_layers);
+            if (side) {
+                hipError_t he = hipEventRecord(side->ready, (hipStream_t)stream);  // enc0 / enc1 (and the previous call's readers) are behind it
+                if (he == hipSuccess) he = hipStreamWaitEvent(side->side, side->ready, 0);
+                if (he != hipSuccess) return (int)he;
+                // the projections are off the critical path (layer l needs its pair ~150 l us into the encoder): they run on HALF the
+                // CUs (MADTP_KV_SIDE_CAP workgroups per XCD, default 16) - a chip-filling persistent GEMM would leave the main
+                // stream's small kernels no CU to start on for its whole duration
+                static int side_cap = -1;
+                if (side_cap < 0) { const char* e = getenv("MADTP_KV_SIDE_CAP"); side_cap = e ? atoi(e) : 16; if (side_cap < 1 || side_cap > 32) side_cap = 16; }
+                struct CapGuard { int prev; explicit CapGuard(int c) : prev(madtp_internal_gemm_wg_cap(c)) {} ~CapGuard() { madtp_internal_gemm_wg_cap(prev); } } cap_guard(side_cap);
+                for (int l = 0; l < n_layers; ++l) {
+                    const madtp_bert_layer_w* w = layers[l];
+                    char* k0 = side->buf + (size_t)(2 * l) * kv_bytes;
+                    TRY(madtp_gemm_pair(enc0, enc1, w->ckv[0].w, w->ckv[1].w, w->ckv[0].b, w->ckv[1].b, k0, k0 + kv_bytes, B * Nk,
+                                        w->ckv[0].n, w->ckv[0].k, pld(dt, D), (dt == MADTP_F16S ? 2 : 1) * w->ckv[0].k, 2 * D, dt, adt,
+                                        w->ckv[0].w_scale, w->ckv[1].w_scale, side->side));
+                    he = hipEventRecord(side->done[l], side->side);
+                    if (he != hipSuccess) return (int)he;
+                }
+            }
+        }
+    }
     for (int l = 0; l < n_layers; ++l) {
         madtp_layer_io& o = io[l];
         const madtp_bert_layer_w* w = layers[l];
@@ -687,6 +778,14 @@ extern "C" int madtp_bert_encoder(const madtp_bert_layer_w* const* layers, int n
         int k_out = 0, k_used = 0;
         const void* kv0 = kv_pre0 ? kv_pre0[l] : nullptr;
         const void* kv1 = kv_pre1 ? kv_pre1[l] : nullptr;
+        if (side) {
+            // (the wait sits in front of the layer's first kernel: only layer 0 can actually stall on it - the side stream is
+            //  ~380 us of GEMM in all, layer l starts ~150 l us into the encoder)
+            const hipError_t he = hipStreamWaitEvent((hipStream_t)stream, side->done[l], 0);
+            if (he != hipSuccess) return (int)he;
+            kv0 = side->buf + (size_t)(2 * l) * kv_bytes;
+            kv1 = (const char*)kv0 + kv_bytes;
+        }
         if (prune)
             TRY(madtp_bert_layer(w, h, mask, o.x_attn, o.y, o.mask_out, ws, ws_bytes, B, L, Nk, o.logits + kp, kp, L * kp, q->K,
                                  temperature, o.score, o.threshold, o.count, o.indices, o.indices_sort, cross_mode, enc0, enc1,

@@ -83,6 +83,26 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     const int b = blockIdx.x, n = N - 1;
     const float* ta_g = ta + (size_t)b * ldb;  // row t <-> patch token t
     TS_MARK(0);
+    // The attention-side operands of this thread's tokens (column-mass partials, CLS attention, context norms: <= 48 values per
+    // token) are requested BEFORE the logits are staged, so that their latency runs under the staging loads instead of after the
+    // row maxima (short sequences; the long-sequence form below loads in batches where it uses them).
+    constexpr int HMAX = 16, RMAX = 16;
+    const bool pre = H <= HMAX && nrt <= RMAX;
+    float on_pre[2][HMAX], pz_pre[2][HMAX], cs_pre[2][RMAX];
+    if (pre) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = min(tid + u * 512, n - 1);  // clamped: straight-line loads, the surplus lanes' values are never used
+#pragma unroll
+            for (int h = 0; h < HMAX; ++h) {
+                const size_t o = ((size_t)b * H + min(h, H - 1)) * N + t + 1;
+                on_pre[u][h] = onorm[o];
+                pz_pre[u][h] = p0[o];
+            }
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) cs_pre[u][r] = colsum[((size_t)b * nrt + min(r, nrt - 1)) * N + t + 1];
+        }
+    }
     if constexpr (STAGED) {
         const int k4 = K >> 2;  // K % 4 == 0 on this path
         for (int idx = tid; idx < n * k4; idx += 512) {
@@ -124,7 +144,6 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     // a = column mass of head-max attention (vit.py:126-127), c = head-diversity weighted CLS attention (vit.py:96-101)
     // All global operands of a token are requested before any is used (fully unrolled, predicated loads: the head and
     // row-tile counts are small): one memory latency instead of one per group of four.
-    constexpr int HMAX = 16, RMAX = 16;
     float a_loc[2], c_loc[2], suma_l = 0.f, sumt_l = 0.f;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -132,22 +151,13 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
         a_loc[u] = 0.f; c_loc[u] = 0.f;
         if (t < n) {
             float a = 0.f, hs = 0.f, c = 0.f;
-            if (H <= HMAX && nrt <= RMAX) {
-                float on[HMAX], pz[HMAX], cs[RMAX];
+            if (pre) {  // (the same sums in the same order as before the loads moved up)
 #pragma unroll
-                for (int h = 0; h < HMAX; ++h) {
-                    const size_t o = ((size_t)b * H + h) * N + t + 1;
-                    on[h] = h < H ? onorm[o] : 0.f;
-                    pz[h] = h < H ? p0[o] : 0.f;
-                }
+                for (int r = 0; r < RMAX; ++r) if (r < nrt) a += cs_pre[u][r];
 #pragma unroll
-                for (int r = 0; r < RMAX; ++r) cs[r] = r < nrt ? colsum[((size_t)b * nrt + r) * N + t + 1] : 0.f;
+                for (int h = 0; h < HMAX; ++h) if (h < H) hs += on_pre[u][h];
 #pragma unroll
-                for (int r = 0; r < RMAX; ++r) if (r < nrt) a += cs[r];
-#pragma unroll
-                for (int h = 0; h < HMAX; ++h) if (h < H) hs += on[h];
-#pragma unroll
-                for (int h = 0; h < HMAX; ++h) if (h < H) c += pz[h] * (on[h] / (hs + 1e-8f));
+                for (int h = 0; h < HMAX; ++h) if (h < H) c += pz_pre[u][h] * (on_pre[u][h] / (hs + 1e-8f));
             } else {
                 // long sequences (nrt = 38..57 row tiles at 605..901 tokens): the same sums in the same order, with the loads of
                 // sixteen row tiles requested before the first add (one load per dependent add was ~60 L2 round trips per token)
@@ -208,10 +218,41 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     //  repeated by the next one)
     float m = -INFINITY;
     const float c2 = 1.44269504088896341f / temperature;  // FAST: logits in log2 units
+    if constexpr (FAST && STAGED) {
+        // fast modes: TWO passes over the staged column and no stores - the maximum of the raw logits (a positive scale commutes
+        // with max), then exp2(fma(x, c2, -c2 max)), its sum and its I-weighted sum together (sw / sum = the softmax-weighted score)
+        if (cval) {
+#pragma unroll 8
+            for (int t = t0; t < t1; ++t) m = fmaxf(m, ta_s[t * K + col]);
+        }
+        colred[slice][col] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(colred[0][col], colred[1][col]), fmaxf(colred[2][col], colred[3][col]));
+        const float off = -m * c2;
+        float se_f = 0.f, sw_f = 0.f;
+        if (cval) {
+#pragma unroll 8
+            for (int t = t0; t < t1; ++t) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(ta_s[t * K + col], c2, off));
+                se_f += e;
+                sw_f = fmaf(e, I_s[t], sw_f);
+            }
+        }
+        __syncthreads();
+        colred[slice][col] = se_f;
+        tw_s[slice * 128 + col] = sw_f;  // (tw_s is free from here on: 4 x 128 partial weighted sums)
+        __syncthreads();
+        if (tid < 128) {
+            const float sum = ((colred[0][col] + colred[1][col]) + colred[2][col]) + colred[3][col];
+            const float sw = ((tw_s[col] + tw_s[128 + col]) + tw_s[256 + col]) + tw_s[384 + col];
+            colstat[tid] = cval ? sw * __builtin_amdgcn_rcpf(sum) : INFINITY;
+        }
+        __syncthreads();
+    } else {
     if (cval) {
 #pragma unroll 8
         for (int t = t0; t < t1; ++t) {
-            const float v = (FAST && STAGED) ? TA(t, col) * c2 : TA(t, col) / temperature;
+            const float v = TA(t, col) / temperature;
             if constexpr (STAGED) ta_s[t * K + col] = v;
             m = fmaxf(m, v);
         }
@@ -225,8 +266,7 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
 #pragma unroll 8
         for (int t = t0; t < t1; ++t) {
             float e;
-            if constexpr (FAST && STAGED) { e = __builtin_amdgcn_exp2f(ta_s[t * K + col] - m); ta_s[t * K + col] = e; }
-            else if constexpr (STAGED) { e = expf(ta_s[t * K + col] - m); ta_s[t * K + col] = e; }
+            if constexpr (STAGED) { e = expf(ta_s[t * K + col] - m); ta_s[t * K + col] = e; }
             else e = expf(TA(t, col) / temperature - m);
             se += e;
         }
@@ -237,22 +277,17 @@ __global__ __launch_bounds__(512) void token_score_kernel(const float* __restric
     __syncthreads();
     float sw = 0.f;
     if (cval) {
-        if constexpr (FAST && STAGED) {
 #pragma unroll 8
-            for (int t = t0; t < t1; ++t) sw = fmaf(ta_s[t * K + col], I_s[t], sw);
-            sw *= __builtin_amdgcn_rcpf(sum);
-        } else {
-#pragma unroll 8
-            for (int t = t0; t < t1; ++t) {
-                const float e = STAGED ? ta_s[t * K + col] : expf(TA(t, col) / temperature - m);
-                sw += (e / sum) * I_s[t];
-            }
+        for (int t = t0; t < t1; ++t) {
+            const float e = STAGED ? ta_s[t * K + col] : expf(TA(t, col) / temperature - m);
+            sw += (e / sum) * I_s[t];
         }
     }
     colred[slice][col] = sw;
     __syncthreads();
     if (tid < 128) colstat[tid] = cval ? ((colred[0][col] + colred[1][col]) + colred[2][col]) + colred[3][col] : INFINITY;
     __syncthreads();
+    }
     TS_MARK(5);
     // threshold = min over columns (vit.py:141)
     float thr = INFINITY;
