@@ -472,6 +472,22 @@ int madtp_bert_encoder(const madtp_bert_layer_w* const* layers, int n_layers, co
                        const float* enc_mask1, const void* const* kv_pre0, const void* const* kv_pre1, const int32_t* kv_index,
                        int kv_ld, void* stream);
 
+/* The same loop WITHOUT the per-layer host read of k (device-side lengths for the text encoders -
+ * models/med.py:369, models/nlvr_encoder.py:432 `topk_num = torch.max(idx.sum(dim=1)).item()`).  As in madtp_vit_encoder_async the
+ * layer's decision stays in a device-side record and every later kernel reads its size from it - including the compaction of
+ * the additive padding mask (med.py:388-390 / nlvr_encoder.py:451-452) and the query count of the cross-attention; grids and
+ * buffers are the unpruned sequence's; ONE host read of the records at the end (io[l].k_out / k_used / n_out).  Linear +
+ * LayerNorm pairs run without split-K (whose factor depends on a row count the host does not know), so the summation order
+ * differs from madtp_bert_encoder's: f32-accurate, pinned against the reference fixtures.  Takes text mode, MED single
+ * cross-attention and the NLVR twin cross-attention (fused or separate projections); B * L0 < 4096 rows, L0 <= 256, Nk <= 256
+ * (MADTP_E_SHAPE otherwise); q, mask0 and temperature > 0 are required, q->att_ft must be NULL; io[l].mask_out is written by
+ * every layer; dims_dev: (n_layers + 2) * 4 int32 of device scratch, dims_host: (n_layers + 1) * 4 int32 of host memory. */
+int madtp_bert_encoder_async(const madtp_bert_layer_w* const* layers, int n_layers, const madtp_query_w* q, const float* hidden0,
+                             const void* hidden0_lp, const float* mask0, madtp_layer_io* io, void* ws, size_t ws_bytes, int B, int L0,
+                             int Nk, float temperature, int cross_mode, const void* enc0, const void* enc1, const float* enc_mask0,
+                             const float* enc_mask1, const void* const* kv_pre0, const void* const* kv_pre1, const int32_t* kv_index,
+                             int kv_ld, int32_t* dims_dev, int32_t* dims_host, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Answer ranking with the teacher-forced decoder (inference half): models/med.py BertLMHeadModel
  * :1036-1042 and models/blip_vqa.py rank_answer :166-172.  The decoder itself is madtp_bert_layer with self_mask_qk set, the

@@ -638,8 +638,12 @@ class _BertEncoderBase(nn.Module):
                 if tns.stride(-1) != 1 or (kv_ld and kv_ld != tns.stride(0)):
                     raise RuntimeError("encoder_kv_cache tensors must be row-major with one common row stride")
                 kv_ld = tns.stride(0)
+        # device-side lengths (madtp_bert_encoder_async, opt-in with the ViT's: MADTP_ENCODER_SYNC_FREE=1): no host read of k
+        # between the layers; shapes it takes: hip.bert_encoder_sync_free_ok
+        from . import vit as _vit
+        sync_free = _vit._SYNC_FREE and query and t > 0 and hip.bert_encoder_sync_free_ok(B, L, Nk, True, qargs, mask2d)
         run = hip.bert_encoder(ws, hidden, lp[0] if lp else None, mask2d, qargs, t, cross, enc0, enc1, Nk, em0, em1,
-                               kv_pre0=kv0, kv_pre1=kv1, kv_index=kv_index, kv_ld=kv_ld)
+                               kv_pre0=kv0, kv_pre1=kv1, kv_index=kv_index, kv_ld=kv_ld, sync_free=sync_free)
         for l, layer in enumerate(self.layer):
             layer.last_prune = run.info(l, t if query else 0)
             layer.__dict__.pop("_kv_pre", None)

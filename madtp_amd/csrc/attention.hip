@@ -42,10 +42,12 @@ struct AttnArgs {
     // sync-free encoder path (self-attention): Nq = Nk = *n_dev tokens per sample, read by the kernel; the launch geometry and the
     // key-tile instantiation are the host's worst case (the unpruned sequence)
     const int32_t* n_dev;
+    int dev_q_only;  // cross-attention on the sync-free path: *n_dev is the number of QUERY tokens per sample, Nk stays the host's
 };
 #define ATTN_DEV_DIMS(a)                                   \
     if ((a).n_dev) {                                       \
-        (a).Nq = (a).Nk = *(a).n_dev;                      \
+        (a).Nq = *(a).n_dev;                               \
+        if (!(a).dev_q_only) (a).Nk = (a).Nq;              \
         (a).nrt = ((a).Nq + 15) / 16;                      \
     }
 
@@ -1951,7 +1953,7 @@ extern "C" int madtp_attention(const void* q, const void* k, const void* v, void
 static int attention_launch(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
                             const float* add_mask, const float* mask_qk, int ld_mask_qk, float* colsum_part, float* p0,
                             float* onorm, int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale,
-                            int io_dtype, void* stream, const int32_t* n_dev = nullptr);
+                            int io_dtype, void* stream, const int32_t* n_dev = nullptr, int dev_q_only = 0);
 
 int madtp_i_attention(const void* q, const void* k, const void* v, void* out, float* colsum_part, float* p0, float* onorm, int B,
                       int H, int N, int ldq, int ldk, int ldv, int ldo, float scale, int io_dtype, const int32_t* n_dev,
@@ -1959,6 +1961,22 @@ int madtp_i_attention(const void* q, const void* k, const void* v, void* out, fl
     if (N > 256) return MADTP_E_SHAPE;  // the two-pass long-sequence kernels keep host-side lengths
     return attention_launch(q, k, v, nullptr, out, nullptr, nullptr, 0, colsum_part, p0, onorm, B, H, N, N, ldq, ldk, ldv, ldo, scale,
                             io_dtype, stream, n_dev);
+}
+// the same with an additive key mask [B, n] (rows of the DEVICE length: the text encoders' compacted padding mask)
+int madtp_i_attention_mask(const void* q, const void* k, const void* v, void* out, const float* add_mask, float* colsum_part, float* p0,
+                           float* onorm, int B, int H, int N, int ldq, int ldk, int ldv, int ldo, float scale, int io_dtype,
+                           const int32_t* n_dev, void* stream) {
+    if (N > 256) return MADTP_E_SHAPE;
+    return attention_launch(q, k, v, nullptr, out, add_mask, nullptr, 0, colsum_part, p0, onorm, B, H, N, N, ldq, ldk, ldv, ldo, scale,
+                            io_dtype, stream, n_dev);
+}
+// cross-attention with *nq_dev query tokens per sample against Nk (host-side) keys of another sequence, optional K/V batch index
+int madtp_i_attention_cross(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out, const float* add_mask,
+                            int B, int H, int Nq_max, int Nk, int ldq, int ldk, int ldv, int ldo, float scale, int io_dtype,
+                            const int32_t* nq_dev, void* stream) {
+    if (Nk > 256 || Nq_max > 256) return MADTP_E_SHAPE;
+    return attention_launch(q, k, v, kv_batch_index, out, add_mask, nullptr, 0, nullptr, nullptr, nullptr, B, H, Nq_max, Nk, ldq, ldk,
+                            ldv, ldo, scale, io_dtype, stream, nq_dev, 1);
 }
 
 extern "C" int madtp_attention_indexed(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
@@ -1981,7 +1999,7 @@ extern "C" int madtp_attention_qk_mask(const void* q, const void* k, const void*
 static int attention_launch(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
                             const float* add_mask, const float* mask_qk, int ld_mask_qk, float* colsum_part, float* p0,
                             float* onorm, int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale,
-                            int io_dtype, void* stream, const int32_t* n_dev) {
+                            int io_dtype, void* stream, const int32_t* n_dev, int dev_q_only) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
     if (kv_batch_index && colsum_part) return MADTP_E_BADARG;  // indexed K/V is a cross-attention feature
     // io_dtype MADTP_F16S: f32 storage, products as three f16 MFMA products of f16-split operands (the f16x3 precision mode)
@@ -2008,7 +2026,7 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
     a.kvidx = kv_batch_index;
     a.pair = 0; a.q2 = a.k2 = a.v2 = nullptr; a.out2 = nullptr; a.mask2 = nullptr; a.hm_ws = nullptr; a.hm_tick = nullptr;
     a.mask_qk = mask_qk; a.ld_mqk = ld_mask_qk;
-    a.n_dev = n_dev;
+    a.n_dev = n_dev; a.dev_q_only = dev_q_only;
     hipStream_t s = (hipStream_t)stream;
     const bool scores = colsum_part != nullptr;
     if (Nk > 256) {  // long sequences (384^2 / 480^2 images): two-pass kernels
@@ -2042,6 +2060,15 @@ extern "C" int madtp_attention_pair(const void* q0, const void* q1, const void* 
                                     const int32_t* kv_batch_index, void* out0, void* out1, const float* add_mask0,
                                     const float* add_mask1, int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo,
                                     float scale, int io_dtype, void* stream) {
+    return madtp_i_attention_pair(q0, q1, k0, k1, v0, v1, kv_batch_index, out0, out1, add_mask0, add_mask1, B, H, Nq, Nk, ldq, ldk, ldv,
+                                  ldo, scale, io_dtype, nullptr, stream);
+}
+// nq_dev != NULL: the sync-free text encoder - *nq_dev query tokens per sample (Nq is the worst case), <= 256 keys
+int madtp_i_attention_pair(const void* q0, const void* q1, const void* k0, const void* k1, const void* v0, const void* v1,
+                           const int32_t* kv_batch_index, void* out0, void* out1, const float* add_mask0, const float* add_mask1, int B,
+                           int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale, int io_dtype, const int32_t* nq_dev,
+                           void* stream) {
+    if (nq_dev && (Nk > 256 || Nq > 256)) return MADTP_E_SHAPE;
     if (!q0 || !q1 || !k0 || !k1 || !v0 || !v1 || !out0 || !out1 || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
     static int pair_env = -1;  // MADTP_ATTN_PAIR=0: always two launches (A/B runs)
     if (pair_env < 0) { const char* e = getenv("MADTP_ATTN_PAIR"); pair_env = e ? atoi(e) : 1; }
@@ -2049,17 +2076,17 @@ extern "C" int madtp_attention_pair(const void* q0, const void* q1, const void* 
                      aligned16(q1) && aligned16(k0) && aligned16(k1) && aligned16(v0) && aligned16(v1) && (ldq * 2) % 16 == 0 &&
                      (ldk * 2) % 16 == 0 && (ldv * 2) % 16 == 0;
     if (!one) {
-        const int rc = madtp_attention_indexed(q0, k0, v0, kv_batch_index, out0, add_mask0, nullptr, nullptr, nullptr, B, H, Nq,
-                                               Nk, ldq, ldk, ldv, ldo, scale, io_dtype, stream);
+        const int rc = attention_launch(q0, k0, v0, kv_batch_index, out0, add_mask0, nullptr, 0, nullptr, nullptr, nullptr, B, H, Nq, Nk,
+                                        ldq, ldk, ldv, ldo, scale, io_dtype, stream, nq_dev, nq_dev ? 1 : 0);
         if (rc) return rc;
-        return madtp_attention_indexed(q1, k1, v1, kv_batch_index, out1, add_mask1, nullptr, nullptr, nullptr, B, H, Nq, Nk, ldq,
-                                       ldk, ldv, ldo, scale, io_dtype, stream);
+        return attention_launch(q1, k1, v1, kv_batch_index, out1, add_mask1, nullptr, 0, nullptr, nullptr, nullptr, B, H, Nq, Nk, ldq, ldk,
+                                ldv, ldo, scale, io_dtype, stream, nq_dev, nq_dev ? 1 : 0);
     }
     AttnArgs a;
     a.q = (const char*)q0; a.k = (const char*)k0; a.v = (const char*)v0; a.out = (char*)out0; a.mask = add_mask0;
     a.q2 = (const char*)q1; a.k2 = (const char*)k1; a.v2 = (const char*)v1; a.out2 = (char*)out1; a.mask2 = add_mask1;
     a.pair = 1;
-    a.mask_qk = nullptr; a.ld_mqk = 0; a.hm_ws = nullptr; a.hm_tick = nullptr; a.n_dev = nullptr;
+    a.mask_qk = nullptr; a.ld_mqk = 0; a.hm_ws = nullptr; a.hm_tick = nullptr; a.n_dev = nq_dev; a.dev_q_only = 1;
     a.colsum = nullptr; a.p0 = nullptr; a.onorm = nullptr;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.nrt = (Nq + 15) / 16;

@@ -33,3 +33,18 @@ MADTP_INTERNAL int madtp_i_align_logits(const float* x, const void* sd_hi, const
 // previous value.  The encoder call's side-stream K/V projections run on part of the chip so that the latency-bound text kernels
 // of the main stream keep finding free CUs.
 MADTP_INTERNAL int madtp_internal_gemm_wg_cap(int cap);
+// ---- device-side lengths for the text encoders (madtp_bert_encoder_async) ----
+MADTP_INTERNAL int madtp_i_cast_lp(const float* src, void* dst, size_t n, int lp_dtype, float scale, DevN n_dev, void* stream);
+MADTP_INTERNAL int madtp_i_attention_mask(const void* q, const void* k, const void* v, void* out, const float* add_mask, float* colsum_part,
+                                          float* p0, float* onorm, int B, int H, int N, int ldq, int ldk, int ldv, int ldo, float scale,
+                                          int io_dtype, const int32_t* n_dev, void* stream);
+MADTP_INTERNAL int madtp_i_attention_cross(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
+                                           const float* add_mask, int B, int H, int Nq_max, int Nk, int ldq, int ldk, int ldv, int ldo,
+                                           float scale, int io_dtype, const int32_t* nq_dev, void* stream);
+MADTP_INTERNAL int madtp_i_attention_pair(const void* q0, const void* q1, const void* k0, const void* k1, const void* v0, const void* v1,
+                                          const int32_t* kv_batch_index, void* out0, void* out1, const float* add_mask0,
+                                          const float* add_mask1, int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo,
+                                          float scale, int io_dtype, const int32_t* nq_dev, void* stream);
+// additive-mask compaction with N, k from dims_l (k == 0: copy); MED: indices then the (k+1)-th of indices_sort, NLVR: indices_sort
+MADTP_INTERNAL int madtp_i_mask_gather_dev(const float* mask, const int64_t* indices, const int64_t* indices_sort, int variant_nlvr,
+                                           float* out, int B, const int32_t* dims_l, void* stream);

@@ -667,6 +667,221 @@ extern "C" int madtp_vit_encoder_async(const madtp_vit_block_w* const* layers, i
     return (rf && *(const volatile int*)rf) ? MADTP_E_RANGE : 0;
 }
 
+// BertEncoder.forward's layer loop WITHOUT the per-layer host read of k (the text side of
+// madtp_vit_encoder_async).  Same device-side record per layer (dims[l] = {L_l, k, k applied under med.py:374-375, L_{l+1}}, written by
+// token_score's last workgroup); every later kernel of the stream reads its size from it: the output projection + LayerNorm, top-k
+// select, the gather (a copy when the layer is not pruned), the compaction of the additive padding mask (med.py:388-390 /
+// nlvr_encoder.py:451-452), the compute-dtype copy, the cross-attention q projection and the attention's QUERY count (keys are the
+// image tokens: host-side), the FFN GEMMs and LayerNorms, and the next layer's alignment logits / qkv GEMM / masked self-attention.
+// Grids and buffers are the unpruned sequence's.  Linear + LayerNorm pairs run as GEMM (f32, residual in the epilogue) + LayerNorm:
+// the split-K factor of the host path depends on the row count, which the host does not know here - so this path has its own
+// (equally f32-accurate) summation order and is pinned against the reference fixtures, not bit-for-bit against the host-k path.
+// Takes: text mode, MED single cross-attention, NLVR twin cross-attention; B * L0 < 4096 rows, L0 <= 256, <= 256 keys.
+static int to_lp_dev(const float* src, void* dst, int rows_max, int dim, int dt, DevN rows, void* stream) {
+    if (dt == MADTP_F16S) return madtp_i_split_f16(src, dim, dst, 2 * dim, rows_max, dim, rows, stream);
+    return madtp_i_cast_lp(src, dst, (size_t)rows_max * dim, dt, 1.0f, DevN{rows.p, rows.mul * dim, 0}, stream);
+}
+// y = LayerNorm(scale * (a @ W^T + b) + residual) with M = m rows: f32 GEMM into `part`, then the row kernel
+static int lin_ln_dev(const void* a, int lda, const madtp_lin& L, const float* residual, float scale, const float* gamma, const float* beta,
+                      float* y32, void* ylp, int M_max, int dt, float eps, float* part, DevN m, void* stream) {
+    TRY(madtp_i_gemm(a, L.w, L.b, residual, part, M_max, L.n, L.k, pld(dt, lda), (dt == MADTP_F16S ? 2 : 1) * L.k, L.n, L.n, dt, MADTP_F32,
+                     MADTP_ACT_NONE, L.w_scale, scale, m, stream));
+    return madtp_i_layernorm(part, gamma, beta, y32, ylp, dt == MADTP_F32 ? MADTP_BF16 : dt, M_max, L.n, eps, m, stream);
+}
+
+extern "C" int madtp_bert_encoder_async(const madtp_bert_layer_w* const* layers, int n_layers, const madtp_query_w* q, const float* hidden0,
+                                        const void* hidden0_lp, const float* mask0, madtp_layer_io* io, void* ws, size_t ws_bytes, int B,
+                                        int L0, int Nk, float temperature, int cross_mode, const void* enc0, const void* enc1,
+                                        const float* enc_mask0, const float* enc_mask1, const void* const* kv_pre0,
+                                        const void* const* kv_pre1, const int32_t* kv_index, int kv_ld, int32_t* dims_dev,
+                                        int32_t* dims_host, void* stream) {
+    if (!layers || !io || !hidden0 || !q || !mask0 || !dims_dev || !dims_host || n_layers <= 0 || B <= 0 || L0 < 3) return MADTP_E_BADARG;
+    if (!(temperature > 0.f) || q->att_ft) return MADTP_E_BADARG;  // (att_ft: the caller's deferred sum, after this call)
+    if ((long)B * L0 >= 4096 || L0 > 256 || (cross_mode && Nk > 256)) return MADTP_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nrec = (size_t)(n_layers + 1) * DIMS_STRIDE;
+    int32_t* ticket = dims_dev + nrec;
+    hipError_t he = hipMemsetAsync(dims_dev, 0, (nrec + 4) * sizeof(int32_t), s);
+    if (he == hipSuccess) he = hipMemsetD32Async((hipDeviceptr_t)dims_dev, L0, 1, s);
+    if (he != hipSuccess) return (int)he;
+    const int kp = (q->K + 127) / 128 * 128;
+    const bool split = q->sd_hi && q->sd_lo;
+    if (split && kp != 128) return MADTP_E_SHAPE;
+    const float* h = hidden0;
+    const void* h_lp = hidden0_lp;
+    const float* mask = mask0;
+    const int Mmax = B * L0;
+    for (int l = 0; l < n_layers; ++l) {
+        madtp_layer_io& o = io[l];
+        const madtp_bert_layer_w* w = layers[l];
+        if (!w || !o.x_attn || !o.y || !o.logits || !o.score || !o.threshold || !o.count || !o.indices || !o.indices_sort || !o.mask_out)
+            return MADTP_E_BADARG;
+        if (w->self_mask_qk) return MADTP_E_SHAPE;  // decoder layers keep the per-layer path
+        const int cross = (cross_mode && w->cross) ? w->cross : 0;
+        bool ok;
+        BertWs v = bert_carve((char*)ws, ws_bytes, B, L0, Nk, w->dim, w->inter.n, w->heads, w->dtype, &ok);
+        if (!ok) return MADTP_E_SHAPE;
+        const int D = w->dim, dt = w->dtype, adt = attn_dt(dt);
+        const size_t e = esz_of(adt);
+        const bool lpm = dt != MADTP_F32;
+        if (lpm && !o.y_lp) return MADTP_E_BADARG;
+        int32_t* dl = dims_dev + (size_t)l * DIMS_STRIDE;
+        const DevN m_in{dl, B, 0}, m_out{dl + DIMS_STRIDE, B, 0};
+        // query model on all rows of the hidden states (med.py:513-524, models/utils.py:170)
+        if (split) TRY(madtp_i_align_logits(h, q->sd_hi, q->sd_lo, o.logits, Mmax, D, q->split_dtype, q->sd_scale, m_in, stream));
+        else TRY(madtp_i_gemm(h, q->sd_w, nullptr, nullptr, o.logits, Mmax, kp, D, D, D, kp, 0, MADTP_F32, MADTP_F32, MADTP_ACT_NONE, 1.f,
+                              1.f, m_in, stream));
+        // ---- self-attention half (bert_attn_impl) ----
+        const void* hc = h;
+        if (lpm) {
+            if (h_lp) hc = h_lp;
+            else { TRY(to_lp_dev(h, v.hc, Mmax, D, dt, m_in, stream)); hc = v.hc; }
+        }
+        TRY(lin_dev(hc, D, w->qkv, nullptr, 0, v.qkv, 3 * D, Mmax, dt, adt, MADTP_ACT_NONE, m_in, stream));
+        const char* qp = (const char*)v.qkv;
+        TRY(madtp_i_attention_mask(qp, qp + (size_t)D * e, qp + (size_t)2 * D * e, v.ctx, mask, v.colsum, v.p0, v.onorm, B, w->heads, L0,
+                                   3 * D, 3 * D, 3 * D, D, w->scale, attn_io(dt), dl, stream));
+        const void* ctx = v.ctx;
+        if (dt == MADTP_F16S) {
+            TRY(madtp_i_split_f16((const float*)v.ctx, D, v.q, 2 * D, Mmax, D, m_in, stream));
+            ctx = v.q;
+        }
+        TRY(madtp_i_token_score_dev(v.colsum, v.p0, v.onorm, o.logits, kp, q->K, temperature, o.score, o.threshold, o.count, B, w->heads,
+                                    L0, dl, ticket, stream));
+        // att = LayerNorm(dense(ctx) + hidden): still L_l tokens per sample
+        TRY(lin_ln_dev(ctx, D, w->attn_out, h, 1.f, w->ln_att_g, w->ln_att_b, o.x_attn, nullptr, Mmax, dt, w->eps, v.part, m_in, stream));
+        // ---- pruning of att and of the mask (bert_rest_impl); an unpruned layer copies both ----
+        TRY(madtp_i_token_select_dev(o.score, o.indices, o.indices_sort, v.dst_pos, v.merge_w, B, L0 - 1, dl, stream));
+        TRY(madtp_i_token_gather_ln_dev(o.x_attn, v.dst_pos, v.merge_w, v.xp, B, L0, D, nullptr, nullptr, 0.f, nullptr, nullptr, MADTP_BF16,
+                                        dl, stream));
+        TRY(madtp_i_mask_gather_dev(mask, o.indices, o.indices_sort, w->variant_nlvr, o.mask_out, B, dl, stream));
+        const float* a32 = v.xp;
+        const void* ac = a32;
+        if (lpm) { TRY(to_lp_dev(a32, v.attc, Mmax, D, dt, m_out, stream)); ac = v.attc; }
+        // ---- cross-attention to the image tokens ----
+        if (cross == 2 && !w->fused_twin) {
+            // twin branches with separate projections (the parity modes' layers >= 6: merge_layer is not folded into the dense
+            // weights there) - the per-branch sequence of bert_rest_impl with device-side row counts
+            void* cbuf[2] = {v.c0, v.c1};
+            for (int br = 0; br < 2; ++br) {
+                const void* enc = br ? enc1 : enc0;
+                const void* const* pre = br ? kv_pre1 : kv_pre0;
+                const float* em = w->variant_nlvr ? (br ? enc_mask1 : enc_mask0) : nullptr;
+                TRY(lin_dev(ac, D, w->cq[br], nullptr, 0, v.q, D, Mmax, dt, adt, MADTP_ACT_NONE, m_out, stream));
+                const void* kv = pre ? pre[l] : nullptr;
+                int ldkv = 2 * D;
+                if (!kv) {
+                    if (!enc) return MADTP_E_BADARG;
+                    TRY(lin(enc, D, w->ckv[br], nullptr, 0, v.kv, 2 * D, B * Nk, dt, adt, MADTP_ACT_NONE, 1.f, stream));
+                    kv = v.kv;
+                } else if (kv_ld) ldkv = kv_ld;
+                TRY(madtp_i_attention_cross(v.q, kv, (const char*)kv + (size_t)D * e, (pre && pre[l]) ? kv_index : nullptr, cbuf[br], em, B,
+                                            w->heads, L0, Nk, D, ldkv, ldkv, D, w->scale, attn_io(dt), dl + DIMS_STRIDE, stream));
+                if (dt == MADTP_F16S) {
+                    if (w->inter.n < 2 * D) return MADTP_E_SHAPE;
+                    void* sp = (char*)v.mid + (size_t)br * Mmax * D * esz_of(dt);
+                    TRY(madtp_i_split_f16((const float*)cbuf[br], D, sp, 2 * D, Mmax, D, m_out, stream));
+                    cbuf[br] = sp;
+                }
+            }
+            if (w->has_merge) {  // nlvr_encoder.py:263-264
+                const int cdt = dt == MADTP_F16S ? MADTP_F32 : dt;
+                char* cat = (char*)v.cat;
+                TRY(lin_dev(cbuf[0], D, w->cdense[0], nullptr, 0, cat, 2 * D, Mmax, dt, cdt, MADTP_ACT_NONE, m_out, stream));
+                TRY(lin_dev(cbuf[1], D, w->cdense[1], nullptr, 0, cat + (size_t)D * esz_of(cdt), 2 * D, Mmax, dt, cdt, MADTP_ACT_NONE, m_out, stream));
+                const void* catc = v.cat;
+                if (dt == MADTP_F16S) {
+                    TRY(madtp_i_split_f16((const float*)v.cat, 2 * D, v.mid, 4 * D, Mmax, 2 * D, m_out, stream));
+                    catc = v.mid;
+                }
+                TRY(lin_dev(catc, 2 * D, w->merge, a32, D, v.s, D, Mmax, dt, MADTP_F32, MADTP_ACT_NONE, m_out, stream));
+            } else {  // :266 (h0 + h1) / 2 folded into the epilogues
+                TRY(madtp_i_gemm(cbuf[0], w->cdense[0].w, w->cdense[0].b, a32, v.t, Mmax, D, w->cdense[0].k, pld(dt, D),
+                                 (dt == MADTP_F16S ? 2 : 1) * w->cdense[0].k, D, D, dt, MADTP_F32, MADTP_ACT_NONE, w->cdense[0].w_scale, 0.5f,
+                                 m_out, stream));
+                TRY(madtp_i_gemm(cbuf[1], w->cdense[1].w, w->cdense[1].b, v.t, v.s, Mmax, D, w->cdense[1].k, pld(dt, D),
+                                 (dt == MADTP_F16S ? 2 : 1) * w->cdense[1].k, D, D, dt, MADTP_F32, MADTP_ACT_NONE, w->cdense[1].w_scale, 0.5f,
+                                 m_out, stream));
+            }
+            TRY(madtp_i_layernorm(v.s, w->ln_cross_g, w->ln_cross_b, v.att2, lpm ? v.attc : nullptr, dt == MADTP_F32 ? MADTP_BF16 : dt, Mmax,
+                                  D, w->eps, m_out, stream));
+            a32 = v.att2;
+            ac = lpm ? (const void*)v.attc : (const void*)v.att2;
+        } else if (cross == 2) {
+            TRY(lin_dev(ac, D, w->cq_fused, nullptr, 0, v.q2, 2 * D, Mmax, dt, adt, MADTP_ACT_NONE, m_out, stream));
+            const void* k0 = kv_pre0 ? kv_pre0[l] : nullptr;
+            const void* k1 = kv_pre1 ? kv_pre1[l] : nullptr;
+            if ((!k0) != (!k1) || (!k0 && (!enc0 || !enc1))) return MADTP_E_BADARG;
+            int ldkv = 2 * D;
+            if (!k0) {
+                if (w->ckv[0].n == w->ckv[1].n && w->ckv[0].k == w->ckv[1].k)
+                    TRY(madtp_gemm_pair(enc0, enc1, w->ckv[0].w, w->ckv[1].w, w->ckv[0].b, w->ckv[1].b, v.kv, v.kv1, B * Nk, w->ckv[0].n,
+                                        w->ckv[0].k, pld(dt, D), (dt == MADTP_F16S ? 2 : 1) * w->ckv[0].k, 2 * D, dt, adt, w->ckv[0].w_scale,
+                                        w->ckv[1].w_scale, stream));
+                else {
+                    TRY(lin(enc0, D, w->ckv[0], nullptr, 0, v.kv, 2 * D, B * Nk, dt, adt, MADTP_ACT_NONE, 1.f, stream));
+                    TRY(lin(enc1, D, w->ckv[1], nullptr, 0, v.kv1, 2 * D, B * Nk, dt, adt, MADTP_ACT_NONE, 1.f, stream));
+                }
+                k0 = v.kv; k1 = v.kv1;
+            } else if (kv_ld) ldkv = kv_ld;
+            const float* em0 = w->variant_nlvr ? enc_mask0 : nullptr;
+            const float* em1 = w->variant_nlvr ? enc_mask1 : nullptr;
+            TRY(madtp_i_attention_pair(v.q2, (const char*)v.q2 + (size_t)D * e, k0, k1, (const char*)k0 + (size_t)D * e,
+                                       (const char*)k1 + (size_t)D * e, (kv_pre0 && kv_pre0[l]) ? kv_index : nullptr, v.cat,
+                                       (char*)v.cat + (size_t)D * e, em0, em1, B, w->heads, L0, Nk, 2 * D, ldkv, ldkv, 2 * D, w->scale,
+                                       attn_io(dt), dl + DIMS_STRIDE, stream));
+            const void* catc = v.cat;
+            if (dt == MADTP_F16S) {
+                TRY(madtp_i_split_f16((const float*)v.cat, 2 * D, v.mid, 4 * D, Mmax, 2 * D, m_out, stream));
+                catc = v.mid;
+            }
+            TRY(lin_ln_dev(catc, 2 * D, w->cdense_fused, a32, w->fused_twin == 2 ? 1.f : 0.5f, w->ln_cross_g, w->ln_cross_b, v.att2,
+                           lpm ? v.attc : nullptr, Mmax, dt, w->eps, v.part, m_out, stream));
+            a32 = v.att2;
+            ac = lpm ? (const void*)v.attc : (const void*)v.att2;
+        } else if (cross == 1) {
+            TRY(lin_dev(ac, D, w->cq[0], nullptr, 0, v.q, D, Mmax, dt, adt, MADTP_ACT_NONE, m_out, stream));
+            const void* k0 = kv_pre0 ? kv_pre0[l] : nullptr;
+            int ldkv = 2 * D;
+            if (!k0) {
+                if (!enc0) return MADTP_E_BADARG;
+                TRY(lin(enc0, D, w->ckv[0], nullptr, 0, v.kv, 2 * D, B * Nk, dt, adt, MADTP_ACT_NONE, 1.f, stream));
+                k0 = v.kv;
+            } else if (kv_ld) ldkv = kv_ld;
+            // (med.py:197-199 drops the encoder mask in cross-attention; nlvr_encoder.py:196-198 applies it)
+            TRY(madtp_i_attention_cross(v.q, k0, (const char*)k0 + (size_t)D * e, (kv_pre0 && kv_pre0[l]) ? kv_index : nullptr, v.c0,
+                                        w->variant_nlvr ? enc_mask0 : nullptr, B, w->heads, L0, Nk, D, ldkv, ldkv, D, w->scale, attn_io(dt),
+                                        dl + DIMS_STRIDE, stream));
+            const void* cc = v.c0;
+            if (dt == MADTP_F16S) {
+                TRY(madtp_i_split_f16((const float*)v.c0, D, v.mid, 2 * D, Mmax, D, m_out, stream));
+                cc = v.mid;
+            }
+            TRY(lin_ln_dev(cc, D, w->cdense[0], a32, 1.f, w->ln_cross_g, w->ln_cross_b, v.att2, lpm ? v.attc : nullptr, Mmax, dt, w->eps,
+                           v.part, m_out, stream));
+            a32 = v.att2;
+            ac = lpm ? (const void*)v.attc : (const void*)v.att2;
+        }
+        // ---- FFN ----
+        TRY(lin_dev(ac, D, w->inter, nullptr, 0, v.mid, w->inter.n, Mmax, dt, dt, MADTP_ACT_GELU_ERF, m_out, stream));
+        TRY(lin_ln_dev(v.mid, w->inter.n, w->out, a32, 1.f, w->ln_out_g, w->ln_out_b, o.y, lpm ? o.y_lp : nullptr, Mmax, dt, w->eps, v.part,
+                       m_out, stream));
+        h = o.y;
+        h_lp = lpm ? o.y_lp : nullptr;
+        mask = o.mask_out;
+    }
+    he = hipMemcpyAsync(dims_host, dims_dev, nrec * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (he == hipSuccess) he = hipStreamSynchronize(s);
+    if (he != hipSuccess) return (int)he;
+    for (int l = 0; l < n_layers; ++l) {
+        io[l].k_out = dims_host[l * DIMS_STRIDE + 1];
+        io[l].k_used = dims_host[l * DIMS_STRIDE + 2];
+        io[l].n_out = dims_host[l * DIMS_STRIDE + 3];
+    }
+    const int* rf = madtp_internal_range_flag();
+    return (rf && *(const volatile int*)rf) ? MADTP_E_RANGE : 0;
+}
+
 // ---- cross-attention K/V of the image tokens on a SIDE stream (round 5) ------------------------------------------------------
 // The twin cross-attention layers project the two images' tokens to [k|v] with one pair GEMM per layer (12 x ~31 us at the
 // headline batch: the only chip-filling launches of the text encoder, whose other ~150 kernels are latency-bound chains on 1280

@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 // f32 -> 2-byte elements (bf16 or plain f16) of src * scale
 template <bool F16>
 __global__ __launch_bounds__(256) void cast_lp_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n, float scale,
-                                                      int* range_flag) {
+                                                      int* range_flag, DevN n_dev = DevN{nullptr, 0, 0}) {
+    if (n_dev.p) n = (size_t)devn(n_dev, 0);  // sync-free encoder path: the element count comes from the layer's device-side record
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     if (i + 3 < n) {
@@ -322,13 +323,16 @@ extern "C" int madtp_add_scale(const float* a, const float* b, float* out, float
 }
 
 extern "C" int madtp_cast_lp(const float* src, void* dst, size_t n, int lp_dtype, float scale, void* stream) {
+    return madtp_i_cast_lp(src, dst, n, lp_dtype, scale, DevN{nullptr, 0, 0}, stream);
+}
+int madtp_i_cast_lp(const float* src, void* dst, size_t n, int lp_dtype, float scale, DevN n_dev, void* stream) {
     if (!src || !dst || n == 0) return MADTP_E_BADARG;
     if (!aligned16(src) || (((uintptr_t)dst) & 7u)) return MADTP_E_ALIGN;
     const dim3 grid((unsigned)(((n + 3) / 4 + 255) / 256));
     if (lp_dtype == MADTP_BF16)
-        hipLaunchKernelGGL(cast_lp_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n, scale, (int*)nullptr);
+        hipLaunchKernelGGL(cast_lp_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n, scale, (int*)nullptr, n_dev);
     else if (lp_dtype == MADTP_F16)
-        hipLaunchKernelGGL(cast_lp_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n, scale, madtp_internal_range_flag());
+        hipLaunchKernelGGL(cast_lp_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n, scale, madtp_internal_range_flag(), n_dev);
     else
         return MADTP_E_DTYPE;
     MADTP_LAUNCH_CHECK();
@@ -368,7 +372,7 @@ extern "C" int madtp_split_f16_weight(const float* w, int ldw, void* dst, int n,
     return 0;
 }
 
-extern "C" int madtp_abi_version(void) { return 24; }
+extern "C" int madtp_abi_version(void) { return 25; }
 
 extern "C" const char* madtp_strerror(int code) {
     switch (code) {

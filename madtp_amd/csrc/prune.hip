@@ -857,9 +857,22 @@ __global__ __launch_bounds__(256) void token_gather_kernel(const float* __restri
 // order2 == NULL: slot p takes mask[1+order[p]] for p in [0,k]            (NLVR: order = indices_sort)
 // order2 != NULL: slots p<k take mask[1+order[p]] (order = indices), slot k takes mask[1+order2[k]] (order2 =
 //                 indices_sort: the (k+1)-th ranked token, med.py:377,388-390)
+// dims_l != NULL (sync-free encoder path): N, k from the layer's device-side record, the index rows at their DEVICE strides
+// (order2 given: order = indices [B, k], order2 = indices_sort [B, N-1]; else order = indices_sort [B, N-1]); k == 0: the layer is
+// not pruned and the mask is copied.
 __global__ void mask_gather_kernel(const float* __restrict__ mask, const int64_t* __restrict__ order, int ld_order,
-                                   const int64_t* __restrict__ order2, int ld_order2, float* __restrict__ out, int N, int k) {
+                                   const int64_t* __restrict__ order2, int ld_order2, float* __restrict__ out, int N, int k,
+                                   const int32_t* dims_l = nullptr) {
     const int b = blockIdx.x;
+    if (dims_l) {
+        N = dims_l[0]; k = dims_l[2];
+        if (k == 0) {
+            for (int p = threadIdx.x; p < N; p += blockDim.x) out[(size_t)b * N + p] = mask[(size_t)b * N + p];
+            return;
+        }
+        ld_order = order2 ? k : N - 1;
+        ld_order2 = N - 1;
+    }
     for (int p = threadIdx.x; p < k + 2; p += blockDim.x) {
         float v;
         if (p == 0) v = mask[(size_t)b * N];
@@ -1923,6 +1936,18 @@ extern "C" int madtp_mask_gather(const float* mask, const int64_t* order, int ld
     if (order2 ? (k > ld_order || k + 1 > ld_order2) : (k + 1 > ld_order)) return MADTP_E_BADARG;
     hipLaunchKernelGGL(mask_gather_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mask, order, ld_order, order2, ld_order2,
                        out, N, k);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+int madtp_i_mask_gather_dev(const float* mask, const int64_t* indices, const int64_t* indices_sort, int variant_nlvr, float* out, int B,
+                            const int32_t* dims_l, void* stream) {
+    if (!mask || !indices || !indices_sort || !out || !dims_l || B <= 0) return MADTP_E_BADARG;
+    if (variant_nlvr)  // nlvr_encoder.py:451-452: the first k+1 entries of the full sort order
+        hipLaunchKernelGGL(mask_gather_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mask, indices_sort, 0, (const int64_t*)nullptr, 0,
+                           out, 0, 0, dims_l);
+    else               // med.py:377,388-390: the kept indices, then the (k+1)-th ranked token
+        hipLaunchKernelGGL(mask_gather_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mask, indices, 0, indices_sort, 0, out, 0, 0, dims_l);
     MADTP_LAUNCH_CHECK();
     return 0;
 }

@@ -13,7 +13,7 @@ import torch
 F32, BF16, F16S, F16 = 0, 1, 2, 3  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 #                                    F16: plain IEEE f16 operands (the "f16" fast mode), see set_lp_format below
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -79,6 +79,9 @@ _SIGS = {
     "madtp_bert_encoder": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
                                    c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                    c_void_p]),
+    "madtp_bert_encoder_async": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
+                                         c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                         c_void_p, c_void_p, c_void_p]),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
     "madtp_gemm_pair": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float, c_float, c_void_p]),
     "madtp_attention_pair": (c_int, [c_void_p] * 11 + [c_int] * 8 + [c_float, c_int, c_void_p]),
@@ -1170,9 +1173,16 @@ def vit_encoder_sync_free_ok(B, N, prune, qargs):
     return bool(prune and qargs is not None and qargs.get("att_ft") is None and B * N < 4096 and 3 <= N <= 256)
 
 
+def bert_encoder_sync_free_ok(B, L, Nk, prune, qargs, mask2d):
+    """shapes / options madtp_bert_encoder_async takes (small-tile GEMMs, <= 256-key attention, a deferred att_ft)"""
+    return bool(prune and qargs is not None and qargs.get("att_ft") is None and mask2d is not None and B * L < 4096
+                and 3 <= L <= 256 and Nk <= 256)
+
+
 def bert_encoder(weights, hidden, hidden_lp, mask2d, qargs, temperature, cross_mode, enc0, enc1, Nk, enc_mask0, enc_mask1,
-                 kv_pre0=None, kv_pre1=None, kv_index=None, kv_ld=0):
-    """BertEncoder's layer loop in ONE library call -> EncoderRun (y_lp of layer l: run.view(l, 'y_lp', ...))."""
+                 kv_pre0=None, kv_pre1=None, kv_index=None, kv_ld=0, sync_free=False):
+    """BertEncoder's layer loop in ONE library call -> EncoderRun (y_lp of layer l: run.view(l, 'y_lp', ...)).
+    sync_free: madtp_bert_encoder_async (device-side lengths: no host read of k between the layers)."""
     B, Lq, D = hidden.shape
     lib = load()
     wstructs, arr = weights
@@ -1186,6 +1196,19 @@ def bert_encoder(weights, hidden, hidden_lp, mask2d, qargs, temperature, cross_m
     q = _query_w(qargs)
     kv0 = (c_void_p * L)(*[_p(t) for t in kv_pre0]) if kv_pre0 is not None else None
     kv1 = (c_void_p * L)(*[_p(t) for t in kv_pre1]) if kv_pre1 is not None else None
+    if sync_free:
+        if not bert_encoder_sync_free_ok(B, Lq, Nk, prune, qargs, mask2d):
+            raise RuntimeError("sync-free encoder call: needs pruning with a deferred att_ft and a padding mask, B * L < 4096 rows, "
+                               "L <= 256 and <= 256 keys")
+        dims_dev = torch.empty(((L + 2) * 4,), device=hidden.device, dtype=torch.int32)
+        dims_host = (ctypes.c_int32 * ((L + 1) * 4))()
+        _check(lib.madtp_bert_encoder_async(arr, L, ctypes.byref(q), _p(hidden), _p(hidden_lp), _p(mask2d), run.io_ptr, _p(ws), ws.numel(),
+                                            B, Lq, Nk, float(temperature), int(cross_mode), _p(enc0), _p(enc1), _p(enc_mask0),
+                                            _p(enc_mask1), kv0, kv1, _p(kv_index), int(kv_ld), _p(dims_dev), ctypes.addressof(dims_host),
+                                            _stream()), "madtp_bert_encoder_async")
+        run.keep = (hidden, hidden_lp, mask2d, wstructs, qargs, enc0, enc1, enc_mask0, enc_mask1, kv_pre0, kv_pre1, kv_index, dims_dev,
+                    dims_host)
+        return run
     _check(lib.madtp_bert_encoder(arr, L, ctypes.byref(q) if q is not None else None, _p(hidden), _p(hidden_lp), _p(mask2d), run.io_ptr,
                                   _p(ws), ws.numel(), B, Lq, Nk, float(temperature if prune else 0.0), int(cross_mode), _p(enc0),
                                   _p(enc1), _p(enc_mask0), _p(enc_mask1), kv0, kv1, _p(kv_index), int(kv_ld), _stream()),

@@ -415,6 +415,92 @@ def test_sync_free_vit_encoder_equals_host_k_paths(mode, B, T, size, monkeypatch
     assert (unpruned > 0) if size < 224 else (pruned >= 12)
 
 
+def _force_sync_free(monkeypatch):
+    """Both encoders on the encoder-level call with device-side lengths (MADTP_ENCODER_CALL=1 MADTP_ENCODER_SYNC_FREE=1)."""
+    from madtp_amd import bert, vit
+    monkeypatch.setattr(vit, "_ENCODER_CALL", True)
+    monkeypatch.setattr(bert, "_ENCODER_CALL", True)
+    monkeypatch.setattr(vit, "_SYNC_FREE", True)
+
+
+@pytest.mark.parametrize("mode", EXACT_MODES)
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c)[:-4] for c in CASES])
+def test_sync_free_encoders_match_reference_fixture(env, path, mode, monkeypatch):
+    """SURVEY 8(f) rank 2 pinned by the REFERENCE's recordings, not by the host-k path: BLIP_NLVR end to end with
+    madtp_vit_encoder_async AND madtp_bert_encoder_async (no host read of k inside either encoder: one read of the device-side
+    records per encoder, at its end) reproduces every fixture's per-layer token counts, kept-token sets of both encoders (the
+    padded-caption fixture prunes the text 35 -> 8 with mask compaction on the device) and the logits within 1e-3."""
+    from madtp_amd import hip
+    harness, runtime, model = env
+    _force_sync_free(monkeypatch)
+    g = np.load(path)
+    B, size, L, T, seed = int(g["B"]), int(g["size"]), int(g["L"]), float(g["temperature"]), int(g["seed"])
+    images, text, targets = harness.nlvr_inputs(B, size, L, seed, pad_tail=int(g["pad_tail"]) if "pad_tail" in g.files else 0)
+    calls = {"vit": 0, "bert": 0}
+    real_v, real_b = hip.vit_encoder, hip.bert_encoder
+    def spy_v(*a, **kw):
+        calls["vit"] += bool(kw.get("sync_free"))
+        return real_v(*a, **kw)
+    def spy_b(*a, **kw):
+        calls["bert"] += bool(kw.get("sync_free"))
+        return real_b(*a, **kw)
+    monkeypatch.setattr(hip, "vit_encoder", spy_v)
+    monkeypatch.setattr(hip, "bert_encoder", spy_b)
+    with runtime.precision(mode):
+        logits, trace = harness.run_nlvr(model, images, text, targets, T)
+    assert calls["vit"] >= 1 and calls["bert"] >= 1, calls  # both encoders really took the device-side-length entry points
+    assert harness.token_lengths(trace["vit"], 197) == g["vit_lens"].tolist()
+    assert harness.token_lengths(trace["text"], L) == g["txt_lens"].tolist()
+    for side, key, n0 in (("vit", "vit", 196), ("text", "txt", L - 1)):
+        mine = harness.compose_ids(trace[side], n0)
+        ref = _golden_sets(g, key, 2 * B, n0)
+        for l in range(12):
+            assert (mine[l] is None) == (ref[l] is None), (side, l)
+            if mine[l] is not None:
+                assert mine[l] == ref[l], f"{side} layer {l}: kept-token sets differ from the reference"
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("mode", EXACT_MODES + ["f16"])
+@pytest.mark.parametrize("path", MED_CASES, ids=[os.path.basename(c)[:-4] for c in MED_CASES])
+def test_sync_free_med_encoder_matches_reference_fixture(path, mode, monkeypatch):
+    """madtp_bert_encoder_async on models/med.py's BertModel (text mode and multimodal mode with single cross-attention, ragged
+    padding masks, text pruned 35 -> 7 with the MED mask rule - kept indices, then the (k+1)-th ranked token) against the
+    reference fixture: token counts, kept sets, CLS row within 1e-3 (parity modes); finite and close in the f16 fast mode."""
+    from madtp_amd import build, hip, harness, runtime, specs
+    from madtp_amd.med import BertConfig, BertModel
+    from tests.test_oracle_golden import med_inputs
+    build.build(verbose=False)
+    hip.load()
+    _force_sync_free(monkeypatch)
+    g = np.load(path)
+    ids, att, enc, enc_att, sd, bert_mode, T = med_inputs(g)
+    model = BertModel(BertConfig.med_default(), add_pooling_layer=False)
+    model.load_state_dict(specs.synth_weights(specs.bert_shapes("", "med"), int(g["seed"])), strict=False)
+    model = model.eval().cuda()
+    used = []
+    real_b = hip.bert_encoder
+    monkeypatch.setattr(hip, "bert_encoder", lambda *a, **kw: (used.append(bool(kw.get("sync_free"))), real_b(*a, **kw))[1])
+    with runtime.precision(mode), torch.no_grad():
+        out, _ = model(ids.cuda(), attention_mask=att.cuda(), encoder_hidden_states=None if enc is None else enc.cuda(),
+                       encoder_attention_mask=None if enc_att is None else enc_att.cuda(), mode=bert_mode,
+                       space_dict=sd.cuda(), temperature=T)
+    assert used == [True]
+    hid = out.last_hidden_state
+    if mode == "f16":
+        assert torch.isfinite(hid).all() and list(hid.shape[::2]) == g["hidden_shape"].tolist()[::2]
+        return
+    assert list(hid.shape) == g["hidden_shape"].tolist()
+    trace = [None if l.last_prune is None else {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in l.last_prune.items()}
+             for l in model.encoder.layer]
+    assert harness.token_lengths(trace, int(g["L"])) == g["txt_lens"].tolist()
+    mine = harness.compose_ids(trace, int(g["L"]) - 1)
+    ref_trace = [{"pruned": True, "indices": g[f"txt{l}_idx"][:, : trace[l]["k"]]} if f"txt{l}_idx" in g.files else None
+                 for l in range(12)]
+    assert mine == harness.compose_ids(ref_trace, int(g["L"]) - 1)
+    assert np.abs(hid[:, 0, :32].cpu().numpy() - g["hidden_cls"]).max() < 1e-3
+
+
 RETR_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "retr_*.npz")))
 
 
