@@ -41,6 +41,7 @@ struct AttnArgs {
     unsigned* hm_ws; int* hm_tick;
     // sync-free encoder path (self-attention): Nq = Nk = *n_dev tokens per sample, read by the kernel; the launch geometry and the
     // key-tile instantiation are the host's worst case (the unpruned sequence)
+    float* o_part;  // attn_bf16_large_kernel<.., HV = 2>: f32 scratch [B, Nq, H, 64] (the first key half's P.V sums)
     const int32_t* n_dev;
     int dev_q_only;  // cross-attention on the sync-free path: *n_dev is the number of QUERY tokens per sample, Nk stays the host's
 };
@@ -1508,11 +1509,20 @@ int launch_attn_large(const AttnArgs& a, hipStream_t s) {
 // one fma + v_exp_f32 on the unscaled score, see scores()).
 // STG: stages of the chunk ring (2 is what launch_attn_bf16_large uses; 3 keeps two chunks in flight behind counted vmcnt waits
 // and was measured slower, see there).
-template <int NCH, bool SCORES, int STG, bool F16 = false>
-__global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) void attn_bf16_large_kernel(AttnArgs a) {
+// HV = 2 (round 5, the 641..1024-key instantiation with scores: VQA's 901 tokens): the head-max of all 64 key tiles is 128
+// registers and pinned the kernel at ONE wave per SIMD (318 registers; a chunk step of a lone wave is bound by its own dependent
+// instruction stream, ~1.85 us against ~1.2 us with two waves per SIMD).  Here the work is re-ordered into three sweeps over the
+// heads - (1) pass A of every head, the row statistics (max, normalising offset) parked in LDS; (2) pass B on the FIRST half of the
+// key chunks of every head: probabilities, head-max of those 32 key tiles (64 registers), CLS row, partial P.V, parked as f32 in a
+// scratch buffer; (3) pass B on the second half, its head-max, the partial sums completed and stored - so that two workgroups fit
+// a CU.  Same arithmetic per element; the P.V sum of a row is split at the half boundary (f32 partial written and re-read
+// exactly), i.e. the same association as the one-sweep order.  gridDim.z == 1.
+template <int NCH, bool SCORES, int STG, bool F16 = false, int HV = 1>
+__global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES || HV == 2)) ? 2 : 1) void attn_bf16_large_kernel(AttnArgs a) {
+    static_assert(HV == 1 || (HV == 2 && SCORES && STG == 2 && NCH % 2 == 0), "the three-sweep order exists with scores on the two-stage ring");
     constexpr int CK = 128;                   // keys per chunk
     constexpr int STAGE = 2 * CK * 128;       // K image (128-byte rows), then V image
-    constexpr int NT = NCH * 8;
+    constexpr int NT = NCH * 8 / HV;          // key tiles whose head-max is held at a time
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1642,6 +1652,178 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
         }
         issue();
     };
+    if constexpr (HV == 2) {
+        constexpr int CH0 = NCH / 2;  // chunks of the first key half
+        // stream of this workgroup's chunk steps: sweep 0 = (h, all chunks, K only), sweep 1 = (h, chunks [0, CH0), K|V),
+        // sweep 2 = (h, chunks [CH0, nch), K|V); the DMA of the step after the current one is issued behind the current barrier
+        int sw_i = 0, h_i = 0, c_i = 0, st_i = 0;
+        auto issue2 = [&]() {
+            if (sw_i < 3) {
+                const int c_lo = sw_i == 2 ? CH0 : 0, c_hi = sw_i == 1 ? CH0 : nch;
+                if (c_i == c_lo) stage_q(h_i);
+                stage(h_i, c_i, sw_i != 0, st_i);
+                st_i ^= 1;
+                if (++c_i == c_hi) {
+                    if (++h_i == a.H) { h_i = 0; ++sw_i; }
+                    c_i = sw_i == 2 ? CH0 : 0;
+                }
+            }
+        };
+        bf16x8 q[2];
+        // barrier (the current step's chunk landed - the barrier drains the DMA - and the other stage is free), the head's Q rows
+        // on its first step (read BEFORE the next step's DMA is issued: that one may carry the next head's Q rows), then the issue
+        auto sync2 = [&](bool first) {
+            __syncthreads();
+            if (first) {
+                q[0] = *(const bf16x8*)(qimg + l16 * 128 + (((0 + g) ^ (l16 & 7)) << 4));
+                q[1] = *(const bf16x8*)(qimg + l16 * 128 + (((4 + g) ^ (l16 & 7)) << 4));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]) :: "memory");
+            }
+            issue2();
+        };
+        float* const stats = (float*)(smem + STG * STAGE + 4 * 2048) + (wave * 16 + l16) * 2;  // [head][wave][row]{max, offset}
+        float* const opart = a.o_part;  // f32 [B, Nq, H, 64]: the first half's P.V sums
+        issue2();
+        // ---- sweep 0: row maximum and sum over all keys of every head ----
+        for (int h = 0; h < a.H; ++h) {
+            float m = -INFINITY, l = 0.f;
+#pragma nounroll
+            for (int c = 0; c < nch; ++c, st ^= 1) {
+                sync2(c == 0);
+                if (!active) continue;
+                f32x4 sc[8];
+                scores(smem + st * STAGE, c, q, sc);
+                float cm = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cm = fmaxf(cm, sc[t][r]);
+                cm = rows4_max(cm);
+                const float mn = fmaxf(m, cm);
+                const float off = -mn * c2;
+                float cs = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cs += __builtin_amdgcn_exp2f(fmaf(sc[t][r], c2, off));
+                cs = rows4_sum(cs);
+                l = l * __builtin_amdgcn_exp2f((m - mn) * c2) + cs;
+                m = mn;
+            }
+            if (g == 0) stats[h * 128 + 1] = -(m * c2 + __builtin_amdgcn_logf(l));  // P = exp2(c2 s + offset): normalised
+        }
+        // ---- sweeps 1, 2: probabilities, head-max, CLS row, P.V on one half of the key chunks ----
+        for (int half = 0; half < 2; ++half) {
+            const int c_lo = half ? CH0 : 0, c_hi = half ? nch : CH0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { pmax[t][0] = (h2){0, 0}; pmax[t][1] = (h2){0, 0}; }
+            for (int h = 0; h < a.H; ++h) {
+                const float poff = stats[h * 128 + 1];
+                f32x4 o[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
+                for (int c = c_lo; c < c_hi; ++c, st ^= 1) {
+                    sync2(c == c_lo);
+                    if (!active) continue;
+                    const char* Ks = smem + st * STAGE;
+                    const char* Vs = Ks + CK * 128;
+                    f32x4 sc[8];
+                    scores(Ks, c, q, sc);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[t][r] = __builtin_amdgcn_exp2f(fmaf(sc[t][r], c2, poff));
+#define PM2_CASE(C)                                                                                     \
+    case C:                                                                                             \
+        if constexpr (C < CH0) {                                                                        \
+            _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                             \
+                constexpr int TT = (C < CH0 ? C : 0) * 8;                                               \
+                const h2 lo = (h2){(_Float16)sc[t][0], (_Float16)sc[t][1]};                           \
+                const h2 hi = (h2){(_Float16)sc[t][2], (_Float16)sc[t][3]};                           \
+                pmax[TT + t][0] = __builtin_elementwise_max(pmax[TT + t][0], lo);                       \
+                pmax[TT + t][1] = __builtin_elementwise_max(pmax[TT + t][1], hi);                       \
+            }                                                                                           \
+        }                                                                                               \
+        break;
+                    switch (c - c_lo) { PM2_CASE(0) PM2_CASE(1) PM2_CASE(2) PM2_CASE(3) default: break; }
+#undef PM2_CASE
+                    if (i0 == 0 && l16 == 0) {  // the wave that owns query row 0: the CLS row of P
+                        float* dst = a.p0 + ((size_t)b * a.H + h) * a.Nk;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int j = c * CK + 16 * t + 4 * g + r;
+                                if (j < a.Nk) dst[j] = sc[t][r];
+                            }
+                    }
+                    bf16x4 vt[2][8];
+                    auto v_reads = [&](int cc, bf16x4 (&d)[8]) {
+                        const int vrow = 32 * cc + 4 * g + (l16 >> 2);
+                        const int vkey = ((vrow >> 1) & 3) << 1;
+                        const char* vr = Vs + vrow * 128 + 8 * (l16 & 1);
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            const unsigned ad = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(vr + (((2 * dt + ((l16 & 3) >> 1)) ^ vkey) << 4));
+                            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(d[2 * dt]) : "v"(ad) : "memory");
+                            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(d[2 * dt + 1]) : "v"(ad) : "memory");
+                        }
+                    };
+                    v_reads(0, vt[0]);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const bf16x8 pa = pack_lp8<F16>(sc[2 * cc], sc[2 * cc + 1]);
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[cc & 1][0]), "+v"(vt[cc & 1][1]), "+v"(vt[cc & 1][2]), "+v"(vt[cc & 1][3]),
+                                     "+v"(vt[cc & 1][4]), "+v"(vt[cc & 1][5]), "+v"(vt[cc & 1][6]), "+v"(vt[cc & 1][7]) :: "memory");
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+                            o[dt] = mfma_lp<F16>(cat_bf16x4(vt[cc & 1][2 * dt], vt[cc & 1][2 * dt + 1]), pa, o[dt], 0, 0, 0);
+                        if (cc + 1 < 4) v_reads(cc + 1, vt[(cc + 1) & 1]);
+                    }
+                }
+                if (active) {  // lane (i = l16, g) holds columns h*64 + 16dt + 4g .. +3 of row i
+                    const int i = i0 + l16;
+                    float* pr = opart + (((size_t)b * a.Nq + min(i, a.Nq - 1)) * a.H + h) * 64 + 4 * g;
+                    if (half == 0) {
+                        if (i < a.Nq) {
+#pragma unroll
+                            for (int dt = 0; dt < 4; ++dt) *(f32x4*)(pr + dt * 16) = o[dt];
+                        }
+                    } else {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) o[dt] += *(const f32x4*)(pr + dt * 16);
+                        float n2 = 0.f;
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) n2 += o[dt][r] * o[dt][r];
+                        n2 = rows4_sum(n2);
+                        if (i < a.Nq) {
+                            bf16_t* orow = (bf16_t*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 2) + 4 * g;
+#pragma unroll
+                            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + dt * 16) = pack_lp4<F16>(o[dt]);
+                            if (g == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
+                        }
+                    }
+                }
+            }
+            if (active) {  // column sums of this half's head-max (vit.py:126-127)
+                const int i = i0 + l16;
+                const bool valid = i >= 1 && i < a.Nq;
+                float* dst = a.colsum + ((size_t)b * a.nrt + rt) * a.Nk;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = row16_sum(valid ? (float)pmax[t][r >> 1][r & 1] : 0.f);
+                        const int j = c_lo * CK + 16 * t + 4 * g + r;
+                        if (l16 == 0 && j < a.Nk) dst[j] = v;
+                    }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < STG - 1; ++i) issue();
     for (int h = blk_z; h < a.H; h += hstep) {
@@ -1814,10 +1996,42 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES)) ? 2 : 1) v
     }
 }
 
+// f32 scratch of the three-sweep order (one per device and stream, grow-only)
+static float* opart_workspace(hipStream_t s, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, std::pair<char*, size_t>> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& e = pool[{dev, s}];
+    if (e.second < bytes) {
+        if (e.first) { (void)hipStreamSynchronize(s); (void)hipFree(e.first); e.first = nullptr; e.second = 0; }
+        if (hipMalloc((void**)&e.first, bytes) != hipSuccess) { (void)hipGetLastError(); e.first = nullptr; return nullptr; }
+        e.second = bytes;
+    }
+    return (float*)e.first;
+}
+
 template <int NCH, bool SCORES, bool F16>
 int launch_attn_bf16_large(const AttnArgs& a_in, hipStream_t s) {
     AttnArgs a = a_in;
     int gz = 1;
+    if constexpr (SCORES && NCH == 8) {
+        // 641..1024 keys with scores: the three-sweep order (HV = 2), two workgroups per CU (MADTP_ATTN_HV=0: the one-sweep order)
+        static int hv_env = -1;
+        if (hv_env < 0) { const char* e = getenv("MADTP_ATTN_HV"); hv_env = e ? atoi(e) : 1; }
+        if (hv_env && a.H <= 16 && (a.Nk + 127) / 128 > NCH / 2) {
+            float* op = opart_workspace(s, (size_t)a.B * a.Nq * a.H * 64 * sizeof(float));
+            if (op) {
+                a.o_part = op;
+                const size_t lds2 = (size_t)2 * 2 * 128 * 128 + 4 * 2048 + (size_t)a.H * 128 * sizeof(float);
+                MADTP_ENSURE_MAX_LDS((attn_bf16_large_kernel<NCH, true, 2, F16, 2>), lds2);
+                hipLaunchKernelGGL((attn_bf16_large_kernel<NCH, true, 2, F16, 2>), dim3((a.Nq + 63) / 64, a.B, 1), dim3(256), lds2, s, a);
+                MADTP_LAUNCH_CHECK();
+                return 0;
+            }
+        }
+    }
     const int wgs = ((a.Nq + 63) / 64) * a.B;
     if (!SCORES) {  // cross-attention against a long image sequence: few query rows, spread the heads over workgroups
         gz = wgs >= 512 ? 1 : (wgs >= 128 ? 4 : a.H);
@@ -2024,7 +2238,7 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
     a.nrt = (Nq + 15) / 16;
     a.scale = scale;
     a.kvidx = kv_batch_index;
-    a.pair = 0; a.q2 = a.k2 = a.v2 = nullptr; a.out2 = nullptr; a.mask2 = nullptr; a.hm_ws = nullptr; a.hm_tick = nullptr;
+    a.pair = 0; a.q2 = a.k2 = a.v2 = nullptr; a.out2 = nullptr; a.mask2 = nullptr; a.hm_ws = nullptr; a.hm_tick = nullptr; a.o_part = nullptr;
     a.mask_qk = mask_qk; a.ld_mqk = ld_mask_qk;
     a.n_dev = n_dev; a.dev_q_only = dev_q_only;
     hipStream_t s = (hipStream_t)stream;
@@ -2086,7 +2300,7 @@ int madtp_i_attention_pair(const void* q0, const void* q1, const void* k0, const
     a.q = (const char*)q0; a.k = (const char*)k0; a.v = (const char*)v0; a.out = (char*)out0; a.mask = add_mask0;
     a.q2 = (const char*)q1; a.k2 = (const char*)k1; a.v2 = (const char*)v1; a.out2 = (char*)out1; a.mask2 = add_mask1;
     a.pair = 1;
-    a.mask_qk = nullptr; a.ld_mqk = 0; a.hm_ws = nullptr; a.hm_tick = nullptr; a.n_dev = nq_dev; a.dev_q_only = 1;
+    a.mask_qk = nullptr; a.ld_mqk = 0; a.hm_ws = nullptr; a.hm_tick = nullptr; a.n_dev = nq_dev; a.dev_q_only = 1; a.o_part = nullptr;
     a.colsum = nullptr; a.p0 = nullptr; a.onorm = nullptr;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.nrt = (Nq + 15) / 16;

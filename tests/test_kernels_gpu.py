@@ -309,6 +309,9 @@ def _ref_attention(qkv, B, N, H, scale, mask=None):
 
 @pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 20, 12), (1, 1 + 16 * 4, 2), (2, 130, 12), (2, 180, 12), (1, 256, 3), (2, 17, 1),
                                    (1, 577, 12), (2, 901, 3), (1, 257, 2), (1, 1024, 1),
+                                   # 641..1024 keys, all heads: the three-sweep order of attn_bf16_large_kernel (round 5; 6 chunks = a
+                                   # second key half of two chunks, 901 = VQA's token count)
+                                   (2, 700, 12), (1, 901, 12),
                                    # head split (two workgroups per row block, halves merged through the ticket) on many row
                                    # blocks at once: 16 x 5 / 24 x 2 blocks, and an odd head count (no split)
                                    (16, 320, 12), (24, 96, 12), (4, 300, 3)])
@@ -1004,7 +1007,7 @@ def test_gemm_f16_operands(hip, M, N, K):
         assert (of - exact.float()).abs().mean().item() < 0.25 * (ob - exact.float()).abs().mean().item()
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 20, 12), (2, 130, 12), (1, 577, 12), (16, 320, 12)])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 20, 12), (2, 130, 12), (1, 577, 12), (16, 320, 12), (1, 901, 12)])
 def test_self_attention_f16_operands(hip, B, N, H):
     from madtp_amd import runtime
     qkv = _rand(B * N, 3 * H * 64, seed=20)
