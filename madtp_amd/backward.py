@@ -36,15 +36,93 @@ def transpose_pad(src, rows_pad, cols_pad):
     return dst
 
 
+# ---- precision of the backward's GEMMs --------------------------------------------------------------------------------------
+# "fp32": exact-f32 MFMA (1/16 of the f16 rate).  "f16x3" (round 5): every product - the recomputed forward, dgrad, wgrad - as
+# three f16 MFMA products of f16-split operands (common.h), the arithmetic the f16x3 FORWARD runs, at 3/16 of the f16 rate.
+#   * the recomputed forward uses the forward's own operand formats and kernels (same planes, same dispatch: same bits, so the
+#     recomputed pruning scores select the forward's kept set);
+#   * a gradient operand dY travels in the ACTIVATION format (P0 + 2^-11 P1: absolute error ~2^-36, so gradients of 1e-6 keep five
+#     digits without a loss scale; the reference trains under autocast + GradScaler, compress_nlvr_dtp.py:46-53, whose scale - if a
+#     caller applies one - simply rides along);
+#   * weights^T travel in the weight format with their per-tensor power-of-two scale (prepared once per parameter version);
+#     wgrad's X^T in the weight format with scale 1 (O(1) activations: ~3e-8 absolute, no host read of max|X|).
+_CACHE = {}
+
+
+def _x3():
+    from . import runtime
+    return runtime.get_precision() == "f16x3"
+
+
+def _mode():
+    from . import runtime
+    return runtime.get_precision()
+
+
+def _in_mode(mode):
+    """context of a backward(): the autograd engine runs it on a worker thread whose thread-local precision mode is the default -
+    the forward's mode is recorded on ctx and re-established here"""
+    from . import runtime
+    return runtime.precision(mode)
+
+
+def _check_mode(what):
+    from . import runtime
+    if runtime.get_precision() not in ("fp32", "f16x3"):
+        raise NotImplementedError(f"{what} is built for the fp32-accurate precision modes (runtime.precision('fp32') or 'f16x3'); "
+                                  f"current mode: {runtime.get_precision()}")
+
+
+def _cached(key, tensors, build):
+    """build() memoised per (key, identity and version of the source tensors): padded / concatenated / transposed / split copies of
+    parameters are made once per parameter VERSION (an optimizer step bumps it) instead of in every backward."""
+    ver = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    hit = _CACHE.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    val = build()
+    if len(_CACHE) > 4096:
+        _CACHE.clear()
+    # the entry holds the source tensors: while it lives their storage cannot be recycled for another tensor at the same address
+    # (a key of addresses + versions alone would alias a freed model's weights with a new model's)
+    _CACHE[key] = (ver, val, tuple(t.detach() for t in tensors))
+    return val
+
+
+def _planes(w32):
+    """f16-split weight planes of a (padded) f32 weight tensor, attached to it (the tensor itself is a cached object)."""
+    pl = getattr(w32, "_madtp_x3_planes", None)
+    if pl is None:
+        pl = hip.split_f16_weight(w32)
+        w32._madtp_x3_planes = pl
+    return pl
+
+
+def _gemm(a, w, bias=None, n=None, residual=None, out_dtype=torch.float32):
+    """act-free Linear of the recomputed forward: a f32 [M, K] @ w f32 [Npad, K]^T (+ bias, + residual) -> f32 [M, n]."""
+    if _x3() and a.shape[1] % 64 == 0:
+        return hip.gemm(hip.split_f16(a.contiguous()), _planes(w), bias, residual, out_dtype=torch.float32, n=n)
+    return hip.gemm(a, w, bias, residual, out_dtype=torch.float32, n=n)
+
+
+def _attention(q, k, v, B, H, Nq, Nk, scale, **kw):
+    """the recomputed forward's attention: the f16x3 mode's three-product kernels where the forward ran them"""
+    return hip.attention(q, k, v, B, H, Nq, Nk, scale, split=_x3(), **kw)
+
+
 def dgrad(dy, weight, residual=None):
     """dX[M, K] = dY[M, N] @ W[N, K] (nn.Linear weight layout) [+ residual[M, K]: the other branch of a residual connection]."""
     N, K = weight.shape
-    Np = _pad(N, 32)  # the GEMM's reduction length (f32 slabs of 32): zero columns for e.g. the 100 dictionary columns
+    x3 = _x3()
+    Np = _pad(N, 64 if x3 else 32)  # the GEMM's reduction length (slabs of 32 f32 / 64 f16): zero columns for e.g. the 100 dictionary columns
     if Np != N:
         dyp = torch.zeros((dy.shape[0], Np), device=dy.device, dtype=torch.float32)
         dyp[:, :N] = dy
         dy = dyp
-    wt = transpose_pad(weight, Np, _pad(K, 128))  # [Kpad, Np]: the GEMM's "weight" with K' = N contiguous
+    # [Kpad, Np]: the GEMM's "weight" with K' = N contiguous - once per parameter version (was: one transpose per backward call)
+    wt = _cached(("wt", weight.data_ptr(), Np), [weight], lambda: transpose_pad(weight, Np, _pad(K, 128)))
+    if x3:
+        return hip.gemm(hip.split_f16(dy.contiguous()), _planes(wt), None, residual, out_dtype=torch.float32, n=K)
     return hip.gemm(dy, wt, n=K, out_dtype=torch.float32, residual=residual)
 
 
@@ -52,9 +130,12 @@ def wgrad(dy, x):
     """dW[N, K] = dY[M, N]^T @ X[M, K]."""
     M, N = dy.shape
     K = x.shape[1]
-    Mp = _pad(M, 32)
+    x3 = _x3()
+    Mp = _pad(M, 64 if x3 else 32)
     dyt = transpose_pad(dy, Mp, N)             # [N, Mp]
     xt = transpose_pad(x, Mp, _pad(K, 128))    # [Kpad, Mp]
+    if x3:  # dY^T in the activation format (tiny values keep their digits), X^T in the weight format at scale 1
+        return hip.gemm(hip.split_f16(dyt), hip.split_f16_weight(xt, log2_scale=0), n=K, out_dtype=torch.float32)
     return hip.gemm(dyt, xt, n=K, out_dtype=torch.float32)
 
 
@@ -145,20 +226,7 @@ def attention_bwd_cross(q, kv, dout, B, H, Nq, Nk, scale, key_mask=None):
     return dq, dkv
 
 
-def _f32_lin(linear):
-    """(weight padded to 128 rows, bias) of an nn.Linear for the exact-f32 GEMM."""
-    w = linear.weight.detach()
-    n = w.shape[0]
-    npad = _pad(n, 128)
-    if npad != n:
-        wp = torch.zeros((npad, w.shape[1]), device=w.device, dtype=torch.float32)
-        wp[:n] = w
-        w = wp
-    return w.contiguous(), (None if linear.bias is None else linear.bias.detach().contiguous())
-
-
-def _f32_wb(w, b):
-    """(weight padded to 128 rows, bias) of a Linear given as tensors, for the exact-f32 GEMM."""
+def _pad_w(w):
     w = w.detach()
     n = w.shape[0]
     npad = _pad(n, 128)
@@ -166,7 +234,32 @@ def _f32_wb(w, b):
         wp = torch.zeros((npad, w.shape[1]), device=w.device, dtype=torch.float32)
         wp[:n] = w
         w = wp
-    return w.contiguous(), (None if b is None else b.detach().contiguous())
+    return w.contiguous()
+
+
+def _f32_lin(linear):
+    """(weight padded to 128 rows, bias) of an nn.Linear for the recomputed forward's GEMM (cached per parameter version)."""
+    w = _cached(("pw", linear.weight.data_ptr()), [linear.weight], lambda: _fresh(_pad_w(linear.weight)))
+    return w, (None if linear.bias is None else linear.bias.detach().contiguous())
+
+
+def _f32_wb(w, b):
+    """(weight padded to 128 rows, bias) of a Linear given as tensors (cached per parameter version)."""
+    wp = _cached(("pw", w.data_ptr()), [w], lambda: _fresh(_pad_w(w)))
+    return wp, (None if b is None else b.detach().contiguous())
+
+
+def _fresh(t):
+    """a tensor OBJECT of the cache's own (attributes such as the split planes hang on it; never the parameter's storage view)"""
+    return t.detach().view(t.shape) if t.requires_grad else t.view(t.shape)
+
+
+def _cat_wb(tag, linears):
+    """[w0; w1; ...] and [b0; b1; ...] of Linears that run as one fused projection (cached per parameter version)."""
+    ws = [l.weight for l in linears]
+    w = _cached(("cat", tag) + tuple(x.data_ptr() for x in ws), ws, lambda: torch.cat([x.detach() for x in ws], 0).contiguous())
+    b = torch.cat([l.bias.detach() for l in linears], 0).contiguous()
+    return w, b
 
 
 class _BlockParts:
@@ -217,9 +310,9 @@ def vit_block_backward(blk, x, token_attn, temperature, k, dy, mask_qk=None, dp_
     wp, bp = _f32_lin(P.proj)
     w1, b1 = _f32_lin(P.fc1)
     w2, b2 = _f32_lin(P.fc2)
-    qkv = hip.gemm(h1, wq, bq, n=3 * D, out_dtype=torch.float32)
-    out, side = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, scale, scores=k > 0, mask_qk=mask_qk)
-    x_attn = hip.gemm(out, wp, bp, residual=x2, n=D, out_dtype=torch.float32)
+    qkv = _gemm(h1, wq, bq, n=3 * D, out_dtype=torch.float32)
+    out, side = _attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, scale, scores=k > 0, mask_qk=mask_qk)
+    x_attn = _gemm(out, wp, bp, residual=x2, n=D, out_dtype=torch.float32)
     if k > 0:
         score, _, _, _ = hip.token_score(side, token_attn, temperature, B, H, N)
         _, _, dst_pos, merge_w = hip.token_select(score, k)
@@ -231,7 +324,7 @@ def vit_block_backward(blk, x, token_attn, temperature, k, dy, mask_qk=None, dp_
     y02 = y0.reshape(M2, D)
     h2, _ = hip.layernorm(y02, P.norm2.weight.detach(), P.norm2.bias.detach(), eps2)
     F = P.fc1.weight.shape[0]
-    u = hip.gemm(h2, w1, b1, n=F, out_dtype=torch.float32)
+    u = _gemm(h2, w1, b1, n=F, out_dtype=torch.float32)
     g = act_fwd(u, P.act)
     # ---- backward ----
     grads = {}
@@ -268,6 +361,7 @@ class VitBlockFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, blk, temperature, max_keep, x, token_attn, *params):
+        ctx.mode = _mode()
         prune = temperature > 0
         y, info = hip.vit_block(blk._weights(), x, token_attn, temperature if prune else 0, max_keep=max_keep)
         blk.last_prune = info
@@ -289,7 +383,7 @@ class VitBlockFunction(torch.autograd.Function):
             att._hook_attn_gradients = False
             B_, N_ = x.shape[0], x.shape[1]
             dp_out = torch.empty((B_, att.num_heads, N_, N_), device=x.device, dtype=torch.float32)
-        with torch.no_grad():
+        with torch.no_grad(), _in_mode(ctx.mode):
             dx, dta, grads = vit_block_backward(ctx.blk, x, ta, ctx.temperature, ctx.k, dy, mask_qk=mask, dp_out=dp_out)
         if dp_out is not None:
             att.save_attn_gradients(dp_out)
@@ -301,10 +395,7 @@ class VitBlockFunction(torch.autograd.Function):
 
 def block_forward_with_grad(blk, x, temperature, token_attn, max_keep=0):
     """Block.forward under autograd (called by madtp_amd.vit.Block.forward when gradients are required)."""
-    from . import runtime
-    if runtime.get_precision() != "fp32":
-        raise NotImplementedError("the block backward is built for the fp32 precision mode (runtime.precision('fp32')); "
-                                  f"current mode: {runtime.get_precision()}")
+    _check_mode("the block backward")
     if token_attn is not None and not token_attn.is_contiguous():
         token_attn = token_attn.contiguous()
     return VitBlockFunction.apply(blk, temperature, max_keep, x, token_attn, *_BlockParts(blk).params())
@@ -354,11 +445,10 @@ def _cross_branch_fwd(sm, y02, enc2, B, H, L2, Nk, scale, key_mask):
     """One cross-attention branch (BertSelfAttention with encoder_hidden_states): -> (cq, ckv, cctx, wckv)."""
     D = H * 64
     wcq, bcq = _f32_lin(sm.query)
-    wckv = torch.cat([sm.key.weight.detach(), sm.value.weight.detach()], 0).contiguous()  # [2D, Denc]
-    bckv = torch.cat([sm.key.bias.detach(), sm.value.bias.detach()], 0).contiguous()
-    cq = hip.gemm(y02, wcq, bcq, n=D, out_dtype=torch.float32)
-    ckv = hip.gemm(enc2, wckv, bckv, n=2 * D, out_dtype=torch.float32)
-    cctx, _ = hip.attention(cq, ckv[:, :D], ckv[:, D:], B, H, L2, Nk, scale, add_mask=key_mask)
+    wckv, bckv = _cat_wb("ckv", [sm.key, sm.value])  # [2D, Denc]
+    cq = _gemm(y02, wcq, bcq, n=D, out_dtype=torch.float32)
+    ckv = _gemm(enc2, wckv, bckv, n=2 * D, out_dtype=torch.float32)
+    cctx, _ = _attention(cq, ckv[:, :D], ckv[:, D:], B, H, L2, Nk, scale, add_mask=key_mask)
     return cq, ckv, cctx, wckv
 
 
@@ -391,15 +481,14 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
     h2 = hidden.reshape(M, D)
     twin = isinstance(enc, (list, tuple))
     # ---- recompute the forward ----
-    wqkv = torch.cat([sa.query.weight.detach(), sa.key.weight.detach(), sa.value.weight.detach()], 0).contiguous()  # [3D, D]
-    bqkv = torch.cat([sa.query.bias.detach(), sa.key.bias.detach(), sa.value.bias.detach()], 0).contiguous()
+    wqkv, bqkv = _cat_wb("qkv", [sa.query, sa.key, sa.value])  # [3D, D]
     wo, bo = _f32_lin(so.dense)
     wi, bi = _f32_lin(layer.intermediate.dense)
     wout, bout = _f32_lin(layer.output.dense)
-    qkv = hip.gemm(h2, wqkv, bqkv, n=3 * D, out_dtype=torch.float32)
-    ctx, side = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, L, L, scale, add_mask=mask2d, scores=k > 0,
+    qkv = _gemm(h2, wqkv, bqkv, n=3 * D, out_dtype=torch.float32)
+    ctx, side = _attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, L, L, scale, add_mask=mask2d, scores=k > 0,
                               mask_qk=causal)   # causal [L,L]: the decoder's mask (med.py:752-786), never together with pruning
-    a0 = hip.gemm(ctx, wo, bo, residual=h2, n=D, out_dtype=torch.float32)
+    a0 = _gemm(ctx, wo, bo, residual=h2, n=D, out_dtype=torch.float32)
     ao, _ = hip.layernorm(a0, so.LayerNorm.weight.detach(), so.LayerNorm.bias.detach(), so.LayerNorm.eps)
     if k > 0:
         score, _, _, _ = hip.token_score(side, token_attn, temperature, B, H, L)
@@ -421,24 +510,24 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
         if twin:
             w0, b0 = _f32_lin(co.dense0)
             w1, b1 = _f32_lin(co.dense1)
-            d0 = hip.gemm(br[0][2], w0, b0, n=D, out_dtype=torch.float32)
-            d1 = hip.gemm(br[1][2], w1, b1, n=D, out_dtype=torch.float32)
+            d0 = _gemm(br[0][2], w0, b0, n=D, out_dtype=torch.float32)
+            d1 = _gemm(br[1][2], w1, b1, n=D, out_dtype=torch.float32)
             if co.merge:
                 d01 = torch.cat([d0, d1], 1).contiguous()  # (a copy: the operand layout of merge_layer)
                 wm, bm = _f32_lin(co.merge_layer)
-                c0 = hip.gemm(d01, wm, bm, residual=y02, n=D, out_dtype=torch.float32)
+                c0 = _gemm(d01, wm, bm, residual=y02, n=D, out_dtype=torch.float32)
             else:
                 c0 = (d0 + d1) * 0.5 + y02
         else:
             wcd, bcd = _f32_lin(co.dense)
-            c0 = hip.gemm(br[0][2], wcd, bcd, residual=y02, n=D, out_dtype=torch.float32)
+            c0 = _gemm(br[0][2], wcd, bcd, residual=y02, n=D, out_dtype=torch.float32)
         x2, _ = hip.layernorm(c0, co.LayerNorm.weight.detach(), co.LayerNorm.bias.detach(), co.LayerNorm.eps)
     else:
         x2 = y02
     F = layer.intermediate.dense.weight.shape[0]
-    u = hip.gemm(x2, wi, bi, n=F, out_dtype=torch.float32)
+    u = _gemm(x2, wi, bi, n=F, out_dtype=torch.float32)
     gl = act_fwd(u, hip.ACT_GELU)
-    f0 = hip.gemm(gl, wout, bout, residual=x2, n=D, out_dtype=torch.float32)
+    f0 = _gemm(gl, wout, bout, residual=x2, n=D, out_dtype=torch.float32)
     # ---- backward ----
     grads = {}
     ln2 = layer.output.LayerNorm
@@ -508,10 +597,13 @@ class MedLayerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, layer, temperature, mask2d, enc_masks, causal, hidden, token_attn, enc0, enc1, *params):
+        ctx.mode = _mode()
         prune = temperature > 0
         cross = enc0 is not None
         twin = enc1 is not None
-        flat = lambda e: e.reshape(-1, e.shape[-1]).contiguous().float()
+        from .runtime import to_compute
+        # encoder tokens as the layer's GEMM operand: f32 in the fp32 mode, f16-split planes in the f16x3 mode
+        flat = lambda e: to_compute(e.reshape(-1, e.shape[-1]).contiguous().float())
         em = enc_masks if enc_masks is not None else (None, None)
         w = layer._weights()
         if causal is not None:  # a copy of the cached struct with this call's causal mask (as BertLayer._forward does)
@@ -540,7 +632,7 @@ class MedLayerFunction(torch.autograd.Function):
         hidden, ta, mask2d, enc0, enc1 = ctx.saved_tensors
         ta = ta if ctx.has_ta else None
         enc = ([enc0, enc1] if ctx.twin else enc0) if ctx.cross else None
-        with torch.no_grad():
+        with torch.no_grad(), _in_mode(ctx.mode):
             dh, dta, denc, grads = med_layer_backward(ctx.layer, hidden, mask2d if ctx.has_mask else None, ta, ctx.temperature,
                                                       ctx.k, dy, enc, ctx.enc_masks, ctx.causal)
         if ctx.has_ta and dta is None:
@@ -554,10 +646,7 @@ def med_layer_forward_with_grad(layer, hidden, mask2d, temperature, token_attn, 
     """BertLayer (MED or NLVR) under autograd -> (output, new additive mask [B,L'] or None); enc: the encoder tokens of mode
     'multimodal' (MED: a tensor; NLVR: a list of two, with enc_masks their additive key masks [B,Nk] or None) or None for mode
     'text'; fp32 mode only."""
-    from . import runtime
-    if runtime.get_precision() != "fp32":
-        raise NotImplementedError("the BERT layer backward is built for the fp32 precision mode (runtime.precision('fp32')); "
-                                  f"current mode: {runtime.get_precision()}")
+    _check_mode("the BERT layer backward")
     if token_attn is not None and not token_attn.is_contiguous():
         token_attn = token_attn.contiguous()
     twin = isinstance(enc, (list, tuple))
@@ -579,6 +668,7 @@ class PatchTokensFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, vit, img, w, b, cls, pos):
+        ctx.mode = _mode()
         patches, np_ = vit.patch_embed.run(img)
         B = img.shape[0]
         x = hip.assemble_tokens(patches, cls, pos, B, np_)
@@ -591,7 +681,7 @@ class PatchTokensFunction(torch.autograd.Function):
     def backward(ctx, dx):
         img, w, pos = ctx.saved_tensors
         B, N, D = dx.shape
-        with torch.no_grad():
+        with torch.no_grad(), _in_mode(ctx.mode):
             dx = dx.contiguous().float()
             dtok = colsum(dx.view(B, N * D)).view(N, D)          # sum over the batch: d pos_embed[:, :N] (row 0 = d cls_token too)
             dpos = torch.zeros_like(pos)
@@ -622,6 +712,7 @@ class QueryModelFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qm, x, sd, *qmap):
+        ctx.mode = _mode()
         ta, att_ft, _ = qm(x[:, 1:, :], sd, return_token_att=True)
         ta = ta.contiguous()
         ctx.save_for_backward(x, sd, ta, *qmap)
@@ -633,12 +724,12 @@ class QueryModelFunction(torch.autograd.Function):
         x, sd, ta = ctx.saved_tensors[:3]
         B, N, D = x.shape
         n, K = N - 1, sd.shape[0]
-        with torch.no_grad():
+        with torch.no_grad(), _in_mode(ctx.mode):
             ft = x[:, 1:, :].contiguous()
             if ctx.has_map:
                 wm, bm = ctx.saved_tensors[3], ctx.saved_tensors[4]
                 wmp, bmp = _f32_wb(wm, bm)
-                q = hip.gemm(ft.view(B * n, D), wmp, bmp, n=wm.shape[0], out_dtype=torch.float32).view(B, n, -1)
+                q = _gemm(ft.view(B * n, D), wmp, bmp, n=wm.shape[0], out_dtype=torch.float32).view(B, n, -1)
             else:
                 q = ft
             dinner = dta.contiguous().float().clone() if dta is not None else torch.zeros_like(ta)
@@ -662,6 +753,7 @@ class QueryModelFunction(torch.autograd.Function):
 class LayerNormFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
+        ctx.mode = _mode()
         ctx.eps = float(eps)
         ctx.save_for_backward(x, gamma)
         y, _ = hip.layernorm(x.contiguous(), gamma.detach(), beta.detach(), eps)
@@ -671,7 +763,7 @@ class LayerNormFunction(torch.autograd.Function):
     def backward(ctx, dy):
         x, gamma = ctx.saved_tensors
         D = x.shape[-1]
-        with torch.no_grad():
+        with torch.no_grad(), _in_mode(ctx.mode):
             dx, dg, db = layernorm_bwd(x.reshape(-1, D).contiguous(), gamma.detach(), dy.reshape(-1, D).contiguous().float(), ctx.eps)
         return dx.view_as(x), dg, db, None
 
@@ -679,10 +771,7 @@ class LayerNormFunction(torch.autograd.Function):
 def vit_forward_with_grad(vit, img, space_dict, temperature, register_blk=-1):
     """VisionTransformer.forward (vit.py:281-310) under autograd -> (x, sd_img_ft_all); called by madtp_amd.vit when gradients
     are required in the fp32 mode."""
-    from . import runtime
-    if runtime.get_precision() != "fp32":
-        raise NotImplementedError("the ViT backward is built for the fp32 precision mode (runtime.precision('fp32')); "
-                                  f"current mode: {runtime.get_precision()}")
+    _check_mode("the ViT backward")
     if img.requires_grad:
         raise NotImplementedError("gradients with respect to the image are not built (the drivers never ask for them)")
     pe = vit.patch_embed.proj
@@ -710,6 +799,7 @@ class EmbeddingsFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ids, word, pos, gamma, beta, eps):
+        ctx.mode = _mode()
         y, _ = hip.bert_embed(ids.contiguous(), word, pos, gamma, beta, eps)
         ctx.eps = float(eps)
         ctx.save_for_backward(ids, word, pos, gamma)
@@ -720,7 +810,7 @@ class EmbeddingsFunction(torch.autograd.Function):
         ids, word, pos, gamma = ctx.saved_tensors
         B, L = ids.shape
         D = word.shape[1]
-        with torch.no_grad():
+        with torch.no_grad(), _in_mode(ctx.mode):
             e = (word.detach()[ids] + pos.detach()[:L]).reshape(B * L, D).contiguous()   # the LayerNorm's input, recomputed
             de, dg, db = layernorm_bwd(e, gamma.detach(), dy.reshape(B * L, D).contiguous().float(), ctx.eps)
             dpos = torch.zeros_like(pos)
@@ -734,13 +824,11 @@ class LinearFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, act):
+        ctx.mode = _mode()
         N = w.shape[0]
-        wp = w.detach()
-        if _pad(N, 128) != N:
-            wp = torch.zeros((_pad(N, 128), w.shape[1]), device=w.device, dtype=torch.float32)
-            wp[:N] = w.detach()
+        wp, bb = _f32_wb(w, b)
         x = x.contiguous().float()
-        u = hip.gemm(x, wp.contiguous(), None if b is None else b.detach().contiguous(), n=N, out_dtype=torch.float32)
+        u = _gemm(x, wp, bb, n=N, out_dtype=torch.float32)
         ctx.act, ctx.has_b = act, b is not None
         ctx.save_for_backward(x, w, u)
         return act_fwd(u, act) if act != hip.ACT_NONE else u
@@ -748,7 +836,7 @@ class LinearFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, u = ctx.saved_tensors
-        with torch.no_grad():
+        with torch.no_grad(), _in_mode(ctx.mode):
             dy = dy.contiguous().float()
             du = act_bwd(u, dy, ctx.act) if ctx.act != hip.ACT_NONE else dy
             dx = dgrad(du, w.detach()) if ctx.needs_input_grad[0] else None
@@ -791,9 +879,10 @@ class ClipPatchTokensFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, img, w, cls, pos, patch):
+        ctx.mode = _mode()
         cols = hip.patchify(img, patch, torch.float32)
         wp, _ = _f32_wb(w.reshape(w.shape[0], -1), None)
-        patches = hip.gemm(cols, wp, None, out_dtype=torch.float32, n=w.shape[0])
+        patches = _gemm(cols, wp, None, out_dtype=torch.float32, n=w.shape[0])
         B = img.shape[0]
         ctx.np_, ctx.patch = patches.shape[0] // B, patch
         ctx.save_for_backward(img, w)
@@ -803,7 +892,7 @@ class ClipPatchTokensFunction(torch.autograd.Function):
     def backward(ctx, dx):
         img, w = ctx.saved_tensors
         B, N, D = dx.shape
-        with torch.no_grad():
+        with torch.no_grad(), _in_mode(ctx.mode):
             dx = dx.contiguous().float()
             dpos = colsum(dx.view(B, N * D)).view(N, D)
             dcls = dpos[0].clone()
@@ -815,10 +904,7 @@ class ClipPatchTokensFunction(torch.autograd.Function):
 
 def clip_vision_forward_with_grad(vt, img, space_dict, temperature, max_keep):
     """clip.model.VisionTransformer.forward under autograd -> (features [B, output_dim], sd_img_ft_all); fp32 mode."""
-    from . import runtime
-    if runtime.get_precision() != "fp32":
-        raise NotImplementedError("the CLIP backward is built for the fp32 precision mode (runtime.precision('fp32')); "
-                                  f"current mode: {runtime.get_precision()}")
+    _check_mode("the CLIP backward")
     tok = ClipPatchTokensFunction.apply(img, vt.conv1.weight, vt.class_embedding, vt.positional_embedding, vt.patch_size)
     tok = LayerNormFunction.apply(tok, vt.ln_pre.weight, vt.ln_pre.bias, vt.ln_pre.eps)
     xs = tok.permute(1, 0, 2)

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import EncoderWeights, PreparedCache, param_epoch, own_modules, get_precision, encoder_call_preference, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
+from .runtime import autograd_precision as _autograd_precision, EncoderWeights, PreparedCache, param_epoch, own_modules, get_precision, encoder_call_preference, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model
 
 
@@ -80,7 +80,7 @@ class BertEmbeddings(nn.Module):
         if input_ids is None or position_ids is not None or past_key_values_length != 0:
             raise NotImplementedError("only the encoder use (input_ids, default positions) is on the pruned forward path")
         require_gpu(input_ids, "input_ids")
-        if torch.is_grad_enabled() and get_precision() == "fp32" and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and _autograd_precision() and any(p.requires_grad for p in self.parameters()):
             from .backward import EmbeddingsFunction  # training use: gradients for the two tables and the LayerNorm
             return EmbeddingsFunction.apply(input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
                                             self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
@@ -365,7 +365,7 @@ class _BertLayerBase(nn.Module):
         cross = mode == 'multimodal'
         # (a call that arrives with a pre-projected K/V cache - rank_answer / teacher-forced decoding against an EncoderKVCache -
         #  has no encoder tokens to differentiate through: it is an inference call whatever the parameters' requires_grad says)
-        if torch.is_grad_enabled() and get_precision() == "fp32" and "_kv_pre" not in self.__dict__:
+        if torch.is_grad_enabled() and _autograd_precision() and "_kv_pre" not in self.__dict__:
             encs = (list(encoder_hidden_states) if isinstance(encoder_hidden_states, (list, tuple)) else [encoder_hidden_states]) \
                 if (cross and encoder_hidden_states is not None) else []
             if (hidden.requires_grad or (token_attn is not None and token_attn.requires_grad) or any(e.requires_grad for e in encs)
@@ -508,7 +508,7 @@ class _BertEncoderBase(nn.Module):
              mode, always_query):
         sd_txt_ft_all = None
         cache = self.__dict__.pop("_kv_cache", None)  # EncoderKVCache for THIS call (MedBertModel.forward(encoder_kv_cache=...))
-        if torch.is_grad_enabled() and get_precision() == "fp32" and cache is None:
+        if torch.is_grad_enabled() and _autograd_precision() and cache is None:
             encs = [] if encoder_hidden_states is None else (list(encoder_hidden_states) if isinstance(encoder_hidden_states, (list, tuple))
                                                               else [encoder_hidden_states])
             if (hidden_states.requires_grad or (space_dict is not None and space_dict.requires_grad)
@@ -956,7 +956,7 @@ class BertLMHeadModel(nn.Module):
                                        inputs_embeds=inputs_embeds, encoder_hidden_states=encoder_hidden_states,
                                        encoder_attention_mask=encoder_attention_mask, is_decoder=is_decoder, mode=mode,
                                        space_dict=space_dict, temperature=temperature, encoder_kv_cache=encoder_kv_cache)
-        if torch.is_grad_enabled() and get_precision() == "fp32" and outputs[0].requires_grad:
+        if torch.is_grad_enabled() and _autograd_precision() and outputs[0].requires_grad:
             # training use: the LM head as autograd Functions on the exact-f32 GEMM, the label-smoothed
             # next-token cross-entropy of :1033-1042 as torch ops on the [B (L-1), V] scores
             from .backward import LayerNormFunction, LinearFunction

@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from . import hip
-from .runtime import PreparedCache, get_precision, f32_ptr, compute_dtype, dtype_code, lin_of, prepare_linear, require_gpu, as_f32_contig, to_compute
+from .runtime import autograd_precision as _autograd_precision, PreparedCache, get_precision, f32_ptr, compute_dtype, dtype_code, lin_of, prepare_linear, require_gpu, as_f32_contig, to_compute
 from .utils import DeferredAttFt, Query_model
 
 
@@ -92,7 +92,7 @@ class ResidualAttentionBlock(nn.Module):
             raise ValueError(f"sequence of {x.shape[0]} tokens exceeds the {self.attn_mask.shape[0]}-token attention mask")
         xb = as_f32_contig(x.permute(1, 0, 2))  # (B, N, C); a no-op view when x came from the previous block
         B, N, C = xb.shape
-        if torch.is_grad_enabled() and get_precision() == "fp32" and (
+        if torch.is_grad_enabled() and _autograd_precision() and (
                 xb.requires_grad or (space_dict is not None and space_dict.requires_grad) or any(p.requires_grad for p in self.parameters())):
             # training use: the block as autograd Functions around the same kernels (madtp_amd/backward.py);
             # sd_ft_all (the running att_ft sum, :241-245) carries a graph as well
@@ -171,7 +171,7 @@ class VisionTransformer(nn.Module):
     def forward(self, x: torch.Tensor, space_dict=None, temperature=0, max_keep=1):
         img = as_f32_contig(require_gpu(x, "image"))
         B = img.shape[0]
-        if torch.is_grad_enabled() and get_precision() == "fp32" and (
+        if torch.is_grad_enabled() and _autograd_precision() and (
                 (space_dict is not None and space_dict.requires_grad) or any(p.requires_grad for p in self.parameters())):
             from .backward import clip_vision_forward_with_grad  # (the tower under autograd)
             return clip_vision_forward_with_grad(self, img, space_dict, temperature, max_keep)

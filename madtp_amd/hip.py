@@ -628,13 +628,17 @@ def split_f16(src):
     return dst
 
 
-def split_f16_weight(w):
-    """f32 [n, K] -> [n, 2K] f16 planes [Q0 | Q1] of w * 2^s (max|w| * 2^s in (2^13, 2^14]); the tensor is tagged with 2^-s."""
+def split_f16_weight(w, log2_scale=None):
+    """f32 [n, K] -> [n, 2K] f16 planes [Q0 | Q1] of w * 2^s (max|w| * 2^s in (2^13, 2^14]); the tensor is tagged with 2^-s.
+    log2_scale: a caller-chosen s instead of the one derived from max|w| (which costs a host read): the backward's wgrad passes 0
+    for O(1) activations - their planes are then accurate to ~3e-8 ABSOLUTE, far inside its tolerance."""
     _req(w, torch.float32, "w")
     n, K = w.shape
-    amax = float(w.abs().max())
     s = 0
-    if amax > 0 and amax == amax and amax != float("inf"):
+    amax = float(w.abs().max()) if log2_scale is None else 0.0
+    if log2_scale is not None:
+        s = int(log2_scale)
+    elif amax > 0 and amax == amax and amax != float("inf"):
         import math
         s = 14 - math.ceil(math.log2(amax))
         s = max(-100, min(100, s))

@@ -51,6 +51,32 @@ def get_precision() -> str:
     return getattr(_state, "mode", _DEFAULT)
 
 
+# The autograd route (madtp_amd/backward.py) of the mirrors: taken in the "fp32" mode, and - opt-in, round 5 - in the "f16x3" mode,
+# whose backward runs every GEMM as three f16 MFMA products as well (MADTP_TRAIN_F16X3=1, or `with runtime.training_f16x3():`).
+# Opt-in because an f16x3 forward without torch.no_grad() is otherwise an inference call.
+_TRAIN_X3 = os.environ.get("MADTP_TRAIN_F16X3", "0") == "1"
+
+
+def autograd_precision():
+    """True when a forward in the current precision mode builds an autograd graph (given grad mode and inputs that need one)."""
+    m = get_precision()
+    return m == "fp32" or (m == "f16x3" and getattr(_state, "train_x3", _TRAIN_X3))
+
+
+class training_f16x3:
+    """context manager: forwards of the f16x3 mode inside build autograd graphs (the backward's GEMMs run as f16x3 too)"""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = getattr(_state, "train_x3", _TRAIN_X3)
+        _state.train_x3 = bool(self.on)
+
+    def __exit__(self, *a):
+        _state.train_x3 = self.prev
+
+
 def set_encoder_call_preference(v):
     """Thread-local override of MADTP_ENCODER_CALL's "auto" rule (None = no override).  The in-flight workers of
     madtp_amd.pipeline set True: with several host threads the per-layer Python path makes the forwards' progress depend on GIL

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .runtime import EncoderWeights, PreparedCache, param_epoch, own_modules, get_precision, encoder_call_preference, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
+from .runtime import autograd_precision as _autograd_precision, EncoderWeights, PreparedCache, param_epoch, own_modules, get_precision, encoder_call_preference, f32_ptr, attn_dtype, compute_dtype, dtype_code, lin_of, require_gpu, as_f32_contig, to_compute
 from .utils import Query_model, vector_gather  # noqa: F401  (re-exported like `from models.utils import *`)
 
 import os as _os
@@ -223,7 +223,7 @@ class Block(nn.Module):
             # (get_attention_map(), f32) and the block's backward leaves d loss / d attention-probabilities [B,H,N,N] in
             # get_attn_gradients() - which needs the autograd path, i.e. grad mode on and the fp32 precision mode.
             from .runtime import get_precision as _gp
-            if not (torch.is_grad_enabled() and _gp() == "fp32"):
+            if not (torch.is_grad_enabled() and _autograd_precision()):
                 raise NotImplementedError("register_hook=True captures attention gradients in the block's backward: it needs grad "
                                           "mode on and runtime.precision('fp32')")
             self.attn._hook_attn_gradients = True
@@ -244,7 +244,7 @@ class Block(nn.Module):
             # parameters that merely have requires_grad = True (the nn.Module default) do not force the autograd path there.
             wants = x.requires_grad or (token_attn is not None and token_attn.requires_grad)
             from .runtime import get_precision
-            if wants or (get_precision() == "fp32" and any(p.requires_grad for p in self.parameters())):
+            if wants or (_autograd_precision() and any(p.requires_grad for p in self.parameters())):
                 from .backward import block_forward_with_grad
                 return block_forward_with_grad(self, x, temperature if prune else 0, token_attn)
         w = self._weights()
@@ -326,7 +326,7 @@ class VisionTransformer(nn.Module):
         """_pending (extension used by BLIP_NLVR): a list - the fast-mode sum of the layers' att_ft then runs on the
         auxiliary stream and the caller makes its stream wait (handle.sync()) before sd_img_ft_all is consumed."""
         B = x.shape[0]
-        if (torch.is_grad_enabled() and get_precision() == "fp32" and type(self) is VisionTransformer
+        if (torch.is_grad_enabled() and _autograd_precision() and type(self) is VisionTransformer
                 and (any(p.requires_grad for p in self.parameters()) or (space_dict is not None and space_dict.requires_grad))):
             # training / compression use (SURVEY 8(f) rank 4): every stage of the forward as an autograd.Function around the same
             # kernels (madtp_amd/backward.py); inference callers run under torch.no_grad() as the reference's evaluate() does

@@ -34,6 +34,21 @@ def _rel(a, b):
     return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
 
 
+TRAIN_MODES = ["fp32", "f16x3"]
+
+
+def _train_mode(mode):
+    """precision context of a gradient test: the exact-f32 mode, or - round 5 - the f16x3 mode with its autograd route switched on
+    (every GEMM of the forward, the recomputed forward, dgrad and wgrad as three f16 MFMA products; same fixtures, same tolerance)"""
+    import contextlib
+    from madtp_amd import runtime
+    st = contextlib.ExitStack()
+    st.enter_context(runtime.precision(mode))
+    if mode == "f16x3":
+        st.enter_context(runtime.training_f16x3())
+    return st
+
+
 def test_transpose_colsum_act(hip):
     from madtp_amd import backward as bw
     x = _rand(197, 100, seed=1).cuda()
@@ -128,8 +143,9 @@ def test_att_ft_bwd(hip, B, n):
     assert torch.equal(d2, dinner) and torch.equal(q2, dq)  # fixed summation order
 
 
+@pytest.mark.parametrize("mode", TRAIN_MODES)
 @pytest.mark.parametrize("path", GRAD_CASES, ids=[os.path.basename(c)[:-4] for c in GRAD_CASES])
-def test_block_backward_matches_reference_grads(hip, path):
+def test_block_backward_matches_reference_grads(hip, path, mode):
     from madtp_amd import runtime, vit
     from oracle import madtp_oracle as O
     from tests import grad_case
@@ -140,7 +156,7 @@ def test_block_backward_matches_reference_grads(hip, path):
     blk = blk.cuda()
     x = c["x"].cuda().requires_grad_(True)
     ta = c["token_attn"].cuda().requires_grad_(True)
-    with runtime.precision("fp32"):
+    with _train_mode(mode):
         y = blk(x, False, 0, c["T"], ta)
         assert tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
         info = blk.last_prune
@@ -191,8 +207,9 @@ def test_block_backward_needs_fp32_mode(hip):
 VITGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "encgrad_*.npz")))
 
 
+@pytest.mark.parametrize("mode", TRAIN_MODES)
 @pytest.mark.parametrize("path", VITGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in VITGRAD_CASES])
-def test_vit_backward_matches_reference_grads(hip, path):
+def test_vit_backward_matches_reference_grads(hip, path, mode):
     """The whole pruned ViT under autograd (madtp_amd/backward.py::vit_forward_with_grad: patch embedding + CLS / position, the
     query model's logits, twelve VitBlockFunctions, final LayerNorm; fp32 mode) against the reference's own .grad of
     models/vit.py VisionTransformer.forward for all 150 parameters and space_dict (tests/golden/encgrad_*.npz), loss =
@@ -213,7 +230,7 @@ def test_vit_backward_matches_reference_grads(hip, path):
     images = synth.synth_images(B, size, seed).cuda()
     space_dict = synth.synth_tensor("space_dict", (100, 768), seed).cuda().requires_grad_(True)
     gv, hv, av = [t.cuda() for t in grad_case.vit_loss_vectors(g)]
-    with runtime.precision("fp32"):
+    with _train_mode(mode):
         y, sd_all = venc(images, space_dict=space_dict, temperature=T)
         assert y.requires_grad and tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
         # kept sets as ORIGINAL patch ids (the two sides order a layer's tokens differently)
@@ -236,8 +253,9 @@ def test_vit_backward_matches_reference_grads(hip, path):
 MEDGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "medgrad_*.npz")))
 
 
+@pytest.mark.parametrize("mode", TRAIN_MODES)
 @pytest.mark.parametrize("path", MEDGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in MEDGRAD_CASES])
-def test_med_layer_backward_matches_reference_grads(hip, path):
+def test_med_layer_backward_matches_reference_grads(hip, path, mode):
     """The MED BertLayer in mode 'text' under autograd (madtp_amd/backward.py::MedTextLayerFunction: masked self-attention, output
     LayerNorm, Reduce_token on the post-LN tokens, FFN; fp32 mode) against the reference's own .grad of models/med.py
     BertLayer.forward (hidden, token_attn, the layer's 16 parameters; tests/golden/medgrad_*.npz, ragged padding masks) and against
@@ -254,7 +272,7 @@ def test_med_layer_backward_matches_reference_grads(hip, path):
     gv, hv = c["g"].cuda(), c["h"].cuda()
     enc = c["enc"].cuda().requires_grad_(True) if c["enc"] is not None else None
     enc_mask = torch.zeros(enc.shape[0], 1, 1, enc.shape[1], device="cuda") if enc is not None else None
-    with runtime.precision("fp32"):
+    with _train_mode(mode):
         out = layer(hidden, mask, None, enc, enc_mask, None, False, mode=c["mode"], token_attn=ta, reduce_num=0, temperature=c["T"])
         y, mask_out = out[0], out[-1]
         assert y.requires_grad and tuple(y.shape) == tuple(int(v) for v in g["out_shape"])
@@ -277,8 +295,9 @@ def test_med_layer_backward_matches_reference_grads(hip, path):
 NLVRGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "nlvrgrad_*.npz")))
 
 
+@pytest.mark.parametrize("mode", TRAIN_MODES)
 @pytest.mark.parametrize("path", NLVRGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in NLVRGRAD_CASES])
-def test_nlvr_layer_backward_matches_reference_grads(hip, path):
+def test_nlvr_layer_backward_matches_reference_grads(hip, path, mode):
     """The NLVR BertLayer (the headline model's text layer: twin cross-attention to the two images' tokens, averaged below layer 6,
     merged by merge_layer from layer 6 on) under autograd against the reference's own .grad of models/nlvr_encoder.py
     BertLayer.forward (hidden, token_attn, both image sequences, all parameters; tests/golden/nlvrgrad_*.npz) and against autograd
@@ -295,7 +314,7 @@ def test_nlvr_layer_backward_matches_reference_grads(hip, path):
     enc = [e.cuda().requires_grad_(True) for e in c["enc"]]
     enc_mask = [m.cuda() for m in c["enc_mask"]]
     gv, hv = c["g"].cuda(), c["h"].cuda()
-    with runtime.precision("fp32"):
+    with _train_mode(mode):
         out = layer(hidden, mask, None, None, enc, enc_mask, None, False, mode="multimodal", token_attn=ta, reduce_num=0,
                     temperature=c["T"])
         y = out[0]
@@ -316,8 +335,9 @@ def test_nlvr_layer_backward_matches_reference_grads(hip, path):
 MODELGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "modelgrad_nlvr_*.npz")))
 
 
+@pytest.mark.parametrize("mode", TRAIN_MODES)
 @pytest.mark.parametrize("path", MODELGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in MODELGRAD_CASES])
-def test_nlvr_model_backward_matches_reference_grads(hip, path):
+def test_nlvr_model_backward_matches_reference_grads(hip, path, mode):
     """loss.backward() through the headline model on the HIP path (BLIP_NLVR.forward(train=False) in the fp32 mode with grad mode
     on: pruned ViT on both images, BERT embeddings, twelve NLVR layers with twin cross-attention, cls_head - every stage an
     autograd.Function of madtp_amd/backward.py) against the reference's own .grad of models/blip_nlvr.py for all 579 parameters
@@ -332,7 +352,7 @@ def test_nlvr_model_backward_matches_reference_grads(hip, path):
         p_.grad = None
     images, text, targets = harness.nlvr_inputs(B, size, L, seed, "cuda", pad_tail=int(g["pad_tail"]))
     c = torch.from_numpy(synth.uniform_pm1("nlvrgrad_c", B * 2, seed).reshape(B, 2)).cuda()
-    with runtime.precision("fp32"):
+    with _train_mode(mode):
         logits = model(images, text, targets, temperature=T, train=False)
         assert logits.requires_grad and (logits.detach().cpu() - torch.from_numpy(g["logits"])).abs().max().item() < 1e-4
         trace = {"vit": [harness._cpu_info(b.last_prune) for b in model.visual_encoder.blocks],
@@ -349,8 +369,9 @@ def test_nlvr_model_backward_matches_reference_grads(hip, path):
 TRAINSTEP_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "trainstep_nlvr_*.npz")))
 
 
+@pytest.mark.parametrize("mode", TRAIN_MODES)
 @pytest.mark.parametrize("path", TRAINSTEP_CASES, ids=[os.path.basename(c)[:-4] for c in TRAINSTEP_CASES])
-def test_nlvr_training_step_matches_reference(hip, path):
+def test_nlvr_training_step_matches_reference(hip, path, mode):
     """One compression training step of the headline model on the HIP path (compress_nlvr_dtp.py:52-56): BLIP_NLVR.forward(
     train=True) -> (loss_ori, loss_fdt), loss = loss_ori + 0.1 loss_fdt, backward - both losses and the gradients of all 579
     parameters against the reference's own (model.eval(): the mirror has no dropout); then three AdamW steps on the same batch
@@ -365,7 +386,7 @@ def test_nlvr_training_step_matches_reference(hip, path):
         p_.grad = None
     images, text, _ = harness.nlvr_inputs(B, size, L, seed, "cuda", pad_tail=int(g["pad_tail"]))
     targets = (torch.arange(B) % 2).cuda()
-    with runtime.precision("fp32"):
+    with _train_mode(mode):
         lo, lf = model(images, text, targets, temperature=T, train=True)
         assert abs(float(lo.detach()) - float(g["loss_ori"])) < 1e-4 and abs(float(lf.detach()) - float(g["loss_fdt"])) < 1e-4
         (lo + 0.1 * lf).backward()
@@ -387,8 +408,9 @@ def test_nlvr_training_step_matches_reference(hip, path):
 DECGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "decgrad_*.npz")))
 
 
+@pytest.mark.parametrize("mode", TRAIN_MODES)
 @pytest.mark.parametrize("path", DECGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in DECGRAD_CASES])
-def test_decoder_backward_matches_reference_grads(hip, path):
+def test_decoder_backward_matches_reference_grads(hip, path, mode):
     """The answer / caption decoder's training forward on the HIP path (BertLMHeadModel.forward with labels, reduction='none':
     embeddings, twelve MED layers with the CAUSAL self-attention mask and cross-attention to the question states, LM head with the
     tied output embedding, label-smoothed next-token cross-entropy) under autograd in the fp32 mode: per-sequence losses and the
@@ -408,7 +430,7 @@ def test_decoder_backward_matches_reference_grads(hip, path):
         p_.grad = None
     enc = c["enc"].cuda().requires_grad_(True)
     B = c["ids"].shape[0]
-    with runtime.precision("fp32"):
+    with _train_mode(mode):
         out = model(c["ids"].cuda(), attention_mask=c["att"].cuda(), encoder_hidden_states=enc,
                     encoder_attention_mask=c["enc_att"].cuda(), labels=c["labels"].cuda(), return_dict=True, reduction='none')
         assert (out.loss.detach().cpu() - torch.from_numpy(g["loss"])).abs().max().item() < 1e-3 * float(np.abs(g["loss"]).max())
@@ -427,8 +449,9 @@ def test_decoder_backward_matches_reference_grads(hip, path):
 VQATRAIN_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "trainstep_vqa_*.npz")))
 
 
+@pytest.mark.parametrize("mode", TRAIN_MODES)
 @pytest.mark.parametrize("path", VQATRAIN_CASES, ids=[os.path.basename(c)[:-4] for c in VQATRAIN_CASES])
-def test_vqa_training_step_matches_reference(hip, path):
+def test_vqa_training_step_matches_reference(hip, path, mode):
     """One training step of BLIP_VQA on the HIP path (blip_vqa.py:57-115: pruned ViT, question encoder = MED in mode 'multimodal'
     with text pruning, answer decoder teacher-forced on the question states repeated n[b] times; loss_vqa + 0.1 loss_fdt) in the
     fp32 mode: both losses and the gradients of all 788 parameters against the reference's own."""
@@ -446,7 +469,7 @@ def test_vqa_training_step_matches_reference(hip, path):
     for p_ in model.parameters():
         p_.requires_grad_(True)
         p_.grad = None
-    with runtime.precision("fp32"):
+    with _train_mode(mode):
         lv, lf = model(c["images"].cuda(), {"input_ids": c["ids"].cuda(), "attention_mask": c["att"].cuda()},
                        {"input_ids": c["a_ids"].cuda(), "attention_mask": c["a_att"].cuda()}, temperature=c["T"], train=True,
                        n=c["n_list"], weights=c["weights"])
@@ -466,8 +489,9 @@ def test_vqa_training_step_matches_reference(hip, path):
 CAPTRAIN_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "trainstep_cap_*.npz")))
 
 
+@pytest.mark.parametrize("mode", TRAIN_MODES)
 @pytest.mark.parametrize("path", CAPTRAIN_CASES, ids=[os.path.basename(c)[:-4] for c in CAPTRAIN_CASES])
-def test_caption_training_step_matches_reference(hip, path):
+def test_caption_training_step_matches_reference(hip, path, mode):
     """One training step of the caption model on the HIP path (BLIP_Decoder.forward(train=True), models/blip.py:111-158: pruned ViT
     + decoder teacher-forced on the caption, prompt and padding masked out of the targets) in the fp32 mode: loss_lm and the
     gradients of all 472 parameters against the reference's own."""
@@ -485,7 +509,7 @@ def test_caption_training_step_matches_reference(hip, path):
     for p_ in model.parameters():
         p_.requires_grad_(True)
         p_.grad = None
-    with runtime.precision("fp32"):
+    with _train_mode(mode):
         lm, lf = model(synth.synth_images(B, size, seed).cuda(), {"input_ids": torch.from_numpy(g["ids"]).cuda(),
                                                                   "attention_mask": torch.from_numpy(g["att"]).cuda()},
                        temperature=float(g["temperature"]), train=True)
@@ -571,8 +595,9 @@ def test_clip_text_block_backward_matches_reference_grads(hip, path):
 CLIPVITGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clipvitgrad_*.npz")))
 
 
+@pytest.mark.parametrize("mode", TRAIN_MODES)
 @pytest.mark.parametrize("path", CLIPVITGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in CLIPVITGRAD_CASES])
-def test_clip_vision_backward_matches_reference_grads(hip, path):
+def test_clip_vision_backward_matches_reference_grads(hip, path, mode):
     """CLIP's vision tower (encode_image) under autograd on the HIP path: conv1 + class / positional embedding, ln_pre, twelve
     pruned blocks with their own query models, ln_post, proj - features, per-layer lengths and the gradients of all 176 parameters
     + space_dict against the reference's own."""
@@ -589,7 +614,7 @@ def test_clip_vision_backward_matches_reference_grads(hip, path):
         p_.requires_grad_(True)
         p_.grad = None
     sd = c["space_dict"].cuda().requires_grad_(True)
-    with runtime.precision("fp32"):
+    with _train_mode(mode):
         feat, sd_all = vt(c["images"].cuda(), sd, c["T"], 1)
         assert feat.requires_grad and (feat.detach().cpu() - torch.from_numpy(g["features"])).abs().max().item() < 1e-4
         lens = [int(b.last_prune["indices"].shape[1]) + 2 if (b.last_prune and b.last_prune.get("pruned")) else None

@@ -1,4 +1,5 @@
-"""Training-step timing of the headline model on the HIP path (fp32 precision mode, madtp_amd/backward.py): forward(train=True),
+"""Training-step timing of the headline model on the HIP path (madtp_amd/backward.py; MADTP_TRAIN_PRECISION=fp32 (default) or
+f16x3 - round 5: every GEMM of the step as three f16 MFMA products): forward(train=True),
 loss_ori + 0.1 loss_fdt, backward, AdamW step - next to the inference forward of the same mode.  Not a BASELINE metric (the
 reference publishes none for training); recorded for DESIGN.md section 5.   python tools/train_step_bench.py [B ...]"""
 import os
@@ -13,12 +14,13 @@ from madtp_amd import build, harness, hip, runtime  # noqa: E402
 build.build(verbose=False)
 hip.load()
 T = 8.612223847001898
+MODE = os.environ.get("MADTP_TRAIN_PRECISION", "fp32")
 model = harness.build_nlvr(224, 0, "cuda")
 opt = torch.optim.AdamW(model.parameters(), lr=1e-6, weight_decay=0.05)
 for B in [int(a) for a in sys.argv[1:]] or [4, 16, 64]:
     images, text, _ = harness.nlvr_inputs(B, 224, 20, 0, "cuda")
     targets = (torch.arange(B) % 2).cuda()
-    with runtime.precision("fp32"):
+    with runtime.precision(MODE), runtime.training_f16x3(MODE == "f16x3"):
         with torch.no_grad():
             for _ in range(2):
                 model(images, text, targets, temperature=T, train=False)
@@ -41,5 +43,5 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 16, 64]:
         losses = [step() for _ in range(3)]
         torch.cuda.synchronize()
         t_tr = (time.time() - t0) / 3
-    print(f"B={B:3d} samples ({2 * B} images): inference forward (fp32 mode) {t_inf * 1e3:8.1f} ms, training step {t_tr * 1e3:8.1f} ms "
+    print(f"B={B:3d} samples ({2 * B} images): inference forward ({MODE} mode) {t_inf * 1e3:8.1f} ms, training step {t_tr * 1e3:8.1f} ms "
           f"({2 * B / t_tr:7.1f} images/s), peak memory {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB, loss_ori {losses[0]:.4f} -> {losses[-1]:.4f}")
