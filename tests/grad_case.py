@@ -7,8 +7,8 @@ from madtp_amd import specs, synth
 from oracle import madtp_oracle as O
 
 
-def grad_sample_index(numel, n=1024):
-    return (np.arange(min(n, numel), dtype=np.int64) * 7919) % numel
+def grad_sample_index(numel, n=1024, stride=7919):
+    return (np.arange(min(n, numel), dtype=np.int64) * stride) % numel
 
 
 def build(g):
@@ -42,6 +42,11 @@ def check_against_fixture(g, grads, rtol, what):
             scale = max(scale, float(np.abs(g[f"g_{name[:-8]}query.bias_sample"]).max()))
         err = float((got - ref).abs().max()) / scale
         assert err < rtol, f"{what}: grad {name}: sampled entries differ by {err:.3e} of their maximum (tolerance {rtol})"
+        if f"g_{name}_bigsample" in g.files:  # the largest parameters of a model-level fixture: 4096 more entries each
+            refb = torch.from_numpy(g[f"g_{name}_bigsample"])
+            gotb = t[torch.from_numpy(grad_sample_index(t.numel(), int(g["nsample_big"]), stride=104729))]
+            errb = float((gotb - refb).abs().max()) / max(float(refb.abs().max()), scale)
+            assert errb < rtol, f"{what}: grad {name}: the 4096-entry sample differs by {errb:.3e} of its maximum (tolerance {rtol})"
         nrm = float(t.double().norm())
         nref = float(g[f"g_{name}_norm"])
         if name.endswith("key.bias"):

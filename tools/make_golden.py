@@ -159,13 +159,18 @@ def nlvr_model_grad_case(name, B, size, L, temperature, seed=0, pad_tail=0, nsam
     if train:
         rec["loss_ori"], rec["loss_fdt"] = np.float64(loss_ori.item()), np.float64(loss_fdt.item())
     n = 0
-    for k, v in model.named_parameters():
-        if v.grad is None:
-            continue
+    with_grad = [(k, v) for k, v in model.named_parameters() if v.grad is not None]
+    # the three LARGEST parameters (word embeddings, the first MLP weights): 4096 sampled entries each on top of the common
+    # sample, so that a localised error in a 23 M-entry gradient cannot hide behind its norm (hygiene)
+    big = {k for k, _ in sorted(with_grad, key=lambda kv: -kv[1].numel())[:3]}
+    rec["nsample_big"] = 4096
+    for k, v in with_grad:
         flat = v.grad.detach().reshape(-1)
         idx = grad_sample_index(flat.numel(), nsample)
         rec[f"g_{k}_sample"] = flat[torch.from_numpy(idx)].numpy()
         rec[f"g_{k}_norm"] = np.float64(flat.double().norm().item())
+        if k in big:
+            rec[f"g_{k}_bigsample"] = flat[torch.from_numpy(grad_sample_index(flat.numel(), 4096, stride=104729))].numpy()
         n += 1
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
     print(f"[{name}] T={temperature} vit_lens={lens_v} txt_lens={lens_t} logits={logits.detach().numpy().round(4).tolist()} "
@@ -429,9 +434,9 @@ def vit_case(name, B, size, temperature, seed=0):
     print(f"[{name}] size={size} T={temperature} vit_lens={lens}")
 
 
-def grad_sample_index(numel, n=1024):
+def grad_sample_index(numel, n=1024, stride=7919):
     """deterministic sample positions of a flattened gradient tensor (shared with tests/test_oracle_golden.py and the GPU test)"""
-    return (np.arange(min(n, numel), dtype=np.int64) * 7919) % numel
+    return (np.arange(min(n, numel), dtype=np.int64) * stride) % numel
 
 
 def vit_block_grad_case(name, B, size, temperature, layer=0, seed=0):
