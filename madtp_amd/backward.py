@@ -80,7 +80,10 @@ def _cached(key, tensors, build):
     hit = _CACHE.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
-    val = build()
+    # (the entry holds its sources alive, so the same addresses and shapes ARE the same parameters at an older version: a builder
+    #  that asks for it gets the previous value - the f16-split scale of a weight is reused across optimizer steps, runtime.SCALE_REUSE)
+    same = hit is not None and len(hit[0]) == len(ver) and all(a[0] == b[0] and a[2] == b[2] for a, b in zip(hit[0], ver))
+    val = build(hit[1] if same else None) if getattr(build, "_takes_prev", False) else build()
     if len(_CACHE) > 4096:
         _CACHE.clear()
     # the entry holds the source tensors: while it lives their storage cannot be recycled for another tensor at the same address
@@ -89,13 +92,31 @@ def _cached(key, tensors, build):
     return val
 
 
-def _planes(w32):
-    """f16-split weight planes of a (padded) f32 weight tensor, attached to it (the tensor itself is a cached object)."""
+def _planes(w32, prev=None):
+    """f16-split weight planes of a (padded) f32 weight tensor, attached to it (the tensor itself is a cached object).  prev: the
+    tensor this one replaces in its cache entry - its scale is reused (no host read of max|w|) up to runtime.SCALE_REUSE times."""
     pl = getattr(w32, "_madtp_x3_planes", None)
     if pl is None:
-        pl = hip.split_f16_weight(w32)
-        w32._madtp_x3_planes = pl
+        from .runtime import SCALE_REUSE
+        s, age = None, 0
+        pp = getattr(prev, "_madtp_x3_planes", None) if prev is not None else None
+        if pp is not None and getattr(prev, "_madtp_x3_age", SCALE_REUSE) < SCALE_REUSE and pp.shape == (w32.shape[0], 2 * w32.shape[1]):
+            s, age = pp._madtp_log2_scale, prev._madtp_x3_age + 1
+        pl = hip.split_f16_weight(w32, log2_scale=s)
+        w32._madtp_x3_planes, w32._madtp_x3_age = pl, age
     return pl
+
+
+def _versioned(make):
+    """builder for _cached: a (padded / concatenated / transposed) f32 weight copy that, in the f16x3 mode, carries its split planes
+    from the start - prepared with the previous version's scale"""
+    def build(prev=None):
+        t = make()
+        if _x3():
+            _planes(t, prev)
+        return t
+    build._takes_prev = True
+    return build
 
 
 def _gemm(a, w, bias=None, n=None, residual=None, out_dtype=torch.float32):
@@ -120,7 +141,7 @@ def dgrad(dy, weight, residual=None):
         dyp[:, :N] = dy
         dy = dyp
     # [Kpad, Np]: the GEMM's "weight" with K' = N contiguous - once per parameter version (was: one transpose per backward call)
-    wt = _cached(("wt", weight.data_ptr(), Np), [weight], lambda: transpose_pad(weight, Np, _pad(K, 128)))
+    wt = _cached(("wt", weight.data_ptr(), Np, x3), [weight], _versioned(lambda: transpose_pad(weight, Np, _pad(K, 128))))
     if x3:
         return hip.gemm(hip.split_f16(dy.contiguous()), _planes(wt), None, residual, out_dtype=torch.float32, n=K)
     return hip.gemm(dy, wt, n=K, out_dtype=torch.float32, residual=residual)
@@ -239,13 +260,13 @@ def _pad_w(w):
 
 def _f32_lin(linear):
     """(weight padded to 128 rows, bias) of an nn.Linear for the recomputed forward's GEMM (cached per parameter version)."""
-    w = _cached(("pw", linear.weight.data_ptr()), [linear.weight], lambda: _fresh(_pad_w(linear.weight)))
+    w = _cached(("pw", linear.weight.data_ptr(), _x3()), [linear.weight], _versioned(lambda: _fresh(_pad_w(linear.weight))))
     return w, (None if linear.bias is None else linear.bias.detach().contiguous())
 
 
 def _f32_wb(w, b):
     """(weight padded to 128 rows, bias) of a Linear given as tensors (cached per parameter version)."""
-    wp = _cached(("pw", w.data_ptr()), [w], lambda: _fresh(_pad_w(w)))
+    wp = _cached(("pw", w.data_ptr(), _x3()), [w], _versioned(lambda: _fresh(_pad_w(w))))
     return wp, (None if b is None else b.detach().contiguous())
 
 
@@ -257,7 +278,7 @@ def _fresh(t):
 def _cat_wb(tag, linears):
     """[w0; w1; ...] and [b0; b1; ...] of Linears that run as one fused projection (cached per parameter version)."""
     ws = [l.weight for l in linears]
-    w = _cached(("cat", tag) + tuple(x.data_ptr() for x in ws), ws, lambda: torch.cat([x.detach() for x in ws], 0).contiguous())
+    w = _cached(("cat", tag, _x3()) + tuple(x.data_ptr() for x in ws), ws, _versioned(lambda: torch.cat([x.detach() for x in ws], 0).contiguous()))
     b = torch.cat([l.bias.detach() for l in linears], 0).contiguous()
     return w, b
 

@@ -645,6 +645,7 @@ def split_f16_weight(w, log2_scale=None):
     dst = torch.empty((n, 2 * K), device=w.device, dtype=torch.float16)
     _check(load().madtp_split_f16_weight(_p(w), K, _p(dst), n, K, float(2.0 ** s), _stream()), "madtp_split_f16_weight")
     dst._madtp_w_scale = float(2.0 ** -s)
+    dst._madtp_log2_scale = s
     return dst
 
 

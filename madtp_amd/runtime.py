@@ -128,11 +128,12 @@ class precision:
 
 class Lin:
     """A Linear prepared for madtp_gemm: weight padded to a multiple of 128 rows in the compute dtype (float16: the three
-    f16 planes of w * 2^s side by side, the tensor tagged with its accumulator scale 2^-s), f32 bias."""
-    __slots__ = ("w", "b", "n")
+    f16 planes of w * 2^s side by side, the tensor tagged with its accumulator scale 2^-s), f32 bias.
+    log2_scale / age: the s of an f16-split weight and how many re-preparations it has served (training: see prepare_linear)."""
+    __slots__ = ("w", "b", "n", "log2_scale", "age")
 
-    def __init__(self, w, b, n):
-        self.w, self.b, self.n = w, b, n
+    def __init__(self, w, b, n, log2_scale=None, age=0):
+        self.w, self.b, self.n, self.log2_scale, self.age = w, b, n, log2_scale, age
 
 
 def _pad_rows(w):
@@ -145,21 +146,34 @@ def _pad_rows(w):
     return out
 
 
-def prepare_linear(weights, biases, dtype):
-    """weights: list of [out_i, in] tensors concatenated along out (fused projections); biases likewise (or None)."""
+# An f16-split weight is stored as w * 2^s with max|w| 2^s in (2^13, 2^14]: s comes from a host read of max|w|.  In TRAINING every
+# optimizer step re-prepares every weight (their versions change) - ~400 host reads per step.  The scale only has to keep
+# max|w| 2^s inside the f16 range with the low plane clear of the subnormals, which a slowly moving weight does for many steps: a
+# re-preparation of the SAME cache entry reuses the previous s up to SCALE_REUSE times (two binades of headroom above 2^14; a
+# weight that outgrows them raises the library's range flag instead of going wrong silently).
+SCALE_REUSE = 64
+
+
+def prepare_linear(weights, biases, dtype, prev=None):
+    """weights: list of [out_i, in] tensors concatenated along out (fused projections); biases likewise (or None).
+    prev: the Lin this one replaces in its cache entry (same parameters, an older version) or None."""
     w = torch.cat([t.detach().reshape(t.shape[0], -1).float() for t in weights], 0) if len(weights) > 1 \
         else weights[0].detach().reshape(weights[0].shape[0], -1).float()
     n = w.shape[0]
     w = _pad_rows(w)
+    s, age = None, 0
     if dtype == torch.bfloat16:
         w = hip.cast_lp_weight(w.contiguous())
     elif dtype == torch.float16:
-        w = hip.split_f16_weight(w.contiguous())
+        if prev is not None and prev.log2_scale is not None and prev.age < SCALE_REUSE and prev.w.shape[0] == w.shape[0]:
+            s, age = prev.log2_scale, prev.age + 1
+        w = hip.split_f16_weight(w.contiguous(), log2_scale=s)
+        s = w._madtp_log2_scale
     b = None
     if biases is not None and all(bb is not None for bb in biases):
         b = torch.cat([bb.detach().float() for bb in biases], 0).contiguous() if len(biases) > 1 \
             else biases[0].detach().float().contiguous()
-    return Lin(w, b, n)
+    return Lin(w, b, n, s, age)
 
 
 class PreparedCache:
@@ -176,7 +190,10 @@ class PreparedCache:
         hit = self._store.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]
-        val = builder()
+        # a builder that takes the entry's previous value (same key, older parameter versions) may reuse parts of it
+        prev = hit[1] if (hit is not None and hit[0][0] == sig[0] and len(hit[0]) == len(sig)
+                          and all((a is None) == (b is None) and (a is None or (a[0] == b[0] and a[2] == b[2])) for a, b in zip(hit[0][1:], sig[1:]))) else None
+        val = builder(prev) if getattr(builder, "_takes_prev", False) else builder()
         self._store.pop(key, None)
         self._store[key] = (sig, val)
         while len(self._store) > self.MAX_ENTRIES:  # bounded: keys may embed id() of caller tensors (a fresh space_dict per call)
@@ -190,8 +207,10 @@ def lin_of(cache, key, linears, dtype=None):
     params = []
     for l in linears:
         params += [l.weight, l.bias]
-    return cache.get((key, dtype), params,
-                     lambda: prepare_linear([l.weight for l in linears], [l.bias for l in linears], dtype))
+    def build(prev=None):
+        return prepare_linear([l.weight for l in linears], [l.bias for l in linears], dtype, prev if isinstance(prev, Lin) else None)
+    build._takes_prev = True
+    return cache.get((key, dtype), params, build)
 
 
 # Parameter RE-ASSIGNMENT (`blk.mlp.fc1.weight = nn.Parameter(...)`, `load_state_dict(assign=True)`) or a replaced sub-module
