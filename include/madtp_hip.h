@@ -488,6 +488,17 @@ int madtp_bert_encoder_async(const madtp_bert_layer_w* const* layers, int n_laye
                              const float* enc_mask1, const void* const* kv_pre0, const void* const* kv_pre1, const int32_t* kv_index,
                              int kv_ld, int32_t* dims_dev, int32_t* dims_host, void* stream);
 
+/* Incremental decoding (models/med.py:1071-1094: prepare_inputs_for_generation feeds the last token only once past_key_values
+ * exist; the reference caches every layer's self-attention key / value): ONE new token per row through all decoder layers.
+ * layers: MED layers with single cross-attention (madtp_bert_layer_w.cross == 1); x [rows, dim] f32 = the embedded new tokens at
+ * position t; kv_cache [n_layers][rows][Lmax][2 dim] in the attention dtype (bf16 / f16 in the fast modes, f32 otherwise): this
+ * call appends position t of every row and attends to positions 0..t; the caller re-orders the rows between steps
+ * (_reorder_cache :1091-1094); kv_pre[l] / kv_index / kv_ld / Nk: the cached cross-attention [k|v] of the encoder states as for
+ * madtp_bert_encoder; y [rows, dim] f32; ws: madtp_bert_layer_workspace(rows, 1, Nk, ...) bytes.  Lmax <= 256. */
+int madtp_bert_decode_step(const madtp_bert_layer_w* const* layers, int n_layers, const float* x, void* kv_cache, int rows, int t,
+                           int Lmax, const void* const* kv_pre, const int32_t* kv_index, int kv_ld, int Nk, float* y, void* ws,
+                           size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Answer ranking with the teacher-forced decoder (inference half): models/med.py BertLMHeadModel
  * :1036-1042 and models/blip_vqa.py rank_answer :166-172.  The decoder itself is madtp_bert_layer with self_mask_qk set, the

@@ -1041,11 +1041,41 @@ class BertLMHeadModel(nn.Module):
         sel = cache.select(torch.arange(B, device=dev).repeat_interleave(num_beams))
         V = self.cls.predictions.decoder.weight.shape[0]
 
-        def step(ids):
+        def step_full(ids):
             outputs, _ = self.bert(ids, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
                                    is_decoder=True, mode='multimodal', encoder_kv_cache=sel)
             _, padded = self.prediction_scores(outputs[0][:, -1:, :].contiguous())
             return padded[:, 0, :]
+
+        # Incremental decoding (med.py:1071-1094; round 5): one new token per beam and step through madtp_bert_decode_step against
+        # the layers' self-attention K/V cache [layers, rows, Lmax, 2 D]; the prompt is fed token by token (<= 4 tokens at the
+        # reference's call sites), the beams' re-ordering is a gather over the cache rows.  MADTP_DECODE_CACHE=0 (or a decoder
+        # whose layers the step does not take) re-runs the whole prefix every step.
+        rows = B * num_beams
+        enc = self.bert.encoder
+        layers = list(enc.layer)
+        use_cache = (os.environ.get("MADTP_DECODE_CACHE", "1") != "0" and max_length <= 256
+                     and all(type(l) is enc.layer_cls and getattr(l, "has_cross", hasattr(l, "crossattention")) for l in layers))
+        state = {"t": 0, "cache": None}
+
+        def step_cached(ids, beam_src=None):
+            emb = self.bert.embeddings
+            D = emb.word_embeddings.weight.shape[1]
+            if state["cache"] is None:
+                state["cache"] = torch.zeros((len(layers), rows, max_length, 2 * D), device=dev, dtype=attn_dtype())
+            elif beam_src is not None:
+                state["cache"] = state["cache"].index_select(1, beam_src)  # _reorder_cache (:1091-1094)
+            ws = enc._encoder_weights()
+            y = None
+            while state["t"] < ids.shape[1]:  # the prompt on the first call, one token afterwards
+                t = state["t"]
+                x, _ = hip.bert_embed(ids[:, t:t + 1].contiguous(), emb.word_embeddings.weight, emb.position_embeddings.weight[t:],
+                                      emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps, lp=None)
+                y = hip.bert_decode_step(ws, x.view(rows, D), state["cache"], t, sel.kv, sel.index, 0, sel.Nk)
+                state["t"] = t + 1
+            _, padded = self.prediction_scores(y.view(rows, 1, D))
+            return padded[:, 0, :]
+        step = step_cached if use_cache else step_full
         prompt = input_ids.to(dev).to(torch.int64).repeat_interleave(num_beams, dim=0)
         with torch.no_grad():
             return generation.beam_search(step, prompt, num_beams, max_length, min_length, eos_token_id, pad_token_id, V,

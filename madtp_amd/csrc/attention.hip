@@ -41,6 +41,8 @@ struct AttnArgs {
     unsigned* hm_ws; int* hm_tick;
     // sync-free encoder path (self-attention): Nq = Nk = *n_dev tokens per sample, read by the kernel; the launch geometry and the
     // key-tile instantiation are the host's worst case (the unpruned sequence)
+    int kvb;        // rows from one sample's K/V block to the next (= Nk for dense [B * Nk, ld] operands; the decoder's self-attention
+                    // cache [rows, Lmax, 2 dim] passes Lmax: a step attends to the first Nk positions of every row's block)
     float* o_part;  // attn_bf16_large_kernel<.., HV = 2>: f32 scratch [B, Nq, H, 64] (the first key half's P.V sums)
     const int32_t* n_dev;
     int dev_q_only;  // cross-attention on the sync-free path: *n_dev is the number of QUERY tokens per sample, Nk stays the host's
@@ -48,7 +50,7 @@ struct AttnArgs {
 #define ATTN_DEV_DIMS(a)                                   \
     if ((a).n_dev) {                                       \
         (a).Nq = *(a).n_dev;                               \
-        if (!(a).dev_q_only) (a).Nk = (a).Nq;              \
+        if (!(a).dev_q_only) { (a).Nk = (a).Nq; (a).kvb = (a).Nq; } \
         (a).nrt = ((a).Nq + 15) / 16;                      \
     }
 
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             kreg[i] = make_uint4(0, 0, 0, 0);
             vreg[i] = make_uint4(0, 0, 0, 0);
             if (idx < NKP * CPR && row < a.Nk) {
-                const size_t grow = (size_t)bkv * a.Nk + row;
+                const size_t grow = (size_t)bkv * a.kvb + row;
                 kreg[i] = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * ESZ + c * 16);
                 vreg[i] = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * ESZ + c * 16);
             }
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                 const int row = idx / CPR, c = idx % CPR;
                 uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
                 if (row < a.Nk) {
-                    const size_t grow = (size_t)bkv * a.Nk + row;
+                    const size_t grow = (size_t)bkv * a.kvb + row;
                     kv = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * ESZ + c * 16);
                     vv = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * ESZ + c * 16);
                 }
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) void attn_f16s_kernel(AttnArgs a) {
             kreg[i] = make_uint4(0, 0, 0, 0);
             vreg[i] = make_uint4(0, 0, 0, 0);
             if (row < a.Nk) {
-                const size_t grow = (size_t)bkv * a.Nk + row;
+                const size_t grow = (size_t)bkv * a.kvb + row;
                 kreg[i] = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * 4 + c * 16);
                 vreg[i] = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * 4 + c * 16);
             }
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(256) void attn_f16s_kernel(AttnArgs a) {
                 const int row = idx >> 4, c = idx & 15;
                 uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
                 if (row < a.Nk) {
-                    const size_t grow = (size_t)bkv * a.Nk + row;
+                    const size_t grow = (size_t)bkv * a.kvb + row;
                     kv = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * 4 + c * 16);
                     vv = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * 4 + c * 16);
                 }
@@ -687,7 +689,7 @@ __global__ __launch_bounds__(256 * HS * RB, (HS == 1 && RB == 1) ? 2 : 1) void a
         int row = (is_v ? grp - NKP / 8 : grp) * 8 + sub;
         const int chunk = is_v ? (pos ^ (((row >> 1) & 3) << 1)) : (pos ^ (row & 7));
         row = row < a.Nk ? row : a.Nk - 1;
-        srcb[i] = (is_v ? a.v + ((size_t)bkv * a.Nk + row) * a.ldv * 2 : a.k + ((size_t)bkv * a.Nk + row) * a.ldk * 2) + chunk * 16;
+        srcb[i] = (is_v ? a.v + ((size_t)bkv * a.kvb + row) * a.ldv * 2 : a.k + ((size_t)bkv * a.kvb + row) * a.ldk * 2) + chunk * 16;
     }
     auto stage_head = [&](int h, int st) {
         char* base = ring + st * STAGE;
@@ -1095,7 +1097,7 @@ __global__ __launch_bounds__(256, 1) void attn_large_kernel(AttnArgs a) {
             const int row = idx / CPR, ch = idx % CPR, j = c * CK + row;
             uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
             if (j < a.Nk) {
-                const size_t grow = (size_t)bkv * a.Nk + j;
+                const size_t grow = (size_t)bkv * a.kvb + j;
                 kv = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * ESZ + ch * 16);
                 if (with_v) vv = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * ESZ + ch * 16);
             }
@@ -1283,7 +1285,7 @@ __global__ __launch_bounds__(256, 1) void attn_large_f16s_kernel(AttnArgs a) {  
                 kr[i] = make_uint4(0, 0, 0, 0);
                 vr[i] = make_uint4(0, 0, 0, 0);
                 if (j < a.Nk) {
-                    const size_t grow = (size_t)bkv * a.Nk + j;
+                    const size_t grow = (size_t)bkv * a.kvb + j;
                     kr[i] = *(const uint4*)(a.k + (grow * a.ldk + h * 64) * 4 + ch * 16);
                     if (with_v) vr[i] = *(const uint4*)(a.v + (grow * a.ldv + h * 64) * 4 + ch * 16);
                 }
@@ -1557,9 +1559,9 @@ __global__ __launch_bounds__(256, (STG == 2 && (NCH <= 5 || !SCORES || HV == 2))
     // a scalar offset - no per-step address arithmetic on the VALU (it was ~150 of the ~450 instructions of a chunk step) - and
     // rows >= Nk fall outside the sample's descriptor and read as zeros (their P is 0 / masked).
     const int sub = lane >> 3, pos = lane & 7;
-    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)(a.k + (size_t)bkv * a.Nk * a.ldk * 2), 0,
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)(a.k + (size_t)bkv * a.kvb * a.ldk * 2), 0,
                                                                           (unsigned)((size_t)a.Nk * a.ldk * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)(a.v + (size_t)bkv * a.Nk * a.ldv * 2), 0,
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)(a.v + (size_t)bkv * a.kvb * a.ldv * 2), 0,
                                                                           (unsigned)((size_t)a.Nk * a.ldv * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)(a.q + (size_t)b * a.Nq * a.ldq * 2), 0,
                                                                           (unsigned)((size_t)a.Nq * a.ldq * 2), 0x00020000);
@@ -2167,7 +2169,7 @@ extern "C" int madtp_attention(const void* q, const void* k, const void* v, void
 static int attention_launch(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
                             const float* add_mask, const float* mask_qk, int ld_mask_qk, float* colsum_part, float* p0,
                             float* onorm, int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale,
-                            int io_dtype, void* stream, const int32_t* n_dev = nullptr, int dev_q_only = 0);
+                            int io_dtype, void* stream, const int32_t* n_dev = nullptr, int dev_q_only = 0, int kv_block_rows = 0);
 
 int madtp_i_attention(const void* q, const void* k, const void* v, void* out, float* colsum_part, float* p0, float* onorm, int B,
                       int H, int N, int ldq, int ldk, int ldv, int ldo, float scale, int io_dtype, const int32_t* n_dev,
@@ -2183,6 +2185,13 @@ int madtp_i_attention_mask(const void* q, const void* k, const void* v, void* ou
     if (N > 256) return MADTP_E_SHAPE;
     return attention_launch(q, k, v, nullptr, out, add_mask, nullptr, 0, colsum_part, p0, onorm, B, H, N, N, ldq, ldk, ldv, ldo, scale,
                             io_dtype, stream, n_dev);
+}
+// attention of Nq queries per sample against the first Nk rows of that sample's K/V BLOCK of kv_block_rows rows (the decoder's
+// self-attention cache [rows, Lmax, 2 dim]: incremental decoding, models/med.py:1071-1094); no scores, <= 256 keys
+int madtp_i_attention_cached(const void* q, const void* k, const void* v, int kv_block_rows, void* out, int B, int H, int Nq, int Nk,
+                             int ldq, int ldk, int ldv, int ldo, float scale, int io_dtype, void* stream) {
+    return attention_launch(q, k, v, nullptr, out, nullptr, nullptr, 0, nullptr, nullptr, nullptr, B, H, Nq, Nk, ldq, ldk, ldv, ldo, scale,
+                            io_dtype, stream, nullptr, 0, kv_block_rows);
 }
 // cross-attention with *nq_dev query tokens per sample against Nk (host-side) keys of another sequence, optional K/V batch index
 int madtp_i_attention_cross(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out, const float* add_mask,
@@ -2213,8 +2222,9 @@ extern "C" int madtp_attention_qk_mask(const void* q, const void* k, const void*
 static int attention_launch(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
                             const float* add_mask, const float* mask_qk, int ld_mask_qk, float* colsum_part, float* p0,
                             float* onorm, int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale,
-                            int io_dtype, void* stream, const int32_t* n_dev, int dev_q_only) {
+                            int io_dtype, void* stream, const int32_t* n_dev, int dev_q_only, int kv_block_rows) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
+    if (kv_block_rows && (kv_block_rows < Nk || Nk > 256 || colsum_part)) return MADTP_E_SHAPE;  // (the <= 256-key kernels without scores)
     if (kv_batch_index && colsum_part) return MADTP_E_BADARG;  // indexed K/V is a cross-attention feature
     // io_dtype MADTP_F16S: f32 storage, products as three f16 MFMA products of f16-split operands (the f16x3 precision mode)
     if (io_dtype != MADTP_F32 && io_dtype != MADTP_BF16 && io_dtype != MADTP_F16S && io_dtype != MADTP_F16) return MADTP_E_DTYPE;
@@ -2241,6 +2251,7 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
     a.pair = 0; a.q2 = a.k2 = a.v2 = nullptr; a.out2 = nullptr; a.mask2 = nullptr; a.hm_ws = nullptr; a.hm_tick = nullptr; a.o_part = nullptr;
     a.mask_qk = mask_qk; a.ld_mqk = ld_mask_qk;
     a.n_dev = n_dev; a.dev_q_only = dev_q_only;
+    a.kvb = kv_block_rows ? kv_block_rows : Nk;
     hipStream_t s = (hipStream_t)stream;
     const bool scores = colsum_part != nullptr;
     if (Nk > 256) {  // long sequences (384^2 / 480^2 images): two-pass kernels
@@ -2303,6 +2314,7 @@ int madtp_i_attention_pair(const void* q0, const void* q1, const void* k0, const
     a.mask_qk = nullptr; a.ld_mqk = 0; a.hm_ws = nullptr; a.hm_tick = nullptr; a.n_dev = nq_dev; a.dev_q_only = 1; a.o_part = nullptr;
     a.colsum = nullptr; a.p0 = nullptr; a.onorm = nullptr;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.kvb = Nk;
     a.nrt = (Nq + 15) / 16;
     a.scale = scale;
     a.kvidx = kv_batch_index;

@@ -48,3 +48,6 @@ MADTP_INTERNAL int madtp_i_attention_pair(const void* q0, const void* q1, const 
 // additive-mask compaction with N, k from dims_l (k == 0: copy); MED: indices then the (k+1)-th of indices_sort, NLVR: indices_sort
 MADTP_INTERNAL int madtp_i_mask_gather_dev(const float* mask, const int64_t* indices, const int64_t* indices_sort, int variant_nlvr,
                                            float* out, int B, const int32_t* dims_l, void* stream);
+// incremental decoding: Nq queries per sample against the first Nk rows of the sample's K/V block of kv_block_rows rows
+MADTP_INTERNAL int madtp_i_attention_cached(const void* q, const void* k, const void* v, int kv_block_rows, void* out, int B, int H, int Nq,
+                                            int Nk, int ldq, int ldk, int ldv, int ldo, float scale, int io_dtype, void* stream);

@@ -552,6 +552,50 @@ extern "C" int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden
                           enc1, Nk, enc_mask0, enc_mask1, true, y_lp, kv_pre0, kv_pre1, kv_index, kv_ld, stream);
 }
 
+// ---- incremental decoding (models/med.py:1071-1094 prepare_inputs_for_generation / past_key_values) ---------------------------
+// One decoder step for ONE new token per row: every layer projects the new token to q|k|v, appends k|v to its self-attention cache
+// at position t (cache [n_layers][rows][Lmax][2 dim] in the attention dtype), attends the new query to positions 0..t of its row
+// (no causal mask needed: everything in the cache is in the past), then output projection + LayerNorm, cross-attention against the
+// caller's cached encoder K/V (kv_pre / kv_index: the EncoderKVCache of f1) and the FFN - the second half is bert_rest_impl on
+// [rows, 1, dim].  x: embedded new tokens [rows, dim] f32 (position t), y: [rows, dim] f32.  Beam re-ordering of the cache between
+// steps (_reorder_cache, :1091-1094) is the caller's gather over the rows.
+extern "C" int madtp_bert_decode_step(const madtp_bert_layer_w* const* layers, int n_layers, const float* x, void* kv_cache, int rows,
+                                      int t, int Lmax, const void* const* kv_pre, const int32_t* kv_index, int kv_ld, int Nk, float* y,
+                                      void* ws, size_t ws_bytes, void* stream) {
+    if (!layers || !x || !kv_cache || !kv_pre || !y || !ws || n_layers <= 0 || rows <= 0 || t < 0 || t >= Lmax || Lmax > 256 || Nk <= 0)
+        return MADTP_E_BADARG;
+    const float* h = x;
+    for (int l = 0; l < n_layers; ++l) {
+        const madtp_bert_layer_w* w = layers[l];
+        if (!w || w->cross != 1 || !kv_pre[l]) return MADTP_E_BADARG;  // MED decoder layers with single cross-attention
+        bool ok;
+        BertWs s = bert_carve((char*)ws, ws_bytes, rows, 1, Nk, w->dim, w->inter.n, w->heads, w->dtype, &ok);
+        if (!ok) return MADTP_E_SHAPE;
+        const int D = w->dim, dt = w->dtype, adt = attn_dt(dt);
+        const size_t e = esz_of(adt);
+        const void* hc = h;
+        if (dt != MADTP_F32) { TRY(to_lp(h, D, s.hc, rows, D, dt, stream)); hc = s.hc; }
+        TRY(lin(hc, D, w->qkv, nullptr, 0, s.qkv, 3 * D, rows, dt, adt, MADTP_ACT_NONE, 1.f, stream));
+        char* cache_l = (char*)kv_cache + (size_t)l * rows * Lmax * 2 * D * e;
+        hipError_t he = hipMemcpy2DAsync(cache_l + (size_t)t * 2 * D * e, (size_t)Lmax * 2 * D * e, (const char*)s.qkv + (size_t)D * e,
+                                         (size_t)3 * D * e, (size_t)2 * D * e, rows, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (he != hipSuccess) return (int)he;
+        TRY(madtp_i_attention_cached(s.qkv, cache_l, cache_l + (size_t)D * e, Lmax, s.ctx, rows, w->heads, 1, t + 1, 3 * D, 2 * D, 2 * D, D,
+                                     w->scale, attn_io(dt), stream));
+        const void* ctx = s.ctx;
+        if (dt == MADTP_F16S) { TRY(to_lp((const float*)s.ctx, D, s.q, rows, D, dt, stream)); ctx = s.q; }
+        float* att = s.t;  // (f32 scratch the second half does not use in the single cross-attention path)
+        TRY(lin_ln(ctx, D, w->attn_out, h, 1.f, w->ln_att_g, w->ln_att_b, att, dt != MADTP_F32 ? s.attc : nullptr, rows, dt, w->eps, s.part,
+                   stream));
+        // the caller's y serves every layer: layer l + 1 reads it as its input (operand copy, residual of the output projection) and
+        // writes it again only with its very last kernel
+        TRY(bert_rest_impl(w, att, nullptr, y, nullptr, ws, ws_bytes, rows, 1, 0, nullptr, nullptr, nullptr, 1, nullptr, nullptr, Nk, nullptr,
+                           nullptr, true, nullptr, kv_pre[l], nullptr, kv_index, kv_ld, stream));
+        h = y;
+    }
+    return 0;
+}
+
 // ---- encoder-level entry points (include/madtp_hip.h): the layer loops of the two encoders in C --------------------------
 static int query_step(const madtp_query_w* q, const float* x, float* logits, int layer, int B, int N, int dim, void* stream) {
     return madtp_query_model(x, q->sd_w, q->sd_hi, q->sd_lo, q->split_dtype, q->sd_scale, q->K, logits, q->att_ft, q->stats_ws,

@@ -3,8 +3,10 @@
 dependency that is not vendored in the reference): generation_utils.py `beam_search` + generation_beam_search.py
 `BeamSearchScorer` / `BeamHypotheses` + `MinLengthLogitsProcessor`; oracle/madtp_oracle.py::beam_search restates it for the tests.
 
-Split of work: per step the decoder runs over the whole prefix of every live beam (no KV cache of the self-attention: answers /
-captions are <= 10 / 30 tokens), the LM head at the last position only; `madtp_beam_topk` (csrc/lmhead.hip) does the
+Split of work: per step the decoder runs ONE new token per live beam against its layers' self-attention key / value cache
+(round 5: incremental decoding, models/med.py:1071-1094; step_fn receives the beam re-ordering of the step before - the
+`_reorder_cache` of :1091-1094 - through `beam_src`; a step_fn without the parameter re-runs the whole prefix), the LM head at the
+last position only; `madtp_beam_topk` (csrc/lmhead.hip) does the
 log-softmax, the beam-score addition, the EOS suppression below min_length and the top-2k selection over num_beams * V
 candidates per item on the GPU; the 2 * num_beams winners per item come to the host (one small copy per step - the search is
 inherently sequential in the step) where the hypothesis book-keeping runs, as it does in the library."""
@@ -44,8 +46,13 @@ class BeamHypotheses:
 
 def beam_search(step_fn, input_ids, num_beams, max_length, min_length, eos_token_id, pad_token_id, n_vocab,
                 repetition_penalty=1.0, length_penalty=1.0, early_stopping=False):
-    """step_fn(input_ids [B * num_beams, t] on the GPU) -> f32 last-position scores [B * num_beams, >= n_vocab] (GPU, unit column
-    stride); input_ids: the prompt already repeated num_beams times per item.  -> int64 [B, <= max_length] on the GPU."""
+    """step_fn(input_ids [B * num_beams, t] on the GPU[, beam_src]) -> f32 last-position scores [B * num_beams, >= n_vocab] (GPU,
+    unit column stride); beam_src (when step_fn takes it): int64 [B * num_beams] on the GPU - row i of input_ids continues row
+    beam_src[i] of the PREVIOUS call (None on the first call); input_ids: the prompt already repeated num_beams times per item.
+    -> int64 [B, <= max_length] on the GPU."""
+    import inspect
+    takes_src = "beam_src" in inspect.signature(step_fn).parameters
+    beam_src = None
     dev = input_ids.device
     n, cur_len = input_ids.shape
     B = n // num_beams
@@ -56,7 +63,7 @@ def beam_search(step_fn, input_ids, num_beams, max_length, min_length, eos_token
     beam_scores = beam_scores.view(-1)
     ids_host = input_ids.cpu()
     while True:
-        logits = step_fn(input_ids)
+        logits = step_fn(input_ids, beam_src=beam_src) if takes_src else step_fn(input_ids)
         suppress = eos_token_id if (min_length is not None and min_length > -1 and cur_len < min_length) else -1
         sc, ix = hip.beam_topk(logits, beam_scores.to(dev), num_beams, n_vocab, suppress_token=suppress,
                                prev_ids=input_ids.contiguous() if repetition_penalty != 1.0 else None,
@@ -90,6 +97,7 @@ def beam_search(step_fn, input_ids, num_beams, max_length, min_length, eos_token
         beam_scores = nb_scores.view(-1)
         ids_host = torch.cat([ids_host[nb_rows.view(-1), :], nb_tokens.view(-1, 1)], dim=-1)
         input_ids = ids_host.to(dev)
+        beam_src = nb_rows.view(-1).to(dev) if takes_src else None
         cur_len += 1
         if all(done) or cur_len >= max_length:
             break

@@ -13,7 +13,7 @@ import torch
 F32, BF16, F16S, F16 = 0, 1, 2, 3  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 #                                    F16: plain IEEE f16 operands (the "f16" fast mode), see set_lp_format below
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -82,6 +82,8 @@ _SIGS = {
     "madtp_bert_encoder_async": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
                                          c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                          c_void_p, c_void_p, c_void_p]),
+    "madtp_bert_decode_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                       c_void_p, c_size_t, c_void_p]),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
     "madtp_gemm_pair": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float, c_float, c_void_p]),
     "madtp_attention_pair": (c_int, [c_void_p] * 11 + [c_int] * 8 + [c_float, c_int, c_void_p]),
@@ -1176,6 +1178,24 @@ def vit_encoder(weights, x, qargs, temperature, sync_free=False):
 def vit_encoder_sync_free_ok(B, N, prune, qargs):
     """shapes / options madtp_vit_encoder_async takes (the launch-bound regime: small-tile GEMMs, <= 256-key attention)"""
     return bool(prune and qargs is not None and qargs.get("att_ft") is None and B * N < 4096 and 3 <= N <= 256)
+
+
+def bert_decode_step(weights, x, kv_cache, t, kv_pre, kv_index, kv_ld, Nk):
+    """One incremental decoding step (madtp_bert_decode_step): x f32 [rows, D] = the embedded new tokens at position t; kv_cache
+    [layers, rows, Lmax, 2 D] in the attention dtype (appended in place); kv_pre: the per-layer cached cross-attention [k|v]
+    tensors, kv_index int32 [rows].  -> y f32 [rows, D]."""
+    rows, D = x.shape
+    lib = load()
+    wstructs, arr = weights
+    L = len(wstructs)
+    w0 = wstructs[0]
+    nbytes = lib.madtp_bert_layer_workspace(rows, 1, Nk, w0.dim, w0.inter.n, w0.heads, w0.dtype)
+    ws = workspace(nbytes, x.device)
+    y = torch.empty_like(x)
+    kv = (c_void_p * L)(*[_p(tn) for tn in kv_pre])
+    _check(lib.madtp_bert_decode_step(arr, L, _p(x), _p(kv_cache), rows, int(t), kv_cache.shape[2], kv, _p(kv_index), int(kv_ld), int(Nk),
+                                      _p(y), _p(ws), ws.numel(), _stream()), "madtp_bert_decode_step")
+    return y
 
 
 def bert_encoder_sync_free_ok(B, L, Nk, prune, qargs, mask2d):

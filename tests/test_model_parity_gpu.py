@@ -716,6 +716,45 @@ def test_vqa_rank_answer_matches_reference_fixture(path, mode):
     assert max_ids.tolist() == g["max_ids"].tolist()
 
 
+@pytest.mark.parametrize("mode", ["fp32", "f16x3", "f16"])
+def test_incremental_decoding_equals_full_prefix_generate(mode, monkeypatch):
+    """BertLMHeadModel.generate through madtp_bert_decode_step (one new token per beam and step against the layers' self-attention
+    K/V cache, beams re-ordered by a gather over the cache rows: models/med.py:1071-1094) against the full-prefix path
+    (MADTP_DECODE_CACHE=0: the decoder re-run over the whole prefix with the causal mask every step): the same generated ids, and
+    the per-step scores of the two paths agree to rounding (the projections' split-K factors differ with the row count)."""
+    from madtp_amd import build, hip, runtime, specs
+    from madtp_amd.med import BertConfig, BertLMHeadModel
+    build.build(verbose=False)
+    hip.load()
+    model = BertLMHeadModel(BertConfig.med_default())
+    sd = specs.synth_weights(specs.bert_shapes("bert.", "med"), 3)
+    model.load_state_dict(sd, strict=False)
+    model.tie_weights()
+    model = model.cuda().eval()
+    model.tie_weights()
+    g = torch.Generator().manual_seed(5)
+    B, nb, Nq = 5, 3, 23
+    enc = torch.randn(B, Nq, 768, generator=g).cuda()
+    prompt = torch.tensor([[30522, 1037, 3861, 1997]] * B)  # [BOS] "a picture of" (models/blip.py:84-86)
+    outs, scores = {}, {}
+    for cached in ("1", "0"):
+        monkeypatch.setenv("MADTP_DECODE_CACHE", cached)
+        rec = []
+        real = model.prediction_scores
+        monkeypatch.setattr(model, "prediction_scores", lambda h, _r=real, _rec=rec: (lambda o: (_rec.append(o[1][:, 0, :64].float().cpu()), o)[1])(_r(h)))
+        with runtime.precision(mode), torch.no_grad():
+            outs[cached] = model.generate(input_ids=prompt, max_length=18, min_length=6, num_beams=nb, eos_token_id=102, pad_token_id=0,
+                                          repetition_penalty=1.0, encoder_hidden_states=enc.repeat_interleave(nb, dim=0),
+                                          encoder_attention_mask=torch.ones(B * nb, Nq, dtype=torch.long).cuda()).cpu()
+        scores[cached] = rec
+        monkeypatch.setattr(model, "prediction_scores", real)
+    assert torch.equal(outs["1"], outs["0"]), (outs["1"], outs["0"])
+    assert len(scores["1"]) == len(scores["0"]) >= 6
+    tol = 2e-3 if mode != "f16" else 6e-2
+    for a, b in zip(scores["1"], scores["0"]):
+        assert (a - b).abs().max().item() < tol * max(1.0, b.abs().max().item())
+
+
 def test_generation_beam_search_equals_oracle_on_toy_models():
     """madtp_amd.generation.beam_search (madtp_beam_topk + the host-side hypothesis book-keeping) against oracle.beam_search
     (transformers 4.15 restated) on first-order toy language models with random tables: EOS frequent enough that hypotheses
