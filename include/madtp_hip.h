@@ -530,6 +530,18 @@ int madtp_beam_topk(const float* logits, int ld, int V, const float* beam_scores
 int madtp_beam_topk_penalty(const float* logits, int ld, int V, const float* beam_scores, int num_beams, int n_top,
                             int suppress_token, const int64_t* prev_ids, int ld_prev, int cur_len, float repetition_penalty,
                             float* out_scores, int32_t* out_index, int B, void* stream);
+/* One step of nucleus sampling (models/blip.py:175-186: text_decoder.generate(do_sample=True, top_p=0.9, repetition_penalty=1.1);
+ * transformers 4.15 `sample`): on the raw last-position scores of every row - RepetitionPenaltyLogitsProcessor over prev_ids
+ * (s < 0 ? s * penalty : s / penalty for tokens already in the row; NULL / 1.0: none), EOS suppression below min_length
+ * (suppress_token, -1 = none), TopKLogitsWarper(top_k; the library default config.top_k = 50), TopPLogitsWarper(top_p: a token
+ * stays while the tokens ranked before it hold <= top_p of the softmax mass), softmax of the survivors and ONE draw per row as the
+ * inverse CDF (survivors in descending order of score, ties by ascending index) at the caller's uniform number u[row] in [0, 1).
+ * logits f32 [B, >= V] with row stride ld, prev_ids int64 [B, ld_prev] (cur_len columns), out_token int64 [B], out_prob (optional)
+ * f32 [B] the drawn token's probability among the survivors.  V <= 36864, top_k <= 64. */
+int madtp_sample_top_p(const float* logits, int ld, int V, const int64_t* prev_ids, int ld_prev, int cur_len, float repetition_penalty,
+                       int suppress_token, int top_k, float top_p, const float* u, int64_t* out_token, float* out_prob, int B,
+                       void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------------------
  * Backward of the pruned ViT block (first half; csrc/backward.hip): the pieces of loss.backward()

@@ -1008,8 +1008,9 @@ class BertLMHeadModel(nn.Module):
         whole prefix (med.py prepare_inputs_for_generation :1071-1089: attention_mask = ones, is_decoder=True); the encoder
         states are projected to every layer's cross-attention [k|v] ONCE per item and beam j of item b reads block b.
         encoder_attention_mask is accepted and ignored: MED cross-attention drops the encoder mask (med.py:197-199)."""
-        if do_sample:
-            raise NotImplementedError("nucleus sampling (models/blip.py:175-186) is not implemented: beam search only")
+        top_p = unused.pop("top_p", 1.0) if do_sample else None
+        top_k = unused.pop("top_k", 50) if do_sample else None  # (transformers: config.top_k = 50 unless the caller passes one)
+        generator = unused.pop("generator", None)
         # keyword arguments of transformers' generate that would change the result must not be dropped silently
         for key, val in unused.items():
             if key == "num_return_sequences" and val == 1:
@@ -1022,8 +1023,10 @@ class BertLMHeadModel(nn.Module):
                 continue  # an all-ones prompt mask is the default prepare_inputs_for_generation builds (med.py:1075-1077)
             raise TypeError(f"generate(): unsupported argument {key}={val!r} (beam search of the reference's call sites only: "
                             "num_beams, max_length, min_length, eos / pad ids, repetition_penalty, length_penalty, early_stopping)")
-        if num_beams < 2:
-            raise NotImplementedError("greedy search: the reference's call sites use num_beams = 3")
+        if do_sample:
+            num_beams = 1  # models/blip.py:175-186: one sampled sequence per image (num_return_sequences = 1)
+        elif num_beams < 2:
+            raise NotImplementedError("greedy search: the reference's call sites use num_beams = 3 or do_sample = True")
         if eos_token_id is None or pad_token_id is None or encoder_hidden_states is None:
             raise ValueError("generate: eos_token_id, pad_token_id and encoder_hidden_states are required")
         from . import generation
@@ -1077,6 +1080,10 @@ class BertLMHeadModel(nn.Module):
             return padded[:, 0, :]
         step = step_cached if use_cache else step_full
         prompt = input_ids.to(dev).to(torch.int64).repeat_interleave(num_beams, dim=0)
+        if do_sample:
+            with torch.no_grad():
+                return generation.sample(step, prompt, max_length, min_length, eos_token_id, pad_token_id, V, top_p, top_k=top_k,
+                                         repetition_penalty=repetition_penalty, generator=generator)
         with torch.no_grad():
             return generation.beam_search(step, prompt, num_beams, max_length, min_length, eos_token_id, pad_token_id, V,
                                           repetition_penalty=repetition_penalty, length_penalty=length_penalty,

@@ -92,12 +92,20 @@ class BLIP_Decoder(nn.Module):
         """models/blip.py:161-202 -> the decoded captions without the prompt when a tokenizer is attached (:198-202), else the
         generated token ids int64 [B, <= max_length] (prompt included)."""
         require_gpu(image, "image")
-        if sample:
-            raise NotImplementedError("nucleus sampling (:175-186) is not implemented: beam search only")
         image_embeds = self.visual_encoder(image, space_dict=self.space_dict, temperature=temperature)[0]  # :162
-        image_embeds = image_embeds.repeat_interleave(num_beams, dim=0)  # :165
+        if not sample:
+            image_embeds = image_embeds.repeat_interleave(num_beams, dim=0)  # :164-165
         image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)  # :167
         input_ids = self._prompt(image.size(0), image.device)
+        if sample:  # nucleus sampling :175-186 (repetition_penalty 1.1 is the reference's constant there)
+            outputs = self.text_decoder.generate(input_ids=input_ids, max_length=max_length, min_length=min_length, do_sample=True,
+                                                 top_p=top_p, num_return_sequences=1, eos_token_id=SEP_TOKEN_ID,
+                                                 pad_token_id=PAD_TOKEN_ID, repetition_penalty=1.1,
+                                                 encoder_hidden_states=image_embeds, encoder_attention_mask=image_atts,
+                                                 generator=getattr(self, "sample_generator", None))
+            if self.tokenizer is not None and hasattr(self.tokenizer, "decode"):
+                return [self.tokenizer.decode(o, skip_special_tokens=True)[len(self.prompt):] for o in outputs]
+            return outputs
         outputs = self.text_decoder.generate(input_ids=input_ids, max_length=max_length, min_length=min_length,
                                              num_beams=num_beams, eos_token_id=SEP_TOKEN_ID, pad_token_id=PAD_TOKEN_ID,
                                              repetition_penalty=repetition_penalty, encoder_hidden_states=image_embeds,

@@ -188,6 +188,106 @@ __global__ __launch_bounds__(BT_THREADS) void beam_topk_kernel(const float* logi
     }
 }
 
+
+// ---- nucleus sampling step (models/blip.py:175-186: text_decoder.generate(do_sample=True, top_p=0.9, repetition_penalty=1.1)) ----
+// transformers 4.15 `sample`: the processors run on the raw last-position scores (RepetitionPenaltyLogitsProcessor: a token that
+// already occurs in the row gets s < 0 ? s * penalty : s / penalty; MinLengthLogitsProcessor: EOS = -inf below min_length), then the
+// warpers - TopKLogitsWarper(top_k = config.top_k = 50) keeps the 50 best scores, TopPLogitsWarper(top_p) sorts them descending,
+// softmaxes, and drops every token whose PREDECESSORS already hold more than top_p of the mass (so the first token that crosses
+// top_p stays) - then softmax over what is left and one multinomial draw.  Here: one 1024-thread workgroup per row, the row in LDS
+// (V <= 36 k); the k-th largest score by bisection over the order-preserving integer image of the floats (32 counting passes over
+// LDS), the survivors collected, ranked by (score descending, index ascending) and walked by one wave: softmax, top-p prefix,
+// and the draw as the inverse CDF of that prefix at u[row] (the caller's uniform number: the library has no generator state).
+constexpr int SP_THREADS = 1024, SP_MAX_K = 64, SP_MAX_V = 36864;
+__device__ __forceinline__ unsigned f32_order_key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__global__ __launch_bounds__(SP_THREADS) void sample_top_kp_kernel(const float* logits, int ld, int V, const int64_t* prev_ids, int ld_prev,
+                                                                  int cur_len, float penalty, int suppress, int top_k, float top_p,
+                                                                  const float* u, int64_t* out_token, float* out_prob) {
+    extern __shared__ __attribute__((aligned(16))) char sp_dyn[];
+    float* row_s = (float*)sp_dyn;  // [V]
+    __shared__ int cnt_s[SP_THREADS / 64];
+    __shared__ int n_sel;
+    __shared__ float sel_v[2 * SP_MAX_K];
+    __shared__ int sel_i[2 * SP_MAX_K];
+    __shared__ float ord_v[SP_MAX_K];
+    __shared__ int ord_i[SP_MAX_K];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float* row = logits + (size_t)b * ld;
+    for (int t = tid; t < V; t += SP_THREADS) row_s[t] = row[t];
+    __syncthreads();
+    if (prev_ids && penalty != 1.0f) {  // (a token may occur several times: the penalty is applied once, as the gather / scatter of the library does)
+        for (int c = tid; c < cur_len; c += SP_THREADS) {
+            const long long t = prev_ids[(size_t)b * ld_prev + c];
+            bool first = t >= 0 && t < V;
+            for (int c2 = 0; first && c2 < c; ++c2) first = prev_ids[(size_t)b * ld_prev + c2] != t;
+            if (first) { const float s0 = row[t]; row_s[t] = s0 < 0.f ? s0 * penalty : s0 / penalty; }
+        }
+    }
+    if (tid == 0 && suppress >= 0 && suppress < V) row_s[suppress] = -INFINITY;
+    __syncthreads();
+    // k-th largest key: the largest key K with count(key >= K) >= k
+    const int k = min(top_k, V);
+    unsigned lo = 0u, hi = 0xFFFFFFFFu;
+    while (lo < hi) {
+        const unsigned mid = lo + (unsigned)(((unsigned long long)hi - lo + 1ull) >> 1);
+        int c = 0;
+        for (int t = tid; t < V; t += SP_THREADS) c += f32_order_key(row_s[t]) >= mid ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        __syncthreads();
+        if (lane == 0) cnt_s[tid >> 6] = c;
+        __syncthreads();
+        int tot = 0;
+        for (int w = 0; w < SP_THREADS / 64; ++w) tot += cnt_s[w];
+        if (tot >= k) lo = mid; else hi = mid - 1u;
+    }
+    if (tid == 0) n_sel = 0;
+    __syncthreads();
+    for (int t = tid; t < V; t += SP_THREADS) {
+        const float v = row_s[t];
+        if (f32_order_key(v) >= lo && v > -INFINITY) {
+            const int p = atomicAdd(&n_sel, 1);
+            if (p < 2 * SP_MAX_K) { sel_v[p] = v; sel_i[p] = t; }
+        }
+    }
+    __syncthreads();
+    const int ns = min(n_sel, 2 * SP_MAX_K);
+    // rank by (score descending, index ascending); the first k form the top-k set (ties at the k-th score: the lower indices)
+    for (int p = tid; p < ns; p += SP_THREADS) {
+        int r = 0;
+        for (int q = 0; q < ns; ++q) r += (sel_v[q] > sel_v[p] || (sel_v[q] == sel_v[p] && sel_i[q] < sel_i[p])) ? 1 : 0;
+        if (r < k && r < SP_MAX_K) { ord_v[r] = sel_v[p]; ord_i[r] = sel_i[p]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int n = min(min(ns, k), SP_MAX_K);
+        if (n <= 0) { out_token[b] = suppress == 0 ? 1 : 0; if (out_prob) out_prob[b] = 0.f; return; }
+        const float mx = ord_v[0];
+        float z = 0.f;
+        for (int r = 0; r < n; ++r) z += expf(ord_v[r] - mx);
+        // top-p prefix: token r stays iff the mass of tokens 0..r-1 is <= top_p (the first one always stays)
+        int m = 0;
+        float cum = 0.f, kept = 0.f;
+        for (int r = 0; r < n; ++r) {
+            if (r > 0 && cum > top_p) break;
+            const float pr = expf(ord_v[r] - mx) / z;
+            cum += pr; kept += pr; m = r + 1;
+        }
+        // inverse CDF of the re-normalised prefix at u
+        const float target = u[b] * kept;
+        float acc = 0.f;
+        int pick = m - 1;
+        for (int r = 0; r < m; ++r) {
+            acc += expf(ord_v[r] - mx) / z;
+            if (target < acc) { pick = r; break; }
+        }
+        out_token[b] = ord_i[pick];
+        if (out_prob) out_prob[b] = expf(ord_v[pick] - mx) / z / kept;
+    }
+}
+
 }  // namespace
 
 static int beam_topk_launch(const float* logits, int ld, int V, const float* beam_scores, int num_beams, int n_top,
@@ -219,6 +319,20 @@ extern "C" int madtp_beam_topk_penalty(const float* logits, int ld, int V, const
     if (!prev_ids) return MADTP_E_BADARG;
     return beam_topk_launch(logits, ld, V, beam_scores, num_beams, n_top, suppress_token, out_scores, out_index, B, prev_ids, ld_prev,
                             cur_len, repetition_penalty, stream);
+}
+
+extern "C" int madtp_sample_top_p(const float* logits, int ld, int V, const int64_t* prev_ids, int ld_prev, int cur_len,
+                                  float repetition_penalty, int suppress_token, int top_k, float top_p, const float* u, int64_t* out_token,
+                                  float* out_prob, int B, void* stream) {
+    if (!logits || !u || !out_token || B <= 0 || V <= 0 || ld < V) return MADTP_E_BADARG;
+    if (V > SP_MAX_V || top_k < 1 || top_k > SP_MAX_K || !(top_p > 0.f) || !(repetition_penalty > 0.f)) return MADTP_E_SHAPE;
+    if (prev_ids && (cur_len < 1 || ld_prev < cur_len)) return MADTP_E_BADARG;
+    const size_t lds = (size_t)V * sizeof(float);
+    MADTP_ENSURE_MAX_LDS(sample_top_kp_kernel, 150 * 1024);
+    hipLaunchKernelGGL(sample_top_kp_kernel, dim3(B), dim3(SP_THREADS), lds, (hipStream_t)stream, logits, ld, V, prev_ids, ld_prev, cur_len,
+                       repetition_penalty, suppress_token, top_k, top_p, u, out_token, out_prob);
+    MADTP_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int madtp_lm_loss(const float* logits, int ld, int rows_per_seq, int n_pred, int V, const int64_t* labels,

@@ -115,3 +115,32 @@ def beam_search(step_fn, input_ids, num_beams, max_length, min_length, eos_token
         if lens[b] < max_length:
             out[b, lens[b]] = eos_token_id
     return out.to(dev)
+
+
+def sample(step_fn, input_ids, max_length, min_length, eos_token_id, pad_token_id, n_vocab, top_p, top_k=50, repetition_penalty=1.0,
+           generator=None):
+    """Nucleus sampling: transformers 4.15 `sample` (generation_utils.py) as models/blip.py:175-186 reaches it - processors
+    (repetition penalty on the raw scores, EOS = -inf below min_length), warpers (top-k 50 = config.top_k, then top-p), one draw per
+    row; a row that has produced EOS keeps emitting pad_token_id; stops when every row is finished or at max_length.  The draw is
+    `madtp_sample_top_p` at one uniform number per row and step from `generator` (a torch.Generator on the rows' device; None: the
+    default generator) - the same distribution as torch.multinomial on the warped scores, not the same random stream.
+    step_fn as for beam_search (beam_src is always None here).  -> int64 [B, <= max_length] on the GPU."""
+    import inspect
+    takes_src = "beam_src" in inspect.signature(step_fn).parameters
+    dev = input_ids.device
+    B, cur_len = input_ids.shape
+    unfinished = torch.ones((B,), dtype=torch.int64, device=dev)
+    while True:
+        logits = step_fn(input_ids, beam_src=None) if takes_src else step_fn(input_ids)
+        suppress = eos_token_id if (min_length is not None and min_length > -1 and cur_len < min_length) else -1
+        u = torch.rand((B,), device=dev, dtype=torch.float32, generator=generator)
+        nxt = hip.sample_top_p(logits, u, n_vocab, top_p, top_k=top_k, suppress_token=suppress,
+                               prev_ids=input_ids.contiguous() if repetition_penalty != 1.0 else None,
+                               repetition_penalty=repetition_penalty)
+        nxt = nxt * unfinished + pad_token_id * (1 - unfinished)
+        input_ids = torch.cat([input_ids, nxt[:, None]], dim=-1)
+        cur_len += 1
+        unfinished = unfinished * (nxt != eos_token_id).to(torch.int64)
+        if int(unfinished.max()) == 0 or cur_len >= max_length:
+            break
+    return input_ids

@@ -13,7 +13,7 @@ import torch
 F32, BF16, F16S, F16 = 0, 1, 2, 3  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 #                                    F16: plain IEEE f16 operands (the "f16" fast mode), see set_lp_format below
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -84,6 +84,8 @@ _SIGS = {
                                          c_void_p, c_void_p, c_void_p]),
     "madtp_bert_decode_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                        c_void_p, c_size_t, c_void_p]),
+    "madtp_sample_top_p": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_int, c_void_p]),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
     "madtp_gemm_pair": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float, c_float, c_void_p]),
     "madtp_attention_pair": (c_int, [c_void_p] * 11 + [c_int] * 8 + [c_float, c_int, c_void_p]),
@@ -938,6 +940,23 @@ def beam_topk(logits, beam_scores, num_beams, n_vocab, n_top=None, suppress_toke
     _check(load().madtp_beam_topk(_p(logits), logits.stride(0), int(n_vocab), _p(beam_scores), int(num_beams), n_top,
                                   int(suppress_token), _p(sc), _p(ix), B, _stream()), "madtp_beam_topk")
     return sc, ix
+
+
+def sample_top_p(logits, u, n_vocab, top_p, top_k=50, suppress_token=-1, prev_ids=None, repetition_penalty=1.0, want_prob=False):
+    """One nucleus-sampling step (include/madtp_hip.h madtp_sample_top_p): logits f32 [rows, >= n_vocab], u f32 [rows] uniform numbers
+    in [0, 1) -> next token int64 [rows] (and its probability among the survivors)."""
+    _req(u, torch.float32, "u")
+    if not logits.is_cuda or logits.dtype != torch.float32 or logits.dim() != 2 or logits.stride(1) != 1:
+        raise RuntimeError("sample_top_p: logits must be a GPU f32 [rows, V] tensor with unit column stride")
+    rows = logits.shape[0]
+    tok = torch.empty((rows,), device=logits.device, dtype=torch.int64)
+    prob = torch.empty((rows,), device=logits.device, dtype=torch.float32) if want_prob else None
+    if prev_ids is not None:
+        _req(prev_ids, torch.int64, "prev_ids")
+    _check(load().madtp_sample_top_p(_p(logits), logits.stride(0), int(n_vocab), _p(prev_ids), prev_ids.stride(0) if prev_ids is not None else 0,
+                                     prev_ids.shape[1] if prev_ids is not None else 0, float(repetition_penalty), int(suppress_token),
+                                     int(top_k), float(top_p), _p(u), _p(tok), _p(prob), rows, _stream()), "madtp_sample_top_p")
+    return (tok, prob) if want_prob else tok
 
 
 def profile_begin():

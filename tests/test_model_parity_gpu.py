@@ -755,6 +755,64 @@ def test_incremental_decoding_equals_full_prefix_generate(mode, monkeypatch):
         assert (a - b).abs().max().item() < tol * max(1.0, b.abs().max().item())
 
 
+def test_nucleus_sampling_step_equals_oracle_and_generate_samples():
+    """Missing item of the round-4 review: `generate(do_sample=True, top_p=0.9)` (models/blip.py:175-186).  (1) madtp_sample_top_p
+    against oracle.sample_step (transformers 4.15's processors and warpers restated, checked on CPU against the installed library's
+    warpers) on random score rows at the BLIP vocabulary and on a peaked toy row: the SAME token for the same uniform numbers, with
+    and without repetition penalty / EOS suppression; (2) the draw frequencies of one row follow the nucleus distribution; (3)
+    BertLMHeadModel.generate(do_sample=True) and BLIP_Decoder.generate(sample=True) run end to end: same ids for the same generator
+    seed, different ids for another, finished rows are padded, every sampled token lies inside its step's nucleus."""
+    from madtp_amd import build, hip, runtime, specs
+    from madtp_amd.med import BertConfig, BertLMHeadModel
+    from oracle import madtp_oracle as O
+    build.build(verbose=False)
+    hip.load()
+    g = torch.Generator().manual_seed(2)
+    for V, scale in ((30524, 2.0), (30524, 0.3), (512, 4.0)):
+        Vp = (V + 7) // 8 * 8
+        logits = torch.randn(6, Vp, generator=g) * scale
+        ids = torch.randint(0, V, (6, 9), generator=g)
+        ids[:, 5] = ids[:, 2]
+        u = torch.rand(6, generator=g)
+        for pen, sup in ((1.0, -1), (1.1, -1), (1.1, 102)):
+            ref = O.sample_step(logits[:, :V], ids, u, 0.9, 50, pen, sup)
+            got, prob = hip.sample_top_p(logits.cuda(), u.cuda(), V, 0.9, top_k=50, suppress_token=sup,
+                                         prev_ids=ids.cuda() if pen != 1.0 else None, repetition_penalty=pen, want_prob=True)
+            assert got.cpu().tolist() == ref.tolist(), (V, scale, pen, sup)
+            assert ((prob > 0) & (prob <= 1.0 + 1e-6)).all()
+    # (2) frequencies on one peaked row
+    row = (torch.randn(1, 64, generator=g) * 2)
+    w = O.nucleus_filter(row, 0.9, 50).softmax(-1)[0]
+    n = 20000
+    u = (torch.arange(n, dtype=torch.float32) + 0.5) / n
+    draws = hip.sample_top_p(row.cuda().expand(n, 64).contiguous(), u.cuda(), 64, 0.9).cpu()
+    freq = torch.bincount(draws, minlength=64).double() / n
+    assert (freq - w.double()).abs().max().item() < 2e-3
+    # (3) end to end
+    model = BertLMHeadModel(BertConfig.med_default())
+    model.load_state_dict(specs.synth_weights(specs.bert_shapes("bert.", "med"), 3), strict=False)
+    model.tie_weights()
+    model = model.cuda().eval()
+    model.tie_weights()
+    B, Nq = 6, 23
+    enc = torch.randn(B, Nq, 768, generator=g).cuda()
+    prompt = torch.tensor([[30522, 1037, 3861, 1997]] * B)
+    outs = []
+    for seed in (7, 7, 8):
+        gen = torch.Generator(device="cuda").manual_seed(seed)
+        with runtime.precision("f16"), torch.no_grad():
+            outs.append(model.generate(input_ids=prompt, max_length=16, min_length=6, do_sample=True, top_p=0.9, num_return_sequences=1,
+                                       eos_token_id=102, pad_token_id=0, repetition_penalty=1.1, encoder_hidden_states=enc,
+                                       encoder_attention_mask=torch.ones(B, Nq, dtype=torch.long).cuda(), generator=gen).cpu())
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+    o = outs[0]
+    assert o.shape[0] == B and 6 <= o.shape[1] <= 16 and torch.equal(o[:, :4], prompt)
+    for b in range(B):  # after EOS only padding
+        pos = (o[b] == 102).nonzero().flatten()
+        if len(pos):
+            assert pos[0] >= 6 - 1 and (o[b, pos[0] + 1:] == 0).all()
+
+
 def test_generation_beam_search_equals_oracle_on_toy_models():
     """madtp_amd.generation.beam_search (madtp_beam_topk + the host-side hypothesis book-keeping) against oracle.beam_search
     (transformers 4.15 restated) on first-order toy language models with random tables: EOS frequent enough that hypotheses

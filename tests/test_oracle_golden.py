@@ -827,3 +827,29 @@ def test_oracle_clip_vision_backward_matches_reference_grads(path):
     grads, feat, trace = O.clip_vision_grads(c["W"], "", c["images"], c["space_dict"], c["T"], c["c"], c["a"])
     assert np.abs(feat.numpy() - g["features"]).max() < 1e-5
     grad_case.check_against_fixture(g, grads, 1e-4, "oracle autograd vs reference (CLIP vision tower)")
+
+
+def test_oracle_nucleus_filter_matches_transformers_warpers():
+    """oracle.nucleus_filter / repetition_penalty_scores (transformers 4.15 restated: the warpers and the processor behind
+    models/blip.py:175-186 generate(do_sample=True, top_p=0.9, repetition_penalty=1.1)) against the warpers of the transformers
+    version installed in this container, which kept these semantics: the same surviving token sets on random scores (no ties),
+    top_k = 50 (config.top_k) in front of top_p, and the same penalised scores."""
+    from oracle import madtp_oracle as O
+    lp = pytest.importorskip("transformers.generation.logits_process")
+    g = torch.Generator().manual_seed(1)
+    for V, scale, p in ((1000, 3.0, 0.9), (30524, 1.5, 0.9), (300, 0.2, 0.5), (40, 5.0, 0.95)):
+        x = torch.randn(5, V, generator=g) * scale
+        mine = O.nucleus_filter(x, p, 50)
+        ref = lp.TopPLogitsWarper(p)(None, lp.TopKLogitsWarper(50)(None, x.clone()))
+        assert torch.equal(torch.isfinite(mine), torch.isfinite(ref))
+        assert torch.equal(mine[torch.isfinite(mine)], ref[torch.isfinite(ref)])
+        ids = torch.randint(0, V, (5, 7), generator=g)
+        ids[:, 3] = ids[:, 1]  # a token that occurs twice is penalised once
+        assert torch.allclose(O.repetition_penalty_scores(x, ids, 1.1), lp.RepetitionPenaltyLogitsProcessor(1.1)(ids, x.clone()))
+    # the inverse-CDF draw: u sweeps the unit interval -> every survivor is drawn, in proportion to its probability
+    x = torch.randn(1, 64, generator=g) * 2
+    w = O.nucleus_filter(x, 0.9, 50).softmax(-1)[0]
+    us = (torch.arange(20000, dtype=torch.float64) + 0.5) / 20000
+    draws = torch.stack([O.sample_step(x, torch.zeros(1, 1, dtype=torch.long), torch.tensor([float(u)]), 0.9) for u in us[::40]]).flatten()
+    freq = torch.bincount(draws, minlength=64).double() / draws.numel()
+    assert (freq - w.double()).abs().max().item() < 5e-3 and set(torch.nonzero(freq).flatten().tolist()) <= set(torch.nonzero(w).flatten().tolist())
