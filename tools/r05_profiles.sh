@@ -28,7 +28,7 @@ for spec in "nlvr f16" "nlvr bf16" "nlvr f16x3" "vqa bf16" "vqa f16x3" "retrieva
   CMD="bench.py --config $C --precision $P --inflight 1 --steps 5 --warmup 2 --traffic off --no-cpu-baseline --no-parity --no-gemm-events"
   rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$T -o p -- python $R/$CMD > $R/gpurun_out/prof_$T.log 2>&1
   DB=$(find $R/gpurun_out/prof_$T -name "*_results.db" | head -1)
-  python $R/tools/rocpd_stats.py $DB "rocprofv3 --kernel-trace --stats -- python $CMD (7 forwards incl. warm-up)" > $R/gpurun_out/${TAG}_${T}_kernel_stats.txt
+  MADTP_STATS_SKIP=1 python $R/tools/rocpd_stats.py $DB "rocprofv3 --kernel-trace --stats -- python $CMD (7 forwards)" > $R/gpurun_out/${TAG}_${T}_kernel_stats.txt
   if [ "$T" = "nlvr_f16" ]; then python $R/tools/rocpd_timeline.py $DB patchify 1 1 330 > $R/gpurun_out/${TAG}_timeline_nlvr.txt; python $R/tools/rocpd_step.py $DB; fi
   rm -rf $R/gpurun_out/prof_$T
 done
