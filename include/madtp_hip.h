@@ -91,6 +91,14 @@ int madtp_gemm_splitk(const void* A, const void* W, float* part, int M, int N, i
 int madtp_splitk_ln(const float* part, int splits, const float* bias, const float* residual, const float* gamma,
                     const float* beta, float* y32, void* ylp, int lp_dtype, int rows, int dim, float eps, float acc_scale,
                     float scale, void* stream);
+
+/* Split-K partials of a LONG-K product (ABI 28): the weight gradient dW = dY^T X of the f16x3 backward (compress_nlvr_dtp.py:46-53's
+ * loss.backward(); K = every token row of the batch) on the 256x256 ping-pong kernel: part[s,M,N] (f32) = acc_scale * A[:, Ks] W[:, Ks]^T
+ * for f16-split operands (MADTP_F16S layouts, lda / ldw >= 2K f16 elements).  K % (128*splits) == 0, N % 8 == 0.  madtp_splitk_sum
+ * adds the slabs in order: out[i] = part[0][i] + part[1][i] + ...; count % 4 == 0. */
+int madtp_gemm_splitk_pp(const void* A, const void* W, float* part, int M, int N, int K, int lda, int ldw, int splits, float acc_scale,
+                         void* stream);
+int madtp_splitk_sum(const float* part, int splits, size_t count, float* out, void* stream);
 /* (with acc_scale: y = LayerNorm(scale * (acc_scale * sum_s part[s] + bias) + residual); ylp in lp_dtype BF16 or F16S) */
 
 /* Two independent GEMMs of identical shape, leading dimensions and dtypes (C_i = A_i @ W_i^T + bias_i; bias0 and bias1 both
@@ -552,6 +560,10 @@ int madtp_sample_top_p(const float* logits, int ld, int V, const int64_t* prev_i
 /* dst[c, r] = src[r, c] (r < R, c < C), zero elsewhere of dst [Cp, Rp] (row stride ld_dst >= Rp): GEMM operands of the
  * backward need K contiguous (nn.Linear layout) and padded (K % 32 == 0, 128-row weight padding). */
 int madtp_transpose_pad(const float* src, int ld_src, int R, int C, float* dst, int ld_dst, int Rp, int Cp, void* stream);
+/* The same transpose straight into the f16-split operand planes of the f16x3 backward's weight gradient (ABI 28): dst f16
+ * [Cp, 2*Rp] with row c = the planes of src[:, c] - weight_format 0: activation planes [P0 | P1] (dY^T), 1: weight planes [Q0 | Q1]
+ * at scale 1 (X^T) - zero beyond R / C.  Rp % 4 == 0.  One pass instead of madtp_transpose_pad + madtp_split_f16(_weight). */
+int madtp_transpose_split(const float* src, int ld_src, int R, int C, void* dst, int Rp, int Cp, int weight_format, void* stream);
 /* out[c] = sum_r dy[r, c]: bias gradients (nn.Linear, LayerNorm beta).  part_ws: 64 * N floats of scratch. */
 int madtp_colsum(const float* dy, int ld, int M, int N, float* out, float* part_ws, void* stream);
 /* g = act(u) (g != NULL) and / or du = dg * act'(u) (du != NULL): Mlp's GELU (vit.py:34) and its derivative; n % 4 == 0. */
@@ -592,8 +604,9 @@ int madtp_attention_bwd_cross(const float* q, int ldq, const float* k, const flo
 /* Backward of the query model's att_ft branch (models/utils.py:174-178: W = softmax over tokens of inner / sqrt(sd_dim), att_ft =
  * W q), the part of VisionTransformer.forward's second output (vit.py:297-303, consumed by the training drivers' alignment loss).
  * Given dA = d att_ft [B,K,D]: dinner[B,n,K] += W (q dA^T - sum_n W q dA^T) / sqrt(sd_dim), dq[B,n,D] += W^T dA.  inner, dinner: dense
- * [B,n,K] (dinner usually already holds the gradient that reaches the logits through token_attn); q, dq: dense [B,n,D]; ws: B*K*n
- * floats.  n <= 1024, K <= 128, D <= 1024.  Exact f32, fixed summation order. */
+ * [B,n,K] (dinner usually already holds the gradient that reaches the logits through token_attn); q, dq: dense [B,n,D]; ws: 2*B*K*n
+ * floats (ABI 28: W and q dA^T, the latter a batched exact-f32 MFMA product).  n <= 1024, K <= 128, D <= 1024.  Exact f32, fixed
+ * summation order. */
 int madtp_att_ft_bwd(const float* inner, const float* q, const float* dA, float inv_sqrt_d, float* dinner, float* dq, float* ws,
                      int B, int n, int K, int D, void* stream);
 

@@ -17,6 +17,8 @@ decision k (activation recomputation: nothing but the two inputs is kept alive b
 """
 import math
 
+import os
+
 import torch
 
 from . import hip
@@ -33,6 +35,18 @@ def transpose_pad(src, rows_pad, cols_pad):
     dst = torch.empty((cols_pad, rows_pad), device=src.device, dtype=torch.float32)
     _check(load().madtp_transpose_pad(_p(src), src.stride(0), R, C, _p(dst), rows_pad, rows_pad, cols_pad, _stream()),
            "madtp_transpose_pad")
+    return dst
+
+
+def transpose_split(src, rows_pad, cols_pad, weight):
+    """src f32 [R, C] -> f16-split planes [cols_pad, 2 rows_pad] of src^T (madtp_transpose_split): activation format, or the weight
+    format at scale 1 (tagged like hip.split_f16_weight(..., log2_scale=0))."""
+    R, C = src.shape
+    dst = torch.empty((cols_pad, 2 * rows_pad), device=src.device, dtype=torch.float16)
+    _check(load().madtp_transpose_split(_p(src), src.stride(0), R, C, _p(dst), rows_pad, cols_pad, 1 if weight else 0, _stream()),
+           "madtp_transpose_split")
+    if weight:
+        dst._madtp_w_scale, dst._madtp_log2_scale = 1.0, 0
     return dst
 
 
@@ -147,16 +161,36 @@ def dgrad(dy, weight, residual=None):
     return hip.gemm(dy, wt, n=K, out_dtype=torch.float32, residual=residual)
 
 
+def _wgrad_splits(M, N, K):
+    """K ranges of the split-K weight-gradient product (0: the plain GEMM dispatch): the [N, K] output has (N/256)(K/256) tiles of
+    the big kernel - enough ranges to give every CU one unit, each at least four 64-row slabs long."""
+    if os.environ.get("MADTP_WGRAD_SPLITK", "1") == "0" or M < 2048 or N < 256 or K < 256 or K % 8:
+        return 0
+    tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    return max(1, min(32, 256 // tiles, (M // 64) // 4))
+
+
 def wgrad(dy, x):
     """dW[N, K] = dY[M, N]^T @ X[M, K]."""
     M, N = dy.shape
     K = x.shape[1]
     x3 = _x3()
     Mp = _pad(M, 64 if x3 else 32)
+    if x3:  # dY^T in the activation format (tiny values keep their digits), X^T in the weight format at scale 1
+        S = _wgrad_splits(M, N, K)
+        if S:  # long K (every token row of the batch), few output tiles: split-K partials on the 256x256 ping-pong kernel
+            Mp = _pad(M, 128 * S)
+            a, w = transpose_split(dy, Mp, N, False), transpose_split(x, Mp, _pad(K, 128), True)
+            part = torch.empty((S, N, K), device=dy.device, dtype=torch.float32)
+            _check(load().madtp_gemm_splitk_pp(_p(a), _p(w), _p(part), N, K, Mp, 2 * Mp, 2 * Mp, S, 1.0, _stream()), "madtp_gemm_splitk_pp")
+            if S == 1:
+                return part[0]
+            out = torch.empty((N, K), device=dy.device, dtype=torch.float32)
+            _check(load().madtp_splitk_sum(_p(part), S, N * K, _p(out), _stream()), "madtp_splitk_sum")
+            return out
+        return hip.gemm(transpose_split(dy, Mp, N, False), transpose_split(x, Mp, _pad(K, 128), True), n=K, out_dtype=torch.float32)
     dyt = transpose_pad(dy, Mp, N)             # [N, Mp]
     xt = transpose_pad(x, Mp, _pad(K, 128))    # [Kpad, Mp]
-    if x3:  # dY^T in the activation format (tiny values keep their digits), X^T in the weight format at scale 1
-        return hip.gemm(hip.split_f16(dyt), hip.split_f16_weight(xt, log2_scale=0), n=K, out_dtype=torch.float32)
     return hip.gemm(dyt, xt, n=K, out_dtype=torch.float32)
 
 
@@ -719,7 +753,7 @@ def att_ft_bwd(inner, q, dA, sd_dim, dinner, dq):
     """madtp_att_ft_bwd: adds the att_ft branch's gradient to dinner [B,n,K] and dq [B,n,D] (both dense f32, in place)."""
     B, n, K = inner.shape
     D = q.shape[-1]
-    ws = torch.empty((B * K * n,), device=inner.device, dtype=torch.float32)
+    ws = torch.empty((2 * B * K * n,), device=inner.device, dtype=torch.float32)
     _check(load().madtp_att_ft_bwd(_p(inner), _p(q), _p(dA), 1.0 / math.sqrt(sd_dim), _p(dinner), _p(dq), _p(ws), B, n, K, D, _stream()),
            "madtp_att_ft_bwd")
 

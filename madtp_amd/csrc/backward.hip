@@ -46,6 +46,40 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
     }
 }
 
+// ---- the same transpose straight into f16-split planes (round 5, the f16x3 backward's wgrad operands): dst[c, :] = the planes of
+// src[:, c] - WEIGHT false: activation format [P0 | P1] (P1 = (x - P0) 2^11), true: weight format [Q0 | Q1] at scale 1 (common.h) -
+// dst f16 [Cp, 2 Rp], zero beyond R / C.  64 x 64 tiles; one pass instead of transpose_pad + split_f16 (f32 written and re-read).
+template <bool WEIGHT>
+__global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ src, int ld_src, int R, int C,
+                                                              _Float16* __restrict__ dst, int Rp, int Cp) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = r0 + ty + 4 * q, c = c0 + tx;
+        tile[ty + 4 * q][tx] = (r < R && c < C) ? src[(size_t)r * ld_src + c] : 0.0f;
+    }
+    __syncthreads();
+    const int r4 = (threadIdx.x & 15) * 4, cy = threadIdx.x >> 4;  // 16 row quads x 16 columns
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int cl = cy + 16 * q, c = c0 + cl, r = r0 + r4;
+        if (c >= Cp || r >= Rp) continue;
+        const f32x4 v = (f32x4){tile[r4][cl], tile[r4 + 1][cl], tile[r4 + 2][cl], tile[r4 + 3][cl]};
+        f16x4 h, l;
+        if constexpr (WEIGHT) {
+            h = __builtin_convertvector(v, f16x4);
+            l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), f16x4);
+        } else {
+            split_f16x4(v, h, l);
+        }
+        _Float16* o = dst + (size_t)c * (2 * Rp) + r;
+        *(f16x4*)o = h;
+        *(f16x4*)(o + Rp) = l;
+    }
+}
+
 // ---- column reductions: out[c] = sum_r f(r, c); XHAT: f = dy * (x - mean_r) * rstd_r (LayerNorm gamma grad), else f = dy --
 // stage 1: grid (ceil(N/64), P): block (64 columns x 4 row lanes), rows r = chunk start + lane, +4, ... in order;
 // stage 2: the P partials of a column in order.
@@ -456,17 +490,74 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnBwdArgs a) {
 // Query_model (models/utils.py:170-178):  W[b,k,:] = softmax_n(inner[b,:,k] / sqrt(sd_dim)),  att_ft[b,k,:] = sum_n W[b,k,n] q[b,n,:].
 // Given dA = d att_ft:  dW[k,n] = <dA[k,:], q[n,:]>,  dS[k,n] = W (dW - sum_n W dW) / sqrt(sd_dim)  (added to d inner[b,n,k]),
 // dq[n,:] += sum_k W[k,n] dA[k,:].  Exact f32, fixed summation orders.
-// kernel 1: one workgroup per (dictionary column k, sample b); W is written to ws for kernel 2.
-constexpr int AF_MAXN = 1024;
+// kernel 0 (round 5; D % 16 == 0): dW[b, k, t] = <dA[b,k,:], q[b,t,:]> as a batched exact-f32 MFMA product (16x16x4 f32) - the
+// first version re-read q[b] (n x D) once per dictionary column, 100 x the operand, and was the second-largest kernel of a
+// training step.  One workgroup per (128 tokens, sample); a wave owns two 16-token tiles x all (<= 8) 16-column dictionary tiles.
+// Operands come straight from global memory as float4 (contraction index d0 + 4 (lane >> 4) + s in MFMA step s - the same
+// permutation of d on both operands); summation order: fixed by the instruction, chunks of 16 d in ascending order.
+constexpr int AF_MAXN = 1024, AF_KT = 8;
+typedef float af_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void att_ft_bwd_dw_kernel(const float* __restrict__ q, const float* __restrict__ dA,
+                                                            float* __restrict__ dW, int n, int K, int D) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y, t0 = blockIdx.x * 128 + wave * 32;
+    if (t0 >= n) return;
+    const int nkt = (K + 15) / 16;
+    const float* qr[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) qr[j] = q + ((size_t)b * n + min(t0 + 16 * j + l16, n - 1)) * D + 4 * g;
+    const float* ar[AF_KT];
+#pragma unroll
+    for (int i = 0; i < AF_KT; ++i) ar[i] = dA + ((size_t)b * K + min(16 * i + l16, K - 1)) * D + 4 * g;
+    af_f32x4 acc[AF_KT][2];
+#pragma unroll
+    for (int i = 0; i < AF_KT; ++i) { acc[i][0] = (af_f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+    for (int d0 = 0; d0 < D; d0 += 16) {
+        float4 qv[2], av[AF_KT];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) qv[j] = *(const float4*)(qr[j] + d0);
+#pragma unroll
+        for (int i = 0; i < AF_KT; ++i) if (i < nkt) av[i] = *(const float4*)(ar[i] + d0);
+#pragma unroll
+        for (int i = 0; i < AF_KT; ++i) {
+            if (i >= nkt) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, qv[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, qv[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, qv[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, qv[j].w, acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    // lane holds rows (dictionary columns) 16 i + 4 g + r, column (token) t0 + 16 j + l16
+#pragma unroll
+    for (int i = 0; i < AF_KT; ++i) {
+        if (i >= nkt) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = t0 + 16 * j + l16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * i + 4 * g + r;
+                if (k < K && t < n) dW[((size_t)b * K + k) * n + t] = acc[i][j][r];
+            }
+        }
+    }
+}
+// kernel 1: one workgroup per (dictionary column k, sample b); W is written to ws for kernel 2.  dw_pre: kernel 0's dW (else the
+// dot products are formed here, a wave per token row).
 __global__ __launch_bounds__(256) void att_ft_bwd_logits_kernel(const float* __restrict__ inner, const float* __restrict__ q,
                                                                 const float* __restrict__ dA, float inv_sqrt_d,
-                                                                float* __restrict__ dinner, float* __restrict__ Wws, int n, int K, int D) {
+                                                                float* __restrict__ dinner, float* __restrict__ Wws,
+                                                                const float* __restrict__ dw_pre, int n, int K, int D) {
     __shared__ float w_s[AF_MAXN], dw_s[AF_MAXN], red[8];
     extern __shared__ float da_s[];  // [D]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = blockIdx.x, b = blockIdx.y;
     const float* in_b = inner + (size_t)b * n * K;
-    for (int d = tid; d < D; d += 256) da_s[d] = dA[((size_t)b * K + k) * D + d];
+    if (!dw_pre)
+        for (int d = tid; d < D; d += 256) da_s[d] = dA[((size_t)b * K + k) * D + d];
     float m = -INFINITY;
     for (int t = tid; t < n; t += 256) { const float v = in_b[(size_t)t * K + k] * inv_sqrt_d; w_s[t] = v; m = fmaxf(m, v); }
     m = wave_max(m);
@@ -478,13 +569,17 @@ __global__ __launch_bounds__(256) void att_ft_bwd_logits_kernel(const float* __r
     float z = 0.f;
     for (int t = tid; t < n; t += 256) { const float e = expf(w_s[t] - m); w_s[t] = e; z += e; }
     const float Z = block_sum256(z, red);
-    // dW[n] = <dA[k,:], q[n,:]>: a wave per token row, lanes over d
-    const float* q_b = q + (size_t)b * n * D;
-    for (int t = wave; t < n; t += 4) {
-        float acc = 0.f;
-        for (int d = lane; d < D; d += 64) acc = fmaf(da_s[d], q_b[(size_t)t * D + d], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) dw_s[t] = acc;
+    if (dw_pre) {
+        for (int t = tid; t < n; t += 256) dw_s[t] = dw_pre[((size_t)b * K + k) * n + t];
+    } else {
+        // dW[n] = <dA[k,:], q[n,:]>: a wave per token row, lanes over d
+        const float* q_b = q + (size_t)b * n * D;
+        for (int t = wave; t < n; t += 4) {
+            float acc = 0.f;
+            for (int d = lane; d < D; d += 64) acc = fmaf(da_s[d], q_b[(size_t)t * D + d], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) dw_s[t] = acc;
+        }
     }
     __syncthreads();
     float c = 0.f;
@@ -534,6 +629,17 @@ extern "C" int madtp_transpose_pad(const float* src, int ld_src, int R, int C, f
     if (!src || !dst || R <= 0 || C <= 0 || Rp < R || Cp < C || ld_src < C || ld_dst < Rp) return MADTP_E_BADARG;
     hipLaunchKernelGGL(transpose_pad_kernel, dim3((Rp + 31) / 32, (Cp + 31) / 32), dim3(256), 0, (hipStream_t)stream, src, ld_src, R, C,
                        dst, ld_dst, Rp, Cp);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_transpose_split(const float* src, int ld_src, int R, int C, void* dst, int Rp, int Cp, int weight_format, void* stream) {
+    if (!src || !dst || R <= 0 || C <= 0 || Rp < R || Cp < C || ld_src < C) return MADTP_E_BADARG;
+    if (Rp % 4) return MADTP_E_SHAPE;
+    if ((uintptr_t)dst & 7) return MADTP_E_ALIGN;
+    const dim3 grid((Rp + 63) / 64, (Cp + 63) / 64);
+    if (weight_format) hipLaunchKernelGGL(transpose_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, R, C, (_Float16*)dst, Rp, Cp);
+    else hipLaunchKernelGGL(transpose_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, R, C, (_Float16*)dst, Rp, Cp);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
@@ -682,13 +788,20 @@ extern "C" int madtp_attention_bwd_cross(const float* q, int ldq, const float* k
 }
 
 // d att_ft -> (d inner += ..., d q += ...), see att_ft_bwd_logits_kernel.  inner / dinner: dense [B, n, K]; q / dq: dense [B, n, D];
-// dA: [B, K, D]; ws: B K n floats.  inv_sqrt_d = 1 / sqrt(sd_dim) (models/utils.py:174).
+// dA: [B, K, D]; ws: 2 B K n floats (W, dW).  inv_sqrt_d = 1 / sqrt(sd_dim) (models/utils.py:174).
 extern "C" int madtp_att_ft_bwd(const float* inner, const float* q, const float* dA, float inv_sqrt_d, float* dinner, float* dq,
                                 float* ws, int B, int n, int K, int D, void* stream) {
     if (!inner || !q || !dA || !dinner || !dq || !ws || B <= 0 || n <= 0 || K <= 0 || D <= 0) return MADTP_E_BADARG;
     if (n > AF_MAXN || K > 128 || D > 1024) return MADTP_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(att_ft_bwd_logits_kernel, dim3(K, B), dim3(256), (size_t)D * sizeof(float), s, inner, q, dA, inv_sqrt_d, dinner, ws, n, K, D);
+    float* dw_pre = nullptr;
+    if (D % 16 == 0 && aligned16(q) && aligned16(dA)) {
+        dw_pre = ws + (size_t)B * K * n;
+        hipLaunchKernelGGL(att_ft_bwd_dw_kernel, dim3((n + 127) / 128, B), dim3(256), 0, s, q, dA, dw_pre, n, K, D);
+        MADTP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(att_ft_bwd_logits_kernel, dim3(K, B), dim3(256), (size_t)D * sizeof(float), s, inner, q, dA, inv_sqrt_d, dinner, ws,
+                       dw_pre, n, K, D);
     MADTP_LAUNCH_CHECK();
     hipLaunchKernelGGL(att_ft_bwd_q_kernel, dim3((n + 7) / 8, B), dim3(256), 0, s, ws, dA, dq, n, K, D);
     MADTP_LAUNCH_CHECK();

@@ -1081,6 +1081,54 @@ extern "C" int madtp_gemm_splitk(const void* A, const void* W, float* part, int 
                        stream);
 }
 
+// Split-K partials of a LONG-K product on the 256x256 ping-pong kernel (round 5; f16-split operands only): part[s, M, N] (f32) =
+// A[:, Ks] W[:, Ks]^T with the accumulator scale applied.  The backward's weight gradient dW = dY^T X is this shape - a few
+// hundred to a few thousand output rows and columns, K = every token row of the batch (10-25 k) - and ran on 64x64 tiles at about
+// half the rate: 9-36 tiles of 256x256 times `splits` K ranges fill the chip instead.  K % (128 splits) == 0, N % 8 == 0;
+// madtp_splitk_sum reduces the slabs in order.
+extern "C" int madtp_gemm_splitk_pp(const void* A, const void* W, float* part, int M, int N, int K, int lda, int ldw, int splits,
+                                    float acc_scale, void* stream) {
+    if (!A || !W || !part || M <= 0 || N <= 0 || K <= 0 || splits < 1) return MADTP_E_BADARG;
+    if (K % (128 * splits) || N % 8 || lda < 2 * K || ldw < 2 * K) return MADTP_E_SHAPE;
+    if (!aligned16(A) || !aligned16(W) || !aligned16(part) || (lda * 2) % 16 || (ldw * 2) % 16) return MADTP_E_ALIGN;
+    if (((size_t)M + 255) * (size_t)lda * 2 >= ((size_t)1 << 32) || ((size_t)N + 255) * (size_t)ldw * 2 >= ((size_t)1 << 32) ||
+        (size_t)N * 256 * 4 >= ((size_t)1 << 31)) return MADTP_E_SHAPE;
+    GemmArgs g{};
+    g.A = (const char*)A; g.W = (const char*)W; g.C = part;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = N; g.act = MADTP_ACT_NONE;
+    g.out_scale = 1.f; g.acc_scale = g.acc_scale2 = acc_scale;
+    g.splitk = splits; g.fast_epi = 1;
+    g.ntm = (M + 255) / 256; g.ntn = (N + 255) / 256;
+    const int slots_max = (g.ntm * g.ntn * splits + 7) / 8, cap = gemm_wg_per_xcd();
+    const int grid = 8 * (slots_max < cap ? slots_max : cap);
+    const int rc = madtp_gemm_pp_launch(&g, OM_F32, 2, 256, grid, stream);
+    if (rc) return rc;
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ part, int splits, size_t count4, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count4) return;
+    float4 a = ((const float4*)part)[i];
+    for (int s = 1; s < splits; ++s) {
+        const float4 b = ((const float4*)part)[(size_t)s * count4 + i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    ((float4*)out)[i] = a;
+}
+}  // namespace
+// out[i] = part[0][i] + part[1][i] + ... (in this order), count % 4 == 0
+extern "C" int madtp_splitk_sum(const float* part, int splits, size_t count, float* out, void* stream) {
+    if (!part || !out || splits < 1 || count == 0) return MADTP_E_BADARG;
+    if (count % 4) return MADTP_E_SHAPE;
+    if (!aligned16(part) || !aligned16(out)) return MADTP_E_ALIGN;
+    hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, splits, count / 4, out);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
 // Stream-K workspace of the wave-specialised kernel: one per (device, stream) - launches on one stream are ordered, launches
 // on different streams must not share partials - allocated on first use (32 MiB of partials + the tickets, zeroed once; every
 // ticket resets itself).  OFF by default (MADTP_GEMM_SK=1 turns it on; madtp_gemm_set_config(5) always uses it): on isolated

@@ -37,7 +37,7 @@
 //     the same accumulators.  P0 and Q0 are staged twice (L2 -> LDS bytes per MFMA = the plain kernel's).
 // ABL (timing experiments only, results are wrong unless 0 or 8/16): bit 0 no steady-state LDS-DMA, bit 1 no MFMAs, bit 2 no
 // steady-state fragment reads, bit 3 the DMA issue moves from the read part to the head of the MFMA part, bit 4 no s_setprio.
-template <int OM, int MODE, int FA = 4, int ABL = 0>
+template <int OM, int MODE, int FA = 4, int ABL = 0, bool SPLITK = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
     static_assert(FA == 4 || FA == 3, "256- or 192-row tiles");
     constexpr bool X3 = MODE == 2, F16 = MODE != 0;
@@ -46,14 +46,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, gl = gridDim.x >> 3;
+    // split-K (round 5, the backward's weight gradients: few tiles, K = every token row of the batch): a unit of work is
+    // (tile, K range s of S), s fastest; unit (t, s) writes the f32 partial product of its range to C + s M ldc (no bias /
+    // activation / residual - the caller reduces the S slabs in order).  S = 1: units are tiles.  SPLITK instantiation: f16-split
+    // operands, f32 output, 256-row tile.
+    const int S = SPLITK ? g.splitk : 1;  // (compile-time 1 in the forward's instantiations)
     int t0, nslots;
-    xcd_tiles(g.ntm * g.ntn, xcd, t0, nslots);
+    xcd_tiles(g.ntm * g.ntn * S, xcd, t0, nslots);
     if (lb >= nslots) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int nkp = g.K / 64;  // k-slabs per operand plane
+    const int nks = __builtin_amdgcn_readfirstlane(nkp / S);  // k-slabs of a unit
 
     // ---- fragment read addresses inside a half-tile image (128 rows of 128 B, 16-byte chunk index ^= key(row)) ----
     // A fragment i: row wr 64 + l16 + 16 i, key l16 & 7; W fragment jj: row rw0 + (wfrag_row(1,0) - wfrag_row(0,0)) jj.
@@ -79,13 +85,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (unsigned)((size_t)g.M * g.lda * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (unsigned)((size_t)npad * g.ldw * 2), 0x00020000);
     unsigned va[2][2], vw[2][2];  // [half][q]: per-lane source byte offsets at k = 0 of the tile the stream is in
-    int is_slot = lb, is_koff = 0;
+    int is_slot = lb, is_koff = 0, is_kend = nkp * ROWB;  // the stream's unit and its byte range [is_koff, is_kend) of a row's plane
     const int plane_b = g.K * 2;                  // bytes from a row's first plane to its second (f16-split rows: [P0 | P1], [Q0 | Q1])
     int is_s = 0;                                 // f16-split: which of the k-slab's three products the stream is in
     int is_offa = 0, is_offw = X3 ? plane_b : 0;  // scalar byte offsets of the stream's current slab: (P0, Q1) first
     auto tile_offsets = [&]() {
         int tm, tn;
-        tile_mn(g, t0 + is_slot, tm, tn);
+        tile_mn(g, S > 1 ? __builtin_amdgcn_readfirstlane((t0 + is_slot) / S) : t0 + is_slot, tm, tn);
         const unsigned lda2 = (unsigned)g.lda * 2u, ldw2 = (unsigned)g.ldw * 2u;
         int ln = lane;  // opaque copy: the per-lane constants below are recomputed per tile instead of living through the main loop
         asm volatile("" : "+v"(ln));
@@ -103,6 +109,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         }
     };
     tile_offsets();
+    auto unit_krange = [&]() {  // K range of the stream's unit
+        if (S > 1) {
+            const int u = t0 + is_slot, sp = __builtin_amdgcn_readfirstlane(u - (u / S) * S);
+            is_koff = sp * nks * ROWB;
+            is_kend = is_koff + nks * ROWB;
+        } else {
+            is_koff = 0;
+        }
+    };
+    unit_krange();
+    is_offa = is_koff; is_offw = is_koff + (X3 ? plane_b : 0);  // first slab of the first unit: (P0, Q1) at its K range
     bool steady = false;
 #define PP_ISSUE(RS, V, SLOT, OFF)                                                                                \
     if (!(ABL & 1) || !steady) {                                                                                  \
@@ -118,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         if (!X3 || ++is_s == 3) {                                                              \
             is_s = 0;                                                                          \
             is_koff += ROWB;                                                                   \
-            if (is_koff == nkp * ROWB) { is_koff = 0; is_slot += gl; tile_offsets(); }         \
+            if (is_koff == is_kend) { is_slot += gl; tile_offsets(); unit_krange(); }          \
         }                                                                                      \
         is_offa = is_koff + ((X3 && is_s == 2) ? plane_b : 0);                                 \
         is_offw = is_koff + ((X3 && is_s == 0) ? plane_b : 0);                                 \
@@ -211,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         for (int i = 0; i < 2 * FA; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = zero4;
-        for (int kt = 0; kt < nkp; kt += 2) {
+        for (int kt = 0; kt < nks; kt += 2) {
             if constexpr (X3) {  // two k-slabs = six slabs of the stream: (P0,Q1) (P0,Q0) (P1,Q0') (P0,Q1) (P0,Q0) (P1,Q0')
                 PP_SLAB(0, false)
                 PP_SLAB(1, false)
@@ -228,7 +245,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with the other row's last barrier
         PP_FENCE();
         int ctm, ctn;
-        tile_mn(g, t0 + slot, ctm, ctn);
+        const int cu = t0 + slot, ct = S > 1 ? __builtin_amdgcn_readfirstlane(cu / S) : cu;
+        tile_mn(g, ct, ctm, ctn);
+        const size_t c_off = S > 1 ? (size_t)(cu - ct * S) * g.M * (size_t)(g.ldc < 0 ? -g.ldc : g.ldc) : 0;
         const int m0 = ctm * BM, n0 = ctn * BN + (wc >> 1) * 128;
         // the epilogue's per-lane addresses are loop invariants of the tile loop: left alone the compiler hoists them above the
         // main loop, where every register is taken (it then spilled the fragment bases and reloaded them with s_waitcnt vmcnt(0)
@@ -238,10 +257,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         const int l16e = lne & 15, grp4e = lne >> 4;
 #define EPI(ACT)                                                                                                  \
     if constexpr (LP_OUT) {                                                                                       \
-        epilogue<OM, ACT, false, 2 * FA, 4, BM, 128>(g, acc, res, m0, n0, wr, wc & 1, l16e, grp4e, 0);             \
+        epilogue<OM, ACT, false, 2 * FA, 4, BM, 128>(g, acc, res, m0, n0, wr, wc & 1, l16e, grp4e, c_off);             \
     } else {                                                                                                      \
-        if (g.residual) epilogue<OM, ACT, true, 2 * FA, 4, BM, 128>(g, acc, res, m0, n0, wr, wc & 1, l16e, grp4e, 0); \
-        else epilogue<OM, ACT, false, 2 * FA, 4, BM, 128>(g, acc, res, m0, n0, wr, wc & 1, l16e, grp4e, 0);        \
+        if (g.residual) epilogue<OM, ACT, true, 2 * FA, 4, BM, 128>(g, acc, res, m0, n0, wr, wc & 1, l16e, grp4e, c_off); \
+        else epilogue<OM, ACT, false, 2 * FA, 4, BM, 128>(g, acc, res, m0, n0, wr, wc & 1, l16e, grp4e, c_off);        \
     }
         switch (g.act) {
             case MADTP_ACT_GELU_ERF: EPI(MADTP_ACT_GELU_ERF) break;
@@ -281,6 +300,12 @@ __attribute__((visibility("hidden"))) int madtp_gemm_pp_launch(const void* args,
 #define PP_ROWS(OM_, MODE_)                                                                                     \
     do { if (rows == 192) PP_LAUNCH(OM_, MODE_, 3, 0); else PP_LAUNCH(OM_, MODE_, 4, 0); } while (0)
     if (rows != 256 && rows != 192) return MADTP_E_BADARG;
+    if (g.splitk > 1) {  // split-K partials (the backward's weight gradients)
+        if (mode != 2 || om != OM_F32 || rows != 256 || g.bias || g.residual || g.act != MADTP_ACT_NONE) return MADTP_E_DTYPE;
+        MADTP_ENSURE_MAX_LDS((gemm_pp_kernel<OM_F32, 2, 4, 0, true>), lds);
+        hipLaunchKernelGGL((gemm_pp_kernel<OM_F32, 2, 4, 0, true>), dim3(grid), dim3(512), lds, s, g);
+        return 0;
+    }
     if (mode == 2) {
         if (om == OM_F16S) PP_ROWS(OM_F16S, 2); else if (om == OM_F32) PP_ROWS(OM_F32, 2); else return MADTP_E_DTYPE;
     } else if (mode == 1) {

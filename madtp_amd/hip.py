@@ -13,7 +13,7 @@ import torch
 F32, BF16, F16S, F16 = 0, 1, 2, 3  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 #                                    F16: plain IEEE f16 operands (the "f16" fast mode), see set_lp_format below
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -103,6 +103,9 @@ _SIGS = {
                                          c_void_p, c_int, c_void_p]),
     # backward of the pruned ViT block (csrc/backward.hip)
     "madtp_transpose_pad": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "madtp_gemm_splitk_pp": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "madtp_splitk_sum": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
+    "madtp_transpose_split": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "madtp_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "madtp_act_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "madtp_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_void_p]),

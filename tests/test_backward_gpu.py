@@ -72,6 +72,42 @@ def test_dgrad_wgrad(hip):
     assert _rel(bw.wgrad(dy, x), (dy.double().t() @ x.double()).float()) < 1e-5
 
 
+def test_transpose_split_equals_transpose_then_split(hip):
+    """madtp_transpose_split (one pass) writes the bits of madtp_transpose_pad + madtp_split_f16 / madtp_split_f16_weight(scale 1),
+    zero padding included - the operands of the f16x3 weight gradient."""
+    from madtp_amd import backward as bw
+    for (R, C, Rp, Cp) in [(394, 2304, 512, 2304), (197, 100, 256, 128), (1001, 768, 1024, 768), (70, 3, 128, 64)]:
+        x = (_rand(R, C, seed=R) * torch.logspace(-6, 1, C)[None, :]).cuda()  # tiny and O(1) columns: both planes carry digits
+        t = bw.transpose_pad(x, Rp, Cp)
+        act, wt = bw.transpose_split(x, Rp, Cp, False), bw.transpose_split(x, Rp, Cp, True)
+        assert act.shape == (Cp, 2 * Rp) and torch.equal(act, hip.split_f16(t))
+        ref_w = hip.split_f16_weight(t, log2_scale=0)
+        assert torch.equal(wt, ref_w) and wt._madtp_log2_scale == 0 and hip.w_scale_of(wt) == 1.0
+
+
+@pytest.mark.parametrize("M,N,K", [(6304, 2304, 768), (25216, 768, 768), (4096, 768, 3072), (2500, 3072, 768), (2100, 264, 776)])
+def test_wgrad_splitk(hip, M, N, K):
+    """the f16x3 weight gradient on split-K partials of the 256x256 ping-pong kernel (madtp_gemm_splitk_pp + madtp_splitk_sum) vs
+    float64, next to the plain dispatch it replaces; gradients of 1e-4 keep their digits (activation-format dY^T: ~2^-36 absolute)."""
+    from madtp_amd import backward as bw, runtime
+    dy = (_rand(M, N, seed=1) * 1e-2).cuda()
+    dy[:, : N // 2] *= 1e-2
+    x = _rand(M, K, seed=2).cuda()
+    ref = dy.double().t() @ x.double()
+    with runtime.precision("f16x3"):
+        assert bw._wgrad_splits(M, N, K) >= 1
+        got = bw.wgrad(dy, x)
+        os.environ["MADTP_WGRAD_SPLITK"] = "0"
+        try:
+            plain = bw.wgrad(dy, x)
+        finally:
+            del os.environ["MADTP_WGRAD_SPLITK"]
+        assert torch.equal(got, bw.wgrad(dy, x))  # fixed summation order
+    col = ref.abs().amax(1, keepdim=True)  # per output row (a dY column): small-gradient rows are held to their own scale
+    assert float(((got.double() - ref).abs() / col).max()) < 2e-6, float(((got.double() - ref).abs() / col).max())
+    assert float(((plain.double() - ref).abs() / col).max()) < 1e-5  # (one f32 accumulation chain over all of K)
+
+
 def test_layernorm_bwd(hip):
     from madtp_amd import backward as bw
     rows, dim = 1001, 768
@@ -123,13 +159,13 @@ def test_attention_bwd_cross(hip, B, Nq, Nk):
         assert _rel(dq, qr.grad) < 2e-5 and _rel(dkv, kvr.grad) < 2e-5
 
 
-@pytest.mark.parametrize("B,n", [(3, 50), (2, 196), (1, 300)])
-def test_att_ft_bwd(hip, B, n):
+@pytest.mark.parametrize("B,n,D", [(3, 50, 768), (2, 196, 768), (1, 300, 768), (2, 197, 512), (2, 40, 72), (64, 197, 768)])
+def test_att_ft_bwd(hip, B, n, D):
     """madtp_att_ft_bwd vs torch autograd through models/utils.py:174-178 (softmax over tokens of inner / sqrt(d), W q); the kernel
     ADDS to the gradients it is given."""
     import math
     from madtp_amd import backward as bw
-    K, D = 100, 768
+    K = 100  # (D % 16 == 0: q dA^T as a batched exact-f32 MFMA product; else the per-column dot-product loop)
     q, sd, dA = _rand(B, n, D, seed=1).cuda(), _rand(K, D, seed=2, scale=0.3).cuda(), _rand(B, K, D, seed=3).cuda()
     qr, ir = q.clone().requires_grad_(True), (q @ sd.t()).clone().requires_grad_(True)
     w = torch.softmax((ir / math.sqrt(D)).permute(0, 2, 1), dim=-1)
