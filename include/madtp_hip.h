@@ -562,8 +562,11 @@ int madtp_sample_top_p(const float* logits, int ld, int V, const int64_t* prev_i
 int madtp_transpose_pad(const float* src, int ld_src, int R, int C, float* dst, int ld_dst, int Rp, int Cp, void* stream);
 /* The same transpose straight into the f16-split operand planes of the f16x3 backward's weight gradient (ABI 28): dst f16
  * [Cp, 2*Rp] with row c = the planes of src[:, c] - weight_format 0: activation planes [P0 | P1] (dY^T), 1: weight planes [Q0 | Q1]
- * at scale 1 (X^T) - zero beyond R / C.  Rp % 4 == 0.  One pass instead of madtp_transpose_pad + madtp_split_f16(_weight). */
-int madtp_transpose_split(const float* src, int ld_src, int R, int C, void* dst, int Rp, int Cp, int weight_format, void* stream);
+ * at scale 1 (X^T) - zero beyond R / C.  Rp % 4 == 0.  One pass instead of madtp_transpose_pad + madtp_split_f16(_weight).
+ * colsum_out (or NULL): f32 [C], the column sums of src over its R rows - the bias gradient of the same dY - from per-tile
+ * partials in colsum_ws (ceil(Rp/64) * C floats), added in a fixed order. */
+int madtp_transpose_split(const float* src, int ld_src, int R, int C, void* dst, int Rp, int Cp, int weight_format,
+                          float* colsum_out, float* colsum_ws, void* stream);
 /* out[c] = sum_r dy[r, c]: bias gradients (nn.Linear, LayerNorm beta).  part_ws: 64 * N floats of scratch. */
 int madtp_colsum(const float* dy, int ld, int M, int N, float* out, float* part_ws, void* stream);
 /* g = act(u) (g != NULL) and / or du = dg * act'(u) (du != NULL): Mlp's GELU (vit.py:34) and its derivative; n % 4 == 0. */

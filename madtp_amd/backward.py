@@ -38,16 +38,19 @@ def transpose_pad(src, rows_pad, cols_pad):
     return dst
 
 
-def transpose_split(src, rows_pad, cols_pad, weight):
+def transpose_split(src, rows_pad, cols_pad, weight, colsum=None):
     """src f32 [R, C] -> f16-split planes [cols_pad, 2 rows_pad] of src^T (madtp_transpose_split): activation format, or the weight
-    format at scale 1 (tagged like hip.split_f16_weight(..., log2_scale=0))."""
+    format at scale 1 (tagged like hip.split_f16_weight(..., log2_scale=0)).  colsum (True / False): -> (planes, column sums of src
+    [C] or None) from the same pass."""
     R, C = src.shape
     dst = torch.empty((cols_pad, 2 * rows_pad), device=src.device, dtype=torch.float16)
-    _check(load().madtp_transpose_split(_p(src), src.stride(0), R, C, _p(dst), rows_pad, cols_pad, 1 if weight else 0, _stream()),
-           "madtp_transpose_split")
+    cs = torch.empty((C,), device=src.device, dtype=torch.float32) if colsum else None
+    ws = torch.empty(((rows_pad + 63) // 64 * C,), device=src.device, dtype=torch.float32) if colsum else None
+    _check(load().madtp_transpose_split(_p(src), src.stride(0), R, C, _p(dst), rows_pad, cols_pad, 1 if weight else 0, _p(cs), _p(ws),
+                                        _stream()), "madtp_transpose_split")
     if weight:
         dst._madtp_w_scale, dst._madtp_log2_scale = 1.0, 0
-    return dst
+    return dst if colsum is None else (dst, cs)
 
 
 # ---- precision of the backward's GEMMs --------------------------------------------------------------------------------------
@@ -164,34 +167,39 @@ def dgrad(dy, weight, residual=None):
 def _wgrad_splits(M, N, K):
     """K ranges of the split-K weight-gradient product (0: the plain GEMM dispatch): the [N, K] output has (N/256)(K/256) tiles of
     the big kernel - enough ranges to give every CU one unit, each at least four 64-row slabs long."""
-    if os.environ.get("MADTP_WGRAD_SPLITK", "1") == "0" or M < 2048 or N < 256 or K < 256 or K % 8:
+    if os.environ.get("MADTP_WGRAD_SPLITK", "1") == "0" or M < 2048 or N < 64 or K < 256 or K % 8:
         return 0
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
     return max(1, min(32, 256 // tiles, (M // 64) // 4))
 
 
-def wgrad(dy, x):
-    """dW[N, K] = dY[M, N]^T @ X[M, K]."""
+def wgrad(dy, x, bias=False):
+    """dW[N, K] = dY[M, N]^T @ X[M, K]; bias: -> (dW, db) with db[N] = the column sums of dY (the f16x3 route takes them from the
+    pass that transposes dY)."""
     M, N = dy.shape
     K = x.shape[1]
     x3 = _x3()
     Mp = _pad(M, 64 if x3 else 32)
     if x3:  # dY^T in the activation format (tiny values keep their digits), X^T in the weight format at scale 1
         S = _wgrad_splits(M, N, K)
+        Mp = _pad(M, 128 * S) if S else Mp
+        a, db = transpose_split(dy, Mp, N, False, colsum=bias)
+        w = transpose_split(x, Mp, _pad(K, 128), True)
         if S:  # long K (every token row of the batch), few output tiles: split-K partials on the 256x256 ping-pong kernel
-            Mp = _pad(M, 128 * S)
-            a, w = transpose_split(dy, Mp, N, False), transpose_split(x, Mp, _pad(K, 128), True)
             part = torch.empty((S, N, K), device=dy.device, dtype=torch.float32)
             _check(load().madtp_gemm_splitk_pp(_p(a), _p(w), _p(part), N, K, Mp, 2 * Mp, 2 * Mp, S, 1.0, _stream()), "madtp_gemm_splitk_pp")
             if S == 1:
-                return part[0]
-            out = torch.empty((N, K), device=dy.device, dtype=torch.float32)
-            _check(load().madtp_splitk_sum(_p(part), S, N * K, _p(out), _stream()), "madtp_splitk_sum")
-            return out
-        return hip.gemm(transpose_split(dy, Mp, N, False), transpose_split(x, Mp, _pad(K, 128), True), n=K, out_dtype=torch.float32)
+                dw = part[0]
+            else:
+                dw = torch.empty((N, K), device=dy.device, dtype=torch.float32)
+                _check(load().madtp_splitk_sum(_p(part), S, N * K, _p(dw), _stream()), "madtp_splitk_sum")
+        else:
+            dw = hip.gemm(a, w, n=K, out_dtype=torch.float32)
+        return (dw, db) if bias else dw
     dyt = transpose_pad(dy, Mp, N)             # [N, Mp]
     xt = transpose_pad(x, Mp, _pad(K, 128))    # [Kpad, Mp]
-    return hip.gemm(dyt, xt, n=K, out_dtype=torch.float32)
+    dw = hip.gemm(dyt, xt, n=K, out_dtype=torch.float32)
+    return (dw, colsum(dy)) if bias else dw
 
 
 def colsum(dy):
@@ -385,10 +393,10 @@ def vit_block_backward(blk, x, token_attn, temperature, k, dy, mask_qk=None, dp_
     grads = {}
     dy2 = dy.reshape(M2, D).contiguous().float()
     dg = dgrad(dy2, P.fc2.weight.detach())               # y = y0 + g W2^T + b2
-    grads[nm["fc2"] + ".weight"], grads[nm["fc2"] + ".bias"] = wgrad(dy2, g), colsum(dy2)
+    grads[nm["fc2"] + ".weight"], grads[nm["fc2"] + ".bias"] = wgrad(dy2, g, bias=True)
     du = act_bwd(u, dg, P.act)
     dh2 = dgrad(du, P.fc1.weight.detach())
-    grads[nm["fc1"] + ".weight"], grads[nm["fc1"] + ".bias"] = wgrad(du, h2), colsum(du)
+    grads[nm["fc1"] + ".weight"], grads[nm["fc1"] + ".bias"] = wgrad(du, h2, bias=True)
     dy0, grads[nm["norm2"] + ".weight"], grads[nm["norm2"] + ".bias"] = layernorm_bwd(y02, P.norm2.weight.detach(), dh2, eps2, add=dy2)
     dta = None
     dnrm = da = dp0 = None
@@ -399,12 +407,13 @@ def vit_block_backward(blk, x, token_attn, temperature, k, dy, mask_qk=None, dp_
     else:
         dxa2 = dy0
     dout = dgrad(dxa2, P.proj.weight.detach())          # x_attn = x + out Wp^T + bp
-    grads[nm["proj"] + ".weight"], grads[nm["proj"] + ".bias"] = wgrad(dxa2, out), colsum(dxa2)
+    grads[nm["proj"] + ".weight"], grads[nm["proj"] + ".bias"] = wgrad(dxa2, out, bias=True)
     dqkv = attention_bwd(qkv, dout, out, B, H, N, scale, dnrm, da, dp0, mask_qk=mask_qk, dp_out=dp_out)
     dh1 = dgrad(dqkv, P.qkv_w.detach())
-    grads[nm["qkv_w"]] = wgrad(dqkv, h1)
     if P.qkv_b is not None:
-        grads[nm["qkv_b"]] = colsum(dqkv)
+        grads[nm["qkv_w"]], grads[nm["qkv_b"]] = wgrad(dqkv, h1, bias=True)
+    else:
+        grads[nm["qkv_w"]] = wgrad(dqkv, h1)
     dx2, grads[nm["norm1"] + ".weight"], grads[nm["norm1"] + ".bias"] = layernorm_bwd(x2, P.norm1.weight.detach(), dh1, eps1, add=dxa2)
     return dx2.view(B, N, D), dta, grads
 
@@ -512,9 +521,9 @@ def _cross_branch_bwd(prefix, sm, grads, dcctx, cq, ckv, wckv, y02, enc2, B, H, 
     D = H * 64
     dcq, dckv = attention_bwd_cross(cq, ckv, dcctx, B, H, L2, Nk, scale, key_mask=key_mask)
     dy0 = dgrad(dcq, sm.query.weight.detach(), residual=dy0_acc)
-    grads[prefix + "query.weight"], grads[prefix + "query.bias"] = wgrad(dcq, y02), colsum(dcq)
+    grads[prefix + "query.weight"], grads[prefix + "query.bias"] = wgrad(dcq, y02, bias=True)
     denc = dgrad(dckv, wckv)
-    gw, gb = wgrad(dckv, enc2), colsum(dckv)
+    gw, gb = wgrad(dckv, enc2, bias=True)
     for i, nm in enumerate(("key", "value")):
         grads[prefix + nm + ".weight"] = gw[i * D:(i + 1) * D]
         grads[prefix + nm + ".bias"] = gb[i * D:(i + 1) * D]
@@ -589,10 +598,10 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
     dy2 = dy.reshape(M2, D).contiguous().float()
     df0, grads["output.LayerNorm.weight"], grads["output.LayerNorm.bias"] = layernorm_bwd(f0, ln2.weight.detach(), dy2, ln2.eps)
     dgl = dgrad(df0, layer.output.dense.weight.detach())
-    grads["output.dense.weight"], grads["output.dense.bias"] = wgrad(df0, gl), colsum(df0)
+    grads["output.dense.weight"], grads["output.dense.bias"] = wgrad(df0, gl, bias=True)
     du = act_bwd(u, dgl, hip.ACT_GELU)
     dx2 = dgrad(du, layer.intermediate.dense.weight.detach(), residual=df0)   # f0 = x2 + ffn(x2)
-    grads["intermediate.dense.weight"], grads["intermediate.dense.bias"] = wgrad(du, x2), colsum(du)
+    grads["intermediate.dense.weight"], grads["intermediate.dense.bias"] = wgrad(du, x2, bias=True)
     denc = None
     if enc is not None:
         P = "crossattention."
@@ -601,7 +610,7 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
         if twin:
             if co.merge:
                 dd01 = dgrad(dc0, co.merge_layer.weight.detach())             # [M2, 2D]
-                grads[P + "output.merge_layer.weight"], grads[P + "output.merge_layer.bias"] = wgrad(dc0, d01), colsum(dc0)
+                grads[P + "output.merge_layer.weight"], grads[P + "output.merge_layer.bias"] = wgrad(dc0, d01, bias=True)
                 dds = [dd01[:, :D].contiguous(), dd01[:, D:].contiguous()]
             else:
                 half = dc0 * 0.5
@@ -611,7 +620,7 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
                 dn = (co.dense0, co.dense1)[i]
                 cq, ckv, cctx, wckv = br[i]
                 dcctx = dgrad(dd, dn.weight.detach())
-                grads[P + f"output.dense{i}.weight"], grads[P + f"output.dense{i}.bias"] = wgrad(dd, cctx), colsum(dd)
+                grads[P + f"output.dense{i}.weight"], grads[P + f"output.dense{i}.bias"] = wgrad(dd, cctx, bias=True)
                 dy0, de = _cross_branch_bwd(P + f"self{i}.", sm, grads, dcctx, cq, ckv, wckv, y02, enc2s[i], B, H, L2, Nk, scale,
                                             ems[i], dy0)
                 dencs.append(de.view(B, Nk, De))
@@ -619,7 +628,7 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
         else:
             cq, ckv, cctx, wckv = br[0]
             dcctx = dgrad(dc0, co.dense.weight.detach())
-            grads[P + "output.dense.weight"], grads[P + "output.dense.bias"] = wgrad(dc0, cctx), colsum(dc0)
+            grads[P + "output.dense.weight"], grads[P + "output.dense.bias"] = wgrad(dc0, cctx, bias=True)
             dy0, de = _cross_branch_bwd(P + "self.", sms[0], grads, dcctx, cq, ckv, wckv, y02, enc2s[0], B, H, L2, Nk, scale, None, dc0)
             denc = de.view(B, Nk, De)
     else:
@@ -635,10 +644,10 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
     da0, grads["attention.output.LayerNorm.weight"], grads["attention.output.LayerNorm.bias"] = layernorm_bwd(
         a0, ln1.weight.detach(), dao.contiguous(), ln1.eps)
     dctx = dgrad(da0, so.dense.weight.detach())                               # a0 = hidden + ctx Wo^T + bo
-    grads["attention.output.dense.weight"], grads["attention.output.dense.bias"] = wgrad(da0, ctx), colsum(da0)
+    grads["attention.output.dense.weight"], grads["attention.output.dense.bias"] = wgrad(da0, ctx, bias=True)
     dqkv = attention_bwd(qkv, dctx, ctx, B, H, L, scale, dnrm, da, dp0, key_mask=mask2d, mask_qk=causal)
     dh = dgrad(dqkv, wqkv, residual=da0)
-    gw, gb = wgrad(dqkv, h2), colsum(dqkv)
+    gw, gb = wgrad(dqkv, h2, bias=True)
     for i, nm in enumerate(("query", "key", "value")):
         grads[f"attention.self.{nm}.weight"] = gw[i * D:(i + 1) * D]
         grads[f"attention.self.{nm}.bias"] = gb[i * D:(i + 1) * D]
@@ -744,8 +753,8 @@ class PatchTokensFunction(torch.autograd.Function):
             dcls = dtok[0].reshape(1, 1, D).clone()
             dpatch = dx[:, 1:, :].reshape(B * ctx.np_, D).contiguous()
             cols = hip.patchify(img.contiguous().float(), ctx.patch, torch.float32)
-            dw = wgrad(dpatch, cols).view_as(w)
-            db = colsum(dpatch) if ctx.has_b else None
+            dw, db = wgrad(dpatch, cols, bias=True) if ctx.has_b else (wgrad(dpatch, cols), None)
+            dw = dw.view_as(w)
         return None, None, dw, db, dcls, dpos
 
 
@@ -796,7 +805,7 @@ class QueryModelFunction(torch.autograd.Function):
             dsd = wgrad(d2, q.reshape(B * n, -1)) if ctx.needs_input_grad[2] else None
             gmap = ()
             if ctx.has_map:
-                gmap = (wgrad(dq2, ft.view(B * n, D)), colsum(dq2))
+                gmap = wgrad(dq2, ft.view(B * n, D), bias=True)
                 dq2 = dgrad(dq2, wm.detach())
             dx = None
             if ctx.needs_input_grad[1]:

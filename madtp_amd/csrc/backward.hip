@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 // dst f16 [Cp, 2 Rp], zero beyond R / C.  64 x 64 tiles; one pass instead of transpose_pad + split_f16 (f32 written and re-read).
 template <bool WEIGHT>
 __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ src, int ld_src, int R, int C,
-                                                              _Float16* __restrict__ dst, int Rp, int Cp) {
+                                                              _Float16* __restrict__ dst, int Rp, int Cp,
+                                                              float* __restrict__ colsum_part) {
     __shared__ float tile[64][65];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
@@ -61,6 +62,15 @@ __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __res
         tile[ty + 4 * q][tx] = (r < R && c < C) ? src[(size_t)r * ld_src + c] : 0.0f;
     }
     __syncthreads();
+    if (colsum_part) {  // the tile's column sums (the bias gradient's partials, rows in order): part[row tile, c]
+        __shared__ float red[4][64];
+        float cs = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) cs += tile[16 * ty + q][tx];
+        red[ty][tx] = cs;
+        __syncthreads();
+        if (ty == 0 && c0 + tx < C) colsum_part[(size_t)blockIdx.x * C + c0 + tx] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    }
     const int r4 = (threadIdx.x & 15) * 4, cy = threadIdx.x >> 4;  // 16 row quads x 16 columns
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -101,12 +111,24 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     __syncthreads();
     if (sub == 0 && c < N) part[(size_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void col_reduce_final_kernel(const float* __restrict__ part, int P, int N, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+// (64 columns x 4 partial lanes per block: lane q adds partials q, q + 4, ... in order - four independent loads in flight per
+//  step instead of one chain of P dependent ones, which cost ~9 us for P = 64 - then the four lane sums in order)
+__global__ __launch_bounds__(256) void col_reduce_final_kernel(const float* __restrict__ part, int P, int N, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[(size_t)p * N + c];
-    out[c] = s;
+    if (c < N) {
+        int p = sub;
+        for (; p + 12 < P; p += 16) {
+            const float a0 = part[(size_t)p * N + c], a1 = part[(size_t)(p + 4) * N + c], a2 = part[(size_t)(p + 8) * N + c],
+                        a3 = part[(size_t)(p + 12) * N + c];
+            s = (((s + a0) + a1) + a2) + a3;
+        }
+        for (; p < P; p += 4) s += part[(size_t)p * N + c];
+    }
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && c < N) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ---- activations -----------------------------------------------------------------------------------------------------
@@ -324,43 +346,66 @@ struct AttnBwdArgs {
                                          // come from another sequence and projection; self-attention: Nk = N, ldk = ld, lddk = ldd)
 };
 
-// P[b,h,i,:] = softmax_j(scale q_i . k_j) for 16 query rows per workgroup
+// The three attention-backward kernels form their matrix products - S = Q K^T, dP = dO V^T, dQ = dS K, dV = P^T dO, dK = dS^T Q -
+// on the exact-f32 MFMA (16x16x4 f32; round 5: the first versions were VALU loops with one LDS broadcast read per FMA and cost a
+// f16x3 training step 12 of its ~100 ms).  A operand: lane (l16, g) holds row l16, contraction index g; B operand: contraction
+// index g, column l16; a float4 along the contraction dimension feeds four MFMA steps (the same permutation of the contraction
+// index on both operands).  Summation orders are fixed (by the instruction, tiles in ascending order, waves' partials in order).
+typedef float af_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ af_f32x4 mfma_f32_4(float4 a, float4 b, af_f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+}
+__host__ __device__ constexpr int attn_ns(int nk) { return (nk + 15) & ~15; }  // LDS row stride of a 16 x Nk score tile
+
+// P[b,h,i,:] = softmax_j(scale q_i . k_j) for 16 query rows per workgroup; a wave forms the 16 x 16 score tiles of key tiles
+// wave, wave + 4, ...
 __global__ __launch_bounds__(256) void attn_probs_kernel(AttnBwdArgs a) {
     extern __shared__ float sm[];
     const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, i0 = blockIdx.y * 16, NQ = a.N, N = a.Nk, tid = threadIdx.x;
+    const int NS = attn_ns(N);
     float* Qs = sm;                 // [16][64]
-    float* S = sm + 16 * HD;        // [16][Nk]
+    float* S = sm + 16 * HD;        // [16][NS]
     for (int e = tid; e < 16 * HD; e += 256) {
         const int r = e >> 6, d = e & 63, i = min(i0 + r, NQ - 1);
         Qs[e] = a.q[(size_t)(b * NQ + i) * a.ld + h * HD + d];
     }
     __syncthreads();
-    for (int j = tid; j < N; j += 256) {
-        float kr[HD];
-        const float* kp = a.k + (size_t)(b * N + j) * a.ldk + h * HD;
+    {
+        const int lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+        float4 qa[4];
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) { const float4 t = *(const float4*)(kp + d); kr[d] = t.x; kr[d + 1] = t.y; kr[d + 2] = t.z; kr[d + 3] = t.w; }
-        for (int r = 0; r < 16; ++r) {
-            float s = 0.f;
+        for (int c = 0; c < 4; ++c) qa[c] = *(const float4*)&Qs[l16 * HD + 16 * c + 4 * g];
+        for (int jt = wave; jt * 16 < N; jt += 4) {
+            const int jj = jt * 16 + l16, j = min(jj, N - 1);
+            const float* kp = a.k + (size_t)(b * N + j) * a.ldk + h * HD + 4 * g;
+            af_f32x4 acc = (af_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int d = 0; d < HD; ++d) s = fmaf(Qs[r * HD + d], kr[d], s);
-            float sv = a.key_mask ? fmaf(s, a.scale, a.key_mask[(size_t)b * N + j]) : s * a.scale;
-            if (a.mask_qk) sv += a.mask_qk[(size_t)min(i0 + r, NQ - 1) * a.ld_mqk + j];
-            S[r * N + j] = sv;
+            for (int c = 0; c < 4; ++c) acc = mfma_f32_4(qa[c], *(const float4*)(kp + 16 * c), acc);
+            const float km = a.key_mask ? a.key_mask[(size_t)b * N + j] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // acc[r] = <q row 4 g + r, k row jj>
+                const int row = 4 * g + r;
+                float sv = a.key_mask ? fmaf(acc[r], a.scale, km) : acc[r] * a.scale;
+                if (a.mask_qk) sv += a.mask_qk[(size_t)min(i0 + row, NQ - 1) * a.ld_mqk + j];
+                S[row * NS + jj] = sv;
+            }
         }
     }
     __syncthreads();
     const int r = tid >> 4, l = tid & 15;  // 16 lanes per row
     float m = -INFINITY;
-    for (int j = l; j < N; j += 16) m = fmaxf(m, S[r * N + j]);
+    for (int j = l; j < N; j += 16) m = fmaxf(m, S[r * NS + j]);
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     float sum = 0.f;
-    for (int j = l; j < N; j += 16) { const float e = expf(S[r * N + j] - m); S[r * N + j] = e; sum += e; }
+    for (int j = l; j < N; j += 16) { const float e = expf(S[r * NS + j] - m); S[r * NS + j] = e; sum += e; }
     sum = row16_sum(sum);
     if (i0 + r < NQ) {
         float* Pr = a.P + ((size_t)bh * NQ + i0 + r) * N;
-        for (int j = l; j < N; j += 16) Pr[j] = S[r * N + j] / sum;
+        for (int j = l; j < N; j += 16) Pr[j] = S[r * NS + j] / sum;
     }
 }
 
@@ -382,9 +427,12 @@ __global__ __launch_bounds__(256) void attn_headmax_kernel(AttnBwdArgs a) {
 __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdArgs a) {
     extern __shared__ float sm[];
     const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, i0 = blockIdx.y * 16, NQ = a.N, N = a.Nk, tid = threadIdx.x;
+    const int NS = attn_ns(N);
+    const int lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
     float* dOs = sm;                  // [16][64]
-    float* Ps = sm + 16 * HD;         // [16][N]
-    float* Ds = Ps + 16 * N;          // [16][N]: dP, then dS
+    float* Ps = sm + 16 * HD;         // [16][NS]
+    float* Ds = Ps + 16 * NS;         // [16][NS]: dP, then dS (zero beyond key N)
+    float* red = Ds + 16 * NS;        // [4][16][64]: the waves' partial dQ tiles
     for (int e = tid; e < 16 * HD; e += 256) {
         const int r = e >> 6, d = e & 63, i = i0 + r;
         float v = 0.f;
@@ -395,93 +443,136 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdArgs a) {
         dOs[e] = v;
     }
     __syncthreads();
-    for (int j = tid; j < N; j += 256) {
-        float vr[HD];
-        const float* vp = a.v + (size_t)(b * N + j) * a.ldk + h * HD;
+    {
+        float4 oa[4];
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) { const float4 t = *(const float4*)(vp + d); vr[d] = t.x; vr[d + 1] = t.y; vr[d + 2] = t.z; vr[d + 3] = t.w; }
-        for (int r = 0; r < 16; ++r) {
-            const int i = i0 + r;
-            float dp = 0.f, p = 0.f;
-            if (i < NQ) {
+        for (int c = 0; c < 4; ++c) oa[c] = *(const float4*)&dOs[l16 * HD + 16 * c + 4 * g];
+        for (int jt = wave; jt * 16 < N; jt += 4) {
+            const int jj = jt * 16 + l16, j = min(jj, N - 1);
+            const float* vp = a.v + (size_t)(b * N + j) * a.ldk + h * HD + 4 * g;
+            af_f32x4 acc = (af_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int d = 0; d < HD; ++d) dp = fmaf(dOs[r * HD + d], vr[d], dp);
-                p = a.P[((size_t)bh * NQ + i) * N + j];
-                if (j >= 1) {
-                    if (i == 0) { if (a.dp0) dp += a.dp0[((size_t)b * a.H + h) * N + j]; }
-                    else if (a.da && a.hm[((size_t)b * N + i) * N + j] == h) dp += a.da[(size_t)b * N + j];
+            for (int c = 0; c < 4; ++c) acc = mfma_f32_4(oa[c], *(const float4*)(vp + 16 * c), acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // acc[r] = <dO row 4 g + r, v row jj>
+                const int row = 4 * g + r, i = i0 + row;
+                float dp = 0.f, p = 0.f;
+                if (i < NQ && jj < N) {
+                    dp = acc[r];
+                    p = a.P[((size_t)bh * NQ + i) * N + jj];
+                    if (jj >= 1) {
+                        if (i == 0) { if (a.dp0) dp += a.dp0[((size_t)b * a.H + h) * N + jj]; }
+                        else if (a.da && a.hm[((size_t)b * N + i) * N + jj] == h) dp += a.da[(size_t)b * N + jj];
+                    }
+                    if (a.dp_out) a.dp_out[((size_t)bh * NQ + i) * N + jj] = dp;
                 }
+                Ps[row * NS + jj] = p;
+                Ds[row * NS + jj] = dp;
             }
-            Ps[r * N + j] = p;
-            Ds[r * N + j] = dp;
-            if (a.dp_out && i < NQ) a.dp_out[((size_t)bh * NQ + i) * N + j] = dp;
         }
     }
     __syncthreads();
     {
         const int r = tid >> 4, l = tid & 15;
         float dsum = 0.f;
-        for (int j = l; j < N; j += 16) dsum += Ps[r * N + j] * Ds[r * N + j];
+        for (int j = l; j < N; j += 16) dsum += Ps[r * NS + j] * Ds[r * NS + j];
         dsum = row16_sum(dsum);
         for (int j = l; j < N; j += 16) {
-            const float ds = Ps[r * N + j] * (Ds[r * N + j] - dsum);
-            Ds[r * N + j] = ds;
+            const float ds = Ps[r * NS + j] * (Ds[r * NS + j] - dsum);
+            Ds[r * NS + j] = ds;
             if (i0 + r < NQ) a.dS[((size_t)bh * NQ + i0 + r) * N + j] = ds;
         }
     }
     __syncthreads();
     {
-        const int r = tid >> 4, dq = (tid & 15) * 4;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int j = 0; j < N; ++j) {
-            const float ds = Ds[r * N + j];
-            const float4 kv = *(const float4*)(a.k + (size_t)(b * N + j) * a.ldk + h * HD + dq);
-            acc.x = fmaf(ds, kv.x, acc.x); acc.y = fmaf(ds, kv.y, acc.y); acc.z = fmaf(ds, kv.z, acc.z); acc.w = fmaf(ds, kv.w, acc.w);
+        // dQ tile [16 rows][64] = sum over key tiles of dS[16][16 keys] K[16 keys][64]; a wave takes key tiles wave, wave + 4, ...
+        af_f32x4 accq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) accq[dt] = (af_f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int jt = wave; jt * 16 < N; jt += 4) {
+            const float4 da = *(const float4*)&Ds[l16 * NS + jt * 16 + 4 * g];  // dS[row l16][keys jt 16 + 4 g ..+3]
+            const float dav[4] = {da.x, da.y, da.z, da.w};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float* kp = a.k + (size_t)(b * N + min(jt * 16 + 4 * g + s4, N - 1)) * a.ldk + h * HD + l16;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) accq[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dav[s4], kp[16 * dt], accq[dt], 0, 0, 0);
+            }
         }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * g + r) * HD + 16 * dt + l16] = accq[dt][r];
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 4, dq = (tid & 15) * 4;
+        const float4 p0 = *(const float4*)&red[(0 * 16 + r) * HD + dq], p1 = *(const float4*)&red[(1 * 16 + r) * HD + dq],
+                     p2 = *(const float4*)&red[(2 * 16 + r) * HD + dq], p3 = *(const float4*)&red[(3 * 16 + r) * HD + dq];
         if (i0 + r < NQ)
             *(float4*)(a.dq + (size_t)(b * NQ + i0 + r) * a.ldd + h * HD + dq) =
-                make_float4(acc.x * a.scale, acc.y * a.scale, acc.z * a.scale, acc.w * a.scale);
+                make_float4(((p0.x + p1.x) + (p2.x + p3.x)) * a.scale, ((p0.y + p1.y) + (p2.y + p3.y)) * a.scale,
+                            ((p0.z + p1.z) + (p2.z + p3.z)) * a.scale, ((p0.w + p1.w) + (p2.w + p3.w)) * a.scale);
     }
 }
 
-// columns pass: dV_j = sum_i P_ij dO_i, dK_j = scale sum_i dS_ij Q_i for 16 keys per workgroup
+// columns pass: dV_j = sum_i P_ij dO_i, dK_j = scale sum_i dS_ij Q_i for 16 keys per workgroup; a wave takes query tiles wave,
+// wave + 4, ... (operands straight from global memory), the four partial tiles are added in order
 __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnBwdArgs a) {
-    __shared__ float Pt[16][17], St[16][17], Qt[16][HD], Ot[16][HD];
+    __shared__ float red[4][2][16][HD];
     const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, j0 = blockIdx.y * 16, NQ = a.N, N = a.Nk, tid = threadIdx.x;
-    const int c = tid >> 4, dq = (tid & 15) * 4;
-    float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), dk = dv;
-    for (int i0 = 0; i0 < NQ; i0 += 16) {
-        __syncthreads();
-        {
-            const int r = tid >> 4, cc = tid & 15, i = i0 + r, j = j0 + cc;
-            const bool ok = i < NQ && j < N;
-            Pt[r][cc] = ok ? a.P[((size_t)bh * NQ + i) * N + j] : 0.f;
-            St[r][cc] = ok ? a.dS[((size_t)bh * NQ + i) * N + j] : 0.f;
-        }
-        for (int e = tid; e < 16 * HD; e += 256) {
-            const int r = e >> 6, d = e & 63, i = i0 + r;
-            float qv = 0.f, ov = 0.f;
-            if (i < NQ) {
-                qv = a.q[(size_t)(b * NQ + i) * a.ld + h * HD + d];
-                ov = a.dout[(size_t)(b * NQ + i) * a.ldo + h * HD + d];
-                if (a.dnrm_scale) ov += a.dnrm_scale[((size_t)b * a.H + h) * NQ + i] * a.out[(size_t)(b * NQ + i) * a.ldout + h * HD + d];
-            }
-            Qt[r][d] = qv;
-            Ot[r][d] = ov;
-        }
-        __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    af_f32x4 accv[4], acck[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = Pt[r][c], ds = St[r][c];
-            const float4 o = *(const float4*)&Ot[r][dq], qv = *(const float4*)&Qt[r][dq];
-            dv.x = fmaf(p, o.x, dv.x); dv.y = fmaf(p, o.y, dv.y); dv.z = fmaf(p, o.z, dv.z); dv.w = fmaf(p, o.w, dv.w);
-            dk.x = fmaf(ds, qv.x, dk.x); dk.y = fmaf(ds, qv.y, dk.y); dk.z = fmaf(ds, qv.z, dk.z); dk.w = fmaf(ds, qv.w, dk.w);
+    for (int dt = 0; dt < 4; ++dt) { accv[dt] = (af_f32x4){0.f, 0.f, 0.f, 0.f}; acck[dt] = accv[dt]; }
+    const int jc = min(j0 + l16, N - 1);
+    for (int it = wave; it * 16 < NQ; it += 4) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int ii = it * 16 + 4 * g + s4, i = min(ii, NQ - 1);
+            const bool ok = ii < NQ;
+            // A operands: P^T / dS^T - row (key) l16, contraction index (query) ii
+            const float pv = ok ? a.P[((size_t)bh * NQ + i) * N + jc] : 0.f;
+            const float sv = ok ? a.dS[((size_t)bh * NQ + i) * N + jc] : 0.f;
+            const float* op = a.dout + (size_t)(b * NQ + i) * a.ldo + h * HD + l16;
+            const float* qp = a.q + (size_t)(b * NQ + i) * a.ld + h * HD + l16;
+            float ov[4], qv[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { ov[dt] = op[16 * dt]; qv[dt] = qp[16 * dt]; }
+            if (a.dnrm_scale) {
+                const float sc = a.dnrm_scale[((size_t)b * a.H + h) * NQ + i];
+                const float* o2 = a.out + (size_t)(b * NQ + i) * a.ldout + h * HD + l16;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) ov[dt] += sc * o2[16 * dt];
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                accv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, ov[dt], accv[dt], 0, 0, 0);
+                acck[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv, qv[dt], acck[dt], 0, 0, 0);
+            }
         }
     }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[wave][0][4 * g + r][16 * dt + l16] = accv[dt][r];
+            red[wave][1][4 * g + r][16 * dt + l16] = acck[dt][r];
+        }
+    __syncthreads();
+    const int c = tid >> 4, dq = (tid & 15) * 4;
     if (j0 + c < N) {
-        *(float4*)(a.dv + (size_t)(b * N + j0 + c) * a.lddk + h * HD + dq) = dv;
+        float4 o[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const float4 p0 = *(const float4*)&red[0][w][c][dq], p1 = *(const float4*)&red[1][w][c][dq], p2 = *(const float4*)&red[2][w][c][dq],
+                         p3 = *(const float4*)&red[3][w][c][dq];
+            o[w] = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                               (p0.w + p1.w) + (p2.w + p3.w));
+        }
+        *(float4*)(a.dv + (size_t)(b * N + j0 + c) * a.lddk + h * HD + dq) = o[0];
         *(float4*)(a.dk + (size_t)(b * N + j0 + c) * a.lddk + h * HD + dq) =
-            make_float4(dk.x * a.scale, dk.y * a.scale, dk.z * a.scale, dk.w * a.scale);
+            make_float4(o[1].x * a.scale, o[1].y * a.scale, o[1].z * a.scale, o[1].w * a.scale);
     }
 }
 
@@ -496,7 +587,6 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnBwdArgs a) {
 // Operands come straight from global memory as float4 (contraction index d0 + 4 (lane >> 4) + s in MFMA step s - the same
 // permutation of d on both operands); summation order: fixed by the instruction, chunks of 16 d in ascending order.
 constexpr int AF_MAXN = 1024, AF_KT = 8;
-typedef float af_f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void att_ft_bwd_dw_kernel(const float* __restrict__ q, const float* __restrict__ dA,
                                                             float* __restrict__ dW, int n, int K, int D) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
@@ -633,14 +723,21 @@ extern "C" int madtp_transpose_pad(const float* src, int ld_src, int R, int C, f
     return 0;
 }
 
-extern "C" int madtp_transpose_split(const float* src, int ld_src, int R, int C, void* dst, int Rp, int Cp, int weight_format, void* stream) {
+extern "C" int madtp_transpose_split(const float* src, int ld_src, int R, int C, void* dst, int Rp, int Cp, int weight_format,
+                                     float* colsum_out, float* colsum_ws, void* stream) {
     if (!src || !dst || R <= 0 || C <= 0 || Rp < R || Cp < C || ld_src < C) return MADTP_E_BADARG;
     if (Rp % 4) return MADTP_E_SHAPE;
     if ((uintptr_t)dst & 7) return MADTP_E_ALIGN;
+    if (colsum_out && !colsum_ws) return MADTP_E_BADARG;
     const dim3 grid((Rp + 63) / 64, (Cp + 63) / 64);
-    if (weight_format) hipLaunchKernelGGL(transpose_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, R, C, (_Float16*)dst, Rp, Cp);
-    else hipLaunchKernelGGL(transpose_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, R, C, (_Float16*)dst, Rp, Cp);
+    float* part = colsum_out ? colsum_ws : nullptr;
+    if (weight_format) hipLaunchKernelGGL(transpose_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, R, C, (_Float16*)dst, Rp, Cp, part);
+    else hipLaunchKernelGGL(transpose_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, R, C, (_Float16*)dst, Rp, Cp, part);
     MADTP_LAUNCH_CHECK();
+    if (colsum_out) {  // column sums of src (sum over its R rows) from the per-row-tile partials, in order
+        hipLaunchKernelGGL(col_reduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, (Rp + 63) / 64, C, colsum_out);
+        MADTP_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -650,7 +747,7 @@ static int col_reduce(const float* dy, int ld, const float* x, int ldx, const fl
     const int rows_per = (M + P - 1) / P;
     if (x) hipLaunchKernelGGL(col_reduce_kernel<true>, dim3((N + 63) / 64, P), dim3(256), 0, s, dy, ld, x, ldx, stats, M, N, rows_per, part);
     else hipLaunchKernelGGL(col_reduce_kernel<false>, dim3((N + 63) / 64, P), dim3(256), 0, s, dy, ld, x, ldx, stats, M, N, rows_per, part);
-    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, P, N, out);
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((N + 63) / 64), dim3(256), 0, s, part, P, N, out);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
@@ -714,7 +811,7 @@ extern "C" int madtp_attention_probs(const float* q, const float* k, int ld, con
     AttnBwdArgs a = {};
     a.q = q; a.k = k; a.ld = ld; a.P = P; a.B = B; a.H = H; a.N = N; a.scale = scale; a.key_mask = key_mask;
     a.Nk = N; a.ldk = ld; a.mask_qk = nullptr; a.ld_mqk = 0;
-    const size_t lds_p = (size_t)(16 * HD + 16 * N) * sizeof(float);
+    const size_t lds_p = (size_t)(16 * HD + 16 * attn_ns(N)) * sizeof(float);
     MADTP_ENSURE_MAX_LDS(attn_probs_kernel, lds_p);
     hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, (N + 15) / 16), dim3(256), lds_p, (hipStream_t)stream, a);
     MADTP_LAUNCH_CHECK();
@@ -744,7 +841,7 @@ extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* 
     a.P = (float*)ws; a.dS = a.P + pn; a.hm = (unsigned char*)(a.dS + pn);
     hipStream_t s = (hipStream_t)stream;
     const int nrt = (N + 15) / 16;
-    const size_t lds_p = (size_t)(16 * HD + 16 * N) * sizeof(float), lds_r = (size_t)(16 * HD + 32 * N) * sizeof(float);
+    const size_t lds_p = (size_t)(16 * HD + 16 * attn_ns(N)) * sizeof(float), lds_r = (size_t)(16 * HD + 32 * attn_ns(N) + 64 * HD) * sizeof(float);
     MADTP_ENSURE_MAX_LDS(attn_probs_kernel, lds_p);
     MADTP_ENSURE_MAX_LDS(attn_bwd_rows_kernel, lds_r);
     hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, nrt), dim3(256), lds_p, s, a);
@@ -777,7 +874,7 @@ extern "C" int madtp_attention_bwd_cross(const float* q, int ldq, const float* k
     const size_t pn = (size_t)B * H * Nq * Nk;
     a.P = (float*)ws; a.dS = a.P + pn;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds_p = (size_t)(16 * HD + 16 * Nk) * sizeof(float), lds_r = (size_t)(16 * HD + 32 * Nk) * sizeof(float);
+    const size_t lds_p = (size_t)(16 * HD + 16 * attn_ns(Nk)) * sizeof(float), lds_r = (size_t)(16 * HD + 32 * attn_ns(Nk) + 64 * HD) * sizeof(float);
     MADTP_ENSURE_MAX_LDS(attn_probs_kernel, lds_p);
     MADTP_ENSURE_MAX_LDS(attn_bwd_rows_kernel, lds_r);
     hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, (Nq + 15) / 16), dim3(256), lds_p, s, a);

@@ -105,7 +105,7 @@ _SIGS = {
     "madtp_transpose_pad": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "madtp_gemm_splitk_pp": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "madtp_splitk_sum": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
-    "madtp_transpose_split": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "madtp_transpose_split": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "madtp_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "madtp_act_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "madtp_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_void_p]),

@@ -83,9 +83,13 @@ def test_transpose_split_equals_transpose_then_split(hip):
         assert act.shape == (Cp, 2 * Rp) and torch.equal(act, hip.split_f16(t))
         ref_w = hip.split_f16_weight(t, log2_scale=0)
         assert torch.equal(wt, ref_w) and wt._madtp_log2_scale == 0 and hip.w_scale_of(wt) == 1.0
+        act2, cs = bw.transpose_split(x, Rp, Cp, False, colsum=True)  # the bias gradient's column sums from the same pass
+        assert torch.equal(act2, act) and _rel(cs.cpu(), x.double().sum(0).float().cpu()) < 1e-5
+        assert torch.equal(cs, bw.transpose_split(x, Rp, Cp, False, colsum=True)[1])
 
 
-@pytest.mark.parametrize("M,N,K", [(6304, 2304, 768), (25216, 768, 768), (4096, 768, 3072), (2500, 3072, 768), (2100, 264, 776)])
+@pytest.mark.parametrize("M,N,K", [(6304, 2304, 768), (25216, 768, 768), (4096, 768, 3072), (2500, 3072, 768), (2100, 264, 776),
+                                   (25088, 100, 768)])
 def test_wgrad_splitk(hip, M, N, K):
     """the f16x3 weight gradient on split-K partials of the 256x256 ping-pong kernel (madtp_gemm_splitk_pp + madtp_splitk_sum) vs
     float64, next to the plain dispatch it replaces; gradients of 1e-4 keep their digits (activation-format dY^T: ~2^-36 absolute)."""
@@ -103,6 +107,8 @@ def test_wgrad_splitk(hip, M, N, K):
         finally:
             del os.environ["MADTP_WGRAD_SPLITK"]
         assert torch.equal(got, bw.wgrad(dy, x))  # fixed summation order
+        got2, db = bw.wgrad(dy, x, bias=True)
+        assert torch.equal(got2, got) and _rel(db.cpu(), dy.double().sum(0).float().cpu()) < 1e-5
     col = ref.abs().amax(1, keepdim=True)  # per output row (a dY column): small-gradient rows are held to their own scale
     assert float(((got.double() - ref).abs() / col).max()) < 2e-6, float(((got.double() - ref).abs() / col).max())
     assert float(((plain.double() - ref).abs() / col).max()) < 1e-5  # (one f32 accumulation chain over all of K)
