@@ -356,10 +356,76 @@ class _BlockParts:
                 self.norm2.bias, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias]
 
 
-def vit_block_backward(blk, x, token_attn, temperature, k, dy, mask_qk=None, dp_out=None):
+def _save_forward():
+    """MADTP_TRAIN_SAVE (default 1): the training forward of a block is composed from the single kernels and KEEPS its intermediates
+    for the backward (round 5) - instead of running the fused layer call and recomputing the layer in the backward (0: the
+    round-4 scheme, a third less activation memory, one more forward's worth of kernels per step)."""
+    return os.environ.get("MADTP_TRAIN_SAVE", "1") != "0"
+
+
+class _Saved:
+    """intermediates of a block's forward, by name"""
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _vit_block_fwd(blk, x, token_attn, temperature, k, mask_qk=None, max_keep=0):
+    """Block.forward from single kernels (the forward's own: same operand formats and dispatch in the f16x3 mode), keeping every
+    intermediate the backward reads.  k: the forward's pruning decision (recompute), or None: decide it here - k = max_b count read
+    on the host, vit.py:145, kept unless k <= max_keep or fewer than two tokens would go (madtp_vit_block_keep's rule)."""
+    P = _BlockParts(blk)
+    B, N, D = x.shape
+    H, scale = P.H, P.scale
+    M = B * N
+    eps1, eps2 = P.norm1.eps, P.norm2.eps
+    x2 = x.reshape(M, D)
+    h1, _ = hip.layernorm(x2, P.norm1.weight.detach(), P.norm1.bias.detach(), eps1)
+    wq, bq = _f32_wb(P.qkv_w, P.qkv_b)
+    wp, bp = _f32_lin(P.proj)
+    w1, b1 = _f32_lin(P.fc1)
+    qkv = _gemm(h1, wq, bq, n=3 * D, out_dtype=torch.float32)
+    prune = temperature > 0 if k is None else k > 0
+    out, side = _attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, scale, scores=prune, mask_qk=mask_qk)
+    x_attn = _gemm(out, wp, bp, residual=x2, n=D, out_dtype=torch.float32)
+    score = dst_pos = merge_w = info = None
+    if prune and k is None:
+        score, thr, count, kk = hip.token_score_sync(side, token_attn, temperature, B, H, N)
+        info = {"k": kk, "score": score, "threshold": thr, "count": count, "pruned": False, "indices": None, "indices_sort": None}
+        k = 0 if (kk <= max_keep or (N - 1 - kk) <= 1) else kk
+    elif prune:
+        score, _, _, _ = hip.token_score(side, token_attn, temperature, B, H, N)
+    k = k or 0
+    if k > 0:
+        indices, indices_sort, dst_pos, merge_w = hip.token_select(score, k)
+        if info is not None:
+            info.update(pruned=True, indices=indices, indices_sort=indices_sort)
+        y0 = hip.token_gather(x_attn.view(B, N, D), dst_pos, merge_w, k)
+    else:
+        y0 = x_attn.view(B, N, D)
+    N2 = y0.shape[1]
+    y02 = y0.reshape(B * N2, D)
+    h2, _ = hip.layernorm(y02, P.norm2.weight.detach(), P.norm2.bias.detach(), eps2)
+    u = _gemm(h2, w1, b1, n=P.fc1.weight.shape[0], out_dtype=torch.float32)
+    g = act_fwd(u, P.act)
+    return _Saved(k=k, info=info, h1=h1, qkv=qkv, out=out, side=side, x_attn=x_attn, score=score, dst_pos=dst_pos, merge_w=merge_w,
+                  y02=y02, h2=h2, u=u, g=g)
+
+
+def vit_block_forward_saved(blk, x, token_attn, temperature, max_keep=0, mask_qk=None):
+    """-> (y [B,N',D], info, saved): Block.forward for training, see _save_forward()."""
+    P = _BlockParts(blk)
+    B, _, D = x.shape
+    s = _vit_block_fwd(blk, x, token_attn, temperature, None, mask_qk=mask_qk, max_keep=max_keep)
+    w2, b2 = _f32_lin(P.fc2)
+    y = _gemm(s.g, w2, b2, residual=s.y02, n=D, out_dtype=torch.float32)
+    return y.view(B, -1, D), s.info, s
+
+
+def vit_block_backward(blk, x, token_attn, temperature, k, dy, mask_qk=None, dp_out=None, saved=None):
     """Gradients of Block.forward (vit.py:183-207; clip/model.py:236-261 for CLIP's block) at (x [B,N,D], token_attn [B,N-1,K])
     for the output gradient dy [B,N',D], with the forward's pruning decision k (0 = the layer was not pruned); mask_qk: the
-    additive [N,N] attention mask of CLIP's text tower or None.  Returns (dx, dtoken_attn or None, {parameter name: grad})."""
+    additive [N,N] attention mask of CLIP's text tower or None.  saved: the forward's intermediates (vit_block_forward_saved), else
+    the forward is recomputed from (x, token_attn, k).  Returns (dx, dtoken_attn or None, {parameter name: grad})."""
     P = _BlockParts(blk)
     nm = P.names
     B, N, D = x.shape
@@ -367,28 +433,11 @@ def vit_block_backward(blk, x, token_attn, temperature, k, dy, mask_qk=None, dp_
     M = B * N
     eps1, eps2 = P.norm1.eps, P.norm2.eps
     x2 = x.reshape(M, D)
-    # ---- recompute the forward (fp32 kernels, the forward's own) ----
-    h1, _ = hip.layernorm(x2, P.norm1.weight.detach(), P.norm1.bias.detach(), eps1)
-    wq, bq = _f32_wb(P.qkv_w, P.qkv_b)
-    wp, bp = _f32_lin(P.proj)
-    w1, b1 = _f32_lin(P.fc1)
-    w2, b2 = _f32_lin(P.fc2)
-    qkv = _gemm(h1, wq, bq, n=3 * D, out_dtype=torch.float32)
-    out, side = _attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, scale, scores=k > 0, mask_qk=mask_qk)
-    x_attn = _gemm(out, wp, bp, residual=x2, n=D, out_dtype=torch.float32)
-    if k > 0:
-        score, _, _, _ = hip.token_score(side, token_attn, temperature, B, H, N)
-        _, _, dst_pos, merge_w = hip.token_select(score, k)
-        y0 = hip.token_gather(x_attn.view(B, N, D), dst_pos, merge_w, k)
-    else:
-        y0 = x_attn.view(B, N, D)
-    N2 = y0.shape[1]
-    M2 = B * N2
-    y02 = y0.reshape(M2, D)
-    h2, _ = hip.layernorm(y02, P.norm2.weight.detach(), P.norm2.bias.detach(), eps2)
-    F = P.fc1.weight.shape[0]
-    u = _gemm(h2, w1, b1, n=F, out_dtype=torch.float32)
-    g = act_fwd(u, P.act)
+    s = saved if saved is not None else _vit_block_fwd(blk, x, token_attn, temperature, k, mask_qk=mask_qk)
+    h1, qkv, out, side, x_attn, score, dst_pos, merge_w = s.h1, s.qkv, s.out, s.side, s.x_attn, s.score, s.dst_pos, s.merge_w
+    y02, h2, u, g = s.y02, s.h2, s.u, s.g
+    M2 = y02.shape[0]
+    N2 = M2 // B
     # ---- backward ----
     grads = {}
     dy2 = dy.reshape(M2, D).contiguous().float()
@@ -427,7 +476,14 @@ class VitBlockFunction(torch.autograd.Function):
     def forward(ctx, blk, temperature, max_keep, x, token_attn, *params):
         ctx.mode = _mode()
         prune = temperature > 0
-        y, info = hip.vit_block(blk._weights(), x, token_attn, temperature if prune else 0, max_keep=max_keep)
+        ctx.saved = None
+        if _save_forward():
+            if getattr(blk, "attn_mask", None) is not None and getattr(blk, "_mask_dev", None) is None:
+                blk._weights()  # (creates the device copy of CLIP's text attention mask)
+            mask = getattr(blk, "_mask_dev", None) if getattr(blk, "attn_mask", None) is not None else None
+            y, info, ctx.saved = vit_block_forward_saved(blk, x, token_attn, temperature if prune else 0, max_keep=max_keep, mask_qk=mask)
+        else:
+            y, info = hip.vit_block(blk._weights(), x, token_attn, temperature if prune else 0, max_keep=max_keep)
         blk.last_prune = info
         ctx.blk, ctx.temperature = blk, float(temperature)
         ctx.k = int(info["indices"].shape[1]) if (info is not None and info.get("pruned")) else 0
@@ -448,7 +504,8 @@ class VitBlockFunction(torch.autograd.Function):
             B_, N_ = x.shape[0], x.shape[1]
             dp_out = torch.empty((B_, att.num_heads, N_, N_), device=x.device, dtype=torch.float32)
         with torch.no_grad(), _in_mode(ctx.mode):
-            dx, dta, grads = vit_block_backward(ctx.blk, x, ta, ctx.temperature, ctx.k, dy, mask_qk=mask, dp_out=dp_out)
+            dx, dta, grads = vit_block_backward(ctx.blk, x, ta, ctx.temperature, ctx.k, dy, mask_qk=mask, dp_out=dp_out, saved=ctx.saved)
+            ctx.saved = None
         if dp_out is not None:
             att.save_attn_gradients(dp_out)
         pg = [grads.get(name) for name in _BlockParts(ctx.blk).order()]
