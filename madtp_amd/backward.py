@@ -587,39 +587,49 @@ def _cross_branch_bwd(prefix, sm, grads, dcctx, cq, ckv, wckv, y02, enc2, B, H, 
     return dy0, denc
 
 
-def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, enc=None, enc_masks=None, causal=None):
-    """Gradients of a BertLayer - MED (med.py:393-462) or NLVR (nlvr_encoder.py:484-554) - at (hidden [B,L,D], token_attn
-    [B,L-1,K]) for the output gradient dy [B,L',D]; mask2d: additive key mask [B,L] or None; k: the forward's pruning decision
-    (0 = not pruned).  enc: None (mode 'text'), the encoder tokens [B,Nk,Denc] (MED, mode 'multimodal': one cross-attention between
-    the pruning step and the FFN, encoder mask ignored, med.py:197-199) or a list of two (NLVR: twin branches self0 / self1 whose
-    outputs are averaged, or merged by merge_layer from layer 6 on, nlvr_encoder.py:259-266; enc_masks: their additive key masks
-    [B,Nk] or None, applied as nlvr_encoder.py:196-198 does).  Returns (dhidden, dtoken_attn or None, denc (None / tensor / list),
-    {parameter name: grad})."""
+def _med_layer_fwd(layer, hidden, mask2d, token_attn, temperature, k, enc=None, enc_masks=None, causal=None):
+    """BertLayer.forward (MED / NLVR) from single kernels, keeping every intermediate the backward reads.  k: the forward's pruning
+    decision (recompute), or None: decide it here (k = max_b count on the host, med.py:374-375; kept unless k < 1 or fewer than two
+    tokens would go - madtp_bert_layer's rule)."""
     B, L, D = hidden.shape
     sa, so = layer.attention.self, layer.attention.output
     H, scale = sa.num_attention_heads, 1.0 / math.sqrt(sa.attention_head_size)
     M = B * L
     h2 = hidden.reshape(M, D)
     twin = isinstance(enc, (list, tuple))
-    # ---- recompute the forward ----
     wqkv, bqkv = _cat_wb("qkv", [sa.query, sa.key, sa.value])  # [3D, D]
     wo, bo = _f32_lin(so.dense)
     wi, bi = _f32_lin(layer.intermediate.dense)
     wout, bout = _f32_lin(layer.output.dense)
     qkv = _gemm(h2, wqkv, bqkv, n=3 * D, out_dtype=torch.float32)
-    ctx, side = _attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, L, L, scale, add_mask=mask2d, scores=k > 0,
-                              mask_qk=causal)   # causal [L,L]: the decoder's mask (med.py:752-786), never together with pruning
+    prune = temperature > 0 if k is None else k > 0
+    ctx, side = _attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, L, L, scale, add_mask=mask2d, scores=prune,
+                           mask_qk=causal)   # causal [L,L]: the decoder's mask (med.py:752-786), never together with pruning
     a0 = _gemm(ctx, wo, bo, residual=h2, n=D, out_dtype=torch.float32)
     ao, _ = hip.layernorm(a0, so.LayerNorm.weight.detach(), so.LayerNorm.bias.detach(), so.LayerNorm.eps)
-    if k > 0:
+    score = dst_pos = merge_w = info = mask_out = None
+    if prune and k is None:
+        score, thr, count, kk = hip.token_score_sync(side, token_attn, temperature, B, H, L)
+        info = {"k": kk, "score": score, "threshold": thr, "count": count, "pruned": False, "indices": None, "indices_sort": None}
+        k = 0 if (kk < 1 or (L - 1 - kk) <= 1) else kk
+    elif prune:
         score, _, _, _ = hip.token_score(side, token_attn, temperature, B, H, L)
-        _, _, dst_pos, merge_w = hip.token_select(score, k)
+    k = k or 0
+    if k > 0:
+        indices, indices_sort, dst_pos, merge_w = hip.token_select(score, k)
+        if info is not None:
+            info.update(pruned=True, indices=indices, indices_sort=indices_sort)
+            if mask2d is not None:  # the pruned sequence's additive mask (nlvr_encoder.py:451-452 / med.py:386-389)
+                mask_out = (hip.mask_gather(mask2d, indices_sort, k) if getattr(layer, "variant", "") == "nlvr"
+                            else hip.mask_gather(mask2d, indices, k, indices_sort))
         y0 = hip.token_gather(ao.view(B, L, D), dst_pos, merge_w, k)
     else:
         y0 = ao.view(B, L, D)
     L2 = y0.shape[1]
     M2 = B * L2
     y02 = y0.reshape(M2, D)
+    br = enc2s = sms = ems = c0 = d01 = None
+    Nk = De = 0
     if enc is not None:
         ca, co = layer.crossattention, layer.crossattention.output
         encs = list(enc) if twin else [enc]
@@ -649,6 +659,39 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
     u = _gemm(x2, wi, bi, n=F, out_dtype=torch.float32)
     gl = act_fwd(u, hip.ACT_GELU)
     f0 = _gemm(gl, wout, bout, residual=x2, n=D, out_dtype=torch.float32)
+    return _Saved(k=k, info=info, mask_out=mask_out, wqkv=wqkv, qkv=qkv, ctx=ctx, side=side, a0=a0, ao=ao, score=score, dst_pos=dst_pos,
+                  merge_w=merge_w, y02=y02, br=br, enc2s=enc2s, sms=sms, ems=ems, Nk=Nk, De=De, c0=c0, d01=d01, x2=x2, u=u, gl=gl, f0=f0)
+
+
+def med_layer_forward_saved(layer, hidden, mask2d, token_attn, temperature, enc=None, enc_masks=None, causal=None):
+    """-> (y [B,L',D], mask_out or None, info, saved): BertLayer.forward for training, see _save_forward()."""
+    s = _med_layer_fwd(layer, hidden, mask2d, token_attn, temperature, None, enc, enc_masks, causal)
+    ln2 = layer.output.LayerNorm
+    y, _ = hip.layernorm(s.f0, ln2.weight.detach(), ln2.bias.detach(), ln2.eps)
+    return y.view(hidden.shape[0], -1, hidden.shape[2]), s.mask_out, s.info, s
+
+
+def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, enc=None, enc_masks=None, causal=None, saved=None):
+    """Gradients of a BertLayer - MED (med.py:393-462) or NLVR (nlvr_encoder.py:484-554) - at (hidden [B,L,D], token_attn
+    [B,L-1,K]) for the output gradient dy [B,L',D]; mask2d: additive key mask [B,L] or None; k: the forward's pruning decision
+    (0 = not pruned).  enc: None (mode 'text'), the encoder tokens [B,Nk,Denc] (MED, mode 'multimodal': one cross-attention between
+    the pruning step and the FFN, encoder mask ignored, med.py:197-199) or a list of two (NLVR: twin branches self0 / self1 whose
+    outputs are averaged, or merged by merge_layer from layer 6 on, nlvr_encoder.py:259-266; enc_masks: their additive key masks
+    [B,Nk] or None, applied as nlvr_encoder.py:196-198 does).  saved: the forward's intermediates (med_layer_forward_saved), else the
+    forward is recomputed.  Returns (dhidden, dtoken_attn or None, denc (None / tensor / list), {parameter name: grad})."""
+    B, L, D = hidden.shape
+    sa, so = layer.attention.self, layer.attention.output
+    H, scale = sa.num_attention_heads, 1.0 / math.sqrt(sa.attention_head_size)
+    M = B * L
+    h2 = hidden.reshape(M, D)
+    twin = isinstance(enc, (list, tuple))
+    s = saved if saved is not None else _med_layer_fwd(layer, hidden, mask2d, token_attn, temperature, k, enc, enc_masks, causal)
+    wqkv, qkv, ctx, side, a0, ao, score, dst_pos, merge_w = s.wqkv, s.qkv, s.ctx, s.side, s.a0, s.ao, s.score, s.dst_pos, s.merge_w
+    y02, br, enc2s, sms, ems, Nk, De, c0, d01, x2, u, gl, f0 = s.y02, s.br, s.enc2s, s.sms, s.ems, s.Nk, s.De, s.c0, s.d01, s.x2, s.u, s.gl, s.f0
+    M2 = y02.shape[0]
+    L2 = M2 // B
+    if enc is not None:
+        co = layer.crossattention.output
     # ---- backward ----
     grads = {}
     ln2 = layer.output.LayerNorm
@@ -726,14 +769,20 @@ class MedLayerFunction(torch.autograd.Function):
         # encoder tokens as the layer's GEMM operand: f32 in the fp32 mode, f16-split planes in the f16x3 mode
         flat = lambda e: to_compute(e.reshape(-1, e.shape[-1]).contiguous().float())
         em = enc_masks if enc_masks is not None else (None, None)
-        w = layer._weights()
-        if causal is not None:  # a copy of the cached struct with this call's causal mask (as BertLayer._forward does)
-            w = hip.BertLayerW.from_buffer_copy(w)
-            w.self_mask_qk, w.ld_self_mask_qk = causal.data_ptr(), causal.stride(0)
         ctx.causal = causal
-        y, mask_out, info, _ = hip.bert_layer(w, hidden, mask2d, token_attn, temperature if prune else 0, cross,
-                                              flat(enc0) if cross else None, flat(enc1) if twin else None,
-                                              enc0.shape[1] if cross else 0, em[0] if twin else None, em[1] if twin else None)
+        ctx.saved = None
+        if _save_forward():
+            enc = ([enc0, enc1] if twin else enc0) if cross else None
+            y, mask_out, info, ctx.saved = med_layer_forward_saved(layer, hidden, mask2d, token_attn, temperature if prune else 0, enc,
+                                                                   em if twin else None, causal)
+        else:
+            w = layer._weights()
+            if causal is not None:  # a copy of the cached struct with this call's causal mask (as BertLayer._forward does)
+                w = hip.BertLayerW.from_buffer_copy(w)
+                w.self_mask_qk, w.ld_self_mask_qk = causal.data_ptr(), causal.stride(0)
+            y, mask_out, info, _ = hip.bert_layer(w, hidden, mask2d, token_attn, temperature if prune else 0, cross,
+                                                  flat(enc0) if cross else None, flat(enc1) if twin else None,
+                                                  enc0.shape[1] if cross else 0, em[0] if twin else None, em[1] if twin else None)
         layer.last_prune = info
         ctx.layer, ctx.temperature, ctx.cross, ctx.twin = layer, float(temperature), cross, twin
         ctx.k = int(info["indices"].shape[1]) if (info is not None and info.get("pruned")) else 0
@@ -755,7 +804,8 @@ class MedLayerFunction(torch.autograd.Function):
         enc = ([enc0, enc1] if ctx.twin else enc0) if ctx.cross else None
         with torch.no_grad(), _in_mode(ctx.mode):
             dh, dta, denc, grads = med_layer_backward(ctx.layer, hidden, mask2d if ctx.has_mask else None, ta, ctx.temperature,
-                                                      ctx.k, dy, enc, ctx.enc_masks, ctx.causal)
+                                                      ctx.k, dy, enc, ctx.enc_masks, ctx.causal, saved=ctx.saved)
+            ctx.saved = None
         if ctx.has_ta and dta is None:
             dta = torch.zeros_like(ta)
         de0, de1 = (denc if ctx.twin else (denc, None)) if ctx.cross else (None, None)
