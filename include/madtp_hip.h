@@ -502,10 +502,12 @@ int madtp_bert_encoder_async(const madtp_bert_layer_w* const* layers, int n_laye
  * position t; kv_cache [n_layers][rows][Lmax][2 dim] in the attention dtype (bf16 / f16 in the fast modes, f32 otherwise): this
  * call appends position t of every row and attends to positions 0..t; the caller re-orders the rows between steps
  * (_reorder_cache :1091-1094); kv_pre[l] / kv_index / kv_ld / Nk: the cached cross-attention [k|v] of the encoder states as for
- * madtp_bert_encoder; y [rows, dim] f32; ws: madtp_bert_layer_workspace(rows, 1, Nk, ...) bytes.  Lmax <= 256. */
+ * madtp_bert_encoder; group (ABI 28): `group` consecutive rows - the beams of one item - share an encoder [k|v] block and run the
+ * cross-attention as one sequence of `group` queries (kv_index then holds rows / group entries; 1: one entry per row); y [rows, dim]
+ * f32; ws: the larger of madtp_bert_layer_workspace(rows, 1, Nk, ...) and (rows / group, group, Nk, ...) bytes.  Lmax <= 256. */
 int madtp_bert_decode_step(const madtp_bert_layer_w* const* layers, int n_layers, const float* x, void* kv_cache, int rows, int t,
-                           int Lmax, const void* const* kv_pre, const int32_t* kv_index, int kv_ld, int Nk, float* y, void* ws,
-                           size_t ws_bytes, void* stream);
+                           int Lmax, const void* const* kv_pre, const int32_t* kv_index, int kv_ld, int Nk, int group, float* y,
+                           void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Answer ranking with the teacher-forced decoder (inference half): models/med.py BertLMHeadModel
@@ -538,6 +540,21 @@ int madtp_beam_topk(const float* logits, int ld, int V, const float* beam_scores
 int madtp_beam_topk_penalty(const float* logits, int ld, int V, const float* beam_scores, int num_beams, int n_top,
                             int suppress_token, const int64_t* prev_ids, int ld_prev, int cur_len, float repetition_penalty,
                             float* out_scores, int32_t* out_index, int B, void* stream);
+/* The hypothesis book-keeping of one beam-search step on the device (ABI 28; transformers 4.15 generation_beam_search.py
+ * BeamSearchScorer.process + BeamHypotheses.add / is_done behind text_decoder.generate(num_beams=...), models/blip_vqa.py:134-140,
+ * models/blip.py:189-196), fed by madtp_beam_topk's candidates [B, n_top]: per item, in rank order, an EOS candidate of rank <
+ * num_beams closes a hypothesis of the cur_len tokens of its row (score = sum_logprobs / denom in double, denom = cur_len **
+ * length_penalty computed by the caller; kept while among the num_beams best), the other candidates become the next beams until
+ * num_beams are found.  ids_in / ids_out: int64 [B * num_beams, ld_ids] (the beams' sequences; ids_out gets the re-ordered rows +
+ * the new token at column cur_len), beam_scores f32 [B * num_beams] (in place), beam_src int64 [B * num_beams] (the row each new
+ * beam continues - the _reorder_cache index of models/med.py:1091-1094).  Hypothesis state per item, S = num_beams + 1 slots:
+ * hyp_n [B] (count), hyp_order [B,S] (list order -> slot), hyp_score [B,S] (double), hyp_len [B,S], hyp_tok [B,S,ld_ids], worst [B]
+ * (double, 1e9 when empty), done [B] (a finished item emits pad tokens, zero scores, source row 0, as the library does).  err [1] is
+ * set when an item has fewer than num_beams open continuations among its candidates.  num_beams <= 8. */
+int madtp_beam_update(const float* cand_scores, const int32_t* cand_index, int n_top, int V, const int64_t* ids_in, int64_t* ids_out,
+                      int ld_ids, int cur_len, float* beam_scores, int64_t* beam_src, int32_t* hyp_n, int32_t* hyp_order,
+                      double* hyp_score, int32_t* hyp_len, int64_t* hyp_tok, double* worst, int32_t* done, int32_t* err, double denom,
+                      int num_beams, int eos_token, int pad_token, int early_stopping, int B, void* stream);
 /* One step of nucleus sampling (models/blip.py:175-186: text_decoder.generate(do_sample=True, top_p=0.9, repetition_penalty=1.1);
  * transformers 4.15 `sample`): on the raw last-position scores of every row - RepetitionPenaltyLogitsProcessor over prev_ids
  * (s < 0 ? s * penalty : s / penalty for tokens already in the row; NULL / 1.0: none), EOS suppression below min_length

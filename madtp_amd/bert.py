@@ -1060,6 +1060,7 @@ class BertLMHeadModel(nn.Module):
         use_cache = (os.environ.get("MADTP_DECODE_CACHE", "1") != "0" and max_length <= 256
                      and all(type(l) is enc.layer_cls and getattr(l, "has_cross", hasattr(l, "crossattention")) for l in layers))
         state = {"t": 0, "cache": None}
+        item_index = sel.index[::num_beams].contiguous()
 
         def step_cached(ids, beam_src=None):
             emb = self.bert.embeddings
@@ -1074,7 +1075,8 @@ class BertLMHeadModel(nn.Module):
                 t = state["t"]
                 x, _ = hip.bert_embed(ids[:, t:t + 1].contiguous(), emb.word_embeddings.weight, emb.position_embeddings.weight[t:],
                                       emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps, lp=None)
-                y = hip.bert_decode_step(ws, x.view(rows, D), state["cache"], t, sel.kv, sel.index, 0, sel.Nk)
+                # (an item's num_beams rows share its encoder K/V block: one cross-attention sequence of num_beams queries per item)
+                y = hip.bert_decode_step(ws, x.view(rows, D), state["cache"], t, sel.kv, item_index, 0, sel.Nk, group=num_beams)
                 state["t"] = t + 1
             _, padded = self.prediction_scores(y.view(rows, 1, D))
             return padded[:, 0, :]

@@ -557,19 +557,21 @@ extern "C" int madtp_bert_layer(const madtp_bert_layer_w* w, const float* hidden
 // at position t (cache [n_layers][rows][Lmax][2 dim] in the attention dtype), attends the new query to positions 0..t of its row
 // (no causal mask needed: everything in the cache is in the past), then output projection + LayerNorm, cross-attention against the
 // caller's cached encoder K/V (kv_pre / kv_index: the EncoderKVCache of f1) and the FFN - the second half is bert_rest_impl on
-// [rows, 1, dim].  x: embedded new tokens [rows, dim] f32 (position t), y: [rows, dim] f32.  Beam re-ordering of the cache between
+// [rows / group, group, dim].  x: embedded new tokens [rows, dim] f32 (position t), y: [rows, dim] f32.  Beam re-ordering of the cache between
 // steps (_reorder_cache, :1091-1094) is the caller's gather over the rows.
 extern "C" int madtp_bert_decode_step(const madtp_bert_layer_w* const* layers, int n_layers, const float* x, void* kv_cache, int rows,
-                                      int t, int Lmax, const void* const* kv_pre, const int32_t* kv_index, int kv_ld, int Nk, float* y,
-                                      void* ws, size_t ws_bytes, void* stream) {
+                                      int t, int Lmax, const void* const* kv_pre, const int32_t* kv_index, int kv_ld, int Nk, int group,
+                                      float* y, void* ws, size_t ws_bytes, void* stream) {
     if (!layers || !x || !kv_cache || !kv_pre || !y || !ws || n_layers <= 0 || rows <= 0 || t < 0 || t >= Lmax || Lmax > 256 || Nk <= 0)
         return MADTP_E_BADARG;
+    if (group < 1 || rows % group) return MADTP_E_BADARG;
     const float* h = x;
     for (int l = 0; l < n_layers; ++l) {
         const madtp_bert_layer_w* w = layers[l];
         if (!w || w->cross != 1 || !kv_pre[l]) return MADTP_E_BADARG;  // MED decoder layers with single cross-attention
         bool ok;
-        BertWs s = bert_carve((char*)ws, ws_bytes, rows, 1, Nk, w->dim, w->inter.n, w->heads, w->dtype, &ok);
+        // (the carve of the second half - bert_rest_impl on [rows / group, group, dim] - so that both halves agree on the buffers)
+        BertWs s = bert_carve((char*)ws, ws_bytes, rows / group, group, Nk, w->dim, w->inter.n, w->heads, w->dtype, &ok);
         if (!ok) return MADTP_E_SHAPE;
         const int D = w->dim, dt = w->dtype, adt = attn_dt(dt);
         const size_t e = esz_of(adt);
@@ -589,8 +591,11 @@ extern "C" int madtp_bert_decode_step(const madtp_bert_layer_w* const* layers, i
                    stream));
         // the caller's y serves every layer: layer l + 1 reads it as its input (operand copy, residual of the output projection) and
         // writes it again only with its very last kernel
-        TRY(bert_rest_impl(w, att, nullptr, y, nullptr, ws, ws_bytes, rows, 1, 0, nullptr, nullptr, nullptr, 1, nullptr, nullptr, Nk, nullptr,
-                           nullptr, true, nullptr, kv_pre[l], nullptr, kv_index, kv_ld, stream));
+        // group > 1: `group` consecutive rows (the beams of one item) read the same cached encoder [k|v] block - the second half
+        // runs them as ONE sequence of `group` query rows (its row-wise kernels do not care, the cross-attention reads the item's
+        // K/V once instead of once per beam); kv_index then has one entry per item
+        TRY(bert_rest_impl(w, att, nullptr, y, nullptr, ws, ws_bytes, rows / group, group, 0, nullptr, nullptr, nullptr, 1, nullptr, nullptr,
+                           Nk, nullptr, nullptr, true, nullptr, kv_pre[l], nullptr, kv_index, kv_ld, stream));
         h = y;
     }
     return 0;

@@ -143,13 +143,14 @@ __global__ __launch_bounds__(BT_THREADS) void beam_topk_kernel(const float* logi
     for (int j = 0; j < num_beams; ++j) {
         const float* row = logits + ((size_t)b * num_beams + j) * ld;
         const float add = beam_scores[b * num_beams + j], lse = lse_s[j];
-#pragma unroll 4
-        for (int t = tid; t < V; t += BT_THREADS) {
-            float lp = row[t] - lse;
+        // a thread visits its elements in ascending flat index (ties keep the lower index): four consecutive tokens per 16-byte load
+        // (the launcher requires 16-byte aligned rows), two loads in flight; V % 4 tokens at the end one by one
+        auto take = [&](float x, int t) {
+            float lp = x - lse;
             if (prev_ids && ((seen[j * vw + (t >> 5)] >> (t & 31)) & 1u)) lp = lp < 0.f ? lp * penalty : lp / penalty;
             float v = lp + add;
             if (t == suppress) v = -INFINITY;
-            if (!(v > -INFINITY)) continue;  // -inf and NaN never become candidates
+            if (!(v > -INFINITY)) return;  // -inf and NaN never become candidates
             if (filled < n_top) {
                 mv[filled] = v; mi[filled] = j * V + t; ++filled;
                 if (filled == n_top) {
@@ -161,7 +162,20 @@ __global__ __launch_bounds__(BT_THREADS) void beam_topk_kernel(const float* logi
                 cur_min = mv[0]; min_pos = 0;
                 for (int q = 1; q < n_top; ++q) if (mv[q] < cur_min) { cur_min = mv[q]; min_pos = q; }
             }
+        };
+        const int V4 = V >> 2;
+        int t4 = tid;
+        for (; t4 + BT_THREADS < V4; t4 += 2 * BT_THREADS) {
+            const float4 x0 = ((const float4*)row)[t4], x1 = ((const float4*)row)[t4 + BT_THREADS];
+            take(x0.x, 4 * t4); take(x0.y, 4 * t4 + 1); take(x0.z, 4 * t4 + 2); take(x0.w, 4 * t4 + 3);
+            const int u4 = t4 + BT_THREADS;
+            take(x1.x, 4 * u4); take(x1.y, 4 * u4 + 1); take(x1.z, 4 * u4 + 2); take(x1.w, 4 * u4 + 3);
         }
+        for (; t4 < V4; t4 += BT_THREADS) {
+            const float4 x0 = ((const float4*)row)[t4];
+            take(x0.x, 4 * t4); take(x0.y, 4 * t4 + 1); take(x0.z, 4 * t4 + 2); take(x0.w, 4 * t4 + 3);
+        }
+        for (int t = 4 * V4 + tid; t < V; t += BT_THREADS) take(row[t], t);
     }
     for (int r = 0; r < n_top; ++r) {
         float bv = -INFINITY;
@@ -319,6 +333,110 @@ extern "C" int madtp_beam_topk_penalty(const float* logits, int ld, int V, const
     if (!prev_ids) return MADTP_E_BADARG;
     return beam_topk_launch(logits, ld, V, beam_scores, num_beams, n_top, suppress_token, out_scores, out_index, B, prev_ids, ld_prev,
                             cur_len, repetition_penalty, stream);
+}
+
+// ---- the hypothesis book-keeping of one beam-search step on the device (round 5) ----------------------------------------------
+// transformers 4.15 generation_beam_search.py BeamSearchScorer.process / BeamHypotheses.add / is_done, restated per batch item: the
+// 2 * num_beams candidates in rank order - an EOS candidate of rank < num_beams closes a hypothesis (score = sum_logprobs /
+// cur_len ** length_penalty in double, kept while among the num_beams best), the others continue as next step's beams until
+// num_beams are found.  With it the search has no host round trip per step: candidates, sequences, scores and the beams' source
+// rows stay in device memory, the host reads the hypotheses once at the end (madtp_amd/generation.py).
+namespace {
+constexpr int BU_MAXNB = 8;
+struct BeamUpdateArgs {
+    const float* sc; const int32_t* ix; int n_top, V;
+    const int64_t* ids_in; int64_t* ids_out; int ld_ids, cur_len;
+    float* beam_scores; int64_t* beam_src;
+    int32_t* hyp_n; int32_t* hyp_order; double* hyp_score; int32_t* hyp_len; int64_t* hyp_tok; double* worst; int32_t* done; int32_t* err;
+    double denom; int nb, eos, pad, early_stopping;
+};
+__global__ __launch_bounds__(64) void beam_update_kernel(BeamUpdateArgs a) {
+    // every lane runs the same (uniform) scalar logic; the lanes share the copies of token rows
+    const int b = blockIdx.x, lane = threadIdx.x, nb = a.nb, S = nb + 1;
+    if (a.done[b]) {  // a finished item: pad tokens, zero scores, source row 0 (as the library's zero-initialised next_beam_* do)
+        for (int j = 0; j < nb; ++j) {
+            const size_t ro = (size_t)(b * nb + j) * a.ld_ids;
+            for (int t = lane; t < a.cur_len; t += 64) a.ids_out[ro + t] = a.ids_in[t];
+            if (lane == 0) { a.ids_out[ro + a.cur_len] = a.pad; a.beam_scores[b * nb + j] = 0.f; a.beam_src[b * nb + j] = 0; }
+        }
+        return;
+    }
+    int n = a.hyp_n[b];
+    double w = a.worst[b];
+    int order[BU_MAXNB + 1];
+    double score[BU_MAXNB + 1];
+#pragma unroll
+    for (int i = 0; i <= BU_MAXNB; ++i) { order[i] = i < S ? a.hyp_order[b * S + i] : 0; score[i] = i < S ? a.hyp_score[b * S + i] : 0.0; }
+    float nb_s[BU_MAXNB];
+    int nb_t[BU_MAXNB], nb_r[BU_MAXNB];
+    int slot = 0;
+    float best = -INFINITY;
+    for (int r = 0; r < a.n_top; ++r) best = fmaxf(best, a.sc[b * a.n_top + r]);
+    for (int r = 0; r < a.n_top && slot < nb; ++r) {
+        const int idx = a.ix[b * a.n_top + r];
+        if (idx < 0) continue;
+        const int beam = idx / a.V, tok = idx - beam * a.V, row = b * nb + beam;
+        const float s = a.sc[b * a.n_top + r];
+        if (tok == a.eos) {
+            if (r >= nb) continue;
+            const double hs = (double)s / a.denom;
+            if (n < nb || hs > w) {
+                unsigned used = 0;  // physical slots in use
+                for (int i = 0; i < n; ++i) used |= 1u << order[i];
+                int p = 0;
+                while (used & (1u << p)) ++p;
+                for (int t = lane; t < a.cur_len; t += 64) a.hyp_tok[((size_t)b * S + p) * a.ld_ids + t] = a.ids_in[(size_t)row * a.ld_ids + t];
+                if (lane == 0) a.hyp_len[b * S + p] = a.cur_len;
+                score[p] = hs;
+                order[n++] = p;
+                if (n > nb) {  // drop the lowest (first of equals), the new worst is the lowest of the rest
+                    int lo = 0;
+                    for (int i = 1; i < n; ++i) if (score[order[i]] < score[order[lo]]) lo = i;
+                    for (int i = lo; i + 1 < n; ++i) order[i] = order[i + 1];
+                    --n;
+                    w = score[order[0]];
+                    for (int i = 1; i < n; ++i) w = fmin(w, score[order[i]]);
+                } else {
+                    w = fmin(hs, w);
+                }
+            }
+        } else {
+            nb_s[slot] = s; nb_t[slot] = tok; nb_r[slot] = row;
+            ++slot;
+        }
+    }
+    if (slot < nb) {  // fewer than num_beams open continuations among the candidates (the library asserts the same)
+        if (lane == 0) *a.err = 1;
+        for (; slot < nb; ++slot) { nb_s[slot] = 0.f; nb_t[slot] = a.pad; nb_r[slot] = b * nb; }
+    }
+    const bool dn = n >= nb && (a.early_stopping || w >= (double)best / a.denom);
+    for (int j = 0; j < nb; ++j) {
+        const size_t ro = (size_t)(b * nb + j) * a.ld_ids, ri = (size_t)nb_r[j] * a.ld_ids;
+        for (int t = lane; t < a.cur_len; t += 64) a.ids_out[ro + t] = a.ids_in[ri + t];
+        if (lane == 0) { a.ids_out[ro + a.cur_len] = nb_t[j]; a.beam_scores[b * nb + j] = nb_s[j]; a.beam_src[b * nb + j] = nb_r[j]; }
+    }
+    if (lane == 0) {
+        a.hyp_n[b] = n; a.worst[b] = w; a.done[b] = dn ? 1 : 0;
+        for (int i = 0; i < S; ++i) { a.hyp_order[b * S + i] = order[i]; a.hyp_score[b * S + i] = score[i]; }
+    }
+}
+}  // namespace
+
+extern "C" int madtp_beam_update(const float* cand_scores, const int32_t* cand_index, int n_top, int V, const int64_t* ids_in,
+                                 int64_t* ids_out, int ld_ids, int cur_len, float* beam_scores, int64_t* beam_src, int32_t* hyp_n,
+                                 int32_t* hyp_order, double* hyp_score, int32_t* hyp_len, int64_t* hyp_tok, double* worst, int32_t* done,
+                                 int32_t* err, double denom, int num_beams, int eos_token, int pad_token, int early_stopping, int B,
+                                 void* stream) {
+    if (!cand_scores || !cand_index || !ids_in || !ids_out || !beam_scores || !beam_src || !hyp_n || !hyp_order || !hyp_score || !hyp_len ||
+        !hyp_tok || !worst || !done || !err || B <= 0 || V <= 0)
+        return MADTP_E_BADARG;
+    if (num_beams < 1 || num_beams > BU_MAXNB || n_top < num_beams || n_top > 2 * BU_MAXNB || cur_len < 1 || cur_len >= ld_ids || !(denom > 0.0))
+        return MADTP_E_SHAPE;
+    BeamUpdateArgs a{cand_scores, cand_index, n_top, V, ids_in, ids_out, ld_ids, cur_len, beam_scores, beam_src, hyp_n, hyp_order, hyp_score,
+                     hyp_len, hyp_tok, worst, done, err, denom, num_beams, eos_token, pad_token, early_stopping};
+    hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    MADTP_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int madtp_sample_top_p(const float* logits, int ld, int V, const int64_t* prev_ids, int ld_prev, int cur_len,

@@ -51,7 +51,11 @@ def beam_search(step_fn, input_ids, num_beams, max_length, min_length, eos_token
     beam_src[i] of the PREVIOUS call (None on the first call); input_ids: the prompt already repeated num_beams times per item.
     -> int64 [B, <= max_length] on the GPU."""
     import inspect
+    import os
     takes_src = "beam_src" in inspect.signature(step_fn).parameters
+    if os.environ.get("MADTP_BEAM_DEVICE", "1") != "0" and input_ids.shape[1] < max_length:
+        return _beam_search_device(step_fn, takes_src, input_ids, num_beams, max_length, min_length, eos_token_id, pad_token_id, n_vocab,
+                                   repetition_penalty, length_penalty, early_stopping)
     beam_src = None
     dev = input_ids.device
     n, cur_len = input_ids.shape
@@ -101,6 +105,12 @@ def beam_search(step_fn, input_ids, num_beams, max_length, min_length, eos_token
         cur_len += 1
         if all(done) or cur_len >= max_length:
             break
+    return _finalize(hyps, done, ids_host, beam_scores, num_beams, max_length, eos_token_id, pad_token_id, dev)
+
+
+def _finalize(hyps, done, ids_host, beam_scores, num_beams, max_length, eos_token_id, pad_token_id, dev):
+    """BeamSearchScorer.finalize: the open beams of unfinished items become hypotheses, the best hypothesis per item is returned."""
+    B = len(hyps)
     for b in range(B):
         if done[b]:
             continue
@@ -115,6 +125,59 @@ def beam_search(step_fn, input_ids, num_beams, max_length, min_length, eos_token
         if lens[b] < max_length:
             out[b, lens[b]] = eos_token_id
     return out.to(dev)
+
+
+def _beam_search_device(step_fn, takes_src, input_ids, num_beams, max_length, min_length, eos_token_id, pad_token_id, n_vocab,
+                        repetition_penalty, length_penalty, early_stopping):
+    """beam_search with the per-step book-keeping on the device (round 5, madtp_beam_update): sequences, beam scores, source rows and
+    the hypothesis lists never leave the GPU during the search - no host round trip per step, the host queues step after step; it
+    looks at the items' done flags through asynchronous copies (an event per step, polled without blocking) and stops queueing once a
+    completed copy shows every item finished - steps queued past that point only emit pad tokens for finished items, the result
+    does not depend on when the host notices.  One synchronisation at the end brings the hypotheses to the host for the library's
+    finalize.  MADTP_BEAM_DEVICE=0: the host book-keeping above."""
+    dev = input_ids.device
+    n, cur_len = input_ids.shape
+    B = n // num_beams
+    st = hip.BeamState(B, num_beams, max_length, pad_token_id, dev)
+    cur = 0
+    st.ids[0][:, :cur_len] = input_ids
+    flags = torch.zeros((max_length, B), dtype=torch.int32).pin_memory()
+    pending = []
+    beam_src = None
+    while True:
+        ids = st.ids[cur][:, :cur_len]
+        logits = step_fn(ids, beam_src=beam_src) if takes_src else step_fn(ids.contiguous())
+        suppress = eos_token_id if (min_length is not None and min_length > -1 and cur_len < min_length) else -1
+        sc, ix = hip.beam_topk(logits, st.beam_scores, num_beams, n_vocab, suppress_token=suppress,
+                               prev_ids=ids if repetition_penalty != 1.0 else None, repetition_penalty=repetition_penalty)
+        hip.beam_update(st, cur, sc, ix, n_vocab, cur_len, float(cur_len) ** length_penalty, eos_token_id, pad_token_id, early_stopping)
+        cur = 1 - cur
+        beam_src = st.beam_src.clone() if takes_src else None  # (the step reads it after the next update has been queued)
+        flags[cur_len].copy_(st.done, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        pending.append((ev, cur_len))
+        cur_len += 1
+        stop = cur_len >= max_length
+        while pending and pending[0][0].query():
+            _, i = pending.pop(0)
+            stop = stop or bool(flags[i].all())
+        if stop:
+            break
+    torch.cuda.synchronize()
+    if int(st.err.cpu()):
+        raise RuntimeError("beam search: fewer than num_beams open continuations among the 2 * num_beams candidates")
+    hn, ho, hs, hl, ht = st.hyp_n.cpu(), st.hyp_order.cpu(), st.hyp_score.cpu(), st.hyp_len.cpu(), st.hyp_tok.cpu()
+    worst, done = st.worst.cpu(), [bool(d) for d in st.done.cpu()]
+    hyps = []
+    for b in range(B):
+        h = BeamHypotheses(num_beams, length_penalty, early_stopping)
+        for i in range(int(hn[b])):
+            p = int(ho[b, i])
+            h.beams.append((float(hs[b, p]), ht[b, p, :int(hl[b, p])].tolist()))
+        h.worst_score = float(worst[b])
+        hyps.append(h)
+    return _finalize(hyps, done, st.ids[cur][:, :cur_len].cpu(), st.beam_scores.cpu(), num_beams, max_length, eos_token_id, pad_token_id, dev)
 
 
 def sample(step_fn, input_ids, max_length, min_length, eos_token_id, pad_token_id, n_vocab, top_p, top_k=50, repetition_penalty=1.0,

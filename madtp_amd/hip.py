@@ -82,8 +82,8 @@ _SIGS = {
     "madtp_bert_encoder_async": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
                                          c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                          c_void_p, c_void_p, c_void_p]),
-    "madtp_bert_decode_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
-                                       c_void_p, c_size_t, c_void_p]),
+    "madtp_bert_decode_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_size_t, c_void_p]),
     "madtp_sample_top_p": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                    c_int, c_void_p]),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
@@ -105,6 +105,9 @@ _SIGS = {
     "madtp_transpose_pad": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "madtp_gemm_splitk_pp": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "madtp_splitk_sum": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p]),
+    "madtp_beam_update": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p]),
     "madtp_transpose_split": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "madtp_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "madtp_act_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
@@ -935,7 +938,8 @@ def beam_topk(logits, beam_scores, num_beams, n_vocab, n_top=None, suppress_toke
     sc = torch.empty((B, n_top), device=logits.device, dtype=torch.float32)
     ix = torch.empty((B, n_top), device=logits.device, dtype=torch.int32)
     if prev_ids is not None and repetition_penalty != 1.0:  # RepetitionPenaltyLogitsProcessor on the beams' sequences so far
-        _req(prev_ids, torch.int64, "prev_ids")
+        if not prev_ids.is_cuda or prev_ids.dtype != torch.int64 or prev_ids.dim() != 2 or prev_ids.stride(1) != 1:
+            raise RuntimeError("beam_topk: prev_ids must be a GPU int64 [rows, cur_len] tensor with unit column stride")
         _check(load().madtp_beam_topk_penalty(_p(logits), logits.stride(0), int(n_vocab), _p(beam_scores), int(num_beams), n_top,
                                               int(suppress_token), _p(prev_ids), prev_ids.stride(0), prev_ids.shape[1],
                                               float(repetition_penalty), _p(sc), _p(ix), B, _stream()), "madtp_beam_topk_penalty")
@@ -943,6 +947,37 @@ def beam_topk(logits, beam_scores, num_beams, n_vocab, n_top=None, suppress_toke
     _check(load().madtp_beam_topk(_p(logits), logits.stride(0), int(n_vocab), _p(beam_scores), int(num_beams), n_top,
                                   int(suppress_token), _p(sc), _p(ix), B, _stream()), "madtp_beam_topk")
     return sc, ix
+
+
+class BeamState:
+    """Device-side hypothesis state of a beam search (madtp_beam_update): B items, num_beams beams, sequences of up to max_length."""
+
+    def __init__(self, B, num_beams, max_length, pad_token_id, device):
+        S, n = num_beams + 1, B * num_beams
+        self.B, self.num_beams, self.max_length = B, num_beams, max_length
+        self.ids = [torch.full((n, max_length), pad_token_id, dtype=torch.int64, device=device) for _ in range(2)]
+        self.beam_scores = torch.zeros((B, num_beams), dtype=torch.float32, device=device)
+        self.beam_scores[:, 1:] = -1e9
+        self.beam_scores = self.beam_scores.view(-1)
+        self.beam_src = torch.zeros((n,), dtype=torch.int64, device=device)
+        self.hyp_n = torch.zeros((B,), dtype=torch.int32, device=device)
+        self.hyp_order = torch.zeros((B, S), dtype=torch.int32, device=device)
+        self.hyp_score = torch.zeros((B, S), dtype=torch.float64, device=device)
+        self.hyp_len = torch.zeros((B, S), dtype=torch.int32, device=device)
+        self.hyp_tok = torch.zeros((B, S, max_length), dtype=torch.int64, device=device)
+        self.worst = torch.full((B,), 1e9, dtype=torch.float64, device=device)
+        self.done = torch.zeros((B,), dtype=torch.int32, device=device)
+        self.err = torch.zeros((1,), dtype=torch.int32, device=device)
+
+
+def beam_update(st, cur, sc, ix, n_vocab, cur_len, denom, eos_token_id, pad_token_id, early_stopping):
+    """One step of hypothesis book-keeping on the device: st.ids[cur] (+ candidates sc / ix of madtp_beam_topk) -> st.ids[1 - cur],
+    st.beam_scores, st.beam_src and the hypothesis state."""
+    _check(load().madtp_beam_update(_p(sc), _p(ix), sc.shape[1], int(n_vocab), _p(st.ids[cur]), _p(st.ids[1 - cur]), st.max_length,
+                                    int(cur_len), _p(st.beam_scores), _p(st.beam_src), _p(st.hyp_n), _p(st.hyp_order), _p(st.hyp_score),
+                                    _p(st.hyp_len), _p(st.hyp_tok), _p(st.worst), _p(st.done), _p(st.err), float(denom), st.num_beams,
+                                    int(eos_token_id), int(pad_token_id), 1 if early_stopping else 0, st.B, _stream()),
+           "madtp_beam_update")
 
 
 def sample_top_p(logits, u, n_vocab, top_p, top_k=50, suppress_token=-1, prev_ids=None, repetition_penalty=1.0, want_prob=False):
@@ -1202,21 +1237,24 @@ def vit_encoder_sync_free_ok(B, N, prune, qargs):
     return bool(prune and qargs is not None and qargs.get("att_ft") is None and B * N < 4096 and 3 <= N <= 256)
 
 
-def bert_decode_step(weights, x, kv_cache, t, kv_pre, kv_index, kv_ld, Nk):
+def bert_decode_step(weights, x, kv_cache, t, kv_pre, kv_index, kv_ld, Nk, group=1):
     """One incremental decoding step (madtp_bert_decode_step): x f32 [rows, D] = the embedded new tokens at position t; kv_cache
     [layers, rows, Lmax, 2 D] in the attention dtype (appended in place); kv_pre: the per-layer cached cross-attention [k|v]
-    tensors, kv_index int32 [rows].  -> y f32 [rows, D]."""
+    tensors, kv_index int32 [rows / group] (group consecutive rows - an item's beams - read one block).  -> y f32 [rows, D]."""
     rows, D = x.shape
     lib = load()
     wstructs, arr = weights
     L = len(wstructs)
     w0 = wstructs[0]
-    nbytes = lib.madtp_bert_layer_workspace(rows, 1, Nk, w0.dim, w0.inter.n, w0.heads, w0.dtype)
+    nbytes = max(lib.madtp_bert_layer_workspace(rows, 1, Nk, w0.dim, w0.inter.n, w0.heads, w0.dtype),
+                 lib.madtp_bert_layer_workspace(rows // group, group, Nk, w0.dim, w0.inter.n, w0.heads, w0.dtype))
     ws = workspace(nbytes, x.device)
     y = torch.empty_like(x)
     kv = (c_void_p * L)(*[_p(tn) for tn in kv_pre])
+    if kv_index.numel() != rows // group:
+        raise ValueError("bert_decode_step: kv_index must hold one entry per group of rows")
     _check(lib.madtp_bert_decode_step(arr, L, _p(x), _p(kv_cache), rows, int(t), kv_cache.shape[2], kv, _p(kv_index), int(kv_ld), int(Nk),
-                                      _p(y), _p(ws), ws.numel(), _stream()), "madtp_bert_decode_step")
+                                      int(group), _p(y), _p(ws), ws.numel(), _stream()), "madtp_bert_decode_step")
     return y
 
 

@@ -814,7 +814,7 @@ def test_nucleus_sampling_step_equals_oracle_and_generate_samples():
 
 
 def test_generation_beam_search_equals_oracle_on_toy_models():
-    """madtp_amd.generation.beam_search (madtp_beam_topk + the host-side hypothesis book-keeping) against oracle.beam_search
+    """madtp_amd.generation.beam_search (madtp_beam_topk + the hypothesis book-keeping, device- and host-side) against oracle.beam_search
     (transformers 4.15 restated) on first-order toy language models with random tables: EOS frequent enough that hypotheses
     finish at every length, min_length in play, items finishing at different steps (padding), the hand-worked cases of
     tests/test_oracle_golden.py included."""
@@ -845,10 +845,18 @@ def test_generation_beam_search_equals_oracle_on_toy_models():
         # every other trial with the library's repetition penalty (generate(repetition_penalty=...), models/blip.py:161,195):
         # tokens already in a beam's sequence have their log-probability scaled (madtp_beam_topk_penalty)
         rp = [1.0, 1.3, 0.8, 2.0][trial % 4]
-        ref = O.beam_search(toy_lm(table), prompt, repetition_penalty=rp, **kw)
-        mine = generation.beam_search(gpu_lm(table, (V + 3) // 4 * 4), prompt.cuda(), kw["num_beams"], kw["max_length"],
-                                      kw["min_length"], 1, 0, V, repetition_penalty=rp)
-        assert mine.cpu().tolist() == ref.tolist(), (trial, rp, mine.tolist(), ref.tolist())
+        # hypothesis scoring / stopping rules beyond the call sites' defaults (BeamHypotheses.add, is_done)
+        lp, es = [1.0, 0.7, 1.6][trial % 3], trial % 5 == 4
+        ref = O.beam_search(toy_lm(table), prompt, repetition_penalty=rp, length_penalty=lp, early_stopping=es, **kw)
+        # the book-keeping on the device (madtp_beam_update, the default) and on the host (MADTP_BEAM_DEVICE=0)
+        for dev_side in ("1", "0"):
+            os.environ["MADTP_BEAM_DEVICE"] = dev_side
+            try:
+                mine = generation.beam_search(gpu_lm(table, (V + 3) // 4 * 4), prompt.cuda(), kw["num_beams"], kw["max_length"],
+                                              kw["min_length"], 1, 0, V, repetition_penalty=rp, length_penalty=lp, early_stopping=es)
+            finally:
+                del os.environ["MADTP_BEAM_DEVICE"]
+            assert mine.cpu().tolist() == ref.tolist(), (trial, dev_side, rp, lp, es, mine.tolist(), ref.tolist())
         n_eos += int((ref == 1).any())
     assert n_eos >= 8   # the finishing rules were exercised
 
