@@ -584,7 +584,8 @@ int madtp_transpose_pad(const float* src, int ld_src, int R, int C, float* dst, 
  * partials in colsum_ws (ceil(Rp/64) * C floats), added in a fixed order. */
 int madtp_transpose_split(const float* src, int ld_src, int R, int C, void* dst, int Rp, int Cp, int weight_format,
                           float* colsum_out, float* colsum_ws, void* stream);
-/* out[c] = sum_r dy[r, c]: bias gradients (nn.Linear, LayerNorm beta).  part_ws: 64 * N floats of scratch. */
+/* out[c] = sum_r dy[r, c]: bias gradients (nn.Linear, LayerNorm beta).  part_ws: P * N floats of scratch, P = 64 for M >= 4096,
+ * 16 for M >= 256, else 1 (the row chunks summed in order; 64 * N always suffices). */
 int madtp_colsum(const float* dy, int ld, int M, int N, float* out, float* part_ws, void* stream);
 /* g = act(u) (g != NULL) and / or du = dg * act'(u) (du != NULL): Mlp's GELU (vit.py:34) and its derivative; n % 4 == 0. */
 int madtp_act_fwd_bwd(const float* u, const float* dg, float* g, float* du, size_t n, int act, void* stream);
@@ -619,7 +620,24 @@ int madtp_token_score_bwd(const float* dw, const float* score, const int32_t* ds
 size_t madtp_attention_bwd_cross_workspace(int B, int H, int Nq, int Nk);
 int madtp_attention_bwd_cross(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* key_mask,
                               const float* dout, int ldo, float* dq, int lddq, float* dk, float* dv, int lddkv, void* ws,
-                              size_t ws_bytes, int B, int H, int Nq, int Nk, float scale, void* stream);
+                              size_t ws_bytes, int B, int H, int Nq, int Nk, float scale, float p_drop,
+                              unsigned long long seed, unsigned long long site, void* stream);
+
+/* Dropout / DropPath of the training forward (ABI 28; models/med.py:55,111,244,323: nn.Dropout at hidden_dropout_prob /
+ * attention_probs_dropout_prob 0.1, configs/med_config.json:5,7; models/vit.py:114,186,205: DropPath): y = residual + x * keep /
+ * (1 - p) (residual may be NULL), keep drawn per element (per_sample == 0) or once per run of per_sample elements (DropPath: one
+ * draw per sample).  Masks are counter-based - Philox4x32-10 keyed by `seed`, counter (index / 4, site), word index & 3, keep = u >= p
+ * with u = (word >> 8) 2^-24 - so the backward applies the same call to dY with the same (seed, site) and nothing is stored.
+ * n % 4 == 0, per_sample % 4 == 0. */
+int madtp_dropout(const float* x, const float* residual, float* y, size_t n, size_t per_sample, float p, unsigned long long seed,
+                  unsigned long long site, void* stream);
+/* Attention of the training forward with attention_probs dropout (med.py:202-222, nlvr_encoder.py:201-223): P = softmax(scale q k^T
+ * + key_mask + mask_qk) written to P [B,H,Nq,Nk] f32, out = (P o mask / (1 - p_drop)) v with the mask of (seed, site) over P's
+ * elements in memory order; colsum_part / p0 / onorm: madtp_attention's side outputs (from the undropped P and the dropped out, as
+ * med.py:227-233 takes them) or NULL.  madtp_attention_bwd / _cross take the same (p_drop, seed, site).  Exact f32. */
+int madtp_attention_train(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* key_mask, const float* mask_qk,
+                          int ld_mqk, float* P, float* out, int ldo, float* colsum_part, float* p0, float* onorm, int B, int H, int Nq,
+                          int Nk, float scale, float p_drop, unsigned long long seed, unsigned long long site, void* stream);
 
 /* Backward of the query model's att_ft branch (models/utils.py:174-178: W = softmax over tokens of inner / sqrt(sd_dim), att_ft =
  * W q), the part of VisionTransformer.forward's second output (vit.py:297-303, consumed by the training drivers' alignment loss).
@@ -642,7 +660,8 @@ int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, 
                         int ldout, const float* dnrm_scale, const float* da, const float* dp0, float* dq, float* dk, float* dv,
                         int ldd, void* ws, size_t ws_bytes,
                         float* dp_out, /* [B,H,N,N] or NULL: the gradient of the attention probabilities (vit.py:189 register_hook) */
-                        int B, int H, int N, float scale, void* stream);
+                        int B, int H, int N, float scale, float p_drop, unsigned long long seed,
+                        unsigned long long site, void* stream);
 
 #ifdef __cplusplus
 }

@@ -205,7 +205,8 @@ def wgrad(dy, x, bias=False):
 def colsum(dy):
     M, N = dy.shape
     out = torch.empty((N,), device=dy.device, dtype=torch.float32)
-    part = torch.empty((64 * N,), device=dy.device, dtype=torch.float32)
+    P = 64 if M >= 4096 else (16 if M >= 256 else 1)  # the row-chunk count csrc/backward.hip col_reduce uses for M rows
+    part = torch.empty((P * N,), device=dy.device, dtype=torch.float32)
     _check(load().madtp_colsum(_p(dy), dy.stride(0), M, N, _p(out), _p(part), _stream()), "madtp_colsum")
     return out
 
@@ -220,6 +221,34 @@ def act_bwd(u, dg, act):
     du = torch.empty_like(u)
     _check(load().madtp_act_fwd_bwd(_p(u), _p(dg), None, _p(du), u.numel(), act, _stream()), "madtp_act_fwd_bwd")
     return du
+
+
+def dropout(x, p, seed, site, residual=None, per_sample=0):
+    """madtp_dropout: residual + x * keep / (1 - p) with the counter-based mask of (seed, site); per_sample > 0: one draw per run of
+    per_sample elements (DropPath).  The backward of the site is the same call on dY (without the residual)."""
+    y = torch.empty_like(x)
+    _check(load().madtp_dropout(_p(x), _p(residual), _p(y), x.numel(), int(per_sample), float(p), int(seed), int(site), _stream()),
+           "madtp_dropout")
+    return y
+
+
+def attention_train(q, k, v, B, H, Nq, Nk, scale, drop, key_mask=None, mask_qk=None, scores=False):
+    """madtp_attention_train: the training forward's attention with attention_probs dropout drop = (p, seed, site) -> (out [B*Nq, H*64],
+    side or None) like hip.attention (exact f32; P is scratch)."""
+    p, seed, site = drop
+    out = torch.empty((B * Nq, H * 64), device=q.device, dtype=torch.float32)
+    P = torch.empty((B * H * Nq * Nk,), device=q.device, dtype=torch.float32)
+    cs = p0 = on = None
+    if scores:
+        cs = torch.empty((B, (Nq + 15) // 16, Nk), device=q.device, dtype=torch.float32)
+        p0 = torch.empty((B, H, Nk), device=q.device, dtype=torch.float32)
+        on = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
+    if k.stride(0) != v.stride(0):
+        raise RuntimeError("attention_train: k and v must share a row stride")
+    _check(load().madtp_attention_train(_p(q), q.stride(0), _p(k), _p(v), k.stride(0), _p(key_mask), _p(mask_qk),
+                                        mask_qk.stride(0) if mask_qk is not None else 0, _p(P), _p(out), out.stride(0), _p(cs), _p(p0), _p(on),
+                                        B, H, Nq, Nk, float(scale), float(p), int(seed), int(site), _stream()), "madtp_attention_train")
+    return out, ((cs, p0, on) if scores else None)
 
 
 def layernorm_bwd(x2d, gamma, dy2d, eps, add=None):
@@ -255,9 +284,10 @@ def token_score_bwd(dw, score, dst_pos, merge_w, side, token_attn, B, H, N):
     return da, dp0, dnrm, dta
 
 
-def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None, key_mask=None, mask_qk=None, dp_out=None):
+def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None, key_mask=None, mask_qk=None, dp_out=None, drop=None):
     """qkv f32 [B*N, 3*H*64] (fused projection), dout / out [B*N, H*64] -> dqkv [B*N, 3*H*64].  key_mask: additive f32 [B,N]
-    over the keys (the BERT layers' padding mask) or None."""
+    over the keys (the BERT layers' padding mask) or None.  drop: (p, seed, site) of the forward's attention_probs dropout or None."""
+    dp, dseed, dsite = drop if drop is not None else (0.0, 0, 0)
     D = H * 64
     dqkv = torch.empty_like(qkv)
     lib = load()
@@ -268,13 +298,14 @@ def attention_bwd(qkv, dout, out, B, H, N, scale, dnrm=None, da=None, dp0=None, 
     _check(lib.madtp_attention_bwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(key_mask), _p(mask_qk),
                                    mask_qk.stride(0) if mask_qk is not None else 0, _p(dout), dout.stride(0), _p(out), out.stride(0), _p(dnrm),
                                    _p(da), _p(dp0), _p(dq), _p(dk), _p(dv), dqkv.stride(0), _p(ws), nbytes, _p(dp_out), B, H, N, float(scale),
-                                   _stream()), "madtp_attention_bwd")
+                                   float(dp), int(dseed), int(dsite), _stream()), "madtp_attention_bwd")
     return dqkv
 
 
-def attention_bwd_cross(q, kv, dout, B, H, Nq, Nk, scale, key_mask=None):
+def attention_bwd_cross(q, kv, dout, B, H, Nq, Nk, scale, key_mask=None, drop=None):
     """Cross-attention backward: q f32 [B*Nq, D], kv f32 [B*Nk, 2D] (fused [k|v] projection of the encoder tokens), dout [B*Nq, D]
-    -> (dq [B*Nq, D], dkv [B*Nk, 2D])."""
+    -> (dq [B*Nq, D], dkv [B*Nk, 2D]).  drop: (p, seed, site) of the forward's attention_probs dropout or None."""
+    dp, dseed, dsite = drop if drop is not None else (0.0, 0, 0)
     D = H * 64
     dq = torch.empty_like(q)
     dkv = torch.empty_like(kv)
@@ -285,7 +316,7 @@ def attention_bwd_cross(q, kv, dout, B, H, Nq, Nk, scale, key_mask=None):
     dk, dv = dkv[:, :D], dkv[:, D:]
     _check(lib.madtp_attention_bwd_cross(_p(q), q.stride(0), _p(k), _p(v), kv.stride(0), _p(key_mask), _p(dout), dout.stride(0),
                                          _p(dq), dq.stride(0), _p(dk), _p(dv), dkv.stride(0), _p(ws), nbytes, B, H, Nq, Nk,
-                                         float(scale), _stream()), "madtp_attention_bwd_cross")
+                                         float(scale), float(dp), int(dseed), int(dsite), _stream()), "madtp_attention_bwd_cross")
     return dq, dkv
 
 
@@ -356,11 +387,69 @@ class _BlockParts:
                 self.norm2.bias, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias]
 
 
+def _note_versions(ctx, params):
+    """the backward reads the module's CURRENT parameters (W^T planes per parameter version) next to activations of the forward: an
+    in-place update between the two (optimizer.step, load_state_dict, an EMA) would pair them wrongly - native autograd raises
+    'modified by an inplace operation' there, so do these Functions"""
+    ctx.param_versions = tuple(p._version if p is not None else -1 for p in params)
+
+
+def _check_versions(ctx, params, what):
+    now = tuple(p._version if p is not None else -1 for p in params)
+    if now != ctx.param_versions:
+        raise RuntimeError(f"{what}: a parameter was modified in place between forward and backward (versions {ctx.param_versions} -> "
+                           f"{now}); back-propagate before the optimizer step / load_state_dict, as native autograd requires")
+
+
+_WARNED_IMPLICIT = [False]
+
+
+def _warn_implicit(wants):
+    """the autograd route was taken only because the parameters have requires_grad = True (the nn.Module default), not because an
+    input asks for a gradient: say so once - a forgotten torch.no_grad() otherwise becomes a silent slowdown (no encoder-level call,
+    activations kept)"""
+    if wants or _WARNED_IMPLICIT[0]:
+        return
+    _WARNED_IMPLICIT[0] = True
+    import warnings
+    warnings.warn("madtp_amd: a forward in grad mode takes the autograd route (hand-written backward, activations kept) because the "
+                  "module's parameters require grad; wrap inference in torch.no_grad() to get the fused inference path", RuntimeWarning,
+                  stacklevel=3)
+
+
 def _save_forward():
     """MADTP_TRAIN_SAVE (default 1): the training forward of a block is composed from the single kernels and KEEPS its intermediates
     for the backward (round 5) - instead of running the fused layer call and recomputing the layer in the backward (0: the
     round-4 scheme, a third less activation memory, one more forward's worth of kernels per step)."""
     return os.environ.get("MADTP_TRAIN_SAVE", "1") != "0"
+
+
+def _site(base, code):
+    """site id of dropout site `code` of the layer call that drew `base` (runtime.next_dropout_base)"""
+    return base * 32 + code
+
+
+def _block_drop(blk):
+    """(p, seed, base) of a ViT block's DropPath in this forward, or None (eval mode / rate 0)"""
+    p = float(getattr(blk, "drop_path_rate", 0.0) or 0.0)
+    if not blk.training or p <= 0.0:
+        return None
+    from .runtime import next_dropout_base
+    seed, base = next_dropout_base()
+    return (p, seed, base)
+
+
+def _layer_drop(layer):
+    """(p_hidden, p_attn, seed, base) of a BERT layer's dropouts in this forward, or None"""
+    if not layer.training:
+        return None
+    ph = float(layer.output.dropout.p)
+    pa = float(layer.attention.self.dropout.p)
+    if ph <= 0.0 and pa <= 0.0:
+        return None
+    from .runtime import next_dropout_base
+    seed, base = next_dropout_base()
+    return (ph, pa, seed, base)
 
 
 class _Saved:
@@ -369,7 +458,7 @@ class _Saved:
         self.__dict__.update(kw)
 
 
-def _vit_block_fwd(blk, x, token_attn, temperature, k, mask_qk=None, max_keep=0):
+def _vit_block_fwd(blk, x, token_attn, temperature, k, mask_qk=None, max_keep=0, drop=None):
     """Block.forward from single kernels (the forward's own: same operand formats and dispatch in the f16x3 mode), keeping every
     intermediate the backward reads.  k: the forward's pruning decision (recompute), or None: decide it here - k = max_b count read
     on the host, vit.py:145, kept unless k <= max_keep or fewer than two tokens would go (madtp_vit_block_keep's rule)."""
@@ -386,7 +475,10 @@ def _vit_block_fwd(blk, x, token_attn, temperature, k, mask_qk=None, max_keep=0)
     qkv = _gemm(h1, wq, bq, n=3 * D, out_dtype=torch.float32)
     prune = temperature > 0 if k is None else k > 0
     out, side = _attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, N, N, scale, scores=prune, mask_qk=mask_qk)
-    x_attn = _gemm(out, wp, bp, residual=x2, n=D, out_dtype=torch.float32)
+    if drop is not None:  # x + drop_path(attn(norm1(x))), vit.py:186: one draw per sample
+        x_attn = dropout(_gemm(out, wp, bp, n=D, out_dtype=torch.float32), drop[0], drop[1], _site(drop[2], 0), residual=x2, per_sample=N * D)
+    else:
+        x_attn = _gemm(out, wp, bp, residual=x2, n=D, out_dtype=torch.float32)
     score = dst_pos = merge_w = info = None
     if prune and k is None:
         score, thr, count, kk = hip.token_score_sync(side, token_attn, temperature, B, H, N)
@@ -408,16 +500,21 @@ def _vit_block_fwd(blk, x, token_attn, temperature, k, mask_qk=None, max_keep=0)
     u = _gemm(h2, w1, b1, n=P.fc1.weight.shape[0], out_dtype=torch.float32)
     g = act_fwd(u, P.act)
     return _Saved(k=k, info=info, h1=h1, qkv=qkv, out=out, side=side, x_attn=x_attn, score=score, dst_pos=dst_pos, merge_w=merge_w,
-                  y02=y02, h2=h2, u=u, g=g)
+                  y02=y02, h2=h2, u=u, g=g, drop=drop)
 
 
 def vit_block_forward_saved(blk, x, token_attn, temperature, max_keep=0, mask_qk=None):
     """-> (y [B,N',D], info, saved): Block.forward for training, see _save_forward()."""
     P = _BlockParts(blk)
     B, _, D = x.shape
-    s = _vit_block_fwd(blk, x, token_attn, temperature, None, mask_qk=mask_qk, max_keep=max_keep)
+    drop = _block_drop(blk)
+    s = _vit_block_fwd(blk, x, token_attn, temperature, None, mask_qk=mask_qk, max_keep=max_keep, drop=drop)
     w2, b2 = _f32_lin(P.fc2)
-    y = _gemm(s.g, w2, b2, residual=s.y02, n=D, out_dtype=torch.float32)
+    if drop is not None:  # x + drop_path(mlp(norm2(x))), vit.py:205
+        y = dropout(_gemm(s.g, w2, b2, n=D, out_dtype=torch.float32), drop[0], drop[1], _site(drop[2], 1), residual=s.y02,
+                    per_sample=(s.y02.shape[0] // B) * D)
+    else:
+        y = _gemm(s.g, w2, b2, residual=s.y02, n=D, out_dtype=torch.float32)
     return y.view(B, -1, D), s.info, s
 
 
@@ -440,9 +537,11 @@ def vit_block_backward(blk, x, token_attn, temperature, k, dy, mask_qk=None, dp_
     N2 = M2 // B
     # ---- backward ----
     grads = {}
+    drop = getattr(s, "drop", None)
     dy2 = dy.reshape(M2, D).contiguous().float()
-    dg = dgrad(dy2, P.fc2.weight.detach())               # y = y0 + g W2^T + b2
-    grads[nm["fc2"] + ".weight"], grads[nm["fc2"] + ".bias"] = wgrad(dy2, g, bias=True)
+    dyb = dropout(dy2, drop[0], drop[1], _site(drop[2], 1), per_sample=N2 * D) if drop is not None else dy2  # the MLP branch's share
+    dg = dgrad(dyb, P.fc2.weight.detach())               # y = y0 + drop_path(g W2^T + b2)
+    grads[nm["fc2"] + ".weight"], grads[nm["fc2"] + ".bias"] = wgrad(dyb, g, bias=True)
     du = act_bwd(u, dg, P.act)
     dh2 = dgrad(du, P.fc1.weight.detach())
     grads[nm["fc1"] + ".weight"], grads[nm["fc1"] + ".bias"] = wgrad(du, h2, bias=True)
@@ -455,8 +554,9 @@ def vit_block_backward(blk, x, token_attn, temperature, k, dy, mask_qk=None, dp_
         dxa2 = dx_attn.view(M, D)
     else:
         dxa2 = dy0
-    dout = dgrad(dxa2, P.proj.weight.detach())          # x_attn = x + out Wp^T + bp
-    grads[nm["proj"] + ".weight"], grads[nm["proj"] + ".bias"] = wgrad(dxa2, out, bias=True)
+    dpb = dropout(dxa2.contiguous(), drop[0], drop[1], _site(drop[2], 0), per_sample=N * D) if drop is not None else dxa2
+    dout = dgrad(dpb, P.proj.weight.detach())           # x_attn = x + drop_path(out Wp^T + bp)
+    grads[nm["proj"] + ".weight"], grads[nm["proj"] + ".bias"] = wgrad(dpb, out, bias=True)
     dqkv = attention_bwd(qkv, dout, out, B, H, N, scale, dnrm, da, dp0, mask_qk=mask_qk, dp_out=dp_out)
     dh1 = dgrad(dqkv, P.qkv_w.detach())
     if P.qkv_b is not None:
@@ -475,9 +575,10 @@ class VitBlockFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, blk, temperature, max_keep, x, token_attn, *params):
         ctx.mode = _mode()
+        _note_versions(ctx, params)
         prune = temperature > 0
         ctx.saved = None
-        if _save_forward():
+        if _save_forward() or (blk.training and float(getattr(blk, "drop_path_rate", 0.0) or 0.0) > 0.0):  # (DropPath: the kept forward only)
             if getattr(blk, "attn_mask", None) is not None and getattr(blk, "_mask_dev", None) is None:
                 blk._weights()  # (creates the device copy of CLIP's text attention mask)
             mask = getattr(blk, "_mask_dev", None) if getattr(blk, "attn_mask", None) is not None else None
@@ -495,6 +596,7 @@ class VitBlockFunction(torch.autograd.Function):
     def backward(ctx, dy):
         x, ta = ctx.saved_tensors
         ta = ta if ctx.has_ta else None
+        _check_versions(ctx, _BlockParts(ctx.blk).params(), "Block backward")
         mask = getattr(ctx.blk, "_mask_dev", None) if getattr(ctx.blk, "attn_mask", None) is not None else None
         # (the full [ctx, ctx] mask: the kernels read its leading [N, N] corner through the row stride, clip/mock.py:309-310)
         dp_out = None
@@ -517,6 +619,7 @@ class VitBlockFunction(torch.autograd.Function):
 def block_forward_with_grad(blk, x, temperature, token_attn, max_keep=0):
     """Block.forward under autograd (called by madtp_amd.vit.Block.forward when gradients are required)."""
     _check_mode("the block backward")
+    _warn_implicit(x.requires_grad or (token_attn is not None and token_attn.requires_grad))
     if token_attn is not None and not token_attn.is_contiguous():
         token_attn = token_attn.contiguous()
     return VitBlockFunction.apply(blk, temperature, max_keep, x, token_attn, *_BlockParts(blk).params())
@@ -562,21 +665,25 @@ def _med_params_of(layer, cross):
     return [mods[n] for n in _layer_param_names(layer, cross)]
 
 
-def _cross_branch_fwd(sm, y02, enc2, B, H, L2, Nk, scale, key_mask):
-    """One cross-attention branch (BertSelfAttention with encoder_hidden_states): -> (cq, ckv, cctx, wckv)."""
+def _cross_branch_fwd(sm, y02, enc2, B, H, L2, Nk, scale, key_mask, drop=None):
+    """One cross-attention branch (BertSelfAttention with encoder_hidden_states): -> (cq, ckv, cctx, wckv).  drop: (p, seed, site) of
+    the attention_probs dropout or None."""
     D = H * 64
     wcq, bcq = _f32_lin(sm.query)
     wckv, bckv = _cat_wb("ckv", [sm.key, sm.value])  # [2D, Denc]
     cq = _gemm(y02, wcq, bcq, n=D, out_dtype=torch.float32)
     ckv = _gemm(enc2, wckv, bckv, n=2 * D, out_dtype=torch.float32)
-    cctx, _ = _attention(cq, ckv[:, :D], ckv[:, D:], B, H, L2, Nk, scale, add_mask=key_mask)
+    if drop is not None:
+        cctx, _ = attention_train(cq, ckv[:, :D], ckv[:, D:], B, H, L2, Nk, scale, drop, key_mask=key_mask)
+    else:
+        cctx, _ = _attention(cq, ckv[:, :D], ckv[:, D:], B, H, L2, Nk, scale, add_mask=key_mask)
     return cq, ckv, cctx, wckv
 
 
-def _cross_branch_bwd(prefix, sm, grads, dcctx, cq, ckv, wckv, y02, enc2, B, H, L2, Nk, scale, key_mask, dy0_acc):
+def _cross_branch_bwd(prefix, sm, grads, dcctx, cq, ckv, wckv, y02, enc2, B, H, L2, Nk, scale, key_mask, dy0_acc, drop=None):
     """Backward of one cross-attention branch; -> (dy0_acc + its contribution to the layer tokens, d encoder tokens [B*Nk, Denc])."""
     D = H * 64
-    dcq, dckv = attention_bwd_cross(cq, ckv, dcctx, B, H, L2, Nk, scale, key_mask=key_mask)
+    dcq, dckv = attention_bwd_cross(cq, ckv, dcctx, B, H, L2, Nk, scale, key_mask=key_mask, drop=drop)
     dy0 = dgrad(dcq, sm.query.weight.detach(), residual=dy0_acc)
     grads[prefix + "query.weight"], grads[prefix + "query.bias"] = wgrad(dcq, y02, bias=True)
     denc = dgrad(dckv, wckv)
@@ -587,7 +694,7 @@ def _cross_branch_bwd(prefix, sm, grads, dcctx, cq, ckv, wckv, y02, enc2, B, H, 
     return dy0, denc
 
 
-def _med_layer_fwd(layer, hidden, mask2d, token_attn, temperature, k, enc=None, enc_masks=None, causal=None):
+def _med_layer_fwd(layer, hidden, mask2d, token_attn, temperature, k, enc=None, enc_masks=None, causal=None, drop=None):
     """BertLayer.forward (MED / NLVR) from single kernels, keeping every intermediate the backward reads.  k: the forward's pruning
     decision (recompute), or None: decide it here (k = max_b count on the host, med.py:374-375; kept unless k < 1 or fewer than two
     tokens would go - madtp_bert_layer's rule)."""
@@ -603,9 +710,21 @@ def _med_layer_fwd(layer, hidden, mask2d, token_attn, temperature, k, enc=None, 
     wout, bout = _f32_lin(layer.output.dense)
     qkv = _gemm(h2, wqkv, bqkv, n=3 * D, out_dtype=torch.float32)
     prune = temperature > 0 if k is None else k > 0
-    ctx, side = _attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, L, L, scale, add_mask=mask2d, scores=prune,
-                           mask_qk=causal)   # causal [L,L]: the decoder's mask (med.py:752-786), never together with pruning
-    a0 = _gemm(ctx, wo, bo, residual=h2, n=D, out_dtype=torch.float32)
+    # drop = (p_hidden, p_attn, seed, base): the layer's dropouts in .train() mode (med.py:55,111,244,323); sites: 0 self-attention
+    # probabilities, 1 self-output, 2 / 3 cross-attention probabilities (branch 0 / 1), 4 cross-output, 5 FFN output
+    ph, pa = (drop[0], drop[1]) if drop is not None else (0.0, 0.0)
+    adrop = (lambda code: (pa, drop[2], _site(drop[3], code))) if pa > 0.0 else (lambda code: None)
+    hdrop = (lambda t, res, code: dropout(t, ph, drop[2], _site(drop[3], code), residual=res))
+    if pa > 0.0:
+        ctx, side = attention_train(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, L, L, scale, adrop(0), key_mask=mask2d, mask_qk=causal,
+                                    scores=prune)
+    else:
+        ctx, side = _attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, L, L, scale, add_mask=mask2d, scores=prune,
+                               mask_qk=causal)   # causal [L,L]: the decoder's mask (med.py:752-786), never together with pruning
+    if ph > 0.0:
+        a0 = hdrop(_gemm(ctx, wo, bo, n=D, out_dtype=torch.float32), h2, 1)   # LayerNorm(dropout(dense(ctx)) + input), med.py:246-250
+    else:
+        a0 = _gemm(ctx, wo, bo, residual=h2, n=D, out_dtype=torch.float32)
     ao, _ = hip.layernorm(a0, so.LayerNorm.weight.detach(), so.LayerNorm.bias.detach(), so.LayerNorm.eps)
     score = dst_pos = merge_w = info = mask_out = None
     if prune and k is None:
@@ -637,7 +756,7 @@ def _med_layer_fwd(layer, hidden, mask2d, token_attn, temperature, k, enc=None, 
         ems = list(enc_masks) if (twin and enc_masks is not None) else [None] * len(encs)
         Nk, De = encs[0].shape[1], encs[0].shape[2]
         enc2s = [e.reshape(B * Nk, De).contiguous().float() for e in encs]
-        br = [_cross_branch_fwd(sm, y02, e2, B, H, L2, Nk, scale, em) for sm, e2, em in zip(sms, enc2s, ems)]
+        br = [_cross_branch_fwd(sm, y02, e2, B, H, L2, Nk, scale, em, drop=adrop(2 + i)) for i, (sm, e2, em) in enumerate(zip(sms, enc2s, ems))]
         if twin:
             w0, b0 = _f32_lin(co.dense0)
             w1, b1 = _f32_lin(co.dense1)
@@ -646,26 +765,29 @@ def _med_layer_fwd(layer, hidden, mask2d, token_attn, temperature, k, enc=None, 
             if co.merge:
                 d01 = torch.cat([d0, d1], 1).contiguous()  # (a copy: the operand layout of merge_layer)
                 wm, bm = _f32_lin(co.merge_layer)
-                c0 = _gemm(d01, wm, bm, residual=y02, n=D, out_dtype=torch.float32)
+                c0 = (hdrop(_gemm(d01, wm, bm, n=D, out_dtype=torch.float32), y02, 4) if ph > 0.0   # nlvr_encoder.py:259-271
+                      else _gemm(d01, wm, bm, residual=y02, n=D, out_dtype=torch.float32))
             else:
-                c0 = (d0 + d1) * 0.5 + y02
+                c0 = hdrop(((d0 + d1) * 0.5).contiguous(), y02, 4) if ph > 0.0 else (d0 + d1) * 0.5 + y02
         else:
             wcd, bcd = _f32_lin(co.dense)
-            c0 = _gemm(br[0][2], wcd, bcd, residual=y02, n=D, out_dtype=torch.float32)
+            c0 = (hdrop(_gemm(br[0][2], wcd, bcd, n=D, out_dtype=torch.float32), y02, 4) if ph > 0.0
+                  else _gemm(br[0][2], wcd, bcd, residual=y02, n=D, out_dtype=torch.float32))
         x2, _ = hip.layernorm(c0, co.LayerNorm.weight.detach(), co.LayerNorm.bias.detach(), co.LayerNorm.eps)
     else:
         x2 = y02
     F = layer.intermediate.dense.weight.shape[0]
     u = _gemm(x2, wi, bi, n=F, out_dtype=torch.float32)
     gl = act_fwd(u, hip.ACT_GELU)
-    f0 = _gemm(gl, wout, bout, residual=x2, n=D, out_dtype=torch.float32)
-    return _Saved(k=k, info=info, mask_out=mask_out, wqkv=wqkv, qkv=qkv, ctx=ctx, side=side, a0=a0, ao=ao, score=score, dst_pos=dst_pos,
+    f0 = (hdrop(_gemm(gl, wout, bout, n=D, out_dtype=torch.float32), x2, 5) if ph > 0.0                # med.py:326-328
+          else _gemm(gl, wout, bout, residual=x2, n=D, out_dtype=torch.float32))
+    return _Saved(drop=drop, k=k, info=info, mask_out=mask_out, wqkv=wqkv, qkv=qkv, ctx=ctx, side=side, a0=a0, ao=ao, score=score, dst_pos=dst_pos,
                   merge_w=merge_w, y02=y02, br=br, enc2s=enc2s, sms=sms, ems=ems, Nk=Nk, De=De, c0=c0, d01=d01, x2=x2, u=u, gl=gl, f0=f0)
 
 
 def med_layer_forward_saved(layer, hidden, mask2d, token_attn, temperature, enc=None, enc_masks=None, causal=None):
     """-> (y [B,L',D], mask_out or None, info, saved): BertLayer.forward for training, see _save_forward()."""
-    s = _med_layer_fwd(layer, hidden, mask2d, token_attn, temperature, None, enc, enc_masks, causal)
+    s = _med_layer_fwd(layer, hidden, mask2d, token_attn, temperature, None, enc, enc_masks, causal, drop=_layer_drop(layer))
     ln2 = layer.output.LayerNorm
     y, _ = hip.layernorm(s.f0, ln2.weight.detach(), ln2.bias.detach(), ln2.eps)
     return y.view(hidden.shape[0], -1, hidden.shape[2]), s.mask_out, s.info, s
@@ -697,8 +819,14 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
     ln2 = layer.output.LayerNorm
     dy2 = dy.reshape(M2, D).contiguous().float()
     df0, grads["output.LayerNorm.weight"], grads["output.LayerNorm.bias"] = layernorm_bwd(f0, ln2.weight.detach(), dy2, ln2.eps)
-    dgl = dgrad(df0, layer.output.dense.weight.detach())
-    grads["output.dense.weight"], grads["output.dense.bias"] = wgrad(df0, gl, bias=True)
+    # the forward's dropouts (see _med_layer_fwd): the branch behind a hidden dropout receives mask o d / (1 - p), the residual all of d
+    drop = getattr(s, "drop", None)
+    ph, pa = (drop[0], drop[1]) if drop is not None else (0.0, 0.0)
+    hd = (lambda t, code: dropout(t.contiguous(), ph, drop[2], _site(drop[3], code))) if ph > 0.0 else (lambda t, code: t)
+    adrop = (lambda code: (pa, drop[2], _site(drop[3], code))) if pa > 0.0 else (lambda code: None)
+    dfb = hd(df0, 5)
+    dgl = dgrad(dfb, layer.output.dense.weight.detach())
+    grads["output.dense.weight"], grads["output.dense.bias"] = wgrad(dfb, gl, bias=True)
     du = act_bwd(u, dgl, hip.ACT_GELU)
     dx2 = dgrad(du, layer.intermediate.dense.weight.detach(), residual=df0)   # f0 = x2 + ffn(x2)
     grads["intermediate.dense.weight"], grads["intermediate.dense.bias"] = wgrad(du, x2, bias=True)
@@ -707,13 +835,14 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
         P = "crossattention."
         dc0, grads[P + "output.LayerNorm.weight"], grads[P + "output.LayerNorm.bias"] = layernorm_bwd(
             c0, co.LayerNorm.weight.detach(), dx2, co.LayerNorm.eps)          # c0 = y0 + combine(branches)
+        dcb = hd(dc0, 4)
         if twin:
             if co.merge:
-                dd01 = dgrad(dc0, co.merge_layer.weight.detach())             # [M2, 2D]
-                grads[P + "output.merge_layer.weight"], grads[P + "output.merge_layer.bias"] = wgrad(dc0, d01, bias=True)
+                dd01 = dgrad(dcb, co.merge_layer.weight.detach())             # [M2, 2D]
+                grads[P + "output.merge_layer.weight"], grads[P + "output.merge_layer.bias"] = wgrad(dcb, d01, bias=True)
                 dds = [dd01[:, :D].contiguous(), dd01[:, D:].contiguous()]
             else:
-                half = dc0 * 0.5
+                half = dcb * 0.5
                 dds = [half, half]
             dy0, dencs = dc0, []
             for i, (sm, dd) in enumerate(zip(sms, dds)):
@@ -722,14 +851,15 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
                 dcctx = dgrad(dd, dn.weight.detach())
                 grads[P + f"output.dense{i}.weight"], grads[P + f"output.dense{i}.bias"] = wgrad(dd, cctx, bias=True)
                 dy0, de = _cross_branch_bwd(P + f"self{i}.", sm, grads, dcctx, cq, ckv, wckv, y02, enc2s[i], B, H, L2, Nk, scale,
-                                            ems[i], dy0)
+                                            ems[i], dy0, drop=adrop(2 + i))
                 dencs.append(de.view(B, Nk, De))
             denc = dencs
         else:
             cq, ckv, cctx, wckv = br[0]
-            dcctx = dgrad(dc0, co.dense.weight.detach())
-            grads[P + "output.dense.weight"], grads[P + "output.dense.bias"] = wgrad(dc0, cctx, bias=True)
-            dy0, de = _cross_branch_bwd(P + "self.", sms[0], grads, dcctx, cq, ckv, wckv, y02, enc2s[0], B, H, L2, Nk, scale, None, dc0)
+            dcctx = dgrad(dcb, co.dense.weight.detach())
+            grads[P + "output.dense.weight"], grads[P + "output.dense.bias"] = wgrad(dcb, cctx, bias=True)
+            dy0, de = _cross_branch_bwd(P + "self.", sms[0], grads, dcctx, cq, ckv, wckv, y02, enc2s[0], B, H, L2, Nk, scale, None, dc0,
+                                        drop=adrop(2))
             denc = de.view(B, Nk, De)
     else:
         dy0 = dx2
@@ -743,9 +873,10 @@ def med_layer_backward(layer, hidden, mask2d, token_attn, temperature, k, dy, en
     ln1 = so.LayerNorm
     da0, grads["attention.output.LayerNorm.weight"], grads["attention.output.LayerNorm.bias"] = layernorm_bwd(
         a0, ln1.weight.detach(), dao.contiguous(), ln1.eps)
-    dctx = dgrad(da0, so.dense.weight.detach())                               # a0 = hidden + ctx Wo^T + bo
-    grads["attention.output.dense.weight"], grads["attention.output.dense.bias"] = wgrad(da0, ctx, bias=True)
-    dqkv = attention_bwd(qkv, dctx, ctx, B, H, L, scale, dnrm, da, dp0, key_mask=mask2d, mask_qk=causal)
+    dab = hd(da0, 1)
+    dctx = dgrad(dab, so.dense.weight.detach())                               # a0 = hidden + dropout(ctx Wo^T + bo)
+    grads["attention.output.dense.weight"], grads["attention.output.dense.bias"] = wgrad(dab, ctx, bias=True)
+    dqkv = attention_bwd(qkv, dctx, ctx, B, H, L, scale, dnrm, da, dp0, key_mask=mask2d, mask_qk=causal, drop=adrop(0))
     dh = dgrad(dqkv, wqkv, residual=da0)
     gw, gb = wgrad(dqkv, h2, bias=True)
     for i, nm in enumerate(("query", "key", "value")):
@@ -762,6 +893,7 @@ class MedLayerFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, layer, temperature, mask2d, enc_masks, causal, hidden, token_attn, enc0, enc1, *params):
         ctx.mode = _mode()
+        _note_versions(ctx, params)
         prune = temperature > 0
         cross = enc0 is not None
         twin = enc1 is not None
@@ -771,8 +903,8 @@ class MedLayerFunction(torch.autograd.Function):
         em = enc_masks if enc_masks is not None else (None, None)
         ctx.causal = causal
         ctx.saved = None
-        if _save_forward():
-            enc = ([enc0, enc1] if twin else enc0) if cross else None
+        if _save_forward() or (layer.training and (layer.output.dropout.p > 0 or layer.attention.self.dropout.p > 0)):  # (dropout: the
+            enc = ([enc0, enc1] if twin else enc0) if cross else None                                                  # kept forward only)
             y, mask_out, info, ctx.saved = med_layer_forward_saved(layer, hidden, mask2d, token_attn, temperature if prune else 0, enc,
                                                                    em if twin else None, causal)
         else:
@@ -801,6 +933,7 @@ class MedLayerFunction(torch.autograd.Function):
     def backward(ctx, dy, _dmask):
         hidden, ta, mask2d, enc0, enc1 = ctx.saved_tensors
         ta = ta if ctx.has_ta else None
+        _check_versions(ctx, _med_params_of(ctx.layer, ctx.cross), "BertLayer backward")
         enc = ([enc0, enc1] if ctx.twin else enc0) if ctx.cross else None
         with torch.no_grad(), _in_mode(ctx.mode):
             dh, dta, denc, grads = med_layer_backward(ctx.layer, hidden, mask2d if ctx.has_mask else None, ta, ctx.temperature,
@@ -818,6 +951,7 @@ def med_layer_forward_with_grad(layer, hidden, mask2d, temperature, token_attn, 
     'multimodal' (MED: a tensor; NLVR: a list of two, with enc_masks their additive key masks [B,Nk] or None) or None for mode
     'text'; fp32 mode only."""
     _check_mode("the BERT layer backward")
+    _warn_implicit(hidden.requires_grad or (token_attn is not None and token_attn.requires_grad))
     if token_attn is not None and not token_attn.is_contiguous():
         token_attn = token_attn.contiguous()
     twin = isinstance(enc, (list, tuple))
@@ -988,6 +1122,29 @@ class EmbeddingsFunction(torch.autograd.Function):
             dpos[:L] = colsum(de.view(B, L * D)).view(L, D)
             dword = torch.zeros_like(word).index_add_(0, ids.reshape(-1), de)
         return None, dword, dpos, dg, db, None
+
+
+class DropoutFunction(torch.autograd.Function):
+    """y = x o mask / (1 - p) with the counter-based mask of (seed, site) (madtp_dropout); the backward applies the same mask."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, site):
+        ctx.args = (float(p), int(seed), int(site))
+        return dropout(x.contiguous().float(), p, seed, site)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, site = ctx.args
+        return dropout(dy.contiguous().float(), p, seed, site), None, None, None
+
+
+def module_dropout(module, p, x):
+    """nn.Dropout(p) of a mirror module on the HIP path: identity in eval mode / p = 0, else a fresh site of the process-wide counter"""
+    if not module.training or p <= 0.0:
+        return x
+    from .runtime import next_dropout_base
+    seed, base = next_dropout_base()
+    return DropoutFunction.apply(x, p, seed, _site(base, 0))
 
 
 class LinearFunction(torch.autograd.Function):

@@ -81,9 +81,10 @@ class BertEmbeddings(nn.Module):
             raise NotImplementedError("only the encoder use (input_ids, default positions) is on the pruned forward path")
         require_gpu(input_ids, "input_ids")
         if torch.is_grad_enabled() and _autograd_precision() and any(p.requires_grad for p in self.parameters()):
-            from .backward import EmbeddingsFunction  # training use: gradients for the two tables and the LayerNorm
-            return EmbeddingsFunction.apply(input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
-                                            self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+            from .backward import EmbeddingsFunction, module_dropout  # training use: gradients for the two tables and the LayerNorm
+            y = EmbeddingsFunction.apply(input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
+                                         self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+            return module_dropout(self, float(self.dropout.p), y)  # med.py:85 (identity in eval mode)
         cdt = compute_dtype()
         y32, ylp = hip.bert_embed(input_ids.contiguous(), self.word_embeddings.weight, self.position_embeddings.weight,
                                   self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps,

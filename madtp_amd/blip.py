@@ -50,9 +50,6 @@ class BLIP_Decoder(nn.Module):
         attached); train=True -> (loss_lm, loss_fdt) - the decoder is not given space_dict, so sd_txt_ft is None and loss_fdt IS
         loss_lm (:146-147) - train=False -> the decoder's output object.  Gradients need the fp32 precision mode."""
         require_gpu(image, "image")
-        if train:
-            from .runtime import warn_no_dropout
-            warn_no_dropout(self)
         image_embeds, _ = self.visual_encoder(image, space_dict=self.space_dict, temperature=temperature)  # :112
         image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)  # :113
         if isinstance(caption, dict) or hasattr(caption, "input_ids"):

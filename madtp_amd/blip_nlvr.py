@@ -83,13 +83,11 @@ class BLIP_NLVR(nn.Module):
         return loss_ori, loss_fdt
 
     def forward(self, image, text, targets, temperature=0, train=True):
-        """blip_nlvr.py:63-100.  train=True returns (loss_ori, loss_fdt) as the reference does; the dropout / DropPath of the
-        reference's training mode are not built (the mirror modules have none), so this is the reference's training forward with
-        model.eval() semantics - what its gradients are checked against.  Gradients need the fp32 precision mode."""
+        """blip_nlvr.py:63-100.  train=True returns (loss_ori, loss_fdt) as the reference does.  In model.train() mode the BERT layers
+        drop hidden states and attention probabilities (p from the config, 0.1) and the ViT blocks apply DropPath, with counter-based
+        masks (runtime.set_dropout_seed, madtp_amd/backward.py); model.eval() is the deterministic forward the reference-recorded
+        gradient fixtures check.  Gradients need the fp32 (or, opted in, the f16x3) precision mode."""
         require_gpu(image, "image")
-        if train:
-            from .runtime import warn_no_dropout
-            warn_no_dropout(self)
         self.visual_encoder.img_query_model.compute_att_ft = self.compute_sd_ft
         self.text_encoder.encoder.txt_query_model.compute_att_ft = self.compute_sd_ft
         # sd_img_ft only feeds the training loss (:86-96): its (fast-mode) sum over the layers runs on the auxiliary stream,

@@ -96,11 +96,9 @@ class BLIP_VQA(nn.Module):
         """blip_vqa.py:66-115: (loss_vqa, loss_fdt).  answer: {'input_ids', 'attention_mask'} of all answers (n[b] per question, in
         question order; position 0 is set to the BOS id as :72 does), weights: one per answer.  The answer decoder runs
         teacher-forced on the question states repeated n[b] times; loss_fdt is the cosine embedding loss of the l2-normalised
-        dictionary features (:102-113).  Gradients need the fp32 precision mode (madtp_amd/backward.py); the reference's dropout is
-        not built (model.eval() semantics)."""
+        dictionary features (:102-113).  Gradients need the fp32 precision mode (madtp_amd/backward.py); the reference's dropout /
+        DropPath apply in model.train() mode (counter-based masks, runtime.set_dropout_seed)."""
         import torch.nn.functional as F
-        from .runtime import warn_no_dropout
-        warn_no_dropout(self)
         if self.text_decoder is None:
             raise RuntimeError("BLIP_VQA(decoder=False) has no answer decoder to train")
         question_states, _, (sd_img_ft, sd_txt_ft) = self.encode_question(image, question, temperature)

@@ -326,6 +326,51 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict_
     }
 }
 
+// ---- dropout / DropPath (round 5: the training forward's stochastic regularisers, models/med.py:55,111,244,323 nn.Dropout at
+// hidden_dropout_prob / attention_probs_dropout_prob = 0.1, models/vit.py:114,186,205 DropPath) -----------------------------------
+// Counter-based masks: Philox4x32-10 keyed by the caller's 64-bit seed, counter = (element index / 4, site id); element i takes word
+// i & 3 of its counter's output, keep = u >= p with u = (word >> 8) 2^-24.  Nothing is stored: the backward regenerates the mask
+// of a site from (seed, site id).  tests/test_backward_gpu.py restates the generator in numpy.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+struct DropArgs { float p, inv_keep; unsigned long long seed, site; };
+// keep factor (0 or 1 / (1 - p)) of element idx of a site
+__device__ __forceinline__ float drop_factor(const DropArgs& d, unsigned long long idx) {
+    unsigned o[4];
+    const unsigned long long c = idx >> 2;
+    philox4x32_10((unsigned)c, (unsigned)(c >> 32), (unsigned)d.site, (unsigned)(d.site >> 32), (unsigned)d.seed, (unsigned)(d.seed >> 32), o);
+    const float u = (float)(o[idx & 3] >> 8) * (1.0f / 16777216.0f);
+    return u >= d.p ? d.inv_keep : 0.f;
+}
+// y = residual + x * keep / (1 - p); per_sample > 0: one draw per run of per_sample elements (DropPath: a sample's whole branch)
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, const float* __restrict__ residual, float* __restrict__ y,
+                                                      size_t n4, size_t per_sample, DropArgs d) {
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= n4) return;
+    float f[4];
+    if (per_sample) {
+        f[0] = f[1] = f[2] = f[3] = drop_factor(d, (4 * i4) / per_sample);
+    } else {
+        unsigned o[4];
+        philox4x32_10((unsigned)i4, (unsigned)(i4 >> 32), (unsigned)d.site, (unsigned)(d.site >> 32), (unsigned)d.seed, (unsigned)(d.seed >> 32), o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = (float)(o[e] >> 8) * (1.0f / 16777216.0f) >= d.p ? d.inv_keep : 0.f;
+    }
+    const float4 v = ((const float4*)x)[i4];
+    float4 r = make_float4(v.x * f[0], v.y * f[1], v.z * f[2], v.w * f[3]);
+    if (residual) { const float4 a = ((const float4*)residual)[i4]; r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w; }
+    ((float4*)y)[i4] = r;
+}
+
 // ---- attention backward ---------------------------------------------------------------------------------------------
 // q/k/v: rows (b*N + i) of a [B*N, ld] f32 matrix, head h at columns [h*64, h*64+64) of each operand's base pointer.
 struct AttnBwdArgs {
@@ -342,6 +387,7 @@ struct AttnBwdArgs {
     const float* key_mask;               // [B,Nk] additive key mask (BERT padding mask, med.py:197-199) or NULL
     const float* mask_qk; int ld_mqk;    // [N, ld_mqk] additive mask over (query, key) pairs (the decoder's causal mask) or NULL
     float* dp_out;                       // [B,H,N,Nk] or NULL: the gradient of the attention probabilities themselves (Grad-CAM hook)
+    DropArgs drop;                       // attention_probs dropout of the forward (p = 0: none): out = (P o mask / (1 - p)) V
     int Nk; int ldk; int lddk;           // keys per sample, leading dimension of k / v and of dk / dv (cross-attention: the keys
                                          // come from another sequence and projection; self-attention: Nk = N, ldk = ld, lddk = ldd)
 };
@@ -459,6 +505,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdArgs a) {
                 float dp = 0.f, p = 0.f;
                 if (i < NQ && jj < N) {
                     dp = acc[r];
+                    if (a.drop.p > 0.f) dp *= drop_factor(a.drop, ((unsigned long long)bh * NQ + i) * N + jj);  // d P = mask o d(P dropped)
                     p = a.P[((size_t)bh * NQ + i) * N + jj];
                     if (jj >= 1) {
                         if (i == 0) { if (a.dp0) dp += a.dp0[((size_t)b * a.H + h) * N + jj]; }
@@ -532,7 +579,8 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnBwdArgs a) {
             const int ii = it * 16 + 4 * g + s4, i = min(ii, NQ - 1);
             const bool ok = ii < NQ;
             // A operands: P^T / dS^T - row (key) l16, contraction index (query) ii
-            const float pv = ok ? a.P[((size_t)bh * NQ + i) * N + jc] : 0.f;
+            float pv = ok ? a.P[((size_t)bh * NQ + i) * N + jc] : 0.f;
+            if (a.drop.p > 0.f) pv *= drop_factor(a.drop, ((unsigned long long)bh * NQ + i) * N + jc);  // dV = (P dropped)^T dO
             const float sv = ok ? a.dS[((size_t)bh * NQ + i) * N + jc] : 0.f;
             const float* op = a.dout + (size_t)(b * NQ + i) * a.ldo + h * HD + l16;
             const float* qp = a.q + (size_t)(b * NQ + i) * a.ld + h * HD + l16;
@@ -576,6 +624,75 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnBwdArgs a) {
     }
 }
 
+
+// ---- attention of the TRAINING forward with attention_probs dropout (med.py:202-222): P materialised by attn_probs_kernel, then
+// out[b, i, h, :] = sum_j P[bh, i, j] mask_ij / (1 - p) V[b, j, h, :]  - the dS K product of the rows pass with V in K's place - and
+// the pruning score's side outputs from the UNDROPPED P and the dropped out (med.py:227-233: cls_attn from attention_probs, the head
+// importance from attn_out), in the layouts of madtp_attention.
+__global__ __launch_bounds__(256) void attn_pv_kernel(AttnBwdArgs a, float* __restrict__ out, int ldo) {
+    extern __shared__ float sm[];
+    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, i0 = blockIdx.y * 16, NQ = a.N, N = a.Nk, tid = threadIdx.x;
+    const int NS = attn_ns(N);
+    const int lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    float* Ps = sm;              // [16][NS]: P o mask / (1 - p), zero beyond the tile's rows / keys
+    float* red = Ps + 16 * NS;   // [4][16][64]
+    for (int e = tid; e < 16 * NS; e += 256) {
+        const int r = e / NS, j = e - r * NS, i = i0 + r;
+        float v = 0.f;
+        if (i < NQ && j < N) {
+            const unsigned long long idx = ((unsigned long long)bh * NQ + i) * N + j;
+            v = a.P[idx];
+            if (a.drop.p > 0.f) v *= drop_factor(a.drop, idx);
+        }
+        Ps[e] = v;
+    }
+    __syncthreads();
+    af_f32x4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = (af_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int jt = wave; jt * 16 < N; jt += 4) {
+        const float4 pa = *(const float4*)&Ps[l16 * NS + jt * 16 + 4 * g];
+        const float pav[4] = {pa.x, pa.y, pa.z, pa.w};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float* vp = a.v + (size_t)(b * N + min(jt * 16 + 4 * g + s4, N - 1)) * a.ldk + h * HD + l16;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pav[s4], vp[16 * dt], acc[dt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * g + r) * HD + 16 * dt + l16] = acc[dt][r];
+    __syncthreads();
+    const int r = tid >> 4, dq = (tid & 15) * 4;
+    const float4 p0 = *(const float4*)&red[(0 * 16 + r) * HD + dq], p1 = *(const float4*)&red[(1 * 16 + r) * HD + dq],
+                 p2 = *(const float4*)&red[(2 * 16 + r) * HD + dq], p3 = *(const float4*)&red[(3 * 16 + r) * HD + dq];
+    const float4 o = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                                 (p0.w + p1.w) + (p2.w + p3.w));
+    if (i0 + r < NQ) *(float4*)(out + (size_t)(b * NQ + i0 + r) * ldo + h * HD + dq) = o;
+    // onorm[b, h, i] = || out[b, i, h, :] ||: 16 lanes per row
+    float sq = o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+    sq = row16_sum(sq);
+    if (!a.hm) return;  // (no side outputs asked; see the launcher: the onorm pointer travels in a.dq)
+    if ((tid & 15) == 0 && i0 + r < NQ) a.dq[((size_t)b * a.H + h) * NQ + i0 + r] = sqrtf(sq);
+}
+// p0[b, h, j] = P[bh, 0, j];  colsum_part[b, rt, j] = sum over rows i of tile rt, i >= 1, of max_h P[b, h, i, j]  (self-attention)
+__global__ __launch_bounds__(256) void attn_side_kernel(const float* __restrict__ P, float* __restrict__ colsum_part, float* __restrict__ p0,
+                                                        int H, int N) {
+    const int b = blockIdx.x, rt = blockIdx.y, nrt = gridDim.y;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        float s = 0.f;
+        for (int i = max(rt * 16, 1); i < min(rt * 16 + 16, N); ++i) {
+            float m = P[(((size_t)b * H) * N + i) * N + j];
+            for (int h = 1; h < H; ++h) m = fmaxf(m, P[(((size_t)b * H + h) * N + i) * N + j]);
+            s += m;
+        }
+        colsum_part[((size_t)b * nrt + rt) * N + j] = s;
+        if (rt == 0)
+            for (int h = 0; h < H; ++h) p0[((size_t)b * H + h) * N + j] = P[(((size_t)b * H + h) * N) * N + j];
+    }
+}
 
 // ------------------------------------------------------------------------------------------------ att_ft backward
 // Query_model (models/utils.py:170-178):  W[b,k,:] = softmax_n(inner[b,:,k] / sqrt(sd_dim)),  att_ft[b,k,:] = sum_n W[b,k,n] q[b,n,:].
@@ -827,7 +944,7 @@ extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* 
                                    int ld_mqk, const float* dout, int ldo,
                                    const float* out, int ldout, const float* dnrm_scale, const float* da, const float* dp0,
                                    float* dq, float* dk, float* dv, int ldd, void* ws, size_t ws_bytes, float* dp_out, int B, int H,
-                                   int N, float scale, void* stream) {
+                                   int N, float scale, float p_drop, unsigned long long seed, unsigned long long site, void* stream) {
     if (!q || !k || !v || !dout || !dq || !dk || !dv || !ws || B <= 0 || H <= 0 || N <= 0) return MADTP_E_BADARG;
     if (dnrm_scale && !out) return MADTP_E_BADARG;
     if (N > 1024) return MADTP_E_SHAPE;  // the row kernels keep 16 x N score rows in LDS (2 x 64 KiB at N = 1024)
@@ -837,6 +954,8 @@ extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* 
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.dout = dout; a.ldo = ldo; a.out = out; a.ldout = ldout; a.dnrm_scale = dnrm_scale;
     a.da = da; a.dp0 = dp0; a.dq = dq; a.dk = dk; a.dv = dv; a.ldd = ldd; a.B = B; a.H = H; a.N = N; a.scale = scale;
     a.key_mask = key_mask; a.Nk = N; a.ldk = ld; a.lddk = ldd; a.mask_qk = mask_qk; a.ld_mqk = ld_mqk; a.dp_out = dp_out;
+    if (!(p_drop >= 0.f) || !(p_drop < 1.f)) return MADTP_E_BADARG;
+    a.drop = DropArgs{p_drop, 1.0f / (1.0f - p_drop), seed, site};
     const size_t pn = (size_t)B * H * N * N;
     a.P = (float*)ws; a.dS = a.P + pn; a.hm = (unsigned char*)(a.dS + pn);
     hipStream_t s = (hipStream_t)stream;
@@ -862,8 +981,10 @@ extern "C" size_t madtp_attention_bwd_cross_workspace(int B, int H, int Nq, int 
 }
 extern "C" int madtp_attention_bwd_cross(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* key_mask,
                                          const float* dout, int ldo, float* dq, int lddq, float* dk, float* dv, int lddkv, void* ws,
-                                         size_t ws_bytes, int B, int H, int Nq, int Nk, float scale, void* stream) {
+                                         size_t ws_bytes, int B, int H, int Nq, int Nk, float scale, float p_drop,
+                                         unsigned long long seed, unsigned long long site, void* stream) {
     if (!q || !k || !v || !dout || !dq || !dk || !dv || !ws || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
+    if (!(p_drop >= 0.f) || !(p_drop < 1.f)) return MADTP_E_BADARG;
     if (Nq > 1024 || Nk > 1024) return MADTP_E_SHAPE;
     if (ws_bytes < madtp_attention_bwd_cross_workspace(B, H, Nq, Nk)) return MADTP_E_BADARG;
     if (ldq % 4 || ldkv % 4 || lddq % 4 || lddkv % 4 || !aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(dq) ||
@@ -871,6 +992,7 @@ extern "C" int madtp_attention_bwd_cross(const float* q, int ldq, const float* k
     AttnBwdArgs a = {};
     a.q = q; a.k = k; a.v = v; a.ld = ldq; a.ldk = ldkv; a.dout = dout; a.ldo = ldo; a.dq = dq; a.dk = dk; a.dv = dv;
     a.ldd = lddq; a.lddk = lddkv; a.B = B; a.H = H; a.N = Nq; a.Nk = Nk; a.scale = scale; a.key_mask = key_mask;
+    a.drop = DropArgs{p_drop, 1.0f / (1.0f - p_drop), seed, site};
     const size_t pn = (size_t)B * H * Nq * Nk;
     a.P = (float*)ws; a.dS = a.P + pn;
     hipStream_t s = (hipStream_t)stream;
@@ -880,6 +1002,45 @@ extern "C" int madtp_attention_bwd_cross(const float* q, int ldq, const float* k
     hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, (Nq + 15) / 16), dim3(256), lds_p, s, a);
     hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(B * H, (Nq + 15) / 16), dim3(256), lds_r, s, a);
     hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(B * H, (Nk + 15) / 16), dim3(256), 0, s, a);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int madtp_dropout(const float* x, const float* residual, float* y, size_t n, size_t per_sample, float p, unsigned long long seed,
+                             unsigned long long site, void* stream) {
+    if (!x || !y || n == 0 || !(p >= 0.f) || !(p < 1.f)) return MADTP_E_BADARG;
+    if (n % 4 || per_sample % 4) return MADTP_E_SHAPE;
+    if (!aligned16(x) || !aligned16(y) || (residual && !aligned16(residual))) return MADTP_E_ALIGN;
+    const DropArgs d{p, 1.0f / (1.0f - p), seed, site};
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, residual, y, n / 4, per_sample, d);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Attention of the training forward (see attn_pv_kernel): P [B,H,Nq,Nk] f32 is written (the caller's scratch - the backward
+// recomputes it), out [B*Nq, ldo]; side outputs as madtp_attention's (self-attention, Nq == Nk) or NULL.
+extern "C" int madtp_attention_train(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* key_mask,
+                                     const float* mask_qk, int ld_mqk, float* P, float* out, int ldo, float* colsum_part, float* p0,
+                                     float* onorm, int B, int H, int Nq, int Nk, float scale, float p_drop, unsigned long long seed,
+                                     unsigned long long site, void* stream) {
+    if (!q || !k || !v || !P || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || !(p_drop >= 0.f) || !(p_drop < 1.f)) return MADTP_E_BADARG;
+    if (Nq > 1024 || Nk > 1024) return MADTP_E_SHAPE;
+    if (colsum_part && (!p0 || !onorm || Nq != Nk)) return MADTP_E_BADARG;
+    if (ldq % 4 || ldkv % 4 || ldo % 4 || !aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out)) return MADTP_E_ALIGN;
+    AttnBwdArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.ld = ldq; a.ldk = ldkv; a.B = B; a.H = H; a.N = Nq; a.Nk = Nk; a.scale = scale; a.key_mask = key_mask;
+    a.mask_qk = mask_qk; a.ld_mqk = ld_mqk; a.P = P;
+    a.drop = DropArgs{p_drop, 1.0f / (1.0f - p_drop), seed, site};
+    // (attn_pv_kernel's optional output onorm rides in a.dq, switched on by a non-null a.hm)
+    a.dq = onorm; a.hm = colsum_part ? (unsigned char*)P : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    const int nrt = (Nq + 15) / 16;
+    const size_t lds_p = (size_t)(16 * HD + 16 * attn_ns(Nk)) * sizeof(float), lds_v = (size_t)(16 * attn_ns(Nk) + 64 * HD) * sizeof(float);
+    MADTP_ENSURE_MAX_LDS(attn_probs_kernel, lds_p);
+    MADTP_ENSURE_MAX_LDS(attn_pv_kernel, lds_v);
+    hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, nrt), dim3(256), lds_p, s, a);
+    hipLaunchKernelGGL(attn_pv_kernel, dim3(B * H, nrt), dim3(256), lds_v, s, a, out, ldo);
+    if (colsum_part) hipLaunchKernelGGL(attn_side_kernel, dim3(B, nrt), dim3(256), 0, s, P, colsum_part, p0, H, Nq);
     MADTP_LAUNCH_CHECK();
     return 0;
 }

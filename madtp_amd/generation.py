@@ -193,6 +193,10 @@ def sample(step_fn, input_ids, max_length, min_length, eos_token_id, pad_token_i
     dev = input_ids.device
     B, cur_len = input_ids.shape
     unfinished = torch.ones((B,), dtype=torch.int64, device=dev)
+    # no host round trip per step (round 5): the rows' unfinished flags reach the host through asynchronous copies polled without
+    # blocking; steps queued after every row has finished only append pad tokens, which are cut off below
+    flags = torch.ones((max_length + 1, B), dtype=torch.int64).pin_memory()
+    pending, n_steps = [], None
     while True:
         logits = step_fn(input_ids, beam_src=None) if takes_src else step_fn(input_ids)
         suppress = eos_token_id if (min_length is not None and min_length > -1 and cur_len < min_length) else -1
@@ -204,6 +208,19 @@ def sample(step_fn, input_ids, max_length, min_length, eos_token_id, pad_token_i
         input_ids = torch.cat([input_ids, nxt[:, None]], dim=-1)
         cur_len += 1
         unfinished = unfinished * (nxt != eos_token_id).to(torch.int64)
-        if int(unfinished.max()) == 0 or cur_len >= max_length:
+        flags[cur_len].copy_(unfinished, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        pending.append((ev, cur_len))
+        stop = cur_len >= max_length
+        while pending and pending[0][0].query():
+            _, i = pending.pop(0)
+            if n_steps is None and int(flags[i].max()) == 0:
+                n_steps = i
+        if stop or n_steps is not None:
             break
-    return input_ids
+    torch.cuda.synchronize()
+    for _, i in pending:  # the length at which the library's loop stops: the first step after which no row is unfinished
+        if n_steps is None and int(flags[i].max()) == 0:
+            n_steps = i
+    return input_ids[:, :n_steps] if n_steps is not None else input_ids

@@ -120,9 +120,13 @@ _SIGS = {
     "madtp_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
     "madtp_attention_bwd_cross_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "madtp_attention_bwd_cross": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
-                                          c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+                                          c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint64,
+                                          ctypes.c_uint64, c_void_p]),
     "madtp_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 6
-                            + [c_int, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+                            + [c_int, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint64, ctypes.c_uint64, c_void_p]),
+    "madtp_dropout": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, ctypes.c_uint64, ctypes.c_uint64, c_void_p]),
+    "madtp_attention_train": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint64, ctypes.c_uint64, c_void_p]),
 }
 
 

@@ -310,15 +310,35 @@ def as_f32_contig(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ---- dropout / DropPath of the training forward (round 5) ---------------------------------------------------------------------------
+# Active when a module is in .train() mode, its rate is > 0 and the forward takes the autograd route (madtp_amd/backward.py).  Masks are
+# counter-based (csrc/backward.hip: Philox4x32-10 over (seed, site, element)): every layer call draws a fresh `base` from the
+# process-wide counter, its sites are base * 32 + a per-site code; the backward regenerates them.  set_dropout_seed(seed) also resets
+# the counter, so two runs with the same seed and the same sequence of calls drop the same elements.
+_DROP_STATE = {"seed": None, "counter": 0}
+_DROP_LOCK = __import__("threading").Lock()
+
+
+def set_dropout_seed(seed):
+    with _DROP_LOCK:
+        _DROP_STATE["seed"] = int(seed) & 0xFFFFFFFFFFFFFFFF
+        _DROP_STATE["counter"] = 0
+
+
+def next_dropout_base():
+    """-> (seed, base): a fresh site base for one layer call of the training forward"""
+    with _DROP_LOCK:
+        if _DROP_STATE["seed"] is None:
+            _DROP_STATE["seed"] = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        b = _DROP_STATE["counter"]
+        _DROP_STATE["counter"] = b + 1
+        return _DROP_STATE["seed"], b
+
+
 _WARNED_DROPOUT = [False]
 
 
 def warn_no_dropout(module):
-    """The training forwards (BLIP_NLVR / BLIP_VQA / BLIP_Decoder with train=True) run the reference's graph WITHOUT its stochastic
-    regularisers: the mirror modules carry nn.Dropout members for state-dict / constructor compatibility, but the kernels have no
-    dropout and the ViT no DropPath.  In module.train() mode that differs from the reference (which drops with p = 0.1): say so once."""
-    if module.training and not _WARNED_DROPOUT[0]:
-        import warnings
-        _WARNED_DROPOUT[0] = True
-        warnings.warn("madtp_amd: train=True runs without dropout / DropPath (not built); gradients are those of the reference in "
-                      "model.eval() mode", RuntimeWarning, stacklevel=3)
+    """kept for callers of earlier rounds: the training forwards now apply the reference's dropout / DropPath in module.train() mode
+    (madtp_amd/backward.py); nothing to warn about."""
+    return None

@@ -154,7 +154,8 @@ class Block(nn.Module):
         self.norm1 = norm_layer(dim)
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
                               proj_drop=drop)
-        self.drop_path = nn.Identity()  # DropPath is the identity in eval (the only mode this path runs in)
+        self.drop_path = nn.Identity()  # (the fused inference call has no DropPath; the training forward applies drop_path_rate
+        self.drop_path_rate = float(drop_path)  # in .train() mode: madtp_amd/backward.py, vit.py:114,186,205)
         self.norm2 = norm_layer(dim)
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
@@ -296,10 +297,11 @@ class VisionTransformer(nn.Module):
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
         self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]  # stochastic depth decay rule (vit.py:250)
         self.blocks = nn.ModuleList([
             Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
-                  drop=drop_rate, attn_drop=attn_drop_rate, drop_path=0., norm_layer=norm_layer)
-            for _ in range(depth)])
+                  drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer)
+            for i in range(depth)])
         self.norm = norm_layer(embed_dim)
         self.depth = depth
         if not evaluate:

@@ -114,6 +114,23 @@ def test_wgrad_splitk(hip, M, N, K):
     assert float(((plain.double() - ref).abs() / col).max()) < 1e-5  # (one f32 accumulation chain over all of K)
 
 
+def test_backward_refuses_parameters_modified_after_forward(hip):
+    """the hand-written backward pairs the forward's activations with the module's current parameters: an in-place update between
+    forward and backward raises, as native autograd's version check would"""
+    from madtp_amd import runtime, vit
+    blk = vit.Block(768, 12, 4.0, qkv_bias=True).cuda()
+    x = _rand(2, 50, 768, seed=1).cuda().requires_grad_(True)
+    with runtime.precision("fp32"):
+        y = blk(x, temperature=0)
+        with torch.no_grad():
+            blk.mlp.fc1.weight.mul_(1.0)
+        with pytest.raises(RuntimeError, match="modified in place"):
+            y.sum().backward()
+        y = blk(x, temperature=0)
+        y.sum().backward()
+    assert x.grad is not None and blk.mlp.fc1.weight.grad is not None
+
+
 def test_layernorm_bwd(hip):
     from madtp_amd import backward as bw
     rows, dim = 1001, 768
@@ -741,3 +758,226 @@ def test_vit_register_blk_routes_the_hook(hip):
             assert tuple(blk.attn.get_attention_map().shape) == tuple(gA.shape)
         else:
             assert gA is None
+
+
+# ---- dropout / DropPath of the training forward (round 5) -----------------------------------------------------------------------------
+# The reference's compress_*_dtp loops run model.train(): BERT dropout 0.1 on hidden states and attention probabilities
+# (med_config.json:5,7), DropPath in the ViT (vit.py:114,186,205).  The HIP path draws its masks from a counter-based generator
+# (Philox4x32-10, csrc/backward.hip); oracle.dropout_mask restates it (pinned to the published Random123 vectors in
+# tests/test_oracle_golden.py), so the oracle can run the reference's graph WITH the very masks the kernels used and autograd gives
+# the gradients to compare - same fixtures' inputs, same 1e-3 tolerance as the eval-mode tests.
+
+def test_dropout_kernel_equals_philox_restatement(hip):
+    from madtp_amd import backward as bw
+    from oracle import madtp_oracle as O
+    x = _rand(37, 768, seed=1).cuda()
+    res = _rand(37, 768, seed=2).cuda()
+    for p, seed, site in [(0.1, 1234567890123, 5), (0.5, 2 ** 63 + 11, 2 ** 40 + 3), (0.0, 7, 0)]:
+        y = bw.dropout(x, p, seed, site, residual=res)
+        m = O.dropout_mask(seed, site, tuple(x.shape), p)
+        assert torch.equal(y.cpu(), (x.cpu() * m + res.cpu())), (p, seed, site)
+        assert abs(float((m > 0).float().mean()) - (1 - p)) < 0.02
+    xs = _rand(6, 50, 768, seed=3).cuda()
+    y = bw.dropout(xs, 0.4, 99, 17, per_sample=50 * 768)  # DropPath: one draw per sample
+    m = O.dropout_mask(99, 17, (6, 50, 768), 0.4, per_sample=True)
+    assert torch.equal(y.cpu(), xs.cpu() * m) and len(set(m.reshape(-1).tolist())) == 2 and abs(float(m.max()) - 1.0 / 0.6) < 1e-6
+
+
+@pytest.mark.parametrize("mode", TRAIN_MODES)
+def test_block_droppath_matches_oracle_with_the_same_masks(hip, mode):
+    """Block.forward in .train() mode with drop_path = 0.35 (vit.py:186,205) - pruned and unpruned - against autograd through the
+    oracle with the HIP path's masks injected; eval mode and rate 0 are the deterministic block."""
+    from madtp_amd import runtime, vit
+    from oracle import madtp_oracle as O
+    from tests import grad_case
+    g = np.load(GRAD_CASES[0])
+    c = grad_case.build(g)
+    p_drop, seed = 0.35, 71  # (a seed under which each of the four DropPath sites below drops exactly one of the two samples)
+    blk = vit.Block(768, 12, qkv_bias=True, drop_path=p_drop, norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6))
+    blk.load_state_dict({k[len(c["prefix"]):]: v for k, v in c["W"].items() if k.startswith(c["prefix"])}, strict=True)
+    blk = blk.cuda().train()
+    B = c["x"].shape[0]
+    for T, base in ((c["T"], 0), (0, 1)):
+        x = c["x"].cuda().requires_grad_(True)
+        ta = c["token_attn"].cuda().requires_grad_(True) if T > 0 else None
+        for p in blk.parameters():
+            p.grad = None
+        if base == 0:
+            runtime.set_dropout_seed(seed)  # (the counter restarts: this call draws base 0, the next base 1)
+        drop = lambda code, t, base=base: t * O.dropout_mask(seed, base * 32 + code, tuple(t.shape), p_drop, per_sample=True)
+        with _train_mode(mode):
+            y = blk(x, False, 0, T, ta)
+            Gref = torch.from_numpy(np.random.RandomState(3).uniform(-1, 1, size=tuple(y.shape)).astype(np.float32))
+            if T > 0:
+                # the oracle keeps tokens in torch.topk's order, the HIP path in ascending order: every TOKEN gets the same upstream
+                # gradient in both (grad_case.permute_G), outputs are compared token by token
+                ref, yo, oinfo = O.vit_block_grads(c["W"], c["prefix"], c["x"], c["token_attn"], T, Gref, drop=drop)
+                own = blk.last_prune["indices"].cpu().numpy()
+                assert np.array_equal(np.sort(oinfo["indices"].numpy(), 1), np.sort(own, 1)), "kept sets differ"
+                Gm = grad_case.permute_G(Gref, oinfo["indices"].numpy(), own)
+                yo = grad_case.permute_G(yo, oinfo["indices"].numpy(), own)
+            else:
+                Gm = Gref
+            (y * Gm.cuda()).sum().backward()
+        if T > 0:
+            grads = {"x": x.grad, "token_attn": ta.grad}
+        else:
+            Wl = {k: v.clone().requires_grad_(True) for k, v in c["W"].items() if k.startswith(c["prefix"])}
+            xl = c["x"].clone().requires_grad_(True)
+            yo, _ = O.vit_block(Wl, c["prefix"], xl, 0, None, drop=drop)
+            (yo * Gm).sum().backward()
+            ref = {"x": xl.grad}
+            ref.update({k[len(c["prefix"]):]: v.grad for k, v in Wl.items()})
+            grads = {"x": x.grad}
+        grads.update({k: p.grad for k, p in blk.named_parameters()})
+        assert _rel(y.detach().cpu(), yo.detach()) < 1e-4
+        for name, r in ref.items():
+            assert _rel(grads[name].cpu(), r) < 1e-3, (T, name)
+        for code in (0, 1):
+            assert int((O.dropout_mask(seed, base * 32 + code, (B, 1, 1), p_drop, per_sample=True) == 0).sum()) == 1, "one sample's branch dropped"
+    blk.eval()
+    with _train_mode(mode), torch.no_grad():
+        y_eval = blk(c["x"].cuda(), False, 0, 0, None)
+    blk.train()
+    blk.drop_path_rate = 0.0
+    with _train_mode(mode):
+        y_p0 = blk(c["x"].cuda().requires_grad_(True), False, 0, 0, None)
+    assert _rel(y_p0.detach().cpu(), y_eval.cpu()) < 1e-5
+
+
+class _LayerDropHook:
+    """oracle.bert_layer's `drop` callable carrying the HIP path's masks: site code -> mask of (seed, base * 32 + code).  The masks are
+    drawn over the tensors' elements in memory order; behind the pruning step the HIP path keeps the tokens in ascending order, the
+    oracle in torch.topk's - there the mask rows are re-ordered so that every TOKEN is dropped as on the HIP path."""
+
+    def __init__(self, O, seed, base, ph, pa, own_indices):
+        self.O, self.seed, self.base, self.ph, self.pa, self.own, self.ref = O, seed, base, ph, pa, own_indices, None
+
+    def on_prune(self, info):
+        self.ref = info["indices"].numpy() if (info is not None and info.get("indices") is not None) else None
+
+    def __call__(self, code, t):
+        from tests import grad_case
+        p = self.pa if code in (0, 2, 3) else self.ph
+        if p <= 0:
+            return t
+        m = self.O.dropout_mask(self.seed, self.base * 32 + code, tuple(t.shape), p)
+        if code >= 2 and self.ref is not None and self.own is not None:
+            if m.dim() == 4:  # attention probabilities [B,H,Lq,Nk]: the query rows
+                m = grad_case.permute_G(m.permute(0, 2, 1, 3).contiguous(), self.own, self.ref).permute(0, 2, 1, 3)
+            else:
+                m = grad_case.permute_G(m, self.own, self.ref)
+        return t * m
+
+
+def _layer_drop_hook(O, seed, base, ph, pa, layer=None):
+    info = getattr(layer, "last_prune", None) if layer is not None else None
+    own = info["indices"].cpu().numpy() if (info is not None and info.get("pruned")) else None
+    return _LayerDropHook(O, seed, base, ph, pa, own)
+
+
+@pytest.mark.parametrize("mode", TRAIN_MODES)
+@pytest.mark.parametrize("path", MEDGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in MEDGRAD_CASES])
+def test_med_layer_dropout_matches_oracle_with_the_same_masks(hip, path, mode):
+    """The MED BertLayer in .train() mode - hidden dropout 0.1 on the self-output, cross-output and FFN output, attention_probs
+    dropout 0.1 in self- and cross-attention (med.py:212,248,327) - against autograd through the oracle with the same masks."""
+    from madtp_amd import runtime
+    from oracle import madtp_oracle as O
+    from tests import grad_case
+    g = np.load(path)
+    c = grad_case.build_med(g)
+    layer = grad_case.build_med_layer(c).train()
+    ph, pa, seed = float(layer.output.dropout.p), float(layer.attention.self.dropout.p), 77123
+    assert ph == 0.1 and pa == 0.1
+    hidden = c["hidden"].cuda().requires_grad_(True)
+    ta = c["token_attn"].cuda().requires_grad_(True)
+    mask = c["add_mask"].cuda()
+    gv, hv = c["g"].cuda(), c["h"].cuda()
+    enc = c["enc"].cuda().requires_grad_(True) if c["enc"] is not None else None
+    enc_mask = torch.zeros(enc.shape[0], 1, 1, enc.shape[1], device="cuda") if enc is not None else None
+    runtime.set_dropout_seed(seed)
+    with _train_mode(mode):
+        out = layer(hidden, mask, None, enc, enc_mask, None, False, mode=c["mode"], token_attn=ta, reduce_num=0, temperature=c["T"])
+        y = out[0]
+        O.vit_loss(y, gv, hv).backward()
+    grads = {"hidden": hidden.grad, "token_attn": ta.grad}
+    if enc is not None:
+        grads["enc"] = enc.grad
+    grads.update({k: p.grad for k, p in layer.named_parameters() if p.grad is not None})
+    ref, yo, _, oinfo = O.bert_layer_grads(c["W"], c["prefix"], c["hidden"], c["add_mask"], c["T"], c["token_attn"], c["g"], c["h"],
+                                           layer_num=c["layer"], enc=c["enc"], drop=_layer_drop_hook(O, seed, 0, ph, pa, layer))
+    assert tuple(y.shape) == tuple(yo.shape)
+    assert abs(float(y.detach().double().norm()) - float(yo.double().norm())) < 1e-4 * float(yo.double().norm())
+    with torch.no_grad():
+        y_eval = O.bert_layer(c["W"], c["prefix"], c["hidden"], c["add_mask"], c["T"], c["token_attn"], c["enc"], None,
+                              "multimodal" if c["enc"] is not None else "text", c["layer"], "med")[0]
+    assert tuple(y_eval.shape) != tuple(yo.shape) or float((y_eval - yo).abs().max()) > 1e-2, "dropout changed the output"
+    assert _rel(y.detach().cpu().sum(1), yo.sum(1)) < 1e-4  # (the two paths order the kept tokens differently: compare over tokens)
+    for name, r in ref.items():
+        scale = ref[name[:-8] + "query.bias"] if name.endswith("key.bias") else r
+        e = float((grads[name].cpu() - r).abs().max()) / max(float(scale.abs().max()), 1e-12)
+        assert e < 1e-3, f"grad {name}: {e:.3e} of its maximum"
+    # a second forward draws new masks; the same seed reproduces the first
+    with _train_mode(mode), torch.no_grad():
+        torch.set_grad_enabled(True)
+        y2 = layer(hidden.detach().requires_grad_(True), mask, None, enc, enc_mask, None, False, mode=c["mode"], token_attn=ta.detach(), reduce_num=0, temperature=c["T"])[0]
+        runtime.set_dropout_seed(seed)
+        y3 = layer(hidden.detach().requires_grad_(True), mask, None, enc, enc_mask, None, False, mode=c["mode"], token_attn=ta.detach(), reduce_num=0, temperature=c["T"])[0]
+    assert not torch.equal(y2.detach(), y.detach()) and torch.equal(y3.detach(), y.detach())
+
+
+@pytest.mark.parametrize("mode", TRAIN_MODES)
+@pytest.mark.parametrize("path", NLVRGRAD_CASES, ids=[os.path.basename(c)[:-4] for c in NLVRGRAD_CASES])
+def test_nlvr_layer_dropout_matches_oracle_with_the_same_masks(hip, path, mode):
+    """The NLVR BertLayer (twin cross-attention, averaged or merged; nlvr_encoder.py:211,259-271,380) in .train() mode against
+    autograd through the oracle with the same masks."""
+    from madtp_amd import runtime
+    from oracle import madtp_oracle as O
+    from tests import grad_case
+    g = np.load(path)
+    c = grad_case.build_nlvr(g)
+    layer = grad_case.build_nlvr_layer(c).train()
+    ph, pa, seed = float(layer.output.dropout.p), float(layer.attention.self.dropout.p), 4242
+    hidden = c["hidden"].cuda().requires_grad_(True)
+    ta = c["token_attn"].cuda().requires_grad_(True)
+    mask = c["add_mask"].cuda()
+    enc = [e.cuda().requires_grad_(True) for e in c["enc"]]
+    enc_mask = [m.cuda() for m in c["enc_mask"]]
+    gv, hv = c["g"].cuda(), c["h"].cuda()
+    runtime.set_dropout_seed(seed)
+    with _train_mode(mode):
+        y = layer(hidden, mask, None, None, enc, enc_mask, None, False, mode="multimodal", token_attn=ta, reduce_num=0,
+                  temperature=c["T"])[0]
+        O.vit_loss(y, gv, hv).backward()
+    grads = {"hidden": hidden.grad, "token_attn": ta.grad, "enc0": enc[0].grad, "enc1": enc[1].grad}
+    grads.update({k: p.grad for k, p in layer.named_parameters() if p.grad is not None})
+    ref, yo, _, _ = O.bert_layer_grads(c["W"], c["prefix"], c["hidden"], c["add_mask"], c["T"], c["token_attn"], c["g"], c["h"],
+                                       layer_num=c["layer"], variant="nlvr", enc=c["enc"], enc_mask=c["enc_mask"],
+                                       drop=_layer_drop_hook(O, seed, 0, ph, pa, layer))
+    assert abs(float(y.detach().double().norm()) - float(yo.double().norm())) < 1e-4 * float(yo.double().norm())
+    for name, r in ref.items():
+        scale = ref[name[:-8] + "query.bias"] if name.endswith("key.bias") else r
+        e = float((grads[name].cpu() - r).abs().max()) / max(float(scale.abs().max()), 1e-12)
+        assert e < 1e-3, f"grad {name}: {e:.3e} of its maximum"
+
+
+def test_nlvr_model_train_mode_runs_with_dropout(hip):
+    """BLIP_NLVR.forward(train=True) in model.train(): the losses are finite, depend on the dropout seed, repeat for the same seed,
+    every parameter gets a gradient; model.eval() is the deterministic forward of the fixtures."""
+    from madtp_amd import harness, runtime
+    model = harness.build_nlvr(224, 0, "cuda")
+    images, text, _ = harness.nlvr_inputs(2, 224, 20, 0, "cuda")
+    targets = torch.tensor([0, 1]).cuda()
+    T = 8.612223847001898
+    losses = {}
+    for tag, train, seed in (("eval", False, 1), ("a", True, 1), ("a2", True, 1), ("b", True, 2)):
+        model.train(train)
+        model.zero_grad(set_to_none=True)
+        runtime.set_dropout_seed(seed)
+        with runtime.precision("fp32"):
+            lo, lf = model(images, text, targets, temperature=T, train=True)
+            (lo + 0.1 * lf).backward()
+        losses[tag] = (float(lo.detach()), float(lf.detach()))
+        assert all(np.isfinite(v) for v in losses[tag])
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.requires_grad)
+    assert losses["a"] == losses["a2"] and losses["a"] != losses["b"] and losses["a"] != losses["eval"]

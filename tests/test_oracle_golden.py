@@ -853,3 +853,39 @@ def test_oracle_nucleus_filter_matches_transformers_warpers():
     draws = torch.stack([O.sample_step(x, torch.zeros(1, 1, dtype=torch.long), torch.tensor([float(u)]), 0.9) for u in us[::40]]).flatten()
     freq = torch.bincount(draws, minlength=64).double() / draws.numel()
     assert (freq - w.double()).abs().max().item() < 5e-3 and set(torch.nonzero(freq).flatten().tolist()) <= set(torch.nonzero(w).flatten().tolist())
+
+
+def test_oracle_philox_matches_random123_known_answers():
+    """oracle.philox_uniform (the restatement of csrc/backward.hip's dropout mask generator) against the published Philox4x32-10
+    known-answer vectors of Random123 (kat_vectors: counter / key all zero, all ones, and the digits of pi)."""
+    import numpy as np
+
+    def words(ctr, key):
+        # the restatement's counter is (index lo, index hi, site lo, site hi), its key the seed
+        idx, site, seed = ctr[0] | (ctr[1] << 32), ctr[2] | (ctr[3] << 32), key[0] | (key[1] << 32)
+        n = 4 * (idx + 1) if idx < 1000 else None
+        if n is not None:
+            u = O.philox_uniform(seed, site, n)[-4:]
+            return [int(round(float(v) * 16777216.0)) for v in u]
+        return None
+    assert words((0, 0, 0, 0), (0, 0)) == [x >> 8 for x in (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)]
+    # counters with a large index: evaluate the generator's words directly through the same arithmetic on one index
+    import oracle.madtp_oracle as M
+    def raw(ctr, key):
+        m = np.uint64(0xFFFFFFFF)
+        c0, c1, c2, c3 = (np.array([v], dtype=np.uint64) for v in ctr)
+        k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+        for _ in range(10):
+            p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+            c0, c1, c2, c3 = (p1 >> np.uint64(32)) ^ c1 ^ k0, p1 & m, (p0 >> np.uint64(32)) ^ c3 ^ k1, p0 & m
+            k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m, (k1 + np.uint64(0xBB67AE85)) & m
+        return [int(c0[0]), int(c1[0]), int(c2[0]), int(c3[0])]
+    assert raw((0xffffffff,) * 4, (0xffffffff,) * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert raw((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # and the restatement agrees with that arithmetic at an arbitrary (seed, site, index)
+    seed, site, i = 0x299f31d0a4093822, 0x0370734413198a2e, 12345
+    u = O.philox_uniform(seed, site, 4 * (i + 1))[-4:]
+    w = raw((i & 0xffffffff, i >> 32, site & 0xffffffff, site >> 32), (seed & 0xffffffff, seed >> 32))
+    assert [int(round(float(v) * 16777216.0)) for v in u] == [x >> 8 for x in w]
+    m = O.dropout_mask(5, 3, (4, 1000), 0.1)
+    assert len(set(m.reshape(-1).tolist())) == 2 and abs(float(m.max()) - 1.0 / 0.9) < 1e-6 and abs(float((m > 0).float().mean()) - 0.9) < 0.02
