@@ -508,6 +508,10 @@ int madtp_bert_encoder_async(const madtp_bert_layer_w* const* layers, int n_laye
 int madtp_bert_decode_step(const madtp_bert_layer_w* const* layers, int n_layers, const float* x, void* kv_cache, int rows, int t,
                            int Lmax, const void* const* kv_pre, const int32_t* kv_index, int kv_ld, int Nk, int group, float* y,
                            void* ws, size_t ws_bytes, void* stream);
+/* _reorder_cache (models/med.py:1091-1094) for that cache: dst[l, r, 0..t) = src[l, beam_src[r], 0..t) for the t positions filled so
+ * far; src / dst: two [n_layers][rows][Lmax][row_bytes] buffers (src != dst), beam_src int64 [rows]; row_bytes % 16 == 0. */
+int madtp_kv_cache_reorder(const void* src, void* dst, const int64_t* beam_src, int n_layers, int rows, int Lmax, int t, int row_bytes,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Answer ranking with the teacher-forced decoder (inference half): models/med.py BertLMHeadModel

@@ -1068,8 +1068,10 @@ class BertLMHeadModel(nn.Module):
             D = emb.word_embeddings.weight.shape[1]
             if state["cache"] is None:
                 state["cache"] = torch.zeros((len(layers), rows, max_length, 2 * D), device=dev, dtype=attn_dtype())
-            elif beam_src is not None:
-                state["cache"] = state["cache"].index_select(1, beam_src)  # _reorder_cache (:1091-1094)
+                state["spare"] = torch.zeros_like(state["cache"])
+            elif beam_src is not None:  # _reorder_cache (:1091-1094): the filled positions of the source rows into the other buffer
+                hip.kv_cache_reorder(state["cache"], state["spare"], beam_src, state["t"])
+                state["cache"], state["spare"] = state["spare"], state["cache"]
             ws = enc._encoder_weights()
             y = None
             while state["t"] < ids.shape[1]:  # the prompt on the first call, one token afterwards

@@ -575,8 +575,10 @@ extern "C" int madtp_bert_decode_step(const madtp_bert_layer_w* const* layers, i
         if (!ok) return MADTP_E_SHAPE;
         const int D = w->dim, dt = w->dtype, adt = attn_dt(dt);
         const size_t e = esz_of(adt);
+        // the compute-dtype copy of the layer input: layer 0 casts x; every later layer finds it in s.hc, where the layer before
+        // left it with its last kernel (the output LayerNorm emits it - same carve, same offset, nothing in between writes there)
         const void* hc = h;
-        if (dt != MADTP_F32) { TRY(to_lp(h, D, s.hc, rows, D, dt, stream)); hc = s.hc; }
+        if (dt != MADTP_F32) { if (l == 0) TRY(to_lp(h, D, s.hc, rows, D, dt, stream)); hc = s.hc; }
         TRY(lin(hc, D, w->qkv, nullptr, 0, s.qkv, 3 * D, rows, dt, adt, MADTP_ACT_NONE, 1.f, stream));
         char* cache_l = (char*)kv_cache + (size_t)l * rows * Lmax * 2 * D * e;
         hipError_t he = hipMemcpy2DAsync(cache_l + (size_t)t * 2 * D * e, (size_t)Lmax * 2 * D * e, (const char*)s.qkv + (size_t)D * e,
@@ -595,9 +597,32 @@ extern "C" int madtp_bert_decode_step(const madtp_bert_layer_w* const* layers, i
         // runs them as ONE sequence of `group` query rows (its row-wise kernels do not care, the cross-attention reads the item's
         // K/V once instead of once per beam); kv_index then has one entry per item
         TRY(bert_rest_impl(w, att, nullptr, y, nullptr, ws, ws_bytes, rows / group, group, 0, nullptr, nullptr, nullptr, 1, nullptr, nullptr,
-                           Nk, nullptr, nullptr, true, nullptr, kv_pre[l], nullptr, kv_index, kv_ld, stream));
+                           Nk, nullptr, nullptr, true, (dt != MADTP_F32 && l + 1 < n_layers) ? s.hc : nullptr, kv_pre[l], nullptr, kv_index,
+                           kv_ld, stream));
         h = y;
     }
+    return 0;
+}
+
+// _reorder_cache (models/med.py:1091-1094) for the cache of madtp_bert_decode_step: dst[l, r, 0..t) = src[l, beam_src[r], 0..t) - only
+// the t positions filled so far (an index_select over the whole [layers, rows, Lmax, 2 dim] tensor moved Lmax / t times the bytes).
+namespace {
+__global__ __launch_bounds__(256) void kv_reorder_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const int64_t* __restrict__ beam_src,
+                                                         int rows, size_t row_u4, size_t used_u4) {
+    const int r = blockIdx.x, l = blockIdx.y;
+    const uint4* s = src + ((size_t)l * rows + (size_t)beam_src[r]) * row_u4;
+    uint4* d = dst + ((size_t)l * rows + r) * row_u4;
+    for (size_t i = threadIdx.x; i < used_u4; i += 256) d[i] = s[i];
+}
+}  // namespace
+extern "C" int madtp_kv_cache_reorder(const void* src, void* dst, const int64_t* beam_src, int n_layers, int rows, int Lmax, int t,
+                                      int row_bytes, void* stream) {
+    if (!src || !dst || !beam_src || src == dst || n_layers <= 0 || rows <= 0 || t < 0 || t > Lmax || row_bytes <= 0) return MADTP_E_BADARG;
+    if (row_bytes % 16 || !aligned16(src) || !aligned16(dst)) return MADTP_E_ALIGN;
+    if (t == 0) return 0;
+    hipLaunchKernelGGL(kv_reorder_kernel, dim3(rows, n_layers), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, beam_src, rows,
+                       (size_t)Lmax * row_bytes / 16, (size_t)t * row_bytes / 16);
+    MADTP_LAUNCH_CHECK();
     return 0;
 }
 

@@ -84,6 +84,7 @@ _SIGS = {
                                          c_void_p, c_void_p, c_void_p]),
     "madtp_bert_decode_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+    "madtp_kv_cache_reorder": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "madtp_sample_top_p": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                    c_int, c_void_p]),
     "madtp_add_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
@@ -1260,6 +1261,13 @@ def bert_decode_step(weights, x, kv_cache, t, kv_pre, kv_index, kv_ld, Nk, group
     _check(lib.madtp_bert_decode_step(arr, L, _p(x), _p(kv_cache), rows, int(t), kv_cache.shape[2], kv, _p(kv_index), int(kv_ld), int(Nk),
                                       int(group), _p(y), _p(ws), ws.numel(), _stream()), "madtp_bert_decode_step")
     return y
+
+
+def kv_cache_reorder(src, dst, beam_src, t):
+    """dst[l, r, :t] = src[l, beam_src[r], :t] for the decode step's cache [layers, rows, Lmax, 2 D] (madtp_kv_cache_reorder)."""
+    L, rows, Lmax, W = src.shape
+    _check(load().madtp_kv_cache_reorder(_p(src), _p(dst), _p(beam_src), L, rows, Lmax, int(t), W * src.element_size(), _stream()),
+           "madtp_kv_cache_reorder")
 
 
 def bert_encoder_sync_free_ok(B, L, Nk, prune, qargs, mask2d):
