@@ -19,7 +19,9 @@ python tools/retrieval_bench.py --no-cpu-baseline 2>/dev/null | tail -1 > gpurun
 python tools/caption_bench.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_caption_bench.json; cut -c1-300 gpurun_out/${TAG}_caption_bench.json
 python tools/gemm_bench.py bf16 ab > gpurun_out/${TAG}_gemm_pp_ab.txt 2>&1
 python tools/latency_table.py f16 > gpurun_out/${TAG}_latency_table_f16.txt 2>&1
-{ for m in fp32 f16x3; do MADTP_TRAIN_PRECISION=$m python tools/train_step_bench.py 4 16 64 2>&1 | grep "^B="; done; } > gpurun_out/${TAG}_train_step.txt
+{ for m in fp32 f16x3; do MADTP_TRAIN_PRECISION=$m python tools/train_step_bench.py 4 16 64 2>&1 | grep "^B="; done;
+  echo "# model.train(): dropout 0.1 + DropPath (counter-based masks)"; MADTP_TRAIN_DROPOUT=1 MADTP_TRAIN_PRECISION=f16x3 python tools/train_step_bench.py 64 2>&1 | grep "^B=";
+  echo "# MADTP_TRAIN_SAVE=0: fused layer calls + recompute in the backward (the round-4 scheme)"; MADTP_TRAIN_SAVE=0 MADTP_TRAIN_PRECISION=f16x3 python tools/train_step_bench.py 64 2>&1 | grep "^B="; } > gpurun_out/${TAG}_train_step.txt
 { for hv in 0 1; do echo "MADTP_ATTN_HV=$hv"; MADTP_ATTN_HV=$hv python tools/attn_large_bench.py 2>&1 | grep "N= 901\|N= 577"; done; } > gpurun_out/${TAG}_attn_large_hv_ab.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -34,8 +36,12 @@ for spec in "nlvr f16" "nlvr bf16" "nlvr f16x3" "vqa bf16" "vqa f16x3" "retrieva
 done
 # training step in the f16x3 mode: where the kernel time goes
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_train -o p -- env MADTP_TRAIN_PRECISION=f16x3 python $R/tools/train_step_bench.py 64 > $R/gpurun_out/prof_train.log 2>&1
-python $R/tools/rocpd_stats.py $(find $R/gpurun_out/prof_train -name "*_results.db" | head -1) "rocprofv3 --kernel-trace --stats -- MADTP_TRAIN_PRECISION=f16x3 python tools/train_step_bench.py 64 (2 + 3 inference forwards, 1 + 3 training steps)" > $R/gpurun_out/${TAG}_train_step_kernel_stats.txt
+MADTP_STATS_SKIP=6 python $R/tools/rocpd_stats.py $(find $R/gpurun_out/prof_train -name "*_results.db" | head -1) "rocprofv3 --kernel-trace --stats -- MADTP_TRAIN_PRECISION=f16x3 python tools/train_step_bench.py 64 (the 3 timed training steps)" > $R/gpurun_out/${TAG}_train_step_kernel_stats.txt
 rm -rf $R/gpurun_out/prof_train
+# caption generation (incremental decoding + device-side beam search): the kernels of the timed generate calls
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_cap -o p -- python $R/tools/caption_bench.py > $R/gpurun_out/prof_cap.log 2>&1
+MADTP_STATS_SKIP=1 python $R/tools/rocpd_stats.py $(find $R/gpurun_out/prof_cap -name "*_results.db" | head -1) "rocprofv3 --kernel-trace --stats -- python tools/caption_bench.py (the generate calls after the first)" > $R/gpurun_out/${TAG}_caption_kernel_stats.txt
+rm -rf $R/gpurun_out/prof_cap
 # four forwards in flight: who overlaps whom
 rocprofv3 --kernel-trace -d $R/gpurun_out/prof_inflight -o p -- python $R/bench.py --steps 24 --warmup 3 --traffic off --no-cpu-baseline --no-parity --no-gemm-events > $R/gpurun_out/prof_inflight.log 2>&1
 python $R/tools/rocpd_overlap.py $(find $R/gpurun_out/prof_inflight -name "*_results.db" | head -1) 400 0.8 > $R/gpurun_out/${TAG}_inflight_overlap.txt

@@ -16,6 +16,7 @@ hip.load()
 T = 8.612223847001898
 MODE = os.environ.get("MADTP_TRAIN_PRECISION", "fp32")
 model = harness.build_nlvr(224, 0, "cuda")
+DROPOUT = os.environ.get("MADTP_TRAIN_DROPOUT", "0") == "1"  # model.train(): dropout 0.1 / DropPath as the reference's loops run
 opt = torch.optim.AdamW(model.parameters(), lr=1e-6, weight_decay=0.05)
 for B in [int(a) for a in sys.argv[1:]] or [4, 16, 64]:
     images, text, _ = harness.nlvr_inputs(B, 224, 20, 0, "cuda")
@@ -31,6 +32,8 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 16, 64]:
             torch.cuda.synchronize()
             t_inf = (time.time() - t0) / 3
 
+        model.train(DROPOUT)
+
         def step():
             opt.zero_grad(set_to_none=True)
             lo, lf = model(images, text, targets, temperature=T, train=True)
@@ -43,5 +46,6 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 16, 64]:
         losses = [step() for _ in range(3)]
         torch.cuda.synchronize()
         t_tr = (time.time() - t0) / 3
-    print(f"B={B:3d} samples ({2 * B} images): inference forward ({MODE} mode) {t_inf * 1e3:8.1f} ms, training step {t_tr * 1e3:8.1f} ms "
+    model.eval()
+    print(f"B={B:3d} samples ({2 * B} images): inference forward ({MODE} mode) {t_inf * 1e3:8.1f} ms, training step{' (train mode, dropout)' if DROPOUT else ''} {t_tr * 1e3:8.1f} ms "
           f"({2 * B / t_tr:7.1f} images/s), peak memory {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB, loss_ori {losses[0]:.4f} -> {losses[-1]:.4f}")
