@@ -18,7 +18,12 @@ def create_vit(vit, image_size, use_grad_checkpointing=False, ckpt_layer=0, drop
                sd_dim=768, map_func=False):
     """models/blip.py:228-252."""
     if vit != 'base':
-        raise NotImplementedError("ViT-L (head_dim 64, 24 layers) is not wired in this round")
+        # the reference's own 'large' branch (models/blip.py:238-246: width 1024) cannot run the pruned forward: Query_model uses the
+        # tokens themselves as queries (models/utils.py:161-170, map_func=False at every call site), so ONE space_dict [100, sd_dim] has
+        # to match the 1024-wide image tokens AND the 768-wide text tokens - sd_dim 768 fails in the ViT, 1024 in the text encoder
+        # ("mat1 and mat2 shapes cannot be multiplied (8x1024 and 768x100)", utils.py:170; run here, DESIGN.md section 9)
+        raise NotImplementedError("vit='large': the reference's large branch cannot run its own pruned forward (image tokens 1024 wide, text "
+                                  "tokens 768 wide, one space_dict; models/utils.py:161-170) - there is nothing to mirror")
     vision_width = 768
     visual_encoder = VisionTransformer(img_size=image_size, patch_size=16, embed_dim=vision_width, depth=12,
                                        num_heads=12, use_grad_checkpointing=use_grad_checkpointing,

@@ -25,7 +25,8 @@ class BLIP_VQA(nn.Module):
                  config=None, decoder=True):
         super().__init__()
         if vit != 'base':
-            raise NotImplementedError("the gfx950 kernels are tuned for ViT-B (768 wide, 12 heads)")
+            raise NotImplementedError("vit='large': the reference's large branch cannot run its own pruned forward (see "
+                                      "madtp_amd/blip_nlvr.py create_vit)")
         self.sd_num = 100 if config is None else config['sd_num']
         self.sd_dim = 768 if config is None else config['sd_dim']
         self.space_dict = nn.Parameter(torch.randn(self.sd_num, self.sd_dim))  # :40
