@@ -543,6 +543,21 @@ def test_vqa_training_step_matches_reference(hip, path, mode):
     missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]
     assert not missing, f"no gradient produced for {len(missing)} tensors, e.g. {missing[:5]}"
     grad_case.check_against_fixture(g, grads, 1e-3, "HIP VQA training step vs reference")
+    # model.train(): embeddings, the encoder's and the decoder's layers (causal self-attention, cross-attention to the question
+    # states) drop as the reference's loop does - finite, repeatable per seed, different across seeds and from model.eval()
+    model.train()
+    vals = []
+    for seed in (11, 11, 12):
+        model.zero_grad(set_to_none=True)
+        runtime.set_dropout_seed(seed)
+        with _train_mode(mode):
+            lv2, lf2 = model(c["images"].cuda(), {"input_ids": c["ids"].cuda(), "attention_mask": c["att"].cuda()},
+                             {"input_ids": c["a_ids"].cuda(), "attention_mask": c["a_att"].cuda()}, temperature=c["T"], train=True,
+                             n=c["n_list"], weights=c["weights"])
+            (lv2 + 0.1 * lf2).backward()
+        vals.append(float(lv2.detach()))
+        assert np.isfinite(vals[-1]) and all(bool(torch.isfinite(p_.grad).all()) for p_ in model.parameters() if p_.grad is not None)
+    assert vals[0] == vals[1] and vals[0] != vals[2] and vals[0] != float(lv.detach())
 
 
 CAPTRAIN_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "trainstep_cap_*.npz")))
@@ -582,6 +597,19 @@ def test_caption_training_step_matches_reference(hip, path, mode):
     missing = [k[2:-7] for k in g.files if k.startswith("g_") and k.endswith("_sample") and k[2:-7] not in grads]
     assert not missing, f"no gradient produced for {len(missing)} tensors, e.g. {missing[:5]}"
     grad_case.check_against_fixture(g, grads, 1e-3, "HIP caption training step vs reference")
+    model.train()  # dropout in the decoder (causal self-attention + cross-attention to the image tokens), DropPath in the ViT
+    vals = []
+    for seed in (21, 21, 22):
+        model.zero_grad(set_to_none=True)
+        runtime.set_dropout_seed(seed)
+        with _train_mode(mode):
+            lm2, lf2 = model(synth.synth_images(B, size, seed=int(g["seed"])).cuda(), {"input_ids": torch.from_numpy(g["ids"]).cuda(),
+                                                                                   "attention_mask": torch.from_numpy(g["att"]).cuda()},
+                             temperature=float(g["temperature"]), train=True)
+            (lm2 + 0.1 * lf2).backward()
+        vals.append(float(lm2.detach()))
+        assert np.isfinite(vals[-1]) and all(bool(torch.isfinite(p_.grad).all()) for p_ in model.parameters() if p_.grad is not None)
+    assert vals[0] == vals[1] and vals[0] != vals[2] and vals[0] != float(lm.detach())
 
 
 CLIPGRAD_CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "clipgrad_*.npz")))
