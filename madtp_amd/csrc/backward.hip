@@ -563,17 +563,19 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdArgs a) {
     }
 }
 
-// columns pass: dV_j = sum_i P_ij dO_i, dK_j = scale sum_i dS_ij Q_i for 16 keys per workgroup; a wave takes query tiles wave,
-// wave + 4, ... (operands straight from global memory), the four partial tiles are added in order
+// columns pass: dV_j = sum_i P_ij dO_i, dK_j = scale sum_i dS_ij Q_i; a workgroup takes 64 keys, each wave one 16-key tile over ALL
+// query tiles in ascending order (operands straight from global memory; the four waves read neighbouring 64-byte runs of the same P /
+// dS rows), so a tile's sum is one accumulation chain - no cross-wave reduction
 __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnBwdArgs a) {
-    __shared__ float red[4][2][16][HD];
-    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, j0 = blockIdx.y * 16, NQ = a.N, N = a.Nk, tid = threadIdx.x;
+    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, NQ = a.N, N = a.Nk, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    const int j0 = (blockIdx.y * 4 + wave) * 16;
+    if (j0 >= N) return;
     af_f32x4 accv[4], acck[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { accv[dt] = (af_f32x4){0.f, 0.f, 0.f, 0.f}; acck[dt] = accv[dt]; }
     const int jc = min(j0 + l16, N - 1);
-    for (int it = wave; it * 16 < NQ; it += 4) {
+    for (int it = 0; it * 16 < NQ; ++it) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const int ii = it * 16 + 4 * g + s4, i = min(ii, NQ - 1);
@@ -600,27 +602,15 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(AttnBwdArgs a) {
             }
         }
     }
+    // lane holds keys j0 + 4 g + r, columns 16 dt + l16
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + 4 * g + r;
+        if (j >= N) continue;
+        float* dvp = a.dv + (size_t)(b * N + j) * a.lddk + h * HD + l16;
+        float* dkp = a.dk + (size_t)(b * N + j) * a.lddk + h * HD + l16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            red[wave][0][4 * g + r][16 * dt + l16] = accv[dt][r];
-            red[wave][1][4 * g + r][16 * dt + l16] = acck[dt][r];
-        }
-    __syncthreads();
-    const int c = tid >> 4, dq = (tid & 15) * 4;
-    if (j0 + c < N) {
-        float4 o[2];
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            const float4 p0 = *(const float4*)&red[0][w][c][dq], p1 = *(const float4*)&red[1][w][c][dq], p2 = *(const float4*)&red[2][w][c][dq],
-                         p3 = *(const float4*)&red[3][w][c][dq];
-            o[w] = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
-                               (p0.w + p1.w) + (p2.w + p3.w));
-        }
-        *(float4*)(a.dv + (size_t)(b * N + j0 + c) * a.lddk + h * HD + dq) = o[0];
-        *(float4*)(a.dk + (size_t)(b * N + j0 + c) * a.lddk + h * HD + dq) =
-            make_float4(o[1].x * a.scale, o[1].y * a.scale, o[1].z * a.scale, o[1].w * a.scale);
+        for (int dt = 0; dt < 4; ++dt) { dvp[16 * dt] = accv[dt][r]; dkp[16 * dt] = acck[dt][r] * a.scale; }
     }
 }
 
@@ -700,55 +690,44 @@ __global__ __launch_bounds__(256) void attn_side_kernel(const float* __restrict_
 // dq[n,:] += sum_k W[k,n] dA[k,:].  Exact f32, fixed summation orders.
 // kernel 0 (round 5; D % 16 == 0): dW[b, k, t] = <dA[b,k,:], q[b,t,:]> as a batched exact-f32 MFMA product (16x16x4 f32) - the
 // first version re-read q[b] (n x D) once per dictionary column, 100 x the operand, and was the second-largest kernel of a
-// training step.  One workgroup per (128 tokens, sample); a wave owns two 16-token tiles x all (<= 8) 16-column dictionary tiles.
+// training step.  One workgroup per (64 tokens, sample); a wave owns one 16-token tile x all (<= 8) 16-column dictionary tiles (with
+// two tiles per wave the launch had 512 waves for 1024 SIMDs and took 90 us).
 // Operands come straight from global memory as float4 (contraction index d0 + 4 (lane >> 4) + s in MFMA step s - the same
 // permutation of d on both operands); summation order: fixed by the instruction, chunks of 16 d in ascending order.
 constexpr int AF_MAXN = 1024, AF_KT = 8;
 __global__ __launch_bounds__(256) void att_ft_bwd_dw_kernel(const float* __restrict__ q, const float* __restrict__ dA,
                                                             float* __restrict__ dW, int n, int K, int D) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
-    const int b = blockIdx.y, t0 = blockIdx.x * 128 + wave * 32;
+    const int b = blockIdx.y, t0 = blockIdx.x * 64 + wave * 16;
     if (t0 >= n) return;
     const int nkt = (K + 15) / 16;
-    const float* qr[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) qr[j] = q + ((size_t)b * n + min(t0 + 16 * j + l16, n - 1)) * D + 4 * g;
+    const float* qr = q + ((size_t)b * n + min(t0 + l16, n - 1)) * D + 4 * g;
     const float* ar[AF_KT];
 #pragma unroll
     for (int i = 0; i < AF_KT; ++i) ar[i] = dA + ((size_t)b * K + min(16 * i + l16, K - 1)) * D + 4 * g;
-    af_f32x4 acc[AF_KT][2];
+    af_f32x4 acc[AF_KT];
 #pragma unroll
-    for (int i = 0; i < AF_KT; ++i) { acc[i][0] = (af_f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+    for (int i = 0; i < AF_KT; ++i) acc[i] = (af_f32x4){0.f, 0.f, 0.f, 0.f};
     for (int d0 = 0; d0 < D; d0 += 16) {
-        float4 qv[2], av[AF_KT];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) qv[j] = *(const float4*)(qr[j] + d0);
+        float4 av[AF_KT];
+        const float4 qv = *(const float4*)(qr + d0);
 #pragma unroll
         for (int i = 0; i < AF_KT; ++i) if (i < nkt) av[i] = *(const float4*)(ar[i] + d0);
 #pragma unroll
         for (int i = 0; i < AF_KT; ++i) {
             if (i >= nkt) continue;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, qv[j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, qv[j].y, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, qv[j].z, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, qv[j].w, acc[i][j], 0, 0, 0);
-            }
+            acc[i] = mfma_f32_4(av[i], qv, acc[i]);
         }
     }
-    // lane holds rows (dictionary columns) 16 i + 4 g + r, column (token) t0 + 16 j + l16
+    // lane holds rows (dictionary columns) 16 i + 4 g + r, column (token) t0 + l16
+    const int t = t0 + l16;
 #pragma unroll
     for (int i = 0; i < AF_KT; ++i) {
         if (i >= nkt) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int t = t0 + 16 * j + l16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = 16 * i + 4 * g + r;
-                if (k < K && t < n) dW[((size_t)b * K + k) * n + t] = acc[i][j][r];
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * i + 4 * g + r;
+            if (k < K && t < n) dW[((size_t)b * K + k) * n + t] = acc[i][r];
         }
     }
 }
@@ -966,7 +945,7 @@ extern "C" int madtp_attention_bwd(const float* q, const float* k, const float* 
     hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, nrt), dim3(256), lds_p, s, a);
     if (da) hipLaunchKernelGGL(attn_headmax_kernel, dim3(B, N), dim3(256), 0, s, a);
     hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(B * H, nrt), dim3(256), lds_r, s, a);
-    hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(B * H, nrt), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(B * H, (N + 63) / 64), dim3(256), 0, s, a);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
@@ -1001,7 +980,7 @@ extern "C" int madtp_attention_bwd_cross(const float* q, int ldq, const float* k
     MADTP_ENSURE_MAX_LDS(attn_bwd_rows_kernel, lds_r);
     hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, (Nq + 15) / 16), dim3(256), lds_p, s, a);
     hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(B * H, (Nq + 15) / 16), dim3(256), lds_r, s, a);
-    hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(B * H, (Nk + 15) / 16), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(B * H, (Nk + 63) / 64), dim3(256), 0, s, a);
     MADTP_LAUNCH_CHECK();
     return 0;
 }
@@ -1055,7 +1034,7 @@ extern "C" int madtp_att_ft_bwd(const float* inner, const float* q, const float*
     float* dw_pre = nullptr;
     if (D % 16 == 0 && aligned16(q) && aligned16(dA)) {
         dw_pre = ws + (size_t)B * K * n;
-        hipLaunchKernelGGL(att_ft_bwd_dw_kernel, dim3((n + 127) / 128, B), dim3(256), 0, s, q, dA, dw_pre, n, K, D);
+        hipLaunchKernelGGL(att_ft_bwd_dw_kernel, dim3((n + 63) / 64, B), dim3(256), 0, s, q, dA, dw_pre, n, K, D);
         MADTP_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(att_ft_bwd_logits_kernel, dim3(K, B), dim3(256), (size_t)D * sizeof(float), s, inner, q, dA, inv_sqrt_d, dinner, ws,
