@@ -588,6 +588,13 @@ int madtp_transpose_pad(const float* src, int ld_src, int R, int C, float* dst, 
  * partials in colsum_ws (ceil(Rp/64) * C floats), added in a fixed order. */
 int madtp_transpose_split(const float* src, int ld_src, int R, int C, void* dst, int Rp, int Cp, int weight_format,
                           float* colsum_out, float* colsum_ws, void* stream);
+/* Both f16-split operand forms of a weight for the f16x3 training step in one pass (ABI 28): w f32 [N, K] (row stride ldw) times
+ * inv_scale = 2^s -> planes f16 [rows, 2K]: rows row0 .. row0+N-1 = [Q0 | Q1] (the forward GEMMs' weight operand; several weights of
+ * a fused projection write their row blocks of one buffer) and planes_t f16 [>= K rows, 2*Ntp]: (k, col0+n) = Q0, (k, Ntp+col0+n) = Q1
+ * of w[n, k] (dgrad's operand W^T).  Either may be NULL.  Padding is not written: the buffers are zero-initialised once by the
+ * caller and reused across parameter versions.  K % 4 == 0, Ntp % 4 == 0, col0 % 4 == 0. */
+int madtp_weight_planes(const float* w, int ldw, int N, int K, float inv_scale, void* planes, int row0, void* planes_t, int Ntp, int col0,
+                        void* stream);
 /* out[c] = sum_r dy[r, c]: bias gradients (nn.Linear, LayerNorm beta).  part_ws: P * N floats of scratch, P = 64 for M >= 4096,
  * 16 for M >= 256, else 1 (the row chunks summed in order; 64 * N always suffices). */
 int madtp_colsum(const float* dy, int ld, int M, int N, float* out, float* part_ws, void* stream);

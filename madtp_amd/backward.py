@@ -93,7 +93,8 @@ def _check_mode(what):
 def _cached(key, tensors, build):
     """build() memoised per (key, identity and version of the source tensors): padded / concatenated / transposed / split copies of
     parameters are made once per parameter VERSION (an optimizer step bumps it) instead of in every backward."""
-    ver = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    from .runtime import update_epoch
+    ver = tuple((t.data_ptr(), (t._version, update_epoch()), tuple(t.shape)) for t in tensors)  # (update_epoch: fused optimizers, runtime.py)
     hit = _CACHE.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
@@ -112,6 +113,8 @@ def _cached(key, tensors, build):
 def _planes(w32, prev=None):
     """f16-split weight planes of a (padded) f32 weight tensor, attached to it (the tensor itself is a cached object).  prev: the
     tensor this one replaces in its cache entry - its scale is reused (no host read of max|w|) up to runtime.SCALE_REUSE times."""
+    if w32.dtype == torch.float16:  # already the planes (_x3_weights)
+        return w32
     pl = getattr(w32, "_madtp_x3_planes", None)
     if pl is None:
         from .runtime import SCALE_REUSE
@@ -136,6 +139,58 @@ def _versioned(make):
     return build
 
 
+class _X3W:
+    """both operand forms of one (possibly fused) weight in the f16x3 mode: planes [pad128(N), 2K] (forward) and planes_t
+    [pad128(K), 2 pad64(N)] (dgrad), with their common power-of-two scale"""
+    __slots__ = ("planes", "planes_t", "s", "age", "sig")
+
+
+def _x3_weights(key, ws):
+    """f16-split planes of the weight(s) ws (f32 [N_i, K], concatenated along N) and of the transpose, made by ONE kernel per part
+    (madtp_weight_planes) into buffers that are allocated - zero padding included - once per cache entry and rewritten in place for
+    every new parameter version; the scale is the previous version's up to runtime.SCALE_REUSE times (else one host read of max|w|)."""
+    def build(prev=None):
+        from .runtime import SCALE_REUSE
+        Ns, K = tuple(int(w.shape[0]) for w in ws), int(ws[0].shape[1])
+        Nt = sum(Ns)
+        Ntp = _pad(Nt, 64)
+        o = _X3W()
+        o.sig = (Ns, K)
+        if isinstance(prev, _X3W) and prev.sig == o.sig:
+            o.planes, o.planes_t = prev.planes, prev.planes_t
+            o.s, o.age = (prev.s, prev.age + 1) if prev.age < SCALE_REUSE else (None, 0)
+        else:
+            dev = ws[0].device
+            o.planes = torch.zeros((_pad(Nt, 128), 2 * K), device=dev, dtype=torch.float16)
+            o.planes_t = torch.zeros((_pad(K, 128), 2 * Ntp), device=dev, dtype=torch.float16)
+            o.s, o.age = None, 0
+        if o.s is None:
+            amax = float(torch.stack([w.detach().abs().max() for w in ws]).max())
+            o.s = 0
+            if amax > 0 and amax == amax and amax != float("inf"):
+                o.s = max(-100, min(100, 14 - math.ceil(math.log2(amax))))
+        row = 0
+        for w in ws:
+            wd = w.detach()
+            if wd.stride(1) != 1:
+                wd = wd.contiguous()
+            _check(load().madtp_weight_planes(_p(wd), wd.stride(0), int(wd.shape[0]), K, float(2.0 ** o.s), _p(o.planes), row, _p(o.planes_t),
+                                              Ntp, row, _stream()), "madtp_weight_planes")
+            row += int(wd.shape[0])
+        for t in (o.planes, o.planes_t):
+            t._madtp_w_scale, t._madtp_log2_scale = float(2.0 ** -o.s), o.s
+        o.planes._madtp_t, o.planes._madtp_n = o.planes_t, Nt
+        return o
+    build._takes_prev = True
+    return _cached(key, list(ws), build)
+
+
+def _x3_ok(w):
+    """the single-pass weight preparation takes 2-D f32 weights whose K feeds an f16x3 GEMM (K % 64 == 0) and whose N keeps the
+    transposed planes' 4-element groups aligned"""
+    return _x3() and w.dim() == 2 and w.dtype == torch.float32 and w.shape[1] % 64 == 0 and w.shape[0] % 4 == 0
+
+
 def _gemm(a, w, bias=None, n=None, residual=None, out_dtype=torch.float32):
     """act-free Linear of the recomputed forward: a f32 [M, K] @ w f32 [Npad, K]^T (+ bias, + residual) -> f32 [M, n]."""
     if _x3() and a.shape[1] % 64 == 0:
@@ -150,14 +205,21 @@ def _attention(q, k, v, B, H, Nq, Nk, scale, **kw):
 
 def dgrad(dy, weight, residual=None):
     """dX[M, K] = dY[M, N] @ W[N, K] (nn.Linear weight layout) [+ residual[M, K]: the other branch of a residual connection]."""
-    N, K = weight.shape
     x3 = _x3()
+    if x3 and weight.dtype == torch.float16:  # the planes of a fused projection (_cat_wb): its W^T planes ride along
+        wtp, N, K = weight._madtp_t, weight._madtp_n, weight.shape[1] // 2
+    elif x3 and _x3_ok(weight):
+        wtp, (N, K) = _x3_weights(("x3w", weight.data_ptr(), tuple(weight.shape)), [weight]).planes_t, weight.shape
+    else:
+        wtp, (N, K) = None, weight.shape
     Np = _pad(N, 64 if x3 else 32)  # the GEMM's reduction length (slabs of 32 f32 / 64 f16): zero columns for e.g. the 100 dictionary columns
     if Np != N:
         dyp = torch.zeros((dy.shape[0], Np), device=dy.device, dtype=torch.float32)
         dyp[:, :N] = dy
         dy = dyp
     # [Kpad, Np]: the GEMM's "weight" with K' = N contiguous - once per parameter version (was: one transpose per backward call)
+    if wtp is not None:
+        return hip.gemm(hip.split_f16(dy.contiguous()), wtp, None, residual, out_dtype=torch.float32, n=K)
     wt = _cached(("wt", weight.data_ptr(), Np, x3), [weight], _versioned(lambda: transpose_pad(weight, Np, _pad(K, 128))))
     if x3:
         return hip.gemm(hip.split_f16(dy.contiguous()), _planes(wt), None, residual, out_dtype=torch.float32, n=K)
@@ -333,12 +395,17 @@ def _pad_w(w):
 
 def _f32_lin(linear):
     """(weight padded to 128 rows, bias) of an nn.Linear for the recomputed forward's GEMM (cached per parameter version)."""
+    b = None if linear.bias is None else linear.bias.detach().contiguous()
+    if _x3_ok(linear.weight):
+        return _x3_weights(("x3w", linear.weight.data_ptr(), tuple(linear.weight.shape)), [linear.weight]).planes, b
     w = _cached(("pw", linear.weight.data_ptr(), _x3()), [linear.weight], _versioned(lambda: _fresh(_pad_w(linear.weight))))
-    return w, (None if linear.bias is None else linear.bias.detach().contiguous())
+    return w, b
 
 
 def _f32_wb(w, b):
     """(weight padded to 128 rows, bias) of a Linear given as tensors (cached per parameter version)."""
+    if _x3_ok(w):
+        return _x3_weights(("x3w", w.data_ptr(), tuple(w.shape)), [w]).planes, (None if b is None else b.detach().contiguous())
     wp = _cached(("pw", w.data_ptr(), _x3()), [w], _versioned(lambda: _fresh(_pad_w(w))))
     return wp, (None if b is None else b.detach().contiguous())
 
@@ -351,6 +418,9 @@ def _fresh(t):
 def _cat_wb(tag, linears):
     """[w0; w1; ...] and [b0; b1; ...] of Linears that run as one fused projection (cached per parameter version)."""
     ws = [l.weight for l in linears]
+    if all(_x3_ok(x) for x in ws):
+        w = _x3_weights(("x3cat", tag) + tuple(x.data_ptr() for x in ws), ws).planes
+        return w, torch.cat([l.bias.detach() for l in linears], 0).contiguous()
     w = _cached(("cat", tag, _x3()) + tuple(x.data_ptr() for x in ws), ws, _versioned(lambda: torch.cat([x.detach() for x in ws], 0).contiguous()))
     b = torch.cat([l.bias.detach() for l in linears], 0).contiguous()
     return w, b
@@ -391,11 +461,13 @@ def _note_versions(ctx, params):
     """the backward reads the module's CURRENT parameters (W^T planes per parameter version) next to activations of the forward: an
     in-place update between the two (optimizer.step, load_state_dict, an EMA) would pair them wrongly - native autograd raises
     'modified by an inplace operation' there, so do these Functions"""
-    ctx.param_versions = tuple(p._version if p is not None else -1 for p in params)
+    from .runtime import update_epoch
+    ctx.param_versions = (update_epoch(),) + tuple(p._version if p is not None else -1 for p in params)
 
 
 def _check_versions(ctx, params, what):
-    now = tuple(p._version if p is not None else -1 for p in params)
+    from .runtime import update_epoch
+    now = (update_epoch(),) + tuple(p._version if p is not None else -1 for p in params)
     if now != ctx.param_versions:
         raise RuntimeError(f"{what}: a parameter was modified in place between forward and backward (versions {ctx.param_versions} -> "
                            f"{now}); back-propagate before the optimizer step / load_state_dict, as native autograd requires")

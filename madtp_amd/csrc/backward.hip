@@ -90,6 +90,56 @@ __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __res
     }
 }
 
+// ---- both f16-split operand forms of a weight in one pass (round 5: a training step re-prepares every weight after the optimizer
+// step - pad copy, zero fill, transpose, two splits: ~1500 small launches, ~10 ms of a b64 step): w f32 [N, K] (row stride ldw) x
+// 2^s -> planes [.., 2 K] rows row0 .. row0 + N - 1 as [Q0 | Q1] (the forward's weight operand; K % 4 == 0) and planes_t
+// [.., 2 Ntp] with (k, col0 + n) = Q0 / (k, Ntp + col0 + n) = Q1 of w[n, k] (dgrad's operand W^T).  Padding rows / columns are not
+// touched (the caller's buffers are zero-initialised once and reused across parameter versions).
+__global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restrict__ w, int ldw, int N, int K, float inv_scale,
+                                                            _Float16* __restrict__ planes, int row0, _Float16* __restrict__ planes_t,
+                                                            int Ntp, int col0) {
+    __shared__ float tile[64][65];
+    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int n = n0 + ty + 4 * q, k = k0 + tx;
+        tile[ty + 4 * q][tx] = (n < N && k < K) ? w[(size_t)n * ldw + k] * inv_scale : 0.0f;
+    }
+    __syncthreads();
+    const int c4 = (threadIdx.x & 15) * 4, ry = threadIdx.x >> 4;  // 16 quads x 16 rows
+    if (planes) {  // row-major: row n, four consecutive k
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nl = ry + 16 * q, n = n0 + nl, k = k0 + c4;
+            if (n >= N || k >= K) continue;
+            const f32x4 v = (f32x4){tile[nl][c4], tile[nl][c4 + 1], tile[nl][c4 + 2], tile[nl][c4 + 3]};
+            const f16x4 h = __builtin_convertvector(v, f16x4);
+            const f16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), f16x4);
+            _Float16* o = planes + (size_t)(row0 + n) * (2 * K) + k;
+            *(f16x4*)o = h;
+            *(f16x4*)(o + K) = l;
+        }
+    }
+    if (planes_t) {  // transposed: row k, four consecutive n
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kl = ry + 16 * q, k = k0 + kl, n = n0 + c4;
+            if (k >= K || n >= N) continue;
+            const f32x4 v = (f32x4){tile[c4][kl], tile[c4 + 1][kl], tile[c4 + 2][kl], tile[c4 + 3][kl]};
+            const f16x4 h = __builtin_convertvector(v, f16x4);
+            const f16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), f16x4);
+            _Float16* o = planes_t + (size_t)k * (2 * Ntp) + col0 + n;
+            if (n + 3 < N) {
+                *(f16x4*)o = h;
+                *(f16x4*)(o + Ntp) = l;
+            } else {
+                for (int e = 0; e < 4 && n + e < N; ++e) { o[e] = h[e]; o[Ntp + e] = l[e]; }
+            }
+        }
+    }
+}
+
 // ---- column reductions: out[c] = sum_r f(r, c); XHAT: f = dy * (x - mean_r) * rstd_r (LayerNorm gamma grad), else f = dy --
 // stage 1: grid (ceil(N/64), P): block (64 columns x 4 row lanes), rows r = chunk start + lane, +4, ... in order;
 // stage 2: the P partials of a column in order.
@@ -834,6 +884,17 @@ extern "C" int madtp_transpose_split(const float* src, int ld_src, int R, int C,
         hipLaunchKernelGGL(col_reduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, (Rp + 63) / 64, C, colsum_out);
         MADTP_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+extern "C" int madtp_weight_planes(const float* w, int ldw, int N, int K, float inv_scale, void* planes, int row0, void* planes_t, int Ntp,
+                                   int col0, void* stream) {
+    if (!w || (!planes && !planes_t) || N <= 0 || K <= 0 || ldw < K || !(inv_scale > 0.f) || row0 < 0 || col0 < 0) return MADTP_E_BADARG;
+    if (K % 4 || (planes_t && (Ntp % 4 || col0 % 4 || col0 + N > Ntp))) return MADTP_E_SHAPE;
+    if (((uintptr_t)planes & 7) || ((uintptr_t)planes_t & 7)) return MADTP_E_ALIGN;
+    hipLaunchKernelGGL(weight_planes_kernel, dim3((N + 63) / 64, (K + 63) / 64), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, inv_scale,
+                       (_Float16*)planes, row0, (_Float16*)planes_t, Ntp, col0);
+    MADTP_LAUNCH_CHECK();
     return 0;
 }
 

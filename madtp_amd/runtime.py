@@ -186,12 +186,12 @@ class PreparedCache:
         self._store = {}
 
     def get(self, key, params, builder):
-        sig = (get_precision(),) + tuple((p.data_ptr(), p._version, p.device) if p is not None else None for p in params)
+        sig = ((get_precision(), _UPDATE_EPOCH[0]),) + tuple((p.data_ptr(), p._version, p.device) if p is not None else None for p in params)
         hit = self._store.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]
         # a builder that takes the entry's previous value (same key, older parameter versions) may reuse parts of it
-        prev = hit[1] if (hit is not None and hit[0][0] == sig[0] and len(hit[0]) == len(sig)
+        prev = hit[1] if (hit is not None and hit[0][0][0] == sig[0][0] and len(hit[0]) == len(sig)
                           and all((a is None) == (b is None) and (a is None or (a[0] == b[0] and a[2] == b[2])) for a, b in zip(hit[0][1:], sig[1:]))) else None
         val = builder(prev) if getattr(builder, "_takes_prev", False) else builder()
         self._store.pop(key, None)
@@ -247,6 +247,35 @@ def param_epoch():
     return _PARAM_EPOCH[0]
 
 
+# In-place parameter UPDATES are normally seen through Parameter._version (every cache signature below carries it) - but not all of
+# them bump it: torch.optim's fused=True implementations (torch._fused_adamw_ and friends) leave _version untouched (checked on this
+# build: a foreach step takes it 0 -> 2, a fused step 0 -> 0), and neither do edits through `.data`.  A stale prepared weight would
+# silently keep multiplying with the old values while LayerNorm parameters (read in place) moved on.  So every optimizer step in the
+# process bumps an update epoch that all signatures carry as well (a global torch.optim step post-hook); code that edits `.data` by
+# hand calls parameters_updated().
+_UPDATE_EPOCH = [0]
+
+
+def _on_optimizer_step(optimizer, args, kwargs):
+    _UPDATE_EPOCH[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
+    _register_step_hook(_on_optimizer_step)
+except ImportError:  # (a torch without global optimizer hooks: version counters only)
+    pass
+
+
+def update_epoch():
+    return _UPDATE_EPOCH[0]
+
+
+def parameters_updated():
+    """Tell the prepared-weight caches that parameters changed through a path that bumps no version counter (`.data` edits)."""
+    _UPDATE_EPOCH[0] += 1
+
+
 class EncoderWeights:
     """The weight structs of all layers of an encoder for the encoder-level calls (hip.vit_encoder / hip.bert_encoder),
     revalidated per forward with ONE pass over the flattened parameter list (version counters and data pointers) instead of
@@ -266,7 +295,7 @@ class EncoderWeights:
                 l._weights()  # (collects l._madtp_params)
             self.flat = [p for l in layers for p in l.__dict__["_madtp_params"]]
             self.sig = None
-        sig = (get_precision(), tuple([p._version for p in self.flat]), tuple([p.data_ptr() for p in self.flat]))
+        sig = (get_precision(), _UPDATE_EPOCH[0], tuple([p._version for p in self.flat]), tuple([p.data_ptr() for p in self.flat]))
         if sig != self.sig:
             ws = [l._weights() for l in layers]
             arr = (ctypes.c_void_p * len(ws))(*[ctypes.addressof(w) for w in ws])

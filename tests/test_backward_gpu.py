@@ -131,6 +131,40 @@ def test_backward_refuses_parameters_modified_after_forward(hip):
     assert x.grad is not None and blk.mlp.fc1.weight.grad is not None
 
 
+@pytest.mark.parametrize("mode", ["fp32", "f16x3", "bf16"])
+def test_prepared_weights_follow_fused_optimizers_and_data_edits(hip, mode):
+    """torch.optim's fused=True steps (and edits through .data) bump no Parameter._version: the prepared-weight caches follow them
+    through the process-wide update epoch (runtime.py: optimizer step post-hook / parameters_updated()).  Two copies of a block, one
+    stepped by the foreach AdamW, one by the fused one, give the same inference output after the steps - and a different one than
+    before; a .data edit + parameters_updated() is seen as well."""
+    import copy
+    from madtp_amd import runtime, vit
+    torch.manual_seed(0)
+    blk_a = vit.Block(768, 12, qkv_bias=True).cuda().eval()
+    blk_b = copy.deepcopy(blk_a)
+    x = _rand(2, 50, 768, seed=1).cuda()
+    opts = [torch.optim.AdamW(blk_a.parameters(), lr=1e-2), torch.optim.AdamW(blk_b.parameters(), lr=1e-2, fused=True)]
+    with runtime.precision(mode), torch.no_grad():
+        y0 = [blk_a(x), blk_b(x)]
+    assert torch.equal(y0[0], y0[1])
+    for _ in range(2):
+        for blk, opt in zip((blk_a, blk_b), opts):
+            opt.zero_grad(set_to_none=True)
+            for i, p_ in enumerate(blk.parameters()):  # (the same synthetic gradient for both copies)
+                p_.grad = _rand(*p_.shape, seed=100 + i).cuda()
+            opt.step()
+    with runtime.precision(mode), torch.no_grad():
+        y1 = [blk_a(x), blk_b(x)]
+    tol = 1e-4 if mode != "bf16" else 5e-2
+    assert _rel(y1[1], y1[0]) < tol, "the fused optimizer's update did not reach the prepared weights"
+    assert _rel(y1[0], y0[0]) > 1e-2, "the steps changed the block"
+    blk_a.mlp.fc2.weight.data.mul_(0.0)
+    runtime.parameters_updated()
+    with runtime.precision(mode), torch.no_grad():
+        y2 = blk_a(x)
+    assert _rel(y2, y1[0]) > 1e-3
+
+
 def test_layernorm_bwd(hip):
     from madtp_amd import backward as bw
     rows, dim = 1001, 768

@@ -17,7 +17,9 @@ T = 8.612223847001898
 MODE = os.environ.get("MADTP_TRAIN_PRECISION", "fp32")
 model = harness.build_nlvr(224, 0, "cuda")
 DROPOUT = os.environ.get("MADTP_TRAIN_DROPOUT", "0") == "1"  # model.train(): dropout 0.1 / DropPath as the reference's loops run
-opt = torch.optim.AdamW(model.parameters(), lr=1e-6, weight_decay=0.05)
+# (the reference's create_optimizer builds torch.optim.AdamW with its defaults = the foreach implementation on a GPU;
+#  MADTP_TRAIN_FUSED_ADAM=1: torch's fused=True variant, for the record)
+opt = torch.optim.AdamW(model.parameters(), lr=1e-6, weight_decay=0.05, **({"fused": True} if os.environ.get("MADTP_TRAIN_FUSED_ADAM") == "1" else {}))
 for B in [int(a) for a in sys.argv[1:]] or [4, 16, 64]:
     images, text, _ = harness.nlvr_inputs(B, 224, 20, 0, "cuda")
     targets = (torch.arange(B) % 2).cuda()
