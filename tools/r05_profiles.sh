@@ -21,7 +21,8 @@ python tools/gemm_bench.py bf16 ab > gpurun_out/${TAG}_gemm_pp_ab.txt 2>&1
 python tools/latency_table.py f16 > gpurun_out/${TAG}_latency_table_f16.txt 2>&1
 { for m in fp32 f16x3; do MADTP_TRAIN_PRECISION=$m python tools/train_step_bench.py 4 16 64 2>&1 | grep "^B="; done;
   echo "# model.train(): dropout 0.1 + DropPath (counter-based masks)"; MADTP_TRAIN_DROPOUT=1 MADTP_TRAIN_PRECISION=f16x3 python tools/train_step_bench.py 64 2>&1 | grep "^B=";
-  echo "# MADTP_TRAIN_SAVE=0: fused layer calls + recompute in the backward (the round-4 scheme)"; MADTP_TRAIN_SAVE=0 MADTP_TRAIN_PRECISION=f16x3 python tools/train_step_bench.py 64 2>&1 | grep "^B="; } > gpurun_out/${TAG}_train_step.txt
+  echo "# MADTP_TRAIN_SAVE=0: fused layer calls + recompute in the backward (the round-4 scheme)"; MADTP_TRAIN_SAVE=0 MADTP_TRAIN_PRECISION=f16x3 python tools/train_step_bench.py 64 2>&1 | grep "^B=";
+  echo "# MADTP_TRAIN_FUSED_ADAM=1: torch.optim.AdamW(fused=True) instead of the default foreach implementation"; MADTP_TRAIN_FUSED_ADAM=1 MADTP_TRAIN_PRECISION=f16x3 python tools/train_step_bench.py 64 2>&1 | grep "^B="; } > gpurun_out/${TAG}_train_step.txt
 { for hv in 0 1; do echo "MADTP_ATTN_HV=$hv"; MADTP_ATTN_HV=$hv python tools/attn_large_bench.py 2>&1 | grep "N= 901\|N= 577"; done; } > gpurun_out/${TAG}_attn_large_hv_ab.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
