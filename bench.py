@@ -106,10 +106,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)  # a multiple of the 2 / 3 / 4 forwards in flight (equal shares per worker; 24 forwards each: the ramp-up and the tail of the pipeline cost 24 steps ~5 %, 48 ~3 %, 96 ~1.5 % of the 192-step figure)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="f16", choices=["bf16", "f16", "fp32", "f16x3"],
-                    help="fast modes: f16 (default since round 4: IEEE f16 operands on the f16 MFMA - the bf16 mode's kernels and speed "
-                         "within 2 %, 0.94 instead of 0.17 of the kept sets identical to the fp32 oracle at the headline batch) or bf16 "
-                         "(BASELINE.json config 2's dtype); parity modes: f16x3, fp32")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "fp32", "f16x3"],
+                    help="fast modes: bf16 (default: the dtype BASELINE.json config 2 names, so `value` is the metric as written) or "
+                         "f16 (IEEE f16 operands on the f16 MFMA - the same kernels and speed within 2 %%, 0.93 instead of 0.17 of the kept "
+                         "sets identical to the fp32 oracle at the headline batch; reported as `f16_value` of a bf16 run); parity modes: "
+                         "f16x3 (reported as `parity_qualified_value` of every run), fp32")
     ap.add_argument("--config", default="nlvr", choices=list(workloads.NAMES),
                     help="BASELINE.json configuration (default: the headline)")
     ap.add_argument("--batch", type=int, default=0, help="samples per GPU (0 = the configuration's BASELINE batch)")
@@ -122,8 +123,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="headline leg only: no parity_mode / bf16 legs, no index_match")
     ap.add_argument("--no-gemm-events", action="store_true")
-    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the timed bf16 leg (bf16_value) of a non-bf16 run")
-    ap.add_argument("--bf16-steps", type=int, default=32, help="timed steps of the bf16 leg")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the timed leg in the OTHER fast mode (f16_value of a bf16 run, bf16_value of an f16 run)")
+    ap.add_argument("--bf16-steps", type=int, default=32, help="timed steps of that leg")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="the timed region repeats the K steps (whole passes of K) until it lasts at least this long; ms_per_step is per step "
+                         "(the driver's --steps 20 is 0.1 s of work: ramp-up and tail of the in-flight pipeline were ~5 %% of it)")
+    ap.add_argument("--partition", default=None,
+                    help="CUs per XCD of the in-flight workers, e.g. 8,8,8,8 (CU-masked streams, madtp_amd/pipeline.py); 'off' = priority "
+                         "streams on the whole chip; default: MADTP_INFLIGHT_CUMASK, else the workload's measured default")
     ap.add_argument("--gemm-breakdown", action="store_true", help="per-shape GEMM time table on stderr")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("MADTP_INFLIGHT", "0")),
                     help="forwards in flight per GPU (madtp_amd.pipeline: one host thread + HIP stream + model replica each; "
@@ -132,8 +139,14 @@ def main():
 
     from madtp_amd import dist as mdist
     world, rank, local_rank = mdist.env_world()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N` (how the driver starts the 1-GPU run): launch the N ranks ourselves, exactly
+        # as the contract's command line does - one process per GPU, rendezvous on 127.0.0.1 (reference launch:
+        # scripts/compress_nlvr_nlvr2_p0.5.sh:6 `python -m torch.distributed.run --nproc_per_node=8 ...`, utils.py:254-276)
+        raise SystemExit(self_launch(args.gpus))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start {args.gpus} ranks (python -m torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) or none (bench.py launches them itself)")
     # roofline.traffic comes from two rocprofv3 --pmc passes over a one-step copy of this command (measure_traffic).  They run
     # FIRST, before this process touches the GPU: launched after the in-flight legs (four streams, two of them high-priority,
     # still alive in this process) the profiled child hung in about every second run until its timeout (profiles/README.md).
@@ -179,9 +192,15 @@ def main():
     if args.inflight > 1:
         from madtp_amd.pipeline import InflightRunner
         # one runner for both legs: the headline uses the first args.inflight workers, the parity_mode leg args.parity_inflight
+        from madtp_amd.pipeline import partition_from_env
         n_slots = args.inflight if args.no_parity else max(args.inflight, args.parity_inflight)
-        runner = InflightRunner(w, n_slots, T, B, "cuda", seed0=rank * n_slots,
-                                models=[model] + [w.build("cuda") for _ in range(n_slots - 1)])
+        if args.partition:
+            os.environ["MADTP_INFLIGHT_CUMASK"] = args.partition
+        part = partition_from_env(n_slots, getattr(w, "default_partition", None))
+        # ONE set of weights: the workers run shared replicas of `model` (round 6; four full replicas before: 20 GB allocated)
+        share = os.environ.get("MADTP_INFLIGHT_SHARE", "1") != "0"
+        runner = InflightRunner(w, n_slots, T, B, "cuda", seed0=rank * n_slots, partition=part,
+                                models=model if share else [model] + [w.build("cuda") for _ in range(n_slots - 1)])
         runner.inputs[0] = inp
 
     def run_steps(n):  # n whole forwards: serial on the current stream, or spread over the in-flight workers
@@ -206,11 +225,18 @@ def main():
             torch.cuda.synchronize()
             single = time.perf_counter() - ts
         torch.cuda.synchronize()
+        # how many passes of K steps make the timed region >= --min-seconds: from one untimed pass, the same count on every rank
+        tp = time.perf_counter()
+        run_steps(args.steps)
+        torch.cuda.synchronize()
+        est = mdist.max_over_ranks(time.perf_counter() - tp, device=red_dev)
+        repeats = max(1, min(200, int(-(-args.min_seconds // max(est, 1e-4)))))
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_steps(args.steps)
+        for _ in range(repeats):
+            run_steps(args.steps)
         torch.cuda.synchronize()
         own = time.perf_counter() - t0  # this rank's K steps, before it waits for the others
         if dist is not None:
@@ -218,6 +244,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         hl_high = runner.n_high if runner is not None else 0  # high-priority streams among the workers the headline leg used
+        hl_part = runner.last_partition if runner is not None else None  # CUs per XCD of its workers (CU-masked streams), or None
         weight_bytes = sum(p.numel() * p.element_size() for p in model.parameters())
         hbm_alloc = torch.cuda.max_memory_allocated()  # every replica's weights (f32 + prepared compute-dtype copies), inputs, workspaces
         lens = w.lens(model)
@@ -233,8 +260,8 @@ def main():
             torch.cuda.synchronize()
             instr_elapsed = time.perf_counter() - t1
             prof_rows = hip.profile_end()
-    elapsed = mdist.max_over_ranks(elapsed, device=red_dev)
-    own_max, own_min = mdist.max_over_ranks(own, device=red_dev), mdist.min_over_ranks(own, device=red_dev)
+    elapsed = mdist.max_over_ranks(elapsed, device=red_dev) / repeats  # per pass of K steps
+    own_max, own_min = mdist.max_over_ranks(own, device=red_dev) / repeats, mdist.min_over_ranks(own, device=red_dev) / repeats
 
     images_per_step = w.images_per_sample * B * world
     value = images_per_step * args.steps / elapsed
@@ -270,10 +297,12 @@ def main():
                                           "ms_per_step": round(ms_all / args.steps, 3)}}
 
     headline = args.config == "nlvr"
+    shared_weights = (runner is not None and runner.n > 1 and next(runner.models[1].parameters()) is next(model.parameters()))
     out = {
         "metric": METRIC if headline else f"images/sec forward, {args.config} configuration of BASELINE.json (p={w.p})",
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "timed_passes_of_k_steps": repeats,
+        "timed_seconds": round(elapsed * repeats, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": {"bf16": "bf16", "f16": "f16", "fp32": "f32", "f16x3": "f16x3 (fp32-accurate)"}[args.precision],
         "data": "synthetic",
         "config": {"workload": w.describe(B), "samples_per_gpu": B, "images_per_gpu": w.images_per_sample * B, "temperature": T,
@@ -281,7 +310,9 @@ def main():
                    "tokens_per_layer": lens, "calibrated_at_batch": calib.get("batch"), "parallelism": f"dp{world}",
                    "inflight_per_gpu": args.inflight,
                    "inflight_high_priority_streams": (hl_high if runner is not None else 0),
-                   "model_replicas_resident": (runner.n if runner is not None else 1),
+                   "inflight_cus_per_xcd": (hl_part if runner is not None else None),
+                   "model_replicas_resident": (runner.n if (runner is not None and not shared_weights) else 1),
+                   "inflight_workers_share_weights": shared_weights,
                    "weight_bytes_per_replica": weight_bytes, "hbm_bytes_allocated": hbm_alloc,
                    "gemm_dispatch_hints_while_in_flight": ({"sq_cost": runner.sq_cost, "small_tile": runner.small_tile}
                                                            if runner is not None else None)},
@@ -350,16 +381,18 @@ def main():
         # to `value` (the fast mode, whose match RATE is reported in index_match).
         out["parity_qualified_value"] = out["parity_mode"]["value"]
         out["parity_qualified_precision"] = pm
-    if args.precision != "bf16" and not args.no_bf16_leg and not args.no_parity:  # (--no-parity = the headline leg only: profiling runs)
-        # BASELINE.json config 2 names bf16: the same runner timed on bf16 operands (same kernels on v_mfma_f32_16x16x32_bf16),
-        # so that one line carries the f16 headline, the bf16 figure as BASELINE writes it, and the parity-qualified figure.
+    if args.precision in ("bf16", "f16") and not args.no_bf16_leg and not args.no_parity:  # (--no-parity = the headline leg only: profiling runs)
+        # BASELINE.json config 2 names bf16 (`value` of a default run); the same runner timed in the OTHER fast mode - the same
+        # kernels on v_mfma_f32_16x16x32_f16 / _bf16 - so that one line carries the bf16 figure as BASELINE writes it, the f16
+        # figure (0.93 of the kept sets identical to the oracle instead of 0.17) and the parity-qualified figure.
+        other = "f16" if args.precision == "bf16" else "bf16"
         bn = args.inflight if runner is not None else 1
-        bel = timed_leg("bf16", args.bf16_steps, bn)
-        out["bf16_value"] = round(images_per_step * args.bf16_steps / bel, 1)
-        out["bf16_ms_per_step"] = round(1e3 * bel / args.bf16_steps, 3)
-        out["bf16_leg"] = {"steps": args.bf16_steps, "inflight_per_gpu": bn, "unit": "images/s",
-                           "what": "same workload and runner as `value`, bf16 GEMM / attention operands (BASELINE.json config 2's dtype); "
-                                   "its kept-set match vs the oracle is index_match.bf16"}
+        bel = timed_leg(other, args.bf16_steps, bn)
+        out[f"{other}_value"] = round(images_per_step * args.bf16_steps / bel, 1)
+        out[f"{other}_ms_per_step"] = round(1e3 * bel / args.bf16_steps, 3)
+        out[f"{other}_leg"] = {"steps": args.bf16_steps, "inflight_per_gpu": bn, "unit": "images/s",
+                               "what": f"same workload and runner as `value`, {other} GEMM / attention operands; "
+                                       f"its kept-set match vs the oracle is index_match.{other}"}
     if rank == 0 and world == 1:
         if not args.no_parity:
             modes = sorted({"fp32", "f16x3", "bf16", "f16", args.precision})
@@ -380,6 +413,23 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-executes this command line under torch.distributed.run with N ranks on this
+    node and returns its exit code (rank 0 of the child prints the JSON line)."""
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver: RCCL needs it
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.call(cmd, env=env)
 
 
 def _flat(o):

@@ -82,6 +82,26 @@ float madtp_gemm_set_sq_cost(float cost);
  * (fewer operand re-reads: less CU time per launch).  Process-wide; results do not depend on it.  Returns the previous value. */
 int madtp_gemm_set_small_tile(int cfg);
 
+/* Per-STREAM scheduling attributes (ABI 29; no reference counterpart - the reference runs one batch at a time on the default
+ * stream, compress_nlvr_dtp.py:73-99).  A caller that keeps several forwards in flight on one GPU can give each forward its own
+ * slice of the chip instead of letting the streams time-slice all 256 CUs kernel by kernel:
+ *   madtp_stream_create_cumask  creates a HIP stream restricted to a CU mask (hipExtStreamCreateWithCUMask).  mask = `words`
+ *       32-bit words; on MI355X bit i enables CU (i / 8) of XCD (i % 8) (measured: tools/probes/probe_cumask.hip,
+ *       profiles/r06_cumask_probe.txt); an XCD whose bits are all zero is NOT excluded - the hardware dispatches workgroups round-robin
+ *       over all eight XCDs and treats an empty per-XCD mask as "every CU" - so a partition is "CUs [c0, c0+n) of EVERY XCD".
+ *   madtp_stream_set_sched      tells the library what the stream owns, so that launches on it are sized for it:
+ *       cus_per_xcd (1..32; 0 = unchanged / the whole chip = 32): the persistent GEMM kernels launch 8 * cus_per_xcd workgroups
+ *           and the dispatch rules count rounds over 8 * cus_per_xcd CUs;
+ *       sq_cost (> 0) and small_tile (-1..3): the two hints above for launches on THIS stream only (<= 0 / -2 = follow the
+ *           process-wide setting) - concurrent callers with different needs do not share state.
+ *       Results never depend on these attributes (same arithmetic per output element in every kernel choice).
+ *   madtp_stream_destroy        forgets the attributes and destroys a stream made by madtp_stream_create_cumask.
+ * Attributes may be set for any stream (also one the caller created); up to 64 streams per process carry attributes. */
+int madtp_stream_create_cumask(void** stream_out, const uint32_t* mask, int words);
+int madtp_stream_set_sched(void* stream, int cus_per_xcd, float sq_cost, int small_tile);
+int madtp_stream_get_sched(void* stream, int* cus_per_xcd, float* sq_cost, int* small_tile);
+int madtp_stream_destroy(void* stream);
+
 /* Split-K form for small-M projections (latency-bound at one workgroup per tile): part[s,M,N] (f32, contiguous) holds
  * the partial product of K range s; madtp_splitk_ln then computes
  *   y = LayerNorm(scale * (sum_s part[s] + bias) + residual)          (med.py:246-250,326-328; nlvr_encoder.py:259-271)

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmadtp_hip.so")
 SOURCES = ["gemm.hip", "gemm_pp.hip", "attention.hip", "norm.hip", "prune.hip", "layers.hip", "lmhead.hip", "backward.hip"]
-HEADERS = ["common.h", "gemm_device.h", "gemm_table.h", os.path.join("..", "..", "include", "madtp_hip.h")]
+HEADERS = ["common.h", "internal.h", "gemm_device.h", "gemm_table.h", os.path.join("..", "..", "include", "madtp_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

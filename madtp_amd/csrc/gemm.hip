@@ -973,15 +973,92 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
 static std::atomic<int> g_wg_per_xcd{-1};
 static thread_local int t_wg_cap = 0;  // per-thread override for the launches of one library call (madtp_internal_gemm_wg_cap)
 int madtp_internal_gemm_wg_cap(int cap) { const int prev = t_wg_cap; t_wg_cap = cap > 0 ? cap : 0; return prev; }
-static int gemm_wg_per_xcd() {
-    if (t_wg_cap > 0) return t_wg_cap;
-    int v = g_wg_per_xcd.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char* e = getenv("MADTP_GEMM_WG_PER_XCD");
-        v = e ? atoi(e) : 32;
-        if (v < 1) v = 32;
-        g_wg_per_xcd.store(v, std::memory_order_relaxed);
+
+// Per-stream scheduling attributes (madtp_stream_set_sched, include/madtp_hip.h): what slice of the chip a stream owns (a CU-masked
+// stream of a caller that partitions the GPU between forwards in flight) and that caller's dispatch hints.  Readers are the launch
+// paths (lock-free scan of a small table: a slot's key is published last), writers take the mutex.
+struct StreamSched { int cus_per_xcd; float sq_cost; int small_tile; };
+constexpr int SCHED_SLOTS = 64;
+static std::atomic<void*> g_sched_key[SCHED_SLOTS];
+static std::atomic<int> g_sched_cus[SCHED_SLOTS];
+static std::atomic<float> g_sched_cost[SCHED_SLOTS];
+static std::atomic<int> g_sched_small[SCHED_SLOTS];
+static std::atomic<int> g_sched_used{0};  // number of slots ever handed out (the readers' scan bound; 0 = nobody uses the table)
+static std::mutex g_sched_mu;
+static StreamSched stream_sched(void* stream) {
+    StreamSched r{32, -1.f, -2};
+    const int n = g_sched_used.load(std::memory_order_acquire);
+    for (int i = 0; i < n; i++)
+        if (g_sched_key[i].load(std::memory_order_acquire) == stream && stream) {
+            r.cus_per_xcd = g_sched_cus[i].load(std::memory_order_relaxed);
+            r.sq_cost = g_sched_cost[i].load(std::memory_order_relaxed);
+            r.small_tile = g_sched_small[i].load(std::memory_order_relaxed);
+            break;
+        }
+    return r;
+}
+extern "C" int madtp_stream_set_sched(void* stream, int cus_per_xcd, float sq_cost, int small_tile) {
+    if (!stream || cus_per_xcd < 0 || cus_per_xcd > 32 || small_tile < -2 || small_tile > 3) return MADTP_E_BADARG;
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    const int n = g_sched_used.load(std::memory_order_relaxed);
+    int slot = -1;
+    for (int i = 0; i < n; i++) if (g_sched_key[i].load(std::memory_order_relaxed) == stream) { slot = i; break; }
+    if (slot < 0)
+        for (int i = 0; i < n; i++) if (g_sched_key[i].load(std::memory_order_relaxed) == nullptr) { slot = i; break; }
+    const bool fresh = slot < 0 || g_sched_key[slot].load(std::memory_order_relaxed) != stream;
+    if (slot < 0) {
+        if (n >= SCHED_SLOTS) return MADTP_E_BADARG;
+        slot = n;
     }
+    if (fresh) { g_sched_cus[slot].store(32, std::memory_order_relaxed); g_sched_cost[slot].store(-1.f, std::memory_order_relaxed); g_sched_small[slot].store(-2, std::memory_order_relaxed); }
+    if (cus_per_xcd > 0) g_sched_cus[slot].store(cus_per_xcd, std::memory_order_relaxed);
+    g_sched_cost[slot].store(sq_cost > 0.f ? sq_cost : -1.f, std::memory_order_relaxed);
+    g_sched_small[slot].store(small_tile, std::memory_order_relaxed);
+    g_sched_key[slot].store(stream, std::memory_order_release);
+    if (slot >= n) g_sched_used.store(slot + 1, std::memory_order_release);
+    return 0;
+}
+extern "C" int madtp_stream_get_sched(void* stream, int* cus_per_xcd, float* sq_cost, int* small_tile) {
+    const StreamSched r = stream_sched(stream);
+    if (cus_per_xcd) *cus_per_xcd = r.cus_per_xcd;
+    if (sq_cost) *sq_cost = r.sq_cost;
+    if (small_tile) *small_tile = r.small_tile;
+    return 0;
+}
+static void stream_sched_forget(void* stream) {
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    const int n = g_sched_used.load(std::memory_order_relaxed);
+    for (int i = 0; i < n; i++) if (g_sched_key[i].load(std::memory_order_relaxed) == stream) g_sched_key[i].store(nullptr, std::memory_order_release);
+}
+extern "C" int madtp_stream_create_cumask(void** stream_out, const uint32_t* mask, int words) {
+    if (!stream_out || !mask || words < 1 || words > 32) return MADTP_E_BADARG;
+    hipStream_t s = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    *stream_out = (void*)s;
+    return 0;
+}
+extern "C" int madtp_stream_destroy(void* stream) {
+    if (!stream) return MADTP_E_BADARG;
+    stream_sched_forget(stream);
+    const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    return 0;
+}
+
+// workgroups per XCD of a persistent big-GEMM launch on `stream`: the process / thread setting scaled to the CUs the stream owns
+static int gemm_wg_per_xcd(const StreamSched& ss) {
+    int v = t_wg_cap;
+    if (v <= 0) {
+        v = g_wg_per_xcd.load(std::memory_order_relaxed);
+        if (v < 0) {
+            const char* e = getenv("MADTP_GEMM_WG_PER_XCD");
+            v = e ? atoi(e) : 32;
+            if (v < 1) v = 32;
+            g_wg_per_xcd.store(v, std::memory_order_relaxed);
+        }
+    }
+    if (ss.cus_per_xcd < 32) { v = v * ss.cus_per_xcd / 32; if (v < 1) v = 1; }
     return v;
 }
 
@@ -1099,7 +1176,7 @@ extern "C" int madtp_gemm_splitk_pp(const void* A, const void* W, float* part, i
     g.out_scale = 1.f; g.acc_scale = g.acc_scale2 = acc_scale;
     g.splitk = splits; g.fast_epi = 1;
     g.ntm = (M + 255) / 256; g.ntn = (N + 255) / 256;
-    const int slots_max = (g.ntm * g.ntn * splits + 7) / 8, cap = gemm_wg_per_xcd();
+    const int slots_max = (g.ntm * g.ntn * splits + 7) / 8, cap = gemm_wg_per_xcd(stream_sched(stream));
     const int grid = 8 * (slots_max < cap ? slots_max : cap);
     const int rc = madtp_gemm_pp_launch(&g, OM_F32, 2, 256, grid, stream);
     if (rc) return rc;
@@ -1163,10 +1240,10 @@ static bool sk_workspace(hipStream_t s, SkWorkspace& out) {
 // launch, while the few tiles of a plain last round run ~25 % faster than in a full round (no contention), so with K = 768
 // (12 slabs, ~13 us per lone tile) the split loses 4-10 us and with K = 3072 it wins 6-14 us (M = 11-14 k rows, N = 768).
 constexpr int SK_MIN_SLABS = 32;
-static float ws_cost(int t256, int nk, bool sk) {
-    const int nsl = (t256 + 7) / 8, rounds = nsl / 32, rem = nsl - rounds * 32;
+static float ws_cost(int t256, int nk, bool sk, int cpx = 32) {
+    const int nsl = (t256 + 7) / 8, rounds = nsl / cpx, rem = nsl - rounds * cpx;
     if (rem == 0) return (float)rounds;
-    const int parts = (sk && nk >= SK_MIN_SLABS) ? sk_parts(rem, 32, nk) : 0;
+    const int parts = (sk && cpx == 32 && nk >= SK_MIN_SLABS) ? sk_parts(rem, 32, nk) : 0;
     return (float)rounds + (parts ? 0.65f : 1.0f);
 }
 
@@ -1231,6 +1308,8 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     // The wave-specialised 256x128 kernel takes a problem once its tiles fill most of the chip (>= 200 of 256 CUs) - e.g. not
     // the 4480 x 768 GEMMs of a 128-pair re-ranking batch (108 tiles), which run better on 420 64x128 tiles.
     int cfg = 0;
+    const StreamSched ss = stream_sched(stream);  // the CUs this stream owns (32 per XCD unless the caller said otherwise) + its hints
+    const int cpx = ss.cus_per_xcd, ncu = 8 * cpx;
     const int t256 = ((M + 255) / 256) * ((N + 127) / 128);
     // Thresholds of the big-tile kernels (persistent 256-row tiles): M >= 4096 and most of the chip covered - what a lone launch
     // wants (latency).  MADTP_GEMM_BIG_MIN_M / _TILES lower them (experiments with several forwards in flight, where a launch's
@@ -1238,16 +1317,17 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     static int big_min_m = -1, big_min_t = -1;
     if (big_min_m < 0) { const char* e = getenv("MADTP_GEMM_BIG_MIN_M"); big_min_m = e ? atoi(e) : 4096; if (big_min_m < 256) big_min_m = 256; }
     if (big_min_t < 0) { const char* e = getenv("MADTP_GEMM_BIG_MIN_TILES"); big_min_t = e ? atoi(e) : 200; if (big_min_t < 1) big_min_t = 1; }
-    const bool big = !m_dev.p && M >= big_min_m && t256 >= big_min_t;
+    const int big_min_tiles = cpx == 32 ? big_min_t : (big_min_t * ncu + 255) / 256;  // "most of the chip" = most of the stream's CUs
+    const bool big = !m_dev.p && M >= big_min_m && t256 >= big_min_tiles;
     const bool lp16 = ab_dtype != MADTP_F32;  // 2-byte operand planes: bf16, or f16-split (three times the slab stream)
     if (lp16 && !big) {
         const int t64 = ((M + 63) / 64) * ((N + 63) / 64) * splitk, t64x128 = ((M + 63) / 64) * ((N + 127) / 128) * splitk;
-        if (t64 <= 768) cfg = 3;
-        else if (t64x128 <= 768) cfg = 1;
+        if (t64 <= 3 * ncu) cfg = 3;
+        else if (t64x128 <= 3 * ncu) cfg = 1;
     }
     const int auto_cfg = cfg;  // the kernel choice below follows the AUTOMATIC tile rule; the hint only picks among the small tiles
     if (lp16 && !big) {
-        const int small = gemm_small_tile();  // scheduling hint (madtp_gemm_set_small_tile), -1 = the rule above
+        const int small = ss.small_tile > -2 ? ss.small_tile : gemm_small_tile();  // scheduling hint (per stream, else madtp_gemm_set_small_tile), -1 = the rule above
         if (small >= 0 && small <= 3) cfg = small;
     }
     // MADTP_GEMM_CFG=5 forces the wave-specialised kernel, 1..4 force a gemm_kernel variant (A/B measurements)
@@ -1256,7 +1336,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
     if (pair) {
         static int pair_env = -1;  // MADTP_GEMM_PAIR=0: always two launches (A/B runs)
         if (pair_env < 0) { const char* e = getenv("MADTP_GEMM_PAIR"); pair_env = e ? atoi(e) : 1; }
-        ws_ok = pair_env && lp16 && force_cfg == 0 && M >= big_min_m && 2 * t256 >= big_min_t && g.fast_epi &&
+        ws_ok = pair_env && lp16 && force_cfg == 0 && M >= big_min_m && 2 * t256 >= big_min_tiles && g.fast_epi &&
                 aligned16(pair->A) && aligned16(pair->W) && aligned16(pair->C) && (!pair->bias || aligned16(pair->bias));
         if (!ws_ok) return PAIR_UNSUPPORTED;
         g.pair = 1; g.A2 = (const char*)pair->A; g.W2 = (const char*)pair->W; g.bias2 = pair->bias; g.C2 = pair->C;
@@ -1285,7 +1365,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         g.ntm = (M + BM_ - 1) / BM_;                                                                                   \
         g.ntn = (N + BN_ - 1) / BN_;                                                                                   \
         const int slots_max = ((g.ntm * g.ntn + 7) / 8) * g.splitk;                                                    \
-        const int per_xcd = 32 * WGCU;                                                                                 \
+        const int per_xcd = cpx * WGCU;                                                                                \
         const int grid = 8 * (slots_max < per_xcd ? slots_max : per_xcd);                                              \
         const size_t lds = (size_t)(BM_ + BN_) * ROWB * ST_;                                                           \
         MADTP_ENSURE_MAX_LDS((gemm_kernel<TT, LP, BM_, BN_, ST_>), lds);                                               \
@@ -1320,8 +1400,9 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         const bool pp_can = (K % 128) == 0;
         pp_ok = pp_can && (force_cfg == 9 || force_cfg == 10 || (force_cfg == 0 && pp_env));
         const bool sq_allowed = sq_env && ((!f16 && !x3) || pp_ok);
-        float unit = gemm_sq_cost();
+        float unit = ss.sq_cost > 0.f ? ss.sq_cost : gemm_sq_cost();
         if (pp_ok && unit > 1.5f) unit = 1.5f;
+        const bool hinted = ss.sq_cost > 0.f || cpx != 32 || g_sq_cost_hinted.load(std::memory_order_relaxed);  // (the table was measured on the whole idle chip)
         // Choice for an automatic launch: (1) the measured table (gemm_table.h: per (operand class, N, K, output) and 64-row bucket
         // of M the fastest of {wave-specialised 256x128, ping-pong 256x256, ping-pong 192x256} on an idle MI355X; MADTP_GEMM_TABLE=0
         // turns it off; it steps aside while a caller's in-flight hint is in force), else (2) the round-count cost model.
@@ -1332,13 +1413,13 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
         else if (force_cfg == 9 && pp_can) choice = 1;
         else if (force_cfg == 10 && pp_can) choice = 2;
         else if (force_cfg == 0 && sq_allowed && ws_ok) {
-            if (pp_ok && tab_env && (tab_env == 2 || !g_sq_cost_hinted.load(std::memory_order_relaxed)))
+            if (pp_ok && tab_env && cpx == 32 && (tab_env == 2 || !hinted))
                 choice = gemm_table_lookup(x3, M, N, K, c_dtype == MADTP_F32);
             if (choice < 0) {
-                const float cost_ws = ws_cost(t256, K / 64, sk_on);
-                const float cost_sq = 2 * t_sq >= big_min_t ? unit * (float)((t_sq + 255) / 256) : 1e9f;
+                const float cost_ws = ws_cost(t256, K / 64, sk_on, cpx);
+                const float cost_sq = 2 * t_sq >= big_min_tiles ? unit * (float)((t_sq + ncu - 1) / ncu) : 1e9f;
                 // a 192-row tile: 3/4 of the MFMAs of a 256-row one behind the same barriers and 7/8 of its DMA stream (measured ~0.8)
-                const float cost_192 = (pp_ok && 2 * t_192 >= big_min_t) ? 0.8f * unit * (float)((t_192 + 255) / 256) : 1e9f;
+                const float cost_192 = (pp_ok && 2 * t_192 >= big_min_tiles) ? 0.8f * unit * (float)((t_192 + ncu - 1) / ncu) : 1e9f;
                 choice = (cost_192 < cost_sq && cost_192 < cost_ws) ? 2 : (cost_sq < cost_ws ? 1 : 0);
             }
         }
@@ -1360,7 +1441,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
             g.ngrp = (grp > 0 && grp < g.ntn) ? grp : 0;
         }
         const int slots_max = (g.ntm * g.ntn + 7) / 8;
-        const int cap = gemm_wg_per_xcd();
+        const int cap = gemm_wg_per_xcd(ss);
         const int grid = 8 * (slots_max < cap ? slots_max : cap);
         const size_t lds = (size_t)2 * (256 + 256) * ROWB;
         if (pp_ok) {
@@ -1388,7 +1469,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, const fl
             g.ngrp = (on && G < g.ntn) ? G : 0;
         }
         const int slots_max = (g.ntm * g.ntn * (g.pair ? 2 : 1) + 7) / 8;
-        const int cap = gemm_wg_per_xcd();
+        const int cap = gemm_wg_per_xcd(ss);
         const int grid = 8 * (slots_max < cap ? slots_max : cap);
         if (sk_on && grid == 256) { g.sk = 1; g.sk_ws = skw.ws; g.sk_tick = skw.tick; }
         const size_t lds = (size_t)3 * (256 + 128) * ROWB;

@@ -372,7 +372,7 @@ extern "C" int madtp_split_f16_weight(const float* w, int ldw, void* dst, int n,
     return 0;
 }
 
-extern "C" int madtp_abi_version(void) { return 28; }
+extern "C" int madtp_abi_version(void) { return 29; }
 
 extern "C" const char* madtp_strerror(int code) {
     switch (code) {

@@ -13,7 +13,7 @@ import torch
 F32, BF16, F16S, F16 = 0, 1, 2, 3  # F16S: f16-split operand planes of the fp32-accurate GEMM (include/madtp_hip.h), torch.float16
 #                                    F16: plain IEEE f16 operands (the "f16" fast mode), see set_lp_format below
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmadtp_hip.so")
@@ -27,6 +27,10 @@ _SIGS = {
     "madtp_gemm_set_config": (c_int, [c_int]),
     "madtp_gemm_set_sq_cost": (c_float, [c_float]),
     "madtp_gemm_set_small_tile": (c_int, [c_int]),
+    "madtp_stream_create_cumask": (c_int, [c_void_p, c_void_p, c_int]),
+    "madtp_stream_set_sched": (c_int, [c_void_p, c_int, c_float, c_int]),
+    "madtp_stream_get_sched": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "madtp_stream_destroy": (c_int, [c_void_p]),
     "madtp_set_score_fast": (c_int, [c_int]),
     "madtp_gemm_splitk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "madtp_splitk_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -335,6 +339,89 @@ def set_score_fast(on):
 def gemm_set_small_tile(cfg):
     """madtp_gemm_set_small_tile (include/madtp_hip.h): tile configuration of the small problems, -1 = automatic.  -> previous."""
     return int(load().madtp_gemm_set_small_tile(int(cfg)))
+
+
+# ---- per-stream scheduling attributes (include/madtp_hip.h, ABI 29) ------------------------------------------------------------------
+XCDS, CUS_PER_XCD = 8, 32  # MI355X
+
+
+def cu_mask_words(cu0, ncus):
+    """The CU mask of "CUs [cu0, cu0 + ncus) of EVERY XCD" as 32-bit words: on MI355X mask bit i enables CU i // 8 of XCD i % 8
+    (profiles/r06_cumask_probe.txt); an XCD cannot be excluded (an all-zero per-XCD mask means every CU)."""
+    if not (0 <= cu0 and ncus >= 1 and cu0 + ncus <= CUS_PER_XCD):
+        raise ValueError(f"CU range [{cu0}, {cu0 + ncus}) outside 0..{CUS_PER_XCD}")
+    words = [0] * (XCDS * CUS_PER_XCD // 32)
+    for cu in range(cu0, cu0 + ncus):
+        for x in range(XCDS):
+            i = cu * XCDS + x
+            words[i // 32] |= 1 << (i % 32)
+    return words
+
+
+class MaskedStream:
+    """A HIP stream that owns CUs [cu0, cu0 + ncus) of every XCD (madtp_stream_create_cumask) wrapped as a torch stream
+    (`.stream`, a torch.cuda.ExternalStream); the library sizes its persistent launches on it for 8 * ncus CUs.
+    HIP streams behind a handle are POOLED, never destroyed while the process lives: torch's caching allocator keeps blocks (and
+    pending events) tagged with a stream it has seen, and destroying that stream under it aborts the process - close() / collection
+    return the stream to the pool, the next MaskedStream of the same device and CU range takes it over."""
+
+    def __init__(self, cu0, ncus, device=None, sq_cost=0.0, small_tile=-2):
+        self.cu0, self.ncus = int(cu0), int(ncus)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        key = (self.device.index, self.cu0, self.ncus)
+        with _MASKED_LOCK:
+            free = _MASKED_POOL.get(key)
+            self.ptr = free.pop() if free else 0
+        if not self.ptr:
+            words = cu_mask_words(self.cu0, self.ncus)
+            arr = (ctypes.c_uint32 * len(words))(*words)
+            out = c_void_p(0)
+            with torch.cuda.device(self.device):
+                _check(load().madtp_stream_create_cumask(ctypes.byref(out), arr, len(words)), "madtp_stream_create_cumask")
+            self.ptr = int(out.value)
+        _check(load().madtp_stream_set_sched(self.ptr, self.ncus, float(sq_cost), int(small_tile)), "madtp_stream_set_sched")
+        self.stream = torch.cuda.ExternalStream(self.ptr, device=self.device)
+        _MASKED[self.ptr] = (self.cu0, self.ncus, float(sq_cost), int(small_tile))
+
+    def close(self):
+        ptr, self.ptr = getattr(self, "ptr", 0), 0
+        if ptr:
+            _MASKED.pop(ptr, None)
+            with _MASKED_LOCK:
+                _MASKED_POOL.setdefault((self.device.index, self.cu0, self.ncus), []).append(ptr)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_MASKED_POOL = {}  # (device, cu0, ncus) -> idle HIP stream pointers
+_MASKED_LOCK = _threading.Lock()
+_MASKED = {}  # stream pointer -> (cu0, ncus, sq_cost, small_tile) of the live MaskedStreams
+
+
+def masked_stream_info(stream_ptr):
+    """(cu0, ncus, sq_cost, small_tile) if the stream was made by MaskedStream, else None"""
+    return _MASKED.get(int(stream_ptr))
+
+
+def stream_set_sched(stream, cus_per_xcd=0, sq_cost=0.0, small_tile=-2):
+    """madtp_stream_set_sched for any torch stream: cus_per_xcd 0 = unchanged, sq_cost <= 0 / small_tile -2 = the process-wide hints."""
+    ptr = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
+    if ptr == 0:
+        raise ValueError("the null stream cannot carry scheduling attributes")
+    _check(load().madtp_stream_set_sched(ptr, int(cus_per_xcd), float(sq_cost), int(small_tile)), "madtp_stream_set_sched")
+
+
+def stream_get_sched(stream):
+    ptr = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
+    a, b, c = c_int(0), c_float(0), c_int(0)
+    load().madtp_stream_get_sched(ptr, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+    return a.value, b.value, c.value
 
 
 def gemm_pair(a0, a1, w0, w1, bias0, bias1, n, out_dtype=None):

@@ -58,16 +58,88 @@ def _hints_exit():
             _hint_prev = (None, None)
 
 
+def shared_replica(model):
+    """A second instance of `model` for another forward in flight that SHARES every parameter, buffer and prepared (compute-dtype)
+    weight with it and owns only the per-call records the forward leaves on its modules (`last_prune`, `score_side`, the encoder
+    runs, ...).  Round 6 (the review's item 1): four in-flight forwards used to hold four full replicas - 4 x 1.04 GB of f32
+    parameters plus their prepared copies, and four address ranges of the same W competing for the L2s / the Infinity Cache.
+    The module tree is copied shallowly: each module object is new (own attribute slots), `_parameters` / `_buffers` are the SAME
+    dicts as the original's (a load_state_dict or a parameter re-assignment on either is seen by both), `_modules` maps to the
+    copied children, PreparedCache objects are shared (and marked so: a weight prepared by one thread is complete before another
+    thread's stream reads it)."""
+    import copy
+    import torch.nn as nn
+    from .runtime import PreparedCache
+    memo = {}
+
+    def clone(m):
+        c = memo.get(id(m))
+        if c is not None:
+            return c
+        c = copy.copy(m)  # new object, shallow copy of __dict__
+        memo[id(m)] = c
+        c._modules = type(m._modules)((k, (clone(v) if v is not None else None)) for k, v in m._modules.items())
+        for stale in ("_enc_weights", "_last_run", "_prepared_weights", "_madtp_params", "_madtp_params_epoch"):
+            c.__dict__.pop(stale, None)  # per-instance derived state: rebuilt on first use (from the shared caches)
+        return c
+
+    root = clone(model)
+
+    def remap(v):
+        if isinstance(v, nn.Module):
+            return memo.get(id(v), v)
+        if isinstance(v, list):
+            return [remap(x) for x in v] if any(isinstance(x, nn.Module) for x in v) else v
+        if isinstance(v, tuple):
+            return tuple(remap(x) for x in v) if any(isinstance(x, nn.Module) for x in v) else v
+        return v
+
+    for c in list(memo.values()):
+        for k, v in list(c.__dict__.items()):
+            if k in ("_modules", "_parameters", "_buffers"):
+                continue
+            if isinstance(v, PreparedCache):
+                v.shared = True
+            else:
+                nv = remap(v)
+                if nv is not v:
+                    c.__dict__[k] = nv
+    return root
+
+
+def partition_from_env(n, default=None):
+    """MADTP_INFLIGHT_CUMASK="8,8,8,8" (CUs per XCD of worker 0, 1, ...; they are laid out one after the other: worker i owns CUs
+    [sum(c[:i]), sum(c[:i+1])) of every XCD), "0" / "off" = no partition (priority streams), unset = `default`."""
+    import os
+    env = os.environ.get("MADTP_INFLIGHT_CUMASK", "").strip().lower()
+    if not env:
+        return default
+    if env in ("0", "off", "none"):
+        return None
+    part = [int(x) for x in env.split(",") if x.strip()]
+    if len(part) < n or sum(part[:n]) > 32 or min(part) < 1:
+        raise ValueError(f"MADTP_INFLIGHT_CUMASK={env!r}: need {n} positive CU counts per XCD with a sum <= 32")
+    return part[:n]
+
+
 class InflightRunner:
     """n_inflight workers, each = (model replica, resident inputs, HIP stream, host thread).  run(steps) executes `steps` forwards
     in total, step i on worker i % n, every worker's steps in order on its own stream; returns after all of them completed."""
 
-    def __init__(self, workload, n_inflight, temperature, batch, device="cuda", seed0=0, models=None):
+    def __init__(self, workload, n_inflight, temperature, batch, device="cuda", seed0=0, models=None, partition=None):
+        """models: one model per worker, or ONE model (the workers then run shared_replica()s of it: one set of weights).
+        partition: None = all workers on the whole chip, told apart by stream priority (rounds 3-5), or a list of CUs per XCD
+        per worker - every worker then runs on a CU-masked stream that owns its slice of every XCD (hip.MaskedStream; an
+        MI355X XCD cannot be masked out as a whole, profiles/r06_cumask_probe.txt)."""
         self.w, self.T, self.n = workload, temperature, int(n_inflight)
         self.device = torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
+        if models is not None and not isinstance(models, (list, tuple)):
+            models = [models] + [shared_replica(models) for _ in range(self.n - 1)]
         self.models = list(models) if models is not None else [workload.build(self.device) for _ in range(self.n)]
+        self.partition = list(partition) if partition else None
+        self._masked = {}  # (worker count, worker) -> hip.MaskedStream
         self.inputs = [workload.inputs(batch, seed=seed0 + i) for i in range(self.n)]
         import os
         # stream priorities: the first n // 2 workers (at least one) HIGH, the others normal (HIP has these two levels;
@@ -111,6 +183,16 @@ class InflightRunner:
             self.errors.append(e)
             self.stop.set()
 
+    def _partition_for(self, n):
+        """CUs per XCD of the n workers of a run(): the configured partition when it names exactly n workers, an even split of its
+        total otherwise (a leg that uses fewer workers than slots still owns the same CUs)."""
+        if self.partition is None or n < 2:
+            return None
+        if len(self.partition) == n:
+            return self.partition
+        total = min(32, sum(self.partition))
+        return [total // n + (1 if i < total % n else 0) for i in range(n)]
+
     def run(self, steps, workers=None):
         """workers (optional): use only the first `workers` of the n in-flight slots (bench.py times the headline with two and
         the parity mode with three of the same runner: a second runner's fresh streams may share hardware queues with the
@@ -122,12 +204,22 @@ class InflightRunner:
             high = [i < len(self.prio_env) and self.prio_env[i] < 0 for i in range(self.n)]
         else:
             high = [i < max(1, n // 2) for i in range(self.n)]
+        part = self._partition_for(n)
         for i in range(n):
+            if part is not None:
+                key = (tuple(part), i)
+                if key not in self._masked:
+                    from . import hip
+                    self._masked[key] = hip.MaskedStream(sum(part[:i]), part[i], device=self.device,
+                                                         sq_cost=self.sq_cost or 0.0, small_tile=-2 if self.small_tile is None else self.small_tile)
+                self.streams[i] = self._masked[key].stream
+                continue
             pr = -1 if high[i] else 0
             if pr not in self._by_prio[i]:
                 self._by_prio[i][pr] = torch.cuda.Stream(device=self.device, priority=pr)
             self.streams[i] = self._by_prio[i][pr]
-        self.n_high = sum(1 for i in range(n) if high[i])
+        self.n_high = 0 if part is not None else sum(1 for i in range(n) if high[i])
+        self.last_partition = part
         self.stop.clear()
         used = [self.streams[i] for i in range(n)]
         for s in used:
@@ -136,7 +228,8 @@ class InflightRunner:
         mode = runtime.get_precision()
         threads = [threading.Thread(target=self._work, args=(i, per[i], mode), name=f"madtp-inflight-{i}")
                    for i in range(self.n) if per[i]]
-        hinted = len(threads) > 1 and _hints_enter(self.sq_cost, self.small_tile)
+        # (CU-masked streams carry their hints themselves - madtp_stream_set_sched - and leave the process-wide state alone)
+        hinted = len(threads) > 1 and part is None and _hints_enter(self.sq_cost, self.small_tile)
         try:
             for t in threads:
                 t.start()

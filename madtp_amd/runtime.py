@@ -184,9 +184,18 @@ class PreparedCache:
 
     def __init__(self):
         self._store = {}
+        self._lock = threading.RLock()
+        self.shared = False  # set by pipeline.shared_replica: several module replicas (host threads, streams) read this cache
 
     def get(self, key, params, builder):
         sig = ((get_precision(), _UPDATE_EPOCH[0]),) + tuple((p.data_ptr(), p._version, p.device) if p is not None else None for p in params)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with self._lock:  # replicas that share this cache (pipeline.shared_replica) may miss at the same time: one of them builds
+            return self._build(key, sig, builder)
+
+    def _build(self, key, sig, builder):
         hit = self._store.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]
@@ -194,6 +203,10 @@ class PreparedCache:
         prev = hit[1] if (hit is not None and hit[0][0][0] == sig[0][0] and len(hit[0]) == len(sig)
                           and all((a is None) == (b is None) and (a is None or (a[0] == b[0] and a[2] == b[2])) for a, b in zip(hit[0][1:], sig[1:]))) else None
         val = builder(prev) if getattr(builder, "_takes_prev", False) else builder()
+        if self.shared and torch.cuda.is_available():
+            # other host threads will use `val` on THEIR streams: its preparation kernels (casts, splits) must have completed,
+            # not merely been enqueued on this thread's stream (rare: once per weight and precision mode)
+            torch.cuda.current_stream().synchronize()
         self._store.pop(key, None)
         self._store[key] = (sig, val)
         while len(self._store) > self.MAX_ENTRIES:  # bounded: keys may embed id() of caller tensors (a fresh space_dict per call)
@@ -304,6 +317,7 @@ class EncoderWeights:
 
 
 _SIDE = {}
+_SIDE_HANDLES = {}  # MaskedStream handles of side streams that follow a CU-masked main stream
 
 
 def side_stream(device=None):
@@ -313,7 +327,13 @@ def side_stream(device=None):
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=dev)
+        info = hip.masked_stream_info(key[1])
+        if info is not None:  # the main stream owns a slice of the chip (hip.MaskedStream): its side work stays on the same CUs
+            h = hip.MaskedStream(info[0], info[1], device=torch.device("cuda", dev), sq_cost=info[2], small_tile=info[3])
+            _SIDE_HANDLES[key] = h
+            _SIDE[key] = h.stream
+        else:
+            _SIDE[key] = torch.cuda.Stream(device=dev)
     return _SIDE[key]
 
 

@@ -113,3 +113,79 @@ def test_inflight_runner_equals_serial_forwards(name, B, mode):
         assert all(torch.equal(a, b) for a, b in zip(_flat(runner.last[0]), serial[0]))
         assert all(torch.equal(a, b) for a, b in zip(_flat(runner.last[1]), keep))
     assert runtime.get_precision() == "bf16"  # the caller's (default) mode is untouched outside the context
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name,B,mode,part", [("nlvr", 4, "f16x3", [8, 8, 8, 8]), ("nlvr", 6, "f16", [16, 16]), ("nlvr", 4, "fp32", [12, 12, 4, 4]),
+                                              ("retrieval", 6, "bf16", [11, 11, 10])])
+def test_partitioned_runner_with_shared_weights_equals_serial_forwards(name, B, mode, part):
+    """Round 6: the workers run on CU-masked streams (hip.MaskedStream: CUs [c0, c0+n) of every XCD, persistent GEMM grids sized
+    for the slice) and SHARE one set of parameters and prepared weights (pipeline.shared_replica).  Outputs, per-layer token
+    counts and every worker's records are bit-identical to the same forwards run one after the other on the whole chip."""
+    from madtp_amd import build, configs, hip, runtime, workloads
+    from madtp_amd.pipeline import InflightRunner, shared_replica
+    build.build(verbose=False)
+    hip.load()
+    w = workloads.get(name)
+    T, _ = configs.temperature_for(name, w.default_batch, w.p)
+    n = len(part)
+    with runtime.precision(mode), torch.no_grad():
+        model = w.build("cuda")
+        runner = InflightRunner(w, n, T, B, "cuda", seed0=3, models=model, partition=part)
+        assert runner.models[0] is model
+        p0 = {k: v.data_ptr() for k, v in model.named_parameters()}
+        for r in runner.models[1:]:
+            assert r is not model and {k: v.data_ptr() for k, v in r.named_parameters()} == p0  # one set of weights
+            assert all(a is not b for a, b in zip(r.modules(), model.modules()))                   # distinct record holders
+        serial = [[t.clone() for t in _flat(w.step(model, runner.inputs[i], T))] for i in range(n)]
+        lens = []
+        for i in range(n):
+            w.step(runner.models[i], runner.inputs[i], T)
+            lens.append(w.lens(runner.models[i]))
+        mem0 = torch.cuda.memory_allocated()
+        for steps in (n, 3 * n + 1, 5 * n):
+            runner.run(steps)
+            assert runner.last_partition == part and runner.n_high == 0
+            for i in range(n):
+                for a, b in zip(_flat(runner.last[i]), serial[i]):
+                    assert torch.equal(a, b), (steps, i, (a - b).abs().max().item())
+                assert w.lens(runner.models[i]) == lens[i]
+        for i in range(n):
+            assert hip.stream_get_sched(runner.streams[i])[0] == part[i]
+        # the replicas added no parameter memory: what the runs left allocated is scratch, far below one more replica (~1 GB)
+        assert torch.cuda.memory_allocated() - mem0 < 0.6 * sum(p.numel() * 4 for p in model.parameters())
+        # fewer workers than slots: the same CUs split evenly
+        runner.run(4, workers=2)
+        assert len(runner.last_partition) == 2 and sum(runner.last_partition) == sum(part)
+        for i in range(2):
+            assert all(torch.equal(a, b) for a, b in zip(_flat(runner.last[i]), serial[i]))
+
+
+def test_stream_sched_attributes_and_cu_mask_words():
+    from madtp_amd import build, hip
+    build.build(verbose=False)
+    hip.load()
+    words = hip.cu_mask_words(8, 8)
+    assert len(words) == 8 and sum(bin(x).count("1") for x in words) == 64
+    assert all(((words[i // 32] >> (i % 32)) & 1) == (1 if 8 <= i // 8 < 16 else 0) for i in range(256))
+    s = torch.cuda.Stream()
+    assert hip.stream_get_sched(s) == (32, -1.0, -2)
+    hip.stream_set_sched(s, 8, 0.9, 0)
+    assert hip.stream_get_sched(s) == (8, pytest.approx(0.9), 0)
+    hip.stream_set_sched(s, 0, 0.0, -2)  # CUs unchanged, hints back to the process-wide ones
+    assert hip.stream_get_sched(s) == (8, -1.0, -2)
+    # a GEMM on a masked stream gives the bits of the same GEMM on the whole chip (persistent grid of 8 x 8 workgroups)
+    a = torch.randn(12288, 768, device="cuda").bfloat16()
+    wt = torch.randn(2304, 768, device="cuda").bfloat16()
+    ref = hip.gemm(a, wt)
+    m = hip.MaskedStream(4, 8)
+    m.stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(m.stream):
+        out = hip.gemm(a, wt)
+    m.stream.synchronize()
+    assert torch.equal(out, ref)
+    ptr = m.ptr
+    m.close()  # back to the pool (HIP streams under torch's allocator are never destroyed): the next handle of that range reuses it
+    assert hip.masked_stream_info(ptr) is None
+    m2 = hip.MaskedStream(4, 8)
+    assert m2.ptr == ptr and hip.stream_get_sched(m2.stream)[0] == 8
