@@ -47,12 +47,97 @@ def gemm_summary(rows, dtype, min_m=0):
     return sum(r["ms"] for r in sel), sum(r["flops"] for r in sel), sum(r["launches"] for r in sel)
 
 
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured with a float4 copy)
+
+
+def gemm_class(r, rows_patch):
+    """the forward's big-GEMM classes by (N, K): the Linear each launch is (vit.py:77,92,31-35; nlvr_encoder.py:177-178)"""
+    N, K = r["N"], r["K"]
+    if (N, K) == (768, 768):
+        return "patch_embed" if r["M"] == rows_patch else "proj"
+    return {(2304, 768): "qkv", (3072, 768): "fc1", (768, 3072): "fc2", (1536, 768): "text_kv_pair"}.get((N, K), f"N{N}_K{K}")
+
+
+def quant_ceiling(M, N, pair=False):
+    """best share of full rounds over the three big tiles on 256 CUs: what tile quantisation alone allows a LONE launch"""
+    best = 0.0
+    for bm, bn in ((256, 256), (192, 256), (256, 128)):
+        t = -(-M // bm) * -(-N // bn) * (2 if pair else 1)
+        useful = (M * N * (2 if pair else 1)) / float(bm * bn)  # tiles' worth of real output
+        best = max(best, useful / (-(-t // 256) * 256))
+    return round(best, 3)
+
+
+def roofline_by_class(rows, dtype, min_m, peak_tf, rows_patch):
+    """every class against ITS bound: arithmetic intensity (algorithmic flop / algorithmic byte) below the ridge peak_tf / 8 TB/s
+    = HBM-bound (proj: f16 A in, f32 residual in, f32 out), else MFMA-bound."""
+    ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+    agg = {}
+    for r in rows:
+        if r["dtype"] != dtype or r["M"] < min_m:
+            continue
+        a = agg.setdefault(gemm_class(r, rows_patch), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "q": 0.0})
+        a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += r["launches"]
+        a["q"] += r["flops"] * quant_ceiling(r["M"], r["N"], pair=(r["N"], r["K"]) == (1536, 768))
+    out = {}
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        tf, gbs, ai = a["flops"] / (a["ms"] * 1e-3) / 1e12, a["bytes"] / (a["ms"] * 1e-3) / 1e9, a["flops"] / a["bytes"]
+        hbm = ai < ridge
+        out[k] = {"bound": "hbm" if hbm else "mfma", "launches": a["launches"], "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
+                  "achieved_tflops": round(tf, 1), "achieved_gbs": round(gbs, 1), "flop_per_byte": round(ai, 1),
+                  "frac": round(gbs / HBM_PEAK_GBS if hbm else tf / peak_tf, 4),
+                  "frac_mfma": round(tf / peak_tf, 4), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4),
+                  "tile_quantisation_ceiling": round(a["q"] / a["flops"], 3), "share_of_big_gemm_time": None}
+    tot = sum(a["ms"] for a in agg.values()) or 1.0
+    for k in out:
+        out[k]["share_of_big_gemm_time"] = round(agg[k]["ms"] / tot, 3)
+    return out
+
+
 def gemm_breakdown(rows, steps):
     out = []
     for r in sorted(rows, key=lambda r: -r["ms"]):
         out.append(f"{r['dtype']:5s} M={r['M']:6d} N={r['N']:5d} K={r['K']:5d} calls/step={r['launches'] / steps:5.1f} "
                    f"ms/step={r['ms'] / steps:7.3f} TFLOP/s={r['flops'] / r['ms'] / 1e9:7.1f}")
     return "\n".join(out)
+
+
+# the SQ counter pass of measure_traffic (8 SQ slots + the GRBM block; MI355X_MICROARCH.md "rocprofv3 PMC slots")
+SQ_PASS = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+           "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "GRBM_GUI_ACTIVE")
+
+
+def sq_summary(c, big):
+    """MFMA-busy and the wave-cycle split of the big-GEMM launches of one --pmc pass (tools/rocpd_sq.py prints the same per kernel):
+    mfma_busy = SUM SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) = share of the launches' time a SIMD's matrix pipe is busy;
+    resident = waves per SIMD while the launch runs / 2 (the big kernels hold two waves per SIMD where they are resident: what tile
+    quantisation, ramp-up and drain leave); wait / issue-stall / active = SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over
+    SQ_WAVE_CYCLES (disjoint)."""
+    cols = [q[1] for q in c.execute("pragma table_info(pmc_events)").fetchall()]
+    key = "dispatch_id" if "dispatch_id" in cols else "start"
+    rows = c.execute(f"select name, counter_name, count(distinct {key}), count(*), sum(counter_value) from pmc_events group by name, counter_name").fetchall()
+    tot, gui = {}, 0.0
+    for name, ctr, nd, nrows, v in rows:
+        if not big(name):
+            continue
+        if ctr == "GRBM_GUI_ACTIVE":
+            gui += float(v) / (nrows / nd)  # a free-running cycle count per instance: the instances' average, summed over launches
+        else:
+            tot[ctr] = tot.get(ctr, 0.0) + float(v)
+    if not gui or "SQ_VALU_MFMA_BUSY_CYCLES" not in tot:
+        return None
+    wc = tot.get("SQ_WAVE_CYCLES", 0.0)
+    mops = tot.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0) + tot.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)
+    rep = {"mfma_busy": round(tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024), 4),
+           "mfma_flop_per_clk_per_cu": round(mops * 512.0 / (gui * 256), 1), "mfma_flop_per_clk_per_cu_peak": 4096,
+           "waves_per_simd": round(wc * 4.0 / (gui * 1024), 3) if wc else None,
+           "how": "this run: one rocprofv3 --pmc pass (" + " ".join(SQ_PASS) + ") over a 1-step serial copy of the command, big-GEMM launches only"}
+    if wc:
+        rep.update({"resident": round(min(1.0, wc * 4.0 / (gui * 1024) / 2.0), 4), "wave_cycles_wait": round(tot.get("SQ_WAIT_ANY", 0.0) / wc, 4),
+                    "wave_cycles_issue_stall": round(tot.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4),
+                    "wave_cycles_active": round(tot.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 4)})
+        rep["mfma_busy_while_resident"] = round(rep["mfma_busy"] / rep["resident"], 4) if rep["resident"] else None
+    return rep
 
 
 def measure_traffic(args):
@@ -67,21 +152,30 @@ def measure_traffic(args):
     out = {}
     tmp = tempfile.mkdtemp(prefix="madtp_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        big = lambda name: "gemm_ws_kernel" in name or "gemm_sq_kernel" in name or "gemm_pp_kernel" in name  # noqa: E731  (the big-GEMM kernels)
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
             d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-                   "--config", args.config, "--precision", args.precision, "--steps", "1", "--warmup", "1", "--traffic", "off",
+            pmc = [counter] if counter != "SQ" else list(SQ_PASS)
+            cmd = [exe, "--pmc"] + pmc + ["--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--config", args.config, "--precision", args.precision, "--steps", "1", "--warmup", "1", "--traffic", "off", "--min-seconds", "0",
                    "--no-cpu-baseline", "--no-parity", "--no-bf16-leg", "--no-gemm-events", "--inflight", "1"] + (["--batch", str(args.batch)] if args.batch else [])
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=int(os.environ.get("MADTP_TRAFFIC_TIMEOUT", "150")))
             dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
             if r.returncode != 0 or not dbs:
                 print(f"[bench] traffic pass {counter}: rc {r.returncode}, {len(dbs)} result files; stderr tail: {r.stderr[-600:]}", file=sys.stderr)
+                if counter == "SQ":
+                    break  # (the byte counters stand on their own)
                 return None
             c = sqlite3.connect(dbs[0])
-            rows = c.execute("select name, count(*), sum(counter_value) from pmc_events where counter_name=? group by name",
+            if counter == "SQ":
+                out["SQ"] = sq_summary(c, big)
+                continue
+            # one row per (dispatch, counter, hardware instance): launches = distinct dispatches, bytes = the sum over the instances
+            cols = [q[1] for q in c.execute("pragma table_info(pmc_events)").fetchall()]
+            key = "dispatch_id" if "dispatch_id" in cols else "start"
+            rows = c.execute(f"select name, count(distinct {key}), sum(counter_value) from pmc_events where counter_name=? group by name",
                              (counter,)).fetchall()
-            big = lambda name: "gemm_ws_kernel" in name or "gemm_sq_kernel" in name or "gemm_pp_kernel" in name  # noqa: E731  (the big-GEMM kernels)
             n = sum(cnt for name, cnt, _ in rows if big(name))
             v = sum(val for name, _, val in rows if big(name))
             if not n:
@@ -95,7 +189,7 @@ def measure_traffic(args):
     f_n, f_b = out["FETCH_SIZE"]
     w_n, w_b = out["WRITE_SIZE"]
     return {"bytes_per_launch": int(2 * f_b + w_b), "fetch_size_raw_bytes_per_launch": int(f_b),
-            "write_size_bytes_per_launch": int(w_b), "launches_profiled": f_n,
+            "write_size_bytes_per_launch": int(w_b), "launches_profiled": f_n, "sq": out.get("SQ"),
             "how": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace (separate passes) over a 1-step copy of the "
                    "command, gemm_ws_kernel + gemm_pp_kernel (+ gemm_sq_kernel) launches only; 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md)"}
 
@@ -147,6 +241,8 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start {args.gpus} ranks (python -m torch.distributed.run "
                          f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) or none (bench.py launches them itself)")
+    if os.environ.get("MADTP_BENCH_DRY") == "1":
+        return dry_run(args, world, rank)
     # roofline.traffic comes from two rocprofv3 --pmc passes over a one-step copy of this command (measure_traffic).  They run
     # FIRST, before this process touches the GPU: launched after the in-flight legs (four streams, two of them high-priority,
     # still alive in this process) the profiled child hung in about every second run until its timeout (profiles/README.md).
@@ -284,8 +380,14 @@ def main():
                               "logical product: achieved/peak are in algorithmic 2MNK flops, peak = f16 dense / 3)",
                      "fp32": "gemm_kernel<float> (madtp_gemm)"}[args.precision]
             traffic = pre_traffic
+            sq = (traffic or {}).get("sq")
+            classes = roofline_by_class(prof_rows, dt_name, min_m, peak, w.images_per_sample * B * 196)
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1),
                     "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "mfma_busy": sq["mfma_busy"] if sq else None, "sq_counters": sq,
+                    "by_class": classes,
+                    "note": "`frac` is over ALL big launches against the MFMA peak (the figure of rounds 1-5); by_class prices each Linear "
+                            "against its own bound - proj moves an f32 residual stream in and out and sits below the ridge (HBM-bound)",
                     "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
                     "algorithmic_bytes_per_launch": round(alg_bytes / cnt),
                     "launches_per_step": cnt // args.steps, "kernel_ms_per_step": round(ms / args.steps, 3),
@@ -413,6 +515,35 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def dry_run(args, world, rank):
+    """MADTP_BENCH_DRY=1: the launch / rendezvous / barrier / max-over-ranks / one-JSON-line protocol of this file with a sleep in
+    place of the GPU forward (gloo, no GPU touched) - what tests/test_distributed_cpu.py runs as `python bench.py --gpus 2` so that
+    the first multi-GPU lease cannot fail in argument or launcher handling.  The figures mean nothing."""
+    from madtp_amd import dist as mdist
+    mdist.init("gloo")
+    dist = torch.distributed if world > 1 else None
+    for _ in range(args.warmup):
+        time.sleep(0.0005)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.0005)
+    if dist is not None:
+        dist.barrier()
+    elapsed = mdist.max_over_ranks(time.perf_counter() - t0, device="cpu")
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": round(128 * world * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+                          "data": "dry-run: sleep instead of the forward, no GPU work (MADTP_BENCH_DRY=1)",
+                          "config": {"workload": "dry-run", "parallelism": f"dp{world}"}, "dry_run": True}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def self_launch(n):

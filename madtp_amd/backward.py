@@ -93,14 +93,17 @@ def _check_mode(what):
 def _cached(key, tensors, build):
     """build() memoised per (key, identity and version of the source tensors): padded / concatenated / transposed / split copies of
     parameters are made once per parameter VERSION (an optimizer step bumps it) instead of in every backward."""
-    from .runtime import update_epoch
-    ver = tuple((t.data_ptr(), (t._version, update_epoch()), tuple(t.shape)) for t in tensors)  # (update_epoch: fused optimizers, runtime.py)
+    from .runtime import update_epoch, param_step_count
+    # (version, per-parameter optimizer step count, process-wide epoch of hand edits: fused optimizers bump no version, runtime.py)
+    ver = tuple((t.data_ptr(), (t._version, param_step_count(t), update_epoch()), tuple(t.shape)) for t in tensors)
     hit = _CACHE.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
     # (the entry holds its sources alive, so the same addresses and shapes ARE the same parameters at an older version: a builder
-    #  that asks for it gets the previous value - the f16-split scale of a weight is reused across optimizer steps, runtime.SCALE_REUSE)
-    same = hit is not None and len(hit[0]) == len(ver) and all(a[0] == b[0] and a[2] == b[2] for a, b in zip(hit[0], ver))
+    #  that asks for it gets the previous value - the f16-split scale of a weight is reused across OPTIMIZER STEPS, runtime.SCALE_REUSE:
+    #  every source that changed was changed by a step; a load_state_dict / copy_ / hand edit prepares from scratch)
+    same = (hit is not None and len(hit[0]) == len(ver) and all(a[0] == b[0] and a[2] == b[2] for a, b in zip(hit[0], ver))
+            and all(a[1] == b[1] or (a[1][1] != b[1][1] and a[1][2] == b[1][2]) for a, b in zip(hit[0], ver)))
     val = build(hit[1] if same else None) if getattr(build, "_takes_prev", False) else build()
     if len(_CACHE) > 4096:
         _CACHE.clear()
@@ -461,16 +464,32 @@ def _note_versions(ctx, params):
     """the backward reads the module's CURRENT parameters (W^T planes per parameter version) next to activations of the forward: an
     in-place update between the two (optimizer.step, load_state_dict, an EMA) would pair them wrongly - native autograd raises
     'modified by an inplace operation' there, so do these Functions"""
-    from .runtime import update_epoch
-    ctx.param_versions = (update_epoch(),) + tuple(p._version if p is not None else -1 for p in params)
+    ctx.param_versions = _versions_of(params)
+
+
+def _versions_of(params):
+    """(process-wide epoch of hand edits, then per parameter: version and optimizer step count).  The step count is per PARAMETER
+    (runtime._on_optimizer_step): a step of another optimizer - a second model, a GAN's other half, a teacher - between this
+    module's forward and backward does not touch it."""
+    from .runtime import update_epoch, param_step_count
+    return (update_epoch(),) + tuple((p._version, param_step_count(p)) if p is not None else -1 for p in params)
 
 
 def _check_versions(ctx, params, what):
-    from .runtime import update_epoch
-    now = (update_epoch(),) + tuple(p._version if p is not None else -1 for p in params)
+    now = _versions_of(params)
     if now != ctx.param_versions:
         raise RuntimeError(f"{what}: a parameter was modified in place between forward and backward (versions {ctx.param_versions} -> "
                            f"{now}); back-propagate before the optimizer step / load_state_dict, as native autograd requires")
+
+
+def _second_backward_guard(ctx, what):
+    """The first backward releases the kept activations (ctx.saved); a second one over a retained graph recomputes the layer - which is
+    the same forward only WITHOUT dropout / DropPath (the recompute draws no masks).  In model.train() with active rates that would be
+    gradients of a different forward than the one that produced the loss: refuse instead."""
+    if ctx.bwd_done and ctx.had_drop:
+        raise RuntimeError(f"{what}: a second backward over a retained graph of a forward that applied dropout / DropPath is not supported "
+                           "(the kept activations and masks were released by the first backward); run the forward again")
+    ctx.bwd_done = True
 
 
 _WARNED_IMPLICIT = [False]
@@ -650,6 +669,7 @@ class VitBlockFunction(torch.autograd.Function):
         _note_versions(ctx, params)
         prune = temperature > 0
         ctx.saved = None
+        ctx.had_drop, ctx.bwd_done = bool(blk.training and float(getattr(blk, "drop_path_rate", 0.0) or 0.0) > 0.0), False
         if _save_forward() or (blk.training and float(getattr(blk, "drop_path_rate", 0.0) or 0.0) > 0.0):  # (DropPath: the kept forward only)
             if getattr(blk, "attn_mask", None) is not None and getattr(blk, "_mask_dev", None) is None:
                 blk._weights()  # (creates the device copy of CLIP's text attention mask)
@@ -669,6 +689,7 @@ class VitBlockFunction(torch.autograd.Function):
         x, ta = ctx.saved_tensors
         ta = ta if ctx.has_ta else None
         _check_versions(ctx, _BlockParts(ctx.blk).params(), "Block backward")
+        _second_backward_guard(ctx, "Block backward")
         mask = getattr(ctx.blk, "_mask_dev", None) if getattr(ctx.blk, "attn_mask", None) is not None else None
         # (the full [ctx, ctx] mask: the kernels read its leading [N, N] corner through the row stride, clip/mock.py:309-310)
         dp_out = None
@@ -975,6 +996,7 @@ class MedLayerFunction(torch.autograd.Function):
         em = enc_masks if enc_masks is not None else (None, None)
         ctx.causal = causal
         ctx.saved = None
+        ctx.had_drop, ctx.bwd_done = bool(layer.training and (layer.output.dropout.p > 0 or layer.attention.self.dropout.p > 0)), False
         if _save_forward() or (layer.training and (layer.output.dropout.p > 0 or layer.attention.self.dropout.p > 0)):  # (dropout: the
             enc = ([enc0, enc1] if twin else enc0) if cross else None                                                  # kept forward only)
             y, mask_out, info, ctx.saved = med_layer_forward_saved(layer, hidden, mask2d, token_attn, temperature if prune else 0, enc,
@@ -1006,6 +1028,7 @@ class MedLayerFunction(torch.autograd.Function):
         hidden, ta, mask2d, enc0, enc1 = ctx.saved_tensors
         ta = ta if ctx.has_ta else None
         _check_versions(ctx, _med_params_of(ctx.layer, ctx.cross), "BertLayer backward")
+        _second_backward_guard(ctx, "BertLayer backward")
         enc = ([enc0, enc1] if ctx.twin else enc0) if ctx.cross else None
         with torch.no_grad(), _in_mode(ctx.mode):
             dh, dta, denc, grads = med_layer_backward(ctx.layer, hidden, mask2d if ctx.has_mask else None, ta, ctx.temperature,

@@ -97,15 +97,19 @@ __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __res
 // touched (the caller's buffers are zero-initialised once and reused across parameter versions).
 __global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restrict__ w, int ldw, int N, int K, float inv_scale,
                                                             _Float16* __restrict__ planes, int row0, _Float16* __restrict__ planes_t,
-                                                            int Ntp, int col0) {
+                                                            int Ntp, int col0, int* range_flag) {
     __shared__ float tile[64][65];
     const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    bool bad = false;  // a reused scale the weight has outgrown (see split_f16_weight_kernel): raise the range flag
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int n = n0 + ty + 4 * q, k = k0 + tx;
-        tile[ty + 4 * q][tx] = (n < N && k < K) ? w[(size_t)n * ldw + k] * inv_scale : 0.0f;
+        const float v = (n < N && k < K) ? w[(size_t)n * ldw + k] * inv_scale : 0.0f;
+        tile[ty + 4 * q][tx] = v;
+        bad |= f16_range_bad(v);
     }
+    f16_range_raise(range_flag, bad);
     __syncthreads();
     const int c4 = (threadIdx.x & 15) * 4, ry = threadIdx.x >> 4;  // 16 quads x 16 rows
     if (planes) {  // row-major: row n, four consecutive k
@@ -893,7 +897,7 @@ extern "C" int madtp_weight_planes(const float* w, int ldw, int N, int K, float 
     if (K % 4 || (planes_t && (Ntp % 4 || col0 % 4 || col0 + N > Ntp))) return MADTP_E_SHAPE;
     if (((uintptr_t)planes & 7) || ((uintptr_t)planes_t & 7)) return MADTP_E_ALIGN;
     hipLaunchKernelGGL(weight_planes_kernel, dim3((N + 63) / 64, (K + 63) / 64), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, inv_scale,
-                       (_Float16*)planes, row0, (_Float16*)planes_t, Ntp, col0);
+                       (_Float16*)planes, row0, (_Float16*)planes_t, Ntp, col0, madtp_internal_range_flag());
     MADTP_LAUNCH_CHECK();
     return 0;
 }

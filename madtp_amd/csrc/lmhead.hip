@@ -226,8 +226,9 @@ __global__ __launch_bounds__(SP_THREADS) void sample_top_kp_kernel(const float* 
     __shared__ int n_sel;
     __shared__ float sel_v[2 * SP_MAX_K];
     __shared__ int sel_i[2 * SP_MAX_K];
-    __shared__ float ord_v[SP_MAX_K];
-    __shared__ int ord_i[SP_MAX_K];
+    __shared__ float ord_v[2 * SP_MAX_K];
+    __shared__ int ord_i[2 * SP_MAX_K];
+    __shared__ int tie_base;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const float* row = logits + (size_t)b * ld;
     for (int t = tid; t < V; t += SP_THREADS) row_s[t] = row[t];
@@ -259,24 +260,48 @@ __global__ __launch_bounds__(SP_THREADS) void sample_top_kp_kernel(const float* 
     }
     if (tid == 0) n_sel = 0;
     __syncthreads();
+    // Survivors = every score >= the k-th largest: TopKLogitsWarper removes `scores < kth`, so ties AT the k-th score all stay.
+    // (1) the strictly greater ones - fewer than k, any arrival order (they are ranked below); (2) the ties in ascending index order,
+    // as many as the 2 * SP_MAX_K slots hold: chunks of SP_THREADS consecutive indices, a workgroup-wide exclusive count per chunk -
+    // the same survivors whatever the scheduling (arrival order used to decide, and ties were cut to exactly k).
     for (int t = tid; t < V; t += SP_THREADS) {
         const float v = row_s[t];
-        if (f32_order_key(v) >= lo && v > -INFINITY) {
+        if (f32_order_key(v) > lo && v > -INFINITY) {
             const int p = atomicAdd(&n_sel, 1);
             if (p < 2 * SP_MAX_K) { sel_v[p] = v; sel_i[p] = t; }
         }
     }
     __syncthreads();
-    const int ns = min(n_sel, 2 * SP_MAX_K);
-    // rank by (score descending, index ascending); the first k form the top-k set (ties at the k-th score: the lower indices)
+    if (tid == 0) tie_base = min(n_sel, 2 * SP_MAX_K);
+    __syncthreads();
+    for (int base = 0; base < V; base += SP_THREADS) {
+        const int t = base + tid;
+        const float v = t < V ? row_s[t] : 0.f;
+        const bool tie = t < V && f32_order_key(v) == lo && v > -INFINITY;
+        const unsigned long long bal = __ballot(tie);
+        if (lane == 0) cnt_s[tid >> 6] = __popcll(bal);
+        __syncthreads();
+        int before = __popcll(bal & ((1ull << lane) - 1ull));
+        for (int w = 0; w < (tid >> 6); ++w) before += cnt_s[w];
+        int chunk = 0;
+        for (int w = 0; w < SP_THREADS / 64; ++w) chunk += cnt_s[w];
+        const int p = tie_base + before;
+        if (tie && p < 2 * SP_MAX_K) { sel_v[p] = v; sel_i[p] = t; }
+        __syncthreads();
+        if (tid == 0) tie_base = min(tie_base + chunk, 2 * SP_MAX_K);
+        __syncthreads();
+        if (tie_base >= 2 * SP_MAX_K) break;  // (uniform: every thread reads the same shared value)
+    }
+    const int ns = tie_base;
+    // rank by (score descending, index ascending)
     for (int p = tid; p < ns; p += SP_THREADS) {
         int r = 0;
         for (int q = 0; q < ns; ++q) r += (sel_v[q] > sel_v[p] || (sel_v[q] == sel_v[p] && sel_i[q] < sel_i[p])) ? 1 : 0;
-        if (r < k && r < SP_MAX_K) { ord_v[r] = sel_v[p]; ord_i[r] = sel_i[p]; }
+        ord_v[r] = sel_v[p]; ord_i[r] = sel_i[p];
     }
     __syncthreads();
     if (tid == 0) {
-        const int n = min(min(ns, k), SP_MAX_K);
+        const int n = ns;
         if (n <= 0) { out_token[b] = suppress == 0 ? 1 : 0; if (out_prob) out_prob[b] = 0.f; return; }
         const float mx = ord_v[0];
         float z = 0.f;

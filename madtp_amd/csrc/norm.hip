@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
 
 // weight planes [Q0 | Q1] of w * inv_scale (common.h): Q0 = f16(w~), Q1 = f16(w~ - Q0)
 __global__ __launch_bounds__(256) void split_f16_weight_kernel(const float* __restrict__ w, int ldw, _Float16* __restrict__ dst,
-                                                               int K4, size_t total4, float inv_scale) {
+                                                               int K4, size_t total4, float inv_scale, int* range_flag) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
     const size_t row = i / K4;
@@ -184,6 +184,9 @@ __global__ __launch_bounds__(256) void split_f16_weight_kernel(const float* __re
     _Float16* o = dst + row * (size_t)(2 * K4 * 4) + col;
     *(f16x4*)o = q0;
     *(f16x4*)(o + K4 * 4) = q1;
+    // a REUSED scale (runtime.prepare_linear: the previous version's 2^s) that the weight has outgrown: Q0 would be an infinity and
+    // Q1 a NaN - flag it (madtp_range_status) instead of handing the GEMMs non-finite planes
+    f16_range_raise(range_flag, f16_range_bad(v));
 }
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
@@ -367,7 +370,7 @@ extern "C" int madtp_split_f16_weight(const float* w, int ldw, void* dst, int n,
     if (!aligned16(w) || ldw % 4 || ((uintptr_t)dst & 7)) return MADTP_E_ALIGN;
     const size_t total4 = (size_t)n * (K / 4);
     hipLaunchKernelGGL(split_f16_weight_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw,
-                       (_Float16*)dst, K / 4, total4, inv_scale);
+                       (_Float16*)dst, K / 4, total4, inv_scale, madtp_internal_range_flag());
     MADTP_LAUNCH_CHECK();
     return 0;
 }

@@ -44,6 +44,29 @@ class BeamHypotheses:
         return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
 
 
+
+# Pinned host buffers of the asynchronous done / unfinished flag copies: one grow-only buffer per (thread, dtype) instead of a
+# hipHostMalloc + free per generate() call (an allocation of pinned memory is expensive and implicitly synchronising, which partly
+# undid the sync-free loop).  A call's view is refilled before use; calls of one thread do not overlap.
+import threading as _threading
+
+_PINNED = _threading.local()
+
+
+def _pinned_flags(shape, dtype, fill):
+    n = 1
+    for d in shape:
+        n *= int(d)
+    pool = getattr(_PINNED, "pool", None)
+    if pool is None:
+        pool = _PINNED.pool = {}
+    buf = pool.get(dtype)
+    if buf is None or buf.numel() < n:
+        buf = pool[dtype] = torch.empty((max(n, 4096),), dtype=dtype).pin_memory()
+    view = buf[:n].view(*shape)
+    view.fill_(fill)
+    return view
+
 def beam_search(step_fn, input_ids, num_beams, max_length, min_length, eos_token_id, pad_token_id, n_vocab,
                 repetition_penalty=1.0, length_penalty=1.0, early_stopping=False):
     """step_fn(input_ids [B * num_beams, t] on the GPU[, beam_src]) -> f32 last-position scores [B * num_beams, >= n_vocab] (GPU,
@@ -141,7 +164,7 @@ def _beam_search_device(step_fn, takes_src, input_ids, num_beams, max_length, mi
     st = hip.BeamState(B, num_beams, max_length, pad_token_id, dev)
     cur = 0
     st.ids[0][:, :cur_len] = input_ids
-    flags = torch.zeros((max_length, B), dtype=torch.int32).pin_memory()
+    flags = _pinned_flags((max_length, B), torch.int32, 0)
     pending = []
     beam_src = None
     while True:
@@ -195,7 +218,7 @@ def sample(step_fn, input_ids, max_length, min_length, eos_token_id, pad_token_i
     unfinished = torch.ones((B,), dtype=torch.int64, device=dev)
     # no host round trip per step (round 5): the rows' unfinished flags reach the host through asynchronous copies polled without
     # blocking; steps queued after every row has finished only append pad tokens, which are cut off below
-    flags = torch.ones((max_length + 1, B), dtype=torch.int64).pin_memory()
+    flags = _pinned_flags((max_length + 1, B), torch.int64, 1)
     pending, n_steps = [], None
     while True:
         logits = step_fn(input_ids, beam_src=None) if takes_src else step_fn(input_ids)

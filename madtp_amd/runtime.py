@@ -136,6 +136,11 @@ class Lin:
         self.w, self.b, self.n, self.log2_scale, self.age = w, b, n, log2_scale, age
 
 
+def param_step_count(p):
+    """how many optimizer steps have updated parameter p in this process (the per-parameter update epoch, see _on_optimizer_step)"""
+    return getattr(p, "_madtp_steps", 0)
+
+
 def _pad_rows(w):
     n = w.shape[0]
     npad = (n + 127) // 128 * 128
@@ -150,7 +155,10 @@ def _pad_rows(w):
 # optimizer step re-prepares every weight (their versions change) - ~400 host reads per step.  The scale only has to keep
 # max|w| 2^s inside the f16 range with the low plane clear of the subnormals, which a slowly moving weight does for many steps: a
 # re-preparation of the SAME cache entry reuses the previous s up to SCALE_REUSE times (two binades of headroom above 2^14; a
-# weight that outgrows them raises the library's range flag instead of going wrong silently).
+# weight that outgrows them raises the library's range flag - split_f16_weight_kernel / weight_planes_kernel - instead of going
+# wrong silently).  Reuse is for OPTIMIZER STEPS only (small moves): the cache hands the previous value to the builder only when
+# every changed parameter was changed by an optimizer step since (param_step_count); a load_state_dict / copy_ over the same storage
+# (a checkpoint over random-init weights can be orders of magnitude away) takes a fresh scale from max|w|.
 SCALE_REUSE = 64
 
 
@@ -188,7 +196,8 @@ class PreparedCache:
         self.shared = False  # set by pipeline.shared_replica: several module replicas (host threads, streams) read this cache
 
     def get(self, key, params, builder):
-        sig = ((get_precision(), _UPDATE_EPOCH[0]),) + tuple((p.data_ptr(), p._version, p.device) if p is not None else None for p in params)
+        sig = ((get_precision(), _UPDATE_EPOCH[0]),) + tuple((p.data_ptr(), p._version, p.device, getattr(p, "_madtp_steps", 0)) if p is not None else None
+                                                             for p in params)
         hit = self._store.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]
@@ -199,9 +208,13 @@ class PreparedCache:
         hit = self._store.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]
-        # a builder that takes the entry's previous value (same key, older parameter versions) may reuse parts of it
-        prev = hit[1] if (hit is not None and hit[0][0][0] == sig[0][0] and len(hit[0]) == len(sig)
-                          and all((a is None) == (b is None) and (a is None or (a[0] == b[0] and a[2] == b[2])) for a, b in zip(hit[0][1:], sig[1:]))) else None
+        # a builder that takes the entry's previous value (same key and storage, older parameter versions) may reuse parts of it (the
+        # f16-split scale) - only across optimizer steps: every parameter whose version moved has a step count that moved too, and no
+        # hand edit (parameters_updated) happened in between
+        prev = hit[1] if (hit is not None and hit[0][0] == sig[0] and len(hit[0]) == len(sig)
+                          and all((a is None) == (b is None) and (a is None or (a[0] == b[0] and a[2] == b[2] and (a[1] == b[1] or a[3] != b[3])))
+                                  for a, b in zip(hit[0][1:], sig[1:]))
+                          and any(a is not None and a[3] != b[3] for a, b in zip(hit[0][1:], sig[1:]))) else None
         val = builder(prev) if getattr(builder, "_takes_prev", False) else builder()
         if self.shared and torch.cuda.is_available():
             # other host threads will use `val` on THEIR streams: its preparation kernels (casts, splits) must have completed,
@@ -263,14 +276,18 @@ def param_epoch():
 # In-place parameter UPDATES are normally seen through Parameter._version (every cache signature below carries it) - but not all of
 # them bump it: torch.optim's fused=True implementations (torch._fused_adamw_ and friends) leave _version untouched (checked on this
 # build: a foreach step takes it 0 -> 2, a fused step 0 -> 0), and neither do edits through `.data`.  A stale prepared weight would
-# silently keep multiplying with the old values while LayerNorm parameters (read in place) moved on.  So every optimizer step in the
-# process bumps an update epoch that all signatures carry as well (a global torch.optim step post-hook); code that edits `.data` by
-# hand calls parameters_updated().
+# silently keep multiplying with the old values while LayerNorm parameters (read in place) moved on.  So every optimizer step bumps
+# a step count ON THE PARAMETERS OF THAT OPTIMIZER (a global torch.optim step post-hook walks its param_groups; `_madtp_steps`), which
+# all signatures carry next to the version - scoped per parameter (round 6): a second optimizer, a second model or a frozen inference
+# model in the same process keeps its prepared weights and its forward/backward consistency check.  Code that edits `.data` by hand
+# calls parameters_updated(), which bumps the process-wide epoch (nothing says WHICH parameters moved).
 _UPDATE_EPOCH = [0]
 
 
 def _on_optimizer_step(optimizer, args, kwargs):
-    _UPDATE_EPOCH[0] += 1
+    for group in optimizer.param_groups:
+        for p in group["params"]:
+            p._madtp_steps = getattr(p, "_madtp_steps", 0) + 1
 
 
 try:
@@ -308,7 +325,8 @@ class EncoderWeights:
                 l._weights()  # (collects l._madtp_params)
             self.flat = [p for l in layers for p in l.__dict__["_madtp_params"]]
             self.sig = None
-        sig = (get_precision(), _UPDATE_EPOCH[0], tuple([p._version for p in self.flat]), tuple([p.data_ptr() for p in self.flat]))
+        sig = (get_precision(), _UPDATE_EPOCH[0], tuple([p._version for p in self.flat]), tuple([p.data_ptr() for p in self.flat]),
+               tuple([getattr(p, "_madtp_steps", 0) for p in self.flat]))
         if sig != self.sig:
             ws = [l._weights() for l in layers]
             arr = (ctypes.c_void_p * len(ws))(*[ctypes.addressof(w) for w in ws])

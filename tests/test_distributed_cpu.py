@@ -181,3 +181,36 @@ def test_allreduce_gradients_equals_full_batch(tmp_path):
             assert (a - b).abs().max().item() < 1e-6
         for a, b in zip(outs[r]["grads"][len(ref):], outs[0]["grads"][len(ref):]):
             assert torch.equal(a, b)   # the rank-0-only layer: the same (averaged) gradient everywhere
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as the driver starts its 1-GPU run (no launcher, no WORLD_SIZE): bench.py re-executes itself under
+    torch.distributed.run with 2 ranks and rank 0 prints ONE JSON line with n_gpus 2 (MADTP_BENCH_DRY=1: gloo and a sleep in place of
+    the GPU forward - the launch, rendezvous, barriers, MAX reduction and the line are the real code).  Started by a launcher
+    (WORLD_SIZE set) the same command does not launch again."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(MADTP_BENCH_DRY="1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    # the contract's own command line (a launcher provides the ranks): same line, no second launch
+    port = "29631"
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                        env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    l2 = [l for l in r2.stdout.splitlines() if l.startswith("{")]
+    assert len(l2) == 1 and json.loads(l2[0])["n_gpus"] == 2
+    # a rank count that does not match the launcher's is refused with a message, not a hang
+    r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                        capture_output=True, text=True, timeout=120)
+    assert r3.returncode != 0 and "WORLD_SIZE=2" in (r3.stderr + r3.stdout)

@@ -780,6 +780,24 @@ def test_nucleus_sampling_step_equals_oracle_and_generate_samples():
                                          prev_ids=ids.cuda() if pen != 1.0 else None, repetition_penalty=pen, want_prob=True)
             assert got.cpu().tolist() == ref.tolist(), (V, scale, pen, sup)
             assert ((prob > 0) & (prob <= 1.0 + 1e-6)).all()
+    # ties AT the k-th best score (quantised scores: dozens of equal values): TopKLogitsWarper keeps every tie (it removes `scores <
+    # kth`), and which ones survive must not depend on scheduling - repeated launches give the oracle's tokens every time, also when
+    # the ties outnumber the kernel's 128 survivor slots (the strictly better scores and the lowest-index ties fill them)
+    for V, levels, top_p in ((30524, 40, 0.9), (30524, 40, 0.999), (4096, 6, 0.95)):
+        Vp = (V + 7) // 8 * 8
+        logits = torch.randint(0, levels, (8, Vp), generator=g).float() * 0.25
+        logits[:, :20] += torch.rand(8, 20, generator=g) + levels * 0.25  # twenty distinct leaders, then plateaus of equal scores
+        u = torch.rand(8, generator=g) * 0.999
+        ref = O.sample_step(logits[:, :V], torch.zeros(8, 1, dtype=torch.long), u, top_p, 50, 1.0, -1)
+        runs = [hip.sample_top_p(logits.cuda(), u.cuda(), V, top_p, top_k=50).cpu().tolist() for _ in range(5)]
+        assert all(r == runs[0] for r in runs), "tie handling depends on arrival order"
+        kth = torch.topk(logits[:, :V], 50)[0][:, -1]
+        n_ge = (logits[:, :V] >= kth[:, None]).sum(1)
+        if int(n_ge.max()) <= 128:  # every survivor fits the kernel's slots: the library's result exactly
+            assert runs[0] == ref.tolist(), (V, levels, top_p, n_ge.tolist())
+        else:  # more ties than slots: deterministic, and every draw is a survivor of the library's filter
+            w = O.nucleus_filter(logits[:, :V], top_p, 50)
+            assert all(w[b, t] > -float("inf") for b, t in enumerate(runs[0]))
     # (2) frequencies on one peaked row
     row = (torch.randn(1, 64, generator=g) * 2)
     w = O.nucleus_filter(row, 0.9, 50).softmax(-1)[0]
