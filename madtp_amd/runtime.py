@@ -195,6 +195,17 @@ class PreparedCache:
         self._lock = threading.RLock()
         self.shared = False  # set by pipeline.shared_replica: several module replicas (host threads, streams) read this cache
 
+    # copy.deepcopy(model) / pickling a module: the copy starts with an EMPTY cache (prepared tensors are derived data keyed by the
+    # original's parameter storage; the lock is not copyable)
+    def __deepcopy__(self, memo):
+        return PreparedCache()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.__init__()
+
     def get(self, key, params, builder):
         sig = ((get_precision(), _UPDATE_EPOCH[0]),) + tuple((p.data_ptr(), p._version, p.device, getattr(p, "_madtp_steps", 0)) if p is not None else None
                                                              for p in params)
