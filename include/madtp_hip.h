@@ -684,6 +684,11 @@ int madtp_att_ft_bwd(const float* inner, const float* q, const float* dA, float 
  * (q / k: f32 row views as in madtp_attention_bwd). */
 int madtp_attention_probs(const float* q, const float* k, int ld, const float* key_mask, float* P, int B, int H, int N, float scale,
                           void* stream);  /* key_mask: additive [B,N] over the keys (BERT padding mask, med.py:197-199) or NULL */
+/* The general form (ABI 29): Nq queries against Nk keys per sample (cross-attention med.py:158-162, or a self-attention whose keys
+ * include a cache, med.py:164-168), an optional additive mask over the keys [B,Nk] and over (query, key) pairs [Nq, ld_mqk] (the
+ * decoder's causal mask) -> P f32 [B,H,Nq,Nk]: what `output_attentions=True` adds to BertLayer.forward's tuple (med.py:221, 450-456). */
+int madtp_attention_probs_x(const float* q, const float* k, int ldq, int ldk, const float* key_mask, const float* mask_qk, int ld_mqk,
+                            float* P, int B, int H, int Nq, int Nk, float scale, void* stream);
 size_t madtp_attention_bwd_workspace(int B, int H, int N);
 int madtp_attention_bwd(const float* q, const float* k, const float* v, int ld, const float* key_mask, const float* mask_qk,
                         int ld_mqk, /* mask_qk: additive [N, ld_mqk] over (query, key) pairs - the decoder's causal mask - or NULL */

@@ -77,9 +77,19 @@ class BertEmbeddings(nn.Module):
         self.config = config
 
     def forward(self, input_ids=None, position_ids=None, inputs_embeds=None, past_key_values_length=0):
-        if input_ids is None or position_ids is not None or past_key_values_length != 0:
-            raise NotImplementedError("only the encoder use (input_ids, default positions) is on the pruned forward path")
+        if input_ids is None or position_ids is not None:
+            raise NotImplementedError("only input_ids with the default (consecutive) positions are implemented")
         require_gpu(input_ids, "input_ids")
+        if past_key_values_length:
+            # med.py:66-67: position_ids[:, past : past + L] - the same kernel on the position table from row `past` on
+            p0 = int(past_key_values_length)
+            if p0 + input_ids.shape[1] > self.position_embeddings.weight.shape[0]:
+                raise ValueError("past_key_values_length + sequence length exceeds max_position_embeddings")
+            cdt = compute_dtype()
+            y32, ylp = hip.bert_embed(input_ids.contiguous(), self.word_embeddings.weight, self.position_embeddings.weight[p0:],
+                                      self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps,
+                                      lp=None if cdt == torch.float32 else cdt)
+            return y32
         if torch.is_grad_enabled() and _autograd_precision() and any(p.requires_grad for p in self.parameters()):
             from .backward import EmbeddingsFunction, module_dropout  # training use: gradients for the two tables and the LayerNorm
             y = EmbeddingsFunction.apply(input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
@@ -92,6 +102,14 @@ class BertEmbeddings(nn.Module):
         if ylp is not None:  # the first layer takes the compute-dtype copy from the embedding LayerNorm (no cast launch)
             y32._madtp_lp = (ylp, y32._version)
         return y32
+
+
+class _LinHolder:
+    """weight / bias of a derived (not registered) Linear for runtime.lin_of"""
+    __slots__ = ("weight", "bias")
+
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
 
 
 class BertSelfAttention(nn.Module):
@@ -265,8 +283,38 @@ class _BertLayerBase(nn.Module):
         return super()._apply(fn, recurse)
 
     # ---- forward --------------------------------------------------------------------------------------------
-    def _weights(self):
-        """madtp_bert_layer_w for the layer-level C entry points."""
+    def _head_mask_vec(self, head_mask, device):
+        """a layer's head_mask ([H] or [1,H,1,1], med.py:215-217 via get_head_mask) as the f32 GPU vector [H], kept per caller tensor
+        and version (it keys the prepared, head-scaled value projections)"""
+        H = self.attention.self.num_attention_heads
+        if head_mask.numel() != H:
+            raise NotImplementedError(f"head_mask with {tuple(head_mask.shape)}: one factor per head ([{H}] or [1,{H},1,1]) is supported")
+        store = self.__dict__.setdefault("_hm_vec", {})
+        key = (head_mask.data_ptr(), head_mask._version, tuple(head_mask.shape), head_mask.dtype, str(head_mask.device))
+        hit = store.get(key)
+        if hit is None:
+            if len(store) >= 4:
+                store.clear()
+            hit = store[key] = (head_mask, head_mask.detach().reshape(H).to(device=device, dtype=torch.float32).contiguous())
+        return hit[1]
+
+    def _scaled_value(self, sm, hm):
+        """head_mask (med.py:215-217: attention_probs_dropped * head_mask, a constant per head) as a scaling of the VALUE projection of
+        head h by hm[h]: P_h (hm_h V_h) = hm_h (P_h V_h) - the context, and the head-importance norms the pruning score takes from it
+        (:229-231), are the reference's; the probabilities themselves (and cls_attn's first factor) stay unmasked, as there.  A
+        weight / bias holder for lin_of (one-time weight preparation per head-mask tensor version; not a parameter)."""
+        store = self.__dict__.setdefault("_hm_store", {})
+        wv, bv = sm.value.weight, sm.value.bias
+        sig = (hm.data_ptr(), hm._version, wv.data_ptr(), wv._version, bv.data_ptr(), bv._version)
+        hit = store.get(id(sm))
+        if hit is None or hit[0] != sig:
+            rows = hm.repeat_interleave(sm.attention_head_size)
+            hit = (sig, _LinHolder((wv.detach().float() * rows[:, None]).contiguous(), (bv.detach().float() * rows).contiguous()), hm)
+            store[id(sm)] = hit
+        return hit[1]
+
+    def _weights(self, hm=None):
+        """madtp_bert_layer_w for the layer-level C entry points (hm: a head-mask vector [H] on the GPU, see _scaled_value)."""
         sa, ao = self.attention.self, self.attention.output
         has_cross = hasattr(self, "crossattention")
         # the Parameter objects whose (data_ptr, version, device) key the prepared weights; collected once per module
@@ -284,6 +332,9 @@ class _BertLayerBase(nn.Module):
                 params += list(self.crossattention.parameters())
             self.__dict__["_madtp_params"] = params
 
+        sfx = "" if hm is None else "_hm"
+        val = (lambda sm: sm.value) if hm is None else (lambda sm: self._scaled_value(sm, hm))
+
         def build():
             keep = []
 
@@ -293,7 +344,7 @@ class _BertLayerBase(nn.Module):
                 return hip.lin_struct(l)
 
             w = hip.BertLayerW()
-            w.qkv = L(sa._cache, "qkv", [sa.query, sa.key, sa.value])
+            w.qkv = L(sa._cache, "qkv" + sfx, [sa.query, sa.key, val(sa)])
             w.attn_out = L(ao._cache, "d", [ao.dense])
             w.ln_att_g, w.ln_att_b = f32_ptr(ao.LayerNorm.weight, "LayerNorm parameter"), f32_ptr(ao.LayerNorm.bias, "LayerNorm parameter")
             w.cross, w.variant_nlvr, w.has_merge = 0, int(self.variant == "nlvr"), 0
@@ -304,7 +355,7 @@ class _BertLayerBase(nn.Module):
                     w.cross = 2
                     for br, sm in enumerate((ca.self0, ca.self1)):
                         w.cq[br] = L(sm._cache, "q", [sm.query])
-                        w.ckv[br] = L(sm._cache, "kv", [sm.key, sm.value])
+                        w.ckv[br] = L(sm._cache, "kv" + sfx, [sm.key, val(sm)])
                     w.cdense[0] = L(co._cache, "d0", [co.dense0])
                     w.cdense[1] = L(co._cache, "d1", [co.dense1])
                     if co.merge:
@@ -321,7 +372,7 @@ class _BertLayerBase(nn.Module):
                 else:
                     w.cross = 1
                     w.cq[0] = L(ca.self._cache, "q", [ca.self.query])
-                    w.ckv[0] = L(ca.self._cache, "kv", [ca.self.key, ca.self.value])
+                    w.ckv[0] = L(ca.self._cache, "kv" + sfx, [ca.self.key, val(ca.self)])
                     w.cdense[0] = L(co._cache, "d", [co.dense])
                 w.ln_cross_g, w.ln_cross_b = f32_ptr(co.LayerNorm.weight, "LayerNorm parameter"), f32_ptr(co.LayerNorm.bias, "LayerNorm parameter")
             w.inter = L(self._cache, "inter", [self.intermediate.dense])
@@ -332,15 +383,26 @@ class _BertLayerBase(nn.Module):
             w.dtype = dtype_code()
             return (w, keep)
 
+        if hm is not None:
+            mods = [sa] + ([self.crossattention.self0, self.crossattention.self1] if (has_cross and self.crossattention.twin)
+                           else ([self.crossattention.self] if has_cross else []))
+            held = [self._scaled_value(sm, hm) for sm in mods]
+            return self._cache.get("w_hm", params + [t for h in held for t in (h.weight, h.bias)], build)[0]
         return self._cache.get("w", params, build)[0]
 
     def _forward(self, hidden_states, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask,
                  past_key_value, output_attentions, mode, token_attn, temperature):
         require_gpu(hidden_states, "hidden_states")
-        if past_key_value is not None or output_attentions or head_mask is not None:
-            raise NotImplementedError("decoder caching / attention outputs / head masks are off the pruned forward path")
         hidden = as_f32_contig(hidden_states)
         B, L, D = hidden.shape
+        hm = None
+        if head_mask is not None:  # med.py:215-217; the reference's get_head_mask hands a layer [1,H,1,1] (or [H])
+            hm = self._head_mask_vec(head_mask, hidden.device)
+        if past_key_value is not None or output_attentions:
+            # the rest of med.py:393-407's signature: the layer composed from the single kernels (an inference call; the pruned
+            # encoder forward above never takes these arguments)
+            return self._forward_general(hidden, attention_mask, hm, encoder_hidden_states, encoder_attention_mask, past_key_value,
+                                         output_attentions, mode, token_attn, temperature)
         mask2d = causal = None
         if attention_mask is not None:
             if attention_mask.dim() == 4 and attention_mask.shape[2] == L and attention_mask.shape[3] == L and L > 1:
@@ -366,7 +428,9 @@ class _BertLayerBase(nn.Module):
         cross = mode == 'multimodal'
         # (a call that arrives with a pre-projected K/V cache - rank_answer / teacher-forced decoding against an EncoderKVCache -
         #  has no encoder tokens to differentiate through: it is an inference call whatever the parameters' requires_grad says)
-        if torch.is_grad_enabled() and _autograd_precision() and "_kv_pre" not in self.__dict__:
+        if hm is not None and torch.is_grad_enabled() and (hidden.requires_grad or (token_attn is not None and token_attn.requires_grad)):
+            raise NotImplementedError("head_mask is an inference argument here: the hand-written backward has no head-mask term")
+        if hm is None and torch.is_grad_enabled() and _autograd_precision() and "_kv_pre" not in self.__dict__:
             encs = (list(encoder_hidden_states) if isinstance(encoder_hidden_states, (list, tuple)) else [encoder_hidden_states]) \
                 if (cross and encoder_hidden_states is not None) else []
             if (hidden.requires_grad or (token_attn is not None and token_attn.requires_grad) or any(e.requires_grad for e in encs)
@@ -406,7 +470,7 @@ class _BertLayerBase(nn.Module):
             else:
                 Nk = encoder_hidden_states.shape[1]
                 enc0 = self._enc_operand(encoder_hidden_states)
-        w = self._weights()
+        w = self._weights(hm)
         if causal is not None:  # a copy of the cached struct with this call's causal mask (kept alive by `causal` below)
             w = hip.BertLayerW.from_buffer_copy(w)
             w.self_mask_qk, w.ld_self_mask_qk = causal.data_ptr(), causal.stride(0)
@@ -428,6 +492,140 @@ class _BertLayerBase(nn.Module):
         if mask_out is not None:
             attention_mask = mask_out[:, None, None, :]
         return (y, None, attention_mask)  # present_key_value is not kept (encoder use, use_cache=False)
+
+    def _forward_general(self, hidden, attention_mask, hm, encoder_hidden_states, encoder_attention_mask, past_key_value,
+                         output_attentions, mode, token_attn, temperature):
+        """BertLayer.forward with `past_key_value` and / or `output_attentions=True` (med.py:393-462; nlvr_encoder.py:484-554),
+        composed from the single kernels in the current precision mode.  Returns the reference's tuple: (layer_output,
+        [self-attention probabilities [B,H,L,Lk], cross-attention probabilities [B,H,L',Nk] (NLVR: one per twin branch, :531-543) if
+        output_attentions], present_key_value = (k, v) f32 [B,H,Lk,64] (med.py:174), attention_mask [B,1,1,L'] or the caller's).
+        past_key_value = (k, v) [B,H,Lp,64]: the cached keys / values go in front of this call's (med.py:164-168) - the queries
+        are the L new tokens, the key mask covers Lp + L keys; pruning needs the square probabilities (the reference's Reduce_token
+        dereferences cls_attn = None otherwise, :229,:424) and is refused together with a cache."""
+        from .runtime import lin_of as _lin
+        if torch.is_grad_enabled() and (hidden.requires_grad or (token_attn is not None and token_attn.requires_grad)):
+            raise NotImplementedError("past_key_value / output_attentions are inference arguments here (no hand-written backward)")
+        B, L, D = hidden.shape
+        sa, so = self.attention.self, self.attention.output
+        H, hd = sa.num_attention_heads, sa.attention_head_size
+        scale = 1.0 / math.sqrt(hd)
+        cdt, adt = compute_dtype(), attn_dtype()
+        split = cdt == torch.float16
+        prune = temperature > 0
+        Lp = 0
+        if past_key_value is not None:
+            if prune:
+                raise NotImplementedError("token pruning against cached keys is not a reference code path (Reduce_token needs the "
+                                          "square attention map, med.py:229,424)")
+            Lp = int(past_key_value[0].shape[2])
+        Lk = Lp + L
+        mask2d = causal = None
+        if attention_mask is not None:
+            if attention_mask.dim() != 4 or attention_mask.shape[-1] != Lk:
+                raise ValueError(f"attention_mask {tuple(attention_mask.shape)}: expected [B,1,1 or L,{Lk}]")
+            if attention_mask.shape[2] == 1:
+                mask2d = as_f32_contig(attention_mask[:, 0, 0, :])
+            elif attention_mask.shape[2] == L and Lp == 0:
+                parts = getattr(attention_mask, "_madtp_causal", None)
+                if parts is None:
+                    mask2d = as_f32_contig(attention_mask[:, 0, L - 1, :])
+                    causal = as_f32_contig(attention_mask[0, 0] - mask2d[0][None, :])
+                else:
+                    mask2d, causal = parts
+            else:
+                raise NotImplementedError("a [B,1,L,Lk] mask together with cached keys: feed the new tokens one at a time")
+        if prune and mask2d is None:
+            raise ValueError("attention_mask is required when temperature > 0 (med.py:424)")
+        to_f32 = (lambda t: t if t.dtype == torch.float32 else hip.lp_to_f32(t))
+        val = (lambda sm: sm.value) if hm is None else (lambda sm: self._scaled_value(sm, hm))
+        sfx = "" if hm is None else "_hm"
+        h2 = hidden.view(B * L, D)
+        h_c = to_compute(h2)
+        qkv = _lin(sa._cache, "qkv" + sfx, [sa.query, sa.key, val(sa)])
+        y = hip.gemm(h_c, qkv.w, qkv.b, n=qkv.n, out_dtype=adt)  # [B*L, 3D]: q | k | v (v scaled per head under a head mask)
+        q, k, v = y[:, :D], y[:, D:2 * D], y[:, 2 * D:]
+        v_cache = v if hm is None else hip.gemm(h_c, *(lambda l: (l.w, l.b))(_lin(sa._cache, "v_raw", [sa.value])), n=D, out_dtype=adt)
+        if Lp:
+            def rows(t):  # [B,H,Lp,64] -> [B, Lp, D] in the attention kernels' dtype
+                r = as_f32_contig(require_gpu(t, "past_key_value")).permute(0, 2, 1, 3).reshape(B, Lp, D).contiguous()
+                return r if adt == torch.float32 else hip.cast_bf16(r)
+            pk, pv = rows(past_key_value[0]), rows(past_key_value[1])
+            k = torch.cat([pk, k.reshape(B, L, D)], 1).view(B * Lk, D)
+            v_cache = torch.cat([pv, v_cache.reshape(B, L, D)], 1).view(B * Lk, D)
+            if hm is None:
+                v = v_cache
+            else:  # the cache holds UNSCALED values (the reference masks the probabilities): scale the cached rows like the new ones
+                pvs = hip.gemm(to_compute(as_f32_contig(pv if pv.dtype == torch.float32 else hip.lp_to_f32(pv)).view(B * Lp, D)),
+                               *(lambda l: (l.w, l.b))(self._head_scale_lin(hm, D)), n=D, out_dtype=adt)
+                v = torch.cat([pvs.view(B, Lp, D), v.reshape(B, L, D)], 1).view(B * Lk, D)
+        o, side = hip.attention(q, k, v, B, H, L, Lk, scale, add_mask=mask2d, scores=prune, mask_qk=causal, split=split)
+        present = (to_f32(k).reshape(B, Lk, H, hd).permute(0, 2, 1, 3), to_f32(v_cache).reshape(B, Lk, H, hd).permute(0, 2, 1, 3))
+        extra = ()
+        if output_attentions:
+            extra = (hip.attention_probs_x(to_f32(q).contiguous(), to_f32(k).contiguous(), B, H, L, Lk, scale, key_mask=mask2d,
+                                           mask_qk=causal),)
+        dl = _lin(so._cache, "d", [so.dense])
+        a0 = hip.gemm(o if o.dtype == cdt else to_compute(o), dl.w, dl.b, residual=h2, out_dtype=torch.float32, n=dl.n)
+        att = hip.layernorm(a0, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps)[0].view(B, L, D)  # med.py:246-250
+        if prune:
+            sa.score_side = side
+            att, mask2d = self.Reduce_token(att, 0, temperature, token_attn=token_attn, mask=mask2d)  # med.py:421-437
+            attention_mask = mask2d[:, None, None, :]
+        L2 = att.shape[1]
+        a2 = att.reshape(B * L2, D)
+        if mode == 'multimodal':
+            assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
+            ca, co = self.crossattention, self.crossattention.output
+            if ca.twin:
+                em = encoder_attention_mask if encoder_attention_mask is not None else (None, None)
+                branches = [(ca.self0, encoder_hidden_states[0], self._enc_mask2d(em[0])),
+                            (ca.self1, encoder_hidden_states[1], self._enc_mask2d(em[1]))]
+            else:
+                branches = [(ca.self, encoder_hidden_states, None)]  # (med.py:197-199: the encoder mask is not applied)
+            a_c = to_compute(a2)
+            ctxs, cps = [], []
+            for sm, e, emask in branches:
+                Nk = e.shape[1]
+                ql = _lin(sm._cache, "q", [sm.query])
+                kvl = _lin(sm._cache, "kv" + sfx, [sm.key, val(sm)])
+                cq = hip.gemm(a_c, ql.w, ql.b, n=ql.n, out_dtype=adt)
+                ckv = hip.gemm(self._enc_operand(e), kvl.w, kvl.b, n=kvl.n, out_dtype=adt)
+                c, _ = hip.attention(cq, ckv[:, :D], ckv[:, D:], B, H, L2, Nk, scale, add_mask=emask, split=split)
+                ctxs.append(c if c.dtype == cdt else to_compute(c))
+                if output_attentions:
+                    cps.append(hip.attention_probs_x(to_f32(cq).contiguous(), to_f32(ckv[:, :D]).contiguous(), B, H, L2, Nk, scale,
+                                                     key_mask=emask))
+            if ca.twin:  # nlvr_encoder.py:259-271
+                d0l, d1l = _lin(co._cache, "d0", [co.dense0]), _lin(co._cache, "d1", [co.dense1])
+                d0 = hip.gemm(ctxs[0], d0l.w, d0l.b, n=d0l.n, out_dtype=torch.float32)
+                d1 = hip.gemm(ctxs[1], d1l.w, d1l.b, n=d1l.n, out_dtype=torch.float32)
+                if co.merge:
+                    ml = _lin(co._cache, "mg", [co.merge_layer])
+                    c0 = hip.gemm(to_compute(torch.cat([d0, d1], 1).contiguous()), ml.w, ml.b, residual=a2, out_dtype=torch.float32, n=ml.n)
+                else:
+                    c0 = hip.add_scale(hip.add_scale(d0, d1, 0.5), a2.contiguous(), 1.0)
+            else:
+                cl = _lin(co._cache, "d", [co.dense])
+                c0 = hip.gemm(ctxs[0], cl.w, cl.b, residual=a2, out_dtype=torch.float32, n=cl.n)
+            a2 = hip.layernorm(c0, co.LayerNorm.weight, co.LayerNorm.bias, co.LayerNorm.eps)[0]
+            extra = extra + tuple(cps)
+        il, ol = _lin(self._cache, "inter", [self.intermediate.dense]), _lin(self._cache, "out", [self.output.dense])
+        mid = hip.gemm(to_compute(a2), il.w, il.b, act=hip.ACT_GELU, n=il.n)                                   # med.py:312-315
+        f0 = hip.gemm(mid, ol.w, ol.b, residual=a2, out_dtype=torch.float32, n=ol.n)                            # :326-328
+        yout = hip.layernorm(f0, self.output.LayerNorm.weight, self.output.LayerNorm.bias, self.output.LayerNorm.eps)[0]
+        return (yout.view(B, L2, D),) + extra + (present, attention_mask)
+
+    def _head_scale_lin(self, hm, D):
+        """diag(head-mask per column) as a prepared Linear: scales cached (unscaled) value rows like the scaled value projection"""
+        store = self.__dict__.setdefault("_hm_store", {})
+        sig = (hm.data_ptr(), hm._version)
+        hit = store.get("diag")
+        if hit is None or hit[0] != sig:
+            rows = hm.repeat_interleave(D // hm.numel())
+            hit = (sig, _LinHolder(torch.diag(rows).contiguous(), torch.zeros(D, device=hm.device)))
+            store["diag"] = hit
+        from .runtime import lin_of as _lin
+        return _lin(self._cache, "hm_diag", [hit[1]])
 
     def _enc_operand(self, enc):
         """compute-dtype 2-D copy of an encoder tensor, shared by the 12 layers that receive the same tensor object
@@ -561,6 +759,49 @@ class _BertEncoderBase(nn.Module):
             sd_txt_ft_all = defer.finish()
         return _Out(hidden_states), sd_txt_ft_all
 
+
+    def _run_options(self, hidden_states, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask, past_key_values,
+                     use_cache, output_attentions, output_hidden_states, mode, space_dict, temperature, always_query):
+        """BertEncoder.forward's layer loop WITH the arguments the pruned-encoder call never passes (med.py:478-598;
+        nlvr_encoder.py:570-687): head_mask[i] and past_key_values[i] go to layer i (:509-510, :554-566), use_cache collects every
+        layer's present_key_value (`layer_outputs[-2]`, :571-572), output_attentions the self- / cross-attention probabilities
+        (:573-575), output_hidden_states the layer inputs and the final output (:507-508, :577-578).  One layer call per iteration on
+        the composed path (BertLayer._forward_general); returns (BaseModelOutput-like tuple with .last_hidden_state,
+        .past_key_values, .hidden_states, .attentions, .cross_attentions, sd_txt_ft_all)."""
+        all_hidden = () if output_hidden_states else None
+        all_self = () if output_attentions else None
+        all_cross = () if (output_attentions and mode == 'multimodal') else None
+        next_cache = () if use_cache else None
+        sd_txt_ft_all = None
+        require_gpu(hidden_states, "hidden_states")
+        for i, layer_module in enumerate(self.layer):
+            layer_module.__dict__.pop("_kv_pre", None)
+            if output_hidden_states:
+                all_hidden = all_hidden + (hidden_states,)
+            token_attn = None
+            if space_dict is not None or always_query:
+                if space_dict is None:
+                    raise TypeError("nlvr_encoder.BertEncoder calls txt_query_model unconditionally (:608): space_dict must be given")
+                token_attn, sd_txt_ft_all, _ = self.txt_query_model(hidden_states[:, 1:, :], space_dict, return_token_att=True,
+                                                                    temperature=temperature, acc_ft=sd_txt_ft_all)
+            t = temperature if space_dict is not None else 0
+            lhm = head_mask[i] if head_mask is not None else None
+            hm = layer_module._head_mask_vec(lhm, hidden_states.device) if lhm is not None else None
+            outs = layer_module._forward_general(as_f32_contig(hidden_states), attention_mask, hm, encoder_hidden_states,
+                                                 encoder_attention_mask, past_key_values[i] if past_key_values is not None else None,
+                                                 bool(output_attentions), mode, token_attn, t)
+            hidden_states, attention_mask = outs[0], outs[-1]
+            if use_cache:
+                next_cache = next_cache + (outs[-2],)
+            if output_attentions:
+                all_self = all_self + (outs[1],)
+                if all_cross is not None:
+                    all_cross = all_cross + ((outs[2] if len(outs) == 5 else tuple(outs[2:-2])),)
+        if output_hidden_states:
+            all_hidden = all_hidden + (hidden_states,)
+        out = _Out(hidden_states)
+        out.past_key_values, out.hidden_states, out.attentions, out.cross_attentions = next_cache, all_hidden, all_self, all_cross
+        return out, sd_txt_ft_all
 
     def _apply(self, fn, recurse=True):
         self.__dict__.pop("_enc_weights", None)  # .to() / .half() may replace Parameter objects
@@ -697,6 +938,10 @@ class MedBertEncoder(_BertEncoderBase):
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_values=None, use_cache=None, output_attentions=False,
                 output_hidden_states=False, return_dict=True, mode='multimodal', space_dict=None, temperature=0):
+        if head_mask is not None or past_key_values is not None or use_cache or output_attentions or output_hidden_states:
+            return self._run_options(hidden_states, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask,
+                                     past_key_values, use_cache, output_attentions, output_hidden_states, mode, space_dict,
+                                     temperature, always_query=False)
         return self._run(hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states,
                          encoder_attention_mask, mode, always_query=False)
 
@@ -708,6 +953,10 @@ class NlvrBertEncoder(_BertEncoderBase):
     def forward(self, hidden_states, attention_mask=None, space_dict=None, temperature=0, head_mask=None,
                 encoder_hidden_states=None, encoder_attention_mask=None, past_key_values=None, use_cache=None,
                 output_attentions=False, output_hidden_states=False, return_dict=True, mode='multimodal'):
+        if head_mask is not None or past_key_values is not None or use_cache or output_attentions or output_hidden_states:
+            return self._run_options(hidden_states, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask,
+                                     past_key_values, use_cache, output_attentions, output_hidden_states, mode, space_dict,
+                                     temperature, always_query=True)
         return self._run(hidden_states, attention_mask, space_dict, temperature, encoder_hidden_states,
                          encoder_attention_mask, mode, always_query=True)
 
@@ -764,7 +1013,7 @@ class _BertModelBase(nn.Module):
         return self.get_extended_attention_mask(m)
 
     def _run(self, input_ids, attention_mask, space_dict, temperature, encoder_embeds, encoder_hidden_states,
-             encoder_attention_mask, mode, inputs_embeds=None, is_decoder=False):
+             encoder_attention_mask, mode, inputs_embeds=None, is_decoder=False, past_len=0):
         if input_ids is not None and inputs_embeds is not None:
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
         if inputs_embeds is not None:
@@ -779,8 +1028,15 @@ class _BertModelBase(nn.Module):
         else:
             raise ValueError("You have to specify either input_ids or inputs_embeds or encoder_embeds")
         if attention_mask is None:
-            attention_mask = torch.ones((batch_size, seq_length), device=device)
-        ext = self.get_extended_attention_mask(attention_mask, (batch_size, seq_length), device, is_decoder)
+            attention_mask = torch.ones((batch_size, seq_length + past_len), device=device)  # med.py:842-843
+        if past_len and is_decoder and attention_mask.dim() == 2:
+            # med.py:752-786 with a prefix: a new token sees every cached position and, causally, the new ones; for ONE new token that
+            # is the padding mask over past + 1 keys
+            if seq_length != 1:
+                raise NotImplementedError("is_decoder with past_key_values: feed one new token per call (as generate does)")
+            ext = self.get_extended_attention_mask(attention_mask, (batch_size, seq_length), device, False)
+        else:
+            ext = self.get_extended_attention_mask(attention_mask, (batch_size, seq_length), device, is_decoder)
         if encoder_hidden_states is not None:
             if isinstance(encoder_hidden_states, list):
                 # (None entry: no padding in that image's tokens - the same values as an all-ones mask without its launches)
@@ -791,7 +1047,7 @@ class _BertModelBase(nn.Module):
                 enc_ext = self.invert_attention_mask(encoder_attention_mask)
         else:
             enc_ext = None
-        emb = self.embeddings(input_ids=input_ids) if encoder_embeds is None else encoder_embeds
+        emb = self.embeddings(input_ids=input_ids, past_key_values_length=past_len) if encoder_embeds is None else encoder_embeds
         return emb, ext, enc_ext
 
 
@@ -805,13 +1061,27 @@ class MedBertModel(_BertModelBase):
                 mode='multimodal', space_dict=None, temperature=0, encoder_kv_cache=None):
         """encoder_kv_cache (extension): an EncoderKVCache - the layers' cross-attention then reads the cached [k|v]
         projections of encoder block index[b] for sample b instead of projecting encoder_hidden_states (which may be None)."""
-        if position_ids is not None or head_mask is not None or past_key_values is not None:
-            raise NotImplementedError("position_ids / head_mask / past_key_values (incremental decoding) are not implemented: the "
-                                      "decoder runs teacher-forced (rank_answer)")
+        if position_ids is not None:
+            raise NotImplementedError("position_ids: only the default consecutive positions are implemented")
         if is_decoder and temperature > 0:
             raise NotImplementedError("token pruning inside the causal decoder is not a reference code path")
+        past_len = int(past_key_values[0][0].shape[2]) if past_key_values is not None else 0  # med.py:838
         emb, ext, enc_ext = self._run(input_ids, attention_mask, space_dict, temperature, encoder_embeds,
-                                      encoder_hidden_states, encoder_attention_mask, mode, inputs_embeds, is_decoder)
+                                      encoder_hidden_states, encoder_attention_mask, mode, inputs_embeds, is_decoder, past_len)
+        options = (head_mask is not None or past_key_values is not None or use_cache or output_attentions or output_hidden_states)
+        if options:
+            # the rest of med.py:803-929's signature (incremental decoding through the reference's own past_key_values / use_cache
+            # protocol, attention outputs, head masks): the per-layer composed path of the encoder
+            if encoder_kv_cache is not None:
+                raise NotImplementedError("encoder_kv_cache together with past_key_values / output_attentions / head_mask")
+            n_layers = len(self.encoder.layer)
+            hms = None
+            if head_mask is not None:  # transformers get_head_mask (med.py:875): [H] -> every layer, [layers, H] -> one row per layer
+                hms = [head_mask] * n_layers if head_mask.dim() == 1 else [head_mask[i] for i in range(n_layers)]
+            return self.encoder(emb, attention_mask=ext, head_mask=hms, encoder_hidden_states=encoder_hidden_states,
+                                encoder_attention_mask=enc_ext, past_key_values=past_key_values, use_cache=use_cache,
+                                output_attentions=bool(output_attentions), output_hidden_states=bool(output_hidden_states),
+                                mode=mode, space_dict=space_dict, temperature=temperature)
         if encoder_kv_cache is not None:
             if self.encoder.layer_cls.variant != "med":
                 raise NotImplementedError("encoder_kv_cache is wired for the single-cross-attention (MED) layers")
@@ -951,11 +1221,11 @@ class BertLMHeadModel(nn.Module):
                 reduction='mean', mode='multimodal', space_dict=None, temperature=0, train=False, encoder_kv_cache=None):
         """encoder_kv_cache (extension, as MedBertModel.forward): cached cross-attention [k|v] of the encoder states - sample b
         attends to block index[b], so rank_answer does not tile / re-project the question states per candidate."""
-        if past_key_values is not None or use_cache or output_attentions or output_hidden_states:
-            raise NotImplementedError("incremental decoding / attention outputs are not implemented (teacher-forced forward only)")
         outputs, sd_txt_ft = self.bert(input_ids, attention_mask=attention_mask, position_ids=position_ids, head_mask=head_mask,
                                        inputs_embeds=inputs_embeds, encoder_hidden_states=encoder_hidden_states,
-                                       encoder_attention_mask=encoder_attention_mask, is_decoder=is_decoder, mode=mode,
+                                       encoder_attention_mask=encoder_attention_mask, past_key_values=past_key_values,
+                                       use_cache=use_cache, output_attentions=output_attentions,
+                                       output_hidden_states=output_hidden_states, is_decoder=is_decoder, mode=mode,
                                        space_dict=space_dict, temperature=temperature, encoder_kv_cache=encoder_kv_cache)
         if torch.is_grad_enabled() and _autograd_precision() and outputs[0].requires_grad:
             # training use (SURVEY 8(f) rank 4): the LM head as autograd Functions on the exact-f32 GEMM, the label-smoothed
@@ -997,8 +1267,25 @@ class BertLMHeadModel(nn.Module):
         if not (return_dict if return_dict is not None else True):
             return ((lm_loss, scores) if lm_loss is not None else (scores,))
         out = _LMOut(lm_loss, scores)
+        # med.py:1046-1060: the encoder's optional outputs ride along (the reference's incremental-decoding protocol: past_key_values
+        # in, use_cache=True -> out.past_key_values back)
+        out.past_key_values, out.hidden_states = getattr(outputs, "past_key_values", None), getattr(outputs, "hidden_states", None)
+        out.attentions, out.cross_attentions = getattr(outputs, "attentions", None), getattr(outputs, "cross_attentions", None)
         return (out, sd_txt_ft) if train else out
 
+    def prepare_inputs_for_generation(self, input_ids, past=None, attention_mask=None, **model_kwargs):
+        """med.py:1071-1089: with a cache only the last token is fed; the attention mask covers the whole prefix."""
+        if attention_mask is None:
+            attention_mask = input_ids.new_ones(input_ids.shape)
+        if past is not None:
+            input_ids = input_ids[:, -1:]
+        return {"input_ids": input_ids, "attention_mask": attention_mask, "past_key_values": past,
+                "encoder_hidden_states": model_kwargs.get("encoder_hidden_states", None),
+                "encoder_attention_mask": model_kwargs.get("encoder_attention_mask", None), "is_decoder": True}
+
+    def _reorder_cache(self, past, beam_idx):
+        """med.py:1091-1094"""
+        return tuple(tuple(past_state.index_select(0, beam_idx) for past_state in layer_past) for layer_past in past)
 
     def generate(self, input_ids, max_length=20, min_length=0, num_beams=1, eos_token_id=None, pad_token_id=None,
                  repetition_penalty=1.0, length_penalty=1.0, early_stopping=False, do_sample=False, encoder_hidden_states=None,

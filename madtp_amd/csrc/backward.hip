@@ -979,6 +979,21 @@ extern "C" int madtp_attention_probs(const float* q, const float* k, int ld, con
     return 0;
 }
 
+extern "C" int madtp_attention_probs_x(const float* q, const float* k, int ldq, int ldk, const float* key_mask, const float* mask_qk,
+                                       int ld_mqk, float* P, int B, int H, int Nq, int Nk, float scale, void* stream) {
+    if (!q || !k || !P || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return MADTP_E_BADARG;
+    if (Nq > 1024 || Nk > 1024 || (mask_qk && ld_mqk < Nk)) return MADTP_E_SHAPE;
+    if (ldq % 4 || ldk % 4 || !aligned16(q) || !aligned16(k)) return MADTP_E_ALIGN;
+    AttnBwdArgs a = {};
+    a.q = q; a.k = k; a.ld = ldq; a.ldk = ldk; a.P = P; a.B = B; a.H = H; a.N = Nq; a.Nk = Nk; a.scale = scale; a.key_mask = key_mask;
+    a.mask_qk = mask_qk; a.ld_mqk = ld_mqk;
+    const size_t lds_p = (size_t)(16 * HD + 16 * attn_ns(Nk)) * sizeof(float);
+    MADTP_ENSURE_MAX_LDS(attn_probs_kernel, lds_p);
+    hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, (Nq + 15) / 16), dim3(256), lds_p, (hipStream_t)stream, a);
+    MADTP_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t madtp_attention_bwd_workspace(int B, int H, int N) {
     const size_t pn = (size_t)B * H * N * N * sizeof(float);
     return 2 * pn + (((size_t)B * N * N + 255) & ~(size_t)255);

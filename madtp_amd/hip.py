@@ -122,6 +122,8 @@ _SIGS = {
     "madtp_token_score_bwd": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4
                               + [c_int, c_int, c_int, c_void_p]),
     "madtp_attention_probs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "madtp_attention_probs_x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_float, c_void_p]),
     "madtp_att_ft_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "madtp_attention_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
     "madtp_attention_bwd_cross_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -533,6 +535,19 @@ def attention_probs(q, k, B, H, N, scale, key_mask=None):
         raise RuntimeError("attention_probs: q and k must share their leading dimension")
     P = torch.empty((B, H, N, N), device=q.device, dtype=torch.float32)
     _check(load().madtp_attention_probs(_p(q), _p(k), q.stride(0), _p(key_mask), _p(P), B, H, N, float(scale), _stream()), "madtp_attention_probs")
+    return P
+
+
+def attention_probs_x(q, k, B, H, Nq, Nk, scale, key_mask=None, mask_qk=None):
+    """P = softmax(scale q k^T [+ key_mask[b, j]] [+ mask_qk[i, j]]) f32 [B, H, Nq, Nk] from f32 row views q [B*Nq, >= H*64],
+    k [B*Nk, >= H*64] (madtp_attention_probs_x): cross-attention or cached-key probabilities for output_attentions=True."""
+    for t in (q, k):
+        if not t.is_cuda or t.dtype != torch.float32 or t.stride(1) != 1:
+            raise RuntimeError("attention_probs_x operands must be GPU f32 row-major views")
+    P = torch.empty((B, H, Nq, Nk), device=q.device, dtype=torch.float32)
+    _check(load().madtp_attention_probs_x(_p(q), _p(k), q.stride(0), k.stride(0), _p(key_mask), _p(mask_qk),
+                                          mask_qk.stride(0) if mask_qk is not None else 0, _p(P), B, H, Nq, Nk, float(scale), _stream()),
+           "madtp_attention_probs_x")
     return P
 
 

@@ -1028,3 +1028,156 @@ def test_block_sees_reassigned_parameters_and_replaced_submodules():
         torch.nn.init.zeros_(blk.mlp.fc2.weight); torch.nn.init.zeros_(blk.mlp.fc2.bias)
         y_attn = blk(x).clone()                                                           # mlp contributes exactly 0
     assert (y2 - (y_attn + delta)).abs().max().item() < 1e-4
+
+
+def _rows_check(g, key, t, tol, what, perm=None):
+    """t against a medopts_* record (shape, first 16 columns, row norms); perm [B, rows]: row r of the RECORD is row perm[b, r] of t"""
+    import numpy as np
+    t = t.detach().float().cpu()
+    assert tuple(t.shape) == tuple(int(v) for v in g[key + "_shape"]), (what, key, tuple(t.shape), g[key + "_shape"])
+    if perm is not None:
+        t = torch.stack([t[b][perm[b]] for b in range(t.shape[0])])
+    ref_sl, ref_nrm = torch.from_numpy(g[key + "_sl"]), torch.from_numpy(g[key + "_rownorm"]).float()
+    err = (t[..., :16] - ref_sl).abs().max().item()
+    nerr = ((t.norm(dim=-1) - ref_nrm).abs() / ref_nrm.clamp_min(1e-6)).max().item()
+    assert err < tol and nerr < tol, (what, key, err, nerr)
+
+
+@pytest.mark.parametrize("mode,tol,ptol", [("fp32", 2e-4, 2e-5), ("f16x3", 2e-4, 2e-5), ("f16", 6e-2, 2e-3)])
+def test_bert_layer_signature_options_match_reference_fixture(mode, tol, ptol):
+    """med.py:393-407 beyond the pruned-encoder call - `output_attentions=True`, `head_mask`, `past_key_value` on BertLayer.forward -
+    against the reference's own recording of one layer call each (tests/golden/medopts_b2.npz, tools/make_golden.py::
+    med_layer_options_case): layer outputs, self- and cross-attention probabilities, the returned cache, pruning decisions and the
+    compacted mask.  Kept tokens come out in ascending order here and in topk order there: rows are compared token by token."""
+    import glob
+    import os
+    import numpy as np
+    from madtp_amd import build, hip, runtime
+    from tests import grad_case
+    build.build(verbose=False)
+    hip.load()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "medopts_b2.npz"))
+    c = grad_case.build_med(g)
+    layer = grad_case.build_med_layer(c)
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    hid, mask, ta, T = c["hidden"].cuda(), c["add_mask"].cuda(), c["token_attn"].cuda(), c["T"]
+    enc = c["enc"].cuda()
+    B, L, D = hid.shape
+    Lp, H = int(g["Lp"]), 12
+    hm = torch.from_numpy(g["head_mask"]).view(1, H, 1, 1).cuda()
+    exact = mode in ("fp32", "f16x3")
+
+    def perm_for(info, ref_idx):
+        """record row r (CLS, the reference's kept order, merged) -> own row (CLS, ascending kept, merged)"""
+        k = int(info["indices"].shape[1])
+        own = info["indices"].cpu().numpy()
+        out = []
+        for b in range(B):
+            pos = {int(t): p for p, t in enumerate(own[b])}
+            out.append([0] + [1 + pos[int(t)] for t in ref_idx[b][:k]] + [k + 1])
+        return out
+
+    with runtime.precision(mode), torch.no_grad():
+        # --- output_attentions, unpruned and pruned
+        for tag, t in (("oa0", 0.0), ("oaT", T)):
+            out = layer(hid, mask, None, enc, None, None, True, mode="multimodal", token_attn=ta.clone() if t > 0 else None, temperature=t)
+            assert len(out) == 5  # (layer_output, self probs, cross probs, present_key_value, attention_mask): med.py:456-460
+            y, sp, cp, present, m = out
+            perm = None
+            if t > 0:
+                info = layer.last_prune
+                assert info["pruned"]
+                if exact:
+                    assert sorted(map(tuple, np.sort(info["indices"].cpu().numpy(), 1).tolist())) == \
+                        sorted(map(tuple, np.sort(g["oaT_idx"][:, : info["indices"].shape[1]], 1).tolist()))
+                elif not np.array_equal(np.sort(info["indices"].cpu().numpy(), 1), np.sort(g["oaT_idx"][:, : info["indices"].shape[1]], 1)):
+                    continue  # (fast mode: a flipped decision changes the sequence; the exact modes carry the claim)
+                perm = perm_for(info, g["oaT_idx"])
+            _rows_check(g, tag + "_out", y, tol, (mode, tag), perm)
+            assert (sp.cpu() - torch.from_numpy(g[tag + "_self_probs"])).abs().max().item() < ptol, (mode, tag, "self probs")
+            cpr = cp.cpu() if perm is None else torch.stack([cp[b].cpu()[:, perm[b], :] for b in range(B)])
+            assert (cpr - torch.from_numpy(g[tag + "_cross_probs"])).abs().max().item() < ptol, (mode, tag, "cross probs")
+            _rows_check(g, tag + "_present_k", present[0], tol, (mode, tag))
+            _rows_check(g, tag + "_present_v", present[1], tol, (mode, tag))
+            mo = m[:, 0, 0, :].cpu()
+            mo = mo if perm is None else torch.stack([mo[b][perm[b]] for b in range(B)])
+            assert torch.equal(mo, torch.from_numpy(g[tag + "_mask_out"]))
+        # --- head_mask on the fused layer call (value projections scaled per head)
+        out = layer(hid, mask, hm, enc, None, None, False, mode="multimodal", temperature=0)
+        _rows_check(g, "hm0_out", out[0], tol, (mode, "hm0"))
+        out = layer(hid, mask, hm, None, None, None, False, mode="text", token_attn=ta.clone(), temperature=T)
+        info = layer.last_prune
+        same = np.array_equal(np.sort(info["indices"].cpu().numpy(), 1), np.sort(g["hmT_idx"][:, : info["indices"].shape[1]], 1))
+        assert same or not exact, "head-masked pruning decision differs from the reference"
+        if same:
+            perm = perm_for(info, g["hmT_idx"])
+            _rows_check(g, "hmT_out", out[0], tol, (mode, "hmT"), perm)
+            mo = out[-1][:, 0, 0, :].cpu()
+            assert torch.equal(torch.stack([mo[b][perm[b]] for b in range(B)]), torch.from_numpy(g["hmT_mask_out"]))
+        # head_mask AND output_attentions (composed path): the same output, probabilities unmasked (med.py:203-217)
+        o2 = layer(hid, mask, hm, enc, None, None, True, mode="multimodal", temperature=0)
+        _rows_check(g, "hm0_out", o2[0], tol, (mode, "hm0+oa"))
+        assert (o2[1].cpu() - torch.from_numpy(g["oa0_self_probs"])).abs().max().item() < ptol
+        _rows_check(g, "oa0_present_v", o2[3][1], tol, (mode, "hm0+oa: the cache holds unscaled values"))
+        # --- past_key_value: the cache of the first Lp tokens, then one / two new tokens against it
+        first = layer(hid[:, :Lp].contiguous(), mask[:, :, :, :Lp].contiguous(), None, enc, None, None, True, mode="multimodal", temperature=0)
+        _rows_check(g, "pk0_out", first[0], tol, (mode, "pk0"))
+        past = first[-2]
+        assert past[0].shape == (B, H, Lp, 64)
+        for tag, n_new in (("pk1", 1), ("pk2", 2)):
+            out = layer(hid[:, Lp:Lp + n_new].contiguous(), mask[:, :, :, :Lp + n_new].contiguous(), None, enc, None, past, False,
+                        mode="multimodal", temperature=0)
+            assert len(out) == 3 and out[0].shape == (B, n_new, D)
+            assert (out[0].cpu() - torch.from_numpy(g[tag + "_out"])).abs().max().item() < tol, (mode, tag)
+            _rows_check(g, tag + "_present_k", out[1][0], tol, (mode, tag))
+            _rows_check(g, tag + "_present_v", out[1][1], tol, (mode, tag))
+        with pytest.raises(NotImplementedError):
+            layer(hid[:, Lp:Lp + 1].contiguous(), mask[:, :, :, :Lp + 1].contiguous(), None, enc, None, past, False, mode="multimodal",
+                  token_attn=ta[:, :1].clone(), temperature=T)
+
+
+def test_incremental_decoding_through_the_reference_cache_protocol():
+    """BertLMHeadModel.forward(past_key_values=..., use_cache=True) - the protocol transformers' generate drives through
+    prepare_inputs_for_generation / _reorder_cache (med.py:1071-1094): feeding a sequence one token at a time against the returned
+    caches gives the logits of the full-prefix decoder forward at every position; output_hidden_states / output_attentions ride along."""
+    from madtp_amd import build, hip, runtime, specs
+    from madtp_amd.med import BertConfig, BertLMHeadModel
+    build.build(verbose=False)
+    hip.load()
+    model = BertLMHeadModel(BertConfig.med_default())
+    model.load_state_dict(specs.synth_weights(specs.bert_shapes("bert.", "med"), 5), strict=False)
+    model.tie_weights()
+    model = model.cuda().eval()
+    model.tie_weights()
+    g = torch.Generator().manual_seed(4)
+    B, Lt, Nq = 3, 7, 11
+    ids = torch.randint(1000, 30000, (B, Lt), generator=g).cuda()
+    ids[:, 0] = 30522
+    enc = torch.randn(B, Nq, 768, generator=g).cuda()
+    enc_att = torch.ones(B, Nq, dtype=torch.long).cuda()
+    for mode, tol in (("fp32", 2e-3), ("f16x3", 2e-3), ("f16", 0.15)):
+        with runtime.precision(mode), torch.no_grad():
+            full = model(ids, attention_mask=torch.ones_like(ids), encoder_hidden_states=enc, encoder_attention_mask=enc_att,
+                         return_dict=True, is_decoder=True)
+            past, steps = None, []
+            for t in range(Lt):
+                kw = model.prepare_inputs_for_generation(ids[:, :t + 1], past=past, attention_mask=torch.ones_like(ids[:, :t + 1]),
+                                                         encoder_hidden_states=enc, encoder_attention_mask=enc_att)
+                out = model(**kw, use_cache=True, return_dict=True)
+                past = out.past_key_values
+                assert len(past) == 12 and past[0][0].shape == (B, 12, t + 1, 64)
+                steps.append(out.logits[:, -1, :])
+            inc = torch.stack(steps, 1)
+            scale = full.logits.abs().max().item()
+            assert (inc - full.logits).abs().max().item() < tol * max(1.0, scale), (mode, (inc - full.logits).abs().max().item(), scale)
+            # beam re-ordering of the cache (med.py:1091-1094) and the optional outputs
+            ro = model._reorder_cache(past, torch.tensor([2, 0, 1]).cuda())
+            assert torch.equal(ro[3][1][0], past[3][1][2])
+            out = model(ids, attention_mask=torch.ones_like(ids), encoder_hidden_states=enc, encoder_attention_mask=enc_att,
+                        return_dict=True, is_decoder=True, output_attentions=True, output_hidden_states=True)
+            assert len(out.hidden_states) == 13 and len(out.attentions) == 12 and len(out.cross_attentions) == 12
+            assert out.attentions[0].shape == (B, 12, Lt, Lt) and out.cross_attentions[0].shape == (B, 12, Lt, Nq)
+            assert (out.attentions[5].sum(-1) - 1).abs().max().item() < 1e-4
+            assert out.attentions[5][0, 0, 2, 3:].abs().max().item() < 1e-6  # causal: token 2 does not see tokens 3..
+            assert (out.logits - full.logits).abs().max().item() < tol * max(1.0, scale)

@@ -889,3 +889,60 @@ def test_oracle_philox_matches_random123_known_answers():
     assert [int(round(float(v) * 16777216.0)) for v in u] == [x >> 8 for x in w]
     m = O.dropout_mask(5, 3, (4, 1000), 0.1)
     assert len(set(m.reshape(-1).tolist())) == 2 and abs(float(m.max()) - 1.0 / 0.9) < 1e-6 and abs(float((m > 0).float().mean()) - 0.9) < 0.02
+
+
+def check_rows(g, key, t, tol, what=""):
+    """a hidden-state / cache tensor against its fixture record (medopts_*: shape, the first 16 columns and the L2 norm of every row)"""
+    t = t.detach().float().cpu()
+    assert tuple(t.shape) == tuple(int(v) for v in g[key + "_shape"]), (what, key, tuple(t.shape), g[key + "_shape"])
+    ref_sl, ref_nrm = torch.from_numpy(g[key + "_sl"]), torch.from_numpy(g[key + "_rownorm"])
+    err = (t[..., :16] - ref_sl).abs().max().item()
+    nerr = ((t.double().norm(dim=-1) - ref_nrm).abs() / ref_nrm.clamp_min(1e-6)).max().item()
+    assert err < tol and nerr < tol, (what, key, err, nerr)
+
+
+def options_inputs(g):
+    """(case of tests/grad_case.py::build_med, head_mask [1,H,1,1]) of a medopts_* fixture"""
+    from tests import grad_case
+    c = grad_case.build_med(g)
+    assert np.abs(c["hidden"][:, :2, :8].numpy() - g["h_head"]).max() < 1e-5  # the layer input the reference saw
+    return c, torch.from_numpy(g["head_mask"]).view(1, -1, 1, 1)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "medopts_*.npz"))))
+def test_oracle_bert_layer_options_match_reference_fixture(path):
+    """med.py:393-407's head_mask / past_key_value / output_attentions on ONE BertLayer call, recorded from the reference
+    (tools/make_golden.py::med_layer_options_case): the oracle returns the same layer outputs, attention probabilities, caches,
+    pruning decisions and masks."""
+    g = np.load(path)
+    c, hm = options_inputs(g)
+    W, p, hid, mask, ta, T, enc = c["W"], c["prefix"], c["hidden"], c["add_mask"], c["token_attn"], c["T"], c["enc"]
+    Lp = int(g["Lp"])
+    with torch.no_grad():
+        for tag, t in (("oa0", 0.0), ("oaT", T)):
+            ex = {}
+            y, m, info = O.bert_layer(W, p, hid, mask, t, ta if t > 0 else None, enc, None, "multimodal", 0, "med", extras=ex)
+            check_rows(g, tag + "_out", y, 2e-5, tag)
+            assert (ex["self_probs"] - torch.from_numpy(g[tag + "_self_probs"])).abs().max() < 1e-6
+            assert (ex["cross_probs"] - torch.from_numpy(g[tag + "_cross_probs"])).abs().max() < 1e-6
+            check_rows(g, tag + "_present_k", ex["present"][0], 2e-5, tag)
+            check_rows(g, tag + "_present_v", ex["present"][1], 2e-5, tag)
+            assert np.array_equal(m[:, 0, 0, :].numpy(), g[tag + "_mask_out"])
+            if t > 0:
+                assert np.array_equal(info["indices"].numpy(), g["oaT_idx"][:, : info["k"]])  # (med.py:377: topk(k+1), the first k are kept)
+        y, _, _ = O.bert_layer(W, p, hid, mask, 0.0, None, enc, None, "multimodal", 0, "med", head_mask=hm)
+        check_rows(g, "hm0_out", y, 2e-5, "hm0")
+        y, m, info = O.bert_layer(W, p, hid, mask, T, ta, None, None, "text", 0, "med", head_mask=hm)
+        check_rows(g, "hmT_out", y, 2e-5, "hmT")
+        assert np.array_equal(info["indices"].numpy(), g["hmT_idx"][:, : info["k"]]) and np.array_equal(m[:, 0, 0, :].numpy(), g["hmT_mask_out"])
+        ex = {}
+        y0, _, _ = O.bert_layer(W, p, hid[:, :Lp], mask[:, :, :, :Lp], 0.0, None, enc, None, "multimodal", 0, "med", extras=ex)
+        check_rows(g, "pk0_out", y0, 2e-5, "pk0")
+        past = ex["present"]
+        for tag, n_new in (("pk1", 1), ("pk2", 2)):
+            ex = {}
+            y, _, _ = O.bert_layer(W, p, hid[:, Lp:Lp + n_new], mask[:, :, :, :Lp + n_new], 0.0, None, enc, None, "multimodal", 0, "med",
+                                   past_key_value=past, extras=ex)
+            assert (y - torch.from_numpy(g[tag + "_out"])).abs().max() < 2e-5
+            check_rows(g, tag + "_present_k", ex["present"][0], 2e-5, tag)
+            check_rows(g, tag + "_present_v", ex["present"][1], 2e-5, tag)

@@ -1087,7 +1087,99 @@ def cap_gen_case(name, B, size, temperature, eos_bias, max_length, min_length, s
     print(f"[{name}] T={temperature} eos_bias={eos_bias} vit_lens={lens_v} sequences={seqs.tolist()} steps={len(steps)} ({dt:.1f}s)")
 
 
+def med_layer_options_case(name, B, L, Nimg, temperature, seed=0, pad_tail=0, Lp=5):
+    """The parts of models/med.py BertLayer.forward's signature beyond the pruned-encoder call (med.py:393-407): `output_attentions=True`
+    (self- and cross-attention probabilities in the returned tuple, :170-222, :450-456), `head_mask` ([1,H,1,1]: attention_probs_dropped *
+    head_mask, :215-217) and `past_key_value` (cached self-attention keys / values concatenated in front of the new ones, :164-168; the
+    returned tuple's [-2] is the updated cache, :458-462).  Layer 0 of the reference BertModel on the embeddings of synthetic ids (the
+    inputs tests/grad_case.py::build_med rebuilds); every call under no_grad:
+      oa0 / oaT   output_attentions=True, mode 'multimodal', temperature 0 / T (T: the layer prunes; cross-attention rows are then in
+                  the reference's kept-token order, recorded)
+      hm0 / hmT   head_mask, mode 'multimodal' at temperature 0; mode 'text' at T (kept sets recorded)
+      pk1 / pk2   past_key_value: the layer on the first Lp tokens gives the cache; then ONE new token (and, separately, TWO new tokens
+                  under a [B,1,1,Lp+2] padding mask) against it, mode 'multimodal'"""
+    import models.med as rmed
+    from madtp_amd import specs
+    cfg = rmed.BertConfig.from_json_file("configs/med_config.json")
+    cfg.encoder_width = 768
+    cfg.evaluate = True
+    model = rmed.BertModel(config=cfg, add_pooling_layer=False)
+    model.eval()
+    msg = model.load_state_dict(specs.synth_weights(specs.bert_shapes("", "med"), seed), strict=False)
+    assert not msg.unexpected_keys
+    space_dict = synth.synth_tensor("space_dict", (100, 768), seed)
+    ids = synth.synth_token_ids(B, L, seed + 1)
+    att = torch.ones_like(ids)
+    if pad_tail:
+        for b in range(B):
+            att[b, L - (b % (pad_tail + 1)):] = 0
+    enc = synth.synth_tensor("image_embeds", (B, Nimg, 768), seed).mul(25.0)
+    enc_att = torch.ones(B, Nimg, dtype=torch.long)
+    cap = {}
+    lay = model.encoder.layer[0]
+    hk = lay.register_forward_pre_hook(lambda m, a, kw: cap.update(h=a[0].detach().clone(), mask=a[1].detach().clone(),
+                                                                    ta=kw["token_attn"].detach().clone()), with_kwargs=True)
+    with torch.no_grad():
+        model(ids, attention_mask=att, encoder_hidden_states=enc, encoder_attention_mask=enc_att, return_dict=True, mode="multimodal",
+              space_dict=space_dict, temperature=temperature)
+    hk.remove()
+    enc_mask = model.invert_attention_mask(enc_att)
+    H = cfg.num_attention_heads
+    hm = torch.from_numpy(0.2 + 0.5 * (synth.uniform_pm1("head_mask", H, seed) + 1.0)).float().view(1, H, 1, 1)  # in [0.2, 1.2]
+    rec = {"kind": "med_layer_options", "B": B, "L": L, "Nimg": Nimg, "temperature": np.float64(temperature), "seed": seed, "layer": 0,
+           "pad_tail": pad_tail, "mode": "multimodal", "Lp": Lp, "head_mask": hm.view(H).numpy(), "h_head": cap["h"][:, :2, :8].numpy()}
+
+    def call(hid, mask, head_mask, past, oa, mode, T, tag):
+        tap = GatherTap(rmed)
+        tap.set_tag(tag)
+        with torch.no_grad():
+            out = lay(hid.clone(), mask.clone(), head_mask, enc if mode == "multimodal" else None, enc_mask if mode == "multimodal" else None,
+                      past, oa, mode=mode, space_dict=space_dict, token_attn=cap["ta"].clone() if T > 0 else None, reduce_num=0, temperature=T)
+        tap.restore()
+        rec.update(tap.records)
+        return out
+
+    def put(key, t):
+        """hidden states / caches: the first 16 columns and the L2 norm of every row (the whole tensors would make a 2.7 MB fixture)"""
+        t = t.detach()
+        rec[key + "_shape"] = np.array(t.shape)
+        rec[key + "_sl"] = t[..., :16].numpy().copy()
+        rec[key + "_rownorm"] = t.double().norm(dim=-1).numpy()
+
+    # --- output_attentions
+    for tag, T in (("oa0", 0.0), ("oaT", temperature)):
+        out = call(cap["h"], cap["mask"], None, None, True, "multimodal", T, tag)
+        assert len(out) == 5, len(out)  # (layer_output, self probs, cross probs, present_key_value, attention_mask)
+        put(f"{tag}_out", out[0])
+        rec[f"{tag}_self_probs"], rec[f"{tag}_cross_probs"] = out[1].numpy(), out[2].numpy()
+        put(f"{tag}_present_k", out[3][0])
+        put(f"{tag}_present_v", out[3][1])
+        rec[f"{tag}_mask_out"] = out[4][:, 0, 0, :].numpy()
+    assert rec["oaT_out_shape"][1] < L, "the layer did not prune at this temperature"
+    # --- head_mask
+    out = call(cap["h"], cap["mask"], hm, None, False, "multimodal", 0.0, "hm0")
+    assert len(out) == 3
+    put("hm0_out", out[0])
+    out = call(cap["h"], cap["mask"], hm, None, False, "text", temperature, "hmT")
+    put("hmT_out", out[0])
+    rec["hmT_mask_out"] = out[2][:, 0, 0, :].numpy()
+    # --- past_key_value
+    first = call(cap["h"][:, :Lp], cap["mask"][:, :, :, :Lp], None, None, False, "multimodal", 0.0, "pk0")
+    past = first[1]
+    put("pk0_out", first[0])
+    for tag, n_new in (("pk1", 1), ("pk2", 2)):
+        out = call(cap["h"][:, Lp:Lp + n_new], cap["mask"][:, :, :, :Lp + n_new], None, past, False, "multimodal", 0.0, tag)
+        rec[f"{tag}_out"] = out[0].numpy()
+        put(f"{tag}_present_k", out[1][0])
+        put(f"{tag}_present_v", out[1][1])
+        assert out[1][0].shape[2] == Lp + n_new
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+    print(f"[{name}] T={temperature} oaT_out {rec['oaT_out_shape']} hmT_out {rec['hmT_out_shape']} pk1 {rec['pk1_out'].shape} "
+          f"keys {sorted(k for k in rec if k.endswith('_idx') or k.endswith('_sort'))}")
+
+
 CASES = {
+    "medopts_b2": lambda: med_layer_options_case("medopts_b2", 2, 35, 10, 30.0, pad_tail=1, Lp=20),
     "cap_gen_b2_T6": lambda: cap_gen_case("cap_gen_b2_T6", 2, 224, 6.0, 0.0, 12, 5),
     "cap_gen_b3_T30_eos": lambda: cap_gen_case("cap_gen_b3_T30_eos", 3, 224, 30.0, 2.4, 12, 5, seed=1),
     "vqa_gen_b2": lambda: vqa_gen_case("vqa_gen_b2", 2, 224, 12, 0.0, 0.0),
