@@ -212,7 +212,8 @@ def main():
     ap.add_argument("--parity-steps", type=int, default=32, help="timed steps of the parity_mode leg (f16x3 precision)")
     ap.add_argument("--parity-inflight", type=int, default=4, help="forwards in flight in the parity_mode leg (when the headline "
                     "leg runs more than one in flight)")
-    ap.add_argument("--parity-batch", type=int, default=0, help="samples of the index_match check (0 = --batch for nlvr, 8 else)")
+    ap.add_argument("--parity-batch", type=int, default=0, help="samples of the index_match check (0 = the run's batch: the FULL BASELINE "
+                    "batch of every configuration since round 6 - the oracle's CPU forward of 128 / 128 / 32 samples takes 15-60 s)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "off"], help="roofline.traffic from live rocprofv3 --pmc passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="headline leg only: no parity_mode / bf16 legs, no index_match")
@@ -502,7 +503,7 @@ def main():
                 from oracle.index_match import nlvr_index_match
                 im = nlvr_index_match(model, T, modes, B=args.parity_batch or B, seed=11)
             else:
-                im = generic_index_match(w, model, args.config, T, modes, args.parity_batch or 8)
+                im = generic_index_match(w, model, args.config, T, modes, args.parity_batch or B)
             out["index_match"] = im
             out["parity_mode"]["index_match"] = im.get("f16x3")
             out["parity_mode"]["index_match_batch"] = im["batch"]

@@ -46,6 +46,11 @@ struct AttnArgs {
     float* o_part;  // attn_bf16_large_kernel<.., HV = 2>: f32 scratch [B, Nq, H, 64] (the first key half's P.V sums)
     const int32_t* n_dev;
     int dev_q_only;  // cross-attention on the sync-free path: *n_dev is the number of QUERY tokens per sample, Nk stays the host's
+    // f16x3 mode (attn_f16s_kernel / attn_large_f16s_kernel), round 6: split_dim > 0 = the context leaves the kernel AS the f16-split
+    // operand planes of the GEMM that consumes it - out is then _Float16 [rows, ldo] (ldo in f16 elements), P0 = f16(o) at column c,
+    // P1 = f16((o - P0) 2^11) at column split_dim + c (common.h) - instead of f32 that a separate split_f16 launch re-reads (49
+    // launches per forward); range_flag: the f16 range flag the split raises (madtp_range_status)
+    int split_dim; int* range_flag;
 };
 #define ATTN_DEV_DIMS(a)                                   \
     if ((a).n_dev) {                                       \
@@ -550,9 +555,23 @@ __global__ __launch_bounds__(256) void attn_f16s_kernel(AttnArgs a) {
                 }
             if constexpr (SCORES) n2 = rows4_sum(n2);
             if (i < a.Nq) {
-                float* orow = (float*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 4) + 4 * g;
+                if (a.split_dim) {  // straight into the consumer GEMM's operand planes (8-byte stores per plane)
+                    _Float16* prow = (_Float16*)a.out + ((size_t)b * a.Nq + i) * a.ldo + h * 64 + 4 * g;
+                    bool bad = false;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) *(f32x4*)(orow + dt * 16) = o[dt];
+                    for (int dt = 0; dt < 4; ++dt) {
+                        f16x4 ph_, pl_;
+                        split_f16x4(o[dt], ph_, pl_);
+                        *(f16x4*)(prow + dt * 16) = ph_;
+                        *(f16x4*)(prow + a.split_dim + dt * 16) = pl_;
+                        bad |= f16_range_bad(o[dt]);
+                    }
+                    f16_range_raise(a.range_flag, bad);
+                } else {
+                    float* orow = (float*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 4) + 4 * g;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) *(f32x4*)(orow + dt * 16) = o[dt];
+                }
                 if constexpr (SCORES)
                     if (g == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
             }
@@ -1432,9 +1451,23 @@ __global__ __launch_bounds__(256, 1) void attn_large_f16s_kernel(AttnArgs a) {  
                 }
             if constexpr (SCORES) n2 = rows4_sum(n2);
             if (i < a.Nq) {
-                float* orow = (float*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 4) + 4 * g;
+                if (a.split_dim) {  // straight into the consumer GEMM's operand planes (8-byte stores per plane)
+                    _Float16* prow = (_Float16*)a.out + ((size_t)b * a.Nq + i) * a.ldo + h * 64 + 4 * g;
+                    bool bad = false;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) *(f32x4*)(orow + dt * 16) = o[dt];
+                    for (int dt = 0; dt < 4; ++dt) {
+                        f16x4 ph_, pl_;
+                        split_f16x4(o[dt], ph_, pl_);
+                        *(f16x4*)(prow + dt * 16) = ph_;
+                        *(f16x4*)(prow + a.split_dim + dt * 16) = pl_;
+                        bad |= f16_range_bad(o[dt]);
+                    }
+                    f16_range_raise(a.range_flag, bad);
+                } else {
+                    float* orow = (float*)(a.out + (((size_t)b * a.Nq + i) * a.ldo + h * 64) * 4) + 4 * g;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) *(f32x4*)(orow + dt * 16) = o[dt];
+                }
                 if constexpr (SCORES)
                     if (g == 0) a.onorm[((size_t)b * a.H + h) * a.Nq + i] = sqrtf(n2);
             }
@@ -2219,6 +2252,19 @@ extern "C" int madtp_attention_qk_mask(const void* q, const void* k, const void*
                             ldv, ldo, scale, io_dtype, stream);
 }
 
+// Split-plane output request of the f16x3 layer calls (layers.hip): the NEXT attention launches of this thread with io_dtype
+// MADTP_F16S write their context as f16-split planes (AttnArgs.split_dim; `out` = f16 planes, ldo in f16 elements) when they run on
+// an f16s kernel, and say so through madtp_internal_attn_split_done() - a launch that falls back to another kernel writes f32 as
+// before is impossible with a planes buffer, so the request is only made where the caller checked the same conditions.
+static thread_local int t_split_dim = 0, t_split_done = 0;
+int madtp_internal_attn_split_out(int split_dim) { t_split_dim = split_dim > 0 ? split_dim : 0; t_split_done = 0; return 0; }
+int madtp_internal_attn_split_done() { return t_split_done; }
+bool madtp_internal_attn_f16s_enabled() {
+    static int f16s_env = -1;  // MADTP_ATTN_F16S=0: the f16x3 mode keeps its attention on the exact-f32 MFMA kernels (A/B runs)
+    if (f16s_env < 0) { const char* e = getenv("MADTP_ATTN_F16S"); f16s_env = e ? atoi(e) : 1; }
+    return f16s_env != 0;
+}
+
 static int attention_launch(const void* q, const void* k, const void* v, const int32_t* kv_batch_index, void* out,
                             const float* add_mask, const float* mask_qk, int ld_mask_qk, float* colsum_part, float* p0,
                             float* onorm, int B, int H, int Nq, int Nk, int ldq, int ldk, int ldv, int ldo, float scale,
@@ -2230,11 +2276,14 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
     if (io_dtype != MADTP_F32 && io_dtype != MADTP_BF16 && io_dtype != MADTP_F16S && io_dtype != MADTP_F16) return MADTP_E_DTYPE;
     bool f16s = io_dtype == MADTP_F16S;
     const bool f16 = io_dtype == MADTP_F16;  // plain f16 operands: the bf16 kernels on the f16 MFMA
+    int split_dim = 0;
     if (f16s) {
-        static int f16s_env = -1;  // MADTP_ATTN_F16S=0: the f16x3 mode keeps its attention on the exact-f32 MFMA kernels (A/B runs)
-        if (f16s_env < 0) { const char* e = getenv("MADTP_ATTN_F16S"); f16s_env = e ? atoi(e) : 1; }
-        f16s = f16s_env != 0;
+        f16s = madtp_internal_attn_f16s_enabled();
         io_dtype = MADTP_F32;
+        split_dim = f16s ? t_split_dim : 0;
+        if (t_split_dim && !f16s) return MADTP_E_BADARG;  // (the caller asks for planes only when the f16s kernels are on)
+    } else if (t_split_dim) {
+        return MADTP_E_BADARG;
     }
     if (colsum_part && (!p0 || !onorm || Nq != Nk)) return MADTP_E_BADARG;
     const int esz = (io_dtype == MADTP_BF16 || f16) ? 2 : 4;
@@ -2252,8 +2301,15 @@ static int attention_launch(const void* q, const void* k, const void* v, const i
     a.mask_qk = mask_qk; a.ld_mqk = ld_mask_qk;
     a.n_dev = n_dev; a.dev_q_only = dev_q_only;
     a.kvb = kv_block_rows ? kv_block_rows : Nk;
+    a.split_dim = split_dim; a.range_flag = split_dim ? madtp_internal_range_flag() : nullptr;
     hipStream_t s = (hipStream_t)stream;
     const bool scores = colsum_part != nullptr;
+    if (split_dim) {  // planes: 8-byte stores at f16 offsets
+        if ((ldo % 4) || (split_dim % 4) || ((uintptr_t)out & 7)) return MADTP_E_ALIGN;
+        t_split_done = 1;
+        if (Nk > 256) return scores ? dispatch_large_f16s<true>(a, s) : dispatch_large_f16s<false>(a, s);
+        return scores ? dispatch_nt_f16s<true>(a, s) : dispatch_nt_f16s<false>(a, s);
+    }
     if (Nk > 256) {  // long sequences (384^2 / 480^2 images): two-pass kernels
         if (f16s && (ldo * 4) % 16 == 0 && aligned16(out))
             return scores ? dispatch_large_f16s<true>(a, s) : dispatch_large_f16s<false>(a, s);
@@ -2312,7 +2368,7 @@ int madtp_i_attention_pair(const void* q0, const void* q1, const void* k0, const
     a.q2 = (const char*)q1; a.k2 = (const char*)k1; a.v2 = (const char*)v1; a.out2 = (char*)out1; a.mask2 = add_mask1;
     a.pair = 1;
     a.mask_qk = nullptr; a.ld_mqk = 0; a.hm_ws = nullptr; a.hm_tick = nullptr; a.n_dev = nq_dev; a.dev_q_only = 1; a.o_part = nullptr;
-    a.colsum = nullptr; a.p0 = nullptr; a.onorm = nullptr;
+    a.colsum = nullptr; a.p0 = nullptr; a.onorm = nullptr; a.split_dim = 0; a.range_flag = nullptr;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.kvb = Nk;
     a.nrt = (Nq + 15) / 16;

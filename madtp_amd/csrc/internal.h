@@ -51,3 +51,9 @@ MADTP_INTERNAL int madtp_i_mask_gather_dev(const float* mask, const int64_t* ind
 // incremental decoding: Nq queries per sample against the first Nk rows of the sample's K/V block of kv_block_rows rows
 MADTP_INTERNAL int madtp_i_attention_cached(const void* q, const void* k, const void* v, int kv_block_rows, void* out, int B, int H, int Nq,
                                             int Nk, int ldq, int ldk, int ldv, int ldo, float scale, int io_dtype, void* stream);
+// f16x3 layer calls: ask the next attention launches of this thread (io_dtype MADTP_F16S) to write their context as the f16-split
+// operand planes of the consuming GEMM (out = _Float16 planes, ldo in f16 elements, P1 at column offset split_dim); 0 = off.
+// _done(): 1 once a launch honoured the request.  _f16s_enabled(): the f16s attention kernels are on (MADTP_ATTN_F16S != 0).
+MADTP_INTERNAL int madtp_internal_attn_split_out(int split_dim);
+MADTP_INTERNAL int madtp_internal_attn_split_done();
+MADTP_INTERNAL bool madtp_internal_attn_f16s_enabled();

@@ -183,10 +183,17 @@ static int vit_attn_impl(const madtp_vit_block_w* w, const float* x, float* x_ou
     TRY(ln_to(x, w->ln1_g, w->ln1_b, nullptr, s.h, M, D, w->eps, dt, stream));
     TRY(lin(s.h, D, w->qkv, nullptr, 0, s.qkv, 3 * D, M, dt, adt, MADTP_ACT_NONE, 1.f, stream));
     const char* q = (const char*)s.qkv;
-    TRY(madtp_attention_qk_mask(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.o, nullptr, w->attn_mask, w->ld_attn_mask,
-                                prune ? s.colsum : nullptr, s.p0, s.onorm, B, w->heads, N, N, 3 * D, 3 * D, 3 * D, D, w->scale, attn_io(dt),
-                                stream));
-    if (dt == MADTP_F16S) {  // the projection GEMM takes the attention output as f16 planes (s.h is free again)
+    // f16x3: the projection GEMM takes the attention output as f16 planes (s.h is free again) - written by the attention kernel itself
+    // (round 6; a separate split_f16 launch re-read the f32 context before), unless the f16s attention kernels are switched off
+    const bool ctx_planes = dt == MADTP_F16S && madtp_internal_attn_f16s_enabled();
+    if (ctx_planes) madtp_internal_attn_split_out(D);
+    const int rc_att = madtp_attention_qk_mask(q, q + (size_t)D * e, q + (size_t)2 * D * e, ctx_planes ? s.h : s.o, nullptr, w->attn_mask,
+                                               w->ld_attn_mask, prune ? s.colsum : nullptr, s.p0, s.onorm, B, w->heads, N, N, 3 * D, 3 * D,
+                                               3 * D, ctx_planes ? 2 * D : D, w->scale, attn_io(dt), stream);
+    madtp_internal_attn_split_out(0);
+    TRY(rc_att);
+    if (ctx_planes) s.o = s.h;
+    else if (dt == MADTP_F16S) {
         TRY(to_lp((const float*)s.o, D, s.h, M, D, dt, stream));
         s.o = s.h;
     }
@@ -336,14 +343,23 @@ static int bert_attn_impl(const madtp_bert_layer_w* w, const float* hidden, cons
     void* att_lp = dt != MADTP_F32 ? s.attc : nullptr;  // compute-dtype copy of att for the second half (same workspace)
     TRY(lin(hc, D, w->qkv, nullptr, 0, s.qkv, 3 * D, M, dt, adt, MADTP_ACT_NONE, 1.f, stream));
     const char* q = (const char*)s.qkv;
+    // f16x3: attention.output.dense takes the context as f16 planes (s.q is scratch of the second half), written by the attention kernel
+    const bool ctx_planes = dt == MADTP_F16S && madtp_internal_attn_f16s_enabled();
+    void* ctx_out = ctx_planes ? s.q : s.ctx;
+    const int ld_ctx = ctx_planes ? 2 * D : D;
+    if (ctx_planes) madtp_internal_attn_split_out(D);
+    int rc_att;
     if (w->self_mask_qk)  // decoder layer (BertModel(is_decoder=True), med.py:752-768): causal [L,L] mask next to the padding mask
-        TRY(madtp_attention_qk_mask(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.ctx, mask2d, w->self_mask_qk, w->ld_self_mask_qk,
-                                    prune ? s.colsum : nullptr, s.p0, s.onorm, B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale,
-                                    attn_io(dt), stream));
+        rc_att = madtp_attention_qk_mask(q, q + (size_t)D * e, q + (size_t)2 * D * e, ctx_out, mask2d, w->self_mask_qk, w->ld_self_mask_qk,
+                                         prune ? s.colsum : nullptr, s.p0, s.onorm, B, w->heads, L, L, 3 * D, 3 * D, 3 * D, ld_ctx, w->scale,
+                                         attn_io(dt), stream);
     else
-        TRY(madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, s.ctx, mask2d, prune ? s.colsum : nullptr, s.p0, s.onorm,
-                            B, w->heads, L, L, 3 * D, 3 * D, 3 * D, D, w->scale, attn_io(dt), stream));
-    if (dt == MADTP_F16S) {  // attention.output.dense takes the context as f16 planes (s.q is scratch of the second half)
+        rc_att = madtp_attention(q, q + (size_t)D * e, q + (size_t)2 * D * e, ctx_out, mask2d, prune ? s.colsum : nullptr, s.p0, s.onorm,
+                                 B, w->heads, L, L, 3 * D, 3 * D, 3 * D, ld_ctx, w->scale, attn_io(dt), stream);
+    madtp_internal_attn_split_out(0);
+    TRY(rc_att);
+    if (ctx_planes) s.ctx = s.q;
+    else if (dt == MADTP_F16S) {
         TRY(to_lp((const float*)s.ctx, D, s.q, M, D, dt, stream));
         s.ctx = s.q;
     }
@@ -444,20 +460,31 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
             }
             const float* em0 = w->variant_nlvr ? enc_mask0 : nullptr;
             const float* em1 = w->variant_nlvr ? enc_mask1 : nullptr;
+            // f16x3: [c0|c1] as the f16 planes of ONE [M, 2D] matrix for the fused output GEMM (s.mid is free until the FFN): branch br
+            // writes columns br D .. of both planes (plane offset 2D, row length 4D f16) from its attention kernel
+            const bool cat_planes = dt == MADTP_F16S && madtp_internal_attn_f16s_enabled();
+            char* cat0 = cat_planes ? (char*)s.mid : (char*)s.cat;
+            char* cat1 = cat_planes ? (char*)s.mid + (size_t)D * 2 : (char*)s.cat + (size_t)D * e;
+            const int ld_cat = cat_planes ? 4 * D : 2 * D;
+            if (cat_planes) madtp_internal_attn_split_out(2 * D);
+            int rc_att = 0;
             if (ldkv[0] == ldkv[1] && (!kv_pre0) == (!kv_pre1)) {
                 // both branches in one launch ([c0|c1] side by side, ld 2D)
-                TRY(madtp_attention_pair(s.q2, (const char*)s.q2 + (size_t)D * e, kvp[0], kvp[1], kvp[0] + (size_t)D * e,
-                                         kvp[1] + (size_t)D * e, kv_pre0 ? kv_index : nullptr, s.cat, (char*)s.cat + (size_t)D * e,
-                                         em0, em1, B, w->heads, Lp, Nk, 2 * D, ldkv[0], ldkv[0], 2 * D, w->scale, attn_io(dt), stream));
+                rc_att = madtp_attention_pair(s.q2, (const char*)s.q2 + (size_t)D * e, kvp[0], kvp[1], kvp[0] + (size_t)D * e,
+                                              kvp[1] + (size_t)D * e, kv_pre0 ? kv_index : nullptr, cat0, cat1,
+                                              em0, em1, B, w->heads, Lp, Nk, 2 * D, ldkv[0], ldkv[0], ld_cat, w->scale, attn_io(dt), stream);
             } else {
-                for (int br = 0; br < 2; ++br)
-                    TRY(madtp_attention_indexed((const char*)s.q2 + (size_t)br * D * e, kvp[br], kvp[br] + (size_t)D * e,
-                                                (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, (char*)s.cat + (size_t)br * D * e,
-                                                br ? em1 : em0, nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, 2 * D, ldkv[br],
-                                                ldkv[br], 2 * D, w->scale, attn_io(dt), stream));
+                for (int br = 0; br < 2 && !rc_att; ++br)
+                    rc_att = madtp_attention_indexed((const char*)s.q2 + (size_t)br * D * e, kvp[br], kvp[br] + (size_t)D * e,
+                                                     (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, br ? cat1 : cat0,
+                                                     br ? em1 : em0, nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, 2 * D, ldkv[br],
+                                                     ldkv[br], ld_cat, w->scale, attn_io(dt), stream);
             }
+            madtp_internal_attn_split_out(0);
+            TRY(rc_att);
             const void* catc = s.cat;
-            if (dt == MADTP_F16S) {  // [c0|c1] f32 -> f16 planes for the fused output GEMM (s.mid is free until the FFN)
+            if (cat_planes) catc = s.mid;
+            else if (dt == MADTP_F16S) {  // [c0|c1] f32 -> f16 planes
                 TRY(to_lp((const float*)s.cat, 2 * D, s.mid, M, 2 * D, dt, stream));
                 catc = s.mid;
             }
@@ -479,13 +506,22 @@ static int bert_rest_impl(const madtp_bert_layer_w* w, const float* att, const f
                 kv = (const char*)s.kv;
             }
             const int ldkv = ((br ? kv_pre1 : kv_pre0) && kv_ld) ? kv_ld : 2 * D;
-            TRY(madtp_attention_indexed(s.q, kv, kv + (size_t)D * e, (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr, cbuf[br], em,
-                                        nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, D, ldkv, ldkv, D, w->scale, attn_io(dt), stream));
-            if (dt == MADTP_F16S) {  // context f32 -> f16 planes for crossattention.output.dense, in s.mid (free until the FFN;
-                                     // hidden >= 2*dim, so both branches fit side by side)
+            // f16x3: the context as f16 planes for crossattention.output.dense, in s.mid (free until the FFN; hidden >= 2*dim, so both
+            // branches fit side by side) - written by the attention kernel, else split from the f32 context
+            const bool ctx_planes = dt == MADTP_F16S && madtp_internal_attn_f16s_enabled();
+            void* sp = nullptr;
+            if (dt == MADTP_F16S) {
                 if (w->inter.n < 2 * D) return MADTP_E_SHAPE;
-                void* sp = (char*)s.mid + (size_t)br * M * D * esz_of(dt);
-                TRY(to_lp((const float*)cbuf[br], D, sp, M, D, dt, stream));
+                sp = (char*)s.mid + (size_t)br * M * D * esz_of(dt);
+            }
+            if (ctx_planes) madtp_internal_attn_split_out(D);
+            const int rc_att = madtp_attention_indexed(s.q, kv, kv + (size_t)D * e, (br ? kv_pre1 : kv_pre0) ? kv_index : nullptr,
+                                                       ctx_planes ? sp : cbuf[br], em, nullptr, nullptr, nullptr, B, w->heads, Lp, Nk, D, ldkv,
+                                                       ldkv, ctx_planes ? 2 * D : D, w->scale, attn_io(dt), stream);
+            madtp_internal_attn_split_out(0);
+            TRY(rc_att);
+            if (dt == MADTP_F16S) {
+                if (!ctx_planes) TRY(to_lp((const float*)cbuf[br], D, sp, M, D, dt, stream));
                 cbuf[br] = sp;
             }
         }
