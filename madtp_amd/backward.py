@@ -71,6 +71,22 @@ def _x3():
     return runtime.get_precision() == "f16x3"
 
 
+def _lp():
+    """the autocast-style route (runtime.training_amp): the fast modes' 2-byte GEMM operands in the training forward and backward"""
+    from . import runtime
+    return runtime.get_precision() in ("bf16", "f16")
+
+
+def _lp_w(w32):
+    """the 2-byte copy (bf16, or f16 of w 2^s tagged with its accumulator scale) of a cached f32 weight / transposed weight, attached
+    to that tensor object (one cast per parameter version and element format)"""
+    hit = getattr(w32, "_madtp_lp_w", None)
+    if hit is None or hit[0] != hip.lp_format():
+        hit = (hip.lp_format(), hip.cast_lp_weight(w32.contiguous()))
+        w32._madtp_lp_w = hit
+    return hit[1]
+
+
 def _mode():
     from . import runtime
     return runtime.get_precision()
@@ -85,6 +101,8 @@ def _in_mode(mode):
 
 def _check_mode(what):
     from . import runtime
+    if runtime.get_precision() in ("bf16", "f16") and runtime.autograd_precision():
+        return  # runtime.training_amp(): approximate gradients on 2-byte operands, asked for
     if runtime.get_precision() not in ("fp32", "f16x3"):
         raise NotImplementedError(f"{what} is built for the fp32-accurate precision modes (runtime.precision('fp32') or 'f16x3'); "
                                   f"current mode: {runtime.get_precision()}")
@@ -198,12 +216,15 @@ def _gemm(a, w, bias=None, n=None, residual=None, out_dtype=torch.float32):
     """act-free Linear of the recomputed forward: a f32 [M, K] @ w f32 [Npad, K]^T (+ bias, + residual) -> f32 [M, n]."""
     if _x3() and a.shape[1] % 64 == 0:
         return hip.gemm(hip.split_f16(a.contiguous()), _planes(w), bias, residual, out_dtype=torch.float32, n=n)
+    if _lp() and a.shape[1] % 64 == 0 and w.dtype == torch.float32:
+        return hip.gemm(hip.cast_bf16(a.contiguous()), _lp_w(w), bias, residual, out_dtype=torch.float32, n=n)
     return hip.gemm(a, w, bias, residual, out_dtype=torch.float32, n=n)
 
 
 def _attention(q, k, v, B, H, Nq, Nk, scale, **kw):
-    """the recomputed forward's attention: the f16x3 mode's three-product kernels where the forward ran them"""
-    return hip.attention(q, k, v, B, H, Nq, Nk, scale, split=_x3(), **kw)
+    """the recomputed forward's attention: the f16x3 mode's three-product kernels where the forward ran them (and on the amp route:
+    q / k / v are f32 there, the three-product kernels are the fast ones for f32 storage)"""
+    return hip.attention(q, k, v, B, H, Nq, Nk, scale, split=_x3() or _lp(), **kw)
 
 
 def dgrad(dy, weight, residual=None):
@@ -215,7 +236,8 @@ def dgrad(dy, weight, residual=None):
         wtp, (N, K) = _x3_weights(("x3w", weight.data_ptr(), tuple(weight.shape)), [weight]).planes_t, weight.shape
     else:
         wtp, (N, K) = None, weight.shape
-    Np = _pad(N, 64 if x3 else 32)  # the GEMM's reduction length (slabs of 32 f32 / 64 f16): zero columns for e.g. the 100 dictionary columns
+    lp = _lp() and not x3
+    Np = _pad(N, 64 if (x3 or lp) else 32)  # the GEMM's reduction length (slabs of 32 f32 / 64 f16): zero columns for e.g. the 100 dictionary columns
     if Np != N:
         dyp = torch.zeros((dy.shape[0], Np), device=dy.device, dtype=torch.float32)
         dyp[:, :N] = dy
@@ -226,6 +248,8 @@ def dgrad(dy, weight, residual=None):
     wt = _cached(("wt", weight.data_ptr(), Np, x3), [weight], _versioned(lambda: transpose_pad(weight, Np, _pad(K, 128))))
     if x3:
         return hip.gemm(hip.split_f16(dy.contiguous()), _planes(wt), None, residual, out_dtype=torch.float32, n=K)
+    if lp:
+        return hip.gemm(hip.cast_bf16(dy.contiguous()), _lp_w(wt), None, residual, out_dtype=torch.float32, n=K)
     return hip.gemm(dy, wt, n=K, out_dtype=torch.float32, residual=residual)
 
 
@@ -261,9 +285,14 @@ def wgrad(dy, x, bias=False):
         else:
             dw = hip.gemm(a, w, n=K, out_dtype=torch.float32)
         return (dw, db) if bias else dw
+    if _lp():
+        Mp = _pad(M, 64)
     dyt = transpose_pad(dy, Mp, N)             # [N, Mp]
     xt = transpose_pad(x, Mp, _pad(K, 128))    # [Kpad, Mp]
-    dw = hip.gemm(dyt, xt, n=K, out_dtype=torch.float32)
+    if _lp():  # amp route: both operands rounded to the mode's 2-byte format (X^T as the "weight" operand at scale 1)
+        dw = hip.gemm(hip.cast_bf16(dyt), hip.cast_bf16(xt), n=K, out_dtype=torch.float32)
+    else:
+        dw = hip.gemm(dyt, xt, n=K, out_dtype=torch.float32)
     return (dw, colsum(dy)) if bias else dw
 
 
@@ -512,7 +541,9 @@ def _save_forward():
     """MADTP_TRAIN_SAVE (default 1): the training forward of a block is composed from the single kernels and KEEPS its intermediates
     for the backward (round 5) - instead of running the fused layer call and recomputing the layer in the backward (0: the
     round-4 scheme, a third less activation memory, one more forward's worth of kernels per step)."""
-    return os.environ.get("MADTP_TRAIN_SAVE", "1") != "0"
+    # (the amp route always keeps its forward: a recompute on other arithmetic than the fused fast-mode layer call could take another
+    #  pruning decision than the forward whose output shape the graph already has)
+    return os.environ.get("MADTP_TRAIN_SAVE", "1") != "0" or _lp()
 
 
 def _site(base, code):

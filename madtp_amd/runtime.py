@@ -57,10 +57,35 @@ def get_precision() -> str:
 _TRAIN_X3 = os.environ.get("MADTP_TRAIN_F16X3", "0") == "1"
 
 
+# Round 6: `--amp` (compress_nlvr_dtp.py:46-53: torch.cuda.amp.autocast around the forward, GradScaler around the backward).  Opt-in,
+# MADTP_TRAIN_AMP=1 or `with runtime.training_amp():` - the autograd route in the FAST modes: every GEMM of the training forward, of dgrad
+# and of wgrad takes its operands rounded to the mode's 2-byte format (bf16, or IEEE f16 - the format autocast uses on GPUs) with f32
+# accumulation, parameters / gradients / LayerNorm / softmax / pruning scores stay f32, as under autocast.  Gradients are approximate by
+# construction (operand rounding 2^-9 / 2^-12); with f16 operands tiny gradients underflow, which is what the reference's GradScaler is
+# for - a caller's scaled loss simply rides through the backward.
+_TRAIN_AMP = os.environ.get("MADTP_TRAIN_AMP", "0") == "1"
+
+
 def autograd_precision():
     """True when a forward in the current precision mode builds an autograd graph (given grad mode and inputs that need one)."""
     m = get_precision()
-    return m == "fp32" or (m == "f16x3" and getattr(_state, "train_x3", _TRAIN_X3))
+    return (m == "fp32" or (m == "f16x3" and getattr(_state, "train_x3", _TRAIN_X3))
+            or (m in ("bf16", "f16") and getattr(_state, "train_amp", _TRAIN_AMP)))
+
+
+class training_amp:
+    """context manager: forwards of the fast modes (bf16 / f16) inside build autograd graphs whose GEMMs run on 2-byte operands - the
+    counterpart of the reference's `torch.cuda.amp.autocast()` (compress_nlvr_dtp.py:46-53)"""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = getattr(_state, "train_amp", _TRAIN_AMP)
+        _state.train_amp = bool(self.on)
+
+    def __exit__(self, *a):
+        _state.train_amp = self.prev
 
 
 class training_f16x3:

@@ -1043,3 +1043,97 @@ def test_nlvr_model_train_mode_runs_with_dropout(hip):
         assert all(np.isfinite(v) for v in losses[tag])
         assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.requires_grad)
     assert losses["a"] == losses["a2"] and losses["a"] != losses["b"] and losses["a"] != losses["eval"]
+
+
+@pytest.mark.parametrize("mode,tol", [("f16", 5e-3), ("bf16", 5e-2)])  # measured on MI355X: 6.1e-4 / 6.2e-3
+def test_amp_block_backward_tracks_reference_grads(hip, mode, tol):
+    """`--amp` (compress_nlvr_dtp.py:46-53: autocast forward + GradScaler backward), round 6: with runtime.training_amp() the FAST modes
+    take the autograd route - every GEMM of the training forward, dgrad and wgrad on the mode's 2-byte operands (f32 accumulation; f32
+    parameters, gradients, LayerNorm, softmax and pruning scores, as under autocast).  Gradients are approximate by construction: on the
+    reference-recorded block fixture they follow the reference's to the operand format's rounding (when the block keeps the reference's
+    token set, which a 2-byte forward need not), a scaled loss (GradScaler) scales them exactly, and without the opt-in the fast modes
+    still refuse."""
+    from madtp_amd import runtime, vit
+    from oracle import madtp_oracle as O
+    from tests import grad_case
+    g = np.load(GRAD_CASES[0])
+    c = grad_case.build(g)
+    blk = vit.Block(768, 12, qkv_bias=True, norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6))
+    blk.load_state_dict({k[len(c["prefix"]):]: v for k, v in c["W"].items() if k.startswith(c["prefix"])}, strict=True)
+    blk = blk.cuda()
+
+    def run(scale):
+        for p in blk.parameters():
+            p.grad = None
+        x = c["x"].cuda().requires_grad_(True)
+        ta = c["token_attn"].cuda().requires_grad_(True)
+        with runtime.precision(mode), runtime.training_amp():
+            y = blk(x, False, 0, c["T"], ta)
+            info = blk.last_prune
+            same = all({int(v) for v in info["indices"][b]} == {int(v) for v in g["blk_idx"][b]} for b in range(x.shape[0]))
+            G = grad_case.permute_G(c["G"], g["blk_idx"], info["indices"].cpu().numpy()) if same else c["G"][:, : y.shape[1]]
+            ((y * G.cuda()).sum() * scale).backward()
+        grads = {"x": x.grad, "token_attn": ta.grad}
+        grads.update({k: p.grad.clone() for k, p in blk.named_parameters()})
+        return grads, same, y
+
+    grads, same, y = run(1.0)
+    assert all(torch.isfinite(v).all() for v in grads.values()) and y.dtype == torch.float32
+    assert all(v.dtype == torch.float32 for v in grads.values())
+    if same:
+        ref, _, _ = O.vit_block_grads(c["W"], c["prefix"], c["x"], c["token_attn"], c["T"], c["G"])
+        worst = max((_rel(grads[n].cpu(), r), n) for n, r in ref.items() if not n.endswith("token_attn"))
+        print(f"amp {mode}: kept set == reference; worst gradient error {worst[0]:.3e} of its maximum ({worst[1]})")
+        assert worst[0] < tol, worst
+    else:
+        print(f"amp {mode}: the 2-byte forward kept another token set than the fp32 reference (gradients not comparable entry by entry)")
+        assert mode == "bf16"  # (f16 reproduces this fixture's sets)
+    # GradScaler: a loss scaled by 2^10 gives gradients scaled by exactly 2^10 (powers of two commute with every rounding here)
+    g2, same2, _ = run(1024.0)
+    assert same2 == same
+    for n in ("x", "attn.qkv.weight", "mlp.fc2.weight", "norm1.weight"):
+        assert _rel(g2[n] / 1024.0, grads[n]) < (1e-6 if mode == "bf16" else 2e-3), n  # (f16: tiny entries leave the subnormals when scaled)
+    # without the opt-in the fast modes refuse, as before
+    x = c["x"].cuda().requires_grad_(True)
+    with runtime.precision(mode), pytest.raises(NotImplementedError):
+        blk(x, False, 0, c["T"], c["token_attn"].cuda())
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+def test_amp_nlvr_training_step_learns(hip, mode):
+    """The headline model's compression training step under runtime.training_amp() (the reference's --amp): losses next to the
+    reference's recorded fp32 losses, finite f32 gradients for every parameter that has one in the fixture, norms of the largest
+    gradients within the operand format's error, and AdamW steps on the same batch lower the loss."""
+    from madtp_amd import harness, runtime
+    g = np.load(TRAINSTEP_CASES[0])
+    B, size, L, T, seed = int(g["B"]), int(g["size"]), int(g["L"]), float(g["temperature"]), int(g["seed"])
+    model = harness.build_nlvr(size, seed, "cuda")
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    images, text, _ = harness.nlvr_inputs(B, size, L, seed, "cuda", pad_tail=int(g["pad_tail"]))
+    targets = (torch.arange(B) % 2).cuda()
+    with runtime.precision(mode), runtime.training_amp():
+        lo, lf = model(images, text, targets, temperature=T, train=True)
+        assert abs(float(lo.detach()) - float(g["loss_ori"])) < 2e-2 and abs(float(lf.detach()) - float(g["loss_fdt"])) < 5e-2 * max(1.0, float(g["loss_fdt"]))
+        (lo + 0.1 * lf).backward()
+        grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        names = [k[2:-5] for k in g.files if k.startswith("g_") and k.endswith("_norm")]
+        assert names and all(n in grads and torch.isfinite(grads[n]).all() and grads[n].dtype == torch.float32 for n in names)
+        big = sorted(names, key=lambda n: -float(g[f"g_{n}_norm"]))[:12]
+        for n in big:
+            ref = float(g[f"g_{n}_norm"])
+            got = float(grads[n].double().norm())
+            assert abs(got - ref) < (0.1 if mode == "f16" else 0.35) * ref, (n, got, ref)
+        opt = torch.optim.AdamW(model.parameters(), lr=2e-5, weight_decay=0.05)
+        losses = [float((lo + 0.1 * lf).detach())]
+        opt.step()
+        for _ in range(3):
+            opt.zero_grad()
+            lo, lf = model(images, text, targets, temperature=T, train=True)
+            loss = lo + 0.1 * lf
+            losses.append(float(loss.detach()))
+            loss.backward()
+            opt.step()
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

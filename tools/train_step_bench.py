@@ -23,7 +23,7 @@ opt = torch.optim.AdamW(model.parameters(), lr=1e-6, weight_decay=0.05, **({"fus
 for B in [int(a) for a in sys.argv[1:]] or [4, 16, 64]:
     images, text, _ = harness.nlvr_inputs(B, 224, 20, 0, "cuda")
     targets = (torch.arange(B) % 2).cuda()
-    with runtime.precision(MODE), runtime.training_f16x3(MODE == "f16x3"):
+    with runtime.precision(MODE), runtime.training_f16x3(MODE == "f16x3"), runtime.training_amp(MODE in ("bf16", "f16")):  # (bf16 / f16: the --amp route, round 6)
         with torch.no_grad():
             for _ in range(2):
                 model(images, text, targets, temperature=T, train=False)
