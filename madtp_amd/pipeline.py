@@ -24,7 +24,9 @@ import threading
 import torch
 
 
-# The GEMM dispatch hints are process-wide state of the library (include/madtp_hip.h): runners that overlap in time share ONE
+# (Rounds 3-5; since round 6 the hints are per-STREAM attributes - madtp_stream_set_sched - and this block only serves
+# MADTP_INFLIGHT_GLOBAL_HINTS=1, the A/B switch.)  The GEMM dispatch hints were process-wide state of the library
+# (include/madtp_hip.h): runners that overlap in time share ONE
 # setting - the first one in sets it and remembers the previous values, the last one out restores them (a nested or concurrent
 # runner neither re-applies its own hints nor restores stale ones).
 _hint_lock = threading.Lock()
@@ -205,6 +207,8 @@ class InflightRunner:
         else:
             high = [i < max(1, n // 2) for i in range(self.n)]
         part = self._partition_for(n)
+        import os
+        per_stream_hints = os.environ.get("MADTP_INFLIGHT_GLOBAL_HINTS", "0") != "1"  # ("1": the rounds-3-5 process-wide setters, A/B)
         for i in range(n):
             if part is not None:
                 key = (tuple(part), i)
@@ -217,6 +221,11 @@ class InflightRunner:
             pr = -1 if high[i] else 0
             if pr not in self._by_prio[i]:
                 self._by_prio[i][pr] = torch.cuda.Stream(device=self.device, priority=pr)
+                if per_stream_hints and (self.sq_cost or self.small_tile is not None):
+                    # the dispatch hints travel with the STREAM (madtp_stream_set_sched, round 6): no process-wide library state, two
+                    # runners (or another user of the library) in one process do not see each other's hints
+                    from . import hip
+                    hip.stream_set_sched(self._by_prio[i][pr], 0, self.sq_cost or 0.0, -2 if self.small_tile is None else self.small_tile)
             self.streams[i] = self._by_prio[i][pr]
         self.n_high = 0 if part is not None else sum(1 for i in range(n) if high[i])
         self.last_partition = part
@@ -229,7 +238,7 @@ class InflightRunner:
         threads = [threading.Thread(target=self._work, args=(i, per[i], mode), name=f"madtp-inflight-{i}")
                    for i in range(self.n) if per[i]]
         # (CU-masked streams carry their hints themselves - madtp_stream_set_sched - and leave the process-wide state alone)
-        hinted = len(threads) > 1 and part is None and _hints_enter(self.sq_cost, self.small_tile)
+        hinted = len(threads) > 1 and part is None and not per_stream_hints and _hints_enter(self.sq_cost, self.small_tile)
         try:
             for t in threads:
                 t.start()
