@@ -74,7 +74,7 @@ def _x3():
 def _lp():
     """the autocast-style route (runtime.training_amp): the fast modes' 2-byte GEMM operands in the training forward and backward"""
     from . import runtime
-    return runtime.get_precision() in ("bf16", "f16")
+    return runtime.get_precision() in ("bf16", "f16") and runtime.autograd_precision()  # (a fast mode AND the amp opt-in)
 
 
 def _lp_w(w32):
@@ -96,6 +96,12 @@ def _in_mode(mode):
     """context of a backward(): the autograd engine runs it on a worker thread whose thread-local precision mode is the default -
     the forward's mode is recorded on ctx and re-established here"""
     from . import runtime
+    if mode in ("bf16", "f16"):  # a graph built in a fast mode was built under runtime.training_amp(): the backward runs under it too
+        import contextlib
+        st = contextlib.ExitStack()
+        st.enter_context(runtime.precision(mode))
+        st.enter_context(runtime.training_amp())
+        return st
     return runtime.precision(mode)
 
 
