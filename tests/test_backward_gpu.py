@@ -131,6 +131,50 @@ def test_backward_refuses_parameters_modified_after_forward(hip):
     assert x.grad is not None and blk.mlp.fc1.weight.grad is not None
 
 
+def test_update_epochs_are_scoped_to_the_stepped_parameters(hip):
+    """ADVICE r5 (round 6): an optimizer step bumps a step count ON ITS OWN parameters (runtime._on_optimizer_step), not a process-wide
+    epoch.  (1) a step of ANOTHER model's optimizer between this block's forward and backward no longer raises 'modified in place';
+    (2) a frozen block's prepared weights survive it (same prepared tensor object); (3) a step of the block's own optimizer still
+    invalidates both; (4) the f16-split scale of a re-prepared weight is reused across an optimizer step but NOT across a copy_ /
+    load_state_dict over the same storage (a checkpoint 64x larger gets a fresh scale instead of inf planes), and a reused scale that
+    IS outgrown raises the range flag."""
+    from madtp_amd import hip as H, runtime, vit
+    from madtp_amd.runtime import lin_of
+    torch.manual_seed(1)
+    blk = vit.Block(768, 12, qkv_bias=True).cuda()
+    other = torch.nn.Linear(16, 16).cuda()
+    opt_other = torch.optim.SGD(other.parameters(), lr=0.1)
+    opt_own = torch.optim.SGD(blk.parameters(), lr=1e-3)
+    x = _rand(2, 50, 768, seed=1).cuda().requires_grad_(True)
+    with runtime.precision("f16x3"), runtime.training_f16x3():
+        with torch.no_grad():
+            blk(x.detach())
+        prepared = lin_of(blk.mlp._cache, "fc1", [blk.mlp.fc1])
+        y = blk(x, temperature=0)
+        other(torch.randn(4, 16, device="cuda")).sum().backward()
+        opt_other.step()                                            # (1) somebody else's step
+        y.sum().backward()
+        assert x.grad is not None
+        assert lin_of(blk.mlp._cache, "fc1", [blk.mlp.fc1]) is prepared   # (2)
+        y = blk(x, temperature=0)
+        opt_own.step()                                              # (3) the block's own step
+        with pytest.raises(RuntimeError, match="modified in place"):
+            y.sum().backward()
+        again = lin_of(blk.mlp._cache, "fc1", [blk.mlp.fc1])
+        assert again is not prepared and again.log2_scale == prepared.log2_scale and again.age == prepared.age + 1   # (4) reused across a step
+        with torch.no_grad():
+            blk.mlp.fc1.weight.copy_(blk.mlp.fc1.weight * 64.0)     # a "checkpoint" far from the old values, no optimizer involved
+        fresh = lin_of(blk.mlp._cache, "fc1", [blk.mlp.fc1])
+        assert fresh.age == 0 and fresh.log2_scale == again.log2_scale - 6
+        assert torch.isfinite(fresh.w.float()).all()
+        # an outgrown REUSED scale is flagged, not silently turned into inf / NaN planes
+        H.range_status(True)
+        w = blk.mlp.fc1.weight.detach().float().contiguous()
+        H.split_f16_weight((w * 4096.0).contiguous(), log2_scale=fresh.log2_scale + 6)
+        torch.cuda.synchronize()
+        assert H.range_status(True) == 1
+
+
 @pytest.mark.parametrize("mode", ["fp32", "f16x3", "bf16"])
 def test_prepared_weights_follow_fused_optimizers_and_data_edits(hip, mode):
     """torch.optim's fused=True steps (and edits through .data) bump no Parameter._version: the prepared-weight caches follow them
