@@ -1604,6 +1604,159 @@ __global__ __launch_bounds__(768, 1) void align_ws_kernel(const float* __restric
     }
 }
 
+// 128-row variant of align_ws_kernel (round 6; the "taller row tile" of DESIGN section 9): one workgroup streams the split dictionary
+// for 128 token rows instead of 64 - half the workgroups and half the dictionary bytes per launch.  Per K slab: 32 KiB of x rows +
+// 2 x 16 KiB of dictionary = 64 KiB, TWO stages (three would not fit 160 KiB): consumers signal "fragments of slab kt are in
+// registers" with a second barrier, after which the loaders refill that stage under the slab's MFMAs.  8 consumer waves = 4 row
+// groups of 32 rows x 2 column halves: a wave's dictionary fragments serve two row tiles (half the LDS fragment reads per MFMA).
+// Per accumulator the product order over (slab, kk, term) is align_ws_kernel's: the same bits.
+constexpr int AW2_XT = 128 * 256, AW2_STAGE = AW2_XT + 2 * AL_TILE;  // 32 KiB + 2 x 16 KiB
+template <bool F16>
+__global__ __launch_bounds__(768, 1) void align_ws2_kernel(const float* __restrict__ x, const char* __restrict__ sd_hi,
+                                                           const char* __restrict__ sd_lo, float* __restrict__ out, int M, int dim,
+                                                           float out_scale, DevN m_dev) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    M = devn(m_dev, M);
+    if ((int)blockIdx.x * 128 >= M) return;
+    constexpr int STAGES = 2, PER = 16;  // 64 one-KiB DMA instructions per slab, 16 per loader wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = dim / 64;
+    const int row0 = blockIdx.x * 128;
+    if (wave >= 8) {
+        // ------------------------------------------ loader ------------------------------------------
+        const int lw = wave - 8;
+        const char* srcp[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx = lw * PER + q;  // 0..31: x groups of 4 rows; 32..47: hi groups of 8 rows; 48..63: lo groups
+            if (idx < 32) {
+                const int r = idx * 4 + (lane >> 4);
+                int row = row0 + r;
+                row = row < M ? row : M - 1;
+                srcp[q] = (const char*)(x + (size_t)row * dim) + (((lane & 15) ^ (r & 15)) << 4);
+            } else {
+                const int grp = (idx - 32) & 15, r = grp * 8 + (lane >> 3);
+                const char* base = idx < 48 ? sd_hi : sd_lo;
+                srcp[q] = base + (size_t)r * dim * 2 + (((lane & 7) ^ (r & 7)) << 4);
+            }
+        }
+        auto issue = [&](int kt) {
+            char* st = smem + (kt % STAGES) * AW2_STAGE + lw * PER * 1024;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int idx = lw * PER + q;
+                const int koff = idx < 32 ? kt * 256 : kt * 128;
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(srcp[q] + koff), LDS_PTR(st + q * 1024), 16, 0, 0);
+            }
+        };
+        issue(0);
+        if (nk > 1) issue(1);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // only slab kt+1 may still fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // A: slab kt landed
+            __builtin_amdgcn_s_barrier();  // B: every consumer holds slab kt's fragments in registers
+            if (kt + 2 < nk) issue(kt + 2);  // into the stage slab kt used
+        }
+        return;
+    }
+    // ------------------------------------------ consumer ------------------------------------------
+    const int l16 = lane & 15, g = lane >> 4;
+    const int rg = wave & 3, cw = wave >> 2;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* st = smem + (kt % STAGES) * AW2_STAGE;
+        const char* sh = st + AW2_XT;
+        const char* sl = sh + AL_TILE;
+        __builtin_amdgcn_s_barrier();  // A
+        f32x4 xa[2][2][2];
+        bf16x8 bh[2][4], bl[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int xr = rg * 32 + t * 16 + l16;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = kk * 8 + g * 2;
+                xa[t][kk][0] = *(const f32x4*)(st + xr * 256 + (((c + 0) ^ (xr & 15)) << 4));
+                xa[t][kk][1] = *(const f32x4*)(st + xr * 256 + (((c + 1) ^ (xr & 15)) << 4));
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rb = (cw * 4 + j) * 16 + l16;
+                const int off = rb * AL_ROWB + (((kk * 4 + g) ^ (rb & 7)) << 4);
+                bh[kk][j] = *(const bf16x8*)(sh + off);
+                bl[kk][j] = *(const bf16x8*)(sl + off);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // B: the stage may be refilled
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bf16x8 ah[2], al[2];
+            if constexpr (F16) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    u32x4 p0, p1;
+                    split_f16x8(xa[t][kk][0], xa[t][kk][1], p0, p1);
+                    ah[kk] = __builtin_bit_cast(bf16x8, p0);
+                    al[kk] = __builtin_bit_cast(bf16x8, p1);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bl[kk][j]), __builtin_bit_cast(f16x8, ah[kk]), acc[t][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bh[kk][j]), __builtin_bit_cast(f16x8, ah[kk]), acc[t][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f16x8 q2 = __builtin_bit_cast(f16x8, bh[kk][j]) * (_Float16)(1.0f / F16S_LO_SCALE);
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q2, __builtin_bit_cast(f16x8, al[kk]), acc[t][j], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    ah[kk] = pack_bf16x8(xa[t][kk][0], xa[t][kk][1]);
+                    f32x4 r0, r1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        r0[e] = xa[t][kk][0][e] - bf16_to_f32((bf16_t)ah[kk][e]);
+                        r1[e] = xa[t][kk][1][e] - bf16_to_f32((bf16_t)ah[kk][4 + e]);
+                    }
+                    al[kk] = pack_bf16x8(r0, r1);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[kk][j], ah[kk], acc[t][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[kk][j], al[kk], acc[t][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[kk][j], ah[kk], acc[t][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = row0 + rg * 32 + t * 16 + l16;
+        if (m < M) {
+            float* o = out + (size_t)m * 128 + cw * 64 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f32x4*)(o + 16 * j) = F16 ? acc[t][j] * out_scale : acc[t][j];
+        }
+    }
+}
+
 }  // namespace
 
 constexpr int SPLIT_MAX_B = 1024, SPLIT_MAX_G = 8;  // per-slot scratch of token_score_split_kernel
@@ -2047,6 +2200,10 @@ extern "C" int madtp_align_logits(const float* x, const void* sd_hi, const void*
                                   int split_dtype, float out_scale, void* stream) {
     return madtp_i_align_logits(x, sd_hi, sd_lo, out, M, dim, split_dtype, out_scale, DevN{nullptr, 0, 0}, stream);
 }
+// tile height of the wave-specialised alignment kernel when MADTP_ALIGN_ROWS does not force one (set from the measurement,
+// profiles/r06_align_rows_ab.txt)
+static int align_rows_auto(int M) { (void)M; return 64; }
+
 int madtp_i_align_logits(const float* x, const void* sd_hi, const void* sd_lo, float* out, int M, int dim, int split_dtype,
                          float out_scale, DevN m_dev, void* stream) {
     if (!x || !sd_hi || !sd_lo || !out || M <= 0) return MADTP_E_BADARG;
@@ -2059,6 +2216,22 @@ int madtp_i_align_logits(const float* x, const void* sd_hi, const void* sd_lo, f
     MADTP_ENSURE_MAX_LDS(align_logits_kernel<0>, lds);
     static int variant = -1;  // MADTP_ALIGN_KERNEL=1 selects the register-prefetching kernel (A/B measurements)
     if (variant < 0) { const char* e = getenv("MADTP_ALIGN_KERNEL"); variant = e ? atoi(e) : 0; }
+    // MADTP_ALIGN_ROWS: 64 (align_ws_kernel), 128 (align_ws2_kernel), 0 = automatic (see align_rows_auto)
+    static int rows_env = -1;
+    if (rows_env < 0) { const char* e = getenv("MADTP_ALIGN_ROWS"); rows_env = e ? atoi(e) : 0; }
+    const int rows_sel = rows_env == 64 || rows_env == 128 ? rows_env : align_rows_auto(M);
+    if ((variant == 0 || split_dtype == MADTP_F16S) && rows_sel == 128 && !m_dev.p) {
+        MADTP_ENSURE_MAX_LDS(align_ws2_kernel<false>, 2 * AW2_STAGE);
+        MADTP_ENSURE_MAX_LDS(align_ws2_kernel<true>, 2 * AW2_STAGE);
+        if (split_dtype == MADTP_F16S)
+            hipLaunchKernelGGL(align_ws2_kernel<true>, dim3((M + 127) / 128), dim3(768), 2 * AW2_STAGE, (hipStream_t)stream, x,
+                               (const char*)sd_hi, (const char*)sd_lo, out, M, dim, out_scale, m_dev);
+        else
+            hipLaunchKernelGGL(align_ws2_kernel<false>, dim3((M + 127) / 128), dim3(768), 2 * AW2_STAGE, (hipStream_t)stream, x,
+                               (const char*)sd_hi, (const char*)sd_lo, out, M, dim, 1.f, m_dev);
+        MADTP_LAUNCH_CHECK();
+        return 0;
+    }
     if (variant == 0 || split_dtype == MADTP_F16S) {
         MADTP_ENSURE_MAX_LDS(align_ws_kernel<false>, 3 * AW_STAGE);
         MADTP_ENSURE_MAX_LDS(align_ws_kernel<true>, 3 * AW_STAGE);

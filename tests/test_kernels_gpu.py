@@ -1082,3 +1082,20 @@ def test_attention_map_accessor(hip):
     qkv = F.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias).reshape(2, 50, 3, 12, 64).permute(2, 0, 3, 1, 4)
     ref = ((qkv[0] @ qkv[1].transpose(-2, -1)) * blk.attn.scale).softmax(-1)
     assert P.shape == (2, 12, 50, 50) and (P - ref).abs().max().item() < 2e-6
+
+
+def test_align_logits_128_row_tile_gives_the_64_row_kernels_bits():
+    """align_ws2_kernel (MADTP_ALIGN_ROWS=128; round 6 - the "taller row tile" experiment: measured slower, shipped off,
+    profiles/r06_align_rows_ab.txt) accumulates every logit in align_ws_kernel's product order: identical bits for both operand
+    flavours (bf16 x 3, f16 x 3) and ragged row counts.  The tile height is a process-wide environment switch, hence two processes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fps = {}
+    for rows in ("64", "128"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "align_bench.py")], env=dict(os.environ, MADTP_ALIGN_ROWS=rows),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        fps[rows] = [(l.split()[2], l.split()[3], l.split()[-1]) for l in r.stdout.splitlines() if l.startswith("rows=")]
+    assert len(fps["64"]) == 18 and fps["64"] == fps["128"]
