@@ -140,6 +140,27 @@ def sq_summary(c, big):
     return rep
 
 
+def run_bounded(cmd, cwd, env, timeout):
+    """subprocess.run(capture_output) in its own session; on timeout the WHOLE process group is killed (rocprofv3 starts the profiled
+    program as a child: killing only the launcher would leave a hung bench.py on the GPU under the timed legs).  -> CompletedProcess
+    or None."""
+    import signal
+    p = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+        return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)  # (the group this call created - nobody else's processes)
+        except ProcessLookupError:
+            pass
+        try:
+            p.communicate(timeout=10)
+        except Exception:
+            pass
+        return None
+
+
 def measure_traffic(args):
     """HBM-side bytes per launch of the dominant kernels (gemm_ws_kernel / gemm_sq_kernel), collected as MI355X_MICROARCH.md prescribes:
     FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --pmc X --kernel-trace` passes over a 1-step run of this very command,
@@ -151,6 +172,7 @@ def measure_traffic(args):
         return None
     out = {}
     tmp = tempfile.mkdtemp(prefix="madtp_pmc_", dir="/tmp")
+    deadline = time.time() + float(os.environ.get("MADTP_TRAFFIC_BUDGET", "200"))
     try:
         big = lambda name: "gemm_ws_kernel" in name or "gemm_sq_kernel" in name or "gemm_pp_kernel" in name  # noqa: E731  (the big-GEMM kernels)
         for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
@@ -160,8 +182,26 @@ def measure_traffic(args):
                    "--config", args.config, "--precision", args.precision, "--steps", "1", "--warmup", "1", "--traffic", "off", "--min-seconds", "0",
                    "--no-cpu-baseline", "--no-parity", "--no-bf16-leg", "--no-gemm-events", "--inflight", "1"] + (["--batch", str(args.batch)] if args.batch else [])
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=int(os.environ.get("MADTP_TRAFFIC_TIMEOUT", "150")))
-            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
+            # A profiled child occasionally hangs (seen about once in ten calls on the pool's boxes, also as the first GPU user of a
+            # call): every pass gets a bounded time and ONE retry, the three passes together at most MADTP_TRAFFIC_BUDGET seconds
+            # (a pass normally takes 12-15 s), so that a hang costs the line its counters at worst, never the run its minutes.
+            r, dbs = None, []
+            for attempt in range(2):
+                left = deadline - time.time()
+                if left < 20:
+                    break
+                shutil.rmtree(d, ignore_errors=True)
+                r = run_bounded(cmd, "/tmp", env, min(left, float(os.environ.get("MADTP_TRAFFIC_TIMEOUT", "75"))))
+                if r is None:
+                    print(f"[bench] traffic pass {counter}: attempt {attempt + 1} timed out", file=sys.stderr)
+                    continue
+                dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
+                if r.returncode == 0 and dbs:
+                    break
+            if r is None:
+                if counter == "SQ":
+                    break
+                return None
             if r.returncode != 0 or not dbs:
                 print(f"[bench] traffic pass {counter}: rc {r.returncode}, {len(dbs)} result files; stderr tail: {r.stderr[-600:]}", file=sys.stderr)
                 if counter == "SQ":
