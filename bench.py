@@ -178,7 +178,12 @@ def measure_traffic(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
             d = os.path.join(tmp, counter)
             pmc = [counter] if counter != "SQ" else list(SQ_PASS)
-            cmd = [exe, "--pmc"] + pmc + ["--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+            # Counters are collected for the big-GEMM kernels ONLY (--kernel-include-regex): with every dispatch of the child under
+            # counter collection - the on-device weight generator's torch kernels included - the profiled child hung before its first
+            # forward in 6 of 10 runs on some boxes of the pool (stack: the first blocking copy behind those kernels); filtered, 0 of 10
+            # on the same box, interleaved (tools/pmc_hang_probe.sh, profiles/r06_pmc_hang_probe.txt), and a pass takes 4 s instead of 6.
+            cmd = [exe, "--pmc"] + pmc + ["--kernel-trace", "--kernel-include-regex", "gemm_(ws|pp|sq)_kernel", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__),
                    "--config", args.config, "--precision", args.precision, "--steps", "1", "--warmup", "1", "--traffic", "off", "--min-seconds", "0",
                    "--no-cpu-baseline", "--no-parity", "--no-bf16-leg", "--no-gemm-events", "--inflight", "1"] + (["--batch", str(args.batch)] if args.batch else [])
             env = dict(os.environ, TMPDIR="/tmp")
@@ -271,6 +276,9 @@ def main():
                     help="forwards in flight per GPU (madtp_amd.pipeline: one host thread + HIP stream + model replica each; "
                          "1 = the serial loop, 0 = the configuration's default).  The K timed steps are K whole forwards either way.")
     args = ap.parse_args()
+    if os.environ.get("MADTP_BENCH_WATCHDOG"):  # debugging aid: dump every thread's Python stack after N seconds (tools/pmc_hang_probe.sh)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["MADTP_BENCH_WATCHDOG"]), repeat=False, file=sys.stderr)
 
     from madtp_amd import dist as mdist
     world, rank, local_rank = mdist.env_world()

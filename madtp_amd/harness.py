@@ -34,7 +34,7 @@ def padded_mask(B, L, pad_tail=0):
 
 
 def nlvr_inputs(B, image_size=224, L=20, seed=0, device="cuda", pad_tail=0):
-    images = synth.synth_images(2 * B, image_size, seed).to(device)
+    images = synth.synth_images(2 * B, image_size, seed, device=device)  # (generated ON the device: same bits, no large H2D copy)
     ids = synth.synth_token_ids(B, L, seed).to(device)
     return images, {"input_ids": ids, "attention_mask": padded_mask(B, L, pad_tail).to(device)}, \
         torch.zeros(B, dtype=torch.long, device=device)
@@ -83,8 +83,8 @@ class RetrievalLoader:
 def retrieval_inputs(n_img, img_bs, n_txt, image_size=224, L=35, seed=0, device="cpu"):
     """Synthetic retrieval evaluation set: image loader batches (list of [<=img_bs,3,S,S]), caption ids/masks [n_txt,L] padded
     to max_length 35 with ragged true lengths (pad id 0), as tokenizer(padding='max_length') yields (compress_retrieval_dtp.py:102)."""
-    images = synth.synth_images(n_img, image_size, seed)
-    batches = [images[i:i + img_bs].to(device) for i in range(0, n_img, img_bs)]
+    images = synth.synth_images(n_img, image_size, seed, device=device)
+    batches = [images[i:i + img_bs] for i in range(0, n_img, img_bs)]
     ids = synth.synth_token_ids(n_txt, L, seed + 1, first_id=101)
     att = torch.ones_like(ids)
     for t in range(n_txt):

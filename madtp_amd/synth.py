@@ -107,10 +107,18 @@ def fill_state_dict(module_or_sd, seed: int = 0, prefix: str = ""):
     return out
 
 
-def synth_images(n: int, size: int = 224, seed: int = 0) -> torch.Tensor:
-    """[n,3,size,size] fp32, zero-mean unit-variance i.i.d. (uniform) pixels."""
+def synth_images(n: int, size: int = 224, seed: int = 0, device=None, on_device: bool = None) -> torch.Tensor:
+    """[n,3,size,size] fp32, zero-mean unit-variance i.i.d. (uniform) pixels.  device = a GPU: the SAME bits generated there with torch
+    integer ops (uniform_pm1_torch; tests/test_synth_cpu.py pins the two paths to each other) instead of a 77 MB pageable host-to-device
+    copy - round 6: under `rocprofv3 --pmc` that copy hung in up to half of the runs on some boxes of the pool (the stack of the
+    hung bench.py child, tools/pmc_hang_probe.sh), which cost bench.py's counter passes their time-outs.  on_device forces the path."""
+    use_torch = on_device if on_device is not None else (device is not None and torch.device(device).type != "cpu")
+    if use_torch:
+        v = uniform_pm1_torch("images", n * 3 * size * size, seed, device if device is not None else "cpu") * float(np.float32(_SQRT3))
+        return v.reshape(n, 3, size, size)
     v = uniform_pm1("images", n * 3 * size * size, seed) * np.float32(_SQRT3)
-    return torch.from_numpy(v.reshape(n, 3, size, size))
+    t = torch.from_numpy(v.reshape(n, 3, size, size))
+    return t if device is None else t.to(device)
 
 
 def synth_clip_tokens(batch: int, ctx: int = 77, seed: int = 0, min_len: int = 6, max_len: int = 40, sot: int = 49406,

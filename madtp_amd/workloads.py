@@ -179,7 +179,7 @@ class Vqa(Workload):
         return model
 
     def inputs(self, B, seed=0, device="cuda"):
-        images = synth.synth_images(B, self.size, seed).to(device)
+        images = synth.synth_images(B, self.size, seed, device=device)
         ids = synth.synth_token_ids(B, self.L, seed).to(device)
         return images, {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
 
@@ -216,7 +216,7 @@ class Clip(Workload):
         return build_model(specs.synth_weights(specs.clip_shapes(self.size), 0, device=device), evaluate=True).eval().to(device)
 
     def inputs(self, B, seed=0, device="cuda"):
-        return synth.synth_images(B, self.size, seed).to(device), synth.synth_clip_tokens(B, self.ctx, seed).to(device)
+        return synth.synth_images(B, self.size, seed, device=device), synth.synth_clip_tokens(B, self.ctx, seed).to(device)
 
     def step(self, model, inp, T):
         images, text = inp

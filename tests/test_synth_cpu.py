@@ -68,3 +68,14 @@ def test_query_model_rejects_dictionaries_the_kernels_cannot_hold():
         qm._dictionary(torch.randn(200, 768))
     with pytest.raises(NotImplementedError, match="128"):
         qm.encoder_args(torch.randn(200, 768), 2, 768, "cpu")
+
+
+def test_synth_images_torch_path_gives_the_numpy_paths_bits():
+    """synth_images(device=<GPU>) generates the pixels on the device with torch integer ops (no large host-to-device copy: round 6,
+    the rocprofv3 --pmc hang); forced onto the CPU here, the torch path must give the numpy path's bits."""
+    import torch
+    from madtp_amd import synth
+    for n, size, seed in ((2, 224, 0), (3, 32, 7), (1, 480, 11)):
+        a = synth.synth_images(n, size, seed)
+        b = synth.synth_images(n, size, seed, device="cpu", on_device=True)
+        assert a.dtype == b.dtype == torch.float32 and a.shape == b.shape and torch.equal(a, b)
