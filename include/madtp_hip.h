@@ -485,7 +485,9 @@ int madtp_vit_encoder(const madtp_vit_block_w* const* layers, int n_layers, cons
  * is enqueued ahead and the host reads the records ONCE at the end (io[l].k_out / k_used / n_out).  Results are bit-identical to
  * madtp_vit_encoder.  For the launch-bound regime: B * N0 < 4096 token rows and N0 <= 256 (MADTP_E_SHAPE otherwise); q and
  * temperature > 0 are required, q->att_ft must be NULL (the caller sums att_ft after the call, when the token counts are known);
- * dims_dev: (n_layers + 2) * 4 int32 of device scratch, dims_host: (n_layers + 1) * 4 int32 of host memory. */
+ * dims_dev: (n_layers + 2) * 4 int32 of device scratch, dims_host: (n_layers + 1) * 4 int32 of host memory - or NULL (round 6):
+ * enqueue only, no copy and no wait (dims_dev[4 l .. 4 l + 3] = {N_l, k, k applied, N_{l+1}} is the caller's to read later): the form a
+ * stream capture into a hipGraph takes (tools/graph_replay_probe.py). */
 int madtp_vit_encoder_async(const madtp_vit_block_w* const* layers, int n_layers, const madtp_query_w* q, const float* x0,
                             madtp_layer_io* io, void* ws, size_t ws_bytes, int B, int N0, float temperature, int32_t* dims_dev,
                             int32_t* dims_host, void* stream);

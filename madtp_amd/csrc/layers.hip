@@ -711,7 +711,7 @@ static int lin_dev(const void* a, int lda, const madtp_lin& L, const float* resi
 extern "C" int madtp_vit_encoder_async(const madtp_vit_block_w* const* layers, int n_layers, const madtp_query_w* q, const float* x0,
                                        madtp_layer_io* io, void* ws, size_t ws_bytes, int B, int N0, float temperature,
                                        int32_t* dims_dev, int32_t* dims_host, void* stream) {
-    if (!layers || !io || !x0 || !q || !dims_dev || !dims_host || n_layers <= 0 || B <= 0 || N0 < 3) return MADTP_E_BADARG;
+    if (!layers || !io || !x0 || !q || !dims_dev || n_layers <= 0 || B <= 0 || N0 < 3) return MADTP_E_BADARG;
     if (!(temperature > 0.f) || q->att_ft) return MADTP_E_BADARG;  // (att_ft: the caller's deferred sum, after this call)
     if ((long)B * N0 >= 4096 || N0 > 256) return MADTP_E_SHAPE;   // small-tile GEMMs and the <= 256-key attention kernels only
     hipStream_t s = (hipStream_t)stream;
@@ -764,6 +764,9 @@ extern "C" int madtp_vit_encoder_async(const madtp_vit_block_w* const* layers, i
         TRY(lin_dev(v.mid, w->fc1.n, w->fc2, v.xp, D, o.y, D, Mmax, dt, MADTP_F32, MADTP_ACT_NONE, m_out, stream));
         x = o.y;
     }
+    // dims_host == NULL (round 6): ENQUEUE ONLY - nothing is copied or waited for, the caller reads dims_dev when it wants the shapes
+    // (a stream capture into a hipGraph, tools/graph_replay_probe.py, or an enqueue-ahead scheduler)
+    if (!dims_host) return 0;
     // the ONE host read of the call: every layer's decision, for the output shapes and the layers' pruning records
     he = hipMemcpyAsync(dims_host, dims_dev, nrec * sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (he == hipSuccess) he = hipStreamSynchronize(s);

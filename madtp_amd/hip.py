@@ -1311,7 +1311,7 @@ def _query_w(qargs):
     return q
 
 
-def vit_encoder(weights, x, qargs, temperature, sync_free=False):
+def vit_encoder(weights, x, qargs, temperature, sync_free=False, enqueue_only=False):
     """VisionTransformer's block loop in ONE library call.  weights: (list of VitBlockW, ctypes array of their addresses)
     from runtime.EncoderWeights; x f32 [B,N,D] contiguous; qargs: query-model operands (see _query_w) or None.  -> EncoderRun."""
     B, N, D = x.shape
@@ -1330,9 +1330,13 @@ def vit_encoder(weights, x, qargs, temperature, sync_free=False):
             raise RuntimeError("sync-free encoder call: needs pruning with a deferred att_ft, B * N < 4096 token rows and N <= 256")
         dims_dev = torch.empty(((L + 2) * 4,), device=x.device, dtype=torch.int32)
         dims_host = (ctypes.c_int32 * ((L + 1) * 4))()
+        # enqueue_only: no copy of the records and no wait (dims_host NULL) - run.dims_dev holds {N_l, k, k applied, N_l+1} per layer
+        # once the stream has run; run.results() is NOT filled (stream capture / enqueue-ahead, tools/graph_replay_probe.py)
         _check(lib.madtp_vit_encoder_async(arr, L, ctypes.byref(q), _p(x), run.io_ptr, _p(ws), ws.numel(), B, N, float(temperature),
-                                           _p(dims_dev), ctypes.addressof(dims_host), _stream()), "madtp_vit_encoder_async")
-        run.keep = (x, wstructs, qargs, dims_dev, dims_host)
+                                           _p(dims_dev), 0 if enqueue_only else ctypes.addressof(dims_host), _stream()),
+               "madtp_vit_encoder_async")
+        run.keep = (x, wstructs, qargs, dims_dev, dims_host, ws)
+        run.dims_dev = dims_dev
         return run
     _check(lib.madtp_vit_encoder(arr, L, ctypes.byref(q) if q is not None else None, _p(x), run.io_ptr, _p(ws), ws.numel(), B, N,
                                  float(temperature if prune else 0.0), _stream()), "madtp_vit_encoder")

@@ -1189,3 +1189,44 @@ def test_incremental_decoding_through_the_reference_cache_protocol():
             assert (out.attentions[5].sum(-1) - 1).abs().max().item() < 1e-4
             assert out.attentions[5][0, 0, 2, 3:].abs().max().item() < 1e-6  # causal: token 2 does not see tokens 3..
             assert (out.logits - full.logits).abs().max().item() < tol * max(1.0, scale)
+
+
+def test_enqueue_only_vit_encoder_and_graph_replay_equal_the_sync_free_call():
+    """madtp_vit_encoder_async with dims_host = NULL (round 6): the twelve blocks are enqueued without a copy or a wait; the device
+    record then holds the sync-free call's per-layer decisions and the buffers its outputs - also when the same enqueue is captured
+    into a hipGraph once and replayed (the measurement that says a replay does not pay is tools/graph_replay_probe.py)."""
+    from madtp_amd import build, configs, harness, hip, runtime
+    build.build(verbose=False)
+    hip.load()
+    T = configs.temperature_for("nlvr", 64, 0.5)[0]
+    model = harness.build_nlvr(224, 0, "cuda")
+    venc = model.visual_encoder
+    images, _, _ = harness.nlvr_inputs(2, 224, 20, seed=3)
+    img = images[:3].contiguous()
+    for mode in ("f16x3", "f16"):
+        with runtime.precision(mode), torch.no_grad():
+            patches, np_ = venc.patch_embed.run(img)
+            x = hip.assemble_tokens(patches, venc.cls_token, venc.pos_embed, 3, np_)
+            weights, qargs, _ = venc._encoder_call_prep(img, model.space_dict)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                ref = hip.vit_encoder(weights, x, qargs, T, sync_free=True)
+                k_out, k_used, n_out = ref.results()
+                run = hip.vit_encoder(weights, x, qargs, T, sync_free=True, enqueue_only=True)
+                s.synchronize()
+                d = run.dims_dev[: 13 * 4].view(13, 4).cpu()
+                assert d[:12, 1].tolist() == list(k_out) and d[:12, 2].tolist() == list(k_used) and d[:12, 3].tolist() == list(n_out)
+                nb = 3 * int(n_out[-1]) * x.shape[-1] * 4
+                o_ref = ref.ptr(11, "y") - ref.buf.data_ptr()
+                o_run = run.ptr(11, "y") - run.buf.data_ptr()
+                assert torch.equal(run.buf[o_run:o_run + nb], ref.buf[o_ref:o_ref + nb])
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    cap = hip.vit_encoder(weights, x, qargs, T, sync_free=True, enqueue_only=True)
+                for _ in range(3):
+                    g.replay()
+                s.synchronize()
+                assert torch.equal(cap.dims_dev[: 13 * 4], run.dims_dev[: 13 * 4])
+                o_cap = cap.ptr(11, "y") - cap.buf.data_ptr()
+                assert torch.equal(cap.buf[o_cap:o_cap + nb], ref.buf[o_ref:o_ref + nb])
