@@ -14,7 +14,12 @@ BASELINE batch of 128 is a global one, is split over the ranks: "strong").
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline     - the dominant kernel (the MFMA GEMM): algorithmic FLOPs of its launches in the timed region / the sum of their
                  durations, measured live with HIP events on the launch stream; `traffic` = HBM bytes per launch from two
-                 rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that THIS run starts on a 1-step copy of itself.
+                 rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that THIS run starts on a 1-step copy of itself; `mfma_busy` /
+                 `sq_counters` from a third pass (SQ_VALU_MFMA_BUSY_CYCLES, wave-cycle split; counters for the GEMM kernels only);
+                 `by_class` = every Linear class against its own bound (MFMA or HBM) with its tile-quantisation ceiling.
+  value        - the bf16 leg (BASELINE.json config 2's dtype); f16_value = the same runner on IEEE f16 operands;
+                 parity_qualified_value = the f16x3 leg (every kept set identical to the oracle).  The timed region repeats the K
+                 steps in whole passes until it lasts >= 1 s (timed_passes_of_k_steps); ms_per_step is per step.
   parity_mode  - the same workload timed in the precision mode that carries the parity claim ("f16x3": fp32-accurate GEMMs
                  on the f16 MFMA) + index_match of every mode vs the CPU oracle at the headline batch.
   cpu_baseline - oracle/ (the CPU restatement of the reference forward, kind "port") timed on this box's host cores on a
